@@ -1,0 +1,189 @@
+/*
+ * read_hip.h — C ABI of libreadhip.so: READ's per-frame render path on MI355X (gfx950).
+ *
+ * This is the drop-in boundary.  Everything above it (the Python mirror of READ's
+ * pcpr / MyRender / PointTexture / UNet / NetAndTexture / TexturePipeline / OGL API in
+ * read_amd/) and any other host (C++, cgo, JNI, ctypes) binds exactly these symbols.
+ *
+ * Conventions
+ *   - every function returns 0 (READ_OK) or a negative READ_E* code and never throws;
+ *     read_last_error() gives the message of the calling thread's last failure;
+ *   - `stream` is a hipStream_t passed as void* (NULL = the default stream); all work is
+ *     enqueued on it, nothing synchronises, nothing allocates after *_create / workspace setup;
+ *   - pointers are DEVICE pointers owned by the caller unless the name ends in `_host`;
+ *   - images are row-major, row 0 = image top; activations are NHWC fp32;
+ *   - matrices are row-major 4x4 applied as M * [x y z 1]^T (point_render.cu:96-121).
+ *
+ * Reference interfaces replaced (file:line under the reference repo):
+ *   read_splat_forward        MyRender/CloudProjection/pcpr_cuda.cpp:23-42 (pcpr.forward),
+ *                             point_render.cu:125-200 (DepthProject + GPU_PCPR), called 5x per
+ *                             iteration by src/READ/gl/myrender.py:32-40; GL twin:
+ *                             READ/gl/render.py:52-85 + READ/gl/programs.py:121-125,164-167
+ *   read_index_to_float       point_render.cu:158 (`out_index[ind] = (float)ids`)
+ *   read_gather_forward       READ/models/texture.py:42-70 (PointTexture.forward = index_select)
+ *   read_gather_backward      autograd of texture.py:61 (index_add into texture_.grad)
+ *   read_texture_to_rows      layout change of PointTexture.texture_ (1,C,N) -> N x C rows
+ *   read_gated_conv_forward   READ/models/unet.py:22-53 (BasicConv) incl. the ResBlock add (:19-20),
+ *                             FAM multiply/add (:115-117), torch.cat (:88,:104,:262,:270,:278) and
+ *                             F.interpolate nearest (:239-250) folded into its prologue/epilogue
+ *   read_bilinear_up4         READ/models/unet.py:200 (nn.Upsample(scale_factor=4, 'bilinear'))
+ *   read_unet_*               READ/models/unet.py:121-285 (UNet.__init__/forward)
+ */
+#ifndef READ_HIP_H
+#define READ_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define READ_OK        0
+#define READ_EINVAL  (-22)   /* bad argument (shape, alignment, null pointer) */
+#define READ_ENOMEM  (-12)   /* workspace too small */
+#define READ_EHIP     (-5)   /* a HIP runtime call failed; see read_last_error() */
+
+#define READ_MAX_LEVELS      5
+#define READ_DESC_CHANNELS   8   /* descriptor size the UNet consumes (READ/pipelines/ogl.py:19-25) */
+
+const char *read_last_error(void);
+int read_abi_version(void);
+/* Fills name[0..len) with the gfx arch of the current device ("gfx950"); READ_EHIP without a GPU. */
+int read_device_arch(char *name, int len);
+
+/* ---------------------------------------------------------------- rasteriser (z-buffer splat) */
+
+/* Bytes of the persistent key image: B * W * H * 8 (packed depth_bits<<32 | point_id). */
+size_t read_splat_workspace_bytes(int B, int W, int H);
+/* Must be called once on a fresh workspace (sets every key to EMPTY).  read_splat_forward
+ * leaves the workspace EMPTY again, so consecutive frames need no further clears. */
+int read_splat_workspace_init(void *ws, size_t ws_bytes, void *stream);
+
+/*
+ * One pass over the cloud for B cameras and `levels` scales.
+ *   xyz          N x 3 fp32 (device)
+ *   M_host       B x 16 fp32 on the HOST: proj @ inv(view) per camera (myrender.py:28-30)
+ *   W,H          level-0 size; level l is int(W*0.5^l) x int(H*0.5^l) (myrender.py:33-34)
+ *   idx_levels   host array of `levels` device pointers, level l = int32 [B][h_l][w_l]
+ *   depth_levels same shape, fp32; either array (or single entries) may be NULL to skip
+ * Semantics (bit-exact, deterministic): per pixel the accepted point of minimum fp32 depth,
+ * ties -> minimum point id; empty pixels (0, 0.0f).  When W or H is not a multiple of
+ * 2^(levels-1) each level is rasterised by its own pass over the points.
+ */
+int read_splat_forward(const float *xyz, int64_t n, const float *M_host, int B, int W, int H,
+                       int levels, int32_t *const *idx_levels, float *const *depth_levels,
+                       void *ws, size_t ws_bytes, void *stream);
+
+/* out[i] = (float)idx[i] — the reference's index image dtype (ids >= 2^24 round). */
+int read_index_to_float(const int32_t *idx, int64_t count, float *out, void *stream);
+
+/* ---------------------------------------------------------------- descriptor gather / scatter */
+
+/* (C, N) channel-major texture  ->  N x C row-major rows (and back, for gradients). */
+int read_texture_to_rows(const float *tex_cn, int64_t n, int C, float *rows_nc, void *stream);
+int read_rows_to_texture(const float *rows_nc, int64_t n, int C, float *tex_cn, void *stream);
+
+/*
+ * feat_l[p][c] = rows[idx_l[p]][c]  for every level l and pixel p (NHWC, C % 4 == 0).
+ *   count_levels[l] = number of pixels of level l (B*h_l*w_l); activation: 0 none, 1 sigmoid, 2 tanh
+ */
+int read_gather_forward(const float *rows_nc, int64_t n, int C, int levels,
+                        const int32_t *const *idx_levels, const int64_t *count_levels,
+                        float *const *feat_levels, int activation, void *stream);
+/* drows[idx_l[p]][c] += dfeat_l[p][c]   (fp32 atomics; drows must be zeroed by the caller). */
+int read_gather_backward(float *drows_nc, int64_t n, int C, int levels,
+                         const int32_t *const *idx_levels, const int64_t *count_levels,
+                         const float *const *dfeat_levels, void *stream);
+
+/* ---------------------------------------------------------------- gated conv (BasicConv) */
+
+#define READ_CONV_MAX_SRC 4
+
+typedef struct read_conv_src {
+    const float *data;   /* NHWC fp32 [srcH][srcW][C] */
+    int C;               /* channels taken from this source (all of them) */
+    int srcH, srcW;
+    int shift;           /* nearest resample folded into addressing: >0: source is 2^shift finer
+                            (src = dst << shift), <0: coarser (src = dst >> -shift), 0: same size */
+} read_conv_src;
+
+typedef struct read_conv_desc {
+    int n_src;                              /* inputs concatenated along C (torch.cat order) */
+    read_conv_src src[READ_CONV_MAX_SRC];
+    const float *mul;                       /* optional: input := src[0] * mul (FAM), same shape */
+    int inH, inW;                           /* logical input size after resampling */
+    int Cout, ksize, stride;                /* ksize in {1,3,4}, stride in {1,2}; pad = (ksize-1)/2 */
+    int elu;                                /* 1: ELU on the feature branch (relu=True) */
+    const float *wpacked;                   /* read_conv_pack_weights() output (device) */
+    const float *params;                    /* 4 x CoutPad: bias_f, bias_m, bn_scale, bn_shift */
+    const float *residual;                  /* optional NHWC [outH][outW][Cout], added after BN */
+    float *out;                             /* NHWC [outH][outW][out_cstride], first Cout written */
+    int out_cstride;                        /* >= Cout */
+    float out_fill;                         /* value for channels Cout..out_cstride-1 when fill_pad */
+    int fill_pad;
+    int config;                             /* tile configuration id, -1 = pick automatically */
+} read_conv_desc;
+
+/* Sizes (in floats) of the packed weight / parameter blocks of one BasicConv. */
+size_t read_conv_packed_floats(int Cin, int Cout, int ksize);
+size_t read_conv_param_floats(int Cout);
+/* Host-side packing from the PyTorch layout (all host pointers):
+ *   wf, wm (Cout,Cin,k,k); bf, bm (Cout); BN gamma, beta, running_mean, running_var (Cout), eps.
+ *   kc = input-channel chunk the kernel stages per step: 16 when every concatenated source has
+ *   C % 16 == 0, else 8 (the packing order depends on it). */
+int read_conv_pack_weights_host(int Cin, int Cout, int ksize, int kc, const float *wf,
+                                const float *wm, float *wpacked_host);
+int read_conv_pack_params_host(int Cout, const float *bf, const float *bm, const float *gamma,
+                               const float *beta, const float *mean, const float *var, float eps,
+                               float *params_host);
+int read_gated_conv_forward(const read_conv_desc *desc, void *stream);
+/* Number of compiled tile configurations and a printable name for each (for tuning sweeps). */
+int read_conv_config_count(void);
+const char *read_conv_config_name(int config);
+
+/* out[y][x][c] = bilinear x4 (align_corners=False) of in, NHWC, C % 4 == 0. */
+int read_bilinear_up4(const float *in, int inH, int inW, int C, float *out, void *stream);
+
+/* ---------------------------------------------------------------- UNet */
+
+typedef struct read_unet read_unet_t;
+
+/* The 101 BasicConvs of READ's UNet in canonical order (99 execute; ConvsOut.* are packed but
+ * never run, unet.py:181-186).  For layer i: state-dict path prefix, Cin, Cout, ksize. */
+int read_unet_layer_count(void);
+int read_unet_layer_info(int i, const char **path, int *cin, int *cout, int *ksize, int *stride,
+                         int *elu);
+/* Total floats of the raw parameter blob: per layer, in order,
+ *   conv_f.weight, conv_f.bias, conv_m.weight, conv_m.bias, norm.weight, norm.bias,
+ *   norm.running_mean, norm.running_var. */
+size_t read_unet_raw_floats(void);
+size_t read_unet_packed_floats(void);
+int read_unet_pack_host(const float *raw_host, float bn_eps, float *packed_host);
+size_t read_unet_workspace_bytes(int H, int W);
+/* H, W multiples of 16 (READ/gl/nn.py:107-109).  `packed` and `ws` are device memory that must
+ * outlive the handle. */
+int read_unet_create(read_unet_t **out, const float *packed, int H, int W, void *ws, size_t ws_bytes);
+void read_unet_destroy(read_unet_t *u);
+/* x0..x3: NHWC [H>>l][W>>l][8] feature pyramids; rgb: NHWC [H][W][rgb_cstride], channels 0..2
+ * written (channel 3 set to 1.0f when rgb_cstride == 4, the viewer's RGBA frame, nn.py:123-124). */
+int read_unet_forward(read_unet_t *u, const float *x0, const float *x1, const float *x2,
+                      const float *x3, float *rgb, int rgb_cstride, void *stream);
+/* Per-layer timing of the last instrumented forward: runs one forward with hipEvents around
+ * every launch and fills ms[0..n) (n = read_unet_launch_count()).  Synchronises. */
+int read_unet_launch_count(read_unet_t *u);
+const char *read_unet_launch_label(read_unet_t *u, int i);
+/* Static facts about launch i of the plan: algorithmic FLOPs (2*MAC, both gate convs), whether it
+ * is one of the dominant 3x3/s1 C->C gated convs, output size and channel counts. */
+int read_unet_launch_info(read_unet_t *u, int i, double *flops, int *is_conv3x3_s1, int *outH,
+                          int *outW, int *cin, int *cout);
+int read_unet_profile(read_unet_t *u, const float *x0, const float *x1, const float *x2,
+                      const float *x3, float *rgb, int rgb_cstride, void *stream, float *ms,
+                      double *flops, int *is_conv3x3_s1);
+/* Device pointer of an intermediate activation by name ("res1", "z8", ...), for layer-level tests. */
+const float *read_unet_debug_tensor(read_unet_t *u, const char *name, int *H, int *W, int *C);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* READ_HIP_H */

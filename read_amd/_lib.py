@@ -1,0 +1,122 @@
+"""ctypes binding of libreadhip.so — the only road from Python into the render path.
+
+There is deliberately NO fallback: if the library is missing or a call fails the caller gets a
+``RuntimeError`` carrying ``read_last_error()``.  Nothing here touches ``oracle/``.
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libreadhip.so")
+
+READ_MAX_LEVELS = 5
+READ_CONV_MAX_SRC = 4
+DESC_CHANNELS = 8
+
+
+class ReadHipError(RuntimeError):
+    pass
+
+
+class ConvSrc(C.Structure):
+    _fields_ = [("data", C.c_void_p), ("C", C.c_int), ("srcH", C.c_int), ("srcW", C.c_int), ("shift", C.c_int)]
+
+
+class ConvDesc(C.Structure):
+    _fields_ = [
+        ("n_src", C.c_int), ("src", ConvSrc * READ_CONV_MAX_SRC), ("mul", C.c_void_p),
+        ("inH", C.c_int), ("inW", C.c_int), ("Cout", C.c_int), ("ksize", C.c_int), ("stride", C.c_int),
+        ("elu", C.c_int), ("wpacked", C.c_void_p), ("params", C.c_void_p), ("residual", C.c_void_p),
+        ("out", C.c_void_p), ("out_cstride", C.c_int), ("out_fill", C.c_float), ("fill_pad", C.c_int),
+        ("config", C.c_int),
+    ]
+
+
+_vp, _i, _i64, _sz, _f = C.c_void_p, C.c_int, C.c_int64, C.c_size_t, C.c_float
+_pp = C.POINTER(C.c_void_p)
+
+# name -> (restype, argtypes): every symbol include/read_hip.h declares
+SIGNATURES = {
+    "read_last_error": (C.c_char_p, []),
+    "read_abi_version": (_i, []),
+    "read_device_arch": (_i, [C.c_char_p, _i]),
+    "read_splat_workspace_bytes": (_sz, [_i, _i, _i]),
+    "read_splat_workspace_init": (_i, [_vp, _sz, _vp]),
+    "read_splat_forward": (_i, [_vp, _i64, C.POINTER(_f), _i, _i, _i, _i, _pp, _pp, _vp, _sz, _vp]),
+    "read_index_to_float": (_i, [_vp, _i64, _vp, _vp]),
+    "read_texture_to_rows": (_i, [_vp, _i64, _i, _vp, _vp]),
+    "read_rows_to_texture": (_i, [_vp, _i64, _i, _vp, _vp]),
+    "read_gather_forward": (_i, [_vp, _i64, _i, _i, _pp, C.POINTER(_i64), _pp, _i, _vp]),
+    "read_gather_backward": (_i, [_vp, _i64, _i, _i, _pp, C.POINTER(_i64), _pp, _vp]),
+    "read_conv_packed_floats": (_sz, [_i, _i, _i]),
+    "read_conv_param_floats": (_sz, [_i]),
+    "read_conv_pack_weights_host": (_i, [_i, _i, _i, _i, _vp, _vp, _vp]),
+    "read_conv_pack_params_host": (_i, [_i, _vp, _vp, _vp, _vp, _vp, _vp, _f, _vp]),
+    "read_gated_conv_forward": (_i, [C.POINTER(ConvDesc), _vp]),
+    "read_conv_config_count": (_i, []),
+    "read_conv_config_name": (C.c_char_p, [_i]),
+    "read_bilinear_up4": (_i, [_vp, _i, _i, _i, _vp, _vp]),
+    "read_unet_layer_count": (_i, []),
+    "read_unet_layer_info": (_i, [_i, C.POINTER(C.c_char_p), C.POINTER(_i), C.POINTER(_i), C.POINTER(_i),
+                                  C.POINTER(_i), C.POINTER(_i)]),
+    "read_unet_raw_floats": (_sz, []),
+    "read_unet_packed_floats": (_sz, []),
+    "read_unet_pack_host": (_i, [_vp, _f, _vp]),
+    "read_unet_workspace_bytes": (_sz, [_i, _i]),
+    "read_unet_create": (_i, [_pp, _vp, _i, _i, _vp, _sz]),
+    "read_unet_destroy": (None, [_vp]),
+    "read_unet_forward": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _vp]),
+    "read_unet_launch_count": (_i, [_vp]),
+    "read_unet_launch_label": (C.c_char_p, [_vp, _i]),
+    "read_unet_launch_info": (_i, [_vp, _i, C.POINTER(C.c_double), C.POINTER(_i), C.POINTER(_i), C.POINTER(_i),
+                                   C.POINTER(_i), C.POINTER(_i)]),
+    "read_unet_profile": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _vp, C.POINTER(_f), C.POINTER(C.c_double),
+                               C.POINTER(_i)]),
+    "read_unet_debug_tensor": (_vp, [_vp, C.c_char_p, C.POINTER(_i), C.POINTER(_i), C.POINTER(_i)]),
+}
+
+_LIB = None
+
+
+def lib():
+    """The loaded library; raises ReadHipError when it has not been built."""
+    global _LIB
+    if _LIB is None:
+        if not os.path.exists(LIB_PATH):
+            raise ReadHipError(
+                f"{LIB_PATH} is missing: the HIP extension is required (there is no CPU fallback). "
+                "Build it with `python -m read_amd.build` (or __graft_entry__.build()).")
+        L = C.CDLL(LIB_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(L, name)          # AttributeError here = header/library mismatch
+            fn.restype = res
+            fn.argtypes = args
+        _LIB = L
+    return _LIB
+
+
+def check(rc, what=""):
+    if rc != 0:
+        msg = lib().read_last_error().decode("utf-8", "replace")
+        raise ReadHipError(f"{what + ': ' if what else ''}libreadhip error {rc}: {msg}")
+
+
+def ptr_array(ptrs):
+    """Host array of device pointers (None -> NULL)."""
+    arr = (C.c_void_p * len(ptrs))()
+    for i, p in enumerate(ptrs):
+        arr[i] = p
+    return arr
+
+
+def require_gpu():
+    import torch
+    if not torch.cuda.is_available():
+        raise ReadHipError("no HIP device visible: READ's render path runs on the MI355X only "
+                           "(there is no CPU fallback in read_amd)")
+    return torch.device("cuda", torch.cuda.current_device())
+
+
+def stream_ptr():
+    import torch
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)

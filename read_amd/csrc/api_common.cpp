@@ -1,0 +1,31 @@
+// Error plumbing + device query of the C ABI.
+#include <stdarg.h>
+
+#include "common.h"
+
+namespace readhip {
+static thread_local char g_err[512] = "";
+void set_error(const char *fmt, ...)
+{
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+}
+}  // namespace readhip
+
+extern "C" const char *read_last_error(void) { return readhip::g_err; }
+extern "C" int read_abi_version(void) { return 1; }
+
+extern "C" int read_device_arch(char *name, int len)
+{
+    READ_CHECK_ARG(name && len > 0, "read_device_arch: bad buffer");
+    int dev = 0;
+    READ_CHECK_HIP(hipGetDevice(&dev));
+    hipDeviceProp_t p;
+    READ_CHECK_HIP(hipGetDeviceProperties(&p, dev));
+    snprintf(name, (size_t)len, "%s", p.gcnArchName);
+    char *colon = strchr(name, ':');
+    if (colon) *colon = 0;
+    return READ_OK;
+}

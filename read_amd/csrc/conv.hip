@@ -1,0 +1,518 @@
+// Gated convolution (READ's BasicConv, READ/models/unet.py:22-53) as ONE fused implicit-GEMM
+// kernel on the gfx950 matrix cores, exact fp32 (v_mfma_f32_32x32x2_f32).
+//
+//   out = BN_eval( act(conv_f(x) + b_f) * sigmoid(conv_m(x) + b_m) ) [+ residual]
+//
+// GEMM view per output tile:  D[pixel][cout] = sum_k A[pixel][k] * B[k][cout],  k = (tap, cin).
+//   * rows (M) = 32 consecutive output pixels of one image row  -> MFMA rows
+//   * cols (N) = 32 output channels; conv_f and conv_m of the SAME 32 channels are two
+//     accumulators with identical lane mapping, so the gate product is lane-local
+//   * A is staged per cin-chunk (KC channels) as an NHWC halo tile in LDS, padded to KC+4 floats per
+//     pixel: ds_read_b128 of 32 consecutive pixels is then bank-conflict free
+//   * B (weights) is pre-packed on the host in exact fragment order, so a wave's B fragment is one
+//     contiguous 1 KiB global_load_dwordx4 (L2 resident: weights are shared by every workgroup)
+//   * torch.cat, nearest F.interpolate and FAM's x1*x2 are folded into the A-tile loader
+//     (multi-source addressing with a per-source power-of-two shift); the ResBlock / FAM
+//     residual add, both biases, ELU, sigmoid, gate and eval-mode BatchNorm live in the epilogue.
+//
+// MFMA 32x32x2 f32 layouts (cdna_hip_programming.md §3): lane l supplies A[i=l&31][k=l>>5] and
+// B[k=l>>5][j=l&31]; D[i][j] sits in lane (j + 32*((i>>2)&1)), register (i&3) + 4*(i>>3).
+// A k-step of 8 is four MFMAs fed from ONE float4 per operand: lanes <32 carry cin 0..3 of the
+// 8-block, lanes >=32 carry cin 4..7 (the k order inside a step is free as long as A and B agree).
+#include "common.h"
+
+using namespace readhip;
+
+typedef float floatx16 __attribute__((ext_vector_type(16)));
+
+namespace {
+
+constexpr int MAX_CHUNKS = 64;
+
+struct SrcDev {
+    const float *p;
+    int C, H, W;
+    int sl, sr;          // source coordinate = (dst << sl) >> sr
+};
+
+struct ConvKArgs {
+    SrcDev src[READ_CONV_MAX_SRC];
+    const float *mul;
+    const float *wp;
+    const float *params;
+    const float *residual;
+    float *out;
+    int inH, inW, outH, outW;
+    int Cout, CoutPad, out_cstride;
+    int nchunks, tiles_x;
+    int elu, fill_pad;
+    float out_fill;
+    unsigned char chunk_src[MAX_CHUNKS];
+    unsigned short chunk_coff[MAX_CHUNKS];
+};
+
+__device__ __forceinline__ float elu1(float x) { return x > 0.0f ? x : expm1f(x); }
+__device__ __forceinline__ float sigmoidf(float x) { return 1.0f / (1.0f + expf(-x)); }
+
+template <int KS, int S, int KC, int P, int QG, int WM, int WN>
+struct Tile {
+    static constexpr int TH = WM * P;                 // output rows per workgroup
+    static constexpr int TW = 32;                     // output columns per workgroup (one MFMA M)
+    static constexpr int IH = (TH - 1) * S + KS;      // input halo tile
+    static constexpr int IW = (TW - 1) * S + KS;
+    static constexpr int PS = KC + 4;                 // padded pixel stride (floats) in LDS
+    static constexpr int BUF = IH * IW * PS;          // floats per LDS buffer
+    static constexpr int Q4 = KC / 4;                 // float4 per pixel per chunk
+    static constexpr int NE = IH * IW * Q4;           // float4 elements per chunk tile
+    static constexpr int NI = (NE + 255) / 256;       // staging registers (float4) per thread
+    static constexpr int KK = KC / 8;                 // k-steps of 8 per (chunk, tap)
+    static constexpr int T = 2 * QG;                  // B tiles (f,m interleaved) per wave
+    static constexpr int PAD = (KS - 1) / 2;          // int(dilation*(k-1)/2), unet.py:30
+};
+
+template <int KS, int S, int KC, int P, int QG, int WM, int WN, bool MUL>
+__global__ __launch_bounds__(256) void gated_conv_kernel(const ConvKArgs a)
+{
+    using TL = Tile<KS, S, KC, P, QG, WM, WN>;
+    static_assert(WM * WN == 4, "4 waves per workgroup");
+    __shared__ __attribute__((aligned(16))) float lds[2 * TL::BUF];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave / WN, wn = wave % WN;
+    const int tx = blockIdx.x % a.tiles_x, ty = blockIdx.x / a.tiles_x;
+    const int ox0 = tx * TL::TW, oy0 = ty * TL::TH;
+    const int ix0 = ox0 * S - TL::PAD, iy0 = oy0 * S - TL::PAD;
+    const int NT = a.CoutPad >> 4;                                  // 2 tiles per 32 channels
+    const int nt0 = ((int)blockIdx.y * WN + wn) * TL::T;
+
+    // Staging registers of the A tile.  The (pixel, quad) a thread stages and its in-image test do
+    // not depend on the chunk; nothing consumes a staged value before lwrite(), so the global
+    // loads of chunk c+1 stay in flight under the MFMAs of chunk c.
+    float4 st[TL::NI];
+    float4 sm[MUL ? TL::NI : 1];
+    unsigned okmask = 0;
+#pragma unroll
+    for (int i = 0; i < TL::NI; ++i) {
+        const int e = tid + i * 256;
+        const int pix = e / TL::Q4;
+        const int gy = iy0 + pix / TL::IW, gx = ix0 + pix % TL::IW;
+        const bool ok = e < TL::NE && gy >= 0 && gy < a.inH && gx >= 0 && gx < a.inW;
+        okmask |= (ok ? 1u : 0u) << i;
+    }
+
+    auto gload = [&](int chunk) {
+        const SrcDev s = a.src[a.chunk_src[chunk]];
+        const int coff = a.chunk_coff[chunk];
+#pragma unroll
+        for (int i = 0; i < TL::NI; ++i) {
+            const int e = tid + i * 256;
+            const int q = e % TL::Q4;
+            const int pix = e / TL::Q4;
+            const int gy = iy0 + pix / TL::IW, gx = ix0 + pix % TL::IW;
+            const int sy = (gy << s.sl) >> s.sr, sx = (gx << s.sl) >> s.sr;
+            // out-of-image elements read element 0 (always mapped) and are zeroed in lwrite()
+            const int off = ((okmask >> i) & 1u) ? (sy * s.W + sx) * s.C + coff + 4 * q : 0;
+            st[i] = *reinterpret_cast<const float4 *>(s.p + off);
+            if (MUL) sm[i] = *reinterpret_cast<const float4 *>(a.mul + off);
+        }
+    };
+    auto lwrite = [&](float *buf) {
+#pragma unroll
+        for (int i = 0; i < TL::NI; ++i) {
+            const int e = tid + i * 256;
+            if (e < TL::NE) {
+                const int q = e % TL::Q4;
+                const int pix = e / TL::Q4;
+                float4 v = st[i];
+                if (MUL) { v.x *= sm[i].x; v.y *= sm[i].y; v.z *= sm[i].z; v.w *= sm[i].w; }
+                if (!((okmask >> i) & 1u)) v = make_float4(0.f, 0.f, 0.f, 0.f);
+                *reinterpret_cast<float4 *>(buf + pix * TL::PS + 4 * q) = v;
+            }
+        }
+    };
+
+    floatx16 acc[P][TL::T];
+#pragma unroll
+    for (int p = 0; p < P; ++p)
+#pragma unroll
+        for (int t = 0; t < TL::T; ++t)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[p][t][r] = 0.0f;
+
+    // B fragments: float4 index (step*NT + nt)*64 + lane
+    const float4 *wl = reinterpret_cast<const float4 *>(a.wp) + (size_t)nt0 * 64 + lane;
+    const int total_steps = a.nchunks * KS * KS * TL::KK;
+    float4 bnext[TL::T];
+#pragma unroll
+    for (int t = 0; t < TL::T; ++t) bnext[t] = wl[t * 64];
+
+    gload(0);
+    lwrite(lds);
+    __syncthreads();
+
+    // A fragment base inside a buffer: row (wm*P + p)*S, column (lane&31)*S, cin 4*(lane>>5)
+    const int abase = ((wm * P) * S * TL::IW + (lane & 31) * S) * TL::PS + 4 * (lane >> 5);
+
+    for (int chunk = 0; chunk < a.nchunks; ++chunk) {
+        const bool more = chunk + 1 < a.nchunks;
+        if (more) gload(chunk + 1);
+        const float *buf = lds + (chunk & 1) * TL::BUF;
+        const int step0 = chunk * KS * KS * TL::KK;
+#pragma unroll
+        for (int tap = 0; tap < KS * KS; ++tap) {
+            const int ky = tap / KS, kx = tap % KS;
+#pragma unroll
+            for (int kk = 0; kk < TL::KK; ++kk) {
+                float4 b[TL::T];
+#pragma unroll
+                for (int t = 0; t < TL::T; ++t) b[t] = bnext[t];
+                int nstep = step0 + tap * TL::KK + kk + 1;
+                nstep = nstep < total_steps ? nstep : total_steps - 1;
+#pragma unroll
+                for (int t = 0; t < TL::T; ++t) bnext[t] = wl[((size_t)nstep * NT + t) * 64];
+                float4 av[P];
+#pragma unroll
+                for (int p = 0; p < P; ++p)
+                    av[p] = *reinterpret_cast<const float4 *>(
+                        buf + abase + ((p * S + ky) * TL::IW + kx) * TL::PS + kk * 8);
+#pragma unroll
+                for (int p = 0; p < P; ++p)
+#pragma unroll
+                    for (int t = 0; t < TL::T; ++t) {
+                        acc[p][t] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[p].x, b[t].x, acc[p][t], 0, 0, 0);
+                        acc[p][t] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[p].y, b[t].y, acc[p][t], 0, 0, 0);
+                        acc[p][t] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[p].z, b[t].z, acc[p][t], 0, 0, 0);
+                        acc[p][t] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[p].w, b[t].w, acc[p][t], 0, 0, 0);
+                    }
+            }
+        }
+        if (more) lwrite(lds + ((chunk + 1) & 1) * TL::BUF);
+        __syncthreads();
+    }
+
+    // ---------------- epilogue: bias, ELU, sigmoid gate, BatchNorm(eval), residual, store
+    const int hi = lane >> 5;
+#pragma unroll
+    for (int g = 0; g < QG; ++g) {
+        const int c = ((nt0 >> 1) + g) * 32 + (lane & 31);
+        const float bf = a.params[c];
+        const float bm = a.params[a.CoutPad + c];
+        const float sc = a.params[2 * a.CoutPad + c];
+        const float sh = a.params[3 * a.CoutPad + c];
+        const bool c_ok = c < a.Cout;
+        const bool c_fill = !c_ok && a.fill_pad && c < a.out_cstride;
+#pragma unroll
+        for (int p = 0; p < P; ++p) {
+            const int oy = oy0 + wm * P + p;
+            if (oy >= a.outH) continue;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int ox = ox0 + (r & 3) + 8 * (r >> 2) + 4 * hi;
+                if (ox >= a.outW) continue;
+                const int opix = oy * a.outW + ox;
+                if (c_ok) {
+                    float f = acc[p][2 * g][r] + bf;
+                    const float m = acc[p][2 * g + 1][r] + bm;
+                    if (a.elu) f = elu1(f);
+                    float v = (f * sigmoidf(m)) * sc + sh;
+                    if (a.residual) v += a.residual[opix * a.Cout + c];
+                    a.out[opix * a.out_cstride + c] = v;
+                } else if (c_fill) {
+                    a.out[opix * a.out_cstride + c] = a.out_fill;
+                }
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// configuration table
+// ------------------------------------------------------------------------------------------
+typedef void (*conv_fn)(const ConvKArgs);
+
+struct ConvConfig {
+    const char *name;
+    int KS, S, KC, P, QG, WM, WN;
+    conv_fn fn;
+    conv_fn fn_mul;      // variant whose loader multiplies by a second tensor (FAM), or null
+};
+
+#define CFG(KS, S, KC, P, QG, WM, WN)                                                  \
+    {"k" #KS "s" #S "c" #KC "_p" #P "q" #QG "m" #WM "n" #WN, KS, S, KC, P, QG, WM, WN, \
+     gated_conv_kernel<KS, S, KC, P, QG, WM, WN, false>, nullptr}
+#define CFGM(KS, S, KC, P, QG, WM, WN)                                                 \
+    {"k" #KS "s" #S "c" #KC "_p" #P "q" #QG "m" #WM "n" #WN, KS, S, KC, P, QG, WM, WN, \
+     gated_conv_kernel<KS, S, KC, P, QG, WM, WN, false>,                               \
+     gated_conv_kernel<KS, S, KC, P, QG, WM, WN, true>}
+
+// Order matters: the first matching entry is the automatic choice.
+const ConvConfig g_configs[] = {
+    // 3x3 stride 1, 16-channel chunks (ResBlocks, FAM, AFF second conv, SCM third conv, fe5)
+    CFG(3, 1, 16, 2, 1, 4, 1),   //  0  G=1
+    CFGM(3, 1, 16, 2, 2, 4, 1),  //  1  G=2
+    CFGM(3, 1, 16, 2, 2, 2, 2),  //  2  G=4 (G=8 with grid.y=2)
+    CFGM(3, 1, 16, 1, 2, 1, 4),  //  3  G=8, one image row per workgroup
+    // 3x3 stride 1, 8-channel chunks (inputs straight from the 8-channel pyramid)
+    CFG(3, 1, 8, 2, 1, 4, 1),    //  4
+    CFG(3, 1, 8, 2, 2, 4, 1),    //  5
+    // 1x1, 16-channel chunks (SCM, AFF first conv, Convs)
+    CFG(1, 1, 16, 2, 1, 4, 1),   //  6
+    CFG(1, 1, 16, 2, 2, 4, 1),   //  7
+    CFG(1, 1, 16, 2, 2, 2, 2),   //  8
+    CFG(1, 1, 16, 1, 2, 1, 4),   //  9
+    // 1x1, 8-channel chunks (SCM tail: cat[x(8), main(P-8)])
+    CFG(1, 1, 8, 2, 2, 4, 1),    // 10
+    CFG(1, 1, 8, 2, 2, 2, 2),    // 11
+    CFG(1, 1, 8, 1, 2, 1, 4),    // 12
+    // 3x3 stride 2 (encoder downsampling)
+    CFG(3, 2, 16, 1, 2, 4, 1),   // 13
+    CFG(3, 2, 16, 1, 2, 2, 2),   // 14
+    // 4x4 stride 2 (decoder, before the bilinear x4)
+    CFG(4, 2, 16, 1, 1, 4, 1),   // 15
+    CFG(4, 2, 16, 1, 2, 4, 1),   // 16
+    CFG(4, 2, 16, 1, 2, 2, 2),   // 17
+    // alternatives kept for tuning sweeps
+    CFG(3, 1, 16, 1, 2, 2, 2),   // 18  G=4/8, two rows per workgroup
+    CFG(3, 1, 16, 1, 1, 4, 1),   // 19  G=1, four rows per workgroup
+    CFG(3, 1, 16, 2, 1, 2, 2),   // 20  G=2, 4 rows, B split over waves
+};
+constexpr int N_CONFIGS = sizeof(g_configs) / sizeof(g_configs[0]);
+
+int pick_config(int ks, int s, int kc, int groups)
+{
+    for (int i = 0; i < N_CONFIGS; ++i) {
+        const ConvConfig &c = g_configs[i];
+        if (c.KS == ks && c.S == s && c.KC == kc && groups % (c.WN * c.QG) == 0 &&
+            (c.WN * c.QG == groups || (c.WN * c.QG == 4 && groups == 8)))
+            return i;
+    }
+    for (int i = 0; i < N_CONFIGS; ++i) {
+        const ConvConfig &c = g_configs[i];
+        if (c.KS == ks && c.S == s && c.KC == kc && groups % (c.WN * c.QG) == 0) return i;
+    }
+    return -1;
+}
+
+int pad32(int c) { return (c + 31) / 32 * 32; }
+
+// ------------------------------------------------------------------------------------------
+// bilinear x4 upsample, align_corners=False (nn.Upsample, unet.py:200)
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void bilinear_up4_kernel(const float *__restrict__ in, int inH, int inW, int C,
+                                                           float *__restrict__ out)
+{
+    const int outH = inH * 4, outW = inW * 4, q4 = C >> 2;
+    const long long total = (long long)outH * outW * q4;
+    for (long long item = (long long)blockIdx.x * blockDim.x + threadIdx.x; item < total;
+         item += (long long)gridDim.x * blockDim.x) {
+        const int q = (int)(item % q4);
+        const long long pix = item / q4;
+        const int ox = (int)(pix % outW), oy = (int)(pix / outW);
+        // area_pixel_compute_source_index: src = 0.25*(dst+0.5)-0.5, clamped at 0
+        float sy = 0.25f * ((float)oy + 0.5f) - 0.5f;
+        float sx = 0.25f * ((float)ox + 0.5f) - 0.5f;
+        sy = sy < 0.f ? 0.f : sy;
+        sx = sx < 0.f ? 0.f : sx;
+        const int y0 = (int)sy, x0 = (int)sx;
+        const int y1 = y0 + (y0 < inH - 1 ? 1 : 0), x1 = x0 + (x0 < inW - 1 ? 1 : 0);
+        const float ly1 = sy - (float)y0, lx1 = sx - (float)x0;
+        const float ly0 = 1.f - ly1, lx0 = 1.f - lx1;
+        const float4 v00 = *reinterpret_cast<const float4 *>(in + ((long long)y0 * inW + x0) * C + 4 * q);
+        const float4 v01 = *reinterpret_cast<const float4 *>(in + ((long long)y0 * inW + x1) * C + 4 * q);
+        const float4 v10 = *reinterpret_cast<const float4 *>(in + ((long long)y1 * inW + x0) * C + 4 * q);
+        const float4 v11 = *reinterpret_cast<const float4 *>(in + ((long long)y1 * inW + x1) * C + 4 * q);
+        float4 o;
+        o.x = ly0 * (lx0 * v00.x + lx1 * v01.x) + ly1 * (lx0 * v10.x + lx1 * v11.x);
+        o.y = ly0 * (lx0 * v00.y + lx1 * v01.y) + ly1 * (lx0 * v10.y + lx1 * v11.y);
+        o.z = ly0 * (lx0 * v00.z + lx1 * v01.z) + ly1 * (lx0 * v10.z + lx1 * v11.z);
+        o.w = ly0 * (lx0 * v00.w + lx1 * v01.w) + ly1 * (lx0 * v10.w + lx1 * v11.w);
+        *reinterpret_cast<float4 *>(out + pix * C + 4 * q) = o;
+    }
+}
+
+}  // namespace
+
+// ------------------------------------------------------------------------------------------
+// C ABI
+// ------------------------------------------------------------------------------------------
+extern "C" int read_conv_config_count(void) { return N_CONFIGS; }
+extern "C" const char *read_conv_config_name(int config)
+{
+    return (config >= 0 && config < N_CONFIGS) ? g_configs[config].name : "";
+}
+
+extern "C" size_t read_conv_packed_floats(int Cin, int Cout, int ksize)
+{
+    if (Cin < 8 || Cin % 8 || Cout < 1 || (ksize != 1 && ksize != 3 && ksize != 4)) return 0;
+    return (size_t)Cin * ksize * ksize * 2 * pad32(Cout);
+}
+extern "C" size_t read_conv_param_floats(int Cout) { return Cout < 1 ? 0 : (size_t)4 * pad32(Cout); }
+
+extern "C" int read_conv_pack_weights_host(int Cin, int Cout, int ksize, int kc, const float *wf, const float *wm,
+                                           float *wpacked_host)
+{
+    READ_CHECK_ARG(wf && wm && wpacked_host, "read_conv_pack_weights_host: null pointer");
+    READ_CHECK_ARG(ksize == 1 || ksize == 3 || ksize == 4, "read_conv_pack_weights_host: ksize must be 1, 3 or 4");
+    READ_CHECK_ARG((kc == 8 || kc == 16) && Cin >= kc && Cin % kc == 0,
+                   "read_conv_pack_weights_host: Cin=%d is not a multiple of kc=%d", Cin, kc);
+    READ_CHECK_ARG(Cout >= 1, "read_conv_pack_weights_host: Cout < 1");
+    const int CoutPad = pad32(Cout), NT = CoutPad / 16, KK = kc / 8, taps = ksize * ksize;
+    const int nchunks = Cin / kc;
+    size_t o = 0;
+    for (int chunk = 0; chunk < nchunks; ++chunk)
+        for (int tap = 0; tap < taps; ++tap)
+            for (int kk = 0; kk < KK; ++kk)
+                for (int nt = 0; nt < NT; ++nt) {
+                    const float *w = (nt & 1) ? wm : wf;
+                    for (int lane = 0; lane < 64; ++lane)
+                        for (int j = 0; j < 4; ++j, ++o) {
+                            const int cout = (nt >> 1) * 32 + (lane & 31);
+                            const int cin = chunk * kc + kk * 8 + 4 * (lane >> 5) + j;
+                            wpacked_host[o] = cout < Cout ? w[((size_t)cout * Cin + cin) * taps + tap] : 0.0f;
+                        }
+                }
+    return READ_OK;
+}
+
+extern "C" int read_conv_pack_params_host(int Cout, const float *bf, const float *bm, const float *gamma,
+                                          const float *beta, const float *mean, const float *var, float eps,
+                                          float *params_host)
+{
+    READ_CHECK_ARG(bf && bm && gamma && beta && mean && var && params_host, "read_conv_pack_params_host: null pointer");
+    READ_CHECK_ARG(Cout >= 1, "read_conv_pack_params_host: Cout < 1");
+    const int CoutPad = pad32(Cout);
+    for (int c = 0; c < CoutPad; ++c) {
+        const bool ok = c < Cout;
+        // eval-mode BatchNorm folded to y = x*scale + shift (applied AFTER the gate product)
+        const float scale = ok ? gamma[c] / sqrtf(var[c] + eps) : 0.0f;
+        params_host[c] = ok ? bf[c] : 0.0f;
+        params_host[CoutPad + c] = ok ? bm[c] : 0.0f;
+        params_host[2 * CoutPad + c] = scale;
+        params_host[3 * CoutPad + c] = ok ? beta[c] - mean[c] * scale : 0.0f;
+    }
+    return READ_OK;
+}
+
+namespace readhip {
+
+// Validates a descriptor, builds kernel arguments and launches.  Shared by the single-layer
+// entry point and the UNet executor.
+int launch_gated_conv(const read_conv_desc *d, hipStream_t stream)
+{
+    READ_CHECK_ARG(d, "read_gated_conv_forward: null descriptor");
+    READ_CHECK_ARG(d->n_src >= 1 && d->n_src <= READ_CONV_MAX_SRC, "read_gated_conv_forward: n_src must be 1..%d",
+                   READ_CONV_MAX_SRC);
+    READ_CHECK_ARG(d->ksize == 1 || d->ksize == 3 || d->ksize == 4, "read_gated_conv_forward: ksize must be 1,3,4");
+    READ_CHECK_ARG(d->stride == 1 || d->stride == 2, "read_gated_conv_forward: stride must be 1 or 2");
+    READ_CHECK_ARG(d->inH >= 1 && d->inW >= 1 && d->Cout >= 1, "read_gated_conv_forward: bad sizes");
+    READ_CHECK_ARG(d->wpacked && d->params && d->out, "read_gated_conv_forward: null weights/params/out");
+    READ_CHECK_ARG(d->out_cstride >= d->Cout, "read_gated_conv_forward: out_cstride < Cout");
+    READ_CHECK_ARG(!d->mul || d->n_src == 1, "read_gated_conv_forward: mul needs a single source");
+    READ_CHECK_ARG((uintptr_t)d->wpacked % 16 == 0, "read_gated_conv_forward: packed weights misaligned");
+
+    ConvKArgs a;
+    memset(&a, 0, sizeof(a));
+    int Cin = 0, kc = 16;
+    for (int i = 0; i < d->n_src; ++i) {
+        const read_conv_src &s = d->src[i];
+        READ_CHECK_ARG(s.data && (uintptr_t)s.data % 16 == 0, "read_gated_conv_forward: source %d null or misaligned", i);
+        READ_CHECK_ARG(s.C >= 8 && s.C % 8 == 0, "read_gated_conv_forward: source %d has C=%d (need a multiple of 8)", i, s.C);
+        READ_CHECK_ARG(s.shift >= -4 && s.shift <= 4, "read_gated_conv_forward: shift out of range");
+        READ_CHECK_ARG((long long)s.srcH * s.srcW * s.C < (1ll << 31), "read_gated_conv_forward: source too large");
+        const int needH = s.shift >= 0 ? ((d->inH - 1) << s.shift) + 1 : ((d->inH - 1) >> -s.shift) + 1;
+        const int needW = s.shift >= 0 ? ((d->inW - 1) << s.shift) + 1 : ((d->inW - 1) >> -s.shift) + 1;
+        READ_CHECK_ARG(s.srcH >= needH && s.srcW >= needW, "read_gated_conv_forward: source %d (%dx%d) too small for %dx%d at shift %d",
+                       i, s.srcH, s.srcW, d->inH, d->inW, s.shift);
+        if (s.C % 16) kc = 8;
+        Cin += s.C;
+        a.src[i].p = s.data;
+        a.src[i].C = s.C;
+        a.src[i].H = s.srcH;
+        a.src[i].W = s.srcW;
+        a.src[i].sl = s.shift > 0 ? s.shift : 0;
+        a.src[i].sr = s.shift < 0 ? -s.shift : 0;
+    }
+    READ_CHECK_ARG(!d->mul || d->src[0].shift == 0, "read_gated_conv_forward: mul needs shift 0");
+    const int nchunks = Cin / kc;
+    READ_CHECK_ARG(nchunks <= MAX_CHUNKS, "read_gated_conv_forward: too many input chunks (%d)", nchunks);
+    {
+        int ch = 0;
+        for (int i = 0; i < d->n_src; ++i)
+            for (int c = 0; c < d->src[i].C; c += kc, ++ch) {
+                a.chunk_src[ch] = (unsigned char)i;
+                a.chunk_coff[ch] = (unsigned short)c;
+            }
+    }
+    const int pad = (d->ksize - 1) / 2;
+    const int outH = (d->inH + 2 * pad - d->ksize) / d->stride + 1;
+    const int outW = (d->inW + 2 * pad - d->ksize) / d->stride + 1;
+    READ_CHECK_ARG(outH >= 1 && outW >= 1, "read_gated_conv_forward: empty output");
+    READ_CHECK_ARG((long long)outH * outW * d->out_cstride < (1ll << 31), "read_gated_conv_forward: output too large");
+    const int CoutPad = pad32(d->Cout), groups = CoutPad / 32;
+    int cfg = d->config;
+    if (cfg < 0) cfg = pick_config(d->ksize, d->stride, kc, groups);
+    READ_CHECK_ARG(cfg >= 0 && cfg < N_CONFIGS, "read_gated_conv_forward: no kernel for k=%d s=%d kc=%d groups=%d",
+                   d->ksize, d->stride, kc, groups);
+    const ConvConfig &c = g_configs[cfg];
+    READ_CHECK_ARG(c.KS == d->ksize && c.S == d->stride && c.KC == kc && groups % (c.WN * c.QG) == 0,
+                   "read_gated_conv_forward: config %s does not fit k=%d s=%d kc=%d groups=%d", c.name, d->ksize,
+                   d->stride, kc, groups);
+    a.mul = d->mul;
+    a.wp = d->wpacked;
+    a.params = d->params;
+    a.residual = d->residual;
+    a.out = d->out;
+    a.inH = d->inH;
+    a.inW = d->inW;
+    a.outH = outH;
+    a.outW = outW;
+    a.Cout = d->Cout;
+    a.CoutPad = CoutPad;
+    a.out_cstride = d->out_cstride;
+    a.nchunks = nchunks;
+    a.tiles_x = ceil_div(outW, 32);
+    a.elu = d->elu;
+    a.fill_pad = d->fill_pad;
+    a.out_fill = d->out_fill;
+    const int tiles_y = ceil_div(outH, c.WM * c.P);
+    const dim3 grid((unsigned)(a.tiles_x * tiles_y), (unsigned)(groups / (c.WN * c.QG)));
+    conv_fn fn = c.fn;
+    if (d->mul) {
+        READ_CHECK_ARG(c.fn_mul, "read_gated_conv_forward: config %s has no multiply variant", c.name);
+        READ_CHECK_ARG((uintptr_t)d->mul % 16 == 0, "read_gated_conv_forward: mul misaligned");
+        fn = c.fn_mul;
+    }
+    hipLaunchKernelGGL(fn, grid, dim3(256), 0, stream, a);
+    READ_CHECK_LAUNCH();
+    return READ_OK;
+}
+
+int conv_kc_for(const read_conv_desc *d)
+{
+    int kc = 16;
+    for (int i = 0; i < d->n_src; ++i)
+        if (d->src[i].C % 16) kc = 8;
+    return kc;
+}
+
+}  // namespace readhip
+
+extern "C" int read_gated_conv_forward(const read_conv_desc *desc, void *stream)
+{
+    return readhip::launch_gated_conv(desc, as_stream(stream));
+}
+
+extern "C" int read_bilinear_up4(const float *in, int inH, int inW, int C, float *out, void *stream)
+{
+    READ_CHECK_ARG(in && out && inH >= 1 && inW >= 1, "read_bilinear_up4: null pointer or empty input");
+    READ_CHECK_ARG(C >= 4 && C % 4 == 0, "read_bilinear_up4: C must be a multiple of 4");
+    READ_CHECK_ARG((uintptr_t)in % 16 == 0 && (uintptr_t)out % 16 == 0, "read_bilinear_up4: misaligned pointer");
+    const long long total = (long long)inH * 4 * inW * 4 * (C / 4);
+    long long blocks = ceil_div64(total, 256);
+    if (blocks > 256 * 8) blocks = 256 * 8;
+    hipLaunchKernelGGL(bilinear_up4_kernel, dim3((unsigned)blocks), dim3(256), 0, as_stream(stream), in, inH, inW, C, out);
+    READ_CHECK_LAUNCH();
+    return READ_OK;
+}

@@ -1,0 +1,215 @@
+// Descriptor gather / scatter-add for gfx950.
+//
+// Replaces PointTexture.forward (READ/models/texture.py:42-70: index_select over a (C, B*N)
+// channel-major table, i.e. C scattered 4-byte reads per pixel at stride 4*N bytes) with a
+// row-major N x C table (32-byte rows at C = 8): one 16-byte load + one 16-byte NHWC store per
+// lane, all pyramid levels in a single launch.  Background pixels carry id 0 and therefore
+// receive descriptor[0], exactly as the reference (SURVEY.md "Empty pixels sample point 0").
+// Backward = scatter-add of dL/dfeat into the rows (autograd of texture.py:61).
+// HBM-bound: algorithmic bytes = sum_l px_l * (4 + 4C + 4C).
+#include "common.h"
+
+using namespace readhip;
+
+namespace {
+
+struct LevelTable {
+    const int32_t *idx[READ_MAX_LEVELS];
+    float *feat[READ_MAX_LEVELS];
+    long long end[READ_MAX_LEVELS];   // exclusive prefix end, in units of (pixel, quad) items
+    int levels;
+};
+
+__device__ __forceinline__ float act_apply(float v, int activation)
+{
+    if (activation == 1) return 1.0f / (1.0f + expf(-v));
+    if (activation == 2) return tanhf(v);
+    return v;
+}
+
+// item = (pixel, quad of 4 channels); consecutive lanes -> consecutive quads of consecutive pixels,
+// so the NHWC store is fully coalesced.
+__global__ __launch_bounds__(256) void gather_forward_kernel(const float *__restrict__ rows, long long n, int C,
+                                                             LevelTable tab, int activation)
+{
+    const int qpp = C >> 2;
+    const long long total = tab.end[tab.levels - 1];
+    for (long long item = (long long)blockIdx.x * blockDim.x + threadIdx.x; item < total;
+         item += (long long)gridDim.x * blockDim.x) {
+        int l = 0;
+        long long base = 0;
+#pragma unroll
+        for (int k = 0; k < READ_MAX_LEVELS - 1; ++k)
+            if (k < tab.levels - 1 && item >= tab.end[k]) { l = k + 1; base = tab.end[k]; }
+        const long long local = item - base;
+        const long long pix = local / qpp;
+        const int q = (int)(local - pix * qpp);
+        long long id = tab.idx[l][pix];
+        id = id < 0 ? 0 : (id >= n ? n - 1 : id);   // defensive clamp; ids come from the rasteriser
+        float4 v = *reinterpret_cast<const float4 *>(rows + id * C + 4 * q);
+        if (activation) {
+            v.x = act_apply(v.x, activation);
+            v.y = act_apply(v.y, activation);
+            v.z = act_apply(v.z, activation);
+            v.w = act_apply(v.w, activation);
+        }
+        *reinterpret_cast<float4 *>(tab.feat[l] + pix * C + 4 * q) = v;
+    }
+}
+
+struct LevelTableBwd {
+    const int32_t *idx[READ_MAX_LEVELS];
+    const float *dfeat[READ_MAX_LEVELS];
+    long long end[READ_MAX_LEVELS];
+    int levels;
+};
+
+__global__ __launch_bounds__(256) void gather_backward_kernel(float *__restrict__ drows, long long n, int C,
+                                                              LevelTableBwd tab)
+{
+    const int qpp = C >> 2;
+    const long long total = tab.end[tab.levels - 1];
+    for (long long item = (long long)blockIdx.x * blockDim.x + threadIdx.x; item < total;
+         item += (long long)gridDim.x * blockDim.x) {
+        int l = 0;
+        long long base = 0;
+#pragma unroll
+        for (int k = 0; k < READ_MAX_LEVELS - 1; ++k)
+            if (k < tab.levels - 1 && item >= tab.end[k]) { l = k + 1; base = tab.end[k]; }
+        const long long local = item - base;
+        const long long pix = local / qpp;
+        const int q = (int)(local - pix * qpp);
+        long long id = tab.idx[l][pix];
+        id = id < 0 ? 0 : (id >= n ? n - 1 : id);
+        const float4 g = *reinterpret_cast<const float4 *>(tab.dfeat[l] + pix * C + 4 * q);
+        float *dst = drows + id * C + 4 * q;
+        atomicAdd(dst + 0, g.x);
+        atomicAdd(dst + 1, g.y);
+        atomicAdd(dst + 2, g.z);
+        atomicAdd(dst + 3, g.w);
+    }
+}
+
+// (C, N) -> N x C: lane = point, C strided-but-coalesced loads, one contiguous row store.
+__global__ __launch_bounds__(256) void texture_to_rows_kernel(const float *__restrict__ tex, long long n, int C,
+                                                              float *__restrict__ rows)
+{
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    for (int c = 0; c < C; c += 4) {
+        float4 v;
+        v.x = tex[(long long)(c + 0) * n + i];
+        v.y = tex[(long long)(c + 1) * n + i];
+        v.z = tex[(long long)(c + 2) * n + i];
+        v.w = tex[(long long)(c + 3) * n + i];
+        *reinterpret_cast<float4 *>(rows + i * C + c) = v;
+    }
+}
+
+__global__ __launch_bounds__(256) void rows_to_texture_kernel(const float *__restrict__ rows, long long n, int C,
+                                                              float *__restrict__ tex)
+{
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    for (int c = 0; c < C; c += 4) {
+        const float4 v = *reinterpret_cast<const float4 *>(rows + i * C + c);
+        tex[(long long)(c + 0) * n + i] = v.x;
+        tex[(long long)(c + 1) * n + i] = v.y;
+        tex[(long long)(c + 2) * n + i] = v.z;
+        tex[(long long)(c + 3) * n + i] = v.w;
+    }
+}
+
+int check_levels(const char *who, int64_t n, int C, int levels, const void *idx, const int64_t *count, const void *ptrs)
+{
+    READ_CHECK_ARG(n >= 1, "%s: empty descriptor table", who);
+    READ_CHECK_ARG(C >= 4 && C % 4 == 0 && C <= 64, "%s: C must be a multiple of 4 in [4,64] (got %d)", who, C);
+    READ_CHECK_ARG(levels >= 1 && levels <= READ_MAX_LEVELS, "%s: levels must be 1..%d", who, READ_MAX_LEVELS);
+    READ_CHECK_ARG(idx && count && ptrs, "%s: null level table", who);
+    return READ_OK;
+}
+
+}  // namespace
+
+extern "C" int read_texture_to_rows(const float *tex_cn, int64_t n, int C, float *rows_nc, void *stream)
+{
+    READ_CHECK_ARG(tex_cn && rows_nc && n >= 1, "read_texture_to_rows: null pointer or empty table");
+    READ_CHECK_ARG(C >= 4 && C % 4 == 0, "read_texture_to_rows: C must be a multiple of 4");
+    READ_CHECK_ARG((uintptr_t)rows_nc % 16 == 0, "read_texture_to_rows: rows must be 16-byte aligned");
+    hipLaunchKernelGGL(texture_to_rows_kernel, dim3((unsigned)ceil_div64(n, 256)), dim3(256), 0, as_stream(stream),
+                       tex_cn, (long long)n, C, rows_nc);
+    READ_CHECK_LAUNCH();
+    return READ_OK;
+}
+
+extern "C" int read_rows_to_texture(const float *rows_nc, int64_t n, int C, float *tex_cn, void *stream)
+{
+    READ_CHECK_ARG(tex_cn && rows_nc && n >= 1, "read_rows_to_texture: null pointer or empty table");
+    READ_CHECK_ARG(C >= 4 && C % 4 == 0, "read_rows_to_texture: C must be a multiple of 4");
+    READ_CHECK_ARG((uintptr_t)rows_nc % 16 == 0, "read_rows_to_texture: rows must be 16-byte aligned");
+    hipLaunchKernelGGL(rows_to_texture_kernel, dim3((unsigned)ceil_div64(n, 256)), dim3(256), 0, as_stream(stream),
+                       rows_nc, (long long)n, C, tex_cn);
+    READ_CHECK_LAUNCH();
+    return READ_OK;
+}
+
+extern "C" int read_gather_forward(const float *rows_nc, int64_t n, int C, int levels,
+                                   const int32_t *const *idx_levels, const int64_t *count_levels,
+                                   float *const *feat_levels, int activation, void *stream)
+{
+    int rc = check_levels("read_gather_forward", n, C, levels, idx_levels, count_levels, feat_levels);
+    if (rc) return rc;
+    READ_CHECK_ARG(rows_nc && (uintptr_t)rows_nc % 16 == 0, "read_gather_forward: rows null or misaligned");
+    READ_CHECK_ARG(activation >= 0 && activation <= 2, "read_gather_forward: activation must be 0,1,2");
+    LevelTable tab;
+    memset(&tab, 0, sizeof(tab));
+    long long acc = 0;
+    const int qpp = C / 4;
+    for (int l = 0; l < levels; ++l) {
+        READ_CHECK_ARG(count_levels[l] >= 0, "read_gather_forward: negative pixel count");
+        READ_CHECK_ARG(count_levels[l] == 0 || (idx_levels[l] && feat_levels[l]), "read_gather_forward: null level %d", l);
+        READ_CHECK_ARG((uintptr_t)feat_levels[l] % 16 == 0, "read_gather_forward: feat level %d misaligned", l);
+        tab.idx[l] = idx_levels[l];
+        tab.feat[l] = feat_levels[l];
+        acc += count_levels[l] * qpp;
+        tab.end[l] = acc;
+    }
+    tab.levels = levels;
+    if (acc == 0) return READ_OK;
+    int64_t blocks = ceil_div64(acc, 256);
+    if (blocks > 256 * 8) blocks = 256 * 8;
+    hipLaunchKernelGGL(gather_forward_kernel, dim3((unsigned)blocks), dim3(256), 0, as_stream(stream), rows_nc,
+                       (long long)n, C, tab, activation);
+    READ_CHECK_LAUNCH();
+    return READ_OK;
+}
+
+extern "C" int read_gather_backward(float *drows_nc, int64_t n, int C, int levels,
+                                    const int32_t *const *idx_levels, const int64_t *count_levels,
+                                    const float *const *dfeat_levels, void *stream)
+{
+    int rc = check_levels("read_gather_backward", n, C, levels, idx_levels, count_levels, dfeat_levels);
+    if (rc) return rc;
+    READ_CHECK_ARG(drows_nc, "read_gather_backward: drows is null");
+    LevelTableBwd tab;
+    memset(&tab, 0, sizeof(tab));
+    long long acc = 0;
+    const int qpp = C / 4;
+    for (int l = 0; l < levels; ++l) {
+        READ_CHECK_ARG(count_levels[l] >= 0, "read_gather_backward: negative pixel count");
+        READ_CHECK_ARG(count_levels[l] == 0 || (idx_levels[l] && dfeat_levels[l]), "read_gather_backward: null level %d", l);
+        READ_CHECK_ARG((uintptr_t)dfeat_levels[l] % 16 == 0, "read_gather_backward: dfeat level %d misaligned", l);
+        tab.idx[l] = idx_levels[l];
+        tab.dfeat[l] = dfeat_levels[l];
+        acc += count_levels[l] * qpp;
+        tab.end[l] = acc;
+    }
+    tab.levels = levels;
+    if (acc == 0) return READ_OK;
+    int64_t blocks = ceil_div64(acc, 256);
+    if (blocks > 256 * 8) blocks = 256 * 8;
+    hipLaunchKernelGGL(gather_backward_kernel, dim3((unsigned)blocks), dim3(256), 0, as_stream(stream), drows_nc,
+                       (long long)n, C, tab);
+    READ_CHECK_LAUNCH();
+    return READ_OK;
+}

@@ -1,0 +1,312 @@
+// Z-buffered point splat for gfx950.
+//
+// Replaces the reference's per-scale, per-camera DepthProject launches
+// (MyRender/CloudProjection/point_render.cu:125-200; GL twin READ/gl/render.py:52-85) with
+//   1. splat_project : ONE pass over the cloud for all B cameras.  Each accepted point becomes a
+//      packed 64-bit key (fp32 depth bits << 32 | point id) and is folded into the level-0 key
+//      image with an unsigned 64-bit atomic min — min depth, ties -> min id, order independent
+//      (SURVEY.md App. A.3).  A relaxed L1-bypassing read of the current key filters out the
+//      points that cannot win before they cost an atomic (keys only ever decrease, so a stale
+//      read is merely conservative).
+//   2. splat_resolve : one small pass over the key image that derives levels 1..4 by 2x2 key-min
+//      (exactly the reference's five rasterisations, App. A.4), unpacks (id, depth) for every
+//      level and resets the key image to EMPTY for the next frame.
+//
+// HBM-bound: algorithmic bytes per frame = 12*N (xyz read once) + 8*sum_l(h_l*w_l) (id + depth).
+// The arithmetic that decides which PIXEL a point lands in is bit-exact fp32: no FMA
+// contraction, IEEE division, left-to-right dot products (helper_math.h:1252-1255).
+#include "common.h"
+
+#pragma clang fp contract(off)
+
+using namespace readhip;
+
+namespace {
+
+constexpr unsigned long long EMPTY_KEY = ~0ull;
+constexpr int MAX_CAMS = 8;          // cameras folded into one pass over the points
+constexpr int PTS_PER_THREAD = 4;    // 3 x float4 = 4 points
+
+struct CamSet {
+    float m[MAX_CAMS][16];
+};
+
+typedef unsigned long long __attribute__((address_space(1))) *gkey_ptr;
+
+// point_render.cu:135-147 for one point and one camera; returns the pixel or -1.
+__device__ __forceinline__ int project_one(float x, float y, float z, const float *M, int W, int H,
+                                           float &depth)
+{
+    const float c0 = M[0] * x + M[1] * y + M[2] * z + M[3] * 1.0f;
+    const float c1 = M[4] * x + M[5] * y + M[6] * z + M[7] * 1.0f;
+    const float c2 = M[8] * x + M[9] * y + M[10] * z + M[11] * 1.0f;
+    const float c3 = M[12] * x + M[13] * y + M[14] * z + M[15] * 1.0f;
+    const float nx = c0 / c3, ny = c1 / c3, nz = c2 / c3;
+    // NaN compares false everywhere: written so that NaN is rejected (canonical semantics).
+    const bool inside = (nx >= -1.0f) & (nx <= 1.0f) & (ny >= -1.0f) & (ny <= 1.0f) &
+                        (nz >= -1.0f) & (nz <= 1.0f);
+    if (!inside) return -1;
+    const float u = ((float)W * (nx + 1.0f)) * 0.5f;
+    const float v = ((float)H * (1.0f - ny)) * 0.5f;
+    depth = (nz + 1.0f) * 0.5f;
+    const int xx = (int)u, yy = (int)v;
+    if (xx < 0 || xx >= W || yy < 0 || yy >= H) return -1;
+    return yy * W + xx;
+}
+
+__device__ __forceinline__ void fold_key(unsigned long long *keys, int pix, float depth, unsigned id)
+{
+    const unsigned long long key = ((unsigned long long)__float_as_uint(depth) << 32) | id;
+    // Early-z: relaxed agent-scope load (global_load_dwordx2 sc1: served by L2, never by the
+    // CU's stale L1).  Keys decrease monotonically, so "not smaller than what I can see" is final.
+    const unsigned long long seen = __hip_atomic_load(keys + pix, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (key < seen) atomicMin(keys + pix, key);
+}
+
+__global__ __launch_bounds__(256) void splat_project_kernel(const float *__restrict__ xyz, long long n,
+                                                            CamSet cams, int B, int W, int H,
+                                                            unsigned long long *__restrict__ keys,
+                                                            int vec_ok)
+{
+    const long long npx = (long long)W * H;
+    const long long groups = n / PTS_PER_THREAD;
+    const long long tid0 = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long long nthreads = (long long)gridDim.x * blockDim.x;
+
+    if (vec_ok) {
+        const float4 *xyz4 = reinterpret_cast<const float4 *>(xyz);
+        for (long long g = tid0; g < groups; g += nthreads) {
+            // 48 contiguous bytes per lane = 4 points
+            const float4 a = xyz4[3 * g + 0];
+            const float4 b = xyz4[3 * g + 1];
+            const float4 c = xyz4[3 * g + 2];
+            const float px[4] = {a.x, a.w, b.z, c.y};
+            const float py[4] = {a.y, b.x, b.w, c.z};
+            const float pz[4] = {a.z, b.y, c.x, c.w};
+            const unsigned id0 = (unsigned)(g * PTS_PER_THREAD);
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                for (int cam = 0; cam < B; ++cam) {
+                    float d;
+                    const int pix = project_one(px[k], py[k], pz[k], cams.m[cam], W, H, d);
+                    if (pix >= 0) fold_key(keys + cam * npx, pix, d, id0 + k);
+                }
+            }
+        }
+    }
+    // tail (n % 4 points), or everything when the pointer is not 16-byte aligned
+    const long long first = vec_ok ? groups * PTS_PER_THREAD : 0;
+    for (long long i = first + tid0; i < n; i += nthreads) {
+        const float x = xyz[3 * i + 0], y = xyz[3 * i + 1], z = xyz[3 * i + 2];
+        for (int cam = 0; cam < B; ++cam) {
+            float d;
+            const int pix = project_one(x, y, z, cams.m[cam], W, H, d);
+            if (pix >= 0) fold_key(keys + cam * npx, pix, d, (unsigned)i);
+        }
+    }
+}
+
+struct ResolveOut {
+    int32_t *idx[READ_MAX_LEVELS];
+    float *depth[READ_MAX_LEVELS];
+};
+
+__device__ __forceinline__ void emit(const ResolveOut &o, int level, long long off, unsigned long long key)
+{
+    const bool empty = key == EMPTY_KEY;
+    if (o.idx[level]) o.idx[level][off] = empty ? 0 : (int32_t)(unsigned)(key & 0xffffffffull);
+    if (o.depth[level]) o.depth[level][off] = empty ? 0.0f : __uint_as_float((unsigned)(key >> 32));
+}
+
+__device__ __forceinline__ unsigned long long kmin(unsigned long long a, unsigned long long b)
+{
+    return a < b ? a : b;
+}
+
+// One 256-thread block = a 32x32 tile of level 0; thread (qx,qy) owns a 2x2 quad.
+// Levels 2..4 are reduced through LDS (16x16 -> 8x8 -> 4x4 -> 2x2 keys).
+__global__ __launch_bounds__(256) void splat_resolve_kernel(unsigned long long *__restrict__ keys, int W, int H,
+                                                            int levels, ResolveOut out, int tiles_x,
+                                                            int tiles_y)
+{
+    __shared__ unsigned long long s1[256], s2[64], s3[16];
+    const int cam = blockIdx.y;
+    const int tx = blockIdx.x % tiles_x, ty = blockIdx.x / tiles_x;
+    const int t = threadIdx.x;
+    const int qx = t & 15, qy = t >> 4;
+    const int x0 = tx * 32 + qx * 2, y0 = ty * 32 + qy * 2;
+    const long long npx0 = (long long)W * H;
+    unsigned long long *kc = keys + cam * npx0;
+
+    unsigned long long k[2][2];
+#pragma unroll
+    for (int dy = 0; dy < 2; ++dy)
+#pragma unroll
+        for (int dx = 0; dx < 2; ++dx) {
+            const int x = x0 + dx, y = y0 + dy;
+            unsigned long long v = EMPTY_KEY;
+            if (x < W && y < H) {
+                const long long off = (long long)y * W + x;
+                v = kc[off];
+                kc[off] = EMPTY_KEY;                 // leave the workspace clean for the next frame
+                emit(out, 0, cam * npx0 + off, v);
+            }
+            k[dy][dx] = v;
+        }
+    if (levels < 2) return;
+    const unsigned long long k1 = kmin(kmin(k[0][0], k[0][1]), kmin(k[1][0], k[1][1]));
+    {
+        const int W1 = W >> 1, H1 = H >> 1, x = x0 >> 1, y = y0 >> 1;
+        if (x < W1 && y < H1) emit(out, 1, (long long)cam * W1 * H1 + (long long)y * W1 + x, k1);
+    }
+    if (levels < 3) return;
+    s1[t] = k1;
+    __syncthreads();
+    if (t < 64) {
+        const int x2 = t & 7, y2 = t >> 3;
+        const unsigned long long *r = s1 + (2 * y2) * 16 + 2 * x2;
+        const unsigned long long k2 = kmin(kmin(r[0], r[1]), kmin(r[16], r[17]));
+        s2[t] = k2;
+        const int W2 = W >> 2, H2 = H >> 2, x = tx * 8 + x2, y = ty * 8 + y2;
+        if (x < W2 && y < H2) emit(out, 2, (long long)cam * W2 * H2 + (long long)y * W2 + x, k2);
+    }
+    if (levels < 4) return;
+    __syncthreads();
+    if (t < 16) {
+        const int x3 = t & 3, y3 = t >> 2;
+        const unsigned long long *r = s2 + (2 * y3) * 8 + 2 * x3;
+        const unsigned long long k3 = kmin(kmin(r[0], r[1]), kmin(r[8], r[9]));
+        s3[t] = k3;
+        const int W3 = W >> 3, H3 = H >> 3, x = tx * 4 + x3, y = ty * 4 + y3;
+        if (x < W3 && y < H3) emit(out, 3, (long long)cam * W3 * H3 + (long long)y * W3 + x, k3);
+    }
+    if (levels < 5) return;
+    __syncthreads();
+    if (t < 4) {
+        const int x4 = t & 1, y4 = t >> 1;
+        const unsigned long long *r = s3 + (2 * y4) * 4 + 2 * x4;
+        const unsigned long long k4 = kmin(kmin(r[0], r[1]), kmin(r[4], r[5]));
+        const int W4 = W >> 4, H4 = H >> 4, x = tx * 2 + x4, y = ty * 2 + y4;
+        if (x < W4 && y < H4) emit(out, 4, (long long)cam * W4 * H4 + (long long)y * W4 + x, k4);
+    }
+}
+
+__global__ __launch_bounds__(256) void fill_keys_kernel(unsigned long long *keys, long long count)
+{
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < count) keys[i] = EMPTY_KEY;
+}
+
+__global__ __launch_bounds__(256) void index_to_float_kernel(const int32_t *__restrict__ idx, long long count,
+                                                             float *__restrict__ out)
+{
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < count) out[i] = (float)idx[i];
+}
+
+int level_dim(int v, int l)
+{
+    // int(v * 0.5**l)  (myrender.py:33-34); exact for the power-of-two scales used here
+    return (int)((double)v * (1.0 / (double)(1 << l)));
+}
+
+int project_and_resolve(const float *xyz, int64_t n, const float *M_host, int B, int W, int H, int levels,
+                        int32_t *const *idx_levels, float *const *depth_levels, int level_base,
+                        unsigned long long *keys, hipStream_t stream)
+{
+    for (int b0 = 0; b0 < B; b0 += MAX_CAMS) {
+        const int nb = (B - b0) < MAX_CAMS ? (B - b0) : MAX_CAMS;
+        CamSet cams;
+        memset(&cams, 0, sizeof(cams));
+        memcpy(cams.m, M_host + 16 * (size_t)b0, sizeof(float) * 16 * (size_t)nb);
+        if (n > 0) {
+            const int64_t work = ceil_div64(n, PTS_PER_THREAD);
+            // HBM-bound stream: cap the grid at 256 CUs x 8 blocks and grid-stride the rest
+            int64_t blocks = ceil_div64(work, 256);
+            if (blocks > 256 * 8) blocks = 256 * 8;
+            const int vec_ok = ((uintptr_t)xyz % 16) == 0;
+            hipLaunchKernelGGL(splat_project_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, xyz,
+                               (long long)n, cams, nb, W, H, keys, vec_ok);
+            READ_CHECK_LAUNCH();
+        }
+        ResolveOut out;
+        memset(&out, 0, sizeof(out));
+        for (int l = 0; l < levels; ++l) {
+            const size_t lpx = (size_t)level_dim(W, l) * level_dim(H, l);
+            if (idx_levels && idx_levels[level_base + l]) out.idx[l] = idx_levels[level_base + l] + lpx * b0;
+            if (depth_levels && depth_levels[level_base + l])
+                out.depth[l] = depth_levels[level_base + l] + lpx * b0;
+        }
+        const int tiles_x = ceil_div(W, 32), tiles_y = ceil_div(H, 32);
+        hipLaunchKernelGGL(splat_resolve_kernel, dim3(tiles_x * tiles_y, nb), dim3(256), 0, stream, keys, W, H,
+                           levels, out, tiles_x, tiles_y);
+        READ_CHECK_LAUNCH();
+    }
+    return READ_OK;
+}
+
+}  // namespace
+
+extern "C" size_t read_splat_workspace_bytes(int B, int W, int H)
+{
+    if (B < 1 || W < 1 || H < 1) return 0;
+    const int nb = B < MAX_CAMS ? B : MAX_CAMS;
+    return (size_t)nb * W * H * sizeof(unsigned long long);
+}
+
+extern "C" int read_splat_workspace_init(void *ws, size_t ws_bytes, void *stream)
+{
+    READ_CHECK_ARG(ws && ws_bytes % 8 == 0, "read_splat_workspace_init: workspace null or not a multiple of 8 bytes");
+    READ_CHECK_ARG((uintptr_t)ws % 16 == 0, "read_splat_workspace_init: workspace must be 16-byte aligned");
+    const long long count = (long long)(ws_bytes / 8);
+    if (count == 0) return READ_OK;
+    hipLaunchKernelGGL(fill_keys_kernel, dim3((unsigned)ceil_div64(count, 256)), dim3(256), 0, as_stream(stream),
+                       (unsigned long long *)ws, count);
+    READ_CHECK_LAUNCH();
+    return READ_OK;
+}
+
+extern "C" int read_splat_forward(const float *xyz, int64_t n, const float *M_host, int B, int W, int H,
+                                  int levels, int32_t *const *idx_levels, float *const *depth_levels,
+                                  void *ws, size_t ws_bytes, void *stream)
+{
+    READ_CHECK_ARG(n >= 0 && (n == 0 || xyz), "read_splat_forward: xyz is null");
+    READ_CHECK_ARG(n <= 0xFFFFFFFEll, "read_splat_forward: point ids must fit 32 bits");
+    READ_CHECK_ARG(M_host, "read_splat_forward: M_host is null");
+    READ_CHECK_ARG(B >= 1 && W >= 1 && H >= 1, "read_splat_forward: bad B/W/H (%d,%d,%d)", B, W, H);
+    READ_CHECK_ARG((long long)W * H < (1ll << 31), "read_splat_forward: image too large");
+    READ_CHECK_ARG(levels >= 1 && levels <= READ_MAX_LEVELS, "read_splat_forward: levels must be 1..%d",
+                   READ_MAX_LEVELS);
+    READ_CHECK_ARG(idx_levels || depth_levels, "read_splat_forward: no outputs requested");
+    READ_CHECK_ARG(level_dim(W, levels - 1) >= 1 && level_dim(H, levels - 1) >= 1,
+                   "read_splat_forward: coarsest level is empty");
+    READ_CHECK_ARG(ws && (uintptr_t)ws % 16 == 0, "read_splat_forward: workspace null or misaligned");
+    if (ws_bytes < read_splat_workspace_bytes(B, W, H)) {
+        set_error("read_splat_forward: workspace %zu < %zu bytes", ws_bytes, read_splat_workspace_bytes(B, W, H));
+        return READ_ENOMEM;
+    }
+    unsigned long long *keys = (unsigned long long *)ws;
+    hipStream_t s = as_stream(stream);
+    const int mask = (1 << (levels - 1)) - 1;
+    if (((W | H) & mask) == 0) {
+        // pyramid identity holds (App. A.4): one pass over the points feeds every level
+        return project_and_resolve(xyz, n, M_host, B, W, H, levels, idx_levels, depth_levels, 0, keys, s);
+    }
+    // generic sizes: rasterise each level directly, as the reference does
+    for (int l = 0; l < levels; ++l) {
+        const int rc = project_and_resolve(xyz, n, M_host, B, level_dim(W, l), level_dim(H, l), 1, idx_levels,
+                                           depth_levels, l, keys, s);
+        if (rc != READ_OK) return rc;
+    }
+    return READ_OK;
+}
+
+extern "C" int read_index_to_float(const int32_t *idx, int64_t count, float *out, void *stream)
+{
+    READ_CHECK_ARG(count >= 0 && (count == 0 || (idx && out)), "read_index_to_float: null pointer");
+    if (count == 0) return READ_OK;
+    hipLaunchKernelGGL(index_to_float_kernel, dim3((unsigned)ceil_div64(count, 256)), dim3(256), 0,
+                       as_stream(stream), idx, (long long)count, out);
+    READ_CHECK_LAUNCH();
+    return READ_OK;
+}

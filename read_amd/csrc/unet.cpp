@@ -1,0 +1,539 @@
+// READ's MIMO-UNet-style refinement CNN (READ/models/unet.py:121-285) as a pre-built launch plan.
+//
+// The network is fixed by the reference (get_net(): UNet(8, 3, feature_scale=4, num_res=4),
+// READ/pipelines/ogl.py:19-27; base_channel 32, unet.py:141), so the plan is built once per
+// resolution: 99 fused gated-conv launches + 3 bilinear x4 upsamples, every torch.cat /
+// F.interpolate(nearest) / FAM multiply / residual add folded into a conv's loader or epilogue.
+// Activations are NHWC fp32 in a caller-provided workspace; one C-ABI call enqueues a frame.
+#include <math.h>
+
+#include <string>
+#include <vector>
+
+#include "common.h"
+
+namespace readhip {
+int launch_gated_conv(const read_conv_desc *d, hipStream_t stream);
+}
+using namespace readhip;
+
+namespace {
+
+constexpr int BASE = 32;      // base_channel, unet.py:141
+constexpr int NUM_RES = 4;    // num_res, ogl.py:24
+constexpr int IN_CH = READ_DESC_CHANNELS;
+
+struct LayerInfo {
+    std::string path;
+    int cin, cout, k, stride, elu, kc;
+    size_t raw_off, w_off, p_off;   // float offsets into the raw / packed blobs
+};
+
+struct Arch {
+    std::vector<LayerInfo> layers;
+    size_t raw_floats = 0, packed_floats = 0;
+    int find(const std::string &p) const
+    {
+        for (size_t i = 0; i < layers.size(); ++i)
+            if (layers[i].path == p) return (int)i;
+        return -1;
+    }
+};
+
+size_t raw_layer_floats(int cin, int cout, int k) { return 2 * ((size_t)cout * cin * k * k + cout) + 4 * (size_t)cout; }
+
+const Arch &arch()
+{
+    static Arch A = [] {
+        Arch a;
+        auto add = [&](const std::string &path, int cin, int cout, int k, int s, int elu, int kc) {
+            LayerInfo L{path, cin, cout, k, s, elu, kc, 0, 0, 0};
+            L.raw_off = a.raw_floats;
+            a.raw_floats += raw_layer_floats(cin, cout, k);
+            L.w_off = a.packed_floats;
+            a.packed_floats += read_conv_packed_floats(cin, cout, k);
+            L.p_off = a.packed_floats;
+            a.packed_floats += read_conv_param_floats(cout);
+            a.layers.push_back(L);
+        };
+        // SCM (unet.py:92-106): SCM2 -> 64 planes @1/2, SCM1 -> 128 @1/4, SCM0 -> 256 @1/8
+        const int scm_planes[3] = {BASE * 8, BASE * 4, BASE * 2};   // SCM0, SCM1, SCM2
+        for (int n = 0; n < 3; ++n) {
+            const int P = scm_planes[n];
+            const std::string p = "SCM" + std::to_string(n);
+            add(p + ".main.0", IN_CH, P / 4, 3, 1, 1, 8);
+            add(p + ".main.1", P / 4, P / 2, 1, 1, 1, 16);
+            add(p + ".main.2", P / 2, P / 2, 3, 1, 1, 16);
+            add(p + ".main.3", P / 2, P - IN_CH, 1, 1, 1, 16);
+            add(p + ".conv", P, P, 1, 1, 0, 8);                     // cat[x(8), main(P-8)]
+        }
+        // feat_extract (unet.py:156-165)
+        add("feat_extract.0", IN_CH, BASE, 3, 1, 1, 8);
+        add("feat_extract.1", BASE, BASE * 2, 3, 2, 1, 16);
+        add("feat_extract.2", BASE * 2, BASE * 4, 3, 2, 1, 16);
+        add("feat_extract.3", BASE * 4, BASE * 2, 4, 2, 1, 16);
+        add("feat_extract.4", BASE * 2, BASE, 4, 2, 1, 16);
+        add("feat_extract.5", BASE, 3, 3, 1, 0, 16);
+        add("feat_extract.6", BASE * 4, BASE * 8, 3, 2, 1, 16);
+        add("feat_extract.7", BASE * 8, BASE * 4, 4, 2, 1, 16);
+        // Encoder / Decoder: 4 blocks x NUM_RES ResBlocks x 2 BasicConvs (unet.py:11-20,56-76)
+        for (int i = 0; i < 4; ++i)
+            for (int j = 0; j < NUM_RES; ++j) {
+                const int C = BASE << i;
+                const std::string p = "Encoder." + std::to_string(i) + ".layers." + std::to_string(j) + ".main.";
+                add(p + "0", C, C, 3, 1, 1, 16);
+                add(p + "1", C, C, 3, 1, 0, 16);
+            }
+        for (int i = 0; i < 4; ++i)
+            for (int j = 0; j < NUM_RES; ++j) {
+                const int C = (BASE * 8) >> i;
+                const std::string p = "Decoder." + std::to_string(i) + ".layers." + std::to_string(j) + ".main.";
+                add(p + "0", C, C, 3, 1, 1, 16);
+                add(p + "1", C, C, 3, 1, 0, 16);
+            }
+        add("Convs.0", BASE * 8, BASE * 4, 1, 1, 1, 16);
+        add("Convs.1", BASE * 4, BASE * 2, 1, 1, 1, 16);
+        add("Convs.2", BASE * 2, BASE, 1, 1, 1, 16);
+        add("ConvsOut.0", BASE * 4, 3, 3, 1, 0, 16);   // never executed (unet.py:181-186)
+        add("ConvsOut.1", BASE * 2, 3, 3, 1, 0, 16);
+        for (int i = 0; i < 3; ++i) {
+            const std::string p = "AFFs." + std::to_string(i) + ".conv.";
+            add(p + "0", BASE * 15, BASE << i, 1, 1, 1, 16);
+            add(p + "1", BASE << i, BASE << i, 3, 1, 0, 16);
+        }
+        add("FAM0.merge", BASE * 8, BASE * 8, 3, 1, 0, 16);
+        add("FAM1.merge", BASE * 4, BASE * 4, 3, 1, 0, 16);
+        add("FAM2.merge", BASE * 2, BASE * 2, 3, 1, 0, 16);
+        return a;
+    }();
+    return A;
+}
+
+// ------------------------------------------------------------------------------------------
+struct Tensor {
+    std::string name;
+    float *p = nullptr;   // null for external tensors until forward()
+    int ext = -1;         // 0..3 = x0..x3, 4 = rgb output
+    int H = 0, W = 0, C = 0;
+};
+
+struct Op {
+    enum Kind { CONV, UP4 } kind;
+    read_conv_desc d;          // CONV
+    int src_t[READ_CONV_MAX_SRC], mul_t, res_t, out_t;   // tensor ids (for external patching)
+    int in_t;                  // UP4
+    double flops;
+    int is_c3s1;
+    std::string label;
+};
+
+}  // namespace
+
+struct read_unet {
+    int H, W;
+    const float *packed;
+    char *ws;
+    size_t ws_bytes, ws_used;
+    std::vector<Tensor> tensors;
+    std::vector<Op> ops;
+    hipEvent_t *events = nullptr;
+    int n_events = 0;
+};
+
+namespace {
+
+size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
+
+struct Builder {
+    read_unet *u;
+    bool dry;                   // size-only pass
+    size_t used = 0;
+
+    int tensor(const std::string &name, int level, int C)
+    {
+        Tensor t;
+        t.name = name;
+        t.H = u->H >> level;
+        t.W = u->W >> level;
+        t.C = C;
+        const size_t bytes = align_up((size_t)t.H * t.W * C * sizeof(float), 256);
+        if (!dry) t.p = reinterpret_cast<float *>(u->ws + used);
+        used += bytes;
+        u->tensors.push_back(t);
+        return (int)u->tensors.size() - 1;
+    }
+    int external(const std::string &name, int ext, int level, int C)
+    {
+        Tensor t;
+        t.name = name;
+        t.ext = ext;
+        t.H = u->H >> level;
+        t.W = u->W >> level;
+        t.C = C;
+        u->tensors.push_back(t);
+        return (int)u->tensors.size() - 1;
+    }
+
+    // One BasicConv.  srcs = {tensor id, shift}; out tensor must already exist.
+    void conv(const std::string &path, std::vector<std::pair<int, int>> srcs, int out_t, int mul_t = -1,
+              int res_t = -1)
+    {
+        const Arch &A = arch();
+        const int li = A.find(path);
+        const LayerInfo &L = A.layers[li];
+        Op op;
+        memset(&op.d, 0, sizeof(op.d));
+        op.kind = Op::CONV;
+        op.label = path;
+        op.mul_t = mul_t;
+        op.res_t = res_t;
+        op.out_t = out_t;
+        op.in_t = -1;
+        for (int i = 0; i < READ_CONV_MAX_SRC; ++i) op.src_t[i] = -1;
+        const Tensor &o = u->tensors[out_t];
+        op.d.n_src = (int)srcs.size();
+        int cin = 0;
+        for (size_t i = 0; i < srcs.size(); ++i) {
+            const Tensor &t = u->tensors[srcs[i].first];
+            op.src_t[i] = srcs[i].first;
+            op.d.src[i].data = t.p;
+            op.d.src[i].C = t.C;
+            op.d.src[i].srcH = t.H;
+            op.d.src[i].srcW = t.W;
+            op.d.src[i].shift = srcs[i].second;
+            cin += t.C;
+        }
+        op.d.inH = o.H * L.stride;
+        op.d.inW = o.W * L.stride;
+        op.d.Cout = L.cout;
+        op.d.ksize = L.k;
+        op.d.stride = L.stride;
+        op.d.elu = L.elu;
+        op.d.wpacked = u->packed + L.w_off;
+        op.d.params = u->packed + L.p_off;
+        op.d.mul = mul_t >= 0 ? u->tensors[mul_t].p : nullptr;
+        op.d.residual = res_t >= 0 ? u->tensors[res_t].p : nullptr;
+        op.d.out = o.p;
+        op.d.out_cstride = o.C;
+        op.d.config = -1;
+        op.flops = 2.0 * 2.0 * (double)o.H * o.W * L.cout * cin * L.k * L.k;
+        op.is_c3s1 = (L.k == 3 && L.stride == 1 && L.cin == L.cout && L.cin >= BASE) ? 1 : 0;
+        if (cin != L.cin) set_error("internal: layer %s expects Cin=%d, plan gives %d", path.c_str(), L.cin, cin);
+        u->ops.push_back(op);
+    }
+    void up4(int in_t, int out_t)
+    {
+        Op op;
+        memset(&op.d, 0, sizeof(op.d));
+        op.kind = Op::UP4;
+        op.label = "up4(" + u->tensors[in_t].name + ")";
+        op.in_t = in_t;
+        op.out_t = out_t;
+        op.mul_t = op.res_t = -1;
+        for (int i = 0; i < READ_CONV_MAX_SRC; ++i) op.src_t[i] = -1;
+        op.flops = 0;
+        op.is_c3s1 = 0;
+        u->ops.push_back(op);
+    }
+
+    // 4 ResBlocks: x + BC1(BC0(x))  (unet.py:11-20); returns the tensor id holding the result.
+    int resblocks(const std::string &prefix, int x, int level, int C)
+    {
+        int t = tensor(prefix + ".t", level, C);
+        int y = tensor(prefix + ".y", level, C);
+        int spare = tensor(prefix + ".y2", level, C);
+        for (int j = 0; j < NUM_RES; ++j) {
+            const std::string p = prefix + ".layers." + std::to_string(j) + ".main.";
+            conv(p + "0", {{x, 0}}, t);
+            conv(p + "1", {{t, 0}}, y, -1, x);
+            // rotate: the block input may be needed later only for j == 0 (never overwritten:
+            // `spare` takes its place in the ring)
+            const int nx = y;
+            y = (j == 0) ? spare : x;
+            x = nx;
+        }
+        return x;
+    }
+
+    int scm(int n, int xin, int level)
+    {
+        const int P = (n == 0) ? BASE * 8 : (n == 1 ? BASE * 4 : BASE * 2);
+        const std::string p = "SCM" + std::to_string(n);
+        int a = tensor(p + ".a", level, P / 4);
+        int b = tensor(p + ".b", level, P / 2);
+        int c = tensor(p + ".c", level, P / 2);
+        int d = tensor(p + ".d", level, P - IN_CH);
+        int z = tensor(p + ".out", level, P);
+        conv(p + ".main.0", {{xin, 0}}, a);
+        conv(p + ".main.1", {{a, 0}}, b);
+        conv(p + ".main.2", {{b, 0}}, c);
+        conv(p + ".main.3", {{c, 0}}, d);
+        conv(p + ".conv", {{xin, 0}, {d, 0}}, z);
+        return z;
+    }
+
+    void build()
+    {
+        u->tensors.clear();
+        u->ops.clear();
+        used = 0;
+        const int x0 = external("x0", 0, 0, IN_CH), x1 = external("x1", 1, 1, IN_CH);
+        const int x2 = external("x2", 2, 2, IN_CH), x3 = external("x3", 3, 3, IN_CH);
+        const int rgb = external("rgb", 4, 0, 3);
+
+        // unet.py:214-216
+        const int z2 = scm(2, x1, 1), z4 = scm(1, x2, 2), z8 = scm(0, x3, 3);
+        // unet.py:219-220
+        int xf = tensor("fe0", 0, BASE);
+        conv("feat_extract.0", {{x0, 0}}, xf);
+        const int res1 = resblocks("Encoder.0", xf, 0, BASE);
+        // unet.py:224-226: z = fe1(res1); z = z + merge(z*z2); res2 = E1(z)
+        int f1 = tensor("fe1", 1, BASE * 2), fam2 = tensor("fam2", 1, BASE * 2);
+        conv("feat_extract.1", {{res1, 0}}, f1);
+        conv("FAM2.merge", {{f1, 0}}, fam2, z2, f1);
+        const int res2 = resblocks("Encoder.1", fam2, 1, BASE * 2);
+        // unet.py:228-230
+        int f2 = tensor("fe2", 2, BASE * 4), fam1 = tensor("fam1", 2, BASE * 4);
+        conv("feat_extract.2", {{res2, 0}}, f2);
+        conv("FAM1.merge", {{f2, 0}}, fam1, z4, f2);
+        const int res3 = resblocks("Encoder.2", fam1, 2, BASE * 4);
+        // unet.py:232-235
+        int f6 = tensor("fe6", 3, BASE * 8), fam0 = tensor("fam0", 3, BASE * 8);
+        conv("feat_extract.6", {{res3, 0}}, f6);
+        conv("FAM0.merge", {{f6, 0}}, fam0, z8, f6);
+        const int zb = resblocks("Encoder.3", fam0, 3, BASE * 8);
+
+        // unet.py:239-254: nearest resamples folded into the AFF 1x1 convs.
+        // shift > 0: source is finer than the destination (down-sampling), < 0: coarser.
+        int a0 = tensor("aff0.t", 0, BASE), r1 = tensor("aff0.out", 0, BASE);
+        conv("AFFs.0.conv.0", {{res1, 0}, {res2, -1}, {res3, -2}, {zb, -3}}, a0);
+        conv("AFFs.0.conv.1", {{a0, 0}}, r1);
+        int a1 = tensor("aff1.t", 1, BASE * 2), r2 = tensor("aff1.out", 1, BASE * 2);
+        conv("AFFs.1.conv.0", {{res1, 1}, {res2, 0}, {res3, -1}, {zb, -2}}, a1);
+        conv("AFFs.1.conv.1", {{a1, 0}}, r2);
+        int a2 = tensor("aff2.t", 2, BASE * 4), r3 = tensor("aff2.out", 2, BASE * 4);
+        conv("AFFs.2.conv.0", {{res1, 2}, {res2, 1}, {res3, 0}, {zb, -1}}, a2);
+        conv("AFFs.2.conv.1", {{a2, 0}}, r3);
+
+        // unet.py:257-265
+        int z = resblocks("Decoder.0", zb, 3, BASE * 8);
+        int f7 = tensor("fe7", 4, BASE * 4), u7 = tensor("up7", 2, BASE * 4), c0 = tensor("convs0", 2, BASE * 4);
+        conv("feat_extract.7", {{z, 0}}, f7);
+        up4(f7, u7);
+        conv("Convs.0", {{u7, 0}, {r3, 0}}, c0);
+        z = resblocks("Decoder.1", c0, 2, BASE * 4);
+        // unet.py:268-273
+        int f3 = tensor("fe3", 3, BASE * 2), u3 = tensor("up3", 1, BASE * 2), c1 = tensor("convs1", 1, BASE * 2);
+        conv("feat_extract.3", {{z, 0}}, f3);
+        up4(f3, u3);
+        conv("Convs.1", {{u3, 0}, {r2, 0}}, c1);
+        z = resblocks("Decoder.2", c1, 1, BASE * 2);
+        // unet.py:276-282
+        int f4 = tensor("fe4", 2, BASE), u4 = tensor("up4", 0, BASE), c2 = tensor("convs2", 0, BASE);
+        conv("feat_extract.4", {{z, 0}}, f4);
+        up4(f4, u4);
+        conv("Convs.2", {{u4, 0}, {r1, 0}}, c2);
+        z = resblocks("Decoder.3", c2, 0, BASE);
+        conv("feat_extract.5", {{z, 0}}, rgb);
+        u->ws_used = used;
+    }
+};
+
+int check_hw(int H, int W)
+{
+    READ_CHECK_ARG(H >= 16 && W >= 16 && H % 16 == 0 && W % 16 == 0,
+                   "UNet viewport must be a positive multiple of 16 in both dimensions (got %dx%d)", W, H);
+    READ_CHECK_ARG((long long)H * W * BASE * 15 < (1ll << 31), "viewport too large");
+    return READ_OK;
+}
+
+int run(read_unet *u, const float *const ext[5], int rgb_cstride, hipStream_t s, bool timed)
+{
+    int ev = 0;
+    for (Op &op : u->ops) {
+        if (timed) READ_CHECK_HIP(hipEventRecord(u->events[ev++], s));
+        auto ptr = [&](int t) -> const float * {
+            if (t < 0) return nullptr;
+            const Tensor &T = u->tensors[t];
+            return T.ext >= 0 ? ext[T.ext] : T.p;
+        };
+        if (op.kind == Op::CONV) {
+            read_conv_desc d = op.d;
+            for (int i = 0; i < d.n_src; ++i) d.src[i].data = ptr(op.src_t[i]);
+            d.mul = ptr(op.mul_t);
+            d.residual = ptr(op.res_t);
+            d.out = const_cast<float *>(ptr(op.out_t));
+            if (u->tensors[op.out_t].ext == 4) {
+                d.out_cstride = rgb_cstride;
+                d.fill_pad = rgb_cstride > d.Cout;   // RGBA: alpha = 1 (READ/gl/nn.py:124)
+                d.out_fill = 1.0f;
+            }
+            const int rc = launch_gated_conv(&d, s);
+            if (rc != READ_OK) return rc;
+        } else {
+            const Tensor &I = u->tensors[op.in_t];
+            const int rc = read_bilinear_up4(ptr(op.in_t), I.H, I.W, I.C, const_cast<float *>(ptr(op.out_t)), s);
+            if (rc != READ_OK) return rc;
+        }
+    }
+    if (timed) READ_CHECK_HIP(hipEventRecord(u->events[ev++], s));
+    return READ_OK;
+}
+
+}  // namespace
+
+extern "C" int read_unet_layer_count(void) { return (int)arch().layers.size(); }
+
+extern "C" int read_unet_layer_info(int i, const char **path, int *cin, int *cout, int *ksize, int *stride, int *elu)
+{
+    const Arch &A = arch();
+    READ_CHECK_ARG(i >= 0 && i < (int)A.layers.size(), "read_unet_layer_info: index %d out of range", i);
+    const LayerInfo &L = A.layers[i];
+    if (path) *path = L.path.c_str();
+    if (cin) *cin = L.cin;
+    if (cout) *cout = L.cout;
+    if (ksize) *ksize = L.k;
+    if (stride) *stride = L.stride;
+    if (elu) *elu = L.elu;
+    return READ_OK;
+}
+
+extern "C" size_t read_unet_raw_floats(void) { return arch().raw_floats; }
+extern "C" size_t read_unet_packed_floats(void) { return arch().packed_floats; }
+
+extern "C" int read_unet_pack_host(const float *raw, float bn_eps, float *packed)
+{
+    READ_CHECK_ARG(raw && packed, "read_unet_pack_host: null pointer");
+    for (const LayerInfo &L : arch().layers) {
+        const size_t wn = (size_t)L.cout * L.cin * L.k * L.k;
+        const float *wf = raw + L.raw_off, *bf = wf + wn, *wm = bf + L.cout, *bm = wm + wn;
+        const float *gamma = bm + L.cout, *beta = gamma + L.cout, *mean = beta + L.cout, *var = mean + L.cout;
+        int rc = read_conv_pack_weights_host(L.cin, L.cout, L.k, L.kc, wf, wm, packed + L.w_off);
+        if (rc) return rc;
+        rc = read_conv_pack_params_host(L.cout, bf, bm, gamma, beta, mean, var, bn_eps, packed + L.p_off);
+        if (rc) return rc;
+    }
+    return READ_OK;
+}
+
+extern "C" size_t read_unet_workspace_bytes(int H, int W)
+{
+    if (check_hw(H, W) != READ_OK) return 0;
+    read_unet tmp;
+    tmp.H = H;
+    tmp.W = W;
+    tmp.packed = nullptr;
+    tmp.ws = nullptr;
+    Builder b{&tmp, true};
+    b.build();
+    return tmp.ws_used;
+}
+
+extern "C" int read_unet_create(read_unet_t **out, const float *packed, int H, int W, void *ws, size_t ws_bytes)
+{
+    READ_CHECK_ARG(out && packed && ws, "read_unet_create: null pointer");
+    READ_CHECK_ARG((uintptr_t)packed % 16 == 0 && (uintptr_t)ws % 256 == 0, "read_unet_create: misaligned weights/workspace");
+    int rc = check_hw(H, W);
+    if (rc) return rc;
+    const size_t need = read_unet_workspace_bytes(H, W);
+    if (ws_bytes < need) {
+        set_error("read_unet_create: workspace %zu < %zu bytes", ws_bytes, need);
+        return READ_ENOMEM;
+    }
+    read_unet *u = new read_unet();
+    u->H = H;
+    u->W = W;
+    u->packed = packed;
+    u->ws = (char *)ws;
+    u->ws_bytes = ws_bytes;
+    set_error("");
+    Builder b{u, false};
+    b.build();
+    if (read_last_error()[0]) {   // the builder reports plan inconsistencies through set_error
+        delete u;
+        return READ_EINVAL;
+    }
+    *out = u;
+    return READ_OK;
+}
+
+extern "C" void read_unet_destroy(read_unet_t *u)
+{
+    if (!u) return;
+    for (int i = 0; i < u->n_events; ++i) (void)hipEventDestroy(u->events[i]);
+    delete[] u->events;
+    delete u;
+}
+
+extern "C" int read_unet_forward(read_unet_t *u, const float *x0, const float *x1, const float *x2,
+                                 const float *x3, float *rgb, int rgb_cstride, void *stream)
+{
+    READ_CHECK_ARG(u && x0 && x1 && x2 && x3 && rgb, "read_unet_forward: null pointer");
+    READ_CHECK_ARG(rgb_cstride == 3 || rgb_cstride == 4, "read_unet_forward: rgb_cstride must be 3 or 4");
+    const float *ext[5] = {x0, x1, x2, x3, rgb};
+    return run(u, ext, rgb_cstride, as_stream(stream), false);
+}
+
+extern "C" int read_unet_launch_count(read_unet_t *u) { return u ? (int)u->ops.size() : 0; }
+
+extern "C" int read_unet_profile(read_unet_t *u, const float *x0, const float *x1, const float *x2,
+                                 const float *x3, float *rgb, int rgb_cstride, void *stream, float *ms,
+                                 double *flops, int *is_conv3x3_s1)
+{
+    READ_CHECK_ARG(u && x0 && x1 && x2 && x3 && rgb && ms, "read_unet_profile: null pointer");
+    READ_CHECK_ARG(rgb_cstride == 3 || rgb_cstride == 4, "read_unet_profile: rgb_cstride must be 3 or 4");
+    const int n = (int)u->ops.size();
+    if (!u->events) {
+        u->events = new hipEvent_t[n + 1];
+        for (int i = 0; i <= n; ++i) READ_CHECK_HIP(hipEventCreate(&u->events[i]));
+        u->n_events = n + 1;
+    }
+    const float *ext[5] = {x0, x1, x2, x3, rgb};
+    hipStream_t s = as_stream(stream);
+    const int rc = run(u, ext, rgb_cstride, s, true);
+    if (rc) return rc;
+    READ_CHECK_HIP(hipStreamSynchronize(s));
+    for (int i = 0; i < n; ++i) {
+        READ_CHECK_HIP(hipEventElapsedTime(&ms[i], u->events[i], u->events[i + 1]));
+        if (flops) flops[i] = u->ops[i].flops;
+        if (is_conv3x3_s1) is_conv3x3_s1[i] = u->ops[i].is_c3s1;
+    }
+    return READ_OK;
+}
+
+extern "C" int read_unet_launch_info(read_unet_t *u, int i, double *flops, int *is_conv3x3_s1, int *outH, int *outW,
+                                     int *cin, int *cout)
+{
+    READ_CHECK_ARG(u && i >= 0 && i < (int)u->ops.size(), "read_unet_launch_info: bad handle or index");
+    const Op &op = u->ops[i];
+    const Tensor &o = u->tensors[op.out_t];
+    if (flops) *flops = op.flops;
+    if (is_conv3x3_s1) *is_conv3x3_s1 = op.is_c3s1;
+    if (outH) *outH = o.H;
+    if (outW) *outW = o.W;
+    int ci = 0;
+    for (int k = 0; k < READ_CONV_MAX_SRC; ++k)
+        if (op.src_t[k] >= 0) ci += u->tensors[op.src_t[k]].C;
+    if (op.kind == Op::UP4) ci = u->tensors[op.in_t].C;
+    if (cin) *cin = ci;
+    if (cout) *cout = o.C;
+    return READ_OK;
+}
+
+extern "C" const char *read_unet_launch_label(read_unet_t *u, int i)
+{
+    return (u && i >= 0 && i < (int)u->ops.size()) ? u->ops[i].label.c_str() : "";
+}
+
+extern "C" const float *read_unet_debug_tensor(read_unet_t *u, const char *name, int *H, int *W, int *C)
+{
+    if (!u || !name) return nullptr;
+    for (const Tensor &t : u->tensors)
+        if (t.name == name) {
+            if (H) *H = t.H;
+            if (W) *W = t.W;
+            if (C) *C = t.C;
+            return t.p;
+        }
+    return nullptr;
+}

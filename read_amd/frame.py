@@ -1,0 +1,63 @@
+"""The fused per-frame path: camera -> point-index pyramids -> descriptor pyramids -> RGB.
+
+This is the hot loop of the reference's viewer (viewer.py:263-285 -> READ/gl/nn.py:113-129 ->
+READ/datasets/dynamic.py:66-99 -> READ/models/compose.py:125-181) with every stage resident on
+one MI355X: 2 rasteriser launches + 1 gather launch + 102 UNet launches, three C calls, no host
+round trips, no per-frame allocation.
+"""
+import numpy as np
+import torch
+
+from . import _lib
+from .camera import level_sizes, total_matrix
+from .raster import PointCloudRasterizer
+from .texture import gather_pyramid, texture_to_rows
+from .unet import UNetEngine, pack_state
+
+LEVELS = 5          # the reference rasterises and gathers 5 scales; the UNet consumes 4 (unet.py:209-212)
+
+
+class FrameRenderer:
+    def __init__(self, xyz, texture_cn, unet_state, W, H, proj_matrix=None, device=None, levels=LEVELS):
+        """xyz (N,3); texture_cn (C,N) descriptors (PointTexture.texture_[0]); unet_state: state dict
+        (tensors or ndarrays) under the reference's names; W,H multiples of 16."""
+        self.device = device if device is not None else _lib.require_gpu()
+        if W % 16 or H % 16:
+            raise ValueError(f"set width {16 * (W // 16)} / height {16 * (H // 16)}")    # READ/gl/nn.py:107-109
+        self.W, self.H, self.levels = W, H, levels
+        self.raster = PointCloudRasterizer(xyz, self.device)
+        tex = torch.as_tensor(texture_cn, dtype=torch.float32).to(self.device).contiguous()
+        self.rows = texture_to_rows(tex)
+        self.packed = torch.from_numpy(pack_state(unet_state)).to(self.device)
+        self.unet = UNetEngine(self.packed, H, W)
+        self.proj = None if proj_matrix is None else np.asarray(proj_matrix, np.float32)
+        sizes = level_sizes(W, H, levels)
+        self.idx = [torch.empty((1, h, w), dtype=torch.int32, device=self.device) for (w, h) in sizes]
+        self.depth = [torch.empty((1, h, w), dtype=torch.float32, device=self.device) for (w, h) in sizes]
+        self.feat = [torch.empty((1, h, w, self.rows.shape[1]), dtype=torch.float32, device=self.device)
+                     for (w, h) in sizes]
+        self.rgba = torch.empty((H, W, 4), dtype=torch.float32, device=self.device)
+
+    def rasterize(self, total_m):
+        return self.raster.render(total_m, self.W, self.H, self.levels, out=(self.idx, self.depth))
+
+    def gather(self):
+        return gather_pyramid(self.rows, self.idx, out=self.feat)
+
+    def refine(self, out=None, channels=4):
+        f = self.feat
+        return self.unet.forward(f[0][0], f[1][0], f[2][0], f[3][0], out=self.rgba if out is None else out,
+                                 channels=channels)
+
+    def render_total(self, total_m, out=None, channels=4):
+        """total_m = proj @ inv(view) (4x4 fp32) -> (H,W,channels) fp32 frame on the device."""
+        self.rasterize(total_m)
+        self.gather()
+        return self.refine(out, channels)
+
+    def render(self, view_matrix, proj_matrix=None, out=None, channels=4):
+        """view_matrix: camera->world 4x4 (the reference's convention); -> H x W x 4 RGBA (alpha = 1)."""
+        proj = self.proj if proj_matrix is None else np.asarray(proj_matrix, np.float32)
+        if proj is None:
+            raise ValueError("no projection matrix set")
+        return self.render_total(total_matrix(proj, view_matrix), out, channels)

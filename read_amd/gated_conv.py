@@ -1,0 +1,84 @@
+"""Single-layer front end of ``read_gated_conv_forward`` (READ's BasicConv, unet.py:22-53).
+
+Used by the layer-level parity tests and the tile-configuration sweeps; the full network goes
+through ``read_unet_forward`` instead (one C call per frame)."""
+import ctypes as C
+
+import numpy as np
+import torch
+
+from . import _lib
+
+
+def kc_for(src_channels):
+    """Input-channel chunk of the kernel: 16 when every concatenated source has C % 16 == 0, else 8."""
+    return 8 if any(c % 16 for c in src_channels) else 16
+
+
+class PackedGatedConv:
+    """Weights of one BasicConv packed for the MFMA kernel and resident on the device."""
+
+    def __init__(self, wf, bf, wm, bm, gamma, beta, mean, var, src_channels=None, eps=1e-5, device=None):
+        device = device if device is not None else _lib.require_gpu()
+        f32 = lambda a: np.ascontiguousarray(a.detach().cpu().numpy() if torch.is_tensor(a) else a, dtype=np.float32)
+        wf, wm, bf, bm, gamma, beta, mean, var = map(f32, (wf, wm, bf, bm, gamma, beta, mean, var))
+        self.cout, self.cin, self.k, _ = wf.shape
+        self.kc = kc_for(src_channels if src_channels is not None else [self.cin])
+        L = _lib.lib()
+        wp = np.empty(L.read_conv_packed_floats(self.cin, self.cout, self.k), np.float32)
+        pp = np.empty(L.read_conv_param_floats(self.cout), np.float32)
+        _lib.check(L.read_conv_pack_weights_host(self.cin, self.cout, self.k, self.kc, wf.ctypes.data, wm.ctypes.data,
+                                                 wp.ctypes.data), "read_conv_pack_weights_host")
+        _lib.check(L.read_conv_pack_params_host(self.cout, bf.ctypes.data, bm.ctypes.data, gamma.ctypes.data,
+                                                beta.ctypes.data, mean.ctypes.data, var.ctypes.data, eps,
+                                                pp.ctypes.data), "read_conv_pack_params_host")
+        self.wpacked = torch.from_numpy(wp).to(device)
+        self.params = torch.from_numpy(pp).to(device)
+
+
+def gated_conv(packed, sources, stride=1, elu=True, mul=None, residual=None, config=-1, out=None,
+               out_channels=None, fill=None):
+    """sources: list of (NHWC tensor (h,w,C), shift).  Returns the NHWC output (outH,outW,Cout)."""
+    t0, s0 = sources[0]
+    inH = (t0.shape[0] >> s0) if s0 >= 0 else (t0.shape[0] << -s0)
+    inW = (t0.shape[1] >> s0) if s0 >= 0 else (t0.shape[1] << -s0)
+    pad = (packed.k - 1) // 2
+    outH = (inH + 2 * pad - packed.k) // stride + 1
+    outW = (inW + 2 * pad - packed.k) // stride + 1
+    cs = out_channels if out_channels is not None else packed.cout
+    if out is None:
+        out = torch.empty((outH, outW, cs), dtype=torch.float32, device=t0.device)
+    d = _lib.ConvDesc()
+    d.n_src = len(sources)
+    for i, (t, sh) in enumerate(sources):
+        assert t.is_contiguous() and t.dtype == torch.float32
+        d.src[i].data = t.data_ptr()
+        d.src[i].C = t.shape[2]
+        d.src[i].srcH, d.src[i].srcW = t.shape[0], t.shape[1]
+        d.src[i].shift = sh
+    d.mul = mul.data_ptr() if mul is not None else None
+    d.inH, d.inW = inH, inW
+    d.Cout, d.ksize, d.stride = packed.cout, packed.k, stride
+    d.elu = 1 if elu else 0
+    d.wpacked, d.params = packed.wpacked.data_ptr(), packed.params.data_ptr()
+    d.residual = residual.data_ptr() if residual is not None else None
+    d.out, d.out_cstride = out.data_ptr(), cs
+    d.fill_pad = 0 if fill is None else 1
+    d.out_fill = 0.0 if fill is None else float(fill)
+    d.config = config
+    _lib.check(_lib.lib().read_gated_conv_forward(C.byref(d), _lib.stream_ptr()), "read_gated_conv_forward")
+    return out
+
+
+def bilinear_up4(x):
+    """NHWC (h,w,C) -> (4h,4w,C), align_corners=False (unet.py:200)."""
+    h, w, c = x.shape
+    out = torch.empty((4 * h, 4 * w, c), dtype=torch.float32, device=x.device)
+    _lib.check(_lib.lib().read_bilinear_up4(x.data_ptr(), h, w, c, out.data_ptr(), _lib.stream_ptr()),
+               "read_bilinear_up4")
+    return out
+
+
+def config_names():
+    L = _lib.lib()
+    return [L.read_conv_config_name(i).decode() for i in range(L.read_conv_config_count())]

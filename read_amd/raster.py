@@ -1,0 +1,69 @@
+"""Device-resident multi-scale point rasteriser (front end of ``read_splat_forward``).
+
+Replaces the reference's per-call upload + 5 x B kernel launches + download
+(MyRender/CloudProjection/pcpr_cuda.cpp:23-42, point_render.cu:169-200,
+src/READ/gl/myrender.py:32-40) with a cloud that stays in HBM, one pass over it per frame
+for all cameras and all scales, and outputs that stay on the device.
+"""
+import ctypes as C
+
+import numpy as np
+import torch
+
+from . import _lib
+from .camera import level_sizes
+
+
+class PointCloudRasterizer:
+    """Holds xyz (N,3) fp32 in HBM plus the persistent 64-bit key image.
+
+    ``render(total_m, W, H, levels)`` -> (idx_levels, depth_levels): lists of int32 / fp32 CUDA
+    tensors shaped (B, h_l, w_l).  Deterministic: per pixel min depth, ties -> min point id;
+    empty pixels are (0, 0.0)."""
+
+    def __init__(self, xyz, device=None):
+        self.device = device if device is not None else _lib.require_gpu()
+        xyz = torch.as_tensor(np.ascontiguousarray(xyz, dtype=np.float32) if not torch.is_tensor(xyz) else xyz)
+        if xyz.dim() != 2 or xyz.shape[1] != 3:
+            raise ValueError(f"xyz must be (N,3), got {tuple(xyz.shape)}")
+        self.xyz = xyz.to(device=self.device, dtype=torch.float32).contiguous()
+        self.n = int(self.xyz.shape[0])
+        self._ws = None
+        self._ws_key = None
+
+    def _workspace(self, B, W, H):
+        need = _lib.lib().read_splat_workspace_bytes(B, W, H)
+        if self._ws is None or self._ws.numel() < need:
+            self._ws = torch.empty(need, dtype=torch.uint8, device=self.device)
+            _lib.check(_lib.lib().read_splat_workspace_init(self._ws.data_ptr(), self._ws.numel(), _lib.stream_ptr()),
+                       "read_splat_workspace_init")
+        return self._ws
+
+    def render(self, total_m, W, H, levels=5, want_depth=True, out=None):
+        """total_m: (B,4,4) or (4,4) fp32 host array/tensor = proj @ inv(view)."""
+        M = np.ascontiguousarray(total_m.detach().cpu().numpy() if torch.is_tensor(total_m) else total_m,
+                                 dtype=np.float32).reshape(-1, 16)
+        B = M.shape[0]
+        sizes = level_sizes(W, H, levels)
+        if out is None:
+            idx = [torch.empty((B, h, w), dtype=torch.int32, device=self.device) for (w, h) in sizes]
+            dep = [torch.empty((B, h, w), dtype=torch.float32, device=self.device) for (w, h) in sizes] \
+                if want_depth else None
+        else:
+            idx, dep = out
+        ws = self._workspace(B, W, H)
+        L = _lib.lib()
+        idx_p = _lib.ptr_array([t.data_ptr() for t in idx])
+        dep_p = _lib.ptr_array([t.data_ptr() for t in dep]) if dep is not None else None
+        _lib.check(L.read_splat_forward(self.xyz.data_ptr(), self.n, M.ctypes.data_as(C.POINTER(C.c_float)), B,
+                                        W, H, levels, idx_p, dep_p, ws.data_ptr(), ws.numel(),
+                                        _lib.stream_ptr()), "read_splat_forward")
+        return idx, dep
+
+
+def index_to_float(idx):
+    """The reference's float32 index image (point_render.cu:158): ids >= 2**24 round."""
+    out = torch.empty(idx.shape, dtype=torch.float32, device=idx.device)
+    _lib.check(_lib.lib().read_index_to_float(idx.data_ptr(), idx.numel(), out.data_ptr(), _lib.stream_ptr()),
+               "read_index_to_float")
+    return out

@@ -1,0 +1,159 @@
+"""Neural point descriptors (mirror of READ/models/texture.py:14-70).
+
+``PointTexture`` keeps the reference's parameter (``texture_`` of shape (1, C, N), same
+state-dict key) so checkpoints interchange, and serves lookups from an N x C row-major copy in
+HBM through the HIP gather (one 32-byte row per point at C = 8 instead of C reads at stride 4N).
+"""
+import ctypes as C
+
+import torch
+import torch.nn as nn
+
+from . import _lib
+
+_ACT = {"none": 0, "sigmoid": 1, "tanh": 2}
+
+
+def texture_to_rows(texture_cn):
+    """(C, N) channel-major CUDA tensor -> (N, C) row-major CUDA tensor."""
+    Cc, n = texture_cn.shape
+    rows = torch.empty((n, Cc), dtype=torch.float32, device=texture_cn.device)
+    _lib.check(_lib.lib().read_texture_to_rows(texture_cn.data_ptr(), n, Cc, rows.data_ptr(), _lib.stream_ptr()),
+               "read_texture_to_rows")
+    return rows
+
+
+def rows_to_texture(rows_nc):
+    n, Cc = rows_nc.shape
+    tex = torch.empty((Cc, n), dtype=torch.float32, device=rows_nc.device)
+    _lib.check(_lib.lib().read_rows_to_texture(rows_nc.data_ptr(), n, Cc, tex.data_ptr(), _lib.stream_ptr()),
+               "read_rows_to_texture")
+    return tex
+
+
+def gather_pyramid(rows_nc, idx_levels, activation="none", out=None):
+    """rows (N,C) + int32 index maps [(B,h,w)...] -> NHWC feature maps [(B,h,w,C)...]."""
+    n, Cc = rows_nc.shape
+    levels = len(idx_levels)
+    if out is None:
+        out = [torch.empty(tuple(i.shape) + (Cc,), dtype=torch.float32, device=rows_nc.device) for i in idx_levels]
+    counts = (C.c_int64 * levels)(*[int(i.numel()) for i in idx_levels])
+    _lib.check(_lib.lib().read_gather_forward(
+        rows_nc.data_ptr(), n, Cc, levels, _lib.ptr_array([i.data_ptr() for i in idx_levels]), counts,
+        _lib.ptr_array([o.data_ptr() for o in out]), _ACT[activation], _lib.stream_ptr()), "read_gather_forward")
+    return out
+
+
+def scatter_pyramid(dfeat_levels, idx_levels, n):
+    """Backward of gather_pyramid: -> (N, C) gradient rows (fp32 atomics)."""
+    Cc = dfeat_levels[0].shape[-1]
+    drows = torch.zeros((n, Cc), dtype=torch.float32, device=dfeat_levels[0].device)
+    levels = len(idx_levels)
+    dfeat_levels = [d.contiguous() for d in dfeat_levels]
+    counts = (C.c_int64 * levels)(*[int(i.numel()) for i in idx_levels])
+    _lib.check(_lib.lib().read_gather_backward(
+        drows.data_ptr(), n, Cc, levels, _lib.ptr_array([i.data_ptr() for i in idx_levels]), counts,
+        _lib.ptr_array([d.data_ptr() for d in dfeat_levels]), _lib.stream_ptr()), "read_gather_backward")
+    return drows
+
+
+class _GatherFn(torch.autograd.Function):
+    """texture_ (1,C,N) x int32 ids (B,H,W) -> NHWC (B,H,W,C); backward = HIP scatter-add."""
+
+    @staticmethod
+    def forward(ctx, texture, ids):
+        rows = texture_to_rows(texture[0])
+        ctx.save_for_backward(ids)
+        ctx.n = texture.shape[-1]
+        return gather_pyramid(rows, [ids])[0]
+
+    @staticmethod
+    def backward(ctx, grad):
+        (ids,) = ctx.saved_tensors
+        drows = scatter_pyramid([grad], [ids], ctx.n)
+        return rows_to_texture(drows)[None], None
+
+
+class Texture(nn.Module):
+    def null_grad(self):
+        raise NotImplementedError()
+
+    def reg_loss(self):
+        return 0.
+
+
+class PointTexture(Texture):
+    """Same constructor, parameter name/shape and ``forward`` contract as the reference."""
+
+    def __init__(self, num_channels, size, activation='none', checkpoint=None, init_method='zeros', reg_weight=0.):
+        super().__init__()
+        assert isinstance(size, int), 'size must be int'
+        shape = 1, num_channels, size
+        if checkpoint:
+            self.texture_ = torch.load(checkpoint, map_location='cpu')['texture'].texture_
+        else:
+            if init_method == 'rand':
+                texture = torch.rand(shape)
+            elif init_method == 'zeros':
+                texture = torch.zeros(shape)
+            else:
+                raise ValueError(init_method)
+            self.texture_ = nn.Parameter(texture.float())
+        if activation not in _ACT:
+            raise ValueError(activation)
+        self.activation = activation
+        self.reg_weight = reg_weight
+        self._rows = None
+        self._rows_version = None
+
+    def null_grad(self):
+        self.texture_.grad = None
+
+    def reg_loss(self):
+        return self.reg_weight * torch.mean(torch.pow(self.texture_, 2))
+
+    def rows(self):
+        """Cached (N, C) row-major copy of texture_ on its device; refreshed when the parameter changes."""
+        t = self.texture_
+        key = (t._version, t.data_ptr(), t.device)
+        if self._rows is None or self._rows_version != key:
+            _lib.require_gpu()
+            if not t.is_cuda:
+                raise _lib.ReadHipError("PointTexture lookups run on the GPU: move the module with .cuda()")
+            self._rows = texture_to_rows(t.detach()[0].contiguous())
+            self._rows_version = key
+        return self._rows
+
+    @staticmethod
+    def _ids(inputs):
+        if isinstance(inputs, dict):
+            ids = None
+            for f, x in inputs.items():
+                if 'uv' in f:
+                    ids = x[:, 0]
+            assert ids is not None, 'Input format does not have uv'
+        else:
+            ids = inputs[:, 0]                      # B x H x W
+        if ids.dtype != torch.int32:
+            ids = ids.to(torch.int32)               # float ids are integer valued (texture.py:53 .long())
+        return ids.contiguous()
+
+    def forward(self, inputs):
+        """ids (B,1|3,H,W) float or int -> (B,C,H,W) view of an NHWC tensor (values as texture.py:55-63)."""
+        ids = self._ids(inputs)
+        if not self.texture_.is_cuda:
+            raise _lib.ReadHipError("PointTexture lookups run on the GPU: move the module with .cuda()")
+        ids = ids.to(self.texture_.device)
+        if torch.is_grad_enabled() and self.texture_.requires_grad:
+            sample = _GatherFn.apply(self.texture_, ids)
+            if self.activation == 'sigmoid':
+                sample = torch.sigmoid(sample)
+            elif self.activation == 'tanh':
+                sample = torch.tanh(sample)
+        else:
+            sample = gather_pyramid(self.rows(), [ids], self.activation)[0]
+        return sample.permute(0, 3, 1, 2)
+
+    def forward_pyramid(self, idx_levels):
+        """Fast path: int32 index maps of all scales -> NHWC feature maps, one launch."""
+        return gather_pyramid(self.rows(), idx_levels, self.activation)

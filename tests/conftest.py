@@ -1,0 +1,26 @@
+import os
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+@pytest.fixture(scope="session")
+def golden_dir():
+    return os.path.join(ROOT, "tests", "golden")
+
+
+@pytest.fixture(scope="session")
+def hip():
+    """The loaded C-ABI library on a box with a GPU (fails loudly if either is missing)."""
+    import torch
+    from read_amd import _lib
+    assert torch.cuda.is_available(), "gpu-marked test on a box without a HIP device"
+    return _lib.lib()

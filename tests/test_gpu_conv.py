@@ -1,0 +1,134 @@
+"""Layer-level parity of the fused gated-conv MFMA kernel with the torch-fp32 oracle
+(oracle.unet_torch.basic_conv == READ/models/unet.py:44-53 on CPU).
+
+Tolerance: the kernel accumulates in exact fp32 (v_mfma_f32_32x32x2_f32) but in a different
+order than oneDNN, so results agree to fp32 round-off of a K-long dot product:
+|diff| <= 2e-5 * max(1, |ref|) for K <= 4320 at unit-scale data."""
+import re
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from oracle import unet_torch
+from read_amd import synthetic
+from read_amd.gated_conv import PackedGatedConv, bilinear_up4, config_names, gated_conv
+
+pytestmark = pytest.mark.gpu
+
+ATOL = RTOL = 2e-5
+
+
+def _state(cin, cout, k, seed=0):
+    return synthetic.make_unet_state([("L", cin, cout, k)], seed)
+
+
+def _pack(st, src_channels):
+    b = "L.block."
+    return PackedGatedConv(st[b + "conv_f.weight"], st[b + "conv_f.bias"], st[b + "conv_m.weight"], st[b + "conv_m.bias"],
+                           st[b + "norm.weight"], st[b + "norm.bias"], st[b + "norm.running_mean"],
+                           st[b + "norm.running_var"], src_channels=src_channels)
+
+
+def _nhwc(x_chw):
+    return x_chw.permute(1, 2, 0).contiguous().cuda()
+
+
+def _close(got_hwc, ref_chw, what):
+    got = got_hwc.cpu().permute(2, 0, 1)
+    assert got.shape == ref_chw.shape, (got.shape, ref_chw.shape)
+    err = (got - ref_chw).abs()
+    tol = ATOL + RTOL * ref_chw.abs()
+    bad = err > tol
+    assert not bool(bad.any()), f"{what}: {int(bad.sum())} of {bad.numel()} off, max err {float(err.max()):.3e}"
+
+
+def _cfg_params(name):
+    m = re.match(r"k(\d)s(\d)c(\d+)_p(\d)q(\d)m(\d)n(\d)", name)
+    return tuple(int(g) for g in m.groups())
+
+
+def test_every_tile_configuration(hip):
+    """Each compiled (ksize, stride, chunk, tiling) configuration against torch on a ragged image
+    (partial tiles in x and y, zero padding on all borders)."""
+    torch.manual_seed(0)
+    for ci, name in enumerate(config_names()):
+        k, s, kc, P, QG, WM, WN = _cfg_params(name)
+        groups = WN * QG
+        for g_mult in ((1, 2) if groups == 4 else (1,)):               # grid.y > 1 path
+            cout = 32 * groups * g_mult - (8 if kc == 16 else 5)         # non-multiple of 32 -> padded channels
+            cin = 24 if kc == 8 else 48
+            H, W = (22, 44) if s == 1 else (24, 80)
+            st = _state(cin, cout, k, seed=ci)
+            x = torch.randn(cin, H, W)
+            ref = unet_torch.basic_conv(st, "L", x[None], k, stride=s, elu=True)[0]
+            got = gated_conv(_pack(st, [cin]), [(_nhwc(x), 0)], stride=s, elu=True, config=ci)
+            _close(got, ref, f"config {ci} {name} cout={cout}")
+
+
+def test_unet_layer_shapes_auto_config(hip):
+    """The (cin, cout, k, stride) shapes the UNet actually runs, automatic configuration choice,
+    elu on/off, residual add."""
+    torch.manual_seed(1)
+    shapes = [(8, 32, 3, 1), (8, 16, 3, 1), (16, 32, 1, 1), (32, 32, 3, 1), (32, 56, 1, 1), (64, 64, 3, 1),
+              (64, 120, 1, 1), (128, 128, 3, 1), (128, 248, 1, 1), (256, 256, 3, 1), (32, 64, 3, 2), (64, 128, 3, 2),
+              (128, 256, 3, 2), (256, 128, 4, 2), (128, 64, 4, 2), (64, 32, 4, 2), (32, 3, 3, 1), (256, 128, 1, 1)]
+    for i, (cin, cout, k, s) in enumerate(shapes):
+        H, W = (16, 48) if s == 1 else (16, 64)
+        st = _state(cin, cout, k, seed=100 + i)
+        x = torch.randn(cin, H, W)
+        elu = i % 2 == 0
+        ref = unet_torch.basic_conv(st, "L", x[None], k, stride=s, elu=elu)[0]
+        res = torch.randn_like(ref) if (s == 1 and cin == cout) else None
+        got = gated_conv(_pack(st, [cin]), [(_nhwc(x), 0)], stride=s, elu=elu,
+                         residual=_nhwc(res) if res is not None else None)
+        _close(got, ref + (res if res is not None else 0), f"shape {cin}->{cout} k{k} s{s}")
+
+
+def test_concat_and_nearest_resample_sources(hip):
+    """AFF-style input: torch.cat of four tensors at four resolutions (unet.py:239-254)."""
+    torch.manual_seed(2)
+    H, W = 16, 32
+    chans, shifts = [32, 64, 128, 256], [1, 0, -1, -2]                   # AFF1's pattern at 1/2 scale
+    xs = [torch.randn(c, (H << sh) if sh > 0 else (H >> -sh), (W << sh) if sh > 0 else (W >> -sh))
+          for c, sh in zip(chans, shifts)]
+    cat = torch.cat([F.interpolate(x[None], size=(H, W), mode="nearest") for x in xs], 1)
+    # F.interpolate(size=) and scale_factor= agree for these power-of-two ratios (src = floor(dst*ratio))
+    st = _state(480, 64, 1, seed=7)
+    ref = unet_torch.basic_conv(st, "L", cat, 1, elu=True)[0]
+    got = gated_conv(_pack(st, chans), [(_nhwc(x), sh) for x, sh in zip(xs, shifts)], elu=True)
+    _close(got, ref, "AFF 1x1 over 4 resampled sources")
+    # SCM tail: cat[x (8 ch), main(x) (56 ch)] -> 8-channel chunks
+    a, b = torch.randn(8, H, W), torch.randn(56, H, W)
+    st = _state(64, 64, 1, seed=8)
+    ref = unet_torch.basic_conv(st, "L", torch.cat([a, b])[None], 1, elu=False)[0]
+    got = gated_conv(_pack(st, [8, 56]), [(_nhwc(a), 0), (_nhwc(b), 0)], elu=False)
+    _close(got, ref, "SCM 1x1 over cat[8,56]")
+
+
+def test_fam_multiply_and_residual(hip):
+    """FAM: x1 + BC(x1*x2) (unet.py:114-117) in one launch."""
+    torch.manual_seed(3)
+    for c in (64, 128, 256):
+        x1, x2 = torch.randn(c, 12, 40), torch.randn(c, 12, 40)
+        st = _state(c, c, 3, seed=c)
+        ref = x1 + unet_torch.basic_conv(st, "L", (x1 * x2)[None], 3, elu=False)[0]
+        got = gated_conv(_pack(st, [c]), [(_nhwc(x1), 0)], elu=False, mul=_nhwc(x2), residual=_nhwc(x1))
+        _close(got, ref, f"FAM C={c}")
+
+
+def test_rgba_output_fill(hip):
+    st = _state(32, 3, 3, seed=9)
+    x = torch.randn(32, 16, 32)
+    ref = unet_torch.basic_conv(st, "L", x[None], 3, elu=False)[0]
+    got = gated_conv(_pack(st, [32]), [(_nhwc(x), 0)], elu=False, out_channels=4, fill=1.0)
+    _close(got[:, :, :3].contiguous(), ref, "rgb")
+    assert bool((got[:, :, 3] == 1.0).all())
+
+
+def test_bilinear_up4(hip):
+    x = torch.randn(64, 6, 10)
+    ref = F.interpolate(x[None], scale_factor=4, mode="bilinear", align_corners=False)[0]
+    got = bilinear_up4(_nhwc(x))
+    torch.testing.assert_close(got.cpu().permute(2, 0, 1), ref, rtol=1e-6, atol=1e-6)

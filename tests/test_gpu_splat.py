@@ -1,0 +1,134 @@
+"""Parity of the HIP rasteriser (read_splat_forward through the C ABI) with the oracle:
+bit-exact int32 index + fp32 depth bit patterns."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+import oracle
+from read_amd import camera, synthetic
+from read_amd.raster import PointCloudRasterizer, index_to_float
+
+pytestmark = pytest.mark.gpu
+
+
+def _check(xyz, Ms, W, H, levels=5, threads=8):
+    r = PointCloudRasterizer(xyz)
+    idx, dep = r.render(Ms, W, H, levels)
+    torch.cuda.synchronize()
+    Ms = np.asarray(Ms, np.float32).reshape(-1, 4, 4)
+    for b in range(Ms.shape[0]):
+        oi, od = oracle.raster_multiscale(xyz, Ms[b], W, H, levels, threads=threads)
+        for l in range(levels):
+            gi, gd = idx[l][b].cpu().numpy(), dep[l][b].cpu().numpy()
+            assert gi.shape == oi[l].shape
+            assert np.array_equal(gi, oi[l]), f"index mismatch cam {b} level {l}: {(gi != oi[l]).sum()} px"
+            assert np.array_equal(gd.view(np.uint32), od[l].view(np.uint32)), f"depth mismatch cam {b} level {l}"
+    return r, idx, dep
+
+
+def test_config0_100k_256(golden_dir, hip):
+    """BASELINE.json configs[0]: 100k random points, 256x256 — vs the oracle AND the committed golden
+    (= the reference's DepthProject source run serially)."""
+    g = np.load(os.path.join(golden_dir, "raster_256_100k.npz"))
+    xyz = synthetic.make_cloud(int(g["N"]), int(g["seed"]))
+    r, idx, dep = _check(xyz, g["M"], 256, 256)
+    for l in range(5):
+        assert np.array_equal(idx[l].cpu().numpy(), g[f"index{l}"])
+        assert np.array_equal(dep[l].cpu().numpy().view(np.uint32), g[f"depth{l}"].view(np.uint32))
+    # API-edge float index (point_render.cu:158)
+    assert np.array_equal(index_to_float(idx[0]).cpu().numpy(), g["index0"].astype(np.float32))
+
+
+def test_1216x352_2M_two_cameras(hip):
+    W, H = 1216, 352
+    xyz = synthetic.make_cloud(2_000_003)                 # n % 4 != 0 exercises the scalar tail
+    Ms = camera.total_matrix(synthetic.make_proj(W, H), np.stack([synthetic.sweep_pose(0), synthetic.sweep_pose(33)]))
+    _check(xyz, Ms, W, H)
+
+
+def test_more_cameras_than_one_pass(hip):
+    W, H = 64, 48
+    xyz = synthetic.make_cloud(20_000)
+    Ms = camera.total_matrix(synthetic.make_proj(W, H, f=40.0), np.stack([synthetic.sweep_pose(k) for k in range(11)]))
+    _check(xyz, Ms, W, H, threads=1)
+
+
+def test_generic_size_falls_back_to_per_level_passes(hip):
+    W, H = 250, 130                                        # not multiples of 16: pyramid identity does not hold
+    xyz = synthetic.make_cloud(150_000)
+    Ms = camera.total_matrix(synthetic.make_proj(W, H, f=200.0), synthetic.sweep_pose(5))
+    _check(xyz, Ms, W, H)
+
+
+def test_single_level_any_size(hip):
+    W, H = 101, 77
+    xyz = synthetic.make_cloud(30_000)
+    Ms = camera.total_matrix(synthetic.make_proj(W, H, f=80.0), np.eye(4, dtype=np.float32))
+    _check(xyz, Ms, W, H, levels=1)
+
+
+def test_ties_resolve_to_smallest_index(hip):
+    W, H = 64, 64
+    base = synthetic.make_cloud(4_000, seed=7)
+    xyz = np.concatenate([base, base[::-1], base])         # every point three times -> exact depth ties
+    Ms = camera.total_matrix(synthetic.make_proj(W, H, f=64.0), np.eye(4, dtype=np.float32))
+    _check(xyz, Ms, W, H)
+
+
+def test_empty_and_invisible_clouds(hip):
+    W, H = 64, 32
+    Ms = camera.total_matrix(synthetic.make_proj(W, H, f=64.0), np.eye(4, dtype=np.float32))
+    behind = synthetic.make_cloud(5_000)
+    behind[:, 2] *= -1                                      # all behind the camera
+    for xyz in (np.zeros((0, 3), np.float32), behind):
+        r = PointCloudRasterizer(xyz)
+        idx, dep = r.render(Ms, W, H, 5)
+        for i, d in zip(idx, dep):
+            assert int(i.abs().sum()) == 0 and float(d.abs().sum()) == 0.0
+
+
+def test_workspace_is_left_clean_and_render_is_idempotent(hip):
+    W, H = 256, 256
+    xyz = synthetic.make_cloud(100_000)
+    Ms = camera.total_matrix(synthetic.make_proj(W, H, f=256.0), synthetic.sweep_pose(9))
+    r = PointCloudRasterizer(xyz)
+    a_i, a_d = r.render(Ms, W, H, 5)
+    b_i, b_d = r.render(Ms, W, H, 5)
+    for x, y in zip(a_i + a_d, b_i + b_d):
+        assert torch.equal(x, y)
+    ws = r._ws.view(torch.int64)
+    assert bool((ws == -1).all()), "key image must be EMPTY after a frame"
+
+
+def test_full_size_30M_properties(hip):
+    """BASELINE configs[2] size: properties that do not need the (slow) full oracle — the on-device
+    pyramid identity, and exactness against the oracle on a 3 M-point subset merged by key-min."""
+    W, H, N = 1216, 352, 30_000_000
+    xyz = synthetic.make_cloud(N)
+    Ms = camera.total_matrix(synthetic.make_proj(W, H), np.eye(4, dtype=np.float32))
+    r = PointCloudRasterizer(xyz)
+    idx, dep = r.render(Ms, W, H, 5)
+    key = (dep[0][0].view(torch.int32).to(torch.int64) << 32) | idx[0][0].to(torch.int64)
+    key[(idx[0][0] == 0) & (dep[0][0] == 0)] = torch.iinfo(torch.int64).max
+    for l in range(1, 5):
+        h, w = key.shape
+        key = key.view(h // 2, 2, w // 2, 2).amin(dim=(1, 3))
+        kl = (dep[l][0].view(torch.int32).to(torch.int64) << 32) | idx[l][0].to(torch.int64)
+        kl[(idx[l][0] == 0) & (dep[l][0] == 0)] = torch.iinfo(torch.int64).max
+        assert torch.equal(key, kl), f"level {l} is not the 2x2 key-min of level {l-1}"
+    # exactness: the winner over all N equals the key-min of the winners of 10 disjoint 3M slices (oracle)
+    best_d = np.full((H, W), np.inf, np.float32)
+    best_i = np.zeros((H, W), np.int64)
+    step = 3_000_000
+    for s in range(0, N, step):
+        oi, od = oracle.raster_level(xyz[s:s + step], Ms[0], W, H, threads=8)
+        hit = (od > 0) | (oi > 0)
+        gi = oi.astype(np.int64) + s
+        better = hit & ((od < best_d) | ((od == best_d) & (gi < best_i)))
+        best_d[better] = od[better]
+        best_i[better] = gi[better]
+    best_d[np.isinf(best_d)] = 0
+    assert np.array_equal(idx[0][0].cpu().numpy().astype(np.int64), best_i)
+    assert np.array_equal(dep[0][0].cpu().numpy().view(np.uint32), best_d.view(np.uint32))
