@@ -1,0 +1,1 @@
+from read_amd.pipeline import Pipeline, load_pipeline, save_pipeline  # noqa: F401

@@ -124,7 +124,7 @@ def main():
             pending[j] = None
         fr.render_total(poses[(i * world + rank) % 256], out=frames[j])
         if world > 1:
-            pending[j] = dist.all_gather_into_tensor(gathered[j], frames[j], async_op=True)
+            pending[j] = dist.all_gather_into_tensor(gathered[j], frames[j][None], async_op=True)
 
     for i in range(a.warmup):
         step(i)

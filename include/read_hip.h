@@ -52,9 +52,14 @@ int read_abi_version(void);
 /* Fills name[0..len) with the gfx arch of the current device ("gfx950"); READ_EHIP without a GPU. */
 int read_device_arch(char *name, int len);
 
+/* Measurement knobs (A/B runs on the GPU box).  "splat_mode": 0 per-XCD key images with L2-local
+ * atomics (default), 1 one image with agent-scope atomics, 2 projection only (timing floor, invalid
+ * results). */
+int read_tuning_set(const char *key, int value);
+
 /* ---------------------------------------------------------------- rasteriser (z-buffer splat) */
 
-/* Bytes of the persistent key image: B * W * H * 8 (packed depth_bits<<32 | point_id). */
+/* Bytes of the persistent key images: min(B,8) cameras x 8 XCDs x W*H x 8 (depth_bits<<32 | point_id). */
 size_t read_splat_workspace_bytes(int B, int W, int H);
 /* Must be called once on a fresh workspace (sets every key to EMPTY).  read_splat_forward
  * leaves the workspace EMPTY again, so consecutive frames need no further clears. */

@@ -29,3 +29,23 @@ extern "C" int read_device_arch(char *name, int len)
     if (colon) *colon = 0;
     return READ_OK;
 }
+
+namespace readhip {
+int splat_set_mode(int m);
+}
+
+// Tuning knobs for A/B measurements on the GPU box (not needed in production):
+//   "splat_mode": 0 = per-XCD key images + L2-local atomics (default), 1 = one image + agent-scope
+//                 atomics, 2 = projection only (timing floor; results invalid), 3 = one image,
+//                 agent-scope atomics, system-scope (L2-bypassing) early-z reads.
+extern "C" int read_tuning_set(const char *key, int value)
+{
+    READ_CHECK_ARG(key, "read_tuning_set: null key");
+    if (!strcmp(key, "splat_mode")) {
+        const int rc = readhip::splat_set_mode(value);
+        if (rc) readhip::set_error("read_tuning_set: splat_mode must be 0..3");
+        return rc;
+    }
+    readhip::set_error("read_tuning_set: unknown key '%s'", key);
+    return READ_EINVAL;
+}

@@ -51,11 +51,18 @@ struct ConvKArgs {
     unsigned short chunk_coff[MAX_CHUNKS];
 };
 
-__device__ __forceinline__ float elu1(float x) { return x > 0.0f ? x : expm1f(x); }
-__device__ __forceinline__ float sigmoidf(float x) { return 1.0f / (1.0f + expf(-x)); }
+// Epilogue transcendentals on the hardware v_exp_f32 / v_rcp_f32 (about 1 ulp each): the gate and
+// the ELU tail are O(1) quantities, so the absolute error stays ~1e-7 — far inside the CNN tolerance
+// (tests/test_gpu_conv.py) — while the epilogue VALU cost drops ~4x against the ocml expf/expm1f/div.
+__device__ __forceinline__ float fast_exp(float x) { return __builtin_amdgcn_exp2f(x * 1.44269504088896341f); }
+__device__ __forceinline__ float elu1(float x) { return x > 0.0f ? x : fast_exp(x) - 1.0f; }
+__device__ __forceinline__ float sigmoidf(float x) { return __builtin_amdgcn_rcpf(1.0f + fast_exp(-x)); }
 
 template <int KS, int S, int KC, int P, int QG, int WM, int WN>
 struct Tile {
+    static constexpr int WK = 4 / (WM * WN);          // waves that split the taps of ONE output tile (split-K)
+    static constexpr int TPW = KS * KS / WK;          // taps per wave
+    static constexpr int NR = 16 / WK;                // accumulator registers a wave finishes in the epilogue
     static constexpr int TH = WM * P;                 // output rows per workgroup
     static constexpr int TW = 32;                     // output columns per workgroup (one MFMA M)
     static constexpr int IH = (TH - 1) * S + KS;      // input halo tile
@@ -70,17 +77,19 @@ struct Tile {
     static constexpr int PAD = (KS - 1) / 2;          // int(dilation*(k-1)/2), unet.py:30
 };
 
-template <int KS, int S, int KC, int P, int QG, int WM, int WN, bool MUL>
+template <int KS, int S, int KC, int P, int QG, int WM, int WN, bool MUL, int PF>
 __global__ __launch_bounds__(256) void gated_conv_kernel(const ConvKArgs a)
 {
     using TL = Tile<KS, S, KC, P, QG, WM, WN>;
-    static_assert(WM * WN == 4, "4 waves per workgroup");
+    static_assert(WM * WN * TL::WK == 4 && (KS * KS) % TL::WK == 0, "4 waves per workgroup; taps split evenly");
+    static_assert(TL::WK == 1 || 4 * P * TL::T * 16 * 64 <= 2 * TL::BUF, "split-K reduction must fit the LDS tile");
     __shared__ __attribute__((aligned(16))) float lds[2 * TL::BUF];
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wm = wave / WN, wn = wave % WN;
+    const int wk = wave / (WM * WN);                  // 0 unless split-K
+    const int wm = (wave / WN) % WM, wn = wave % WN;
     const int tx = blockIdx.x % a.tiles_x, ty = blockIdx.x / a.tiles_x;
     const int ox0 = tx * TL::TW, oy0 = ty * TL::TH;
     const int ix0 = ox0 * S - TL::PAD, iy0 = oy0 * S - TL::PAD;
@@ -141,12 +150,24 @@ __global__ __launch_bounds__(256) void gated_conv_kernel(const ConvKArgs a)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[p][t][r] = 0.0f;
 
-    // B fragments: float4 index (step*NT + nt)*64 + lane
+    // B fragments: float4 index (step*NT + nt)*64 + lane.  A ring of PF steps is kept in flight so a
+    // fragment is requested PF k-steps (PF * P*T*4 MFMAs) before its first use.
     const float4 *wl = reinterpret_cast<const float4 *>(a.wp) + (size_t)nt0 * 64 + lane;
-    const int total_steps = a.nchunks * KS * KS * TL::KK;
-    float4 bnext[TL::T];
+    // This wave walks local steps ls = (chunk, tap in its TPW-tap share, kk); gstep() maps to the packed order.
+    constexpr int SPC = TL::TPW * TL::KK;             // local steps per chunk
+    const int total_steps = a.nchunks * SPC;
+    auto gstep = [&](int ls) {
+        ls = ls < total_steps ? ls : total_steps - 1;
+        const int chunk = ls / SPC, rem = ls % SPC;
+        return (chunk * KS * KS + wk * TL::TPW + rem / TL::KK) * TL::KK + rem % TL::KK;
+    };
+    float4 bq[PF][TL::T];
 #pragma unroll
-    for (int t = 0; t < TL::T; ++t) bnext[t] = wl[t * 64];
+    for (int d = 0; d < PF; ++d) {
+        const int sidx = gstep(d);
+#pragma unroll
+        for (int t = 0; t < TL::T; ++t) bq[d][t] = wl[((size_t)sidx * NT + t) * 64];
+    }
 
     gload(0);
     lwrite(lds);
@@ -159,19 +180,23 @@ __global__ __launch_bounds__(256) void gated_conv_kernel(const ConvKArgs a)
         const bool more = chunk + 1 < a.nchunks;
         if (more) gload(chunk + 1);
         const float *buf = lds + (chunk & 1) * TL::BUF;
-        const int step0 = chunk * KS * KS * TL::KK;
+        const int step0 = chunk * SPC;
 #pragma unroll
-        for (int tap = 0; tap < KS * KS; ++tap) {
+        for (int ltap = 0; ltap < TL::TPW; ++ltap) {
+            const int tap = wk * TL::TPW + ltap;      // wk == 0 whenever TPW == KS*KS, so this stays a constant
             const int ky = tap / KS, kx = tap % KS;
 #pragma unroll
             for (int kk = 0; kk < TL::KK; ++kk) {
                 float4 b[TL::T];
 #pragma unroll
-                for (int t = 0; t < TL::T; ++t) b[t] = bnext[t];
-                int nstep = step0 + tap * TL::KK + kk + 1;
-                nstep = nstep < total_steps ? nstep : total_steps - 1;
+                for (int t = 0; t < TL::T; ++t) b[t] = bq[0][t];
 #pragma unroll
-                for (int t = 0; t < TL::T; ++t) bnext[t] = wl[((size_t)nstep * NT + t) * 64];
+                for (int d = 0; d + 1 < PF; ++d)
+#pragma unroll
+                    for (int t = 0; t < TL::T; ++t) bq[d][t] = bq[d + 1][t];
+                const int nstep = gstep(step0 + ltap * TL::KK + kk + PF);
+#pragma unroll
+                for (int t = 0; t < TL::T; ++t) bq[PF - 1][t] = wl[((size_t)nstep * NT + t) * 64];
                 float4 av[P];
 #pragma unroll
                 for (int p = 0; p < P; ++p)
@@ -192,6 +217,20 @@ __global__ __launch_bounds__(256) void gated_conv_kernel(const ConvKArgs a)
         __syncthreads();
     }
 
+    // ---------------- split-K: the WK waves of a tile exchange partial sums through LDS; wave wk then
+    // finishes accumulator registers [wk*NR, wk*NR+NR) (every tile, every group).
+    if (TL::WK > 1) {
+        // the chunk loop ended with a barrier: the A tiles are dead, reuse the LDS
+#pragma unroll
+        for (int p = 0; p < P; ++p)
+#pragma unroll
+            for (int t = 0; t < TL::T; ++t)
+#pragma unroll
+                for (int r = 0; r < 16; ++r)
+                    lds[(((wave * P + p) * TL::T + t) * 16 + r) * 64 + lane] = acc[p][t][r];
+        __syncthreads();
+    }
+
     // ---------------- epilogue: bias, ELU, sigmoid gate, BatchNorm(eval), residual, store
     const int hi = lane >> 5;
 #pragma unroll
@@ -208,13 +247,26 @@ __global__ __launch_bounds__(256) void gated_conv_kernel(const ConvKArgs a)
             const int oy = oy0 + wm * P + p;
             if (oy >= a.outH) continue;
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
+            for (int rr = 0; rr < TL::NR; ++rr) {
+                const int r = wk * TL::NR + rr;
                 const int ox = ox0 + (r & 3) + 8 * (r >> 2) + 4 * hi;
                 if (ox >= a.outW) continue;
                 const int opix = oy * a.outW + ox;
                 if (c_ok) {
-                    float f = acc[p][2 * g][r] + bf;
-                    const float m = acc[p][2 * g + 1][r] + bm;
+                    float f, m;
+                    if (TL::WK > 1) {
+                        f = m = 0.0f;
+#pragma unroll
+                        for (int w = 0; w < TL::WK; ++w) {
+                            f += lds[(((w * P + p) * TL::T + 2 * g) * 16 + r) * 64 + lane];
+                            m += lds[(((w * P + p) * TL::T + 2 * g + 1) * 16 + r) * 64 + lane];
+                        }
+                    } else {
+                        f = acc[p][2 * g][rr];        // WK == 1: r == rr
+                        m = acc[p][2 * g + 1][rr];
+                    }
+                    f += bf;
+                    m += bm;
                     if (a.elu) f = elu1(f);
                     float v = (f * sigmoidf(m)) * sc + sh;
                     if (a.residual) v += a.residual[opix * a.Cout + c];
@@ -234,59 +286,79 @@ typedef void (*conv_fn)(const ConvKArgs);
 
 struct ConvConfig {
     const char *name;
-    int KS, S, KC, P, QG, WM, WN;
+    int KS, S, KC, P, QG, WM, WN, PF;
     conv_fn fn;
     conv_fn fn_mul;      // variant whose loader multiplies by a second tensor (FAM), or null
 };
 
-#define CFG(KS, S, KC, P, QG, WM, WN)                                                  \
-    {"k" #KS "s" #S "c" #KC "_p" #P "q" #QG "m" #WM "n" #WN, KS, S, KC, P, QG, WM, WN, \
-     gated_conv_kernel<KS, S, KC, P, QG, WM, WN, false>, nullptr}
-#define CFGM(KS, S, KC, P, QG, WM, WN)                                                 \
-    {"k" #KS "s" #S "c" #KC "_p" #P "q" #QG "m" #WM "n" #WN, KS, S, KC, P, QG, WM, WN, \
-     gated_conv_kernel<KS, S, KC, P, QG, WM, WN, false>,                               \
-     gated_conv_kernel<KS, S, KC, P, QG, WM, WN, true>}
+#define CFG(KS, S, KC, P, QG, WM, WN, PF)                                                      \
+    {"k" #KS "s" #S "c" #KC "_p" #P "q" #QG "m" #WM "n" #WN "f" #PF, KS, S, KC, P, QG, WM, WN, PF, \
+     gated_conv_kernel<KS, S, KC, P, QG, WM, WN, false, PF>, nullptr}
+#define CFGM(KS, S, KC, P, QG, WM, WN, PF)                                                     \
+    {"k" #KS "s" #S "c" #KC "_p" #P "q" #QG "m" #WM "n" #WN "f" #PF, KS, S, KC, P, QG, WM, WN, PF, \
+     gated_conv_kernel<KS, S, KC, P, QG, WM, WN, false, PF>,                                   \
+     gated_conv_kernel<KS, S, KC, P, QG, WM, WN, true, PF>}
 
-// Order matters: the first matching entry is the automatic choice.
+// Order matters: pick_config() takes the first entry whose (ksize, stride, chunk) match and whose
+// channel-group coverage divides the layer's groups; remaining groups go to grid.y.  The order below
+// follows the measured sweep on MI355X (profiles/r1_sweep_conv.md): small tiles + group splitting over
+// grid.y beat wide per-wave tiles at every level (more workgroups in flight, 3-5 waves/SIMD).
 const ConvConfig g_configs[] = {
     // 3x3 stride 1, 16-channel chunks (ResBlocks, FAM, AFF second conv, SCM third conv, fe5)
-    CFG(3, 1, 16, 2, 1, 4, 1),   //  0  G=1
-    CFGM(3, 1, 16, 2, 2, 4, 1),  //  1  G=2
-    CFGM(3, 1, 16, 2, 2, 2, 2),  //  2  G=4 (G=8 with grid.y=2)
-    CFGM(3, 1, 16, 1, 2, 1, 4),  //  3  G=8, one image row per workgroup
+    CFGM(3, 1, 16, 2, 1, 4, 1, 1),  //  0  8x32 px, one 32-channel group per workgroup
+    CFGM(3, 1, 16, 1, 1, 4, 1, 1),  //  1  4x32 px
+    CFGM(3, 1, 16, 2, 1, 2, 2, 1),  //  2  4x32 px, two groups (B split over waves)
+    CFGM(3, 1, 16, 2, 2, 4, 1, 1),  //  3  8x32 px, two groups per wave
+    CFGM(3, 1, 16, 2, 2, 2, 2, 1),  //  4  4x32 px, four groups
+    CFGM(3, 1, 16, 1, 2, 1, 4, 1),  //  5  1x32 px, eight groups
+    CFGM(3, 1, 16, 2, 1, 4, 1, 2),  //  6  as 0, B prefetch depth 2
+    CFGM(3, 1, 16, 1, 1, 4, 1, 2),  //  7  as 1, depth 2
+    CFGM(3, 1, 16, 2, 1, 2, 2, 2),  //  8  as 2, depth 2
     // 3x3 stride 1, 8-channel chunks (inputs straight from the 8-channel pyramid)
-    CFG(3, 1, 8, 2, 1, 4, 1),    //  4
-    CFG(3, 1, 8, 2, 2, 4, 1),    //  5
+    CFG(3, 1, 8, 2, 1, 4, 1, 1),    //  9
+    CFG(3, 1, 8, 1, 1, 4, 1, 1),    // 10
     // 1x1, 16-channel chunks (SCM, AFF first conv, Convs)
-    CFG(1, 1, 16, 2, 1, 4, 1),   //  6
-    CFG(1, 1, 16, 2, 2, 4, 1),   //  7
-    CFG(1, 1, 16, 2, 2, 2, 2),   //  8
-    CFG(1, 1, 16, 1, 2, 1, 4),   //  9
+    CFG(1, 1, 16, 2, 1, 4, 1, 1),   // 11
+    CFG(1, 1, 16, 1, 1, 4, 1, 1),   // 12
+    CFG(1, 1, 16, 2, 2, 2, 2, 1),   // 13
+    CFG(1, 1, 16, 2, 1, 4, 1, 2),   // 14
     // 1x1, 8-channel chunks (SCM tail: cat[x(8), main(P-8)])
-    CFG(1, 1, 8, 2, 2, 4, 1),    // 10
-    CFG(1, 1, 8, 2, 2, 2, 2),    // 11
-    CFG(1, 1, 8, 1, 2, 1, 4),    // 12
+    CFG(1, 1, 8, 2, 1, 4, 1, 1),    // 15
+    CFG(1, 1, 8, 1, 1, 4, 1, 1),    // 16
     // 3x3 stride 2 (encoder downsampling)
-    CFG(3, 2, 16, 1, 2, 4, 1),   // 13
-    CFG(3, 2, 16, 1, 2, 2, 2),   // 14
-    // 4x4 stride 2 (decoder, before the bilinear x4)
-    CFG(4, 2, 16, 1, 1, 4, 1),   // 15
-    CFG(4, 2, 16, 1, 2, 4, 1),   // 16
-    CFG(4, 2, 16, 1, 2, 2, 2),   // 17
-    // alternatives kept for tuning sweeps
-    CFG(3, 1, 16, 1, 2, 2, 2),   // 18  G=4/8, two rows per workgroup
-    CFG(3, 1, 16, 1, 1, 4, 1),   // 19  G=1, four rows per workgroup
-    CFG(3, 1, 16, 2, 1, 2, 2),   // 20  G=2, 4 rows, B split over waves
+    CFG(3, 2, 16, 1, 1, 4, 1, 1),   // 17
+    CFG(3, 2, 16, 1, 2, 2, 2, 1),   // 18
+    CFG(3, 2, 16, 1, 2, 4, 1, 1),   // 19
+    // 4x4 stride 2 (decoder, before the bilinear x4): outputs are 1/4 .. 1/16 scale, so the 16 taps of
+    // ONE 1x32-pixel tile are split over the four waves (split-K, WM*WN == 1) to fill the chip
+    CFG(4, 2, 16, 1, 1, 1, 1, 1),   // 20  split-K, one group
+    CFG(4, 2, 16, 1, 1, 4, 1, 1),   // 21
+    CFG(4, 2, 16, 1, 2, 2, 2, 1),   // 22
 };
 constexpr int N_CONFIGS = sizeof(g_configs) / sizeof(g_configs[0]);
 
-int pick_config(int ks, int s, int kc, int groups)
+int find_config(int ks, int s, int kc, int P, int QG, int WM, int WN, int PF)
 {
     for (int i = 0; i < N_CONFIGS; ++i) {
         const ConvConfig &c = g_configs[i];
-        if (c.KS == ks && c.S == s && c.KC == kc && groups % (c.WN * c.QG) == 0 &&
-            (c.WN * c.QG == groups || (c.WN * c.QG == 4 && groups == 8)))
+        if (c.KS == ks && c.S == s && c.KC == kc && c.P == P && c.QG == QG && c.WM == WM && c.WN == WN && c.PF == PF)
             return i;
+    }
+    return -1;
+}
+
+// Automatic choice.  Measured on MI355X at 1216x352 (profiles/r1_sweep_conv.md): 8x32-pixel tiles win
+// only while they still give >= ~4 workgroups per CU; below that 4x32 tiles (twice the workgroups)
+// win, and at exactly four channel groups the 4x32 x 2-group tile (A tile shared by two wave pairs)
+// is best.
+int pick_config(int ks, int s, int kc, int groups, int outH, int outW)
+{
+    if (ks == 3 && s == 1 && kc == 16) {
+        const long wg8 = (long)ceil_div(outW, 32) * ceil_div(outH, 8) * groups;
+        int c = -1;
+        if (groups == 4) c = find_config(3, 1, 16, 2, 1, 2, 2, 1);
+        else if (wg8 < 1024) c = find_config(3, 1, 16, 1, 1, 4, 1, 1);
+        if (c >= 0) return c;
     }
     for (int i = 0; i < N_CONFIGS; ++i) {
         const ConvConfig &c = g_configs[i];
@@ -452,7 +524,7 @@ int launch_gated_conv(const read_conv_desc *d, hipStream_t stream)
     READ_CHECK_ARG((long long)outH * outW * d->out_cstride < (1ll << 31), "read_gated_conv_forward: output too large");
     const int CoutPad = pad32(d->Cout), groups = CoutPad / 32;
     int cfg = d->config;
-    if (cfg < 0) cfg = pick_config(d->ksize, d->stride, kc, groups);
+    if (cfg < 0) cfg = pick_config(d->ksize, d->stride, kc, groups, outH, outW);
     READ_CHECK_ARG(cfg >= 0 && cfg < N_CONFIGS, "read_gated_conv_forward: no kernel for k=%d s=%d kc=%d groups=%d",
                    d->ksize, d->stride, kc, groups);
     const ConvConfig &c = g_configs[cfg];

@@ -3,14 +3,14 @@
 // Replaces the reference's per-scale, per-camera DepthProject launches
 // (MyRender/CloudProjection/point_render.cu:125-200; GL twin READ/gl/render.py:52-85) with
 //   1. splat_project : ONE pass over the cloud for all B cameras.  Each accepted point becomes a
-//      packed 64-bit key (fp32 depth bits << 32 | point id) and is folded into the level-0 key
+//      packed 64-bit key (fp32 depth bits << 32 | point id) and is folded into a level-0 key
 //      image with an unsigned 64-bit atomic min — min depth, ties -> min id, order independent
 //      (SURVEY.md App. A.3).  A relaxed L1-bypassing read of the current key filters out the
 //      points that cannot win before they cost an atomic (keys only ever decrease, so a stale
-//      read is merely conservative).
-//   2. splat_resolve : one small pass over the key image that derives levels 1..4 by 2x2 key-min
-//      (exactly the reference's five rasterisations, App. A.4), unpacks (id, depth) for every
-//      level and resets the key image to EMPTY for the next frame.
+//      read is merely conservative).  Each XCD folds into its own image with L2-local atomics.
+//   2. splat_resolve : one small pass over the key images that takes the min over the XCDs, derives
+//      levels 1..4 by 2x2 key-min (exactly the reference's five rasterisations, App. A.4), unpacks
+//      (id, depth) for every level and resets the key images to EMPTY for the next frame.
 //
 // HBM-bound: algorithmic bytes per frame = 12*N (xyz read once) + 8*sum_l(h_l*w_l) (id + depth).
 // The arithmetic that decides which PIXEL a point lands in is bit-exact fp32: no FMA
@@ -45,33 +45,95 @@ __device__ __forceinline__ int project_one(float x, float y, float z, const floa
     // NaN compares false everywhere: written so that NaN is rejected (canonical semantics).
     const bool inside = (nx >= -1.0f) & (nx <= 1.0f) & (ny >= -1.0f) & (ny <= 1.0f) &
                         (nz >= -1.0f) & (nz <= 1.0f);
-    if (!inside) return -1;
     const float u = ((float)W * (nx + 1.0f)) * 0.5f;
     const float v = ((float)H * (1.0f - ny)) * 0.5f;
     depth = (nz + 1.0f) * 0.5f;
     const int xx = (int)u, yy = (int)v;
-    if (xx < 0 || xx >= W || yy < 0 || yy >= H) return -1;
-    return yy * W + xx;
+    const bool ok = inside & (xx >= 0) & (xx < W) & (yy >= 0) & (yy < H);
+    return ok ? yy * W + xx : -1;
 }
 
-__device__ __forceinline__ void fold_key(unsigned long long *keys, int pix, float depth, unsigned id)
+// Key-image update policies (read_tuning_set("splat_mode", m)):
+//   MODE_XCD   (default) one private key image per XCD.  Workgroups read HW_REG_XCC_ID and fold into
+//              "their" image with WORKGROUP-scope atomics, which execute in that XCD's L2 and never
+//              cross the fabric; the 3.4 MB image stays L2 resident, and the early-z read (sc1: L2,
+//              not the CU's L1) sees every earlier fold of the same XCD.  The resolve pass takes the
+//              min over the 8 images.  Correctness needs only that all accesses to image x come
+//              from XCD x inside the launch, plus ordinary kernel-boundary visibility.
+//   MODE_AGENT one shared image, agent-scope atomics (memory-side), early-z through a possibly
+//              stale L2 copy (conservative, but filters less).
+//   MODE_NOZ   projection only, no z-buffer traffic: timing floor for tuning, results are invalid.
+//   MODE_SYS   one shared image, agent-scope atomics, early-z read at SYSTEM scope (sc0 sc1: bypasses
+//              the XCD L2 too, so the filter is exact but every read crosses the fabric).
+enum { MODE_XCD = 0, MODE_AGENT = 1, MODE_NOZ = 2, MODE_SYS = 3 };
+constexpr int XCD_COPIES = 8;
+
+__device__ __forceinline__ unsigned xcc_id()
 {
-    const unsigned long long key = ((unsigned long long)__float_as_uint(depth) << 32) | id;
-    // Early-z: relaxed agent-scope load (global_load_dwordx2 sc1: served by L2, never by the
-    // CU's stale L1).  Keys decrease monotonically, so "not smaller than what I can see" is final.
-    const unsigned long long seen = __hip_atomic_load(keys + pix, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    if (key < seen) atomicMin(keys + pix, key);
+    // s_getreg_b32 hwreg(HW_REG_XCC_ID = 20, offset 0, size 4)
+    return __builtin_amdgcn_s_getreg((3 << 11) | 20) & (XCD_COPIES - 1);
 }
 
+template <int MODE>
+__device__ __forceinline__ unsigned long long peek_key(const unsigned long long *k)
+{
+    // relaxed agent-scope load = global_load_dwordx2 sc1: served by L2, never by the CU's stale L1
+    if (MODE == MODE_SYS) return __hip_atomic_load(k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    return __hip_atomic_load(k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+template <int MODE>
+__device__ __forceinline__ void fold_key(unsigned long long *k, unsigned long long key)
+{
+    if (MODE == MODE_XCD)
+        __hip_atomic_fetch_min(k, key, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    else
+        __hip_atomic_fetch_min(k, key, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+// NP points of one thread against one camera: all projections first, then all early-z reads in
+// flight together, then the (few) atomics — no dependent memory round trip per point.
+template <int MODE, int NP>
+__device__ __forceinline__ void splat_points(const float (&px)[NP], const float (&py)[NP], const float (&pz)[NP],
+                                             unsigned id0, int nvalid, const float *M, int W, int H,
+                                             unsigned long long *keys, unsigned &sink)
+{
+    int pix[NP];
+    unsigned long long key[NP], seen[NP];
+#pragma unroll
+    for (int k = 0; k < NP; ++k) {
+        float d;
+        pix[k] = project_one(px[k], py[k], pz[k], M, W, H, d);
+        if (k >= nvalid) pix[k] = -1;
+        key[k] = ((unsigned long long)__float_as_uint(d) << 32) | (id0 + k);
+    }
+    if (MODE == MODE_NOZ) {
+#pragma unroll
+        for (int k = 0; k < NP; ++k) sink += (unsigned)pix[k];
+        return;
+    }
+#pragma unroll
+    for (int k = 0; k < NP; ++k) seen[k] = pix[k] >= 0 ? peek_key<MODE>(keys + pix[k]) : 0ull;
+    // keys only ever decrease, so "not smaller than what I can see" is final
+#pragma unroll
+    for (int k = 0; k < NP; ++k)
+        if (key[k] < seen[k]) fold_key<MODE>(keys + pix[k], key[k]);
+}
+
+template <int MODE>
 __global__ __launch_bounds__(256) void splat_project_kernel(const float *__restrict__ xyz, long long n,
                                                             CamSet cams, int B, int W, int H,
                                                             unsigned long long *__restrict__ keys,
-                                                            int vec_ok)
+                                                            int vec_ok, unsigned *sink_out)
 {
     const long long npx = (long long)W * H;
     const long long groups = n / PTS_PER_THREAD;
     const long long tid0 = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     const long long nthreads = (long long)gridDim.x * blockDim.x;
+    // image layout: [camera][copy][pixel]; a workgroup only ever touches its own XCD's copy
+    const int copies = MODE == MODE_XCD ? XCD_COPIES : 1;
+    unsigned long long *kbase = keys + (MODE == MODE_XCD ? (long long)xcc_id() * npx : 0);
+    unsigned sink = 0;
 
     if (vec_ok) {
         const float4 *xyz4 = reinterpret_cast<const float4 *>(xyz);
@@ -83,27 +145,20 @@ __global__ __launch_bounds__(256) void splat_project_kernel(const float *__restr
             const float px[4] = {a.x, a.w, b.z, c.y};
             const float py[4] = {a.y, b.x, b.w, c.z};
             const float pz[4] = {a.z, b.y, c.x, c.w};
-            const unsigned id0 = (unsigned)(g * PTS_PER_THREAD);
-#pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                for (int cam = 0; cam < B; ++cam) {
-                    float d;
-                    const int pix = project_one(px[k], py[k], pz[k], cams.m[cam], W, H, d);
-                    if (pix >= 0) fold_key(keys + cam * npx, pix, d, id0 + k);
-                }
-            }
+            for (int cam = 0; cam < B; ++cam)
+                splat_points<MODE, 4>(px, py, pz, (unsigned)(g * PTS_PER_THREAD), 4, cams.m[cam], W, H,
+                                      kbase + (long long)cam * copies * npx, sink);
         }
     }
     // tail (n % 4 points), or everything when the pointer is not 16-byte aligned
     const long long first = vec_ok ? groups * PTS_PER_THREAD : 0;
     for (long long i = first + tid0; i < n; i += nthreads) {
-        const float x = xyz[3 * i + 0], y = xyz[3 * i + 1], z = xyz[3 * i + 2];
-        for (int cam = 0; cam < B; ++cam) {
-            float d;
-            const int pix = project_one(x, y, z, cams.m[cam], W, H, d);
-            if (pix >= 0) fold_key(keys + cam * npx, pix, d, (unsigned)i);
-        }
+        const float px[1] = {xyz[3 * i + 0]}, py[1] = {xyz[3 * i + 1]}, pz[1] = {xyz[3 * i + 2]};
+        for (int cam = 0; cam < B; ++cam)
+            splat_points<MODE, 1>(px, py, pz, (unsigned)i, 1, cams.m[cam], W, H,
+                                  kbase + (long long)cam * copies * npx, sink);
     }
+    if (MODE == MODE_NOZ && sink == 0x7fffffffu && sink_out) *sink_out = sink;   // keeps the projection live
 }
 
 struct ResolveOut {
@@ -127,7 +182,7 @@ __device__ __forceinline__ unsigned long long kmin(unsigned long long a, unsigne
 // Levels 2..4 are reduced through LDS (16x16 -> 8x8 -> 4x4 -> 2x2 keys).
 __global__ __launch_bounds__(256) void splat_resolve_kernel(unsigned long long *__restrict__ keys, int W, int H,
                                                             int levels, ResolveOut out, int tiles_x,
-                                                            int tiles_y)
+                                                            int tiles_y, int copies)
 {
     __shared__ unsigned long long s1[256], s2[64], s3[16];
     const int cam = blockIdx.y;
@@ -136,7 +191,7 @@ __global__ __launch_bounds__(256) void splat_resolve_kernel(unsigned long long *
     const int qx = t & 15, qy = t >> 4;
     const int x0 = tx * 32 + qx * 2, y0 = ty * 32 + qy * 2;
     const long long npx0 = (long long)W * H;
-    unsigned long long *kc = keys + cam * npx0;
+    unsigned long long *kc = keys + (long long)cam * copies * npx0;
 
     unsigned long long k[2][2];
 #pragma unroll
@@ -147,8 +202,10 @@ __global__ __launch_bounds__(256) void splat_resolve_kernel(unsigned long long *
             unsigned long long v = EMPTY_KEY;
             if (x < W && y < H) {
                 const long long off = (long long)y * W + x;
-                v = kc[off];
-                kc[off] = EMPTY_KEY;                 // leave the workspace clean for the next frame
+                for (int c = 0; c < copies; ++c) {   // min over the per-XCD images
+                    v = kmin(v, kc[c * npx0 + off]);
+                    kc[c * npx0 + off] = EMPTY_KEY;  // leave the workspace clean for the next frame
+                }
                 emit(out, 0, cam * npx0 + off, v);
             }
             k[dy][dx] = v;
@@ -210,10 +267,14 @@ int level_dim(int v, int l)
     return (int)((double)v * (1.0 / (double)(1 << l)));
 }
 
+int g_splat_mode = MODE_XCD;
+
 int project_and_resolve(const float *xyz, int64_t n, const float *M_host, int B, int W, int H, int levels,
                         int32_t *const *idx_levels, float *const *depth_levels, int level_base,
                         unsigned long long *keys, hipStream_t stream)
 {
+    const int mode = g_splat_mode;
+    const int copies = mode == MODE_XCD ? XCD_COPIES : 1;
     for (int b0 = 0; b0 < B; b0 += MAX_CAMS) {
         const int nb = (B - b0) < MAX_CAMS ? (B - b0) : MAX_CAMS;
         CamSet cams;
@@ -225,8 +286,11 @@ int project_and_resolve(const float *xyz, int64_t n, const float *M_host, int B,
             int64_t blocks = ceil_div64(work, 256);
             if (blocks > 256 * 8) blocks = 256 * 8;
             const int vec_ok = ((uintptr_t)xyz % 16) == 0;
-            hipLaunchKernelGGL(splat_project_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, xyz,
-                               (long long)n, cams, nb, W, H, keys, vec_ok);
+            auto kern = mode == MODE_XCD ? splat_project_kernel<MODE_XCD>
+                        : mode == MODE_AGENT ? splat_project_kernel<MODE_AGENT>
+                        : mode == MODE_SYS ? splat_project_kernel<MODE_SYS> : splat_project_kernel<MODE_NOZ>;
+            hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(256), 0, stream, xyz, (long long)n, cams, nb, W, H,
+                               keys, vec_ok, (unsigned *)nullptr);
             READ_CHECK_LAUNCH();
         }
         ResolveOut out;
@@ -239,7 +303,7 @@ int project_and_resolve(const float *xyz, int64_t n, const float *M_host, int B,
         }
         const int tiles_x = ceil_div(W, 32), tiles_y = ceil_div(H, 32);
         hipLaunchKernelGGL(splat_resolve_kernel, dim3(tiles_x * tiles_y, nb), dim3(256), 0, stream, keys, W, H,
-                           levels, out, tiles_x, tiles_y);
+                           levels, out, tiles_x, tiles_y, copies);
         READ_CHECK_LAUNCH();
     }
     return READ_OK;
@@ -251,7 +315,17 @@ extern "C" size_t read_splat_workspace_bytes(int B, int W, int H)
 {
     if (B < 1 || W < 1 || H < 1) return 0;
     const int nb = B < MAX_CAMS ? B : MAX_CAMS;
-    return (size_t)nb * W * H * sizeof(unsigned long long);
+    // sized for the largest layout (one key image per XCD and camera) whatever mode is active
+    return (size_t)nb * XCD_COPIES * W * H * sizeof(unsigned long long);
+}
+
+namespace readhip {
+int splat_set_mode(int m)
+{
+    if (m < MODE_XCD || m > MODE_SYS) return READ_EINVAL;
+    g_splat_mode = m;
+    return READ_OK;
+}
 }
 
 extern "C" int read_splat_workspace_init(void *ws, size_t ws_bytes, void *stream)

@@ -1,0 +1,93 @@
+"""``NetAndTexture``: the texture-lookup + refinement-net composite that READ's pipelines train and
+render with (interface of READ/models/compose.py:84-181).
+
+Contract kept from the reference: constructor ``(net, textures, supersampling=1,
+temporal_average=False)``; textures live on the CPU until ``load_textures(ids)`` registers them as
+sub-modules named ``str(id)`` (so ``.cuda()``, ``state_dict()`` and optimizers see them);
+``forward(inputs)`` consumes a dict ``{'id': ids, <token>: (B,1|3,h,w) index maps, ...}``, REMOVES
+``'id'`` from it, processes the batch item by item (each item may use a different texture) and
+returns ``(B,3,H,W)`` — plus the last item's network inputs when ``return_input=True``.
+
+MI355X specifics: an item whose inputs are all ``uv*`` index maps (the only layout
+TexturePipeline produces) is gathered at every scale by ONE HIP launch into NHWC feature maps that
+the UNet engine consumes without a copy.
+"""
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from .texture import gather_pyramid
+
+
+def _as_id_list(ids):
+    if torch.is_tensor(ids):
+        return ids.cpu().tolist() if ids.dim() else [int(ids)]
+    return [ids] if isinstance(ids, int) else list(ids)
+
+
+class NetAndTexture(nn.Module):
+    def __init__(self, net, textures, supersampling=1, temporal_average=False):
+        super().__init__()
+        self.net = net
+        self.ss = supersampling
+        self.temporal_average = temporal_average
+        self.last_input = None
+        if not hasattr(textures, 'items'):
+            try:
+                textures = dict(textures)
+            except TypeError:
+                textures = {0: textures}
+        self._textures = {tid: tex.cpu() for tid, tex in textures.items()}
+        self._loaded_textures = []
+
+    # ---- texture residency -------------------------------------------------------------------
+    def load_textures(self, texture_ids):
+        ids = _as_id_list(texture_ids)
+        for tid in ids:
+            self._modules[str(tid)] = self._textures[tid]
+        self._loaded_textures = ids
+
+    def unload_textures(self):
+        for tid in self._loaded_textures:
+            self._modules.pop(str(tid)).cpu()
+        self._loaded_textures = []
+
+    def reg_loss(self):
+        return sum((self._modules[str(tid)].reg_loss() for tid in self._loaded_textures), 0)
+
+    # ---- one batch item ------------------------------------------------------------------------
+    def _sample_item(self, texture, item):
+        """item: ordered {token: (1,c,h,w)}.  Each 'uv' token opens a scale; non-uv tokens that follow it
+        are concatenated in front of its texture sample (compose.py:140-160)."""
+        tokens = list(item)
+        assert 'uv' in tokens[0], 'first input must be uv'
+        only_uv = all('uv' in t for t in tokens)
+        needs_grad = torch.is_grad_enabled() and texture.texture_.requires_grad
+        if only_uv and self.ss == 1 and not needs_grad:
+            ids = [texture._ids(item[t]).to(texture.texture_.device) for t in tokens]
+            return [f.permute(0, 3, 1, 2) for f in gather_pyramid(texture.rows(), ids, texture.activation)]
+        scales, extras = [], []
+        for t in tokens:
+            if 'uv' in t:
+                scales.append([texture(item[t])])
+                extras = scales[-1]
+            else:
+                extras.insert(len(extras) - 1, item[t].to(texture.texture_.device))
+        out = [torch.cat(parts, 1) if len(parts) > 1 else parts[0] for parts in scales]
+        if self.ss > 1:
+            out = [F.interpolate(x, scale_factor=1. / self.ss, mode='bilinear') for x in out]
+        return out
+
+    def forward(self, inputs, **kwargs):
+        texture_ids = _as_id_list(inputs.pop('id'))            # the caller's dict loses 'id', as in the reference
+        frames, net_input = [], None
+        for b, tid in enumerate(texture_ids):
+            texture = self._modules[str(tid)]
+            net_input = self._sample_item(texture, {k: v[b][None] for k, v in inputs.items()})
+            if self.temporal_average:
+                if self.last_input is not None:
+                    net_input = [(cur + prev) / 2 for cur, prev in zip(net_input, self.last_input)]
+                self.last_input = list(net_input)
+            frames.append(self.net(*net_input, **kwargs))
+        out = torch.cat(frames, 0)
+        return (out, net_input) if kwargs.get('return_input') else out

@@ -1,0 +1,79 @@
+"""Viewer-side glue with the interface of READ/gl/nn.py:76-129 (``OGL``): rasterise the scene's
+current camera, look up descriptors, run the net, hand back an ``H x W x 4`` RGBA frame.
+
+``OGL(scene, scene_data, viewport_size, net_ckpt, texture_ckpt, ...)`` loads a pipeline checkpoint
+exactly like the reference; ``OGL.from_model(scene, model, input_format, viewport_size)`` wraps an
+already-built ``NetAndTexture`` (used when no checkpoint file exists, e.g. synthetic scenes).
+``infer()`` keeps every stage on the device: int32 index pyramids -> one gather launch -> one UNet
+plan, no ToTensor / host copies (nn.py:115-117)."""
+import torch
+
+from . import _lib
+from .render import MultiscaleRender
+from .texture import gather_pyramid
+
+
+class OGL:
+    def __init__(self, scene, scene_data, viewport_size, net_ckpt, texture_ckpt, out_buffer_location='numpy',
+                 supersampling=1, gpu=True, clear_color=None, temporal_average=False):
+        from .pipeline import load_pipeline
+        args_upd = {'inference': True}
+        if texture_ckpt:
+            args_upd['texture_ckpt'] = texture_ckpt
+            if 'pointcloud' in scene_data:
+                args_upd['n_points'] = scene_data['pointcloud']['xyz'].shape[0]
+        pipeline, args = load_pipeline(net_ckpt, args_to_update=args_upd)
+        model = pipeline.model
+        model.load_textures(0)
+        self._setup(scene, model, args.input_format, viewport_size, out_buffer_location, supersampling, gpu,
+                    clear_color, temporal_average)
+
+    @classmethod
+    def from_model(cls, scene, model, input_format, viewport_size, out_buffer_location='torch', supersampling=1,
+                   temporal_average=False):
+        self = cls.__new__(cls)
+        self._setup(scene, model, input_format, viewport_size, out_buffer_location, supersampling, True, None,
+                    temporal_average)
+        return self
+
+    def _setup(self, scene, model, input_format, viewport_size, out_buffer_location, supersampling, gpu, clear_color,
+               temporal_average):
+        if not gpu:
+            raise _lib.ReadHipError("OGL(gpu=False): the render path has no CPU implementation")
+        self.gpu = True
+        self.model = model.cuda().eval()
+        if supersampling > 1:
+            self.model.ss = supersampling
+        self.model.temporal_average = temporal_average
+        factor = 16
+        assert viewport_size[0] % 16 == 0, f'set width {factor * (viewport_size[0] // factor)}'
+        assert viewport_size[1] % 16 == 0, f'set height {factor * (viewport_size[1] // factor)}'
+        self.viewport_size = viewport_size
+        self.input_format = input_format
+        self.renderer = MultiscaleRender(scene, input_format, viewport_size, out_buffer_location='torch',
+                                         supersampling=self.model.ss, clear_color=clear_color)
+
+    def infer(self, input_dict=None):
+        """-> {'output': H x W x 4 float tensor (RGB + alpha 1), 'net_input': list of NCHW feature maps}."""
+        model = self.model
+        texture = model._modules[str(model._loaded_textures[0])] if model._loaded_textures else model._modules['0']
+        fast = (input_dict is None and model.ss == 1 and not model.temporal_average
+                and hasattr(model.net, 'engine'))
+        with torch.set_grad_enabled(False):
+            if fast:
+                scene = self.renderer.scene
+                W, H = self.viewport_size
+                fmts = self.input_format.replace(' ', '').split(',')
+                idx, _ = scene.rasterizer().render(scene.total_matrix(), W, H, len(fmts), want_depth=False)
+                feats = gather_pyramid(texture.rows(), idx, texture.activation)
+                out = model.net.engine(H, W).forward(feats[0][0], feats[1][0], feats[2][0], feats[3][0], channels=4)
+                net_input = [f.permute(0, 3, 1, 2) for f in feats]
+            else:
+                if input_dict is None:
+                    input_dict = {k: v.permute(2, 0, 1)[None] for k, v in self.renderer.render().items()}
+                input_dict = dict(input_dict)
+                input_dict['id'] = 0
+                o, net_input = model(input_dict, return_input=True)
+                o = o[0].detach().permute(1, 2, 0)
+                out = torch.cat([o, torch.ones_like(o[:, :, :1])], 2).contiguous()
+        return {'output': out, 'net_input': net_input}

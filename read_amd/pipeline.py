@@ -1,0 +1,170 @@
+"""Pipeline plug-in seam of READ (READ/pipelines/pipeline.py:10-71, READ/pipelines/ogl.py:58-154).
+
+``TexturePipeline`` keeps the reference's method/attribute set (export_args, create, state_objects,
+dataset_load/unload, extra_optimizer, get_net; model, net, textures, ds_train, ds_val, optimizer,
+criterion, args) so ``--pipeline read_amd.pipeline.TexturePipeline`` (or the ``READ.pipelines.ogl``
+alias in the ``READ/`` shim package) is selectable by dotted path without editing train.py.
+Checkpoints use the reference's format ``{'state_dict', 'args'}`` (READ/utils/train.py:42-66).
+
+Datasets, losses and the training loop are NOT rebuilt here (out of the hot path, SURVEY.md §2.1
+#17-#21): ``create`` in training mode obtains datasets through ``args.get_datasets`` and the
+criterion through ``args.criterion_module``, both supplied by the caller's training script.
+"""
+import importlib
+import os
+from pathlib import Path
+from types import SimpleNamespace
+
+import torch
+from torch import optim
+
+from .net_texture import NetAndTexture
+from .texture import PointTexture
+from .unet import UNet
+
+TextureOptimizerClass = optim.RMSprop
+
+
+def _locate(dotted):
+    mod, _, name = dotted.rpartition('.')
+    return getattr(importlib.import_module(mod), name)
+
+
+def load_model_checkpoint(path, model):
+    """READ/utils/train.py:60-66."""
+    ckpt = torch.load(path, map_location='cpu', weights_only=False)
+    model.load_state_dict(ckpt['state_dict'])
+    return model
+
+
+def save_model(save_path, model, args=None):
+    """READ/utils/train.py:42-57: {'state_dict', 'args'}."""
+    model = model.module if hasattr(model, 'module') else model
+    d = {'state_dict': model.state_dict()}
+    if args is not None:
+        d['args'] = dict(vars(args)) if not isinstance(args, dict) else dict(args)
+    torch.save(d, save_path)
+
+
+class Pipeline:
+    def export_args(self, parser):
+        raise NotImplementedError()
+
+    def create(self, args):
+        raise NotImplementedError()
+
+    def dataset_load(self, *args, **kwargs):
+        pass
+
+    def dataset_unload(self, *args, **kwargs):
+        pass
+
+    def get_net(self):
+        raise NotImplementedError()
+
+    def extra_optimizer(self, *args):
+        return None
+
+
+class TexturePipeline(Pipeline):
+    def export_args(self, parser):
+        add = getattr(parser, 'add', parser.add_argument)
+        parser.add_argument('--descriptor_size', type=int, default=8)
+        parser.add_argument('--texture_size', type=int)
+        parser.add_argument('--texture_ckpt', type=Path)
+        add('--texture_lr', type=float, default=1e-1)
+        add('--texture_activation', type=str, default='none')
+        add('--n_points', type=int, default=0, help='this is for inference')
+
+    @staticmethod
+    def _texture(args, size):
+        if getattr(args, 'use_mesh', False):
+            raise NotImplementedError("MeshTexture (use_mesh) is outside the point-cloud render path")
+        tex = PointTexture(args.descriptor_size, size, activation=getattr(args, 'texture_activation', 'none'),
+                           reg_weight=getattr(args, 'reg_weight', 0.))
+        if getattr(args, 'texture_ckpt', None):
+            tex = load_model_checkpoint(args.texture_ckpt, tex)
+        return tex
+
+    def create(self, args):
+        if isinstance(args, dict):
+            args = SimpleNamespace(**args)
+        if not hasattr(args, 'descriptor_size'):
+            args.descriptor_size = 8
+        net = UNet(num_input_channels=8, num_output_channels=3, feature_scale=4, num_res=4)   # ogl.py:19-27
+        textures = {}
+        self.ds_train = self.ds_val = None
+        self.optimizer = self.criterion = self._extra_optimizer = None
+        if getattr(args, 'inference', False):
+            textures = {0: self._texture(args, int(args.n_points))}
+        else:
+            get_datasets = getattr(args, 'get_datasets', None)
+            if get_datasets is None:
+                raise RuntimeError("training mode needs args.get_datasets(args) -> (ds_train, ds_val); "
+                                   "dataset code is not part of read_amd (see INTEGRATION.md)")
+            self.ds_train, self.ds_val = get_datasets(args)
+            for ds in self.ds_train:
+                assert ds.scene_data['pointcloud'] is not None, 'set pointcloud'
+                textures[ds.id] = self._texture(args, ds.scene_data['pointcloud']['xyz'].shape[0])
+            self.optimizer = optim.Adam(net.parameters(), lr=args.lr)
+            if len(textures) == 1:
+                self._extra_optimizer = TextureOptimizerClass(textures[0].parameters(), lr=args.texture_lr)
+            crit = getattr(args, 'criterion_module', None)
+            if crit is not None:
+                crit = _locate(crit) if isinstance(crit, str) else crit
+                self.criterion = crit(**getattr(args, 'criterion_args', {})).cuda()
+        self.net = net
+        self.textures = textures
+        self.model = NetAndTexture(net, textures, getattr(args, 'supersampling', 1))
+        self.args = args
+
+    def state_objects(self):
+        objs = {'net': self.net}
+        objs.update({ds.name: self.textures[ds.id] for ds in (self.ds_train or [])})
+        return objs
+
+    def dataset_load(self, dataset):
+        self.model.load_textures([ds.id for ds in dataset])
+        for ds in dataset:
+            ds.load()
+
+    def extra_optimizer(self, dataset):
+        lr_drop = self.optimizer.param_groups[0]['lr'] / self.args.lr
+        if self._extra_optimizer is not None:       # single dataset: keep optimizer state across epochs
+            self._extra_optimizer.param_groups[0]['lr'] = self.args.texture_lr * lr_drop
+            return self._extra_optimizer
+        groups = [{'params': self.textures[ds.id].parameters()} for ds in dataset]
+        return TextureOptimizerClass(groups, lr=self.args.texture_lr * lr_drop)
+
+    def dataset_unload(self, dataset):
+        self.model.unload_textures()
+        for ds in dataset:
+            ds.unload()
+            self.textures[ds.id].null_grad()
+
+    def get_net(self):
+        return self.net
+
+
+def load_pipeline(checkpoint, args_to_update=None):
+    """READ/pipelines/pipeline.py:34-56: rebuild the pipeline from ckpt['args'], then load the net weights."""
+    ckpt = torch.load(checkpoint, map_location='cpu', weights_only=False)
+    assert 'args' in ckpt
+    a = dict(ckpt['args'])
+    if args_to_update:
+        a.update(args_to_update)
+    a['pipeline'] = 'READ.pipelines.ogl.TexturePipeline'
+    args = SimpleNamespace(**a)
+    pipeline = TexturePipeline()
+    pipeline.create(args)
+    load_model_checkpoint(checkpoint, pipeline.get_net())
+    return pipeline, args
+
+
+def save_pipeline(pipeline, save_dir, epoch, stage, args):
+    """READ/pipelines/pipeline.py:59-71: one .pth per state object."""
+    for name, obj in pipeline.state_objects().items():
+        filename = f'{obj.__class__.__name__}_stage_{stage}_epoch_{epoch}'
+        if name:
+            filename = f"{filename}_{name.replace('/', '_')}"
+        save_model(os.path.join(save_dir, filename + '.pth'), obj, args=args)

@@ -1,0 +1,148 @@
+"""CPU: the C-ABI library loads without a GPU, exports every symbol include/read_hip.h declares,
+rejects bad arguments with READ_EINVAL + a message, and its host-side packers produce the layout the
+kernels index.  No compute call is made."""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+import pytest
+
+from read_amd import _lib
+from read_amd.gated_conv import kc_for
+from tests.unet_spec import UNET_SPEC
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _declared_symbols():
+    txt = open(os.path.join(ROOT, "include", "read_hip.h")).read()
+    txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
+    return sorted(set(re.findall(r"\b(read_[a-z0-9_]+)\s*\(", txt)))
+
+
+def test_library_exports_every_declared_symbol():
+    L = C.CDLL(_lib.LIB_PATH)
+    names = _declared_symbols()
+    assert len(names) >= 30
+    for n in names:
+        assert hasattr(L, n), f"{n} declared in read_hip.h but not exported"
+    assert set(names) == set(_lib.SIGNATURES), set(names) ^ set(_lib.SIGNATURES)
+    assert _lib.lib().read_abi_version() == 1
+
+
+def test_layer_table_matches_independent_spec():
+    from read_amd.unet import layer_table, weight_spec
+    assert weight_spec() == UNET_SPEC
+    strides = {p: s for (p, _, _, _, s, _) in layer_table()}
+    assert [p for p, s in strides.items() if s == 2] == ["feat_extract.1", "feat_extract.2", "feat_extract.3",
+                                                         "feat_extract.4", "feat_extract.6", "feat_extract.7"]
+    no_elu = {p for (p, _, _, _, _, e) in layer_table() if not e}
+    assert "feat_extract.5" in no_elu and "Encoder.0.layers.0.main.1" in no_elu and "SCM0.conv" in no_elu
+    assert "Encoder.0.layers.0.main.0" not in no_elu
+
+
+def test_bad_arguments_fail_loudly():
+    L = _lib.lib()
+    assert L.read_splat_workspace_bytes(1, 1216, 352) == 8 * 1216 * 352 * 8
+    assert L.read_splat_workspace_bytes(0, 10, 10) == 0
+    rc = L.read_splat_forward(None, 10, None, 1, 64, 64, 5, None, None, None, 0, None)
+    assert rc == -22 and b"xyz" in L.read_last_error()
+    rc = L.read_gather_forward(None, 0, 8, 1, None, None, None, 0, None)
+    assert rc == -22
+    assert L.read_unet_workspace_bytes(100, 100) == 0                  # not a multiple of 16
+    with pytest.raises(_lib.ReadHipError):
+        _lib.check(L.read_bilinear_up4(None, 4, 4, 8, None, None), "up4")
+    d = _lib.ConvDesc()
+    assert L.read_gated_conv_forward(C.byref(d), None) == -22
+
+
+def test_weight_packing_layout():
+    """wpacked[(((chunk*taps+tap)*KK+kk)*NT+nt)*256 + lane*4 + j] = W{f|m}[cout][cin][tap] with
+    cout = (nt//2)*32 + lane%32, cin = chunk*kc + kk*8 + 4*(lane//32) + j  (conv.hip header)."""
+    L = _lib.lib()
+    rng = np.random.default_rng(0)
+    for (cin, cout, k, kc) in [(32, 32, 3, 16), (24, 40, 3, 8), (64, 56, 1, 8), (48, 3, 4, 16)]:
+        wf = rng.standard_normal((cout, cin, k, k)).astype(np.float32)
+        wm = rng.standard_normal((cout, cin, k, k)).astype(np.float32)
+        n = L.read_conv_packed_floats(cin, cout, k)
+        cp = (cout + 31) // 32 * 32
+        assert n == cin * k * k * 2 * cp
+        out = np.full(n, np.nan, np.float32)
+        _lib.check(L.read_conv_pack_weights_host(cin, cout, k, kc, wf.ctypes.data, wm.ctypes.data, out.ctypes.data))
+        NT, KK, taps = cp // 16, kc // 8, k * k
+        o = out.reshape(cin // kc, taps, KK, NT, 64, 4)
+        for _ in range(200):
+            ch, tap, kk, nt, lane, j = (rng.integers(0, s) for s in o.shape)
+            co, ci = (nt // 2) * 32 + lane % 32, ch * kc + kk * 8 + 4 * (lane // 32) + j
+            w = wm if nt % 2 else wf
+            want = w[co, ci, tap // k, tap % k] if co < cout else 0.0
+            assert o[ch, tap, kk, nt, lane, j] == want
+        assert L.read_conv_pack_weights_host(cin, cout, k, 16 if cin % 16 else 8 if cin % 8 else 16, None, None, None) == -22
+
+
+def test_param_packing_folds_batchnorm():
+    L = _lib.lib()
+    rng = np.random.default_rng(1)
+    cout = 40
+    bf, bm, g, b, m = (rng.standard_normal(cout).astype(np.float32) for _ in range(5))
+    v = rng.uniform(0.5, 1.5, cout).astype(np.float32)
+    out = np.empty(L.read_conv_param_floats(cout), np.float32)
+    _lib.check(L.read_conv_pack_params_host(cout, bf.ctypes.data, bm.ctypes.data, g.ctypes.data, b.ctypes.data,
+                                            m.ctypes.data, v.ctypes.data, 1e-5, out.ctypes.data))
+    o = out.reshape(4, 64)
+    scale = g / np.sqrt(v + np.float32(1e-5))
+    np.testing.assert_allclose(o[0, :cout], bf)
+    np.testing.assert_allclose(o[1, :cout], bm)
+    np.testing.assert_allclose(o[2, :cout], scale, rtol=1e-6)
+    np.testing.assert_allclose(o[3, :cout], b - m * scale, rtol=1e-5, atol=1e-6)
+    assert not o[:, cout:].any()
+
+
+def test_unet_blob_sizes_and_plan_flops():
+    """The launch plan can be built without a GPU (create only records pointers): 99 convs + 3
+    upsamples, algorithmic FLOPs as measured on the reference module."""
+    L = _lib.lib()
+    raw = sum(2 * (co * ci * k * k + co) + 4 * co for (_, ci, co, k) in UNET_SPEC)
+    assert L.read_unet_raw_floats() == raw
+    for (H, W, gflop) in [(352, 1216, 1221.73), (256, 256, 187.06)]:
+        need = L.read_unet_workspace_bytes(H, W)
+        ws = np.empty(need + 256, np.uint8)
+        base = (ws.ctypes.data + 255) // 256 * 256
+        pk = np.empty(64, np.float32)
+        h = C.c_void_p()
+        _lib.check(L.read_unet_create(C.byref(h), (pk.ctypes.data + 15) // 16 * 16, H, W, base, need))
+        n = L.read_unet_launch_count(h)
+        assert n == 102
+        tot = 0.0
+        for i in range(n):
+            fl = C.c_double()
+            L.read_unet_launch_info(h, i, C.byref(fl), None, None, None, None, None)
+            tot += fl.value
+        assert abs(tot / 1e9 - gflop) < 0.01
+        L.read_unet_destroy(h)
+    assert kc_for([8, 56]) == 8 and kc_for([32, 64, 128, 256]) == 16
+
+
+def test_product_path_refuses_to_run_without_gpu():
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    from read_amd.raster import PointCloudRasterizer
+    with pytest.raises(_lib.ReadHipError):
+        PointCloudRasterizer(np.zeros((4, 3), np.float32))
+    from read_amd.unet import UNet
+    net = UNet().eval()
+    with pytest.raises(_lib.ReadHipError), torch.no_grad():
+        net(*[torch.zeros(1, 8, 16 >> l, 16 >> l) for l in range(4)])
+    with pytest.raises(NotImplementedError):                      # training through the HIP UNet: not built
+        net.train()(*[torch.zeros(1, 8, 16 >> l, 16 >> l) for l in range(4)])
+
+
+def test_no_oracle_import_in_product():
+    """read_amd/ must never import oracle/ (the checker is not the product)."""
+    for dirpath, _, files in os.walk(os.path.join(ROOT, "read_amd")):
+        for f in files:
+            if f.endswith((".py", ".hip", ".cpp", ".h")):
+                src = open(os.path.join(dirpath, f)).read()
+                assert not re.search(r"^\s*(from|import)\s+oracle\b", src, flags=re.M), f

@@ -1,0 +1,99 @@
+"""CPU: host-side mirrors of the reference interface (no GPU work): camera conventions, module tree /
+state-dict names, input-format parsing, checkpoint round trip, NetAndTexture bookkeeping."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from read_amd import camera, synthetic
+from read_amd.net_texture import NetAndTexture
+from read_amd.pipeline import TexturePipeline, load_model_checkpoint, save_model
+from read_amd.render import Scene, parse_input_string
+from read_amd.texture import PointTexture
+from read_amd.unet import UNet, pack_state, raw_blob_from_state
+from tests.unet_spec import UNET_SPEC
+
+
+def test_proj_matrix_golden(golden_dir):
+    g = np.load(os.path.join(golden_dir, "proj_1216x352.npz"))
+    P = camera.get_proj_matrix(g["K"], (1216, 352), float(g["znear"]), float(g["zfar"]))
+    assert np.array_equal(P, g["P"])
+    # clip-space convention: a point straight ahead (-z) lands in the image centre, depth in (0,1)
+    M = camera.total_matrix(P.astype(np.float32), np.eye(4, dtype=np.float32))[0]
+    c = M @ np.array([0, 0, -10, 1], np.float32)
+    assert abs(c[0] / c[3]) < 1e-6 and abs(c[1] / c[3]) < 1e-6 and -1 < c[2] / c[3] < 1
+
+
+def test_level_sizes():
+    assert camera.level_sizes(1216, 352) == [(1216, 352), (608, 176), (304, 88), (152, 44), (76, 22)]
+    assert camera.level_sizes(250, 130, 3) == [(250, 130), (125, 65), (62, 32)]
+
+
+def test_unet_state_dict_names_and_blob():
+    net = UNet()
+    sd = net.state_dict()
+    assert len(sd) == 909
+    for (path, cin, cout, k) in UNET_SPEC:
+        assert tuple(sd[f"{path}.block.conv_f.weight"].shape) == (cout, cin, k, k)
+        assert tuple(sd[f"{path}.block.norm.running_var"].shape) == (cout,)
+    assert sum(p.numel() for p in net.parameters()) == 30_193_988
+    state = synthetic.make_unet_state(UNET_SPEC, 3)
+    net.load_state_dict({k: torch.from_numpy(np.asarray(v)) for k, v in state.items()})
+    assert np.array_equal(raw_blob_from_state(net.state_dict()), raw_blob_from_state(state))
+    packed = pack_state(state)
+    assert packed.dtype == np.float32 and np.isfinite(packed).all()
+    with pytest.raises(ValueError):
+        UNet(num_input_channels=3)
+
+
+def test_input_format_tokens():
+    assert parse_input_string("uv_1d_p1") == {'mode': 'uv_1d', 'point_size': 1, 'splat_mode': False}
+    assert parse_input_string("uv_1d_p1_ds3")['downscale'] == 3
+    for bad in ("colors_p1", "uv_1d_ps4", "uv_2d"):
+        with pytest.raises(NotImplementedError):
+            parse_input_string(bad)
+
+
+def test_scene_total_matrix_matches_myrender_formula():
+    s = Scene(synthetic.make_cloud(10))
+    proj, pose = synthetic.make_proj(64, 48, f=40.0), synthetic.sweep_pose(5)
+    s.set_proj_matrix(proj)
+    s.set_camera_view(pose)
+    np.testing.assert_allclose(s.total_matrix()[0], camera.total_matrix(proj, pose)[0], rtol=1e-6, atol=1e-6)
+
+
+def test_checkpoint_roundtrip(tmp_path):
+    t = PointTexture(8, 100, init_method='rand')
+    p = tmp_path / "PointTexture_x.pth"
+    save_model(str(p), t, args={'descriptor_size': 8})
+    ck = torch.load(p, weights_only=False)
+    assert set(ck) == {'state_dict', 'args'} and list(ck['state_dict']) == ['texture_']
+    assert tuple(ck['state_dict']['texture_'].shape) == (1, 8, 100)
+    t2 = load_model_checkpoint(str(p), PointTexture(8, 100))
+    assert torch.equal(t2.texture_, t.texture_)
+
+
+def test_pipeline_inference_create_and_netandtexture_bookkeeping():
+    pl = TexturePipeline()
+    pl.create({'inference': True, 'n_points': 64, 'descriptor_size': 8, 'texture_activation': 'none',
+               'texture_ckpt': None, 'use_mesh': False})
+    for attr in ('model', 'net', 'textures', 'args'):
+        assert hasattr(pl, attr)
+    assert isinstance(pl.model, NetAndTexture) and pl.get_net() is pl.net
+    m = pl.model
+    assert '0' not in m._modules
+    m.load_textures(0)
+    assert m._modules['0'] is pl.textures[0]
+    assert any(k == '0.texture_' for k in m.state_dict())
+    m.unload_textures()
+    assert '0' not in m._modules
+    # the reference's dotted path resolves through the alias package
+    from READ.pipelines.ogl import TexturePipeline as Alias
+    assert Alias is TexturePipeline
+    import pcpr
+    assert callable(pcpr.forward)
+    with pytest.raises(RuntimeError):
+        pcpr.forward(torch.zeros(4, 3), torch.zeros(4, 4), 8, 8, 512)     # "batch_size check": total_m must be 3-D
+    with pytest.raises(RuntimeError):
+        pcpr.forward(torch.zeros(4, 3, dtype=torch.float64), torch.zeros(1, 4, 4), 8, 8, 512)

@@ -1,0 +1,118 @@
+"""CPU: the rasteriser oracle against (a) the committed golden vectors, which are the output of the
+reference's own DepthProject source run serially (tests/golden/make_golden.py), (b) an independent
+NumPy restatement, (c) the live reference-source build when it is present (oracle/_ref)."""
+import os
+
+import numpy as np
+import pytest
+
+import oracle
+from oracle import ref_c
+from oracle.raster_np import raster_level_np
+from read_amd import camera, synthetic
+
+
+def _bits(a):
+    return np.ascontiguousarray(a).view(np.uint32)
+
+
+def test_golden_config0(golden_dir):
+    g = np.load(os.path.join(golden_dir, "raster_256_100k.npz"))
+    xyz = synthetic.make_cloud(int(g["N"]), int(g["seed"]))
+    for b in range(g["M"].shape[0]):
+        idx, dep = oracle.raster_multiscale(xyz, g["M"][b], 256, 256, 5)
+        for l in range(5):
+            assert np.array_equal(idx[l], g[f"index{l}"][b])
+            assert np.array_equal(_bits(dep[l]), _bits(g[f"depth{l}"][b]))
+
+
+def test_golden_matrix_is_reproducible(golden_dir):
+    """total_m itself is an input; the recipe must regenerate the stored one."""
+    g = np.load(os.path.join(golden_dir, "raster_256_100k.npz"))
+    Ms = camera.total_matrix(synthetic.make_proj(256, 256, f=256.0),
+                             np.stack([np.eye(4, dtype=np.float32), synthetic.sweep_pose(40)]))
+    assert np.array_equal(Ms, g["M"])
+
+
+@pytest.mark.parametrize("W,H,N,f", [(256, 256, 100_000, 256.0), (1216, 352, 400_000, 720.0), (77, 33, 9_000, 60.0)])
+def test_c_equals_numpy_and_threads(W, H, N, f):
+    xyz = synthetic.make_cloud(N, seed=11)
+    M = camera.total_matrix(synthetic.make_proj(W, H, f=f), synthetic.sweep_pose(7))[0]
+    ci, cd = oracle.raster_level(xyz, M, W, H)
+    ni, nd = raster_level_np(xyz, M, W, H)
+    assert np.array_equal(ci, ni) and np.array_equal(_bits(cd), _bits(nd))
+    ti, td = oracle.raster_level(xyz, M, W, H, threads=4)
+    assert np.array_equal(ci, ti) and np.array_equal(_bits(cd), _bits(td))
+
+
+@pytest.mark.skipif(not ref_c.available(), reason="oracle/_ref not built (needs /root/reference)")
+def test_oracle_equals_reference_source_run_serially():
+    """The pin: the reference's own kernel text, compiled for the CPU, one emulated thread per point."""
+    for (W, H, N, f) in [(256, 256, 100_000, 256.0), (1216, 352, 300_000, 720.0), (40, 24, 3_000, 30.0)]:
+        xyz = synthetic.make_cloud(N, seed=3)
+        Ms = camera.total_matrix(synthetic.make_proj(W, H, f=f), np.stack([synthetic.sweep_pose(k) for k in (0, 21)]))
+        ri, rd = ref_c.pcpr_ref_forward(xyz, Ms, W, H)
+        for b in range(2):
+            oi, od = oracle.raster_level(xyz, Ms[b], W, H)
+            assert not (od[oi > 0] == 0).any()                      # no d == 0 points (documented departure)
+            assert np.array_equal(oracle.index_to_float(oi), ri[b])
+            assert np.array_equal(_bits(od), _bits(rd[b]))
+
+
+def test_pyramid_identity():
+    """level l == 2x2 key-min of level l-1 when W,H are multiples of 16."""
+    W, H = 304, 176
+    xyz = synthetic.make_cloud(250_000, seed=5)
+    M = camera.total_matrix(synthetic.make_proj(W, H, f=200.0), np.eye(4, dtype=np.float32))[0]
+    idx, dep = oracle.raster_multiscale(xyz, M, W, H, 5)
+
+    def keys(i, d):
+        k = (_bits(d).astype(np.uint64) << np.uint64(32)) | i.astype(np.uint32).astype(np.uint64)
+        k[(i == 0) & (d == 0)] = np.uint64(0xFFFFFFFFFFFFFFFF)
+        return k
+    k = keys(idx[0], dep[0])
+    for l in range(1, 5):
+        h, w = k.shape
+        k = k.reshape(h // 2, 2, w // 2, 2).min(axis=(1, 3))
+        assert np.array_equal(k, keys(idx[l], dep[l]))
+
+
+def test_edge_cases():
+    W, H = 64, 32
+    M = camera.total_matrix(synthetic.make_proj(W, H, f=64.0), np.eye(4, dtype=np.float32))[0]
+    # empty cloud
+    i, d = oracle.raster_level(np.zeros((0, 3), np.float32), M, W, H)
+    assert not i.any() and not d.any()
+    # behind the camera / outside the frustum: nothing lands
+    pts = np.array([[0, 0, 5], [1000, 0, -1], [0, 0, -0.01], [0, 0, -5000]], np.float32)
+    i, d = oracle.raster_level(pts, M, W, H)
+    assert not i.any() and not d.any()
+    # exact ties -> smallest index; nearer point wins regardless of order
+    pts = np.array([[0.3, 0.2, -9], [0, 0, -10], [0, 0, -10], [0, 0, -4], [0, 0, -10]], np.float32)
+    i, d = oracle.raster_level(pts, M, W, H)
+    assert i[H // 2, W // 2] == 3
+    i, d = oracle.raster_level(pts[[0, 1, 2, 4]], M, W, H)
+    assert i[H // 2, W // 2] == 1
+    # w == 0 (NaN/inf NDC) is rejected, not UB
+    i, d = oracle.raster_level(np.array([[0, 0, 0]], np.float32), M, W, H)
+    assert not i.any()
+
+
+def test_float_index_rounding():
+    idx = np.array([0, 1, (1 << 24) - 1, (1 << 24) + 1, 29_999_999], np.int32)
+    assert np.array_equal(oracle.index_to_float(idx), idx.astype(np.float32))
+    assert oracle.index_to_float(idx)[3] == float(1 << 24)           # ids >= 2^24 round (point_render.cu:158)
+
+
+def test_gather_and_backward_oracle():
+    rng = np.random.default_rng(0)
+    tex = rng.random((8, 500), dtype=np.float32)
+    idx = rng.integers(0, 500, (12, 20)).astype(np.int32)
+    out = oracle.gather_chw(tex, idx)
+    assert np.array_equal(out, tex[:, idx])
+    g = rng.standard_normal((8, 12, 20)).astype(np.float32)
+    gt = oracle.gather_backward_chw(g, idx, 500)
+    ref = np.zeros((8, 500), np.float32)
+    for c in range(8):
+        np.add.at(ref[c], idx.reshape(-1), g[c].reshape(-1))
+    np.testing.assert_allclose(gt, ref, rtol=1e-6, atol=1e-6)

@@ -1,0 +1,29 @@
+#!/usr/bin/env bash
+# One GPU-box visit: parity tests, A/B tools, bench, rocprofv3 kernel stats and PMC passes.
+# Usage (from the repo root on the GPU box):  bash tools/gpu_round.sh <tag> [steps...]
+# Every step is wrapped in its own timeout and logs under gpurun_out/<tag>_*.
+set -u
+TAG=${1:-rX}; shift || true
+STEPS=${*:-"pytest splat sweep bench prof pmc"}
+R=${GRAFT_REPO_ROOT:-$(pwd)}
+O=$R/gpurun_out
+mkdir -p "$O"
+export TMPDIR=/tmp
+run() { local name=$1 t=$2; shift 2; ( cd "$R" && timeout "$t" "$@" ) > "$O/${TAG}_${name}.log" 2>&1; echo "rc=$?" >> "$O/${TAG}_${name}.log"; tail -n 4 "$O/${TAG}_${name}.log"; }
+for s in $STEPS; do
+  case $s in
+    pytest) run pytest 900 python -m pytest tests -m gpu -q --timeout 600 -p no:cacheprovider -s ;;
+    splat)  run splat 300 python tools/splat_modes.py --out "$O/${TAG}_splat_modes.json" ;;
+    sweep)  run sweep 400 python tools/sweep_conv.py --out "$O/${TAG}_sweep.json" ;;
+    bench)  run bench 500 python bench.py --steps 20 --warmup 3 --detail "$O/${TAG}_detail.json" ;;
+    prof)   ( cd /tmp && timeout 400 rocprofv3 --kernel-trace --stats -d "$O/${TAG}_prof" -o bench -- python "$R/bench.py" --steps 5 --warmup 2 --no-cpu-baseline ) > "$O/${TAG}_prof.log" 2>&1; echo "rc=$?" >> "$O/${TAG}_prof.log"; tail -n 3 "$O/${TAG}_prof.log"
+            find "$O/${TAG}_prof" -name "*kernel_stats*" | head -3 ;;
+    pmc)    ( cd /tmp && timeout 120 rocprofv3 -L > "$O/${TAG}_counters.txt" 2>&1 )
+            ( cd /tmp && timeout 300 rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_WAVES -d "$O/${TAG}_pmc_mfma" -o conv -- python "$R/tools/sweep_conv.py" --main-only --iters 2 --out "$O/${TAG}_pmc_sweep.json" ) > "$O/${TAG}_pmc_mfma.log" 2>&1; echo "rc=$?" >> "$O/${TAG}_pmc_mfma.log"; tail -n 2 "$O/${TAG}_pmc_mfma.log"
+            ( cd /tmp && timeout 300 rocprofv3 --kernel-trace --pmc FETCH_SIZE -d "$O/${TAG}_pmc_fetch" -o splat -- python "$R/tools/splat_modes.py" --out "$O/${TAG}_pmc_splat.json" ) > "$O/${TAG}_pmc_fetch.log" 2>&1; echo "rc=$?" >> "$O/${TAG}_pmc_fetch.log"
+            ( cd /tmp && timeout 300 rocprofv3 --kernel-trace --pmc WRITE_SIZE -d "$O/${TAG}_pmc_write" -o splat -- python "$R/tools/splat_modes.py" --out "$O/${TAG}_pmc_splat.json" ) > "$O/${TAG}_pmc_write.log" 2>&1; echo "rc=$?" >> "$O/${TAG}_pmc_write.log" ;;
+  esac
+done
+# keep the merge-back small: drop raw traces, keep csv summaries
+find "$O" -name "*.db" -size +20M -delete 2>/dev/null
+du -sh "$O" | tail -1

@@ -1,0 +1,64 @@
+"""A/B the rasteriser's key-image policies on the GPU box (read_tuning_set("splat_mode", m)).
+
+    python tools/splat_modes.py [--points 30000000] [--out gpurun_out/splat_modes.json]
+"""
+import argparse
+import json
+import os
+import sys
+
+import numpy as np
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from read_amd import _lib, camera, synthetic          # noqa: E402
+from read_amd.raster import PointCloudRasterizer      # noqa: E402
+
+NAMES = {0: "per-XCD images, L2-local atomics", 1: "one image, agent atomics, sc1 early-z",
+         3: "one image, agent atomics, system-scope early-z", 2: "projection only (floor, invalid results)"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--points", type=int, default=30_000_000)
+    ap.add_argument("--out", default="gpurun_out/splat_modes.json")
+    a = ap.parse_args()
+    W, H = 1216, 352
+    xyz = synthetic.make_cloud(a.points)
+    M = camera.total_matrix(synthetic.make_proj(W, H), synthetic.sweep_pose(0))
+    r = PointCloudRasterizer(xyz)
+    L = _lib.lib()
+    ref = None
+    res = []
+    bytes_algo = 12.0 * a.points + 8.0 * sum(w * h for (w, h) in camera.level_sizes(W, H, 5))
+    for mode in (0, 1, 3, 2, 0):
+        _lib.check(L.read_tuning_set(b"splat_mode", mode))
+        for _ in range(3):
+            idx, dep = r.render(M, W, H, 5)
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(10):
+            idx, dep = r.render(M, W, H, 5)
+        e1.record()
+        e1.synchronize()
+        ms = e0.elapsed_time(e1) / 10
+        same = None
+        if mode != 2:
+            cur = [i.clone() for i in idx] + [d.clone() for d in dep]
+            if ref is None:
+                ref = cur
+            same = all(torch.equal(x, y) for x, y in zip(ref, cur))
+        row = {"mode": mode, "name": NAMES[mode], "ms": ms, "GBps": bytes_algo / ms / 1e6,
+               "frac_hbm_8TBs": bytes_algo / ms / 1e6 / 8000.0, "identical_to_mode0": same}
+        print(row, flush=True)
+        res.append(row)
+        # the workspace may hold garbage after the projection-only mode: re-initialise
+        _lib.check(L.read_splat_workspace_init(r._ws.data_ptr(), r._ws.numel(), _lib.stream_ptr()))
+    _lib.check(L.read_tuning_set(b"splat_mode", 0))
+    os.makedirs(os.path.dirname(os.path.abspath(a.out)), exist_ok=True)
+    json.dump(res, open(a.out, "w"), indent=1)
+
+
+if __name__ == "__main__":
+    main()

@@ -40,10 +40,12 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--out", default="gpurun_out/sweep_conv.json")
     ap.add_argument("--iters", type=int, default=5)
+    ap.add_argument("--main-only", action="store_true", help="only the four dominant 3x3 shapes, automatic config")
     a = ap.parse_args()
     names = config_names()
     res = []
-    for (label, srcs, cout, k, s, oh, ow) in SHAPES:
+    shapes = SHAPES[:4] if a.main_only else SHAPES
+    for (label, srcs, cout, k, s, oh, ow) in shapes:
         cin = sum(c for c, _ in srcs)
         kc = 8 if any(c % 16 for c, _ in srcs) else 16
         st = synthetic.make_unet_state([("L", cin, cout, k)], 1)
@@ -60,7 +62,13 @@ def main():
         out = torch.empty(oh, ow, cout, device="cuda")
         groups = (cout + 31) // 32
         flops = 4.0 * oh * ow * cout * cin * k * k
-        for ci, name in enumerate(names):
+        cand = [(-1, "auto")] if a.main_only else list(enumerate(names))
+        for ci, name in cand:
+            if ci < 0:
+                for _ in range(a.iters + 2):
+                    gated_conv(pk, xs, stride=s, elu=True, config=-1, out=out)
+                torch.cuda.synchronize()
+                continue
             m = re.match(r"k(\d)s(\d)c(\d+)_p(\d)q(\d)m(\d)n(\d)", name)
             ks, ss, kcc, P, QG, WM, WN = (int(g) for g in m.groups())
             if (ks, ss, kcc) != (k, s, kc) or groups % (WN * QG):
