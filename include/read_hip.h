@@ -52,9 +52,9 @@ int read_abi_version(void);
 /* Fills name[0..len) with the gfx arch of the current device ("gfx950"); READ_EHIP without a GPU. */
 int read_device_arch(char *name, int len);
 
-/* Measurement knobs (A/B runs on the GPU box).  "splat_mode": 0 per-XCD key images with L2-local
- * atomics (default), 1 one image with agent-scope atomics, 2 projection only (timing floor, invalid
- * results). */
+/* Measurement knobs (A/B runs on the GPU box).  "splat_mode": 1 (default) one key image with
+ * agent-scope atomics and L1-bypassing early-z reads, 0 per-XCD key images, 3 system-scope early-z;
+ * 2/4/5/6 are attribution probes whose results are invalid (see csrc/splat.hip). */
 int read_tuning_set(const char *key, int value);
 
 /* ---------------------------------------------------------------- rasteriser (z-buffer splat) */

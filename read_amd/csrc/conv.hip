@@ -77,13 +77,13 @@ struct Tile {
     static constexpr int PAD = (KS - 1) / 2;          // int(dilation*(k-1)/2), unet.py:30
 };
 
-template <int KS, int S, int KC, int P, int QG, int WM, int WN, bool MUL, int PF>
+template <int KS, int S, int KC, int P, int QG, int WM, int WN, bool MUL, int PF, int NBUF>
 __global__ __launch_bounds__(256) void gated_conv_kernel(const ConvKArgs a)
 {
     using TL = Tile<KS, S, KC, P, QG, WM, WN>;
     static_assert(WM * WN * TL::WK == 4 && (KS * KS) % TL::WK == 0, "4 waves per workgroup; taps split evenly");
-    static_assert(TL::WK == 1 || 4 * P * TL::T * 16 * 64 <= 2 * TL::BUF, "split-K reduction must fit the LDS tile");
-    __shared__ __attribute__((aligned(16))) float lds[2 * TL::BUF];
+    static_assert(TL::WK == 1 || 4 * P * TL::T * 16 * 64 <= NBUF * TL::BUF, "split-K reduction must fit the LDS tile");
+    __shared__ __attribute__((aligned(16))) float lds[NBUF * TL::BUF];
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -179,42 +179,58 @@ __global__ __launch_bounds__(256) void gated_conv_kernel(const ConvKArgs a)
     for (int chunk = 0; chunk < a.nchunks; ++chunk) {
         const bool more = chunk + 1 < a.nchunks;
         if (more) gload(chunk + 1);
-        const float *buf = lds + (chunk & 1) * TL::BUF;
+        const float *buf = lds + (NBUF == 2 ? (chunk & 1) * TL::BUF : 0);
         const int step0 = chunk * SPC;
+        // A fragments are read one k-step ahead of their MFMAs (LDS latency off the critical path)
+        auto aread = [&](int ls, float4(&dst)[P]) {
+            const int tap = wk * TL::TPW + ls / TL::KK;   // wk == 0 whenever TPW == KS*KS: a constant then
+            const int ky = tap / KS, kx = tap % KS, kk = ls % TL::KK;
 #pragma unroll
-        for (int ltap = 0; ltap < TL::TPW; ++ltap) {
-            const int tap = wk * TL::TPW + ltap;      // wk == 0 whenever TPW == KS*KS, so this stays a constant
-            const int ky = tap / KS, kx = tap % KS;
+            for (int p = 0; p < P; ++p)
+                dst[p] = *reinterpret_cast<const float4 *>(buf + abase + ((p * S + ky) * TL::IW + kx) * TL::PS + kk * 8);
+        };
+        float4 acur[P], anext[P];
+        aread(0, acur);
 #pragma unroll
-            for (int kk = 0; kk < TL::KK; ++kk) {
-                float4 b[TL::T];
+        for (int ls = 0; ls < SPC; ++ls) {
+            float4 b[TL::T];
 #pragma unroll
-                for (int t = 0; t < TL::T; ++t) b[t] = bq[0][t];
+            for (int t = 0; t < TL::T; ++t) b[t] = bq[0][t];
 #pragma unroll
-                for (int d = 0; d + 1 < PF; ++d)
+            for (int d = 0; d + 1 < PF; ++d)
 #pragma unroll
-                    for (int t = 0; t < TL::T; ++t) bq[d][t] = bq[d + 1][t];
-                const int nstep = gstep(step0 + ltap * TL::KK + kk + PF);
+                for (int t = 0; t < TL::T; ++t) bq[d][t] = bq[d + 1][t];
+            // issue the prefetches of later steps FIRST and pin them there: left alone, hipcc sinks
+            // these loads to one MFMA before their first use and every k-step then waits out a full
+            // L2 round trip (seen in the ISA of the first version; MFMA busy 60 %).
+            const int nstep = gstep(step0 + ls + PF);
 #pragma unroll
-                for (int t = 0; t < TL::T; ++t) bq[PF - 1][t] = wl[((size_t)nstep * NT + t) * 64];
-                float4 av[P];
+            for (int t = 0; t < TL::T; ++t) bq[PF - 1][t] = wl[((size_t)nstep * NT + t) * 64];
+            if (ls + 1 < SPC) aread(ls + 1, anext);
+            __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-                for (int p = 0; p < P; ++p)
-                    av[p] = *reinterpret_cast<const float4 *>(
-                        buf + abase + ((p * S + ky) * TL::IW + kx) * TL::PS + kk * 8);
+            for (int p = 0; p < P; ++p)
 #pragma unroll
-                for (int p = 0; p < P; ++p)
+                for (int t = 0; t < TL::T; ++t) {
+                    acc[p][t] = __builtin_amdgcn_mfma_f32_32x32x2f32(acur[p].x, b[t].x, acc[p][t], 0, 0, 0);
+                    acc[p][t] = __builtin_amdgcn_mfma_f32_32x32x2f32(acur[p].y, b[t].y, acc[p][t], 0, 0, 0);
+                    acc[p][t] = __builtin_amdgcn_mfma_f32_32x32x2f32(acur[p].z, b[t].z, acc[p][t], 0, 0, 0);
+                    acc[p][t] = __builtin_amdgcn_mfma_f32_32x32x2f32(acur[p].w, b[t].w, acc[p][t], 0, 0, 0);
+                }
+            __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-                    for (int t = 0; t < TL::T; ++t) {
-                        acc[p][t] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[p].x, b[t].x, acc[p][t], 0, 0, 0);
-                        acc[p][t] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[p].y, b[t].y, acc[p][t], 0, 0, 0);
-                        acc[p][t] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[p].z, b[t].z, acc[p][t], 0, 0, 0);
-                        acc[p][t] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[p].w, b[t].w, acc[p][t], 0, 0, 0);
-                    }
+            for (int p = 0; p < P; ++p) acur[p] = anext[p];
+        }
+        if (NBUF == 2) {
+            if (more) lwrite(lds + ((chunk + 1) & 1) * TL::BUF);
+            __syncthreads();
+        } else {
+            __syncthreads();                      // everyone is done reading the single buffer
+            if (more) {
+                lwrite(lds);
+                __syncthreads();
             }
         }
-        if (more) lwrite(lds + ((chunk + 1) & 1) * TL::BUF);
-        __syncthreads();
     }
 
     // ---------------- split-K: the WK waves of a tile exchange partial sums through LDS; wave wk then
@@ -291,13 +307,14 @@ struct ConvConfig {
     conv_fn fn_mul;      // variant whose loader multiplies by a second tensor (FAM), or null
 };
 
-#define CFG(KS, S, KC, P, QG, WM, WN, PF)                                                      \
-    {"k" #KS "s" #S "c" #KC "_p" #P "q" #QG "m" #WM "n" #WN "f" #PF, KS, S, KC, P, QG, WM, WN, PF, \
-     gated_conv_kernel<KS, S, KC, P, QG, WM, WN, false, PF>, nullptr}
-#define CFGM(KS, S, KC, P, QG, WM, WN, PF)                                                     \
-    {"k" #KS "s" #S "c" #KC "_p" #P "q" #QG "m" #WM "n" #WN "f" #PF, KS, S, KC, P, QG, WM, WN, PF, \
-     gated_conv_kernel<KS, S, KC, P, QG, WM, WN, false, PF>,                                   \
-     gated_conv_kernel<KS, S, KC, P, QG, WM, WN, true, PF>}
+#define CFGN(KS, S, KC, P, QG, WM, WN, PF, NB)                                                        \
+    {"k" #KS "s" #S "c" #KC "_p" #P "q" #QG "m" #WM "n" #WN "f" #PF "b" #NB, KS, S, KC, P, QG, WM, WN, PF, \
+     gated_conv_kernel<KS, S, KC, P, QG, WM, WN, false, PF, NB>, nullptr}
+#define CFG(KS, S, KC, P, QG, WM, WN, PF) CFGN(KS, S, KC, P, QG, WM, WN, PF, 2)
+#define CFGM(KS, S, KC, P, QG, WM, WN, PF)                                                           \
+    {"k" #KS "s" #S "c" #KC "_p" #P "q" #QG "m" #WM "n" #WN "f" #PF "b2", KS, S, KC, P, QG, WM, WN, PF, \
+     gated_conv_kernel<KS, S, KC, P, QG, WM, WN, false, PF, 2>,                                     \
+     gated_conv_kernel<KS, S, KC, P, QG, WM, WN, true, PF, 2>}
 
 // Order matters: pick_config() takes the first entry whose (ksize, stride, chunk) match and whose
 // channel-group coverage divides the layer's groups; remaining groups go to grid.y.  The order below
@@ -314,6 +331,9 @@ const ConvConfig g_configs[] = {
     CFGM(3, 1, 16, 2, 1, 4, 1, 2),  //  6  as 0, B prefetch depth 2
     CFGM(3, 1, 16, 1, 1, 4, 1, 2),  //  7  as 1, depth 2
     CFGM(3, 1, 16, 2, 1, 2, 2, 2),  //  8  as 2, depth 2
+    CFGN(3, 1, 16, 2, 1, 4, 1, 2, 1),  // single LDS buffer (3 workgroups per CU), depth 2
+    CFGN(3, 1, 16, 1, 1, 4, 1, 2, 1),
+    CFGN(3, 1, 16, 2, 1, 2, 2, 2, 1),
     // 3x3 stride 1, 8-channel chunks (inputs straight from the 8-channel pyramid)
     CFG(3, 1, 8, 2, 1, 4, 1, 1),    //  9
     CFG(3, 1, 8, 1, 1, 4, 1, 1),    // 10

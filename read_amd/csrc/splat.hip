@@ -54,18 +54,20 @@ __device__ __forceinline__ int project_one(float x, float y, float z, const floa
 }
 
 // Key-image update policies (read_tuning_set("splat_mode", m)):
-//   MODE_XCD   (default) one private key image per XCD.  Workgroups read HW_REG_XCC_ID and fold into
+//   MODE_XCD   one private key image per XCD.  Workgroups read HW_REG_XCC_ID and fold into
 //              "their" image with WORKGROUP-scope atomics, which execute in that XCD's L2 and never
 //              cross the fabric; the 3.4 MB image stays L2 resident, and the early-z read (sc1: L2,
 //              not the CU's L1) sees every earlier fold of the same XCD.  The resolve pass takes the
 //              min over the 8 images.  Correctness needs only that all accesses to image x come
 //              from XCD x inside the launch, plus ordinary kernel-boundary visibility.
-//   MODE_AGENT one shared image, agent-scope atomics (memory-side), early-z through a possibly
+//   MODE_AGENT (default) one shared image, agent-scope atomics (memory-side), early-z through a possibly
 //              stale L2 copy (conservative, but filters less).
 //   MODE_NOZ   projection only, no z-buffer traffic: timing floor for tuning, results are invalid.
 //   MODE_SYS   one shared image, agent-scope atomics, early-z read at SYSTEM scope (sc0 sc1: bypasses
 //              the XCD L2 too, so the filter is exact but every read crosses the fabric).
-enum { MODE_XCD = 0, MODE_AGENT = 1, MODE_NOZ = 2, MODE_SYS = 3 };
+//   MODE_PEEK / MODE_PEEK_L1 / MODE_ATOM  attribution probes (invalid results): early-z reads only (sc1 /
+//              plain L1-cached), and atomics only (no early-z filter).
+enum { MODE_XCD = 0, MODE_AGENT = 1, MODE_NOZ = 2, MODE_SYS = 3, MODE_PEEK = 4, MODE_PEEK_L1 = 5, MODE_ATOM = 6 };
 constexpr int XCD_COPIES = 8;
 
 __device__ __forceinline__ unsigned xcc_id()
@@ -79,6 +81,7 @@ __device__ __forceinline__ unsigned long long peek_key(const unsigned long long 
 {
     // relaxed agent-scope load = global_load_dwordx2 sc1: served by L2, never by the CU's stale L1
     if (MODE == MODE_SYS) return __hip_atomic_load(k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    if (MODE == MODE_PEEK_L1) return *k;
     return __hip_atomic_load(k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
@@ -112,8 +115,19 @@ __device__ __forceinline__ void splat_points(const float (&px)[NP], const float 
         for (int k = 0; k < NP; ++k) sink += (unsigned)pix[k];
         return;
     }
+    if (MODE == MODE_ATOM) {
+#pragma unroll
+        for (int k = 0; k < NP; ++k)
+            if (pix[k] >= 0) fold_key<MODE>(keys + pix[k], key[k]);
+        return;
+    }
 #pragma unroll
     for (int k = 0; k < NP; ++k) seen[k] = pix[k] >= 0 ? peek_key<MODE>(keys + pix[k]) : 0ull;
+    if (MODE == MODE_PEEK || MODE == MODE_PEEK_L1) {
+#pragma unroll
+        for (int k = 0; k < NP; ++k) sink += (unsigned)(seen[k] >> 32) + (unsigned)pix[k];
+        return;
+    }
     // keys only ever decrease, so "not smaller than what I can see" is final
 #pragma unroll
     for (int k = 0; k < NP; ++k)
@@ -158,7 +172,8 @@ __global__ __launch_bounds__(256) void splat_project_kernel(const float *__restr
             splat_points<MODE, 1>(px, py, pz, (unsigned)i, 1, cams.m[cam], W, H,
                                   kbase + (long long)cam * copies * npx, sink);
     }
-    if (MODE == MODE_NOZ && sink == 0x7fffffffu && sink_out) *sink_out = sink;   // keeps the projection live
+    if ((MODE == MODE_NOZ || MODE == MODE_PEEK || MODE == MODE_PEEK_L1) && sink == 0x7fffffffu && sink_out)
+        *sink_out = sink;                                                       // keeps the probes live
 }
 
 struct ResolveOut {
@@ -267,7 +282,7 @@ int level_dim(int v, int l)
     return (int)((double)v * (1.0 / (double)(1 << l)));
 }
 
-int g_splat_mode = MODE_XCD;
+int g_splat_mode = MODE_AGENT;   // fastest of the measured policies (profiles/README.md)
 
 int project_and_resolve(const float *xyz, int64_t n, const float *M_host, int B, int W, int H, int levels,
                         int32_t *const *idx_levels, float *const *depth_levels, int level_base,
@@ -288,7 +303,10 @@ int project_and_resolve(const float *xyz, int64_t n, const float *M_host, int B,
             const int vec_ok = ((uintptr_t)xyz % 16) == 0;
             auto kern = mode == MODE_XCD ? splat_project_kernel<MODE_XCD>
                         : mode == MODE_AGENT ? splat_project_kernel<MODE_AGENT>
-                        : mode == MODE_SYS ? splat_project_kernel<MODE_SYS> : splat_project_kernel<MODE_NOZ>;
+                        : mode == MODE_SYS ? splat_project_kernel<MODE_SYS>
+                        : mode == MODE_PEEK ? splat_project_kernel<MODE_PEEK>
+                        : mode == MODE_PEEK_L1 ? splat_project_kernel<MODE_PEEK_L1>
+                        : mode == MODE_ATOM ? splat_project_kernel<MODE_ATOM> : splat_project_kernel<MODE_NOZ>;
             hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(256), 0, stream, xyz, (long long)n, cams, nb, W, H,
                                keys, vec_ok, (unsigned *)nullptr);
             READ_CHECK_LAUNCH();
@@ -322,7 +340,7 @@ extern "C" size_t read_splat_workspace_bytes(int B, int W, int H)
 namespace readhip {
 int splat_set_mode(int m)
 {
-    if (m < MODE_XCD || m > MODE_SYS) return READ_EINVAL;
+    if (m < MODE_XCD || m > MODE_ATOM) return READ_EINVAL;
     g_splat_mode = m;
     return READ_OK;
 }

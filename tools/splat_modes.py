@@ -14,8 +14,11 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from read_amd import _lib, camera, synthetic          # noqa: E402
 from read_amd.raster import PointCloudRasterizer      # noqa: E402
 
-NAMES = {0: "per-XCD images, L2-local atomics", 1: "one image, agent atomics, sc1 early-z",
-         3: "one image, agent atomics, system-scope early-z", 2: "projection only (floor, invalid results)"}
+NAMES = {0: "per-XCD images, workgroup-scope atomics", 1: "one image, agent atomics, sc1 early-z (default)",
+         3: "one image, agent atomics, system-scope early-z", 2: "probe: projection only",
+         4: "probe: projection + sc1 early-z reads, no atomics", 5: "probe: projection + plain (L1) early-z reads",
+         6: "probe: projection + atomics, no early-z"}
+INVALID = (2, 4, 5, 6)
 
 
 def main():
@@ -31,7 +34,7 @@ def main():
     ref = None
     res = []
     bytes_algo = 12.0 * a.points + 8.0 * sum(w * h for (w, h) in camera.level_sizes(W, H, 5))
-    for mode in (0, 1, 3, 2, 0):
+    for mode in (1, 0, 3, 2, 4, 5, 6, 1):
         _lib.check(L.read_tuning_set(b"splat_mode", mode))
         for _ in range(3):
             idx, dep = r.render(M, W, H, 5)
@@ -44,18 +47,18 @@ def main():
         e1.synchronize()
         ms = e0.elapsed_time(e1) / 10
         same = None
-        if mode != 2:
+        if mode not in INVALID:
             cur = [i.clone() for i in idx] + [d.clone() for d in dep]
             if ref is None:
                 ref = cur
             same = all(torch.equal(x, y) for x, y in zip(ref, cur))
         row = {"mode": mode, "name": NAMES[mode], "ms": ms, "GBps": bytes_algo / ms / 1e6,
-               "frac_hbm_8TBs": bytes_algo / ms / 1e6 / 8000.0, "identical_to_mode0": same}
+               "frac_hbm_8TBs": bytes_algo / ms / 1e6 / 8000.0, "identical_to_first": same}
         print(row, flush=True)
         res.append(row)
         # the workspace may hold garbage after the projection-only mode: re-initialise
         _lib.check(L.read_splat_workspace_init(r._ws.data_ptr(), r._ws.numel(), _lib.stream_ptr()))
-    _lib.check(L.read_tuning_set(b"splat_mode", 0))
+    _lib.check(L.read_tuning_set(b"splat_mode", 1))
     os.makedirs(os.path.dirname(os.path.abspath(a.out)), exist_ok=True)
     json.dump(res, open(a.out, "w"), indent=1)
 
