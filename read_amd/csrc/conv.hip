@@ -27,7 +27,7 @@ typedef float floatx16 __attribute__((ext_vector_type(16)));
 
 namespace {
 
-constexpr int MAX_CHUNKS = 64;
+constexpr long long OOB_LIMIT = 0x7ffffff0ll;   // byte offsets below this are in range for the epilogue's buffer ops
 
 struct SrcDev {
     const float *p;
@@ -44,11 +44,9 @@ struct ConvKArgs {
     float *out;
     int inH, inW, outH, outW;
     int Cout, CoutPad, out_cstride;
-    int nchunks, tiles_x;
+    int nchunks, tiles_x, n_src;
     int elu, fill_pad;
     float out_fill;
-    unsigned char chunk_src[MAX_CHUNKS];
-    unsigned short chunk_coff[MAX_CHUNKS];
 };
 
 // Epilogue transcendentals on the hardware v_exp_f32 / v_rcp_f32 (about 1 ulp each): the gate and
@@ -111,9 +109,14 @@ __global__ __launch_bounds__(256) void gated_conv_kernel(const ConvKArgs a)
         okmask |= (ok ? 1u : 0u) << i;
     }
 
-    auto gload = [&](int chunk) {
-        const SrcDev s = a.src[a.chunk_src[chunk]];
-        const int coff = a.chunk_coff[chunk];
+    // (source, channel offset) of the NEXT chunk to stage, advanced with scalar arithmetic.  A table
+    // indexed by the chunk number in the kernarg segment turns into a vector load + readfirstlane in
+    // front of every chunk's loads (seen in the ISA): ~1 us of exposed latency per chunk.
+    int nsrc_i = 0, ncoff = 0;
+    SrcDev ns = a.src[0];
+    auto gload = [&]() {
+        const SrcDev s = ns;
+        const int coff = ncoff;
 #pragma unroll
         for (int i = 0; i < TL::NI; ++i) {
             const int e = tid + i * 256;
@@ -125,6 +128,12 @@ __global__ __launch_bounds__(256) void gated_conv_kernel(const ConvKArgs a)
             const int off = ((okmask >> i) & 1u) ? (sy * s.W + sx) * s.C + coff + 4 * q : 0;
             st[i] = *reinterpret_cast<const float4 *>(s.p + off);
             if (MUL) sm[i] = *reinterpret_cast<const float4 *>(a.mul + off);
+        }
+        ncoff += KC;
+        if (ncoff >= s.C && nsrc_i + 1 < a.n_src) {       // uniform: next chunk comes from the next source
+            ++nsrc_i;
+            ncoff = 0;
+            ns = a.src[nsrc_i];
         }
     };
     auto lwrite = [&](float *buf) {
@@ -169,7 +178,7 @@ __global__ __launch_bounds__(256) void gated_conv_kernel(const ConvKArgs a)
         for (int t = 0; t < TL::T; ++t) bq[d][t] = wl[((size_t)sidx * NT + t) * 64];
     }
 
-    gload(0);
+    gload();
     lwrite(lds);
     __syncthreads();
 
@@ -178,7 +187,7 @@ __global__ __launch_bounds__(256) void gated_conv_kernel(const ConvKArgs a)
 
     for (int chunk = 0; chunk < a.nchunks; ++chunk) {
         const bool more = chunk + 1 < a.nchunks;
-        if (more) gload(chunk + 1);
+        if (more) gload();
         const float *buf = lds + (NBUF == 2 ? (chunk & 1) * TL::BUF : 0);
         const int step0 = chunk * SPC;
         // A fragments are read one k-step ahead of their MFMAs (LDS latency off the critical path)
@@ -247,8 +256,17 @@ __global__ __launch_bounds__(256) void gated_conv_kernel(const ConvKArgs a)
         __syncthreads();
     }
 
-    // ---------------- epilogue: bias, ELU, sigmoid gate, BatchNorm(eval), residual, store
+    // ---------------- epilogue: bias, ELU, sigmoid gate, BatchNorm(eval), residual, store.
+    // Raw buffer loads/stores with the hardware range check do the masking (partial tiles, padded
+    // channels): no per-element branches, all residual loads of a tile in flight together, all
+    // stores issued back to back.  (The first version branched per element and hipcc put an
+    // s_waitcnt vmcnt(0) in front of every store — one memory round trip per output value.)
+    constexpr int OOB = 0x7ffffff0;
     const int hi = lane >> 5;
+    const __amdgpu_buffer_rsrc_t orsrc = __builtin_amdgcn_make_buffer_rsrc(
+        (void *)a.out, 0, a.outH * a.outW * a.out_cstride * 4, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rrsrc = __builtin_amdgcn_make_buffer_rsrc(
+        (void *)(a.residual ? a.residual : a.out), 0, a.residual ? a.outH * a.outW * a.Cout * 4 : 0, 0x00020000);
 #pragma unroll
     for (int g = 0; g < QG; ++g) {
         const int c = ((nt0 >> 1) + g) * 32 + (lane & 31);
@@ -257,39 +275,43 @@ __global__ __launch_bounds__(256) void gated_conv_kernel(const ConvKArgs a)
         const float sc = a.params[2 * a.CoutPad + c];
         const float sh = a.params[3 * a.CoutPad + c];
         const bool c_ok = c < a.Cout;
-        const bool c_fill = !c_ok && a.fill_pad && c < a.out_cstride;
+        const bool c_st = c_ok || (a.fill_pad && c < a.out_cstride);
 #pragma unroll
         for (int p = 0; p < P; ++p) {
             const int oy = oy0 + wm * P + p;
-            if (oy >= a.outH) continue;
+            int ooff[TL::NR];
+            float rv[TL::NR];
 #pragma unroll
             for (int rr = 0; rr < TL::NR; ++rr) {
                 const int r = wk * TL::NR + rr;
                 const int ox = ox0 + (r & 3) + 8 * (r >> 2) + 4 * hi;
-                if (ox >= a.outW) continue;
+                const bool in = (oy < a.outH) & (ox < a.outW);
                 const int opix = oy * a.outW + ox;
-                if (c_ok) {
-                    float f, m;
-                    if (TL::WK > 1) {
-                        f = m = 0.0f;
+                ooff[rr] = (in & c_st) ? (opix * a.out_cstride + c) * 4 : OOB;
+                const int roff = (in & c_ok) ? (opix * a.Cout + c) * 4 : OOB;
+                rv[rr] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rrsrc, roff, 0, 0));
+            }
 #pragma unroll
-                        for (int w = 0; w < TL::WK; ++w) {
-                            f += lds[(((w * P + p) * TL::T + 2 * g) * 16 + r) * 64 + lane];
-                            m += lds[(((w * P + p) * TL::T + 2 * g + 1) * 16 + r) * 64 + lane];
-                        }
-                    } else {
-                        f = acc[p][2 * g][rr];        // WK == 1: r == rr
-                        m = acc[p][2 * g + 1][rr];
+            for (int rr = 0; rr < TL::NR; ++rr) {
+                const int r = wk * TL::NR + rr;
+                float f, m;
+                if (TL::WK > 1) {
+                    f = m = 0.0f;
+#pragma unroll
+                    for (int w = 0; w < TL::WK; ++w) {
+                        f += lds[(((w * P + p) * TL::T + 2 * g) * 16 + r) * 64 + lane];
+                        m += lds[(((w * P + p) * TL::T + 2 * g + 1) * 16 + r) * 64 + lane];
                     }
-                    f += bf;
-                    m += bm;
-                    if (a.elu) f = elu1(f);
-                    float v = (f * sigmoidf(m)) * sc + sh;
-                    if (a.residual) v += a.residual[opix * a.Cout + c];
-                    a.out[opix * a.out_cstride + c] = v;
-                } else if (c_fill) {
-                    a.out[opix * a.out_cstride + c] = a.out_fill;
+                } else {
+                    f = acc[p][2 * g][rr];            // WK == 1: r == rr
+                    m = acc[p][2 * g + 1][rr];
                 }
+                f += bf;
+                m += bm;
+                if (a.elu) f = elu1(f);
+                float v = (f * sigmoidf(m)) * sc + sh + rv[rr];
+                v = c_ok ? v : a.out_fill;
+                __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), orsrc, ooff[rr], 0, 0);
             }
         }
     }
@@ -528,20 +550,12 @@ int launch_gated_conv(const read_conv_desc *d, hipStream_t stream)
     }
     READ_CHECK_ARG(!d->mul || d->src[0].shift == 0, "read_gated_conv_forward: mul needs shift 0");
     const int nchunks = Cin / kc;
-    READ_CHECK_ARG(nchunks <= MAX_CHUNKS, "read_gated_conv_forward: too many input chunks (%d)", nchunks);
-    {
-        int ch = 0;
-        for (int i = 0; i < d->n_src; ++i)
-            for (int c = 0; c < d->src[i].C; c += kc, ++ch) {
-                a.chunk_src[ch] = (unsigned char)i;
-                a.chunk_coff[ch] = (unsigned short)c;
-            }
-    }
+    a.n_src = d->n_src;
     const int pad = (d->ksize - 1) / 2;
     const int outH = (d->inH + 2 * pad - d->ksize) / d->stride + 1;
     const int outW = (d->inW + 2 * pad - d->ksize) / d->stride + 1;
     READ_CHECK_ARG(outH >= 1 && outW >= 1, "read_gated_conv_forward: empty output");
-    READ_CHECK_ARG((long long)outH * outW * d->out_cstride < (1ll << 31), "read_gated_conv_forward: output too large");
+    READ_CHECK_ARG((long long)outH * outW * d->out_cstride * 4 < OOB_LIMIT, "read_gated_conv_forward: output too large");
     const int CoutPad = pad32(d->Cout), groups = CoutPad / 32;
     int cfg = d->config;
     if (cfg < 0) cfg = pick_config(d->ksize, d->stride, kc, groups, outH, outW);
