@@ -56,6 +56,10 @@ int read_device_arch(char *name, int len);
  * agent-scope atomics and L1-bypassing early-z reads, 0 per-XCD key images, 3 system-scope early-z;
  * 2/4/5/6 are attribution probes whose results are invalid (see csrc/splat.hip). */
 int read_tuning_set(const char *key, int value);
+/* Debug timeline of the following gated-conv launches: 64 bytes per workgroup in `buf` (device):
+ * s_memrealtime at entry / after prologue / after the k-loop / at exit, HW_ID, XCC_ID, blockIdx.x/y.
+ * NULL switches tracing off (the default). */
+int read_debug_set_trace(void *buf, size_t bytes);
 
 /* ---------------------------------------------------------------- rasteriser (z-buffer splat) */
 

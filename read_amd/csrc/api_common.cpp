@@ -32,6 +32,16 @@ extern "C" int read_device_arch(char *name, int len)
 
 namespace readhip {
 int splat_set_mode(int m);
+void conv_set_trace(void *buf, size_t bytes);
+}
+
+// Debug: per-workgroup timeline of the next gated-conv launches.  buf = device memory, 64 bytes per
+// workgroup: s_memrealtime (100 MHz) at kernel entry / after the prologue / after the k-loop / at exit,
+// HW_ID, XCC_ID, blockIdx.x, blockIdx.y.  NULL switches it off.
+extern "C" int read_debug_set_trace(void *buf, size_t bytes)
+{
+    readhip::conv_set_trace(buf, bytes);
+    return READ_OK;
 }
 
 // Tuning knobs for A/B measurements on the GPU box (not needed in production):

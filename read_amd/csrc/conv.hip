@@ -47,6 +47,7 @@ struct ConvKArgs {
     int nchunks, tiles_x, n_src;
     int elu, fill_pad;
     float out_fill;
+    unsigned long long *trace;     // optional timeline: 8 x u64 per workgroup (read_debug_set_trace)
 };
 
 // Epilogue transcendentals on the hardware v_exp_f32 / v_rcp_f32 (about 1 ulp each): the gate and
@@ -83,6 +84,8 @@ __global__ __launch_bounds__(256) void gated_conv_kernel(const ConvKArgs a)
     static_assert(TL::WK == 1 || 4 * P * TL::T * 16 * 64 <= NBUF * TL::BUF, "split-K reduction must fit the LDS tile");
     __shared__ __attribute__((aligned(16))) float lds[NBUF * TL::BUF];
 
+    unsigned long long t_trace[4];
+    if (a.trace) t_trace[0] = __builtin_amdgcn_s_memrealtime();
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -181,6 +184,7 @@ __global__ __launch_bounds__(256) void gated_conv_kernel(const ConvKArgs a)
     gload();
     lwrite(lds);
     __syncthreads();
+    if (a.trace) t_trace[1] = __builtin_amdgcn_s_memrealtime();
 
     // A fragment base inside a buffer: row (wm*P + p)*S, column (lane&31)*S, cin 4*(lane>>5)
     const int abase = ((wm * P) * S * TL::IW + (lane & 31) * S) * TL::PS + 4 * (lane >> 5);
@@ -241,6 +245,8 @@ __global__ __launch_bounds__(256) void gated_conv_kernel(const ConvKArgs a)
             }
         }
     }
+
+    if (a.trace) t_trace[2] = __builtin_amdgcn_s_memrealtime();
 
     // ---------------- split-K: the WK waves of a tile exchange partial sums through LDS; wave wk then
     // finishes accumulator registers [wk*NR, wk*NR+NR) (every tile, every group).
@@ -315,6 +321,19 @@ __global__ __launch_bounds__(256) void gated_conv_kernel(const ConvKArgs a)
             }
         }
     }
+    if (a.trace && tid == 0) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // include this wave's stores
+        t_trace[3] = __builtin_amdgcn_s_memrealtime();
+        unsigned long long *rec = a.trace + ((size_t)blockIdx.y * gridDim.x + blockIdx.x) * 8;
+        rec[0] = t_trace[0];
+        rec[1] = t_trace[1];
+        rec[2] = t_trace[2];
+        rec[3] = t_trace[3];
+        rec[4] = __builtin_amdgcn_s_getreg((31 << 11) | 4);   // HW_REG_HW_ID (wave/simd/cu/sh/se)
+        rec[5] = __builtin_amdgcn_s_getreg((3 << 11) | 20);   // HW_REG_XCC_ID
+        rec[6] = blockIdx.x;
+        rec[7] = blockIdx.y;
+    }
 }
 
 // ------------------------------------------------------------------------------------------
@@ -324,17 +343,21 @@ typedef void (*conv_fn)(const ConvKArgs);
 
 struct ConvConfig {
     const char *name;
-    int KS, S, KC, P, QG, WM, WN, PF;
+    int KS, S, KC, P, QG, WM, WN, PF, NB;
     conv_fn fn;
     conv_fn fn_mul;      // variant whose loader multiplies by a second tensor (FAM), or null
 };
 
 #define CFGN(KS, S, KC, P, QG, WM, WN, PF, NB)                                                        \
-    {"k" #KS "s" #S "c" #KC "_p" #P "q" #QG "m" #WM "n" #WN "f" #PF "b" #NB, KS, S, KC, P, QG, WM, WN, PF, \
+    {"k" #KS "s" #S "c" #KC "_p" #P "q" #QG "m" #WM "n" #WN "f" #PF "b" #NB, KS, S, KC, P, QG, WM, WN, PF, NB, \
      gated_conv_kernel<KS, S, KC, P, QG, WM, WN, false, PF, NB>, nullptr}
+#define CFGNM(KS, S, KC, P, QG, WM, WN, PF, NB)                                                       \
+    {"k" #KS "s" #S "c" #KC "_p" #P "q" #QG "m" #WM "n" #WN "f" #PF "b" #NB, KS, S, KC, P, QG, WM, WN, PF, NB, \
+     gated_conv_kernel<KS, S, KC, P, QG, WM, WN, false, PF, NB>,                                      \
+     gated_conv_kernel<KS, S, KC, P, QG, WM, WN, true, PF, NB>}
 #define CFG(KS, S, KC, P, QG, WM, WN, PF) CFGN(KS, S, KC, P, QG, WM, WN, PF, 2)
 #define CFGM(KS, S, KC, P, QG, WM, WN, PF)                                                           \
-    {"k" #KS "s" #S "c" #KC "_p" #P "q" #QG "m" #WM "n" #WN "f" #PF "b2", KS, S, KC, P, QG, WM, WN, PF, \
+    {"k" #KS "s" #S "c" #KC "_p" #P "q" #QG "m" #WM "n" #WN "f" #PF "b2", KS, S, KC, P, QG, WM, WN, PF, 2, \
      gated_conv_kernel<KS, S, KC, P, QG, WM, WN, false, PF, 2>,                                     \
      gated_conv_kernel<KS, S, KC, P, QG, WM, WN, true, PF, 2>}
 
@@ -353,9 +376,9 @@ const ConvConfig g_configs[] = {
     CFGM(3, 1, 16, 2, 1, 4, 1, 2),  //  6  as 0, B prefetch depth 2
     CFGM(3, 1, 16, 1, 1, 4, 1, 2),  //  7  as 1, depth 2
     CFGM(3, 1, 16, 2, 1, 2, 2, 2),  //  8  as 2, depth 2
-    CFGN(3, 1, 16, 2, 1, 4, 1, 2, 1),  // single LDS buffer (3 workgroups per CU), depth 2
-    CFGN(3, 1, 16, 1, 1, 4, 1, 2, 1),
-    CFGN(3, 1, 16, 2, 1, 2, 2, 2, 1),
+    CFGN(3, 1, 16, 2, 1, 4, 1, 2, 1),   //  9  single LDS buffer, depth 2
+    CFGNM(3, 1, 16, 1, 1, 4, 1, 2, 1),  // 10  4x32 px, single buffer: best at <= 2 channel groups
+    CFGNM(3, 1, 16, 2, 1, 2, 2, 2, 1),  // 11  4x32 px x 2 groups, single buffer: best at 8 groups
     // 3x3 stride 1, 8-channel chunks (inputs straight from the 8-channel pyramid)
     CFG(3, 1, 8, 2, 1, 4, 1, 1),    //  9
     CFG(3, 1, 8, 1, 1, 4, 1, 1),    // 10
@@ -379,32 +402,37 @@ const ConvConfig g_configs[] = {
 };
 constexpr int N_CONFIGS = sizeof(g_configs) / sizeof(g_configs[0]);
 
-int find_config(int ks, int s, int kc, int P, int QG, int WM, int WN, int PF)
+int find_config(int ks, int s, int kc, int P, int QG, int WM, int WN, int PF, int NB)
 {
     for (int i = 0; i < N_CONFIGS; ++i) {
         const ConvConfig &c = g_configs[i];
-        if (c.KS == ks && c.S == s && c.KC == kc && c.P == P && c.QG == QG && c.WM == WM && c.WN == WN && c.PF == PF)
+        if (c.KS == ks && c.S == s && c.KC == kc && c.P == P && c.QG == QG && c.WM == WM && c.WN == WN && c.PF == PF &&
+            c.NB == NB)
             return i;
     }
     return -1;
 }
 
-// Automatic choice.  Measured on MI355X at 1216x352 (profiles/r1_sweep_conv.md): 8x32-pixel tiles win
-// only while they still give >= ~4 workgroups per CU; below that 4x32 tiles (twice the workgroups)
-// win, and at exactly four channel groups the 4x32 x 2-group tile (A tile shared by two wave pairs)
-// is best.
+// Automatic choice, from the measured sweeps on MI355X at 1216x352 (profiles/README.md):
+//   3x3/s1, 16-ch chunks:  <= 2 channel groups -> 4x32-px tiles, single LDS buffer (4 workgroups per CU);
+//                          4 groups -> 4x32 px x 2 groups per wave pair; 8 groups -> 4x32 px x 2 groups, single buffer
+//   1x1:                   1 group -> 8x32 px with B prefetch depth 2; more -> 4x32 px
 int pick_config(int ks, int s, int kc, int groups, int outH, int outW)
 {
+    (void)outH;
+    (void)outW;
+    int c = -1;
     if (ks == 3 && s == 1 && kc == 16) {
-        const long wg8 = (long)ceil_div(outW, 32) * ceil_div(outH, 8) * groups;
-        int c = -1;
-        if (groups == 4) c = find_config(3, 1, 16, 2, 1, 2, 2, 1);
-        else if (wg8 < 1024) c = find_config(3, 1, 16, 1, 1, 4, 1, 1);
-        if (c >= 0) return c;
+        if (groups % 8 == 0) c = find_config(3, 1, 16, 2, 1, 2, 2, 2, 1);
+        else if (groups % 4 == 0) c = find_config(3, 1, 16, 2, 2, 2, 2, 1, 2);
+        else c = find_config(3, 1, 16, 1, 1, 4, 1, 2, 1);
+    } else if (ks == 1 && s == 1 && kc == 16) {
+        c = groups == 1 ? find_config(1, 1, 16, 2, 1, 4, 1, 2, 2) : find_config(1, 1, 16, 1, 1, 4, 1, 1, 2);
     }
+    if (c >= 0) return c;
     for (int i = 0; i < N_CONFIGS; ++i) {
-        const ConvConfig &c = g_configs[i];
-        if (c.KS == ks && c.S == s && c.KC == kc && groups % (c.WN * c.QG) == 0) return i;
+        const ConvConfig &k = g_configs[i];
+        if (k.KS == ks && k.S == s && k.KC == kc && groups % (k.WN * k.QG) == 0) return i;
     }
     return -1;
 }
@@ -511,6 +539,14 @@ extern "C" int read_conv_pack_params_host(int Cout, const float *bf, const float
 
 namespace readhip {
 
+static unsigned long long *g_trace = nullptr;
+static size_t g_trace_records = 0;
+void conv_set_trace(void *buf, size_t bytes)
+{
+    g_trace = (unsigned long long *)buf;
+    g_trace_records = buf ? bytes / 64 : 0;
+}
+
 // Validates a descriptor, builds kernel arguments and launches.  Shared by the single-layer
 // entry point and the UNet executor.
 int launch_gated_conv(const read_conv_desc *d, hipStream_t stream)
@@ -559,6 +595,14 @@ int launch_gated_conv(const read_conv_desc *d, hipStream_t stream)
     const int CoutPad = pad32(d->Cout), groups = CoutPad / 32;
     int cfg = d->config;
     if (cfg < 0) cfg = pick_config(d->ksize, d->stride, kc, groups, outH, outW);
+    if (d->config < 0 && d->mul && cfg >= 0 && !g_configs[cfg].fn_mul)
+        for (int i = 0; i < N_CONFIGS; ++i) {
+            const ConvConfig &k = g_configs[i];
+            if (k.fn_mul && k.KS == d->ksize && k.S == d->stride && k.KC == kc && groups % (k.WN * k.QG) == 0) {
+                cfg = i;
+                break;
+            }
+        }
     READ_CHECK_ARG(cfg >= 0 && cfg < N_CONFIGS, "read_gated_conv_forward: no kernel for k=%d s=%d kc=%d groups=%d",
                    d->ksize, d->stride, kc, groups);
     const ConvConfig &c = g_configs[cfg];
@@ -584,6 +628,7 @@ int launch_gated_conv(const read_conv_desc *d, hipStream_t stream)
     a.out_fill = d->out_fill;
     const int tiles_y = ceil_div(outH, c.WM * c.P);
     const dim3 grid((unsigned)(a.tiles_x * tiles_y), (unsigned)(groups / (c.WN * c.QG)));
+    a.trace = ((size_t)grid.x * grid.y <= g_trace_records) ? g_trace : nullptr;
     conv_fn fn = c.fn;
     if (d->mul) {
         READ_CHECK_ARG(c.fn_mul, "read_gated_conv_forward: config %s has no multiply variant", c.name);
