@@ -41,6 +41,7 @@ def parse():
     p.add_argument("--no-cpu-baseline", action="store_true")
     p.add_argument("--cpu-frames", type=int, default=2)
     p.add_argument("--detail", type=str, default="", help="write per-launch timings to this JSON file")
+    p.add_argument("--tune", type=str, default="", help="comma list of key=value for read_tuning_set (A/B runs)")
     return p.parse_args()
 
 
@@ -88,6 +89,11 @@ def main():
     assert world == a.gpus, f"--gpus {a.gpus} but WORLD_SIZE={world}"
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
+    if a.tune:
+        from read_amd import _lib
+        for kv in a.tune.split(","):
+            k, v = kv.split("=")
+            _lib.check(_lib.lib().read_tuning_set(k.encode(), int(v)), "read_tuning_set")
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", device_id=dev)

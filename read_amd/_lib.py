@@ -93,6 +93,8 @@ def lib():
             fn = getattr(L, name)          # AttributeError here = header/library mismatch
             fn.restype = res
             fn.argtypes = args
+        if os.environ.get("READ_CONV_WAVE"):          # A/B switch for tests: wave-autonomous conv kernels
+            L.read_tuning_set(b"conv_wave", int(os.environ["READ_CONV_WAVE"]))
         _LIB = L
     return _LIB
 

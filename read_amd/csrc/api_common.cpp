@@ -33,6 +33,7 @@ extern "C" int read_device_arch(char *name, int len)
 namespace readhip {
 int splat_set_mode(int m);
 void conv_set_trace(void *buf, size_t bytes);
+void conv_set_prefer_wave(int v);
 }
 
 // Debug: per-workgroup timeline of the next gated-conv launches.  buf = device memory, 64 bytes per
@@ -55,6 +56,10 @@ extern "C" int read_tuning_set(const char *key, int value)
         const int rc = readhip::splat_set_mode(value);
         if (rc) readhip::set_error("read_tuning_set: splat_mode must be 0..6");
         return rc;
+    }
+    if (!strcmp(key, "conv_wave")) {
+        readhip::conv_set_prefer_wave(value != 0);
+        return READ_OK;
     }
     readhip::set_error("read_tuning_set: unknown key '%s'", key);
     return READ_EINVAL;

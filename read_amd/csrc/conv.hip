@@ -45,6 +45,7 @@ struct ConvKArgs {
     int inH, inW, outH, outW;
     int Cout, CoutPad, out_cstride;
     int nchunks, tiles_x, n_src;
+    int tiles_y, n_units;          // wave-autonomous kernel: units = (group set, x tile, y tile)
     int elu, fill_pad;
     float out_fill;
     unsigned long long *trace;     // optional timeline: 8 x u64 per workgroup (read_debug_set_trace)
@@ -336,6 +337,232 @@ __global__ __launch_bounds__(256) void gated_conv_kernel(const ConvKArgs a)
     }
 }
 
+
+// ------------------------------------------------------------------------------------------
+// Wave-autonomous persistent variant (the default for 3x3/s1 and 1x1 layers).
+//
+// The workgroup-tiled kernel above runs its k-loop at ~95 % MFMA occupancy, but a timeline trace
+// (tools/trace_conv.py, profiles/README.md) showed a whole launch at only 60 %: every workgroup
+// exposes its prologue (first tile load) and epilogue, the barrier couples its four waves, and the
+// last round of workgroups leaves most CUs idle (work is quantised in 4- or 8-unit workgroups).
+// Here every WAVE is an independent worker:
+//   * unit of work = P image rows x 32 pixels x QG channel groups; a wave owns a private LDS tile
+//     (no s_barrier anywhere) and walks units  u = wave_id, wave_id + n_waves, ...  (persistent grid);
+//   * the stream of (unit, chunk) items is software-pipelined ACROSS units: while chunk c is being
+//     multiplied, chunk c+1 (possibly the next unit's first) is in registers on its way from L2, and
+//     the B-fragment ring also runs ahead into the next unit — a unit's epilogue stores and the next
+//     unit's first loads overlap the MFMAs of the co-resident waves;
+//   * consecutive wave ids take vertically adjacent tiles of the same channel group, so their halos
+//     and weight fragments meet in L1/L2.
+template <int KS, int S, int KC, int P, int QG, int PF>
+__global__ __launch_bounds__(256, (P * QG >= 2 ? 2 : 3)) void gated_conv_wave_kernel(const ConvKArgs a)
+{
+    constexpr int IH = (P - 1) * S + KS, IW = 31 * S + KS, PS = KC + 4, BUF = IH * IW * PS;
+    constexpr int Q4 = KC / 4, NE = IH * IW * Q4, NI = (NE + 63) / 64, KK = KC / 8, T = 2 * QG;
+    constexpr int PAD = (KS - 1) / 2, SPC = KS * KS * KK;
+    __shared__ __attribute__((aligned(16))) float lds_all[4 * BUF];
+
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    float *lds = lds_all + wave * BUF;
+    const int gw = (int)blockIdx.x * 4 + wave;
+    const int nw = (int)gridDim.x * 4;
+    const int NT = a.CoutPad >> 4;
+    const int total_steps = a.nchunks * SPC;
+    if (gw >= a.n_units) return;
+
+    auto unit_coords = [&](int u, int &ox0, int &oy0, int &gs) {
+        const int ty = u % a.tiles_y, r = u / a.tiles_y;
+        ox0 = (r % a.tiles_x) * 32;
+        oy0 = ty * P;
+        gs = r / a.tiles_x;
+    };
+
+    // ---- staging cursor: which (unit, chunk) goes into the staging registers next
+    int lu = gw, lc = 0, nsrc_i = 0, ncoff = 0;
+    SrcDev ns = a.src[0];
+    float4 st[NI];
+    unsigned okmask = 0;
+    bool staged = false;
+    auto gload = [&]() {
+        int ox0, oy0, gs;
+        unit_coords(lu, ox0, oy0, gs);
+        const int ix0 = ox0 * S - PAD, iy0 = oy0 * S - PAD;
+        const SrcDev s = ns;
+        const int coff = ncoff;
+        okmask = 0;
+#pragma unroll
+        for (int i = 0; i < NI; ++i) {
+            const int e = lane + i * 64;
+            const int q = e % Q4, pix = e / Q4;
+            const int gy = iy0 + pix / IW, gx = ix0 + pix % IW;
+            const bool ok = e < NE && gy >= 0 && gy < a.inH && gx >= 0 && gx < a.inW;
+            okmask |= (ok ? 1u : 0u) << i;
+            const int sy = (gy << s.sl) >> s.sr, sx = (gx << s.sl) >> s.sr;
+            const int off = ok ? (sy * s.W + sx) * s.C + coff + 4 * q : 0;
+            st[i] = *reinterpret_cast<const float4 *>(s.p + off);
+        }
+        staged = true;
+        ncoff += KC;
+        if (ncoff >= s.C && nsrc_i + 1 < a.n_src) {
+            ++nsrc_i;
+            ncoff = 0;
+            ns = a.src[nsrc_i];
+        }
+        if (++lc == a.nchunks) {        // next item belongs to this wave's next unit
+            lc = 0;
+            lu += nw;
+            nsrc_i = 0;
+            ncoff = 0;
+            ns = a.src[0];
+        }
+    };
+    auto lwrite = [&]() {
+#pragma unroll
+        for (int i = 0; i < NI; ++i) {
+            const int e = lane + i * 64;
+            if (e < NE) {
+                float4 v = st[i];
+                if (!((okmask >> i) & 1u)) v = make_float4(0.f, 0.f, 0.f, 0.f);
+                *reinterpret_cast<float4 *>(lds + (e / Q4) * PS + 4 * (e % Q4)) = v;
+            }
+        }
+        staged = false;
+    };
+
+    const float4 *wp4 = reinterpret_cast<const float4 *>(a.wp) + lane;
+    const int abase = ((lane & 31) * S) * PS + 4 * (lane >> 5);
+    constexpr int OOB = 0x7ffffff0;
+    const int hi = lane >> 5;
+    const __amdgpu_buffer_rsrc_t orsrc = __builtin_amdgcn_make_buffer_rsrc(
+        (void *)a.out, 0, a.outH * a.outW * a.out_cstride * 4, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rrsrc = __builtin_amdgcn_make_buffer_rsrc(
+        (void *)(a.residual ? a.residual : a.out), 0, a.residual ? a.outH * a.outW * a.Cout * 4 : 0, 0x00020000);
+
+    // ---- prologue: first item into LDS, second into registers, B ring of the first unit
+    gload();
+    lwrite();
+    if (lu < a.n_units) gload();
+    float4 bq[PF][T];
+    {
+        int ox0, oy0, gs;
+        unit_coords(gw, ox0, oy0, gs);
+        const float4 *wl = wp4 + (size_t)gs * T * 64;
+#pragma unroll
+        for (int d = 0; d < PF; ++d) {
+            const int sidx = d < total_steps ? d : total_steps - 1;
+#pragma unroll
+            for (int t = 0; t < T; ++t) bq[d][t] = wl[((size_t)sidx * NT + t) * 64];
+        }
+    }
+
+    for (int u = gw; u < a.n_units; u += nw) {
+        int ox0, oy0, gs, nox0, noy0, ngs;
+        unit_coords(u, ox0, oy0, gs);
+        unit_coords(u + nw < a.n_units ? u + nw : u, nox0, noy0, ngs);
+        const float4 *wl = wp4 + (size_t)gs * T * 64;
+        const float4 *wl_next = wp4 + (size_t)ngs * T * 64;   // the B ring runs ahead into the next unit
+
+        floatx16 acc[P][T];
+#pragma unroll
+        for (int p = 0; p < P; ++p)
+#pragma unroll
+            for (int t = 0; t < T; ++t)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[p][t][r] = 0.0f;
+
+        for (int chunk = 0; chunk < a.nchunks; ++chunk) {
+            const int step0 = chunk * SPC;
+            auto aread = [&](int ls, float4(&dst)[P]) {
+                const int tap = ls / KK, kk = ls % KK;
+                const int ky = tap / KS, kx = tap % KS;
+#pragma unroll
+                for (int p = 0; p < P; ++p)
+                    dst[p] = *reinterpret_cast<const float4 *>(lds + abase + ((p * S + ky) * IW + kx) * PS + kk * 8);
+            };
+            float4 acur[P], anext[P];
+            aread(0, acur);
+#pragma unroll
+            for (int ls = 0; ls < SPC; ++ls) {
+                float4 b[T];
+#pragma unroll
+                for (int t = 0; t < T; ++t) b[t] = bq[0][t];
+#pragma unroll
+                for (int d = 0; d + 1 < PF; ++d)
+#pragma unroll
+                    for (int t = 0; t < T; ++t) bq[d][t] = bq[d + 1][t];
+                {   // prefetch PF steps ahead, pinned in front of the MFMA block (see the kernel above)
+                    int nstep = step0 + ls + PF;
+                    const float4 *base = wl;
+                    if (nstep >= total_steps) {
+                        nstep -= total_steps;
+                        base = wl_next;
+                    }
+#pragma unroll
+                    for (int t = 0; t < T; ++t) bq[PF - 1][t] = base[((size_t)nstep * NT + t) * 64];
+                }
+                if (ls + 1 < SPC) aread(ls + 1, anext);
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int p = 0; p < P; ++p)
+#pragma unroll
+                    for (int t = 0; t < T; ++t) {
+                        acc[p][t] = __builtin_amdgcn_mfma_f32_32x32x2f32(acur[p].x, b[t].x, acc[p][t], 0, 0, 0);
+                        acc[p][t] = __builtin_amdgcn_mfma_f32_32x32x2f32(acur[p].y, b[t].y, acc[p][t], 0, 0, 0);
+                        acc[p][t] = __builtin_amdgcn_mfma_f32_32x32x2f32(acur[p].z, b[t].z, acc[p][t], 0, 0, 0);
+                        acc[p][t] = __builtin_amdgcn_mfma_f32_32x32x2f32(acur[p].w, b[t].w, acc[p][t], 0, 0, 0);
+                    }
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int p = 0; p < P; ++p) acur[p] = anext[p];
+            }
+            // this wave's reads of the tile are done (their data fed the MFMAs above): restage
+            if (staged) {
+                lwrite();
+                if (lu < a.n_units) gload();
+            }
+        }
+
+        // ---- epilogue of this unit (same math as the workgroup kernel; the next unit's first chunk is
+        // already in LDS and its second on the way, so these loads/stores overlap real work)
+#pragma unroll
+        for (int g = 0; g < QG; ++g) {
+            const int c = (gs * QG + g) * 32 + (lane & 31);
+            const float bf = a.params[c];
+            const float bm = a.params[a.CoutPad + c];
+            const float sc = a.params[2 * a.CoutPad + c];
+            const float sh = a.params[3 * a.CoutPad + c];
+            const bool c_ok = c < a.Cout;
+            const bool c_st = c_ok || (a.fill_pad && c < a.out_cstride);
+#pragma unroll
+            for (int p = 0; p < P; ++p) {
+                const int oy = oy0 + p;
+                int ooff[16];
+                float rv[16];
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int ox = ox0 + (r & 3) + 8 * (r >> 2) + 4 * hi;
+                    const bool in = (oy < a.outH) & (ox < a.outW);
+                    const int opix = oy * a.outW + ox;
+                    ooff[r] = (in & c_st) ? (opix * a.out_cstride + c) * 4 : OOB;
+                    const int roff = (in & c_ok) ? (opix * a.Cout + c) * 4 : OOB;
+                    rv[r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rrsrc, roff, 0, 0));
+                }
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    float f = acc[p][2 * g][r] + bf;
+                    const float m = acc[p][2 * g + 1][r] + bm;
+                    if (a.elu) f = elu1(f);
+                    float v = (f * sigmoidf(m)) * sc + sh + rv[r];
+                    v = c_ok ? v : a.out_fill;
+                    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), orsrc, ooff[r], 0, 0);
+                }
+                __builtin_amdgcn_sched_barrier(0);   // one 16-value batch at a time: bounds the live registers
+            }
+        }
+    }
+}
+
 // ------------------------------------------------------------------------------------------
 // configuration table
 // ------------------------------------------------------------------------------------------
@@ -346,6 +573,8 @@ struct ConvConfig {
     int KS, S, KC, P, QG, WM, WN, PF, NB;
     conv_fn fn;
     conv_fn fn_mul;      // variant whose loader multiplies by a second tensor (FAM), or null
+    int wave;            // 1: wave-autonomous persistent kernel (WM = WN = 1 means "one wave per unit")
+    int wg_per_cu;       // wave kernel: persistent workgroups per CU (LDS / register limited)
 };
 
 #define CFGN(KS, S, KC, P, QG, WM, WN, PF, NB)                                                        \
@@ -360,6 +589,10 @@ struct ConvConfig {
     {"k" #KS "s" #S "c" #KC "_p" #P "q" #QG "m" #WM "n" #WN "f" #PF "b2", KS, S, KC, P, QG, WM, WN, PF, 2, \
      gated_conv_kernel<KS, S, KC, P, QG, WM, WN, false, PF, 2>,                                     \
      gated_conv_kernel<KS, S, KC, P, QG, WM, WN, true, PF, 2>}
+
+#define CFGW(KS, S, KC, P, QG, PF, WGCU)                                                      \
+    {"k" #KS "s" #S "c" #KC "_wave_p" #P "q" #QG "f" #PF, KS, S, KC, P, QG, 1, 1, PF, 1,        \
+     gated_conv_wave_kernel<KS, S, KC, P, QG, PF>, nullptr, 1, WGCU}
 
 // Order matters: pick_config() takes the first entry whose (ksize, stride, chunk) match and whose
 // channel-group coverage divides the layer's groups; remaining groups go to grid.y.  The order below
@@ -394,6 +627,13 @@ const ConvConfig g_configs[] = {
     CFG(3, 2, 16, 1, 1, 4, 1, 1),   // 17
     CFG(3, 2, 16, 1, 2, 2, 2, 1),   // 18
     CFG(3, 2, 16, 1, 2, 4, 1, 1),   // 19
+    // wave-autonomous persistent kernels
+    CFGW(3, 1, 16, 2, 1, 1, 2),
+    CFGW(3, 1, 16, 2, 1, 2, 2),
+    CFGW(3, 1, 16, 1, 1, 2, 3),
+    CFGW(1, 1, 16, 2, 1, 2, 2),
+    CFGW(1, 1, 16, 1, 1, 2, 4),
+    CFGW(3, 1, 8, 2, 1, 1, 2),
     // 4x4 stride 2 (decoder, before the bilinear x4): outputs are 1/4 .. 1/16 scale, so the 16 taps of
     // ONE 1x32-pixel tile are split over the four waves (split-K, WM*WN == 1) to fill the chip
     CFG(4, 2, 16, 1, 1, 1, 1, 1),   // 20  split-K, one group
@@ -417,11 +657,28 @@ int find_config(int ks, int s, int kc, int P, int QG, int WM, int WN, int PF, in
 //   3x3/s1, 16-ch chunks:  <= 2 channel groups -> 4x32-px tiles, single LDS buffer (4 workgroups per CU);
 //                          4 groups -> 4x32 px x 2 groups per wave pair; 8 groups -> 4x32 px x 2 groups, single buffer
 //   1x1:                   1 group -> 8x32 px with B prefetch depth 2; more -> 4x32 px
+int g_prefer_wave = 0;   // read_tuning_set("conv_wave", 1): wave-autonomous kernels where they exist
+
+int find_wave_config(int ks, int s, int kc, int P, int QG)
+{
+    int best = -1;
+    for (int i = 0; i < N_CONFIGS; ++i) {
+        const ConvConfig &c = g_configs[i];
+        if (c.wave && c.KS == ks && c.S == s && c.KC == kc && c.P == P && c.QG == QG) best = i;   // last = deepest prefetch
+    }
+    return best;
+}
+
 int pick_config(int ks, int s, int kc, int groups, int outH, int outW)
 {
-    (void)outH;
-    (void)outW;
     int c = -1;
+    if (g_prefer_wave) {
+        // 2-row units while they still give every wave slot (256 CUs x 2 WGs x 4 waves) >= 2 units, else 1-row units
+        const long units2 = (long)ceil_div(outW, 32) * ceil_div(outH, 2) * groups;
+        c = units2 >= 4096 ? find_wave_config(ks, s, kc, 2, 1) : find_wave_config(ks, s, kc, 1, 1);
+        if (c < 0) c = find_wave_config(ks, s, kc, 2, 1);
+        if (c >= 0) return c;
+    }
     if (ks == 3 && s == 1 && kc == 16) {
         if (groups % 8 == 0) c = find_config(3, 1, 16, 2, 1, 2, 2, 2, 1);
         else if (groups % 4 == 0) c = find_config(3, 1, 16, 2, 2, 2, 2, 1, 2);
@@ -539,6 +796,8 @@ extern "C" int read_conv_pack_params_host(int Cout, const float *bf, const float
 
 namespace readhip {
 
+void conv_set_prefer_wave(int v) { g_prefer_wave = v; }
+
 static unsigned long long *g_trace = nullptr;
 static size_t g_trace_records = 0;
 void conv_set_trace(void *buf, size_t bytes)
@@ -627,8 +886,23 @@ int launch_gated_conv(const read_conv_desc *d, hipStream_t stream)
     a.fill_pad = d->fill_pad;
     a.out_fill = d->out_fill;
     const int tiles_y = ceil_div(outH, c.WM * c.P);
-    const dim3 grid((unsigned)(a.tiles_x * tiles_y), (unsigned)(groups / (c.WN * c.QG)));
+    dim3 grid((unsigned)(a.tiles_x * tiles_y), (unsigned)(groups / (c.WN * c.QG)));
     a.trace = ((size_t)grid.x * grid.y <= g_trace_records) ? g_trace : nullptr;
+    if (c.wave) {
+        // persistent grid: every wave walks units u = wave, wave + n_waves, ...
+        a.tiles_y = ceil_div(outH, c.P);
+        a.n_units = a.tiles_x * a.tiles_y * (groups / c.QG);
+        a.trace = nullptr;
+        static int n_cu = 0;
+        if (!n_cu) {
+            int dev = 0;
+            hipDeviceProp_t prop;
+            n_cu = (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess &&
+                    prop.multiProcessorCount > 0) ? prop.multiProcessorCount : 256;
+        }
+        const int want = ceil_div(a.n_units, 4), cap = n_cu * c.wg_per_cu;
+        grid = dim3((unsigned)(want < cap ? want : cap), 1);
+    }
     conv_fn fn = c.fn;
     if (d->mul) {
         READ_CHECK_ARG(c.fn_mul, "read_gated_conv_forward: config %s has no multiply variant", c.name);

@@ -45,8 +45,8 @@ def _close(got_hwc, ref_chw, what):
 
 
 def _cfg_params(name):
-    m = re.match(r"k(\d)s(\d)c(\d+)_p(\d)q(\d)m(\d)n(\d)", name)
-    return tuple(int(g) for g in m.groups())
+    m = re.match(r"k(\d)s(\d)c(\d+)_(?:wave_)?p(\d)q(\d)(?:m(\d)n(\d))?", name)
+    return tuple(int(g) if g is not None else 1 for g in m.groups())
 
 
 def test_every_tile_configuration(hip):

@@ -69,8 +69,8 @@ def main():
                     gated_conv(pk, xs, stride=s, elu=True, config=-1, out=out)
                 torch.cuda.synchronize()
                 continue
-            m = re.match(r"k(\d)s(\d)c(\d+)_p(\d)q(\d)m(\d)n(\d)", name)
-            ks, ss, kcc, P, QG, WM, WN = (int(g) for g in m.groups())
+            m = re.match(r"k(\d)s(\d)c(\d+)_(?:wave_)?p(\d)q(\d)(?:m(\d)n(\d))?", name)
+            ks, ss, kcc, P, QG, WM, WN = (int(g) if g is not None else 1 for g in m.groups())
             if (ks, ss, kcc) != (k, s, kc) or groups % (WN * QG):
                 continue
             try:
