@@ -46,6 +46,8 @@ struct ConvKArgs {
     int Cout, CoutPad, out_cstride;
     int nchunks, tiles_x, n_src;
     int tiles_y, n_units;          // wave-autonomous kernel: units = (group set, x tile, y tile)
+    int n_full, col_split;         //   units [0,n_full) are P-row units of columns [0,col_split); the rest are
+                                   //   1-row units of the remaining (group set, x tile) columns (balanced tail)
     int elu, fill_pad;
     float out_fill;
     unsigned long long *trace;     // optional timeline: 8 x u64 per workgroup (read_debug_set_trace)
@@ -371,11 +373,21 @@ __global__ __launch_bounds__(256, (P * QG >= 2 ? 2 : 3)) void gated_conv_wave_ke
     const int total_steps = a.nchunks * SPC;
     if (gw >= a.n_units) return;
 
-    auto unit_coords = [&](int u, int &ox0, int &oy0, int &gs) {
-        const int ty = u % a.tiles_y, r = u / a.tiles_y;
-        ox0 = (r % a.tiles_x) * 32;
-        oy0 = ty * P;
-        gs = r / a.tiles_x;
+    // unit -> tile origin, channel-group set and number of valid rows (P for full units, 1 for tail units)
+    auto unit_coords = [&](int u, int &ox0, int &oy0, int &gs, int &nrows) {
+        int col;
+        if (u < a.n_full) {
+            col = u / a.tiles_y;
+            oy0 = (u % a.tiles_y) * P;
+            nrows = P;
+        } else {
+            const int v = u - a.n_full;
+            col = a.col_split + v / a.outH;
+            oy0 = v % a.outH;
+            nrows = 1;
+        }
+        ox0 = (col % a.tiles_x) * 32;
+        gs = col / a.tiles_x;
     };
 
     // ---- staging cursor: which (unit, chunk) goes into the staging registers next
@@ -385,8 +397,8 @@ __global__ __launch_bounds__(256, (P * QG >= 2 ? 2 : 3)) void gated_conv_wave_ke
     unsigned okmask = 0;
     bool staged = false;
     auto gload = [&]() {
-        int ox0, oy0, gs;
-        unit_coords(lu, ox0, oy0, gs);
+        int ox0, oy0, gs, nr;
+        unit_coords(lu, ox0, oy0, gs, nr);
         const int ix0 = ox0 * S - PAD, iy0 = oy0 * S - PAD;
         const SrcDev s = ns;
         const int coff = ncoff;
@@ -445,8 +457,8 @@ __global__ __launch_bounds__(256, (P * QG >= 2 ? 2 : 3)) void gated_conv_wave_ke
     if (lu < a.n_units) gload();
     float4 bq[PF][T];
     {
-        int ox0, oy0, gs;
-        unit_coords(gw, ox0, oy0, gs);
+        int ox0, oy0, gs, nr;
+        unit_coords(gw, ox0, oy0, gs, nr);
         const float4 *wl = wp4 + (size_t)gs * T * 64;
 #pragma unroll
         for (int d = 0; d < PF; ++d) {
@@ -457,9 +469,9 @@ __global__ __launch_bounds__(256, (P * QG >= 2 ? 2 : 3)) void gated_conv_wave_ke
     }
 
     for (int u = gw; u < a.n_units; u += nw) {
-        int ox0, oy0, gs, nox0, noy0, ngs;
-        unit_coords(u, ox0, oy0, gs);
-        unit_coords(u + nw < a.n_units ? u + nw : u, nox0, noy0, ngs);
+        int ox0, oy0, gs, nrows, nox0, noy0, ngs, nnr;
+        unit_coords(u, ox0, oy0, gs, nrows);
+        unit_coords(u + nw < a.n_units ? u + nw : u, nox0, noy0, ngs, nnr);
         const float4 *wl = wp4 + (size_t)gs * T * 64;
         const float4 *wl_next = wp4 + (size_t)ngs * T * 64;   // the B ring runs ahead into the next unit
 
@@ -504,7 +516,8 @@ __global__ __launch_bounds__(256, (P * QG >= 2 ? 2 : 3)) void gated_conv_wave_ke
                 if (ls + 1 < SPC) aread(ls + 1, anext);
                 __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-                for (int p = 0; p < P; ++p)
+                for (int p = 0; p < P; ++p) {
+                    if (p > 0 && p >= nrows) continue;      // tail unit: only its first row is real work (uniform)
 #pragma unroll
                     for (int t = 0; t < T; ++t) {
                         acc[p][t] = __builtin_amdgcn_mfma_f32_32x32x2f32(acur[p].x, b[t].x, acc[p][t], 0, 0, 0);
@@ -512,6 +525,7 @@ __global__ __launch_bounds__(256, (P * QG >= 2 ? 2 : 3)) void gated_conv_wave_ke
                         acc[p][t] = __builtin_amdgcn_mfma_f32_32x32x2f32(acur[p].z, b[t].z, acc[p][t], 0, 0, 0);
                         acc[p][t] = __builtin_amdgcn_mfma_f32_32x32x2f32(acur[p].w, b[t].w, acc[p][t], 0, 0, 0);
                     }
+                }
                 __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                 for (int p = 0; p < P; ++p) acur[p] = anext[p];
@@ -537,6 +551,7 @@ __global__ __launch_bounds__(256, (P * QG >= 2 ? 2 : 3)) void gated_conv_wave_ke
 #pragma unroll
             for (int p = 0; p < P; ++p) {
                 const int oy = oy0 + p;
+                if (p > 0 && p >= nrows) continue;
                 int ooff[16];
                 float rv[16];
 #pragma unroll
@@ -674,9 +689,8 @@ int pick_config(int ks, int s, int kc, int groups, int outH, int outW)
     int c = -1;
     if (g_prefer_wave) {
         // 2-row units while they still give every wave slot (256 CUs x 2 WGs x 4 waves) >= 2 units, else 1-row units
-        const long units2 = (long)ceil_div(outW, 32) * ceil_div(outH, 2) * groups;
-        c = units2 >= 4096 ? find_wave_config(ks, s, kc, 2, 1) : find_wave_config(ks, s, kc, 1, 1);
-        if (c < 0) c = find_wave_config(ks, s, kc, 2, 1);
+        c = find_wave_config(ks, s, kc, 2, 1);      // 2-row units, balanced 1-row tail
+        if (c < 0) c = find_wave_config(ks, s, kc, 1, 1);
         if (c >= 0) return c;
     }
     if (ks == 3 && s == 1 && kc == 16) {
@@ -891,7 +905,6 @@ int launch_gated_conv(const read_conv_desc *d, hipStream_t stream)
     if (c.wave) {
         // persistent grid: every wave walks units u = wave, wave + n_waves, ...
         a.tiles_y = ceil_div(outH, c.P);
-        a.n_units = a.tiles_x * a.tiles_y * (groups / c.QG);
         a.trace = nullptr;
         static int n_cu = 0;
         if (!n_cu) {
@@ -900,6 +913,21 @@ int launch_gated_conv(const read_conv_desc *d, hipStream_t stream)
             n_cu = (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess &&
                     prop.multiProcessorCount > 0) ? prop.multiProcessorCount : 256;
         }
+        // Balanced schedule: whole rounds of P-row units over all wave slots, the remainder as 1-row
+        // units, so the last round costs about half a unit instead of a full one (the trace of the
+        // workgroup-tiled kernel showed 20 % of a launch spent in a quarter-filled last round).
+        const int ncol = a.tiles_x * (groups / c.QG);
+        const long slots = (long)n_cu * c.wg_per_cu * 4;
+        const long unitsP = (long)ncol * a.tiles_y;
+        int col_split = ncol;
+        if (c.P > 1) {
+            const long rounds = unitsP / slots;
+            col_split = (int)((rounds * slots) / a.tiles_y);
+            if (col_split > ncol) col_split = ncol;
+        }
+        a.col_split = col_split;
+        a.n_full = col_split * a.tiles_y;
+        a.n_units = a.n_full + (ncol - col_split) * outH;
         const int want = ceil_div(a.n_units, 4), cap = n_cu * c.wg_per_cu;
         grid = dim3((unsigned)(want < cap ? want : cap), 1);
     }

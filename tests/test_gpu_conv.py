@@ -132,3 +132,22 @@ def test_bilinear_up4(hip):
     ref = F.interpolate(x[None], scale_factor=4, mode="bilinear", align_corners=False)[0]
     got = bilinear_up4(_nhwc(x))
     torch.testing.assert_close(got.cpu().permute(2, 0, 1), ref, rtol=1e-6, atol=1e-6)
+
+
+def test_wave_kernel_full_and_tail_units_at_frame_size(hip):
+    """At 1216x352 the persistent wave kernel schedules whole rounds of 2-row units plus a tail of 1-row
+    units; small test images only exercise the tail path.  Same k order as the workgroup-tiled kernel
+    (already checked against the oracle), so the two must agree to the last bit or nearly so."""
+    torch.manual_seed(5)
+    names = config_names()
+    for (c, H, W) in ((32, 352, 1216), (64, 176, 608)):
+        st = _state(c, c, 3, seed=c)
+        x = torch.randn(H, W, c, device="cuda")
+        res = torch.randn(H, W, c, device="cuda")
+        pk = _pack(st, [c])
+        ref = gated_conv(pk, [(x, 0)], elu=True, residual=res, config=names.index("k3s1c16_p2q1m4n1f1b2"))
+        for name in names:
+            if name.startswith("k3s1c16_wave"):
+                got = gated_conv(pk, [(x, 0)], elu=True, residual=res, config=names.index(name))
+                err = float((got - ref).abs().max())
+                assert err <= 1e-5, f"{name} at {W}x{H}x{c}: max diff {err:.3e}"
