@@ -60,6 +60,10 @@ int read_tuning_set(const char *key, int value);
  * s_memrealtime at entry / after prologue / after the k-loop / at exit, HW_ID, XCC_ID, blockIdx.x/y.
  * NULL switches tracing off (the default). */
 int read_debug_set_trace(void *buf, size_t bytes);
+/* Debug probe: `blocks` workgroups x 4 waves, each wave issues iters*nacc*4 v_mfma_f32_32x32x2_f32
+ * (4096 FLOP each) from registers — the sustained matrix-core ceiling for the conv kernels.
+ * scratch: >= blocks*256 floats (never written in practice). */
+int read_debug_mfma_probe(int blocks, int iters, int nacc, float *scratch, void *stream);
 
 /* ---------------------------------------------------------------- rasteriser (z-buffer splat) */
 

@@ -34,6 +34,8 @@ namespace readhip {
 int splat_set_mode(int m);
 void conv_set_trace(void *buf, size_t bytes);
 void conv_set_prefer_wave(int v);
+void conv_set_stagger(int ticks);
+void conv_set_ablate(int bits);
 }
 
 // Debug: per-workgroup timeline of the next gated-conv launches.  buf = device memory, 64 bytes per
@@ -56,6 +58,14 @@ extern "C" int read_tuning_set(const char *key, int value)
         const int rc = readhip::splat_set_mode(value);
         if (rc) readhip::set_error("read_tuning_set: splat_mode must be 0..6");
         return rc;
+    }
+    if (!strcmp(key, "conv_ablate")) {
+        readhip::conv_set_ablate(value);
+        return READ_OK;
+    }
+    if (!strcmp(key, "conv_stagger")) {
+        readhip::conv_set_stagger(value);
+        return READ_OK;
     }
     if (!strcmp(key, "conv_wave")) {
         readhip::conv_set_prefer_wave(value != 0);

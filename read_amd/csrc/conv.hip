@@ -46,6 +46,9 @@ struct ConvKArgs {
     int Cout, CoutPad, out_cstride;
     int nchunks, tiles_x, n_src;
     int tiles_y, n_units;          // wave-autonomous kernel: units = (group set, x tile, y tile)
+    int ablate;                    // debug ablation bits: 1 no epilogue loads/stores, 2 no A restaging, 4 B loads pinned to
+                                   //   step 0, 8 no MFMAs (results invalid; tools/ablate_conv.py)
+    int stagger_ticks;             //   start delay (10 ns ticks) of waves in odd hardware slots: de-phases SIMD partners
     int n_full, col_split;         //   units [0,n_full) are P-row units of columns [0,col_split); the rest are
                                    //   1-row units of the remaining (group set, x tile) columns (balanced tail)
     int elu, fill_pad;
@@ -59,6 +62,63 @@ struct ConvKArgs {
 __device__ __forceinline__ float fast_exp(float x) { return __builtin_amdgcn_exp2f(x * 1.44269504088896341f); }
 __device__ __forceinline__ float elu1(float x) { return x > 0.0f ? x : fast_exp(x) - 1.0f; }
 __device__ __forceinline__ float sigmoidf(float x) { return __builtin_amdgcn_rcpf(1.0f + fast_exp(-x)); }
+
+
+// ------------------------------------------------------------------------------------------
+// The k-steps of one input-channel chunk for one wave, hand-interleaved.
+//
+// A wave issues in order and an MFMA blocks it until the matrix pipe accepts it, so whatever follows a
+// block of back-to-back MFMAs runs while the pipe drains and then idles it.  The first versions of this
+// loop did exactly that ([prefetch loads][16 MFMAs]); an ablation on MI355X (profiles/README.md) showed
+// kernel time = MFMA time + time of the MFMA-free skeleton, i.e. zero overlap, and co-resident waves
+// phase-lock through round-robin arbitration so they do not cover for each other.  Here every
+// prefetch (B fragments of step s+PF from L2, A fragments of step s+1 from LDS) is issued in the
+// shadow of an MFMA of step s: one item right after each of the first T+P MFMAs, pinned with
+// sched_barrier so hipcc cannot sink them.  Register rings are indexed statically (the loop is fully
+// unrolled), so there are no rotation moves.
+//   bq[RING][T]: B ring, slot (step % RING); requires SPC % RING == 0 so slots line up across chunks
+//   bnext(ls)  : wave-uniform pointer to tile 0 of the step that is PF ahead of local step ls
+template <int KS, int S, int IW, int PS, int KK, int P, int T, int PF, int SPC, typename BNext>
+__device__ __forceinline__ void chunk_steps(const float *buf, int abase, int tap0, int lane, floatx16 (&acc)[P][T],
+                                            float4 (&bq)[PF + 1][T], BNext bnext)
+{
+    constexpr int RING = PF + 1;
+    static_assert(SPC % RING == 0, "B ring slots must line up across chunks");
+    float4 aq[2][P];
+    auto a_addr = [&](int ls, int p) {
+        const int tap = tap0 + ls / KK, kk = ls % KK;
+        const int ky = tap / KS, kx = tap % KS;
+        return reinterpret_cast<const float4 *>(buf + abase + ((p * S + ky) * IW + kx) * PS + kk * 8);
+    };
+#pragma unroll
+    for (int p = 0; p < P; ++p) aq[0][p] = *a_addr(0, p);
+    const float4 *nb_next = bnext(0) + lane;
+#pragma unroll
+    for (int ls = 0; ls < SPC; ++ls) {
+        const int cur = ls % RING, nxt = (ls + PF) % RING, ac = ls & 1, an = ac ^ 1;
+        const float4 *nb = nb_next;
+        if (PF == 0) {
+#pragma unroll
+            for (int t = 0; t < T; ++t) bq[0][t] = nb[t * 64];
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int p = 0; p < P; ++p)
+#pragma unroll
+                for (int t = 0; t < T; ++t) {
+                    const float av = j == 0 ? aq[ac][p].x : j == 1 ? aq[ac][p].y : j == 2 ? aq[ac][p].z : aq[ac][p].w;
+                    const float bv = j == 0 ? bq[cur][t].x : j == 1 ? bq[cur][t].y : j == 2 ? bq[cur][t].z : bq[cur][t].w;
+                    acc[p][t] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc[p][t], 0, 0, 0);
+                    const int m = (j * P + p) * T + t;          // one prefetch item in the shadow of MFMA m
+                    if (PF > 0 && m < T) bq[nxt][m] = nb[m * 64];
+                    else if (m >= T && m < T + P && ls + 1 < SPC) aq[an][m - T] = *a_addr(ls + 1, m - T);
+                    else if (m == T + P && ls + 1 < SPC) nb_next = bnext(ls + 1) + lane;   // address math in the shadow too
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+    }
+}
 
 template <int KS, int S, int KC, int P, int QG, int WM, int WN>
 struct Tile {
@@ -165,10 +225,10 @@ __global__ __launch_bounds__(256) void gated_conv_kernel(const ConvKArgs a)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[p][t][r] = 0.0f;
 
-    // B fragments: float4 index (step*NT + nt)*64 + lane.  A ring of PF steps is kept in flight so a
-    // fragment is requested PF k-steps (PF * P*T*4 MFMAs) before its first use.
-    const float4 *wl = reinterpret_cast<const float4 *>(a.wp) + (size_t)nt0 * 64 + lane;
-    // This wave walks local steps ls = (chunk, tap in its TPW-tap share, kk); gstep() maps to the packed order.
+    // B fragments: float4 index (step*NT + nt)*64 + lane, addressed as (wave-uniform pointer) + lane so the
+    // loads take the scalar-base form.  This wave walks local steps ls = (chunk, tap in its TPW-tap share,
+    // kk); gstep() maps them to the packed order.  A static ring keeps PF steps in flight.
+    const float4 *wtile = reinterpret_cast<const float4 *>(a.wp) + (size_t)nt0 * 64;
     constexpr int SPC = TL::TPW * TL::KK;             // local steps per chunk
     const int total_steps = a.nchunks * SPC;
     auto gstep = [&](int ls) {
@@ -176,12 +236,12 @@ __global__ __launch_bounds__(256) void gated_conv_kernel(const ConvKArgs a)
         const int chunk = ls / SPC, rem = ls % SPC;
         return (chunk * KS * KS + wk * TL::TPW + rem / TL::KK) * TL::KK + rem % TL::KK;
     };
-    float4 bq[PF][TL::T];
+    float4 bq[PF + 1][TL::T];
 #pragma unroll
     for (int d = 0; d < PF; ++d) {
-        const int sidx = gstep(d);
+        const float4 *bp = wtile + (size_t)gstep(d) * NT * 64 + lane;
 #pragma unroll
-        for (int t = 0; t < TL::T; ++t) bq[d][t] = wl[((size_t)sidx * NT + t) * 64];
+        for (int t = 0; t < TL::T; ++t) bq[d][t] = bp[t * 64];
     }
 
     gload();
@@ -193,50 +253,13 @@ __global__ __launch_bounds__(256) void gated_conv_kernel(const ConvKArgs a)
     const int abase = ((wm * P) * S * TL::IW + (lane & 31) * S) * TL::PS + 4 * (lane >> 5);
 
     for (int chunk = 0; chunk < a.nchunks; ++chunk) {
-        const bool more = chunk + 1 < a.nchunks;
+        const bool more = chunk + 1 < a.nchunks && !(a.ablate & 2);
         if (more) gload();
         const float *buf = lds + (NBUF == 2 ? (chunk & 1) * TL::BUF : 0);
         const int step0 = chunk * SPC;
-        // A fragments are read one k-step ahead of their MFMAs (LDS latency off the critical path)
-        auto aread = [&](int ls, float4(&dst)[P]) {
-            const int tap = wk * TL::TPW + ls / TL::KK;   // wk == 0 whenever TPW == KS*KS: a constant then
-            const int ky = tap / KS, kx = tap % KS, kk = ls % TL::KK;
-#pragma unroll
-            for (int p = 0; p < P; ++p)
-                dst[p] = *reinterpret_cast<const float4 *>(buf + abase + ((p * S + ky) * TL::IW + kx) * TL::PS + kk * 8);
-        };
-        float4 acur[P], anext[P];
-        aread(0, acur);
-#pragma unroll
-        for (int ls = 0; ls < SPC; ++ls) {
-            float4 b[TL::T];
-#pragma unroll
-            for (int t = 0; t < TL::T; ++t) b[t] = bq[0][t];
-#pragma unroll
-            for (int d = 0; d + 1 < PF; ++d)
-#pragma unroll
-                for (int t = 0; t < TL::T; ++t) bq[d][t] = bq[d + 1][t];
-            // issue the prefetches of later steps FIRST and pin them there: left alone, hipcc sinks
-            // these loads to one MFMA before their first use and every k-step then waits out a full
-            // L2 round trip (seen in the ISA of the first version; MFMA busy 60 %).
-            const int nstep = gstep(step0 + ls + PF);
-#pragma unroll
-            for (int t = 0; t < TL::T; ++t) bq[PF - 1][t] = wl[((size_t)nstep * NT + t) * 64];
-            if (ls + 1 < SPC) aread(ls + 1, anext);
-            __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-            for (int p = 0; p < P; ++p)
-#pragma unroll
-                for (int t = 0; t < TL::T; ++t) {
-                    acc[p][t] = __builtin_amdgcn_mfma_f32_32x32x2f32(acur[p].x, b[t].x, acc[p][t], 0, 0, 0);
-                    acc[p][t] = __builtin_amdgcn_mfma_f32_32x32x2f32(acur[p].y, b[t].y, acc[p][t], 0, 0, 0);
-                    acc[p][t] = __builtin_amdgcn_mfma_f32_32x32x2f32(acur[p].z, b[t].z, acc[p][t], 0, 0, 0);
-                    acc[p][t] = __builtin_amdgcn_mfma_f32_32x32x2f32(acur[p].w, b[t].w, acc[p][t], 0, 0, 0);
-                }
-            __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-            for (int p = 0; p < P; ++p) acur[p] = anext[p];
-        }
+        chunk_steps<KS, S, TL::IW, TL::PS, TL::KK, P, TL::T, PF, SPC>(
+            buf, abase, TL::WK == 1 ? 0 : wk * TL::TPW, lane, acc, bq,
+            [&](int ls) { return wtile + (size_t)gstep(step0 + ls + PF) * NT * 64; });
         if (NBUF == 2) {
             if (more) lwrite(lds + ((chunk + 1) & 1) * TL::BUF);
             __syncthreads();
@@ -298,7 +321,8 @@ __global__ __launch_bounds__(256) void gated_conv_kernel(const ConvKArgs a)
                 const int opix = oy * a.outW + ox;
                 ooff[rr] = (in & c_st) ? (opix * a.out_cstride + c) * 4 : OOB;
                 const int roff = (in & c_ok) ? (opix * a.Cout + c) * 4 : OOB;
-                rv[rr] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rrsrc, roff, 0, 0));
+                rv[rr] = (a.ablate & 1) ? 0.0f : __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rrsrc, roff, 0, 0));
+                if ((a.ablate & 1) && !(in && oy == 0 && ox == 0)) ooff[rr] = OOB;      // one store per tile keeps the math live
             }
 #pragma unroll
             for (int rr = 0; rr < TL::NR; ++rr) {
@@ -372,6 +396,16 @@ __global__ __launch_bounds__(256, (P * QG >= 2 ? 2 : 3)) void gated_conv_wave_ke
     const int NT = a.CoutPad >> 4;
     const int total_steps = a.nchunks * SPC;
     if (gw >= a.n_units) return;
+    if (a.stagger_ticks > 0) {
+        // Waves sharing a SIMD do identical work and would stay in lockstep for the whole launch: both
+        // in their epilogue (MFMA pipe idle) at the same moments.  Delay the odd hardware wave slot once;
+        // its partner runs alone at full MFMA rate meanwhile, so nothing is lost.
+        const unsigned hw = __builtin_amdgcn_s_getreg((31 << 11) | 4);     // HW_REG_HW_ID, WAVE_ID = bits 3:0
+        if (hw & 1u) {
+            const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+            while (__builtin_amdgcn_s_memrealtime() - t0 < (unsigned long long)a.stagger_ticks) __builtin_amdgcn_s_sleep(20);
+        }
+    }
 
     // unit -> tile origin, channel-group set and number of valid rows (P for full units, 1 for tail units)
     auto unit_coords = [&](int u, int &ox0, int &oy0, int &gs, int &nrows) {
@@ -442,7 +476,7 @@ __global__ __launch_bounds__(256, (P * QG >= 2 ? 2 : 3)) void gated_conv_wave_ke
         staged = false;
     };
 
-    const float4 *wp4 = reinterpret_cast<const float4 *>(a.wp) + lane;
+    const float4 *wp4base = reinterpret_cast<const float4 *>(a.wp);
     const int abase = ((lane & 31) * S) * PS + 4 * (lane >> 5);
     constexpr int OOB = 0x7ffffff0;
     const int hi = lane >> 5;
@@ -455,16 +489,16 @@ __global__ __launch_bounds__(256, (P * QG >= 2 ? 2 : 3)) void gated_conv_wave_ke
     gload();
     lwrite();
     if (lu < a.n_units) gload();
-    float4 bq[PF][T];
+    float4 bq[PF + 1][T];
     {
         int ox0, oy0, gs, nr;
         unit_coords(gw, ox0, oy0, gs, nr);
-        const float4 *wl = wp4 + (size_t)gs * T * 64;
+        const float4 *wl = wp4base + (size_t)gs * T * 64;
 #pragma unroll
         for (int d = 0; d < PF; ++d) {
             const int sidx = d < total_steps ? d : total_steps - 1;
 #pragma unroll
-            for (int t = 0; t < T; ++t) bq[d][t] = wl[((size_t)sidx * NT + t) * 64];
+            for (int t = 0; t < T; ++t) bq[d][t] = wl[((size_t)sidx * NT + t) * 64 + lane];
         }
     }
 
@@ -472,8 +506,8 @@ __global__ __launch_bounds__(256, (P * QG >= 2 ? 2 : 3)) void gated_conv_wave_ke
         int ox0, oy0, gs, nrows, nox0, noy0, ngs, nnr;
         unit_coords(u, ox0, oy0, gs, nrows);
         unit_coords(u + nw < a.n_units ? u + nw : u, nox0, noy0, ngs, nnr);
-        const float4 *wl = wp4 + (size_t)gs * T * 64;
-        const float4 *wl_next = wp4 + (size_t)ngs * T * 64;   // the B ring runs ahead into the next unit
+        const float4 *wl = wp4base + (size_t)gs * T * 64;
+        const float4 *wl_next = wp4base + (size_t)ngs * T * 64;   // the B ring runs ahead into the next unit
 
         floatx16 acc[P][T];
 #pragma unroll
@@ -485,51 +519,15 @@ __global__ __launch_bounds__(256, (P * QG >= 2 ? 2 : 3)) void gated_conv_wave_ke
 
         for (int chunk = 0; chunk < a.nchunks; ++chunk) {
             const int step0 = chunk * SPC;
-            auto aread = [&](int ls, float4(&dst)[P]) {
-                const int tap = ls / KK, kk = ls % KK;
-                const int ky = tap / KS, kx = tap % KS;
-#pragma unroll
-                for (int p = 0; p < P; ++p)
-                    dst[p] = *reinterpret_cast<const float4 *>(lds + abase + ((p * S + ky) * IW + kx) * PS + kk * 8);
-            };
-            float4 acur[P], anext[P];
-            aread(0, acur);
-#pragma unroll
-            for (int ls = 0; ls < SPC; ++ls) {
-                float4 b[T];
-#pragma unroll
-                for (int t = 0; t < T; ++t) b[t] = bq[0][t];
-#pragma unroll
-                for (int d = 0; d + 1 < PF; ++d)
-#pragma unroll
-                    for (int t = 0; t < T; ++t) bq[d][t] = bq[d + 1][t];
-                {   // prefetch PF steps ahead, pinned in front of the MFMA block (see the kernel above)
-                    int nstep = step0 + ls + PF;
-                    const float4 *base = wl;
-                    if (nstep >= total_steps) {
-                        nstep -= total_steps;
-                        base = wl_next;
-                    }
-#pragma unroll
-                    for (int t = 0; t < T; ++t) bq[PF - 1][t] = base[((size_t)nstep * NT + t) * 64];
+            chunk_steps<KS, S, IW, PS, KK, P, T, PF, SPC>(lds, abase, 0, lane, acc, bq, [&](int ls) {
+                int nstep = step0 + ls + PF;
+                const float4 *base = wl;
+                if (nstep >= total_steps) {          // ring runs ahead into this wave's next unit
+                    nstep -= total_steps;
+                    base = wl_next;
                 }
-                if (ls + 1 < SPC) aread(ls + 1, anext);
-                __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-                for (int p = 0; p < P; ++p) {
-                    if (p > 0 && p >= nrows) continue;      // tail unit: only its first row is real work (uniform)
-#pragma unroll
-                    for (int t = 0; t < T; ++t) {
-                        acc[p][t] = __builtin_amdgcn_mfma_f32_32x32x2f32(acur[p].x, b[t].x, acc[p][t], 0, 0, 0);
-                        acc[p][t] = __builtin_amdgcn_mfma_f32_32x32x2f32(acur[p].y, b[t].y, acc[p][t], 0, 0, 0);
-                        acc[p][t] = __builtin_amdgcn_mfma_f32_32x32x2f32(acur[p].z, b[t].z, acc[p][t], 0, 0, 0);
-                        acc[p][t] = __builtin_amdgcn_mfma_f32_32x32x2f32(acur[p].w, b[t].w, acc[p][t], 0, 0, 0);
-                    }
-                }
-                __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-                for (int p = 0; p < P; ++p) acur[p] = anext[p];
-            }
+                return base + (size_t)nstep * NT * 64;
+            });
             // this wave's reads of the tile are done (their data fed the MFMAs above): restage
             if (staged) {
                 lwrite();
@@ -628,16 +626,15 @@ const ConvConfig g_configs[] = {
     CFGNM(3, 1, 16, 1, 1, 4, 1, 2, 1),  // 10  4x32 px, single buffer: best at <= 2 channel groups
     CFGNM(3, 1, 16, 2, 1, 2, 2, 2, 1),  // 11  4x32 px x 2 groups, single buffer: best at 8 groups
     // 3x3 stride 1, 8-channel chunks (inputs straight from the 8-channel pyramid)
-    CFG(3, 1, 8, 2, 1, 4, 1, 1),    //  9
-    CFG(3, 1, 8, 1, 1, 4, 1, 1),    // 10
+    CFG(3, 1, 8, 2, 1, 4, 1, 2),    //  9
+    CFG(3, 1, 8, 1, 1, 4, 1, 2),    // 10
     // 1x1, 16-channel chunks (SCM, AFF first conv, Convs)
     CFG(1, 1, 16, 2, 1, 4, 1, 1),   // 11
     CFG(1, 1, 16, 1, 1, 4, 1, 1),   // 12
     CFG(1, 1, 16, 2, 2, 2, 2, 1),   // 13
-    CFG(1, 1, 16, 2, 1, 4, 1, 2),   // 14
     // 1x1, 8-channel chunks (SCM tail: cat[x(8), main(P-8)])
-    CFG(1, 1, 8, 2, 1, 4, 1, 1),    // 15
-    CFG(1, 1, 8, 1, 1, 4, 1, 1),    // 16
+    CFG(1, 1, 8, 2, 1, 4, 1, 0),    // 15
+    CFG(1, 1, 8, 1, 1, 4, 1, 0),    // 16
     // 3x3 stride 2 (encoder downsampling)
     CFG(3, 2, 16, 1, 1, 4, 1, 1),   // 17
     CFG(3, 2, 16, 1, 2, 2, 2, 1),   // 18
@@ -646,9 +643,9 @@ const ConvConfig g_configs[] = {
     CFGW(3, 1, 16, 2, 1, 1, 2),
     CFGW(3, 1, 16, 2, 1, 2, 2),
     CFGW(3, 1, 16, 1, 1, 2, 3),
-    CFGW(1, 1, 16, 2, 1, 2, 2),
-    CFGW(1, 1, 16, 1, 1, 2, 4),
-    CFGW(3, 1, 8, 2, 1, 1, 2),
+    CFGW(1, 1, 16, 2, 1, 1, 2),
+    CFGW(1, 1, 16, 1, 1, 1, 4),
+    CFGW(3, 1, 8, 2, 1, 2, 2),
     // 4x4 stride 2 (decoder, before the bilinear x4): outputs are 1/4 .. 1/16 scale, so the 16 taps of
     // ONE 1x32-pixel tile are split over the four waves (split-K, WM*WN == 1) to fill the chip
     CFG(4, 2, 16, 1, 1, 1, 1, 1),   // 20  split-K, one group
@@ -672,7 +669,9 @@ int find_config(int ks, int s, int kc, int P, int QG, int WM, int WN, int PF, in
 //   3x3/s1, 16-ch chunks:  <= 2 channel groups -> 4x32-px tiles, single LDS buffer (4 workgroups per CU);
 //                          4 groups -> 4x32 px x 2 groups per wave pair; 8 groups -> 4x32 px x 2 groups, single buffer
 //   1x1:                   1 group -> 8x32 px with B prefetch depth 2; more -> 4x32 px
-int g_prefer_wave = 0;   // read_tuning_set("conv_wave", 1): wave-autonomous kernels where they exist
+int g_prefer_wave = 0;
+int g_stagger_ticks = 0;
+int g_ablate = 0;          // read_tuning_set("conv_ablate", bits)   // read_tuning_set("conv_stagger", ticks of 10 ns)   // read_tuning_set("conv_wave", 1): wave-autonomous kernels where they exist
 
 int find_wave_config(int ks, int s, int kc, int P, int QG)
 {
@@ -698,7 +697,7 @@ int pick_config(int ks, int s, int kc, int groups, int outH, int outW)
         else if (groups % 4 == 0) c = find_config(3, 1, 16, 2, 2, 2, 2, 1, 2);
         else c = find_config(3, 1, 16, 1, 1, 4, 1, 2, 1);
     } else if (ks == 1 && s == 1 && kc == 16) {
-        c = groups == 1 ? find_config(1, 1, 16, 2, 1, 4, 1, 2, 2) : find_config(1, 1, 16, 1, 1, 4, 1, 1, 2);
+        c = groups == 1 ? find_config(1, 1, 16, 2, 1, 4, 1, 1, 2) : find_config(1, 1, 16, 1, 1, 4, 1, 1, 2);
     }
     if (c >= 0) return c;
     for (int i = 0; i < N_CONFIGS; ++i) {
@@ -811,6 +810,8 @@ extern "C" int read_conv_pack_params_host(int Cout, const float *bf, const float
 namespace readhip {
 
 void conv_set_prefer_wave(int v) { g_prefer_wave = v; }
+void conv_set_stagger(int ticks) { g_stagger_ticks = ticks < 0 ? 0 : ticks; }
+void conv_set_ablate(int bits) { g_ablate = bits; }
 
 static unsigned long long *g_trace = nullptr;
 static size_t g_trace_records = 0;
@@ -897,6 +898,7 @@ int launch_gated_conv(const read_conv_desc *d, hipStream_t stream)
     a.nchunks = nchunks;
     a.tiles_x = ceil_div(outW, 32);
     a.elu = d->elu;
+    a.ablate = g_ablate;
     a.fill_pad = d->fill_pad;
     a.out_fill = d->out_fill;
     const int tiles_y = ceil_div(outH, c.WM * c.P);
@@ -919,12 +921,11 @@ int launch_gated_conv(const read_conv_desc *d, hipStream_t stream)
         const int ncol = a.tiles_x * (groups / c.QG);
         const long slots = (long)n_cu * c.wg_per_cu * 4;
         const long unitsP = (long)ncol * a.tiles_y;
-        int col_split = ncol;
-        if (c.P > 1) {
-            const long rounds = unitsP / slots;
-            col_split = (int)((rounds * slots) / a.tiles_y);
-            if (col_split > ncol) col_split = ncol;
-        }
+        // (a balanced tail of 1-row units was tried and measured neutral-to-negative; all units are P rows)
+        (void)slots;
+        (void)unitsP;
+        const int col_split = ncol;
+        a.stagger_ticks = g_stagger_ticks;
         a.col_split = col_split;
         a.n_full = col_split * a.tiles_y;
         a.n_units = a.n_full + (ncol - col_split) * outH;

@@ -18,6 +18,7 @@ for s in $STEPS; do
     trace)  run trace 300 bash -c "python tools/trace_conv.py --shape L0 --configs 0,10 --out $O/${TAG}_trace; python tools/trace_conv.py --shape L1 --configs 10 --out $O/${TAG}_trace; python tools/trace_conv.py --shape L2 --configs 4 --out $O/${TAG}_trace; python tools/trace_conv.py --shape L3 --configs 11 --out $O/${TAG}_trace" ;;
     benchw) run benchw 500 python bench.py --steps 20 --warmup 3 --no-cpu-baseline --tune conv_wave=1 --detail "$O/${TAG}_detailw.json" ;;
     pytestw) run pytestw 600 env READ_CONV_WAVE=1 python -m pytest tests/test_gpu_unet.py tests/test_gpu_api.py -m gpu -q --timeout 600 -p no:cacheprovider -s ;;
+    stagger) for t in 0 400 800 1600; do run stagger$t 200 python tools/sweep_conv.py --shapes 4 --only wave --tune conv_stagger=$t --iters 10 --out "$O/${TAG}_stagger$t.json"; done ;;
     bench)  run bench 500 python bench.py --steps 20 --warmup 3 --detail "$O/${TAG}_detail.json" ;;
     prof)   ( cd /tmp && timeout 400 rocprofv3 --kernel-trace --stats -d "$O/${TAG}_prof" -o bench -- python "$R/bench.py" --steps 5 --warmup 2 --no-cpu-baseline ) > "$O/${TAG}_prof.log" 2>&1; echo "rc=$?" >> "$O/${TAG}_prof.log"; tail -n 3 "$O/${TAG}_prof.log"
             find "$O/${TAG}_prof" -name "*kernel_stats*" | head -3 ;;

@@ -41,10 +41,18 @@ def main():
     ap.add_argument("--out", default="gpurun_out/sweep_conv.json")
     ap.add_argument("--iters", type=int, default=5)
     ap.add_argument("--main-only", action="store_true", help="only the four dominant 3x3 shapes, automatic config")
+    ap.add_argument("--only", default="", help="substring a config name must contain")
+    ap.add_argument("--shapes", type=int, default=0, help="first N shapes only")
+    ap.add_argument("--tune", default="", help="key=value[,key=value] for read_tuning_set")
     a = ap.parse_args()
     names = config_names()
+    if a.tune:
+        from read_amd import _lib
+        for kv in a.tune.split(","):
+            k_, v_ = kv.split("=")
+            _lib.check(_lib.lib().read_tuning_set(k_.encode(), int(v_)))
     res = []
-    shapes = SHAPES[:4] if a.main_only else SHAPES
+    shapes = SHAPES[:4] if a.main_only else (SHAPES[:a.shapes] if a.shapes else SHAPES)
     for (label, srcs, cout, k, s, oh, ow) in shapes:
         cin = sum(c for c, _ in srcs)
         kc = 8 if any(c % 16 for c, _ in srcs) else 16
@@ -71,7 +79,7 @@ def main():
                 continue
             m = re.match(r"k(\d)s(\d)c(\d+)_(?:wave_)?p(\d)q(\d)(?:m(\d)n(\d))?", name)
             ks, ss, kcc, P, QG, WM, WN = (int(g) if g is not None else 1 for g in m.groups())
-            if (ks, ss, kcc) != (k, s, kc) or groups % (WN * QG):
+            if (ks, ss, kcc) != (k, s, kc) or groups % (WN * QG) or a.only not in name:
                 continue
             try:
                 for _ in range(2):
