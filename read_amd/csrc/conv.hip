@@ -665,11 +665,7 @@ int find_config(int ks, int s, int kc, int P, int QG, int WM, int WN, int PF, in
     return -1;
 }
 
-// Automatic choice, from the measured sweeps on MI355X at 1216x352 (profiles/README.md):
-//   3x3/s1, 16-ch chunks:  <= 2 channel groups -> 4x32-px tiles, single LDS buffer (4 workgroups per CU);
-//                          4 groups -> 4x32 px x 2 groups per wave pair; 8 groups -> 4x32 px x 2 groups, single buffer
-//   1x1:                   1 group -> 8x32 px with B prefetch depth 2; more -> 4x32 px
-int g_prefer_wave = 0;
+int g_prefer_wave = 1;   // read_tuning_set("conv_wave", 0): workgroup-tiled kernels only
 int g_stagger_ticks = 0;
 int g_ablate = 0;          // read_tuning_set("conv_ablate", bits)   // read_tuning_set("conv_stagger", ticks of 10 ns)   // read_tuning_set("conv_wave", 1): wave-autonomous kernels where they exist
 
@@ -683,23 +679,31 @@ int find_wave_config(int ks, int s, int kc, int P, int QG)
     return best;
 }
 
+// Automatic choice = the measured-best entry per layer family on MI355X at 1216x352
+// (profiles/README.md, sweep r1k).  read_tuning_set("conv_wave", 0) restricts it to the workgroup-tiled
+// kernels (A/B runs).
 int pick_config(int ks, int s, int kc, int groups, int outH, int outW)
 {
+    (void)outH;
+    (void)outW;
     int c = -1;
-    if (g_prefer_wave) {
-        // 2-row units while they still give every wave slot (256 CUs x 2 WGs x 4 waves) >= 2 units, else 1-row units
-        c = find_wave_config(ks, s, kc, 2, 1);      // 2-row units, balanced 1-row tail
-        if (c < 0) c = find_wave_config(ks, s, kc, 1, 1);
-        if (c >= 0) return c;
-    }
     if (ks == 3 && s == 1 && kc == 16) {
-        if (groups % 8 == 0) c = find_config(3, 1, 16, 2, 1, 2, 2, 2, 1);
-        else if (groups % 4 == 0) c = find_config(3, 1, 16, 2, 2, 2, 2, 1, 2);
+        if (groups % 4 == 0 && groups % 8 != 0) c = find_config(3, 1, 16, 2, 2, 2, 2, 1, 2);     // 128 ch: 108.8 TF
+        else if (g_prefer_wave) c = find_wave_config(3, 1, 16, 1, 1);                               // 104-117 TF
+        else if (groups % 8 == 0) c = find_config(3, 1, 16, 2, 1, 2, 2, 2, 1);
         else c = find_config(3, 1, 16, 1, 1, 4, 1, 2, 1);
+    } else if (ks == 3 && s == 1 && kc == 8) {
+        c = g_prefer_wave ? find_wave_config(3, 1, 8, 2, 1) : find_config(3, 1, 8, 1, 1, 4, 1, 2, 2);
     } else if (ks == 1 && s == 1 && kc == 16) {
-        c = groups == 1 ? find_config(1, 1, 16, 2, 1, 4, 1, 1, 2) : find_config(1, 1, 16, 1, 1, 4, 1, 1, 2);
+        if (groups % 4 == 0) c = find_config(1, 1, 16, 2, 2, 2, 2, 1, 2);
+        else if (g_prefer_wave) c = find_wave_config(1, 1, 16, groups == 1 ? 2 : 1, 1);
+        else c = groups == 1 ? find_config(1, 1, 16, 2, 1, 4, 1, 1, 2) : find_config(1, 1, 16, 1, 1, 4, 1, 1, 2);
+    } else if (ks == 3 && s == 2) {
+        c = groups % 4 == 0 ? find_config(3, 2, 16, 1, 2, 2, 2, 1, 2) : find_config(3, 2, 16, 1, 2, 4, 1, 1, 2);
+    } else if (ks == 4 && s == 2) {
+        c = groups == 1 ? find_config(4, 2, 16, 1, 1, 4, 1, 1, 2) : find_config(4, 2, 16, 1, 1, 1, 1, 1, 2);
     }
-    if (c >= 0) return c;
+    if (c >= 0 && groups % (g_configs[c].WN * g_configs[c].QG) == 0) return c;
     for (int i = 0; i < N_CONFIGS; ++i) {
         const ConvConfig &k = g_configs[i];
         if (k.KS == ks && k.S == s && k.KC == kc && groups % (k.WN * k.QG) == 0) return i;

@@ -20,9 +20,10 @@ for s in $STEPS; do
     pytestw) run pytestw 600 env READ_CONV_WAVE=1 python -m pytest tests/test_gpu_unet.py tests/test_gpu_api.py -m gpu -q --timeout 600 -p no:cacheprovider -s ;;
     stagger) for t in 0 400 800 1600; do run stagger$t 200 python tools/sweep_conv.py --shapes 4 --only wave --tune conv_stagger=$t --iters 10 --out "$O/${TAG}_stagger$t.json"; done ;;
     bench)  run bench 500 python bench.py --steps 20 --warmup 3 --detail "$O/${TAG}_detail.json" ;;
-    prof)   ( cd /tmp && timeout 400 rocprofv3 --kernel-trace --stats -d "$O/${TAG}_prof" -o bench -- python "$R/bench.py" --steps 5 --warmup 2 --no-cpu-baseline ) > "$O/${TAG}_prof.log" 2>&1; echo "rc=$?" >> "$O/${TAG}_prof.log"; tail -n 3 "$O/${TAG}_prof.log"
+    prof)   ( cd /tmp && timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d "$O/${TAG}_prof" -o bench -- python "$R/bench.py" --steps 5 --warmup 2 --no-cpu-baseline ) > "$O/${TAG}_prof.log" 2>&1; echo "rc=$?" >> "$O/${TAG}_prof.log"; tail -n 3 "$O/${TAG}_prof.log"
             find "$O/${TAG}_prof" -name "*kernel_stats*" | head -3 ;;
     pmcconv) ( cd /tmp && timeout 300 rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_WAIT_INST_LDS SQ_BUSY_CYCLES GRBM_GUI_ACTIVE -d "$O/${TAG}_pmc_mfma" -o conv -- python "$R/tools/sweep_conv.py" --main-only --iters 2 --out "$O/${TAG}_pmc_sweep.json" ) > "$O/${TAG}_pmc_mfma.log" 2>&1; echo "rc=$?" >> "$O/${TAG}_pmc_mfma.log"; tail -n 2 "$O/${TAG}_pmc_mfma.log" ;;
+    pmctraffic) for cnt in FETCH_SIZE WRITE_SIZE; do ( cd /tmp && timeout 300 rocprofv3 --kernel-trace --pmc $cnt --output-format csv -d "$O/${TAG}_pmc_$cnt" -o bench -- python "$R/bench.py" --steps 2 --warmup 1 --no-cpu-baseline ) > "$O/${TAG}_pmc_$cnt.log" 2>&1; echo "rc=$?" >> "$O/${TAG}_pmc_$cnt.log"; done; find "$O" -name "*counter_collection.csv" | head ;;
     pmc)    ( cd /tmp && timeout 120 rocprofv3 -L > "$O/${TAG}_counters.txt" 2>&1 )
             ( cd /tmp && timeout 300 rocprofv3 --kernel-trace --pmc FETCH_SIZE -d "$O/${TAG}_pmc_fetch" -o splat -- python "$R/tools/splat_modes.py" --out "$O/${TAG}_pmc_splat.json" ) > "$O/${TAG}_pmc_fetch.log" 2>&1; echo "rc=$?" >> "$O/${TAG}_pmc_fetch.log"
             ( cd /tmp && timeout 300 rocprofv3 --kernel-trace --pmc WRITE_SIZE -d "$O/${TAG}_pmc_write" -o splat -- python "$R/tools/splat_modes.py" --out "$O/${TAG}_pmc_splat.json" ) > "$O/${TAG}_pmc_write.log" 2>&1; echo "rc=$?" >> "$O/${TAG}_pmc_write.log" ;;

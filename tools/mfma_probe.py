@@ -11,9 +11,9 @@ from read_amd import _lib  # noqa: E402
 L = _lib.lib()
 scratch = torch.zeros(256 * 8192, device="cuda")
 res = []
-for nacc in (4, 2):
-    for wg_per_cu in (1, 2, 4):
-        for iters in (2000, 20000, 200000):
+for nacc in (4, -4):
+    for wg_per_cu in (2,):
+        for iters in (2000, 20000, 100000):
             blocks = 256 * wg_per_cu
             for _ in range(2):
                 _lib.check(L.read_debug_mfma_probe(blocks, 200, nacc, scratch.data_ptr(), _lib.stream_ptr()))
@@ -24,7 +24,7 @@ for nacc in (4, 2):
             e1.record()
             e1.synchronize()
             ms = e0.elapsed_time(e1)
-            flops = blocks * 4 * iters * nacc * 4 * 4096.0
+            flops = blocks * 4 * iters * abs(nacc) * 4 * 4096.0
             row = {"nacc": nacc, "wg_per_cu": wg_per_cu, "iters": iters, "ms": ms, "tflops": flops / ms / 1e9}
             print(row, flush=True)
             res.append(row)

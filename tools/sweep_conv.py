@@ -44,6 +44,7 @@ def main():
     ap.add_argument("--only", default="", help="substring a config name must contain")
     ap.add_argument("--shapes", type=int, default=0, help="first N shapes only")
     ap.add_argument("--tune", default="", help="key=value[,key=value] for read_tuning_set")
+    ap.add_argument("--fill", default="randn", help="input data: randn | zeros | ones (DVFS sensitivity)")
     a = ap.parse_args()
     names = config_names()
     if a.tune:
@@ -66,7 +67,12 @@ def main():
         for c, sh in srcs:
             hh = (ih << sh) if sh > 0 else (ih >> -sh)
             ww = (iw << sh) if sh > 0 else (iw >> -sh)
-            xs.append((torch.randn(hh, ww, c, device="cuda"), sh))
+            t = torch.randn(hh, ww, c, device="cuda")
+            if a.fill == "zeros":
+                t.zero_()
+            elif a.fill == "ones":
+                t.fill_(1.0)
+            xs.append((t, sh))
         out = torch.empty(oh, ow, cout, device="cuda")
         groups = (cout + 31) // 32
         flops = 4.0 * oh * ow * cout * cin * k * k
