@@ -56,6 +56,23 @@ def hip_time_ms(fn, iters):
     return e0.elapsed_time(e1) / iters
 
 
+def profiled_traffic():
+    """HBM bytes per launch of the dominant kernel family from the committed rocprofv3 PMC passes
+    (profiles/r1_traffic.json: separate FETCH_SIZE / WRITE_SIZE runs of this same command, FETCH_SIZE x2 as
+    MI355X_MICROARCH.md prescribes for gfx950, factor re-derived there from a kernel of known byte count)."""
+    path = os.path.join(ROOT, "profiles", "r1_traffic.json")
+    try:
+        ks = json.load(open(path))["kernels"]
+    except (OSError, ValueError, KeyError):
+        return None
+    n = tot = 0
+    for name, v in ks.items():
+        if name.startswith("gated_conv") and "<3, 1, 16" in name:
+            n += v["launches"]
+            tot += (v["read_bytes"] + v["write_bytes"]) * v["launches"]
+    return tot / n if n else None
+
+
 def cpu_baseline(xyz, desc, state, proj, frames):
     """The oracle (CPU restatement of the reference path) on this box's host cores: bounded sample."""
     import oracle
@@ -188,7 +205,8 @@ def main():
             "roofline": {
                 "kernel": "gated_conv_kernel 3x3/s1 C->C (v_mfma_f32_32x32x2_f32)", "bound": "mfma",
                 "achieved": achieved_tfs, "peak": FP32_MFMA_PEAK_TFS, "unit": "TFLOP/s",
-                "frac": achieved_tfs / FP32_MFMA_PEAK_TFS, "traffic": None,
+                "frac": achieved_tfs / FP32_MFMA_PEAK_TFS, "traffic": profiled_traffic(),
+                "traffic_unit": "HBM bytes per launch (rocprofv3 FETCH_SIZE*2 + WRITE_SIZE, profiles/r1_traffic.json)",
                 "launches_per_frame": n_c3, "avg_launch_ms": c3_ms / max(n_c3, 1),
                 "flops_per_frame": c3_fl},
             "stages": {
