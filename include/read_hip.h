@@ -52,9 +52,10 @@ int read_abi_version(void);
 /* Fills name[0..len) with the gfx arch of the current device ("gfx950"); READ_EHIP without a GPU. */
 int read_device_arch(char *name, int len);
 
-/* Measurement knobs (A/B runs on the GPU box).  "splat_mode": 1 (default) one key image with
- * agent-scope atomics and L1-bypassing early-z reads, 0 per-XCD key images, 3 system-scope early-z;
- * 2/4/5/6 are attribution probes whose results are invalid (see csrc/splat.hip). */
+/* Measurement knobs (A/B runs on the GPU box).  "splat_mode": 7 (default) warm start + LDS hierarchical-Z
+ * in front of 1 = one key image with agent-scope atomics and L1-bypassing early-z reads; 0 per-XCD key
+ * images, 3 system-scope early-z; 2/4/5/6 are attribution probes whose results are invalid (csrc/splat.hip).
+ * "conv_wave" 0/1, "conv_stagger" ticks, "conv_ablate" bits: see csrc/conv.hip. */
 int read_tuning_set(const char *key, int value);
 /* Debug timeline of the following gated-conv launches: 64 bytes per workgroup in `buf` (device):
  * s_memrealtime at entry / after prologue / after the k-loop / at exit, HW_ID, XCC_ID, blockIdx.x/y.
@@ -67,7 +68,10 @@ int read_debug_mfma_probe(int blocks, int iters, int nacc, float *scratch, void 
 
 /* ---------------------------------------------------------------- rasteriser (z-buffer splat) */
 
-/* Bytes of the persistent key images: min(B,8) cameras x 8 XCDs x W*H x 8 (depth_bits<<32 | point_id). */
+/* Bytes of the persistent rasteriser state for ONE (B, W, H): a 256-byte header, the key images
+ * (min(B,8) cameras x 8 x W*H x 8 B, depth_bits<<32 | point_id), the hierarchical-Z bound image and the
+ * previous frame's winners (warm start of the next frame).  A workspace serves the (B, W, H) it was sized
+ * for; re-run read_splat_workspace_init before using it with another size. */
 size_t read_splat_workspace_bytes(int B, int W, int H);
 /* Must be called once on a fresh workspace (sets every key to EMPTY).  read_splat_forward
  * leaves the workspace EMPTY again, so consecutive frames need no further clears. */

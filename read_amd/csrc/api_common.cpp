@@ -56,7 +56,7 @@ extern "C" int read_tuning_set(const char *key, int value)
     READ_CHECK_ARG(key, "read_tuning_set: null key");
     if (!strcmp(key, "splat_mode")) {
         const int rc = readhip::splat_set_mode(value);
-        if (rc) readhip::set_error("read_tuning_set: splat_mode must be 0..6");
+        if (rc) readhip::set_error("read_tuning_set: splat_mode must be 0..7");
         return rc;
     }
     if (!strcmp(key, "conv_ablate")) {

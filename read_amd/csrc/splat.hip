@@ -35,7 +35,7 @@ typedef unsigned long long __attribute__((address_space(1))) *gkey_ptr;
 
 // point_render.cu:135-147 for one point and one camera; returns the pixel or -1.
 __device__ __forceinline__ int project_one(float x, float y, float z, const float *M, int W, int H,
-                                           float &depth)
+                                           float &depth, int &xx_out, int &yy_out)
 {
     const float c0 = M[0] * x + M[1] * y + M[2] * z + M[3] * 1.0f;
     const float c1 = M[4] * x + M[5] * y + M[6] * z + M[7] * 1.0f;
@@ -50,6 +50,8 @@ __device__ __forceinline__ int project_one(float x, float y, float z, const floa
     depth = (nz + 1.0f) * 0.5f;
     const int xx = (int)u, yy = (int)v;
     const bool ok = inside & (xx >= 0) & (xx < W) & (yy >= 0) & (yy < H);
+    xx_out = xx;
+    yy_out = yy;
     return ok ? yy * W + xx : -1;
 }
 
@@ -67,7 +69,15 @@ __device__ __forceinline__ int project_one(float x, float y, float z, const floa
 //              the XCD L2 too, so the filter is exact but every read crosses the fabric).
 //   MODE_PEEK / MODE_PEEK_L1 / MODE_ATOM  attribution probes (invalid results): early-z reads only (sc1 /
 //              plain L1-cached), and atomics only (no early-z filter).
-enum { MODE_XCD = 0, MODE_AGENT = 1, MODE_NOZ = 2, MODE_SYS = 3, MODE_PEEK = 4, MODE_PEEK_L1 = 5, MODE_ATOM = 6 };
+//   MODE_HIZ   (default) MODE_AGENT plus a temporal warm start and a hierarchical-Z reject that lives in LDS:
+//              before the point pass the previous frame's per-pixel winners are re-projected with the new
+//              camera and folded in, a conservative far bound per 4x4-pixel block (max of the current depths,
+//              +inf if any pixel is empty) is built, and every workgroup copies that bound image (107 KB at
+//              1216x352) into LDS.  A point whose depth exceeds its block's bound cannot win (keys only
+//              decrease), so it is dropped without touching global memory — ~90 % of the points of a frame.
+//              Exact: seeds are real points of this cloud, bounds are upper bounds of the final depths.
+enum { MODE_XCD = 0, MODE_AGENT = 1, MODE_NOZ = 2, MODE_SYS = 3, MODE_PEEK = 4, MODE_PEEK_L1 = 5, MODE_ATOM = 6,
+       MODE_HIZ = 7 };
 constexpr int XCD_COPIES = 8;
 
 __device__ __forceinline__ unsigned xcc_id()
@@ -99,15 +109,22 @@ __device__ __forceinline__ void fold_key(unsigned long long *k, unsigned long lo
 template <int MODE, int NP>
 __device__ __forceinline__ void splat_points(const float (&px)[NP], const float (&py)[NP], const float (&pz)[NP],
                                              unsigned id0, int nvalid, const float *M, int W, int H,
-                                             unsigned long long *keys, unsigned &sink)
+                                             unsigned long long *keys, unsigned &sink, const float *hiz = nullptr,
+                                             int nbx = 0)
 {
     int pix[NP];
     unsigned long long key[NP], seen[NP];
 #pragma unroll
     for (int k = 0; k < NP; ++k) {
         float d;
-        pix[k] = project_one(px[k], py[k], pz[k], M, W, H, d);
+        int xx, yy;
+        pix[k] = project_one(px[k], py[k], pz[k], M, W, H, d, xx, yy);
         if (k >= nvalid) pix[k] = -1;
+        if (MODE == MODE_HIZ) {
+            // LDS-resident far bound of the point's 4x4 block; strictly greater cannot win (ties must pass)
+            const float bound = hiz[pix[k] >= 0 ? (yy >> 2) * nbx + (xx >> 2) : 0];
+            if (d > bound) pix[k] = -1;
+        }
         key[k] = ((unsigned long long)__float_as_uint(d) << 32) | (id0 + k);
     }
     if (MODE == MODE_NOZ) {
@@ -176,6 +193,83 @@ __global__ __launch_bounds__(256) void splat_project_kernel(const float *__restr
         *sink_out = sink;                                                       // keeps the probes live
 }
 
+
+// ---- MODE_HIZ pieces ------------------------------------------------------------------------------
+struct SplatHeader {          // first 256 bytes of the workspace
+    int valid, W, H, pad;
+};
+constexpr size_t HEADER_BYTES = 256;
+
+// Re-project the previous frame's winners (one per level-0 pixel) with the new camera and fold them in.
+__global__ __launch_bounds__(256) void splat_seed_kernel(const float *__restrict__ xyz, long long n, CamSet cams,
+                                                         int W, int H, unsigned long long *__restrict__ keys,
+                                                         const SplatHeader *hdr, const int *__restrict__ prev_idx)
+{
+    const int p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= W * H) return;
+    if (!(hdr->valid == 1 && hdr->W == W && hdr->H == H)) return;
+    const int id = prev_idx[p];
+    if (id < 0 || id >= n) return;
+    float d;
+    int xx, yy;
+    const int pix = project_one(xyz[3ll * id], xyz[3ll * id + 1], xyz[3ll * id + 2], cams.m[0], W, H, d, xx, yy);
+    if (pix >= 0) fold_key<MODE_AGENT>(keys + pix, ((unsigned long long)__float_as_uint(d) << 32) | (unsigned)id);
+}
+
+// bound[block] = max over the block's pixels of the current depth, +inf if any pixel is still empty.
+__global__ __launch_bounds__(256) void splat_hiz_kernel(const unsigned long long *__restrict__ keys, int W, int H,
+                                                        int nbx, int nby, float *__restrict__ hiz)
+{
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= nbx * nby) return;
+    const int bx = b % nbx, by = b / nbx;
+    unsigned m = 0;
+#pragma unroll
+    for (int dy = 0; dy < 4; ++dy)
+#pragma unroll
+        for (int dx = 0; dx < 4; ++dx) {
+            const int x = bx * 4 + dx, y = by * 4 + dy;
+            if (x < W && y < H) {
+                const unsigned bits = (unsigned)(keys[(long long)y * W + x] >> 32);    // EMPTY -> 0xffffffff
+                m = bits > m ? bits : m;
+            }
+        }
+    hiz[b] = __uint_as_float(m > 0x7f800000u ? 0x7f800000u : m);
+}
+
+// The point pass of MODE_HIZ: one 1024-thread workgroup per CU (persistent, grid-stride) with the whole
+// bound image in LDS.
+__global__ __launch_bounds__(1024) void splat_project_hiz_kernel(const float *__restrict__ xyz, long long n, CamSet cams,
+                                                                 int W, int H, unsigned long long *__restrict__ keys,
+                                                                 int vec_ok, const float *__restrict__ hiz_g, int nbx,
+                                                                 int nblocks)
+{
+    extern __shared__ __attribute__((aligned(16))) float hiz[];
+    for (int i = threadIdx.x; i < nblocks; i += blockDim.x) hiz[i] = hiz_g[i];
+    __syncthreads();
+    const long long groups = n / PTS_PER_THREAD;
+    const long long tid0 = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long long nthreads = (long long)gridDim.x * blockDim.x;
+    unsigned sink = 0;
+    if (vec_ok) {
+        const float4 *xyz4 = reinterpret_cast<const float4 *>(xyz);
+        for (long long g = tid0; g < groups; g += nthreads) {
+            const float4 a = xyz4[3 * g + 0];
+            const float4 b = xyz4[3 * g + 1];
+            const float4 c = xyz4[3 * g + 2];
+            const float px[4] = {a.x, a.w, b.z, c.y};
+            const float py[4] = {a.y, b.x, b.w, c.z};
+            const float pz[4] = {a.z, b.y, c.x, c.w};
+            splat_points<MODE_HIZ, 4>(px, py, pz, (unsigned)(g * PTS_PER_THREAD), 4, cams.m[0], W, H, keys, sink, hiz, nbx);
+        }
+    }
+    const long long first = vec_ok ? groups * PTS_PER_THREAD : 0;
+    for (long long i = first + tid0; i < n; i += nthreads) {
+        const float px[1] = {xyz[3 * i + 0]}, py[1] = {xyz[3 * i + 1]}, pz[1] = {xyz[3 * i + 2]};
+        splat_points<MODE_HIZ, 1>(px, py, pz, (unsigned)i, 1, cams.m[0], W, H, keys, sink, hiz, nbx);
+    }
+}
+
 struct ResolveOut {
     int32_t *idx[READ_MAX_LEVELS];
     float *depth[READ_MAX_LEVELS];
@@ -197,7 +291,8 @@ __device__ __forceinline__ unsigned long long kmin(unsigned long long a, unsigne
 // Levels 2..4 are reduced through LDS (16x16 -> 8x8 -> 4x4 -> 2x2 keys).
 __global__ __launch_bounds__(256) void splat_resolve_kernel(unsigned long long *__restrict__ keys, int W, int H,
                                                             int levels, ResolveOut out, int tiles_x,
-                                                            int tiles_y, int copies)
+                                                            int tiles_y, int copies, int *__restrict__ prev_idx,
+                                                            SplatHeader *hdr)
 {
     __shared__ unsigned long long s1[256], s2[64], s3[16];
     const int cam = blockIdx.y;
@@ -222,9 +317,15 @@ __global__ __launch_bounds__(256) void splat_resolve_kernel(unsigned long long *
                     kc[c * npx0 + off] = EMPTY_KEY;  // leave the workspace clean for the next frame
                 }
                 emit(out, 0, cam * npx0 + off, v);
+                if (prev_idx) prev_idx[off] = v == EMPTY_KEY ? -1 : (int)(unsigned)(v & 0xffffffffull);   // next frame's seeds
             }
             k[dy][dx] = v;
         }
+    if (hdr && blockIdx.x == 0 && blockIdx.y == 0 && t == 0) {
+        hdr->valid = 1;
+        hdr->W = W;
+        hdr->H = H;
+    }
     if (levels < 2) return;
     const unsigned long long k1 = kmin(kmin(k[0][0], k[0][1]), kmin(k[1][0], k[1][1]));
     {
@@ -282,25 +383,85 @@ int level_dim(int v, int l)
     return (int)((double)v * (1.0 / (double)(1 << l)));
 }
 
-int g_splat_mode = MODE_AGENT;   // fastest of the measured policies (profiles/README.md)
+int g_splat_mode = MODE_HIZ;
+
+// Workspace layout (fixed by the (B, W, H) it was sized for; one workspace serves one such triple):
+//   [header 256 B][key images: min(B,8) x 8 x W*H x 8 B][hi-z bounds: ceil(W/4)*ceil(H/4) x 4 B][previous winners: W*H x 4 B]
+struct WsLayout {
+    SplatHeader *hdr;
+    unsigned long long *keys;
+    float *hiz;
+    int *prev;
+    int nbx, nby;
+    size_t total;
+};
+
+WsLayout ws_layout(void *ws, int B, int W, int H)
+{
+    WsLayout L;
+    const int nb = B < MAX_CAMS ? B : MAX_CAMS;
+    char *p = (char *)ws;
+    L.hdr = (SplatHeader *)p;
+    size_t off = HEADER_BYTES;
+    L.keys = (unsigned long long *)(p + off);
+    off += (size_t)nb * XCD_COPIES * W * H * sizeof(unsigned long long);
+    L.nbx = ceil_div(W, 4);
+    L.nby = ceil_div(H, 4);
+    L.hiz = (float *)(p + off);
+    off += ((size_t)L.nbx * L.nby * sizeof(float) + 255) / 256 * 256;
+    L.prev = (int *)(p + off);
+    off += (size_t)W * H * sizeof(int);
+    L.total = (off + 255) / 256 * 256;
+    return L;
+}
+
+constexpr size_t HIZ_LDS_LIMIT = 150 * 1024;   // of the 160 KiB per CU
 
 int project_and_resolve(const float *xyz, int64_t n, const float *M_host, int B, int W, int H, int levels,
                         int32_t *const *idx_levels, float *const *depth_levels, int level_base,
-                        unsigned long long *keys, hipStream_t stream)
+                        const WsLayout &ws, bool allow_hiz, hipStream_t stream)
 {
-    const int mode = g_splat_mode;
+    unsigned long long *keys = ws.keys;
+    const size_t hiz_bytes = (size_t)ws.nbx * ws.nby * sizeof(float);
+    const bool use_hiz = g_splat_mode == MODE_HIZ && allow_hiz && B == 1 && n > 0 && hiz_bytes <= HIZ_LDS_LIMIT;
+    const int mode = g_splat_mode == MODE_HIZ ? MODE_AGENT : g_splat_mode;
     const int copies = mode == MODE_XCD ? XCD_COPIES : 1;
     for (int b0 = 0; b0 < B; b0 += MAX_CAMS) {
         const int nb = (B - b0) < MAX_CAMS ? (B - b0) : MAX_CAMS;
         CamSet cams;
         memset(&cams, 0, sizeof(cams));
         memcpy(cams.m, M_host + 16 * (size_t)b0, sizeof(float) * 16 * (size_t)nb);
-        if (n > 0) {
+        const int vec_ok = ((uintptr_t)xyz % 16) == 0;
+        if (use_hiz) {
+            hipLaunchKernelGGL(splat_seed_kernel, dim3(ceil_div(W * H, 256)), dim3(256), 0, stream, xyz, (long long)n, cams,
+                               W, H, keys, ws.hdr, ws.prev);
+            READ_CHECK_LAUNCH();
+            hipLaunchKernelGGL(splat_hiz_kernel, dim3(ceil_div(ws.nbx * ws.nby, 256)), dim3(256), 0, stream, keys, W, H,
+                               ws.nbx, ws.nby, ws.hiz);
+            READ_CHECK_LAUNCH();
+            static bool attr_set = false;
+            if (!attr_set) {
+                READ_CHECK_HIP(hipFuncSetAttribute((const void *)splat_project_hiz_kernel,
+                                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)HIZ_LDS_LIMIT));
+                attr_set = true;
+            }
+            static int n_cu = 0;
+            if (!n_cu) {
+                int dev = 0;
+                hipDeviceProp_t prop;
+                n_cu = (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess &&
+                        prop.multiProcessorCount > 0) ? prop.multiProcessorCount : 256;
+            }
+            int64_t blocks = ceil_div64(ceil_div64(n, PTS_PER_THREAD), 1024);
+            if (blocks > n_cu) blocks = n_cu;
+            hipLaunchKernelGGL(splat_project_hiz_kernel, dim3((unsigned)blocks), dim3(1024), hiz_bytes, stream, xyz,
+                               (long long)n, cams, W, H, keys, vec_ok, ws.hiz, ws.nbx, ws.nbx * ws.nby);
+            READ_CHECK_LAUNCH();
+        } else if (n > 0) {
             const int64_t work = ceil_div64(n, PTS_PER_THREAD);
             // HBM-bound stream: cap the grid at 256 CUs x 8 blocks and grid-stride the rest
             int64_t blocks = ceil_div64(work, 256);
             if (blocks > 256 * 8) blocks = 256 * 8;
-            const int vec_ok = ((uintptr_t)xyz % 16) == 0;
             auto kern = mode == MODE_XCD ? splat_project_kernel<MODE_XCD>
                         : mode == MODE_AGENT ? splat_project_kernel<MODE_AGENT>
                         : mode == MODE_SYS ? splat_project_kernel<MODE_SYS>
@@ -320,8 +481,11 @@ int project_and_resolve(const float *xyz, int64_t n, const float *M_host, int B,
                 out.depth[l] = depth_levels[level_base + l] + lpx * b0;
         }
         const int tiles_x = ceil_div(W, 32), tiles_y = ceil_div(H, 32);
+        // the winners of a single-camera frame seed the next frame rendered through this workspace
+        const bool keep = g_splat_mode == MODE_HIZ && allow_hiz && B == 1;
         hipLaunchKernelGGL(splat_resolve_kernel, dim3(tiles_x * tiles_y, nb), dim3(256), 0, stream, keys, W, H,
-                           levels, out, tiles_x, tiles_y, copies);
+                           levels, out, tiles_x, tiles_y, copies, keep ? ws.prev : (int *)nullptr,
+                           keep ? ws.hdr : (SplatHeader *)nullptr);
         READ_CHECK_LAUNCH();
     }
     return READ_OK;
@@ -332,29 +496,37 @@ int project_and_resolve(const float *xyz, int64_t n, const float *M_host, int B,
 extern "C" size_t read_splat_workspace_bytes(int B, int W, int H)
 {
     if (B < 1 || W < 1 || H < 1) return 0;
-    const int nb = B < MAX_CAMS ? B : MAX_CAMS;
-    // sized for the largest layout (one key image per XCD and camera) whatever mode is active
-    return (size_t)nb * XCD_COPIES * W * H * sizeof(unsigned long long);
+    return ws_layout(nullptr, B, W, H).total;
 }
 
 namespace readhip {
 int splat_set_mode(int m)
 {
-    if (m < MODE_XCD || m > MODE_ATOM) return READ_EINVAL;
+    if (m < MODE_XCD || m > MODE_HIZ) return READ_EINVAL;
     g_splat_mode = m;
     return READ_OK;
 }
 }
 
+__global__ __launch_bounds__(64) void splat_header_clear_kernel(int *hdr)
+{
+    hdr[threadIdx.x] = 0;       // 64 ints = the 256-byte header: no previous frame
+}
+
 extern "C" int read_splat_workspace_init(void *ws, size_t ws_bytes, void *stream)
 {
     READ_CHECK_ARG(ws && ws_bytes % 8 == 0, "read_splat_workspace_init: workspace null or not a multiple of 8 bytes");
+    // everything becomes EMPTY (all ones); the header is then zeroed: "no previous frame"
     READ_CHECK_ARG((uintptr_t)ws % 16 == 0, "read_splat_workspace_init: workspace must be 16-byte aligned");
     const long long count = (long long)(ws_bytes / 8);
     if (count == 0) return READ_OK;
     hipLaunchKernelGGL(fill_keys_kernel, dim3((unsigned)ceil_div64(count, 256)), dim3(256), 0, as_stream(stream),
                        (unsigned long long *)ws, count);
     READ_CHECK_LAUNCH();
+    if (ws_bytes >= HEADER_BYTES) {
+        hipLaunchKernelGGL(splat_header_clear_kernel, dim3(1), dim3(64), 0, as_stream(stream), (int *)ws);
+        READ_CHECK_LAUNCH();
+    }
     return READ_OK;
 }
 
@@ -377,17 +549,21 @@ extern "C" int read_splat_forward(const float *xyz, int64_t n, const float *M_ho
         set_error("read_splat_forward: workspace %zu < %zu bytes", ws_bytes, read_splat_workspace_bytes(B, W, H));
         return READ_ENOMEM;
     }
-    unsigned long long *keys = (unsigned long long *)ws;
+    const WsLayout L = ws_layout(ws, B, W, H);
     hipStream_t s = as_stream(stream);
     const int mask = (1 << (levels - 1)) - 1;
     if (((W | H) & mask) == 0) {
         // pyramid identity holds (App. A.4): one pass over the points feeds every level
-        return project_and_resolve(xyz, n, M_host, B, W, H, levels, idx_levels, depth_levels, 0, keys, s);
+        return project_and_resolve(xyz, n, M_host, B, W, H, levels, idx_levels, depth_levels, 0, L, true, s);
     }
-    // generic sizes: rasterise each level directly, as the reference does
+    // generic sizes: rasterise each level directly, as the reference does (no warm start: the key image
+    // of every level lives at the front of the same region)
     for (int l = 0; l < levels; ++l) {
+        WsLayout Ll = L;
+        Ll.nbx = ceil_div(level_dim(W, l), 4);
+        Ll.nby = ceil_div(level_dim(H, l), 4);
         const int rc = project_and_resolve(xyz, n, M_host, B, level_dim(W, l), level_dim(H, l), 1, idx_levels,
-                                           depth_levels, l, keys, s);
+                                           depth_levels, l, Ll, false, s);
         if (rc != READ_OK) return rc;
     }
     return READ_OK;

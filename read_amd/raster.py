@@ -28,16 +28,22 @@ class PointCloudRasterizer:
             raise ValueError(f"xyz must be (N,3), got {tuple(xyz.shape)}")
         self.xyz = xyz.to(device=self.device, dtype=torch.float32).contiguous()
         self.n = int(self.xyz.shape[0])
+        self._workspaces = {}
         self._ws = None
-        self._ws_key = None
 
     def _workspace(self, B, W, H):
-        need = _lib.lib().read_splat_workspace_bytes(B, W, H)
-        if self._ws is None or self._ws.numel() < need:
-            self._ws = torch.empty(need, dtype=torch.uint8, device=self.device)
-            _lib.check(_lib.lib().read_splat_workspace_init(self._ws.data_ptr(), self._ws.numel(), _lib.stream_ptr()),
+        """One persistent workspace per (min(B,8), W, H): key images, hi-z bounds and the previous frame's
+        winners (the warm start of the next frame rendered at that size)."""
+        key = (min(B, 8), W, H)
+        ws = self._workspaces.get(key)
+        if ws is None:
+            need = _lib.lib().read_splat_workspace_bytes(B, W, H)
+            ws = torch.empty(need, dtype=torch.uint8, device=self.device)
+            _lib.check(_lib.lib().read_splat_workspace_init(ws.data_ptr(), ws.numel(), _lib.stream_ptr()),
                        "read_splat_workspace_init")
-        return self._ws
+            self._workspaces[key] = ws
+        self._ws = ws
+        return ws
 
     def render(self, total_m, W, H, levels=5, want_depth=True, out=None):
         """total_m: (B,4,4) or (4,4) fp32 host array/tensor = proj @ inv(view)."""

@@ -44,7 +44,7 @@ def test_layer_table_matches_independent_spec():
 
 def test_bad_arguments_fail_loudly():
     L = _lib.lib()
-    assert L.read_splat_workspace_bytes(1, 1216, 352) == 8 * 1216 * 352 * 8
+    assert L.read_splat_workspace_bytes(1, 1216, 352) == 256 + 8 * 1216 * 352 * 8 + 304 * 88 * 4 + 1216 * 352 * 4
     assert L.read_splat_workspace_bytes(0, 10, 10) == 0
     rc = L.read_splat_forward(None, 10, None, 1, 64, 64, 5, None, None, None, 0, None)
     assert rc == -22 and b"xyz" in L.read_last_error()

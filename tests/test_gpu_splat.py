@@ -98,8 +98,30 @@ def test_workspace_is_left_clean_and_render_is_idempotent(hip):
     b_i, b_d = r.render(Ms, W, H, 5)
     for x, y in zip(a_i + a_d, b_i + b_d):
         assert torch.equal(x, y)
-    ws = r._ws.view(torch.int64)
-    assert bool((ws == -1).all()), "key image must be EMPTY after a frame"
+    keys = r._ws[256:256 + 8 * W * H * 8].view(torch.int64)
+    assert bool((keys == -1).all()), "key images must be EMPTY after a frame"
+
+
+def test_warm_start_sequence_is_exact(hip):
+    """Consecutive poses through ONE rasteriser: from the second frame on, the previous winners seed the
+    key image and the LDS hierarchical-Z rejects most points — results must stay bit-exact."""
+    W, H = 304, 176
+    xyz = synthetic.make_cloud(1_500_000)
+    proj = synthetic.make_proj(W, H, f=180.0)
+    r = PointCloudRasterizer(xyz)
+    for k in (0, 1, 2, 40, 41, 200):                       # small steps and large jumps
+        M = camera.total_matrix(proj, synthetic.sweep_pose(k))
+        idx, dep = r.render(M, W, H, 5)
+        oi, od = oracle.raster_multiscale(xyz, M[0], W, H, 5, threads=8)
+        for l in range(5):
+            assert np.array_equal(idx[l][0].cpu().numpy(), oi[l]), f"pose {k} level {l}"
+            assert np.array_equal(dep[l][0].cpu().numpy().view(np.uint32), od[l].view(np.uint32))
+    # a batch of two cameras through the same object uses its own workspace and the plain path
+    Ms = camera.total_matrix(proj, np.stack([synthetic.sweep_pose(3), synthetic.sweep_pose(77)]))
+    idx, dep = r.render(Ms, W, H, 5)
+    for b in range(2):
+        oi, od = oracle.raster_multiscale(xyz, Ms[b], W, H, 5, threads=8)
+        assert np.array_equal(idx[0][b].cpu().numpy(), oi[0])
 
 
 def test_full_size_30M_properties(hip):

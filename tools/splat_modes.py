@@ -14,7 +14,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from read_amd import _lib, camera, synthetic          # noqa: E402
 from read_amd.raster import PointCloudRasterizer      # noqa: E402
 
-NAMES = {0: "per-XCD images, workgroup-scope atomics", 1: "one image, agent atomics, sc1 early-z (default)",
+NAMES = {7: "warm start + LDS hi-z + agent atomics (default)", 0: "per-XCD images, workgroup-scope atomics", 1: "one image, agent atomics, sc1 early-z",
          3: "one image, agent atomics, system-scope early-z", 2: "probe: projection only",
          4: "probe: projection + sc1 early-z reads, no atomics", 5: "probe: projection + plain (L1) early-z reads",
          6: "probe: projection + atomics, no early-z"}
@@ -28,21 +28,22 @@ def main():
     a = ap.parse_args()
     W, H = 1216, 352
     xyz = synthetic.make_cloud(a.points)
-    M = camera.total_matrix(synthetic.make_proj(W, H), synthetic.sweep_pose(0))
+    proj = synthetic.make_proj(W, H)
+    Ms = [camera.total_matrix(proj, synthetic.sweep_pose(k)) for k in range(32)]     # a moving camera, like bench.py
     r = PointCloudRasterizer(xyz)
     L = _lib.lib()
     ref = None
     res = []
     bytes_algo = 12.0 * a.points + 8.0 * sum(w * h for (w, h) in camera.level_sizes(W, H, 5))
-    for mode in (1, 0, 3, 2, 4, 5, 6, 1):
+    for mode in (7, 1, 2, 4, 6, 7):
         _lib.check(L.read_tuning_set(b"splat_mode", mode))
-        for _ in range(3):
-            idx, dep = r.render(M, W, H, 5)
+        for k in range(3):
+            idx, dep = r.render(Ms[k], W, H, 5)
         torch.cuda.synchronize()
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
-        for _ in range(10):
-            idx, dep = r.render(M, W, H, 5)
+        for k in range(10):
+            idx, dep = r.render(Ms[3 + k], W, H, 5)
         e1.record()
         e1.synchronize()
         ms = e0.elapsed_time(e1) / 10
@@ -58,7 +59,7 @@ def main():
         res.append(row)
         # the workspace may hold garbage after the projection-only mode: re-initialise
         _lib.check(L.read_splat_workspace_init(r._ws.data_ptr(), r._ws.numel(), _lib.stream_ptr()))
-    _lib.check(L.read_tuning_set(b"splat_mode", 1))
+    _lib.check(L.read_tuning_set(b"splat_mode", 7))
     os.makedirs(os.path.dirname(os.path.abspath(a.out)), exist_ok=True)
     json.dump(res, open(a.out, "w"), indent=1)
 
