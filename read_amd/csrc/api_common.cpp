@@ -32,6 +32,9 @@ extern "C" int read_device_arch(char *name, int len)
 
 namespace readhip {
 int splat_set_mode(int m);
+void splat_set_subset(int v);
+void splat_set_stats(int v);
+void splat_set_pipe(int v);
 void conv_set_trace(void *buf, size_t bytes);
 void conv_set_prefer_wave(int v);
 void conv_set_stagger(int ticks);
@@ -58,6 +61,18 @@ extern "C" int read_tuning_set(const char *key, int value)
         const int rc = readhip::splat_set_mode(value);
         if (rc) readhip::set_error("read_tuning_set: splat_mode must be 0..7");
         return rc;
+    }
+    if (!strcmp(key, "splat_pipe")) {
+        readhip::splat_set_pipe(value);
+        return READ_OK;
+    }
+    if (!strcmp(key, "splat_stats")) {
+        readhip::splat_set_stats(value);
+        return READ_OK;
+    }
+    if (!strcmp(key, "splat_subset")) {
+        readhip::splat_set_subset(value);
+        return READ_OK;
     }
     if (!strcmp(key, "conv_ablate")) {
         readhip::conv_set_ablate(value);

@@ -110,7 +110,7 @@ template <int MODE, int NP>
 __device__ __forceinline__ void splat_points(const float (&px)[NP], const float (&py)[NP], const float (&pz)[NP],
                                              unsigned id0, int nvalid, const float *M, int W, int H,
                                              unsigned long long *keys, unsigned &sink, const float *hiz = nullptr,
-                                             int nbx = 0)
+                                             int nbx = 0, unsigned *stat = nullptr)
 {
     int pix[NP];
     unsigned long long key[NP], seen[NP];
@@ -120,11 +120,13 @@ __device__ __forceinline__ void splat_points(const float (&px)[NP], const float 
         int xx, yy;
         pix[k] = project_one(px[k], py[k], pz[k], M, W, H, d, xx, yy);
         if (k >= nvalid) pix[k] = -1;
+        if (stat && pix[k] >= 0) stat[0]++;                 // visible
         if (MODE == MODE_HIZ) {
             // LDS-resident far bound of the point's 4x4 block; strictly greater cannot win (ties must pass)
             const float bound = hiz[pix[k] >= 0 ? (yy >> 2) * nbx + (xx >> 2) : 0];
             if (d > bound) pix[k] = -1;
         }
+        if (stat && pix[k] >= 0) stat[1]++;                 // survived the LDS hi-z (or no hi-z)
         key[k] = ((unsigned long long)__float_as_uint(d) << 32) | (id0 + k);
     }
     if (MODE == MODE_NOZ) {
@@ -148,15 +150,22 @@ __device__ __forceinline__ void splat_points(const float (&px)[NP], const float 
     // keys only ever decrease, so "not smaller than what I can see" is final
 #pragma unroll
     for (int k = 0; k < NP; ++k)
-        if (key[k] < seen[k]) fold_key<MODE>(keys + pix[k], key[k]);
+        if (key[k] < seen[k]) {
+            fold_key<MODE>(keys + pix[k], key[k]);
+            if (stat) stat[2]++;                            // atomics issued
+        }
 }
 
 template <int MODE>
 __global__ __launch_bounds__(256) void splat_project_kernel(const float *__restrict__ xyz, long long n,
                                                             CamSet cams, int B, int W, int H,
                                                             unsigned long long *__restrict__ keys,
-                                                            int vec_ok, unsigned *sink_out)
+                                                            int vec_ok, unsigned *sink_out, int sub_mod,
+                                                            unsigned long long *stats)
 {
+    unsigned st_local[3] = {0, 0, 0};
+    unsigned *stp = stats ? st_local : nullptr;
+    // sub_mod > 0: bootstrap pass of MODE_HIZ — only every sub_mod-th chunk of 256 point groups (1024 points)
     const long long npx = (long long)W * H;
     const long long groups = n / PTS_PER_THREAD;
     const long long tid0 = (long long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -169,6 +178,7 @@ __global__ __launch_bounds__(256) void splat_project_kernel(const float *__restr
     if (vec_ok) {
         const float4 *xyz4 = reinterpret_cast<const float4 *>(xyz);
         for (long long g = tid0; g < groups; g += nthreads) {
+            if (sub_mod > 0 && ((g >> 8) % sub_mod) != 0) continue;
             // 48 contiguous bytes per lane = 4 points
             const float4 a = xyz4[3 * g + 0];
             const float4 b = xyz4[3 * g + 1];
@@ -178,12 +188,12 @@ __global__ __launch_bounds__(256) void splat_project_kernel(const float *__restr
             const float pz[4] = {a.z, b.y, c.x, c.w};
             for (int cam = 0; cam < B; ++cam)
                 splat_points<MODE, 4>(px, py, pz, (unsigned)(g * PTS_PER_THREAD), 4, cams.m[cam], W, H,
-                                      kbase + (long long)cam * copies * npx, sink);
+                                      kbase + (long long)cam * copies * npx, sink, nullptr, 0, stp);
         }
     }
     // tail (n % 4 points), or everything when the pointer is not 16-byte aligned
     const long long first = vec_ok ? groups * PTS_PER_THREAD : 0;
-    for (long long i = first + tid0; i < n; i += nthreads) {
+    for (long long i = first + tid0; i < n && sub_mod <= 0; i += nthreads) {     // (the bootstrap pass leaves the tail to the main pass)
         const float px[1] = {xyz[3 * i + 0]}, py[1] = {xyz[3 * i + 1]}, pz[1] = {xyz[3 * i + 2]};
         for (int cam = 0; cam < B; ++cam)
             splat_points<MODE, 1>(px, py, pz, (unsigned)i, 1, cams.m[cam], W, H,
@@ -191,6 +201,8 @@ __global__ __launch_bounds__(256) void splat_project_kernel(const float *__restr
     }
     if ((MODE == MODE_NOZ || MODE == MODE_PEEK || MODE == MODE_PEEK_L1) && sink == 0x7fffffffu && sink_out)
         *sink_out = sink;                                                       // keeps the probes live
+    if (stats)
+        for (int i = 0; i < 3; ++i) atomicAdd(stats + i, (unsigned long long)st_local[i]);
 }
 
 
@@ -242,9 +254,11 @@ __global__ __launch_bounds__(256) void splat_hiz_kernel(const unsigned long long
 __global__ __launch_bounds__(1024) void splat_project_hiz_kernel(const float *__restrict__ xyz, long long n, CamSet cams,
                                                                  int W, int H, unsigned long long *__restrict__ keys,
                                                                  int vec_ok, const float *__restrict__ hiz_g, int nbx,
-                                                                 int nblocks)
+                                                                 int nblocks, int sub_mod, unsigned long long *stats)
 {
     extern __shared__ __attribute__((aligned(16))) float hiz[];
+    unsigned st_local[3] = {0, 0, 0};
+    unsigned *stp = stats ? st_local : nullptr;
     for (int i = threadIdx.x; i < nblocks; i += blockDim.x) hiz[i] = hiz_g[i];
     __syncthreads();
     const long long groups = n / PTS_PER_THREAD;
@@ -254,20 +268,138 @@ __global__ __launch_bounds__(1024) void splat_project_hiz_kernel(const float *__
     if (vec_ok) {
         const float4 *xyz4 = reinterpret_cast<const float4 *>(xyz);
         for (long long g = tid0; g < groups; g += nthreads) {
+            if (sub_mod > 0 && ((g >> 8) % sub_mod) == 0) continue;       // already folded in by the bootstrap pass
             const float4 a = xyz4[3 * g + 0];
             const float4 b = xyz4[3 * g + 1];
             const float4 c = xyz4[3 * g + 2];
             const float px[4] = {a.x, a.w, b.z, c.y};
             const float py[4] = {a.y, b.x, b.w, c.z};
             const float pz[4] = {a.z, b.y, c.x, c.w};
-            splat_points<MODE_HIZ, 4>(px, py, pz, (unsigned)(g * PTS_PER_THREAD), 4, cams.m[0], W, H, keys, sink, hiz, nbx);
+            splat_points<MODE_HIZ, 4>(px, py, pz, (unsigned)(g * PTS_PER_THREAD), 4, cams.m[0], W, H, keys, sink, hiz, nbx, stp);
         }
     }
     const long long first = vec_ok ? groups * PTS_PER_THREAD : 0;
     for (long long i = first + tid0; i < n; i += nthreads) {
         const float px[1] = {xyz[3 * i + 0]}, py[1] = {xyz[3 * i + 1]}, pz[1] = {xyz[3 * i + 2]};
-        splat_points<MODE_HIZ, 1>(px, py, pz, (unsigned)i, 1, cams.m[0], W, H, keys, sink, hiz, nbx);
+        splat_points<MODE_HIZ, 1>(px, py, pz, (unsigned)i, 1, cams.m[0], W, H, keys, sink, hiz, nbx, stp);
     }
+    if (stats)
+        for (int i = 0; i < 3; ++i) atomicAdd(stats + 4 + i, (unsigned long long)st_local[i]);
+}
+
+
+// ---- software-pipelined point pass (MODE_AGENT and MODE_HIZ) ------------------------------------------
+// vmcnt retires in order and counts atomics, so in the straightforward loop every wave-iteration that
+// issued an atomic waits out its memory-side round trip before it may consume the next group's loads
+// (measured: 1.9 M filtered atomics cost as much as 200 us, ~5x their throughput cost).  Here an iteration
+//   1. issues the loads of the NEXT point group,
+//   2. projects the current group and issues its early-z reads,
+//   3. issues the atomics that the PREVIOUS iteration decided on (younger than 1./2., so waiting for the
+//      reads does not wait for them; they have a whole iteration to complete),
+//   4. consumes the early-z reads and records this iteration's survivors as pending.
+// sub_sel: 0 all point chunks, 1 only chunks with (chunk % sub_mod) == 0 (bootstrap), 2 only the others.
+template <bool HIZ>
+__global__ __launch_bounds__(HIZ ? 1024 : 256) void splat_pipe_kernel(const float *__restrict__ xyz, long long n,
+                                                                      CamSet cams, int B, int W, int H,
+                                                                      unsigned long long *__restrict__ keys,
+                                                                      const float *__restrict__ hiz_g, int nbx,
+                                                                      int nblocks, int sub_mod, int sub_sel,
+                                                                      unsigned long long *stats)
+{
+    extern __shared__ __attribute__((aligned(16))) float hiz[];
+    if (HIZ) {
+        for (int i = threadIdx.x; i < nblocks; i += blockDim.x) hiz[i] = hiz_g[i];
+        __syncthreads();
+    }
+    const long long npx = (long long)W * H;
+    const long long groups = n / PTS_PER_THREAD;
+    const long long tid0 = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long long nthreads = (long long)gridDim.x * blockDim.x;
+    const float4 *xyz4 = reinterpret_cast<const float4 *>(xyz);
+    unsigned st_local[3] = {0, 0, 0};
+
+    auto wanted = [&](long long g) {
+        if (sub_sel == 0) return true;
+        const bool boot = ((g >> 8) % sub_mod) == 0;
+        return sub_sel == 1 ? boot : !boot;
+    };
+    auto advance = [&](long long g) {            // next group of this thread that belongs to the pass
+        while (g < groups && !wanted(g)) g += nthreads;
+        return g;
+    };
+
+    long long pidx[4] = {-1, -1, -1, -1};        // pending atomics: index into keys (camera offset included)
+    unsigned long long pkey[4] = {0, 0, 0, 0};
+    long long g = advance(tid0);
+    float4 a, b, c;
+    if (g < groups) {
+        a = xyz4[3 * g + 0];
+        b = xyz4[3 * g + 1];
+        c = xyz4[3 * g + 2];
+    }
+    while (g < groups) {
+        const long long gn = advance(g + nthreads);
+        float4 an = a, bn = b, cn = c;
+        if (gn < groups) {                        // 1. next group's loads first
+            an = xyz4[3 * gn + 0];
+            bn = xyz4[3 * gn + 1];
+            cn = xyz4[3 * gn + 2];
+        }
+        const float px[4] = {a.x, a.w, b.z, c.y};
+        const float py[4] = {a.y, b.x, b.w, c.z};
+        const float pz[4] = {a.z, b.y, c.x, c.w};
+        const unsigned id0 = (unsigned)(g * PTS_PER_THREAD);
+        for (int cam = 0; cam < B; ++cam) {
+            int pix[4];
+            unsigned long long key[4], seen[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {         // 2. project + early-z reads
+                float d;
+                int xx, yy;
+                pix[k] = project_one(px[k], py[k], pz[k], cams.m[cam], W, H, d, xx, yy);
+                if (stats && pix[k] >= 0) st_local[0]++;
+                if (HIZ) {
+                    const float bound = hiz[pix[k] >= 0 ? (yy >> 2) * nbx + (xx >> 2) : 0];
+                    if (d > bound) pix[k] = -1;
+                }
+                if (stats && pix[k] >= 0) st_local[1]++;
+                key[k] = ((unsigned long long)__float_as_uint(d) << 32) | (id0 + k);
+            }
+#pragma unroll
+            for (int k = 0; k < 4; ++k)
+                seen[k] = pix[k] >= 0 ? peek_key<MODE_AGENT>(keys + cam * npx + pix[k]) : 0ull;
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int k = 0; k < 4; ++k)           // 3. the previous step's atomics
+                if (pidx[k] >= 0) fold_key<MODE_AGENT>(keys + pidx[k], pkey[k]);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {         // 4. decide; keys only decrease, so a stale read is conservative
+                const bool win = key[k] < seen[k];
+                pidx[k] = win ? cam * npx + pix[k] : -1;
+                pkey[k] = key[k];
+                if (stats && win) st_local[2]++;
+            }
+        }
+        a = an;
+        b = bn;
+        c = cn;
+        g = gn;
+    }
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+        if (pidx[k] >= 0) fold_key<MODE_AGENT>(keys + pidx[k], pkey[k]);
+    // tail (n % 4 points): left to the pass that takes "the others"
+    if (sub_sel != 1) {
+        unsigned sink = 0;
+        for (long long i = groups * PTS_PER_THREAD + tid0; i < n; i += nthreads) {
+            const float px[1] = {xyz[3 * i + 0]}, py[1] = {xyz[3 * i + 1]}, pz[1] = {xyz[3 * i + 2]};
+            for (int cam = 0; cam < B; ++cam)
+                splat_points<MODE_AGENT, 1>(px, py, pz, (unsigned)i, 1, cams.m[cam], W, H, keys + cam * npx, sink);
+        }
+    }
+    if (stats)
+        for (int i = 0; i < 3; ++i) atomicAdd(stats + (HIZ ? 4 : 0) + i, (unsigned long long)st_local[i]);
 }
 
 struct ResolveOut {
@@ -384,6 +516,10 @@ int level_dim(int v, int l)
 }
 
 int g_splat_mode = MODE_HIZ;
+int g_splat_subset = 8;
+int g_splat_pipe = 0;          // 1: software-pipelined point pass (measured slower: 0.43 vs 0.39 ms in MODE_AGENT)
+int g_splat_stats = 0;         // debug: accumulate counters in the workspace header (u64 at byte 64: pass A visible /
+                               // survivors / atomics / -, pass B visible / survivors / atomics)        // MODE_HIZ bootstrap: every g_splat_subset-th 1024-point chunk (0 = seeds only)
 
 // Workspace layout (fixed by the (B, W, H) it was sized for; one workspace serves one such triple):
 //   [header 256 B][key images: min(B,8) x 8 x W*H x 8 B][hi-z bounds: ceil(W/4)*ceil(H/4) x 4 B][previous winners: W*H x 4 B]
@@ -423,7 +559,8 @@ int project_and_resolve(const float *xyz, int64_t n, const float *M_host, int B,
 {
     unsigned long long *keys = ws.keys;
     const size_t hiz_bytes = (size_t)ws.nbx * ws.nby * sizeof(float);
-    const bool use_hiz = g_splat_mode == MODE_HIZ && allow_hiz && B == 1 && n > 0 && hiz_bytes <= HIZ_LDS_LIMIT;
+    const bool use_hiz = g_splat_mode == MODE_HIZ && allow_hiz && B == 1 && n > 0 && hiz_bytes <= HIZ_LDS_LIMIT &&
+                         ((uintptr_t)xyz % 16) == 0;
     const int mode = g_splat_mode == MODE_HIZ ? MODE_AGENT : g_splat_mode;
     const int copies = mode == MODE_XCD ? XCD_COPIES : 1;
     for (int b0 = 0; b0 < B; b0 += MAX_CAMS) {
@@ -432,15 +569,28 @@ int project_and_resolve(const float *xyz, int64_t n, const float *M_host, int B,
         memset(&cams, 0, sizeof(cams));
         memcpy(cams.m, M_host + 16 * (size_t)b0, sizeof(float) * 16 * (size_t)nb);
         const int vec_ok = ((uintptr_t)xyz % 16) == 0;
+        unsigned long long *stats = g_splat_stats ? (unsigned long long *)((char *)ws.hdr + 64) : nullptr;
         if (use_hiz) {
             hipLaunchKernelGGL(splat_seed_kernel, dim3(ceil_div(W * H, 256)), dim3(256), 0, stream, xyz, (long long)n, cams,
                                W, H, keys, ws.hdr, ws.prev);
             READ_CHECK_LAUNCH();
+            // bootstrap: a strided 1/sub of the cloud (only when the vector path is usable) on top of the seeds,
+            // so that nearly every pixel is covered before the bounds are taken
+            const int sub = (vec_ok && g_splat_subset > 1 && n >= (1 << 20)) ? g_splat_subset : 0;
+            if (sub) {
+                int64_t blocks = ceil_div64(ceil_div64(n, PTS_PER_THREAD), 256);
+                if (blocks > 256 * 8) blocks = 256 * 8;
+                hipLaunchKernelGGL(splat_pipe_kernel<false>, dim3((unsigned)blocks), dim3(256), 0, stream, xyz,
+                                   (long long)n, cams, 1, W, H, keys, (const float *)nullptr, 0, 0, sub, 1, stats);
+                READ_CHECK_LAUNCH();
+            }
             hipLaunchKernelGGL(splat_hiz_kernel, dim3(ceil_div(ws.nbx * ws.nby, 256)), dim3(256), 0, stream, keys, W, H,
                                ws.nbx, ws.nby, ws.hiz);
             READ_CHECK_LAUNCH();
             static bool attr_set = false;
             if (!attr_set) {
+                READ_CHECK_HIP(hipFuncSetAttribute((const void *)splat_pipe_kernel<true>,
+                                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)HIZ_LDS_LIMIT));
                 READ_CHECK_HIP(hipFuncSetAttribute((const void *)splat_project_hiz_kernel,
                                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)HIZ_LDS_LIMIT));
                 attr_set = true;
@@ -454,14 +604,23 @@ int project_and_resolve(const float *xyz, int64_t n, const float *M_host, int B,
             }
             int64_t blocks = ceil_div64(ceil_div64(n, PTS_PER_THREAD), 1024);
             if (blocks > n_cu) blocks = n_cu;
-            hipLaunchKernelGGL(splat_project_hiz_kernel, dim3((unsigned)blocks), dim3(1024), hiz_bytes, stream, xyz,
-                               (long long)n, cams, W, H, keys, vec_ok, ws.hiz, ws.nbx, ws.nbx * ws.nby);
+            if (g_splat_pipe)
+                hipLaunchKernelGGL(splat_pipe_kernel<true>, dim3((unsigned)blocks), dim3(1024), hiz_bytes, stream, xyz,
+                                   (long long)n, cams, 1, W, H, keys, ws.hiz, ws.nbx, ws.nbx * ws.nby, sub, sub ? 2 : 0, stats);
+            else
+                hipLaunchKernelGGL(splat_project_hiz_kernel, dim3((unsigned)blocks), dim3(1024), hiz_bytes, stream, xyz,
+                                   (long long)n, cams, W, H, keys, vec_ok, ws.hiz, ws.nbx, ws.nbx * ws.nby, sub, stats);
             READ_CHECK_LAUNCH();
         } else if (n > 0) {
             const int64_t work = ceil_div64(n, PTS_PER_THREAD);
             // HBM-bound stream: cap the grid at 256 CUs x 8 blocks and grid-stride the rest
             int64_t blocks = ceil_div64(work, 256);
             if (blocks > 256 * 8) blocks = 256 * 8;
+            if (mode == MODE_AGENT && vec_ok && g_splat_pipe) {
+                hipLaunchKernelGGL(splat_pipe_kernel<false>, dim3((unsigned)blocks), dim3(256), 0, stream, xyz, (long long)n,
+                                   cams, nb, W, H, keys, (const float *)nullptr, 0, 0, 0, 0, stats);
+                READ_CHECK_LAUNCH();
+            } else {
             auto kern = mode == MODE_XCD ? splat_project_kernel<MODE_XCD>
                         : mode == MODE_AGENT ? splat_project_kernel<MODE_AGENT>
                         : mode == MODE_SYS ? splat_project_kernel<MODE_SYS>
@@ -469,8 +628,9 @@ int project_and_resolve(const float *xyz, int64_t n, const float *M_host, int B,
                         : mode == MODE_PEEK_L1 ? splat_project_kernel<MODE_PEEK_L1>
                         : mode == MODE_ATOM ? splat_project_kernel<MODE_ATOM> : splat_project_kernel<MODE_NOZ>;
             hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(256), 0, stream, xyz, (long long)n, cams, nb, W, H,
-                               keys, vec_ok, (unsigned *)nullptr);
+                               keys, vec_ok, (unsigned *)nullptr, 0, stats);
             READ_CHECK_LAUNCH();
+            }
         }
         ResolveOut out;
         memset(&out, 0, sizeof(out));
@@ -500,6 +660,9 @@ extern "C" size_t read_splat_workspace_bytes(int B, int W, int H)
 }
 
 namespace readhip {
+void splat_set_subset(int v) { g_splat_subset = v < 0 ? 0 : v; }
+void splat_set_stats(int v) { g_splat_stats = v; }
+void splat_set_pipe(int v) { g_splat_pipe = v; }
 int splat_set_mode(int m)
 {
     if (m < MODE_XCD || m > MODE_HIZ) return READ_EINVAL;

@@ -35,7 +35,16 @@ def main():
     ref = None
     res = []
     bytes_algo = 12.0 * a.points + 8.0 * sum(w * h for (w, h) in camera.level_sizes(W, H, 5))
-    for mode in (7, 1, 2, 4, 6, 7):
+    for mode in (7, 1, 1001, 2, 7007, 7016, 7):
+        sub = 0
+        pipe = 0
+        if mode == 1001:            # mode 1 with the straightforward (non-pipelined) loop
+            mode, pipe = 1, 0
+        _lib.check(L.read_tuning_set(b"splat_pipe", pipe))
+        if mode >= 7000:            # 70xx = mode 7 with bootstrap subset xx (0 = seeds only)
+            sub, mode = mode - 7000, 7
+            sub = 0 if sub == 7 else sub
+        _lib.check(L.read_tuning_set(b"splat_subset", sub))
         _lib.check(L.read_tuning_set(b"splat_mode", mode))
         for k in range(3):
             idx, dep = r.render(Ms[k], W, H, 5)
@@ -53,13 +62,14 @@ def main():
             if ref is None:
                 ref = cur
             same = all(torch.equal(x, y) for x, y in zip(ref, cur))
-        row = {"mode": mode, "name": NAMES[mode], "ms": ms, "GBps": bytes_algo / ms / 1e6,
+        row = {"mode": mode, "subset": sub, "pipe": pipe, "name": NAMES[mode], "ms": ms, "GBps": bytes_algo / ms / 1e6,
                "frac_hbm_8TBs": bytes_algo / ms / 1e6 / 8000.0, "identical_to_first": same}
         print(row, flush=True)
         res.append(row)
         # the workspace may hold garbage after the projection-only mode: re-initialise
         _lib.check(L.read_splat_workspace_init(r._ws.data_ptr(), r._ws.numel(), _lib.stream_ptr()))
     _lib.check(L.read_tuning_set(b"splat_mode", 7))
+    _lib.check(L.read_tuning_set(b"splat_subset", 0))
     os.makedirs(os.path.dirname(os.path.abspath(a.out)), exist_ok=True)
     json.dump(res, open(a.out, "w"), indent=1)
 
