@@ -156,6 +156,25 @@ __device__ __forceinline__ void splat_points(const float (&px)[NP], const float 
         }
 }
 
+// Point groups (4 points) are split into chunks of 256 groups (1024 points).  The bootstrap pass of MODE_HIZ
+// takes every sub-th chunk, the main pass the others.  Threads walk a COMPACT index t over the groups of
+// their pass (a strided walk over all groups with a skip test aliases with the power-of-two grid stride:
+// chunk % sub never changes along a thread's walk and 1/sub of the threads would do all the work).
+__device__ __forceinline__ long long pass_groups(long long groups, int sub, int sel)
+{
+    if (sub <= 0 || sel == 0) return groups;
+    const long long chunks = (groups + 255) >> 8;
+    const long long boot = (chunks + sub - 1) / sub;                 // chunks 0, sub, 2 sub, ...
+    return (sel == 1 ? boot : chunks - boot) << 8;                   // upper bound; map_group() may return >= groups
+}
+__device__ __forceinline__ long long map_group(long long t, int sub, int sel)
+{
+    if (sub <= 0 || sel == 0) return t;
+    const long long c = t >> 8;
+    const long long chunk = sel == 1 ? c * sub : (c / (sub - 1)) * sub + (c % (sub - 1)) + 1;
+    return (chunk << 8) | (t & 255);
+}
+
 template <int MODE>
 __global__ __launch_bounds__(256) void splat_project_kernel(const float *__restrict__ xyz, long long n,
                                                             CamSet cams, int B, int W, int H,
@@ -177,8 +196,10 @@ __global__ __launch_bounds__(256) void splat_project_kernel(const float *__restr
 
     if (vec_ok) {
         const float4 *xyz4 = reinterpret_cast<const float4 *>(xyz);
-        for (long long g = tid0; g < groups; g += nthreads) {
-            if (sub_mod > 0 && ((g >> 8) % sub_mod) != 0) continue;
+        const long long npass = pass_groups(groups, sub_mod, sub_mod > 0 ? 1 : 0);
+        for (long long t = tid0; t < npass; t += nthreads) {
+            const long long g = map_group(t, sub_mod, sub_mod > 0 ? 1 : 0);
+            if (g >= groups) continue;
             // 48 contiguous bytes per lane = 4 points
             const float4 a = xyz4[3 * g + 0];
             const float4 b = xyz4[3 * g + 1];
@@ -267,8 +288,10 @@ __global__ __launch_bounds__(1024) void splat_project_hiz_kernel(const float *__
     unsigned sink = 0;
     if (vec_ok) {
         const float4 *xyz4 = reinterpret_cast<const float4 *>(xyz);
-        for (long long g = tid0; g < groups; g += nthreads) {
-            if (sub_mod > 0 && ((g >> 8) % sub_mod) == 0) continue;       // already folded in by the bootstrap pass
+        const long long npass = pass_groups(groups, sub_mod, sub_mod > 0 ? 2 : 0);
+        for (long long t = tid0; t < npass; t += nthreads) {
+            const long long g = map_group(t, sub_mod, sub_mod > 0 ? 2 : 0);   // bootstrap chunks are already folded in
+            if (g >= groups) continue;
             const float4 a = xyz4[3 * g + 0];
             const float4 b = xyz4[3 * g + 1];
             const float4 c = xyz4[3 * g + 2];
@@ -580,8 +603,8 @@ int project_and_resolve(const float *xyz, int64_t n, const float *M_host, int B,
             if (sub) {
                 int64_t blocks = ceil_div64(ceil_div64(n, PTS_PER_THREAD), 256);
                 if (blocks > 256 * 8) blocks = 256 * 8;
-                hipLaunchKernelGGL(splat_pipe_kernel<false>, dim3((unsigned)blocks), dim3(256), 0, stream, xyz,
-                                   (long long)n, cams, 1, W, H, keys, (const float *)nullptr, 0, 0, sub, 1, stats);
+                hipLaunchKernelGGL(splat_project_kernel<MODE_AGENT>, dim3((unsigned)blocks), dim3(256), 0, stream, xyz,
+                                   (long long)n, cams, 1, W, H, keys, vec_ok, (unsigned *)nullptr, sub, stats);
                 READ_CHECK_LAUNCH();
             }
             hipLaunchKernelGGL(splat_hiz_kernel, dim3(ceil_div(ws.nbx * ws.nby, 256)), dim3(256), 0, stream, keys, W, H,
@@ -604,7 +627,7 @@ int project_and_resolve(const float *xyz, int64_t n, const float *M_host, int B,
             }
             int64_t blocks = ceil_div64(ceil_div64(n, PTS_PER_THREAD), 1024);
             if (blocks > n_cu) blocks = n_cu;
-            if (g_splat_pipe)
+            if (g_splat_pipe && !sub)
                 hipLaunchKernelGGL(splat_pipe_kernel<true>, dim3((unsigned)blocks), dim3(1024), hiz_bytes, stream, xyz,
                                    (long long)n, cams, 1, W, H, keys, ws.hiz, ws.nbx, ws.nbx * ws.nby, sub, sub ? 2 : 0, stats);
             else

@@ -35,7 +35,7 @@ def main():
     ref = None
     res = []
     bytes_algo = 12.0 * a.points + 8.0 * sum(w * h for (w, h) in camera.level_sizes(W, H, 5))
-    for mode in (7, 1, 1001, 2, 7007, 7016, 7):
+    for mode in (7, 1, 7004, 7008, 7016, 7032, 7):
         sub = 0
         pipe = 0
         if mode == 1001:            # mode 1 with the straightforward (non-pipelined) loop
