@@ -36,7 +36,7 @@ def main():
     res = []
     bytes_algo = 12.0 * a.points + 8.0 * sum(w * h for (w, h) in camera.level_sizes(W, H, 5))
     for mode in (7, 1, 7004, 7008, 7016, 7032, 7):
-        sub = 0
+        sub = 8
         pipe = 0
         if mode == 1001:            # mode 1 with the straightforward (non-pipelined) loop
             mode, pipe = 1, 0
@@ -69,7 +69,7 @@ def main():
         # the workspace may hold garbage after the projection-only mode: re-initialise
         _lib.check(L.read_splat_workspace_init(r._ws.data_ptr(), r._ws.numel(), _lib.stream_ptr()))
     _lib.check(L.read_tuning_set(b"splat_mode", 7))
-    _lib.check(L.read_tuning_set(b"splat_subset", 0))
+    _lib.check(L.read_tuning_set(b"splat_subset", 8))
     os.makedirs(os.path.dirname(os.path.abspath(a.out)), exist_ok=True)
     json.dump(res, open(a.out, "w"), indent=1)
 
