@@ -140,6 +140,8 @@ typedef struct read_conv_desc {
     float out_fill;                         /* value for channels Cout..out_cstride-1 when fill_pad */
     int fill_pad;
     int config;                             /* tile configuration id, -1 = pick automatically */
+    const float *wpacked_wino;              /* optional: read_conv_pack_wino_host() output (device); enables the
+                                               Winograd F(2x2,3x3) kernel for 3x3/s1 single-source layers */
 } read_conv_desc;
 
 /* Sizes (in floats) of the packed weight / parameter blocks of one BasicConv. */
@@ -151,6 +153,9 @@ size_t read_conv_param_floats(int Cout);
  *   C % 16 == 0, else 8 (the packing order depends on it). */
 int read_conv_pack_weights_host(int Cin, int Cout, int ksize, int kc, const float *wf,
                                 const float *wm, float *wpacked_host);
+/* Winograd F(2x2,3x3): transformed weights G g G^T in fragment order, Cin % 16 == 0 (16/9 the plain size). */
+size_t read_conv_wino_floats(int Cin, int Cout);
+int read_conv_pack_wino_host(int Cin, int Cout, const float *wf, const float *wm, float *wpacked_wino_host);
 int read_conv_pack_params_host(int Cout, const float *bf, const float *bm, const float *gamma,
                                const float *beta, const float *mean, const float *var, float eps,
                                float *params_host);

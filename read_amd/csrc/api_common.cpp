@@ -39,6 +39,7 @@ void conv_set_trace(void *buf, size_t bytes);
 void conv_set_prefer_wave(int v);
 void conv_set_stagger(int ticks);
 void conv_set_ablate(int bits);
+void conv_set_wino(int max_cin);
 }
 
 // Debug: per-workgroup timeline of the next gated-conv launches.  buf = device memory, 64 bytes per
@@ -72,6 +73,10 @@ extern "C" int read_tuning_set(const char *key, int value)
     }
     if (!strcmp(key, "splat_subset")) {
         readhip::splat_set_subset(value);
+        return READ_OK;
+    }
+    if (!strcmp(key, "conv_wino")) {       // value = largest Cin that takes the Winograd kernel (0 = off)
+        readhip::conv_set_wino(value);
         return READ_OK;
     }
     if (!strcmp(key, "conv_ablate")) {
