@@ -98,6 +98,10 @@ def lib():
             fn.argtypes = args
         if os.environ.get("READ_CONV_WAVE"):          # A/B switch for tests: wave-autonomous conv kernels
             L.read_tuning_set(b"conv_wave", int(os.environ["READ_CONV_WAVE"]))
+        for kv in filter(None, os.environ.get("READ_TUNE", "").split(",")):   # A/B switches: "key=value,key=value"
+            k, v = kv.split("=")
+            if L.read_tuning_set(k.encode(), int(v)) != 0:
+                raise ReadHipError(f"READ_TUNE: {L.read_last_error().decode()}")
         _LIB = L
     return _LIB
 

@@ -587,12 +587,17 @@ __global__ __launch_bounds__(256, (P * QG >= 2 ? 2 : 3)) void gated_conv_wave_ke
 //
 // Workgroup = 4 waves = the 4 frequency ROWS i of one block of 32 tiles (4 x 8 tiles = 8 x 16 output pixels)
 // and one 32-channel group; MFMA row = tile, MFMA column = output channel, k = input channel.
-//   * the 10 x 18-pixel input patch of a 16-channel chunk is staged once in LDS for all four waves;
-//   * wave i builds its A fragments on the fly: t[c] = +-d[ra][c] +- d[rb][c] (row pair of B^T for its i), then the
-//     four column combinations V[i][0..3] — 8 ds_read_b128 + 32 float4 adds per 8-channel k-step, which feeds
-//     32 MFMAs (4 frequencies x {conv_f, conv_m} x 4);
+//   * the 10 x 18-pixel input patch of a 16-channel chunk is staged in LDS for all four waves, three buffers,
+//     fetched two chunks ahead (so the transform of the next chunk's first k-step can run under this chunk's
+//     MFMAs and the in-order vmcnt never makes a B wait cover a fresh patch load);
+//   * wave i builds its A fragments on the fly: t[c] = d[ra][c] +- d[rb][c] (row pair of B^T for its i; row 2 is
+//     taken negated, the sign lives in the packed weights), then the four column combinations V[i][0..3] —
+//     8 ds_read_b128 + 32 VALU per 8-channel k-step, which feeds 32 MFMAs (4 frequencies x {conv_f, conv_m} x 4);
 //   * B = transformed weights, packed [group][k8 step][row i][j][f|m][lane][4]: a wave reads 8 KiB per k-step,
 //     contiguous; prefetched half a k-step (4 fragments) ahead;
+//   * every non-MFMA instruction of the loop is an "item" issued right after one MFMA and pinned there
+//     (see chunk_steps above for why): B loads after MFMAs 0-3 of each half-step, patch loads, LDS reads,
+//     transform arithmetic and LDS writes after the others;
 //   * output: each wave reduces its row over j with A^T (R_b = sum_j A^T[b][j] M[i][j]), the four rows meet in LDS
 //     (64 KiB, aliasing the dead input buffers), wave w finishes accumulator registers 4w..4w+3: Y[a][b] =
 //     sum_i A^T[a][i] R_b(i), then the usual gated epilogue and 2x2-pixel stores.
@@ -603,8 +608,15 @@ struct WinoGeom {
     static constexpr int KC = 16, PS = KC + 4, BUF = IH * IW * PS;
     static constexpr int NE = IH * IW * (KC / 4), NI = (NE + 255) / 256;
     static constexpr int RED = 4 * 2 * 2 * 16 * 64;      // floats of the cross-wave reduction (64 KiB)
-    static constexpr int LDS_FLOATS = RED > 2 * BUF ? RED : 2 * BUF;
+    static constexpr int LDS_FLOATS = RED > 3 * BUF + 4 ? RED : 3 * BUF + 4;      // + a dummy float4 slot
 };
+
+// (scalar base + 32-bit lane offset) load: hipcc selects the saddr form global_load_dwordx4 v, voff, s[base:base+1],
+// no per-load 64-bit VALU address math.  (raw_buffer_load_b64/b128 builtins of this ROCm load a single dword.)
+__device__ __forceinline__ float4 load_f4(const char *sbase, unsigned voff)
+{
+    return *reinterpret_cast<const float4 *>(sbase + voff);
+}
 
 __global__ __launch_bounds__(256, 2) void gated_conv_wino_kernel(const ConvKArgs a)
 {
@@ -618,58 +630,55 @@ __global__ __launch_bounds__(256, 2) void gated_conv_wino_kernel(const ConvKArgs
     const int iy0 = oy0 - 1, ix0 = ox0 - 1;
     const SrcDev s = a.src[0];
 
-    // ---- staging of the input patch (same scheme as the direct kernels)
-    float4 st[WG::NI];
+    // ---- input patch staging: per-lane byte offsets into the source; pixels outside the image load offset 0 and
+    // are zeroed on the way into LDS
+    unsigned aoff[WG::NI];
+    int loff[WG::NI];
     unsigned okmask = 0;
 #pragma unroll
     for (int i = 0; i < WG::NI; ++i) {
-        const int e = tid + i * 256, pix = e / 4;
+        const int e = tid + i * 256, q = e % 4, pix = e / 4;
         const int gy = iy0 + pix / WG::IW, gx = ix0 + pix % WG::IW;
         const bool ok = e < WG::NE && gy >= 0 && gy < a.inH && gx >= 0 && gx < a.inW;
         okmask |= (ok ? 1u : 0u) << i;
+        aoff[i] = ok ? (unsigned)(((gy * s.W + gx) * s.C + 4 * q) * 4) : 0u;
+        loff[i] = e < WG::NE ? pix * WG::PS + 4 * q : -1;
     }
-    auto gload = [&](int chunk) {
-#pragma unroll
-        for (int i = 0; i < WG::NI; ++i) {
-            const int e = tid + i * 256, q = e % 4, pix = e / 4;
-            const int gy = iy0 + pix / WG::IW, gx = ix0 + pix % WG::IW;
-            const int off = ((okmask >> i) & 1u) ? (gy * s.W + gx) * s.C + chunk * WG::KC + 4 * q : 0;
-            st[i] = *reinterpret_cast<const float4 *>(s.p + off);
-        }
+    const int last_chunk = a.nchunks - 1;
+    const char *const abase = reinterpret_cast<const char *>(s.p);
+    float4 st[WG::NI];
+    auto gload1 = [&](int i, int chunk) {                               // chunk clamped: a repeated load is harmless
+        chunk = chunk < last_chunk ? chunk : last_chunk;
+        st[i] = load_f4(abase + chunk * (WG::KC * 4), aoff[i]);
     };
-    auto lwrite = [&](float *buf) {
-#pragma unroll
-        for (int i = 0; i < WG::NI; ++i) {
-            const int e = tid + i * 256;
-            if (e < WG::NE) {
-                float4 v = st[i];
-                if (!((okmask >> i) & 1u)) v = make_float4(0.f, 0.f, 0.f, 0.f);
-                *reinterpret_cast<float4 *>(buf + (e / 4) * WG::PS + 4 * (e % 4)) = v;
-            }
-        }
+    auto lwrite1 = [&](int i, int obuf) {                               // lanes past the patch write a dummy slot
+        const float4 v = ((okmask >> i) & 1u) ? st[i] : make_float4(0.f, 0.f, 0.f, 0.f);
+        *reinterpret_cast<float4 *>(lds + (loff[i] >= 0 ? obuf + loff[i] : 3 * WG::BUF)) = v;
     };
 
-    // ---- per-wave constants of the input transform: rows (ra, rb) of the 4x4 patch and their signs
+    // ---- per-wave constants of the input transform: rows (ra, rb) of the 4x4 patch, t = d[ra] + rs * d[rb]
+    // (row 0: d0 - d2, row 1: d1 + d2, row 2: d1 - d2 = -(B^T d)[2], row 3: d1 - d3)
     const int ra = row == 0 ? 0 : 1, rb = row == 3 ? 3 : 2;
-    const float sa = row == 2 ? -1.0f : 1.0f, sb = (row == 0 || row == 3) ? -1.0f : 1.0f;
+    const float rs = row == 1 ? 1.0f : -1.0f;
     const int t = lane & 31, tr = t >> 3, tc = t & 7, half = lane >> 5;
     const int abase_a = ((2 * tr + ra) * WG::IW + 2 * tc) * WG::PS + 4 * half;
     const int abase_b = ((2 * tr + rb) * WG::IW + 2 * tc) * WG::PS + 4 * half;
-    auto transform = [&](const float *buf, int kk, float4(&V)[4]) {
-        float4 tt[4];
-#pragma unroll
-        for (int c = 0; c < 4; ++c) {
-            const float4 da = *reinterpret_cast<const float4 *>(buf + abase_a + c * WG::PS + kk * 8);
-            const float4 db = *reinterpret_cast<const float4 *>(buf + abase_b + c * WG::PS + kk * 8);
-            tt[c].x = sa * da.x + sb * db.x;
-            tt[c].y = sa * da.y + sb * db.y;
-            tt[c].z = sa * da.z + sb * db.z;
-            tt[c].w = sa * da.w + sb * db.w;
-        }
-        V[0] = make_float4(tt[0].x - tt[2].x, tt[0].y - tt[2].y, tt[0].z - tt[2].z, tt[0].w - tt[2].w);
-        V[1] = make_float4(tt[1].x + tt[2].x, tt[1].y + tt[2].y, tt[1].z + tt[2].z, tt[1].w + tt[2].w);
-        V[2] = make_float4(tt[2].x - tt[1].x, tt[2].y - tt[1].y, tt[2].z - tt[1].z, tt[2].w - tt[1].w);
-        V[3] = make_float4(tt[1].x - tt[3].x, tt[1].y - tt[3].y, tt[1].z - tt[3].z, tt[1].w - tt[3].w);
+    float4 da[4], db[4];                                               // transform scratch (t[c] ends up in da[c])
+    auto rd1 = [&](const float *buf, int kk, int r) {                  // LDS read r = 2c + {0: row ra, 1: row rb}
+        const int c = r >> 1;
+        if (r & 1) db[c] = *reinterpret_cast<const float4 *>(buf + abase_b + c * WG::PS + kk * 8);
+        else da[c] = *reinterpret_cast<const float4 *>(buf + abase_a + c * WG::PS + kk * 8);
+    };
+    auto tt1 = [&](int c) {
+        da[c].x = __builtin_fmaf(db[c].x, rs, da[c].x);
+        da[c].y = __builtin_fmaf(db[c].y, rs, da[c].y);
+        da[c].z = __builtin_fmaf(db[c].z, rs, da[c].z);
+        da[c].w = __builtin_fmaf(db[c].w, rs, da[c].w);
+    };
+    auto sub4 = [](const float4 &x, const float4 &y) { return make_float4(x.x - y.x, x.y - y.y, x.z - y.z, x.w - y.w); };
+    auto add4 = [](const float4 &x, const float4 &y) { return make_float4(x.x + y.x, x.y + y.y, x.z + y.z, x.w + y.w); };
+    auto vv1 = [&](float4(&O)[4], int j) {                             // column combination j of B^T d B
+        O[j] = j == 0 ? sub4(da[0], da[2]) : j == 1 ? add4(da[1], da[2]) : j == 2 ? sub4(da[2], da[1]) : sub4(da[1], da[3]);
     };
 
     floatx16 acc[4][2];
@@ -682,57 +691,85 @@ __global__ __launch_bounds__(256, 2) void gated_conv_wino_kernel(const ConvKArgs
 
     // ---- B fragments: wave (g, row) reads 8 tiles per k8 step, [j][f|m]; half-step = 4 tiles (two frequencies)
     const int nsteps = a.nchunks * 2;                               // k8 steps of the layer
-    const float4 *wb = reinterpret_cast<const float4 *>(a.wp_wino) + ((size_t)g * nsteps * 4 + row) * 8 * 64 + lane;
-    auto bptr = [&](int hs) {                                       // half-step hs = 2*step + h
-        hs = hs < 2 * nsteps ? hs : 2 * nsteps - 1;
-        return wb + ((size_t)(hs >> 1) * 4 * 8 + (hs & 1) * 4) * 64;
-    };
+    const char *const bbase = reinterpret_cast<const char *>(a.wp_wino) +
+                              ((size_t)g * nsteps * 4 + row) * (8 * 64 * 16);            // wave-uniform
+    const unsigned bvoff = lane * 16;
+    const int last_hs = 2 * nsteps - 1;
     float4 bq[2][4];
+    auto bload1 = [&](int slot, int q, int hs) {                    // half-step hs = 2*step + h, clamped at the end
+        hs = hs < last_hs ? hs : last_hs;
+        bq[slot][q] = load_f4(bbase + (size_t)(hs >> 1) * (4 * 8 * 64 * 16) + (hs & 1) * (4 * 64 * 16) + q * 1024, bvoff);
+    };
+
+    // ---- prologue: chunks 0 and 1 into LDS, first B half-step, A fragments of k-step 0
     {
-        const float4 *b0 = bptr(0);
+        float4 st1[WG::NI];
 #pragma unroll
-        for (int q = 0; q < 4; ++q) bq[0][q] = b0[q * 64];
-    }
-
-    gload(0);
-    lwrite(lds);
-    __syncthreads();
-
-    for (int chunk = 0; chunk < a.nchunks; ++chunk) {
-        const bool more = chunk + 1 < a.nchunks;
-        if (more) gload(chunk + 1);
-        const float *buf = lds + (chunk & 1) * WG::BUF;
-        float4 V[4], Vn[4];
-        transform(buf, 0, V);
-#pragma unroll
-        for (int kk = 0; kk < 2; ++kk) {
-#pragma unroll
-            for (int h = 0; h < 2; ++h) {
-                const int hs = (chunk * 2 + kk) * 2 + h;
-                const int cur = h, nxt = h ^ 1;                      // hs parity == h (two half-steps per step)
-                const float4 *nb = bptr(hs + 1);
-#pragma unroll
-                for (int q = 0; q < 4; ++q) bq[nxt][q] = nb[q * 64];
-                if (h == 0 && kk == 0) transform(buf, 1, Vn);         // next k8 step's A fragments, under these MFMAs
-                __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-                for (int e = 0; e < 4; ++e)
-#pragma unroll
-                    for (int jj = 0; jj < 2; ++jj)
-#pragma unroll
-                        for (int fm = 0; fm < 2; ++fm) {
-                            const int j = 2 * h + jj;
-                            const float4 av = kk == 0 ? V[j] : Vn[j];
-                            const float4 bv = bq[cur][jj * 2 + fm];
-                            const float ae = e == 0 ? av.x : e == 1 ? av.y : e == 2 ? av.z : av.w;
-                            const float be = e == 0 ? bv.x : e == 1 ? bv.y : e == 2 ? bv.z : bv.w;
-                            acc[j][fm] = __builtin_amdgcn_mfma_f32_32x32x2f32(ae, be, acc[j][fm], 0, 0, 0);
-                        }
-                __builtin_amdgcn_sched_barrier(0);
-            }
+        for (int i = 0; i < WG::NI; ++i) {
+            gload1(i, 0);
+            st1[i] = load_f4(abase + (last_chunk > 0 ? 1 : 0) * (WG::KC * 4), aoff[i]);
         }
-        if (more) lwrite(lds + ((chunk + 1) & 1) * WG::BUF);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) bload1(0, q, 0);
+#pragma unroll
+        for (int i = 0; i < WG::NI; ++i) {
+            lwrite1(i, 0);
+            if (loff[i] >= 0)
+                *reinterpret_cast<float4 *>(lds + WG::BUF + loff[i]) = ((okmask >> i) & 1u) ? st1[i] : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+    }
+    __syncthreads();
+    float4 V[4], Vn[4];                                             // A fragments of k-step 0 / 1 of the running chunk
+#pragma unroll
+    for (int r = 0; r < 8; ++r) rd1(lds, 0, r);
+#pragma unroll
+    for (int c = 0; c < 4; ++c) tt1(c);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) vv1(V, j);
+
+    int o_cur = 0, o_nxt = WG::BUF, o_nn = 2 * WG::BUF;             // LDS buffers of chunk, chunk+1, chunk+2
+    for (int chunk = 0; chunk < a.nchunks; ++chunk) {
+        const float *buf = lds + o_cur, *bufn = lds + o_nxt;
+#pragma unroll
+        for (int q4 = 0; q4 < 4; ++q4) {                             // half-steps: (k-step q4 >> 1, frequency pair q4 & 1)
+            const int hs = chunk * 4 + q4;
+            const int cur = q4 & 1, nxt = cur ^ 1;
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+#pragma unroll
+                for (int jj = 0; jj < 2; ++jj)
+#pragma unroll
+                    for (int fm = 0; fm < 2; ++fm) {
+                        const int j = 2 * (q4 & 1) + jj, m = e * 4 + jj * 2 + fm;
+                        const float4 av = q4 < 2 ? V[j] : Vn[j];
+                        const float4 bv = bq[cur][jj * 2 + fm];
+                        const float ae = e == 0 ? av.x : e == 1 ? av.y : e == 2 ? av.z : av.w;
+                        const float be = e == 0 ? bv.x : e == 1 ? bv.y : e == 2 ? bv.z : bv.w;
+                        acc[j][fm] = __builtin_amdgcn_mfma_f32_32x32x2f32(ae, be, acc[j][fm], 0, 0, 0);
+                        // ---- one item in the shadow of MFMA m
+                        if (m < 4) bload1(nxt, m, hs + 1);
+                        else if (q4 == 0) {
+                            if (m - 4 < WG::NI) gload1(m - 4, chunk + 2);           // patch of chunk + 2 -> registers
+                            else if (m >= 8) rd1(buf, 1, m - 8);                     // k-step 1 of this chunk
+                        } else if (q4 == 1) {
+                            if (m < 8) tt1(m - 4);
+                            else if (m < 12) vv1(Vn, m - 8);
+                        } else if (q4 == 2) {
+                            if (m < 12) rd1(bufn, 0, m - 4);                         // k-step 0 of the next chunk
+                            else if (m - 12 < WG::NI) lwrite1(m - 12, o_nn);         // patch of chunk + 2 -> LDS
+                        } else {
+                            if (m < 8) tt1(m - 4);
+                            else if (m < 12) vv1(V, m - 8);
+                        }
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+        }
         __syncthreads();
+        const int o = o_cur;
+        o_cur = o_nxt;
+        o_nxt = o_nn;
+        o_nn = o;
     }
 
     // ---- output transform, stage 1 (in-wave): R_b = sum_j A^T[b][j] M[row][j]
@@ -1047,7 +1084,7 @@ extern "C" int read_conv_pack_wino_host(int Cin, int Cout, const float *wf, cons
                                     for (int a = 0; a < 3; ++a)
                                         for (int b = 0; b < 3; ++b) u += G[i][a] * k[a * 3 + b] * G[j][b];
                                 }
-                                out[o] = u;
+                                out[o] = i == 2 ? -u : u;      // the kernel builds row 2 of B^T d negated
                             }
                     }
     return READ_OK;
@@ -1136,8 +1173,8 @@ int launch_gated_conv(const read_conv_desc *d, hipStream_t stream)
     int cfg = d->config;
     if (cfg < 0 && g_use_wino && d->ksize == 3 && d->stride == 1 && kc == 16 && d->n_src == 1 && !d->mul &&
         d->src[0].shift == 0 && d->wpacked_wino && Cin <= g_use_wino)
-        for (int i = 0; i < N_CONFIGS; ++i)
-            if (g_configs[i].wino) cfg = i;
+        for (int i = N_CONFIGS - 1; i >= 0; --i)
+            if (g_configs[i].wino) cfg = i;       // first Winograd entry = the product kernel
     if (cfg < 0) cfg = pick_config(d->ksize, d->stride, kc, groups, outH, outW);
     if (d->config < 0 && d->mul && cfg >= 0 && !g_configs[cfg].fn_mul)
         for (int i = 0; i < N_CONFIGS; ++i) {

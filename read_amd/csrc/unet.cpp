@@ -27,7 +27,9 @@ struct LayerInfo {
     std::string path;
     int cin, cout, k, stride, elu, kc;
     size_t raw_off, w_off, p_off;   // float offsets into the raw / packed blobs
+    size_t wino_off;                // Winograd-transformed weights of 3x3/s1 layers with Cin % 16 == 0, else NO_WINO
 };
+constexpr size_t NO_WINO = ~(size_t)0;
 
 struct Arch {
     std::vector<LayerInfo> layers;
@@ -47,13 +49,17 @@ const Arch &arch()
     static Arch A = [] {
         Arch a;
         auto add = [&](const std::string &path, int cin, int cout, int k, int s, int elu, int kc) {
-            LayerInfo L{path, cin, cout, k, s, elu, kc, 0, 0, 0};
+            LayerInfo L{path, cin, cout, k, s, elu, kc, 0, 0, 0, NO_WINO};
             L.raw_off = a.raw_floats;
             a.raw_floats += raw_layer_floats(cin, cout, k);
             L.w_off = a.packed_floats;
             a.packed_floats += read_conv_packed_floats(cin, cout, k);
             L.p_off = a.packed_floats;
             a.packed_floats += read_conv_param_floats(cout);
+            if (k == 3 && s == 1 && kc == 16 && cin % 16 == 0) {
+                L.wino_off = a.packed_floats;
+                a.packed_floats += read_conv_wino_floats(cin, cout);
+            }
             a.layers.push_back(L);
         };
         // SCM (unet.py:92-106): SCM2 -> 64 planes @1/2, SCM1 -> 128 @1/4, SCM0 -> 256 @1/8
@@ -211,6 +217,7 @@ struct Builder {
         op.d.elu = L.elu;
         op.d.wpacked = u->packed + L.w_off;
         op.d.params = u->packed + L.p_off;
+        op.d.wpacked_wino = L.wino_off != NO_WINO ? u->packed + L.wino_off : nullptr;
         op.d.mul = mul_t >= 0 ? u->tensors[mul_t].p : nullptr;
         op.d.residual = res_t >= 0 ? u->tensors[res_t].p : nullptr;
         op.d.out = o.p;
@@ -412,6 +419,10 @@ extern "C" int read_unet_pack_host(const float *raw, float bn_eps, float *packed
         if (rc) return rc;
         rc = read_conv_pack_params_host(L.cout, bf, bm, gamma, beta, mean, var, bn_eps, packed + L.p_off);
         if (rc) return rc;
+        if (L.wino_off != NO_WINO) {
+            rc = read_conv_pack_wino_host(L.cin, L.cout, wf, wm, packed + L.wino_off);
+            if (rc) return rc;
+        }
     }
     return READ_OK;
 }

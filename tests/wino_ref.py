@@ -1,4 +1,4 @@
-"""NumPy model of the Winograd F(2x2,3x3) gated-conv kernel (read_amd/csrc/conv_wino.hip): the filter
+"""NumPy model of the Winograd F(2x2,3x3) gated-conv kernel (gated_conv_wino_kernel in read_amd/csrc/conv.hip): the filter
 transform + fragment packing, the per-wave input transform, the MFMA contraction per frequency and the
 cross-wave output transform — written with the SAME index maps as the HIP kernel so that layout mistakes
 show up on the CPU.  Used by tests/test_wino_cpu.py against torch's conv2d."""
@@ -15,7 +15,8 @@ def filter_transform(w):
 
 
 def pack_wino(wf, wm):
-    """-> flat float32 array ordered [group][k8 step][row i][j][f|m][lane 64][4], cout padded to 32."""
+    """-> flat float32 array ordered [group][k8 step][row i][j][f|m][lane 64][4], cout padded to 32;
+    row 2 negated (the kernel forms d1 - d2 = -(B^T d)[2] so that every row is d[ra] +- d[rb])."""
     cout, cin = wf.shape[:2]
     cp = (cout + 31) // 32 * 32
     Uf, Um = filter_transform(wf), filter_transform(wm)
@@ -29,8 +30,9 @@ def pack_wino(wf, wm):
                 ci = 8 * s + 4 * (lane >> 5) + e
                 for i in range(4):
                     for j in range(4):
-                        out[g, s, i, j, 0, ok, e] = Uf[i, j, ci[ok], co[ok]]
-                        out[g, s, i, j, 1, ok, e] = Um[i, j, ci[ok], co[ok]]
+                        sg = -1.0 if i == 2 else 1.0
+                        out[g, s, i, j, 0, ok, e] = sg * Uf[i, j, ci[ok], co[ok]]
+                        out[g, s, i, j, 1, ok, e] = sg * Um[i, j, ci[ok], co[ok]]
     return out.reshape(-1)
 
 
@@ -47,7 +49,7 @@ def wino_conv_model(x_hwc, packed, cin, cout):
     lane = np.arange(64)
     t = lane & 31
     tr, tc, half = t >> 3, t & 7, lane >> 5
-    sign = {0: (0, 2, 1, -1), 1: (1, 2, 1, 1), 2: (1, 2, -1, 1), 3: (1, 3, 1, -1)}
+    sign = {0: (0, 2, 1, -1), 1: (1, 2, 1, 1), 2: (1, 2, 1, -1), 3: (1, 3, 1, -1)}
     for by in range((H + 7) // 8):
         for bx in range((W + 15) // 16):
             oy0, ox0 = by * 8, bx * 16
