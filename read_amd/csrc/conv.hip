@@ -52,6 +52,7 @@ struct ConvKArgs {
     int stagger_ticks;             //   start delay (10 ns ticks) of waves in odd hardware slots: de-phases SIMD partners
     int n_full, col_split;         //   units [0,n_full) are P-row units of columns [0,col_split); the rest are
                                    //   1-row units of the remaining (group set, x tile) columns (balanced tail)
+    int wino_dby, wino_dbx;        // Winograd kernel: (tile row, tile column) step between a workgroup's units
     int elu, fill_pad;
     float out_fill;
     unsigned long long *trace;     // optional timeline: 8 x u64 per workgroup (read_debug_set_trace)
@@ -607,50 +608,85 @@ struct WinoGeom {
     static constexpr int IH = 2 * TR + 2, IW = 2 * TC + 2;   // 10 x 18 input pixels
     static constexpr int KC = 16, PS = KC + 4, BUF = IH * IW * PS;
     static constexpr int NE = IH * IW * (KC / 4), NI = (NE + 255) / 256;
-    static constexpr int RED = 4 * 2 * 2 * 16 * 64;      // floats of the cross-wave reduction (64 KiB)
-    static constexpr int LDS_FLOATS = RED > 3 * BUF + 4 ? RED : 3 * BUF + 4;      // + a dummy float4 slot
+    static constexpr int RED = 4 * 2 * 16 * 64;          // floats of the cross-wave reduction of one of {f, m} (32 KiB)
+    static constexpr int LDS_FLOATS = 3 * BUF + 4 + RED; // three patch buffers, a dummy float4 slot, the reduction
 };
 
 // (scalar base + 32-bit lane offset) load: hipcc selects the saddr form global_load_dwordx4 v, voff, s[base:base+1],
 // no per-load 64-bit VALU address math.  (raw_buffer_load_b64/b128 builtins of this ROCm load a single dword.)
 __device__ __forceinline__ float4 load_f4(const char *sbase, unsigned voff)
 {
+    asm volatile("" : "+v"(voff));      // opaque: keeps hipcc from folding the lane offset into hoisted 64-bit VGPR bases
     return *reinterpret_cast<const float4 *>(sbase + voff);
 }
 
+template <bool TRACE>
 __global__ __launch_bounds__(256, 2) void gated_conv_wino_kernel(const ConvKArgs a)
 {
     using WG = WinoGeom;
     __shared__ __attribute__((aligned(16))) float lds[WG::LDS_FLOATS];
+    // TRACE: rec = {start, end of prologue, ticks in epilogues: total, to 3rd barrier passed, to last LDS read landed,
+    //        to residual/parameter loads landed, end, hw id} (10 ns ticks; tools/trace_conv.py)
+    unsigned long long t_trace[2] = {0, 0}, t_ep[4] = {0, 0, 0, 0};
+    if (TRACE) t_trace[0] = __builtin_amdgcn_s_memrealtime();
     const int tid = threadIdx.x, lane = tid & 63;
     const int row = __builtin_amdgcn_readfirstlane(tid >> 6);          // frequency row i of this wave
-    const int bx = blockIdx.x % a.tiles_x, by = blockIdx.x / a.tiles_x;
-    const int g = blockIdx.y;
-    const int oy0 = by * (2 * WG::TR), ox0 = bx * (2 * WG::TC);
-    const int iy0 = oy0 - 1, ix0 = ox0 - 1;
     const SrcDev s = a.src[0];
+    const int groups = a.CoutPad >> 5, G = gridDim.x;                  // G % groups == 0: g is fixed per workgroup
+    const int g = blockIdx.x % groups;
+    const int n = a.nchunks;
 
-    // ---- input patch staging: per-lane byte offsets into the source; pixels outside the image load offset 0 and
-    // are zeroed on the way into LDS
-    unsigned aoff[WG::NI];
+    // ---- units: u = blockIdx.x + k G  ->  tile u / groups = (by, bx), advanced by (wino_dby, wino_dbx) per step
+    int by = (blockIdx.x / groups) / a.tiles_x, bx = (blockIdx.x / groups) % a.tiles_x;      // running unit
+    int pby = by, pbx = bx, pu = blockIdx.x, pchunk = 0;                                     // prefetch cursor
+    auto step_tile = [&](int &ty_, int &tx_) {
+        ty_ += a.wino_dby;
+        tx_ += a.wino_dbx;
+        if (tx_ >= a.tiles_x) {
+            tx_ -= a.tiles_x;
+            ++ty_;
+        }
+    };
+
+    // ---- input patch staging.  Lane constants: LDS slot and byte offset of its float4s relative to the patch
+    // origin; per unit only the scalar origin and the inside-the-image mask change.  Outside pixels load the
+    // patch's (1,1) pixel (always inside) and are zeroed on the way into LDS.
     int loff[WG::NI];
+    unsigned rel[WG::NI], aoff[WG::NI];
     unsigned okmask = 0;
 #pragma unroll
     for (int i = 0; i < WG::NI; ++i) {
         const int e = tid + i * 256, q = e % 4, pix = e / 4;
-        const int gy = iy0 + pix / WG::IW, gx = ix0 + pix % WG::IW;
-        const bool ok = e < WG::NE && gy >= 0 && gy < a.inH && gx >= 0 && gx < a.inW;
-        okmask |= (ok ? 1u : 0u) << i;
-        aoff[i] = ok ? (unsigned)(((gy * s.W + gx) * s.C + 4 * q) * 4) : 0u;
         loff[i] = e < WG::NE ? pix * WG::PS + 4 * q : -1;
+        rel[i] = (unsigned)(((pix / WG::IW) * s.W + pix % WG::IW) * s.C + 4 * q) * 4u;
     }
-    const int last_chunk = a.nchunks - 1;
-    const char *const abase = reinterpret_cast<const char *>(s.p);
-    float4 st[WG::NI];
-    auto gload1 = [&](int i, int chunk) {                               // chunk clamped: a repeated load is harmless
-        chunk = chunk < last_chunk ? chunk : last_chunk;
-        st[i] = load_f4(abase + chunk * (WG::KC * 4), aoff[i]);
+    const unsigned safe_rel = (unsigned)((s.W + 1) * s.C) * 4u;
+    const char *pbase = nullptr;                                        // patch origin of the cursor unit (+ chunk)
+    auto set_patch = [&]() {
+        const int y0 = pby * (2 * WG::TR) - 1, x0 = pbx * (2 * WG::TC) - 1;
+        pbase = reinterpret_cast<const char *>(s.p) + ((long)y0 * s.W + x0) * (long)(s.C * 4);
+        okmask = 0;
+#pragma unroll
+        for (int i = 0; i < WG::NI; ++i) {
+            const int e = tid + i * 256, pix = e / 4, ppy = pix / WG::IW, ppx = pix % WG::IW;
+            const bool ok = (e < WG::NE) & (ppy >= -y0) & (ppy < a.inH - y0) & (ppx >= -x0) & (ppx < a.inW - x0);
+            okmask |= (ok ? 1u : 0u) << i;
+            aoff[i] = ok ? rel[i] : safe_rel;
+        }
     };
+    // the cursor runs two chunks ahead of the MFMAs and crosses unit boundaries (past the last unit it repeats it)
+    auto advance = [&]() {
+        if (++pchunk == n) {
+            pchunk = 0;
+            if (pu + G < a.n_units) {
+                pu += G;
+                step_tile(pby, pbx);
+            }
+            set_patch();
+        }
+    };
+    float4 st[WG::NI];
+    auto gload1 = [&](int i) { st[i] = load_f4(pbase + pchunk * (WG::KC * 4), aoff[i]); };
     auto lwrite1 = [&](int i, int obuf) {                               // lanes past the patch write a dummy slot
         const float4 v = ((okmask >> i) & 1u) ? st[i] : make_float4(0.f, 0.f, 0.f, 0.f);
         *reinterpret_cast<float4 *>(lds + (loff[i] >= 0 ? obuf + loff[i] : 3 * WG::BUF)) = v;
@@ -681,42 +717,44 @@ __global__ __launch_bounds__(256, 2) void gated_conv_wino_kernel(const ConvKArgs
         O[j] = j == 0 ? sub4(da[0], da[2]) : j == 1 ? add4(da[1], da[2]) : j == 2 ? sub4(da[2], da[1]) : sub4(da[1], da[3]);
     };
 
-    floatx16 acc[4][2];
-#pragma unroll
-    for (int j = 0; j < 4; ++j)
-#pragma unroll
-        for (int fm = 0; fm < 2; ++fm)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[j][fm][r] = 0.0f;
+    floatx16 acc[4][2];                                             // written (C = 0) by the first chunk of every unit
 
     // ---- B fragments: wave (g, row) reads 8 tiles per k8 step, [j][f|m]; half-step = 4 tiles (two frequencies)
-    const int nsteps = a.nchunks * 2;                               // k8 steps of the layer
+    const int nhs = n * 4;                                          // half-steps of one unit
     const char *const bbase = reinterpret_cast<const char *>(a.wp_wino) +
-                              ((size_t)g * nsteps * 4 + row) * (8 * 64 * 16);            // wave-uniform
+                              ((size_t)g * (n * 2) * 4 + row) * (8 * 64 * 16);           // wave-uniform
     const unsigned bvoff = lane * 16;
-    const int last_hs = 2 * nsteps - 1;
     float4 bq[2][4];
-    auto bload1 = [&](int slot, int q, int hs) {                    // half-step hs = 2*step + h, clamped at the end
-        hs = hs < last_hs ? hs : last_hs;
+    auto bload1 = [&](int slot, int q, int hs) {                    // half-step hs = 2*step + h of the unit
         bq[slot][q] = load_f4(bbase + (size_t)(hs >> 1) * (4 * 8 * 64 * 16) + (hs & 1) * (4 * 64 * 16) + q * 1024, bvoff);
     };
 
-    // ---- prologue: chunks 0 and 1 into LDS, first B half-step, A fragments of k-step 0
+    constexpr int OOB = 0x7ffffff0;
+    const int cch = g * 32 + (lane & 31);
+    float *const red = lds + 3 * WG::BUF + 4;                       // [row][b][register][lane], one of {f, m} at a time
+
+    // ---- prologue: the first two chunks of the stream into LDS, first B half-step, A fragments of k-step 0
+    set_patch();
     {
         float4 st1[WG::NI];
 #pragma unroll
-        for (int i = 0; i < WG::NI; ++i) {
-            gload1(i, 0);
-            st1[i] = load_f4(abase + (last_chunk > 0 ? 1 : 0) * (WG::KC * 4), aoff[i]);
-        }
+        for (int i = 0; i < WG::NI; ++i) gload1(i);
+        const unsigned ok0 = okmask;
+        advance();
+#pragma unroll
+        for (int i = 0; i < WG::NI; ++i) st1[i] = load_f4(pbase + pchunk * (WG::KC * 4), aoff[i]);
 #pragma unroll
         for (int q = 0; q < 4; ++q) bload1(0, q, 0);
 #pragma unroll
         for (int i = 0; i < WG::NI; ++i) {
-            lwrite1(i, 0);
-            if (loff[i] >= 0)
-                *reinterpret_cast<float4 *>(lds + WG::BUF + loff[i]) = ((okmask >> i) & 1u) ? st1[i] : make_float4(0.f, 0.f, 0.f, 0.f);
+            const float4 v0 = ((ok0 >> i) & 1u) ? st[i] : make_float4(0.f, 0.f, 0.f, 0.f);
+            const float4 v1 = ((okmask >> i) & 1u) ? st1[i] : make_float4(0.f, 0.f, 0.f, 0.f);
+            if (loff[i] >= 0) {
+                *reinterpret_cast<float4 *>(lds + loff[i]) = v0;
+                *reinterpret_cast<float4 *>(lds + WG::BUF + loff[i]) = v1;
+            }
         }
+        advance();
     }
     __syncthreads();
     float4 V[4], Vn[4];                                             // A fragments of k-step 0 / 1 of the running chunk
@@ -726,13 +764,19 @@ __global__ __launch_bounds__(256, 2) void gated_conv_wino_kernel(const ConvKArgs
     for (int c = 0; c < 4; ++c) tt1(c);
 #pragma unroll
     for (int j = 0; j < 4; ++j) vv1(V, j);
+    if (TRACE) t_trace[1] = __builtin_amdgcn_s_memrealtime();
 
-    int o_cur = 0, o_nxt = WG::BUF, o_nn = 2 * WG::BUF;             // LDS buffers of chunk, chunk+1, chunk+2
-    for (int chunk = 0; chunk < a.nchunks; ++chunk) {
+    int o_cur = 0, o_nxt = WG::BUF, o_nn = 2 * WG::BUF;             // LDS buffers of chunk, chunk+1, chunk+2 of the stream
+
+    // One chunk = 4 half-steps x 16 MFMAs, every other instruction an item in an MFMA's shadow.  FIRST: the unit's
+    // first chunk starts the accumulators from C = 0 (no zeroing pass).
+    auto chunk_body = [&](auto first_tag, int chunk) {
+        constexpr bool FIRST = decltype(first_tag)::value;
         const float *buf = lds + o_cur, *bufn = lds + o_nxt;
 #pragma unroll
         for (int q4 = 0; q4 < 4; ++q4) {                             // half-steps: (k-step q4 >> 1, frequency pair q4 & 1)
-            const int hs = chunk * 4 + q4;
+            int hs1 = chunk * 4 + q4 + 1;                            // next half-step; wraps into the next unit (same g)
+            if (q4 == 3) hs1 = hs1 == nhs ? 0 : hs1;
             const int cur = q4 & 1, nxt = cur ^ 1;
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
@@ -746,93 +790,146 @@ __global__ __launch_bounds__(256, 2) void gated_conv_wino_kernel(const ConvKArgs
                         const float4 bv = bq[cur][jj * 2 + fm];
                         const float ae = e == 0 ? av.x : e == 1 ? av.y : e == 2 ? av.z : av.w;
                         const float be = e == 0 ? bv.x : e == 1 ? bv.y : e == 2 ? bv.z : bv.w;
-                        acc[j][fm] = __builtin_amdgcn_mfma_f32_32x32x2f32(ae, be, acc[j][fm], 0, 0, 0);
-                        // ---- one item in the shadow of MFMA m
-                        if (m < 4) bload1(nxt, m, hs + 1);
-                        else if (q4 == 0) {
-                            if (m - 4 < WG::NI) gload1(m - 4, chunk + 2);           // patch of chunk + 2 -> registers
-                            else if (m >= 8) rd1(buf, 1, m - 8);                     // k-step 1 of this chunk
-                        } else if (q4 == 1) {
-                            if (m < 8) tt1(m - 4);
-                            else if (m < 12) vv1(Vn, m - 8);
-                        } else if (q4 == 2) {
-                            if (m < 12) rd1(bufn, 0, m - 4);                         // k-step 0 of the next chunk
-                            else if (m - 12 < WG::NI) lwrite1(m - 12, o_nn);         // patch of chunk + 2 -> LDS
+                        if (FIRST && q4 < 2 && e == 0) {
+                            const floatx16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+                            acc[j][fm] = __builtin_amdgcn_mfma_f32_32x32x2f32(ae, be, zero, 0, 0, 0);
+                        } else
+                            acc[j][fm] = __builtin_amdgcn_mfma_f32_32x32x2f32(ae, be, acc[j][fm], 0, 0, 0);
+                        // ---- one item in the shadow of MFMA m.  Even half-step: patch load / LDS write, then LDS
+                        // reads 0..6 of the next k-step's transform with t[0], t[1] as soon as their rows are in;
+                        // odd half-step: read 7, t[2], t[3], the four column combinations.
+                        const float *tb = q4 < 2 ? buf : bufn;               // k-step 1 of this chunk / k-step 0 of the next
+                        const int tk = q4 < 2 ? 1 : 0;
+                        if (m < 4) bload1(nxt, m, hs1);
+                        else if ((q4 & 1) == 0) {
+                            if (m - 4 < WG::NI) {
+                                if (q4 == 0) gload1(m - 4);                              // patch at the cursor -> registers
+                                else lwrite1(m - 4, o_nn);                               // ... -> LDS, half a chunk later
+                            } else if (m >= 7 && m <= 10) rd1(tb, tk, m - 7);
+                            else if (m == 11) tt1(0);
+                            else if (m == 12 || m == 13) rd1(tb, tk, m - 8);
+                            else if (m == 14) tt1(1);
+                            else if (m == 15) rd1(tb, tk, 6);
                         } else {
-                            if (m < 8) tt1(m - 4);
-                            else if (m < 12) vv1(V, m - 8);
+                            if (m == 4) rd1(tb, tk, 7);
+                            else if (m == 5) tt1(2);
+                            else if (m == 7) tt1(3);
+                            else if (m >= 8 && m < 12) { if (q4 == 1) vv1(Vn, m - 8); else vv1(V, m - 8); }
                         }
                         __builtin_amdgcn_sched_barrier(0);
                     }
         }
+        advance();
         __syncthreads();
         const int o = o_cur;
         o_cur = o_nxt;
         o_nxt = o_nn;
         o_nn = o;
-    }
+    };
 
-    // ---- output transform, stage 1 (in-wave): R_b = sum_j A^T[b][j] M[row][j]
-    // red[(row*2 + b)*2 + fm][r][lane]
-    float *red = lds;
+    for (int u = blockIdx.x; u < a.n_units; u += G) {
+        chunk_body(std::true_type{}, 0);
+        for (int chunk = 1; chunk < n; ++chunk) chunk_body(std::false_type{}, chunk);
+
+        // ================= unit epilogue =================
+        // Wave `row` finishes accumulator registers 4 row .. 4 row + 3 of every (a, b): MFMA D row of register
+        // 4 row + rr is tile (ty, tx) = (row, rr + 4 half), i.e. output pixels (oy0 + 2 row + a, ox0 + 8 half + 2 rr + b).
+        unsigned long long t_e0 = 0;
+        if (TRACE) t_e0 = __builtin_amdgcn_s_memrealtime();
+        __builtin_amdgcn_s_setprio(3);        // the co-resident workgroup's MFMA stream otherwise starves this phase
+        const int oy = by * (2 * WG::TR) + 2 * row, ox = bx * (2 * WG::TC) + 8 * half;      // (a, rr, b) = (0, 0, 0)
+        const __amdgpu_buffer_rsrc_t orsrc = __builtin_amdgcn_make_buffer_rsrc(
+            (void *)a.out, 0, a.outH * a.outW * a.out_cstride * 4, 0x00020000);
+        const __amdgpu_buffer_rsrc_t rrsrc = __builtin_amdgcn_make_buffer_rsrc(
+            (void *)(a.residual ? a.residual : a.out), 0, a.residual ? a.outH * a.outW * a.Cout * 4 : 0, 0x00020000);
+        const bool c_ok = cch < a.Cout;
+        const bool c_st = c_ok || (a.fill_pad && cch < a.out_cstride);
+        const float bf = a.params[cch], bm = a.params[a.CoutPad + cch];
+        const float sc = a.params[2 * a.CoutPad + cch], sh = a.params[3 * a.CoutPad + cch];
+        const int xlim = a.outW - ox;                                // column 2 rr + b is inside iff < xlim
+        const bool row_in[2] = {oy < a.outH, oy + 1 < a.outH};       // wave-uniform
+        // residual loads first, so the memory latency runs under the cross-wave reduction; the pixel / row steps go
+        // into the scalar offset of the buffer instruction
+        float rv[2][4][2];
+        {
+            const int rbase = ((oy * a.outW + ox) * a.Cout + cch) * 4;
 #pragma unroll
-    for (int fm = 0; fm < 2; ++fm)
+            for (int aa = 0; aa < 2; ++aa)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const float r0 = acc[0][fm][r] + acc[1][fm][r] + acc[2][fm][r];
-            const float r1 = acc[1][fm][r] - acc[2][fm][r] - acc[3][fm][r];
-            red[((((row * 2 + 0) * 2 + fm) * 16) + r) * 64 + lane] = r0;
-            red[((((row * 2 + 1) * 2 + fm) * 16) + r) * 64 + lane] = r1;
+                for (int rr = 0; rr < 4; ++rr)
+#pragma unroll
+                    for (int b = 0; b < 2; ++b) {
+                        const int voff = (c_ok && row_in[aa] && 2 * rr + b < xlim) ? rbase : OOB;
+                        rv[aa][rr][b] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(
+                            rrsrc, voff, (aa * a.outW + 2 * rr + b) * a.Cout * 4, 0));
+                    }
         }
-    __syncthreads();
-
-    // ---- stage 2 + gated epilogue: wave `row` finishes registers 4*row .. 4*row+3 of every (a, b)
-    constexpr int OOB = 0x7ffffff0;
-    const __amdgpu_buffer_rsrc_t orsrc = __builtin_amdgcn_make_buffer_rsrc(
-        (void *)a.out, 0, a.outH * a.outW * a.out_cstride * 4, 0x00020000);
-    const __amdgpu_buffer_rsrc_t rrsrc = __builtin_amdgcn_make_buffer_rsrc(
-        (void *)(a.residual ? a.residual : a.out), 0, a.residual ? a.outH * a.outW * a.Cout * 4 : 0, 0x00020000);
-    const int c = g * 32 + (lane & 31);
-    const float bf = a.params[c], bm = a.params[a.CoutPad + c];
-    const float sc = a.params[2 * a.CoutPad + c], sh = a.params[3 * a.CoutPad + c];
-    const bool c_ok = c < a.Cout;
-    const bool c_st = c_ok || (a.fill_pad && c < a.out_cstride);
+        // output transform: in-wave over j (R_b = sum_j A^T[b][j] M[row][j]), across the four row-waves through LDS
+        // (Y[a][b] = sum_i A^T[a][i] R_b(i)), conv_f then conv_m through the same 32 KiB
+        float Y[2][2][4][2];                                         // [f|m][a][rr][b]
 #pragma unroll
-    for (int rr = 0; rr < 4; ++rr) {
-        const int r = row * 4 + rr;
-        const int tile = (r & 3) + 8 * (r >> 2) + 4 * half;          // MFMA D row of register r
-        const int ty = tile >> 3, tx = tile & 7;
-        float Yf[2][2], Ym[2][2];
+        for (int fm = 0; fm < 2; ++fm) {
 #pragma unroll
-        for (int b = 0; b < 2; ++b)
-#pragma unroll
-            for (int fm = 0; fm < 2; ++fm) {
-                float R[4];
-#pragma unroll
-                for (int i = 0; i < 4; ++i) R[i] = red[((((i * 2 + b) * 2 + fm) * 16) + r) * 64 + lane];
-                const float y0 = R[0] + R[1] + R[2], y1 = R[1] - R[2] - R[3];
-                if (fm == 0) { Yf[0][b] = y0; Yf[1][b] = y1; } else { Ym[0][b] = y0; Ym[1][b] = y1; }
+            for (int r = 0; r < 16; ++r) {
+                const float r0 = acc[0][fm][r] + acc[1][fm][r] + acc[2][fm][r];
+                const float r1 = acc[1][fm][r] - acc[2][fm][r] - acc[3][fm][r];
+                red[((row * 2 + 0) * 16 + r) * 64 + lane] = r0;
+                red[((row * 2 + 1) * 16 + r) * 64 + lane] = r1;
             }
-        int ooff[4];
-        float rv[4];
+            __syncthreads();
+            if (TRACE && fm == 1) t_ep[1] += __builtin_amdgcn_s_memrealtime() - t_e0;
 #pragma unroll
-        for (int ab = 0; ab < 4; ++ab) {
-            const int oy = oy0 + 2 * ty + (ab >> 1), ox = ox0 + 2 * tx + (ab & 1);
-            const bool in = (oy < a.outH) & (ox < a.outW);
-            const int opix = oy * a.outW + ox;
-            ooff[ab] = (in & c_st) ? (opix * a.out_cstride + c) * 4 : OOB;
-            const int roff = (in & c_ok) ? (opix * a.Cout + c) * 4 : OOB;
-            rv[ab] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rrsrc, roff, 0, 0));
-        }
+            for (int rr = 0; rr < 4; ++rr) {
+                const int r = row * 4 + rr;
 #pragma unroll
-        for (int ab = 0; ab < 4; ++ab) {
-            float f = Yf[ab >> 1][ab & 1] + bf;
-            const float m = Ym[ab >> 1][ab & 1] + bm;
-            if (a.elu) f = elu1(f);
-            float v = (f * sigmoidf(m)) * sc + sh + rv[ab];
-            v = c_ok ? v : a.out_fill;
-            __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), orsrc, ooff[ab], 0, 0);
+                for (int b = 0; b < 2; ++b) {
+                    float R[4];
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) R[i] = red[((i * 2 + b) * 16 + r) * 64 + lane];
+                    Y[fm][0][rr][b] = R[0] + R[1] + R[2];
+                    Y[fm][1][rr][b] = R[1] - R[2] - R[3];
+                }
+            }
+            if (fm == 0) __syncthreads();      // (after conv_m the next writer is a whole chunk of barriers away)
         }
+        if (TRACE) t_ep[2] += __builtin_amdgcn_s_memrealtime() - t_e0;
+        if (TRACE) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            t_ep[3] += __builtin_amdgcn_s_memrealtime() - t_e0;
+        }
+        {
+            const int obase = ((oy * a.outW + ox) * a.out_cstride + cch) * 4;
+#pragma unroll
+            for (int aa = 0; aa < 2; ++aa)
+#pragma unroll
+                for (int rr = 0; rr < 4; ++rr)
+#pragma unroll
+                    for (int b = 0; b < 2; ++b) {
+                        float f = Y[0][aa][rr][b] + bf;
+                        const float mm = Y[1][aa][rr][b] + bm;
+                        if (a.elu) f = elu1(f);
+                        float v = (f * sigmoidf(mm)) * sc + sh + rv[aa][rr][b];
+                        v = c_ok ? v : a.out_fill;
+                        const int voff = (c_st && row_in[aa] && 2 * rr + b < xlim) ? obase : OOB;
+                        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), orsrc, voff,
+                                                              (aa * a.outW + 2 * rr + b) * a.out_cstride * 4, 0);
+                    }
+        }
+        step_tile(by, bx);
+        __builtin_amdgcn_s_setprio(0);
+        if (TRACE) t_ep[0] += __builtin_amdgcn_s_memrealtime() - t_e0;
+    }
+    if (TRACE && a.trace && lane == 0) {                        // one record per wave: 4 per workgroup
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        unsigned long long *rec = a.trace + ((size_t)blockIdx.x * 4 + row) * 8;
+        rec[0] = t_trace[0];
+        rec[1] = t_trace[1];
+        rec[2] = t_ep[0];
+        rec[3] = t_ep[1];
+        rec[4] = t_ep[2];
+        rec[5] = t_ep[3];
+        rec[6] = __builtin_amdgcn_s_memrealtime();
+        rec[7] = __builtin_amdgcn_s_getreg((31 << 11) | 4);   // HW_REG_HW_ID (wave/simd/cu/sh/se)
     }
 }
 
@@ -907,7 +1004,7 @@ const ConvConfig g_configs[] = {
     CFGW(1, 1, 16, 2, 1, 1, 2),
     CFGW(1, 1, 16, 1, 1, 1, 4),
     CFGW(3, 1, 8, 2, 1, 2, 2),
-    {"k3s1c16_p1q1_wino", 3, 1, 16, 1, 1, 4, 1, 1, 2, gated_conv_wino_kernel, nullptr, 0, 0, 1},
+    {"k3s1c16_p1q1_wino", 3, 1, 16, 1, 1, 4, 1, 1, 2, gated_conv_wino_kernel<false>, nullptr, 0, 0, 1},
     // 4x4 stride 2 (decoder, before the bilinear x4): outputs are 1/4 .. 1/16 scale, so the 16 taps of
     // ONE 1x32-pixel tile are split over the four waves (split-K, WM*WN == 1) to fill the chip
     CFG(4, 2, 16, 1, 1, 1, 1, 1),   // 20  split-K, one group
@@ -928,7 +1025,7 @@ int find_config(int ks, int s, int kc, int P, int QG, int WM, int WN, int PF, in
 }
 
 int g_prefer_wave = 1;   // read_tuning_set("conv_wave", 0): workgroup-tiled kernels only
-int g_use_wino = 0;        // read_tuning_set("conv_wino", 1): Winograd kernel for eligible 3x3 layers
+int g_use_wino = 1 << 30;  // read_tuning_set("conv_wino", max Cin): Winograd kernel for eligible 3x3 layers (0 = off)
 int g_stagger_ticks = 0;
 int g_ablate = 0;          // read_tuning_set("conv_ablate", bits)   // read_tuning_set("conv_stagger", ticks of 10 ns)   // read_tuning_set("conv_wave", 1): wave-autonomous kernels where they exist
 
@@ -1126,6 +1223,8 @@ void conv_set_trace(void *buf, size_t bytes)
 
 // Validates a descriptor, builds kernel arguments and launches.  Shared by the single-layer
 // entry point and the UNet executor.
+int conv_uses_wino(const read_conv_desc *d);
+
 int launch_gated_conv(const read_conv_desc *d, hipStream_t stream)
 {
     READ_CHECK_ARG(d, "read_gated_conv_forward: null descriptor");
@@ -1171,8 +1270,7 @@ int launch_gated_conv(const read_conv_desc *d, hipStream_t stream)
     READ_CHECK_ARG((long long)outH * outW * d->out_cstride * 4 < OOB_LIMIT, "read_gated_conv_forward: output too large");
     const int CoutPad = pad32(d->Cout), groups = CoutPad / 32;
     int cfg = d->config;
-    if (cfg < 0 && g_use_wino && d->ksize == 3 && d->stride == 1 && kc == 16 && d->n_src == 1 && !d->mul &&
-        d->src[0].shift == 0 && d->wpacked_wino && Cin <= g_use_wino)
+    if (cfg < 0 && conv_uses_wino(d))
         for (int i = N_CONFIGS - 1; i >= 0; --i)
             if (g_configs[i].wino) cfg = i;       // first Winograd entry = the product kernel
     if (cfg < 0) cfg = pick_config(d->ksize, d->stride, kc, groups, outH, outW);
@@ -1217,8 +1315,21 @@ int launch_gated_conv(const read_conv_desc *d, hipStream_t stream)
         READ_CHECK_ARG(d->n_src == 1 && d->src[0].shift == 0 && !d->mul && d->src[0].C % 16 == 0,
                        "read_gated_conv_forward: the Winograd kernel takes one un-resampled source with C %% 16 == 0");
         a.tiles_x = ceil_div(outW, 16);
-        grid = dim3((unsigned)(a.tiles_x * ceil_div(outH, 8)), (unsigned)groups);
-        a.trace = nullptr;
+        a.n_units = a.tiles_x * ceil_div(outH, 8) * groups;       // unit u = (tile u / groups, group u % groups)
+        static int n_cu_w = 0;
+        if (!n_cu_w) {
+            int dev = 0;
+            hipDeviceProp_t prop;
+            n_cu_w = (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess &&
+                      prop.multiProcessorCount > 0) ? prop.multiProcessorCount : 256;
+        }
+        int nwg = a.n_units < 2 * n_cu_w ? a.n_units : 2 * n_cu_w;    // persistent: two workgroups per CU
+        nwg -= nwg % groups;                                          // keeps the group fixed per workgroup
+        if (nwg < groups) nwg = groups;
+        grid = dim3((unsigned)nwg, 1);
+        a.wino_dby = (nwg / groups) / a.tiles_x;
+        a.wino_dbx = (nwg / groups) % a.tiles_x;
+        a.trace = ((size_t)grid.x * 4 <= g_trace_records) ? g_trace : nullptr;
     }
     if (c.wave) {
         // persistent grid: every wave walks units u = wave, wave + n_waves, ...
@@ -1249,6 +1360,7 @@ int launch_gated_conv(const read_conv_desc *d, hipStream_t stream)
         grid = dim3((unsigned)(want < cap ? want : cap), 1);
     }
     conv_fn fn = c.fn;
+    if (c.wino && a.trace) fn = gated_conv_wino_kernel<true>;
     if (d->mul) {
         READ_CHECK_ARG(c.fn_mul, "read_gated_conv_forward: config %s has no multiply variant", c.name);
         READ_CHECK_ARG((uintptr_t)d->mul % 16 == 0, "read_gated_conv_forward: mul misaligned");
@@ -1257,6 +1369,13 @@ int launch_gated_conv(const read_conv_desc *d, hipStream_t stream)
     hipLaunchKernelGGL(fn, grid, dim3(256), 0, stream, a);
     READ_CHECK_LAUNCH();
     return READ_OK;
+}
+
+// the automatic choice takes the Winograd kernel for every layer it can run (measured faster on all four levels)
+int conv_uses_wino(const read_conv_desc *d)
+{
+    return d->config < 0 && g_use_wino && d->ksize == 3 && d->stride == 1 && d->n_src == 1 && !d->mul &&
+           d->src[0].shift == 0 && d->src[0].C % 16 == 0 && d->wpacked_wino && d->src[0].C <= g_use_wino;
 }
 
 int conv_kc_for(const read_conv_desc *d)

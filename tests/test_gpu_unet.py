@@ -98,3 +98,30 @@ def test_full_frame_256_100k_vs_oracle(hip):
     got = rgba[:, :, :3].permute(2, 0, 1)
     print("frame 256: max|diff| %.3e  PSNR %.1f dB" % ((got - ref).abs().max(), unet_torch.psnr(got, ref)))
     assert unet_torch.psnr(got, ref) >= MIN_PSNR
+
+
+def test_winograd_and_direct_conv_paths_agree(hip):
+    """The automatic plan runs the 3x3/s1 layers through the Winograd F(2x2,3x3) kernel; with the knob off the
+    same layers run the direct implicit-GEMM kernel.  Both must meet the tolerance against the oracle, and they
+    must differ in round-off (i.e. the knob really switches kernels)."""
+    from read_amd import _lib
+    torch.manual_seed(3)
+    state = synthetic.make_unet_state(UNET_SPEC, 9)
+    net = UNet()
+    net.load_state_dict({k: torch.from_numpy(np.asarray(v)) for k, v in state.items()})
+    net.cuda().eval()
+    xs = [torch.rand(1, 8, 128 >> l, 192 >> l) for l in range(5)]
+    ref = unet_torch.unet_forward(state, *xs[:4])
+    outs = {}
+    try:
+        for name, knob in (("winograd", 1 << 30), ("direct", 0)):
+            _lib.check(_lib.lib().read_tuning_set(b"conv_wino", knob))
+            with torch.no_grad():
+                outs[name] = net(*[x.cuda() for x in xs]).cpu()
+            err = float((outs[name] - ref).abs().max())
+            print("%s: max|diff| %.3e  PSNR %.1f dB" % (name, err, unet_torch.psnr(outs[name], ref)))
+            assert err <= MAX_ABS and unet_torch.psnr(outs[name], ref) >= MIN_PSNR
+    finally:
+        _lib.check(_lib.lib().read_tuning_set(b"conv_wino", 1 << 30))
+    assert not torch.equal(outs["winograd"], outs["direct"])
+    assert float((outs["winograd"] - outs["direct"]).abs().max()) <= 1e-4

@@ -33,7 +33,7 @@ def main():
     out = torch.empty(H, W, C, device="cuda")
     L = _lib.lib()
     names = config_names()
-    for ci in [int(c) for c in a.configs.split(",")]:
+    for ci in [names.index(c) if not c.isdigit() else int(c) for c in a.configs.split(",")]:
         for _ in range(3):
             gated_conv(pk, [(x, 0)], elu=True, residual=res, config=ci, out=out)
         torch.cuda.synchronize()
@@ -49,12 +49,31 @@ def main():
         rec = rec[rec[:, 0] != 0]
         t0 = rec[:, 0].min()
         np.savez_compressed(f"{a.out}_{a.shape}_c{ci}.npz", rec=rec, name=names[ci], ms=e0.elapsed_time(e1))
+        if "wino" in names[ci]:                  # persistent kernel: one record per wave, rec[2] = ticks in unit epilogues
+            ep = rec[:, 2] * 0.01
+            tot = (rec[:, 6] - rec[:, 0]) * 0.01
+            pro = (rec[:, 1] - rec[:, 0]) * 0.01
+            C_, H_, W_ = SHAPES[a.shape]
+            units = -(-H_ // 8) * -(-W_ // 16) * (C_ // 32)
+            per = units / (len(rec) / 4)
+            print(f"{a.shape} {names[ci]}: {len(rec) // 4} workgroups, {units} units ({per:.2f}/workgroup), kernel "
+                  f"{e0.elapsed_time(e1) * 1e3:.1f} us (event), first start -> last exit {(rec[:, 3].max() - t0) * 0.01:.1f} us")
+            for nm, d in (("prologue", pro), ("epilogues", ep), ("loop", tot - pro - ep), ("total", tot)):
+                print("    %-9s p10 %.2f  p50 %.2f  p90 %.2f  max %.2f us" % (nm, *np.percentile(d, [10, 50, 90]), d.max()))
+            print("    epilogue per unit (medians, us): 3rd barrier passed at %.2f, LDS reads landed %.2f, loads landed %.2f, end %.2f" % (
+                np.median(rec[:, 3]) * 0.01 / per, np.median(rec[:, 4]) * 0.01 / per, np.median(rec[:, 5]) * 0.01 / per,
+                np.median(ep) / per))
+            print("    per unit: loop %.2f us, epilogue %.2f us ; per chunk %.2f us" % (
+                np.median(tot - pro - ep) / per, np.median(ep) / per, np.median(tot - pro - ep) / per / (C_ // 16)))
+            continue
         tt = (rec[:, :4] - t0) * 0.01            # us (100 MHz)
         print(f"{a.shape} config {ci} {names[ci]}: {len(rec)} WGs, kernel {e0.elapsed_time(e1) * 1e3:.1f} us (event), "
               f"last exit {tt[:, 3].max():.1f} us")
         print("  per-WG us: prologue %.2f  loop %.2f  epilogue %.2f  total %.2f (medians)" % (
             np.median(tt[:, 1] - tt[:, 0]), np.median(tt[:, 2] - tt[:, 1]), np.median(tt[:, 3] - tt[:, 2]),
             np.median(tt[:, 3] - tt[:, 0])))
+        for nm, d in (("prologue", tt[:, 1] - tt[:, 0]), ("loop", tt[:, 2] - tt[:, 1]), ("epilogue", tt[:, 3] - tt[:, 2])):
+            print("    %-8s p10 %.2f  p50 %.2f  p90 %.2f  max %.2f" % (nm, *np.percentile(d, [10, 50, 90]), d.max()))
         # concurrency over time
         ev = np.concatenate([np.stack([tt[:, 0], np.ones(len(tt))], 1), np.stack([tt[:, 3], -np.ones(len(tt))], 1)])
         ev = ev[np.argsort(ev[:, 0], kind="stable")]
