@@ -620,7 +620,7 @@ __device__ __forceinline__ float4 load_f4(const char *sbase, unsigned voff)
     return *reinterpret_cast<const float4 *>(sbase + voff);
 }
 
-template <bool TRACE>
+template <bool TRACE, bool MUL>
 __global__ __launch_bounds__(256, 2) void gated_conv_wino_kernel(const ConvKArgs a)
 {
     using WG = WinoGeom;
@@ -662,6 +662,8 @@ __global__ __launch_bounds__(256, 2) void gated_conv_wino_kernel(const ConvKArgs
     }
     const unsigned safe_rel = (unsigned)((s.W + 1) * s.C) * 4u;
     const char *pbase = nullptr;                                        // patch origin of the cursor unit (+ chunk)
+    long pdelta = 0;                                                    // MUL: byte distance source -> multiplier tensor
+    if constexpr (MUL) pdelta = reinterpret_cast<const char *>(a.mul) - reinterpret_cast<const char *>(s.p);
     auto set_patch = [&]() {
         const int y0 = pby * (2 * WG::TR) - 1, x0 = pbx * (2 * WG::TC) - 1;
         pbase = reinterpret_cast<const char *>(s.p) + ((long)y0 * s.W + x0) * (long)(s.C * 4);
@@ -685,10 +687,18 @@ __global__ __launch_bounds__(256, 2) void gated_conv_wino_kernel(const ConvKArgs
             set_patch();
         }
     };
-    float4 st[WG::NI];
-    auto gload1 = [&](int i) { st[i] = load_f4(pbase + pchunk * (WG::KC * 4), aoff[i]); };
+    float4 st[WG::NI], stm[MUL ? WG::NI : 1];                           // MUL (FAM): the conv input is src * mul
+    auto gload1 = [&](int i) {
+        st[i] = load_f4(pbase + pchunk * (WG::KC * 4), aoff[i]);
+        if constexpr (MUL) stm[i] = load_f4(pbase + pdelta + pchunk * (WG::KC * 4), aoff[i]);
+    };
+    auto staged = [&](int i, unsigned mask, const float4 &x, const float4 *y) {
+        float4 v = x;
+        if constexpr (MUL) v = make_float4(x.x * y[i].x, x.y * y[i].y, x.z * y[i].z, x.w * y[i].w);
+        return ((mask >> i) & 1u) ? v : make_float4(0.f, 0.f, 0.f, 0.f);
+    };
     auto lwrite1 = [&](int i, int obuf) {                               // lanes past the patch write a dummy slot
-        const float4 v = ((okmask >> i) & 1u) ? st[i] : make_float4(0.f, 0.f, 0.f, 0.f);
+        const float4 v = staged(i, okmask, st[i], stm);
         *reinterpret_cast<float4 *>(lds + (loff[i] >= 0 ? obuf + loff[i] : 3 * WG::BUF)) = v;
     };
 
@@ -736,19 +746,22 @@ __global__ __launch_bounds__(256, 2) void gated_conv_wino_kernel(const ConvKArgs
     // ---- prologue: the first two chunks of the stream into LDS, first B half-step, A fragments of k-step 0
     set_patch();
     {
-        float4 st1[WG::NI];
+        float4 st1[WG::NI], stm1[MUL ? WG::NI : 1];
 #pragma unroll
         for (int i = 0; i < WG::NI; ++i) gload1(i);
         const unsigned ok0 = okmask;
         advance();
 #pragma unroll
-        for (int i = 0; i < WG::NI; ++i) st1[i] = load_f4(pbase + pchunk * (WG::KC * 4), aoff[i]);
+        for (int i = 0; i < WG::NI; ++i) {
+            st1[i] = load_f4(pbase + pchunk * (WG::KC * 4), aoff[i]);
+            if constexpr (MUL) stm1[i] = load_f4(pbase + pdelta + pchunk * (WG::KC * 4), aoff[i]);
+        }
 #pragma unroll
         for (int q = 0; q < 4; ++q) bload1(0, q, 0);
 #pragma unroll
         for (int i = 0; i < WG::NI; ++i) {
-            const float4 v0 = ((ok0 >> i) & 1u) ? st[i] : make_float4(0.f, 0.f, 0.f, 0.f);
-            const float4 v1 = ((okmask >> i) & 1u) ? st1[i] : make_float4(0.f, 0.f, 0.f, 0.f);
+            const float4 v0 = staged(i, ok0, st[i], stm);
+            const float4 v1 = staged(i, okmask, st1[i], stm1);
             if (loff[i] >= 0) {
                 *reinterpret_cast<float4 *>(lds + loff[i]) = v0;
                 *reinterpret_cast<float4 *>(lds + WG::BUF + loff[i]) = v1;
@@ -1004,7 +1017,7 @@ const ConvConfig g_configs[] = {
     CFGW(1, 1, 16, 2, 1, 1, 2),
     CFGW(1, 1, 16, 1, 1, 1, 4),
     CFGW(3, 1, 8, 2, 1, 2, 2),
-    {"k3s1c16_p1q1_wino", 3, 1, 16, 1, 1, 4, 1, 1, 2, gated_conv_wino_kernel<false>, nullptr, 0, 0, 1},
+    {"k3s1c16_p1q1_wino", 3, 1, 16, 1, 1, 4, 1, 1, 2, gated_conv_wino_kernel<false, false>, gated_conv_wino_kernel<false, true>, 0, 0, 1},
     // 4x4 stride 2 (decoder, before the bilinear x4): outputs are 1/4 .. 1/16 scale, so the 16 taps of
     // ONE 1x32-pixel tile are split over the four waves (split-K, WM*WN == 1) to fill the chip
     CFG(4, 2, 16, 1, 1, 1, 1, 1),   // 20  split-K, one group
@@ -1312,7 +1325,7 @@ int launch_gated_conv(const read_conv_desc *d, hipStream_t stream)
     a.trace = ((size_t)grid.x * grid.y <= g_trace_records) ? g_trace : nullptr;
     if (c.wino) {
         READ_CHECK_ARG(d->wpacked_wino && (uintptr_t)d->wpacked_wino % 16 == 0, "read_gated_conv_forward: config %s needs wpacked_wino", c.name);
-        READ_CHECK_ARG(d->n_src == 1 && d->src[0].shift == 0 && !d->mul && d->src[0].C % 16 == 0,
+        READ_CHECK_ARG(d->n_src == 1 && d->src[0].shift == 0 && d->src[0].C % 16 == 0,
                        "read_gated_conv_forward: the Winograd kernel takes one un-resampled source with C %% 16 == 0");
         a.tiles_x = ceil_div(outW, 16);
         a.n_units = a.tiles_x * ceil_div(outH, 8) * groups;       // unit u = (tile u / groups, group u % groups)
@@ -1360,7 +1373,7 @@ int launch_gated_conv(const read_conv_desc *d, hipStream_t stream)
         grid = dim3((unsigned)(want < cap ? want : cap), 1);
     }
     conv_fn fn = c.fn;
-    if (c.wino && a.trace) fn = gated_conv_wino_kernel<true>;
+    if (c.wino && a.trace && !d->mul) fn = gated_conv_wino_kernel<true, false>;
     if (d->mul) {
         READ_CHECK_ARG(c.fn_mul, "read_gated_conv_forward: config %s has no multiply variant", c.name);
         READ_CHECK_ARG((uintptr_t)d->mul % 16 == 0, "read_gated_conv_forward: mul misaligned");
@@ -1374,7 +1387,7 @@ int launch_gated_conv(const read_conv_desc *d, hipStream_t stream)
 // the automatic choice takes the Winograd kernel for every layer it can run (measured faster on all four levels)
 int conv_uses_wino(const read_conv_desc *d)
 {
-    return d->config < 0 && g_use_wino && d->ksize == 3 && d->stride == 1 && d->n_src == 1 && !d->mul &&
+    return d->config < 0 && g_use_wino && d->ksize == 3 && d->stride == 1 && d->n_src == 1 &&
            d->src[0].shift == 0 && d->src[0].C % 16 == 0 && d->wpacked_wino && d->src[0].C <= g_use_wino;
 }
 
