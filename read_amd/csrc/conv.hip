@@ -739,8 +739,6 @@ __global__ __launch_bounds__(256, 2) void gated_conv_wino_kernel(const ConvKArgs
         bq[slot][q] = load_f4(bbase + (size_t)(hs >> 1) * (4 * 8 * 64 * 16) + (hs & 1) * (4 * 64 * 16) + q * 1024, bvoff);
     };
 
-    constexpr int OOB = 0x7ffffff0;
-    const int cch = g * 32 + (lane & 31);
     float *const red = lds + 3 * WG::BUF + 4;                       // [row][b][register][lane], one of {f, m} at a time
 
     // ---- prologue: the first two chunks of the stream into LDS, first B half-step, A fragments of k-step 0
@@ -845,41 +843,49 @@ __global__ __launch_bounds__(256, 2) void gated_conv_wino_kernel(const ConvKArgs
         for (int chunk = 1; chunk < n; ++chunk) chunk_body(std::false_type{}, chunk);
 
         // ================= unit epilogue =================
-        // Wave `row` finishes accumulator registers 4 row .. 4 row + 3 of every (a, b): MFMA D row of register
-        // 4 row + rr is tile (ty, tx) = (row, rr + 4 half), i.e. output pixels (oy0 + 2 row + a, ox0 + 8 half + 2 rr + b).
+        // MFMA D layout: register 4 row' + rr of lane (half, cout) is tile (row', rr + 4 half), i.e. output pixels
+        // (oy0 + 2 row' + a, ox0 + 8 half + 2 rr + b).  Wave `row` finishes the registers with row' = row.  The data goes
+        // through LDS anyway (cross-wave sum over the frequency rows), so it comes back TRANSPOSED: lane = (slot, channel
+        // quad) with slot = (rr, half), 4 consecutive channels per lane -> 128-bit residual loads and output stores
+        // (4 + 4 memory instructions per unit instead of 16 + 16; dword stores were the most expensive part of this phase).
         unsigned long long t_e0 = 0;
         if (TRACE) t_e0 = __builtin_amdgcn_s_memrealtime();
         __builtin_amdgcn_s_setprio(3);        // the co-resident workgroup's MFMA stream otherwise starves this phase
-        const int oy = by * (2 * WG::TR) + 2 * row, ox = bx * (2 * WG::TC) + 8 * half;      // (a, rr, b) = (0, 0, 0)
-        const __amdgpu_buffer_rsrc_t orsrc = __builtin_amdgcn_make_buffer_rsrc(
-            (void *)a.out, 0, a.outH * a.outW * a.out_cstride * 4, 0x00020000);
-        const __amdgpu_buffer_rsrc_t rrsrc = __builtin_amdgcn_make_buffer_rsrc(
-            (void *)(a.residual ? a.residual : a.out), 0, a.residual ? a.outH * a.outW * a.Cout * 4 : 0, 0x00020000);
-        const bool c_ok = cch < a.Cout;
-        const bool c_st = c_ok || (a.fill_pad && cch < a.out_cstride);
-        const float bf = a.params[cch], bm = a.params[a.CoutPad + cch];
-        const float sc = a.params[2 * a.CoutPad + cch], sh = a.params[3 * a.CoutPad + cch];
-        const int xlim = a.outW - ox;                                // column 2 rr + b is inside iff < xlim
-        const bool row_in[2] = {oy < a.outH, oy + 1 < a.outH};       // wave-uniform
-        // residual loads first, so the memory latency runs under the cross-wave reduction; the pixel / row steps go
-        // into the scalar offset of the buffer instruction
-        float rv[2][4][2];
-        {
-            const int rbase = ((oy * a.outW + ox) * a.Cout + cch) * 4;
+        typedef float f32x4 __attribute__((ext_vector_type(4)));
+        const int cq = lane & 7, e_rr = (lane >> 3) & 3, e_hf = lane >> 5;
+        const int c0 = g * 32 + 4 * cq;                                                       // first channel of this lane
+        const int oy = by * (2 * WG::TR) + 2 * row, ox = bx * (2 * WG::TC) + 8 * e_hf + 2 * e_rr;      // (a, b) = (0, 0)
+        const int c_lim = a.fill_pad ? a.out_cstride : a.Cout;                              // channels stored per pixel
+        const bool quad_st = c0 + 3 < c_lim && (a.out_cstride & 3) == 0;                     // whole-quad 128-bit stores
+        const bool quad_ld = a.residual && c0 + 3 < a.Cout && (a.Cout & 3) == 0;
+        const f32x4 bf = *reinterpret_cast<const f32x4 *>(a.params + c0);
+        const f32x4 bm = *reinterpret_cast<const f32x4 *>(a.params + a.CoutPad + c0);
+        const f32x4 sc = *reinterpret_cast<const f32x4 *>(a.params + 2 * a.CoutPad + c0);
+        const f32x4 sh = *reinterpret_cast<const f32x4 *>(a.params + 3 * a.CoutPad + c0);
+        bool pix_in[2][2];
 #pragma unroll
-            for (int aa = 0; aa < 2; ++aa)
+        for (int aa = 0; aa < 2; ++aa)
 #pragma unroll
-                for (int rr = 0; rr < 4; ++rr)
+            for (int b = 0; b < 2; ++b) pix_in[aa][b] = (oy + aa < a.outH) & (ox + b < a.outW);
+        // residual loads first, so the memory latency runs under the cross-wave reduction
+        f32x4 rv[2][2];
 #pragma unroll
-                    for (int b = 0; b < 2; ++b) {
-                        const int voff = (c_ok && row_in[aa] && 2 * rr + b < xlim) ? rbase : OOB;
-                        rv[aa][rr][b] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(
-                            rrsrc, voff, (aa * a.outW + 2 * rr + b) * a.Cout * 4, 0));
-                    }
-        }
-        // output transform: in-wave over j (R_b = sum_j A^T[b][j] M[row][j]), across the four row-waves through LDS
-        // (Y[a][b] = sum_i A^T[a][i] R_b(i)), conv_f then conv_m through the same 32 KiB
-        float Y[2][2][4][2];                                         // [f|m][a][rr][b]
+        for (int aa = 0; aa < 2; ++aa)
+#pragma unroll
+            for (int b = 0; b < 2; ++b) {
+                rv[aa][b] = f32x4{0.f, 0.f, 0.f, 0.f};
+                const float *rp = a.residual + ((size_t)(oy + aa) * a.outW + ox + b) * a.Cout + c0;
+                if (pix_in[aa][b] && quad_ld) rv[aa][b] = *reinterpret_cast<const f32x4 *>(rp);
+                else if (pix_in[aa][b] && a.residual) {
+#pragma unroll
+                    for (int k = 0; k < 4; ++k)
+                        if (c0 + k < a.Cout) rv[aa][b][k] = rp[k];
+                }
+            }
+        // output transform: in-wave over j (R_b = sum_j A^T[b][j] M[row][j]) into red[(row * 2 + b) * 16 + reg][lane],
+        // then across the four row-waves (Y[a][b] = sum_i A^T[a][i] R_b(i)), conv_f then conv_m through the same 32 KiB
+        f32x4 Y[2][2][2];                                            // [f|m][a][b], component = channel of the quad
+        const int rsrc_lane = ((row * 4 + e_rr) * 64 + e_hf * 32 + 4 * cq);                  // (register, source lane) to read
 #pragma unroll
         for (int fm = 0; fm < 2; ++fm) {
 #pragma unroll
@@ -892,16 +898,12 @@ __global__ __launch_bounds__(256, 2) void gated_conv_wino_kernel(const ConvKArgs
             __syncthreads();
             if (TRACE && fm == 1) t_ep[1] += __builtin_amdgcn_s_memrealtime() - t_e0;
 #pragma unroll
-            for (int rr = 0; rr < 4; ++rr) {
-                const int r = row * 4 + rr;
+            for (int b = 0; b < 2; ++b) {
+                f32x4 R[4];
 #pragma unroll
-                for (int b = 0; b < 2; ++b) {
-                    float R[4];
-#pragma unroll
-                    for (int i = 0; i < 4; ++i) R[i] = red[((i * 2 + b) * 16 + r) * 64 + lane];
-                    Y[fm][0][rr][b] = R[0] + R[1] + R[2];
-                    Y[fm][1][rr][b] = R[1] - R[2] - R[3];
-                }
+                for (int i = 0; i < 4; ++i) R[i] = *reinterpret_cast<const f32x4 *>(red + (i * 2 + b) * 16 * 64 + rsrc_lane);
+                Y[fm][0][b] = R[0] + R[1] + R[2];
+                Y[fm][1][b] = R[1] - R[2] - R[3];
             }
             if (fm == 0) __syncthreads();      // (after conv_m the next writer is a whole chunk of barriers away)
         }
@@ -911,22 +913,34 @@ __global__ __launch_bounds__(256, 2) void gated_conv_wino_kernel(const ConvKArgs
             t_ep[3] += __builtin_amdgcn_s_memrealtime() - t_e0;
         }
         {
-            const int obase = ((oy * a.outW + ox) * a.out_cstride + cch) * 4;
+            constexpr float LOG2E = 1.44269504088896341f;
 #pragma unroll
             for (int aa = 0; aa < 2; ++aa)
 #pragma unroll
-                for (int rr = 0; rr < 4; ++rr)
+                for (int b = 0; b < 2; ++b) {
+                    f32x4 f = Y[0][aa][b] + bf;
+                    const f32x4 mm = (Y[1][aa][b] + bm) * -LOG2E;
+                    if (a.elu) {                                     // x > 0 ? x : exp(x) - 1
+                        const f32x4 fe = f * LOG2E;
 #pragma unroll
-                    for (int b = 0; b < 2; ++b) {
-                        float f = Y[0][aa][rr][b] + bf;
-                        const float mm = Y[1][aa][rr][b] + bm;
-                        if (a.elu) f = elu1(f);
-                        float v = (f * sigmoidf(mm)) * sc + sh + rv[aa][rr][b];
-                        v = c_ok ? v : a.out_fill;
-                        const int voff = (c_st && row_in[aa] && 2 * rr + b < xlim) ? obase : OOB;
-                        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), orsrc, voff,
-                                                              (aa * a.outW + 2 * rr + b) * a.out_cstride * 4, 0);
+                        for (int k = 0; k < 4; ++k) f[k] = f[k] > 0.0f ? f[k] : __builtin_amdgcn_exp2f(fe[k]) - 1.0f;
                     }
+                    f32x4 sg;                                        // sigmoid(m) = 1 / (1 + exp(-m))
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) sg[k] = __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(mm[k]));
+                    f32x4 v = (f * sg) * sc + sh + rv[aa][b];
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) v[k] = c0 + k < a.Cout ? v[k] : a.out_fill;
+                    float *op = a.out + ((size_t)(oy + aa) * a.outW + ox + b) * a.out_cstride + c0;
+                    if (pix_in[aa][b]) {
+                        if (quad_st) *reinterpret_cast<f32x4 *>(op) = v;
+                        else {
+#pragma unroll
+                            for (int k = 0; k < 4; ++k)
+                                if (c0 + k < c_lim) op[k] = v[k];
+                        }
+                    }
+                }
         }
         step_tile(by, bx);
         __builtin_amdgcn_s_setprio(0);

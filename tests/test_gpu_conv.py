@@ -74,13 +74,14 @@ def test_winograd_kernel_on_unet_shapes(hip):
     torch.manual_seed(11)
     ci = [i for i, n in enumerate(config_names()) if "wino" in n]
     assert ci, "no Winograd configuration compiled"
-    for j, (c, H, W) in enumerate([(32, 37, 75), (64, 24, 48), (128, 9, 17), (256, 8, 16), (32, 1, 1)]):
+    for j, (c, H, W) in enumerate([(32, 37, 75), (64, 24, 48), (128, 9, 17), (256, 8, 16), (32, 1, 1), (32, 352, 1216)]):
         st = _state(c, c, 3, seed=300 + j)
         x = torch.randn(c, H, W)
         res = torch.randn(c, H, W)
         ref = unet_torch.basic_conv(st, "L", x[None], 3, elu=j % 2 == 0)[0] + res
-        got = gated_conv(_pack(st, [c]), [(_nhwc(x), 0)], elu=j % 2 == 0, residual=_nhwc(res), config=ci[0])
-        _close(got, ref, f"winograd {c}->{c} {H}x{W}", scale=5.0)
+        for cfg in ci:           # one and two unit streams per workgroup; the last shape gives every stream several units
+            got = gated_conv(_pack(st, [c]), [(_nhwc(x), 0)], elu=j % 2 == 0, residual=_nhwc(res), config=cfg)
+            _close(got, ref, f"winograd config {cfg} {c}->{c} {H}x{W}", scale=5.0)
 
 
 def test_unet_layer_shapes_auto_config(hip):

@@ -21,6 +21,7 @@ def main():
     ap.add_argument("--shape", default="L0")
     ap.add_argument("--configs", default="0")
     ap.add_argument("--out", default="gpurun_out/trace")
+    ap.add_argument("--tune", default="", help="key=value[,key=value] for read_tuning_set")
     a = ap.parse_args()
     C, H, W = SHAPES[a.shape]
     st = synthetic.make_unet_state([("L", C, C, 3)], 1)
@@ -32,6 +33,8 @@ def main():
     res = torch.randn(H, W, C, device="cuda")
     out = torch.empty(H, W, C, device="cuda")
     L = _lib.lib()
+    for kv in filter(None, a.tune.split(",")):
+        _lib.check(L.read_tuning_set(kv.split("=")[0].encode(), int(kv.split("=")[1])))
     names = config_names()
     for ci in [names.index(c) if not c.isdigit() else int(c) for c in a.configs.split(",")]:
         for _ in range(3):
