@@ -55,11 +55,13 @@ int read_device_arch(char *name, int len);
 /* Measurement knobs (A/B runs on the GPU box).  "splat_mode": 7 (default) warm start + LDS hierarchical-Z
  * in front of 1 = one key image with agent-scope atomics and L1-bypassing early-z reads; 0 per-XCD key
  * images, 3 system-scope early-z; 2/4/5/6 are attribution probes whose results are invalid (csrc/splat.hip).
- * "conv_wave" 0/1, "conv_stagger" ticks, "conv_ablate" bits: see csrc/conv.hip. */
+ * "conv_wino" = largest Cin that takes the Winograd F(2x2,3x3) kernel (default: all eligible 3x3/s1 layers; 0 = direct
+ * implicit-GEMM kernels everywhere), "conv_wave" 0/1, "conv_stagger" ticks, "conv_ablate" bits: see csrc/conv.hip. */
 int read_tuning_set(const char *key, int value);
-/* Debug timeline of the following gated-conv launches: 64 bytes per workgroup in `buf` (device):
- * s_memrealtime at entry / after prologue / after the k-loop / at exit, HW_ID, XCC_ID, blockIdx.x/y.
- * NULL switches tracing off (the default). */
+/* Debug timeline of the following gated-conv launches: 64 bytes per workgroup (direct kernels: s_memrealtime at
+ * entry / after prologue / after the k-loop / at exit, HW_ID, XCC_ID, blockIdx.x/y) or per wave (Winograd kernel:
+ * entry, end of prologue, ticks spent in unit epilogues split three ways, exit, HW_ID) in `buf` (device);
+ * read by tools/trace_conv.py.  NULL switches tracing off (the default). */
 int read_debug_set_trace(void *buf, size_t bytes);
 /* Debug probe: `blocks` workgroups x 4 waves, each wave issues iters*nacc*4 v_mfma_f32_32x32x2_f32
  * (4096 FLOP each) from registers — the sustained matrix-core ceiling for the conv kernels.
