@@ -84,6 +84,32 @@ def test_winograd_kernel_on_unet_shapes(hip):
             _close(got, ref, f"winograd config {cfg} {c}->{c} {H}x{W}", scale=5.0)
 
 
+def test_winograd_kernel_odd_channel_counts_and_strides(hip):
+    """Edge cases of the Winograd kernel's transposed epilogue: Cout that is not a multiple of 4 (scalar store
+    fallback, partial last channel quad), padded output rows (out_cstride > Cout, with and without fill), a
+    single 16-channel chunk, images smaller than one 8x16 tile block, residual on odd channel counts."""
+    torch.manual_seed(12)
+    ci = [i for i, n in enumerate(config_names()) if "wino" in n][0]
+    cases = [(16, 30, 9, 21, None, None), (16, 3, 16, 16, 4, 1.0), (32, 41, 5, 3, 44, None), (48, 64, 8, 16, 64, None),
+             (16, 32, 1, 40, None, None), (32, 6, 10, 18, 8, 0.25)]
+    for j, (cin, cout, H, W, cs, fill) in enumerate(cases):
+        st = _state(cin, cout, 3, seed=400 + j)
+        x = torch.randn(cin, H, W)
+        res = torch.randn(cout, H, W) if j % 2 == 0 else None
+        ref = unet_torch.basic_conv(st, "L", x[None], 3, elu=j % 2 == 1)[0]
+        if res is not None:
+            ref = ref + res
+        width = cs if cs is not None else cout
+        out = torch.full((H, W, width), -7.0, device="cuda")           # sentinel: untouched channels must stay
+        got = gated_conv(_pack(st, [cin]), [(_nhwc(x), 0)], elu=j % 2 == 1, config=ci, out=out, out_channels=width,
+                         residual=_nhwc(res) if res is not None else None, fill=fill)
+        _close(got[:, :, :cout].contiguous(), ref, f"winograd edge case {j}: {cin}->{cout} {H}x{W} cs={cs}", scale=5.0)
+        if width > cout:
+            pad = got[:, :, cout:].cpu()
+            want = fill if fill is not None else -7.0
+            assert bool((pad == want).all()), f"case {j}: padded channels hold {pad.unique().tolist()}, want {want}"
+
+
 def test_unet_layer_shapes_auto_config(hip):
     """The (cin, cout, k, stride) shapes the UNet actually runs, automatic configuration choice,
     elu on/off, residual add."""
