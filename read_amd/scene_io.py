@@ -1,0 +1,362 @@
+"""Scene and camera ingest of READ without trimesh / cv2.
+
+Mirrors the reference's host-side loaders so a real scene directory (``scene.yaml`` + ``pointcloud.ply`` +
+Metashape ``camera.xml``) flows into ``Scene`` / ``OGL`` / ``MultiscaleRender`` unchanged:
+
+* ``load_scene_data(path)``          READ/gl/utils.py:258-353 — same keys, same relative-path rule
+* ``import_model3d(path)``           READ/gl/utils.py:396-477 — point-cloud branch (``is_mesh=False``)
+* ``intrinsics_from_xml`` / ``extrinsics_from_xml`` / ``extrinsics_from_view_matrix``   utils.py:170-208
+* ``setup_scene(scene, data)``       READ/gl/utils.py:214-255 — the subset a point-cloud ``Scene`` has
+* ``recalc_proj_matrix_planes``, ``rescale_K``, ``crop_intrinsic_matrix``, ``get_xyz_colors``, ``get_valid_matrices``,
+  ``fix_relative_path``               utils.py:109-120,153-167,365-389
+
+The PLY reader is written from the PLY 1.0 format description (ascii, binary_little_endian, binary_big_endian;
+scalar and list properties) — the reference delegates to ``trimesh.load`` (un-vendored dependency,
+``requirement.sh``), of which only ``vertices``, ``colors`` and the raw ``nx, ny, nz`` columns are consumed.
+
+Mesh / texture entries of a scene file are outside the point-cloud render path: they raise
+``NotImplementedError`` instead of being silently dropped.
+"""
+import os
+import xml.etree.ElementTree as ET
+
+import numpy as np
+import yaml
+
+_PLY_TYPES = {
+    'char': 'i1', 'int8': 'i1', 'uchar': 'u1', 'uint8': 'u1', 'short': 'i2', 'int16': 'i2', 'ushort': 'u2',
+    'uint16': 'u2', 'int': 'i4', 'int32': 'i4', 'uint': 'u4', 'uint32': 'u4', 'float': 'f4', 'float32': 'f4',
+    'double': 'f8', 'float64': 'f8',
+}
+
+
+class PlyError(ValueError):
+    pass
+
+
+def _ply_header(fh):
+    """-> (format, [(element name, count, [(prop name, dtype) | (prop name, (count dtype, item dtype))])])."""
+    if fh.readline().strip() != b'ply':
+        raise PlyError("not a PLY file (missing 'ply' magic)")
+    fmt = None
+    elements = []
+    while True:
+        line = fh.readline()
+        if not line:
+            raise PlyError("unexpected end of file inside the PLY header")
+        tok = line.decode('ascii', 'replace').split()
+        if not tok or tok[0] in ('comment', 'obj_info'):
+            continue
+        if tok[0] == 'format':
+            if tok[1] not in ('ascii', 'binary_little_endian', 'binary_big_endian'):
+                raise PlyError(f"unknown PLY format {tok[1]!r}")
+            fmt = tok[1]
+        elif tok[0] == 'element':
+            elements.append((tok[1], int(tok[2]), []))
+        elif tok[0] == 'property':
+            if not elements:
+                raise PlyError("property before any element")
+            if tok[1] == 'list':
+                if tok[2] not in _PLY_TYPES or tok[3] not in _PLY_TYPES:
+                    raise PlyError(f"unknown PLY list types {tok[2]} {tok[3]}")
+                elements[-1][2].append((tok[4], (_PLY_TYPES[tok[2]], _PLY_TYPES[tok[3]])))
+            else:
+                if tok[1] not in _PLY_TYPES:
+                    raise PlyError(f"unknown PLY scalar type {tok[1]!r}")
+                elements[-1][2].append((tok[2], _PLY_TYPES[tok[1]]))
+        elif tok[0] == 'end_header':
+            break
+        else:
+            raise PlyError(f"unknown PLY header keyword {tok[0]!r}")
+    if fmt is None:
+        raise PlyError("PLY header has no format line")
+    return fmt, elements
+
+
+def read_ply(path):
+    """{element: {property: ndarray}}; list properties become a list of arrays (or one 2-D array when every
+    entry has the same length, e.g. triangle faces)."""
+    out = {}
+    with open(path, 'rb') as fh:
+        fmt, elements = _ply_header(fh)
+        if fmt == 'ascii':
+            tokens = fh.read().split()
+            pos = 0
+            for name, count, props in elements:
+                cols = {p: [] for p, _ in props}
+                for _ in range(count):
+                    for p, t in props:
+                        if isinstance(t, tuple):
+                            n = int(tokens[pos])
+                            cols[p].append(np.array(tokens[pos + 1:pos + 1 + n], dtype=np.float64).astype(t[1]))
+                            pos += 1 + n
+                        else:
+                            cols[p].append(tokens[pos])
+                            pos += 1
+                out[name] = {p: (_stack_lists(cols[p]) if isinstance(t, tuple) else
+                                 np.array(cols[p], dtype=np.float64).astype(t)) for p, t in props}
+            return out
+        end = '<' if fmt == 'binary_little_endian' else '>'
+        for name, count, props in elements:
+            if all(not isinstance(t, tuple) for _, t in props):
+                dt = np.dtype([(p, end + t) for p, t in props])
+                raw = fh.read(dt.itemsize * count)
+                if len(raw) != dt.itemsize * count:
+                    raise PlyError(f"PLY element {name!r} is truncated")
+                rec = np.frombuffer(raw, dtype=dt, count=count)
+                out[name] = {p: np.ascontiguousarray(rec[p]).astype(t) for p, t in props}
+            else:                                   # rows of variable length: walk them
+                cols = {p: [] for p, _ in props}
+                for _ in range(count):
+                    for p, t in props:
+                        if isinstance(t, tuple):
+                            n = int(np.frombuffer(fh.read(np.dtype(t[0]).itemsize), dtype=end + t[0])[0])
+                            item = np.dtype(end + t[1])
+                            cols[p].append(np.frombuffer(fh.read(item.itemsize * n), dtype=item).astype(t[1]))
+                        else:
+                            item = np.dtype(end + t)
+                            cols[p].append(np.frombuffer(fh.read(item.itemsize), dtype=item)[0])
+                out[name] = {p: (_stack_lists(cols[p]) if isinstance(t, tuple) else np.array(cols[p], dtype=t))
+                             for p, t in props}
+    return out
+
+
+def _stack_lists(rows):
+    if rows and all(len(r) == len(rows[0]) for r in rows):
+        return np.stack(rows)
+    return rows
+
+
+def write_ply(path, xyz, rgb=None, normals=None, fmt='binary_little_endian'):
+    """Point-cloud PLY writer (tests and fixtures; the reference has none)."""
+    xyz = np.asarray(xyz, np.float32)
+    cols = [('x', 'f4', xyz[:, 0]), ('y', 'f4', xyz[:, 1]), ('z', 'f4', xyz[:, 2])]
+    if normals is not None:
+        normals = np.asarray(normals, np.float32)
+        cols += [('nx', 'f4', normals[:, 0]), ('ny', 'f4', normals[:, 1]), ('nz', 'f4', normals[:, 2])]
+    if rgb is not None:
+        rgb = np.asarray(rgb, np.uint8)
+        cols += [('red', 'u1', rgb[:, 0]), ('green', 'u1', rgb[:, 1]), ('blue', 'u1', rgb[:, 2])]
+    names = {'f4': 'float', 'u1': 'uchar'}
+    head = ['ply', f'format {fmt} 1.0', 'comment written by read_amd.scene_io', f'element vertex {len(xyz)}']
+    head += [f'property {names[t]} {n}' for n, t, _ in cols] + ['end_header']
+    with open(path, 'wb') as fh:
+        fh.write(('\n'.join(head) + '\n').encode('ascii'))
+        if fmt == 'ascii':
+            for i in range(len(xyz)):
+                fh.write((' '.join(repr(float(c[i])) if t == 'f4' else str(int(c[i])) for _, t, c in cols) + '\n').encode())
+        else:
+            end = '<' if fmt == 'binary_little_endian' else '>'
+            rec = np.empty(len(xyz), dtype=[(n, end + t) for n, t, _ in cols])
+            for n, _, c in cols:
+                rec[n] = c
+            fh.write(rec.tobytes())
+
+
+# ---------------------------------------------------------------------------------------------- model import
+def get_xyz_colors(xyz, r=8):
+    """READ/gl/utils.py:385-389."""
+    mmin, mmax = xyz.min(axis=0), xyz.max(axis=0)
+    color = (xyz - mmin) / (mmax - mmin)
+    return np.clip(color, 0., 1.).astype(np.float32)
+
+
+def import_model3d(model_path, uv_order=None, is_mesh=False):
+    """READ/gl/utils.py:396-477, point-cloud branch: the dict ``setup_scene`` / ``DynamicDataset`` consume
+    (xyz, rgb in [0,1], normals, uv1d = point ids, uv2d zeros, dummy faces, xyz_c)."""
+    if is_mesh:
+        raise NotImplementedError("mesh import is outside the point-cloud render path (DESIGN.md §6)")
+    if not str(model_path).lower().endswith('.ply'):
+        raise NotImplementedError(f"only PLY point clouds are read natively, got {model_path}")
+    ply = read_ply(model_path)
+    if 'vertex' not in ply:
+        raise PlyError(f"{model_path} has no vertex element")
+    v = ply['vertex']
+    for k in 'xyz':
+        if k not in v:
+            raise PlyError(f"{model_path}: vertex element has no {k!r} property")
+    # trimesh keeps float32 file data as float64 vertices; the reference then hands them to float32 GL buffers
+    xyz = np.stack([v['x'], v['y'], v['z']], axis=1).astype(np.float64)
+    n_pts = xyz.shape[0]
+    model = {'rgb': None, 'normals': None, 'uv2d': None, 'faces': None}
+    if all(k in v for k in ('red', 'green', 'blue')):
+        model['rgb'] = np.stack([v['red'], v['green'], v['blue']], axis=1) / 255.
+    if all(k in v for k in ('nx', 'ny', 'nz')):
+        normals = np.zeros((n_pts, 3), dtype=np.float32)
+        normals[:, 0], normals[:, 1], normals[:, 2] = v['nx'], v['ny'], v['nz']
+        model['normals'] = normals
+    model['uv2d'] = np.zeros((n_pts, 2), dtype=np.float32)
+    model['xyz'] = xyz
+    model['xyz_c'] = get_xyz_colors(xyz)
+    model['uv1d'] = np.arange(n_pts)
+    if model['rgb'] is None:
+        model['rgb'] = np.zeros((n_pts, 3), dtype=np.float32)
+    if model['normals'] is None:                    # (the reference zeroes rgb here, utils.py:456-458; kept)
+        model['rgb'] = np.zeros((n_pts, 3), dtype=np.float32)
+    model['faces'] = np.array([0, 1, 2], dtype=np.uint32)
+    return model
+
+
+# ---------------------------------------------------------------------------------------------- cameras
+def recalc_proj_matrix_planes(pm, new_near=.01, new_far=1000.):
+    """READ/gl/utils.py:109-120."""
+    depth = float(new_far - new_near)
+    out = pm.copy()
+    out[2, 2] = -(new_far + new_near) / depth
+    out[2, 3] = -2 * (new_far * new_near) / depth
+    return out
+
+
+def rescale_K(K_, sx, sy, keep_fov=True):
+    """READ/gl/utils.py:153-160."""
+    K = K_.copy()
+    K[0, 2] = sx * K[0, 2]
+    K[1, 2] = sy * K[1, 2]
+    if keep_fov:
+        K[0, 0] = sx * K[0, 0]
+        K[1, 1] = sy * K[1, 1]
+    return K
+
+
+def crop_intrinsic_matrix(K, old_size, new_size):
+    """READ/gl/utils.py:163-167."""
+    K = K.copy()
+    K[0, 2] = new_size[0] * K[0, 2] / old_size[0]
+    K[1, 2] = new_size[1] * K[1, 2] / old_size[1]
+    return K
+
+
+def intrinsics_from_xml(xml_file):
+    """Metashape calibration -> (K fp32 with the principal point at the image centre, (width, height));
+    READ/gl/utils.py:170-187."""
+    root = ET.parse(xml_file).getroot()
+    calibration = root.find('chunk/sensors/sensor/calibration')
+    if calibration is None:
+        raise ValueError(f"{xml_file}: no chunk/sensors/sensor/calibration element")
+    resolution = calibration.find('resolution')
+    width = float(resolution.get('width'))
+    height = float(resolution.get('height'))
+    f = float(calibration.find('f').text)
+    K = np.array([[f, 0, width / 2], [0, f, height / 2], [0, 0, 1]], dtype=np.float32)
+    return K, (width, height)
+
+
+def extrinsics_from_xml(xml_file, verbose=False):
+    """camera->world 4x4 per aligned camera in file order, y and z axes flipped to the GL convention
+    (``extrinsic[:, 1:3] *= -1``); READ/gl/utils.py:190-208."""
+    root = ET.parse(xml_file).getroot()
+    transforms = {}
+    for e in root.findall('chunk/cameras')[0].findall('camera'):
+        label = e.get('label')
+        t = e.find('transform')
+        if t is None:                               # not aligned by Metashape
+            if verbose:
+                print('failed to align camera', label)
+            continue
+        transforms[label] = t.text
+    view_matrices = []
+    labels_sort = list(transforms)
+    for label in labels_sort:
+        extrinsic = np.array([float(x) for x in transforms[label].split()]).reshape(4, 4)
+        extrinsic[:, 1:3] *= -1
+        view_matrices.append(extrinsic)
+    return view_matrices, labels_sort
+
+
+def get_valid_matrices(mlist):
+    """READ/gl/utils.py:374-382."""
+    ilist, vmlist = [], []
+    for i, m in enumerate(mlist):
+        if np.isfinite(m).all():
+            ilist.append(i)
+            vmlist.append(m)
+    return vmlist, ilist
+
+
+def extrinsics_from_view_matrix(path):
+    """Text file of stacked 4x4 matrices; non-finite ones are dropped, labels are their indices as strings;
+    READ/gl/utils.py:211-218 (src numbering)."""
+    vm = np.loadtxt(path).reshape(-1, 4, 4)
+    vm, ids = get_valid_matrices(vm)
+    return vm, [str(i) for i in ids]
+
+
+def fix_relative_path(path, config_path):
+    """READ/gl/utils.py:365-371: a path that does not exist as given is tried relative to the scene file."""
+    if not os.path.exists(path) and not os.path.isabs(path):
+        abspath = os.path.join(os.path.dirname(config_path), path)
+        if os.path.exists(abspath):
+            return abspath
+    return path
+
+
+def load_scene_data(path):
+    """READ/gl/utils.py:258-353: scene yaml -> the ``scene_data`` dict of the datasets, ``OGL`` and the viewer."""
+    with open(path, 'r') as f:
+        config = yaml.safe_load(f)
+    pointcloud = import_model3d(fix_relative_path(config['pointcloud'], path)) if 'pointcloud' in config else None
+    if config.get('mesh'):
+        raise NotImplementedError("scene files with a mesh are outside the point-cloud render path")
+    if config.get('texture'):
+        raise NotImplementedError("scene files with a mesh texture are outside the point-cloud render path")
+    if 'intrinsic_matrix' in config:
+        apath = fix_relative_path(config['intrinsic_matrix'], path)
+        if apath[-3:] == 'xml':
+            intrinsic_matrix, (width, height) = intrinsics_from_xml(apath)
+            assert tuple(config['viewport_size']) == (width, height), f'calibration width, height: ({width}, {height})'
+        else:
+            intrinsic_matrix = np.loadtxt(apath)[:3, :3]
+    else:
+        intrinsic_matrix = None
+    if 'proj_matrix' in config:
+        proj_matrix = recalc_proj_matrix_planes(np.loadtxt(fix_relative_path(config['proj_matrix'], path)))
+    else:
+        proj_matrix = None
+    camera_labels = None                            # (the reference leaves it unbound without a view_matrix entry)
+    if 'view_matrix' in config:
+        apath = fix_relative_path(config['view_matrix'], path)
+        if apath[-3:] == 'xml':
+            view_matrix, camera_labels = extrinsics_from_xml(apath)
+        else:
+            view_matrix, camera_labels = extrinsics_from_view_matrix(apath)
+    else:
+        view_matrix = None
+    if 'model3d_origin' in config:
+        model3d_origin = np.loadtxt(fix_relative_path(config['model3d_origin'], path))
+    else:
+        model3d_origin = np.eye(4)
+    point_sizes = np.load(fix_relative_path(config['point_sizes'], path)) if 'point_sizes' in config else None
+    config['viewport_size'] = tuple(config['viewport_size'])
+    if 'net_path' in config:
+        net_ckpt = fix_relative_path(os.path.join(config['net_path'], 'checkpoints', config['ckpt']), path)
+        tex_ckpt = fix_relative_path(os.path.join(config['net_path'], 'checkpoints', config['texture_ckpt']), path)
+    else:
+        net_ckpt = tex_ckpt = None
+    return {
+        'pointcloud': pointcloud, 'point_sizes': point_sizes, 'mesh': None, 'texture': None,
+        'proj_matrix': proj_matrix, 'intrinsic_matrix': intrinsic_matrix, 'view_matrix': view_matrix,
+        'camera_labels': camera_labels, 'model3d_origin': model3d_origin, 'config': config,
+        'net_ckpt': net_ckpt, 'tex_ckpt': tex_ckpt,
+    }
+
+
+def setup_scene(scene, data, use_mesh=False, use_texture=False):
+    """READ/gl/utils.py:214-255 for a point-cloud ``read_amd.render.Scene``: positions, projection, first camera
+    pose, model matrix (colours / normals / faces / point sizes have no consumer on the uv_1d path)."""
+    if use_mesh or use_texture or data.get('pointcloud') is None:
+        raise NotImplementedError("only point-cloud scenes are rendered (DESIGN.md §6)")
+    scene.set_vertices(data['pointcloud']['xyz'])
+    if data.get('proj_matrix') is not None:
+        scene.set_proj_matrix(data['proj_matrix'])
+    if data.get('view_matrix') is not None and len(data['view_matrix']) > 0:
+        scene.set_camera_view(data['view_matrix'][0])
+    scene.set_model_view(data['model3d_origin'])
+
+
+def load_scene(config_path):
+    """READ/gl/utils.py:356-362 (which drops its result; this one returns it)."""
+    from .render import Scene
+    scene_data = load_scene_data(config_path)
+    scene = Scene()
+    setup_scene(scene, scene_data)
+    return scene, scene_data
