@@ -183,8 +183,11 @@ def main():
     # ---- per-kernel durations, live, with HIP events on the launch stream (rank 0)
     out = None
     if rank == 0:
-        M0 = poses[0]
-        ms_splat = hip_time_ms(lambda: fr.rasterize(M0), 10)
+        # the rasteriser warm-starts from the previous frame, so it is timed over consecutive poses of the sweep
+        # (as in the timed loop), not over one repeated pose
+        it = iter(range(1, 10 ** 6))
+        fr.rasterize(poses[0])
+        ms_splat = hip_time_ms(lambda: fr.rasterize(poses[next(it) % 256]), 16)
         ms_gather = hip_time_ms(lambda: fr.gather(), 10)
         ms_unet = hip_time_ms(lambda: fr.refine(), 5)
         f = fr.feat

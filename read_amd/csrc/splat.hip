@@ -104,12 +104,27 @@ __device__ __forceinline__ void fold_key(unsigned long long *k, unsigned long lo
         __hip_atomic_fetch_min(k, key, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
+// Far bounds are stored as 16 bits: the upper half (bfloat16, truncated = rounded DOWN) of e = fl(1 - d_max).  Depth
+// is d = 1 - O(znear / z), so e keeps 8 mantissa bits of the DISTANCE (0.4 %) where a half-precision d would resolve
+// only ~5 m at 30 m; and 16-bit bounds let two 1024-thread workgroups share a CU's LDS (8 waves per SIMD instead of
+// 4 for this latency-bound pass).  Reject iff fl(1 - d) < bound: rounding is monotonic, so fl(1 - d) < fl(1 - d_max)
+// implies d > d_max strictly (ties pass), and truncation only lowers the bound.  Empty block -> -1 (never rejects).
+__device__ __forceinline__ unsigned short hiz_encode(unsigned depth_bits_max)
+{
+    if (depth_bits_max > 0x7f800000u) return 0xbf80;                  // a pixel of the block is still EMPTY: e = -1
+    return (unsigned short)(__float_as_uint(1.0f - __uint_as_float(depth_bits_max)) >> 16);
+}
+__device__ __forceinline__ bool hiz_reject(unsigned short bound, float d)
+{
+    return (1.0f - d) < __uint_as_float((unsigned)bound << 16);
+}
+
 // NP points of one thread against one camera: all projections first, then all early-z reads in
 // flight together, then the (few) atomics — no dependent memory round trip per point.
 template <int MODE, int NP>
 __device__ __forceinline__ void splat_points(const float (&px)[NP], const float (&py)[NP], const float (&pz)[NP],
                                              unsigned id0, int nvalid, const float *M, int W, int H,
-                                             unsigned long long *keys, unsigned &sink, const float *hiz = nullptr,
+                                             unsigned long long *keys, unsigned &sink, const unsigned short *hiz = nullptr,
                                              int nbx = 0, unsigned *stat = nullptr)
 {
     int pix[NP];
@@ -123,8 +138,7 @@ __device__ __forceinline__ void splat_points(const float (&px)[NP], const float 
         if (stat && pix[k] >= 0) stat[0]++;                 // visible
         if (MODE == MODE_HIZ) {
             // LDS-resident far bound of the point's 4x4 block; strictly greater cannot win (ties must pass)
-            const float bound = hiz[pix[k] >= 0 ? (yy >> 2) * nbx + (xx >> 2) : 0];
-            if (d > bound) pix[k] = -1;
+            if (hiz_reject(hiz[pix[k] >= 0 ? (yy >> 2) * nbx + (xx >> 2) : 0], d)) pix[k] = -1;
         }
         if (stat && pix[k] >= 0) stat[1]++;                 // survived the LDS hi-z (or no hi-z)
         key[k] = ((unsigned long long)__float_as_uint(d) << 32) | (id0 + k);
@@ -251,7 +265,7 @@ __global__ __launch_bounds__(256) void splat_seed_kernel(const float *__restrict
 
 // bound[block] = max over the block's pixels of the current depth, +inf if any pixel is still empty.
 __global__ __launch_bounds__(256) void splat_hiz_kernel(const unsigned long long *__restrict__ keys, int W, int H,
-                                                        int nbx, int nby, float *__restrict__ hiz)
+                                                        int nbx, int nby, unsigned short *__restrict__ hiz)
 {
     const int b = blockIdx.x * blockDim.x + threadIdx.x;
     if (b >= nbx * nby) return;
@@ -267,17 +281,17 @@ __global__ __launch_bounds__(256) void splat_hiz_kernel(const unsigned long long
                 m = bits > m ? bits : m;
             }
         }
-    hiz[b] = __uint_as_float(m > 0x7f800000u ? 0x7f800000u : m);
+    hiz[b] = hiz_encode(m);
 }
 
 // The point pass of MODE_HIZ: one 1024-thread workgroup per CU (persistent, grid-stride) with the whole
 // bound image in LDS.
 __global__ __launch_bounds__(1024) void splat_project_hiz_kernel(const float *__restrict__ xyz, long long n, CamSet cams,
                                                                  int W, int H, unsigned long long *__restrict__ keys,
-                                                                 int vec_ok, const float *__restrict__ hiz_g, int nbx,
+                                                                 int vec_ok, const unsigned short *__restrict__ hiz_g, int nbx,
                                                                  int nblocks, int sub_mod, unsigned long long *stats)
 {
-    extern __shared__ __attribute__((aligned(16))) float hiz[];
+    extern __shared__ __attribute__((aligned(16))) unsigned short hiz[];
     unsigned st_local[3] = {0, 0, 0};
     unsigned *stp = stats ? st_local : nullptr;
     for (int i = threadIdx.x; i < nblocks; i += blockDim.x) hiz[i] = hiz_g[i];
@@ -325,11 +339,11 @@ template <bool HIZ>
 __global__ __launch_bounds__(HIZ ? 1024 : 256) void splat_pipe_kernel(const float *__restrict__ xyz, long long n,
                                                                       CamSet cams, int B, int W, int H,
                                                                       unsigned long long *__restrict__ keys,
-                                                                      const float *__restrict__ hiz_g, int nbx,
+                                                                      const unsigned short *__restrict__ hiz_g, int nbx,
                                                                       int nblocks, int sub_mod, int sub_sel,
                                                                       unsigned long long *stats)
 {
-    extern __shared__ __attribute__((aligned(16))) float hiz[];
+    extern __shared__ __attribute__((aligned(16))) unsigned short hiz[];
     if (HIZ) {
         for (int i = threadIdx.x; i < nblocks; i += blockDim.x) hiz[i] = hiz_g[i];
         __syncthreads();
@@ -382,8 +396,7 @@ __global__ __launch_bounds__(HIZ ? 1024 : 256) void splat_pipe_kernel(const floa
                 pix[k] = project_one(px[k], py[k], pz[k], cams.m[cam], W, H, d, xx, yy);
                 if (stats && pix[k] >= 0) st_local[0]++;
                 if (HIZ) {
-                    const float bound = hiz[pix[k] >= 0 ? (yy >> 2) * nbx + (xx >> 2) : 0];
-                    if (d > bound) pix[k] = -1;
+                    if (hiz_reject(hiz[pix[k] >= 0 ? (yy >> 2) * nbx + (xx >> 2) : 0], d)) pix[k] = -1;
                 }
                 if (stats && pix[k] >= 0) st_local[1]++;
                 key[k] = ((unsigned long long)__float_as_uint(d) << 32) | (id0 + k);
@@ -550,7 +563,7 @@ int g_splat_stats = 0;         // debug: accumulate counters in the workspace he
 struct WsLayout {
     SplatHeader *hdr;
     unsigned long long *keys;
-    float *hiz;
+    unsigned short *hiz;       // 16-bit far bounds (the region keeps its 4 bytes per block)
     int *prev;
     int nbx, nby;
     size_t total;
@@ -567,7 +580,7 @@ WsLayout ws_layout(void *ws, int B, int W, int H)
     off += (size_t)nb * XCD_COPIES * W * H * sizeof(unsigned long long);
     L.nbx = ceil_div(W, 4);
     L.nby = ceil_div(H, 4);
-    L.hiz = (float *)(p + off);
+    L.hiz = (unsigned short *)(p + off);
     off += ((size_t)L.nbx * L.nby * sizeof(float) + 255) / 256 * 256;
     L.prev = (int *)(p + off);
     off += (size_t)W * H * sizeof(int);
@@ -582,7 +595,7 @@ int project_and_resolve(const float *xyz, int64_t n, const float *M_host, int B,
                         const WsLayout &ws, bool allow_hiz, hipStream_t stream)
 {
     unsigned long long *keys = ws.keys;
-    const size_t hiz_bytes = (size_t)ws.nbx * ws.nby * sizeof(float);
+    const size_t hiz_bytes = (((size_t)ws.nbx * ws.nby * sizeof(unsigned short)) + 15) & ~(size_t)15;
     const bool use_hiz = g_splat_mode == MODE_HIZ && allow_hiz && B == 1 && n > 0 && hiz_bytes <= HIZ_LDS_LIMIT &&
                          ((uintptr_t)xyz % 16) == 0;
     const int mode = g_splat_mode == MODE_HIZ ? MODE_AGENT : g_splat_mode;
@@ -627,7 +640,8 @@ int project_and_resolve(const float *xyz, int64_t n, const float *M_host, int B,
                         prop.multiProcessorCount > 0) ? prop.multiProcessorCount : 256;
             }
             int64_t blocks = ceil_div64(ceil_div64(n, PTS_PER_THREAD), 1024);
-            if (blocks > n_cu) blocks = n_cu;
+            const int per_cu = 2 * hiz_bytes <= 150 * 1024 ? 2 : 1;     // two workgroups per CU when their bounds fit
+            if (blocks > (int64_t)n_cu * per_cu) blocks = (int64_t)n_cu * per_cu;
             if (g_splat_pipe && !sub)
                 hipLaunchKernelGGL(splat_pipe_kernel<true>, dim3((unsigned)blocks), dim3(1024), hiz_bytes, stream, xyz,
                                    (long long)n, cams, 1, W, H, keys, ws.hiz, ws.nbx, ws.nbx * ws.nby, sub, sub ? 2 : 0, stats);
@@ -642,7 +656,7 @@ int project_and_resolve(const float *xyz, int64_t n, const float *M_host, int B,
             if (blocks > 256 * 8) blocks = 256 * 8;
             if (mode == MODE_AGENT && vec_ok && g_splat_pipe) {
                 hipLaunchKernelGGL(splat_pipe_kernel<false>, dim3((unsigned)blocks), dim3(256), 0, stream, xyz, (long long)n,
-                                   cams, nb, W, H, keys, (const float *)nullptr, 0, 0, 0, 0, stats);
+                                   cams, nb, W, H, keys, (const unsigned short *)nullptr, 0, 0, 0, 0, stats);
                 READ_CHECK_LAUNCH();
             } else {
             auto kern = mode == MODE_XCD ? splat_project_kernel<MODE_XCD>
