@@ -94,6 +94,20 @@ int read_splat_forward(const float *xyz, int64_t n, const float *M_host, int B, 
                        int levels, int32_t *const *idx_levels, float *const *depth_levels,
                        void *ws, size_t ws_bytes, void *stream);
 
+/* Cell-ordered copy of a cloud (optional accelerator of the single-camera path; results are bit-identical).
+ * read_splat_cells_build_host() sorts the points once along a Morton curve into chunks of 1024 with their bounding
+ * boxes (host arrays in, host blob of read_splat_cells_bytes(n) out); the caller uploads the blob (16-byte aligned)
+ * and passes it to read_splat_forward_cells() together with the ORIGINAL xyz (still used for the warm start).
+ * Whole chunks outside the frustum, or behind the far depth bound of every 4x4 pixel block they can touch, are then
+ * skipped without reading their points.  The tail of the blob is per-frame scratch (chunk lists), so one blob
+ * serves one stream at a time.  With cells == NULL, B > 1, n < 2^20 or sizes that are not multiples of
+ * 2^(levels-1) the call is exactly read_splat_forward(). */
+size_t read_splat_cells_bytes(int64_t n);
+int read_splat_cells_build_host(const float *xyz_host, int64_t n, void *cells_host, size_t cells_bytes);
+int read_splat_forward_cells(const float *xyz, void *cells, int64_t n, const float *M_host, int B, int W, int H,
+                             int levels, int32_t *const *idx_levels, float *const *depth_levels,
+                             void *workspace, size_t workspace_bytes, void *stream);
+
 /* out[i] = (float)idx[i] — the reference's index image dtype (ids >= 2^24 round). */
 int read_index_to_float(const int32_t *idx, int64_t count, float *out, void *stream);
 

@@ -46,6 +46,9 @@ SIGNATURES = {
     "read_splat_workspace_bytes": (_sz, [_i, _i, _i]),
     "read_splat_workspace_init": (_i, [_vp, _sz, _vp]),
     "read_splat_forward": (_i, [_vp, _i64, C.POINTER(_f), _i, _i, _i, _i, _pp, _pp, _vp, _sz, _vp]),
+    "read_splat_cells_bytes": (_sz, [_i64]),
+    "read_splat_cells_build_host": (_i, [_vp, _i64, _vp, _sz]),
+    "read_splat_forward_cells": (_i, [_vp, _vp, _i64, C.POINTER(_f), _i, _i, _i, _i, _pp, _pp, _vp, _sz, _vp]),
     "read_index_to_float": (_i, [_vp, _i64, _vp, _vp]),
     "read_texture_to_rows": (_i, [_vp, _i64, _i, _vp, _vp]),
     "read_rows_to_texture": (_i, [_vp, _i64, _i, _vp, _vp]),

@@ -40,6 +40,8 @@ void conv_set_prefer_wave(int v);
 void conv_set_stagger(int ticks);
 void conv_set_ablate(int bits);
 void conv_set_wino(int max_cin);
+void splat_set_near(int v);
+void splat_set_cells(int v);
 }
 
 // Debug: per-workgroup timeline of the next gated-conv launches.  buf = device memory, 64 bytes per
@@ -73,6 +75,14 @@ extern "C" int read_tuning_set(const char *key, int value)
     }
     if (!strcmp(key, "splat_subset")) {
         readhip::splat_set_subset(value);
+        return READ_OK;
+    }
+    if (!strcmp(key, "splat_near")) {      // cell path: expected points per pixel in front of the pass-A split distance
+        readhip::splat_set_near(value);
+        return READ_OK;
+    }
+    if (!strcmp(key, "splat_cells")) {     // 0: ignore the cell-ordered copy
+        readhip::splat_set_cells(value);
         return READ_OK;
     }
     if (!strcmp(key, "conv_wino")) {       // value = largest Cin that takes the Winograd kernel (0 = off)

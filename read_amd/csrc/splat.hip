@@ -122,10 +122,10 @@ __device__ __forceinline__ bool hiz_reject(unsigned short bound, float d)
 // NP points of one thread against one camera: all projections first, then all early-z reads in
 // flight together, then the (few) atomics — no dependent memory round trip per point.
 template <int MODE, int NP>
-__device__ __forceinline__ void splat_points(const float (&px)[NP], const float (&py)[NP], const float (&pz)[NP],
-                                             unsigned id0, int nvalid, const float *M, int W, int H,
-                                             unsigned long long *keys, unsigned &sink, const unsigned short *hiz = nullptr,
-                                             int nbx = 0, unsigned *stat = nullptr)
+__device__ __forceinline__ void splat_points_ids(const float (&px)[NP], const float (&py)[NP], const float (&pz)[NP],
+                                                 const unsigned (&ids)[NP], int nvalid, const float *M, int W, int H,
+                                                 unsigned long long *keys, unsigned &sink,
+                                                 const unsigned short *hiz = nullptr, int nbx = 0, unsigned *stat = nullptr)
 {
     int pix[NP];
     unsigned long long key[NP], seen[NP];
@@ -141,7 +141,7 @@ __device__ __forceinline__ void splat_points(const float (&px)[NP], const float 
             if (hiz_reject(hiz[pix[k] >= 0 ? (yy >> 2) * nbx + (xx >> 2) : 0], d)) pix[k] = -1;
         }
         if (stat && pix[k] >= 0) stat[1]++;                 // survived the LDS hi-z (or no hi-z)
-        key[k] = ((unsigned long long)__float_as_uint(d) << 32) | (id0 + k);
+        key[k] = ((unsigned long long)__float_as_uint(d) << 32) | ids[k];
     }
     if (MODE == MODE_NOZ) {
 #pragma unroll
@@ -168,6 +168,18 @@ __device__ __forceinline__ void splat_points(const float (&px)[NP], const float 
             fold_key<MODE>(keys + pix[k], key[k]);
             if (stat) stat[2]++;                            // atomics issued
         }
+}
+
+template <int MODE, int NP>
+__device__ __forceinline__ void splat_points(const float (&px)[NP], const float (&py)[NP], const float (&pz)[NP],
+                                             unsigned id0, int nvalid, const float *M, int W, int H,
+                                             unsigned long long *keys, unsigned &sink, const unsigned short *hiz = nullptr,
+                                             int nbx = 0, unsigned *stat = nullptr)
+{
+    unsigned ids[NP];
+#pragma unroll
+    for (int k = 0; k < NP; ++k) ids[k] = id0 + k;
+    splat_points_ids<MODE, NP>(px, py, pz, ids, nvalid, M, W, H, keys, sink, hiz, nbx, stat);
 }
 
 // Point groups (4 points) are split into chunks of 256 groups (1024 points).  The bootstrap pass of MODE_HIZ
@@ -247,22 +259,6 @@ struct SplatHeader {          // first 256 bytes of the workspace
 };
 constexpr size_t HEADER_BYTES = 256;
 
-// Re-project the previous frame's winners (one per level-0 pixel) with the new camera and fold them in.
-__global__ __launch_bounds__(256) void splat_seed_kernel(const float *__restrict__ xyz, long long n, CamSet cams,
-                                                         int W, int H, unsigned long long *__restrict__ keys,
-                                                         const SplatHeader *hdr, const int *__restrict__ prev_idx)
-{
-    const int p = blockIdx.x * blockDim.x + threadIdx.x;
-    if (p >= W * H) return;
-    if (!(hdr->valid == 1 && hdr->W == W && hdr->H == H)) return;
-    const int id = prev_idx[p];
-    if (id < 0 || id >= n) return;
-    float d;
-    int xx, yy;
-    const int pix = project_one(xyz[3ll * id], xyz[3ll * id + 1], xyz[3ll * id + 2], cams.m[0], W, H, d, xx, yy);
-    if (pix >= 0) fold_key<MODE_AGENT>(keys + pix, ((unsigned long long)__float_as_uint(d) << 32) | (unsigned)id);
-}
-
 // bound[block] = max over the block's pixels of the current depth, +inf if any pixel is still empty.
 __global__ __launch_bounds__(256) void splat_hiz_kernel(const unsigned long long *__restrict__ keys, int W, int H,
                                                         int nbx, int nby, unsigned short *__restrict__ hiz)
@@ -322,6 +318,232 @@ __global__ __launch_bounds__(1024) void splat_project_hiz_kernel(const float *__
     }
     if (stats)
         for (int i = 0; i < 3; ++i) atomicAdd(stats + 4 + i, (unsigned long long)st_local[i]);
+}
+
+
+// ---- cell-ordered cloud: chunk-level frustum / occlusion culling ---------------------------------------------
+// read_splat_cells_build_host() sorts the cloud once along a Morton curve and cuts it into chunks of 1024 points with
+// their bounding boxes; the original point ids travel with the points (keys carry the ORIGINAL id, so the result is
+// bit-identical to the unsorted pass — atomic min does not care about order).  Per frame:
+//   splat_seed_kernel      (extra blocks) classifies every chunk from the 8 projected corners of its box: outside the
+//                          frustum -> dropped (no point of it is read); nearest corner closer than w_split, or every
+//                          sub-th chunk -> list A; the rest -> list B with its screen rectangle and depth threshold.
+//                          Lists are compacted with one atomic per wave.
+//   splat_cells_kernel<A>  one wave per list-A chunk: plain early-z + atomic min (these chunks set the first bounds).
+//   splat_hiz_kernel       far bound per 4x4 block.
+//   splat_cells_kernel<B>  one wave per list-B chunk: skipped when its nearest possible depth is behind the bound of
+//                          EVERY block its rectangle touches, otherwise the LDS hi-z point pass.
+// Conservative arithmetic: the fp32 projection of a point and of the box corners differ by rounding; with
+// S_k = sum_j |M_kj| max|box_j| + |M_k3| every computed clip coordinate is within gamma S_k of the exact one, so ndc
+// errors are bounded by gamma (S_k + S_3) / w_min + ulp; the rectangle is widened and the depth test tightened by that
+// much (gamma = 1e-6, >= 4x the worst case of a 4-term fp32 dot product).  A box with a corner at or behind the camera
+// plane is never culled (list A).  A single dynamic chunk counter was tried first: 37 K same-address atomics cost
+// 0.65 ms per pass (~17 ns each) — hence classification + static walks over compact lists.
+struct CellHeader {            // first 256 bytes of the cell-ordered cloud (device and host)
+    long long n;
+    int nchunks, version;
+    float bbox[6];
+    float density;             // points per unit volume of the bounding box
+};
+constexpr int CELL_CHUNK = 1024;
+constexpr size_t CELL_HEADER_BYTES = 256;
+constexpr size_t CELL_COUNTER_OFFSET = 192;   // two ints in the WORKSPACE header: lengths of list A / list B
+
+struct CellEntryB {            // 16 bytes per list-B chunk
+    int chunk;
+    unsigned bx;               // bx0 << 16 | bx1 (4x4-pixel block columns, inclusive)
+    unsigned by;
+    float e_thr;               // cull iff e_thr < min over the rectangle of (1 - far bound)
+};
+
+struct CellCloud {             // device pointers into the blob
+    const CellHeader *hdr;
+    const float *xyz;          // nchunks * 1024 * 3, Morton order, tail padded with copies of the last point
+    const unsigned *ids;       // original point id of every sorted point
+    const float *aabb;         // nchunks * 8: min xyz, max xyz, 2 pad
+    int *list_a;               // scratch: chunk ids of this frame's list A
+    CellEntryB *list_b;        // scratch: list B
+    int nchunks;
+};
+
+// class of one chunk for camera M: 0 dropped, 1 list A, 2 list B (then e fills in)
+__device__ __forceinline__ int classify_chunk(const float *bb, const float *M, int W, int H, float w_split, bool boot,
+                                              CellEntryB &e)
+{
+    constexpr float GAMMA = 1e-6f;
+    const float mn[3] = {bb[0], bb[1], bb[2]}, mx[3] = {bb[3], bb[4], bb[5]};
+    const float ax = fmaxf(fabsf(mn[0]), fabsf(mx[0])), ay = fmaxf(fabsf(mn[1]), fabsf(mx[1])),
+                az = fmaxf(fabsf(mn[2]), fabsf(mx[2]));
+    float S[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+        S[k] = fabsf(M[4 * k]) * ax + fabsf(M[4 * k + 1]) * ay + fabsf(M[4 * k + 2]) * az + fabsf(M[4 * k + 3]);
+    float c[8][4];
+    float wmin = 3.0e38f;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const float cx = (i & 1) ? mx[0] : mn[0], cy = (i & 2) ? mx[1] : mn[1], cz = (i & 4) ? mx[2] : mn[2];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) c[i][k] = M[4 * k] * cx + M[4 * k + 1] * cy + M[4 * k + 2] * cz + M[4 * k + 3] * 1.0f;
+        wmin = fminf(wmin, c[i][3]);
+    }
+    if (!(wmin > fmaxf(1e-3f, 1e-5f * S[3]))) return 1;           // a corner at / behind the camera plane: never culled
+    float lo[3] = {3.0e38f, 3.0e38f, 3.0e38f}, hi[3] = {-3.0e38f, -3.0e38f, -3.0e38f};
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const float inv = 1.0f / c[i][3];
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            const float v = c[i][k] * inv;
+            lo[k] = fminf(lo[k], v);
+            hi[k] = fmaxf(hi[k], v);
+        }
+    }
+    const float rw = GAMMA / wmin;
+    const float ex = rw * (S[0] + S[3]) + 4e-7f, ey = rw * (S[1] + S[3]) + 4e-7f, ez = rw * (S[2] + S[3]) + 4e-7f;
+    if (hi[0] < -1.0f - ex || lo[0] > 1.0f + ex || hi[1] < -1.0f - ey || lo[1] > 1.0f + ey || hi[2] < -1.0f - ez ||
+        lo[2] > 1.0f + ez)
+        return 0;
+    if (wmin < w_split || boot) return 1;
+    const float dmin = (fmaxf(lo[2], -1.0f) + 1.0f) * 0.5f;
+    e.e_thr = (1.0f - dmin) + 2.0f * (0.5f * ez + 2e-7f);
+    const float px0 = (float)W * (lo[0] + 1.0f) * 0.5f - ((float)W * 0.5f * ex + 1.0f);
+    const float px1 = (float)W * (hi[0] + 1.0f) * 0.5f + ((float)W * 0.5f * ex + 1.0f);
+    const float py0 = (float)H * (1.0f - hi[1]) * 0.5f - ((float)H * 0.5f * ey + 1.0f);
+    const float py1 = (float)H * (1.0f - lo[1]) * 0.5f + ((float)H * 0.5f * ey + 1.0f);
+    const unsigned bx0 = (unsigned)fminf(fmaxf(px0, 0.0f), (float)(W - 1)) >> 2;
+    const unsigned bx1 = (unsigned)fminf(fmaxf(px1, 0.0f), (float)(W - 1)) >> 2;
+    const unsigned by0 = (unsigned)fminf(fmaxf(py0, 0.0f), (float)(H - 1)) >> 2;
+    const unsigned by1 = (unsigned)fminf(fmaxf(py1, 0.0f), (float)(H - 1)) >> 2;
+    e.bx = bx0 << 16 | bx1;
+    e.by = by0 << 16 | by1;
+    return 2;
+}
+
+// The classification blocks of splat_seed_kernel (blockIdx >= pix_blocks): one thread per chunk.
+__device__ __forceinline__ void classify_block(const CellCloud &cc, const float *M, int W, int H, int sub, float near_count,
+                                               int block, int *counts)
+{
+    const int chunk = block * 256 + threadIdx.x;
+    // list A takes the chunks nearer than the distance within which a pixel expects `near_count` points
+    const float focal = sqrtf(M[0] * M[0] + M[1] * M[1] + M[2] * M[2]) * (float)W * 0.5f;
+    const float w_split = cbrtf(3.0f * near_count * focal * focal / fmaxf(cc.hdr->density, 1e-20f));
+    CellEntryB e;
+    e.chunk = chunk;
+    e.bx = e.by = 0;
+    e.e_thr = 0.0f;
+    int cls = 0;
+    if (chunk < cc.nchunks)
+        cls = classify_chunk(cc.aabb + (size_t)chunk * 8, M, W, H, w_split, sub > 0 && chunk % sub == 0, e);
+    // wave-aggregated append: one atomic per wave and list
+    const int lane = threadIdx.x & 63;
+    const unsigned long long ma = __ballot(cls == 1), mb = __ballot(cls == 2);
+    int base_a = 0, base_b = 0;
+    if (lane == 0) {
+        if (ma) base_a = atomicAdd(counts + 0, __popcll(ma));
+        if (mb) base_b = atomicAdd(counts + 1, __popcll(mb));
+    }
+    base_a = __shfl(base_a, 0);
+    base_b = __shfl(base_b, 0);
+    const unsigned long long below = lane == 0 ? 0ull : (~0ull >> (64 - lane));
+    if (cls == 1) cc.list_a[base_a + __popcll(ma & below)] = chunk;
+    if (cls == 2) cc.list_b[base_b + __popcll(mb & below)] = e;
+}
+
+// Re-project the previous frame's winners (one per level-0 pixel) with the new camera and fold them in.
+__global__ __launch_bounds__(256) void splat_seed_kernel(const float *__restrict__ xyz, long long n, CamSet cams,
+                                                         int W, int H, unsigned long long *__restrict__ keys,
+                                                         SplatHeader *hdr, const int *__restrict__ prev_idx,
+                                                         CellCloud cc, int pix_blocks, int sub, float near_count)
+{
+    if ((int)blockIdx.x >= pix_blocks) {           // the extra blocks classify the chunks of the cell-ordered cloud
+        classify_block(cc, cams.m[0], W, H, sub, near_count, (int)blockIdx.x - pix_blocks,
+                       (int *)((char *)hdr + CELL_COUNTER_OFFSET));
+        return;
+    }
+    const int p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= W * H) return;
+    if (!(hdr->valid == 1 && hdr->W == W && hdr->H == H)) return;
+    const int id = prev_idx[p];
+    if (id < 0 || id >= n) return;
+    float d;
+    int xx, yy;
+    const int pix = project_one(xyz[3ll * id], xyz[3ll * id + 1], xyz[3ll * id + 2], cams.m[0], W, H, d, xx, yy);
+    if (pix >= 0) fold_key<MODE_AGENT>(keys + pix, ((unsigned long long)__float_as_uint(d) << 32) | (unsigned)id);
+}
+
+template <bool PASS_B>
+__global__ __launch_bounds__(PASS_B ? 1024 : 256) void splat_cells_kernel(CellCloud cc, CamSet cams, int W, int H,
+                                                                         unsigned long long *__restrict__ keys,
+                                                                         const unsigned short *__restrict__ hiz_g, int nbx,
+                                                                         int nby, const int *counts,
+                                                                         unsigned long long *stats)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned short hiz[];
+    if (PASS_B) {
+        for (int i = threadIdx.x; i < nbx * nby; i += blockDim.x) hiz[i] = hiz_g[i];
+        __syncthreads();
+    }
+    const float *M = cams.m[0];
+    const int lane = threadIdx.x & 63;
+    unsigned st_local[3] = {0, 0, 0};
+    unsigned *stp = stats ? st_local : nullptr;
+    unsigned n_proc = 0, n_cull = 0;
+    const float4 *xyz4 = reinterpret_cast<const float4 *>(cc.xyz);
+    const uint4 *ids4 = reinterpret_cast<const uint4 *>(cc.ids);
+    const int n_list = counts[PASS_B ? 1 : 0];
+    // one wave per chunk, lists walked in (roughly Morton) order by neighbouring waves.  Measured alternatives: a team
+    // of four waves per chunk (one quarter each) 76 / 48 us for pass A / B instead of 78 / 38; a transposed walk that
+    // keeps concurrent waves far apart 94 / 50 (locality of the key image matters more than contention).
+    const int wave = __builtin_amdgcn_readfirstlane((int)(blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)));
+    const int n_waves = gridDim.x * (blockDim.x >> 6);
+    unsigned sink = 0;
+    for (int i = wave; i < n_list; i += n_waves) {
+        int chunk;
+        if (PASS_B) {
+            const CellEntryB e = cc.list_b[i];
+            chunk = e.chunk;
+            const int bx0 = (int)(e.bx >> 16), bx1 = (int)(e.bx & 0xffffu), by0 = (int)(e.by >> 16), by1 = (int)(e.by & 0xffffu);
+            if ((bx1 - bx0 + 1) * (by1 - by0 + 1) <= 8192) {
+                float emin = 3.0e38f;                                  // min over the rectangle of (1 - far bound)
+                for (int ry = by0; ry <= by1; ++ry)
+                    for (int rx = bx0 + lane; rx <= bx1; rx += 64)
+                        emin = fminf(emin, __uint_as_float((unsigned)hiz[ry * nbx + rx] << 16));
+#pragma unroll
+                for (int o = 32; o > 0; o >>= 1) emin = fminf(emin, __shfl_xor(emin, o));
+                if (e.e_thr < emin) {                                  // every point of the box is behind every bound
+                    ++n_cull;
+                    continue;
+                }
+            }
+        } else {
+            chunk = cc.list_a[i];
+        }
+        chunk = __builtin_amdgcn_readfirstlane(chunk);
+        ++n_proc;
+        // ---- the chunk's 1024 points: 4 rounds of 4 points per lane
+#pragma unroll 2
+        for (int it = 0; it < 4; ++it) {
+            const long long g = (long long)chunk * 256 + it * 64 + lane;        // group of 4 points
+            const float4 a = xyz4[3 * g + 0];
+            const float4 b = xyz4[3 * g + 1];
+            const float4 c = xyz4[3 * g + 2];
+            const uint4 id = ids4[g];
+            const float px[4] = {a.x, a.w, b.z, c.y};
+            const float py[4] = {a.y, b.x, b.w, c.z};
+            const float pz[4] = {a.z, b.y, c.x, c.w};
+            const unsigned ids[4] = {id.x, id.y, id.z, id.w};
+            if (PASS_B)
+                splat_points_ids<MODE_HIZ, 4>(px, py, pz, ids, 4, M, W, H, keys, sink, hiz, nbx, stp);
+            else
+                splat_points_ids<MODE_AGENT, 4>(px, py, pz, ids, 4, M, W, H, keys, sink, nullptr, 0, stp);
+        }
+    }
+    if (stats && lane == 0) {
+        for (int i = 0; i < 3; ++i) atomicAdd(stats + (PASS_B ? 4 : 0) + i, (unsigned long long)st_local[i]);
+        atomicAdd(stats + (PASS_B ? 11 : 8), (unsigned long long)n_proc);
+        if (PASS_B) atomicAdd(stats + 9, (unsigned long long)n_cull);
+    }
 }
 
 
@@ -493,6 +715,8 @@ __global__ __launch_bounds__(256) void splat_resolve_kernel(unsigned long long *
         hdr->valid = 1;
         hdr->W = W;
         hdr->H = H;
+        ((int *)((char *)hdr + 192))[0] = 0;       // list lengths of the cell-ordered passes (CELL_COUNTER_OFFSET)
+        ((int *)((char *)hdr + 192))[1] = 0;
     }
     if (levels < 2) return;
     const unsigned long long k1 = kmin(kmin(k[0][0], k[0][1]), kmin(k[1][0], k[1][1]));
@@ -590,9 +814,12 @@ WsLayout ws_layout(void *ws, int B, int W, int H)
 
 constexpr size_t HIZ_LDS_LIMIT = 150 * 1024;   // of the 160 KiB per CU
 
+int g_splat_near = 8;          // cell path: pass A takes chunks nearer than the depth at which a pixel expects this many points
+int g_splat_cells = 1;         // 0: ignore the cell-ordered copy (A/B)
+
 int project_and_resolve(const float *xyz, int64_t n, const float *M_host, int B, int W, int H, int levels,
                         int32_t *const *idx_levels, float *const *depth_levels, int level_base,
-                        const WsLayout &ws, bool allow_hiz, hipStream_t stream)
+                        const WsLayout &ws, bool allow_hiz, hipStream_t stream, const CellCloud *cells = nullptr)
 {
     unsigned long long *keys = ws.keys;
     const size_t hiz_bytes = (((size_t)ws.nbx * ws.nby * sizeof(unsigned short)) + 15) & ~(size_t)15;
@@ -608,13 +835,32 @@ int project_and_resolve(const float *xyz, int64_t n, const float *M_host, int B,
         const int vec_ok = ((uintptr_t)xyz % 16) == 0;
         unsigned long long *stats = g_splat_stats ? (unsigned long long *)((char *)ws.hdr + 64) : nullptr;
         if (use_hiz) {
-            hipLaunchKernelGGL(splat_seed_kernel, dim3(ceil_div(W * H, 256)), dim3(256), 0, stream, xyz, (long long)n, cams,
-                               W, H, keys, ws.hdr, ws.prev);
-            READ_CHECK_LAUNCH();
             // bootstrap: a strided 1/sub of the cloud (only when the vector path is usable) on top of the seeds,
             // so that nearly every pixel is covered before the bounds are taken
             const int sub = (vec_ok && g_splat_subset > 1 && n >= (1 << 20)) ? g_splat_subset : 0;
-            if (sub) {
+            static int n_cu_c = 0;
+            if (!n_cu_c) {
+                int dev = 0;
+                hipDeviceProp_t prop;
+                n_cu_c = (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess &&
+                          prop.multiProcessorCount > 0) ? prop.multiProcessorCount : 256;
+            }
+            const bool use_cells = cells && g_splat_cells;
+            const int *counts = (const int *)((const char *)ws.hdr + CELL_COUNTER_OFFSET);
+            CellCloud cc_none;
+            memset(&cc_none, 0, sizeof(cc_none));
+            const int pix_blocks = ceil_div(W * H, 256);
+            // seeds (previous winners re-projected) + classification of the chunks of the cell-ordered cloud
+            hipLaunchKernelGGL(splat_seed_kernel, dim3(pix_blocks + (use_cells ? ceil_div(cells->nchunks, 256) : 0)), dim3(256),
+                               0, stream, xyz, (long long)n, cams, W, H, keys, ws.hdr, ws.prev, use_cells ? *cells : cc_none,
+                               pix_blocks, 2 * g_splat_subset, (float)g_splat_near);
+            READ_CHECK_LAUNCH();
+            if (use_cells) {
+                // pass A: near chunks + every (2 sub)-th chunk, straight early-z splat, one wave per chunk
+                hipLaunchKernelGGL(splat_cells_kernel<false>, dim3((unsigned)(n_cu_c * 8)), dim3(256), 0, stream, *cells, cams,
+                                   W, H, keys, (const unsigned short *)nullptr, ws.nbx, ws.nby, counts, stats);
+                READ_CHECK_LAUNCH();
+            } else if (sub) {
                 int64_t blocks = ceil_div64(ceil_div64(n, PTS_PER_THREAD), 256);
                 if (blocks > 256 * 8) blocks = 256 * 8;
                 hipLaunchKernelGGL(splat_project_kernel<MODE_AGENT>, dim3((unsigned)blocks), dim3(256), 0, stream, xyz,
@@ -642,7 +888,16 @@ int project_and_resolve(const float *xyz, int64_t n, const float *M_host, int B,
             int64_t blocks = ceil_div64(ceil_div64(n, PTS_PER_THREAD), 1024);
             const int per_cu = 2 * hiz_bytes <= 150 * 1024 ? 2 : 1;     // two workgroups per CU when their bounds fit
             if (blocks > (int64_t)n_cu * per_cu) blocks = (int64_t)n_cu * per_cu;
-            if (g_splat_pipe && !sub)
+            if (use_cells) {
+                static bool attr_c = false;
+                if (!attr_c) {
+                    READ_CHECK_HIP(hipFuncSetAttribute((const void *)splat_cells_kernel<true>,
+                                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)HIZ_LDS_LIMIT));
+                    attr_c = true;
+                }
+                hipLaunchKernelGGL(splat_cells_kernel<true>, dim3((unsigned)(n_cu * per_cu)), dim3(1024), hiz_bytes, stream,
+                                   *cells, cams, W, H, keys, ws.hiz, ws.nbx, ws.nby, counts, stats);
+            } else if (g_splat_pipe && !sub)
                 hipLaunchKernelGGL(splat_pipe_kernel<true>, dim3((unsigned)blocks), dim3(1024), hiz_bytes, stream, xyz,
                                    (long long)n, cams, 1, W, H, keys, ws.hiz, ws.nbx, ws.nbx * ws.nby, sub, sub ? 2 : 0, stats);
             else
@@ -768,6 +1023,161 @@ extern "C" int read_splat_forward(const float *xyz, int64_t n, const float *M_ho
         if (rc != READ_OK) return rc;
     }
     return READ_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// cell-ordered cloud
+// ---------------------------------------------------------------------------------------------------------------
+namespace {
+
+size_t cells_chunks(int64_t n) { return (size_t)((n + CELL_CHUNK - 1) / CELL_CHUNK); }
+
+struct CellOffsets {
+    size_t xyz, ids, aabb, list_a, list_b, total;
+};
+CellOffsets cell_offsets(int64_t n)
+{
+    const size_t nc = cells_chunks(n);
+    CellOffsets o;
+    o.xyz = CELL_HEADER_BYTES;
+    o.ids = o.xyz + nc * CELL_CHUNK * 3 * sizeof(float);
+    o.aabb = o.ids + nc * CELL_CHUNK * sizeof(unsigned);
+    o.list_a = o.aabb + nc * 8 * sizeof(float);                      // per-frame scratch (written by the passes)
+    o.list_b = o.list_a + ((nc * sizeof(int) + 15) & ~(size_t)15);
+    o.total = o.list_b + nc * sizeof(CellEntryB);
+    return o;
+}
+
+inline uint32_t spread10(uint32_t v)       // 10 bits -> every third bit
+{
+    v &= 0x3ffu;
+    v = (v | (v << 16)) & 0x30000ffu;
+    v = (v | (v << 8)) & 0x300f00fu;
+    v = (v | (v << 4)) & 0x30c30c3u;
+    v = (v | (v << 2)) & 0x9249249u;
+    return v;
+}
+
+}  // namespace
+
+extern "C" size_t read_splat_cells_bytes(int64_t n)
+{
+    if (n < 1 || n > 0xFFFFFFFEll) return 0;
+    return cell_offsets(n).total;
+}
+
+// Host-side build (once per cloud): Morton order over a 1024^3 grid of the bounding box (stable LSD radix sort, so equal
+// codes keep ascending ids), chunks of 1024 consecutive points with their exact bounding boxes.
+extern "C" int read_splat_cells_build_host(const float *xyz, int64_t n, void *blob, size_t blob_bytes)
+{
+    READ_CHECK_ARG(xyz && blob, "read_splat_cells_build_host: null pointer");
+    READ_CHECK_ARG(n >= 1 && n <= 0xFFFFFFFEll, "read_splat_cells_build_host: n out of range");
+    const CellOffsets o = cell_offsets(n);
+    READ_CHECK_ARG(blob_bytes >= o.total, "read_splat_cells_build_host: buffer %zu < %zu bytes", blob_bytes, o.total);
+    float lo[3] = {xyz[0], xyz[1], xyz[2]}, hi[3] = {xyz[0], xyz[1], xyz[2]};
+    for (int64_t i = 0; i < n; ++i)
+        for (int k = 0; k < 3; ++k) {
+            const float v = xyz[3 * i + k];
+            READ_CHECK_ARG(v == v && v - v == 0.0f, "read_splat_cells_build_host: point %lld is not finite", (long long)i);
+            lo[k] = v < lo[k] ? v : lo[k];
+            hi[k] = v > hi[k] ? v : hi[k];
+        }
+    float ext = 0.0f;
+    for (int k = 0; k < 3; ++k) ext = (hi[k] - lo[k]) > ext ? (hi[k] - lo[k]) : ext;
+    const float scale = ext > 0.0f ? 1023.999f / ext : 0.0f;
+    std::vector<uint64_t> a((size_t)n), b((size_t)n);
+    for (int64_t i = 0; i < n; ++i) {
+        uint32_t q[3];
+        for (int k = 0; k < 3; ++k) {
+            float t = (xyz[3 * i + k] - lo[k]) * scale;
+            q[k] = t <= 0.0f ? 0u : (t >= 1023.0f ? 1023u : (uint32_t)t);
+        }
+        const uint64_t code = spread10(q[0]) | ((uint64_t)spread10(q[1]) << 1) | ((uint64_t)spread10(q[2]) << 2);
+        a[(size_t)i] = (code << 32) | (uint64_t)(uint32_t)i;
+    }
+    for (int pass = 0; pass < 3; ++pass) {                      // 30 code bits, 10 per pass
+        const int shift = 32 + 10 * pass;
+        size_t hist[1025] = {0};
+        for (size_t i = 0; i < (size_t)n; ++i) ++hist[((a[i] >> shift) & 1023u) + 1];
+        for (int k = 0; k < 1024; ++k) hist[k + 1] += hist[k];
+        for (size_t i = 0; i < (size_t)n; ++i) b[hist[(a[i] >> shift) & 1023u]++] = a[i];
+        a.swap(b);
+    }
+    char *base = (char *)blob;
+    memset(base, 0, CELL_HEADER_BYTES);
+    float *xs = (float *)(base + o.xyz);
+    unsigned *ids = (unsigned *)(base + o.ids);
+    float *bb = (float *)(base + o.aabb);
+    const size_t nc = cells_chunks(n), padded = nc * CELL_CHUNK;
+    for (size_t i = 0; i < padded; ++i) {
+        const uint32_t id = (uint32_t)(a[i < (size_t)n ? i : (size_t)n - 1] & 0xffffffffu);   // tail: copies of the last point
+        ids[i] = id;
+        xs[3 * i + 0] = xyz[3 * (size_t)id + 0];
+        xs[3 * i + 1] = xyz[3 * (size_t)id + 1];
+        xs[3 * i + 2] = xyz[3 * (size_t)id + 2];
+    }
+    for (size_t c = 0; c < nc; ++c) {
+        float mn[3], mx[3];
+        for (int k = 0; k < 3; ++k) mn[k] = mx[k] = xs[3 * c * CELL_CHUNK + k];
+        for (size_t i = c * CELL_CHUNK; i < (c + 1) * CELL_CHUNK; ++i)
+            for (int k = 0; k < 3; ++k) {
+                const float v = xs[3 * i + k];
+                mn[k] = v < mn[k] ? v : mn[k];
+                mx[k] = v > mx[k] ? v : mx[k];
+            }
+        float *r = bb + 8 * c;
+        r[0] = mn[0]; r[1] = mn[1]; r[2] = mn[2]; r[3] = mx[0]; r[4] = mx[1]; r[5] = mx[2]; r[6] = r[7] = 0.0f;
+    }
+    CellHeader *h = (CellHeader *)base;
+    h->n = n;
+    h->nchunks = (int)nc;
+    h->version = 1;
+    double vol = 1.0;
+    for (int k = 0; k < 3; ++k) {
+        h->bbox[k] = lo[k];
+        h->bbox[3 + k] = hi[k];
+        const double e = (double)hi[k] - lo[k];
+        vol *= e > 1e-6 * ext ? e : (ext > 0 ? 1e-6 * ext : 1.0);   // a flat cloud still gets a finite density
+    }
+    h->density = (float)((double)n / (vol > 0 ? vol : 1.0));
+    return READ_OK;
+}
+
+extern "C" int read_splat_forward_cells(const float *xyz, void *cells, int64_t n, const float *M_host, int B,
+                                        int W, int H, int levels, int32_t *const *idx_levels,
+                                        float *const *depth_levels, void *ws, size_t ws_bytes, void *stream)
+{
+    const int mask = levels >= 1 && levels <= READ_MAX_LEVELS ? (1 << (levels - 1)) - 1 : 0;
+    // the cell-ordered passes serve the single-camera, pyramid-identity case (the per-frame render path); everything
+    // else goes through the plain pass
+    if (!cells || B != 1 || n < (1 << 20) || ((W | H) & mask) != 0 || !xyz || !M_host || !ws || W < 1 || H < 1)
+        return read_splat_forward(xyz, n, M_host, B, W, H, levels, idx_levels, depth_levels, ws, ws_bytes, stream);
+    READ_CHECK_ARG(n <= 0xFFFFFFFEll, "read_splat_forward_cells: point ids must fit 32 bits");
+    READ_CHECK_ARG(levels >= 1 && levels <= READ_MAX_LEVELS, "read_splat_forward_cells: levels must be 1..%d",
+                   READ_MAX_LEVELS);
+    READ_CHECK_ARG(idx_levels || depth_levels, "read_splat_forward_cells: no outputs requested");
+    READ_CHECK_ARG((long long)W * H < (1ll << 31), "read_splat_forward_cells: image too large");
+    READ_CHECK_ARG((uintptr_t)ws % 16 == 0 && (uintptr_t)cells % 16 == 0, "read_splat_forward_cells: misaligned pointer");
+    if (ws_bytes < read_splat_workspace_bytes(B, W, H)) {
+        set_error("read_splat_forward_cells: workspace %zu < %zu bytes", ws_bytes, read_splat_workspace_bytes(B, W, H));
+        return READ_ENOMEM;
+    }
+    const CellOffsets o = cell_offsets(n);
+    CellCloud cc;
+    cc.hdr = (const CellHeader *)cells;
+    cc.xyz = (const float *)((const char *)cells + o.xyz);
+    cc.ids = (const unsigned *)((const char *)cells + o.ids);
+    cc.aabb = (const float *)((const char *)cells + o.aabb);
+    cc.list_a = (int *)((char *)cells + o.list_a);
+    cc.list_b = (CellEntryB *)((char *)cells + o.list_b);
+    cc.nchunks = (int)cells_chunks(n);
+    const WsLayout L = ws_layout(ws, B, W, H);
+    return project_and_resolve(xyz, n, M_host, B, W, H, levels, idx_levels, depth_levels, 0, L, true, as_stream(stream), &cc);
+}
+
+namespace readhip {
+void splat_set_near(int v) { g_splat_near = v < 1 ? 1 : v; }
+void splat_set_cells(int v) { g_splat_cells = v; }
 }
 
 extern "C" int read_index_to_float(const int32_t *idx, int64_t count, float *out, void *stream)

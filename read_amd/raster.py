@@ -21,7 +21,9 @@ class PointCloudRasterizer:
     tensors shaped (B, h_l, w_l).  Deterministic: per pixel min depth, ties -> min point id;
     empty pixels are (0, 0.0)."""
 
-    def __init__(self, xyz, device=None):
+    CELLS_MIN_POINTS = 1 << 20      # below this the plain pass is used (read_splat_forward_cells falls back anyway)
+
+    def __init__(self, xyz, device=None, cells=True):
         self.device = device if device is not None else _lib.require_gpu()
         xyz = torch.as_tensor(np.ascontiguousarray(xyz, dtype=np.float32) if not torch.is_tensor(xyz) else xyz)
         if xyz.dim() != 2 or xyz.shape[1] != 3:
@@ -30,6 +32,10 @@ class PointCloudRasterizer:
         self.n = int(self.xyz.shape[0])
         self._workspaces = {}
         self._ws = None
+        # cell-ordered copy (Morton-sorted chunks of 1024 points + bounding boxes), built once on the host
+        self.cells = None
+        if cells and self.n >= self.CELLS_MIN_POINTS:
+            self.cells = torch.from_numpy(build_cells(xyz.detach().cpu().numpy())).to(self.device)
 
     def _workspace(self, B, W, H):
         """One persistent workspace per (min(B,8), W, H): key images, hi-z bounds and the previous frame's
@@ -61,10 +67,24 @@ class PointCloudRasterizer:
         L = _lib.lib()
         idx_p = _lib.ptr_array([t.data_ptr() for t in idx])
         dep_p = _lib.ptr_array([t.data_ptr() for t in dep]) if dep is not None else None
-        _lib.check(L.read_splat_forward(self.xyz.data_ptr(), self.n, M.ctypes.data_as(C.POINTER(C.c_float)), B,
-                                        W, H, levels, idx_p, dep_p, ws.data_ptr(), ws.numel(),
-                                        _lib.stream_ptr()), "read_splat_forward")
+        _lib.check(L.read_splat_forward_cells(self.xyz.data_ptr(),
+                                              self.cells.data_ptr() if self.cells is not None else None, self.n,
+                                              M.ctypes.data_as(C.POINTER(C.c_float)), B, W, H, levels, idx_p, dep_p,
+                                              ws.data_ptr(), ws.numel(), _lib.stream_ptr()), "read_splat_forward_cells")
         return idx, dep
+
+
+def build_cells(xyz):
+    """Host blob of ``read_splat_cells_build_host`` for an (N,3) float32 array (uint8 ndarray, upload as is)."""
+    xyz = np.ascontiguousarray(xyz, dtype=np.float32)
+    L = _lib.lib()
+    nbytes = L.read_splat_cells_bytes(xyz.shape[0])
+    if nbytes == 0:
+        raise ValueError(f"cannot build cells for {xyz.shape[0]} points")
+    blob = np.empty(nbytes, np.uint8)
+    _lib.check(L.read_splat_cells_build_host(xyz.ctypes.data, xyz.shape[0], blob.ctypes.data, nbytes),
+               "read_splat_cells_build_host")
+    return blob
 
 
 def index_to_float(idx):
