@@ -42,6 +42,9 @@ void conv_set_ablate(int bits);
 void conv_set_wino(int max_cin);
 void splat_set_near(int v);
 void splat_set_cells(int v);
+void splat_set_seeds(int v);
+void splat_set_l1(int v);
+void splat_set_cells_sub(int v);
 }
 
 // Debug: per-workgroup timeline of the next gated-conv launches.  buf = device memory, 64 bytes per
@@ -79,6 +82,18 @@ extern "C" int read_tuning_set(const char *key, int value)
     }
     if (!strcmp(key, "splat_near")) {      // cell path: expected points per pixel in front of the pass-A split distance
         readhip::splat_set_near(value);
+        return READ_OK;
+    }
+    if (!strcmp(key, "splat_l1")) {
+        readhip::splat_set_l1(value);
+        return READ_OK;
+    }
+    if (!strcmp(key, "splat_cells_sub")) {
+        readhip::splat_set_cells_sub(value);
+        return READ_OK;
+    }
+    if (!strcmp(key, "splat_seeds")) {     // 0: no warm start from the previous frame
+        readhip::splat_set_seeds(value);
         return READ_OK;
     }
     if (!strcmp(key, "splat_cells")) {     // 0: ignore the cell-ordered copy

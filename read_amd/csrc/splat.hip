@@ -76,8 +76,12 @@ __device__ __forceinline__ int project_one(float x, float y, float z, const floa
 //              1216x352) into LDS.  A point whose depth exceeds its block's bound cannot win (keys only
 //              decrease), so it is dropped without touching global memory — ~90 % of the points of a frame.
 //              Exact: seeds are real points of this cloud, bounds are upper bounds of the final depths.
+//   MODE_AGENT_L1 / MODE_HIZ_L1 (cell-ordered passes, read_tuning_set("splat_l1", 1)): as MODE_AGENT / MODE_HIZ with
+//              the early-z read served by the CU's L1.  A stale copy is only ever LARGER than the live key (keys
+//              decrease), so the filter stays conservative; the chunks are spatially compact, so their reads share
+//              cache lines, and the seeds of the previous launch are visible (L1 is invalidated at kernel start).
 enum { MODE_XCD = 0, MODE_AGENT = 1, MODE_NOZ = 2, MODE_SYS = 3, MODE_PEEK = 4, MODE_PEEK_L1 = 5, MODE_ATOM = 6,
-       MODE_HIZ = 7 };
+       MODE_HIZ = 7, MODE_AGENT_L1 = 8, MODE_HIZ_L1 = 9 };
 constexpr int XCD_COPIES = 8;
 
 __device__ __forceinline__ unsigned xcc_id()
@@ -91,7 +95,7 @@ __device__ __forceinline__ unsigned long long peek_key(const unsigned long long 
 {
     // relaxed agent-scope load = global_load_dwordx2 sc1: served by L2, never by the CU's stale L1
     if (MODE == MODE_SYS) return __hip_atomic_load(k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-    if (MODE == MODE_PEEK_L1) return *k;
+    if (MODE == MODE_PEEK_L1 || MODE == MODE_AGENT_L1 || MODE == MODE_HIZ_L1) return *k;
     return __hip_atomic_load(k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
@@ -136,7 +140,7 @@ __device__ __forceinline__ void splat_points_ids(const float (&px)[NP], const fl
         pix[k] = project_one(px[k], py[k], pz[k], M, W, H, d, xx, yy);
         if (k >= nvalid) pix[k] = -1;
         if (stat && pix[k] >= 0) stat[0]++;                 // visible
-        if (MODE == MODE_HIZ) {
+        if (MODE == MODE_HIZ || MODE == MODE_HIZ_L1) {
             // LDS-resident far bound of the point's 4x4 block; strictly greater cannot win (ties must pass)
             if (hiz_reject(hiz[pix[k] >= 0 ? (yy >> 2) * nbx + (xx >> 2) : 0], d)) pix[k] = -1;
         }
@@ -462,7 +466,7 @@ __global__ __launch_bounds__(256) void splat_seed_kernel(const float *__restrict
         return;
     }
     const int p = blockIdx.x * blockDim.x + threadIdx.x;
-    if (p >= W * H) return;
+    if (p >= W * H || !prev_idx) return;
     if (!(hdr->valid == 1 && hdr->W == W && hdr->H == H)) return;
     const int id = prev_idx[p];
     if (id < 0 || id >= n) return;
@@ -472,7 +476,7 @@ __global__ __launch_bounds__(256) void splat_seed_kernel(const float *__restrict
     if (pix >= 0) fold_key<MODE_AGENT>(keys + pix, ((unsigned long long)__float_as_uint(d) << 32) | (unsigned)id);
 }
 
-template <bool PASS_B>
+template <bool PASS_B, bool L1>
 __global__ __launch_bounds__(PASS_B ? 1024 : 256) void splat_cells_kernel(CellCloud cc, CamSet cams, int W, int H,
                                                                          unsigned long long *__restrict__ keys,
                                                                          const unsigned short *__restrict__ hiz_g, int nbx,
@@ -534,9 +538,9 @@ __global__ __launch_bounds__(PASS_B ? 1024 : 256) void splat_cells_kernel(CellCl
             const float pz[4] = {a.z, b.y, c.x, c.w};
             const unsigned ids[4] = {id.x, id.y, id.z, id.w};
             if (PASS_B)
-                splat_points_ids<MODE_HIZ, 4>(px, py, pz, ids, 4, M, W, H, keys, sink, hiz, nbx, stp);
+                splat_points_ids<L1 ? MODE_HIZ_L1 : MODE_HIZ, 4>(px, py, pz, ids, 4, M, W, H, keys, sink, hiz, nbx, stp);
             else
-                splat_points_ids<MODE_AGENT, 4>(px, py, pz, ids, 4, M, W, H, keys, sink, nullptr, 0, stp);
+                splat_points_ids<L1 ? MODE_AGENT_L1 : MODE_AGENT, 4>(px, py, pz, ids, 4, M, W, H, keys, sink, nullptr, 0, stp);
         }
     }
     if (stats && lane == 0) {
@@ -814,8 +818,11 @@ WsLayout ws_layout(void *ws, int B, int W, int H)
 
 constexpr size_t HIZ_LDS_LIMIT = 150 * 1024;   // of the 160 KiB per CU
 
-int g_splat_near = 8;          // cell path: pass A takes chunks nearer than the depth at which a pixel expects this many points
+int g_splat_near = 12;         // cell path: pass A takes chunks nearer than the depth at which a pixel expects this many points
 int g_splat_cells = 1;         // 0: ignore the cell-ordered copy (A/B)
+int g_splat_l1 = 1;            // early-z reads of the cell-ordered passes through the L1 (0: L2, A/B)
+int g_splat_cells_sub = 32;    // list A also takes every n-th chunk (0: none): a first bound where nothing is near
+int g_splat_seeds = 1;         // 0: no warm start from the previous frame's winners (A/B)
 
 int project_and_resolve(const float *xyz, int64_t n, const float *M_host, int B, int W, int H, int levels,
                         int32_t *const *idx_levels, float *const *depth_levels, int level_base,
@@ -852,12 +859,14 @@ int project_and_resolve(const float *xyz, int64_t n, const float *M_host, int B,
             const int pix_blocks = ceil_div(W * H, 256);
             // seeds (previous winners re-projected) + classification of the chunks of the cell-ordered cloud
             hipLaunchKernelGGL(splat_seed_kernel, dim3(pix_blocks + (use_cells ? ceil_div(cells->nchunks, 256) : 0)), dim3(256),
-                               0, stream, xyz, (long long)n, cams, W, H, keys, ws.hdr, ws.prev, use_cells ? *cells : cc_none,
-                               pix_blocks, 2 * g_splat_subset, (float)g_splat_near);
+                               0, stream, xyz, (long long)n, cams, W, H, keys, ws.hdr, g_splat_seeds ? ws.prev : (int *)nullptr,
+                               use_cells ? *cells : cc_none,
+                               pix_blocks, g_splat_cells_sub, (float)g_splat_near);
             READ_CHECK_LAUNCH();
             if (use_cells) {
                 // pass A: near chunks + every (2 sub)-th chunk, straight early-z splat, one wave per chunk
-                hipLaunchKernelGGL(splat_cells_kernel<false>, dim3((unsigned)(n_cu_c * 8)), dim3(256), 0, stream, *cells, cams,
+                auto kern_a = g_splat_l1 ? splat_cells_kernel<false, true> : splat_cells_kernel<false, false>;
+                hipLaunchKernelGGL(kern_a, dim3((unsigned)(n_cu_c * 8)), dim3(256), 0, stream, *cells, cams,
                                    W, H, keys, (const unsigned short *)nullptr, ws.nbx, ws.nby, counts, stats);
                 READ_CHECK_LAUNCH();
             } else if (sub) {
@@ -891,11 +900,16 @@ int project_and_resolve(const float *xyz, int64_t n, const float *M_host, int B,
             if (use_cells) {
                 static bool attr_c = false;
                 if (!attr_c) {
-                    READ_CHECK_HIP(hipFuncSetAttribute((const void *)splat_cells_kernel<true>,
-                                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)HIZ_LDS_LIMIT));
+                    auto kb0 = splat_cells_kernel<true, false>;
+                    auto kb1 = splat_cells_kernel<true, true>;
+                    READ_CHECK_HIP(hipFuncSetAttribute((const void *)kb0, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                                       (int)HIZ_LDS_LIMIT));
+                    READ_CHECK_HIP(hipFuncSetAttribute((const void *)kb1, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                                       (int)HIZ_LDS_LIMIT));
                     attr_c = true;
                 }
-                hipLaunchKernelGGL(splat_cells_kernel<true>, dim3((unsigned)(n_cu * per_cu)), dim3(1024), hiz_bytes, stream,
+                auto kern_b = g_splat_l1 ? splat_cells_kernel<true, true> : splat_cells_kernel<true, false>;
+                hipLaunchKernelGGL(kern_b, dim3((unsigned)(n_cu * per_cu)), dim3(1024), hiz_bytes, stream,
                                    *cells, cams, W, H, keys, ws.hiz, ws.nbx, ws.nby, counts, stats);
             } else if (g_splat_pipe && !sub)
                 hipLaunchKernelGGL(splat_pipe_kernel<true>, dim3((unsigned)blocks), dim3(1024), hiz_bytes, stream, xyz,
@@ -1178,6 +1192,9 @@ extern "C" int read_splat_forward_cells(const float *xyz, void *cells, int64_t n
 namespace readhip {
 void splat_set_near(int v) { g_splat_near = v < 1 ? 1 : v; }
 void splat_set_cells(int v) { g_splat_cells = v; }
+void splat_set_seeds(int v) { g_splat_seeds = v; }
+void splat_set_l1(int v) { g_splat_l1 = v; }
+void splat_set_cells_sub(int v) { g_splat_cells_sub = v < 0 ? 0 : v; }
 }
 
 extern "C" int read_index_to_float(const int32_t *idx, int64_t count, float *out, void *stream)

@@ -154,3 +154,61 @@ def test_full_size_30M_properties(hip):
     best_d[np.isinf(best_d)] = 0
     assert np.array_equal(idx[0][0].cpu().numpy().astype(np.int64), best_i)
     assert np.array_equal(dep[0][0].cpu().numpy().view(np.uint32), best_d.view(np.uint32))
+
+
+def test_cell_ordered_passes_are_exact_for_hard_cameras(hip):
+    """The cell-ordered path (Morton chunks, frustum / hi-Z chunk culling; n >= 2^20) against the oracle for cameras
+    that stress the conservative chunk tests: inside the cloud (boxes straddling the camera plane), rolled and pitched
+    views, a far-away camera (everything beyond the pass-A split), large world offsets (fp32 projection noise), and
+    every tuning of the split; then against the plain path on the same object."""
+    from read_amd import _lib
+    W, H = 304, 176
+    rng = np.random.default_rng(17)
+    xyz = synthetic.make_cloud(1_200_000, seed=23)
+    proj = synthetic.make_proj(W, H, f=180.0)
+
+    def pose(tx, ty, tz, yaw, pitch, roll):
+        cy, sy, cp, sp, cr, sr = np.cos(yaw), np.sin(yaw), np.cos(pitch), np.sin(pitch), np.cos(roll), np.sin(roll)
+        Ry = np.array([[cy, 0, sy], [0, 1, 0], [-sy, 0, cy]])
+        Rx = np.array([[1, 0, 0], [0, cp, -sp], [0, sp, cp]])
+        Rz = np.array([[cr, -sr, 0], [sr, cr, 0], [0, 0, 1]])
+        m = np.eye(4, dtype=np.float32)
+        m[:3, :3] = (Ry @ Rx @ Rz).astype(np.float32)
+        m[:3, 3] = [tx, ty, tz]
+        return m
+
+    poses = [pose(0, 0, 0, 0, 0, 0), pose(3, 2, -60, 0.4, -0.1, 0.3), pose(-20, 5, -100, 2.5, 0.2, -1.0),
+             pose(0, 0, 400, 0, 0, 0), pose(10, 30, -60, 0.1, -1.2, 0.0), pose(0, 4, -119.5, 3.14, 0, 0)]
+    r = PointCloudRasterizer(xyz)
+    assert r.cells is not None
+    L = _lib.lib()
+    try:
+        for near in (12, 1, 200):
+            _lib.check(L.read_tuning_set(b"splat_near", near))
+            for k, p in enumerate(poses):
+                M = camera.total_matrix(proj, p)
+                idx, dep = r.render(M, W, H, 5)
+                oi, od = oracle.raster_multiscale(xyz, M[0], W, H, 5, threads=8)
+                for l in range(5):
+                    assert np.array_equal(idx[l][0].cpu().numpy(), oi[l]), f"near {near} pose {k} level {l}"
+                    assert np.array_equal(dep[l][0].cpu().numpy().view(np.uint32), od[l].view(np.uint32))
+    finally:
+        _lib.check(L.read_tuning_set(b"splat_near", 12))
+    # large world coordinates: the same cloud and camera moved 5 km away (projection rounding grows ~100x)
+    off = np.array([5000.0, -3000.0, 4000.0], np.float32)
+    far = PointCloudRasterizer(xyz + off)
+    p = pose(3, 2, -60, 0.4, -0.1, 0.3)
+    p[:3, 3] += off
+    M = camera.total_matrix(proj, p)
+    for _ in range(2):                                        # cold, then warm-started
+        idx, dep = far.render(M, W, H, 5)
+        oi, od = oracle.raster_multiscale(xyz + off, M[0], W, H, 5, threads=8)
+        assert np.array_equal(idx[0][0].cpu().numpy(), oi[0]) and np.array_equal(idx[4][0].cpu().numpy(), oi[4])
+        assert np.array_equal(dep[0][0].cpu().numpy().view(np.uint32), od[0].view(np.uint32))
+    # and the plain path of the same object agrees bit for bit
+    try:
+        _lib.check(L.read_tuning_set(b"splat_cells", 0))
+        idx2, dep2 = far.render(M, W, H, 5)
+    finally:
+        _lib.check(L.read_tuning_set(b"splat_cells", 1))
+    assert all(torch.equal(a, b) for a, b in zip(idx, idx2)) and all(torch.equal(a, b) for a, b in zip(dep, dep2))
