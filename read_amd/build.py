@@ -20,7 +20,7 @@ ARCH = "gfx950"
 FLAGS = ["-O3", "-std=c++17", "-fPIC", f"--offload-arch={ARCH}", "-x", "hip",
          "-I", os.path.join(ROOT, "include"), "-I", CSRC, "-Wall", "-Wno-unused-function"]
 # the rasteriser's pixel assignment must be bit-exact fp32: no a*b+c contraction
-PER_FILE = {"splat.hip": ["-ffp-contract=off"]}
+PER_FILE = {"splat.hip": ["-ffp-contract=off"], "conv.hip": ["-fno-slp-vectorize"]}
 
 
 def _hipcc():
