@@ -40,6 +40,7 @@ void conv_set_prefer_wave(int v);
 void conv_set_stagger(int ticks);
 void conv_set_ablate(int bits);
 void conv_set_wino(int max_cin);
+void unet_set_streams(int v);
 void splat_set_near(int v);
 void splat_set_cells(int v);
 void splat_set_seeds(int v);
@@ -98,6 +99,10 @@ extern "C" int read_tuning_set(const char *key, int value)
     }
     if (!strcmp(key, "splat_cells")) {     // 0: ignore the cell-ordered copy
         readhip::splat_set_cells(value);
+        return READ_OK;
+    }
+    if (!strcmp(key, "unet_streams")) {    // 0: the SCM chains stay on the caller's stream
+        readhip::unet_set_streams(value);
         return READ_OK;
     }
     if (!strcmp(key, "conv_wino")) {       // value = largest Cin that takes the Winograd kernel (0 = off)
