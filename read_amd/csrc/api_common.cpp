@@ -40,6 +40,7 @@ void conv_set_prefer_wave(int v);
 void conv_set_stagger(int ticks);
 void conv_set_ablate(int bits);
 void conv_set_wino(int max_cin);
+void conv_set_kc32(int v);
 void unet_set_streams(int v);
 void splat_set_near(int v);
 void splat_set_cells(int v);
@@ -103,6 +104,10 @@ extern "C" int read_tuning_set(const char *key, int value)
     }
     if (!strcmp(key, "unet_streams")) {    // 0: the SCM chains stay on the caller's stream
         readhip::unet_set_streams(value);
+        return READ_OK;
+    }
+    if (!strcmp(key, "conv_kc32")) {
+        readhip::conv_set_kc32(value);
         return READ_OK;
     }
     if (!strcmp(key, "conv_wino")) {       // value = largest Cin that takes the Winograd kernel (0 = off)

@@ -1017,6 +1017,11 @@ const ConvConfig g_configs[] = {
     CFG(1, 1, 16, 2, 1, 4, 1, 1),   // 11
     CFG(1, 1, 16, 1, 1, 4, 1, 1),   // 12
     CFG(1, 1, 16, 2, 2, 2, 2, 1),   // 13
+    // 1x1, 32-channel chunks (AFF first conv, Convs: every source a multiple of 32 channels): twice the MFMAs per
+    // staged tile and per barrier of the 16-channel chunks
+    CFG(1, 1, 32, 2, 1, 4, 1, 1),
+    CFG(1, 1, 32, 1, 1, 4, 1, 1),
+    CFG(1, 1, 32, 2, 2, 2, 2, 1),
     // 1x1, 8-channel chunks (SCM tail: cat[x(8), main(P-8)])
     CFG(1, 1, 8, 2, 1, 4, 1, 0),    // 15
     CFG(1, 1, 8, 1, 1, 4, 1, 0),    // 16
@@ -1030,6 +1035,8 @@ const ConvConfig g_configs[] = {
     CFGW(3, 1, 16, 1, 1, 2, 3),
     CFGW(1, 1, 16, 2, 1, 1, 2),
     CFGW(1, 1, 16, 1, 1, 1, 4),
+    CFGW(1, 1, 32, 2, 1, 1, 2),
+    CFGW(1, 1, 32, 1, 1, 1, 4),
     CFGW(3, 1, 8, 2, 1, 2, 2),
     {"k3s1c16_p1q1_wino", 3, 1, 16, 1, 1, 4, 1, 1, 2, gated_conv_wino_kernel<false, false>, gated_conv_wino_kernel<false, true>, 0, 0, 1},
     // 4x4 stride 2 (decoder, before the bilinear x4): outputs are 1/4 .. 1/16 scale, so the 16 taps of
@@ -1052,6 +1059,7 @@ int find_config(int ks, int s, int kc, int P, int QG, int WM, int WN, int PF, in
 }
 
 int g_prefer_wave = 1;   // read_tuning_set("conv_wave", 0): workgroup-tiled kernels only
+int g_kc32 = 1;            // 32-channel chunks for 1x1 layers whose sources are all multiples of 32 (read_tuning_set("conv_kc32", 0): 16)
 int g_use_wino = 1 << 30;  // read_tuning_set("conv_wino", max Cin): Winograd kernel for eligible 3x3 layers (0 = off)
 int g_stagger_ticks = 0;
 int g_ablate = 0;          // read_tuning_set("conv_ablate", bits)   // read_tuning_set("conv_stagger", ticks of 10 ns)   // read_tuning_set("conv_wave", 1): wave-autonomous kernels where they exist
@@ -1081,6 +1089,9 @@ int pick_config(int ks, int s, int kc, int groups, int outH, int outW)
         else c = find_config(3, 1, 16, 1, 1, 4, 1, 2, 1);
     } else if (ks == 3 && s == 1 && kc == 8) {
         c = g_prefer_wave ? find_wave_config(3, 1, 8, 2, 1) : find_config(3, 1, 8, 1, 1, 4, 1, 2, 2);
+    } else if (ks == 1 && s == 1 && kc == 32) {
+        if (groups % 4 == 0) c = find_config(1, 1, 32, 2, 2, 2, 2, 1, 2);      // 91 TF at 128 channels
+        else c = find_wave_config(1, 1, 32, 1, 1);                            // 99-103 TF (16-channel chunks: 93-97)
     } else if (ks == 1 && s == 1 && kc == 16) {
         if (groups % 4 == 0) c = find_config(1, 1, 16, 2, 2, 2, 2, 1, 2);
         else if (g_prefer_wave) c = find_wave_config(1, 1, 16, groups == 1 ? 2 : 1, 1);
@@ -1158,7 +1169,9 @@ extern "C" int read_conv_pack_weights_host(int Cin, int Cout, int ksize, int kc,
 {
     READ_CHECK_ARG(wf && wm && wpacked_host, "read_conv_pack_weights_host: null pointer");
     READ_CHECK_ARG(ksize == 1 || ksize == 3 || ksize == 4, "read_conv_pack_weights_host: ksize must be 1, 3 or 4");
-    READ_CHECK_ARG((kc == 8 || kc == 16) && Cin >= kc && Cin % kc == 0,
+    // (for 1x1 layers the fragment order does not depend on kc: k8 steps are simply consecutive, so 16- and 32-channel
+    //  chunk kernels read the same blob)
+    READ_CHECK_ARG((kc == 8 || kc == 16 || (kc == 32 && ksize == 1)) && Cin >= kc && Cin % kc == 0,
                    "read_conv_pack_weights_host: Cin=%d is not a multiple of kc=%d", Cin, kc);
     READ_CHECK_ARG(Cout >= 1, "read_conv_pack_weights_host: Cout < 1");
     const int CoutPad = pad32(Cout), NT = CoutPad / 16, KK = kc / 8, taps = ksize * ksize;
@@ -1239,6 +1252,7 @@ void conv_set_prefer_wave(int v) { g_prefer_wave = v; }
 void conv_set_stagger(int ticks) { g_stagger_ticks = ticks < 0 ? 0 : ticks; }
 void conv_set_ablate(int bits) { g_ablate = bits; }
 void conv_set_wino(int max_cin) { g_use_wino = max_cin; }
+void conv_set_kc32(int v) { g_kc32 = v; }
 
 static unsigned long long *g_trace = nullptr;
 static size_t g_trace_records = 0;
@@ -1288,6 +1302,11 @@ int launch_gated_conv(const read_conv_desc *d, hipStream_t stream)
         a.src[i].sr = s.shift < 0 ? -s.shift : 0;
     }
     READ_CHECK_ARG(!d->mul || d->src[0].shift == 0, "read_gated_conv_forward: mul needs shift 0");
+    {   // 1x1 layers whose sources are all multiples of 32 channels run 32-channel chunks (weights packed with kc = 32)
+        bool all32 = d->ksize == 1;
+        for (int i = 0; i < d->n_src; ++i) all32 = all32 && d->src[i].C % 32 == 0;
+        if (all32 && (d->config >= 0 ? (d->config < N_CONFIGS && g_configs[d->config].KC == 32) : g_kc32 != 0)) kc = 32;
+    }
     const int nchunks = Cin / kc;
     a.n_src = d->n_src;
     const int pad = (d->ksize - 1) / 2;

@@ -18,12 +18,12 @@ def kc_for(src_channels):
 class PackedGatedConv:
     """Weights of one BasicConv packed for the MFMA kernel and resident on the device."""
 
-    def __init__(self, wf, bf, wm, bm, gamma, beta, mean, var, src_channels=None, eps=1e-5, device=None):
+    def __init__(self, wf, bf, wm, bm, gamma, beta, mean, var, src_channels=None, eps=1e-5, device=None, kc=None):
         device = device if device is not None else _lib.require_gpu()
         f32 = lambda a: np.ascontiguousarray(a.detach().cpu().numpy() if torch.is_tensor(a) else a, dtype=np.float32)
         wf, wm, bf, bm, gamma, beta, mean, var = map(f32, (wf, wm, bf, bm, gamma, beta, mean, var))
         self.cout, self.cin, self.k, _ = wf.shape
-        self.kc = kc_for(src_channels if src_channels is not None else [self.cin])
+        self.kc = kc if kc is not None else kc_for(src_channels if src_channels is not None else [self.cin])
         L = _lib.lib()
         wp = np.empty(L.read_conv_packed_floats(self.cin, self.cout, self.k), np.float32)
         pp = np.empty(L.read_conv_param_floats(self.cout), np.float32)

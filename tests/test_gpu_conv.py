@@ -58,7 +58,7 @@ def test_every_tile_configuration(hip):
         groups = WN * QG
         for g_mult in ((1, 2) if groups == 4 else (1,)):               # grid.y > 1 path
             cout = 32 * groups * g_mult - (8 if kc == 16 else 5)         # non-multiple of 32 -> padded channels
-            cin = 24 if kc == 8 else 48
+            cin = {8: 24, 16: 48, 32: 64}[kc]
             H, W = (22, 44) if s == 1 else (24, 80)
             st = _state(cin, cout, k, seed=ci)
             x = torch.randn(cin, H, W)

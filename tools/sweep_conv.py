@@ -62,6 +62,12 @@ def main():
         pk = PackedGatedConv(st[b + "conv_f.weight"], st[b + "conv_f.bias"], st[b + "conv_m.weight"],
                              st[b + "conv_m.bias"], st[b + "norm.weight"], st[b + "norm.bias"],
                              st[b + "norm.running_mean"], st[b + "norm.running_var"], src_channels=[c for c, _ in srcs])
+        pk32 = None
+        if k == 1 and all(c % 32 == 0 for c, _ in srcs):           # 1x1 with 32-channel chunks: its own packing
+            pk32 = PackedGatedConv(st[b + "conv_f.weight"], st[b + "conv_f.bias"], st[b + "conv_m.weight"],
+                                   st[b + "conv_m.bias"], st[b + "norm.weight"], st[b + "norm.bias"],
+                                   st[b + "norm.running_mean"], st[b + "norm.running_var"],
+                                   src_channels=[c for c, _ in srcs], kc=32)
         ih, iw = oh * s, ow * s
         xs = []
         for c, sh in srcs:
@@ -85,15 +91,17 @@ def main():
                 continue
             m = re.match(r"k(\d)s(\d)c(\d+)_(?:wave_)?p(\d)q(\d)(?:m(\d)n(\d))?", name)
             ks, ss, kcc, P, QG, WM, WN = (int(g) if g is not None else 1 for g in m.groups())
-            if (ks, ss, kcc) != (k, s, kc) or groups % (WN * QG) or a.only not in name:
+            use32 = kcc == 32 and pk32 is not None and (ks, ss) == (k, s)
+            if ((ks, ss, kcc) != (k, s, kc) and not use32) or groups % (WN * QG) or a.only not in name:
                 continue
+            pkc = pk32 if use32 else pk
             try:
                 for _ in range(2):
-                    gated_conv(pk, xs, stride=s, elu=True, config=ci, out=out)
+                    gated_conv(pkc, xs, stride=s, elu=True, config=ci, out=out)
                 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                 e0.record()
                 for _ in range(a.iters):
-                    gated_conv(pk, xs, stride=s, elu=True, config=ci, out=out)
+                    gated_conv(pkc, xs, stride=s, elu=True, config=ci, out=out)
                 e1.record()
                 e1.synchronize()
                 ms = e0.elapsed_time(e1) / a.iters
