@@ -125,3 +125,55 @@ def test_netandtexture_forward_contract(hip):
             ref = unet_torch.net_and_texture_forward(state, tex.texture_.detach().cpu().numpy(),
                                                      [m[b, 0].astype(np.int32) for m in maps])[0]
             assert unet_torch.psnr(out[b].cpu(), ref) >= 80.0
+
+
+def test_scene_directory_and_checkpoints_to_frame(hip, tmp_path):
+    """SURVEY §8f rows 1-2 end to end: a scene directory on disk (scene.yaml + pointcloud.ply + Metashape camera.xml) and
+    reference-format checkpoints ({'state_dict', 'args'}) -> load_scene_data / setup_scene -> OGL(...) -> RGBA frame,
+    equal to the oracle run on the same files' contents."""
+    from read_amd import scene_io
+    from read_amd.pipeline import save_model
+    W, H, N = 128, 64, 20_000
+    xyz = synthetic.make_cloud(N, seed=5)
+    scene_io.write_ply(str(tmp_path / "pointcloud.ply"), xyz, rgb=np.zeros((N, 3), np.uint8), normals=np.zeros((N, 3)))
+    poses = [synthetic.sweep_pose(3), synthetic.sweep_pose(9)]
+    cams = []
+    for k, p in enumerate(poses):
+        m = p.astype(np.float64).copy()
+        m[:, 1:3] *= -1                                   # Metashape convention on disk; the loader flips it back
+        cams.append(f'<camera id="{k}" label="{k}"><transform>' + " ".join(repr(float(v)) for v in m.reshape(-1))
+                    + "</transform></camera>")
+    (tmp_path / "camera.xml").write_text(
+        f'<document><chunk><sensors><sensor id="0"><calibration><resolution width="{W}" height="{H}"/>'
+        f'<f>80.0</f></calibration></sensor></sensors><cameras>{"".join(cams)}</cameras></chunk></document>')
+    ck = tmp_path / "run" / "checkpoints"
+    ck.mkdir(parents=True)
+    state = synthetic.make_unet_state(UNET_SPEC, 21)
+    net = UNet()
+    net.load_state_dict({k: torch.from_numpy(np.asarray(v)) for k, v in state.items()})
+    tex = PointTexture(8, N, init_method='rand')
+    args = dict(input_format=FMT, descriptor_size=8, texture_activation='none', n_points=N, supersampling=1,
+                pipeline='READ.pipelines.ogl.TexturePipeline', inference=False, lr=1e-4, texture_lr=1e-1)
+    save_model(str(ck / "UNet_stage_0_epoch_1_net.pth"), net, args=args)
+    save_model(str(ck / "PointTexture_stage_0_epoch_1.pth"), tex, args=args)
+    (tmp_path / "scene.yaml").write_text(
+        f"viewport_size: [{W}, {H}]\nintrinsic_matrix: camera.xml\nview_matrix: camera.xml\npointcloud: pointcloud.ply\n"
+        f"net_path: {tmp_path / 'run'}\nckpt: UNet_stage_0_epoch_1_net.pth\ntexture_ckpt: PointTexture_stage_0_epoch_1.pth\n")
+
+    sd = scene_io.load_scene_data(str(tmp_path / "scene.yaml"))
+    assert sd["camera_labels"] == ["0", "1"] and np.allclose(sd["view_matrix"][1], poses[1], atol=1e-6)
+    scene = Scene()
+    scene_io.setup_scene(scene, sd)
+    K = sd["intrinsic_matrix"]
+    proj = camera.get_proj_matrix(K, sd["config"]["viewport_size"], 0.1, 1000.).astype(np.float32)
+    scene.set_proj_matrix(proj)
+    ogl = OGL(scene, sd, sd["config"]["viewport_size"], sd["net_ckpt"], sd["tex_ckpt"], out_buffer_location='torch')
+    for k in (1, 0):
+        scene.set_camera_view(sd["view_matrix"][k])
+        out = ogl.infer()["output"]
+        assert out.shape == (H, W, 4) and bool((out[..., 3] == 1).all())
+        M = camera.total_matrix(proj, np.asarray(sd["view_matrix"][k], np.float32))[0]
+        oi, _ = oracle.raster_multiscale(np.asarray(sd["pointcloud"]["xyz"], np.float32), M, W, H, 5)
+        with torch.no_grad():
+            ref = unet_torch.net_and_texture_forward(state, tex.texture_.detach().cpu().numpy(), oi)[0]
+        assert unet_torch.psnr(out[..., :3].permute(2, 0, 1).cpu(), ref) >= 80.0, f"camera {k}"
