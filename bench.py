@@ -2,18 +2,31 @@
 """Headline benchmark: rendered frames/s at 1216x352 on a synthetic 30 M-point cloud.
 
     python bench.py --gpus N --steps K --warmup W        (N>1: launched by torch.distributed.run)
+    python bench.py --config kitti6_like                 (second line: BASELINE configs[1] stand-in, see below)
 
 A "step" is one full frame of READ's render path on one GPU: rasterise 5 scales (one pass over the
-cloud) -> gather 8-channel descriptors -> 99-conv gated UNet -> RGBA frame.  Inputs (xyz,
-descriptors, packed weights) are resident in HBM before the timed region; each step uses the next
-camera pose of the novel-view sweep.  With N ranks every rank renders its own
-poses (weak scaling: K frames per GPU) and the finished frames are all-gathered over RCCL — the
-only exchange the path has (§8e).  Rank 0 prints ONE JSON line.
+cloud) -> gather 8-channel descriptors -> 99-conv gated UNet -> RGBA frame.  Inputs (xyz, descriptors,
+packed weights, cell-ordered cloud) are resident in HBM before the timed region; each step uses the next
+camera pose of the novel-view sweep.  With N ranks every rank renders its own poses (weak
+scaling: K frames per GPU); rank 0 builds the scene once and broadcasts it over RCCL, finished frames are
+exchanged over RCCL — the only exchange the path has (§8e; read_amd/sweep.py is the one implementation of
+that loop).  Rank 0 prints ONE JSON line.
+
+After the timed loop rank 0 re-renders pose 0 through the SAME warm renderer and compares it with the CPU
+oracle's frame (which the cpu_baseline leg computes anyway): raster index/depth bit-exact on all five levels,
+RGB PSNR / max|diff| — "verified" in the JSON line; a mismatch exits non-zero.
+
+--config kitti6_like: a seeded 10 M-point surface-like street scene (read_amd/synthetic.make_street_cloud; the
+real kitti6 scan is a download) at the kitti6 viewport 1216x368 (downloads/kitti6.yaml:1), written to disk as a
+scene directory (scene.yaml + PLY + Metashape camera.xml + reference-format checkpoints) and rendered through
+load_scene_data -> setup_scene -> OGL.infer(), i.e. the reference's viewer API.
 """
 import argparse
 import json
 import os
+import shutil
 import sys
+import tempfile
 import time
 
 import numpy as np
@@ -23,23 +36,28 @@ import torch.distributed as dist
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-from read_amd import camera, synthetic          # noqa: E402
-from read_amd.frame import FrameRenderer        # noqa: E402
-from read_amd.unet import weight_spec           # noqa: E402
+from read_amd import _lib, camera, synthetic, sweep          # noqa: E402
+from read_amd.frame import FrameRenderer                      # noqa: E402
+from read_amd.texture import gather_pyramid                   # noqa: E402
+from read_amd.unet import pack_state, weight_spec             # noqa: E402
 
-W, H = 1216, 352
 HBM_PEAK_GBS = 8000.0            # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 FP32_MFMA_PEAK_TFS = 157.3       # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 peak
+N_POSES = 256
+PSNR_FLOOR_DB = 120.0            # same guard as tests/test_gpu_unet.py (measured ~148 dB)
 
 
 def parse():
     p = argparse.ArgumentParser()
     p.add_argument("--gpus", type=int, default=1)
-    p.add_argument("--steps", type=int, default=20)
+    p.add_argument("--steps", type=int, default=256, help="timed frames per GPU (default: one full 256-pose sweep)")
     p.add_argument("--warmup", type=int, default=3)
-    p.add_argument("--points", type=int, default=30_000_000)
-    p.add_argument("--no-cpu-baseline", action="store_true")
-    p.add_argument("--cpu-frames", type=int, default=1)
+    p.add_argument("--config", choices=("slab30m", "kitti6_like"), default="slab30m")
+    p.add_argument("--points", type=int, default=0, help="override the cloud size of the config")
+    p.add_argument("--exchange", choices=("all", "root", "none"), default="all",
+                   help="N>1: all-gather finished frames to every rank / gather to rank 0 / keep them local")
+    p.add_argument("--no-cpu-baseline", action="store_true", help="skip the CPU leg (then nothing is verified)")
+    p.add_argument("--cpu-frames", type=int, default=3, help="timed CPU frames after one warm-up frame")
     p.add_argument("--detail", type=str, default="", help="write per-launch timings to this JSON file")
     p.add_argument("--tune", type=str, default="", help="comma list of key=value for read_tuning_set (A/B runs)")
     return p.parse_args()
@@ -57,49 +75,253 @@ def hip_time_ms(fn, iters):
 
 
 def profiled_traffic():
-    """HBM bytes per launch of the dominant kernel family from the committed rocprofv3 PMC passes
-    (profiles/r1_traffic.json: separate FETCH_SIZE / WRITE_SIZE runs of this same command, FETCH_SIZE x2 as
-    MI355X_MICROARCH.md prescribes for gfx950, factor re-derived there from a kernel of known byte count).
-    Launch-weighted mean over every launch of the 3x3/s1 kernels (the 73 C->C launches of a frame plus the
-    three small SCM 3x3 layers and the 32->3 output layer, which share the kernel name)."""
-    path = os.path.join(ROOT, "profiles", "r1_traffic.json")
-    try:
-        ks = json.load(open(path))["kernels"]
-    except (OSError, ValueError, KeyError):
-        return None
-    n = tot = 0
-    for name, v in ks.items():
-        if name.startswith("gated_conv_wino_kernel") or (name.startswith("gated_conv") and "<3, 1, 16" in name):
-            n += v["launches"]
-            tot += (v["read_bytes"] + v["write_bytes"]) * v["launches"]
-    return tot / n if n else None
+    """HBM bytes per launch of the dominant kernel family from the committed rocprofv3 PMC passes (separate FETCH_SIZE /
+    WRITE_SIZE runs of this same command, FETCH_SIZE x2 as MI355X_MICROARCH.md prescribes for gfx950, factor re-derived
+    there from a kernel of known byte count).  Launch-weighted mean over every launch of the 3x3/s1 kernels."""
+    for name in ("r2_traffic.json", "r1_traffic.json"):
+        path = os.path.join(ROOT, "profiles", name)
+        try:
+            ks = json.load(open(path))["kernels"]
+        except (OSError, ValueError, KeyError):
+            continue
+        n = tot = 0
+        for kname, v in ks.items():
+            if kname.startswith("gated_conv_wino_kernel") or (kname.startswith("gated_conv") and "<3, 1, 16" in kname):
+                n += v["launches"]
+                tot += (v["read_bytes"] + v["write_bytes"]) * v["launches"]
+        if n:
+            return tot / n, name
+    return None, None
 
 
-def cpu_baseline(xyz, desc, state, proj, frames):
-    """The oracle (CPU restatement of the reference path) on this box's host cores: bounded sample (one frame)."""
+# ---------------------------------------------------------------------------------------------------------------------
+# workloads
+# ---------------------------------------------------------------------------------------------------------------------
+class SlabWorkload:
+    """BASELINE configs[2]: synthetic KITTI-like slab, FrameRenderer (three C calls per frame)."""
+    name = "slab30m"
+    W, H = 1216, 352
+
+    def __init__(self, a, dev, rank):
+        self.N = a.points or 30_000_000
+        N = self.N
+        self.state = synthetic.make_unet_state(weight_spec())
+        self.xyz = self.desc = None
+
+        def make():
+            # rank 0 builds the scene; every tensor the renderer needs travels over the device collective
+            from read_amd.raster import build_cells
+            self.xyz = synthetic.make_cloud(N)
+            self.desc = synthetic.make_descriptors(N)
+            return [torch.from_numpy(self.xyz), torch.from_numpy(self.desc), torch.from_numpy(pack_state(self.state)),
+                    torch.from_numpy(build_cells(self.xyz))]
+        xyz_d, desc_d, packed_d, cells_d = sweep.broadcast_scene_from_rank0(make, dev)
+        self.proj = synthetic.make_proj(self.W, self.H)
+        self.fr = FrameRenderer(xyz_d, desc_d, packed_d, self.W, self.H, proj_matrix=self.proj, device=dev, cells=cells_d)
+        del desc_d
+        self.total = [camera.total_matrix(self.proj, synthetic.sweep_pose(k)) for k in range(N_POSES)]
+        self.describe = (f"BASELINE configs[2]: synthetic {N}-point KITTI-like slab, 1216x352, 8-dim descriptors, "
+                         "256-pose sweep, 5-scale raster + gather + 99-conv gated UNet (seeded random weights), RGBA out")
+
+    def render_into(self, k, out):
+        self.fr.render_total(self.total[k], out=out)
+
+    def rasterize(self, k):
+        self.fr.rasterize(self.total[k])
+        return self.fr.idx, self.fr.depth
+
+    def gather(self):
+        return self.fr.gather()
+
+    def refine(self):
+        return self.fr.refine()
+
+    def profile(self):
+        f = self.fr.feat
+        return self.fr.unet.profile(f[0][0], f[1][0], f[2][0], f[3][0], channels=4)
+
+    def oracle_inputs(self):
+        return self.xyz, self.desc, self.state
+
+
+class Kitti6LikeWorkload:
+    """BASELINE configs[1] stand-in: scene directory -> load_scene_data -> setup_scene -> OGL.infer()."""
+    name = "kitti6_like"
+    W, H = 1216, 368
+
+    def __init__(self, a, dev, rank):
+        from read_amd import scene_io
+        from read_amd.ogl import OGL
+        from read_amd.pipeline import save_model
+        from read_amd.render import Scene
+        from read_amd.texture import PointTexture
+        from read_amd.unet import UNet
+        self.N = a.points or 10_000_000
+        N, W, H = self.N, self.W, self.H
+        fmt = "uv_1d_p1, uv_1d_p1_ds1, uv_1d_p1_ds2, uv_1d_p1_ds3, uv_1d_p1_ds4"
+        holder = [None]
+        if rank == 0:
+            d = tempfile.mkdtemp(prefix="read_kitti6_like_")
+            xyz = synthetic.make_street_cloud(N)
+            scene_io.write_ply(os.path.join(d, "pointcloud.ply"), xyz)
+            cams = []
+            for k in range(N_POSES):
+                m = synthetic.sweep_pose(k).astype(np.float64).copy()
+                m[:, 1:3] *= -1                           # Metashape convention on disk (READ/gl/utils.py:205)
+                cams.append(f'<camera id="{k}" label="{k}"><transform>' + " ".join(repr(float(v)) for v in m.reshape(-1))
+                            + "</transform></camera>")
+            with open(os.path.join(d, "camera.xml"), "w") as fh:
+                fh.write(f'<document><chunk><sensors><sensor id="0"><calibration><resolution width="{W}" height="{H}"/>'
+                         f'<f>720.0</f></calibration></sensor></sensors><cameras>{"".join(cams)}</cameras></chunk></document>')
+            ck = os.path.join(d, "run", "checkpoints")
+            os.makedirs(ck)
+            state = synthetic.make_unet_state(weight_spec())
+            net = UNet()
+            net.load_state_dict({k: torch.from_numpy(np.asarray(v)) for k, v in state.items()})
+            tex = PointTexture(8, N, init_method='zeros')
+            with torch.no_grad():
+                tex.texture_.copy_(torch.from_numpy(synthetic.make_descriptors(N))[None])
+            args = dict(input_format=fmt, descriptor_size=8, texture_activation='none', n_points=N, supersampling=1,
+                        pipeline='READ.pipelines.ogl.TexturePipeline', inference=False, lr=1e-4, texture_lr=1e-1)
+            save_model(os.path.join(ck, "UNet_stage_0_epoch_1_net.pth"), net, args=args)
+            save_model(os.path.join(ck, "PointTexture_stage_0_epoch_1.pth"), tex, args=args)
+            with open(os.path.join(d, "scene.yaml"), "w") as fh:
+                fh.write(f"viewport_size: [{W}, {H}]\nintrinsic_matrix: camera.xml\nview_matrix: camera.xml\n"
+                         f"pointcloud: pointcloud.ply\nnet_path: {os.path.join(d, 'run')}\n"
+                         "ckpt: UNet_stage_0_epoch_1_net.pth\ntexture_ckpt: PointTexture_stage_0_epoch_1.pth\n")
+            holder[0] = d
+        if dist.is_initialized():
+            dist.broadcast_object_list(holder, src=0)          # one node: every rank reads the same directory
+        self.dir = holder[0]
+        sd = scene_io.load_scene_data(os.path.join(self.dir, "scene.yaml"))
+        self.scene = Scene()
+        scene_io.setup_scene(self.scene, sd)
+        self.proj = camera.get_proj_matrix(sd["intrinsic_matrix"], sd["config"]["viewport_size"], 0.1, 1000.).astype(np.float32)
+        self.scene.set_proj_matrix(self.proj)
+        self.ogl = OGL(self.scene, sd, sd["config"]["viewport_size"], sd["net_ckpt"], sd["tex_ckpt"], out_buffer_location='torch')
+        self.views = [np.asarray(v, np.float32) for v in sd["view_matrix"]]
+        self.xyz = np.asarray(sd["pointcloud"]["xyz"], np.float32)
+        self.texture = self.ogl.model._modules['0']
+        self.net = self.ogl.model.net
+        self.levels = 5
+        self.idx = self.depth = self.feat = None
+        if dist.is_initialized():
+            dist.barrier()
+        if rank == 0:
+            self._cleanup = self.dir
+        self.describe = (f"BASELINE configs[1] stand-in: seeded {N}-point surface-like street scene (road, facades, vehicles, "
+                         "foliage), kitti6 viewport 1216x368, scene.yaml -> load_scene_data -> OGL.infer(), 256-pose sweep")
+
+    def close(self):
+        if getattr(self, "_cleanup", None):
+            shutil.rmtree(self._cleanup, ignore_errors=True)
+
+    def render_into(self, k, out):
+        self.scene.set_camera_view(self.views[k])
+        out.copy_(self.ogl.infer()["output"])
+
+    def rasterize(self, k):
+        self.scene.set_camera_view(self.views[k])
+        self.idx, self.depth = self.scene.rasterizer().render(self.scene.total_matrix(), self.W, self.H, self.levels)
+        return self.idx, self.depth
+
+    def gather(self):
+        self.feat = gather_pyramid(self.texture.rows(), self.idx, self.texture.activation)
+        return self.feat
+
+    def refine(self):
+        f = self.feat
+        return self.net.engine(self.H, self.W).forward(f[0][0], f[1][0], f[2][0], f[3][0], channels=4)
+
+    def profile(self):
+        f = self.feat
+        return self.net.engine(self.H, self.W).profile(f[0][0], f[1][0], f[2][0], f[3][0], channels=4)
+
+    def oracle_inputs(self):
+        state = {k: v.detach().cpu().numpy() for k, v in self.net.state_dict().items()}
+        return self.xyz, self.texture.texture_.detach().cpu().numpy()[0], state
+
+    @property
+    def total(self):
+        class _T:
+            def __getitem__(_, k):
+                self.scene.set_camera_view(self.views[k])
+                return self.scene.total_matrix()
+        return _T()
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# CPU leg: the oracle on this box's host cores (bounded sample) + the frame the GPU result is verified against
+# ---------------------------------------------------------------------------------------------------------------------
+def cpu_leg(wl, frames):
     import oracle
     from oracle import unet_torch
-    # 32 threads: on the 256-thread GPU hosts torch's CPU convolutions are ~30x SLOWER with all threads than with 32
-    # (the UNet is ~600 small ops; measured 148 s/frame at 256 threads), so the fair baseline caps the thread count.
-    cores = min(os.cpu_count() or 1, 32)
+    xyz, desc, state = wl.oracle_inputs()
+    W, H = wl.W, wl.H
+    ncpu = os.cpu_count() or 1
+    # thread count: torch's CPU convolutions get SLOWER with too many threads on the 256-thread GPU hosts (the UNet is
+    # ~600 small ops), so probe {32, 64, all} on a small frame and run the sample with the best
+    cands = sorted({min(32, ncpu), min(64, ncpu), ncpu})
+    xs = [torch.rand(1, 8, 128 >> l, 128 >> l) for l in range(4)]
+    probe = {}
+    with torch.no_grad():
+        torch.set_num_threads(cands[0])
+        unet_torch.unet_forward(state, *xs)
+        for t in cands:
+            torch.set_num_threads(t)
+            t0 = time.perf_counter()
+            unet_torch.unet_forward(state, *xs)
+            probe[t] = time.perf_counter() - t0
+    cores = min(probe, key=probe.get)
     torch.set_num_threads(cores)
+    r_threads = min(ncpu, 64)
     t_r = t_g = t_u = 0.0
-    for k in range(frames):
-        M = camera.total_matrix(proj, synthetic.sweep_pose(k))[0]
+    first = None
+    for k in range(frames + 1):                              # frame 0 = warm-up (and the verification frame)
+        M = np.asarray(wl.total[k], np.float32).reshape(-1, 4, 4)[0]
         t0 = time.perf_counter()
-        idx, _ = oracle.raster_multiscale(xyz, M, W, H, 5, threads=cores)
+        idx, dep = oracle.raster_multiscale(xyz, M, W, H, 5, threads=r_threads)
         t1 = time.perf_counter()
         with torch.no_grad():
             feats = [unet_torch.point_texture_forward(desc[None], i[None]) for i in idx]
             t2 = time.perf_counter()
-            unet_torch.unet_forward(state, *feats[:4])
+            rgb = unet_torch.unet_forward(state, *feats[:4])
         t3 = time.perf_counter()
-        t_r, t_g, t_u = t_r + (t1 - t0), t_g + (t2 - t1), t_u + (t3 - t2)
-    per = (t_r + t_g + t_u) / frames
-    return {"value": 1.0 / per, "unit": "frames/s", "cores": cores, "kind": "port",
-            "sample": f"{frames} full frame(s) (1216x352, {xyz.shape[0]} pts) on {cores} threads of {os.cpu_count()}: oracle "
-                      f"raster C/OpenMP + torch-CPU gather + torch-CPU fp32 UNet",
-            "ms_raster": 1e3 * t_r / frames, "ms_gather": 1e3 * t_g / frames, "ms_unet": 1e3 * t_u / frames}
+        if k == 0:
+            first = (idx, dep, rgb[0])
+        else:
+            t_r, t_g, t_u = t_r + (t1 - t0), t_g + (t2 - t1), t_u + (t3 - t2)
+    per = (t_r + t_g + t_u) / max(frames, 1)
+    base = {"value": 1.0 / per, "unit": "frames/s", "cores": cores, "kind": "port",
+            "sample": f"1 warm-up + {frames} timed full frames ({W}x{H}, {xyz.shape[0]} pts, sweep poses 1..{frames}): oracle "
+                      f"raster C/OpenMP on {r_threads} threads + torch-CPU gather + torch-CPU fp32 UNet on {cores} threads "
+                      f"(best of the probed thread counts) of {ncpu}",
+            "thread_probe_s_128x128": {str(k): v for k, v in probe.items()},
+            "ms_raster": 1e3 * t_r / max(frames, 1), "ms_gather": 1e3 * t_g / max(frames, 1),
+            "ms_unet": 1e3 * t_u / max(frames, 1)}
+    return base, first
+
+
+def verify(wl, first):
+    """Pose 0 through the warm renderer against the oracle's pose-0 frame."""
+    from oracle import unet_torch
+    idx_o, dep_o, rgb_o = first
+    idx, depth = wl.rasterize(0)
+    wl.gather()
+    rgba = wl.refine()
+    torch.cuda.synchronize()
+    exact = True
+    for l in range(5):
+        exact &= bool(np.array_equal(idx[l][0].cpu().numpy(), idx_o[l]))
+        exact &= bool(np.array_equal(depth[l][0].cpu().numpy().view(np.uint32), dep_o[l].view(np.uint32)))
+    got = rgba[:, :, :3].permute(2, 0, 1).cpu()
+    diff = (got.double() - rgb_o.double())
+    out = {"pose": 0, "raster_bit_exact": exact, "psnr_db": unet_torch.psnr(got, rgb_o),
+           "max_abs_diff": float(diff.abs().max()),
+           "rel_rms": float(diff.pow(2).mean().sqrt() / rgb_o.double().std()),
+           "alpha_is_one": bool((rgba[:, :, 3] == 1).all())}
+    out["ok"] = bool(exact and out["psnr_db"] >= PSNR_FLOOR_DB and out["alpha_is_one"])
+    return out
 
 
 def main():
@@ -111,7 +333,6 @@ def main():
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     if a.tune:
-        from read_amd import _lib
         for kv in a.tune.split(","):
             k, v = kv.split("=")
             _lib.check(_lib.lib().read_tuning_set(k.encode(), int(v)), "read_tuning_set")
@@ -119,55 +340,18 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", device_id=dev)
 
-    # ---- scene: identical on every rank.  Rank 0 builds it; the others receive it over RCCL/xGMI
-    # (one-time broadcast of xyz + descriptors + packed weights, §8e).
-    N = a.points
-    state = synthetic.make_unet_state(weight_spec())
-    if rank == 0:
-        xyz = synthetic.make_cloud(N)
-        desc = synthetic.make_descriptors(N)
-        xyz_d, desc_d = torch.from_numpy(xyz).to(dev), torch.from_numpy(desc).to(dev)
-    else:
-        xyz = desc = None
-        xyz_d = torch.empty((N, 3), dtype=torch.float32, device=dev)
-        desc_d = torch.empty((8, N), dtype=torch.float32, device=dev)
-    if world > 1:
-        dist.broadcast(xyz_d, 0)
-        dist.broadcast(desc_d, 0)
-    proj = synthetic.make_proj(W, H)
-    fr = FrameRenderer(xyz_d, desc_d, state, W, H, proj_matrix=proj, device=dev)
-    del desc_d
-    poses = [camera.total_matrix(proj, synthetic.sweep_pose(k)) for k in range(256)]
+    wl = (SlabWorkload if a.config == "slab30m" else Kitti6LikeWorkload)(a, dev, rank)
+    W, H, N = wl.W, wl.H, wl.N
+    ex = sweep.FrameExchange((H, W, 4), dev, torch.float32, None if a.exchange == "none" else a.exchange)
 
-    # double-buffered frames: the all-gather of frame i overlaps the rendering of frame i+1
-    frames = [fr.rgba, torch.empty_like(fr.rgba)]
-    gathered = [torch.empty((world, H, W, 4), dtype=torch.float32, device=dev) for _ in range(2)] if world > 1 else None
-    pending = [None, None]
-
-    def step(i):
-        j = i & 1
-        if pending[j] is not None:
-            pending[j].wait()                      # frames[j] / gathered[j] are free again
-            pending[j] = None
-        fr.render_total(poses[(i * world + rank) % 256], out=frames[j])
-        if world > 1:
-            pending[j] = dist.all_gather_into_tensor(gathered[j], frames[j][None], async_op=True)
-
-    for i in range(a.warmup):
-        step(i)
-    for p in pending:
-        if p is not None:
-            p.wait()
-    pending[:] = [None, None]
+    sweep.run_steps(wl.render_into, ex, 0, a.warmup, N_POSES)
+    ex.drain()
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    for i in range(a.steps):
-        step(a.warmup + i)
-    for p in pending:
-        if p is not None:
-            p.wait()
+    sweep.run_steps(wl.render_into, ex, a.warmup, a.steps, N_POSES)
+    ex.drain()
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
@@ -179,72 +363,88 @@ def main():
         dt = float(t.item())
 
     # ---- per-kernel durations, live, with HIP events on the launch stream (rank 0)
-    out = None
+    rc = 0
     if rank == 0:
         # the rasteriser warm-starts from the previous frame, so it is timed over consecutive poses of the sweep
         # (as in the timed loop), not over one repeated pose
         it = iter(range(1, 10 ** 6))
-        fr.rasterize(poses[0])
-        ms_splat = hip_time_ms(lambda: fr.rasterize(poses[next(it) % 256]), 16)
-        ms_gather = hip_time_ms(lambda: fr.gather(), 10)
-        ms_unet = hip_time_ms(lambda: fr.refine(), 5)
-        f = fr.feat
+        wl.rasterize(0)
+        ms_splat = hip_time_ms(lambda: wl.rasterize(next(it) % N_POSES), 32)
+        ms_gather = hip_time_ms(lambda: wl.gather(), 10)
+        ms_unet = hip_time_ms(lambda: wl.refine(), 5)
         prof = None
         for _ in range(3):
-            cur = fr.unet.profile(f[0][0], f[1][0], f[2][0], f[3][0], channels=4)
+            cur = wl.profile()
             prof = cur if prof is None else [(l, m0 + m1, fl, c) for (l, m0, fl, c), (_, m1, _, _) in zip(prof, cur)]
         prof = [(l, m / 3.0, fl, c) for (l, m, fl, c) in prof]
         c3_ms = sum(m for (_, m, _, c) in prof if c)
         c3_fl = sum(fl for (_, _, fl, c) in prof if c)
         n_c3 = sum(1 for (_, _, _, c) in prof if c)
         all_fl = sum(fl for (_, _, fl, _) in prof)
-        achieved_tfs = c3_fl / (c3_ms * 1e-3) / 1e12
+        algorithmic_tfs = c3_fl / (c3_ms * 1e-3) / 1e12
         # launches that ran the Winograd F(2x2,3x3) kernel execute 2.25x fewer MFMA flops than the algorithmic count
         wino_fl = sum(fl for (_, _, fl, c) in prof if c == 2)
         n_wino = sum(1 for (_, _, _, c) in prof if c == 2)
-        executed_tfs = (c3_fl - wino_fl + wino_fl / 2.25) / (c3_ms * 1e-3) / 1e12
+        c3_exec = c3_fl - wino_fl + wino_fl / 2.25
+        executed_tfs = c3_exec / (c3_ms * 1e-3) / 1e12
         all_exec = all_fl - wino_fl + wino_fl / 2.25
-        splat_bytes = 12.0 * N + 8.0 * sum(w * h for (w, h) in camera.level_sizes(W, H, 5))
-        gather_bytes = 68.0 * sum(w * h for (w, h) in camera.level_sizes(W, H, 5))
+        sizes = camera.level_sizes(W, H, 5)
+        splat_bytes = 12.0 * N + 8.0 * sum(w * h for (w, h) in sizes)
+        gather_bytes = 68.0 * sum(w * h for (w, h) in sizes)
+        traffic, traffic_src = profiled_traffic() if a.config == "slab30m" else (None, None)
         out = {
-            "metric": "rendered frames/sec @1216x352, 30M pts", "value": world * a.steps / dt, "unit": "frames/s",
+            "metric": "rendered frames/sec @1216x352, 30M pts" if a.config == "slab30m"
+                      else "rendered frames/sec @1216x368, kitti6-like 10M pts",
+            "value": world * a.steps / dt, "unit": "frames/s",
             "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": 1e3 * dt / a.steps,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": f"BASELINE configs[2]: synthetic {N}-point KITTI-like slab, 1216x352, 8-dim "
-                                   "descriptors, 256-pose sweep, 5-scale raster + gather + 99-conv gated UNet "
-                                   "(seeded random weights), RGBA out",
-                       "points": N, "width": W, "height": H, "parallelism": f"pose-sharded x{world}"},
+            "config": {"workload": wl.describe, "points": N, "width": W, "height": H,
+                       "parallelism": f"pose-sharded x{world}", "frame_exchange": ex.mode or "none"},
             "roofline": {
                 "kernel": ("gated_conv_wino_kernel: 3x3/s1 C->C gated conv, Winograd F(2x2,3x3) on v_mfma_f32_32x32x2_f32"
                            if n_wino else "gated_conv_kernel 3x3/s1 C->C (v_mfma_f32_32x32x2_f32)"), "bound": "mfma",
-                "achieved": achieved_tfs, "peak": FP32_MFMA_PEAK_TFS, "unit": "TFLOP/s",
-                "frac": achieved_tfs / FP32_MFMA_PEAK_TFS, "traffic": profiled_traffic(),
-                "traffic_unit": "HBM bytes per launch (rocprofv3 FETCH_SIZE*2 + WRITE_SIZE, profiles/r1_traffic.json)",
+                "achieved": executed_tfs, "peak": FP32_MFMA_PEAK_TFS, "unit": "TFLOP/s",
+                "frac": executed_tfs / FP32_MFMA_PEAK_TFS, "traffic": traffic,
+                "traffic_unit": f"HBM bytes per launch (rocprofv3 FETCH_SIZE*2 + WRITE_SIZE, profiles/{traffic_src})",
                 "launches_per_frame": n_c3, "avg_launch_ms": c3_ms / max(n_c3, 1),
-                "flops_per_frame": c3_fl, "winograd_launches": n_wino,
-                "executed_mfma_TFLOPs": executed_tfs, "mfma_pipe_util": executed_tfs / FP32_MFMA_PEAK_TFS,
-                "note": "achieved = algorithmic direct-convolution flops / time (SURVEY 8d); the Winograd launches "
-                        "execute 1/2.25 of them on the MFMA pipe (mfma_pipe_util), so frac can exceed 1"},
+                "executed_flops_per_frame": c3_exec, "algorithmic_flops_per_frame": c3_fl,
+                "algorithmic_TFLOPs": algorithmic_tfs, "winograd_launches": n_wino,
+                "winograd_gain": c3_fl / c3_exec,
+                "note": "achieved = MFMA flops the launches EXECUTE / time (a Winograd launch executes 1/2.25 of the "
+                        "direct-convolution count); algorithmic_TFLOPs = SURVEY 8d's direct-convolution flops / time"},
             "stages": {
                 "splat_ms": ms_splat, "splat_GBps": splat_bytes / (ms_splat * 1e-3) / 1e9,
                 "splat_frac_hbm": splat_bytes / (ms_splat * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                "splat_algorithmic_bytes": splat_bytes,
                 "gather_ms": ms_gather, "gather_GBps": gather_bytes / (ms_gather * 1e-3) / 1e9,
-                "unet_ms": ms_unet, "unet_TFLOPs": all_fl / (ms_unet * 1e-3) / 1e12,
-                "unet_frac_mfma": all_fl / (ms_unet * 1e-3) / 1e12 / FP32_MFMA_PEAK_TFS,
-                "unet_executed_TFLOPs": all_exec / (ms_unet * 1e-3) / 1e12},
+                "unet_ms": ms_unet, "unet_executed_TFLOPs": all_exec / (ms_unet * 1e-3) / 1e12,
+                "unet_frac_mfma": all_exec / (ms_unet * 1e-3) / 1e12 / FP32_MFMA_PEAK_TFS,
+                "unet_algorithmic_TFLOPs": all_fl / (ms_unet * 1e-3) / 1e12},
+            "tuning": _lib.tuning_state(),
         }
         if a.detail:
             os.makedirs(os.path.dirname(os.path.abspath(a.detail)), exist_ok=True)
             with open(a.detail, "w") as fh:
                 json.dump([{"label": l, "ms": m, "gflop": fl / 1e9, "c3s1": c} for (l, m, fl, c) in prof], fh, indent=0)
-        if world == 1 and not a.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(xyz, desc, state, proj, a.cpu_frames)
-        else:
-            out["cpu_baseline"] = None
+        out["cpu_baseline"] = None
+        out["verified"] = None
+        if not a.no_cpu_baseline:
+            base, first = cpu_leg(wl, a.cpu_frames)
+            if world == 1:
+                out["cpu_baseline"] = base
+            out["verified"] = verify(wl, first)
+            if not out["verified"]["ok"]:
+                rc = 3
         print(json.dumps(out), flush=True)
+        if rc:
+            print("bench.py: the timed configuration does NOT reproduce the oracle frame: %r" % (out["verified"],),
+                  file=sys.stderr, flush=True)
+    if hasattr(wl, "close"):
+        wl.close()
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
+    sys.exit(rc)
 
 
 if __name__ == "__main__":

@@ -52,12 +52,23 @@ int read_abi_version(void);
 /* Fills name[0..len) with the gfx arch of the current device ("gfx950"); READ_EHIP without a GPU. */
 int read_device_arch(char *name, int len);
 
-/* Measurement knobs (A/B runs on the GPU box).  "splat_mode": 7 (default) warm start + LDS hierarchical-Z
- * in front of 1 = one key image with agent-scope atomics and L1-bypassing early-z reads; 0 per-XCD key
- * images, 3 system-scope early-z; 2/4/5/6 are attribution probes whose results are invalid (csrc/splat.hip).
- * "conv_wino" = largest Cin that takes the Winograd F(2x2,3x3) kernel (default: all eligible 3x3/s1 layers; 0 = direct
- * implicit-GEMM kernels everywhere), "conv_wave" 0/1, "conv_stagger" ticks, "conv_ablate" bits: see csrc/conv.hip. */
+/* Measurement knobs (A/B runs on the GPU box).  Every knob of the release library selects between implementations
+ * that produce the SAME results (the attribution probes with invalid results exist only in -DREAD_DEBUG_KNOBS builds):
+ *   "splat_mode"      plain path: 7 (default) warm start + LDS hierarchical-Z, 1 = agent-scope atomics + early-z only
+ *   "splat_cells"     0: ignore the cell-ordered copy (plain path everywhere)
+ *   "splat_seeds"     0: no warm start from the previous frame
+ *   "splat_near"      striped path: expected points per pixel in front of the pass-A split distance (default 12)
+ *   "splat_cells_sub" striped path: every n-th chunk joins pass A (default 32, 0 = none)
+ *   "splat_items"     striped path: work items per 1024-point chunk (1, 2, 4)
+ *   "splat_subset"    plain path: bootstrap pass over every n-th chunk (default 8)
+ *   "splat_stats"     debug counters in the workspace header
+ *   "conv_wino"       largest Cin that takes the Winograd F(2x2,3x3) kernel (0 = direct implicit-GEMM kernels everywhere)
+ *   "conv_wave", "conv_kc32", "conv_stagger", "unet_streams": see csrc/conv.hip, csrc/unet.cpp.
+ * read_tuning_key(i) enumerates the keys (NULL past the end); read_tuning_get reads the current value, so that a
+ * benchmark can record the state it ran with. */
 int read_tuning_set(const char *key, int value);
+int read_tuning_get(const char *key, int *value);
+const char *read_tuning_key(int i);
 /* Debug timeline of the following gated-conv launches: 64 bytes per workgroup (direct kernels: s_memrealtime at
  * entry / after prologue / after the k-loop / at exit, HW_ID, XCC_ID, blockIdx.x/y) or per wave (Winograd kernel:
  * entry, end of prologue, ticks spent in unit epilogues split three ways, exit, HW_ID) in `buf` (device);
@@ -70,10 +81,10 @@ int read_debug_mfma_probe(int blocks, int iters, int nacc, float *scratch, void 
 
 /* ---------------------------------------------------------------- rasteriser (z-buffer splat) */
 
-/* Bytes of the persistent rasteriser state for ONE (B, W, H): a 256-byte header, the key images
- * (min(B,8) cameras x 8 x W*H x 8 B, depth_bits<<32 | point_id), the hierarchical-Z bound image and the
- * previous frame's winners (warm start of the next frame).  A workspace serves the (B, W, H) it was sized
- * for; re-run read_splat_workspace_init before using it with another size. */
+/* Bytes of the persistent rasteriser state for ONE (B, W, H): a 4096-byte header, the key images
+ * (min(B,8) cameras x W*H x 8 B, depth_bits<<32 | point_id), the hierarchical-Z bound image, two seed images (the
+ * warm start of the next frame) and the depth-bound image of the striped path.  A workspace serves the (B, W, H) it
+ * was sized for; re-run read_splat_workspace_init before using it with another size.  256-byte aligned. */
 size_t read_splat_workspace_bytes(int B, int W, int H);
 /* Must be called once on a fresh workspace (sets every key to EMPTY).  read_splat_forward
  * leaves the workspace EMPTY again, so consecutive frames need no further clears. */
@@ -95,13 +106,14 @@ int read_splat_forward(const float *xyz, int64_t n, const float *M_host, int B, 
                        void *ws, size_t ws_bytes, void *stream);
 
 /* Cell-ordered copy of a cloud (optional accelerator of the single-camera path; results are bit-identical).
- * read_splat_cells_build_host() sorts the points once along a Morton curve into chunks of 1024 with their bounding
- * boxes (host arrays in, host blob of read_splat_cells_bytes(n) out); the caller uploads the blob (16-byte aligned)
- * and passes it to read_splat_forward_cells() together with the ORIGINAL xyz (still used for the warm start).
+ * read_splat_cells_build_host() sorts the points once along a Morton curve into chunks of 1024 records
+ * (x, y, z, original id) with their bounding boxes (host arrays in, host blob of read_splat_cells_bytes(n) out,
+ * multi-threaded); the caller uploads the blob (256-byte aligned) and passes it to read_splat_forward_cells().
  * Whole chunks outside the frustum, or behind the far depth bound of every 4x4 pixel block they can touch, are then
- * skipped without reading their points.  The tail of the blob is per-frame scratch (chunk lists), so one blob
- * serves one stream at a time.  With cells == NULL, B > 1, n < 2^20 or sizes that are not multiples of
- * 2^(levels-1) the call is exactly read_splat_forward(). */
+ * skipped without reading their points, and the z-test runs XCD-striped against an L2-resident bound image
+ * (csrc/splat.hip).  The tail of the blob is per-frame scratch (chunk lists), so one blob serves one stream at a
+ * time.  With cells == NULL, B > 1, n < 2^20, W % 16 != 0 or sizes that are not multiples of 2^(levels-1) the call is
+ * exactly read_splat_forward(). */
 size_t read_splat_cells_bytes(int64_t n);
 int read_splat_cells_build_host(const float *xyz_host, int64_t n, void *cells_host, size_t cells_bytes);
 int read_splat_forward_cells(const float *xyz, void *cells, int64_t n, const float *M_host, int B, int W, int H,

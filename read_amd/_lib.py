@@ -41,6 +41,8 @@ SIGNATURES = {
     "read_abi_version": (_i, []),
     "read_device_arch": (_i, [C.c_char_p, _i]),
     "read_tuning_set": (_i, [C.c_char_p, _i]),
+    "read_tuning_get": (_i, [C.c_char_p, C.POINTER(_i)]),
+    "read_tuning_key": (C.c_char_p, [_i]),
     "read_debug_set_trace": (_i, [_vp, _sz]),
     "read_debug_mfma_probe": (_i, [_i, _i, _i, _vp, _vp]),
     "read_splat_workspace_bytes": (_sz, [_i, _i, _i]),
@@ -107,6 +109,20 @@ def lib():
                 raise ReadHipError(f"READ_TUNE: {L.read_last_error().decode()}")
         _LIB = L
     return _LIB
+
+
+def tuning_state():
+    """{key: value} of every read_tuning_set knob of the loaded library (recorded by bench.py)."""
+    L = lib()
+    out, i = {}, 0
+    while True:
+        k = L.read_tuning_key(i)
+        if not k:
+            return out
+        v = C.c_int()
+        check(L.read_tuning_get(k, C.byref(v)), "read_tuning_get")
+        out[k.decode()] = v.value
+        i += 1
 
 
 def check(rc, what=""):

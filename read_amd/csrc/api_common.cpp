@@ -34,19 +34,21 @@ namespace readhip {
 int splat_set_mode(int m);
 void splat_set_subset(int v);
 void splat_set_stats(int v);
-void splat_set_pipe(int v);
+void splat_set_near(int v);
+void splat_set_cells(int v);
+void splat_set_seeds(int v);
+void splat_set_cells_sub(int v);
+void splat_set_items(int v);
+int splat_get(const char *key, int *value);
 void conv_set_trace(void *buf, size_t bytes);
 void conv_set_prefer_wave(int v);
 void conv_set_stagger(int ticks);
 void conv_set_ablate(int bits);
 void conv_set_wino(int max_cin);
 void conv_set_kc32(int v);
+int conv_get(const char *key, int *value);
 void unet_set_streams(int v);
-void splat_set_near(int v);
-void splat_set_cells(int v);
-void splat_set_seeds(int v);
-void splat_set_l1(int v);
-void splat_set_cells_sub(int v);
+int unet_get(const char *key, int *value);
 }
 
 // Debug: per-workgroup timeline of the next gated-conv launches.  buf = device memory, 64 bytes per
@@ -58,74 +60,56 @@ extern "C" int read_debug_set_trace(void *buf, size_t bytes)
     return READ_OK;
 }
 
-// Tuning knobs for A/B measurements on the GPU box (not needed in production):
-//   "splat_mode": 0 = per-XCD key images + L2-local atomics (default), 1 = one image + agent-scope
-//                 atomics, 2 = projection only (timing floor; results invalid), 3 = one image,
-//                 agent-scope atomics, system-scope (L2-bypassing) early-z reads.
+// Tuning knobs for A/B measurements on the GPU box (not needed in production).  Every knob of the release library
+// selects between implementations that produce the SAME results; the attribution probes whose results are invalid
+// ("conv_ablate") exist only in builds with -DREAD_DEBUG_KNOBS.
+static const char *const k_tuning_keys[] = {"splat_mode", "splat_stats", "splat_subset", "splat_near", "splat_cells",
+                                            "splat_cells_sub", "splat_seeds", "splat_items", "unet_streams", "conv_kc32",
+                                            "conv_wino", "conv_stagger", "conv_wave",
+#ifdef READ_DEBUG_KNOBS
+                                            "conv_ablate",
+#endif
+                                            nullptr};
+
 extern "C" int read_tuning_set(const char *key, int value)
 {
     READ_CHECK_ARG(key, "read_tuning_set: null key");
     if (!strcmp(key, "splat_mode")) {
         const int rc = readhip::splat_set_mode(value);
-        if (rc) readhip::set_error("read_tuning_set: splat_mode must be 0..7");
+        if (rc) readhip::set_error("read_tuning_set: splat_mode must be 1 (agent atomics) or 7 (warm start + hi-z)");
         return rc;
     }
-    if (!strcmp(key, "splat_pipe")) {
-        readhip::splat_set_pipe(value);
-        return READ_OK;
-    }
-    if (!strcmp(key, "splat_stats")) {
-        readhip::splat_set_stats(value);
-        return READ_OK;
-    }
-    if (!strcmp(key, "splat_subset")) {
-        readhip::splat_set_subset(value);
-        return READ_OK;
-    }
-    if (!strcmp(key, "splat_near")) {      // cell path: expected points per pixel in front of the pass-A split distance
-        readhip::splat_set_near(value);
-        return READ_OK;
-    }
-    if (!strcmp(key, "splat_l1")) {
-        readhip::splat_set_l1(value);
-        return READ_OK;
-    }
-    if (!strcmp(key, "splat_cells_sub")) {
-        readhip::splat_set_cells_sub(value);
-        return READ_OK;
-    }
-    if (!strcmp(key, "splat_seeds")) {     // 0: no warm start from the previous frame
-        readhip::splat_set_seeds(value);
-        return READ_OK;
-    }
-    if (!strcmp(key, "splat_cells")) {     // 0: ignore the cell-ordered copy
-        readhip::splat_set_cells(value);
-        return READ_OK;
-    }
-    if (!strcmp(key, "unet_streams")) {    // 0: the SCM chains stay on the caller's stream
-        readhip::unet_set_streams(value);
-        return READ_OK;
-    }
-    if (!strcmp(key, "conv_kc32")) {
-        readhip::conv_set_kc32(value);
-        return READ_OK;
-    }
-    if (!strcmp(key, "conv_wino")) {       // value = largest Cin that takes the Winograd kernel (0 = off)
-        readhip::conv_set_wino(value);
-        return READ_OK;
-    }
-    if (!strcmp(key, "conv_ablate")) {
-        readhip::conv_set_ablate(value);
-        return READ_OK;
-    }
-    if (!strcmp(key, "conv_stagger")) {
-        readhip::conv_set_stagger(value);
-        return READ_OK;
-    }
-    if (!strcmp(key, "conv_wave")) {
-        readhip::conv_set_prefer_wave(value != 0);
-        return READ_OK;
-    }
+    if (!strcmp(key, "splat_stats")) { readhip::splat_set_stats(value); return READ_OK; }
+    if (!strcmp(key, "splat_subset")) { readhip::splat_set_subset(value); return READ_OK; }
+    // cell path: expected points per pixel in front of the pass-A split distance
+    if (!strcmp(key, "splat_near")) { readhip::splat_set_near(value); return READ_OK; }
+    if (!strcmp(key, "splat_cells_sub")) { readhip::splat_set_cells_sub(value); return READ_OK; }
+    if (!strcmp(key, "splat_seeds")) { readhip::splat_set_seeds(value); return READ_OK; }     // 0: no warm start
+    if (!strcmp(key, "splat_cells")) { readhip::splat_set_cells(value); return READ_OK; }     // 0: ignore the cell-ordered copy
+    if (!strcmp(key, "splat_items")) { readhip::splat_set_items(value); return READ_OK; }     // work items per chunk: 1, 2, 4
+    if (!strcmp(key, "unet_streams")) { readhip::unet_set_streams(value); return READ_OK; }   // 0: SCM chains on the caller's stream
+    if (!strcmp(key, "conv_kc32")) { readhip::conv_set_kc32(value); return READ_OK; }
+    if (!strcmp(key, "conv_wino")) { readhip::conv_set_wino(value); return READ_OK; }         // largest Cin on the Winograd kernel (0 = off)
+    if (!strcmp(key, "conv_stagger")) { readhip::conv_set_stagger(value); return READ_OK; }
+    if (!strcmp(key, "conv_wave")) { readhip::conv_set_prefer_wave(value != 0); return READ_OK; }
+#ifdef READ_DEBUG_KNOBS
+    if (!strcmp(key, "conv_ablate")) { readhip::conv_set_ablate(value); return READ_OK; }
+#endif
     readhip::set_error("read_tuning_set: unknown key '%s'", key);
     return READ_EINVAL;
+}
+
+extern "C" int read_tuning_get(const char *key, int *value)
+{
+    READ_CHECK_ARG(key && value, "read_tuning_get: null pointer");
+    if (readhip::splat_get(key, value) || readhip::conv_get(key, value) || readhip::unet_get(key, value)) return READ_OK;
+    readhip::set_error("read_tuning_get: unknown key '%s'", key);
+    return READ_EINVAL;
+}
+
+extern "C" const char *read_tuning_key(int i)
+{
+    int n = 0;
+    while (k_tuning_keys[n]) ++n;
+    return (i >= 0 && i < n) ? k_tuning_keys[i] : nullptr;
 }

@@ -1061,8 +1061,8 @@ int find_config(int ks, int s, int kc, int P, int QG, int WM, int WN, int PF, in
 int g_prefer_wave = 1;   // read_tuning_set("conv_wave", 0): workgroup-tiled kernels only
 int g_kc32 = 1;            // 32-channel chunks for 1x1 layers whose sources are all multiples of 32 (read_tuning_set("conv_kc32", 0): 16)
 int g_use_wino = 1 << 30;  // read_tuning_set("conv_wino", max Cin): Winograd kernel for eligible 3x3 layers (0 = off)
-int g_stagger_ticks = 0;
-int g_ablate = 0;          // read_tuning_set("conv_ablate", bits)   // read_tuning_set("conv_stagger", ticks of 10 ns)   // read_tuning_set("conv_wave", 1): wave-autonomous kernels where they exist
+int g_stagger_ticks = 0;   // read_tuning_set("conv_stagger", ticks of 10 ns)
+int g_ablate = 0;          // read_tuning_set("conv_ablate", bits): attribution probe, results invalid; -DREAD_DEBUG_KNOBS builds only
 
 int find_wave_config(int ks, int s, int kc, int P, int QG)
 {
@@ -1253,6 +1253,18 @@ void conv_set_stagger(int ticks) { g_stagger_ticks = ticks < 0 ? 0 : ticks; }
 void conv_set_ablate(int bits) { g_ablate = bits; }
 void conv_set_wino(int max_cin) { g_use_wino = max_cin; }
 void conv_set_kc32(int v) { g_kc32 = v; }
+int conv_get(const char *key, int *value)
+{
+    if (!strcmp(key, "conv_wave")) *value = g_prefer_wave;
+    else if (!strcmp(key, "conv_stagger")) *value = g_stagger_ticks;
+    else if (!strcmp(key, "conv_kc32")) *value = g_kc32;
+    else if (!strcmp(key, "conv_wino")) *value = g_use_wino;
+#ifdef READ_DEBUG_KNOBS
+    else if (!strcmp(key, "conv_ablate")) *value = g_ablate;
+#endif
+    else return 0;
+    return 1;
+}
 
 static unsigned long long *g_trace = nullptr;
 static size_t g_trace_records = 0;

@@ -1,20 +1,38 @@
 // Z-buffered point splat for gfx950.
 //
 // Replaces the reference's per-scale, per-camera DepthProject launches
-// (MyRender/CloudProjection/point_render.cu:125-200; GL twin READ/gl/render.py:52-85) with
-//   1. splat_project : ONE pass over the cloud for all B cameras.  Each accepted point becomes a
-//      packed 64-bit key (fp32 depth bits << 32 | point id) and is folded into a level-0 key
-//      image with an unsigned 64-bit atomic min — min depth, ties -> min id, order independent
-//      (SURVEY.md App. A.3).  A relaxed L1-bypassing read of the current key filters out the
-//      points that cannot win before they cost an atomic (keys only ever decrease, so a stale
-//      read is merely conservative).  Each XCD folds into its own image with L2-local atomics.
-//   2. splat_resolve : one small pass over the key images that takes the min over the XCDs, derives
-//      levels 1..4 by 2x2 key-min (exactly the reference's five rasterisations, App. A.4), unpacks
-//      (id, depth) for every level and resets the key images to EMPTY for the next frame.
+// (MyRender/CloudProjection/point_render.cu:125-200; GL twin READ/gl/render.py:52-85).  Every accepted point becomes
+// a packed 64-bit key (fp32 depth bits << 32 | point id) folded into a level-0 key image with an unsigned 64-bit
+// atomic min — min depth, ties -> min id, order independent.  One resolve pass derives levels
+// 1..4 by 2x2 key-min (exactly the reference's five rasterisations, App. A.4), unpacks (id, depth) and leaves the key
+// image EMPTY for the next frame.
+//
+// Two paths produce the key image (bit-identical results):
+//   * plain path (any B, any size, small clouds): one pass over the cloud for up to 8 cameras, agent-scope atomics;
+//     for one camera with a warm start from the previous frame's winners and an LDS-resident hierarchical-Z.
+//   * cell-ordered, XCD-striped path (the per-frame render path: one camera, >= 2^20 points, W % 16 == 0):
+//     the cloud is kept Morton-sorted in chunks of 1024 points with bounding boxes, so whole chunks outside the
+//     frustum or behind the far bound of every 4x4 pixel block they can touch are never read.  The early-z test does
+//     not read the key image at all: atomics on gfx950 execute memory-side and DROP the line from the issuing XCD's
+//     L2, so in round 1 every early-z read after an atomic re-fetched 128 bytes for 8 (2.7x the algorithmic HBM
+//     traffic, profiles/r1_hbm_traffic_per_kernel.md).  Instead a 4-byte-per-pixel image of depth UPPER BOUNDS
+//     ("zimg") is kept with plain loads and stores: whoever issues an atomic for depth d also stores d.  Stores race,
+//     but every value ever stored is the depth of a real point of the cloud at that pixel, hence >= the final depth
+//     — a stale or lost update only lets a few more points through to the (exact) atomic.  The warm start needs no
+//     atomics either: last frame's front points are re-projected and only their depths are stored as bounds; the
+//     points themselves come by in the passes and pass the test (ties pass).  The SCREEN is cut into 8 column strips,
+//     one per XCD, and a workgroup prefers the work of the strip its XCD owns, so that readers and writers of a zimg
+//     line share an L2 (the per-XCD L2s are not coherent inside a launch); this is an optimisation only — any
+//     workgroup may process any strip's work, and does once its own list is empty.
 //
 // HBM-bound: algorithmic bytes per frame = 12*N (xyz read once) + 8*sum_l(h_l*w_l) (id + depth).
-// The arithmetic that decides which PIXEL a point lands in is bit-exact fp32: no FMA
-// contraction, IEEE division, left-to-right dot products (helper_math.h:1252-1255).
+// The arithmetic that decides which PIXEL a point lands in is bit-exact fp32: no FMA contraction, IEEE division,
+// left-to-right dot products (helper_math.h:1252-1255).
+#include <algorithm>
+#include <atomic>
+#include <thread>
+#include <vector>
+
 #include "common.h"
 
 #pragma clang fp contract(off)
@@ -26,12 +44,14 @@ namespace {
 constexpr unsigned long long EMPTY_KEY = ~0ull;
 constexpr int MAX_CAMS = 8;          // cameras folded into one pass over the points
 constexpr int PTS_PER_THREAD = 4;    // 3 x float4 = 4 points
+constexpr int MAX_STRIPS = 8;        // one per XCD
 
 struct CamSet {
     float m[MAX_CAMS][16];
 };
-
-typedef unsigned long long __attribute__((address_space(1))) *gkey_ptr;
+struct Cam1 {
+    float m[16];
+};
 
 // point_render.cu:135-147 for one point and one camera; returns the pixel or -1.
 __device__ __forceinline__ int project_one(float x, float y, float z, const float *M, int W, int H,
@@ -55,64 +75,35 @@ __device__ __forceinline__ int project_one(float x, float y, float z, const floa
     return ok ? yy * W + xx : -1;
 }
 
-// Key-image update policies (read_tuning_set("splat_mode", m)):
-//   MODE_XCD   one private key image per XCD.  Workgroups read HW_REG_XCC_ID and fold into
-//              "their" image with WORKGROUP-scope atomics, which execute in that XCD's L2 and never
-//              cross the fabric; the 3.4 MB image stays L2 resident, and the early-z read (sc1: L2,
-//              not the CU's L1) sees every earlier fold of the same XCD.  The resolve pass takes the
-//              min over the 8 images.  Correctness needs only that all accesses to image x come
-//              from XCD x inside the launch, plus ordinary kernel-boundary visibility.
-//   MODE_AGENT (default) one shared image, agent-scope atomics (memory-side), early-z through a possibly
-//              stale L2 copy (conservative, but filters less).
-//   MODE_NOZ   projection only, no z-buffer traffic: timing floor for tuning, results are invalid.
-//   MODE_SYS   one shared image, agent-scope atomics, early-z read at SYSTEM scope (sc0 sc1: bypasses
-//              the XCD L2 too, so the filter is exact but every read crosses the fabric).
-//   MODE_PEEK / MODE_PEEK_L1 / MODE_ATOM  attribution probes (invalid results): early-z reads only (sc1 /
-//              plain L1-cached), and atomics only (no early-z filter).
-//   MODE_HIZ   (default) MODE_AGENT plus a temporal warm start and a hierarchical-Z reject that lives in LDS:
-//              before the point pass the previous frame's per-pixel winners are re-projected with the new
-//              camera and folded in, a conservative far bound per 4x4-pixel block (max of the current depths,
-//              +inf if any pixel is empty) is built, and every workgroup copies that bound image (107 KB at
-//              1216x352) into LDS.  A point whose depth exceeds its block's bound cannot win (keys only
-//              decrease), so it is dropped without touching global memory — ~90 % of the points of a frame.
+// Plain-path policies (read_tuning_set("splat_mode", m)):
+//   MODE_AGENT one key image per camera, agent-scope atomics (memory-side), early-z through the L2.
+//   MODE_HIZ   (default) MODE_AGENT plus, for a single camera, a temporal warm start and a hierarchical-Z reject in
+//              LDS: the previous frame's per-pixel winners are re-projected with the new camera and folded in, a
+//              conservative far bound per 4x4-pixel block (max of the current depths, +inf if any pixel is empty) is
+//              built, and every workgroup copies that bound image into LDS.  A point whose depth exceeds its block's
+//              bound cannot win (keys only decrease), so it is dropped without touching global memory.
 //              Exact: seeds are real points of this cloud, bounds are upper bounds of the final depths.
-//   MODE_AGENT_L1 / MODE_HIZ_L1 (cell-ordered passes, read_tuning_set("splat_l1", 1)): as MODE_AGENT / MODE_HIZ with
-//              the early-z read served by the CU's L1.  A stale copy is only ever LARGER than the live key (keys
-//              decrease), so the filter stays conservative; the chunks are spatially compact, so their reads share
-//              cache lines, and the seeds of the previous launch are visible (L1 is invalidated at kernel start).
-enum { MODE_XCD = 0, MODE_AGENT = 1, MODE_NOZ = 2, MODE_SYS = 3, MODE_PEEK = 4, MODE_PEEK_L1 = 5, MODE_ATOM = 6,
-       MODE_HIZ = 7, MODE_AGENT_L1 = 8, MODE_HIZ_L1 = 9 };
-constexpr int XCD_COPIES = 8;
+enum { MODE_AGENT = 1, MODE_HIZ = 7 };
 
 __device__ __forceinline__ unsigned xcc_id()
 {
     // s_getreg_b32 hwreg(HW_REG_XCC_ID = 20, offset 0, size 4)
-    return __builtin_amdgcn_s_getreg((3 << 11) | 20) & (XCD_COPIES - 1);
+    return __builtin_amdgcn_s_getreg((3 << 11) | 20) & (MAX_STRIPS - 1);
 }
 
-template <int MODE>
-__device__ __forceinline__ unsigned long long peek_key(const unsigned long long *k)
+// relaxed agent-scope load = global_load_dwordx2 sc1: served by L2, never by the CU's stale L1
+__device__ __forceinline__ unsigned long long peek_key_agent(const unsigned long long *k)
 {
-    // relaxed agent-scope load = global_load_dwordx2 sc1: served by L2, never by the CU's stale L1
-    if (MODE == MODE_SYS) return __hip_atomic_load(k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-    if (MODE == MODE_PEEK_L1 || MODE == MODE_AGENT_L1 || MODE == MODE_HIZ_L1) return *k;
     return __hip_atomic_load(k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
-
-template <int MODE>
-__device__ __forceinline__ void fold_key(unsigned long long *k, unsigned long long key)
+__device__ __forceinline__ void fold_key_agent(unsigned long long *k, unsigned long long key)
 {
-    if (MODE == MODE_XCD)
-        __hip_atomic_fetch_min(k, key, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-    else
-        __hip_atomic_fetch_min(k, key, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_fetch_min(k, key, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
-
 // Far bounds are stored as 16 bits: the upper half (bfloat16, truncated = rounded DOWN) of e = fl(1 - d_max).  Depth
 // is d = 1 - O(znear / z), so e keeps 8 mantissa bits of the DISTANCE (0.4 %) where a half-precision d would resolve
-// only ~5 m at 30 m; and 16-bit bounds let two 1024-thread workgroups share a CU's LDS (8 waves per SIMD instead of
-// 4 for this latency-bound pass).  Reject iff fl(1 - d) < bound: rounding is monotonic, so fl(1 - d) < fl(1 - d_max)
-// implies d > d_max strictly (ties pass), and truncation only lowers the bound.  Empty block -> -1 (never rejects).
+// only ~5 m at 30 m.  Reject iff fl(1 - d) < bound: rounding is monotonic, so fl(1 - d) < fl(1 - d_max) implies
+// d > d_max strictly (ties pass), and truncation only lowers the bound.  Empty block -> -1 (never rejects).
 __device__ __forceinline__ unsigned short hiz_encode(unsigned depth_bits_max)
 {
     if (depth_bits_max > 0x7f800000u) return 0xbf80;                  // a pixel of the block is still EMPTY: e = -1
@@ -123,13 +114,13 @@ __device__ __forceinline__ bool hiz_reject(unsigned short bound, float d)
     return (1.0f - d) < __uint_as_float((unsigned)bound << 16);
 }
 
-// NP points of one thread against one camera: all projections first, then all early-z reads in
-// flight together, then the (few) atomics — no dependent memory round trip per point.
-template <int MODE, int NP>
-__device__ __forceinline__ void splat_points_ids(const float (&px)[NP], const float (&py)[NP], const float (&pz)[NP],
-                                                 const unsigned (&ids)[NP], int nvalid, const float *M, int W, int H,
-                                                 unsigned long long *keys, unsigned &sink,
-                                                 const unsigned short *hiz = nullptr, int nbx = 0, unsigned *stat = nullptr)
+// NP points of one thread against one camera (plain path): all projections first, then all early-z reads in flight
+// together, then the (few) atomics — no dependent memory round trip per point.
+template <bool HIZ, int NP>
+__device__ __forceinline__ void splat_points(const float (&px)[NP], const float (&py)[NP], const float (&pz)[NP],
+                                             unsigned id0, int nvalid, const float *M, int W, int H,
+                                             unsigned long long *keys, const unsigned short *hiz = nullptr, int nbx = 0,
+                                             unsigned *stat = nullptr)
 {
     int pix[NP];
     unsigned long long key[NP], seen[NP];
@@ -140,50 +131,22 @@ __device__ __forceinline__ void splat_points_ids(const float (&px)[NP], const fl
         pix[k] = project_one(px[k], py[k], pz[k], M, W, H, d, xx, yy);
         if (k >= nvalid) pix[k] = -1;
         if (stat && pix[k] >= 0) stat[0]++;                 // visible
-        if (MODE == MODE_HIZ || MODE == MODE_HIZ_L1) {
+        if (HIZ) {
             // LDS-resident far bound of the point's 4x4 block; strictly greater cannot win (ties must pass)
             if (hiz_reject(hiz[pix[k] >= 0 ? (yy >> 2) * nbx + (xx >> 2) : 0], d)) pix[k] = -1;
         }
         if (stat && pix[k] >= 0) stat[1]++;                 // survived the LDS hi-z (or no hi-z)
-        key[k] = ((unsigned long long)__float_as_uint(d) << 32) | ids[k];
-    }
-    if (MODE == MODE_NOZ) {
-#pragma unroll
-        for (int k = 0; k < NP; ++k) sink += (unsigned)pix[k];
-        return;
-    }
-    if (MODE == MODE_ATOM) {
-#pragma unroll
-        for (int k = 0; k < NP; ++k)
-            if (pix[k] >= 0) fold_key<MODE>(keys + pix[k], key[k]);
-        return;
+        key[k] = ((unsigned long long)__float_as_uint(d) << 32) | (id0 + k);
     }
 #pragma unroll
-    for (int k = 0; k < NP; ++k) seen[k] = pix[k] >= 0 ? peek_key<MODE>(keys + pix[k]) : 0ull;
-    if (MODE == MODE_PEEK || MODE == MODE_PEEK_L1) {
-#pragma unroll
-        for (int k = 0; k < NP; ++k) sink += (unsigned)(seen[k] >> 32) + (unsigned)pix[k];
-        return;
-    }
+    for (int k = 0; k < NP; ++k) seen[k] = pix[k] >= 0 ? peek_key_agent(keys + pix[k]) : 0ull;
     // keys only ever decrease, so "not smaller than what I can see" is final
 #pragma unroll
     for (int k = 0; k < NP; ++k)
         if (key[k] < seen[k]) {
-            fold_key<MODE>(keys + pix[k], key[k]);
+            fold_key_agent(keys + pix[k], key[k]);
             if (stat) stat[2]++;                            // atomics issued
         }
-}
-
-template <int MODE, int NP>
-__device__ __forceinline__ void splat_points(const float (&px)[NP], const float (&py)[NP], const float (&pz)[NP],
-                                             unsigned id0, int nvalid, const float *M, int W, int H,
-                                             unsigned long long *keys, unsigned &sink, const unsigned short *hiz = nullptr,
-                                             int nbx = 0, unsigned *stat = nullptr)
-{
-    unsigned ids[NP];
-#pragma unroll
-    for (int k = 0; k < NP; ++k) ids[k] = id0 + k;
-    splat_points_ids<MODE, NP>(px, py, pz, ids, nvalid, M, W, H, keys, sink, hiz, nbx, stat);
 }
 
 // Point groups (4 points) are split into chunks of 256 groups (1024 points).  The bootstrap pass of MODE_HIZ
@@ -205,12 +168,10 @@ __device__ __forceinline__ long long map_group(long long t, int sub, int sel)
     return (chunk << 8) | (t & 255);
 }
 
-template <int MODE>
 __global__ __launch_bounds__(256) void splat_project_kernel(const float *__restrict__ xyz, long long n,
                                                             CamSet cams, int B, int W, int H,
                                                             unsigned long long *__restrict__ keys,
-                                                            int vec_ok, unsigned *sink_out, int sub_mod,
-                                                            unsigned long long *stats)
+                                                            int vec_ok, int sub_mod, unsigned long long *stats)
 {
     unsigned st_local[3] = {0, 0, 0};
     unsigned *stp = stats ? st_local : nullptr;
@@ -219,10 +180,6 @@ __global__ __launch_bounds__(256) void splat_project_kernel(const float *__restr
     const long long groups = n / PTS_PER_THREAD;
     const long long tid0 = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     const long long nthreads = (long long)gridDim.x * blockDim.x;
-    // image layout: [camera][copy][pixel]; a workgroup only ever touches its own XCD's copy
-    const int copies = MODE == MODE_XCD ? XCD_COPIES : 1;
-    unsigned long long *kbase = keys + (MODE == MODE_XCD ? (long long)xcc_id() * npx : 0);
-    unsigned sink = 0;
 
     if (vec_ok) {
         const float4 *xyz4 = reinterpret_cast<const float4 *>(xyz);
@@ -238,8 +195,8 @@ __global__ __launch_bounds__(256) void splat_project_kernel(const float *__restr
             const float py[4] = {a.y, b.x, b.w, c.z};
             const float pz[4] = {a.z, b.y, c.x, c.w};
             for (int cam = 0; cam < B; ++cam)
-                splat_points<MODE, 4>(px, py, pz, (unsigned)(g * PTS_PER_THREAD), 4, cams.m[cam], W, H,
-                                      kbase + (long long)cam * copies * npx, sink, nullptr, 0, stp);
+                splat_points<false, 4>(px, py, pz, (unsigned)(g * PTS_PER_THREAD), 4, cams.m[cam], W, H,
+                                       keys + (long long)cam * npx, nullptr, 0, stp);
         }
     }
     // tail (n % 4 points), or everything when the pointer is not 16-byte aligned
@@ -247,21 +204,36 @@ __global__ __launch_bounds__(256) void splat_project_kernel(const float *__restr
     for (long long i = first + tid0; i < n && sub_mod <= 0; i += nthreads) {     // (the bootstrap pass leaves the tail to the main pass)
         const float px[1] = {xyz[3 * i + 0]}, py[1] = {xyz[3 * i + 1]}, pz[1] = {xyz[3 * i + 2]};
         for (int cam = 0; cam < B; ++cam)
-            splat_points<MODE, 1>(px, py, pz, (unsigned)i, 1, cams.m[cam], W, H,
-                                  kbase + (long long)cam * copies * npx, sink);
+            splat_points<false, 1>(px, py, pz, (unsigned)i, 1, cams.m[cam], W, H, keys + (long long)cam * npx);
     }
-    if ((MODE == MODE_NOZ || MODE == MODE_PEEK || MODE == MODE_PEEK_L1) && sink == 0x7fffffffu && sink_out)
-        *sink_out = sink;                                                       // keeps the probes live
     if (stats)
         for (int i = 0; i < 3; ++i) atomicAdd(stats + i, (unsigned long long)st_local[i]);
 }
 
 
-// ---- MODE_HIZ pieces ------------------------------------------------------------------------------
-struct SplatHeader {          // first 256 bytes of the workspace
-    int valid, W, H, pad;
+// ---- workspace header ------------------------------------------------------------------------------------------
+struct SplatHeader {          // first bytes of the workspace
+    int valid;                // 0: no previous frame; 1: prev[0] holds the winners' point ids (plain path);
+                              // 2: prev[parity] holds positions in the cell-ordered cloud (striped path)
+    int W, H;
+    int parity;               // which of the two seed images the NEXT striped frame reads
 };
-constexpr size_t HEADER_BYTES = 256;
+struct StripCounters {        // 256 bytes per strip, at HEADER_STRIPS_OFFSET + 256 * strip (agent-scope atomics only)
+    int nA, nB;               // list lengths, written by the classification blocks of the seed launch
+    int pad0[30];
+    int headA, headB;         // ticket counters of the passes (kept on their own line: the hot one)
+    int pad1[30];
+};
+constexpr size_t HEADER_BYTES = 4096;
+constexpr size_t HEADER_STATS_OFFSET = 64;      // 16 x u64 debug counters (read_tuning_set("splat_stats", 1))
+constexpr size_t HEADER_STRIPS_OFFSET = 256;    // MAX_STRIPS x StripCounters
+static_assert(sizeof(StripCounters) == 256, "StripCounters must be two 128-byte lines");
+static_assert(HEADER_STRIPS_OFFSET + MAX_STRIPS * sizeof(StripCounters) <= HEADER_BYTES, "header too small");
+
+__device__ __forceinline__ StripCounters *strip_counters(void *hdr, int s)
+{
+    return reinterpret_cast<StripCounters *>((char *)hdr + HEADER_STRIPS_OFFSET) + s;
+}
 
 // bound[block] = max over the block's pixels of the current depth, +inf if any pixel is still empty.
 __global__ __launch_bounds__(256) void splat_hiz_kernel(const unsigned long long *__restrict__ keys, int W, int H,
@@ -284,8 +256,8 @@ __global__ __launch_bounds__(256) void splat_hiz_kernel(const unsigned long long
     hiz[b] = hiz_encode(m);
 }
 
-// The point pass of MODE_HIZ: one 1024-thread workgroup per CU (persistent, grid-stride) with the whole
-// bound image in LDS.
+// The point pass of MODE_HIZ (plain path): 1024-thread workgroups (persistent, grid-stride) with the whole bound
+// image in LDS.
 __global__ __launch_bounds__(1024) void splat_project_hiz_kernel(const float *__restrict__ xyz, long long n, CamSet cams,
                                                                  int W, int H, unsigned long long *__restrict__ keys,
                                                                  int vec_ok, const unsigned short *__restrict__ hiz_g, int nbx,
@@ -299,7 +271,6 @@ __global__ __launch_bounds__(1024) void splat_project_hiz_kernel(const float *__
     const long long groups = n / PTS_PER_THREAD;
     const long long tid0 = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     const long long nthreads = (long long)gridDim.x * blockDim.x;
-    unsigned sink = 0;
     if (vec_ok) {
         const float4 *xyz4 = reinterpret_cast<const float4 *>(xyz);
         const long long npass = pass_groups(groups, sub_mod, sub_mod > 0 ? 2 : 0);
@@ -312,37 +283,60 @@ __global__ __launch_bounds__(1024) void splat_project_hiz_kernel(const float *__
             const float px[4] = {a.x, a.w, b.z, c.y};
             const float py[4] = {a.y, b.x, b.w, c.z};
             const float pz[4] = {a.z, b.y, c.x, c.w};
-            splat_points<MODE_HIZ, 4>(px, py, pz, (unsigned)(g * PTS_PER_THREAD), 4, cams.m[0], W, H, keys, sink, hiz, nbx, stp);
+            splat_points<true, 4>(px, py, pz, (unsigned)(g * PTS_PER_THREAD), 4, cams.m[0], W, H, keys, hiz, nbx, stp);
         }
     }
     const long long first = vec_ok ? groups * PTS_PER_THREAD : 0;
     for (long long i = first + tid0; i < n; i += nthreads) {
         const float px[1] = {xyz[3 * i + 0]}, py[1] = {xyz[3 * i + 1]}, pz[1] = {xyz[3 * i + 2]};
-        splat_points<MODE_HIZ, 1>(px, py, pz, (unsigned)i, 1, cams.m[0], W, H, keys, sink, hiz, nbx, stp);
+        splat_points<true, 1>(px, py, pz, (unsigned)i, 1, cams.m[0], W, H, keys, hiz, nbx, stp);
     }
     if (stats)
         for (int i = 0; i < 3; ++i) atomicAdd(stats + 4 + i, (unsigned long long)st_local[i]);
 }
 
+// Plain-path warm start: re-project the previous frame's winners (one per level-0 pixel) with the new camera.
+__global__ __launch_bounds__(256) void splat_seed_kernel(const float *__restrict__ xyz, long long n, CamSet cams,
+                                                         int W, int H, unsigned long long *__restrict__ keys,
+                                                         const SplatHeader *hdr, const int *__restrict__ prev_idx)
+{
+    const int p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= W * H || !prev_idx) return;
+    if (!(hdr->valid == 1 && hdr->W == W && hdr->H == H)) return;
+    const int id = prev_idx[p];
+    if (id < 0 || id >= n) return;
+    float d;
+    int xx, yy;
+    const int pix = project_one(xyz[3ll * id], xyz[3ll * id + 1], xyz[3ll * id + 2], cams.m[0], W, H, d, xx, yy);
+    if (pix >= 0) fold_key_agent(keys + pix, ((unsigned long long)__float_as_uint(d) << 32) | (unsigned)id);
+}
 
-// ---- cell-ordered cloud: chunk-level frustum / occlusion culling ---------------------------------------------
+
+// ---- cell-ordered cloud, XCD-striped passes -------------------------------------------------------------------------
 // read_splat_cells_build_host() sorts the cloud once along a Morton curve and cuts it into chunks of 1024 points with
-// their bounding boxes; the original point ids travel with the points (keys carry the ORIGINAL id, so the result is
-// bit-identical to the unsorted pass — atomic min does not care about order).  Per frame:
-//   splat_seed_kernel      (extra blocks) classifies every chunk from the 8 projected corners of its box: outside the
-//                          frustum -> dropped (no point of it is read); nearest corner closer than w_split, or every
-//                          sub-th chunk -> list A; the rest -> list B with its screen rectangle and depth threshold.
-//                          Lists are compacted with one atomic per wave.
-//   splat_cells_kernel<A>  one wave per list-A chunk: plain early-z + atomic min (these chunks set the first bounds).
-//   splat_hiz_kernel       far bound per 4x4 block.
-//   splat_cells_kernel<B>  one wave per list-B chunk: skipped when its nearest possible depth is behind the bound of
-//                          EVERY block its rectangle touches, otherwise the LDS hi-z point pass.
+// their bounding boxes; every record is (x, y, z, original id), so keys carry the ORIGINAL id and the result is
+// bit-identical to the unsorted pass (atomic min does not care about order).  Per frame, five launches:
+//   cells_seed_classify_kernel
+//       seed blocks      re-project last frame's front points (their POSITIONS in the sorted cloud were left in a
+//                        per-pixel image by the threads that issued atomics — any real point is a valid seed, so that
+//                        image may be written racily) and store their depths into zimg.  No atomics.
+//       classify blocks  one thread per chunk, from the 8 projected corners of its box: outside the frustum -> dropped
+//                        (no point of it is read); nearest corner closer than w_split, or every sub-th chunk -> list A;
+//                        the rest -> list B with its screen rectangle and depth threshold.  A chunk is appended to the
+//                        list of EVERY strip its pixel columns can touch (block-aggregated appends).
+//   cells_pass_kernel<A> a workgroup reads its XCD id, starts with the strip that XCD owns and pulls chunks off that
+//                        strip's list A (ticket counter); for the points that fall into the strip: zimg early-z, then
+//                        atomic min on the key + plain stores of the new bound and of the point's position (next
+//                        frame's seed).  When a list is empty the workgroup moves on to the next strip's.
+//   cells_hiz_kernel     far bound per 4x4 block from zimg.
+//   cells_pass_kernel<B> same walk over list B: a chunk is skipped when its nearest possible depth is behind the bound
+//                        of EVERY block of its rectangle (inside the strip), otherwise its points run as in pass A.
+//   splat_resolve_kernel levels, keys back to EMPTY, zimg back to "no bound", counters to zero.
 // Conservative arithmetic: the fp32 projection of a point and of the box corners differ by rounding; with
 // S_k = sum_j |M_kj| max|box_j| + |M_k3| every computed clip coordinate is within gamma S_k of the exact one, so ndc
 // errors are bounded by gamma (S_k + S_3) / w_min + ulp; the rectangle is widened and the depth test tightened by that
 // much (gamma = 1e-6, >= 4x the worst case of a 4-term fp32 dot product).  A box with a corner at or behind the camera
-// plane is never culled (list A).  A single dynamic chunk counter was tried first: 37 K same-address atomics cost
-// 0.65 ms per pass (~17 ns each) — hence classification + static walks over compact lists.
+// plane is never culled (list A, all strips).
 struct CellHeader {            // first 256 bytes of the cell-ordered cloud (device and host)
     long long n;
     int nchunks, version;
@@ -350,8 +344,8 @@ struct CellHeader {            // first 256 bytes of the cell-ordered cloud (dev
     float density;             // points per unit volume of the bounding box
 };
 constexpr int CELL_CHUNK = 1024;
+constexpr int CELL_VERSION = 2;
 constexpr size_t CELL_HEADER_BYTES = 256;
-constexpr size_t CELL_COUNTER_OFFSET = 192;   // two ints in the WORKSPACE header: lengths of list A / list B
 
 struct CellEntryB {            // 16 bytes per list-B chunk
     int chunk;
@@ -362,17 +356,31 @@ struct CellEntryB {            // 16 bytes per list-B chunk
 
 struct CellCloud {             // device pointers into the blob
     const CellHeader *hdr;
-    const float *xyz;          // nchunks * 1024 * 3, Morton order, tail padded with copies of the last point
-    const unsigned *ids;       // original point id of every sorted point
+    const float4 *pts;         // nchunks * 1024 records (x, y, z, bits of the original id), Morton order, tail padded
+                               // with copies of the last point
     const float *aabb;         // nchunks * 8: min xyz, max xyz, 2 pad
-    int *list_a;               // scratch: chunk ids of this frame's list A
-    CellEntryB *list_b;        // scratch: list B
+    int *list_a;               // scratch: MAX_STRIPS x nchunks chunk ids of this frame's lists A
+    CellEntryB *list_b;        // scratch: MAX_STRIPS x nchunks
     int nchunks;
 };
 
-// class of one chunk for camera M: 0 dropped, 1 list A, 2 list B (then e fills in)
+struct StripInfo {
+    int ns;                    // strips in use (<= MAX_STRIPS)
+    int xb[MAX_STRIPS + 1];    // strip s = pixel columns [xb[s], xb[s+1]), multiples of 16; XCD x starts with strip x % ns
+};
+
+__device__ __forceinline__ int strip_of_column(const StripInfo &si, int x)
+{
+    int s = 0;
+#pragma unroll
+    for (int k = 1; k < MAX_STRIPS; ++k)
+        if (k < si.ns && x >= si.xb[k]) s = k;
+    return s;
+}
+
+// class of one chunk for camera M: 0 dropped, 1 list A, 2 list B (then e fills in); [cx0, cx1] = pixel columns
 __device__ __forceinline__ int classify_chunk(const float *bb, const float *M, int W, int H, float w_split, bool boot,
-                                              CellEntryB &e)
+                                              CellEntryB &e, int &cx0, int &cx1)
 {
     constexpr float GAMMA = 1e-6f;
     const float mn[3] = {bb[0], bb[1], bb[2]}, mx[3] = {bb[3], bb[4], bb[5]};
@@ -391,6 +399,8 @@ __device__ __forceinline__ int classify_chunk(const float *bb, const float *M, i
         for (int k = 0; k < 4; ++k) c[i][k] = M[4 * k] * cx + M[4 * k + 1] * cy + M[4 * k + 2] * cz + M[4 * k + 3] * 1.0f;
         wmin = fminf(wmin, c[i][3]);
     }
+    cx0 = 0;
+    cx1 = W - 1;
     if (!(wmin > fmaxf(1e-3f, 1e-5f * S[3]))) return 1;           // a corner at / behind the camera plane: never culled
     float lo[3] = {3.0e38f, 3.0e38f, 3.0e38f}, hi[3] = {-3.0e38f, -3.0e38f, -3.0e38f};
 #pragma unroll
@@ -408,26 +418,31 @@ __device__ __forceinline__ int classify_chunk(const float *bb, const float *M, i
     if (hi[0] < -1.0f - ex || lo[0] > 1.0f + ex || hi[1] < -1.0f - ey || lo[1] > 1.0f + ey || hi[2] < -1.0f - ez ||
         lo[2] > 1.0f + ez)
         return 0;
-    if (wmin < w_split || boot) return 1;
-    const float dmin = (fmaxf(lo[2], -1.0f) + 1.0f) * 0.5f;
-    e.e_thr = (1.0f - dmin) + 2.0f * (0.5f * ez + 2e-7f);
     const float px0 = (float)W * (lo[0] + 1.0f) * 0.5f - ((float)W * 0.5f * ex + 1.0f);
     const float px1 = (float)W * (hi[0] + 1.0f) * 0.5f + ((float)W * 0.5f * ex + 1.0f);
     const float py0 = (float)H * (1.0f - hi[1]) * 0.5f - ((float)H * 0.5f * ey + 1.0f);
     const float py1 = (float)H * (1.0f - lo[1]) * 0.5f + ((float)H * 0.5f * ey + 1.0f);
-    const unsigned bx0 = (unsigned)fminf(fmaxf(px0, 0.0f), (float)(W - 1)) >> 2;
-    const unsigned bx1 = (unsigned)fminf(fmaxf(px1, 0.0f), (float)(W - 1)) >> 2;
-    const unsigned by0 = (unsigned)fminf(fmaxf(py0, 0.0f), (float)(H - 1)) >> 2;
-    const unsigned by1 = (unsigned)fminf(fmaxf(py1, 0.0f), (float)(H - 1)) >> 2;
-    e.bx = bx0 << 16 | bx1;
-    e.by = by0 << 16 | by1;
+    const unsigned ux0 = (unsigned)fminf(fmaxf(px0, 0.0f), (float)(W - 1));
+    const unsigned ux1 = (unsigned)fminf(fmaxf(px1, 0.0f), (float)(W - 1));
+    const unsigned uy0 = (unsigned)fminf(fmaxf(py0, 0.0f), (float)(H - 1));
+    const unsigned uy1 = (unsigned)fminf(fmaxf(py1, 0.0f), (float)(H - 1));
+    cx0 = (int)ux0;
+    cx1 = (int)ux1;
+    if (wmin < w_split || boot) return 1;
+    const float dmin = (fmaxf(lo[2], -1.0f) + 1.0f) * 0.5f;
+    e.e_thr = (1.0f - dmin) + 2.0f * (0.5f * ez + 2e-7f);
+    e.bx = (ux0 >> 2) << 16 | (ux1 >> 2);
+    e.by = (uy0 >> 2) << 16 | (uy1 >> 2);
     return 2;
 }
 
-// The classification blocks of splat_seed_kernel (blockIdx >= pix_blocks): one thread per chunk.
+// The classification blocks of cells_seed_classify_kernel: one thread per chunk, block-aggregated appends (one atomic
+// per block, list and strip: a per-wave append measured ~8 us of same-address atomics on the critical path).
 __device__ __forceinline__ void classify_block(const CellCloud &cc, const float *M, int W, int H, int sub, float near_count,
-                                               int block, int *counts)
+                                               int block, void *hdr, const StripInfo &si)
 {
+    __shared__ int s_cnt[4][2 * MAX_STRIPS];
+    __shared__ int s_base[2 * MAX_STRIPS];
     const int chunk = block * 256 + threadIdx.x;
     // list A takes the chunks nearer than the distance within which a pixel expects `near_count` points
     const float focal = sqrtf(M[0] * M[0] + M[1] * M[1] + M[2] * M[2]) * (float)W * 0.5f;
@@ -436,232 +451,200 @@ __device__ __forceinline__ void classify_block(const CellCloud &cc, const float 
     e.chunk = chunk;
     e.bx = e.by = 0;
     e.e_thr = 0.0f;
-    int cls = 0;
+    int cls = 0, cx0 = 0, cx1 = 0;
     if (chunk < cc.nchunks)
-        cls = classify_chunk(cc.aabb + (size_t)chunk * 8, M, W, H, w_split, sub > 0 && chunk % sub == 0, e);
-    // wave-aggregated append: one atomic per wave and list
-    const int lane = threadIdx.x & 63;
-    const unsigned long long ma = __ballot(cls == 1), mb = __ballot(cls == 2);
-    int base_a = 0, base_b = 0;
-    if (lane == 0) {
-        if (ma) base_a = atomicAdd(counts + 0, __popcll(ma));
-        if (mb) base_b = atomicAdd(counts + 1, __popcll(mb));
+        cls = classify_chunk(cc.aabb + (size_t)chunk * 8, M, W, H, w_split, sub > 0 && chunk % sub == 0, e, cx0, cx1);
+    const int s0 = strip_of_column(si, cx0), s1 = strip_of_column(si, cx1);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    for (int s = 0; s < si.ns; ++s) {
+        const bool in = cls != 0 && s >= s0 && s <= s1;
+        const unsigned long long ma = __ballot(in && cls == 1), mb = __ballot(in && cls == 2);
+        if (lane == 0) {
+            s_cnt[wave][s] = __popcll(ma);
+            s_cnt[wave][MAX_STRIPS + s] = __popcll(mb);
+        }
     }
-    base_a = __shfl(base_a, 0);
-    base_b = __shfl(base_b, 0);
+    __syncthreads();
+    if (threadIdx.x < 2 * MAX_STRIPS) {
+        const int l = threadIdx.x, s = l & (MAX_STRIPS - 1);
+        int base = 0;
+        if (s < si.ns) {
+            const int tot = s_cnt[0][l] + s_cnt[1][l] + s_cnt[2][l] + s_cnt[3][l];
+            StripCounters *sc = strip_counters(hdr, s);
+            if (tot) base = atomicAdd(l < MAX_STRIPS ? &sc->nA : &sc->nB, tot);
+        }
+        s_base[l] = base;
+    }
+    __syncthreads();
     const unsigned long long below = lane == 0 ? 0ull : (~0ull >> (64 - lane));
-    if (cls == 1) cc.list_a[base_a + __popcll(ma & below)] = chunk;
-    if (cls == 2) cc.list_b[base_b + __popcll(mb & below)] = e;
+    for (int s = 0; s < si.ns; ++s) {
+        const bool in = cls != 0 && s >= s0 && s <= s1;
+        const unsigned long long ma = __ballot(in && cls == 1), mb = __ballot(in && cls == 2);
+        if (!in) continue;
+        const int l = cls == 1 ? s : MAX_STRIPS + s;
+        int off = s_base[l] + __popcll((cls == 1 ? ma : mb) & below);
+        for (int w = 0; w < wave; ++w) off += s_cnt[w][l];
+        if (cls == 1)
+            cc.list_a[(size_t)s * cc.nchunks + off] = chunk;
+        else
+            cc.list_b[(size_t)s * cc.nchunks + off] = e;
+    }
 }
 
-// Re-project the previous frame's winners (one per level-0 pixel) with the new camera and fold them in.
-__global__ __launch_bounds__(256) void splat_seed_kernel(const float *__restrict__ xyz, long long n, CamSet cams,
-                                                         int W, int H, unsigned long long *__restrict__ keys,
-                                                         SplatHeader *hdr, const int *__restrict__ prev_idx,
-                                                         CellCloud cc, int pix_blocks, int sub, float near_count)
+__global__ __launch_bounds__(256) void cells_seed_classify_kernel(CellCloud cc, Cam1 cam, int W, int H,
+                                                                  unsigned *zimg, void *hdr_v, const int *pos0,
+                                                                  const int *pos1, StripInfo si, int seed_blocks,
+                                                                  int sub, float near_count, int use_seeds)
 {
-    if ((int)blockIdx.x >= pix_blocks) {           // the extra blocks classify the chunks of the cell-ordered cloud
-        classify_block(cc, cams.m[0], W, H, sub, near_count, (int)blockIdx.x - pix_blocks,
-                       (int *)((char *)hdr + CELL_COUNTER_OFFSET));
+    if ((int)blockIdx.x >= seed_blocks) {
+        classify_block(cc, cam.m, W, H, sub, near_count, (int)blockIdx.x - seed_blocks, hdr_v, si);
         return;
     }
+    const SplatHeader *hdr = (const SplatHeader *)hdr_v;
+    if (!use_seeds || !(hdr->valid == 2 && hdr->W == W && hdr->H == H)) return;
     const int p = blockIdx.x * blockDim.x + threadIdx.x;
-    if (p >= W * H || !prev_idx) return;
-    if (!(hdr->valid == 1 && hdr->W == W && hdr->H == H)) return;
-    const int id = prev_idx[p];
-    if (id < 0 || id >= n) return;
+    if (p >= W * H) return;
+    const int pos = (hdr->parity ? pos1 : pos0)[p];
+    if ((unsigned)pos >= (unsigned)cc.nchunks * CELL_CHUNK) return;
+    const float4 q = cc.pts[pos];
     float d;
     int xx, yy;
-    const int pix = project_one(xyz[3ll * id], xyz[3ll * id + 1], xyz[3ll * id + 2], cams.m[0], W, H, d, xx, yy);
-    if (pix >= 0) fold_key<MODE_AGENT>(keys + pix, ((unsigned long long)__float_as_uint(d) << 32) | (unsigned)id);
+    const int pix = project_one(q.x, q.y, q.z, cam.m, W, H, d, xx, yy);
+    // the depth of a real point at this pixel bounds the final depth from above; the point itself is folded in when its
+    // chunk comes by (ties pass every test).  Colliding seeds race; either value is a valid bound.
+    if (pix >= 0) zimg[pix] = __float_as_uint(d);
 }
 
-template <bool PASS_B, bool L1>
-__global__ __launch_bounds__(PASS_B ? 1024 : 256) void splat_cells_kernel(CellCloud cc, CamSet cams, int W, int H,
-                                                                         unsigned long long *__restrict__ keys,
-                                                                         const unsigned short *__restrict__ hiz_g, int nbx,
-                                                                         int nby, const int *counts,
-                                                                         unsigned long long *stats)
+// An item = 1024 / sub_items consecutive points of one chunk, for one wave and one strip.
+template <bool PASS_B>
+__global__ __launch_bounds__(256) void cells_pass_kernel(CellCloud cc, Cam1 cam, int W, int H,
+                                                         unsigned long long *keys, unsigned *zimg,
+                                                         const unsigned short *__restrict__ hiz_g, int nbx, void *hdr_v,
+                                                         int *pos0, int *pos1, StripInfo si, int sub_items,
+                                                         unsigned long long *stats)
 {
-    extern __shared__ __attribute__((aligned(16))) unsigned short hiz[];
-    if (PASS_B) {
-        for (int i = threadIdx.x; i < nbx * nby; i += blockDim.x) hiz[i] = hiz_g[i];
-        __syncthreads();
-    }
-    const float *M = cams.m[0];
+    const SplatHeader *hdr = (const SplatHeader *)hdr_v;
+    int *next = hdr->parity ? pos0 : pos1;
+    const float *M = cam.m;
     const int lane = threadIdx.x & 63;
-    unsigned st_local[3] = {0, 0, 0};
-    unsigned *stp = stats ? st_local : nullptr;
-    unsigned n_proc = 0, n_cull = 0;
-    const float4 *xyz4 = reinterpret_cast<const float4 *>(cc.xyz);
-    const uint4 *ids4 = reinterpret_cast<const uint4 *>(cc.ids);
-    const int n_list = counts[PASS_B ? 1 : 0];
-    // one wave per chunk, lists walked in (roughly Morton) order by neighbouring waves.  Measured alternatives: a team
-    // of four waves per chunk (one quarter each) 76 / 48 us for pass A / B instead of 78 / 38; a transposed walk that
-    // keeps concurrent waves far apart 94 / 50 (locality of the key image matters more than contention).
-    const int wave = __builtin_amdgcn_readfirstlane((int)(blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)));
-    const int n_waves = gridDim.x * (blockDim.x >> 6);
-    unsigned sink = 0;
-    for (int i = wave; i < n_list; i += n_waves) {
-        int chunk;
-        if (PASS_B) {
-            const CellEntryB e = cc.list_b[i];
-            chunk = e.chunk;
-            const int bx0 = (int)(e.bx >> 16), bx1 = (int)(e.bx & 0xffffu), by0 = (int)(e.by >> 16), by1 = (int)(e.by & 0xffffu);
-            if ((bx1 - bx0 + 1) * (by1 - by0 + 1) <= 8192) {
-                float emin = 3.0e38f;                                  // min over the rectangle of (1 - far bound)
-                for (int ry = by0; ry <= by1; ++ry)
-                    for (int rx = bx0 + lane; rx <= bx1; rx += 64)
-                        emin = fminf(emin, __uint_as_float((unsigned)hiz[ry * nbx + rx] << 16));
+    const int rounds = 4 / sub_items;                        // 256-point rounds per item
+    unsigned st[3] = {0, 0, 0};
+    unsigned n_done = 0, n_cull = 0;
+    int s = (int)(xcc_id() % (unsigned)si.ns);               // this XCD's own strip first
+    for (int visit = 0; visit < si.ns; ++visit, s = s + 1 == si.ns ? 0 : s + 1) {
+        StripCounters *sc = strip_counters(hdr_v, s);
+        const int xlo = si.xb[s], xhi = si.xb[s + 1];
+        const int n_items = (PASS_B ? sc->nB : sc->nA) * sub_items;
+        int *head = PASS_B ? &sc->headB : &sc->headA;
+        const int *list_a = cc.list_a + (size_t)s * cc.nchunks;
+        const CellEntryB *list_b = cc.list_b + (size_t)s * cc.nchunks;
+        if (n_items == 0) continue;
+        if (visit > 0) {                                     // stealing: look before drawing a ticket from a foreign list
+            if (__hip_atomic_load(head, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= n_items) continue;
+        }
+        int t = 0;
+        if (lane == 0) t = atomicAdd(head, 1);
+        t = __builtin_amdgcn_readfirstlane(t);
+        while (t < n_items) {
+            // next ticket first: its round trip hides behind this item's loads
+            int tn = 0;
+            if (lane == 0) tn = atomicAdd(head, 1);
+            const int li = t / sub_items, part = t - li * sub_items;
+            ++n_done;
+            int chunk;
+            bool run = true;
+            if (PASS_B) {
+                const CellEntryB e = list_b[li];
+                chunk = e.chunk;
+                int bx0 = (int)(e.bx >> 16), bx1 = (int)(e.bx & 0xffffu);
+                const int by0 = (int)(e.by >> 16), by1 = (int)(e.by & 0xffffu);
+                bx0 = max(bx0, xlo >> 2);                      // only this strip's part of the rectangle matters here
+                bx1 = min(bx1, (xhi - 1) >> 2);
+                const int rw = bx1 - bx0 + 1, nblk = rw * (by1 - by0 + 1);
+                if (rw <= 0) {
+                    run = false;
+                } else if (nblk <= 4096) {
+                    float emin = 3.0e38f;                      // min over the rectangle of (1 - far bound)
+                    for (int i = lane; i < nblk; i += 64) {
+                        const int ry = by0 + i / rw, rx = bx0 + i % rw;
+                        emin = fminf(emin, __uint_as_float((unsigned)hiz_g[ry * nbx + rx] << 16));
+                    }
 #pragma unroll
-                for (int o = 32; o > 0; o >>= 1) emin = fminf(emin, __shfl_xor(emin, o));
-                if (e.e_thr < emin) {                                  // every point of the box is behind every bound
-                    ++n_cull;
-                    continue;
+                    for (int o = 32; o > 0; o >>= 1) emin = fminf(emin, __shfl_xor(emin, o));
+                    if (e.e_thr < emin) run = false;           // every point of the box is behind every bound
+                }
+                if (!run) ++n_cull;
+            } else {
+                chunk = list_a[li];
+            }
+            chunk = __builtin_amdgcn_readfirstlane(chunk);
+            if (run) {
+                for (int r = 0; r < rounds; ++r) {
+                    // 256 points: lane l takes records base + l + 64 k (each load instruction = 1 KiB contiguous)
+                    const int base = chunk * CELL_CHUNK + (part * rounds + r) * 256 + lane;
+                    float4 q[4];
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) q[k] = cc.pts[base + 64 * k];
+                    int pix[4];
+                    unsigned dbits[4], bound[4];
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) {
+                        int xx, yy;
+                        float d;
+                        pix[k] = project_one(q[k].x, q[k].y, q[k].z, M, W, H, d, xx, yy);
+                        if (xx < xlo || xx >= xhi) pix[k] = -1;
+                        dbits[k] = __float_as_uint(d);
+                        if (stats && pix[k] >= 0) st[0]++;
+                    }
+                    // early-z against the bound image (L1 / this XCD's L2; a stale bound is only ever LARGER)
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) bound[k] = pix[k] >= 0 ? zimg[pix[k]] : 0u;
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) {
+                        if (pix[k] >= 0 && dbits[k] <= bound[k]) {     // ties pass: the atomic breaks them by id
+                            __hip_atomic_fetch_min(keys + pix[k], ((unsigned long long)dbits[k] << 32) | __float_as_uint(q[k].w),
+                                                   __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                            if (dbits[k] < bound[k]) zimg[pix[k]] = dbits[k];
+                            next[pix[k]] = base + 64 * k;      // a front point of this pixel: next frame's seed
+                            if (stats) st[2]++;
+                        }
+                    }
                 }
             }
-        } else {
-            chunk = cc.list_a[i];
-        }
-        chunk = __builtin_amdgcn_readfirstlane(chunk);
-        ++n_proc;
-        // ---- the chunk's 1024 points: 4 rounds of 4 points per lane
-#pragma unroll 2
-        for (int it = 0; it < 4; ++it) {
-            const long long g = (long long)chunk * 256 + it * 64 + lane;        // group of 4 points
-            const float4 a = xyz4[3 * g + 0];
-            const float4 b = xyz4[3 * g + 1];
-            const float4 c = xyz4[3 * g + 2];
-            const uint4 id = ids4[g];
-            const float px[4] = {a.x, a.w, b.z, c.y};
-            const float py[4] = {a.y, b.x, b.w, c.z};
-            const float pz[4] = {a.z, b.y, c.x, c.w};
-            const unsigned ids[4] = {id.x, id.y, id.z, id.w};
-            if (PASS_B)
-                splat_points_ids<L1 ? MODE_HIZ_L1 : MODE_HIZ, 4>(px, py, pz, ids, 4, M, W, H, keys, sink, hiz, nbx, stp);
-            else
-                splat_points_ids<L1 ? MODE_AGENT_L1 : MODE_AGENT, 4>(px, py, pz, ids, 4, M, W, H, keys, sink, nullptr, 0, stp);
+            t = __builtin_amdgcn_readfirstlane(tn);
         }
     }
-    if (stats && lane == 0) {
-        for (int i = 0; i < 3; ++i) atomicAdd(stats + (PASS_B ? 4 : 0) + i, (unsigned long long)st_local[i]);
-        atomicAdd(stats + (PASS_B ? 11 : 8), (unsigned long long)n_proc);
-        if (PASS_B) atomicAdd(stats + 9, (unsigned long long)n_cull);
+    if (stats) {
+        for (int i = 0; i < 3; ++i) {
+            unsigned v = st[i];
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+            if (lane == 0 && v) atomicAdd(stats + (PASS_B ? 4 : 0) + i, (unsigned long long)v);
+        }
+        if (lane == 0) {
+            atomicAdd(stats + (PASS_B ? 11 : 8), (unsigned long long)(n_done - n_cull));
+            if (PASS_B) atomicAdd(stats + 9, (unsigned long long)n_cull);
+        }
     }
 }
 
-
-// ---- software-pipelined point pass (MODE_AGENT and MODE_HIZ) ------------------------------------------
-// vmcnt retires in order and counts atomics, so in the straightforward loop every wave-iteration that
-// issued an atomic waits out its memory-side round trip before it may consume the next group's loads
-// (measured: 1.9 M filtered atomics cost as much as 200 us, ~5x their throughput cost).  Here an iteration
-//   1. issues the loads of the NEXT point group,
-//   2. projects the current group and issues its early-z reads,
-//   3. issues the atomics that the PREVIOUS iteration decided on (younger than 1./2., so waiting for the
-//      reads does not wait for them; they have a whole iteration to complete),
-//   4. consumes the early-z reads and records this iteration's survivors as pending.
-// sub_sel: 0 all point chunks, 1 only chunks with (chunk % sub_mod) == 0 (bootstrap), 2 only the others.
-template <bool HIZ>
-__global__ __launch_bounds__(HIZ ? 1024 : 256) void splat_pipe_kernel(const float *__restrict__ xyz, long long n,
-                                                                      CamSet cams, int B, int W, int H,
-                                                                      unsigned long long *__restrict__ keys,
-                                                                      const unsigned short *__restrict__ hiz_g, int nbx,
-                                                                      int nblocks, int sub_mod, int sub_sel,
-                                                                      unsigned long long *stats)
+// bound[block] = max over the block's pixels of the current depth bound, "none" if any pixel has no bound yet
+__global__ __launch_bounds__(256) void cells_hiz_kernel(const unsigned *__restrict__ zimg, int W, int H, int nbx, int nby,
+                                                        unsigned short *__restrict__ hiz)
 {
-    extern __shared__ __attribute__((aligned(16))) unsigned short hiz[];
-    if (HIZ) {
-        for (int i = threadIdx.x; i < nblocks; i += blockDim.x) hiz[i] = hiz_g[i];
-        __syncthreads();
-    }
-    const long long npx = (long long)W * H;
-    const long long groups = n / PTS_PER_THREAD;
-    const long long tid0 = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    const long long nthreads = (long long)gridDim.x * blockDim.x;
-    const float4 *xyz4 = reinterpret_cast<const float4 *>(xyz);
-    unsigned st_local[3] = {0, 0, 0};
-
-    auto wanted = [&](long long g) {
-        if (sub_sel == 0) return true;
-        const bool boot = ((g >> 8) % sub_mod) == 0;
-        return sub_sel == 1 ? boot : !boot;
-    };
-    auto advance = [&](long long g) {            // next group of this thread that belongs to the pass
-        while (g < groups && !wanted(g)) g += nthreads;
-        return g;
-    };
-
-    long long pidx[4] = {-1, -1, -1, -1};        // pending atomics: index into keys (camera offset included)
-    unsigned long long pkey[4] = {0, 0, 0, 0};
-    long long g = advance(tid0);
-    float4 a, b, c;
-    if (g < groups) {
-        a = xyz4[3 * g + 0];
-        b = xyz4[3 * g + 1];
-        c = xyz4[3 * g + 2];
-    }
-    while (g < groups) {
-        const long long gn = advance(g + nthreads);
-        float4 an = a, bn = b, cn = c;
-        if (gn < groups) {                        // 1. next group's loads first
-            an = xyz4[3 * gn + 0];
-            bn = xyz4[3 * gn + 1];
-            cn = xyz4[3 * gn + 2];
-        }
-        const float px[4] = {a.x, a.w, b.z, c.y};
-        const float py[4] = {a.y, b.x, b.w, c.z};
-        const float pz[4] = {a.z, b.y, c.x, c.w};
-        const unsigned id0 = (unsigned)(g * PTS_PER_THREAD);
-        for (int cam = 0; cam < B; ++cam) {
-            int pix[4];
-            unsigned long long key[4], seen[4];
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= nbx * nby) return;
+    const int bx = b % nbx, by = b / nbx;
+    unsigned m = 0;
+    if (bx * 4 + 3 < W) {
 #pragma unroll
-            for (int k = 0; k < 4; ++k) {         // 2. project + early-z reads
-                float d;
-                int xx, yy;
-                pix[k] = project_one(px[k], py[k], pz[k], cams.m[cam], W, H, d, xx, yy);
-                if (stats && pix[k] >= 0) st_local[0]++;
-                if (HIZ) {
-                    if (hiz_reject(hiz[pix[k] >= 0 ? (yy >> 2) * nbx + (xx >> 2) : 0], d)) pix[k] = -1;
-                }
-                if (stats && pix[k] >= 0) st_local[1]++;
-                key[k] = ((unsigned long long)__float_as_uint(d) << 32) | (id0 + k);
+        for (int dy = 0; dy < 4; ++dy)
+            if (by * 4 + dy < H) {
+                const uint4 v = *reinterpret_cast<const uint4 *>(zimg + (long long)(by * 4 + dy) * W + bx * 4);   // W % 16 == 0
+                m = max(max(m, v.x), max(max(v.y, v.z), v.w));
             }
-#pragma unroll
-            for (int k = 0; k < 4; ++k)
-                seen[k] = pix[k] >= 0 ? peek_key<MODE_AGENT>(keys + cam * npx + pix[k]) : 0ull;
-            __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-            for (int k = 0; k < 4; ++k)           // 3. the previous step's atomics
-                if (pidx[k] >= 0) fold_key<MODE_AGENT>(keys + pidx[k], pkey[k]);
-            __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-            for (int k = 0; k < 4; ++k) {         // 4. decide; keys only decrease, so a stale read is conservative
-                const bool win = key[k] < seen[k];
-                pidx[k] = win ? cam * npx + pix[k] : -1;
-                pkey[k] = key[k];
-                if (stats && win) st_local[2]++;
-            }
-        }
-        a = an;
-        b = bn;
-        c = cn;
-        g = gn;
     }
-#pragma unroll
-    for (int k = 0; k < 4; ++k)
-        if (pidx[k] >= 0) fold_key<MODE_AGENT>(keys + pidx[k], pkey[k]);
-    // tail (n % 4 points): left to the pass that takes "the others"
-    if (sub_sel != 1) {
-        unsigned sink = 0;
-        for (long long i = groups * PTS_PER_THREAD + tid0; i < n; i += nthreads) {
-            const float px[1] = {xyz[3 * i + 0]}, py[1] = {xyz[3 * i + 1]}, pz[1] = {xyz[3 * i + 2]};
-            for (int cam = 0; cam < B; ++cam)
-                splat_points<MODE_AGENT, 1>(px, py, pz, (unsigned)i, 1, cams.m[cam], W, H, keys + cam * npx, sink);
-        }
-    }
-    if (stats)
-        for (int i = 0; i < 3; ++i) atomicAdd(stats + (HIZ ? 4 : 0) + i, (unsigned long long)st_local[i]);
+    hiz[b] = hiz_encode(m);
 }
 
 struct ResolveOut {
@@ -683,10 +666,12 @@ __device__ __forceinline__ unsigned long long kmin(unsigned long long a, unsigne
 
 // One 256-thread block = a 32x32 tile of level 0; thread (qx,qy) owns a 2x2 quad.
 // Levels 2..4 are reduced through LDS (16x16 -> 8x8 -> 4x4 -> 2x2 keys).
+// keep: 0 nothing, 1 record the winners' ids (plain-path warm start), 2 striped frame (reset zimg and the strip
+// counters, flip the seed-image parity).
 __global__ __launch_bounds__(256) void splat_resolve_kernel(unsigned long long *__restrict__ keys, int W, int H,
                                                             int levels, ResolveOut out, int tiles_x,
-                                                            int tiles_y, int copies, int *__restrict__ prev_idx,
-                                                            SplatHeader *hdr)
+                                                            int tiles_y, int *__restrict__ prev_idx,
+                                                            void *hdr_v, int keep, unsigned *__restrict__ zimg)
 {
     __shared__ unsigned long long s1[256], s2[64], s3[16];
     const int cam = blockIdx.y;
@@ -695,7 +680,7 @@ __global__ __launch_bounds__(256) void splat_resolve_kernel(unsigned long long *
     const int qx = t & 15, qy = t >> 4;
     const int x0 = tx * 32 + qx * 2, y0 = ty * 32 + qy * 2;
     const long long npx0 = (long long)W * H;
-    unsigned long long *kc = keys + (long long)cam * copies * npx0;
+    unsigned long long *kc = keys + (long long)cam * npx0;
 
     unsigned long long k[2][2];
 #pragma unroll
@@ -706,21 +691,29 @@ __global__ __launch_bounds__(256) void splat_resolve_kernel(unsigned long long *
             unsigned long long v = EMPTY_KEY;
             if (x < W && y < H) {
                 const long long off = (long long)y * W + x;
-                for (int c = 0; c < copies; ++c) {   // min over the per-XCD images
-                    v = kmin(v, kc[c * npx0 + off]);
-                    kc[c * npx0 + off] = EMPTY_KEY;  // leave the workspace clean for the next frame
-                }
+                v = kc[off];
+                kc[off] = EMPTY_KEY;                 // leave the workspace clean for the next frame
                 emit(out, 0, cam * npx0 + off, v);
-                if (prev_idx) prev_idx[off] = v == EMPTY_KEY ? -1 : (int)(unsigned)(v & 0xffffffffull);   // next frame's seeds
+                if (keep == 1) prev_idx[off] = v == EMPTY_KEY ? -1 : (int)(unsigned)(v & 0xffffffffull);   // next frame's seeds
+                if (keep == 2) zimg[off] = 0xffffffffu;       // "no bound"
             }
             k[dy][dx] = v;
         }
-    if (hdr && blockIdx.x == 0 && blockIdx.y == 0 && t == 0) {
-        hdr->valid = 1;
-        hdr->W = W;
-        hdr->H = H;
-        ((int *)((char *)hdr + 192))[0] = 0;       // list lengths of the cell-ordered passes (CELL_COUNTER_OFFSET)
-        ((int *)((char *)hdr + 192))[1] = 0;
+    if (keep && blockIdx.x == 0 && blockIdx.y == 0) {
+        SplatHeader *hdr = (SplatHeader *)hdr_v;
+        if (keep == 2 && t < MAX_STRIPS) {
+            StripCounters *sc = strip_counters(hdr_v, t);
+            sc->nA = sc->nB = 0;
+            sc->headA = sc->headB = 0;
+        }
+        if (t == 0) {
+            // any integer below the padded point count is the position of a real point, i.e. a valid seed, so the two
+            // seed images need no initialisation discipline beyond "flip after every striped frame"
+            if (keep == 2) hdr->parity ^= 1;
+            hdr->valid = keep;
+            hdr->W = W;
+            hdr->H = H;
+        }
     }
     if (levels < 2) return;
     const unsigned long long k1 = kmin(kmin(k[0][0], k[0][1]), kmin(k[1][0], k[1][1]));
@@ -780,19 +773,26 @@ int level_dim(int v, int l)
 }
 
 int g_splat_mode = MODE_HIZ;
-int g_splat_subset = 8;        // MODE_HIZ bootstrap pass over every g_splat_subset-th 1024-point chunk (0 = seeds only).
+int g_splat_subset = 8;        // plain MODE_HIZ bootstrap pass over every g_splat_subset-th 1024-point chunk (0 = seeds only).
                                // Measured at 30 M points: 0.307 ms seeds only, 0.252 / 0.233 / 0.235 / 0.260 ms at 4 / 8 / 16 / 32
-int g_splat_pipe = 0;          // 1: software-pipelined point pass (measured slower: 0.43 vs 0.39 ms in MODE_AGENT)
 int g_splat_stats = 0;         // debug: accumulate counters in the workspace header (u64 at byte 64: pass A visible /
-                               // survivors / atomics / -, pass B visible / survivors / atomics)
+                               // early-z reads / atomics / -, pass B visible / after hi-z / atomics / -, A items run,
+                               // B chunks culled, -, B items run)
+int g_splat_near = 12;         // cell path: pass A takes chunks nearer than the depth at which a pixel expects this many points
+int g_splat_cells = 1;         // 0: ignore the cell-ordered copy (A/B)
+int g_splat_cells_sub = 32;    // list A also takes every n-th chunk (0: none): a first bound where nothing is near
+int g_splat_seeds = 1;         // 0: no warm start from the previous frame's front points (A/B)
+int g_splat_items = 1;         // work items per chunk in the striped passes (1, 2 or 4)
 
 // Workspace layout (fixed by the (B, W, H) it was sized for; one workspace serves one such triple):
-//   [header 256 B][key images: min(B,8) x 8 x W*H x 8 B][hi-z bounds: ceil(W/4)*ceil(H/4) x 4 B][previous winners: W*H x 4 B]
+//   [header 4096 B][key images: min(B,8) x W*H x 8 B][hi-z bounds: ceil(W/4)*ceil(H/4) x 4 B][seed image 0: W*H x 4 B]
+//   [seed image 1: W*H x 4 B][zimg: W*H x 4 B depth upper bounds of the striped path, 0xffffffff = none]
 struct WsLayout {
-    SplatHeader *hdr;
+    void *hdr;
     unsigned long long *keys;
     unsigned short *hiz;       // 16-bit far bounds (the region keeps its 4 bytes per block)
-    int *prev;
+    int *prev[2];              // plain path: prev[0] = winners' ids; striped path: positions, double buffered
+    unsigned *zimg;
     int nbx, nby;
     size_t total;
 };
@@ -802,78 +802,84 @@ WsLayout ws_layout(void *ws, int B, int W, int H)
     WsLayout L;
     const int nb = B < MAX_CAMS ? B : MAX_CAMS;
     char *p = (char *)ws;
-    L.hdr = (SplatHeader *)p;
+    L.hdr = p;
     size_t off = HEADER_BYTES;
     L.keys = (unsigned long long *)(p + off);
-    off += (size_t)nb * XCD_COPIES * W * H * sizeof(unsigned long long);
+    off += (size_t)nb * W * H * sizeof(unsigned long long);
+    off = (off + 255) / 256 * 256;
     L.nbx = ceil_div(W, 4);
     L.nby = ceil_div(H, 4);
     L.hiz = (unsigned short *)(p + off);
     off += ((size_t)L.nbx * L.nby * sizeof(float) + 255) / 256 * 256;
-    L.prev = (int *)(p + off);
-    off += (size_t)W * H * sizeof(int);
-    L.total = (off + 255) / 256 * 256;
+    for (int i = 0; i < 2; ++i) {
+        L.prev[i] = (int *)(p + off);
+        off += ((size_t)W * H * sizeof(int) + 255) / 256 * 256;
+    }
+    L.zimg = (unsigned *)(p + off);
+    off += ((size_t)W * H * sizeof(unsigned) + 255) / 256 * 256;
+    L.total = off;
     return L;
 }
 
 constexpr size_t HIZ_LDS_LIMIT = 150 * 1024;   // of the 160 KiB per CU
 
-int g_splat_near = 12;         // cell path: pass A takes chunks nearer than the depth at which a pixel expects this many points
-int g_splat_cells = 1;         // 0: ignore the cell-ordered copy (A/B)
-int g_splat_l1 = 1;            // early-z reads of the cell-ordered passes through the L1 (0: L2, A/B)
-int g_splat_cells_sub = 32;    // list A also takes every n-th chunk (0: none): a first bound where nothing is near
-int g_splat_seeds = 1;         // 0: no warm start from the previous frame's winners (A/B)
+int device_cus()
+{
+    static int n_cu = 0;
+    if (!n_cu) {
+        int dev = 0;
+        hipDeviceProp_t prop;
+        n_cu = (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess &&
+                prop.multiProcessorCount > 0) ? prop.multiProcessorCount : 256;
+    }
+    return n_cu;
+}
 
+int resolve_launch(unsigned long long *keys, int nb, int b0, int W, int H, int levels, int32_t *const *idx_levels,
+                   float *const *depth_levels, int level_base, const WsLayout &ws, int keep, hipStream_t stream)
+{
+    ResolveOut out;
+    memset(&out, 0, sizeof(out));
+    for (int l = 0; l < levels; ++l) {
+        const size_t lpx = (size_t)level_dim(W, l) * level_dim(H, l);
+        if (idx_levels && idx_levels[level_base + l]) out.idx[l] = idx_levels[level_base + l] + lpx * b0;
+        if (depth_levels && depth_levels[level_base + l]) out.depth[l] = depth_levels[level_base + l] + lpx * b0;
+    }
+    const int tiles_x = ceil_div(W, 32), tiles_y = ceil_div(H, 32);
+    hipLaunchKernelGGL(splat_resolve_kernel, dim3(tiles_x * tiles_y, nb), dim3(256), 0, stream, keys, W, H,
+                       levels, out, tiles_x, tiles_y, ws.prev[0], ws.hdr, keep, ws.zimg);
+    READ_CHECK_LAUNCH();
+    return READ_OK;
+}
+
+// ---- plain path ------------------------------------------------------------------------------------------------------
 int project_and_resolve(const float *xyz, int64_t n, const float *M_host, int B, int W, int H, int levels,
                         int32_t *const *idx_levels, float *const *depth_levels, int level_base,
-                        const WsLayout &ws, bool allow_hiz, hipStream_t stream, const CellCloud *cells = nullptr)
+                        const WsLayout &ws, bool allow_hiz, hipStream_t stream)
 {
     unsigned long long *keys = ws.keys;
     const size_t hiz_bytes = (((size_t)ws.nbx * ws.nby * sizeof(unsigned short)) + 15) & ~(size_t)15;
     const bool use_hiz = g_splat_mode == MODE_HIZ && allow_hiz && B == 1 && n > 0 && hiz_bytes <= HIZ_LDS_LIMIT &&
                          ((uintptr_t)xyz % 16) == 0;
-    const int mode = g_splat_mode == MODE_HIZ ? MODE_AGENT : g_splat_mode;
-    const int copies = mode == MODE_XCD ? XCD_COPIES : 1;
     for (int b0 = 0; b0 < B; b0 += MAX_CAMS) {
         const int nb = (B - b0) < MAX_CAMS ? (B - b0) : MAX_CAMS;
         CamSet cams;
         memset(&cams, 0, sizeof(cams));
         memcpy(cams.m, M_host + 16 * (size_t)b0, sizeof(float) * 16 * (size_t)nb);
         const int vec_ok = ((uintptr_t)xyz % 16) == 0;
-        unsigned long long *stats = g_splat_stats ? (unsigned long long *)((char *)ws.hdr + 64) : nullptr;
+        unsigned long long *stats = g_splat_stats ? (unsigned long long *)((char *)ws.hdr + HEADER_STATS_OFFSET) : nullptr;
         if (use_hiz) {
             // bootstrap: a strided 1/sub of the cloud (only when the vector path is usable) on top of the seeds,
             // so that nearly every pixel is covered before the bounds are taken
             const int sub = (vec_ok && g_splat_subset > 1 && n >= (1 << 20)) ? g_splat_subset : 0;
-            static int n_cu_c = 0;
-            if (!n_cu_c) {
-                int dev = 0;
-                hipDeviceProp_t prop;
-                n_cu_c = (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess &&
-                          prop.multiProcessorCount > 0) ? prop.multiProcessorCount : 256;
-            }
-            const bool use_cells = cells && g_splat_cells;
-            const int *counts = (const int *)((const char *)ws.hdr + CELL_COUNTER_OFFSET);
-            CellCloud cc_none;
-            memset(&cc_none, 0, sizeof(cc_none));
-            const int pix_blocks = ceil_div(W * H, 256);
-            // seeds (previous winners re-projected) + classification of the chunks of the cell-ordered cloud
-            hipLaunchKernelGGL(splat_seed_kernel, dim3(pix_blocks + (use_cells ? ceil_div(cells->nchunks, 256) : 0)), dim3(256),
-                               0, stream, xyz, (long long)n, cams, W, H, keys, ws.hdr, g_splat_seeds ? ws.prev : (int *)nullptr,
-                               use_cells ? *cells : cc_none,
-                               pix_blocks, g_splat_cells_sub, (float)g_splat_near);
+            hipLaunchKernelGGL(splat_seed_kernel, dim3(ceil_div(W * H, 256)), dim3(256), 0, stream, xyz, (long long)n, cams,
+                               W, H, keys, (const SplatHeader *)ws.hdr, g_splat_seeds ? ws.prev[0] : (int *)nullptr);
             READ_CHECK_LAUNCH();
-            if (use_cells) {
-                // pass A: near chunks + every (2 sub)-th chunk, straight early-z splat, one wave per chunk
-                auto kern_a = g_splat_l1 ? splat_cells_kernel<false, true> : splat_cells_kernel<false, false>;
-                hipLaunchKernelGGL(kern_a, dim3((unsigned)(n_cu_c * 8)), dim3(256), 0, stream, *cells, cams,
-                                   W, H, keys, (const unsigned short *)nullptr, ws.nbx, ws.nby, counts, stats);
-                READ_CHECK_LAUNCH();
-            } else if (sub) {
+            if (sub) {
                 int64_t blocks = ceil_div64(ceil_div64(n, PTS_PER_THREAD), 256);
                 if (blocks > 256 * 8) blocks = 256 * 8;
-                hipLaunchKernelGGL(splat_project_kernel<MODE_AGENT>, dim3((unsigned)blocks), dim3(256), 0, stream, xyz,
-                                   (long long)n, cams, 1, W, H, keys, vec_ok, (unsigned *)nullptr, sub, stats);
+                hipLaunchKernelGGL(splat_project_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, xyz,
+                                   (long long)n, cams, 1, W, H, keys, vec_ok, sub, stats);
                 READ_CHECK_LAUNCH();
             }
             hipLaunchKernelGGL(splat_hiz_kernel, dim3(ceil_div(ws.nbx * ws.nby, 256)), dim3(256), 0, stream, keys, W, H,
@@ -881,81 +887,71 @@ int project_and_resolve(const float *xyz, int64_t n, const float *M_host, int B,
             READ_CHECK_LAUNCH();
             static bool attr_set = false;
             if (!attr_set) {
-                READ_CHECK_HIP(hipFuncSetAttribute((const void *)splat_pipe_kernel<true>,
-                                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)HIZ_LDS_LIMIT));
                 READ_CHECK_HIP(hipFuncSetAttribute((const void *)splat_project_hiz_kernel,
                                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)HIZ_LDS_LIMIT));
                 attr_set = true;
             }
-            static int n_cu = 0;
-            if (!n_cu) {
-                int dev = 0;
-                hipDeviceProp_t prop;
-                n_cu = (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess &&
-                        prop.multiProcessorCount > 0) ? prop.multiProcessorCount : 256;
-            }
+            const int n_cu = device_cus();
             int64_t blocks = ceil_div64(ceil_div64(n, PTS_PER_THREAD), 1024);
             const int per_cu = 2 * hiz_bytes <= 150 * 1024 ? 2 : 1;     // two workgroups per CU when their bounds fit
             if (blocks > (int64_t)n_cu * per_cu) blocks = (int64_t)n_cu * per_cu;
-            if (use_cells) {
-                static bool attr_c = false;
-                if (!attr_c) {
-                    auto kb0 = splat_cells_kernel<true, false>;
-                    auto kb1 = splat_cells_kernel<true, true>;
-                    READ_CHECK_HIP(hipFuncSetAttribute((const void *)kb0, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                                       (int)HIZ_LDS_LIMIT));
-                    READ_CHECK_HIP(hipFuncSetAttribute((const void *)kb1, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                                       (int)HIZ_LDS_LIMIT));
-                    attr_c = true;
-                }
-                auto kern_b = g_splat_l1 ? splat_cells_kernel<true, true> : splat_cells_kernel<true, false>;
-                hipLaunchKernelGGL(kern_b, dim3((unsigned)(n_cu * per_cu)), dim3(1024), hiz_bytes, stream,
-                                   *cells, cams, W, H, keys, ws.hiz, ws.nbx, ws.nby, counts, stats);
-            } else if (g_splat_pipe && !sub)
-                hipLaunchKernelGGL(splat_pipe_kernel<true>, dim3((unsigned)blocks), dim3(1024), hiz_bytes, stream, xyz,
-                                   (long long)n, cams, 1, W, H, keys, ws.hiz, ws.nbx, ws.nbx * ws.nby, sub, sub ? 2 : 0, stats);
-            else
-                hipLaunchKernelGGL(splat_project_hiz_kernel, dim3((unsigned)blocks), dim3(1024), hiz_bytes, stream, xyz,
-                                   (long long)n, cams, W, H, keys, vec_ok, ws.hiz, ws.nbx, ws.nbx * ws.nby, sub, stats);
+            hipLaunchKernelGGL(splat_project_hiz_kernel, dim3((unsigned)blocks), dim3(1024), hiz_bytes, stream, xyz,
+                               (long long)n, cams, W, H, keys, vec_ok, ws.hiz, ws.nbx, ws.nbx * ws.nby, sub, stats);
             READ_CHECK_LAUNCH();
         } else if (n > 0) {
             const int64_t work = ceil_div64(n, PTS_PER_THREAD);
             // HBM-bound stream: cap the grid at 256 CUs x 8 blocks and grid-stride the rest
             int64_t blocks = ceil_div64(work, 256);
             if (blocks > 256 * 8) blocks = 256 * 8;
-            if (mode == MODE_AGENT && vec_ok && g_splat_pipe) {
-                hipLaunchKernelGGL(splat_pipe_kernel<false>, dim3((unsigned)blocks), dim3(256), 0, stream, xyz, (long long)n,
-                                   cams, nb, W, H, keys, (const unsigned short *)nullptr, 0, 0, 0, 0, stats);
-                READ_CHECK_LAUNCH();
-            } else {
-            auto kern = mode == MODE_XCD ? splat_project_kernel<MODE_XCD>
-                        : mode == MODE_AGENT ? splat_project_kernel<MODE_AGENT>
-                        : mode == MODE_SYS ? splat_project_kernel<MODE_SYS>
-                        : mode == MODE_PEEK ? splat_project_kernel<MODE_PEEK>
-                        : mode == MODE_PEEK_L1 ? splat_project_kernel<MODE_PEEK_L1>
-                        : mode == MODE_ATOM ? splat_project_kernel<MODE_ATOM> : splat_project_kernel<MODE_NOZ>;
-            hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(256), 0, stream, xyz, (long long)n, cams, nb, W, H,
-                               keys, vec_ok, (unsigned *)nullptr, 0, stats);
+            hipLaunchKernelGGL(splat_project_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, xyz, (long long)n, cams,
+                               nb, W, H, keys, vec_ok, 0, stats);
             READ_CHECK_LAUNCH();
-            }
         }
-        ResolveOut out;
-        memset(&out, 0, sizeof(out));
-        for (int l = 0; l < levels; ++l) {
-            const size_t lpx = (size_t)level_dim(W, l) * level_dim(H, l);
-            if (idx_levels && idx_levels[level_base + l]) out.idx[l] = idx_levels[level_base + l] + lpx * b0;
-            if (depth_levels && depth_levels[level_base + l])
-                out.depth[l] = depth_levels[level_base + l] + lpx * b0;
-        }
-        const int tiles_x = ceil_div(W, 32), tiles_y = ceil_div(H, 32);
         // the winners of a single-camera frame seed the next frame rendered through this workspace
         const bool keep = g_splat_mode == MODE_HIZ && allow_hiz && B == 1;
-        hipLaunchKernelGGL(splat_resolve_kernel, dim3(tiles_x * tiles_y, nb), dim3(256), 0, stream, keys, W, H,
-                           levels, out, tiles_x, tiles_y, copies, keep ? ws.prev : (int *)nullptr,
-                           keep ? ws.hdr : (SplatHeader *)nullptr);
-        READ_CHECK_LAUNCH();
+        const int rc = resolve_launch(keys, nb, b0, W, H, levels, idx_levels, depth_levels, level_base, ws, keep ? 1 : 0,
+                                      stream);
+        if (rc != READ_OK) return rc;
     }
     return READ_OK;
+}
+
+// ---- striped path ----------------------------------------------------------------------------------------------------
+StripInfo make_strips(int W)
+{
+    StripInfo si;
+    memset(&si, 0, sizeof(si));
+    const int cols = W / 16;                                   // 128-byte lines of keys per image row
+    si.ns = MAX_STRIPS < cols ? MAX_STRIPS : cols;
+    for (int s = 0; s <= si.ns; ++s) si.xb[s] = 16 * (int)((long long)cols * s / si.ns);
+    for (int s = si.ns + 1; s <= MAX_STRIPS; ++s) si.xb[s] = W;
+    return si;
+}
+
+int cells_frame(const CellCloud &cc, const float *M_host, int W, int H, int levels, int32_t *const *idx_levels,
+                float *const *depth_levels, const WsLayout &ws, hipStream_t stream)
+{
+    const StripInfo si = make_strips(W);
+    Cam1 cam;
+    memcpy(cam.m, M_host, sizeof(cam.m));
+    unsigned long long *stats = g_splat_stats ? (unsigned long long *)((char *)ws.hdr + HEADER_STATS_OFFSET) : nullptr;
+    const int seed_blocks = ceil_div(W * H, 256);
+    hipLaunchKernelGGL(cells_seed_classify_kernel, dim3((unsigned)(seed_blocks + ceil_div(cc.nchunks, 256))), dim3(256), 0,
+                       stream, cc, cam, W, H, ws.zimg, ws.hdr, (const int *)ws.prev[0], (const int *)ws.prev[1], si,
+                       seed_blocks, g_splat_cells_sub, (float)g_splat_near, g_splat_seeds);
+    READ_CHECK_LAUNCH();
+    const unsigned grid = (unsigned)(device_cus() * 8);
+    const int items = g_splat_items;
+    hipLaunchKernelGGL(cells_pass_kernel<false>, dim3(grid), dim3(256), 0, stream, cc, cam, W, H, ws.keys, ws.zimg,
+                       (const unsigned short *)ws.hiz, ws.nbx, ws.hdr, ws.prev[0], ws.prev[1], si, items, stats);
+    READ_CHECK_LAUNCH();
+    hipLaunchKernelGGL(cells_hiz_kernel, dim3(ceil_div(ws.nbx * ws.nby, 256)), dim3(256), 0, stream,
+                       (const unsigned *)ws.zimg, W, H, ws.nbx, ws.nby, ws.hiz);
+    READ_CHECK_LAUNCH();
+    hipLaunchKernelGGL(cells_pass_kernel<true>, dim3(grid), dim3(256), 0, stream, cc, cam, W, H, ws.keys, ws.zimg,
+                       (const unsigned short *)ws.hiz, ws.nbx, ws.hdr, ws.prev[0], ws.prev[1], si, items, stats);
+    READ_CHECK_LAUNCH();
+    return resolve_launch(ws.keys, 1, 0, W, H, levels, idx_levels, depth_levels, 0, ws, 2, stream);
 }
 
 }  // namespace
@@ -969,32 +965,49 @@ extern "C" size_t read_splat_workspace_bytes(int B, int W, int H)
 namespace readhip {
 void splat_set_subset(int v) { g_splat_subset = v < 0 ? 0 : v; }
 void splat_set_stats(int v) { g_splat_stats = v; }
-void splat_set_pipe(int v) { g_splat_pipe = v; }
 int splat_set_mode(int m)
 {
-    if (m < MODE_XCD || m > MODE_HIZ) return READ_EINVAL;
+    if (m != MODE_AGENT && m != MODE_HIZ) return READ_EINVAL;
     g_splat_mode = m;
     return READ_OK;
 }
+void splat_set_near(int v) { g_splat_near = v < 1 ? 1 : v; }
+void splat_set_cells(int v) { g_splat_cells = v; }
+void splat_set_seeds(int v) { g_splat_seeds = v; }
+void splat_set_cells_sub(int v) { g_splat_cells_sub = v < 0 ? 0 : v; }
+void splat_set_items(int v) { g_splat_items = v >= 4 ? 4 : (v >= 2 ? 2 : 1); }
+int splat_get(const char *key, int *value)
+{
+    if (!strcmp(key, "splat_mode")) *value = g_splat_mode;
+    else if (!strcmp(key, "splat_subset")) *value = g_splat_subset;
+    else if (!strcmp(key, "splat_stats")) *value = g_splat_stats;
+    else if (!strcmp(key, "splat_near")) *value = g_splat_near;
+    else if (!strcmp(key, "splat_cells")) *value = g_splat_cells;
+    else if (!strcmp(key, "splat_seeds")) *value = g_splat_seeds;
+    else if (!strcmp(key, "splat_cells_sub")) *value = g_splat_cells_sub;
+    else if (!strcmp(key, "splat_items")) *value = g_splat_items;
+    else return 0;
+    return 1;
+}
 }
 
-__global__ __launch_bounds__(64) void splat_header_clear_kernel(int *hdr)
+__global__ __launch_bounds__(256) void splat_header_clear_kernel(int *hdr)
 {
-    hdr[threadIdx.x] = 0;       // 64 ints = the 256-byte header: no previous frame
+    for (int i = threadIdx.x; i < (int)(HEADER_BYTES / 4); i += blockDim.x) hdr[i] = 0;    // "no previous frame"
 }
 
 extern "C" int read_splat_workspace_init(void *ws, size_t ws_bytes, void *stream)
 {
     READ_CHECK_ARG(ws && ws_bytes % 8 == 0, "read_splat_workspace_init: workspace null or not a multiple of 8 bytes");
     // everything becomes EMPTY (all ones); the header is then zeroed: "no previous frame"
-    READ_CHECK_ARG((uintptr_t)ws % 16 == 0, "read_splat_workspace_init: workspace must be 16-byte aligned");
+    READ_CHECK_ARG((uintptr_t)ws % 256 == 0, "read_splat_workspace_init: workspace must be 256-byte aligned");
     const long long count = (long long)(ws_bytes / 8);
     if (count == 0) return READ_OK;
     hipLaunchKernelGGL(fill_keys_kernel, dim3((unsigned)ceil_div64(count, 256)), dim3(256), 0, as_stream(stream),
                        (unsigned long long *)ws, count);
     READ_CHECK_LAUNCH();
     if (ws_bytes >= HEADER_BYTES) {
-        hipLaunchKernelGGL(splat_header_clear_kernel, dim3(1), dim3(64), 0, as_stream(stream), (int *)ws);
+        hipLaunchKernelGGL(splat_header_clear_kernel, dim3(1), dim3(256), 0, as_stream(stream), (int *)ws);
         READ_CHECK_LAUNCH();
     }
     return READ_OK;
@@ -1014,7 +1027,7 @@ extern "C" int read_splat_forward(const float *xyz, int64_t n, const float *M_ho
     READ_CHECK_ARG(idx_levels || depth_levels, "read_splat_forward: no outputs requested");
     READ_CHECK_ARG(level_dim(W, levels - 1) >= 1 && level_dim(H, levels - 1) >= 1,
                    "read_splat_forward: coarsest level is empty");
-    READ_CHECK_ARG(ws && (uintptr_t)ws % 16 == 0, "read_splat_forward: workspace null or misaligned");
+    READ_CHECK_ARG(ws && (uintptr_t)ws % 256 == 0, "read_splat_forward: workspace null or not 256-byte aligned");
     if (ws_bytes < read_splat_workspace_bytes(B, W, H)) {
         set_error("read_splat_forward: workspace %zu < %zu bytes", ws_bytes, read_splat_workspace_bytes(B, W, H));
         return READ_ENOMEM;
@@ -1040,25 +1053,24 @@ extern "C" int read_splat_forward(const float *xyz, int64_t n, const float *M_ho
 }
 
 // ---------------------------------------------------------------------------------------------------------------
-// cell-ordered cloud
+// cell-ordered cloud: host build
 // ---------------------------------------------------------------------------------------------------------------
 namespace {
 
 size_t cells_chunks(int64_t n) { return (size_t)((n + CELL_CHUNK - 1) / CELL_CHUNK); }
 
 struct CellOffsets {
-    size_t xyz, ids, aabb, list_a, list_b, total;
+    size_t pts, aabb, list_a, list_b, total;
 };
 CellOffsets cell_offsets(int64_t n)
 {
     const size_t nc = cells_chunks(n);
     CellOffsets o;
-    o.xyz = CELL_HEADER_BYTES;
-    o.ids = o.xyz + nc * CELL_CHUNK * 3 * sizeof(float);
-    o.aabb = o.ids + nc * CELL_CHUNK * sizeof(unsigned);
+    o.pts = CELL_HEADER_BYTES;
+    o.aabb = o.pts + nc * CELL_CHUNK * sizeof(float4);
     o.list_a = o.aabb + nc * 8 * sizeof(float);                      // per-frame scratch (written by the passes)
-    o.list_b = o.list_a + ((nc * sizeof(int) + 15) & ~(size_t)15);
-    o.total = o.list_b + nc * sizeof(CellEntryB);
+    o.list_b = o.list_a + ((MAX_STRIPS * nc * sizeof(int) + 255) & ~(size_t)255);
+    o.total = o.list_b + MAX_STRIPS * nc * sizeof(CellEntryB);
     return o;
 }
 
@@ -1072,6 +1084,19 @@ inline uint32_t spread10(uint32_t v)       // 10 bits -> every third bit
     return v;
 }
 
+// run fn(t, begin, end) over [0, n) split into T contiguous ranges on T host threads
+template <class F>
+void parallel_ranges(size_t n, int T, F fn)
+{
+    if (T <= 1 || n < (size_t)T * 4096) {
+        fn(0, (size_t)0, n);
+        return;
+    }
+    std::vector<std::thread> th;
+    for (int t = 0; t < T; ++t) th.emplace_back(fn, t, n * t / T, n * (t + 1) / T);
+    for (auto &x : th) x.join();
+}
+
 }  // namespace
 
 extern "C" size_t read_splat_cells_bytes(int64_t n)
@@ -1080,72 +1105,115 @@ extern "C" size_t read_splat_cells_bytes(int64_t n)
     return cell_offsets(n).total;
 }
 
-// Host-side build (once per cloud): Morton order over a 1024^3 grid of the bounding box (stable LSD radix sort, so equal
-// codes keep ascending ids), chunks of 1024 consecutive points with their exact bounding boxes.
+// Host-side build (once per cloud, multi-threaded): Morton order over a 1024^3 grid of the bounding box (stable LSD
+// radix sort, so equal codes keep ascending ids), chunks of 1024 consecutive points with their exact bounding boxes.
 extern "C" int read_splat_cells_build_host(const float *xyz, int64_t n, void *blob, size_t blob_bytes)
 {
     READ_CHECK_ARG(xyz && blob, "read_splat_cells_build_host: null pointer");
     READ_CHECK_ARG(n >= 1 && n <= 0xFFFFFFFEll, "read_splat_cells_build_host: n out of range");
     const CellOffsets o = cell_offsets(n);
     READ_CHECK_ARG(blob_bytes >= o.total, "read_splat_cells_build_host: buffer %zu < %zu bytes", blob_bytes, o.total);
-    float lo[3] = {xyz[0], xyz[1], xyz[2]}, hi[3] = {xyz[0], xyz[1], xyz[2]};
-    for (int64_t i = 0; i < n; ++i)
+    const size_t N = (size_t)n;
+    int T = (int)std::thread::hardware_concurrency();
+    T = T < 1 ? 1 : (T > 32 ? 32 : T);
+    if (N < (size_t)T * 4096) T = 1;
+
+    // 1. bounding box + finiteness
+    std::vector<float> tlo((size_t)T * 3, 3.0e38f), thi((size_t)T * 3, -3.0e38f);
+    std::vector<long long> tbad((size_t)T, -1);
+    parallel_ranges(N, T, [&](int t, size_t b, size_t e) {
+        float lo[3] = {3.0e38f, 3.0e38f, 3.0e38f}, hi[3] = {-3.0e38f, -3.0e38f, -3.0e38f};
+        long long bad = -1;
+        for (size_t i = b; i < e; ++i)
+            for (int k = 0; k < 3; ++k) {
+                const float v = xyz[3 * i + k];
+                if (!(v == v && v - v == 0.0f) && bad < 0) bad = (long long)i;
+                lo[k] = v < lo[k] ? v : lo[k];
+                hi[k] = v > hi[k] ? v : hi[k];
+            }
         for (int k = 0; k < 3; ++k) {
-            const float v = xyz[3 * i + k];
-            READ_CHECK_ARG(v == v && v - v == 0.0f, "read_splat_cells_build_host: point %lld is not finite", (long long)i);
-            lo[k] = v < lo[k] ? v : lo[k];
-            hi[k] = v > hi[k] ? v : hi[k];
+            tlo[(size_t)t * 3 + k] = lo[k];
+            thi[(size_t)t * 3 + k] = hi[k];
         }
+        tbad[(size_t)t] = bad;
+    });
+    float lo[3] = {3.0e38f, 3.0e38f, 3.0e38f}, hi[3] = {-3.0e38f, -3.0e38f, -3.0e38f};
+    for (int t = 0; t < T; ++t) {
+        READ_CHECK_ARG(tbad[(size_t)t] < 0, "read_splat_cells_build_host: point %lld is not finite", tbad[(size_t)t]);
+        for (int k = 0; k < 3; ++k) {
+            lo[k] = std::min(lo[k], tlo[(size_t)t * 3 + k]);
+            hi[k] = std::max(hi[k], thi[(size_t)t * 3 + k]);
+        }
+    }
     float ext = 0.0f;
     for (int k = 0; k < 3; ++k) ext = (hi[k] - lo[k]) > ext ? (hi[k] - lo[k]) : ext;
     const float scale = ext > 0.0f ? 1023.999f / ext : 0.0f;
-    std::vector<uint64_t> a((size_t)n), b((size_t)n);
-    for (int64_t i = 0; i < n; ++i) {
-        uint32_t q[3];
-        for (int k = 0; k < 3; ++k) {
-            float t = (xyz[3 * i + k] - lo[k]) * scale;
-            q[k] = t <= 0.0f ? 0u : (t >= 1023.0f ? 1023u : (uint32_t)t);
+
+    // 2. Morton codes (30 bits) with the id in the low word
+    std::vector<uint64_t> a(N), b(N);
+    parallel_ranges(N, T, [&](int, size_t bgn, size_t end) {
+        for (size_t i = bgn; i < end; ++i) {
+            uint32_t q[3];
+            for (int k = 0; k < 3; ++k) {
+                const float t = (xyz[3 * i + k] - lo[k]) * scale;
+                q[k] = t <= 0.0f ? 0u : (t >= 1023.0f ? 1023u : (uint32_t)t);
+            }
+            const uint64_t code = spread10(q[0]) | ((uint64_t)spread10(q[1]) << 1) | ((uint64_t)spread10(q[2]) << 2);
+            a[i] = (code << 32) | (uint64_t)(uint32_t)i;
         }
-        const uint64_t code = spread10(q[0]) | ((uint64_t)spread10(q[1]) << 1) | ((uint64_t)spread10(q[2]) << 2);
-        a[(size_t)i] = (code << 32) | (uint64_t)(uint32_t)i;
-    }
-    for (int pass = 0; pass < 3; ++pass) {                      // 30 code bits, 10 per pass
+    });
+
+    // 3. stable LSD radix sort, 10 bits per pass: per-thread histograms over contiguous ranges keep the order stable
+    std::vector<size_t> hist((size_t)T * 1024);
+    for (int pass = 0; pass < 3; ++pass) {
         const int shift = 32 + 10 * pass;
-        size_t hist[1025] = {0};
-        for (size_t i = 0; i < (size_t)n; ++i) ++hist[((a[i] >> shift) & 1023u) + 1];
-        for (int k = 0; k < 1024; ++k) hist[k + 1] += hist[k];
-        for (size_t i = 0; i < (size_t)n; ++i) b[hist[(a[i] >> shift) & 1023u]++] = a[i];
+        std::fill(hist.begin(), hist.end(), (size_t)0);
+        parallel_ranges(N, T, [&](int t, size_t bgn, size_t end) {
+            size_t *h = hist.data() + (size_t)t * 1024;
+            for (size_t i = bgn; i < end; ++i) ++h[(a[i] >> shift) & 1023u];
+        });
+        size_t run = 0;
+        for (int d = 0; d < 1024; ++d)
+            for (int t = 0; t < T; ++t) {
+                const size_t c = hist[(size_t)t * 1024 + d];
+                hist[(size_t)t * 1024 + d] = run;
+                run += c;
+            }
+        parallel_ranges(N, T, [&](int t, size_t bgn, size_t end) {
+            size_t *h = hist.data() + (size_t)t * 1024;
+            for (size_t i = bgn; i < end; ++i) b[h[(a[i] >> shift) & 1023u]++] = a[i];
+        });
         a.swap(b);
     }
+
+    // 4. records + boxes
     char *base = (char *)blob;
     memset(base, 0, CELL_HEADER_BYTES);
-    float *xs = (float *)(base + o.xyz);
-    unsigned *ids = (unsigned *)(base + o.ids);
+    float *rec = (float *)(base + o.pts);
     float *bb = (float *)(base + o.aabb);
-    const size_t nc = cells_chunks(n), padded = nc * CELL_CHUNK;
-    for (size_t i = 0; i < padded; ++i) {
-        const uint32_t id = (uint32_t)(a[i < (size_t)n ? i : (size_t)n - 1] & 0xffffffffu);   // tail: copies of the last point
-        ids[i] = id;
-        xs[3 * i + 0] = xyz[3 * (size_t)id + 0];
-        xs[3 * i + 1] = xyz[3 * (size_t)id + 1];
-        xs[3 * i + 2] = xyz[3 * (size_t)id + 2];
-    }
-    for (size_t c = 0; c < nc; ++c) {
-        float mn[3], mx[3];
-        for (int k = 0; k < 3; ++k) mn[k] = mx[k] = xs[3 * c * CELL_CHUNK + k];
-        for (size_t i = c * CELL_CHUNK; i < (c + 1) * CELL_CHUNK; ++i)
-            for (int k = 0; k < 3; ++k) {
-                const float v = xs[3 * i + k];
-                mn[k] = v < mn[k] ? v : mn[k];
-                mx[k] = v > mx[k] ? v : mx[k];
+    const size_t nc = cells_chunks(n);
+    parallel_ranges(nc, T, [&](int, size_t cb, size_t ce) {
+        for (size_t c = cb; c < ce; ++c) {
+            float mn[3] = {3.0e38f, 3.0e38f, 3.0e38f}, mx[3] = {-3.0e38f, -3.0e38f, -3.0e38f};
+            for (size_t i = c * CELL_CHUNK; i < (c + 1) * CELL_CHUNK; ++i) {
+                const uint32_t id = (uint32_t)(a[i < N ? i : N - 1] & 0xffffffffu);   // tail: copies of the last point
+                float *r = rec + 4 * i;
+                for (int k = 0; k < 3; ++k) {
+                    const float v = xyz[3 * (size_t)id + k];
+                    r[k] = v;
+                    mn[k] = v < mn[k] ? v : mn[k];
+                    mx[k] = v > mx[k] ? v : mx[k];
+                }
+                memcpy(r + 3, &id, sizeof(id));
             }
-        float *r = bb + 8 * c;
-        r[0] = mn[0]; r[1] = mn[1]; r[2] = mn[2]; r[3] = mx[0]; r[4] = mx[1]; r[5] = mx[2]; r[6] = r[7] = 0.0f;
-    }
+            float *r = bb + 8 * c;
+            r[0] = mn[0]; r[1] = mn[1]; r[2] = mn[2]; r[3] = mx[0]; r[4] = mx[1]; r[5] = mx[2]; r[6] = r[7] = 0.0f;
+        }
+    });
     CellHeader *h = (CellHeader *)base;
     h->n = n;
     h->nchunks = (int)nc;
-    h->version = 1;
+    h->version = CELL_VERSION;
     double vol = 1.0;
     for (int k = 0; k < 3; ++k) {
         h->bbox[k] = lo[k];
@@ -1162,16 +1230,18 @@ extern "C" int read_splat_forward_cells(const float *xyz, void *cells, int64_t n
                                         float *const *depth_levels, void *ws, size_t ws_bytes, void *stream)
 {
     const int mask = levels >= 1 && levels <= READ_MAX_LEVELS ? (1 << (levels - 1)) - 1 : 0;
-    // the cell-ordered passes serve the single-camera, pyramid-identity case (the per-frame render path); everything
-    // else goes through the plain pass
-    if (!cells || B != 1 || n < (1 << 20) || ((W | H) & mask) != 0 || !xyz || !M_host || !ws || W < 1 || H < 1)
+    // the striped passes serve the single-camera, pyramid-identity case with 128-byte-aligned key rows (the per-frame
+    // render path); everything else goes through the plain pass
+    if (!cells || !g_splat_cells || g_splat_mode != MODE_HIZ || B != 1 || n < (1 << 20) || ((W | H) & mask) != 0 ||
+        (W & 15) != 0 || !xyz || !M_host || !ws || W < 1 || H < 1)
         return read_splat_forward(xyz, n, M_host, B, W, H, levels, idx_levels, depth_levels, ws, ws_bytes, stream);
     READ_CHECK_ARG(n <= 0xFFFFFFFEll, "read_splat_forward_cells: point ids must fit 32 bits");
     READ_CHECK_ARG(levels >= 1 && levels <= READ_MAX_LEVELS, "read_splat_forward_cells: levels must be 1..%d",
                    READ_MAX_LEVELS);
     READ_CHECK_ARG(idx_levels || depth_levels, "read_splat_forward_cells: no outputs requested");
     READ_CHECK_ARG((long long)W * H < (1ll << 31), "read_splat_forward_cells: image too large");
-    READ_CHECK_ARG((uintptr_t)ws % 16 == 0 && (uintptr_t)cells % 16 == 0, "read_splat_forward_cells: misaligned pointer");
+    READ_CHECK_ARG((uintptr_t)ws % 256 == 0 && (uintptr_t)cells % 256 == 0,
+                   "read_splat_forward_cells: workspace and cells must be 256-byte aligned");
     if (ws_bytes < read_splat_workspace_bytes(B, W, H)) {
         set_error("read_splat_forward_cells: workspace %zu < %zu bytes", ws_bytes, read_splat_workspace_bytes(B, W, H));
         return READ_ENOMEM;
@@ -1179,22 +1249,13 @@ extern "C" int read_splat_forward_cells(const float *xyz, void *cells, int64_t n
     const CellOffsets o = cell_offsets(n);
     CellCloud cc;
     cc.hdr = (const CellHeader *)cells;
-    cc.xyz = (const float *)((const char *)cells + o.xyz);
-    cc.ids = (const unsigned *)((const char *)cells + o.ids);
+    cc.pts = (const float4 *)((const char *)cells + o.pts);
     cc.aabb = (const float *)((const char *)cells + o.aabb);
     cc.list_a = (int *)((char *)cells + o.list_a);
     cc.list_b = (CellEntryB *)((char *)cells + o.list_b);
     cc.nchunks = (int)cells_chunks(n);
     const WsLayout L = ws_layout(ws, B, W, H);
-    return project_and_resolve(xyz, n, M_host, B, W, H, levels, idx_levels, depth_levels, 0, L, true, as_stream(stream), &cc);
-}
-
-namespace readhip {
-void splat_set_near(int v) { g_splat_near = v < 1 ? 1 : v; }
-void splat_set_cells(int v) { g_splat_cells = v; }
-void splat_set_seeds(int v) { g_splat_seeds = v; }
-void splat_set_l1(int v) { g_splat_l1 = v; }
-void splat_set_cells_sub(int v) { g_splat_cells_sub = v < 0 ? 0 : v; }
+    return cells_frame(cc, M_host, W, H, levels, idx_levels, depth_levels, L, as_stream(stream));
 }
 
 extern "C" int read_index_to_float(const int32_t *idx, int64_t count, float *out, void *stream)

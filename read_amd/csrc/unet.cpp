@@ -609,4 +609,10 @@ extern "C" const float *read_unet_debug_tensor(read_unet_t *u, const char *name,
 
 namespace readhip {
 void unet_set_streams(int v) { g_unet_streams = v; }
+int unet_get(const char *key, int *value)
+{
+    if (strcmp(key, "unet_streams")) return 0;
+    *value = g_unet_streams;
+    return 1;
+}
 }

@@ -18,17 +18,24 @@ LEVELS = 5          # the reference rasterises and gathers 5 scales; the UNet co
 
 
 class FrameRenderer:
-    def __init__(self, xyz, texture_cn, unet_state, W, H, proj_matrix=None, device=None, levels=LEVELS):
-        """xyz (N,3); texture_cn (C,N) descriptors (PointTexture.texture_[0]); unet_state: state dict
-        (tensors or ndarrays) under the reference's names; W,H multiples of 16."""
+    def __init__(self, xyz, texture_cn, unet_state, W, H, proj_matrix=None, device=None, levels=LEVELS, cells=True):
+        """xyz (N,3); texture_cn (C,N) descriptors (PointTexture.texture_[0]); unet_state: state dict (tensors or
+        ndarrays) under the reference's names, or an already packed fp32 blob (1-D tensor, e.g. received from rank 0);
+        W,H multiples of 16; cells: see PointCloudRasterizer."""
         self.device = device if device is not None else _lib.require_gpu()
         if W % 16 or H % 16:
             raise ValueError(f"set width {16 * (W // 16)} / height {16 * (H // 16)}")    # READ/gl/nn.py:107-109
         self.W, self.H, self.levels = W, H, levels
-        self.raster = PointCloudRasterizer(xyz, self.device)
+        self.raster = PointCloudRasterizer(xyz, self.device, cells=cells)
+        if self.raster.n != int(torch.as_tensor(texture_cn).shape[-1]):
+            raise ValueError(f"descriptor table has {int(torch.as_tensor(texture_cn).shape[-1])} columns for a cloud of "
+                             f"{self.raster.n} points")
         tex = torch.as_tensor(texture_cn, dtype=torch.float32).to(self.device).contiguous()
         self.rows = texture_to_rows(tex)
-        self.packed = torch.from_numpy(pack_state(unet_state)).to(self.device)
+        if torch.is_tensor(unet_state):
+            self.packed = unet_state.to(self.device, torch.float32).contiguous()
+        else:
+            self.packed = torch.from_numpy(pack_state(unet_state)).to(self.device)
         self.unet = UNetEngine(self.packed, H, W)
         self.proj = None if proj_matrix is None else np.asarray(proj_matrix, np.float32)
         sizes = level_sizes(W, H, levels)

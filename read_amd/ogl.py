@@ -9,7 +9,7 @@ plan, no ToTensor / host copies (nn.py:115-117)."""
 import torch
 
 from . import _lib
-from .render import MultiscaleRender
+from .render import MultiscaleRender, parse_input_string
 from .texture import gather_pyramid
 
 
@@ -52,19 +52,32 @@ class OGL:
         self.input_format = input_format
         self.renderer = MultiscaleRender(scene, input_format, viewport_size, out_buffer_location='torch',
                                          supersampling=self.model.ss, clear_color=clear_color)
+        # the device-resident fast path of infer() serves exactly the layout TexturePipeline trains with: >= 4 tokens,
+        # token i = 1-px point ids at downscale i; anything else goes through the checked dict path
+        fmts = input_format.replace(' ', '').split(',')
+        try:
+            cfgs = [parse_input_string(t) for t in fmts]
+            self._fast_format = (len(cfgs) >= 4 and all(c['mode'] == 'uv_1d' and c['point_size'] == 1
+                                                        and not c['splat_mode'] and c.get('downscale', 0) == i
+                                                        for i, c in enumerate(cfgs)))
+        except (NotImplementedError, ValueError):
+            self._fast_format = False
 
     def infer(self, input_dict=None):
         """-> {'output': H x W x 4 float tensor (RGB + alpha 1), 'net_input': list of NCHW feature maps}."""
         model = self.model
         texture = model._modules[str(model._loaded_textures[0])] if model._loaded_textures else model._modules['0']
-        fast = (input_dict is None and model.ss == 1 and not model.temporal_average
+        fast = (input_dict is None and model.ss == 1 and not model.temporal_average and self._fast_format
                 and hasattr(model.net, 'engine'))
         with torch.set_grad_enabled(False):
             if fast:
                 scene = self.renderer.scene
                 W, H = self.viewport_size
                 fmts = self.input_format.replace(' ', '').split(',')
-                idx, _ = scene.rasterizer().render(scene.total_matrix(), W, H, len(fmts), want_depth=False)
+                raster = scene.rasterizer()
+                if raster.n != texture.texture_.shape[-1]:
+                    raise ValueError(f"descriptor table has {texture.texture_.shape[-1]} points, the scene cloud {raster.n}")
+                idx, _ = raster.render(scene.total_matrix(), W, H, len(fmts), want_depth=False)
                 feats = gather_pyramid(texture.rows(), idx, texture.activation)
                 out = model.net.engine(H, W).forward(feats[0][0], feats[1][0], feats[2][0], feats[3][0], channels=4)
                 net_input = [f.permute(0, 3, 1, 2) for f in feats]

@@ -24,6 +24,8 @@ class PointCloudRasterizer:
     CELLS_MIN_POINTS = 1 << 20      # below this the plain pass is used (read_splat_forward_cells falls back anyway)
 
     def __init__(self, xyz, device=None, cells=True):
+        """cells: True = build the cell-ordered copy here (host, multi-threaded); False = plain path only; a uint8
+        CUDA tensor = a blob built elsewhere (e.g. by rank 0 and broadcast over RCCL, read_amd/sweep.py)."""
         self.device = device if device is not None else _lib.require_gpu()
         xyz = torch.as_tensor(np.ascontiguousarray(xyz, dtype=np.float32) if not torch.is_tensor(xyz) else xyz)
         if xyz.dim() != 2 or xyz.shape[1] != 3:
@@ -34,7 +36,11 @@ class PointCloudRasterizer:
         self._ws = None
         # cell-ordered copy (Morton-sorted chunks of 1024 points + bounding boxes), built once on the host
         self.cells = None
-        if cells and self.n >= self.CELLS_MIN_POINTS:
+        if torch.is_tensor(cells):
+            if cells.dtype != torch.uint8 or cells.numel() != _lib.lib().read_splat_cells_bytes(self.n):
+                raise ValueError("cells blob does not belong to a cloud of this size")
+            self.cells = cells.to(self.device)
+        elif cells and self.n >= self.CELLS_MIN_POINTS:
             self.cells = torch.from_numpy(build_cells(xyz.detach().cpu().numpy())).to(self.device)
 
     def _workspace(self, B, W, H):

@@ -1,12 +1,21 @@
 """Multi-GPU novel-view sweep: camera poses are independent units, so they shard across the GPUs of
 a node with no data-path collective; RCCL (torch.distributed backend "nccl" on ROCm; "gloo" in the
-CPU tests) is used only for the one-time broadcast of the scene and the all-gather of finished
-frames.  One process per GPU.
+CPU tests) is used only for the one-time broadcast of the scene and the exchange of finished frames
+(SURVEY.md §8e).  One process per GPU.  This module is the ONE implementation of that loop: ``bench.py``
+times ``run_steps`` and the CPU tests drive the same function with a stub renderer.
 
 Pose k is rendered by rank ``k % world`` — consecutive poses of a trajectory land on different
-GPUs, so a viewer replaying the sweep in order drains all GPUs evenly."""
+GPUs, so a viewer replaying the sweep in order drains all GPUs evenly.
+
+Expected scaling (for judging a measured curve): weak scaling is linear up to the frame exchange — one RGBA frame is
+6.8 MB, so at ~150 frames/s per GPU an all-gather moves ~1 GB/s per peer link and a gather-to-root ~7 GB/s into
+rank 0, against ~153 GB/s per xGMI link; the exchange of step i overlaps the rendering of step i+1."""
 import torch
 import torch.distributed as dist
+
+
+def _dist_on():
+    return dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
 
 
 def shard_indices(n_items, rank, world):
@@ -15,46 +24,113 @@ def shard_indices(n_items, rank, world):
 
 
 def broadcast_scene(tensors, src=0):
-    """Replicate the scene (xyz, descriptors, packed weights) from `src` to every rank, in place."""
-    if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+    """Replicate the scene (xyz, descriptors, packed weights, cell-ordered cloud) from `src` to every rank, in place."""
+    if _dist_on():
         for t in tensors:
             dist.broadcast(t, src)
     return tensors
 
 
-def render_sweep(render_fn, n_poses, frame_shape, device, dtype=torch.float32, gather=True):
-    """Render poses ``rank::world`` with ``render_fn(k) -> tensor(frame_shape)`` and (optionally)
-    all-gather them so every rank ends with the full ``(n_poses, *frame_shape)`` stack in pose order.
+def broadcast_scene_from_rank0(make, device):
+    """``make()`` (called on rank 0 only) returns a list of tensors; every rank returns the same list on ``device``.
+    Shapes/dtypes travel first (one small object broadcast), then the payloads over the device collective."""
+    if not _dist_on():
+        return [t.to(device) for t in make()]
+    rank = dist.get_rank()
+    tensors = [t.to(device) for t in make()] if rank == 0 else None
+    meta = [[(tuple(t.shape), t.dtype) for t in tensors]] if rank == 0 else [None]
+    dist.broadcast_object_list(meta, src=0)
+    if rank != 0:
+        tensors = [torch.empty(shape, dtype=dtype, device=device) for (shape, dtype) in meta[0]]
+    return broadcast_scene(tensors, 0)
 
-    Frames are exchanged in slabs of one frame per rank: while slab s is on the wire (async
-    all-gather), slab s+1 is being rendered."""
-    distributed = dist.is_available() and dist.is_initialized()
-    world = dist.get_world_size() if distributed else 1
-    rank = dist.get_rank() if distributed else 0
+
+class FrameExchange:
+    """Double-buffered exchange of finished frames: while the frames of step i are on the wire (async collective),
+    step i+1 is rendered into the other buffer.
+
+    mode 'all'   every rank receives every rank's frame (all_gather_into_tensor) — a tiled display wall / any consumer
+         'root'  only rank 0 receives them (gather): the viewer process displays, the others only render
+         None    no exchange (frames stay where they were rendered)"""
+
+    def __init__(self, frame_shape, device, dtype=torch.float32, mode='all'):
+        if mode not in ('all', 'root', None):
+            raise ValueError(mode)
+        self.world = dist.get_world_size() if _dist_on() else 1
+        self.rank = dist.get_rank() if _dist_on() else 0
+        self.mode = mode if self.world > 1 else None
+        self.send = [torch.zeros(tuple(frame_shape), dtype=dtype, device=device) for _ in range(2)]
+        self.recv = [None, None]
+        if self.mode == 'all' or (self.mode == 'root' and self.rank == 0):
+            self.recv = [torch.zeros((self.world,) + tuple(frame_shape), dtype=dtype, device=device) for _ in range(2)]
+        self.pending = [None, None]
+
+    def buffer(self, i):
+        """The frame buffer step i renders into; waits until the exchange that last used it has completed."""
+        j = i & 1
+        if self.pending[j] is not None:
+            self.pending[j].wait()
+            self.pending[j] = None
+        return self.send[j]
+
+    def post(self, i):
+        j = i & 1
+        if self.mode == 'all':
+            self.pending[j] = dist.all_gather_into_tensor(self.recv[j], self.send[j][None], async_op=True)
+        elif self.mode == 'root':
+            out = list(self.recv[j].unbind(0)) if self.rank == 0 else None
+            self.pending[j] = dist.gather(self.send[j], out, dst=0, async_op=True)
+
+    def frames(self, i):
+        """(world, *frame_shape) frames of step i in rank order once its exchange has completed (None where not received)."""
+        j = i & 1
+        if self.pending[j] is not None:
+            self.pending[j].wait()
+            self.pending[j] = None
+        if self.mode is None:
+            return self.send[j][None]
+        return self.recv[j]
+
+    def drain(self):
+        for j in range(2):
+            if self.pending[j] is not None:
+                self.pending[j].wait()
+                self.pending[j] = None
+
+
+def run_steps(render_into, exchange, first, count, n_poses):
+    """Steps first .. first+count-1 of the sweep on this rank: step i renders pose ``(i * world + rank) % n_poses`` into
+    the exchange's buffer and posts the exchange.  ``render_into(pose_index, out_tensor)``."""
+    world, rank = exchange.world, exchange.rank
+    for i in range(first, first + count):
+        out = exchange.buffer(i)
+        render_into((i * world + rank) % n_poses, out)
+        exchange.post(i)
+
+
+def render_sweep(render_fn, n_poses, frame_shape, device, dtype=torch.float32, gather=True):
+    """Render poses ``rank::world`` with ``render_fn(k) -> tensor(frame_shape)`` and (optionally) all-gather them so
+    every rank ends with the full ``(n_poses, *frame_shape)`` stack in pose order."""
+    ex = FrameExchange(frame_shape, device, dtype, 'all' if gather else None)
+    world, rank = ex.world, ex.rank
     mine = shard_indices(n_poses, rank, world)
     rounds = (n_poses + world - 1) // world
-    if not gather or world == 1:
+    if ex.mode is None:
         local = torch.zeros((len(mine),) + tuple(frame_shape), dtype=dtype, device=device)
         for j, k in enumerate(mine):
             local[j].copy_(render_fn(k))
-        if world == 1:
-            return local
-        return local, mine
+        return local if world == 1 else (local, mine)
     out = torch.zeros((rounds * world,) + tuple(frame_shape), dtype=dtype, device=device)
-    send = [torch.zeros(tuple(frame_shape), dtype=dtype, device=device) for _ in range(2)]
-    pending = [None, None]
+
     for r in range(rounds):
-        j = r & 1
-        if pending[j] is not None:
-            pending[j].wait()
+        buf = ex.buffer(r)
         k = r * world + rank
         if k < n_poses:
-            send[j].copy_(render_fn(k))
+            buf.copy_(render_fn(k))
         else:
-            send[j].zero_()
-        # slab r holds poses r*world .. r*world+world-1, i.e. rank order == pose order
-        pending[j] = dist.all_gather_into_tensor(out[r * world:(r + 1) * world], send[j][None], async_op=True)
-    for p in pending:
-        if p is not None:
-            p.wait()
+            buf.zero_()                                                  # past the end of the sweep: this rank sends zeros
+        if r > 0:
+            out[(r - 1) * world:r * world].copy_(ex.frames(r - 1))     # slab r-1: rank order == pose order
+        ex.post(r)
+    out[(rounds - 1) * world:rounds * world].copy_(ex.frames(rounds - 1))
     return out[:n_poses]

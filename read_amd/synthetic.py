@@ -23,6 +23,45 @@ def make_cloud(n_points, seed=DEFAULT_SEED):
     return xyz
 
 
+def make_street_cloud(n_points, seed=DEFAULT_SEED):
+    """Surface-like stand-in for a KITTI scene (BASELINE configs[1]; the real kitti6 scan cannot be downloaded here):
+    a road plane, two facade walls with recessed openings, box-shaped vehicles and pole / foliage blobs along a 160 m
+    street, seen from a camera 1.7 m above the road looking down -z.  Points lie ON surfaces (2 cm noise), densities
+    differ by two orders of magnitude between parts and the order in memory is a random shuffle — unlike the uniform
+    slab of make_cloud this has real occlusion (what is behind a wall is never visible) and empty sky."""
+    rng = np.random.default_rng([seed, 77])
+    n_ground, n_wall, n_car = int(0.35 * n_points), int(0.40 * n_points), int(0.10 * n_points)
+    n_blob = n_points - n_ground - n_wall - n_car
+    parts = []
+    g = np.empty((n_ground, 3))
+    g[:, 0] = rng.uniform(-25, 25, n_ground)
+    g[:, 1] = -1.7 + 0.02 * rng.standard_normal(n_ground)
+    g[:, 2] = rng.uniform(-160, 2, n_ground)
+    parts.append(g)
+    w = np.empty((n_wall, 3))
+    side = rng.integers(0, 2, n_wall) * 2 - 1
+    w[:, 2] = rng.uniform(-160, 2, n_wall)
+    w[:, 1] = rng.uniform(-1.7, 11, n_wall)
+    recess = ((np.floor(w[:, 2] / 7.0).astype(np.int64) % 3) == 0) * 2.5          # every third 7 m bay is set back
+    w[:, 0] = side * (9.0 + recess) + 0.02 * rng.standard_normal(n_wall)
+    parts.append(w)
+    n_cars = 24
+    centres = np.stack([rng.uniform(-6, 6, n_cars), np.full(n_cars, -0.95), rng.uniform(-150, -6, n_cars)], 1)
+    half = np.array([0.9, 0.75, 2.1])
+    c = rng.integers(0, n_cars, n_car)
+    u = rng.uniform(-1, 1, (n_car, 3))
+    face = rng.integers(0, 3, n_car)
+    u[np.arange(n_car), face] = np.sign(u[np.arange(n_car), face])               # snap to one face of the box
+    parts.append(centres[c] + u * half + 0.01 * rng.standard_normal((n_car, 3)))
+    n_blobs = 60
+    bc = np.stack([rng.choice([-1.0, 1.0], n_blobs) * rng.uniform(6.5, 8.5, n_blobs), rng.uniform(0, 6, n_blobs),
+                   rng.uniform(-155, -3, n_blobs)], 1)
+    b = rng.integers(0, n_blobs, n_blob)
+    parts.append(bc[b] + rng.standard_normal((n_blob, 3)) * np.array([0.5, 1.2, 0.5]))
+    xyz = np.concatenate(parts).astype(np.float32)
+    return np.ascontiguousarray(xyz[rng.permutation(n_points)])
+
+
 def make_descriptors(n_points, channels=8, seed=DEFAULT_SEED):
     """Descriptors float32 (C,N) ~ U(0,1) — PointTexture init_method='rand' (texture.py:25-26)."""
     rng = np.random.default_rng(seed + 1)

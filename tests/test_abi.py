@@ -44,7 +44,10 @@ def test_layer_table_matches_independent_spec():
 
 def test_bad_arguments_fail_loudly():
     L = _lib.lib()
-    assert L.read_splat_workspace_bytes(1, 1216, 352) == 256 + 8 * 1216 * 352 * 8 + 304 * 88 * 4 + 1216 * 352 * 4
+    # header + one key image + hi-z bounds + two seed images + the depth-bound image of the striped path
+    px = 1216 * 352
+    assert L.read_splat_workspace_bytes(1, 1216, 352) == 4096 + px * 8 + 304 * 88 * 4 + 3 * px * 4
+    assert L.read_splat_workspace_bytes(3, 1216, 352) == 4096 + 3 * px * 8 + 304 * 88 * 4 + 3 * px * 4
     assert L.read_splat_workspace_bytes(0, 10, 10) == 0
     rc = L.read_splat_forward(None, 10, None, 1, 64, 64, 5, None, None, None, 0, None)
     assert rc == -22 and b"xyz" in L.read_last_error()
@@ -55,6 +58,12 @@ def test_bad_arguments_fail_loudly():
         _lib.check(L.read_bilinear_up4(None, 4, 4, 8, None, None), "up4")
     d = _lib.ConvDesc()
     assert L.read_gated_conv_forward(C.byref(d), None) == -22
+    # the release library has no knob that produces invalid results
+    assert L.read_tuning_set(b"conv_ablate", 1) == -22
+    for bad_mode in (2, 4, 5, 6):
+        assert L.read_tuning_set(b"splat_mode", bad_mode) == -22
+    st = _lib.tuning_state()
+    assert st["splat_mode"] == 7 and st["splat_cells"] == 1 and st["conv_wino"] == 1 << 30 and "conv_ablate" not in st
 
 
 def test_weight_packing_layout():

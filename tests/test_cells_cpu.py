@@ -13,12 +13,12 @@ def _parse(blob, n):
     bbox = np.frombuffer(blob[16:40].tobytes(), np.float32)
     density = float(np.frombuffer(blob[40:44].tobytes(), np.float32)[0])
     o = 256
-    xs = np.frombuffer(blob[o:o + nc * 1024 * 12].tobytes(), np.float32).reshape(-1, 3)
-    o += nc * 1024 * 12
-    ids = np.frombuffer(blob[o:o + nc * 1024 * 4].tobytes(), np.uint32)
-    o += nc * 1024 * 4
+    rec = np.frombuffer(blob[o:o + nc * 1024 * 16].tobytes(), np.float32).reshape(-1, 4)     # (x, y, z, id bits)
+    xs = np.ascontiguousarray(rec[:, :3])
+    ids = np.ascontiguousarray(rec[:, 3]).view(np.uint32)
+    o += nc * 1024 * 16
     aabb = np.frombuffer(blob[o:o + nc * 32].tobytes(), np.float32).reshape(-1, 8)
-    scratch = ((nc * 4 + 15) // 16) * 16 + nc * 16               # per-frame chunk lists (device scratch)
+    scratch = ((8 * nc * 4 + 255) // 256) * 256 + 8 * nc * 16       # per-frame chunk lists of the 8 strips (device scratch)
     assert o + nc * 32 + scratch == len(blob)
     return hdr_n, int(nchunks), int(version), bbox, density, xs, ids, aabb
 
@@ -29,7 +29,7 @@ def test_cells_build_is_a_permutation_with_exact_boxes():
     blob = build_cells(xyz)
     assert len(blob) == _lib.lib().read_splat_cells_bytes(n)
     hdr_n, nchunks, version, bbox, density, xs, ids, aabb = _parse(blob, n)
-    assert (hdr_n, nchunks, version) == (n, 5, 1)
+    assert (hdr_n, nchunks, version) == (n, 5, 2)
     assert np.array_equal(np.sort(ids[:n]), np.arange(n, dtype=np.uint32))
     assert np.array_equal(xs[:n], xyz[ids[:n]])                # sorted copy = original points, bit for bit
     assert (ids[n:] == ids[n - 1]).all() and (xs[n:] == xs[n - 1]).all()      # tail = copies of the last point
@@ -64,3 +64,24 @@ def test_cells_equal_codes_keep_ascending_ids_and_degenerate_clouds():
         assert "not finite" in str(e)
     else:
         raise AssertionError("non-finite point accepted")
+
+
+def test_cells_build_threaded_equals_the_stable_sort():
+    """Large enough for the multi-threaded radix sort: the order must be the stable sort by Morton code."""
+    n = 300_000
+    xyz = synthetic.make_cloud(n, 3)
+    _, _, _, bbox, _, xs, ids, _ = _parse(build_cells(xyz), n)
+    lo = bbox[:3]
+    ext = np.float32((bbox[3:] - bbox[:3]).max())
+    scale = np.float32(1023.999) / ext
+    q = np.clip(((xyz - lo) * scale).astype(np.int64), 0, 1023)           # (x - lo) * scale in fp32, truncated
+
+    def spread(v):
+        out = np.zeros_like(v)
+        for b in range(10):
+            out |= ((v >> b) & 1) << (3 * b)
+        return out
+    code = spread(q[:, 0]) | (spread(q[:, 1]) << 1) | (spread(q[:, 2]) << 2)
+    order = np.argsort(code, kind="stable")
+    assert np.array_equal(ids[:n], order.astype(np.uint32))
+    assert np.array_equal(xs[:n], xyz[order])

@@ -2,8 +2,9 @@
 produced by the reference's own modules (tests/golden/make_golden.py); larger sizes are checked
 against the oracle restatement.
 
-Stated tolerance (fp32 MFMA vs fp32 oneDNN, 40+ gated-conv layers deep): max |diff| <= 2e-3 on
-O(1) activations and PSNR >= 80 dB on the RGB output (the north-star budget is 0.5 dB)."""
+Stated tolerance (fp32 MFMA vs fp32 oneDNN, 40+ gated-conv layers deep; measured 2e-7 / 148 dB): max |diff| <= 5e-6,
+PSNR >= 120 dB, and — because the random-weight RGB output has a per-channel spread of only ~0.01-0.03 — the error
+RELATIVE to the signal: rms(diff) <= 1e-4 * std(ref) (the north-star budget is 0.5 dB of PSNR)."""
 import os
 
 import numpy as np
@@ -19,8 +20,20 @@ from tests.unet_spec import UNET_SPEC
 
 pytestmark = pytest.mark.gpu
 
-MAX_ABS = 2e-3
-MIN_PSNR = 80.0
+MAX_ABS = 5e-6
+MIN_PSNR = 120.0
+MAX_REL_RMS = 1e-4          # rms(got - ref) / std(ref)
+TAP_REL = 2e-5              # intermediates: |diff| <= TAP_REL * max(1, |ref|) elementwise
+
+
+def _check_rgb(got, ref, what):
+    diff = (got.double() - ref.double())
+    err, p = float(diff.abs().max()), unet_torch.psnr(got, ref)
+    rel = float(diff.pow(2).mean().sqrt() / ref.double().std())
+    print("%s: max|diff| %.3e  PSNR %.1f dB  rms/std %.2e" % (what, err, p, rel))
+    assert err <= MAX_ABS, f"{what}: max|diff| {err:.3e}"
+    assert p >= MIN_PSNR, f"{what}: PSNR {p:.1f} dB"
+    assert rel <= MAX_REL_RMS, f"{what}: relative rms {rel:.3e}"
 
 
 def test_layer_table_matches_independent_spec(hip):
@@ -49,9 +62,7 @@ def test_golden_frame_end_to_end(golden_dir, hip):
     got = rgba[:, :, :3].permute(2, 0, 1).cpu()
     ref = torch.from_numpy(g["rgb"])
     assert bool((rgba[:, :, 3] == 1).all())
-    print("golden frame: max|diff| %.3e  PSNR %.1f dB" % ((got - ref).abs().max(), unet_torch.psnr(got, ref)))
-    assert float((got - ref).abs().max()) <= MAX_ABS
-    assert unet_torch.psnr(got, ref) >= MIN_PSNR
+    _check_rgb(got, ref, "golden frame")
     # intermediates (sub-sampled in the golden file to keep it small)
     taps = {"res1": ("Encoder.0.y2", (slice(None, None, 4), slice(None, None, 4))),
             "zb": ("Encoder.3.y2", (slice(None), slice(None))), "z8": ("SCM0.out", (slice(None), slice(None))),
@@ -59,7 +70,8 @@ def test_golden_frame_end_to_end(golden_dir, hip):
     for key, (name, sl) in taps.items():
         t = fr.unet.debug_tensor(name).permute(2, 0, 1).cpu()[(slice(None),) + sl]
         r = torch.from_numpy(g[key])
-        assert float((t - r).abs().max()) <= MAX_ABS, f"{key}: {float((t - r).abs().max()):.3e}"
+        bad = float(((t - r).abs() / r.abs().clamp(min=1.0)).max())
+        assert bad <= TAP_REL, f"{key}: relative error {bad:.3e}"
 
 
 def test_unet_module_256_vs_oracle(hip):
@@ -74,9 +86,7 @@ def test_unet_module_256_vs_oracle(hip):
         got = net(*[x.cuda() for x in xs]).cpu()
         ref = unet_torch.unet_forward(state, *xs[:4])
     assert got.shape == (1, 3, 256, 256)
-    print("256x256: max|diff| %.3e  PSNR %.1f dB" % ((got - ref).abs().max(), unet_torch.psnr(got, ref)))
-    assert float((got - ref).abs().max()) <= MAX_ABS
-    assert unet_torch.psnr(got, ref) >= MIN_PSNR
+    _check_rgb(got, ref, "256x256")
     # state-dict names are the reference's: 909 tensors
     assert len(net.state_dict()) == 909
 
@@ -96,8 +106,7 @@ def test_full_frame_256_100k_vs_oracle(hip):
     with torch.no_grad():
         ref = unet_torch.net_and_texture_forward(state, desc[None], idx)[0]
     got = rgba[:, :, :3].permute(2, 0, 1)
-    print("frame 256: max|diff| %.3e  PSNR %.1f dB" % ((got - ref).abs().max(), unet_torch.psnr(got, ref)))
-    assert unet_torch.psnr(got, ref) >= MIN_PSNR
+    _check_rgb(got, ref, "frame 256")
 
 
 def test_winograd_and_direct_conv_paths_agree(hip):
@@ -118,10 +127,32 @@ def test_winograd_and_direct_conv_paths_agree(hip):
             _lib.check(_lib.lib().read_tuning_set(b"conv_wino", knob))
             with torch.no_grad():
                 outs[name] = net(*[x.cuda() for x in xs]).cpu()
-            err = float((outs[name] - ref).abs().max())
-            print("%s: max|diff| %.3e  PSNR %.1f dB" % (name, err, unet_torch.psnr(outs[name], ref)))
-            assert err <= MAX_ABS and unet_torch.psnr(outs[name], ref) >= MIN_PSNR
+            _check_rgb(outs[name], ref, name)
     finally:
         _lib.check(_lib.lib().read_tuning_set(b"conv_wino", 1 << 30))
     assert not torch.equal(outs["winograd"], outs["direct"])
-    assert float((outs["winograd"] - outs["direct"]).abs().max()) <= 1e-4
+    assert float((outs["winograd"] - outs["direct"]).abs().max()) <= 2 * MAX_ABS
+
+
+def test_headline_frame_1216x352_vs_oracle(hip):
+    """The configuration bench.py times: the full UNet at 1216x352 (every persistent-scheduling path of the 32/64/128/256
+    channel Winograd launches at 352x1216 / 176x608 / 88x304 / 44x152) on the descriptor pyramids of a rasterised
+    frame, against the oracle; plus the kitti6 viewport 1216x368 (H not a multiple of 32)."""
+    torch.set_num_threads(min(os.cpu_count() or 1, 32))
+    state = synthetic.make_unet_state(UNET_SPEC)
+    for (W, H, N, pose) in ((1216, 352, 3_000_000, 7), (1216, 368, 1_500_000, 3)):
+        xyz = synthetic.make_cloud(N) if H == 352 else synthetic.make_street_cloud(N)
+        desc = synthetic.make_descriptors(N)
+        proj = synthetic.make_proj(W, H)
+        fr = FrameRenderer(xyz, desc, state, W, H, proj_matrix=proj)
+        fr.render(synthetic.sweep_pose(pose - 1))                   # warm start, as in the sweep
+        rgba = fr.render(synthetic.sweep_pose(pose)).cpu()
+        M = camera.total_matrix(proj, synthetic.sweep_pose(pose))[0]
+        idx, dep = oracle.raster_multiscale(xyz, M, W, H, 5, threads=8)
+        for l in range(5):
+            assert np.array_equal(fr.idx[l][0].cpu().numpy(), idx[l]), f"{W}x{H} index level {l}"
+            assert np.array_equal(fr.depth[l][0].cpu().numpy().view(np.uint32), dep[l].view(np.uint32))
+        with torch.no_grad():
+            ref = unet_torch.net_and_texture_forward(state, desc[None], idx)[0]
+        _check_rgb(rgba[:, :, :3].permute(2, 0, 1), ref, f"frame {W}x{H}")
+        assert bool((rgba[:, :, 3] == 1).all())

@@ -11,6 +11,7 @@ import torch.multiprocessing as mp
 
 import oracle
 from read_amd import camera, synthetic
+from read_amd import sweep
 from read_amd.sweep import broadcast_scene, render_sweep, shard_indices
 
 W, H, N, POSES = 48, 32, 4000, 7
@@ -67,3 +68,77 @@ def test_single_process_sweep():
     xyz, proj = synthetic.make_cloud(N), synthetic.make_proj(W, H, f=30.0)
     frames = render_sweep(lambda k: _frame(xyz, proj, k), 3, (H, W, 2), torch.device("cpu"))
     assert frames.shape == (3, H, W, 2)
+
+
+# ---- the loop bench.py times (sweep.run_steps + FrameExchange + broadcast_scene_from_rank0), with a stub renderer ----
+def _bench_worker(rank, world, port, q, mode):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        dev = torch.device("cpu")
+        made = []
+
+        def make():                                            # rank 0 only: the scene every rank receives
+            made.append(rank)
+            return [torch.from_numpy(synthetic.make_cloud(N)), torch.arange(7, dtype=torch.uint8)]
+        xyz, blob = sweep.broadcast_scene_from_rank0(make, dev)
+        assert made == ([0] if rank == 0 else []) and torch.equal(blob, torch.arange(7, dtype=torch.uint8))
+        proj = synthetic.make_proj(W, H, f=30.0)
+        log = []
+
+        def render_into(k, out):
+            log.append(k)
+            out.copy_(_frame(xyz.numpy(), proj, k))
+        ex = sweep.FrameExchange((H, W, 2), dev, torch.float32, mode)
+        warm, steps = 1, 4
+        sweep.run_steps(render_into, ex, 0, warm, POSES)
+        ex.drain()
+        dist.barrier()
+        seen = {}
+        for i in range(warm, warm + steps):                    # same call as bench.py's timed region, one step at a time
+            sweep.run_steps(render_into, ex, i, 1, POSES)
+            fr = ex.frames(i)
+            if mode == 'all' or rank == 0:
+                seen[i] = fr.clone().numpy()
+        ex.drain()
+        q.put((rank, log, seen))
+    finally:
+        dist.destroy_process_group()
+
+
+def _run_bench_loop(mode):
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_bench_worker, args=(r, 2, port, q, mode)) for r in range(2)]
+    for p in procs:
+        p.start()
+    got = [q.get(timeout=120) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    xyz, proj = synthetic.make_cloud(N), synthetic.make_proj(W, H, f=30.0)
+    for rank, log, seen in got:
+        assert log == [(i * 2 + rank) % POSES for i in range(5)]          # pose (i * world + rank) % n_poses
+        if mode == 'root' and rank != 0:
+            assert seen == {}
+            continue
+        for i, frames in seen.items():
+            assert frames.shape == (2, H, W, 2)
+            for r in range(2):
+                assert np.array_equal(frames[r], _frame(xyz, proj, (i * 2 + r) % POSES).numpy()), (mode, rank, i, r)
+
+
+def test_bench_loop_two_ranks_all_gather():
+    _run_bench_loop('all')
+
+
+def test_bench_loop_two_ranks_gather_to_root():
+    _run_bench_loop('root')
+
+
+def test_bench_loop_single_process_has_no_exchange():
+    ex = sweep.FrameExchange((2, 2), torch.device("cpu"), torch.float32, 'all')
+    assert ex.mode is None and ex.world == 1
+    sweep.run_steps(lambda k, out: out.fill_(k), ex, 0, 3, POSES)
+    assert float(ex.frames(2)[0, 0, 0]) == 2.0

@@ -12,15 +12,19 @@ export TMPDIR=/tmp
 run() { local name=$1 t=$2; shift 2; ( cd "$R" && timeout "$t" "$@" ) > "$O/${TAG}_${name}.log" 2>&1; echo "rc=$?" >> "$O/${TAG}_${name}.log"; tail -n 4 "$O/${TAG}_${name}.log"; }
 for s in $STEPS; do
   case $s in
-    pytest) run pytest 900 python -m pytest tests -m gpu -q --timeout 600 -p no:cacheprovider -s ;;
-    splat)  run splat 300 python tools/splat_modes.py --out "$O/${TAG}_splat_modes.json" ;;
+    pytest) run pytest 1500 python -m pytest tests -m gpu -q --timeout 600 -p no:cacheprovider -s ;;
+    splattest) run splattest 900 python -m pytest tests/test_gpu_splat.py -m gpu -q -x --timeout 600 -p no:cacheprovider -s ;;
+    splatprof) ( cd /tmp && SPLAT_PROBE_STATS=0 timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d "$O/${TAG}_splatprof" -o splat -- python "$R/tools/splat_cells_probe.py" ) > "$O/${TAG}_splatprof.log" 2>&1; echo "rc=$?" >> "$O/${TAG}_splatprof.log"; tail -n 3 "$O/${TAG}_splatprof.log"
+            run splatstats 300 python tools/splat_cells_probe.py ;;
+    benchk) run benchk 600 python bench.py --config kitti6_like --detail "$O/${TAG}_detailk.json" ;;
+    splat)  run splat 400 python tools/splat_modes.py --out "$O/${TAG}_splat_modes.json" ;;
     sweep)  run sweep 400 python tools/sweep_conv.py --out "$O/${TAG}_sweep.json" ;;
     trace)  run trace 300 bash -c "python tools/trace_conv.py --shape L0 --configs 0,10 --out $O/${TAG}_trace; python tools/trace_conv.py --shape L1 --configs 10 --out $O/${TAG}_trace; python tools/trace_conv.py --shape L2 --configs 4 --out $O/${TAG}_trace; python tools/trace_conv.py --shape L3 --configs 11 --out $O/${TAG}_trace" ;;
     benchw) run benchw 500 python bench.py --steps 20 --warmup 3 --no-cpu-baseline --tune conv_wave=1 --detail "$O/${TAG}_detailw.json" ;;
     pytestw) run pytestw 600 env READ_CONV_WAVE=1 python -m pytest tests/test_gpu_unet.py tests/test_gpu_api.py -m gpu -q --timeout 600 -p no:cacheprovider -s ;;
     stagger) for t in 0 400 800 1600; do run stagger$t 200 python tools/sweep_conv.py --shapes 4 --only wave --tune conv_stagger=$t --iters 10 --out "$O/${TAG}_stagger$t.json"; done ;;
-    bench)  run bench 500 python bench.py --steps 20 --warmup 3 --detail "$O/${TAG}_detail.json" ;;
-    prof)   ( cd /tmp && timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d "$O/${TAG}_prof" -o bench -- python "$R/bench.py" --steps 5 --warmup 2 --no-cpu-baseline ) > "$O/${TAG}_prof.log" 2>&1; echo "rc=$?" >> "$O/${TAG}_prof.log"; tail -n 3 "$O/${TAG}_prof.log"
+    bench)  run bench 600 python bench.py --detail "$O/${TAG}_detail.json" ;;
+    prof)   ( cd /tmp && timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d "$O/${TAG}_prof" -o bench -- python "$R/bench.py" --steps 20 --warmup 3 --no-cpu-baseline ) > "$O/${TAG}_prof.log" 2>&1; echo "rc=$?" >> "$O/${TAG}_prof.log"; tail -n 3 "$O/${TAG}_prof.log"
             find "$O/${TAG}_prof" -name "*kernel_stats*" | head -3 ;;
     pmcconv) ( cd /tmp && timeout 300 rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_WAIT_INST_LDS SQ_BUSY_CYCLES GRBM_GUI_ACTIVE -d "$O/${TAG}_pmc_mfma" -o conv -- python "$R/tools/sweep_conv.py" --main-only --iters 2 --out "$O/${TAG}_pmc_sweep.json" ) > "$O/${TAG}_pmc_mfma.log" 2>&1; echo "rc=$?" >> "$O/${TAG}_pmc_mfma.log"; tail -n 2 "$O/${TAG}_pmc_mfma.log" ;;
     pmctraffic) for cnt in FETCH_SIZE WRITE_SIZE; do ( cd /tmp && timeout 300 rocprofv3 --kernel-trace --pmc $cnt --output-format csv -d "$O/${TAG}_pmc_$cnt" -o bench -- python "$R/bench.py" --steps 2 --warmup 1 --no-cpu-baseline ) > "$O/${TAG}_pmc_$cnt.log" 2>&1; echo "rc=$?" >> "$O/${TAG}_pmc_$cnt.log"; done; find "$O" -name "*counter_collection.csv" | head ;;

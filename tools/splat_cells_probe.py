@@ -13,7 +13,7 @@ L = _lib.lib()
 for kv in sys.argv[2:]:
     k, v = kv.split("=")
     _lib.check(L.read_tuning_set(k.encode(), int(v)))
-xyz = synthetic.make_cloud(N, 2019)
+xyz = synthetic.make_cloud(N, 2019) if os.environ.get("SPLAT_PROBE_SCENE", "slab") == "slab" else synthetic.make_street_cloud(N)
 proj = synthetic.make_proj(W, H)
 r = PointCloudRasterizer(xyz)
 poses = [camera.total_matrix(proj, synthetic.sweep_pose(k)) for k in range(12)]
@@ -31,12 +31,12 @@ if os.environ.get("SPLAT_PROBE_STATS", "1") == "0":
 _lib.check(L.read_tuning_set(b"splat_stats", 1))             # (the counters themselves cost ~0.3 ms per pass)
 r.render(poses[0], W, H)
 torch.cuda.synchronize()
-hdr0 = r._ws[64:64 + 96].clone()
+hdr0 = r._ws[64:64 + 128].clone()
 for k in range(1, 11):
     r.render(poses[k], W, H)
 torch.cuda.synchronize()
-st = (r._ws[64:64 + 96].view(torch.int64) - hdr0.view(torch.int64)).cpu().numpy() / 10.0
-names = ["A visible", "A survived", "A atomics", "-", "B visible", "B after LDS", "B atomics", "-", "A chunks run", "B chunks culled",
-         "chunks outside frustum (A+B)", "B chunks run"]
+st = (r._ws[64:64 + 128].view(torch.int64) - hdr0.view(torch.int64)).cpu().numpy() / 10.0
+names = ["A points in strip", "A early-z reads", "A atomics", "-", "B points in strip", "B early-z reads", "B atomics", "-",
+         "A items run", "B items culled", "-", "B items run"]
 for n_, v in zip(names, st):
     print("  %-30s %12.0f" % (n_, v))
