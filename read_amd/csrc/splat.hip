@@ -85,12 +85,6 @@ __device__ __forceinline__ int project_one(float x, float y, float z, const floa
 //              Exact: seeds are real points of this cloud, bounds are upper bounds of the final depths.
 enum { MODE_AGENT = 1, MODE_HIZ = 7 };
 
-__device__ __forceinline__ unsigned xcc_id()
-{
-    // s_getreg_b32 hwreg(HW_REG_XCC_ID = 20, offset 0, size 4)
-    return __builtin_amdgcn_s_getreg((3 << 11) | 20) & (MAX_STRIPS - 1);
-}
-
 // relaxed agent-scope load = global_load_dwordx2 sc1: served by L2, never by the CU's stale L1
 __device__ __forceinline__ unsigned long long peek_key_agent(const unsigned long long *k)
 {
@@ -218,11 +212,9 @@ struct SplatHeader {          // first bytes of the workspace
     int W, H;
     int parity;               // which of the two seed images the NEXT striped frame reads
 };
-struct StripCounters {        // 256 bytes per strip, at HEADER_STRIPS_OFFSET + 256 * strip (agent-scope atomics only)
-    int nA, nB;               // list lengths, written by the classification blocks of the seed launch
-    int pad0[30];
-    int headA, headB;         // ticket counters of the passes (kept on their own line: the hot one)
-    int pad1[30];
+struct StripCounters {        // 256 bytes per strip, at HEADER_STRIPS_OFFSET + 256 * strip
+    int nA, nB;               // list lengths, written by the classification blocks of the seed launch (agent-scope atomics)
+    int pad0[62];
 };
 constexpr size_t HEADER_BYTES = 4096;
 constexpr size_t HEADER_STATS_OFFSET = 64;      // 16 x u64 debug counters (read_tuning_set("splat_stats", 1))
@@ -530,25 +522,22 @@ __global__ __launch_bounds__(256) void cells_pass_kernel(CellCloud cc, Cam1 cam,
     const int rounds = 4 / sub_items;                        // 256-point rounds per item
     unsigned st[3] = {0, 0, 0};
     unsigned n_done = 0, n_cull = 0;
-    int s = (int)(xcc_id() % (unsigned)si.ns);               // this XCD's own strip first
-    for (int visit = 0; visit < si.ns; ++visit, s = s + 1 == si.ns ? 0 : s + 1) {
-        StripCounters *sc = strip_counters(hdr_v, s);
+    // Strip = blockIdx % ns: with the round-robin dispatch of workgroups over the XCDs (block b -> XCD b % 8, observed, not
+    // promised) all work of a strip runs on one XCD and shares its L2 view of zimg; any other placement only makes
+    // bounds staler.  Lists are walked statically — wave w of the strip takes entries w, w + n_waves, ... — because a
+    // ticket counter per strip costs ~30 ns per draw (same-address atomics serialise memory-side: 20 K draws = 75 us).
+    const int s = (int)(blockIdx.x % (unsigned)si.ns);
+    const int wg_in_strip = (int)(blockIdx.x / (unsigned)si.ns), n_wg = (int)(gridDim.x / (unsigned)si.ns);
+    if (wg_in_strip >= n_wg) return;
+    const int n_waves = n_wg * (int)(blockDim.x >> 6);
+    const int wave = __builtin_amdgcn_readfirstlane(wg_in_strip * (int)(blockDim.x >> 6) + (int)(threadIdx.x >> 6));
+    {
+        const StripCounters *sc = strip_counters(hdr_v, s);
         const int xlo = si.xb[s], xhi = si.xb[s + 1];
         const int n_items = (PASS_B ? sc->nB : sc->nA) * sub_items;
-        int *head = PASS_B ? &sc->headB : &sc->headA;
         const int *list_a = cc.list_a + (size_t)s * cc.nchunks;
         const CellEntryB *list_b = cc.list_b + (size_t)s * cc.nchunks;
-        if (n_items == 0) continue;
-        if (visit > 0) {                                     // stealing: look before drawing a ticket from a foreign list
-            if (__hip_atomic_load(head, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= n_items) continue;
-        }
-        int t = 0;
-        if (lane == 0) t = atomicAdd(head, 1);
-        t = __builtin_amdgcn_readfirstlane(t);
-        while (t < n_items) {
-            // next ticket first: its round trip hides behind this item's loads
-            int tn = 0;
-            if (lane == 0) tn = atomicAdd(head, 1);
+        for (int t = wave; t < n_items; t += n_waves) {
             const int li = t / sub_items, part = t - li * sub_items;
             ++n_done;
             int chunk;
@@ -611,7 +600,6 @@ __global__ __launch_bounds__(256) void cells_pass_kernel(CellCloud cc, Cam1 cam,
                     }
                 }
             }
-            t = __builtin_amdgcn_readfirstlane(tn);
         }
     }
     if (stats) {
@@ -628,22 +616,30 @@ __global__ __launch_bounds__(256) void cells_pass_kernel(CellCloud cc, Cam1 cam,
     }
 }
 
-// bound[block] = max over the block's pixels of the current depth bound, "none" if any pixel has no bound yet
-__global__ __launch_bounds__(256) void cells_hiz_kernel(const unsigned *__restrict__ zimg, int W, int H, int nbx, int nby,
-                                                        unsigned short *__restrict__ hiz)
+// After pass A: bound[block] = max over the block's pixels of the current depth (from the exact key image), "none" if a
+// pixel is still empty; and zimg is set to the exact current depths (the racy stores of pass A may have left a larger
+// value than the minimum), so pass B's early-z is exact.
+__global__ __launch_bounds__(256) void cells_hiz_kernel(const unsigned long long *__restrict__ keys, unsigned *__restrict__ zimg,
+                                                        int W, int H, int nbx, int nby, unsigned short *__restrict__ hiz)
 {
     const int b = blockIdx.x * blockDim.x + threadIdx.x;
     if (b >= nbx * nby) return;
     const int bx = b % nbx, by = b / nbx;
     unsigned m = 0;
-    if (bx * 4 + 3 < W) {
 #pragma unroll
-        for (int dy = 0; dy < 4; ++dy)
-            if (by * 4 + dy < H) {
-                const uint4 v = *reinterpret_cast<const uint4 *>(zimg + (long long)(by * 4 + dy) * W + bx * 4);   // W % 16 == 0
-                m = max(max(m, v.x), max(max(v.y, v.z), v.w));
-            }
-    }
+    for (int dy = 0; dy < 4; ++dy)
+        if (by * 4 + dy < H) {                                  // W % 16 == 0: the block's 4 columns exist
+            const long long off = (long long)(by * 4 + dy) * W + bx * 4;
+            const ulonglong2 k01 = *reinterpret_cast<const ulonglong2 *>(keys + off);
+            const ulonglong2 k23 = *reinterpret_cast<const ulonglong2 *>(keys + off + 2);
+            uint4 z;
+            z.x = (unsigned)(k01.x >> 32);                      // EMPTY -> 0xffffffff = "none"
+            z.y = (unsigned)(k01.y >> 32);
+            z.z = (unsigned)(k23.x >> 32);
+            z.w = (unsigned)(k23.y >> 32);
+            *reinterpret_cast<uint4 *>(zimg + off) = z;
+            m = max(max(m, z.x), max(max(z.y, z.z), z.w));
+        }
     hiz[b] = hiz_encode(m);
 }
 
@@ -704,7 +700,6 @@ __global__ __launch_bounds__(256) void splat_resolve_kernel(unsigned long long *
         if (keep == 2 && t < MAX_STRIPS) {
             StripCounters *sc = strip_counters(hdr_v, t);
             sc->nA = sc->nB = 0;
-            sc->headA = sc->headB = 0;
         }
         if (t == 0) {
             // any integer below the padded point count is the position of a real point, i.e. a valid seed, so the two
@@ -783,6 +778,7 @@ int g_splat_cells = 1;         // 0: ignore the cell-ordered copy (A/B)
 int g_splat_cells_sub = 32;    // list A also takes every n-th chunk (0: none): a first bound where nothing is near
 int g_splat_seeds = 1;         // 0: no warm start from the previous frame's front points (A/B)
 int g_splat_items = 1;         // work items per chunk in the striped passes (1, 2 or 4)
+int g_splat_strips = MAX_STRIPS;   // column strips of the striped passes (1, 2, 4 or 8)
 
 // Workspace layout (fixed by the (B, W, H) it was sized for; one workspace serves one such triple):
 //   [header 4096 B][key images: min(B,8) x W*H x 8 B][hi-z bounds: ceil(W/4)*ceil(H/4) x 4 B][seed image 0: W*H x 4 B]
@@ -922,7 +918,7 @@ StripInfo make_strips(int W)
     StripInfo si;
     memset(&si, 0, sizeof(si));
     const int cols = W / 16;                                   // 128-byte lines of keys per image row
-    si.ns = MAX_STRIPS < cols ? MAX_STRIPS : cols;
+    si.ns = g_splat_strips < cols ? g_splat_strips : cols;
     for (int s = 0; s <= si.ns; ++s) si.xb[s] = 16 * (int)((long long)cols * s / si.ns);
     for (int s = si.ns + 1; s <= MAX_STRIPS; ++s) si.xb[s] = W;
     return si;
@@ -946,7 +942,7 @@ int cells_frame(const CellCloud &cc, const float *M_host, int W, int H, int leve
                        (const unsigned short *)ws.hiz, ws.nbx, ws.hdr, ws.prev[0], ws.prev[1], si, items, stats);
     READ_CHECK_LAUNCH();
     hipLaunchKernelGGL(cells_hiz_kernel, dim3(ceil_div(ws.nbx * ws.nby, 256)), dim3(256), 0, stream,
-                       (const unsigned *)ws.zimg, W, H, ws.nbx, ws.nby, ws.hiz);
+                       (const unsigned long long *)ws.keys, ws.zimg, W, H, ws.nbx, ws.nby, ws.hiz);
     READ_CHECK_LAUNCH();
     hipLaunchKernelGGL(cells_pass_kernel<true>, dim3(grid), dim3(256), 0, stream, cc, cam, W, H, ws.keys, ws.zimg,
                        (const unsigned short *)ws.hiz, ws.nbx, ws.hdr, ws.prev[0], ws.prev[1], si, items, stats);
@@ -976,6 +972,7 @@ void splat_set_cells(int v) { g_splat_cells = v; }
 void splat_set_seeds(int v) { g_splat_seeds = v; }
 void splat_set_cells_sub(int v) { g_splat_cells_sub = v < 0 ? 0 : v; }
 void splat_set_items(int v) { g_splat_items = v >= 4 ? 4 : (v >= 2 ? 2 : 1); }
+void splat_set_strips(int v) { g_splat_strips = v >= 8 ? 8 : (v >= 4 ? 4 : (v >= 2 ? 2 : 1)); }
 int splat_get(const char *key, int *value)
 {
     if (!strcmp(key, "splat_mode")) *value = g_splat_mode;
@@ -986,6 +983,7 @@ int splat_get(const char *key, int *value)
     else if (!strcmp(key, "splat_seeds")) *value = g_splat_seeds;
     else if (!strcmp(key, "splat_cells_sub")) *value = g_splat_cells_sub;
     else if (!strcmp(key, "splat_items")) *value = g_splat_items;
+    else if (!strcmp(key, "splat_strips")) *value = g_splat_strips;
     else return 0;
     return 1;
 }
