@@ -260,8 +260,9 @@ def cpu_leg(wl, frames):
     W, H = wl.W, wl.H
     ncpu = os.cpu_count() or 1
     # thread count: torch's CPU convolutions get SLOWER with too many threads on the 256-thread GPU hosts (the UNet is
-    # ~600 small ops), so probe {32, 64, all} on a small frame and run the sample with the best
-    cands = sorted({min(32, ncpu), min(64, ncpu), ncpu})
+    # ~600 small ops; measured on a 128x128 frame: 0.18 s at 32 threads, 0.39 s at 64, 149 s at all 256 —
+    # profiles/r2_bench.log), so probe {16, 32, 64, all if <= 128} on a small frame and run the sample with the best
+    cands = sorted({min(16, ncpu), min(32, ncpu), min(64, ncpu)} | ({ncpu} if ncpu <= 128 else set()))
     xs = [torch.rand(1, 8, 128 >> l, 128 >> l) for l in range(4)]
     probe = {}
     with torch.no_grad():

@@ -120,6 +120,32 @@ int read_splat_forward_cells(const float *xyz, void *cells, int64_t n, const flo
                              int levels, int32_t *const *idx_levels, float *const *depth_levels,
                              void *workspace, size_t workspace_bytes, void *stream);
 
+/* GL twin features of the rasteriser (READ/gl/programs.py:121-198, READ/gl/render.py:52-85, READ/gl/dataset.py:39-82,
+ * READ/datasets/dynamic.py:235-239): ONE level of ONE camera rasterised at its own size W x H with
+ *   point_size / relative / min_point_size   "pN" tokens: a square of N pixels; "psN" tokens (relative = 1): side
+ *                                             max(min_point_size, N / clip.z); never below one pixel
+ *   discard                                   optional device array of N bytes, 1 = point not drawn (set_point_discard)
+ *   drop_threshold, drop_seed                 seeded drop: point i is dropped iff rnd(i, seed) < threshold (0 = off);
+ *                                             threshold = p * (2^32 - 1)
+ *   perturb                                   optional device array N x 2 added to clip.xy (set_point_perturb)
+ *   perturb_amp, perturb_seed                 seeded perturbation amp * (u01(i, seed) - 0.5) per axis (0 = off)
+ * Exact semantics: csrc/splat.hip (splat_project_gl_kernel) == oracle/raster.c (oracle_raster_level_gl).  With the default
+ * options {1, 0, 1, NULL, 0, 0, NULL, 0, 0} the result equals read_splat_forward(levels = 1).  The workspace is the one of
+ * read_splat_workspace_bytes(1, W, H); it is left EMPTY. */
+typedef struct read_splat_gl_opts {
+    float point_size;
+    int relative;
+    float min_point_size;
+    const unsigned char *discard;
+    uint32_t drop_threshold, drop_seed;
+    const float *perturb;
+    float perturb_amp;
+    uint32_t perturb_seed;
+} read_splat_gl_opts;
+int read_splat_forward_gl(const float *xyz, int64_t n, const float *M_host, int W, int H,
+                          const read_splat_gl_opts *opts, int32_t *idx, float *depth, void *workspace,
+                          size_t workspace_bytes, void *stream);
+
 /* out[i] = (float)idx[i] — the reference's index image dtype (ids >= 2^24 round). */
 int read_index_to_float(const int32_t *idx, int64_t count, float *out, void *stream);
 
@@ -136,6 +162,13 @@ int read_rows_to_texture(const float *rows_nc, int64_t n, int C, float *tex_cn, 
 int read_gather_forward(const float *rows_nc, int64_t n, int C, int levels,
                         const int32_t *const *idx_levels, const int64_t *count_levels,
                         float *const *feat_levels, int activation, void *stream);
+/* Supersampled lookup (READ/gl/nn.py:100-101 + READ/models/compose.py:162-163): index maps rendered at ss x the feature
+ * size; feat_l = bilinear-downscale-by-ss (align_corners = False, torch's F.interpolate(scale_factor = 1/ss)) of the
+ * activated samples, fused: each output pixel blends the four samples around source coordinate (o + 0.5) * ss - 0.5.
+ *   h_levels[l], w_levels[l] = OUTPUT size of level l; idx_l is [B][ss*h][ss*w]; feat_l is [B][h][w][C]. */
+int read_gather_forward_ss(const float *rows_nc, int64_t n, int C, int levels, int B,
+                           const int32_t *const *idx_levels, const int *h_levels, const int *w_levels, int ss,
+                           float *const *feat_levels, int activation, void *stream);
 /* drows[idx_l[p]][c] += dfeat_l[p][c]   (fp32 atomics; drows must be zeroed by the caller). */
 int read_gather_backward(float *drows_nc, int64_t n, int C, int levels,
                          const int32_t *const *idx_levels, const int64_t *count_levels,

@@ -28,7 +28,7 @@
  * Parity pin: the reference repo holds no golden vectors for this path
  * (SURVEY.md §4, §8c).  This restatement is pinned instead against the reference's
  * own kernel source compiled for the CPU and executed serially (oracle/_ref,
- * built by oracle/build_ref.sh; tests/test_oracle_ref.py).
+ * built by oracle/build_ref.sh; tests/test_oracle_raster.py).
  */
 #include <stdint.h>
 #include <stddef.h>
@@ -154,6 +154,117 @@ void oracle_raster_multiscale(const float *xyz, int64_t n, const float *M, int W
         if (nthreads > 1) oracle_raster_level_mt(xyz, n, M, w, h, out_index + off, out_depth + off, nthreads);
         else oracle_raster_level(xyz, n, M, w, h, out_index + off, out_depth + off);
         off += (size_t)w * (size_t)h;
+    }
+}
+
+/* ------------------------------------------------------------------------------------------------
+ * GL twin features (READ/gl/programs.py:121-198 vertex shader, READ/gl/render.py:52-85): point sizes,
+ * perspective ("ps") splats, point discard and clip-space perturbation.  The reference implements these
+ * in OpenGL, which cannot run here and whose point rasterisation is implementation-defined at pixel
+ * boundaries; this is the canonical restatement the HIP kernel is held to (parity unpinned against GL):
+ *   - clip = M * (x,y,z,1); clip.x += perturb.x; clip.y += perturb.y           (programs.py:125-128)
+ *   - the point is clipped by its CENTRE (same tests as the 1-px rule above)
+ *   - size s = point_size, or max(min_point_size, point_size / clip.z) for "ps" tokens (:183-192),
+ *     never below 1; the point covers pixel columns floor(u - (s-1)/2) .. floor(u + (s-1)/2) and rows
+ *     floor(v - (s-1)/2) .. floor(v + (s-1)/2) of the level it is drawn into (s = 1: exactly the 1-px
+ *     rule), clipped to the viewport; every covered pixel gets the point's depth and id (flat shading)
+ *   - discarded points (a_discard == 1, :102,:236) are not drawn
+ *   - z-test: min depth, ties -> min id (GL_LESS in draw order)
+ * Seeded variants of the two augmentations (READ/datasets/dynamic.py:235-239 draws them from numpy's
+ * global RNG): point i is dropped iff rnd(i, seed, 0) < drop_threshold; perturb = amp * (u01 - 0.5)
+ * with u01 = (rnd(i, seed, 1 | 2) >> 8) * 2^-24.
+ */
+static inline uint32_t hash32(uint32_t x)
+{
+    x ^= x >> 16; x *= 0x7feb352du; x ^= x >> 15; x *= 0x846ca68bu; x ^= x >> 16;
+    return x;
+}
+static inline uint32_t rnd32(uint32_t i, uint32_t seed, uint32_t k)
+{
+    return hash32(i ^ hash32(seed + 0x9e3779b9u * (k + 1u)));
+}
+
+typedef struct oracle_gl_opts {
+    float point_size;            /* pN / psN */
+    int relative;                /* 1: "ps" token (size / clip.z) */
+    float min_point_size;
+    const uint8_t *discard;      /* optional N bytes, 1 = not drawn */
+    uint32_t drop_threshold;     /* seeded drop: rnd < threshold (0 = off) */
+    uint32_t drop_seed;
+    const float *perturb;        /* optional N x 2 clip-space offsets */
+    float perturb_amp;           /* seeded perturbation amplitude (0 = off) */
+    uint32_t perturb_seed;
+} oracle_gl_opts;
+
+void oracle_raster_level_gl(const float *xyz, int64_t n, const float *M, int W, int H, const oracle_gl_opts *o,
+                            int32_t *out_index, float *out_depth)
+{
+    const size_t npx = (size_t)W * (size_t)H;
+    uint64_t *keys = (uint64_t *)__builtin_malloc(npx * sizeof(uint64_t));
+    memset(keys, 0xFF, npx * sizeof(uint64_t));
+    for (int64_t i = 0; i < n; ++i) {
+        if (o->discard && o->discard[i]) continue;
+        if (o->drop_threshold && rnd32((uint32_t)i, o->drop_seed, 0) < o->drop_threshold) continue;
+        const float x = xyz[3 * i], y = xyz[3 * i + 1], z = xyz[3 * i + 2];
+        float c0 = M[0] * x + M[1] * y + M[2] * z + M[3] * 1.0f;
+        float c1 = M[4] * x + M[5] * y + M[6] * z + M[7] * 1.0f;
+        const float c2 = M[8] * x + M[9] * y + M[10] * z + M[11] * 1.0f;
+        const float c3 = M[12] * x + M[13] * y + M[14] * z + M[15] * 1.0f;
+        if (o->perturb) { c0 = c0 + o->perturb[2 * i]; c1 = c1 + o->perturb[2 * i + 1]; }
+        if (o->perturb_amp != 0.0f) {
+            const float ux = (float)(rnd32((uint32_t)i, o->perturb_seed, 1) >> 8) * (1.0f / 16777216.0f);
+            const float uy = (float)(rnd32((uint32_t)i, o->perturb_seed, 2) >> 8) * (1.0f / 16777216.0f);
+            c0 = c0 + o->perturb_amp * (ux - 0.5f);
+            c1 = c1 + o->perturb_amp * (uy - 0.5f);
+        }
+        const float nx = c0 / c3, ny = c1 / c3, nz = c2 / c3;
+        if (!(nx == nx) || !(ny == ny) || !(nz == nz)) continue;
+        if (nx < -1.0f || nx > 1.0f || ny < -1.0f || ny > 1.0f || nz < -1.0f || nz > 1.0f) continue;
+        const float u = ((float)W * (nx + 1.0f)) * 0.5f;
+        const float v = ((float)H * (1.0f - ny)) * 0.5f;
+        const float d = (nz + 1.0f) * 0.5f;
+        if ((int)u < 0 || (int)u >= W || (int)v < 0 || (int)v >= H) continue;
+        float sz = o->point_size;
+        if (o->relative) { sz = o->point_size / c2; if (!(sz > o->min_point_size)) sz = o->min_point_size; }
+        if (!(sz > 1.0f)) sz = 1.0f;
+        if (sz > 4096.0f) sz = 4096.0f;
+        const float half = 0.5f * (sz - 1.0f);
+        int x0 = (int)floorf(u - half), x1 = (int)floorf(u + half);
+        int y0 = (int)floorf(v - half), y1 = (int)floorf(v + half);
+        if (x0 < 0) x0 = 0;
+        if (y0 < 0) y0 = 0;
+        if (x1 > W - 1) x1 = W - 1;
+        if (y1 > H - 1) y1 = H - 1;
+        const uint64_t key = make_key(d, i);
+        for (int yy = y0; yy <= y1; ++yy)
+            for (int xx = x0; xx <= x1; ++xx) {
+                uint64_t *k = keys + (size_t)yy * W + xx;
+                if (key < *k) *k = key;
+            }
+    }
+    for (size_t p = 0; p < npx; ++p) {
+        if (keys[p] == ~(uint64_t)0) { out_index[p] = 0; out_depth[p] = 0.0f; }
+        else {
+            const uint32_t b = (uint32_t)(keys[p] >> 32);
+            memcpy(&out_depth[p], &b, 4);
+            out_index[p] = (int32_t)(uint32_t)keys[p];
+        }
+    }
+    __builtin_free(keys);
+}
+
+/* The seeded augmentation streams themselves (for tests that pass explicit arrays). */
+void oracle_drop_mask(int64_t n, uint32_t threshold, uint32_t seed, uint8_t *mask)
+{
+    for (int64_t i = 0; i < n; ++i) mask[i] = rnd32((uint32_t)i, seed, 0) < threshold;
+}
+void oracle_perturb_array(int64_t n, float amp, uint32_t seed, float *out_n2)
+{
+    for (int64_t i = 0; i < n; ++i) {
+        const float ux = (float)(rnd32((uint32_t)i, seed, 1) >> 8) * (1.0f / 16777216.0f);
+        const float uy = (float)(rnd32((uint32_t)i, seed, 2) >> 8) * (1.0f / 16777216.0f);
+        out_n2[2 * i] = amp * (ux - 0.5f);
+        out_n2[2 * i + 1] = amp * (uy - 0.5f);
     }
 }
 

@@ -9,6 +9,12 @@ from . import build as _build
 _LIB = None
 
 
+class GLOpts(C.Structure):
+    _fields_ = [("point_size", C.c_float), ("relative", C.c_int), ("min_point_size", C.c_float),
+                ("discard", C.c_void_p), ("drop_threshold", C.c_uint32), ("drop_seed", C.c_uint32),
+                ("perturb", C.c_void_p), ("perturb_amp", C.c_float), ("perturb_seed", C.c_uint32)]
+
+
 def lib_path() -> str:
     return _build.OUT
 
@@ -16,8 +22,7 @@ def lib_path() -> str:
 def _lib():
     global _LIB
     if _LIB is None:
-        if not os.path.exists(_build.OUT):
-            _build.build()
+        _build.build()                     # no-op when liboracle_raster.so is newer than raster.c
         L = C.CDLL(_build.OUT)
         f32p, i32p = C.POINTER(C.c_float), C.POINTER(C.c_int32)
         L.oracle_raster_level.argtypes = [f32p, C.c_int64, f32p, C.c_int, C.c_int, i32p, f32p]
@@ -27,6 +32,11 @@ def _lib():
         L.oracle_index_to_float.argtypes = [i32p, C.c_size_t, f32p]
         L.oracle_gather_chw.argtypes = [f32p, C.c_int64, C.c_int, i32p, C.c_size_t, f32p]
         L.oracle_gather_backward_chw.argtypes = [f32p, i32p, C.c_size_t, C.c_int, C.c_int64, f32p]
+        L.oracle_raster_level_gl.argtypes = [f32p, C.c_int64, f32p, C.c_int, C.c_int, C.POINTER(GLOpts), i32p, f32p]
+        L.oracle_drop_mask.argtypes = [C.c_int64, C.c_uint32, C.c_uint32, C.POINTER(C.c_uint8)]
+        L.oracle_perturb_array.argtypes = [C.c_int64, C.c_float, C.c_uint32, f32p]
+        for fn in (L.oracle_raster_level_gl, L.oracle_drop_mask, L.oracle_perturb_array):
+            fn.restype = None
         for fn in (L.oracle_raster_level, L.oracle_raster_level_mt, L.oracle_raster_multiscale,
                    L.oracle_index_to_float, L.oracle_gather_chw, L.oracle_gather_backward_chw):
             fn.restype = None
@@ -102,4 +112,47 @@ def gather_backward_chw(grad_chw, idx, n):
     out = np.zeros((Cc, n), np.float32)
     _lib().oracle_gather_backward_chw(_p(g, C.c_float), _p(idx, C.c_int32), idx.size, Cc, n,
                                       _p(out, C.c_float))
+    return out
+
+
+def drop_threshold(p):
+    """Probability -> the u32 threshold of the seeded drop (point i dropped iff rnd(i, seed, 0) < threshold)."""
+    return int(min(max(float(p), 0.0), 1.0) * 4294967295.0)
+
+
+def raster_level_gl(xyz, M, W, H, point_size=1.0, relative=False, min_point_size=1.0, discard=None, drop=None,
+                    perturb=None, perturb_hash=None):
+    """GL-twin rasterisation of ONE level at its own size (see raster.c): point sizes / "ps" splats, discard mask or
+    seeded drop=(p, seed), perturb array (N,2) or seeded perturb_hash=(amp, seed) -> (index int32 [H,W], depth [H,W])."""
+    xyz, M = _f32(xyz), _f32(M).reshape(16)
+    o = GLOpts(float(point_size), int(bool(relative)), float(min_point_size), None, 0, 0, None, 0.0, 0)
+    keep = []
+    if discard is not None:
+        dm = np.ascontiguousarray(discard, dtype=np.uint8)
+        keep.append(dm)
+        o.discard = dm.ctypes.data
+    if drop is not None:
+        o.drop_threshold, o.drop_seed = drop_threshold(drop[0]), int(drop[1]) & 0xffffffff
+    if perturb is not None:
+        pa = _f32(perturb)
+        keep.append(pa)
+        o.perturb = pa.ctypes.data
+    if perturb_hash is not None:
+        o.perturb_amp, o.perturb_seed = float(perturb_hash[0]), int(perturb_hash[1]) & 0xffffffff
+    idx = np.empty((H, W), np.int32)
+    dep = np.empty((H, W), np.float32)
+    _lib().oracle_raster_level_gl(_p(xyz, C.c_float), xyz.shape[0], _p(M, C.c_float), W, H, C.byref(o),
+                                  _p(idx, C.c_int32), _p(dep, C.c_float))
+    return idx, dep
+
+
+def drop_mask(n, p, seed):
+    m = np.empty(n, np.uint8)
+    _lib().oracle_drop_mask(n, drop_threshold(p), int(seed) & 0xffffffff, _p(m, C.c_uint8))
+    return m.astype(bool)
+
+
+def perturb_array(n, amp, seed):
+    out = np.empty((n, 2), np.float32)
+    _lib().oracle_perturb_array(n, float(amp), int(seed) & 0xffffffff, _p(out, C.c_float))
     return out

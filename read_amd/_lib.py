@@ -32,6 +32,12 @@ class ConvDesc(C.Structure):
     ]
 
 
+class SplatGlOpts(C.Structure):
+    _fields_ = [("point_size", C.c_float), ("relative", C.c_int), ("min_point_size", C.c_float),
+                ("discard", C.c_void_p), ("drop_threshold", C.c_uint32), ("drop_seed", C.c_uint32),
+                ("perturb", C.c_void_p), ("perturb_amp", C.c_float), ("perturb_seed", C.c_uint32)]
+
+
 _vp, _i, _i64, _sz, _f = C.c_void_p, C.c_int, C.c_int64, C.c_size_t, C.c_float
 _pp = C.POINTER(C.c_void_p)
 
@@ -51,10 +57,12 @@ SIGNATURES = {
     "read_splat_cells_bytes": (_sz, [_i64]),
     "read_splat_cells_build_host": (_i, [_vp, _i64, _vp, _sz]),
     "read_splat_forward_cells": (_i, [_vp, _vp, _i64, C.POINTER(_f), _i, _i, _i, _i, _pp, _pp, _vp, _sz, _vp]),
+    "read_splat_forward_gl": (_i, [_vp, _i64, C.POINTER(_f), _i, _i, _vp, _vp, _vp, _vp, _sz, _vp]),
     "read_index_to_float": (_i, [_vp, _i64, _vp, _vp]),
     "read_texture_to_rows": (_i, [_vp, _i64, _i, _vp, _vp]),
     "read_rows_to_texture": (_i, [_vp, _i64, _i, _vp, _vp]),
     "read_gather_forward": (_i, [_vp, _i64, _i, _i, _pp, C.POINTER(_i64), _pp, _i, _vp]),
+    "read_gather_forward_ss": (_i, [_vp, _i64, _i, _i, _i, _pp, C.POINTER(_i), C.POINTER(_i), _i, _pp, _i, _vp]),
     "read_gather_backward": (_i, [_vp, _i64, _i, _i, _pp, C.POINTER(_i64), _pp, _vp]),
     "read_conv_packed_floats": (_sz, [_i, _i, _i]),
     "read_conv_param_floats": (_sz, [_i]),

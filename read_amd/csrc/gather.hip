@@ -57,6 +57,69 @@ __global__ __launch_bounds__(256) void gather_forward_kernel(const float *__rest
     }
 }
 
+// Supersampled lookup: index maps at ss x the output size; out = bilinear downscale (align_corners = False) of the activated
+// samples — torch's F.interpolate(scale_factor = 1 / ss) as READ/models/compose.py:162-163 applies it to the texture samples.
+struct LevelTableSS {
+    const int32_t *idx[READ_MAX_LEVELS];
+    float *feat[READ_MAX_LEVELS];
+    long long end[READ_MAX_LEVELS];   // exclusive prefix end in (pixel, quad) items over all B images of a level
+    int h[READ_MAX_LEVELS], w[READ_MAX_LEVELS];
+    int levels;
+};
+
+__device__ __forceinline__ float4 act4(float4 v, int activation)
+{
+    if (activation) {
+        v.x = act_apply(v.x, activation);
+        v.y = act_apply(v.y, activation);
+        v.z = act_apply(v.z, activation);
+        v.w = act_apply(v.w, activation);
+    }
+    return v;
+}
+
+__global__ __launch_bounds__(256) void gather_forward_ss_kernel(const float *__restrict__ rows, long long n, int C,
+                                                                LevelTableSS tab, int ss, int activation)
+{
+    const int qpp = C >> 2;
+    const long long total = tab.end[tab.levels - 1];
+    for (long long item = (long long)blockIdx.x * blockDim.x + threadIdx.x; item < total;
+         item += (long long)gridDim.x * blockDim.x) {
+        int l = 0;
+        long long base = 0;
+#pragma unroll
+        for (int k = 0; k < READ_MAX_LEVELS - 1; ++k)
+            if (k < tab.levels - 1 && item >= tab.end[k]) { l = k + 1; base = tab.end[k]; }
+        const long long local = item - base;
+        const long long pix = local / qpp;
+        const int q = (int)(local - pix * qpp);
+        const int h = tab.h[l], w = tab.w[l], sh = h * ss, sw = w * ss;
+        const int ox = (int)(pix % w), oy = (int)((pix / w) % h);
+        const long long b = pix / ((long long)w * h);
+        // source coordinate (o + 0.5) * ss - 0.5 >= 0 for ss >= 1
+        const float sy = ((float)oy + 0.5f) * (float)ss - 0.5f, sx = ((float)ox + 0.5f) * (float)ss - 0.5f;
+        const int y0 = (int)sy, x0 = (int)sx;
+        const int y1 = y0 + (y0 < sh - 1 ? 1 : 0), x1 = x0 + (x0 < sw - 1 ? 1 : 0);
+        const float ly = sy - (float)y0, lx = sx - (float)x0;
+        const int32_t *im = tab.idx[l] + b * (long long)sh * sw;
+        float4 v[4];
+        const int yy[4] = {y0, y0, y1, y1}, xx[4] = {x0, x1, x0, x1};
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            long long id = im[(long long)yy[k] * sw + xx[k]];
+            id = id < 0 ? 0 : (id >= n ? n - 1 : id);
+            v[k] = act4(*reinterpret_cast<const float4 *>(rows + id * C + 4 * q), activation);
+        }
+        const float wy0 = 1.0f - ly, wx0 = 1.0f - lx;
+        float4 o;
+        o.x = wy0 * (wx0 * v[0].x + lx * v[1].x) + ly * (wx0 * v[2].x + lx * v[3].x);
+        o.y = wy0 * (wx0 * v[0].y + lx * v[1].y) + ly * (wx0 * v[2].y + lx * v[3].y);
+        o.z = wy0 * (wx0 * v[0].z + lx * v[1].z) + ly * (wx0 * v[2].z + lx * v[3].z);
+        o.w = wy0 * (wx0 * v[0].w + lx * v[1].w) + ly * (wx0 * v[2].w + lx * v[3].w);
+        *reinterpret_cast<float4 *>(tab.feat[l] + pix * C + 4 * q) = o;
+    }
+}
+
 struct LevelTableBwd {
     const int32_t *idx[READ_MAX_LEVELS];
     const float *dfeat[READ_MAX_LEVELS];
@@ -180,6 +243,39 @@ extern "C" int read_gather_forward(const float *rows_nc, int64_t n, int C, int l
     if (blocks > 256 * 8) blocks = 256 * 8;
     hipLaunchKernelGGL(gather_forward_kernel, dim3((unsigned)blocks), dim3(256), 0, as_stream(stream), rows_nc,
                        (long long)n, C, tab, activation);
+    READ_CHECK_LAUNCH();
+    return READ_OK;
+}
+
+extern "C" int read_gather_forward_ss(const float *rows_nc, int64_t n, int C, int levels, int B,
+                                      const int32_t *const *idx_levels, const int *h_levels, const int *w_levels, int ss,
+                                      float *const *feat_levels, int activation, void *stream)
+{
+    int rc = check_levels("read_gather_forward_ss", n, C, levels, idx_levels, (const int64_t *)h_levels, feat_levels);
+    if (rc) return rc;
+    READ_CHECK_ARG(rows_nc && (uintptr_t)rows_nc % 16 == 0, "read_gather_forward_ss: rows null or misaligned");
+    READ_CHECK_ARG(w_levels && B >= 1 && ss >= 1 && ss <= 8, "read_gather_forward_ss: bad B / ss / sizes");
+    READ_CHECK_ARG(activation >= 0 && activation <= 2, "read_gather_forward_ss: activation must be 0,1,2");
+    LevelTableSS tab;
+    memset(&tab, 0, sizeof(tab));
+    long long acc = 0;
+    const int qpp = C / 4;
+    for (int l = 0; l < levels; ++l) {
+        READ_CHECK_ARG(h_levels[l] >= 1 && w_levels[l] >= 1 && idx_levels[l] && feat_levels[l],
+                       "read_gather_forward_ss: bad level %d", l);
+        READ_CHECK_ARG((uintptr_t)feat_levels[l] % 16 == 0, "read_gather_forward_ss: feat level %d misaligned", l);
+        tab.idx[l] = idx_levels[l];
+        tab.feat[l] = feat_levels[l];
+        tab.h[l] = h_levels[l];
+        tab.w[l] = w_levels[l];
+        acc += (long long)B * h_levels[l] * w_levels[l] * qpp;
+        tab.end[l] = acc;
+    }
+    tab.levels = levels;
+    int64_t blocks = ceil_div64(acc, 256);
+    if (blocks > 256 * 8) blocks = 256 * 8;
+    hipLaunchKernelGGL(gather_forward_ss_kernel, dim3((unsigned)blocks), dim3(256), 0, as_stream(stream), rows_nc,
+                       (long long)n, C, tab, ss, activation);
     READ_CHECK_LAUNCH();
     return READ_OK;
 }

@@ -311,16 +311,15 @@ __global__ __launch_bounds__(256) void splat_seed_kernel(const float *__restrict
 //   cells_seed_classify_kernel
 //       seed blocks      re-project last frame's front points (their POSITIONS in the sorted cloud were left in a
 //                        per-pixel image by the threads that issued atomics — any real point is a valid seed, so that
-//                        image may be written racily) and store their depths into zimg.  No atomics.
+//                        image may be written racily) and store key, depth bound and position with plain stores.
 //       classify blocks  one thread per chunk, from the 8 projected corners of its box: outside the frustum -> dropped
 //                        (no point of it is read); nearest corner closer than w_split, or every sub-th chunk -> list A;
 //                        the rest -> list B with its screen rectangle and depth threshold.  A chunk is appended to the
 //                        list of EVERY strip its pixel columns can touch (block-aggregated appends).
-//   cells_pass_kernel<A> a workgroup reads its XCD id, starts with the strip that XCD owns and pulls chunks off that
-//                        strip's list A (ticket counter); for the points that fall into the strip: zimg early-z, then
-//                        atomic min on the key + plain stores of the new bound and of the point's position (next
-//                        frame's seed).  When a list is empty the workgroup moves on to the next strip's.
-//   cells_hiz_kernel     far bound per 4x4 block from zimg.
+//   cells_pass_kernel<A> workgroup b works on strip b % ns and walks that strip's list A statically; for the points that
+//                        fall into the strip: zimg early-z, then atomic min on the key + plain stores of the new bound
+//                        and of the point's position (next frame's seed).
+//   cells_hiz_kernel     far bound per 4x4 block from the (exact) key image; zimg := exact current depths.
 //   cells_pass_kernel<B> same walk over list B: a chunk is skipped when its nearest possible depth is behind the bound
 //                        of EVERY block of its rectangle (inside the strip), otherwise its points run as in pass A.
 //   splat_resolve_kernel levels, keys back to EMPTY, zimg back to "no bound", counters to zero.
@@ -484,8 +483,8 @@ __device__ __forceinline__ void classify_block(const CellCloud &cc, const float 
 }
 
 __global__ __launch_bounds__(256) void cells_seed_classify_kernel(CellCloud cc, Cam1 cam, int W, int H,
-                                                                  unsigned *zimg, void *hdr_v, const int *pos0,
-                                                                  const int *pos1, StripInfo si, int seed_blocks,
+                                                                  unsigned long long *keys, unsigned *zimg, void *hdr_v,
+                                                                  int *pos0, int *pos1, StripInfo si, int seed_blocks,
                                                                   int sub, float near_count, int use_seeds)
 {
     if ((int)blockIdx.x >= seed_blocks) {
@@ -497,17 +496,70 @@ __global__ __launch_bounds__(256) void cells_seed_classify_kernel(CellCloud cc, 
     const int p = blockIdx.x * blockDim.x + threadIdx.x;
     if (p >= W * H) return;
     const int pos = (hdr->parity ? pos1 : pos0)[p];
+    int *next = hdr->parity ? pos0 : pos1;
     if ((unsigned)pos >= (unsigned)cc.nchunks * CELL_CHUNK) return;
     const float4 q = cc.pts[pos];
     float d;
     int xx, yy;
     const int pix = project_one(q.x, q.y, q.z, cam.m, W, H, d, xx, yy);
-    // the depth of a real point at this pixel bounds the final depth from above; the point itself is folded in when its
-    // chunk comes by (ties pass every test).  Colliding seeds race; either value is a valid bound.
-    if (pix >= 0) zimg[pix] = __float_as_uint(d);
+    if (pix < 0) return;
+    // Plain stores, no atomics: the key image is EMPTY here, and whatever lands in a pixel — colliding seeds race, and
+    // the three stores of two seeds may interleave — is (i) the key of a real point at this pixel, (ii) the depth of a
+    // real point at this pixel = an upper bound of the final depth, (iii) the position of a real point = a valid seed.
+    // Every point of the cloud still comes by in the passes and passes the test when it can win (ties pass), so the
+    // minimum is established there; a seed that IS the winner finds its own key and skips its atomic.
+    keys[pix] = ((unsigned long long)__float_as_uint(d) << 32) | __float_as_uint(q.w);
+    zimg[pix] = __float_as_uint(d);
+    next[pix] = pos;
 }
 
-// An item = 1024 / sub_items consecutive points of one chunk, for one wave and one strip.
+// `rounds` x 256 consecutive points of one chunk for one wave and one strip: zimg early-z, then atomic min on the key +
+// plain stores of the new bound and of the point's position (next frame's seed).
+__device__ __forceinline__ void strip_points(const CellCloud &cc, const float *M, int W, int H, int xlo, int xhi,
+                                             unsigned long long *keys, unsigned *zimg, int *next, int first, int rounds,
+                                             int lane, unsigned *st)
+{
+    for (int r = 0; r < rounds; ++r) {
+        // 256 points: lane l takes records base + l + 64 k (each load instruction = 1 KiB contiguous)
+        const int base = first + r * 256 + lane;
+        float4 q[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) q[k] = cc.pts[base + 64 * k];
+        int pix[4];
+        unsigned dbits[4], bound[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            int xx, yy;
+            float d;
+            pix[k] = project_one(q[k].x, q[k].y, q[k].z, M, W, H, d, xx, yy);
+            if (xx < xlo || xx >= xhi) pix[k] = -1;
+            dbits[k] = __float_as_uint(d);
+            if (st && pix[k] >= 0) st[0]++;
+        }
+        // early-z against the bound image (L1 / this XCD's L2; a stale bound is only ever LARGER)
+#pragma unroll
+        for (int k = 0; k < 4; ++k) bound[k] = pix[k] >= 0 ? zimg[pix[k]] : 0u;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            if (pix[k] < 0 || dbits[k] > bound[k]) continue;       // ties pass: the atomic breaks them by id
+            const unsigned long long key = ((unsigned long long)dbits[k] << 32) | __float_as_uint(q[k].w);
+            if (dbits[k] == bound[k]) {
+                // A tie is almost always the seed point meeting its own key (cells_seed_classify_kernel): nothing to do.
+                // A stale copy of the key is only ever larger than the live one, so "it is me" stays true when stale.
+                if (st) st[1]++;
+                if (keys[pix[k]] == key) continue;
+            }
+            __hip_atomic_fetch_min(keys + pix[k], key, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (dbits[k] < bound[k]) zimg[pix[k]] = dbits[k];
+            next[pix[k]] = base + 64 * k;                          // a front point of this pixel: next frame's seed
+            if (st) st[2]++;
+        }
+    }
+}
+
+// Pass A: an item = 1024 / sub_items consecutive points of one list-A chunk, for one wave and one strip.
+// Pass B: four list-B entries per wave step, one per group of 16 lanes: each group scans the hi-Z bounds of its chunk's
+// rectangle (inside the strip); chunks that survive are then processed by the whole wave.
 template <bool PASS_B>
 __global__ __launch_bounds__(256) void cells_pass_kernel(CellCloud cc, Cam1 cam, int W, int H,
                                                          unsigned long long *keys, unsigned *zimg,
@@ -519,11 +571,11 @@ __global__ __launch_bounds__(256) void cells_pass_kernel(CellCloud cc, Cam1 cam,
     int *next = hdr->parity ? pos0 : pos1;
     const float *M = cam.m;
     const int lane = threadIdx.x & 63;
-    const int rounds = 4 / sub_items;                        // 256-point rounds per item
-    unsigned st[3] = {0, 0, 0};
-    unsigned n_done = 0, n_cull = 0;
+    unsigned st_local[3] = {0, 0, 0};
+    unsigned *st = stats ? st_local : nullptr;
+    unsigned n_run = 0, n_cull = 0;
     // Strip = blockIdx % ns: with the round-robin dispatch of workgroups over the XCDs (block b -> XCD b % 8, observed, not
-    // promised) all work of a strip runs on one XCD and shares its L2 view of zimg; any other placement only makes
+    // promised) all work of a strip runs on the same XCDs and shares their L2 view of zimg; any other placement only makes
     // bounds staler.  Lists are walked statically — wave w of the strip takes entries w, w + n_waves, ... — because a
     // ticket counter per strip costs ~30 ns per draw (same-address atomics serialise memory-side: 20 K draws = 75 us).
     const int s = (int)(blockIdx.x % (unsigned)si.ns);
@@ -531,87 +583,73 @@ __global__ __launch_bounds__(256) void cells_pass_kernel(CellCloud cc, Cam1 cam,
     if (wg_in_strip >= n_wg) return;
     const int n_waves = n_wg * (int)(blockDim.x >> 6);
     const int wave = __builtin_amdgcn_readfirstlane(wg_in_strip * (int)(blockDim.x >> 6) + (int)(threadIdx.x >> 6));
-    {
-        const StripCounters *sc = strip_counters(hdr_v, s);
-        const int xlo = si.xb[s], xhi = si.xb[s + 1];
-        const int n_items = (PASS_B ? sc->nB : sc->nA) * sub_items;
+    const StripCounters *sc = strip_counters(hdr_v, s);
+    const int xlo = si.xb[s], xhi = si.xb[s + 1];
+    if (!PASS_B) {
         const int *list_a = cc.list_a + (size_t)s * cc.nchunks;
-        const CellEntryB *list_b = cc.list_b + (size_t)s * cc.nchunks;
+        const int n_items = sc->nA * sub_items, rounds = 4 / sub_items;
         for (int t = wave; t < n_items; t += n_waves) {
             const int li = t / sub_items, part = t - li * sub_items;
-            ++n_done;
-            int chunk;
-            bool run = true;
-            if (PASS_B) {
-                const CellEntryB e = list_b[li];
+            const int chunk = __builtin_amdgcn_readfirstlane(list_a[li]);
+            ++n_run;
+            strip_points(cc, M, W, H, xlo, xhi, keys, zimg, next, chunk * CELL_CHUNK + part * rounds * 256, rounds, lane, st);
+        }
+    } else {
+        const CellEntryB *list_b = cc.list_b + (size_t)s * cc.nchunks;
+        const int n_list = sc->nB;
+        const int grp = lane >> 4, gl = lane & 15;
+        for (int t0 = wave * 4; t0 < n_list; t0 += n_waves * 4) {
+            const int t = t0 + grp;
+            bool run = false;
+            int chunk = 0;
+            if (t < n_list) {
+                const CellEntryB e = list_b[t];
                 chunk = e.chunk;
                 int bx0 = (int)(e.bx >> 16), bx1 = (int)(e.bx & 0xffffu);
                 const int by0 = (int)(e.by >> 16), by1 = (int)(e.by & 0xffffu);
-                bx0 = max(bx0, xlo >> 2);                      // only this strip's part of the rectangle matters here
+                bx0 = max(bx0, xlo >> 2);                          // only this strip's part of the rectangle matters here
                 bx1 = min(bx1, (xhi - 1) >> 2);
                 const int rw = bx1 - bx0 + 1, nblk = rw * (by1 - by0 + 1);
-                if (rw <= 0) {
-                    run = false;
-                } else if (nblk <= 4096) {
-                    float emin = 3.0e38f;                      // min over the rectangle of (1 - far bound)
-                    for (int i = lane; i < nblk; i += 64) {
-                        const int ry = by0 + i / rw, rx = bx0 + i % rw;
-                        emin = fminf(emin, __uint_as_float((unsigned)hiz_g[ry * nbx + rx] << 16));
-                    }
-#pragma unroll
-                    for (int o = 32; o > 0; o >>= 1) emin = fminf(emin, __shfl_xor(emin, o));
-                    if (e.e_thr < emin) run = false;           // every point of the box is behind every bound
-                }
-                if (!run) ++n_cull;
-            } else {
-                chunk = list_a[li];
-            }
-            chunk = __builtin_amdgcn_readfirstlane(chunk);
-            if (run) {
-                for (int r = 0; r < rounds; ++r) {
-                    // 256 points: lane l takes records base + l + 64 k (each load instruction = 1 KiB contiguous)
-                    const int base = chunk * CELL_CHUNK + (part * rounds + r) * 256 + lane;
-                    float4 q[4];
-#pragma unroll
-                    for (int k = 0; k < 4; ++k) q[k] = cc.pts[base + 64 * k];
-                    int pix[4];
-                    unsigned dbits[4], bound[4];
-#pragma unroll
-                    for (int k = 0; k < 4; ++k) {
-                        int xx, yy;
-                        float d;
-                        pix[k] = project_one(q[k].x, q[k].y, q[k].z, M, W, H, d, xx, yy);
-                        if (xx < xlo || xx >= xhi) pix[k] = -1;
-                        dbits[k] = __float_as_uint(d);
-                        if (stats && pix[k] >= 0) st[0]++;
-                    }
-                    // early-z against the bound image (L1 / this XCD's L2; a stale bound is only ever LARGER)
-#pragma unroll
-                    for (int k = 0; k < 4; ++k) bound[k] = pix[k] >= 0 ? zimg[pix[k]] : 0u;
-#pragma unroll
-                    for (int k = 0; k < 4; ++k) {
-                        if (pix[k] >= 0 && dbits[k] <= bound[k]) {     // ties pass: the atomic breaks them by id
-                            __hip_atomic_fetch_min(keys + pix[k], ((unsigned long long)dbits[k] << 32) | __float_as_uint(q[k].w),
-                                                   __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                            if (dbits[k] < bound[k]) zimg[pix[k]] = dbits[k];
-                            next[pix[k]] = base + 64 * k;      // a front point of this pixel: next frame's seed
-                            if (stats) st[2]++;
+                if (rw > 0) {
+                    run = true;
+                    if (nblk <= 4096) {
+                        float emin = 3.0e38f;                      // min over the rectangle of (1 - far bound)
+                        for (int i = gl; i < nblk; i += 16) {
+                            const int ry = by0 + i / rw, rx = bx0 + i % rw;
+                            emin = fminf(emin, __uint_as_float((unsigned)hiz_g[ry * nbx + rx] << 16));
                         }
+#pragma unroll
+                        for (int o = 8; o > 0; o >>= 1) emin = fminf(emin, __shfl_xor(emin, o));
+                        if (e.e_thr < emin) run = false;           // every point of the box is behind every bound
                     }
                 }
+                if (gl == 0) {
+                    if (run) ++n_run;
+                    else ++n_cull;
+                }
+            }
+            unsigned long long todo = __ballot(run && gl == 0);
+            while (todo) {
+                const int src = __builtin_ctzll(todo);
+                todo &= todo - 1;
+                const int c = __builtin_amdgcn_readfirstlane(__shfl(chunk, src));
+                strip_points(cc, M, W, H, xlo, xhi, keys, zimg, next, c * CELL_CHUNK, 4, lane, st);
             }
         }
     }
     if (stats) {
-        for (int i = 0; i < 3; ++i) {
-            unsigned v = st[i];
+        unsigned v[5] = {st_local[0], st_local[1], st_local[2], n_run, n_cull};
 #pragma unroll
-            for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
-            if (lane == 0 && v) atomicAdd(stats + (PASS_B ? 4 : 0) + i, (unsigned long long)v);
+        for (int i = 0; i < 5; ++i) {
+            if (i >= 3 && !PASS_B) v[i] = lane == 0 ? v[i] : 0;        // pass A counts per wave, pass B per 16-lane group
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) v[i] += __shfl_xor(v[i], o);
         }
         if (lane == 0) {
-            atomicAdd(stats + (PASS_B ? 11 : 8), (unsigned long long)(n_done - n_cull));
-            if (PASS_B) atomicAdd(stats + 9, (unsigned long long)n_cull);
+            for (int i = 0; i < 3; ++i)
+                if (v[i]) atomicAdd(stats + (PASS_B ? 4 : 0) + i, (unsigned long long)v[i]);
+            atomicAdd(stats + (PASS_B ? 11 : 8), (unsigned long long)v[3]);
+            if (PASS_B) atomicAdd(stats + 9, (unsigned long long)v[4]);
         }
     }
 }
@@ -641,6 +679,82 @@ __global__ __launch_bounds__(256) void cells_hiz_kernel(const unsigned long long
             m = max(max(m, z.x), max(max(z.y, z.z), z.w));
         }
     hiz[b] = hiz_encode(m);
+}
+
+// ---- GL twin features: point sizes, "ps" splats, discard, clip-space perturbation ------------------------------------
+// READ/gl/programs.py:121-198 (vertex shader) + READ/gl/render.py:52-85, canonical semantics as restated in
+// oracle/raster.c (oracle_raster_level_gl): perturbed clip coordinates, centre clipping, a square of side
+// s = point_size (or max(min_point_size, point_size / clip.z) for "ps" tokens, never below 1) covering pixel columns
+// floor(u - (s-1)/2) .. floor(u + (s-1)/2) (rows likewise) of THE LEVEL IT IS DRAWN INTO — so every level is rasterised
+// by its own pass (the 2x2 key-min pyramid only holds for 1-px points).  Augmentation path of the datasets
+// (READ/datasets/dynamic.py:235-239), not the per-frame viewer path: one plain pass over the cloud per level.
+struct GlOpts {
+    float point_size;
+    int relative;
+    float min_point_size;
+    const unsigned char *discard;
+    unsigned drop_threshold, drop_seed;
+    const float *perturb;
+    float perturb_amp;
+    unsigned perturb_seed;
+};
+
+__device__ __forceinline__ unsigned hash32(unsigned x)
+{
+    x ^= x >> 16; x *= 0x7feb352du; x ^= x >> 15; x *= 0x846ca68bu; x ^= x >> 16;
+    return x;
+}
+__device__ __forceinline__ unsigned rnd32(unsigned i, unsigned seed, unsigned k)
+{
+    return hash32(i ^ hash32(seed + 0x9e3779b9u * (k + 1u)));
+}
+
+__global__ __launch_bounds__(256) void splat_project_gl_kernel(const float *__restrict__ xyz, long long n, Cam1 cam,
+                                                               int W, int H, unsigned long long *__restrict__ keys, GlOpts o)
+{
+    const float *M = cam.m;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+        if (o.discard && o.discard[i]) continue;
+        if (o.drop_threshold && rnd32((unsigned)i, o.drop_seed, 0) < o.drop_threshold) continue;
+        const float x = xyz[3 * i], y = xyz[3 * i + 1], z = xyz[3 * i + 2];
+        float c0 = M[0] * x + M[1] * y + M[2] * z + M[3] * 1.0f;
+        float c1 = M[4] * x + M[5] * y + M[6] * z + M[7] * 1.0f;
+        const float c2 = M[8] * x + M[9] * y + M[10] * z + M[11] * 1.0f;
+        const float c3 = M[12] * x + M[13] * y + M[14] * z + M[15] * 1.0f;
+        if (o.perturb) {
+            c0 = c0 + o.perturb[2 * i];
+            c1 = c1 + o.perturb[2 * i + 1];
+        }
+        if (o.perturb_amp != 0.0f) {
+            const float ux = (float)(rnd32((unsigned)i, o.perturb_seed, 1) >> 8) * (1.0f / 16777216.0f);
+            const float uy = (float)(rnd32((unsigned)i, o.perturb_seed, 2) >> 8) * (1.0f / 16777216.0f);
+            c0 = c0 + o.perturb_amp * (ux - 0.5f);
+            c1 = c1 + o.perturb_amp * (uy - 0.5f);
+        }
+        const float nx = c0 / c3, ny = c1 / c3, nz = c2 / c3;
+        const bool inside = (nx >= -1.0f) & (nx <= 1.0f) & (ny >= -1.0f) & (ny <= 1.0f) & (nz >= -1.0f) & (nz <= 1.0f);
+        if (!inside) continue;
+        const float u = ((float)W * (nx + 1.0f)) * 0.5f;
+        const float v = ((float)H * (1.0f - ny)) * 0.5f;
+        const float d = (nz + 1.0f) * 0.5f;
+        if ((int)u < 0 || (int)u >= W || (int)v < 0 || (int)v >= H) continue;
+        float sz = o.point_size;
+        if (o.relative) {
+            sz = o.point_size / c2;
+            if (!(sz > o.min_point_size)) sz = o.min_point_size;
+        }
+        if (!(sz > 1.0f)) sz = 1.0f;
+        if (sz > 4096.0f) sz = 4096.0f;
+        const float half = 0.5f * (sz - 1.0f);
+        const int x0 = max((int)floorf(u - half), 0), x1 = min((int)floorf(u + half), W - 1);
+        const int y0 = max((int)floorf(v - half), 0), y1 = min((int)floorf(v + half), H - 1);
+        const unsigned long long key = ((unsigned long long)__float_as_uint(d) << 32) | (unsigned)i;
+        for (int yy = y0; yy <= y1; ++yy)
+            for (int xx = x0; xx <= x1; ++xx) {
+                unsigned long long *k = keys + (long long)yy * W + xx;
+                if (key < peek_key_agent(k)) fold_key_agent(k, key);
+            }
+    }
 }
 
 struct ResolveOut {
@@ -933,7 +1047,7 @@ int cells_frame(const CellCloud &cc, const float *M_host, int W, int H, int leve
     unsigned long long *stats = g_splat_stats ? (unsigned long long *)((char *)ws.hdr + HEADER_STATS_OFFSET) : nullptr;
     const int seed_blocks = ceil_div(W * H, 256);
     hipLaunchKernelGGL(cells_seed_classify_kernel, dim3((unsigned)(seed_blocks + ceil_div(cc.nchunks, 256))), dim3(256), 0,
-                       stream, cc, cam, W, H, ws.zimg, ws.hdr, (const int *)ws.prev[0], (const int *)ws.prev[1], si,
+                       stream, cc, cam, W, H, ws.keys, ws.zimg, ws.hdr, ws.prev[0], ws.prev[1], si,
                        seed_blocks, g_splat_cells_sub, (float)g_splat_near, g_splat_seeds);
     READ_CHECK_LAUNCH();
     const unsigned grid = (unsigned)(device_cus() * 8);
@@ -1254,6 +1368,47 @@ extern "C" int read_splat_forward_cells(const float *xyz, void *cells, int64_t n
     cc.nchunks = (int)cells_chunks(n);
     const WsLayout L = ws_layout(ws, B, W, H);
     return cells_frame(cc, M_host, W, H, levels, idx_levels, depth_levels, L, as_stream(stream));
+}
+
+extern "C" int read_splat_forward_gl(const float *xyz, int64_t n, const float *M_host, int W, int H,
+                                     const read_splat_gl_opts *opts, int32_t *idx, float *depth, void *ws,
+                                     size_t ws_bytes, void *stream)
+{
+    READ_CHECK_ARG(n >= 0 && (n == 0 || xyz), "read_splat_forward_gl: xyz is null");
+    READ_CHECK_ARG(n <= 0xFFFFFFFEll, "read_splat_forward_gl: point ids must fit 32 bits");
+    READ_CHECK_ARG(M_host && opts, "read_splat_forward_gl: M_host / opts is null");
+    READ_CHECK_ARG(W >= 1 && H >= 1 && (long long)W * H < (1ll << 31), "read_splat_forward_gl: bad size (%d,%d)", W, H);
+    READ_CHECK_ARG(idx || depth, "read_splat_forward_gl: no outputs requested");
+    READ_CHECK_ARG(opts->point_size >= 1.0f && opts->min_point_size >= 0.0f, "read_splat_forward_gl: point_size must be >= 1");
+    READ_CHECK_ARG(ws && (uintptr_t)ws % 256 == 0, "read_splat_forward_gl: workspace null or not 256-byte aligned");
+    if (ws_bytes < read_splat_workspace_bytes(1, W, H)) {
+        set_error("read_splat_forward_gl: workspace %zu < %zu bytes", ws_bytes, read_splat_workspace_bytes(1, W, H));
+        return READ_ENOMEM;
+    }
+    const WsLayout L = ws_layout(ws, 1, W, H);
+    hipStream_t s = as_stream(stream);
+    if (n > 0) {
+        Cam1 cam;
+        memcpy(cam.m, M_host, sizeof(cam.m));
+        GlOpts o;
+        o.point_size = opts->point_size;
+        o.relative = opts->relative;
+        o.min_point_size = opts->min_point_size;
+        o.discard = opts->discard;
+        o.drop_threshold = opts->drop_threshold;
+        o.drop_seed = opts->drop_seed;
+        o.perturb = opts->perturb;
+        o.perturb_amp = opts->perturb_amp;
+        o.perturb_seed = opts->perturb_seed;
+        int64_t blocks = ceil_div64(n, 256);
+        if (blocks > (int64_t)device_cus() * 8) blocks = (int64_t)device_cus() * 8;
+        hipLaunchKernelGGL(splat_project_gl_kernel, dim3((unsigned)blocks), dim3(256), 0, s, xyz, (long long)n, cam, W, H,
+                           L.keys, o);
+        READ_CHECK_LAUNCH();
+    }
+    int32_t *idx_l[1] = {idx};
+    float *dep_l[1] = {depth};
+    return resolve_launch(L.keys, 1, 0, W, H, 1, idx ? idx_l : nullptr, depth ? dep_l : nullptr, 0, L, 0, s);
 }
 
 extern "C" int read_index_to_float(const int32_t *idx, int64_t count, float *out, void *stream)
