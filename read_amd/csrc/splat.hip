@@ -311,7 +311,7 @@ __global__ __launch_bounds__(256) void splat_seed_kernel(const float *__restrict
 //   cells_seed_classify_kernel
 //       seed blocks      re-project last frame's front points (their POSITIONS in the sorted cloud were left in a
 //                        per-pixel image by the threads that issued atomics — any real point is a valid seed, so that
-//                        image may be written racily) and store key, depth bound and position with plain stores.
+//                        image may be written racily) and store their depths into zimg.  No atomics.
 //       classify blocks  one thread per chunk, from the 8 projected corners of its box: outside the frustum -> dropped
 //                        (no point of it is read); nearest corner closer than w_split, or every sub-th chunk -> list A;
 //                        the rest -> list B with its screen rectangle and depth threshold.  A chunk is appended to the
@@ -496,35 +496,35 @@ __global__ __launch_bounds__(256) void cells_seed_classify_kernel(CellCloud cc, 
     const int p = blockIdx.x * blockDim.x + threadIdx.x;
     if (p >= W * H) return;
     const int pos = (hdr->parity ? pos1 : pos0)[p];
-    int *next = hdr->parity ? pos0 : pos1;
     if ((unsigned)pos >= (unsigned)cc.nchunks * CELL_CHUNK) return;
     const float4 q = cc.pts[pos];
     float d;
     int xx, yy;
     const int pix = project_one(q.x, q.y, q.z, cam.m, W, H, d, xx, yy);
-    if (pix < 0) return;
-    // Plain stores, no atomics: the key image is EMPTY here, and whatever lands in a pixel — colliding seeds race, and
-    // the three stores of two seeds may interleave — is (i) the key of a real point at this pixel, (ii) the depth of a
-    // real point at this pixel = an upper bound of the final depth, (iii) the position of a real point = a valid seed.
-    // Every point of the cloud still comes by in the passes and passes the test when it can win (ties pass), so the
-    // minimum is established there; a seed that IS the winner finds its own key and skips its atomic.
-    keys[pix] = ((unsigned long long)__float_as_uint(d) << 32) | __float_as_uint(q.w);
-    zimg[pix] = __float_as_uint(d);
-    next[pix] = pos;
+    // the depth of a real point at this pixel bounds the final depth from above; the point itself is folded in when its
+    // chunk comes by (ties pass every test).  Colliding seeds race; either value is a valid bound.  (Also storing the
+    // seed's KEY with a plain store, so that the seed point can skip its atomic after reading its own key back, was
+    // measured slower: the dependent key reads cost more than the ~200 K atomics they saved.)
+    if (pix >= 0) zimg[pix] = __float_as_uint(d);
 }
 
 // `rounds` x 256 consecutive points of one chunk for one wave and one strip: zimg early-z, then atomic min on the key +
-// plain stores of the new bound and of the point's position (next frame's seed).
+// plain stores of the new bound and of the point's position (next frame's seed).  The records of round r+1 are loaded
+// before round r is processed (one HBM round trip per chunk instead of one per round on the critical path).
 __device__ __forceinline__ void strip_points(const CellCloud &cc, const float *M, int W, int H, int xlo, int xhi,
                                              unsigned long long *keys, unsigned *zimg, int *next, int first, int rounds,
                                              int lane, unsigned *st)
 {
+    float4 q[4], qn[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) q[k] = cc.pts[first + lane + 64 * k];
     for (int r = 0; r < rounds; ++r) {
         // 256 points: lane l takes records base + l + 64 k (each load instruction = 1 KiB contiguous)
         const int base = first + r * 256 + lane;
-        float4 q[4];
+        if (r + 1 < rounds) {
 #pragma unroll
-        for (int k = 0; k < 4; ++k) q[k] = cc.pts[base + 64 * k];
+            for (int k = 0; k < 4; ++k) qn[k] = cc.pts[base + 256 + 64 * k];
+        }
         int pix[4];
         unsigned dbits[4], bound[4];
 #pragma unroll
@@ -542,24 +542,20 @@ __device__ __forceinline__ void strip_points(const CellCloud &cc, const float *M
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
             if (pix[k] < 0 || dbits[k] > bound[k]) continue;       // ties pass: the atomic breaks them by id
-            const unsigned long long key = ((unsigned long long)dbits[k] << 32) | __float_as_uint(q[k].w);
-            if (dbits[k] == bound[k]) {
-                // A tie is almost always the seed point meeting its own key (cells_seed_classify_kernel): nothing to do.
-                // A stale copy of the key is only ever larger than the live one, so "it is me" stays true when stale.
-                if (st) st[1]++;
-                if (keys[pix[k]] == key) continue;
-            }
-            __hip_atomic_fetch_min(keys + pix[k], key, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_fetch_min(keys + pix[k], ((unsigned long long)dbits[k] << 32) | __float_as_uint(q[k].w),
+                                   __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             if (dbits[k] < bound[k]) zimg[pix[k]] = dbits[k];
             next[pix[k]] = base + 64 * k;                          // a front point of this pixel: next frame's seed
             if (st) st[2]++;
         }
+#pragma unroll
+        for (int k = 0; k < 4; ++k) q[k] = qn[k];
     }
 }
 
 // Pass A: an item = 1024 / sub_items consecutive points of one list-A chunk, for one wave and one strip.
-// Pass B: four list-B entries per wave step, one per group of 16 lanes: each group scans the hi-Z bounds of its chunk's
-// rectangle (inside the strip); chunks that survive are then processed by the whole wave.
+// Pass B: four list-B entries in flight per wave: the hi-Z bounds of their rectangles (inside the strip) are loaded together,
+// then reduced; chunks that survive are processed like pass-A chunks.
 template <bool PASS_B>
 __global__ __launch_bounds__(256) void cells_pass_kernel(CellCloud cc, Cam1 cam, int W, int H,
                                                          unsigned long long *keys, unsigned *zimg,
@@ -597,43 +593,45 @@ __global__ __launch_bounds__(256) void cells_pass_kernel(CellCloud cc, Cam1 cam,
     } else {
         const CellEntryB *list_b = cc.list_b + (size_t)s * cc.nchunks;
         const int n_list = sc->nB;
-        const int grp = lane >> 4, gl = lane & 15;
-        for (int t0 = wave * 4; t0 < n_list; t0 += n_waves * 4) {
-            const int t = t0 + grp;
-            bool run = false;
-            int chunk = 0;
-            if (t < n_list) {
-                const CellEntryB e = list_b[t];
-                chunk = e.chunk;
-                int bx0 = (int)(e.bx >> 16), bx1 = (int)(e.bx & 0xffffu);
-                const int by0 = (int)(e.by >> 16), by1 = (int)(e.by & 0xffffu);
+        constexpr int NB = 4;                                       // entries in flight per wave step
+        for (int t0 = wave; t0 < n_list; t0 += n_waves * NB) {
+            CellEntryB e[NB];
+            float emin[NB];
+            bool big[NB];
+#pragma unroll
+            for (int j = 0; j < NB; ++j) {
+                const int t = t0 + j * n_waves;
+                e[j] = list_b[t < n_list ? t : t0];
+            }
+#pragma unroll
+            for (int j = 0; j < NB; ++j) {
+                int bx0 = (int)(e[j].bx >> 16), bx1 = (int)(e[j].bx & 0xffffu);
+                const int by0 = (int)(e[j].by >> 16), by1 = (int)(e[j].by & 0xffffu);
                 bx0 = max(bx0, xlo >> 2);                          // only this strip's part of the rectangle matters here
                 bx1 = min(bx1, (xhi - 1) >> 2);
-                const int rw = bx1 - bx0 + 1, nblk = rw * (by1 - by0 + 1);
-                if (rw > 0) {
-                    run = true;
-                    if (nblk <= 4096) {
-                        float emin = 3.0e38f;                      // min over the rectangle of (1 - far bound)
-                        for (int i = gl; i < nblk; i += 16) {
-                            const int ry = by0 + i / rw, rx = bx0 + i % rw;
-                            emin = fminf(emin, __uint_as_float((unsigned)hiz_g[ry * nbx + rx] << 16));
-                        }
-#pragma unroll
-                        for (int o = 8; o > 0; o >>= 1) emin = fminf(emin, __shfl_xor(emin, o));
-                        if (e.e_thr < emin) run = false;           // every point of the box is behind every bound
+                const int rw = max(bx1 - bx0 + 1, 0), nblk = rw * (by1 - by0 + 1);
+                big[j] = nblk > 4096;
+                emin[j] = 3.0e38f;                                 // min over the rectangle of (1 - far bound)
+                if (!big[j])
+                    for (int i = lane; i < nblk; i += 64) {
+                        const int ry = by0 + i / rw, rx = bx0 + i % rw;
+                        emin[j] = fminf(emin[j], __uint_as_float((unsigned)hiz_g[ry * nbx + rx] << 16));
                     }
-                }
-                if (gl == 0) {
-                    if (run) ++n_run;
-                    else ++n_cull;
-                }
             }
-            unsigned long long todo = __ballot(run && gl == 0);
-            while (todo) {
-                const int src = __builtin_ctzll(todo);
-                todo &= todo - 1;
-                const int c = __builtin_amdgcn_readfirstlane(__shfl(chunk, src));
-                strip_points(cc, M, W, H, xlo, xhi, keys, zimg, next, c * CELL_CHUNK, 4, lane, st);
+#pragma unroll
+            for (int j = 0; j < NB; ++j) {
+                if (t0 + j * n_waves >= n_list) continue;
+#pragma unroll
+                for (int o = 32; o > 0; o >>= 1) emin[j] = fminf(emin[j], __shfl_xor(emin[j], o));
+                // an empty intersection with the strip leaves emin at +big: culled; otherwise cull iff every point of
+                // the box is behind every bound
+                if (!big[j] && e[j].e_thr < emin[j]) {
+                    ++n_cull;
+                    continue;
+                }
+                ++n_run;
+                strip_points(cc, M, W, H, xlo, xhi, keys, zimg, next, __builtin_amdgcn_readfirstlane(e[j].chunk) * CELL_CHUNK,
+                             4, lane, st);
             }
         }
     }
@@ -641,7 +639,7 @@ __global__ __launch_bounds__(256) void cells_pass_kernel(CellCloud cc, Cam1 cam,
         unsigned v[5] = {st_local[0], st_local[1], st_local[2], n_run, n_cull};
 #pragma unroll
         for (int i = 0; i < 5; ++i) {
-            if (i >= 3 && !PASS_B) v[i] = lane == 0 ? v[i] : 0;        // pass A counts per wave, pass B per 16-lane group
+            if (i >= 3) v[i] = lane == 0 ? v[i] : 0;                   // per-wave counters
 #pragma unroll
             for (int o = 32; o > 0; o >>= 1) v[i] += __shfl_xor(v[i], o);
         }
@@ -892,7 +890,7 @@ int g_splat_cells = 1;         // 0: ignore the cell-ordered copy (A/B)
 int g_splat_cells_sub = 32;    // list A also takes every n-th chunk (0: none): a first bound where nothing is near
 int g_splat_seeds = 1;         // 0: no warm start from the previous frame's front points (A/B)
 int g_splat_items = 1;         // work items per chunk in the striped passes (1, 2 or 4)
-int g_splat_strips = MAX_STRIPS;   // column strips of the striped passes (1, 2, 4 or 8)
+int g_splat_strips = 2;         // column strips of the striped passes (1, 2, 4 or 8); measured 0.1155 / 0.1064 / 0.1048 / 0.1059 ms at 8 / 4 / 2 / 1
 
 // Workspace layout (fixed by the (B, W, H) it was sized for; one workspace serves one such triple):
 //   [header 4096 B][key images: min(B,8) x W*H x 8 B][hi-z bounds: ceil(W/4)*ceil(H/4) x 4 B][seed image 0: W*H x 4 B]

@@ -63,9 +63,13 @@ class NetAndTexture(nn.Module):
         assert 'uv' in tokens[0], 'first input must be uv'
         only_uv = all('uv' in t for t in tokens)
         needs_grad = torch.is_grad_enabled() and texture.texture_.requires_grad
-        if only_uv and self.ss == 1 and not needs_grad:
+        if only_uv and not needs_grad:
             ids = [texture._ids(item[t]).to(texture.texture_.device) for t in tokens]
-            return [f.permute(0, 3, 1, 2) for f in gather_pyramid(texture.rows(), ids, texture.activation)]
+            if int(ids[0].max()) >= texture.texture_.shape[-1]:
+                raise IndexError(f"point id {int(ids[0].max())} out of range for a descriptor table of "
+                                 f"{texture.texture_.shape[-1]} points (wrong texture for this scene?)")
+            feats = gather_pyramid(texture.rows(), ids, texture.activation, ss=self.ss)     # ss > 1: fused bilinear reduce
+            return [f.permute(0, 3, 1, 2) for f in feats]
         scales, extras = [], []
         for t in tokens:
             if 'uv' in t:

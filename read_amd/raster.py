@@ -79,6 +79,47 @@ class PointCloudRasterizer:
                                               ws.data_ptr(), ws.numel(), _lib.stream_ptr()), "read_splat_forward_cells")
         return idx, dep
 
+    def render_gl(self, total_m, W, H, point_size=1.0, relative=False, min_point_size=1.0, discard=None, drop=None,
+                  perturb=None, perturb_hash=None, want_depth=True):
+        """ONE level of ONE camera at its own size with the GL twin's point options (read_splat_forward_gl):
+        point_size / relative ("pN" / "psN" tokens, READ/gl/programs.py:183-192), discard = bool/uint8 (N,) array or
+        tensor (set_point_discard), drop = (p, seed) seeded drop, perturb = (N,2) clip-space offsets
+        (set_point_perturb), perturb_hash = (amp, seed).  -> (idx (1,H,W) int32, depth (1,H,W) fp32 | None)."""
+        M = np.ascontiguousarray(total_m.detach().cpu().numpy() if torch.is_tensor(total_m) else total_m,
+                                 dtype=np.float32).reshape(-1, 16)
+        if M.shape[0] != 1:
+            raise ValueError("render_gl renders one camera per call")
+        o = _lib.SplatGlOpts(float(point_size), int(bool(relative)), float(min_point_size), None, 0, 0, None, 0.0, 0)
+        keep = []
+        if discard is not None:
+            d = torch.as_tensor(discard).to(self.device, torch.uint8).contiguous()
+            if d.numel() != self.n:
+                raise ValueError(f"discard mask has {d.numel()} entries for {self.n} points")
+            keep.append(d)
+            o.discard = d.data_ptr()
+        if drop is not None:
+            o.drop_threshold, o.drop_seed = drop_threshold(drop[0]), int(drop[1]) & 0xffffffff
+        if perturb is not None:
+            pt = torch.as_tensor(perturb).to(self.device, torch.float32).contiguous()
+            if tuple(pt.shape) != (self.n, 2):
+                raise ValueError(f"perturb must be ({self.n}, 2), got {tuple(pt.shape)}")
+            keep.append(pt)
+            o.perturb = pt.data_ptr()
+        if perturb_hash is not None:
+            o.perturb_amp, o.perturb_seed = float(perturb_hash[0]), int(perturb_hash[1]) & 0xffffffff
+        idx = torch.empty((1, H, W), dtype=torch.int32, device=self.device)
+        dep = torch.empty((1, H, W), dtype=torch.float32, device=self.device) if want_depth else None
+        ws = self._workspace(1, W, H)
+        _lib.check(_lib.lib().read_splat_forward_gl(self.xyz.data_ptr(), self.n, M.ctypes.data_as(C.POINTER(C.c_float)), W, H,
+                                                    C.byref(o), idx.data_ptr(), dep.data_ptr() if dep is not None else None,
+                                                    ws.data_ptr(), ws.numel(), _lib.stream_ptr()), "read_splat_forward_gl")
+        return idx, dep
+
+
+def drop_threshold(p):
+    """Probability -> u32 threshold of the seeded drop (point i dropped iff rnd(i, seed) < threshold)."""
+    return int(min(max(float(p), 0.0), 1.0) * 4294967295.0)
+
 
 def build_cells(xyz):
     """Host blob of ``read_splat_cells_build_host`` for an (N,3) float32 array (uint8 ndarray, upload as is)."""

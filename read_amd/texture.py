@@ -31,10 +31,26 @@ def rows_to_texture(rows_nc):
     return tex
 
 
-def gather_pyramid(rows_nc, idx_levels, activation="none", out=None):
-    """rows (N,C) + int32 index maps [(B,h,w)...] -> NHWC feature maps [(B,h,w,C)...]."""
+def gather_pyramid(rows_nc, idx_levels, activation="none", out=None, ss=1):
+    """rows (N,C) + int32 index maps [(B,h,w)...] -> NHWC feature maps [(B,h,w,C)...].
+    ss > 1: the index maps were rendered at ss x the feature size (READ/gl/nn.py:100-101) and the samples are reduced by
+    the bilinear downscale of READ/models/compose.py:162-163 inside the same launch -> [(B,h/ss,w/ss,C)...]."""
     n, Cc = rows_nc.shape
     levels = len(idx_levels)
+    if ss > 1:
+        B = int(idx_levels[0].shape[0])
+        hs = [int(i.shape[1]) // ss for i in idx_levels]
+        wsz = [int(i.shape[2]) // ss for i in idx_levels]
+        for i, h, w in zip(idx_levels, hs, wsz):
+            if i.shape[0] != B or h * ss != i.shape[1] or w * ss != i.shape[2]:
+                raise ValueError(f"index map {tuple(i.shape)} is not a multiple of supersampling {ss}")
+        if out is None:
+            out = [torch.empty((B, h, w, Cc), dtype=torch.float32, device=rows_nc.device) for h, w in zip(hs, wsz)]
+        _lib.check(_lib.lib().read_gather_forward_ss(
+            rows_nc.data_ptr(), n, Cc, levels, B, _lib.ptr_array([i.data_ptr() for i in idx_levels]),
+            (C.c_int * levels)(*hs), (C.c_int * levels)(*wsz), int(ss), _lib.ptr_array([o.data_ptr() for o in out]),
+            _ACT[activation], _lib.stream_ptr()), "read_gather_forward_ss")
+        return out
     if out is None:
         out = [torch.empty(tuple(i.shape) + (Cc,), dtype=torch.float32, device=rows_nc.device) for i in idx_levels]
     counts = (C.c_int64 * levels)(*[int(i.numel()) for i in idx_levels])
