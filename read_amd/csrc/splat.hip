@@ -511,9 +511,10 @@ __global__ __launch_bounds__(256) void cells_seed_classify_kernel(CellCloud cc, 
 // `rounds` x 256 consecutive points of one chunk for one wave and one strip: zimg early-z, then atomic min on the key +
 // plain stores of the new bound and of the point's position (next frame's seed).  The records of round r+1 are loaded
 // before round r is processed (one HBM round trip per chunk instead of one per round on the critical path).
+template <bool STATS>
 __device__ __forceinline__ void strip_points(const CellCloud &cc, const float *M, int W, int H, int xlo, int xhi,
                                              unsigned long long *keys, unsigned *zimg, int *next, int first, int rounds,
-                                             int lane, unsigned *st)
+                                             int lane, unsigned &st_in, unsigned &st_atomics)
 {
     float4 q[4], qn[4];
 #pragma unroll
@@ -534,7 +535,7 @@ __device__ __forceinline__ void strip_points(const CellCloud &cc, const float *M
             pix[k] = project_one(q[k].x, q[k].y, q[k].z, M, W, H, d, xx, yy);
             if (xx < xlo || xx >= xhi) pix[k] = -1;
             dbits[k] = __float_as_uint(d);
-            if (st && pix[k] >= 0) st[0]++;
+            if (STATS && pix[k] >= 0) st_in++;
         }
         // early-z against the bound image (L1 / this XCD's L2; a stale bound is only ever LARGER)
 #pragma unroll
@@ -546,7 +547,7 @@ __device__ __forceinline__ void strip_points(const CellCloud &cc, const float *M
                                    __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             if (dbits[k] < bound[k]) zimg[pix[k]] = dbits[k];
             next[pix[k]] = base + 64 * k;                          // a front point of this pixel: next frame's seed
-            if (st) st[2]++;
+            if (STATS) st_atomics++;
         }
 #pragma unroll
         for (int k = 0; k < 4; ++k) q[k] = qn[k];
@@ -556,7 +557,7 @@ __device__ __forceinline__ void strip_points(const CellCloud &cc, const float *M
 // Pass A: an item = 1024 / sub_items consecutive points of one list-A chunk, for one wave and one strip.
 // Pass B: four list-B entries in flight per wave: the hi-Z bounds of their rectangles (inside the strip) are loaded together,
 // then reduced; chunks that survive are processed like pass-A chunks.
-template <bool PASS_B>
+template <bool PASS_B, bool STATS>
 __global__ __launch_bounds__(256) void cells_pass_kernel(CellCloud cc, Cam1 cam, int W, int H,
                                                          unsigned long long *keys, unsigned *zimg,
                                                          const unsigned short *__restrict__ hiz_g, int nbx, void *hdr_v,
@@ -567,9 +568,7 @@ __global__ __launch_bounds__(256) void cells_pass_kernel(CellCloud cc, Cam1 cam,
     int *next = hdr->parity ? pos0 : pos1;
     const float *M = cam.m;
     const int lane = threadIdx.x & 63;
-    unsigned st_local[3] = {0, 0, 0};
-    unsigned *st = stats ? st_local : nullptr;
-    unsigned n_run = 0, n_cull = 0;
+    unsigned st_in = 0, st_atomics = 0, n_run = 0, n_cull = 0;
     // Strip = blockIdx % ns: with the round-robin dispatch of workgroups over the XCDs (block b -> XCD b % 8, observed, not
     // promised) all work of a strip runs on the same XCDs and shares their L2 view of zimg; any other placement only makes
     // bounds staler.  Lists are walked statically — wave w of the strip takes entries w, w + n_waves, ... — because a
@@ -588,66 +587,65 @@ __global__ __launch_bounds__(256) void cells_pass_kernel(CellCloud cc, Cam1 cam,
             const int li = t / sub_items, part = t - li * sub_items;
             const int chunk = __builtin_amdgcn_readfirstlane(list_a[li]);
             ++n_run;
-            strip_points(cc, M, W, H, xlo, xhi, keys, zimg, next, chunk * CELL_CHUNK + part * rounds * 256, rounds, lane, st);
+            strip_points<STATS>(cc, M, W, H, xlo, xhi, keys, zimg, next, chunk * CELL_CHUNK + part * rounds * 256, rounds, lane,
+                                st_in, st_atomics);
         }
     } else {
         const CellEntryB *list_b = cc.list_b + (size_t)s * cc.nchunks;
         const int n_list = sc->nB;
-        constexpr int NB = 4;                                       // entries in flight per wave step
-        for (int t0 = wave; t0 < n_list; t0 += n_waves * NB) {
-            CellEntryB e[NB];
-            float emin[NB];
-            bool big[NB];
+        // up to three entries per wave (2.3 on the benchmark scene): their records are fetched together, then each
+        // rectangle's bounds (one 2-byte load per lane for rectangles of <= 64 blocks); survivors are queued in a bit mask
+        // so that the point loop exists once in the code
+        for (int t0 = wave; t0 < n_list; t0 += 3 * n_waves) {
+            const int t1 = t0 + n_waves, t2 = t0 + 2 * n_waves;
+            const CellEntryB e0 = list_b[t0], e1 = list_b[t1 < n_list ? t1 : t0], e2 = list_b[t2 < n_list ? t2 : t0];
+            unsigned todo = 0;
 #pragma unroll
-            for (int j = 0; j < NB; ++j) {
-                const int t = t0 + j * n_waves;
-                e[j] = list_b[t < n_list ? t : t0];
-            }
-#pragma unroll
-            for (int j = 0; j < NB; ++j) {
-                int bx0 = (int)(e[j].bx >> 16), bx1 = (int)(e[j].bx & 0xffffu);
-                const int by0 = (int)(e[j].by >> 16), by1 = (int)(e[j].by & 0xffffu);
+            for (int j = 0; j < 3; ++j) {
+                const CellEntryB e = j == 0 ? e0 : (j == 1 ? e1 : e2);
+                if (j > 0 && t0 + j * n_waves >= n_list) continue;
+                int bx0 = (int)(e.bx >> 16), bx1 = (int)(e.bx & 0xffffu);
+                const int by0 = (int)(e.by >> 16), by1 = (int)(e.by & 0xffffu);
                 bx0 = max(bx0, xlo >> 2);                          // only this strip's part of the rectangle matters here
                 bx1 = min(bx1, (xhi - 1) >> 2);
-                const int rw = max(bx1 - bx0 + 1, 0), nblk = rw * (by1 - by0 + 1);
-                big[j] = nblk > 4096;
-                emin[j] = 3.0e38f;                                 // min over the rectangle of (1 - far bound)
-                if (!big[j])
+                const int rw = bx1 - bx0 + 1, nblk = rw * (by1 - by0 + 1);
+                bool run = rw > 0;
+                if (run && nblk <= 4096) {
+                    float emin = 3.0e38f;                          // min over the rectangle of (1 - far bound)
+                    const float inv_rw = 1.0f / (float)rw;
                     for (int i = lane; i < nblk; i += 64) {
-                        const int ry = by0 + i / rw, rx = bx0 + i % rw;
-                        emin[j] = fminf(emin[j], __uint_as_float((unsigned)hiz_g[ry * nbx + rx] << 16));
+                        int ry = (int)(((float)i + 0.5f) * inv_rw);   // i / rw for i < 4096 (exact: |error| << 0.5 / rw)
+                        const int rx = i - ry * rw;
+                        emin = fminf(emin, __uint_as_float((unsigned)hiz_g[(by0 + ry) * nbx + bx0 + rx] << 16));
                     }
-            }
 #pragma unroll
-            for (int j = 0; j < NB; ++j) {
-                if (t0 + j * n_waves >= n_list) continue;
-#pragma unroll
-                for (int o = 32; o > 0; o >>= 1) emin[j] = fminf(emin[j], __shfl_xor(emin[j], o));
-                // an empty intersection with the strip leaves emin at +big: culled; otherwise cull iff every point of
-                // the box is behind every bound
-                if (!big[j] && e[j].e_thr < emin[j]) {
-                    ++n_cull;
-                    continue;
+                    for (int o = 32; o > 0; o >>= 1) emin = fminf(emin, __shfl_xor(emin, o));
+                    run = !(e.e_thr < emin);                       // cull iff every point of the box is behind every bound
                 }
+                if (run) todo |= 1u << j;
+                else ++n_cull;
+            }
+            todo = __builtin_amdgcn_readfirstlane(todo);
+            while (todo) {
+                const int j = __builtin_ctz(todo);
+                todo &= todo - 1;
+                const int chunk = __builtin_amdgcn_readfirstlane(j == 0 ? e0.chunk : (j == 1 ? e1.chunk : e2.chunk));
                 ++n_run;
-                strip_points(cc, M, W, H, xlo, xhi, keys, zimg, next, __builtin_amdgcn_readfirstlane(e[j].chunk) * CELL_CHUNK,
-                             4, lane, st);
+                strip_points<STATS>(cc, M, W, H, xlo, xhi, keys, zimg, next, chunk * CELL_CHUNK, 4, lane, st_in, st_atomics);
             }
         }
     }
-    if (stats) {
-        unsigned v[5] = {st_local[0], st_local[1], st_local[2], n_run, n_cull};
+    if (STATS) {
+        unsigned v[4] = {st_in, st_atomics, lane == 0 ? n_run : 0u, lane == 0 ? n_cull : 0u};
 #pragma unroll
-        for (int i = 0; i < 5; ++i) {
-            if (i >= 3) v[i] = lane == 0 ? v[i] : 0;                   // per-wave counters
+        for (int i = 0; i < 4; ++i)
 #pragma unroll
             for (int o = 32; o > 0; o >>= 1) v[i] += __shfl_xor(v[i], o);
-        }
         if (lane == 0) {
-            for (int i = 0; i < 3; ++i)
-                if (v[i]) atomicAdd(stats + (PASS_B ? 4 : 0) + i, (unsigned long long)v[i]);
-            atomicAdd(stats + (PASS_B ? 11 : 8), (unsigned long long)v[3]);
-            if (PASS_B) atomicAdd(stats + 9, (unsigned long long)v[4]);
+            if (v[0]) atomicAdd(stats + (PASS_B ? 4 : 0), (unsigned long long)v[0]);
+            if (v[1]) atomicAdd(stats + (PASS_B ? 6 : 2), (unsigned long long)v[1]);
+            atomicAdd(stats + (PASS_B ? 11 : 8), (unsigned long long)v[2]);
+            if (PASS_B) atomicAdd(stats + 9, (unsigned long long)v[3]);
         }
     }
 }
@@ -890,6 +888,7 @@ int g_splat_cells = 1;         // 0: ignore the cell-ordered copy (A/B)
 int g_splat_cells_sub = 32;    // list A also takes every n-th chunk (0: none): a first bound where nothing is near
 int g_splat_seeds = 1;         // 0: no warm start from the previous frame's front points (A/B)
 int g_splat_items = 1;         // work items per chunk in the striped passes (1, 2 or 4)
+int g_splat_wgs = 8;            // workgroups per CU of the striped passes
 int g_splat_strips = 2;         // column strips of the striped passes (1, 2, 4 or 8); measured 0.1155 / 0.1064 / 0.1048 / 0.1059 ms at 8 / 4 / 2 / 1
 
 // Workspace layout (fixed by the (B, W, H) it was sized for; one workspace serves one such triple):
@@ -1048,15 +1047,17 @@ int cells_frame(const CellCloud &cc, const float *M_host, int W, int H, int leve
                        stream, cc, cam, W, H, ws.keys, ws.zimg, ws.hdr, ws.prev[0], ws.prev[1], si,
                        seed_blocks, g_splat_cells_sub, (float)g_splat_near, g_splat_seeds);
     READ_CHECK_LAUNCH();
-    const unsigned grid = (unsigned)(device_cus() * 8);
+    const unsigned grid = (unsigned)(device_cus() * g_splat_wgs);
     const int items = g_splat_items;
-    hipLaunchKernelGGL(cells_pass_kernel<false>, dim3(grid), dim3(256), 0, stream, cc, cam, W, H, ws.keys, ws.zimg,
+    auto pass_a = stats ? cells_pass_kernel<false, true> : cells_pass_kernel<false, false>;
+    auto pass_b = stats ? cells_pass_kernel<true, true> : cells_pass_kernel<true, false>;
+    hipLaunchKernelGGL(pass_a, dim3(grid), dim3(256), 0, stream, cc, cam, W, H, ws.keys, ws.zimg,
                        (const unsigned short *)ws.hiz, ws.nbx, ws.hdr, ws.prev[0], ws.prev[1], si, items, stats);
     READ_CHECK_LAUNCH();
     hipLaunchKernelGGL(cells_hiz_kernel, dim3(ceil_div(ws.nbx * ws.nby, 256)), dim3(256), 0, stream,
                        (const unsigned long long *)ws.keys, ws.zimg, W, H, ws.nbx, ws.nby, ws.hiz);
     READ_CHECK_LAUNCH();
-    hipLaunchKernelGGL(cells_pass_kernel<true>, dim3(grid), dim3(256), 0, stream, cc, cam, W, H, ws.keys, ws.zimg,
+    hipLaunchKernelGGL(pass_b, dim3(grid), dim3(256), 0, stream, cc, cam, W, H, ws.keys, ws.zimg,
                        (const unsigned short *)ws.hiz, ws.nbx, ws.hdr, ws.prev[0], ws.prev[1], si, items, stats);
     READ_CHECK_LAUNCH();
     return resolve_launch(ws.keys, 1, 0, W, H, levels, idx_levels, depth_levels, 0, ws, 2, stream);
@@ -1084,6 +1085,7 @@ void splat_set_cells(int v) { g_splat_cells = v; }
 void splat_set_seeds(int v) { g_splat_seeds = v; }
 void splat_set_cells_sub(int v) { g_splat_cells_sub = v < 0 ? 0 : v; }
 void splat_set_items(int v) { g_splat_items = v >= 4 ? 4 : (v >= 2 ? 2 : 1); }
+void splat_set_wgs(int v) { g_splat_wgs = v < 1 ? 1 : (v > 16 ? 16 : v); }
 void splat_set_strips(int v) { g_splat_strips = v >= 8 ? 8 : (v >= 4 ? 4 : (v >= 2 ? 2 : 1)); }
 int splat_get(const char *key, int *value)
 {
@@ -1096,6 +1098,7 @@ int splat_get(const char *key, int *value)
     else if (!strcmp(key, "splat_cells_sub")) *value = g_splat_cells_sub;
     else if (!strcmp(key, "splat_items")) *value = g_splat_items;
     else if (!strcmp(key, "splat_strips")) *value = g_splat_strips;
+    else if (!strcmp(key, "splat_wgs")) *value = g_splat_wgs;
     else return 0;
     return 1;
 }

@@ -4,9 +4,14 @@
 ``Scene``             the camera/cloud state of READ/gl/programs.py::NNScene that the render path reads
 ``MultiscaleRender``  READ/datasets/dynamic.py:50-99  (viewer / dataset path; GL FBOs replaced by the HIP splat)
 
-Only the ``uv_1d_p1[_dsK]`` input-format tokens (point ids, 1-px points) are rendered — the mode
-TexturePipeline uses; other GL modes (colours, normals, splat sizes > 1) are outside the hot path
- and raise NotImplementedError.
+``uv_1d_p1[_dsK]`` tokens (point ids, 1-px points: the layout TexturePipeline trains and renders with) take the single-pass
+pyramid rasteriser.  Every other token of the input-format DSL (READ/gl/dataset.py:39-82) that makes sense for a point cloud
+— ``pN`` point sizes, ``psN`` perspective splats, ``colors``, ``normals_{m,r,l,d}``, ``xyz``, ``depth``, ``labels`` — plus
+the dataset augmentations ``set_point_discard`` / ``set_point_perturb`` (READ/gl/programs.py:347-357) is rendered level by
+level through ``read_splat_forward_gl`` (the GL twin restated in oracle/raster.c): the z-buffer decides the winning point
+of every pixel, the vertex colour of that point (programs.py:133-181, flat shading) is looked up on the device.  Tokens
+that need triangles (no ``p``: mesh rendering, ``uv_2d`` mesh textures) and per-point size arrays raise
+NotImplementedError.
 """
 import re
 
@@ -18,22 +23,54 @@ from .camera import level_sizes, total_matrix
 from .raster import PointCloudRasterizer, index_to_float
 
 
+MODE_COLOR, MODE_NORMALS, MODE_DEPTH, MODE_UV, MODE_XYZ, MODE_LABEL = 0, 1, 2, 3, 4, 5      # NNScene.MODE_* (programs.py:16-21)
+UV_TYPE_1D, UV_TYPE_2D = 0, 1
+_NORMALS = ('normals_m', 'normals_r', 'normals_l', 'normals_d')
+
+
 def parse_input_string(string):
-    """Subset of READ/gl/dataset.py:39-82 needed on this path: mode, point size, downscale."""
-    if not re.search('^uv', string):
-        raise NotImplementedError(f"input format '{string}': only uv_1d point-id rendering is on the HIP path")
-    config = {'mode': 'uv_1d' if 'uv_1d' in string else 'uv_2d'}
-    if config['mode'] != 'uv_1d':
-        raise NotImplementedError("uv_2d (mesh textures) is outside the point-cloud hot path")
-    res = re.findall('ps[0-9]+|p[0-9]+', string)
-    config['point_size'] = int(re.search('[0-9]+', res[-1]).group()) if res else 1
-    config['splat_mode'] = bool(res) and res[-1].startswith('ps')
-    if config['point_size'] != 1 or config['splat_mode']:
-        raise NotImplementedError("point sizes > 1 / perspective splats are not on the HIP path")
-    res = re.findall('ds[0-5]+', string)
-    if res:
-        config['downscale'] = int(re.search('[0-9]+', res[-1]).group())
+    """The input-format DSL of READ/gl/dataset.py:39-82: ``<what>[_<variant>][_pN|_psN][_dsK]``.
+    -> {'mode': (mode0, mode1), 'draw_points', 'flat_color', 'point_size', 'splat_mode'[, 'downscale']}."""
+    config = {}
+    if re.search('^colors', string):
+        config['mode'] = (MODE_COLOR, None)
+    elif re.search('^uv', string):
+        kinds = re.findall('uv_1d|uv_2d', string)
+        if not kinds:
+            raise ValueError(string)
+        config['mode'] = (MODE_UV, UV_TYPE_1D if kinds[-1] == 'uv_1d' else UV_TYPE_2D)
+    elif re.search('^normals', string):
+        kinds = re.findall('|'.join(_NORMALS), string)
+        if not kinds:
+            raise ValueError(string)
+        config['mode'] = (MODE_NORMALS, _NORMALS.index(kinds[-1]))
+    elif re.search('^xyz', string):
+        config['mode'] = (MODE_XYZ, None)
+    elif re.search('^depth', string):
+        config['mode'] = (MODE_DEPTH, None)
+    elif re.search('^labels', string):
+        config['mode'] = (MODE_LABEL, None)
+    else:
+        raise ValueError(string)
+    sizes = re.findall('ps[0-9]+|p[0-9]+', string)
+    config['draw_points'] = config['flat_color'] = bool(sizes)
+    config['point_size'] = int(re.search('[0-9]+', sizes[-1]).group()) if sizes else 1
+    config['splat_mode'] = bool(sizes) and sizes[-1].startswith('ps')
+    scales = re.findall('ds[0-5]+', string)
+    if scales:
+        config['downscale'] = int(re.search('[0-9]+', scales[-1]).group())
     return config
+
+
+def is_point_id_pyramid(input_format):
+    """True when the tokens are exactly ``uv_1d_p1`` at downscale 0, 1, 2, ... — the layout served by ONE pass over the
+    cloud (pyramid identity)."""
+    try:
+        cfgs = [parse_input_string(t) for t in input_format.replace(' ', '').split(',')]
+    except ValueError:
+        return False
+    return all(c['mode'] == (MODE_UV, UV_TYPE_1D) and c['draw_points'] and c['point_size'] == 1 and not c['splat_mode']
+               and c.get('downscale', 0) == i for i, c in enumerate(cfgs))
 
 
 class MyRender:
@@ -90,7 +127,9 @@ class MyRender:
 
 
 class Scene:
-    """Camera + cloud state with NNScene's setter names (READ/gl/programs.py:330-415), no GL."""
+    """Camera + cloud state with NNScene's setter names (READ/gl/programs.py:300-415), no GL: positions and the
+    per-point attributes the vertex shader reads, the discard / perturb augmentation buffers, the draw parameters
+    ``set_params(**parse_input_string(token))`` sets."""
 
     def __init__(self, xyz=None):
         self.model_matrix = np.eye(4, dtype=np.float32)
@@ -99,12 +138,48 @@ class Scene:
         self._raster = None
         self._dirty = True
         self.xyz = None
+        self.colors = self.normals = None
+        self._dev = {}
+        self.point_discard = None         # bool (N,)  set_point_discard  (programs.py:347-351)
+        self.point_perturb = None         # float (N,2) set_point_perturb (programs.py:353-357)
+        self.point_drop = None            # (p, seed): seeded drop evaluated on the device
+        self.point_perturb_seeded = None  # (amp, seed)
+        self.params = {'mode': (MODE_UV, UV_TYPE_1D), 'draw_points': True, 'flat_color': True, 'point_size': 1,
+                       'splat_mode': False}
         if xyz is not None:
             self.set_vertices(xyz)
 
-    def set_vertices(self, positions):
+    def set_vertices(self, positions, colors=None, normals=None, uv1d=None, uv2d=None, texture=None):
+        positions = np.asarray(positions)
+        for name, a in (('colors', colors), ('normals', normals), ('uv1d', uv1d), ('uv2d', uv2d)):
+            assert a is None or positions.shape[0] == np.asarray(a).shape[0], 'arrays must have the same shape[0]'
         self.xyz = np.ascontiguousarray(positions, dtype=np.float32)
+        self.colors = None if colors is None else np.ascontiguousarray(colors, dtype=np.float32)
+        self.normals = None if normals is None else np.ascontiguousarray(normals, dtype=np.float32)
+        if uv1d is not None and not np.array_equal(np.asarray(uv1d).reshape(-1), np.arange(positions.shape[0])):
+            raise NotImplementedError("uv1d other than the point index (import_model3d's arange) is not supported")
+        self.xyz_min, self.xyz_max = self.xyz.min(axis=0), self.xyz.max(axis=0)          # programs.py:334-335
+        self.point_discard = self.point_perturb = None
+        self._dev = {}
         self._dirty = True
+
+    def set_point_sizes(self, point_sizes):
+        raise NotImplementedError("per-point size arrays (scene 'point_sizes') are not rendered; use pN / psN tokens")
+
+    def set_point_discard(self, arr):
+        self.point_discard = None if arr is None else np.ascontiguousarray(arr).astype(bool)
+
+    def set_point_perturb(self, arr):
+        self.point_perturb = None if arr is None else np.ascontiguousarray(arr, dtype=np.float32).reshape(-1, 2)
+
+    def set_point_drop(self, p, seed=0):
+        """Seeded form of ``set_point_discard(np.random.rand(N) < p)`` (READ/datasets/dynamic.py:235-236): evaluated on
+        the device from a hash of (point id, seed), restated bit for bit by oracle.drop_mask."""
+        self.point_drop = (float(p), int(seed)) if p else None
+
+    def set_point_perturb_seeded(self, amp, seed=0):
+        """Seeded form of ``set_point_perturb(amp * (rand(N,2) - 0.5))`` (dynamic.py:176-179,238-239)."""
+        self.point_perturb_seeded = (float(amp), int(seed)) if amp else None
 
     def set_model_view(self, m):
         self.model_matrix = np.asarray(m, np.float32)
@@ -117,10 +192,27 @@ class Scene:
         self.proj_matrix = np.asarray(m, np.float32)
 
     def set_use_light(self, use_light):
-        pass
+        if use_light:
+            raise NotImplementedError("the viewer's lighting pass is not part of the render path")
 
-    def set_params(self, **kwargs):
-        pass
+    def set_params(self, skip=(), **kwargs):
+        """programs.py:404-416: every key with a setter is applied; here the draw parameters are simply recorded."""
+        for k, v in kwargs.items():
+            if k not in skip:
+                self.params[k] = v
+
+    def augmented(self):
+        return (self.point_discard is not None or self.point_perturb is not None or self.point_drop is not None
+                or self.point_perturb_seeded is not None)
+
+    def device_array(self, name):
+        """colors / normals / xyz as (N,3) CUDA tensors, uploaded on first use."""
+        if name not in self._dev:
+            a = getattr(self, name)
+            if a is None:
+                a = np.zeros((self.xyz.shape[0], 3), np.float32)        # programs.py:326-327: missing attributes are zeros
+            self._dev[name] = torch.from_numpy(np.ascontiguousarray(a, np.float32)).to(_lib.require_gpu())
+        return self._dev[name]
 
     def rasterizer(self):
         if self._raster is None or self._dirty:
@@ -158,19 +250,88 @@ class MultiscaleRender:
         proj_matrix = self.proj_matrix if proj_matrix is None else proj_matrix
         if proj_matrix is not None:
             self.scene.set_proj_matrix(proj_matrix)
+        self.scene.set_use_light(False)
         input_format = input_format if input_format else self.input_format
         fmts = input_format.replace(' ', '').split(',')
-        cfgs = [parse_input_string(f) for f in fmts]
-        scales = [c.get('downscale', 0) for c in cfgs]
+        scene = self.scene
         W, H = self.ss * self.viewport_size[0], self.ss * self.viewport_size[1]
-        idx, _ = self.scene.rasterizer().render(self.scene.total_matrix(), W, H, max(scales) + 1, want_depth=False)
-        self.last_index = idx
         out = {}
-        for fmt, s in zip(fmts, scales):
-            ids = index_to_float(idx[s][0])
-            if self.gl_frame:
-                ids = ids.flip([0])
-            x = torch.zeros(ids.shape + (3,), dtype=torch.float32, device=ids.device)
-            x[..., 0] = ids
-            out[fmt] = x if self.out_buffer_location == 'torch' else x.cpu().numpy()
+        if is_point_id_pyramid(input_format) and not scene.augmented() and W % (1 << (len(fmts) - 1)) == 0 \
+                and H % (1 << (len(fmts) - 1)) == 0:
+            # the layout of TexturePipeline: one pass over the cloud feeds every scale
+            idx, _ = scene.rasterizer().render(scene.total_matrix(), W, H, len(fmts), want_depth=False)
+            self.last_index = idx
+            for fmt, ids_l in zip(fmts, idx):
+                out[fmt] = self._package(self._id_image(ids_l[0]), fmt)
+            return out
+        self.last_index = []
+        for fmt in fmts:
+            cfg = parse_input_string(fmt)
+            scene.set_params(**cfg)
+            s = cfg.get('downscale', 0)
+            w, h = W // 2 ** s, H // 2 ** s                       # dynamic.py:61: ss * viewport // 2**i
+            x = self._render_token(cfg, w, h)
+            out[fmt] = self._package(x, fmt)
         return out
+
+    # ---- one token = one GL draw of the reference (READ/gl/render.py:52-85) -------------------------------------------
+    def _id_image(self, ids):
+        x = torch.zeros(ids.shape + (3,), dtype=torch.float32, device=ids.device)
+        x[..., 0] = index_to_float(ids)
+        return x
+
+    def _package(self, x, fmt):
+        if self.gl_frame:
+            x = x.flip([0])
+        if ('depth' in fmt and 'depth3' not in fmt) or 'label' in fmt:          # dynamic.py:92-95
+            x = x[..., :1]
+        return x if self.out_buffer_location == 'torch' else x.cpu().numpy()
+
+    def _render_token(self, cfg, w, h):
+        scene = self.scene
+        if not cfg['draw_points']:
+            raise NotImplementedError("tokens without a point size draw triangles (mesh rendering); a point cloud needs pN / psN")
+        mode0, mode1 = cfg['mode']
+        if mode0 == MODE_UV and mode1 == UV_TYPE_2D:
+            raise NotImplementedError("uv_2d (mesh textures) is outside the point-cloud render path")
+        M = scene.total_matrix()
+        idx, dep = scene.rasterizer().render_gl(M, w, h, point_size=cfg['point_size'], relative=cfg['splat_mode'],
+                                                min_point_size=1.0, discard=scene.point_discard, drop=scene.point_drop,
+                                                perturb=scene.point_perturb, perturb_hash=scene.point_perturb_seeded)
+        self.last_index.append(idx)
+        ids, covered = idx[0], (dep[0] != 0) | (idx[0] != 0)
+        if mode0 == MODE_UV:
+            return self._id_image(ids)
+        lid = ids.long()
+        if mode0 == MODE_COLOR:
+            col = scene.device_array('colors')[lid]
+        elif mode0 == MODE_LABEL:                                                # programs.py:176-178
+            col = torch.zeros(ids.shape + (3,), dtype=torch.float32, device=ids.device)
+            col[..., 0] = scene.device_array('normals')[lid][..., 0] / 255.
+        elif mode0 == MODE_XYZ:                                                  # programs.py:172-175
+            lo = torch.from_numpy(scene.xyz_min).to(ids.device)
+            hi = torch.from_numpy(scene.xyz_max).to(ids.device)
+            col = (scene.device_array('xyz')[lid] - lo) / (hi - lo + 1e-9)
+        elif mode0 == MODE_DEPTH:                                                # programs.py:160-164: gl_Position.z
+            pos = scene.device_array('xyz')[lid]
+            m2 = torch.from_numpy(M[0, 2].copy()).to(ids.device)
+            d = m2[0] * pos[..., 0] + m2[1] * pos[..., 1] + m2[2] * pos[..., 2] + m2[3]
+            col = d[..., None].expand(-1, -1, 3)
+        else:                                                                    # programs.py:137-159
+            nrm = scene.device_array('normals')[lid]
+            cam = torch.from_numpy(np.ascontiguousarray(scene.view_matrix[:3, 3])).to(ids.device)
+            unit = lambda v: v / v.norm(dim=-1, keepdim=True)
+            if mode1 == 0:
+                col = nrm * 0.5 + 0.5
+            else:
+                vdir = unit(cam - scene.device_array('xyz')[lid])
+                if mode1 == 1:                                                   # reflect(I, N) = I - 2 dot(N, I) N
+                    col = unit(vdir - 2.0 * (nrm * vdir).sum(-1, keepdim=True) * nrm) * 0.5 + 0.5
+                elif mode1 == 2:                                                 # normal in the camera frame
+                    w2c = torch.from_numpy(np.linalg.inv(scene.view_matrix.astype(np.float32))).to(ids.device)
+                    p = cam + nrm
+                    local = p @ w2c[:3, :3].T + w2c[:3, 3]
+                    col = unit(local) * 0.5 + 0.5
+                else:
+                    col = vdir * 0.5 + 0.5
+        return torch.where(covered[..., None], col.float(), torch.zeros((), device=ids.device))

@@ -14,7 +14,12 @@ for s in $STEPS; do
   case $s in
     pytest) run pytest 1500 python -m pytest tests -m gpu -q --timeout 600 -p no:cacheprovider -s ;;
     splattest) run splattest 900 python -m pytest tests/test_gpu_splat.py -m gpu -q -x --timeout 600 -p no:cacheprovider -s ;;
-    splatprof) ( cd /tmp && SPLAT_PROBE_STATS=0 timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d "$O/${TAG}_splatprof" -o splat -- python "$R/tools/splat_cells_probe.py" ) > "$O/${TAG}_splatprof.log" 2>&1; echo "rc=$?" >> "$O/${TAG}_splatprof.log"; tail -n 3 "$O/${TAG}_splatprof.log"
+    splatprof) for v in "d" "s8:splat_strips=8" "s1i4:splat_strips=1 splat_items=4" "s2i2:splat_items=2" "s2i4:splat_items=4" "w7:splat_wgs=7" "w4:splat_wgs=4" "n24:splat_near=24" ${SPLAT_VARIANTS:-}; do
+              name=${v%%:*}; knobs=""; [ "$v" != "$name" ] && knobs=${v#*:}
+              ( cd /tmp && SPLAT_PROBE_STATS=0 timeout 200 rocprofv3 --kernel-trace --stats --output-format csv -d "$O/${TAG}_sp_$name" -o splat -- python "$R/tools/splat_cells_probe.py" 30000000 $knobs ) > "$O/${TAG}_sp_$name.log" 2>&1
+              grep "ms/frame" "$O/${TAG}_sp_$name.log" | sed "s/^/$name: /"
+            done
+            python "$R/tools/splat_kstats.py" "$O"/${TAG}_sp_*/ | tee "$O/${TAG}_splat_kernels.txt"
             run splatstats 300 python tools/splat_cells_probe.py ;;
     benchk) run benchk 600 python bench.py --config kitti6_like --detail "$O/${TAG}_detailk.json" ;;
     splat)  run splat 400 python tools/splat_modes.py --out "$O/${TAG}_splat_modes.json" ;;
