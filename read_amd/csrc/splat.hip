@@ -511,7 +511,7 @@ __global__ __launch_bounds__(256) void cells_seed_classify_kernel(CellCloud cc, 
 // `rounds` x 256 consecutive points of one chunk for one wave and one strip: zimg early-z, then atomic min on the key +
 // plain stores of the new bound and of the point's position (next frame's seed).  The records of round r+1 are loaded
 // before round r is processed (one HBM round trip per chunk instead of one per round on the critical path).
-template <bool STATS>
+template <bool STATS, bool ZL2>
 __device__ __forceinline__ void strip_points(const CellCloud &cc, const float *M, int W, int H, int xlo, int xhi,
                                              unsigned long long *keys, unsigned *zimg, int *next, int first, int rounds,
                                              int lane, unsigned &st_in, unsigned &st_atomics)
@@ -539,7 +539,10 @@ __device__ __forceinline__ void strip_points(const CellCloud &cc, const float *M
         }
         // early-z against the bound image (L1 / this XCD's L2; a stale bound is only ever LARGER)
 #pragma unroll
-        for (int k = 0; k < 4; ++k) bound[k] = pix[k] >= 0 ? zimg[pix[k]] : 0u;
+        for (int k = 0; k < 4; ++k)
+            bound[k] = pix[k] < 0 ? 0u
+                       : ZL2 ? __hip_atomic_load(zimg + pix[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)   // sc1: L2, not L1
+                             : zimg[pix[k]];
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
             if (pix[k] < 0 || dbits[k] > bound[k]) continue;       // ties pass: the atomic breaks them by id
@@ -557,7 +560,7 @@ __device__ __forceinline__ void strip_points(const CellCloud &cc, const float *M
 // Pass A: an item = 1024 / sub_items consecutive points of one list-A chunk, for one wave and one strip.
 // Pass B: four list-B entries in flight per wave: the hi-Z bounds of their rectangles (inside the strip) are loaded together,
 // then reduced; chunks that survive are processed like pass-A chunks.
-template <bool PASS_B, bool STATS>
+template <bool PASS_B, bool STATS, bool ZL2>
 __global__ __launch_bounds__(256) void cells_pass_kernel(CellCloud cc, Cam1 cam, int W, int H,
                                                          unsigned long long *keys, unsigned *zimg,
                                                          const unsigned short *__restrict__ hiz_g, int nbx, void *hdr_v,
@@ -587,7 +590,7 @@ __global__ __launch_bounds__(256) void cells_pass_kernel(CellCloud cc, Cam1 cam,
             const int li = t / sub_items, part = t - li * sub_items;
             const int chunk = __builtin_amdgcn_readfirstlane(list_a[li]);
             ++n_run;
-            strip_points<STATS>(cc, M, W, H, xlo, xhi, keys, zimg, next, chunk * CELL_CHUNK + part * rounds * 256, rounds, lane,
+            strip_points<STATS, ZL2>(cc, M, W, H, xlo, xhi, keys, zimg, next, chunk * CELL_CHUNK + part * rounds * 256, rounds, lane,
                                 st_in, st_atomics);
         }
     } else {
@@ -631,7 +634,7 @@ __global__ __launch_bounds__(256) void cells_pass_kernel(CellCloud cc, Cam1 cam,
                 todo &= todo - 1;
                 const int chunk = __builtin_amdgcn_readfirstlane(j == 0 ? e0.chunk : (j == 1 ? e1.chunk : e2.chunk));
                 ++n_run;
-                strip_points<STATS>(cc, M, W, H, xlo, xhi, keys, zimg, next, chunk * CELL_CHUNK, 4, lane, st_in, st_atomics);
+                strip_points<STATS, ZL2>(cc, M, W, H, xlo, xhi, keys, zimg, next, chunk * CELL_CHUNK, 4, lane, st_in, st_atomics);
             }
         }
     }
@@ -888,8 +891,10 @@ int g_splat_cells = 1;         // 0: ignore the cell-ordered copy (A/B)
 int g_splat_cells_sub = 32;    // list A also takes every n-th chunk (0: none): a first bound where nothing is near
 int g_splat_seeds = 1;         // 0: no warm start from the previous frame's front points (A/B)
 int g_splat_items = 1;         // work items per chunk in the striped passes (1, 2 or 4)
+int g_splat_zl2 = 0;            // 1: early-z loads bypass the L1 (sc1)
 int g_splat_wgs = 8;            // workgroups per CU of the striped passes
-int g_splat_strips = 2;         // column strips of the striped passes (1, 2, 4 or 8); measured 0.1155 / 0.1064 / 0.1048 / 0.1059 ms at 8 / 4 / 2 / 1
+int g_splat_strips = MAX_STRIPS;   // column strips of the striped passes (1, 2, 4 or 8); pass A measured 61.5 / 75.5 / 70 us at
+                               // 8 / 2 / 1 (with 4 items per chunk): its time follows the number of atomics (0.92 M / 1.16 M)
 
 // Workspace layout (fixed by the (B, W, H) it was sized for; one workspace serves one such triple):
 //   [header 4096 B][key images: min(B,8) x W*H x 8 B][hi-z bounds: ceil(W/4)*ceil(H/4) x 4 B][seed image 0: W*H x 4 B]
@@ -1049,8 +1054,10 @@ int cells_frame(const CellCloud &cc, const float *M_host, int W, int H, int leve
     READ_CHECK_LAUNCH();
     const unsigned grid = (unsigned)(device_cus() * g_splat_wgs);
     const int items = g_splat_items;
-    auto pass_a = stats ? cells_pass_kernel<false, true> : cells_pass_kernel<false, false>;
-    auto pass_b = stats ? cells_pass_kernel<true, true> : cells_pass_kernel<true, false>;
+    auto pass_a = stats ? cells_pass_kernel<false, true, false>
+                        : (g_splat_zl2 ? cells_pass_kernel<false, false, true> : cells_pass_kernel<false, false, false>);
+    auto pass_b = stats ? cells_pass_kernel<true, true, false>
+                        : (g_splat_zl2 ? cells_pass_kernel<true, false, true> : cells_pass_kernel<true, false, false>);
     hipLaunchKernelGGL(pass_a, dim3(grid), dim3(256), 0, stream, cc, cam, W, H, ws.keys, ws.zimg,
                        (const unsigned short *)ws.hiz, ws.nbx, ws.hdr, ws.prev[0], ws.prev[1], si, items, stats);
     READ_CHECK_LAUNCH();
@@ -1085,6 +1092,7 @@ void splat_set_cells(int v) { g_splat_cells = v; }
 void splat_set_seeds(int v) { g_splat_seeds = v; }
 void splat_set_cells_sub(int v) { g_splat_cells_sub = v < 0 ? 0 : v; }
 void splat_set_items(int v) { g_splat_items = v >= 4 ? 4 : (v >= 2 ? 2 : 1); }
+void splat_set_zl2(int v) { g_splat_zl2 = v != 0; }
 void splat_set_wgs(int v) { g_splat_wgs = v < 1 ? 1 : (v > 16 ? 16 : v); }
 void splat_set_strips(int v) { g_splat_strips = v >= 8 ? 8 : (v >= 4 ? 4 : (v >= 2 ? 2 : 1)); }
 int splat_get(const char *key, int *value)
@@ -1099,6 +1107,7 @@ int splat_get(const char *key, int *value)
     else if (!strcmp(key, "splat_items")) *value = g_splat_items;
     else if (!strcmp(key, "splat_strips")) *value = g_splat_strips;
     else if (!strcmp(key, "splat_wgs")) *value = g_splat_wgs;
+    else if (!strcmp(key, "splat_zl2")) *value = g_splat_zl2;
     else return 0;
     return 1;
 }

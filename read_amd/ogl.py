@@ -67,8 +67,8 @@ class OGL:
         """-> {'output': H x W x 4 float tensor (RGB + alpha 1), 'net_input': list of NCHW feature maps}."""
         model = self.model
         texture = model._modules[str(model._loaded_textures[0])] if model._loaded_textures else model._modules['0']
-        fast = (input_dict is None and model.ss == 1 and not model.temporal_average and self._fast_format
-                and hasattr(model.net, 'engine'))
+        fast = (input_dict is None and not model.temporal_average and self._fast_format
+                and not self.renderer.scene.augmented() and hasattr(model.net, 'engine'))
         with torch.set_grad_enabled(False):
             if fast:
                 scene = self.renderer.scene
@@ -77,8 +77,9 @@ class OGL:
                 raster = scene.rasterizer()
                 if raster.n != texture.texture_.shape[-1]:
                     raise ValueError(f"descriptor table has {texture.texture_.shape[-1]} points, the scene cloud {raster.n}")
-                idx, _ = raster.render(scene.total_matrix(), W, H, len(fmts), want_depth=False)
-                feats = gather_pyramid(texture.rows(), idx, texture.activation)
+                ss = int(model.ss)                               # supersampling: raster at ss x, reduce in the gather
+                idx, _ = raster.render(scene.total_matrix(), ss * W, ss * H, len(fmts), want_depth=False)
+                feats = gather_pyramid(texture.rows(), idx, texture.activation, ss=ss)
                 out = model.net.engine(H, W).forward(feats[0][0], feats[1][0], feats[2][0], feats[3][0], channels=4)
                 net_input = [f.permute(0, 3, 1, 2) for f in feats]
             else:

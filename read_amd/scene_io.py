@@ -341,16 +341,19 @@ def load_scene_data(path):
 
 
 def setup_scene(scene, data, use_mesh=False, use_texture=False):
-    """READ/gl/utils.py:214-255 for a point-cloud ``read_amd.render.Scene``: positions, projection, first camera
-    pose, model matrix (colours / normals / faces / point sizes have no consumer on the uv_1d path)."""
+    """READ/gl/utils.py:214-255 for a point-cloud ``read_amd.render.Scene``: positions, colours, normals, projection,
+    first camera pose, model matrix (faces have no consumer without mesh rendering; per-point size arrays raise)."""
     if use_mesh or use_texture or data.get('pointcloud') is None:
         raise NotImplementedError("only point-cloud scenes are rendered (DESIGN.md §6)")
-    scene.set_vertices(data['pointcloud']['xyz'])
+    pc = data['pointcloud']
+    scene.set_vertices(positions=pc['xyz'], colors=pc.get('rgb'), normals=pc.get('normals'), uv1d=pc.get('uv1d'))
     if data.get('proj_matrix') is not None:
         scene.set_proj_matrix(data['proj_matrix'])
     if data.get('view_matrix') is not None and len(data['view_matrix']) > 0:
         scene.set_camera_view(data['view_matrix'][0])
     scene.set_model_view(data['model3d_origin'])
+    if data.get('point_sizes') is not None:
+        scene.set_point_sizes(data['point_sizes'])
 
 
 def load_scene(config_path):

@@ -47,12 +47,48 @@ def test_unet_state_dict_names_and_blob():
         UNet(num_input_channels=3)
 
 
-def test_input_format_tokens():
-    assert parse_input_string("uv_1d_p1") == {'mode': 'uv_1d', 'point_size': 1, 'splat_mode': False}
-    assert parse_input_string("uv_1d_p1_ds3")['downscale'] == 3
-    for bad in ("colors_p1", "uv_1d_ps4", "uv_2d"):
-        with pytest.raises(NotImplementedError):
+def test_input_format_tokens(golden_dir):
+    """The whole DSL against the reference's own parse_input_string (tests/golden/make_tokens_golden.py executes its
+    source text): every key and value equal."""
+    import json
+    from read_amd.render import is_point_id_pyramid
+    g = json.load(open(os.path.join(golden_dir, "input_tokens.json")))
+    assert len(g["tokens"]) >= 19
+    for tok, want in g["tokens"].items():
+        got = parse_input_string(tok)
+        got["mode"] = list(got["mode"])
+        assert got == want, (tok, got, want)
+    for bad in g["value_error"]:
+        with pytest.raises(ValueError):
             parse_input_string(bad)
+    assert is_point_id_pyramid("uv_1d_p1, uv_1d_p1_ds1, uv_1d_p1_ds2, uv_1d_p1_ds3, uv_1d_p1_ds4")
+    for fmt in ("uv_1d_p1, uv_1d_p2_ds1", "uv_1d_p1_ds1", "colors_p1", "uv_1d_ps4", "uv_1d_p1, uv_1d_p1_ds2"):
+        assert not is_point_id_pyramid(fmt)
+
+
+def test_scene_setters_and_refusals():
+    """NNScene's setter surface (READ/gl/programs.py:300-415) on the GL-free Scene."""
+    xyz = synthetic.make_cloud(50)
+    s = Scene()
+    s.set_vertices(xyz, colors=np.ones((50, 3)), normals=np.zeros((50, 3)), uv1d=np.arange(50), uv2d=np.zeros((50, 2)))
+    assert not s.augmented()
+    s.set_point_discard(np.arange(50) % 2 == 0)
+    assert s.augmented() and s.point_discard.dtype == bool
+    s.set_point_discard(None)
+    s.set_point_perturb(np.zeros((50, 2)))
+    assert s.augmented()
+    s.set_point_perturb(None)
+    s.set_point_drop(0.25, seed=3)
+    s.set_point_perturb_seeded(0.1, seed=4)
+    assert s.point_drop == (0.25, 3) and s.point_perturb_seeded == (0.1, 4)
+    s.set_params(**parse_input_string("colors_ps7_ds1"))
+    assert s.params["point_size"] == 7 and s.params["splat_mode"] and s.params["mode"] == (0, None)
+    with pytest.raises(NotImplementedError):
+        s.set_point_sizes(np.ones(50))
+    with pytest.raises(NotImplementedError):
+        s.set_vertices(xyz, uv1d=np.arange(50)[::-1])
+    with pytest.raises(AssertionError):
+        s.set_vertices(xyz, colors=np.ones((49, 3)))
 
 
 def test_scene_total_matrix_matches_myrender_formula():

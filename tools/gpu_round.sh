@@ -14,7 +14,7 @@ for s in $STEPS; do
   case $s in
     pytest) run pytest 1500 python -m pytest tests -m gpu -q --timeout 600 -p no:cacheprovider -s ;;
     splattest) run splattest 900 python -m pytest tests/test_gpu_splat.py -m gpu -q -x --timeout 600 -p no:cacheprovider -s ;;
-    splatprof) for v in "d" "s8:splat_strips=8" "s1i4:splat_strips=1 splat_items=4" "s2i2:splat_items=2" "s2i4:splat_items=4" "w7:splat_wgs=7" "w4:splat_wgs=4" "n24:splat_near=24" ${SPLAT_VARIANTS:-}; do
+    splatprof) for v in ${SPLAT_VARIANTS:-"d" "zl2:splat_zl2=1" "i2:splat_items=2" "i4:splat_items=4" "zl2i4:splat_zl2=1 splat_items=4"}; do
               name=${v%%:*}; knobs=""; [ "$v" != "$name" ] && knobs=${v#*:}
               ( cd /tmp && SPLAT_PROBE_STATS=0 timeout 200 rocprofv3 --kernel-trace --stats --output-format csv -d "$O/${TAG}_sp_$name" -o splat -- python "$R/tools/splat_cells_probe.py" 30000000 $knobs ) > "$O/${TAG}_sp_$name.log" 2>&1
               grep "ms/frame" "$O/${TAG}_sp_$name.log" | sed "s/^/$name: /"
