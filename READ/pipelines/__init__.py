@@ -1,1 +1,4 @@
-from read_amd.pipeline import Pipeline, load_pipeline, save_pipeline  # noqa: F401
+from pkgutil import extend_path
+
+__path__ = extend_path(__path__, __name__)   # the rest of this package keeps resolving to the reference checkout
+from read_amd.pipeline import Pipeline, load_pipeline, save_pipeline  # noqa: F401,E402

@@ -890,8 +890,8 @@ int g_splat_near = 12;         // cell path: pass A takes chunks nearer than the
 int g_splat_cells = 1;         // 0: ignore the cell-ordered copy (A/B)
 int g_splat_cells_sub = 32;    // list A also takes every n-th chunk (0: none): a first bound where nothing is near
 int g_splat_seeds = 1;         // 0: no warm start from the previous frame's front points (A/B)
-int g_splat_items = 1;         // work items per chunk in the striped passes (1, 2 or 4)
-int g_splat_zl2 = 0;            // 1: early-z loads bypass the L1 (sc1)
+int g_splat_items = 4;         // work items per chunk in the striped passes (1, 2 or 4): 0.101 / 0.101 / 0.097 ms per frame
+int g_splat_zl2 = 0;            // 1: early-z loads bypass the L1 (sc1); measured slower (0.107 vs 0.101 ms)
 int g_splat_wgs = 8;            // workgroups per CU of the striped passes
 int g_splat_strips = MAX_STRIPS;   // column strips of the striped passes (1, 2, 4 or 8); pass A measured 61.5 / 75.5 / 70 us at
                                // 8 / 2 / 1 (with 4 items per chunk): its time follows the number of atomics (0.92 M / 1.16 M)

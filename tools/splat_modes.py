@@ -14,7 +14,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from read_amd import _lib, camera, synthetic          # noqa: E402
 from read_amd.raster import PointCloudRasterizer      # noqa: E402
 
-DEFAULTS = {"splat_mode": 7, "splat_cells": 1, "splat_seeds": 1, "splat_near": 12, "splat_cells_sub": 32, "splat_items": 1,
+DEFAULTS = {"splat_mode": 7, "splat_cells": 1, "splat_seeds": 1, "splat_near": 12, "splat_cells_sub": 32, "splat_items": 4,
             "splat_subset": 8, "splat_strips": 8, "splat_zl2": 0, "splat_wgs": 8}
 VARIANTS = [
     ("default: striped cell-ordered passes, zimg early-z, warm start", {}),
@@ -25,7 +25,7 @@ VARIANTS = [
     ("1 strip, items per chunk 2", {"splat_strips": 1, "splat_items": 2}),
     ("1 strip, items per chunk 4", {"splat_strips": 1, "splat_items": 4}),
     ("items per chunk 2", {"splat_items": 2}),
-    ("items per chunk 4", {"splat_items": 4}),
+    ("items per chunk 1", {"splat_items": 1}),
     ("near split 6 points/pixel", {"splat_near": 6}),
     ("near split 24 points/pixel", {"splat_near": 24}),
     ("near split 48 points/pixel", {"splat_near": 48}),
