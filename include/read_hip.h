@@ -203,6 +203,9 @@ typedef struct read_conv_desc {
     int config;                             /* tile configuration id, -1 = pick automatically */
     const float *wpacked_wino;              /* optional: read_conv_pack_wino_host() output (device); enables the
                                                Winograd F(2x2,3x3) kernel for 3x3/s1 single-source layers */
+    int linear;                             /* 1: plain convolution (training path): out[..][c] = conv_f + b_f,
+                                               out[..][Cout + c] = conv_m + b_m, out_cstride >= 2 * Cout; no gate /
+                                               BatchNorm / residual; always the workgroup-tiled kernel */
 } read_conv_desc;
 
 /* Sizes (in floats) of the packed weight / parameter blocks of one BasicConv. */
@@ -227,6 +230,51 @@ const char *read_conv_config_name(int config);
 
 /* out[y][x][c] = bilinear x4 (align_corners=False) of in, NHWC, C % 4 == 0. */
 int read_bilinear_up4(const float *in, int inH, int inW, int C, float *out, void *stream);
+
+/* ---------------------------------------------------------------- training step (csrc/train.hip)
+ * Backward of one BasicConv, y = BN_eval(act(f) * sigmoid(m)) with [f | m] = conv_{f|m}(x) + b (READ/models/unet.py:44-53 under
+ * torch.autograd in src/train.py:132-203); BatchNorm as the eval-mode affine map (configs/train_example.yaml eval_in_train).
+ *   forward (training)  read_conv_pack_params_device + read_conv_pack_weights_device, read_gated_conv_forward with
+ *                       desc.linear = 1 -> pre-activations [pixels][2*Cout], read_gate_forward -> y
+ *   backward            read_gate_backward: dy, [f|m] -> dfm [pixels][2*Cp] (Cp = Cout rounded up to 8; df | dm) and the
+ *                       per-channel sums S[4][Cout] = {sum df, sum dm, sum dy, sum dy*g}; read_bn_param_grads turns them
+ *                       into db_f, db_m, dgamma, dbeta (accumulating);
+ *                       dgrad: stride 1 -> read_conv_pack_dgrad_device + read_gated_conv_forward(linear = 1) over dfm with
+ *                       Cout := Cin/2, zero biases (the same MFMA kernel with flipped, transposed weights);
+ *                       stride 2 -> read_conv_dgrad_generic;
+ *                       read_conv_wgrad: x, dfm -> dW_f, dW_m in the PyTorch layout (Cout, Cin, k, k), MFMA, split over
+ *                       pixel rows with a scratch of read_conv_wgrad_scratch_floats(). */
+int read_conv_pack_params_device(int Cout, const float *bf, const float *bm, const float *gamma, const float *beta,
+                                 const float *mean, const float *var, float eps, float *params, void *stream);
+int read_conv_pack_weights_device(int Cin, int Cout, int ksize, int kc, const float *wf, const float *wm, float *wpacked,
+                                  void *stream);
+size_t read_conv_dgrad_packed_floats(int Cin, int Cout, int ksize);
+int read_conv_pack_dgrad_device(int Cin, int Cout, int ksize, int kc, const float *wf, const float *wm, float *wpacked,
+                                void *stream);
+int read_gate_forward(const float *fm, int64_t pixels, int Cout, const float *params, int elu, const float *residual,
+                      float *y, void *stream);
+int read_gate_backward(const float *dy, const float *fm, int64_t pixels, int Cout, const float *params, int elu, float *dfm,
+                       float *sums, void *stream);
+int read_bn_param_grads(int Cout, const float *sums, const float *mean, const float *var, float eps, float *dbf, float *dbm,
+                        float *dgamma, float *dbeta, void *stream);
+size_t read_conv_dgrad_generic_floats(int Cin, int Cout, int ksize);
+int read_conv_dgrad_generic(const float *dfm, int outH, int outW, int Cin, int Cout, int ksize, int stride, const float *wf,
+                            const float *wm, float *wscratch, int inH, int inW, float *dx, void *stream);
+size_t read_conv_wgrad_scratch_floats(int Cin, int Cout, int ksize, int outH);
+int read_conv_wgrad(const float *x, int inH, int inW, int Cin, const float *dfm, int Cout, int ksize, int stride, float *dwf,
+                    float *dwm, int accumulate, float *scratch, size_t scratch_floats, void *stream);
+/* adjoint of read_bilinear_up4: dout [4*inH][4*inW][C] -> din [inH][inW][C] */
+int read_bilinear_up4_backward(const float *dout, int inH, int inW, int C, float *din, void *stream);
+/* F.huber_loss(out, target) (delta 1, mean; src/READ/models/compose.py:35,38): *loss_sum = sum of the per-element losses
+ * (divide by n), grad[i] = grad_scale * clip(out - target, -1, 1).  Either output may be NULL. */
+int read_huber_loss(const float *out, const float *target, int64_t n, float grad_scale, float *loss_sum, float *grad,
+                    void *stream);
+/* RMSprop (READ/pipelines/ogl.py:16,99-100 defaults: alpha 0.99, eps 1e-8) over the descriptor ROWS the step touched only:
+ * ids = the step's int32 index maps; every touched row is updated once, its gradient row is zeroed again, and the decay
+ * of the steps in which it was not touched (gradient 0 in the dense optimizer) is applied lazily from `stamp`
+ * (int32 per row, zero-initialised; step counts from 1).  rows / sq / grad are N x C. */
+int read_rmsprop_sparse(float *rows, float *sq, float *grad, int32_t *stamp, int C, int64_t n_rows, const int32_t *ids,
+                        int64_t n_ids, int step, float lr, float alpha, float eps, void *stream);
 
 /* ---------------------------------------------------------------- UNet */
 

@@ -28,7 +28,7 @@ class ConvDesc(C.Structure):
         ("inH", C.c_int), ("inW", C.c_int), ("Cout", C.c_int), ("ksize", C.c_int), ("stride", C.c_int),
         ("elu", C.c_int), ("wpacked", C.c_void_p), ("params", C.c_void_p), ("residual", C.c_void_p),
         ("out", C.c_void_p), ("out_cstride", C.c_int), ("out_fill", C.c_float), ("fill_pad", C.c_int),
-        ("config", C.c_int), ("wpacked_wino", C.c_void_p),
+        ("config", C.c_int), ("wpacked_wino", C.c_void_p), ("linear", C.c_int),
     ]
 
 
@@ -74,6 +74,20 @@ SIGNATURES = {
     "read_conv_config_count": (_i, []),
     "read_conv_config_name": (C.c_char_p, [_i]),
     "read_bilinear_up4": (_i, [_vp, _i, _i, _i, _vp, _vp]),
+    "read_conv_pack_params_device": (_i, [_i, _vp, _vp, _vp, _vp, _vp, _vp, _f, _vp, _vp]),
+    "read_conv_pack_weights_device": (_i, [_i, _i, _i, _i, _vp, _vp, _vp, _vp]),
+    "read_conv_dgrad_packed_floats": (_sz, [_i, _i, _i]),
+    "read_conv_pack_dgrad_device": (_i, [_i, _i, _i, _i, _vp, _vp, _vp, _vp]),
+    "read_gate_forward": (_i, [_vp, _i64, _i, _vp, _i, _vp, _vp, _vp]),
+    "read_gate_backward": (_i, [_vp, _vp, _i64, _i, _vp, _i, _vp, _vp, _vp]),
+    "read_bn_param_grads": (_i, [_i, _vp, _vp, _vp, _f, _vp, _vp, _vp, _vp, _vp]),
+    "read_conv_dgrad_generic_floats": (_sz, [_i, _i, _i]),
+    "read_conv_dgrad_generic": (_i, [_vp, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp, _i, _i, _vp, _vp]),
+    "read_conv_wgrad_scratch_floats": (_sz, [_i, _i, _i, _i]),
+    "read_conv_wgrad": (_i, [_vp, _i, _i, _i, _vp, _i, _i, _i, _vp, _vp, _i, _vp, _sz, _vp]),
+    "read_bilinear_up4_backward": (_i, [_vp, _i, _i, _i, _vp, _vp]),
+    "read_huber_loss": (_i, [_vp, _vp, _i64, _f, _vp, _vp, _vp]),
+    "read_rmsprop_sparse": (_i, [_vp, _vp, _vp, _vp, _i, _i64, _vp, _i64, _i, _f, _f, _f, _vp]),
     "read_unet_layer_count": (_i, []),
     "read_unet_layer_info": (_i, [_i, C.POINTER(C.c_char_p), C.POINTER(_i), C.POINTER(_i), C.POINTER(_i),
                                   C.POINTER(_i), C.POINTER(_i)]),

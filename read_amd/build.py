@@ -15,7 +15,7 @@ ROOT = os.path.dirname(HERE)
 CSRC = os.path.join(HERE, "csrc")
 OBJ = os.path.join(HERE, "csrc", "_obj")
 LIB = os.path.join(HERE, "libreadhip.so")
-SOURCES = ["api_common.cpp", "splat.hip", "gather.hip", "conv.hip", "unet.cpp", "probe.hip"]
+SOURCES = ["api_common.cpp", "splat.hip", "gather.hip", "conv.hip", "train.hip", "unet.cpp", "probe.hip"]
 ARCH = "gfx950"
 FLAGS = ["-O3", "-std=c++17", "-fPIC", f"--offload-arch={ARCH}", "-x", "hip",
          "-I", os.path.join(ROOT, "include"), "-I", CSRC, "-Wall", "-Wno-unused-function"]

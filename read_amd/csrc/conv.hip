@@ -54,6 +54,8 @@ struct ConvKArgs {
                                    //   1-row units of the remaining (group set, x tile) columns (balanced tail)
     int wino_dby, wino_dbx;        // Winograd kernel: (tile row, tile column) step between a workgroup's units
     int elu, fill_pad;
+    int linear;                    // 1: plain convolution — store conv_f + b_f at channel c and conv_m + b_m at channel Cout + c
+                                   //    (no gate, no BatchNorm, no residual): the training path's pre-activations and dgrad
     float out_fill;
     unsigned long long *trace;     // optional timeline: 8 x u64 per workgroup (read_debug_set_trace)
 };
@@ -343,6 +345,13 @@ __global__ __launch_bounds__(256) void gated_conv_kernel(const ConvKArgs a)
                 }
                 f += bf;
                 m += bm;
+                if (a.linear) {
+                    // ooff addresses channel c of the first half; the second half starts Cout channels later
+                    const int o2 = (ooff[rr] != OOB && c_ok) ? ooff[rr] + a.Cout * 4 : OOB;
+                    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, f), orsrc, c_ok ? ooff[rr] : OOB, 0, 0);
+                    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, m), orsrc, o2, 0, 0);
+                    continue;
+                }
                 if (a.elu) f = elu1(f);
                 float v = (f * sigmoidf(m)) * sc + sh + rv[rr];
                 v = c_ok ? v : a.out_fill;
@@ -1287,7 +1296,8 @@ int launch_gated_conv(const read_conv_desc *d, hipStream_t stream)
     READ_CHECK_ARG(d->stride == 1 || d->stride == 2, "read_gated_conv_forward: stride must be 1 or 2");
     READ_CHECK_ARG(d->inH >= 1 && d->inW >= 1 && d->Cout >= 1, "read_gated_conv_forward: bad sizes");
     READ_CHECK_ARG(d->wpacked && d->params && d->out, "read_gated_conv_forward: null weights/params/out");
-    READ_CHECK_ARG(d->out_cstride >= d->Cout, "read_gated_conv_forward: out_cstride < Cout");
+    READ_CHECK_ARG(d->out_cstride >= (d->linear ? 2 : 1) * d->Cout, "read_gated_conv_forward: out_cstride too small");
+    READ_CHECK_ARG(!d->linear || (!d->residual && !d->fill_pad), "read_gated_conv_forward: linear mode takes no residual / fill");
     READ_CHECK_ARG(!d->mul || d->n_src == 1, "read_gated_conv_forward: mul needs a single source");
     READ_CHECK_ARG((uintptr_t)d->wpacked % 16 == 0, "read_gated_conv_forward: packed weights misaligned");
 
@@ -1328,6 +1338,17 @@ int launch_gated_conv(const read_conv_desc *d, hipStream_t stream)
     READ_CHECK_ARG((long long)outH * outW * d->out_cstride * 4 < OOB_LIMIT, "read_gated_conv_forward: output too large");
     const int CoutPad = pad32(d->Cout), groups = CoutPad / 32;
     int cfg = d->config;
+    if (d->linear) {
+        // the plain-convolution epilogue exists in the workgroup-tiled kernel only
+        READ_CHECK_ARG(cfg < 0 || (cfg < N_CONFIGS && !g_configs[cfg].wave && !g_configs[cfg].wino),
+                       "read_gated_conv_forward: linear mode needs a workgroup-tiled config");
+        for (int i = 0; cfg < 0 && i < N_CONFIGS; ++i) {
+            const ConvConfig &k = g_configs[i];
+            if (!k.wave && !k.wino && k.KS == d->ksize && k.S == d->stride && k.KC == kc && groups % (k.WN * k.QG) == 0 &&
+                (!d->mul || k.fn_mul))
+                cfg = i;
+        }
+    }
     if (cfg < 0 && conv_uses_wino(d))
         for (int i = N_CONFIGS - 1; i >= 0; --i)
             if (g_configs[i].wino) cfg = i;       // first Winograd entry = the product kernel
@@ -1362,6 +1383,7 @@ int launch_gated_conv(const read_conv_desc *d, hipStream_t stream)
     a.nchunks = nchunks;
     a.tiles_x = ceil_div(outW, 32);
     a.elu = d->elu;
+    a.linear = d->linear;
     a.ablate = g_ablate;
     a.fill_pad = d->fill_pad;
     a.out_fill = d->out_fill;

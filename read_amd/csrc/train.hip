@@ -1,0 +1,609 @@
+// Training step of READ's gated convolutions on gfx950: what torch.autograd + cuDNN do for
+// READ/models/unet.py:22-53 under src/train.py:132-203, plus the loss of src/READ/models/compose.py:29-40 (Huber part)
+// and the descriptor optimizer of READ/pipelines/ogl.py:16,99-100 (RMSprop) restricted to the rows a step touched.
+//
+// One BasicConv, y = BN_eval( act(f) * sigmoid(m) ), f|m = conv_{f|m}(x) + b:
+//   forward (training)  read_gated_conv_forward(linear = 1)  -> pre-activations [f | m] (kept for the backward pass)
+//                       gate_forward_kernel                   -> y
+//   backward            gate_backward_kernel   dy, [f|m] -> d[f|m] (channel-padded) + per-channel sums for db_f, db_m, dgamma, dbeta
+//                       dgrad                  d[f|m] -> dx: for stride-1 layers the SAME MFMA convolution kernel with flipped,
+//                                              transposed weights (pack_dgrad_weights_kernel + linear = 1); stride 2: dgrad_generic_kernel
+//                       wgrad_mfma_kernel      x, d[f|m] -> dW_f, dW_m on the matrix cores (pixels are the reduction dimension)
+// BatchNorm is the eval-mode affine map (running statistics frozen, gamma/beta trained) — the configuration the reference
+// trains with (configs/train_example.yaml: eval_in_train: True, train.py:271-277).
+// Weights change every optimizer step, so the MFMA fragment orders are produced on the device (pack_*_kernel).
+#include "common.h"
+
+using namespace readhip;
+
+typedef float floatx16 __attribute__((ext_vector_type(16)));
+
+namespace {
+
+__device__ __forceinline__ float fast_exp(float x) { return __builtin_amdgcn_exp2f(x * 1.44269504088896341f); }
+
+int grid_for(long long items, int per_block = 256, int cap = 256 * 16)
+{
+    long long b = (items + per_block - 1) / per_block;
+    return (int)(b < 1 ? 1 : (b > cap ? cap : b));
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// parameter / weight packing on the device
+// ---------------------------------------------------------------------------------------------------------------------
+// params block of the conv kernels: 4 x CoutPad = bias_f, bias_m, bn_scale, bn_shift (read_conv_pack_params_host)
+__global__ void pack_params_kernel(int Cout, int CoutPad, const float *bf, const float *bm, const float *gamma,
+                                   const float *beta, const float *mean, const float *var, float eps, float *out)
+{
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= CoutPad) return;
+    const bool ok = c < Cout;
+    const float sc = ok ? gamma[c] / sqrtf(var[c] + eps) : 0.0f;
+    out[c] = ok && bf ? bf[c] : 0.0f;
+    out[CoutPad + c] = ok && bm ? bm[c] : 0.0f;
+    out[2 * CoutPad + c] = sc;
+    out[3 * CoutPad + c] = ok ? beta[c] - mean[c] * sc : 0.0f;
+}
+
+// Direct-kernel fragment order of read_conv_pack_weights_host: [chunk][tap][k8][tile(f,m)][lane][4].
+// mode 0: the layer's own weights  W{f|m}[cout][cin][tap]                                    (forward)
+// mode 1: dgrad as a convolution over d[f|m] (2*Cp channels: df then dm, Cp = padded Cout of the layer):
+//         virtual conv with Cin_v = 2*Cp input channels and Cout_v = Cin/2 gated output channels per half;
+//         W_v{half}[co_v][ci_v][tap] = W{ci_v < Cp ? f : m}[ci_v % Cp][half * Cin/2 + co_v][k*k - 1 - tap]   (flipped, transposed)
+__global__ void pack_weights_kernel(int mode, int Cin, int Cout, int ksize, int kc, int Cp, const float *wf, const float *wm,
+                                    float *out, long long total)
+{
+    const int taps = ksize * ksize;
+    const int CinV = mode ? 2 * Cp : Cin, CoutV = mode ? Cin / 2 : Cout;
+    const int CoutPad = (CoutV + 31) / 32 * 32, NT = CoutPad / 16, KK = kc / 8;
+    for (long long o = (long long)blockIdx.x * blockDim.x + threadIdx.x; o < total; o += (long long)gridDim.x * blockDim.x) {
+        long long r = o;
+        const int j = (int)(r & 3); r >>= 2;
+        const int lane = (int)(r & 63); r >>= 6;
+        const int nt = (int)(r % NT); r /= NT;
+        const int kk = (int)(r % KK); r /= KK;
+        const int tap = (int)(r % taps);
+        const int chunk = (int)(r / taps);
+        const int cout = (nt >> 1) * 32 + (lane & 31);
+        const int cin = chunk * kc + kk * 8 + 4 * (lane >> 5) + j;
+        float v = 0.0f;
+        if (cout < CoutV && cin < CinV) {
+            if (!mode) {
+                v = ((nt & 1) ? wm : wf)[((size_t)cout * Cin + cin) * taps + tap];
+            } else {
+                const int layer_co = cin % Cp, layer_ci = (nt & 1) * (Cin / 2) + cout;
+                if (layer_co < Cout) v = (cin < Cp ? wf : wm)[((size_t)layer_co * Cin + layer_ci) * taps + (taps - 1 - tap)];
+            }
+        }
+        out[o] = v;
+    }
+}
+
+// weights for dgrad_generic_kernel: [tap][co' in 2*Cp][ci]  (ci contiguous)
+__global__ void pack_dgrad_generic_kernel(int Cin, int Cout, int taps, int Cp, const float *wf, const float *wm, float *out,
+                                          long long total)
+{
+    for (long long o = (long long)blockIdx.x * blockDim.x + threadIdx.x; o < total; o += (long long)gridDim.x * blockDim.x) {
+        const int ci = (int)(o % Cin);
+        const int cp = (int)((o / Cin) % (2 * Cp));
+        const int tap = (int)(o / ((long long)Cin * 2 * Cp));
+        const int co = cp % Cp;
+        out[o] = co < Cout ? (cp < Cp ? wf : wm)[((size_t)co * Cin + ci) * taps + tap] : 0.0f;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// gate forward / backward (elementwise over pixels x channels)
+// ---------------------------------------------------------------------------------------------------------------------
+// fm: [pixels][2*Cout] = f (bias included) | m;  y = (act(f) * sigmoid(m)) * scale + shift (+ residual)
+__global__ __launch_bounds__(256) void gate_forward_kernel(const float *__restrict__ fm, long long pixels, int Cout, int CoutPad,
+                                                           const float *__restrict__ params, int elu,
+                                                           const float *__restrict__ residual, float *__restrict__ y)
+{
+    const long long total = pixels * Cout;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+        const long long p = i / Cout;
+        const int c = (int)(i - p * Cout);
+        float f = fm[p * 2 * Cout + c];
+        const float m = fm[p * 2 * Cout + Cout + c];
+        if (elu) f = f > 0.0f ? f : fast_exp(f) - 1.0f;
+        const float s = __builtin_amdgcn_rcpf(1.0f + fast_exp(-m));
+        float v = (f * s) * params[2 * CoutPad + c] + params[3 * CoutPad + c];
+        if (residual) v += residual[i];
+        y[i] = v;
+    }
+}
+
+// dy [pixels][Cout], fm [pixels][2*Cout]  ->  dfm [pixels][2*Cp] (df | dm, channels >= Cout zero) and
+// sums[4][Cout] += { sum df, sum dm, sum dy, sum dy * g }  with g = act(f) * sigmoid(m)   (db_f, db_m, dbeta, dgamma pieces)
+// One workgroup = 64 pixels x all channels (thread t: channel t % CW ... ), block-level partial sums in LDS, one
+// atomicAdd per channel and workgroup.
+template <int CW>
+__global__ __launch_bounds__(256) void gate_backward_kernel(const float *__restrict__ dy, const float *__restrict__ fm,
+                                                            long long pixels, int Cout, int CoutPad, int Cp,
+                                                            const float *__restrict__ params, int elu,
+                                                            float *__restrict__ dfm, float *__restrict__ sums)
+{
+    constexpr int ROWS = 256 / CW;                       // pixels handled concurrently by a workgroup
+    __shared__ float red[4][256];
+    const int c0 = threadIdx.x % CW, r = threadIdx.x / CW;
+    for (int cb = 0; cb < Cp; cb += CW) {                // channel blocks of CW
+        const int c = cb + c0;
+        const bool ok = c < Cout;
+        const float sc = ok ? params[2 * CoutPad + c] : 0.0f;
+        float s_df = 0.f, s_dm = 0.f, s_dy = 0.f, s_dyg = 0.f;
+        for (long long p = (long long)blockIdx.x * ROWS + r; p < pixels; p += (long long)gridDim.x * ROWS) {
+            float df = 0.f, dm = 0.f;
+            if (ok) {
+                const float f = fm[p * 2 * Cout + c], m = fm[p * 2 * Cout + Cout + c];
+                const float g = dy[p * Cout + c];
+                const float a = elu ? (f > 0.0f ? f : fast_exp(f) - 1.0f) : f;
+                const float da = elu ? (f > 0.0f ? 1.0f : a + 1.0f) : 1.0f;          // ELU'(f) = exp(f) = a + 1 for f <= 0
+                const float s = __builtin_amdgcn_rcpf(1.0f + fast_exp(-m));
+                const float gs = g * sc;                                             // through the BatchNorm scale
+                df = gs * s * da;
+                dm = gs * a * s * (1.0f - s);
+                s_df += df;
+                s_dm += dm;
+                s_dy += g;
+                s_dyg += g * (a * s);
+            }
+            if (c < Cp) {
+                dfm[p * 2 * Cp + c] = df;
+                dfm[p * 2 * Cp + Cp + c] = dm;
+            }
+        }
+        red[0][threadIdx.x] = s_df;
+        red[1][threadIdx.x] = s_dm;
+        red[2][threadIdx.x] = s_dy;
+        red[3][threadIdx.x] = s_dyg;
+        __syncthreads();
+        if (threadIdx.x < CW && ok) {
+            float t[4] = {0.f, 0.f, 0.f, 0.f};
+            for (int k = 0; k < ROWS; ++k)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) t[q] += red[q][k * CW + threadIdx.x];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) atomicAdd(sums + q * Cout + c, t[q]);
+        }
+        __syncthreads();
+    }
+}
+
+// dbf = S0, dbm = S1, dbeta = S2, dgamma = (S3 - mean * S2) / sqrt(var + eps)      (y = g * gamma * r + beta - mean * gamma * r)
+__global__ void bn_grads_kernel(int Cout, const float *sums, const float *mean, const float *var, float eps, float *dbf,
+                                float *dbm, float *dgamma, float *dbeta)
+{
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= Cout) return;
+    const float rstd = 1.0f / sqrtf(var[c] + eps);
+    if (dbf) dbf[c] += sums[c];
+    if (dbm) dbm[c] += sums[Cout + c];
+    if (dbeta) dbeta[c] += sums[2 * Cout + c];
+    if (dgamma) dgamma[c] += (sums[3 * Cout + c] - mean[c] * sums[2 * Cout + c]) * rstd;
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// dgrad, generic form (any ksize / stride): dx[p][ci] = sum over taps, co' of dfm[q][co'] * W[tap][co'][ci] with
+// q * stride + tap - pad == p.  Thread = (input pixel, 4 input channels).  Used for the six stride-2 layers.
+// ---------------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void dgrad_generic_kernel(const float *__restrict__ dfm, int outH, int outW, int C2,
+                                                            const float *__restrict__ wt, int Cin, int ksize, int stride,
+                                                            int inH, int inW, float *__restrict__ dx)
+{
+    const int pad = (ksize - 1) / 2, q4 = Cin >> 2;
+    const long long total = (long long)inH * inW * q4;
+    for (long long item = (long long)blockIdx.x * blockDim.x + threadIdx.x; item < total;
+         item += (long long)gridDim.x * blockDim.x) {
+        const int q = (int)(item % q4);
+        const long long pix = item / q4;
+        const int x = (int)(pix % inW), y = (int)(pix / inW);
+        float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int ky = 0; ky < ksize; ++ky) {
+            const int ty = y + pad - ky;
+            if (ty < 0 || ty % stride) continue;
+            const int oy = ty / stride;
+            if (oy >= outH) continue;
+            for (int kx = 0; kx < ksize; ++kx) {
+                const int tx = x + pad - kx;
+                if (tx < 0 || tx % stride) continue;
+                const int ox = tx / stride;
+                if (ox >= outW) continue;
+                const float *g = dfm + ((long long)oy * outW + ox) * C2;
+                const float *w = wt + ((long long)(ky * ksize + kx) * C2) * Cin + 4 * q;
+                for (int c = 0; c < C2; ++c) {
+                    const float gv = g[c];
+                    const float4 wv = *reinterpret_cast<const float4 *>(w + (long long)c * Cin);
+                    acc.x += gv * wv.x;
+                    acc.y += gv * wv.y;
+                    acc.z += gv * wv.z;
+                    acc.w += gv * wv.w;
+                }
+            }
+        }
+        *reinterpret_cast<float4 *>(dx + pix * Cin + 4 * q) = acc;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// wgrad on the matrix cores: dW_tap[ci][co'] = sum over output pixels of x[in(pixel, tap)][ci] * dfm[pixel][co'].
+// v_mfma_f32_32x32x2_f32 with M = 32 input channels, N = 32 channels of d[f|m], K = 2 output pixels: lane l supplies
+// A[i = l & 31][k = l >> 5] = x[pixel + k][ci0 + i] and B[k][j = l & 31] = dfm[pixel + k][co0 + j] — with NHWC tensors both
+// are two coalesced 128-byte rows per instruction, no transposition anywhere.  A wave owns one (ci tile, co' tile) and
+// accumulates NT taps at once (144 accumulator registers for a 3x3 layer), B is loaded once per pixel pair and shared by
+// the taps.  The pixel range is split over grid.z (split-K); partial tiles go to a scratch buffer and
+// wgrad_reduce_kernel sums them into dW_f / dW_m in the PyTorch layout (Cout, Cin, k, k).
+// ---------------------------------------------------------------------------------------------------------------------
+template <int NT>
+__global__ __launch_bounds__(64) void wgrad_mfma_kernel(const float *__restrict__ x, int inH, int inW, int Cin,
+                                                        const float *__restrict__ dfm, int outH, int outW, int C2, int ksize,
+                                                        int stride, int tiles_co, int rows_per_split,
+                                                        float *__restrict__ partial)
+{
+    const int lane = threadIdx.x;
+    const int ci0 = ((int)blockIdx.x / tiles_co) * 32, co0 = ((int)blockIdx.x % tiles_co) * 32;
+    const int pad = (ksize - 1) / 2;
+    const int i = lane & 31, kk = lane >> 5;
+    const bool ci_ok = ci0 + i < Cin, co_ok = co0 + i < C2;
+    floatx16 acc[NT];
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[t][r] = 0.0f;
+    const int y_begin = (int)blockIdx.z * rows_per_split;
+    const int y_end = min(outH, y_begin + rows_per_split);
+    for (int oy = y_begin; oy < y_end; ++oy) {
+        for (int ox = 0; ox < outW; ox += 2) {
+            const int px = ox + kk;                                      // this half-wave's output pixel
+            const bool p_ok = px < outW;
+            const float b = (p_ok && co_ok) ? dfm[((long long)oy * outW + px) * C2 + co0 + i] : 0.0f;
+            float a[NT];
+#pragma unroll
+            for (int t = 0; t < NT; ++t) {
+                const int tap = (int)blockIdx.y * NT + t, ky = tap / ksize, kx = tap - ky * ksize;
+                const int iy = oy * stride + ky - pad, ix = px * stride + kx - pad;
+                const bool ok = p_ok && ci_ok && tap < ksize * ksize && iy >= 0 && iy < inH && ix >= 0 && ix < inW;
+                a[t] = ok ? x[((long long)iy * inW + ix) * Cin + ci0 + i] : 0.0f;
+            }
+#pragma unroll
+            for (int t = 0; t < NT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[t], b, acc[t], 0, 0, 0);
+        }
+    }
+    // D[i][j] sits in lane (j + 32 * ((i >> 2) & 1)), register (i & 3) + 4 * (i >> 3): row i = ci, column j = co'
+    float *dst = partial + (((long long)blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x) * (NT * 1024);
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int row = (r & 3) + 8 * (r >> 2) + 4 * kk;
+            dst[(t * 32 + row) * 32 + i] = acc[t][r];                    // [tap][ci][co'] within the tile
+        }
+}
+
+// dW{f|m}[co][ci][tap] (+)= sum over splits of partial[split][tapgroup][tile][t][ci][co']
+__global__ void wgrad_reduce_kernel(const float *__restrict__ partial, int splits, int tap_groups, int NT, int tiles_ci,
+                                    int tiles_co, int Cin, int Cout, int Cp, int taps, float *dwf, float *dwm, int accumulate)
+{
+    const long long total = (long long)2 * Cout * Cin * taps;
+    const long long tile_stride = (long long)NT * 1024;
+    const long long tiles = (long long)tiles_ci * tiles_co;
+    for (long long o = (long long)blockIdx.x * blockDim.x + threadIdx.x; o < total; o += (long long)gridDim.x * blockDim.x) {
+        const int tap = (int)(o % taps);
+        const int ci = (int)((o / taps) % Cin);
+        const int co = (int)((o / ((long long)taps * Cin)) % Cout);
+        const int half = (int)(o / ((long long)taps * Cin * Cout));
+        const int cp = half * Cp + co;
+        const int tg = tap / NT, t = tap % NT;
+        const long long tile = (long long)(ci / 32) * tiles_co + cp / 32;
+        float s = 0.0f;
+        for (int k = 0; k < splits; ++k)
+            s += partial[(((long long)k * tap_groups + tg) * tiles + tile) * tile_stride + (t * 32 + (ci & 31)) * 32 + (cp & 31)];
+        float *dst = (half ? dwm : dwf) + ((long long)co * Cin + ci) * taps + tap;
+        *dst = accumulate ? *dst + s : s;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// bilinear x4 upsample, backward (adjoint of bilinear_up4_kernel in conv.hip): thread = (input pixel, 4 channels)
+// gathers the up-to-6x6 output pixels that read it.
+// ---------------------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ void up4_src(int o, int n_in, int &i0, int &i1, float &l1)
+{
+    float s = 0.25f * ((float)o + 0.5f) - 0.5f;
+    s = s < 0.f ? 0.f : s;
+    i0 = (int)s;
+    i1 = i0 + (i0 < n_in - 1 ? 1 : 0);
+    l1 = s - (float)i0;
+}
+
+__global__ __launch_bounds__(256) void bilinear_up4_backward_kernel(const float *__restrict__ dout, int inH, int inW, int C,
+                                                                    float *__restrict__ din)
+{
+    const int outH = inH * 4, outW = inW * 4, q4 = C >> 2;
+    const long long total = (long long)inH * inW * q4;
+    for (long long item = (long long)blockIdx.x * blockDim.x + threadIdx.x; item < total;
+         item += (long long)gridDim.x * blockDim.x) {
+        const int q = (int)(item % q4);
+        const long long pix = item / q4;
+        const int x = (int)(pix % inW), y = (int)(pix / inW);
+        float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+        // output rows whose source interval [i0, i1] contains y lie within 4y-4 .. 4y+5 (borders: clamped sources)
+        for (int oy = max(0, 4 * y - 4); oy <= min(outH - 1, 4 * y + 5); ++oy) {
+            int y0, y1;
+            float ly1;
+            up4_src(oy, inH, y0, y1, ly1);
+            const float wy = (y0 == y ? 1.f - ly1 : 0.f) + (y1 == y ? ly1 : 0.f);
+            if (wy == 0.f) continue;
+            for (int ox = max(0, 4 * x - 4); ox <= min(outW - 1, 4 * x + 5); ++ox) {
+                int x0, x1;
+                float lx1;
+                up4_src(ox, inW, x0, x1, lx1);
+                const float wx = (x0 == x ? 1.f - lx1 : 0.f) + (x1 == x ? lx1 : 0.f);
+                if (wx == 0.f) continue;
+                const float4 g = *reinterpret_cast<const float4 *>(dout + ((long long)oy * outW + ox) * C + 4 * q);
+                const float w = wy * wx;
+                acc.x += w * g.x;
+                acc.y += w * g.y;
+                acc.z += w * g.z;
+                acc.w += w * g.w;
+            }
+        }
+        *reinterpret_cast<float4 *>(din + pix * C + 4 * q) = acc;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Huber loss (F.huber_loss, delta = 1, mean reduction; src/READ/models/compose.py:35,38) and its gradient
+// ---------------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void huber_kernel(const float *__restrict__ out, const float *__restrict__ target,
+                                                    long long n, float scale, float *__restrict__ loss_sum,
+                                                    float *__restrict__ grad)
+{
+    __shared__ float red[256];
+    float s = 0.0f;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+        const float d = out[i] - target[i];
+        const float ad = fabsf(d);
+        s += ad < 1.0f ? 0.5f * d * d : ad - 0.5f;
+        if (grad) grad[i] = scale * (ad < 1.0f ? d : (d > 0.f ? 1.0f : -1.0f));
+    }
+    red[threadIdx.x] = s;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+        if ((int)threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0 && loss_sum) atomicAdd(loss_sum, red[0]);
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Sparse RMSprop over the descriptor rows a step touched (torch.optim.RMSprop defaults of READ/pipelines/ogl.py:16:
+// alpha 0.99, eps 1e-8, no momentum, not centered):  sq = alpha sq + (1 - alpha) g^2;  p -= lr g / (sqrt(sq) + eps).
+// ids are the int32 index maps of the step (all levels, all batch items); a per-row epoch stamp makes every touched row
+// update exactly once however many pixels hit it.  Rows that no pixel touched have zero gradient; the dense optimizer
+// would still decay their sq by alpha each step — `lazy_decay` applies alpha^(steps missed) when a row is touched again, so
+// the trajectory of every row equals the dense one (tests/test_gpu_train.py).
+// ---------------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void rmsprop_sparse_kernel(float *__restrict__ rows, float *__restrict__ sq,
+                                                             float *__restrict__ grad, int *__restrict__ stamp, int C,
+                                                             long long n_rows, const int32_t *__restrict__ ids,
+                                                             long long n_ids, int step, float lr, float alpha, float eps)
+{
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n_ids; i += (long long)gridDim.x * blockDim.x) {
+        long long id = ids[i];
+        if (id < 0 || id >= n_rows) continue;
+        const int last = atomicExch(stamp + id, step);                 // first thread to see an old stamp owns the row
+        if (last == step) continue;
+        const float decay = powf(alpha, (float)(step - 1 - last));      // steps in which the dense optimizer saw g = 0
+        for (int c = 0; c < C; ++c) {
+            const float g = grad[id * C + c];
+            const float v = alpha * (sq[id * C + c] * decay) + (1.0f - alpha) * g * g;
+            sq[id * C + c] = v;
+            rows[id * C + c] -= lr * g / (sqrtf(v) + eps);
+            grad[id * C + c] = 0.0f;                                   // leave the gradient buffer clean for the next step
+        }
+    }
+}
+
+}  // namespace
+
+// ---------------------------------------------------------------------------------------------------------------------
+// C ABI
+// ---------------------------------------------------------------------------------------------------------------------
+extern "C" int read_conv_pack_params_device(int Cout, const float *bf, const float *bm, const float *gamma, const float *beta,
+                                            const float *mean, const float *var, float eps, float *params, void *stream)
+{
+    READ_CHECK_ARG(Cout >= 1 && gamma && beta && mean && var && params, "read_conv_pack_params_device: null pointer");
+    const int CoutPad = (Cout + 31) / 32 * 32;
+    hipLaunchKernelGGL(pack_params_kernel, dim3(ceil_div(CoutPad, 64)), dim3(64), 0, as_stream(stream), Cout, CoutPad, bf, bm,
+                       gamma, beta, mean, var, eps, params);
+    READ_CHECK_LAUNCH();
+    return READ_OK;
+}
+
+extern "C" int read_conv_pack_weights_device(int Cin, int Cout, int ksize, int kc, const float *wf, const float *wm,
+                                             float *wpacked, void *stream)
+{
+    READ_CHECK_ARG(wf && wm && wpacked, "read_conv_pack_weights_device: null pointer");
+    READ_CHECK_ARG(ksize == 1 || ksize == 3 || ksize == 4, "read_conv_pack_weights_device: ksize must be 1, 3 or 4");
+    READ_CHECK_ARG((kc == 8 || kc == 16 || (kc == 32 && ksize == 1)) && Cin >= kc && Cin % kc == 0,
+                   "read_conv_pack_weights_device: Cin=%d is not a multiple of kc=%d", Cin, kc);
+    const long long total = (long long)read_conv_packed_floats(Cin, Cout, ksize);
+    hipLaunchKernelGGL(pack_weights_kernel, dim3(grid_for(total)), dim3(256), 0, as_stream(stream), 0, Cin, Cout, ksize, kc, 0,
+                       wf, wm, wpacked, total);
+    READ_CHECK_LAUNCH();
+    return READ_OK;
+}
+
+extern "C" size_t read_conv_dgrad_packed_floats(int Cin, int Cout, int ksize)
+{
+    if (Cin < 2 || Cin % 2 || Cout < 1) return 0;
+    const int Cp = (Cout + 7) / 8 * 8;
+    return read_conv_packed_floats(2 * Cp, Cin / 2, ksize);
+}
+
+extern "C" int read_conv_pack_dgrad_device(int Cin, int Cout, int ksize, int kc, const float *wf, const float *wm,
+                                           float *wpacked, void *stream)
+{
+    READ_CHECK_ARG(wf && wm && wpacked, "read_conv_pack_dgrad_device: null pointer");
+    READ_CHECK_ARG(Cin >= 2 && Cin % 2 == 0, "read_conv_pack_dgrad_device: Cin must be even");
+    const int Cp = (Cout + 7) / 8 * 8;
+    READ_CHECK_ARG((kc == 8 || kc == 16) && (2 * Cp) % kc == 0, "read_conv_pack_dgrad_device: 2*pad8(Cout)=%d is not a multiple of kc=%d",
+                   2 * Cp, kc);
+    const long long total = (long long)read_conv_dgrad_packed_floats(Cin, Cout, ksize);
+    hipLaunchKernelGGL(pack_weights_kernel, dim3(grid_for(total)), dim3(256), 0, as_stream(stream), 1, Cin, Cout, ksize, kc, Cp,
+                       wf, wm, wpacked, total);
+    READ_CHECK_LAUNCH();
+    return READ_OK;
+}
+
+extern "C" int read_gate_forward(const float *fm, int64_t pixels, int Cout, const float *params, int elu,
+                                 const float *residual, float *y, void *stream)
+{
+    READ_CHECK_ARG(fm && params && y && pixels >= 1 && Cout >= 1, "read_gate_forward: null pointer or empty tensor");
+    hipLaunchKernelGGL(gate_forward_kernel, dim3(grid_for(pixels * Cout)), dim3(256), 0, as_stream(stream), fm,
+                       (long long)pixels, Cout, (Cout + 31) / 32 * 32, params, elu, residual, y);
+    READ_CHECK_LAUNCH();
+    return READ_OK;
+}
+
+extern "C" int read_gate_backward(const float *dy, const float *fm, int64_t pixels, int Cout, const float *params, int elu,
+                                  float *dfm, float *sums, void *stream)
+{
+    READ_CHECK_ARG(dy && fm && params && dfm && sums && pixels >= 1 && Cout >= 1, "read_gate_backward: null pointer or empty tensor");
+    const int Cp = (Cout + 7) / 8 * 8, CoutPad = (Cout + 31) / 32 * 32;
+    READ_CHECK_HIP(hipMemsetAsync(sums, 0, sizeof(float) * 4 * (size_t)Cout, as_stream(stream)));
+    if (Cp <= 8) {
+        const int blocks = grid_for(pixels, 32, 2048);
+        hipLaunchKernelGGL(gate_backward_kernel<8>, dim3(blocks), dim3(256), 0, as_stream(stream), dy, fm, (long long)pixels, Cout,
+                           CoutPad, Cp, params, elu, dfm, sums);
+    } else {
+        const int blocks = grid_for(pixels, 8, 2048);
+        hipLaunchKernelGGL(gate_backward_kernel<32>, dim3(blocks), dim3(256), 0, as_stream(stream), dy, fm, (long long)pixels, Cout,
+                           CoutPad, Cp, params, elu, dfm, sums);
+    }
+    READ_CHECK_LAUNCH();
+    return READ_OK;
+}
+
+extern "C" int read_bn_param_grads(int Cout, const float *sums, const float *mean, const float *var, float eps, float *dbf,
+                                   float *dbm, float *dgamma, float *dbeta, void *stream)
+{
+    READ_CHECK_ARG(Cout >= 1 && sums && mean && var, "read_bn_param_grads: null pointer");
+    hipLaunchKernelGGL(bn_grads_kernel, dim3(ceil_div(Cout, 64)), dim3(64), 0, as_stream(stream), Cout, sums, mean, var, eps, dbf,
+                       dbm, dgamma, dbeta);
+    READ_CHECK_LAUNCH();
+    return READ_OK;
+}
+
+extern "C" size_t read_conv_dgrad_generic_floats(int Cin, int Cout, int ksize)
+{
+    const int Cp = (Cout + 7) / 8 * 8;
+    return (size_t)ksize * ksize * 2 * Cp * Cin;
+}
+
+extern "C" int read_conv_dgrad_generic(const float *dfm, int outH, int outW, int Cin, int Cout, int ksize, int stride,
+                                       const float *wf, const float *wm, float *wscratch, int inH, int inW, float *dx,
+                                       void *stream)
+{
+    READ_CHECK_ARG(dfm && wf && wm && wscratch && dx, "read_conv_dgrad_generic: null pointer");
+    READ_CHECK_ARG(Cin >= 4 && Cin % 4 == 0 && Cout >= 1, "read_conv_dgrad_generic: Cin must be a multiple of 4");
+    READ_CHECK_ARG(ksize >= 1 && ksize <= 4 && (stride == 1 || stride == 2), "read_conv_dgrad_generic: bad ksize / stride");
+    const int Cp = (Cout + 7) / 8 * 8, pad = (ksize - 1) / 2;
+    READ_CHECK_ARG(outH == (inH + 2 * pad - ksize) / stride + 1 && outW == (inW + 2 * pad - ksize) / stride + 1,
+                   "read_conv_dgrad_generic: %dx%d is not the output size of a %dx%d input", outH, outW, inH, inW);
+    const long long wtotal = (long long)read_conv_dgrad_generic_floats(Cin, Cout, ksize);
+    hipLaunchKernelGGL(pack_dgrad_generic_kernel, dim3(grid_for(wtotal)), dim3(256), 0, as_stream(stream), Cin, Cout,
+                       ksize * ksize, Cp, wf, wm, wscratch, wtotal);
+    READ_CHECK_LAUNCH();
+    hipLaunchKernelGGL(dgrad_generic_kernel, dim3(grid_for((long long)inH * inW * (Cin / 4))), dim3(256), 0, as_stream(stream),
+                       dfm, outH, outW, 2 * Cp, (const float *)wscratch, Cin, ksize, stride, inH, inW, dx);
+    READ_CHECK_LAUNCH();
+    return READ_OK;
+}
+
+namespace {
+struct WgradPlan {
+    int NT, tap_groups, tiles_ci, tiles_co, splits, rows_per_split;
+    size_t partial_floats;
+};
+WgradPlan wgrad_plan(int Cin, int Cout, int ksize, int outH)
+{
+    WgradPlan p;
+    const int Cp = (Cout + 7) / 8 * 8, taps = ksize * ksize;
+    p.NT = taps == 1 ? 1 : (taps == 9 ? 9 : 8);
+    p.tap_groups = (taps + p.NT - 1) / p.NT;
+    p.tiles_ci = (Cin + 31) / 32;
+    p.tiles_co = (2 * Cp + 31) / 32;
+    const int waves = p.tiles_ci * p.tiles_co * p.tap_groups;
+    int splits = (4096 + waves - 1) / waves;                    // ~4 waves per SIMD over the chip
+    if (splits > outH) splits = outH;
+    if (splits < 1) splits = 1;
+    p.rows_per_split = (outH + splits - 1) / splits;
+    p.splits = (outH + p.rows_per_split - 1) / p.rows_per_split;
+    p.partial_floats = (size_t)p.splits * waves * p.NT * 1024;
+    return p;
+}
+}  // namespace
+
+extern "C" size_t read_conv_wgrad_scratch_floats(int Cin, int Cout, int ksize, int outH)
+{
+    if (Cin < 1 || Cout < 1 || outH < 1) return 0;
+    return wgrad_plan(Cin, Cout, ksize, outH).partial_floats;
+}
+
+extern "C" int read_conv_wgrad(const float *x, int inH, int inW, int Cin, const float *dfm, int Cout, int ksize, int stride,
+                               float *dwf, float *dwm, int accumulate, float *scratch, size_t scratch_floats, void *stream)
+{
+    READ_CHECK_ARG(x && dfm && dwf && dwm && scratch, "read_conv_wgrad: null pointer");
+    READ_CHECK_ARG(ksize == 1 || ksize == 3 || ksize == 4, "read_conv_wgrad: ksize must be 1, 3 or 4");
+    READ_CHECK_ARG(stride == 1 || stride == 2, "read_conv_wgrad: stride must be 1 or 2");
+    const int pad = (ksize - 1) / 2, Cp = (Cout + 7) / 8 * 8;
+    const int outH = (inH + 2 * pad - ksize) / stride + 1, outW = (inW + 2 * pad - ksize) / stride + 1;
+    READ_CHECK_ARG(outH >= 1 && outW >= 1, "read_conv_wgrad: empty output");
+    const WgradPlan p = wgrad_plan(Cin, Cout, ksize, outH);
+    READ_CHECK_ARG(scratch_floats >= p.partial_floats, "read_conv_wgrad: scratch %zu < %zu floats", scratch_floats, p.partial_floats);
+    const dim3 grid((unsigned)(p.tiles_ci * p.tiles_co), (unsigned)p.tap_groups, (unsigned)p.splits);
+    auto kern = p.NT == 9 ? wgrad_mfma_kernel<9> : (p.NT == 8 ? wgrad_mfma_kernel<8> : wgrad_mfma_kernel<1>);
+    hipLaunchKernelGGL(kern, grid, dim3(64), 0, as_stream(stream), x, inH, inW, Cin, dfm, outH, outW, 2 * Cp, ksize, stride,
+                       p.tiles_co, p.rows_per_split, scratch);
+    READ_CHECK_LAUNCH();
+    const long long total = (long long)2 * Cout * Cin * ksize * ksize;
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(grid_for(total)), dim3(256), 0, as_stream(stream), (const float *)scratch,
+                       p.splits, p.tap_groups, p.NT, p.tiles_ci, p.tiles_co, Cin, Cout, Cp, ksize * ksize, dwf, dwm, accumulate);
+    READ_CHECK_LAUNCH();
+    return READ_OK;
+}
+
+extern "C" int read_bilinear_up4_backward(const float *dout, int inH, int inW, int C, float *din, void *stream)
+{
+    READ_CHECK_ARG(dout && din && inH >= 1 && inW >= 1, "read_bilinear_up4_backward: null pointer or empty input");
+    READ_CHECK_ARG(C >= 4 && C % 4 == 0, "read_bilinear_up4_backward: C must be a multiple of 4");
+    hipLaunchKernelGGL(bilinear_up4_backward_kernel, dim3(grid_for((long long)inH * inW * (C / 4))), dim3(256), 0,
+                       as_stream(stream), dout, inH, inW, C, din);
+    READ_CHECK_LAUNCH();
+    return READ_OK;
+}
+
+extern "C" int read_huber_loss(const float *out, const float *target, int64_t n, float grad_scale, float *loss_sum, float *grad,
+                               void *stream)
+{
+    READ_CHECK_ARG(out && target && n >= 1 && (loss_sum || grad), "read_huber_loss: null pointer or empty tensor");
+    if (loss_sum) READ_CHECK_HIP(hipMemsetAsync(loss_sum, 0, sizeof(float), as_stream(stream)));
+    hipLaunchKernelGGL(huber_kernel, dim3(grid_for(n, 256, 1024)), dim3(256), 0, as_stream(stream), out, target, (long long)n,
+                       grad_scale, loss_sum, grad);
+    READ_CHECK_LAUNCH();
+    return READ_OK;
+}
+
+extern "C" int read_rmsprop_sparse(float *rows, float *sq, float *grad, int32_t *stamp, int C, int64_t n_rows,
+                                   const int32_t *ids, int64_t n_ids, int step, float lr, float alpha, float eps, void *stream)
+{
+    READ_CHECK_ARG(rows && sq && grad && stamp && ids, "read_rmsprop_sparse: null pointer");
+    READ_CHECK_ARG(C >= 1 && n_rows >= 1 && n_ids >= 0 && step >= 1, "read_rmsprop_sparse: bad sizes / step");
+    if (n_ids == 0) return READ_OK;
+    hipLaunchKernelGGL(rmsprop_sparse_kernel, dim3(grid_for(n_ids)), dim3(256), 0, as_stream(stream), rows, sq, grad, stamp, C,
+                       (long long)n_rows, ids, (long long)n_ids, step, lr, alpha, eps);
+    READ_CHECK_LAUNCH();
+    return READ_OK;
+}

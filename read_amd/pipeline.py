@@ -6,9 +6,12 @@ criterion, args) so ``--pipeline read_amd.pipeline.TexturePipeline`` (or the ``R
 alias in the ``READ/`` shim package) is selectable by dotted path without editing train.py.
 Checkpoints use the reference's format ``{'state_dict', 'args'}`` (READ/utils/train.py:42-66).
 
-Datasets, losses and the training loop are NOT rebuilt here (out of the hot path, SURVEY.md §2.1
-#17-#21): ``create`` in training mode obtains datasets through ``args.get_datasets`` and the
-criterion through ``args.criterion_module``, both supplied by the caller's training script.
+Datasets, the VGG criterion and the training loop are NOT rebuilt here (out of the hot path):
+``create`` in training mode obtains the datasets exactly as the reference does — ``READ.datasets.dynamic.get_datasets(args)``
+(READ/pipelines/ogl.py:6,82; resolved through the ``READ`` alias package, which forwards to the reference checkout behind it on
+``sys.path``) unless the caller supplies ``args.get_datasets`` — and the criterion from ``args.criterion_module``.  The training
+STEP itself is native: ``UNet.forward`` builds an autograd graph of HIP nodes (read_amd/train.py) and the descriptor optimizer
+is ``SparseDescriptorRMSprop``.
 """
 import importlib
 import os
@@ -37,12 +40,26 @@ def load_model_checkpoint(path, model):
     return model
 
 
+def deval_args(args):
+    """READ/utils/arguments.py: checkpoints carry plain data only — callables / classes / modules become dotted names."""
+    d = dict(vars(args)) if not isinstance(args, dict) else dict(args)
+    out = {}
+    for k, v in d.items():
+        if isinstance(v, (str, int, float, bool, type(None), list, tuple, dict, Path)):
+            out[k] = v
+        elif hasattr(v, '__module__') and hasattr(v, '__qualname__'):
+            out[k] = f"{v.__module__}.{v.__qualname__}"
+        else:
+            out[k] = repr(v)
+    return out
+
+
 def save_model(save_path, model, args=None):
     """READ/utils/train.py:42-57: {'state_dict', 'args'}."""
     model = model.module if hasattr(model, 'module') else model
     d = {'state_dict': model.state_dict()}
     if args is not None:
-        d['args'] = dict(vars(args)) if not isinstance(args, dict) else dict(args)
+        d['args'] = deval_args(args)
     torch.save(d, save_path)
 
 
@@ -99,16 +116,22 @@ class TexturePipeline(Pipeline):
             textures = {0: self._texture(args, int(args.n_points))}
         else:
             get_datasets = getattr(args, 'get_datasets', None)
-            if get_datasets is None:
-                raise RuntimeError("training mode needs args.get_datasets(args) -> (ds_train, ds_val); "
-                                   "dataset code is not part of read_amd (see INTEGRATION.md)")
+            if get_datasets is None:                       # READ/pipelines/ogl.py:6,82
+                try:
+                    get_datasets = importlib.import_module('READ.datasets.dynamic').get_datasets
+                except (ImportError, AttributeError) as e:
+                    raise RuntimeError("training mode needs READ.datasets.dynamic.get_datasets (put the reference checkout "
+                                       "behind this repo on PYTHONPATH, INTEGRATION.md) or args.get_datasets(args)") from e
             self.ds_train, self.ds_val = get_datasets(args)
             for ds in self.ds_train:
                 assert ds.scene_data['pointcloud'] is not None, 'set pointcloud'
                 textures[ds.id] = self._texture(args, ds.scene_data['pointcloud']['xyz'].shape[0])
             self.optimizer = optim.Adam(net.parameters(), lr=args.lr)
+            self.sparse_textures = bool(getattr(args, 'sparse_texture_optimizer', True)) and not getattr(args, 'reg_weight', 0.)
+            for tex in textures.values():
+                tex.sparse_training = self.sparse_textures
             if len(textures) == 1:
-                self._extra_optimizer = TextureOptimizerClass(textures[0].parameters(), lr=args.texture_lr)
+                self._extra_optimizer = self._texture_optimizer([next(iter(textures.values()))], args.texture_lr)
             crit = getattr(args, 'criterion_module', None)
             if crit is not None:
                 crit = _locate(crit) if isinstance(crit, str) else crit
@@ -117,6 +140,14 @@ class TexturePipeline(Pipeline):
         self.textures = textures
         self.model = NetAndTexture(net, textures, getattr(args, 'supersampling', 1))
         self.args = args
+
+    def _texture_optimizer(self, texs, lr):
+        """RMSprop over the descriptors (ogl.py:16,99-100): the sparse HIP optimizer unless it is switched off
+        (``args.sparse_texture_optimizer = False``) or a dense regulariser (``reg_weight``) needs dense gradients."""
+        if getattr(self, 'sparse_textures', False):
+            from .train import SparseDescriptorRMSprop
+            return SparseDescriptorRMSprop(texs, lr=lr)
+        return TextureOptimizerClass([{'params': t.parameters()} for t in texs], lr=lr)
 
     def state_objects(self):
         objs = {'net': self.net}
@@ -133,8 +164,7 @@ class TexturePipeline(Pipeline):
         if self._extra_optimizer is not None:       # single dataset: keep optimizer state across epochs
             self._extra_optimizer.param_groups[0]['lr'] = self.args.texture_lr * lr_drop
             return self._extra_optimizer
-        groups = [{'params': self.textures[ds.id].parameters()} for ds in dataset]
-        return TextureOptimizerClass(groups, lr=self.args.texture_lr * lr_drop)
+        return self._texture_optimizer([self.textures[ds.id] for ds in dataset], self.args.texture_lr * lr_drop)
 
     def dataset_unload(self, dataset):
         self.model.unload_textures()
@@ -153,9 +183,16 @@ def load_pipeline(checkpoint, args_to_update=None):
     a = dict(ckpt['args'])
     if args_to_update:
         a.update(args_to_update)
-    a['pipeline'] = 'READ.pipelines.ogl.TexturePipeline'
+    # READ/pipelines/pipeline.py:34-56: the checkpoint names its pipeline class by dotted path
+    name = a.get('pipeline') or 'READ.pipelines.ogl.TexturePipeline'
+    try:
+        cls = _locate(name) if isinstance(name, str) else name
+    except (ImportError, AttributeError) as e:
+        raise ImportError(f"checkpoint pipeline '{name}' cannot be imported") from e
+    if not (isinstance(cls, type) and issubclass(cls, Pipeline)):
+        raise TypeError(f"checkpoint pipeline '{name}' is not a read_amd Pipeline (only TexturePipeline is on the HIP path)")
     args = SimpleNamespace(**a)
-    pipeline = TexturePipeline()
+    pipeline = cls()
     pipeline.create(args)
     load_model_checkpoint(checkpoint, pipeline.get_net())
     return pipeline, args

@@ -90,6 +90,31 @@ class _GatherFn(torch.autograd.Function):
         return rows_to_texture(drows)[None], None
 
 
+class _GatherRowsFn(torch.autograd.Function):
+    """Sparse-training lookup: the live (N,C) rows are the master copy; backward scatter-adds into the texture's persistent
+    gradient ROWS and records which ids were touched (SparseDescriptorRMSprop consumes both).  ``texture_`` itself gets no
+    dense (1,C,N) gradient — at 30 M points that tensor alone is 960 MB per step."""
+
+    @staticmethod
+    def forward(ctx, texture, ids, module):
+        ctx.module = module
+        ctx.save_for_backward(ids)
+        return gather_pyramid(module.training_rows(), [ids])[0]
+
+    @staticmethod
+    def backward(ctx, grad):
+        (ids,) = ctx.saved_tensors
+        m = ctx.module
+        drows = m.grad_rows()
+        g = grad.contiguous()
+        counts = (C.c_int64 * 1)(int(ids.numel()))
+        _lib.check(_lib.lib().read_gather_backward(drows.data_ptr(), drows.shape[0], drows.shape[1], 1,
+                                                   _lib.ptr_array([ids.data_ptr()]), counts, _lib.ptr_array([g.data_ptr()]),
+                                                   _lib.stream_ptr()), "read_gather_backward")
+        m._touched.append(ids.reshape(-1))
+        return None, None, None
+
+
 class Texture(nn.Module):
     def null_grad(self):
         raise NotImplementedError()
@@ -121,9 +146,49 @@ class PointTexture(Texture):
         self.reg_weight = reg_weight
         self._rows = None
         self._rows_version = None
+        self.sparse_training = False        # True: gradients go to grad_rows() + touched ids (SparseDescriptorRMSprop)
+        self._grad_rows = None
+        self._touched = []
+        self._rows_newer = False            # the rows were stepped by the sparse optimizer; texture_ is stale until synced
 
     def null_grad(self):
         self.texture_.grad = None
+        self._touched = []
+
+    # ---- sparse training state ---------------------------------------------------------------------------------------
+    def training_rows(self):
+        return self.rows()
+
+    def grad_rows(self):
+        rows = self.rows()
+        if self._grad_rows is None or self._grad_rows.shape != rows.shape or self._grad_rows.device != rows.device:
+            self._grad_rows = torch.zeros_like(rows)
+        return self._grad_rows
+
+    def take_touched(self):
+        if not self._touched:
+            return None
+        ids = torch.cat(self._touched).contiguous()
+        self._touched = []
+        return ids
+
+    def rows_changed(self):
+        self._rows_newer = True
+
+    def sync_texture(self):
+        """Write the (N,C) rows back into ``texture_`` (checkpoints, dense consumers) after sparse optimizer steps."""
+        if self._rows_newer and self._rows is not None:
+            self.texture_.data.copy_(rows_to_texture(self._rows)[None])     # .data: no version bump, the row cache stays valid
+            self._rows_newer = False
+
+    def state_dict(self, *args, **kwargs):
+        self.sync_texture()
+        return super().state_dict(*args, **kwargs)
+
+    def invalidate(self):
+        """Drop the cached rows (call after editing ``texture_`` through ``.data`` or other version-blind paths)."""
+        self._rows = None
+        self._rows_newer = False
 
     def reg_loss(self):
         return self.reg_weight * torch.mean(torch.pow(self.texture_, 2))
@@ -160,8 +225,11 @@ class PointTexture(Texture):
         if not self.texture_.is_cuda:
             raise _lib.ReadHipError("PointTexture lookups run on the GPU: move the module with .cuda()")
         ids = ids.to(self.texture_.device)
+        if int(ids.max()) >= self.texture_.shape[-1] or int(ids.min()) < 0:
+            raise IndexError(f"point id out of range for a descriptor table of {self.texture_.shape[-1]} points")
         if torch.is_grad_enabled() and self.texture_.requires_grad:
-            sample = _GatherFn.apply(self.texture_, ids)
+            sample = (_GatherRowsFn.apply(self.texture_, ids, self) if self.sparse_training
+                      else _GatherFn.apply(self.texture_, ids))
             if self.activation == 'sigmoid':
                 sample = torch.sigmoid(sample)
             elif self.activation == 'tanh':

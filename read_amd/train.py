@@ -1,0 +1,286 @@
+"""Native training step of READ's render path (BASELINE configs[4]).
+
+What the reference gets from torch.autograd + cuDNN under ``src/train.py:132-203`` — backward of every ``BasicConv``
+(READ/models/unet.py:22-53), of the ×4 bilinear upsample, of the descriptor lookup (READ/models/texture.py:61), the Huber
+loss (src/READ/models/compose.py:35,38) and the descriptor optimizer (READ/pipelines/ogl.py:16,99-100) — runs here on the
+HIP kernels of csrc/train.hip + csrc/conv.hip:
+
+  GatedConvFn     forward  = MFMA convolution in linear mode (pre-activations f|m kept) + gate kernel
+                  backward = gate backward (+ bias / BatchNorm-affine sums), dgrad (the same MFMA kernel over d[f|m] with
+                             flipped, transposed weights; generic kernel for the six stride-2 layers), MFMA wgrad
+  Up4Fn           bilinear x4 and its adjoint
+  huber_loss      loss value + gradient in one launch
+  SparseDescriptorRMSprop   RMSprop over the descriptor rows a step touched (the reference sweeps all N rows: 960 MB of
+                             gradient + state at 30 M points every step)
+
+The graph around the convolutions (torch.cat, nearest resampling, FAM's product, residual adds) is expressed with torch
+tensor ops on the device so that autograd does the bookkeeping of the 99-layer graph; every FLOP-carrying node is HIP.
+BatchNorm runs as the eval-mode affine map with trainable gamma/beta — the configuration the reference trains with
+(configs/train_example.yaml ``eval_in_train: True``; train.py:271-277 puts the model in ``.eval()``); batch-statistics
+BatchNorm (``model.train()``) raises.
+"""
+import ctypes as C
+
+import torch
+
+from . import _lib
+
+BN_EPS = 1e-5
+
+
+def _ptr(t):
+    return t.data_ptr() if t is not None else None
+
+
+def _kc_for(cin):
+    if cin % 8:
+        raise ValueError(f"the HIP convolution needs input channels in multiples of 8 (got {cin})")
+    return 16 if cin % 16 == 0 else 8
+
+
+def _linear_conv(x, cin, wpacked, params, cout, k, stride, out):
+    """x (H,W,cin) NHWC -> out (Ho,Wo,2*cout): [conv_f + b_f | conv_m + b_m] through the MFMA kernel (linear epilogue)."""
+    H, W = int(x.shape[0]), int(x.shape[1])
+    d = _lib.ConvDesc()
+    d.n_src = 1
+    d.src[0].data = x.data_ptr()
+    d.src[0].C, d.src[0].srcH, d.src[0].srcW, d.src[0].shift = cin, H, W, 0
+    d.inH, d.inW, d.Cout, d.ksize, d.stride, d.elu = H, W, cout, k, stride, 0
+    d.wpacked, d.params, d.out, d.out_cstride = wpacked.data_ptr(), params.data_ptr(), out.data_ptr(), 2 * cout
+    d.config, d.linear = -1, 1
+    _lib.check(_lib.lib().read_gated_conv_forward(C.byref(d), _lib.stream_ptr()), "read_gated_conv_forward(linear)")
+    return out
+
+
+class GatedConvFn(torch.autograd.Function):
+    """y = BN_eval(act(conv_f(x) + b_f) * sigmoid(conv_m(x) + b_m)) for ONE image, x (H,W,Cin) NHWC -> (Ho,Wo,Cout)."""
+
+    @staticmethod
+    def forward(ctx, x, wf, bf, wm, bm, gamma, beta, mean, var, k, stride, elu):
+        L = _lib.lib()
+        st = _lib.stream_ptr()
+        x = x.contiguous()
+        H, W, cin = (int(v) for v in x.shape)
+        cout = int(wf.shape[0])
+        pad = (k - 1) // 2
+        Ho, Wo = (H + 2 * pad - k) // stride + 1, (W + 2 * pad - k) // stride + 1
+        dev = x.device
+        wf_c, wm_c = wf.detach().contiguous(), wm.detach().contiguous()
+        params = torch.empty(L.read_conv_param_floats(cout), dtype=torch.float32, device=dev)
+        _lib.check(L.read_conv_pack_params_device(cout, _ptr(bf.detach()), _ptr(bm.detach()), _ptr(gamma.detach()),
+                                                  _ptr(beta.detach()), _ptr(mean), _ptr(var), BN_EPS, params.data_ptr(), st))
+        wp = torch.empty(L.read_conv_packed_floats(cin, cout, k), dtype=torch.float32, device=dev)
+        _lib.check(L.read_conv_pack_weights_device(cin, cout, k, _kc_for(cin), wf_c.data_ptr(), wm_c.data_ptr(), wp.data_ptr(), st))
+        fm = torch.empty((Ho, Wo, 2 * cout), dtype=torch.float32, device=dev)
+        _linear_conv(x, cin, wp, params, cout, k, stride, fm)
+        y = torch.empty((Ho, Wo, cout), dtype=torch.float32, device=dev)
+        _lib.check(L.read_gate_forward(fm.data_ptr(), Ho * Wo, cout, params.data_ptr(), int(elu), None, y.data_ptr(), st))
+        ctx.save_for_backward(x, fm, params, wf_c, wm_c, mean, var)
+        ctx.cfg = (k, stride, int(elu), H, W, cin, cout, Ho, Wo)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        L = _lib.lib()
+        st = _lib.stream_ptr()
+        x, fm, params, wf, wm, mean, var = ctx.saved_tensors
+        k, stride, elu, H, W, cin, cout, Ho, Wo = ctx.cfg
+        dev = x.device
+        dy = dy.contiguous()
+        cp = (cout + 7) // 8 * 8
+        dfm = torch.empty((Ho, Wo, 2 * cp), dtype=torch.float32, device=dev)
+        sums = torch.empty((4, cout), dtype=torch.float32, device=dev)
+        _lib.check(L.read_gate_backward(dy.data_ptr(), fm.data_ptr(), Ho * Wo, cout, params.data_ptr(), elu, dfm.data_ptr(),
+                                        sums.data_ptr(), st))
+        dbf, dbm, dgamma, dbeta = (torch.zeros(cout, dtype=torch.float32, device=dev) for _ in range(4))
+        _lib.check(L.read_bn_param_grads(cout, sums.data_ptr(), mean.data_ptr(), var.data_ptr(), BN_EPS, dbf.data_ptr(),
+                                         dbm.data_ptr(), dgamma.data_ptr(), dbeta.data_ptr(), st))
+        dx = None
+        if ctx.needs_input_grad[0]:
+            dx = torch.empty((H, W, cin), dtype=torch.float32, device=dev)
+            if stride == 1:
+                # dgrad = the same MFMA convolution over d[f|m] with flipped, transposed weights; the two "gate halves" of
+                # the kernel's output tile are simply the two halves of the input channels
+                wd = torch.empty(L.read_conv_dgrad_packed_floats(cin, cout, k), dtype=torch.float32, device=dev)
+                _lib.check(L.read_conv_pack_dgrad_device(cin, cout, k, 16, wf.data_ptr(), wm.data_ptr(), wd.data_ptr(), st))
+                zero = torch.zeros(L.read_conv_param_floats(cin // 2), dtype=torch.float32, device=dev)
+                _linear_conv(dfm, 2 * cp, wd, zero, cin // 2, k, 1, dx)
+            else:
+                ws = torch.empty(L.read_conv_dgrad_generic_floats(cin, cout, k), dtype=torch.float32, device=dev)
+                _lib.check(L.read_conv_dgrad_generic(dfm.data_ptr(), Ho, Wo, cin, cout, k, stride, wf.data_ptr(), wm.data_ptr(),
+                                                     ws.data_ptr(), H, W, dx.data_ptr(), st))
+        dwf, dwm = torch.empty_like(wf), torch.empty_like(wm)
+        n_scr = L.read_conv_wgrad_scratch_floats(cin, cout, k, Ho)
+        scratch = torch.empty(n_scr, dtype=torch.float32, device=dev)
+        _lib.check(L.read_conv_wgrad(x.data_ptr(), H, W, cin, dfm.data_ptr(), cout, k, stride, dwf.data_ptr(), dwm.data_ptr(), 0,
+                                     scratch.data_ptr(), n_scr, st))
+        return dx, dwf, dbf, dwm, dbm, dgamma, dbeta, None, None, None, None, None
+
+
+class Up4Fn(torch.autograd.Function):
+    """nn.Upsample(scale_factor=4, mode='bilinear') (unet.py:200) on an (H,W,C) NHWC image, and its adjoint."""
+
+    @staticmethod
+    def forward(ctx, x):
+        x = x.contiguous()
+        H, W, c = (int(v) for v in x.shape)
+        out = torch.empty((4 * H, 4 * W, c), dtype=torch.float32, device=x.device)
+        _lib.check(_lib.lib().read_bilinear_up4(x.data_ptr(), H, W, c, out.data_ptr(), _lib.stream_ptr()))
+        ctx.shape = (H, W, c)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        H, W, c = ctx.shape
+        dout = dout.contiguous()
+        din = torch.empty((H, W, c), dtype=torch.float32, device=dout.device)
+        _lib.check(_lib.lib().read_bilinear_up4_backward(dout.data_ptr(), H, W, c, din.data_ptr(), _lib.stream_ptr()))
+        return din
+
+
+class _HuberFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, out, target):
+        out, target = out.contiguous(), target.contiguous().to(out.device, torch.float32)
+        n = out.numel()
+        loss = torch.empty(1, dtype=torch.float32, device=out.device)
+        grad = torch.empty_like(out)
+        _lib.check(_lib.lib().read_huber_loss(out.data_ptr(), target.data_ptr(), n, 1.0 / n, loss.data_ptr(), grad.data_ptr(),
+                                              _lib.stream_ptr()))
+        ctx.save_for_backward(grad)
+        return loss[0] / n
+
+    @staticmethod
+    def backward(ctx, g):
+        (grad,) = ctx.saved_tensors
+        return grad * g, None
+
+
+def huber_loss(out, target):
+    """``F.huber_loss(out, target)`` (delta 1, mean) with value and gradient from one HIP launch."""
+    return _HuberFn.apply(out, target)
+
+
+# -----------------------------------------------------------------------------------------------------------------------
+# the UNet graph in training mode (READ/models/unet.py:202-285), one image, NHWC
+# -----------------------------------------------------------------------------------------------------------------------
+def _bc(net, path, x, k, stride=1, elu=True):
+    node = net
+    for p in path.split('.'):
+        node = node._modules[p]
+    b = node.block
+    n = b['norm']
+    return GatedConvFn.apply(x, b['conv_f'].weight, b['conv_f'].bias, b['conv_m'].weight, b['conv_m'].bias, n.weight, n.bias,
+                             n.running_mean, n.running_var, k, stride, elu)
+
+
+def _res_blocks(net, prefix, x):
+    for j in range(4):
+        p = f"{prefix}.layers.{j}.main."
+        x = _bc(net, p + "1", _bc(net, p + "0", x, 3), 3, elu=False) + x
+    return x
+
+
+def _scm(net, name, x):
+    y = _bc(net, name + ".main.0", x, 3)
+    y = _bc(net, name + ".main.1", y, 1)
+    y = _bc(net, name + ".main.2", y, 3)
+    y = _bc(net, name + ".main.3", y, 1)
+    return _bc(net, name + ".conv", torch.cat([x, y], -1), 1, elu=False)
+
+
+def _down(x, s):                       # F.interpolate(scale_factor=1/s), nearest: source index = dst * s
+    return x[::s, ::s]
+
+
+def _up(x, s):                         # nearest up: source index = dst // s
+    return x.repeat_interleave(s, 0).repeat_interleave(s, 1)
+
+
+def unet_forward_train(net, x, x2, x4, x8):
+    """(h,w,8) NHWC pyramids of ONE image -> (H,W,3); every tensor carries autograd history."""
+    z2, z4, z8 = _scm(net, "SCM2", x2), _scm(net, "SCM1", x4), _scm(net, "SCM0", x8)
+    res1 = _res_blocks(net, "Encoder.0", _bc(net, "feat_extract.0", x, 3))
+    z = _bc(net, "feat_extract.1", res1, 3, stride=2)
+    z = z + _bc(net, "FAM2.merge", z * z2, 3, elu=False)
+    res2 = _res_blocks(net, "Encoder.1", z)
+    z = _bc(net, "feat_extract.2", res2, 3, stride=2)
+    z = z + _bc(net, "FAM1.merge", z * z4, 3, elu=False)
+    res3 = _res_blocks(net, "Encoder.2", z)
+    z = _bc(net, "feat_extract.6", res3, 3, stride=2)
+    z = z + _bc(net, "FAM0.merge", z * z8, 3, elu=False)
+    z = _res_blocks(net, "Encoder.3", z)
+    z12, z13 = _down(res1, 2), _down(res1, 4)
+    z21, z23 = _up(res2, 2), _down(res2, 2)
+    z32, z31 = _up(res3, 2), _up(res3, 4)
+    z43 = _up(z, 2)
+    z42 = _up(z43, 2)
+    z41 = _up(z42, 2)
+
+    def aff(name, xs):
+        return _bc(net, name + ".conv.1", _bc(net, name + ".conv.0", torch.cat(xs, -1), 1), 3, elu=False)
+    r1, r2, r3 = aff("AFFs.0", [res1, z21, z31, z41]), aff("AFFs.1", [z12, res2, z32, z42]), aff("AFFs.2", [z13, z23, res3, z43])
+    z = _res_blocks(net, "Decoder.0", z)
+    z = Up4Fn.apply(_bc(net, "feat_extract.7", z, 4, stride=2))
+    z = _res_blocks(net, "Decoder.1", _bc(net, "Convs.0", torch.cat([z, r3], -1), 1))
+    z = Up4Fn.apply(_bc(net, "feat_extract.3", z, 4, stride=2))
+    z = _res_blocks(net, "Decoder.2", _bc(net, "Convs.1", torch.cat([z, r2], -1), 1))
+    z = Up4Fn.apply(_bc(net, "feat_extract.4", z, 4, stride=2))
+    z = _res_blocks(net, "Decoder.3", _bc(net, "Convs.2", torch.cat([z, r1], -1), 1))
+    return _bc(net, "feat_extract.5", z, 3, elu=False)
+
+
+# -----------------------------------------------------------------------------------------------------------------------
+# descriptor optimizer
+# -----------------------------------------------------------------------------------------------------------------------
+class SparseDescriptorRMSprop:
+    """RMSprop (torch defaults, READ/pipelines/ogl.py:16: alpha 0.99, eps 1e-8, no momentum) over the descriptor ROWS that
+    the step's index maps touched.  The dense optimizer of the reference reads and writes all N rows of gradient, state
+    and parameter every step; rows without a pixel have zero gradient, so only their second-moment decay is owed — it is
+    applied lazily when the row is touched again (csrc/train.hip), which makes every row's trajectory equal the dense one.
+
+    Duck-types what ``train.py`` uses of a torch optimizer: ``step()``, ``zero_grad()``, ``param_groups`` (lr),
+    ``state_dict()`` / ``load_state_dict()``."""
+
+    def __init__(self, textures, lr=1e-1, alpha=0.99, eps=1e-8):
+        self.textures = list(textures)
+        self.param_groups = [{'params': [t.texture_ for t in self.textures], 'lr': lr, 'alpha': alpha, 'eps': eps}]
+        self.state = {}
+
+    def _state(self, tex):
+        s = self.state.get(id(tex))
+        if s is None:
+            rows = tex.training_rows()
+            s = self.state[id(tex)] = {'step': 0, 'sq': torch.zeros_like(rows),
+                                       'stamp': torch.zeros(rows.shape[0], dtype=torch.int32, device=rows.device)}
+        return s
+
+    def step(self, closure=None):
+        g = self.param_groups[0]
+        for tex in self.textures:
+            ids = tex.take_touched()
+            if ids is None:
+                continue
+            s = self._state(tex)
+            s['step'] += 1
+            rows, grad = tex.training_rows(), tex.grad_rows()
+            _lib.check(_lib.lib().read_rmsprop_sparse(rows.data_ptr(), s['sq'].data_ptr(), grad.data_ptr(), s['stamp'].data_ptr(),
+                                                      int(rows.shape[1]), int(rows.shape[0]), ids.data_ptr(), ids.numel(),
+                                                      s['step'], float(g['lr']), float(g['alpha']), float(g['eps']),
+                                                      _lib.stream_ptr()), "read_rmsprop_sparse")
+            tex.rows_changed()
+
+    def zero_grad(self, set_to_none=True):
+        pass                                      # step() leaves every touched gradient row zero again
+
+    def state_dict(self):
+        return {'param_groups': [{k: v for k, v in self.param_groups[0].items() if k != 'params'}],
+                'state': [{k: (v.cpu() if torch.is_tensor(v) else v) for k, v in self._state(t).items()} for t in self.textures]}
+
+    def load_state_dict(self, sd):
+        self.param_groups[0].update(sd['param_groups'][0])
+        for t, s in zip(self.textures, sd['state']):
+            cur = self._state(t)
+            cur['step'] = s['step']
+            cur['sq'].copy_(s['sq'])
+            cur['stamp'].copy_(s['stamp'])

@@ -179,6 +179,15 @@ class UNet(nn.Module):
             self._engines = {}
         return self._packed
 
+    def invalidate(self):
+        """Drop the packed weights (call after editing parameters through ``.data``, which does not bump ``_version``)."""
+        self._packed = None
+        self._engines = {}
+
+    def load_state_dict(self, *args, **kwargs):
+        self.invalidate()
+        return super().load_state_dict(*args, **kwargs)
+
     def engine(self, H, W):
         packed = self.packed_weights()
         e = self._engines.get((H, W))
@@ -192,11 +201,22 @@ class UNet(nn.Module):
         inputs = list(inputs)
         if len(inputs) < 4:
             raise ValueError("UNet.forward needs the 1, 1/2, 1/4 and 1/8 scale inputs")
-        if torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()) and self.training:
+        if self.training:
             raise NotImplementedError(
-                "the HIP UNet is forward-only in this build; run inference under torch.no_grad() / .eval()")
+                "batch-statistics BatchNorm (model.train()) is not built: train with the model in .eval(), i.e. "
+                "eval_in_train: True as in the reference's configs/train_example.yaml (train.py:271-277)")
         _lib.require_gpu()
         dev = next(self.parameters()).device
+        wants_grad = torch.is_grad_enabled() and (any(p.requires_grad for p in self.parameters())
+                                                  or any(torch.is_tensor(x) and x.requires_grad for x in inputs[:4]))
+        if wants_grad:
+            # training step: every BasicConv is an autograd node backed by the HIP kernels of csrc/train.hip
+            from .train import unet_forward_train
+            outs = []
+            for b in range(inputs[0].shape[0]):
+                xs = [x[b].to(dev, torch.float32).permute(1, 2, 0).contiguous() for x in inputs[:4]]
+                outs.append(unet_forward_train(self, *xs).permute(2, 0, 1))
+            return torch.stack(outs, 0)
         xs = [x.to(dev, torch.float32).permute(0, 2, 3, 1).contiguous() for x in inputs[:4]]
         B, H, W, _ = xs[0].shape
         eng = self.engine(H, W)

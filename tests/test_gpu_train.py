@@ -1,0 +1,232 @@
+"""Parity of the native training step with torch.autograd through the oracle (oracle/unet_torch.py,
+the functional restatement of the reference's modules): per-layer gradients of every BasicConv flavour, the bilinear x4
+adjoint, the Huber loss, the full UNet backward on a crop, the sparse descriptor RMSprop against torch.optim.RMSprop, and
+one whole optimisation step through TexturePipeline.  Stated tolerance: gradients rtol 1e-4 of the largest gradient entry of
+the tensor (fp32, different summation orders; wgrad sums ~10^4..10^5 products per weight)."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from oracle import unet_torch
+from read_amd import synthetic
+from read_amd.train import GatedConvFn, SparseDescriptorRMSprop, Up4Fn, huber_loss, unet_forward_train
+from read_amd.unet import UNet
+from tests.unet_spec import UNET_SPEC
+
+pytestmark = pytest.mark.gpu
+
+RTOL = 1e-4
+
+
+def _close(got, ref, what, rtol=RTOL):
+    got, ref = got.detach().cpu().double(), ref.detach().cpu().double()
+    assert got.shape == ref.shape, (what, got.shape, ref.shape)
+    scale = max(float(ref.abs().max()), 1e-30)
+    err = float((got - ref).abs().max()) / scale
+    assert err <= rtol, f"{what}: max error {err:.3e} of the largest entry ({scale:.3e})"
+    return err
+
+
+@pytest.mark.parametrize("cin,cout,k,stride,elu,H,W", [
+    (32, 32, 3, 1, True, 24, 40), (64, 64, 3, 1, False, 17, 33), (8, 32, 3, 1, True, 32, 48), (32, 3, 3, 1, False, 16, 32),
+    (480, 32, 1, 1, True, 16, 24), (64, 56, 1, 1, True, 12, 20), (16, 32, 1, 1, True, 9, 31),
+    (32, 64, 3, 2, True, 32, 48), (128, 256, 3, 2, True, 16, 16), (256, 128, 4, 2, True, 16, 24), (64, 32, 4, 2, True, 32, 32),
+])
+def test_gated_conv_layer_gradients(hip, cin, cout, k, stride, elu, H, W):
+    rng = np.random.default_rng(cin * 1000 + cout + k)
+    b = 1.0 / np.sqrt(cin * k * k)
+    t = lambda a: torch.from_numpy(np.asarray(a, np.float32))
+    p = dict(wf=t(rng.uniform(-b, b, (cout, cin, k, k))), bf=t(rng.uniform(-b, b, cout)), wm=t(rng.uniform(-b, b, (cout, cin, k, k))),
+             bm=t(rng.uniform(-b, b, cout)), gamma=t(rng.uniform(0.5, 1.5, cout)), beta=t(0.1 * rng.standard_normal(cout)),
+             mean=t(0.1 * rng.standard_normal(cout)), var=t(rng.uniform(0.5, 1.5, cout)))
+    x = t(rng.standard_normal((1, cin, H, W)))
+    pad = (k - 1) // 2
+    # oracle: the reference's BasicConv arithmetic under torch.autograd
+    ref_in = {n: v.clone().requires_grad_(n not in ("mean", "var")) for n, v in p.items()}
+    xr = x.clone().requires_grad_(True)
+    f = F.conv2d(xr, ref_in["wf"], ref_in["bf"], stride=stride, padding=pad)
+    m = F.conv2d(xr, ref_in["wm"], ref_in["bm"], stride=stride, padding=pad)
+    yr = F.batch_norm((F.elu(f) if elu else f) * torch.sigmoid(m), ref_in["mean"], ref_in["var"], ref_in["gamma"], ref_in["beta"],
+                      training=False, eps=1e-5)
+    g = t(rng.standard_normal(tuple(yr.shape)))
+    yr.backward(g)
+    # HIP
+    dev = {n: v.cuda().requires_grad_(n not in ("mean", "var")) for n, v in p.items()}
+    xd = x[0].permute(1, 2, 0).contiguous().cuda().requires_grad_(True)
+    y = GatedConvFn.apply(xd, dev["wf"], dev["bf"], dev["wm"], dev["bm"], dev["gamma"], dev["beta"], dev["mean"], dev["var"], k, stride, elu)
+    _close(y.permute(2, 0, 1)[None], yr, "forward", rtol=2e-5)
+    y.backward(g[0].permute(1, 2, 0).contiguous().cuda())
+    _close(xd.grad.permute(2, 0, 1)[None], xr.grad, "dx")
+    for n in ("wf", "wm", "bf", "bm", "gamma", "beta"):
+        _close(dev[n].grad, ref_in[n].grad, "d" + n)
+
+
+def test_up4_and_huber(hip):
+    rng = np.random.default_rng(1)
+    x = torch.from_numpy(rng.standard_normal((1, 16, 9, 13)).astype(np.float32))
+    xr = x.clone().requires_grad_(True)
+    yr = F.interpolate(xr, scale_factor=4, mode="bilinear", align_corners=False)
+    g = torch.from_numpy(rng.standard_normal(tuple(yr.shape)).astype(np.float32))
+    yr.backward(g)
+    xd = x[0].permute(1, 2, 0).contiguous().cuda().requires_grad_(True)
+    y = Up4Fn.apply(xd)
+    _close(y.permute(2, 0, 1)[None], yr, "up4 forward", rtol=1e-6)
+    y.backward(g[0].permute(1, 2, 0).contiguous().cuda())
+    _close(xd.grad.permute(2, 0, 1)[None], xr.grad, "up4 backward", rtol=1e-5)
+    out = torch.from_numpy((2.0 * rng.standard_normal((2, 3, 20, 24))).astype(np.float32))       # both Huber branches
+    tgt = torch.from_numpy(rng.random((2, 3, 20, 24)).astype(np.float32))
+    o_r = out.clone().requires_grad_(True)
+    l_r = F.huber_loss(o_r, tgt)
+    (1e4 * l_r).backward()                                                                          # huber_ratio, train.py:549
+    o_d = out.cuda().requires_grad_(True)
+    l_d = huber_loss(o_d, tgt.cuda())
+    (1e4 * l_d).backward()
+    assert abs(float(l_d) - float(l_r)) <= 1e-6 * abs(float(l_r))
+    _close(o_d.grad, o_r.grad, "huber grad", rtol=1e-6)
+
+
+def test_unet_training_graph_vs_oracle_autograd(hip):
+    """The whole UNet on a 64x96 crop: output, input gradients (they become descriptor gradients) and all 606 parameter
+    gradients against torch.autograd through the oracle's functional restatement of the reference modules."""
+    H, W = 64, 96
+    state = synthetic.make_unet_state(UNET_SPEC, 13)
+    net = UNet()
+    net.load_state_dict({k: torch.from_numpy(np.asarray(v)) for k, v in state.items()})
+    net.cuda().eval()
+    rng = np.random.default_rng(3)
+    xs = [torch.from_numpy(rng.random((1, 8, H >> l, W >> l)).astype(np.float32)) for l in range(4)]
+    # oracle
+    st_r = {k: torch.from_numpy(np.asarray(v)).clone().requires_grad_(np.asarray(v).dtype == np.float32 and "running" not in k)
+            for k, v in state.items()}
+    xs_r = [x.clone().requires_grad_(True) for x in xs]
+    out_r = unet_torch.unet_forward(st_r, *xs_r)
+    g = torch.from_numpy(rng.standard_normal(tuple(out_r.shape)).astype(np.float32))
+    out_r.backward(g)
+    # HIP
+    xs_d = [x.cuda().requires_grad_(True) for x in xs]
+    out = net(*xs_d)
+    assert out.shape == (1, 3, H, W) and out.grad_fn is not None
+    _close(out, out_r, "forward", rtol=2e-5)
+    out.backward(g.cuda())
+    for l in range(4):
+        _close(xs_d[l].grad, xs_r[l].grad, f"dx level {l}")
+    worst = 0.0
+    n = 0
+    for name, p in net.named_parameters():
+        ref = st_r[name].grad
+        assert p.grad is not None and ref is not None, name
+        worst = max(worst, _close(p.grad, ref, name, rtol=2e-4))
+        n += 1
+    # 99 executed BasicConvs x 6 trainable tensors (ConvsOut.* are never executed: no gradient, unet.py:181-186)
+    print(f"{n} parameter gradients, worst relative error {worst:.2e}")
+    assert n >= 594
+    # inference afterwards still uses the fused plan and sees the same weights
+    with torch.no_grad():
+        y2 = net(*[x.cuda() for x in xs])
+    _close(y2, out_r, "fused forward after training forward", rtol=2e-5)
+    with pytest.raises(NotImplementedError):
+        net.train()(*xs_d)                                           # batch-statistics BatchNorm is not built
+    net.eval()
+
+
+def test_sparse_rmsprop_equals_dense_torch_rmsprop(hip):
+    """Rows touched in some steps only: the lazily decayed sparse update must follow torch.optim.RMSprop's dense trajectory."""
+    from read_amd.texture import PointTexture
+    N, Cc = 4000, 8
+    rng = np.random.default_rng(4)
+    init = rng.random((1, Cc, N)).astype(np.float32)
+    tex = PointTexture(Cc, N, init_method='zeros')
+    with torch.no_grad():
+        tex.texture_.copy_(torch.from_numpy(init))
+    tex.cuda()
+    tex.sparse_training = True
+    opt = SparseDescriptorRMSprop([tex], lr=0.1)
+    ref_p = torch.nn.Parameter(torch.from_numpy(init.copy()))
+    ref_opt = torch.optim.RMSprop([ref_p], lr=0.1)
+    for step in range(5):
+        ids = torch.from_numpy(rng.integers(0, N if step != 2 else N // 10, (2, 1, 24, 32)).astype(np.float32))
+        w = torch.from_numpy(rng.standard_normal((2, Cc, 24, 32)).astype(np.float32))
+        (tex(ids.cuda()) * w.cuda()).sum().backward()
+        opt.step()
+        opt.zero_grad()
+        ref_opt.zero_grad()
+        (ref_p[0][:, ids[:, 0].long()].permute(1, 0, 2, 3) * w).sum().backward()
+        ref_opt.step()
+        assert tex.texture_.grad is None
+    got = tex.state_dict()["texture_"].cpu()                       # state_dict() writes the rows back into texture_
+    _close(got, ref_p.detach(), "descriptors after 5 sparse steps", rtol=1e-5)
+    assert float(tex.grad_rows().abs().max()) == 0.0               # gradient rows are clean again
+    # forward after the steps serves the updated rows
+    ids = torch.arange(64, dtype=torch.float32).view(1, 1, 8, 8)
+    with torch.no_grad():
+        _close(tex(ids.cuda()), ref_p.detach()[0][:, ids[0, 0].long()][None], "lookup after training", rtol=1e-5)
+
+
+def test_texture_pipeline_training_step(hip):
+    """B5: TexturePipeline.create in training mode (datasets + criterion supplied like the reference's args), two full
+    optimisation steps (HIP forward/backward, Adam on the net, sparse RMSprop on the descriptors) against the same steps done
+    with torch modules of the oracle and torch optimizers."""
+    from types import SimpleNamespace
+    from read_amd.pipeline import TexturePipeline
+    H, W, N = 32, 48, 3000
+    rng = np.random.default_rng(6)
+
+    class DS:
+        id, name = 0, "scene0"
+        scene_data = {'pointcloud': {'xyz': np.zeros((N, 3), np.float32)}}
+        def load(self): pass
+        def unload(self): pass
+
+    class Crit(torch.nn.Module):
+        def forward(self, out, target):
+            return huber_loss(out, target)
+
+    args = SimpleNamespace(inference=False, descriptor_size=8, texture_activation='none', use_mesh=False, supersampling=1,
+                           lr=1e-3, texture_lr=1e-1, texture_ckpt=None, get_datasets=lambda a: ([DS()], [DS()]),
+                           criterion_module=Crit, criterion_args={}, pipeline='READ.pipelines.ogl.TexturePipeline')
+    pipe = TexturePipeline()
+    pipe.create(args)
+    state = synthetic.make_unet_state(UNET_SPEC, 2)
+    pipe.net.load_state_dict({k: torch.from_numpy(np.asarray(v)) for k, v in state.items()})
+    tex = pipe.textures[0]
+    init = rng.random((1, 8, N)).astype(np.float32)
+    with torch.no_grad():
+        tex.texture_.copy_(torch.from_numpy(init))
+    model = pipe.model.cuda()
+    pipe.dataset_load([DS()])
+    model.cuda().eval()                                             # eval_in_train: True (train.py:271-277)
+    extra = pipe.extra_optimizer([DS()])
+    assert isinstance(extra, SparseDescriptorRMSprop)
+    # oracle twin
+    st_r = {k: torch.nn.Parameter(torch.from_numpy(np.asarray(v)).clone()) if (np.asarray(v).dtype == np.float32 and "running" not in k)
+            else torch.from_numpy(np.asarray(v)).clone() for k, v in state.items()}
+    tex_r = torch.nn.Parameter(torch.from_numpy(init.copy()))
+    opt_r = torch.optim.Adam([p for p in st_r.values() if isinstance(p, torch.nn.Parameter)], lr=1e-3)
+    ext_r = torch.optim.RMSprop([tex_r], lr=1e-1)
+    keys = "uv_1d_p1, uv_1d_p1_ds1, uv_1d_p1_ds2, uv_1d_p1_ds3, uv_1d_p1_ds4".replace(' ', '').split(',')
+    for step in range(2):
+        maps = [rng.integers(0, N, (2, 1, H >> l, W >> l)) for l in range(5)]
+        target = torch.from_numpy(rng.random((2, 3, H, W)).astype(np.float32))
+        inputs = {'id': torch.tensor([0, 0])}
+        inputs.update({k: torch.from_numpy(m).float().cuda() for k, m in zip(keys, maps)})
+        out = model(inputs)
+        loss = pipe.criterion(out, target.cuda()) * 1e4
+        loss.backward()
+        pipe.optimizer.step()
+        pipe.optimizer.zero_grad()
+        extra.step()
+        extra.zero_grad()
+        outs = []
+        for b in range(2):
+            feats = [tex_r[:, :, torch.from_numpy(m[b, 0]).long()] for m in maps]
+            outs.append(unet_torch.unet_forward(st_r, *feats[:4]))
+        loss_r = F.huber_loss(torch.cat(outs, 0), target) * 1e4
+        loss_r.backward()
+        opt_r.step(); opt_r.zero_grad(); ext_r.step(); ext_r.zero_grad()
+        assert abs(float(loss) - float(loss_r)) <= 1e-4 * abs(float(loss_r)), (step, float(loss), float(loss_r))
+    _close(tex.state_dict()["texture_"].cpu(), tex_r.detach(), "descriptors after two steps", rtol=1e-3)
+    sd = pipe.net.state_dict()
+    for name in ("feat_extract.0.block.conv_f.weight", "Encoder.3.layers.2.main.0.block.conv_m.weight", "feat_extract.5.block.norm.weight",
+                 "AFFs.1.conv.0.block.conv_f.bias"):
+        _close(sd[name].cpu(), st_r[name].detach(), name, rtol=2e-3)   # Adam divides by sqrt(v): early steps amplify round-off
