@@ -82,7 +82,7 @@ def test_up4_and_huber(hip):
     o_d = out.cuda().requires_grad_(True)
     l_d = huber_loss(o_d, tgt.cuda())
     (1e4 * l_d).backward()
-    assert abs(float(l_d) - float(l_r)) <= 1e-6 * abs(float(l_r))
+    assert abs(float(l_d.detach()) - float(l_r.detach())) <= 1e-6 * abs(float(l_r.detach()))
     _close(o_d.grad, o_r.grad, "huber grad", rtol=1e-6)
 
 
@@ -115,6 +115,9 @@ def test_unet_training_graph_vs_oracle_autograd(hip):
     n = 0
     for name, p in net.named_parameters():
         ref = st_r[name].grad
+        if name.startswith("ConvsOut."):                            # never executed (unet.py:181-186): no gradient on either side
+            assert p.grad is None and ref is None, name
+            continue
         assert p.grad is not None and ref is not None, name
         worst = max(worst, _close(p.grad, ref, name, rtol=2e-4))
         n += 1
