@@ -52,7 +52,7 @@ def parse():
     p.add_argument("--gpus", type=int, default=1)
     p.add_argument("--steps", type=int, default=256, help="timed frames per GPU (default: one full 256-pose sweep)")
     p.add_argument("--warmup", type=int, default=3)
-    p.add_argument("--config", choices=("slab30m", "kitti6_like"), default="slab30m")
+    p.add_argument("--config", choices=("slab30m", "kitti6_like", "train"), default="slab30m")
     p.add_argument("--points", type=int, default=0, help="override the cloud size of the config")
     p.add_argument("--exchange", choices=("all", "root", "none"), default="all",
                    help="N>1: all-gather finished frames to every rank / gather to rank 0 / keep them local")
@@ -251,6 +251,106 @@ class Kitti6LikeWorkload:
 
 
 # ---------------------------------------------------------------------------------------------------------------------
+# BASELINE configs[4]: training iterations/s (train.py --crop_size 256x256, batch_size 2 x inner_batch 4 = 8 crops)
+# ---------------------------------------------------------------------------------------------------------------------
+def run_train(a, dev):
+    """One iteration = what src/train.py:150-265 does per batch with the headless renderer: rasterise 8 cameras x 5 scales
+    (MyRender), look the descriptors up, UNet forward, loss, backward, Adam on the net, RMSprop on the descriptors.  The
+    criterion is the Huber term (x 1e4, train.py:549) only: the VGG term needs downloaded VGG weights (no network)."""
+    from types import SimpleNamespace
+    from read_amd.pipeline import TexturePipeline
+    from read_amd.render import MyRender
+    from read_amd.train import huber_loss
+    N, B, S = a.points or 10_000_000, 8, 256
+    xyz = synthetic.make_street_cloud(N)
+    fmt = "uv_1d_p1, uv_1d_p1_ds1, uv_1d_p1_ds2, uv_1d_p1_ds3, uv_1d_p1_ds4"
+
+    class DS:
+        id, name, input_format, tgt_sh = 0, "kitti6_like", fmt, (S, S)
+        scene_data = {'pointcloud': {'xyz': xyz}}
+        def load(self): pass
+        def unload(self): pass
+
+    class Crit(torch.nn.Module):
+        def forward(self, out, target):
+            return huber_loss(out, target)
+
+    args = SimpleNamespace(inference=False, descriptor_size=8, texture_activation='none', use_mesh=False, supersampling=1,
+                           lr=1e-4, texture_lr=1e-1, texture_ckpt=None, get_datasets=lambda _a: ([DS()], [DS()]),
+                           criterion_module=Crit, criterion_args={}, pipeline='READ.pipelines.ogl.TexturePipeline')
+    pipe = TexturePipeline()
+    pipe.create(args)
+    state = synthetic.make_unet_state(weight_spec())
+    pipe.net.load_state_dict({k: torch.from_numpy(np.asarray(v)) for k, v in state.items()})
+    with torch.no_grad():
+        pipe.textures[0].texture_.copy_(torch.from_numpy(synthetic.make_descriptors(N))[None])
+    model = pipe.model
+    pipe.dataset_load([DS()])
+    model.cuda().eval()                                           # eval_in_train: True (configs/train_example.yaml)
+    extra = pipe.extra_optimizer([DS()])
+    renderer = MyRender([DS()], device_outputs=True)
+    rng = np.random.default_rng(2019)
+    proj = synthetic.make_proj(S, S).astype(np.float32)
+    targets = torch.from_numpy(rng.random((4, B, 3, S, S)).astype(np.float32)).to(dev)
+
+    def step(i):
+        views = np.stack([synthetic.sweep_pose(int(k)) for k in rng.integers(0, N_POSES, B)])
+        data = {'input': {'id': torch.zeros(B, dtype=torch.long)}, 'view_matrix': torch.from_numpy(views),
+                'proj_matrix': torch.from_numpy(np.repeat(proj[None], B, 0))}
+        inputs, _ = renderer.render(data)
+        out = model(inputs)
+        loss = pipe.criterion(out, targets[i % 4]) * 1e4
+        loss.backward()
+        pipe.optimizer.step()
+        pipe.optimizer.zero_grad()
+        extra.step()
+        extra.zero_grad()
+        return loss
+
+    steps, warm = (a.steps if a.steps != 256 else 10), max(a.warmup, 2)
+    for i in range(warm):
+        step(i)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(steps):
+        loss = step(warm + i)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    fwd_flops = 187.06e9 * B                                      # SURVEY.md 8d: conv MACs x 2 at 256x256, measured on the reference module
+    achieved = 3.0 * fwd_flops / (dt / steps) / 1e12               # forward + dgrad + wgrad
+    out = {"metric": "training iterations/sec (8 crops of 256x256 per iteration)", "value": steps / dt, "unit": "iters/s",
+           "n_gpus": 1, "steps": steps, "warmup": warm, "ms_per_step": 1e3 * dt / steps, "higher_is_better": True,
+           "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+           "config": {"workload": f"BASELINE configs[4] stand-in: TexturePipeline training step on a seeded {N}-point street scene, "
+                                  "batch_size 2 x inner_batch 4 = 8 crops of 256x256: MyRender raster (8 cameras x 5 scales) + "
+                                  "gather + UNet forward/backward (HIP autograd nodes) + Huber x 1e4 (no VGG term: weights are a "
+                                  "download) + Adam(net) + sparse RMSprop(descriptors), BatchNorm in eval mode (eval_in_train)",
+                      "points": N, "crop": S, "batch": B, "parallelism": "single GPU (DataParallel of the reference not rebuilt)"},
+           "roofline": {"kernel": "whole step (MFMA convolutions forward + dgrad + wgrad)", "bound": "mfma",
+                        "achieved": achieved, "peak": FP32_MFMA_PEAK_TFS, "unit": "TFLOP/s", "frac": achieved / FP32_MFMA_PEAK_TFS,
+                        "traffic": None, "flops_per_step": 3.0 * fwd_flops,
+                        "note": "3 x the forward convolution FLOPs of 8 crops / wall time of a step (host-side autograd "
+                                "bookkeeping included)"},
+           "final_loss": float(loss.detach()), "tuning": _lib.tuning_state(), "cpu_baseline": None, "verified": None}
+    if not a.no_cpu_baseline:
+        from oracle import unet_torch
+        import torch.nn.functional as Fnn
+        torch.set_num_threads(min(os.cpu_count() or 1, 32))
+        st_r = {k: torch.nn.Parameter(torch.from_numpy(np.asarray(v)).clone()) if (np.asarray(v).dtype == np.float32 and "running" not in k)
+                else torch.from_numpy(np.asarray(v)) for k, v in state.items()}
+        idx = [torch.from_numpy(rng.integers(0, N, (B, S >> l, S >> l))) for l in range(5)]
+        tex_r = torch.nn.Parameter(torch.from_numpy(synthetic.make_descriptors(N))[None])
+        t0 = time.perf_counter()
+        outs = [unet_torch.unet_forward(st_r, *[tex_r[:, :, i[b]] for i in idx[:4]]) for b in range(B)]
+        (Fnn.huber_loss(torch.cat(outs, 0), targets[0].cpu()) * 1e4).backward()
+        t_cpu = time.perf_counter() - t0
+        out["cpu_baseline"] = {"value": 1.0 / t_cpu, "unit": "iters/s", "cores": torch.get_num_threads(), "kind": "port",
+                               "sample": "1 iteration (8 crops): torch-CPU gather + UNet forward/backward + Huber through the oracle; "
+                                         "rasterisation and optimizer steps not included"}
+    print(json.dumps(out), flush=True)
+
+
+# ---------------------------------------------------------------------------------------------------------------------
 # CPU leg: the oracle on this box's host cores (bounded sample) + the frame the GPU result is verified against
 # ---------------------------------------------------------------------------------------------------------------------
 def cpu_leg(wl, frames):
@@ -341,6 +441,10 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", device_id=dev)
 
+    if a.config == "train":
+        assert world == 1, "the training step is single-GPU (the reference's nn.DataParallel is not rebuilt)"
+        run_train(a, dev)
+        return
     wl = (SlabWorkload if a.config == "slab30m" else Kitti6LikeWorkload)(a, dev, rank)
     W, H, N = wl.W, wl.H, wl.N
     ex = sweep.FrameExchange((H, W, 4), dev, torch.float32, None if a.exchange == "none" else a.exchange)

@@ -52,6 +52,30 @@ def _linear_conv(x, cin, wpacked, params, cout, k, stride, out):
     return out
 
 
+# packed copies of a layer's weights, reused by every image of a batch (weights only change at optimizer steps, which bump
+# the parameters' _version): key = id of the conv_f weight -> (versions, params block, forward fragments, dgrad fragments)
+_PACK_CACHE = {}
+
+
+def _packed_for(wf, bf, wm, bm, gamma, beta, mean, var, cin, cout, k):
+    L = _lib.lib()
+    st = _lib.stream_ptr()
+    ver = tuple(t._version for t in (wf, bf, wm, bm, gamma, beta, mean, var)) + (wf.data_ptr(), wm.data_ptr())
+    hit = _PACK_CACHE.get(id(wf))
+    if hit is not None and hit[0] == ver:
+        return hit
+    dev = wf.device
+    params = torch.empty(L.read_conv_param_floats(cout), dtype=torch.float32, device=dev)
+    _lib.check(L.read_conv_pack_params_device(cout, _ptr(bf.detach()), _ptr(bm.detach()), _ptr(gamma.detach()),
+                                              _ptr(beta.detach()), _ptr(mean), _ptr(var), BN_EPS, params.data_ptr(), st))
+    wf_c, wm_c = wf.detach().contiguous(), wm.detach().contiguous()
+    wp = torch.empty(L.read_conv_packed_floats(cin, cout, k), dtype=torch.float32, device=dev)
+    _lib.check(L.read_conv_pack_weights_device(cin, cout, k, _kc_for(cin), wf_c.data_ptr(), wm_c.data_ptr(), wp.data_ptr(), st))
+    entry = [ver, params, wp, None]
+    _PACK_CACHE[id(wf)] = entry
+    return entry
+
+
 class GatedConvFn(torch.autograd.Function):
     """y = BN_eval(act(conv_f(x) + b_f) * sigmoid(conv_m(x) + b_m)) for ONE image, x (H,W,Cin) NHWC -> (Ho,Wo,Cout)."""
 
@@ -66,11 +90,9 @@ class GatedConvFn(torch.autograd.Function):
         Ho, Wo = (H + 2 * pad - k) // stride + 1, (W + 2 * pad - k) // stride + 1
         dev = x.device
         wf_c, wm_c = wf.detach().contiguous(), wm.detach().contiguous()
-        params = torch.empty(L.read_conv_param_floats(cout), dtype=torch.float32, device=dev)
-        _lib.check(L.read_conv_pack_params_device(cout, _ptr(bf.detach()), _ptr(bm.detach()), _ptr(gamma.detach()),
-                                                  _ptr(beta.detach()), _ptr(mean), _ptr(var), BN_EPS, params.data_ptr(), st))
-        wp = torch.empty(L.read_conv_packed_floats(cin, cout, k), dtype=torch.float32, device=dev)
-        _lib.check(L.read_conv_pack_weights_device(cin, cout, k, _kc_for(cin), wf_c.data_ptr(), wm_c.data_ptr(), wp.data_ptr(), st))
+        entry = _packed_for(wf, bf, wm, bm, gamma, beta, mean, var, cin, cout, k)
+        params, wp = entry[1], entry[2]
+        ctx.pack = entry
         fm = torch.empty((Ho, Wo, 2 * cout), dtype=torch.float32, device=dev)
         _linear_conv(x, cin, wp, params, cout, k, stride, fm)
         y = torch.empty((Ho, Wo, cout), dtype=torch.float32, device=dev)
@@ -101,8 +123,11 @@ class GatedConvFn(torch.autograd.Function):
             if stride == 1:
                 # dgrad = the same MFMA convolution over d[f|m] with flipped, transposed weights; the two "gate halves" of
                 # the kernel's output tile are simply the two halves of the input channels
-                wd = torch.empty(L.read_conv_dgrad_packed_floats(cin, cout, k), dtype=torch.float32, device=dev)
-                _lib.check(L.read_conv_pack_dgrad_device(cin, cout, k, 16, wf.data_ptr(), wm.data_ptr(), wd.data_ptr(), st))
+                wd = ctx.pack[3]
+                if wd is None:
+                    wd = torch.empty(L.read_conv_dgrad_packed_floats(cin, cout, k), dtype=torch.float32, device=dev)
+                    _lib.check(L.read_conv_pack_dgrad_device(cin, cout, k, 16, wf.data_ptr(), wm.data_ptr(), wd.data_ptr(), st))
+                    ctx.pack[3] = wd
                 zero = torch.zeros(L.read_conv_param_floats(cin // 2), dtype=torch.float32, device=dev)
                 _linear_conv(dfm, 2 * cp, wd, zero, cin // 2, k, 1, dx)
             else:

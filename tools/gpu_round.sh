@@ -21,6 +21,7 @@ for s in $STEPS; do
             done
             python "$R/tools/splat_kstats.py" "$O"/${TAG}_sp_*/ | tee "$O/${TAG}_splat_kernels.txt"
             run splatstats 300 python tools/splat_cells_probe.py ;;
+    bencht) run bencht 900 python bench.py --config train ;;
     benchk) run benchk 600 python bench.py --config kitti6_like --detail "$O/${TAG}_detailk.json" ;;
     splat)  run splat 400 python tools/splat_modes.py --out "$O/${TAG}_splat_modes.json" ;;
     sweep)  run sweep 400 python tools/sweep_conv.py --out "$O/${TAG}_sweep.json" ;;
