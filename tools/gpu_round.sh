@@ -21,6 +21,26 @@ for s in $STEPS; do
             done
             python "$R/tools/splat_kstats.py" "$O"/${TAG}_sp_*/ | tee "$O/${TAG}_splat_kernels.txt"
             run splatstats 300 python tools/splat_cells_probe.py ;;
+    trainprof) ( cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d "$O/${TAG}_trainprof" -o train -- python "$R/bench.py" --config train --steps 3 --warmup 2 --no-cpu-baseline ) > "$O/${TAG}_trainprof.log" 2>&1; echo "rc=$?" >> "$O/${TAG}_trainprof.log"; tail -n 2 "$O/${TAG}_trainprof.log" | cut -c1-300
+            python - "$O/${TAG}_trainprof" <<'PY'
+import csv, glob, sys
+rows = []
+for f in glob.glob(sys.argv[1] + "/**/*kernel_stats.csv", recursive=True):
+    rows += list(csv.DictReader(open(f)))
+rows.sort(key=lambda r: -float(r["TotalDurationNs"]))
+tot = sum(float(r["TotalDurationNs"]) for r in rows)
+print("total kernel time %.1f ms" % (tot / 1e6))
+for r in rows[:25]:
+    print("%8.2f ms %6s calls %9.1f us avg  %s" % (float(r["TotalDurationNs"]) / 1e6, r["Calls"], float(r["AverageNs"]) / 1e3, r["Name"][:110]))
+PY
+            ;;
+    streetprof) for v in "st_d" "st_n48:splat_near=48" "st_n200:splat_near=200" "st_n3:splat_near=3" "st_sub8:splat_cells_sub=8"; do
+              name=${v%%:*}; knobs=""; [ "$v" != "$name" ] && knobs=${v#*:}
+              ( cd /tmp && SPLAT_PROBE_STATS=0 SPLAT_PROBE_SCENE=street SPLAT_PROBE_H=368 timeout 200 rocprofv3 --kernel-trace --stats --output-format csv -d "$O/${TAG}_sp_$name" -o splat -- python "$R/tools/splat_cells_probe.py" 10000000 $knobs ) > "$O/${TAG}_sp_$name.log" 2>&1
+              grep "ms/frame" "$O/${TAG}_sp_$name.log" | sed "s/^/$name: /"
+            done
+            python "$R/tools/splat_kstats.py" "$O"/${TAG}_sp_st_*/ | tee "$O/${TAG}_street_kernels.txt"
+            ( cd "$R" && SPLAT_PROBE_SCENE=street SPLAT_PROBE_H=368 timeout 200 python tools/splat_cells_probe.py 10000000 ) 2>&1 | tail -14 ;;
     bencht) run bencht 900 python bench.py --config train ;;
     benchk) run benchk 600 python bench.py --config kitti6_like --detail "$O/${TAG}_detailk.json" ;;
     splat)  run splat 400 python tools/splat_modes.py --out "$O/${TAG}_splat_modes.json" ;;

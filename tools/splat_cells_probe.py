@@ -8,7 +8,7 @@ from read_amd import _lib, camera, synthetic
 from read_amd.raster import PointCloudRasterizer
 
 N = int(sys.argv[1]) if len(sys.argv) > 1 else 30_000_000
-W, H = 1216, 352
+W, H = 1216, int(os.environ.get('SPLAT_PROBE_H', '352'))
 L = _lib.lib()
 for kv in sys.argv[2:]:
     k, v = kv.split("=")
