@@ -280,24 +280,26 @@ __global__ __launch_bounds__(64) void wgrad_mfma_kernel(const float *__restrict_
         }
 }
 
-// dW{f|m}[co][ci][tap] (+)= sum over splits of partial[split][tapgroup][tile][t][ci][co']
+// dW{f|m}[co][ci][tap] (+)= sum over splits of partial[split][tapgroup][tile][t][ci][co'].  Threads walk the PARTIAL layout
+// (co' fastest), so the `splits` reads of a thread's element are coalesced across the wave; the one scattered access is the
+// final store.  (Walking the output layout instead cost 94 us per layer: every read of every split was a 4-byte gather.)
 __global__ void wgrad_reduce_kernel(const float *__restrict__ partial, int splits, int tap_groups, int NT, int tiles_ci,
                                     int tiles_co, int Cin, int Cout, int Cp, int taps, float *dwf, float *dwm, int accumulate)
 {
-    const long long total = (long long)2 * Cout * Cin * taps;
     const long long tile_stride = (long long)NT * 1024;
     const long long tiles = (long long)tiles_ci * tiles_co;
-    for (long long o = (long long)blockIdx.x * blockDim.x + threadIdx.x; o < total; o += (long long)gridDim.x * blockDim.x) {
-        const int tap = (int)(o % taps);
-        const int ci = (int)((o / taps) % Cin);
-        const int co = (int)((o / ((long long)taps * Cin)) % Cout);
-        const int half = (int)(o / ((long long)taps * Cin * Cout));
-        const int cp = half * Cp + co;
-        const int tg = tap / NT, t = tap % NT;
-        const long long tile = (long long)(ci / 32) * tiles_co + cp / 32;
+    const long long per_split = (long long)tap_groups * tiles * tile_stride;
+    for (long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x; e < per_split; e += (long long)gridDim.x * blockDim.x) {
+        const int col = (int)(e & 31), row = (int)((e >> 5) & 31);
+        const int t = (int)((e >> 10) % NT);
+        const long long tt = e / tile_stride;                      // tapgroup * tiles + tile
+        const int tile = (int)(tt % tiles), tg = (int)(tt / tiles);
+        const int tap = tg * NT + t;
+        const int ci = (tile / tiles_co) * 32 + row, cp = (tile % tiles_co) * 32 + col;
+        const int half = cp >= Cp ? 1 : 0, co = cp - half * Cp;
+        if (tap >= taps || ci >= Cin || co >= Cout || cp >= 2 * Cp) continue;
         float s = 0.0f;
-        for (int k = 0; k < splits; ++k)
-            s += partial[(((long long)k * tap_groups + tg) * tiles + tile) * tile_stride + (t * 32 + (ci & 31)) * 32 + (cp & 31)];
+        for (int k = 0; k < splits; ++k) s += partial[(long long)k * per_split + e];
         float *dst = (half ? dwm : dwf) + ((long long)co * Cin + ci) * taps + tap;
         *dst = accumulate ? *dst + s : s;
     }
@@ -568,7 +570,7 @@ extern "C" int read_conv_wgrad(const float *x, int inH, int inW, int Cin, const 
     hipLaunchKernelGGL(kern, grid, dim3(64), 0, as_stream(stream), x, inH, inW, Cin, dfm, outH, outW, 2 * Cp, ksize, stride,
                        p.tiles_co, p.rows_per_split, scratch);
     READ_CHECK_LAUNCH();
-    const long long total = (long long)2 * Cout * Cin * ksize * ksize;
+    const long long total = (long long)p.tap_groups * p.tiles_ci * p.tiles_co * p.NT * 1024;
     hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(grid_for(total)), dim3(256), 0, as_stream(stream), (const float *)scratch,
                        p.splits, p.tap_groups, p.NT, p.tiles_ci, p.tiles_co, Cin, Cout, Cp, ksize * ksize, dwf, dwm, accumulate);
     READ_CHECK_LAUNCH();

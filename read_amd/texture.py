@@ -112,6 +112,9 @@ class _GatherRowsFn(torch.autograd.Function):
                                                    _lib.ptr_array([ids.data_ptr()]), counts, _lib.ptr_array([g.data_ptr()]),
                                                    _lib.stream_ptr()), "read_gather_backward")
         m._touched.append(ids.reshape(-1))
+        ev = torch.cuda.Event()                     # the scatter may run on a batch item's own stream (NetAndTexture.forward)
+        ev.record()
+        m._scatter_events.append(ev)
         return None, None, None
 
 
@@ -149,11 +152,13 @@ class PointTexture(Texture):
         self.sparse_training = False        # True: gradients go to grad_rows() + touched ids (SparseDescriptorRMSprop)
         self._grad_rows = None
         self._touched = []
+        self._scatter_events = []
         self._rows_newer = False            # the rows were stepped by the sparse optimizer; texture_ is stale until synced
 
     def null_grad(self):
         self.texture_.grad = None
         self._touched = []
+        self._scatter_events = []
 
     # ---- sparse training state ---------------------------------------------------------------------------------------
     def training_rows(self):
@@ -168,6 +173,10 @@ class PointTexture(Texture):
     def take_touched(self):
         if not self._touched:
             return None
+        cur = torch.cuda.current_stream()
+        for ev in self._scatter_events:             # gradient rows written on other streams must have landed
+            cur.wait_event(ev)
+        self._scatter_events = []
         ids = torch.cat(self._touched).contiguous()
         self._touched = []
         return ids

@@ -63,6 +63,10 @@ def _packed_for(wf, bf, wm, bm, gamma, beta, mean, var, cin, cout, k):
     ver = tuple(t._version for t in (wf, bf, wm, bm, gamma, beta, mean, var)) + (wf.data_ptr(), wm.data_ptr())
     hit = _PACK_CACHE.get(id(wf))
     if hit is not None and hit[0] == ver:
+        cur = torch.cuda.current_stream()
+        cur.wait_event(hit[4])                              # packed on another item's stream
+        hit[1].record_stream(cur)
+        hit[2].record_stream(cur)
         return hit
     dev = wf.device
     params = torch.empty(L.read_conv_param_floats(cout), dtype=torch.float32, device=dev)
@@ -71,7 +75,9 @@ def _packed_for(wf, bf, wm, bm, gamma, beta, mean, var, cin, cout, k):
     wf_c, wm_c = wf.detach().contiguous(), wm.detach().contiguous()
     wp = torch.empty(L.read_conv_packed_floats(cin, cout, k), dtype=torch.float32, device=dev)
     _lib.check(L.read_conv_pack_weights_device(cin, cout, k, _kc_for(cin), wf_c.data_ptr(), wm_c.data_ptr(), wp.data_ptr(), st))
-    entry = [ver, params, wp, None]
+    ev = torch.cuda.Event()
+    ev.record()
+    entry = [ver, params, wp, None, ev]
     _PACK_CACHE[id(wf)] = entry
     return entry
 
@@ -127,7 +133,13 @@ class GatedConvFn(torch.autograd.Function):
                 if wd is None:
                     wd = torch.empty(L.read_conv_dgrad_packed_floats(cin, cout, k), dtype=torch.float32, device=dev)
                     _lib.check(L.read_conv_pack_dgrad_device(cin, cout, k, 16, wf.data_ptr(), wm.data_ptr(), wd.data_ptr(), st))
-                    ctx.pack[3] = wd
+                    ev = torch.cuda.Event()
+                    ev.record()
+                    ctx.pack[3] = (wd, ev)
+                else:
+                    wd, ev = wd
+                    torch.cuda.current_stream().wait_event(ev)
+                    wd.record_stream(torch.cuda.current_stream())
                 zero = torch.zeros(L.read_conv_param_floats(cin // 2), dtype=torch.float32, device=dev)
                 _linear_conv(dfm, 2 * cp, wd, zero, cin // 2, k, 1, dx)
             else:
