@@ -251,10 +251,14 @@ int read_conv_pack_weights_device(int Cin, int Cout, int ksize, int kc, const fl
 size_t read_conv_dgrad_packed_floats(int Cin, int Cout, int ksize);
 int read_conv_pack_dgrad_device(int Cin, int Cout, int ksize, int kc, const float *wf, const float *wm, float *wpacked,
                                 void *stream);
+/* A training batch is ONE tall image: the items stacked vertically, block_h rows per item of which the first valid_h are
+ * the item and the rest a separator that stays zero in every activation — it is the zero padding between neighbours, so the
+ * convolutions need no batch dimension and one launch covers the batch.  The gate kernels keep the separators zero (forward)
+ * and give them zero gradient (backward); W = row length in pixels; block_h = 0 means a single image. */
 int read_gate_forward(const float *fm, int64_t pixels, int Cout, const float *params, int elu, const float *residual,
-                      float *y, void *stream);
+                      float *y, int W, int block_h, int valid_h, void *stream);
 int read_gate_backward(const float *dy, const float *fm, int64_t pixels, int Cout, const float *params, int elu, float *dfm,
-                       float *sums, void *stream);
+                       float *sums, int W, int block_h, int valid_h, void *stream);
 int read_bn_param_grads(int Cout, const float *sums, const float *mean, const float *var, float eps, float *dbf, float *dbm,
                         float *dgamma, float *dbeta, void *stream);
 size_t read_conv_dgrad_generic_floats(int Cin, int Cout, int ksize);
@@ -263,8 +267,10 @@ int read_conv_dgrad_generic(const float *dfm, int outH, int outW, int Cin, int C
 size_t read_conv_wgrad_scratch_floats(int Cin, int Cout, int ksize, int outH);
 int read_conv_wgrad(const float *x, int inH, int inW, int Cin, const float *dfm, int Cout, int ksize, int stride, float *dwf,
                     float *dwm, int accumulate, float *scratch, size_t scratch_floats, void *stream);
-/* adjoint of read_bilinear_up4: dout [4*inH][4*inW][C] -> din [inH][inW][C] */
-int read_bilinear_up4_backward(const float *dout, int inH, int inW, int C, float *din, void *stream);
+/* read_bilinear_up4 for a vertically stacked batch (rows interpolate inside an item only) and the adjoint of both:
+ * dout [4*inH][4*inW][C] -> din [inH][inW][C] */
+int read_bilinear_up4_blocks(const float *in, int inH, int inW, int C, float *out, int block_h, int valid_h, void *stream);
+int read_bilinear_up4_backward(const float *dout, int inH, int inW, int C, float *din, int block_h, int valid_h, void *stream);
 /* F.huber_loss(out, target) (delta 1, mean; src/READ/models/compose.py:35,38): *loss_sum = sum of the per-element losses
  * (divide by n), grad[i] = grad_scale * clip(out - target, -1, 1).  Either output may be NULL. */
 int read_huber_loss(const float *out, const float *target, int64_t n, float grad_scale, float *loss_sum, float *grad,

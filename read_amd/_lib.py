@@ -78,14 +78,15 @@ SIGNATURES = {
     "read_conv_pack_weights_device": (_i, [_i, _i, _i, _i, _vp, _vp, _vp, _vp]),
     "read_conv_dgrad_packed_floats": (_sz, [_i, _i, _i]),
     "read_conv_pack_dgrad_device": (_i, [_i, _i, _i, _i, _vp, _vp, _vp, _vp]),
-    "read_gate_forward": (_i, [_vp, _i64, _i, _vp, _i, _vp, _vp, _vp]),
-    "read_gate_backward": (_i, [_vp, _vp, _i64, _i, _vp, _i, _vp, _vp, _vp]),
+    "read_gate_forward": (_i, [_vp, _i64, _i, _vp, _i, _vp, _vp, _i, _i, _i, _vp]),
+    "read_gate_backward": (_i, [_vp, _vp, _i64, _i, _vp, _i, _vp, _vp, _i, _i, _i, _vp]),
     "read_bn_param_grads": (_i, [_i, _vp, _vp, _vp, _f, _vp, _vp, _vp, _vp, _vp]),
     "read_conv_dgrad_generic_floats": (_sz, [_i, _i, _i]),
     "read_conv_dgrad_generic": (_i, [_vp, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp, _i, _i, _vp, _vp]),
     "read_conv_wgrad_scratch_floats": (_sz, [_i, _i, _i, _i]),
     "read_conv_wgrad": (_i, [_vp, _i, _i, _i, _vp, _i, _i, _i, _vp, _vp, _i, _vp, _sz, _vp]),
-    "read_bilinear_up4_backward": (_i, [_vp, _i, _i, _i, _vp, _vp]),
+    "read_bilinear_up4_blocks": (_i, [_vp, _i, _i, _i, _vp, _i, _i, _vp]),
+    "read_bilinear_up4_backward": (_i, [_vp, _i, _i, _i, _vp, _i, _i, _vp]),
     "read_huber_loss": (_i, [_vp, _vp, _i64, _f, _vp, _vp, _vp]),
     "read_rmsprop_sparse": (_i, [_vp, _vp, _vp, _vp, _i, _i64, _vp, _i64, _i, _f, _f, _f, _vp]),
     "read_unet_layer_count": (_i, []),

@@ -96,14 +96,27 @@ __global__ void pack_dgrad_generic_kernel(int Cin, int Cout, int taps, int Cp, c
 // gate forward / backward (elementwise over pixels x channels)
 // ---------------------------------------------------------------------------------------------------------------------
 // fm: [pixels][2*Cout] = f (bias included) | m;  y = (act(f) * sigmoid(m)) * scale + shift (+ residual)
+// Batches are stacked vertically into one tall image, `block_h` rows per item of which the first `valid_h` are the item and
+// the rest a separator that must stay ZERO in every activation (it is the zero padding between neighbours): rows with
+// (row % block_h) >= valid_h are written as 0 here and get zero gradient in gate_backward_kernel.  block_h = 0: no blocks.
+__device__ __forceinline__ bool separator_row(long long pixel, int W, int block_h, int valid_h)
+{
+    return block_h > 0 && (int)((pixel / W) % block_h) >= valid_h;
+}
+
 __global__ __launch_bounds__(256) void gate_forward_kernel(const float *__restrict__ fm, long long pixels, int Cout, int CoutPad,
                                                            const float *__restrict__ params, int elu,
-                                                           const float *__restrict__ residual, float *__restrict__ y)
+                                                           const float *__restrict__ residual, float *__restrict__ y, int W,
+                                                           int block_h, int valid_h)
 {
     const long long total = pixels * Cout;
     for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
         const long long p = i / Cout;
         const int c = (int)(i - p * Cout);
+        if (separator_row(p, W, block_h, valid_h)) {
+            y[i] = 0.0f;
+            continue;
+        }
         float f = fm[p * 2 * Cout + c];
         const float m = fm[p * 2 * Cout + Cout + c];
         if (elu) f = f > 0.0f ? f : fast_exp(f) - 1.0f;
@@ -122,7 +135,8 @@ template <int CW>
 __global__ __launch_bounds__(256) void gate_backward_kernel(const float *__restrict__ dy, const float *__restrict__ fm,
                                                             long long pixels, int Cout, int CoutPad, int Cp,
                                                             const float *__restrict__ params, int elu,
-                                                            float *__restrict__ dfm, float *__restrict__ sums)
+                                                            float *__restrict__ dfm, float *__restrict__ sums, int W, int block_h,
+                                                            int valid_h)
 {
     constexpr int ROWS = 256 / CW;                       // pixels handled concurrently by a workgroup
     __shared__ float red[4][256];
@@ -134,7 +148,7 @@ __global__ __launch_bounds__(256) void gate_backward_kernel(const float *__restr
         float s_df = 0.f, s_dm = 0.f, s_dy = 0.f, s_dyg = 0.f;
         for (long long p = (long long)blockIdx.x * ROWS + r; p < pixels; p += (long long)gridDim.x * ROWS) {
             float df = 0.f, dm = 0.f;
-            if (ok) {
+            if (ok && !separator_row(p, W, block_h, valid_h)) {
                 const float f = fm[p * 2 * Cout + c], m = fm[p * 2 * Cout + Cout + c];
                 const float g = dy[p * Cout + c];
                 const float a = elu ? (f > 0.0f ? f : fast_exp(f) - 1.0f) : f;
@@ -299,7 +313,13 @@ __global__ void wgrad_reduce_kernel(const float *__restrict__ partial, int split
         const int half = cp >= Cp ? 1 : 0, co = cp - half * Cp;
         if (tap >= taps || ci >= Cin || co >= Cout || cp >= 2 * Cp) continue;
         float s = 0.0f;
-        for (int k = 0; k < splits; ++k) s += partial[(long long)k * per_split + e];
+        int k = 0;
+        for (; k + 4 <= splits; k += 4) {
+            const float a0 = partial[(long long)k * per_split + e], a1 = partial[(long long)(k + 1) * per_split + e];
+            const float a2 = partial[(long long)(k + 2) * per_split + e], a3 = partial[(long long)(k + 3) * per_split + e];
+            s += (a0 + a1) + (a2 + a3);
+        }
+        for (; k < splits; ++k) s += partial[(long long)k * per_split + e];
         float *dst = (half ? dwm : dwf) + ((long long)co * Cin + ci) * taps + tap;
         *dst = accumulate ? *dst + s : s;
     }
@@ -318,36 +338,76 @@ __device__ __forceinline__ void up4_src(int o, int n_in, int &i0, int &i1, float
     l1 = s - (float)i0;
 }
 
-__global__ __launch_bounds__(256) void bilinear_up4_backward_kernel(const float *__restrict__ dout, int inH, int inW, int C,
-                                                                    float *__restrict__ din)
+// Vertically stacked batch: rows are interpolated INSIDE an item (block_h input rows per item, the first valid_h valid),
+// exactly as nn.Upsample treats separate images; separator rows of the output are zero.  block_h = 0: one image.
+__global__ __launch_bounds__(256) void bilinear_up4_blocks_kernel(const float *__restrict__ in, int inH, int inW, int C,
+                                                                  float *__restrict__ out, int block_h, int valid_h)
 {
-    const int outH = inH * 4, outW = inW * 4, q4 = C >> 2;
+    const int outW = inW * 4, q4 = C >> 2;
+    const int bh = block_h > 0 ? block_h : inH, vh = block_h > 0 ? valid_h : inH;
+    const long long total = (long long)inH * 4 * outW * q4;
+    for (long long item = (long long)blockIdx.x * blockDim.x + threadIdx.x; item < total;
+         item += (long long)gridDim.x * blockDim.x) {
+        const int q = (int)(item % q4);
+        const long long pix = item / q4;
+        const int ox = (int)(pix % outW), oy = (int)(pix / outW);
+        const int blk = oy / (4 * bh), oyl = oy - blk * 4 * bh;
+        float4 o = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (oyl < 4 * vh) {
+            int y0, y1, x0, x1;
+            float ly1, lx1;
+            up4_src(oyl, vh, y0, y1, ly1);
+            up4_src(ox, inW, x0, x1, lx1);
+            const float ly0 = 1.f - ly1, lx0 = 1.f - lx1;
+            const float *base = in + (long long)blk * bh * inW * C + 4 * q;
+            const float4 v00 = *reinterpret_cast<const float4 *>(base + ((long long)y0 * inW + x0) * C);
+            const float4 v01 = *reinterpret_cast<const float4 *>(base + ((long long)y0 * inW + x1) * C);
+            const float4 v10 = *reinterpret_cast<const float4 *>(base + ((long long)y1 * inW + x0) * C);
+            const float4 v11 = *reinterpret_cast<const float4 *>(base + ((long long)y1 * inW + x1) * C);
+            o.x = ly0 * (lx0 * v00.x + lx1 * v01.x) + ly1 * (lx0 * v10.x + lx1 * v11.x);
+            o.y = ly0 * (lx0 * v00.y + lx1 * v01.y) + ly1 * (lx0 * v10.y + lx1 * v11.y);
+            o.z = ly0 * (lx0 * v00.z + lx1 * v01.z) + ly1 * (lx0 * v10.z + lx1 * v11.z);
+            o.w = ly0 * (lx0 * v00.w + lx1 * v01.w) + ly1 * (lx0 * v10.w + lx1 * v11.w);
+        }
+        *reinterpret_cast<float4 *>(out + pix * C + 4 * q) = o;
+    }
+}
+
+__global__ __launch_bounds__(256) void bilinear_up4_backward_kernel(const float *__restrict__ dout, int inH, int inW, int C,
+                                                                    float *__restrict__ din, int block_h, int valid_h)
+{
+    const int outW = inW * 4, q4 = C >> 2;
+    const int bh = block_h > 0 ? block_h : inH, vh = block_h > 0 ? valid_h : inH;
     const long long total = (long long)inH * inW * q4;
     for (long long item = (long long)blockIdx.x * blockDim.x + threadIdx.x; item < total;
          item += (long long)gridDim.x * blockDim.x) {
         const int q = (int)(item % q4);
         const long long pix = item / q4;
-        const int x = (int)(pix % inW), y = (int)(pix / inW);
+        const int x = (int)(pix % inW), yg = (int)(pix / inW);
+        const int blk = yg / bh, y = yg - blk * bh;
         float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
-        // output rows whose source interval [i0, i1] contains y lie within 4y-4 .. 4y+5 (borders: clamped sources)
-        for (int oy = max(0, 4 * y - 4); oy <= min(outH - 1, 4 * y + 5); ++oy) {
-            int y0, y1;
-            float ly1;
-            up4_src(oy, inH, y0, y1, ly1);
-            const float wy = (y0 == y ? 1.f - ly1 : 0.f) + (y1 == y ? ly1 : 0.f);
-            if (wy == 0.f) continue;
-            for (int ox = max(0, 4 * x - 4); ox <= min(outW - 1, 4 * x + 5); ++ox) {
-                int x0, x1;
-                float lx1;
-                up4_src(ox, inW, x0, x1, lx1);
-                const float wx = (x0 == x ? 1.f - lx1 : 0.f) + (x1 == x ? lx1 : 0.f);
-                if (wx == 0.f) continue;
-                const float4 g = *reinterpret_cast<const float4 *>(dout + ((long long)oy * outW + ox) * C + 4 * q);
-                const float w = wy * wx;
-                acc.x += w * g.x;
-                acc.y += w * g.y;
-                acc.z += w * g.z;
-                acc.w += w * g.w;
+        if (y < vh) {
+            const float *base = dout + (long long)blk * 4 * bh * outW * C + 4 * q;
+            // output rows whose source interval [i0, i1] contains y lie within 4y-4 .. 4y+5 (borders: clamped sources)
+            for (int oy = max(0, 4 * y - 4); oy <= min(4 * vh - 1, 4 * y + 5); ++oy) {
+                int y0, y1;
+                float ly1;
+                up4_src(oy, vh, y0, y1, ly1);
+                const float wy = (y0 == y ? 1.f - ly1 : 0.f) + (y1 == y ? ly1 : 0.f);
+                if (wy == 0.f) continue;
+                for (int ox = max(0, 4 * x - 4); ox <= min(outW - 1, 4 * x + 5); ++ox) {
+                    int x0, x1;
+                    float lx1;
+                    up4_src(ox, inW, x0, x1, lx1);
+                    const float wx = (x0 == x ? 1.f - lx1 : 0.f) + (x1 == x ? lx1 : 0.f);
+                    if (wx == 0.f) continue;
+                    const float4 g = *reinterpret_cast<const float4 *>(base + ((long long)oy * outW + ox) * C);
+                    const float w = wy * wx;
+                    acc.x += w * g.x;
+                    acc.y += w * g.y;
+                    acc.z += w * g.z;
+                    acc.w += w * g.w;
+                }
             }
         }
         *reinterpret_cast<float4 *>(din + pix * C + 4 * q) = acc;
@@ -460,29 +520,32 @@ extern "C" int read_conv_pack_dgrad_device(int Cin, int Cout, int ksize, int kc,
 }
 
 extern "C" int read_gate_forward(const float *fm, int64_t pixels, int Cout, const float *params, int elu,
-                                 const float *residual, float *y, void *stream)
+                                 const float *residual, float *y, int W, int block_h, int valid_h, void *stream)
 {
     READ_CHECK_ARG(fm && params && y && pixels >= 1 && Cout >= 1, "read_gate_forward: null pointer or empty tensor");
+    READ_CHECK_ARG(block_h == 0 || (W >= 1 && valid_h >= 1 && valid_h <= block_h), "read_gate_forward: bad block geometry");
     hipLaunchKernelGGL(gate_forward_kernel, dim3(grid_for(pixels * Cout)), dim3(256), 0, as_stream(stream), fm,
-                       (long long)pixels, Cout, (Cout + 31) / 32 * 32, params, elu, residual, y);
+                       (long long)pixels, Cout, (Cout + 31) / 32 * 32, params, elu, residual, y, W > 0 ? W : 1, block_h, valid_h);
     READ_CHECK_LAUNCH();
     return READ_OK;
 }
 
 extern "C" int read_gate_backward(const float *dy, const float *fm, int64_t pixels, int Cout, const float *params, int elu,
-                                  float *dfm, float *sums, void *stream)
+                                  float *dfm, float *sums, int W, int block_h, int valid_h, void *stream)
 {
     READ_CHECK_ARG(dy && fm && params && dfm && sums && pixels >= 1 && Cout >= 1, "read_gate_backward: null pointer or empty tensor");
+    READ_CHECK_ARG(block_h == 0 || (W >= 1 && valid_h >= 1 && valid_h <= block_h), "read_gate_backward: bad block geometry");
+    if (W < 1) W = 1;
     const int Cp = (Cout + 7) / 8 * 8, CoutPad = (Cout + 31) / 32 * 32;
     READ_CHECK_HIP(hipMemsetAsync(sums, 0, sizeof(float) * 4 * (size_t)Cout, as_stream(stream)));
     if (Cp <= 8) {
         const int blocks = grid_for(pixels, 32, 2048);
         hipLaunchKernelGGL(gate_backward_kernel<8>, dim3(blocks), dim3(256), 0, as_stream(stream), dy, fm, (long long)pixels, Cout,
-                           CoutPad, Cp, params, elu, dfm, sums);
+                           CoutPad, Cp, params, elu, dfm, sums, W, block_h, valid_h);
     } else {
         const int blocks = grid_for(pixels, 8, 2048);
         hipLaunchKernelGGL(gate_backward_kernel<32>, dim3(blocks), dim3(256), 0, as_stream(stream), dy, fm, (long long)pixels, Cout,
-                           CoutPad, Cp, params, elu, dfm, sums);
+                           CoutPad, Cp, params, elu, dfm, sums, W, block_h, valid_h);
     }
     READ_CHECK_LAUNCH();
     return READ_OK;
@@ -538,7 +601,7 @@ WgradPlan wgrad_plan(int Cin, int Cout, int ksize, int outH)
     p.tiles_ci = (Cin + 31) / 32;
     p.tiles_co = (2 * Cp + 31) / 32;
     const int waves = p.tiles_ci * p.tiles_co * p.tap_groups;
-    int splits = (4096 + waves - 1) / waves;                    // ~4 waves per SIMD over the chip
+    int splits = (2048 + waves - 1) / waves;                    // ~2 waves per SIMD over the chip
     if (splits > outH) splits = outH;
     if (splits < 1) splits = 1;
     p.rows_per_split = (outH + splits - 1) / splits;
@@ -577,12 +640,26 @@ extern "C" int read_conv_wgrad(const float *x, int inH, int inW, int Cin, const 
     return READ_OK;
 }
 
-extern "C" int read_bilinear_up4_backward(const float *dout, int inH, int inW, int C, float *din, void *stream)
+extern "C" int read_bilinear_up4_blocks(const float *in, int inH, int inW, int C, float *out, int block_h, int valid_h,
+                                        void *stream)
+{
+    READ_CHECK_ARG(in && out && inH >= 1 && inW >= 1, "read_bilinear_up4_blocks: null pointer or empty input");
+    READ_CHECK_ARG(C >= 4 && C % 4 == 0, "read_bilinear_up4_blocks: C must be a multiple of 4");
+    READ_CHECK_ARG(block_h == 0 || (valid_h >= 1 && valid_h <= block_h && inH % block_h == 0), "read_bilinear_up4_blocks: bad block geometry");
+    hipLaunchKernelGGL(bilinear_up4_blocks_kernel, dim3(grid_for((long long)inH * 4 * inW * 4 * (C / 4))), dim3(256), 0,
+                       as_stream(stream), in, inH, inW, C, out, block_h, valid_h);
+    READ_CHECK_LAUNCH();
+    return READ_OK;
+}
+
+extern "C" int read_bilinear_up4_backward(const float *dout, int inH, int inW, int C, float *din, int block_h, int valid_h,
+                                          void *stream)
 {
     READ_CHECK_ARG(dout && din && inH >= 1 && inW >= 1, "read_bilinear_up4_backward: null pointer or empty input");
     READ_CHECK_ARG(C >= 4 && C % 4 == 0, "read_bilinear_up4_backward: C must be a multiple of 4");
+    READ_CHECK_ARG(block_h == 0 || (valid_h >= 1 && valid_h <= block_h && inH % block_h == 0), "read_bilinear_up4_backward: bad block geometry");
     hipLaunchKernelGGL(bilinear_up4_backward_kernel, dim3(grid_for((long long)inH * inW * (C / 4))), dim3(256), 0,
-                       as_stream(stream), dout, inH, inW, C, din);
+                       as_stream(stream), dout, inH, inW, C, din, block_h, valid_h);
     READ_CHECK_LAUNCH();
     return READ_OK;
 }

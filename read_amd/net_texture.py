@@ -39,13 +39,7 @@ class NetAndTexture(nn.Module):
                 textures = {0: textures}
         self._textures = {tid: tex.cpu() for tid, tex in textures.items()}
         self._loaded_textures = []
-        self.item_streams = 8            # HIP streams over which the items of a training batch are spread (1 = off)
-        self._stream_pool = []
 
-    def _streams(self, n):
-        while len(self._stream_pool) < n:
-            self._stream_pool.append(torch.cuda.Stream())
-        return self._stream_pool[:n]
 
     # ---- texture residency -------------------------------------------------------------------
     def load_textures(self, texture_ids):
@@ -92,33 +86,22 @@ class NetAndTexture(nn.Module):
     def forward(self, inputs, **kwargs):
         texture_ids = _as_id_list(inputs.pop('id'))            # the caller's dict loses 'id', as in the reference
         frames, net_input = [], None
-        # Training: the items of a batch are independent graphs of small launches (one 256x256 crop fills a fraction of
-        # the chip), so each item runs on its own HIP stream — forward here, and backward too, because autograd replays a
-        # node on the stream its forward ran on.  Inference keeps the caller's stream.
-        first = next(iter(inputs.values()))
-        par = (torch.is_grad_enabled() and len(texture_ids) > 1 and torch.is_tensor(first) and first.is_cuda
-               and not self.temporal_average and self.item_streams > 1)
-        cur = torch.cuda.current_stream() if par else None
-        streams = self._streams(min(self.item_streams, len(texture_ids))) if par else None
+        if torch.is_grad_enabled() and len(texture_ids) > 1 and not self.temporal_average:
+            # training: sample every item (each may use its own texture), then ONE network call for the batch — the HIP
+            # training graph stacks the items into a single tall image (read_amd/train.py), so a 256x256 crop does not
+            # leave most of the chip idle; the per-item results are the same as item-by-item calls
+            per_item = [self._sample_item(self._modules[str(tid)], {k: v[b][None] for k, v in inputs.items()})
+                        for b, tid in enumerate(texture_ids)]
+            net_input = [torch.cat([it[l] for it in per_item], 0) for l in range(len(per_item[0]))]
+            out = self.net(*net_input, **kwargs)
+            return (out, net_input) if kwargs.get('return_input') else out
         for b, tid in enumerate(texture_ids):
             texture = self._modules[str(tid)]
-            if par:
-                s = streams[b % len(streams)]
-                s.wait_stream(cur)
-                with torch.cuda.stream(s):
-                    net_input = self._sample_item(texture, {k: v[b][None] for k, v in inputs.items()})
-                    frames.append(self.net(*net_input, **kwargs))
-                continue
             net_input = self._sample_item(texture, {k: v[b][None] for k, v in inputs.items()})
             if self.temporal_average:
                 if self.last_input is not None:
-                    net_input = [(cur_ + prev) / 2 for cur_, prev in zip(net_input, self.last_input)]
+                    net_input = [(cur + prev) / 2 for cur, prev in zip(net_input, self.last_input)]
                 self.last_input = list(net_input)
             frames.append(self.net(*net_input, **kwargs))
-        if par:
-            for s in streams:
-                cur.wait_stream(s)
-            for f in frames:
-                f.record_stream(cur)
         out = torch.cat(frames, 0)
         return (out, net_input) if kwargs.get('return_input') else out

@@ -86,7 +86,7 @@ class GatedConvFn(torch.autograd.Function):
     """y = BN_eval(act(conv_f(x) + b_f) * sigmoid(conv_m(x) + b_m)) for ONE image, x (H,W,Cin) NHWC -> (Ho,Wo,Cout)."""
 
     @staticmethod
-    def forward(ctx, x, wf, bf, wm, bm, gamma, beta, mean, var, k, stride, elu):
+    def forward(ctx, x, wf, bf, wm, bm, gamma, beta, mean, var, k, stride, elu, nb=1, v_num=1, v_den=1):
         L = _lib.lib()
         st = _lib.stream_ptr()
         x = x.contiguous()
@@ -102,9 +102,12 @@ class GatedConvFn(torch.autograd.Function):
         fm = torch.empty((Ho, Wo, 2 * cout), dtype=torch.float32, device=dev)
         _linear_conv(x, cin, wp, params, cout, k, stride, fm)
         y = torch.empty((Ho, Wo, cout), dtype=torch.float32, device=dev)
-        _lib.check(L.read_gate_forward(fm.data_ptr(), Ho * Wo, cout, params.data_ptr(), int(elu), None, y.data_ptr(), st))
+        # a batch is one tall image of nb stacked items; separator rows (block geometry at THIS layer's output scale) stay zero
+        bh = Ho // nb if nb > 1 else 0
+        vh = bh * v_num // v_den
+        _lib.check(L.read_gate_forward(fm.data_ptr(), Ho * Wo, cout, params.data_ptr(), int(elu), None, y.data_ptr(), Wo, bh, vh, st))
         ctx.save_for_backward(x, fm, params, wf_c, wm_c, mean, var)
-        ctx.cfg = (k, stride, int(elu), H, W, cin, cout, Ho, Wo)
+        ctx.cfg = (k, stride, int(elu), H, W, cin, cout, Ho, Wo, bh, vh)
         return y
 
     @staticmethod
@@ -112,14 +115,14 @@ class GatedConvFn(torch.autograd.Function):
         L = _lib.lib()
         st = _lib.stream_ptr()
         x, fm, params, wf, wm, mean, var = ctx.saved_tensors
-        k, stride, elu, H, W, cin, cout, Ho, Wo = ctx.cfg
+        k, stride, elu, H, W, cin, cout, Ho, Wo, bh, vh = ctx.cfg
         dev = x.device
         dy = dy.contiguous()
         cp = (cout + 7) // 8 * 8
         dfm = torch.empty((Ho, Wo, 2 * cp), dtype=torch.float32, device=dev)
         sums = torch.empty((4, cout), dtype=torch.float32, device=dev)
         _lib.check(L.read_gate_backward(dy.data_ptr(), fm.data_ptr(), Ho * Wo, cout, params.data_ptr(), elu, dfm.data_ptr(),
-                                        sums.data_ptr(), st))
+                                        sums.data_ptr(), Wo, bh, vh, st))
         dbf, dbm, dgamma, dbeta = (torch.zeros(cout, dtype=torch.float32, device=dev) for _ in range(4))
         _lib.check(L.read_bn_param_grads(cout, sums.data_ptr(), mean.data_ptr(), var.data_ptr(), BN_EPS, dbf.data_ptr(),
                                          dbm.data_ptr(), dgamma.data_ptr(), dbeta.data_ptr(), st))
@@ -151,28 +154,31 @@ class GatedConvFn(torch.autograd.Function):
         scratch = torch.empty(n_scr, dtype=torch.float32, device=dev)
         _lib.check(L.read_conv_wgrad(x.data_ptr(), H, W, cin, dfm.data_ptr(), cout, k, stride, dwf.data_ptr(), dwm.data_ptr(), 0,
                                      scratch.data_ptr(), n_scr, st))
-        return dx, dwf, dbf, dwm, dbm, dgamma, dbeta, None, None, None, None, None
+        return dx, dwf, dbf, dwm, dbm, dgamma, dbeta, None, None, None, None, None, None, None, None
 
 
 class Up4Fn(torch.autograd.Function):
-    """nn.Upsample(scale_factor=4, mode='bilinear') (unet.py:200) on an (H,W,C) NHWC image, and its adjoint."""
+    """nn.Upsample(scale_factor=4, mode='bilinear') (unet.py:200) on an (H,W,C) NHWC image — or on nb vertically stacked
+    items, each interpolated on its own — and its adjoint."""
 
     @staticmethod
-    def forward(ctx, x):
+    def forward(ctx, x, nb=1, v_num=1, v_den=1):
         x = x.contiguous()
         H, W, c = (int(v) for v in x.shape)
+        bh = H // nb if nb > 1 else 0
+        vh = bh * v_num // v_den
         out = torch.empty((4 * H, 4 * W, c), dtype=torch.float32, device=x.device)
-        _lib.check(_lib.lib().read_bilinear_up4(x.data_ptr(), H, W, c, out.data_ptr(), _lib.stream_ptr()))
-        ctx.shape = (H, W, c)
+        _lib.check(_lib.lib().read_bilinear_up4_blocks(x.data_ptr(), H, W, c, out.data_ptr(), bh, vh, _lib.stream_ptr()))
+        ctx.shape = (H, W, c, bh, vh)
         return out
 
     @staticmethod
     def backward(ctx, dout):
-        H, W, c = ctx.shape
+        H, W, c, bh, vh = ctx.shape
         dout = dout.contiguous()
         din = torch.empty((H, W, c), dtype=torch.float32, device=dout.device)
-        _lib.check(_lib.lib().read_bilinear_up4_backward(dout.data_ptr(), H, W, c, din.data_ptr(), _lib.stream_ptr()))
-        return din
+        _lib.check(_lib.lib().read_bilinear_up4_backward(dout.data_ptr(), H, W, c, din.data_ptr(), bh, vh, _lib.stream_ptr()))
+        return din, None, None, None
 
 
 class _HuberFn(torch.autograd.Function):
@@ -201,29 +207,29 @@ def huber_loss(out, target):
 # -----------------------------------------------------------------------------------------------------------------------
 # the UNet graph in training mode (READ/models/unet.py:202-285), one image, NHWC
 # -----------------------------------------------------------------------------------------------------------------------
-def _bc(net, path, x, k, stride=1, elu=True):
+def _bc(net, path, x, k, stride=1, elu=True, blk=(1, 1, 1)):
     node = net
     for p in path.split('.'):
         node = node._modules[p]
     b = node.block
     n = b['norm']
     return GatedConvFn.apply(x, b['conv_f'].weight, b['conv_f'].bias, b['conv_m'].weight, b['conv_m'].bias, n.weight, n.bias,
-                             n.running_mean, n.running_var, k, stride, elu)
+                             n.running_mean, n.running_var, k, stride, elu, *blk)
 
 
-def _res_blocks(net, prefix, x):
+def _res_blocks(net, prefix, x, blk):
     for j in range(4):
         p = f"{prefix}.layers.{j}.main."
-        x = _bc(net, p + "1", _bc(net, p + "0", x, 3), 3, elu=False) + x
+        x = _bc(net, p + "1", _bc(net, p + "0", x, 3, blk=blk), 3, elu=False, blk=blk) + x
     return x
 
 
-def _scm(net, name, x):
-    y = _bc(net, name + ".main.0", x, 3)
-    y = _bc(net, name + ".main.1", y, 1)
-    y = _bc(net, name + ".main.2", y, 3)
-    y = _bc(net, name + ".main.3", y, 1)
-    return _bc(net, name + ".conv", torch.cat([x, y], -1), 1, elu=False)
+def _scm(net, name, x, blk):
+    y = _bc(net, name + ".main.0", x, 3, blk=blk)
+    y = _bc(net, name + ".main.1", y, 1, blk=blk)
+    y = _bc(net, name + ".main.2", y, 3, blk=blk)
+    y = _bc(net, name + ".main.3", y, 1, blk=blk)
+    return _bc(net, name + ".conv", torch.cat([x, y], -1), 1, elu=False, blk=blk)
 
 
 def _down(x, s):                       # F.interpolate(scale_factor=1/s), nearest: source index = dst * s
@@ -234,19 +240,21 @@ def _up(x, s):                         # nearest up: source index = dst // s
     return x.repeat_interleave(s, 0).repeat_interleave(s, 1)
 
 
-def unet_forward_train(net, x, x2, x4, x8):
-    """(h,w,8) NHWC pyramids of ONE image -> (H,W,3); every tensor carries autograd history."""
-    z2, z4, z8 = _scm(net, "SCM2", x2), _scm(net, "SCM1", x4), _scm(net, "SCM0", x8)
-    res1 = _res_blocks(net, "Encoder.0", _bc(net, "feat_extract.0", x, 3))
-    z = _bc(net, "feat_extract.1", res1, 3, stride=2)
-    z = z + _bc(net, "FAM2.merge", z * z2, 3, elu=False)
-    res2 = _res_blocks(net, "Encoder.1", z)
-    z = _bc(net, "feat_extract.2", res2, 3, stride=2)
-    z = z + _bc(net, "FAM1.merge", z * z4, 3, elu=False)
-    res3 = _res_blocks(net, "Encoder.2", z)
-    z = _bc(net, "feat_extract.6", res3, 3, stride=2)
-    z = z + _bc(net, "FAM0.merge", z * z8, 3, elu=False)
-    z = _res_blocks(net, "Encoder.3", z)
+def unet_forward_train(net, x, x2, x4, x8, blk=(1, 1, 1)):
+    """(h,w,8) NHWC pyramids -> (H,W,3); every tensor carries autograd history.  blk = (nb, v_num, v_den): the tensors hold
+    nb items stacked vertically, v_num of every v_den rows of an item's block are valid (the rest: zero separator rows;
+    ``stack_batch``).  Nearest resampling, concatenation, products and sums keep the separators zero by themselves."""
+    z2, z4, z8 = _scm(net, "SCM2", x2, blk), _scm(net, "SCM1", x4, blk), _scm(net, "SCM0", x8, blk)
+    res1 = _res_blocks(net, "Encoder.0", _bc(net, "feat_extract.0", x, 3, blk=blk), blk)
+    z = _bc(net, "feat_extract.1", res1, 3, stride=2, blk=blk)
+    z = z + _bc(net, "FAM2.merge", z * z2, 3, elu=False, blk=blk)
+    res2 = _res_blocks(net, "Encoder.1", z, blk)
+    z = _bc(net, "feat_extract.2", res2, 3, stride=2, blk=blk)
+    z = z + _bc(net, "FAM1.merge", z * z4, 3, elu=False, blk=blk)
+    res3 = _res_blocks(net, "Encoder.2", z, blk)
+    z = _bc(net, "feat_extract.6", res3, 3, stride=2, blk=blk)
+    z = z + _bc(net, "FAM0.merge", z * z8, 3, elu=False, blk=blk)
+    z = _res_blocks(net, "Encoder.3", z, blk)
     z12, z13 = _down(res1, 2), _down(res1, 4)
     z21, z23 = _up(res2, 2), _down(res2, 2)
     z32, z31 = _up(res3, 2), _up(res3, 4)
@@ -255,16 +263,40 @@ def unet_forward_train(net, x, x2, x4, x8):
     z41 = _up(z42, 2)
 
     def aff(name, xs):
-        return _bc(net, name + ".conv.1", _bc(net, name + ".conv.0", torch.cat(xs, -1), 1), 3, elu=False)
+        return _bc(net, name + ".conv.1", _bc(net, name + ".conv.0", torch.cat(xs, -1), 1, blk=blk), 3, elu=False, blk=blk)
     r1, r2, r3 = aff("AFFs.0", [res1, z21, z31, z41]), aff("AFFs.1", [z12, res2, z32, z42]), aff("AFFs.2", [z13, z23, res3, z43])
-    z = _res_blocks(net, "Decoder.0", z)
-    z = Up4Fn.apply(_bc(net, "feat_extract.7", z, 4, stride=2))
-    z = _res_blocks(net, "Decoder.1", _bc(net, "Convs.0", torch.cat([z, r3], -1), 1))
-    z = Up4Fn.apply(_bc(net, "feat_extract.3", z, 4, stride=2))
-    z = _res_blocks(net, "Decoder.2", _bc(net, "Convs.1", torch.cat([z, r2], -1), 1))
-    z = Up4Fn.apply(_bc(net, "feat_extract.4", z, 4, stride=2))
-    z = _res_blocks(net, "Decoder.3", _bc(net, "Convs.2", torch.cat([z, r1], -1), 1))
-    return _bc(net, "feat_extract.5", z, 3, elu=False)
+    z = _res_blocks(net, "Decoder.0", z, blk)
+    z = Up4Fn.apply(_bc(net, "feat_extract.7", z, 4, stride=2, blk=blk), *blk)
+    z = _res_blocks(net, "Decoder.1", _bc(net, "Convs.0", torch.cat([z, r3], -1), 1, blk=blk), blk)
+    z = Up4Fn.apply(_bc(net, "feat_extract.3", z, 4, stride=2, blk=blk), *blk)
+    z = _res_blocks(net, "Decoder.2", _bc(net, "Convs.1", torch.cat([z, r2], -1), 1, blk=blk), blk)
+    z = Up4Fn.apply(_bc(net, "feat_extract.4", z, 4, stride=2, blk=blk), *blk)
+    z = _res_blocks(net, "Decoder.3", _bc(net, "Convs.2", torch.cat([z, r1], -1), 1, blk=blk), blk)
+    return _bc(net, "feat_extract.5", z, 3, elu=False, blk=blk)
+
+
+SEPARATOR_ROWS = 16        # zero rows between the items of a stacked batch at full resolution (1 row at the 1/16 scale)
+
+
+def stack_batch(x_nchw, level):
+    """(B,C,h,w) -> (B * (h + gap), w, C) NHWC: the items of a batch stacked vertically with SEPARATOR_ROWS >> level zero
+    rows after each — the zero padding every convolution expects between neighbours, so one launch covers the batch."""
+    B, c, h, w = x_nchw.shape
+    x = x_nchw.permute(0, 2, 3, 1)
+    if B > 1:
+        x = torch.nn.functional.pad(x, (0, 0, 0, 0, 0, SEPARATOR_ROWS >> level))
+    return x.reshape(-1, w, c).contiguous()
+
+
+def unet_forward_train_batch(net, xs):
+    """xs: four (B,8,h,w) pyramids -> (B,3,H,W) through ONE stacked image."""
+    B, _, H, W = xs[0].shape
+    if H % 16 or W % 16:
+        raise ValueError(f"training crops must be multiples of 16, got {W}x{H}")
+    blk = (B, H, H + SEPARATOR_ROWS) if B > 1 else (1, 1, 1)
+    out = unet_forward_train(net, *[stack_batch(x, l) for l, x in enumerate(xs)], blk=blk)
+    out = out.reshape(B, -1, W, 3)[:, :H]
+    return out.permute(0, 3, 1, 2)
 
 
 # -----------------------------------------------------------------------------------------------------------------------

@@ -211,12 +211,8 @@ class UNet(nn.Module):
                                                   or any(torch.is_tensor(x) and x.requires_grad for x in inputs[:4]))
         if wants_grad:
             # training step: every BasicConv is an autograd node backed by the HIP kernels of csrc/train.hip
-            from .train import unet_forward_train
-            outs = []
-            for b in range(inputs[0].shape[0]):
-                xs = [x[b].to(dev, torch.float32).permute(1, 2, 0).contiguous() for x in inputs[:4]]
-                outs.append(unet_forward_train(self, *xs).permute(2, 0, 1))
-            return torch.stack(outs, 0)
+            from .train import unet_forward_train_batch
+            return unet_forward_train_batch(self, [x.to(dev, torch.float32) for x in inputs[:4]])
         xs = [x.to(dev, torch.float32).permute(0, 2, 3, 1).contiguous() for x in inputs[:4]]
         B, H, W, _ = xs[0].shape
         eng = self.engine(H, W)

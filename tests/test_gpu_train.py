@@ -87,15 +87,16 @@ def test_up4_and_huber(hip):
 
 
 def test_unet_training_graph_vs_oracle_autograd(hip):
-    """The whole UNet on a 64x96 crop: output, input gradients (they become descriptor gradients) and all 606 parameter
-    gradients against torch.autograd through the oracle's functional restatement of the reference modules."""
-    H, W = 64, 96
+    """The whole UNet on a batch of three 64x96 crops (stacked into one tall image with zero separator rows by the HIP
+    graph): output, input gradients (they become descriptor gradients) and all 594 parameter gradients against
+    torch.autograd through the oracle's functional restatement of the reference modules, which sees a plain batch."""
+    H, W, B = 64, 96, 3
     state = synthetic.make_unet_state(UNET_SPEC, 13)
     net = UNet()
     net.load_state_dict({k: torch.from_numpy(np.asarray(v)) for k, v in state.items()})
     net.cuda().eval()
     rng = np.random.default_rng(3)
-    xs = [torch.from_numpy(rng.random((1, 8, H >> l, W >> l)).astype(np.float32)) for l in range(4)]
+    xs = [torch.from_numpy(rng.random((B, 8, H >> l, W >> l)).astype(np.float32)) for l in range(4)]
     # oracle
     st_r = {k: torch.from_numpy(np.asarray(v)).clone().requires_grad_(np.asarray(v).dtype == np.float32 and "running" not in k)
             for k, v in state.items()}
@@ -106,7 +107,7 @@ def test_unet_training_graph_vs_oracle_autograd(hip):
     # HIP
     xs_d = [x.cuda().requires_grad_(True) for x in xs]
     out = net(*xs_d)
-    assert out.shape == (1, 3, H, W) and out.grad_fn is not None
+    assert out.shape == (B, 3, H, W) and out.grad_fn is not None
     _close(out, out_r, "forward", rtol=2e-5)
     out.backward(g.cuda())
     for l in range(4):
@@ -124,6 +125,9 @@ def test_unet_training_graph_vs_oracle_autograd(hip):
     # 99 executed BasicConvs x 6 trainable tensors (ConvsOut.* are never executed: no gradient, unet.py:181-186)
     print(f"{n} parameter gradients, worst relative error {worst:.2e}")
     assert n >= 594
+    # a single item takes the unstacked graph and gives the same numbers
+    one = net(*[x[1:2].cuda().requires_grad_(True) for x in xs])
+    _close(one, out_r[1:2], "single-item training forward", rtol=2e-5)
     # inference afterwards still uses the fused plan and sees the same weights
     with torch.no_grad():
         y2 = net(*[x.cuda() for x in xs])
