@@ -20,7 +20,9 @@ ARCH = "gfx950"
 FLAGS = ["-O3", "-std=c++17", "-fPIC", f"--offload-arch={ARCH}", "-x", "hip",
          "-I", os.path.join(ROOT, "include"), "-I", CSRC, "-Wall", "-Wno-unused-function"]
 # the rasteriser's pixel assignment must be bit-exact fp32: no a*b+c contraction
-PER_FILE = {"splat.hip": ["-ffp-contract=off"], "conv.hip": ["-fno-slp-vectorize"]}
+# gather / train: fp32 atomicAdd as the hardware global_atomic_add_f32 (the default lowers it to a compare-and-swap loop)
+PER_FILE = {"splat.hip": ["-ffp-contract=off"], "conv.hip": ["-fno-slp-vectorize"], "gather.hip": ["-munsafe-fp-atomics"],
+            "train.hip": ["-munsafe-fp-atomics"]}
 
 
 def _hipcc():

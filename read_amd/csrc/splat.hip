@@ -511,10 +511,21 @@ __global__ __launch_bounds__(256) void cells_seed_classify_kernel(CellCloud cc, 
 // `rounds` x 256 consecutive points of one chunk for one wave and one strip: zimg early-z, then atomic min on the key +
 // plain stores of the new bound and of the point's position (next frame's seed).  The records of round r+1 are loaded
 // before round r is processed (one HBM round trip per chunk instead of one per round on the critical path).
-template <bool STATS, bool ZL2>
+//
+// LDS (template flag): the candidates of a round are first folded into a 256-slot hash table in LDS that belongs to the
+// wave (slot = hash(pixel); ds_cmpst claims it, ds_min_u64 keeps the smallest key), and only the table's survivors go to
+// the memory-side atomics.  The 256 points of a round are Morton neighbours: on a densely sampled surface they share a
+// handful of pixels and differ in depth by the sampling noise, so most of them beat the bound — and each other — and
+// without the table every one of them costs a 15 G/s memory-side atomic (measured on the street scene: 9 atomics per
+// covered pixel).  On a sparse cloud nearly every candidate keeps its own slot and the table is a few LDS operations of
+// overhead.  Candidates that find their probe slots taken by other pixels go to memory directly.
+constexpr int LDS_SLOTS = 256;       // per wave
+
+template <bool STATS, bool ZL2, bool LDS>
 __device__ __forceinline__ void strip_points(const CellCloud &cc, const float *M, int W, int H, int xlo, int xhi,
                                              unsigned long long *keys, unsigned *zimg, int *next, int first, int rounds,
-                                             int lane, unsigned &st_in, unsigned &st_atomics)
+                                             int lane, unsigned &st_in, unsigned &st_atomics, unsigned *tag,
+                                             unsigned long long *hkey, int *hpos)
 {
     float4 q[4], qn[4];
 #pragma unroll
@@ -546,11 +557,42 @@ __device__ __forceinline__ void strip_points(const CellCloud &cc, const float *M
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
             if (pix[k] < 0 || dbits[k] > bound[k]) continue;       // ties pass: the atomic breaks them by id
-            __hip_atomic_fetch_min(keys + pix[k], ((unsigned long long)dbits[k] << 32) | __float_as_uint(q[k].w),
-                                   __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const unsigned long long key = ((unsigned long long)dbits[k] << 32) | __float_as_uint(q[k].w);
             if (dbits[k] < bound[k]) zimg[pix[k]] = dbits[k];
-            next[pix[k]] = base + 64 * k;                          // a front point of this pixel: next frame's seed
-            if (STATS) st_atomics++;
+            bool direct = true;
+            if (LDS) {
+                unsigned h = ((unsigned)pix[k] * 2654435761u) >> 24;
+#pragma unroll
+                for (int probe = 0; probe < 2 && direct; ++probe, h = (h + 1) & (LDS_SLOTS - 1)) {
+                    const unsigned old = atomicCAS(tag + h, 0u, (unsigned)pix[k] + 1u);
+                    if (old == 0u || old == (unsigned)pix[k] + 1u) {
+                        if (key < atomicMin(hkey + h, key)) hpos[h] = base + 64 * k;
+                        direct = false;
+                    }
+                }
+            }
+            if (direct) {
+                __hip_atomic_fetch_min(keys + pix[k], key, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                next[pix[k]] = base + 64 * k;                      // a front point of this pixel: next frame's seed
+                if (STATS) st_atomics++;
+            }
+        }
+        if (LDS) {
+            // the wave's own table: its LDS operations complete in program order, no barrier needed
+            __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+#pragma unroll
+            for (int j = 0; j < LDS_SLOTS / 64; ++j) {
+                const int sl = lane + 64 * j;
+                const unsigned t = tag[sl];
+                if (t) {
+                    __hip_atomic_fetch_min(keys + (t - 1u), hkey[sl], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    next[t - 1u] = hpos[sl];
+                    tag[sl] = 0u;
+                    hkey[sl] = ~0ull;
+                    if (STATS) st_atomics++;
+                }
+            }
+            __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
         }
 #pragma unroll
         for (int k = 0; k < 4; ++k) q[k] = qn[k];
@@ -560,17 +602,30 @@ __device__ __forceinline__ void strip_points(const CellCloud &cc, const float *M
 // Pass A: an item = 1024 / sub_items consecutive points of one list-A chunk, for one wave and one strip.
 // Pass B: four list-B entries in flight per wave: the hi-Z bounds of their rectangles (inside the strip) are loaded together,
 // then reduced; chunks that survive are processed like pass-A chunks.
-template <bool PASS_B, bool STATS, bool ZL2>
+template <bool PASS_B, bool STATS, bool ZL2, bool LDS>
 __global__ __launch_bounds__(256) void cells_pass_kernel(CellCloud cc, Cam1 cam, int W, int H,
                                                          unsigned long long *keys, unsigned *zimg,
                                                          const unsigned short *__restrict__ hiz_g, int nbx, void *hdr_v,
                                                          int *pos0, int *pos1, StripInfo si, int sub_items,
                                                          unsigned long long *stats)
 {
+    __shared__ unsigned s_tag[LDS ? 4 * LDS_SLOTS : 1];
+    __shared__ unsigned long long s_key[LDS ? 4 * LDS_SLOTS : 1];
+    __shared__ int s_pos[LDS ? 4 * LDS_SLOTS : 1];
     const SplatHeader *hdr = (const SplatHeader *)hdr_v;
     int *next = hdr->parity ? pos0 : pos1;
     const float *M = cam.m;
     const int lane = threadIdx.x & 63;
+    unsigned *tag = s_tag + (LDS ? (threadIdx.x >> 6) * LDS_SLOTS : 0);
+    unsigned long long *hkey = s_key + (LDS ? (threadIdx.x >> 6) * LDS_SLOTS : 0);
+    int *hpos = s_pos + (LDS ? (threadIdx.x >> 6) * LDS_SLOTS : 0);
+    if (LDS) {
+        for (int j = lane; j < LDS_SLOTS; j += 64) {
+            tag[j] = 0u;
+            hkey[j] = ~0ull;
+        }
+        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+    }
     unsigned st_in = 0, st_atomics = 0, n_run = 0, n_cull = 0;
     // Strip = blockIdx % ns: with the round-robin dispatch of workgroups over the XCDs (block b -> XCD b % 8, observed, not
     // promised) all work of a strip runs on the same XCDs and shares their L2 view of zimg; any other placement only makes
@@ -590,8 +645,8 @@ __global__ __launch_bounds__(256) void cells_pass_kernel(CellCloud cc, Cam1 cam,
             const int li = t / sub_items, part = t - li * sub_items;
             const int chunk = __builtin_amdgcn_readfirstlane(list_a[li]);
             ++n_run;
-            strip_points<STATS, ZL2>(cc, M, W, H, xlo, xhi, keys, zimg, next, chunk * CELL_CHUNK + part * rounds * 256, rounds, lane,
-                                st_in, st_atomics);
+            strip_points<STATS, ZL2, LDS>(cc, M, W, H, xlo, xhi, keys, zimg, next, chunk * CELL_CHUNK + part * rounds * 256, rounds,
+                                          lane, st_in, st_atomics, tag, hkey, hpos);
         }
     } else {
         const CellEntryB *list_b = cc.list_b + (size_t)s * cc.nchunks;
@@ -634,7 +689,8 @@ __global__ __launch_bounds__(256) void cells_pass_kernel(CellCloud cc, Cam1 cam,
                 todo &= todo - 1;
                 const int chunk = __builtin_amdgcn_readfirstlane(j == 0 ? e0.chunk : (j == 1 ? e1.chunk : e2.chunk));
                 ++n_run;
-                strip_points<STATS, ZL2>(cc, M, W, H, xlo, xhi, keys, zimg, next, chunk * CELL_CHUNK, 4, lane, st_in, st_atomics);
+                strip_points<STATS, ZL2, LDS>(cc, M, W, H, xlo, xhi, keys, zimg, next, chunk * CELL_CHUNK, 4, lane, st_in, st_atomics,
+                                              tag, hkey, hpos);
             }
         }
     }
@@ -892,6 +948,7 @@ int g_splat_cells_sub = 32;    // list A also takes every n-th chunk (0: none): 
 int g_splat_seeds = 1;         // 0: no warm start from the previous frame's front points (A/B)
 int g_splat_items = 4;         // work items per chunk in the striped passes (1, 2 or 4): 0.101 / 0.101 / 0.097 ms per frame
 int g_splat_zl2 = 0;            // 1: early-z loads bypass the L1 (sc1); measured slower (0.107 vs 0.101 ms)
+int g_splat_lds = 1;            // 1: per-wave LDS hash table in front of the memory-side atomics (strip_points)
 int g_splat_wgs = 8;            // workgroups per CU of the striped passes
 int g_splat_strips = MAX_STRIPS;   // column strips of the striped passes (1, 2, 4 or 8); pass A measured 61.5 / 75.5 / 70 us at
                                // 8 / 2 / 1 (with 4 items per chunk): its time follows the number of atomics (0.92 M / 1.16 M)
@@ -1054,10 +1111,12 @@ int cells_frame(const CellCloud &cc, const float *M_host, int W, int H, int leve
     READ_CHECK_LAUNCH();
     const unsigned grid = (unsigned)(device_cus() * g_splat_wgs);
     const int items = g_splat_items;
-    auto pass_a = stats ? cells_pass_kernel<false, true, false>
-                        : (g_splat_zl2 ? cells_pass_kernel<false, false, true> : cells_pass_kernel<false, false, false>);
-    auto pass_b = stats ? cells_pass_kernel<true, true, false>
-                        : (g_splat_zl2 ? cells_pass_kernel<true, false, true> : cells_pass_kernel<true, false, false>);
+    auto pass_a = stats ? (g_splat_lds ? cells_pass_kernel<false, true, false, true> : cells_pass_kernel<false, true, false, false>)
+                  : g_splat_zl2 ? cells_pass_kernel<false, false, true, false>
+                  : g_splat_lds ? cells_pass_kernel<false, false, false, true> : cells_pass_kernel<false, false, false, false>;
+    auto pass_b = stats ? (g_splat_lds ? cells_pass_kernel<true, true, false, true> : cells_pass_kernel<true, true, false, false>)
+                  : g_splat_zl2 ? cells_pass_kernel<true, false, true, false>
+                  : g_splat_lds ? cells_pass_kernel<true, false, false, true> : cells_pass_kernel<true, false, false, false>;
     hipLaunchKernelGGL(pass_a, dim3(grid), dim3(256), 0, stream, cc, cam, W, H, ws.keys, ws.zimg,
                        (const unsigned short *)ws.hiz, ws.nbx, ws.hdr, ws.prev[0], ws.prev[1], si, items, stats);
     READ_CHECK_LAUNCH();
@@ -1093,6 +1152,7 @@ void splat_set_seeds(int v) { g_splat_seeds = v; }
 void splat_set_cells_sub(int v) { g_splat_cells_sub = v < 0 ? 0 : v; }
 void splat_set_items(int v) { g_splat_items = v >= 4 ? 4 : (v >= 2 ? 2 : 1); }
 void splat_set_zl2(int v) { g_splat_zl2 = v != 0; }
+void splat_set_lds(int v) { g_splat_lds = v != 0; }
 void splat_set_wgs(int v) { g_splat_wgs = v < 1 ? 1 : (v > 16 ? 16 : v); }
 void splat_set_strips(int v) { g_splat_strips = v >= 8 ? 8 : (v >= 4 ? 4 : (v >= 2 ? 2 : 1)); }
 int splat_get(const char *key, int *value)
@@ -1108,6 +1168,7 @@ int splat_get(const char *key, int *value)
     else if (!strcmp(key, "splat_strips")) *value = g_splat_strips;
     else if (!strcmp(key, "splat_wgs")) *value = g_splat_wgs;
     else if (!strcmp(key, "splat_zl2")) *value = g_splat_zl2;
+    else if (!strcmp(key, "splat_lds")) *value = g_splat_lds;
     else return 0;
     return 1;
 }

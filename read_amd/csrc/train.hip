@@ -266,22 +266,33 @@ __global__ __launch_bounds__(64) void wgrad_mfma_kernel(const float *__restrict_
         for (int r = 0; r < 16; ++r) acc[t][r] = 0.0f;
     const int y_begin = (int)blockIdx.z * rows_per_split;
     const int y_end = min(outH, y_begin + rows_per_split);
-    for (int oy = y_begin; oy < y_end; ++oy) {
-        for (int ox = 0; ox < outW; ox += 2) {
-            const int px = ox + kk;                                      // this half-wave's output pixel
-            const bool p_ok = px < outW;
-            const float b = (p_ok && co_ok) ? dfm[((long long)oy * outW + px) * C2 + co0 + i] : 0.0f;
-            float a[NT];
+    const int taps = ksize * ksize;
+    // One k-step = two output pixels (px = ox + kk).  The operands of step s+1 are fetched before the MFMAs of step s issue
+    // (an in-order wave would otherwise sit out the full load latency in front of every group of NT MFMAs), and the
+    // per-row part of every tap's address is hoisted out of the pixel loop.
+    const int n_pairs = (outW + 1) >> 1;
+    const long long total_steps = (long long)(y_end - y_begin) * n_pairs;
+    auto fetch = [&](long long step, float (&a)[NT], float &b) {
+        const int oy = y_begin + (int)(step / n_pairs), px = 2 * (int)(step % n_pairs) + kk;
+        const bool p_ok = step < total_steps && px < outW;
+        b = (p_ok && co_ok) ? dfm[((long long)oy * outW + px) * C2 + co0 + i] : 0.0f;
 #pragma unroll
-            for (int t = 0; t < NT; ++t) {
-                const int tap = (int)blockIdx.y * NT + t, ky = tap / ksize, kx = tap - ky * ksize;
-                const int iy = oy * stride + ky - pad, ix = px * stride + kx - pad;
-                const bool ok = p_ok && ci_ok && tap < ksize * ksize && iy >= 0 && iy < inH && ix >= 0 && ix < inW;
-                a[t] = ok ? x[((long long)iy * inW + ix) * Cin + ci0 + i] : 0.0f;
-            }
-#pragma unroll
-            for (int t = 0; t < NT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[t], b, acc[t], 0, 0, 0);
+        for (int t = 0; t < NT; ++t) {
+            const int tap = (int)blockIdx.y * NT + t, ky = tap / ksize, kx = tap - ky * ksize;
+            const int iy = oy * stride + ky - pad, ix = px * stride + kx - pad;
+            const bool ok = p_ok && ci_ok && tap < taps && iy >= 0 && iy < inH && ix >= 0 && ix < inW;
+            a[t] = ok ? x[((long long)iy * inW + ix) * Cin + ci0 + i] : 0.0f;
         }
+    };
+    float a_cur[NT], a_nxt[NT], b_cur, b_nxt;
+    fetch(0, a_cur, b_cur);
+    for (long long step = 0; step < total_steps; ++step) {
+        fetch(step + 1, a_nxt, b_nxt);
+#pragma unroll
+        for (int t = 0; t < NT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a_cur[t], b_cur, acc[t], 0, 0, 0);
+#pragma unroll
+        for (int t = 0; t < NT; ++t) a_cur[t] = a_nxt[t];
+        b_cur = b_nxt;
     }
     // D[i][j] sits in lane (j + 32 * ((i >> 2) & 1)), register (i & 3) + 4 * (i >> 3): row i = ci, column j = co'
     float *dst = partial + (((long long)blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x) * (NT * 1024);

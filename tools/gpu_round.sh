@@ -14,7 +14,7 @@ for s in $STEPS; do
   case $s in
     pytest) run pytest 1500 python -m pytest tests -m gpu -q --timeout 600 -p no:cacheprovider -s ;;
     splattest) run splattest 900 python -m pytest tests/test_gpu_splat.py -m gpu -q -x --timeout 600 -p no:cacheprovider -s ;;
-    splatprof) for v in ${SPLAT_VARIANTS:-"d" "zl2:splat_zl2=1" "i2:splat_items=2" "i4:splat_items=4" "zl2i4:splat_zl2=1 splat_items=4"}; do
+    splatprof) for v in ${SPLAT_VARIANTS:-"d" "nolds:splat_lds=0" "i1:splat_items=1" "i1nolds:splat_items=1 splat_lds=0"}; do
               name=${v%%:*}; knobs=""; [ "$v" != "$name" ] && knobs=${v#*:}
               ( cd /tmp && SPLAT_PROBE_STATS=0 timeout 200 rocprofv3 --kernel-trace --stats --output-format csv -d "$O/${TAG}_sp_$name" -o splat -- python "$R/tools/splat_cells_probe.py" 30000000 $knobs ) > "$O/${TAG}_sp_$name.log" 2>&1
               grep "ms/frame" "$O/${TAG}_sp_$name.log" | sed "s/^/$name: /"
@@ -34,7 +34,7 @@ for r in rows[:25]:
     print("%8.2f ms %6s calls %9.1f us avg  %s" % (float(r["TotalDurationNs"]) / 1e6, r["Calls"], float(r["AverageNs"]) / 1e3, r["Name"][:110]))
 PY
             ;;
-    streetprof) for v in "st_d" "st_n48:splat_near=48" "st_n200:splat_near=200" "st_n3:splat_near=3" "st_sub8:splat_cells_sub=8"; do
+    streetprof) for v in "st_d" "st_nolds:splat_lds=0" "st_n48:splat_near=48" "st_i1:splat_items=1"; do
               name=${v%%:*}; knobs=""; [ "$v" != "$name" ] && knobs=${v#*:}
               ( cd /tmp && SPLAT_PROBE_STATS=0 SPLAT_PROBE_SCENE=street SPLAT_PROBE_H=368 timeout 200 rocprofv3 --kernel-trace --stats --output-format csv -d "$O/${TAG}_sp_$name" -o splat -- python "$R/tools/splat_cells_probe.py" 10000000 $knobs ) > "$O/${TAG}_sp_$name.log" 2>&1
               grep "ms/frame" "$O/${TAG}_sp_$name.log" | sed "s/^/$name: /"
