@@ -1001,43 +1001,44 @@ struct ConvConfig {
     {"k" #KS "s" #S "c" #KC "_wave_p" #P "q" #QG "f" #PF, KS, S, KC, P, QG, 1, 1, PF, 1,        \
      gated_conv_wave_kernel<KS, S, KC, P, QG, PF>, nullptr, 1, WGCU}
 
+// Entries are addressed by name / parameters (find_config), never by position.
 // Order matters: pick_config() takes the first entry whose (ksize, stride, chunk) match and whose
 // channel-group coverage divides the layer's groups; remaining groups go to grid.y.  The order below
 // follows the measured sweep on MI355X (profiles/r1_sweep_conv.md): small tiles + group splitting over
 // grid.y beat wide per-wave tiles at every level (more workgroups in flight, 3-5 waves/SIMD).
 const ConvConfig g_configs[] = {
     // 3x3 stride 1, 16-channel chunks (ResBlocks, FAM, AFF second conv, SCM third conv, fe5)
-    CFGM(3, 1, 16, 2, 1, 4, 1, 1),  //  0  8x32 px, one 32-channel group per workgroup
-    CFGM(3, 1, 16, 1, 1, 4, 1, 1),  //  1  4x32 px
-    CFGM(3, 1, 16, 2, 1, 2, 2, 1),  //  2  4x32 px, two groups (B split over waves)
-    CFGM(3, 1, 16, 2, 2, 4, 1, 1),  //  3  8x32 px, two groups per wave
-    CFGM(3, 1, 16, 2, 2, 2, 2, 1),  //  4  4x32 px, four groups
-    CFGM(3, 1, 16, 1, 2, 1, 4, 1),  //  5  1x32 px, eight groups
-    CFGM(3, 1, 16, 2, 1, 4, 1, 2),  //  6  as 0, B prefetch depth 2
-    CFGM(3, 1, 16, 1, 1, 4, 1, 2),  //  7  as 1, depth 2
-    CFGM(3, 1, 16, 2, 1, 2, 2, 2),  //  8  as 2, depth 2
-    CFGN(3, 1, 16, 2, 1, 4, 1, 2, 1),   //  9  single LDS buffer, depth 2
-    CFGNM(3, 1, 16, 1, 1, 4, 1, 2, 1),  // 10  4x32 px, single buffer: best at <= 2 channel groups
-    CFGNM(3, 1, 16, 2, 1, 2, 2, 2, 1),  // 11  4x32 px x 2 groups, single buffer: best at 8 groups
+    CFGM(3, 1, 16, 2, 1, 4, 1, 1),  // 8x32 px, one 32-channel group per workgroup
+    CFGM(3, 1, 16, 1, 1, 4, 1, 1),  // 4x32 px
+    CFGM(3, 1, 16, 2, 1, 2, 2, 1),  // 4x32 px, two groups (B split over waves)
+    CFGM(3, 1, 16, 2, 2, 4, 1, 1),  // 8x32 px, two groups per wave
+    CFGM(3, 1, 16, 2, 2, 2, 2, 1),  // 4x32 px, four groups
+    CFGM(3, 1, 16, 1, 2, 1, 4, 1),  // 1x32 px, eight groups
+    CFGM(3, 1, 16, 2, 1, 4, 1, 2),  // 8x32 px, one group, B prefetch depth 2
+    CFGM(3, 1, 16, 1, 1, 4, 1, 2),  // 4x32 px, depth 2
+    CFGM(3, 1, 16, 2, 1, 2, 2, 2),  // 4x32 px, two groups, depth 2
+    CFGN(3, 1, 16, 2, 1, 4, 1, 2, 1),   // single LDS buffer, depth 2
+    CFGNM(3, 1, 16, 1, 1, 4, 1, 2, 1),  // 4x32 px, single buffer: best at <= 2 channel groups
+    CFGNM(3, 1, 16, 2, 1, 2, 2, 2, 1),  // 4x32 px x 2 groups, single buffer: best at 8 groups
     // 3x3 stride 1, 8-channel chunks (inputs straight from the 8-channel pyramid)
-    CFG(3, 1, 8, 2, 1, 4, 1, 2),    //  9
-    CFG(3, 1, 8, 1, 1, 4, 1, 2),    // 10
+    CFG(3, 1, 8, 2, 1, 4, 1, 2),
+    CFG(3, 1, 8, 1, 1, 4, 1, 2),
     // 1x1, 16-channel chunks (SCM, AFF first conv, Convs)
-    CFG(1, 1, 16, 2, 1, 4, 1, 1),   // 11
-    CFG(1, 1, 16, 1, 1, 4, 1, 1),   // 12
-    CFG(1, 1, 16, 2, 2, 2, 2, 1),   // 13
+    CFG(1, 1, 16, 2, 1, 4, 1, 1),
+    CFG(1, 1, 16, 1, 1, 4, 1, 1),
+    CFG(1, 1, 16, 2, 2, 2, 2, 1),
     // 1x1, 32-channel chunks (AFF first conv, Convs: every source a multiple of 32 channels): twice the MFMAs per
     // staged tile and per barrier of the 16-channel chunks
     CFG(1, 1, 32, 2, 1, 4, 1, 1),
     CFG(1, 1, 32, 1, 1, 4, 1, 1),
     CFG(1, 1, 32, 2, 2, 2, 2, 1),
     // 1x1, 8-channel chunks (SCM tail: cat[x(8), main(P-8)])
-    CFG(1, 1, 8, 2, 1, 4, 1, 0),    // 15
-    CFG(1, 1, 8, 1, 1, 4, 1, 0),    // 16
+    CFG(1, 1, 8, 2, 1, 4, 1, 0),
+    CFG(1, 1, 8, 1, 1, 4, 1, 0),
     // 3x3 stride 2 (encoder downsampling)
-    CFG(3, 2, 16, 1, 1, 4, 1, 1),   // 17
-    CFG(3, 2, 16, 1, 2, 2, 2, 1),   // 18
-    CFG(3, 2, 16, 1, 2, 4, 1, 1),   // 19
+    CFG(3, 2, 16, 1, 1, 4, 1, 1),
+    CFG(3, 2, 16, 1, 2, 2, 2, 1),
+    CFG(3, 2, 16, 1, 2, 4, 1, 1),
     // wave-autonomous persistent kernels
     CFGW(3, 1, 16, 2, 1, 1, 2),
     CFGW(3, 1, 16, 2, 1, 2, 2),
@@ -1050,9 +1051,9 @@ const ConvConfig g_configs[] = {
     {"k3s1c16_p1q1_wino", 3, 1, 16, 1, 1, 4, 1, 1, 2, gated_conv_wino_kernel<false, false>, gated_conv_wino_kernel<false, true>, 0, 0, 1},
     // 4x4 stride 2 (decoder, before the bilinear x4): outputs are 1/4 .. 1/16 scale, so the 16 taps of
     // ONE 1x32-pixel tile are split over the four waves (split-K, WM*WN == 1) to fill the chip
-    CFG(4, 2, 16, 1, 1, 1, 1, 1),   // 20  split-K, one group
-    CFG(4, 2, 16, 1, 1, 4, 1, 1),   // 21
-    CFG(4, 2, 16, 1, 2, 2, 2, 1),   // 22
+    CFG(4, 2, 16, 1, 1, 1, 1, 1),   // split-K, one group
+    CFG(4, 2, 16, 1, 1, 4, 1, 1),
+    CFG(4, 2, 16, 1, 2, 2, 2, 1),
 };
 constexpr int N_CONFIGS = sizeof(g_configs) / sizeof(g_configs[0]);
 

@@ -208,22 +208,22 @@ def recalc_proj_matrix_planes(pm, new_near=.01, new_far=1000.):
 
 
 def rescale_K(K_, sx, sy, keep_fov=True):
-    """READ/gl/utils.py:153-160."""
-    K = K_.copy()
-    K[0, 2] = sx * K[0, 2]
-    K[1, 2] = sy * K[1, 2]
+    """Intrinsics of an image resized by (sx, sy): the principal point always moves with the pixels, the focal lengths only
+    when the field of view is to be kept (READ/gl/utils.py:153-160)."""
+    scale = np.ones((3, 3), dtype=np.asarray(K_).dtype)
+    scale[0, 2], scale[1, 2] = sx, sy
     if keep_fov:
-        K[0, 0] = sx * K[0, 0]
-        K[1, 1] = sy * K[1, 1]
-    return K
+        scale[0, 0], scale[1, 1] = sx, sy
+    return np.asarray(K_) * scale
 
 
 def crop_intrinsic_matrix(K, old_size, new_size):
-    """READ/gl/utils.py:163-167."""
-    K = K.copy()
-    K[0, 2] = new_size[0] * K[0, 2] / old_size[0]
-    K[1, 2] = new_size[1] * K[1, 2] / old_size[1]
-    return K
+    """Intrinsics after a centred crop from old_size to new_size (w, h): only the principal point scales
+    (READ/gl/utils.py:163-167)."""
+    out = np.array(K, copy=True)
+    for axis in (0, 1):
+        out[axis, 2] = new_size[axis] * K[axis, 2] / old_size[axis]
+    return out
 
 
 def intrinsics_from_xml(xml_file):
@@ -243,24 +243,21 @@ def intrinsics_from_xml(xml_file):
 
 def extrinsics_from_xml(xml_file, verbose=False):
     """camera->world 4x4 per aligned camera in file order, y and z axes flipped to the GL convention
-    (``extrinsic[:, 1:3] *= -1``); READ/gl/utils.py:190-208."""
-    root = ET.parse(xml_file).getroot()
-    transforms = {}
-    for e in root.findall('chunk/cameras')[0].findall('camera'):
-        label = e.get('label')
-        t = e.find('transform')
-        if t is None:                               # not aligned by Metashape
+    (``extrinsic[:, 1:3] *= -1``); READ/gl/utils.py:190-208.  A label that occurs twice keeps its first position and its
+    last transform (the reference collects them in a dict)."""
+    cameras = ET.parse(xml_file).getroot().findall('chunk/cameras')[0].findall('camera')
+    by_label = {}
+    for cam in cameras:
+        node = cam.find('transform')
+        if node is None:                            # not aligned by Metashape
             if verbose:
-                print('failed to align camera', label)
+                print('failed to align camera', cam.get('label'))
             continue
-        transforms[label] = t.text
-    view_matrices = []
-    labels_sort = list(transforms)
-    for label in labels_sort:
-        extrinsic = np.array([float(x) for x in transforms[label].split()]).reshape(4, 4)
-        extrinsic[:, 1:3] *= -1
-        view_matrices.append(extrinsic)
-    return view_matrices, labels_sort
+        by_label[cam.get('label')] = node.text
+    flip = np.array([1.0, -1.0, -1.0, 1.0])
+    labels = list(by_label)
+    poses = [np.array(by_label[l].split(), dtype=np.float64).reshape(4, 4) * flip for l in labels]
+    return poses, labels
 
 
 def get_valid_matrices(mlist):
@@ -291,53 +288,46 @@ def fix_relative_path(path, config_path):
 
 
 def load_scene_data(path):
-    """READ/gl/utils.py:258-353: scene yaml -> the ``scene_data`` dict of the datasets, ``OGL`` and the viewer."""
+    """Scene yaml -> the ``scene_data`` dict the datasets, ``OGL`` and the viewer consume (READ/gl/utils.py:258-353).
+    Keys of the yaml: viewport_size, pointcloud, intrinsic_matrix (.xml = Metashape calibration, else a text matrix),
+    proj_matrix, view_matrix (.xml or stacked text matrices), model3d_origin, point_sizes, net_path + ckpt + texture_ckpt."""
     with open(path, 'r') as f:
         config = yaml.safe_load(f)
-    pointcloud = import_model3d(fix_relative_path(config['pointcloud'], path)) if 'pointcloud' in config else None
-    if config.get('mesh'):
-        raise NotImplementedError("scene files with a mesh are outside the point-cloud render path")
-    if config.get('texture'):
-        raise NotImplementedError("scene files with a mesh texture are outside the point-cloud render path")
-    if 'intrinsic_matrix' in config:
-        apath = fix_relative_path(config['intrinsic_matrix'], path)
-        if apath[-3:] == 'xml':
-            intrinsic_matrix, (width, height) = intrinsics_from_xml(apath)
-            assert tuple(config['viewport_size']) == (width, height), f'calibration width, height: ({width}, {height})'
-        else:
-            intrinsic_matrix = np.loadtxt(apath)[:3, :3]
-    else:
-        intrinsic_matrix = None
+    for key in ('mesh', 'texture'):
+        if config.get(key):
+            raise NotImplementedError(f"scene files with a {key} entry are outside the point-cloud render path")
+
+    def entry(key):
+        """Resolved path of an optional yaml entry, or None."""
+        return fix_relative_path(config[key], path) if key in config else None
+
+    out = {'mesh': None, 'texture': None, 'config': config,
+           'pointcloud': import_model3d(entry('pointcloud')) if 'pointcloud' in config else None,
+           'intrinsic_matrix': None, 'proj_matrix': None, 'view_matrix': None,
+           'camera_labels': None,                   # (the reference leaves it unbound without a view_matrix entry)
+           'model3d_origin': np.eye(4), 'point_sizes': None, 'net_ckpt': None, 'tex_ckpt': None}
+    k_path = entry('intrinsic_matrix')
+    if k_path is not None and k_path.endswith('xml'):
+        out['intrinsic_matrix'], size = intrinsics_from_xml(k_path)
+        assert tuple(config['viewport_size']) == size, f'calibration width, height: ({size[0]}, {size[1]})'
+    elif k_path is not None:
+        out['intrinsic_matrix'] = np.loadtxt(k_path)[:3, :3]
     if 'proj_matrix' in config:
-        proj_matrix = recalc_proj_matrix_planes(np.loadtxt(fix_relative_path(config['proj_matrix'], path)))
-    else:
-        proj_matrix = None
-    camera_labels = None                            # (the reference leaves it unbound without a view_matrix entry)
-    if 'view_matrix' in config:
-        apath = fix_relative_path(config['view_matrix'], path)
-        if apath[-3:] == 'xml':
-            view_matrix, camera_labels = extrinsics_from_xml(apath)
-        else:
-            view_matrix, camera_labels = extrinsics_from_view_matrix(apath)
-    else:
-        view_matrix = None
+        out['proj_matrix'] = recalc_proj_matrix_planes(np.loadtxt(entry('proj_matrix')))
+    v_path = entry('view_matrix')
+    if v_path is not None:
+        reader = extrinsics_from_xml if v_path.endswith('xml') else extrinsics_from_view_matrix
+        out['view_matrix'], out['camera_labels'] = reader(v_path)
     if 'model3d_origin' in config:
-        model3d_origin = np.loadtxt(fix_relative_path(config['model3d_origin'], path))
-    else:
-        model3d_origin = np.eye(4)
-    point_sizes = np.load(fix_relative_path(config['point_sizes'], path)) if 'point_sizes' in config else None
+        out['model3d_origin'] = np.loadtxt(entry('model3d_origin'))
+    if 'point_sizes' in config:
+        out['point_sizes'] = np.load(entry('point_sizes'))
     config['viewport_size'] = tuple(config['viewport_size'])
     if 'net_path' in config:
-        net_ckpt = fix_relative_path(os.path.join(config['net_path'], 'checkpoints', config['ckpt']), path)
-        tex_ckpt = fix_relative_path(os.path.join(config['net_path'], 'checkpoints', config['texture_ckpt']), path)
-    else:
-        net_ckpt = tex_ckpt = None
-    return {
-        'pointcloud': pointcloud, 'point_sizes': point_sizes, 'mesh': None, 'texture': None,
-        'proj_matrix': proj_matrix, 'intrinsic_matrix': intrinsic_matrix, 'view_matrix': view_matrix,
-        'camera_labels': camera_labels, 'model3d_origin': model3d_origin, 'config': config,
-        'net_ckpt': net_ckpt, 'tex_ckpt': tex_ckpt,
-    }
+        ckpt_dir = os.path.join(config['net_path'], 'checkpoints')
+        out['net_ckpt'] = fix_relative_path(os.path.join(ckpt_dir, config['ckpt']), path)
+        out['tex_ckpt'] = fix_relative_path(os.path.join(ckpt_dir, config['texture_ckpt']), path)
+    return out
 
 
 def setup_scene(scene, data, use_mesh=False, use_texture=False):
