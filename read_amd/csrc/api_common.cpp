@@ -43,6 +43,7 @@ void splat_set_strips(int v);
 void splat_set_wgs(int v);
 void splat_set_zl2(int v);
 void splat_set_lds(int v);
+void splat_set_kslot(int v);
 int splat_get(const char *key, int *value);
 void conv_set_trace(void *buf, size_t bytes);
 void conv_set_prefer_wave(int v);
@@ -68,7 +69,7 @@ extern "C" int read_debug_set_trace(void *buf, size_t bytes)
 // selects between implementations that produce the SAME results; the attribution probes whose results are invalid
 // ("conv_ablate") exist only in builds with -DREAD_DEBUG_KNOBS.
 static const char *const k_tuning_keys[] = {"splat_mode", "splat_stats", "splat_subset", "splat_near", "splat_cells",
-                                            "splat_cells_sub", "splat_seeds", "splat_items", "splat_strips", "splat_wgs", "splat_zl2", "splat_lds", "unet_streams", "conv_kc32",
+                                            "splat_cells_sub", "splat_seeds", "splat_items", "splat_strips", "splat_wgs", "splat_zl2", "splat_lds", "splat_kslot", "unet_streams", "conv_kc32",
                                             "conv_wino", "conv_stagger", "conv_wave",
 #ifdef READ_DEBUG_KNOBS
                                             "conv_ablate",
@@ -91,6 +92,7 @@ extern "C" int read_tuning_set(const char *key, int value)
     if (!strcmp(key, "splat_seeds")) { readhip::splat_set_seeds(value); return READ_OK; }     // 0: no warm start
     if (!strcmp(key, "splat_cells")) { readhip::splat_set_cells(value); return READ_OK; }     // 0: ignore the cell-ordered copy
     if (!strcmp(key, "splat_items")) { readhip::splat_set_items(value); return READ_OK; }     // work items per chunk: 1, 2, 4
+    if (!strcmp(key, "splat_kslot")) { readhip::splat_set_kslot(value); return READ_OK; }     // key-image layout: 0 linear, 1 strided, 2 scattered
     if (!strcmp(key, "splat_lds")) { readhip::splat_set_lds(value); return READ_OK; }         // 0: no LDS table in front of the atomics
     if (!strcmp(key, "splat_zl2")) { readhip::splat_set_zl2(value); return READ_OK; }         // 1: early-z loads bypass the L1
     if (!strcmp(key, "splat_wgs")) { readhip::splat_set_wgs(value); return READ_OK; }         // workgroups per CU of the passes

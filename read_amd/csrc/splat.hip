@@ -94,6 +94,19 @@ __device__ __forceinline__ void fold_key_agent(unsigned long long *k, unsigned l
 {
     __hip_atomic_fetch_min(k, key, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
+// Where pixel p's key lives in the key image of the striped path.  Mode 0: slot p.  Mode 1: slot 8 p (one key per 64 bytes).
+// Mode 2: slot (p * odd) mod 2^k, a bijection that scatters neighbouring pixels over the whole image — the memory-side atomic
+// units serialise atomics that hit the same line / channel, and the candidates of a round are Morton neighbours, i.e.
+// pixels of a few adjacent 128-byte lines (read_tuning_set("splat_kslot", m); measured in profiles/README.md).
+struct KeySlots {
+    int mode;
+    unsigned mask;           // 2^k - 1 >= W*H - 1 (mode 2)
+};
+__device__ __forceinline__ unsigned key_slot(const KeySlots ks, unsigned pix)
+{
+    return ks.mode == 0 ? pix : (ks.mode == 1 ? pix << 3 : (pix * 0x9E3779B1u) & ks.mask);
+}
+
 // Far bounds are stored as 16 bits: the upper half (bfloat16, truncated = rounded DOWN) of e = fl(1 - d_max).  Depth
 // is d = 1 - O(znear / z), so e keeps 8 mantissa bits of the DISTANCE (0.4 %) where a half-precision d would resolve
 // only ~5 m at 30 m.  Reject iff fl(1 - d) < bound: rounding is monotonic, so fl(1 - d) < fl(1 - d_max) implies
@@ -529,7 +542,7 @@ template <bool STATS, bool ZL2, bool LDS>
 __device__ __forceinline__ void strip_points(const CellCloud &cc, const float *M, int W, int H, int xlo, int xhi,
                                              unsigned long long *keys, unsigned *zimg, int *next, int first, int rounds,
                                              int lane, unsigned &st_in, unsigned &st_atomics, unsigned *tag,
-                                             unsigned long long *hkey, int *hpos)
+                                             unsigned long long *hkey, int *hpos, const KeySlots ks)
 {
     float4 q[4], qn[4];
 #pragma unroll
@@ -576,7 +589,7 @@ __device__ __forceinline__ void strip_points(const CellCloud &cc, const float *M
                 }
             }
             if (direct) {
-                __hip_atomic_fetch_min(keys + pix[k], key, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_fetch_min(keys + key_slot(ks, (unsigned)pix[k]), key, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 next[pix[k]] = base + 64 * k;                      // a front point of this pixel: next frame's seed
                 if (STATS) st_atomics++;
             }
@@ -589,7 +602,7 @@ __device__ __forceinline__ void strip_points(const CellCloud &cc, const float *M
                 const int sl = lane + 64 * j;
                 const unsigned t = tag[sl];
                 if (t) {
-                    __hip_atomic_fetch_min(keys + (t - 1u), hkey[sl], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    __hip_atomic_fetch_min(keys + key_slot(ks, t - 1u), hkey[sl], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                     next[t - 1u] = hpos[sl];
                     tag[sl] = 0u;
                     hkey[sl] = ~0ull;
@@ -611,7 +624,7 @@ __global__ __launch_bounds__(256) void cells_pass_kernel(CellCloud cc, Cam1 cam,
                                                          unsigned long long *keys, unsigned *zimg,
                                                          const unsigned short *__restrict__ hiz_g, int nbx, void *hdr_v,
                                                          int *pos0, int *pos1, StripInfo si, int sub_items,
-                                                         unsigned long long *stats)
+                                                         unsigned long long *stats, KeySlots ks)
 {
     __shared__ unsigned s_tag[LDS ? 4 * LDS_SLOTS : 1];
     __shared__ unsigned long long s_key[LDS ? 4 * LDS_SLOTS : 1];
@@ -650,7 +663,7 @@ __global__ __launch_bounds__(256) void cells_pass_kernel(CellCloud cc, Cam1 cam,
             const int chunk = __builtin_amdgcn_readfirstlane(list_a[li]);
             ++n_run;
             strip_points<STATS, ZL2, LDS>(cc, M, W, H, xlo, xhi, keys, zimg, next, chunk * CELL_CHUNK + part * rounds * 256, rounds,
-                                          lane, st_in, st_atomics, tag, hkey, hpos);
+                                          lane, st_in, st_atomics, tag, hkey, hpos, ks);
         }
     } else {
         const CellEntryB *list_b = cc.list_b + (size_t)s * cc.nchunks;
@@ -692,7 +705,7 @@ __global__ __launch_bounds__(256) void cells_pass_kernel(CellCloud cc, Cam1 cam,
                 const int chunk = __builtin_amdgcn_readfirstlane(j == 0 ? e0.chunk : (j == 1 ? e1.chunk : e2.chunk));
                 ++n_run;
                 strip_points<STATS, ZL2, LDS>(cc, M, W, H, xlo, xhi, keys, zimg, next, chunk * CELL_CHUNK, 4, lane, st_in, st_atomics,
-                                              tag, hkey, hpos);
+                                              tag, hkey, hpos, ks);
             }
         }
     }
@@ -715,7 +728,8 @@ __global__ __launch_bounds__(256) void cells_pass_kernel(CellCloud cc, Cam1 cam,
 // pixel is still empty; and zimg is set to the exact current depths (the racy stores of pass A may have left a larger
 // value than the minimum), so pass B's early-z is exact.
 __global__ __launch_bounds__(256) void cells_hiz_kernel(const unsigned long long *__restrict__ keys, unsigned *__restrict__ zimg,
-                                                        int W, int H, int nbx, int nby, unsigned short *__restrict__ hiz)
+                                                        int W, int H, int nbx, int nby, unsigned short *__restrict__ hiz,
+                                                        KeySlots ks)
 {
     const int b = blockIdx.x * blockDim.x + threadIdx.x;
     if (b >= nbx * nby) return;
@@ -725,13 +739,20 @@ __global__ __launch_bounds__(256) void cells_hiz_kernel(const unsigned long long
     for (int dy = 0; dy < 4; ++dy)
         if (by * 4 + dy < H) {                                  // W % 16 == 0: the block's 4 columns exist
             const long long off = (long long)(by * 4 + dy) * W + bx * 4;
-            const ulonglong2 k01 = *reinterpret_cast<const ulonglong2 *>(keys + off);
-            const ulonglong2 k23 = *reinterpret_cast<const ulonglong2 *>(keys + off + 2);
             uint4 z;
-            z.x = (unsigned)(k01.x >> 32);                      // EMPTY -> 0xffffffff = "none"
-            z.y = (unsigned)(k01.y >> 32);
-            z.z = (unsigned)(k23.x >> 32);
-            z.w = (unsigned)(k23.y >> 32);
+            if (ks.mode == 0) {
+                const ulonglong2 k01 = *reinterpret_cast<const ulonglong2 *>(keys + off);
+                const ulonglong2 k23 = *reinterpret_cast<const ulonglong2 *>(keys + off + 2);
+                z.x = (unsigned)(k01.x >> 32);                  // EMPTY -> 0xffffffff = "none"
+                z.y = (unsigned)(k01.y >> 32);
+                z.z = (unsigned)(k23.x >> 32);
+                z.w = (unsigned)(k23.y >> 32);
+            } else {
+                z.x = (unsigned)(keys[key_slot(ks, (unsigned)off)] >> 32);
+                z.y = (unsigned)(keys[key_slot(ks, (unsigned)off + 1)] >> 32);
+                z.z = (unsigned)(keys[key_slot(ks, (unsigned)off + 2)] >> 32);
+                z.w = (unsigned)(keys[key_slot(ks, (unsigned)off + 3)] >> 32);
+            }
             *reinterpret_cast<uint4 *>(zimg + off) = z;
             m = max(max(m, z.x), max(max(z.y, z.z), z.w));
         }
@@ -838,7 +859,7 @@ __device__ __forceinline__ unsigned long long kmin(unsigned long long a, unsigne
 __global__ __launch_bounds__(256) void splat_resolve_kernel(unsigned long long *__restrict__ keys, int W, int H,
                                                             int levels, ResolveOut out, int tiles_x,
                                                             int tiles_y, int *__restrict__ prev_idx,
-                                                            void *hdr_v, int keep, unsigned *__restrict__ zimg)
+                                                            void *hdr_v, int keep, unsigned *__restrict__ zimg, KeySlots ks)
 {
     __shared__ unsigned long long s1[256], s2[64], s3[16];
     const int cam = blockIdx.y;
@@ -858,8 +879,9 @@ __global__ __launch_bounds__(256) void splat_resolve_kernel(unsigned long long *
             unsigned long long v = EMPTY_KEY;
             if (x < W && y < H) {
                 const long long off = (long long)y * W + x;
-                v = kc[off];
-                kc[off] = EMPTY_KEY;                 // leave the workspace clean for the next frame
+                const long long slot = keep == 2 ? (long long)key_slot(ks, (unsigned)off) : off;
+                v = kc[slot];
+                kc[slot] = EMPTY_KEY;                // leave the workspace clean for the next frame
                 emit(out, 0, cam * npx0 + off, v);
                 if (keep == 1) prev_idx[off] = v == EMPTY_KEY ? -1 : (int)(unsigned)(v & 0xffffffffull);   // next frame's seeds
                 if (keep == 2) zimg[off] = 0xffffffffu;       // "no bound"
@@ -950,6 +972,7 @@ int g_splat_cells_sub = 32;    // list A also takes every n-th chunk (0: none): 
 int g_splat_seeds = 1;         // 0: no warm start from the previous frame's front points (A/B)
 int g_splat_items = 4;         // work items per chunk in the striped passes (1, 2 or 4): 0.101 / 0.101 / 0.097 ms per frame
 int g_splat_zl2 = 0;            // 1: early-z loads bypass the L1 (sc1); measured slower (0.107 vs 0.101 ms)
+int g_splat_kslot = 0;          // key-image layout of the striped path: 0 linear, 1 one key per 64 B, 2 scattered (key_slot)
 int g_splat_lds = 1;            // 1: per-wave LDS hash table in front of the memory-side atomics (strip_points)
 int g_splat_wgs = 8;            // workgroups per CU of the striped passes
 int g_splat_strips = MAX_STRIPS;   // column strips of the striped passes (1, 2, 4 or 8); pass A measured 61.5 / 75.5 / 70 us at
@@ -964,6 +987,7 @@ struct WsLayout {
     unsigned short *hiz;       // 16-bit far bounds (the region keeps its 4 bytes per block)
     int *prev[2];              // plain path: prev[0] = winners' ids; striped path: positions, double buffered
     unsigned *zimg;
+    size_t key_slots;
     int nbx, nby;
     size_t total;
 };
@@ -976,7 +1000,8 @@ WsLayout ws_layout(void *ws, int B, int W, int H)
     L.hdr = p;
     size_t off = HEADER_BYTES;
     L.keys = (unsigned long long *)(p + off);
-    off += (size_t)nb * W * H * sizeof(unsigned long long);
+    L.key_slots = (size_t)(nb < 8 ? 8 : nb) * W * H;            // >= 8 W H: room for the scattered key layouts of the striped path
+    off += L.key_slots * sizeof(unsigned long long);
     off = (off + 255) / 256 * 256;
     L.nbx = ceil_div(W, 4);
     L.nby = ceil_div(H, 4);
@@ -1007,7 +1032,8 @@ int device_cus()
 }
 
 int resolve_launch(unsigned long long *keys, int nb, int b0, int W, int H, int levels, int32_t *const *idx_levels,
-                   float *const *depth_levels, int level_base, const WsLayout &ws, int keep, hipStream_t stream)
+                   float *const *depth_levels, int level_base, const WsLayout &ws, int keep, hipStream_t stream,
+                   KeySlots ks = KeySlots{0, 0})
 {
     ResolveOut out;
     memset(&out, 0, sizeof(out));
@@ -1018,7 +1044,7 @@ int resolve_launch(unsigned long long *keys, int nb, int b0, int W, int H, int l
     }
     const int tiles_x = ceil_div(W, 32), tiles_y = ceil_div(H, 32);
     hipLaunchKernelGGL(splat_resolve_kernel, dim3(tiles_x * tiles_y, nb), dim3(256), 0, stream, keys, W, H,
-                       levels, out, tiles_x, tiles_y, ws.prev[0], ws.hdr, keep, ws.zimg);
+                       levels, out, tiles_x, tiles_y, ws.prev[0], ws.hdr, keep, ws.zimg, ks);
     READ_CHECK_LAUNCH();
     return READ_OK;
 }
@@ -1113,6 +1139,12 @@ int cells_frame(const CellCloud &cc, const float *M_host, int W, int H, int leve
     READ_CHECK_LAUNCH();
     const unsigned grid = (unsigned)(device_cus() * g_splat_wgs);
     const int items = g_splat_items;
+    KeySlots ks;
+    ks.mode = g_splat_kslot;
+    ks.mask = 1;
+    while (ks.mask < (unsigned)(W * H)) ks.mask <<= 1;
+    ks.mask -= 1;
+    if (ks.mode == 2 && (size_t)ks.mask + 1 > ws.key_slots) ks.mode = 0;      // (a workspace of this size always has 8 W H slots)
     auto pass_a = stats ? (g_splat_lds ? cells_pass_kernel<false, true, false, true> : cells_pass_kernel<false, true, false, false>)
                   : g_splat_zl2 ? cells_pass_kernel<false, false, true, false>
                   : g_splat_lds ? cells_pass_kernel<false, false, false, true> : cells_pass_kernel<false, false, false, false>;
@@ -1120,15 +1152,15 @@ int cells_frame(const CellCloud &cc, const float *M_host, int W, int H, int leve
                   : g_splat_zl2 ? cells_pass_kernel<true, false, true, false>
                   : g_splat_lds ? cells_pass_kernel<true, false, false, true> : cells_pass_kernel<true, false, false, false>;
     hipLaunchKernelGGL(pass_a, dim3(grid), dim3(256), 0, stream, cc, cam, W, H, ws.keys, ws.zimg,
-                       (const unsigned short *)ws.hiz, ws.nbx, ws.hdr, ws.prev[0], ws.prev[1], si, items, stats);
+                       (const unsigned short *)ws.hiz, ws.nbx, ws.hdr, ws.prev[0], ws.prev[1], si, items, stats, ks);
     READ_CHECK_LAUNCH();
     hipLaunchKernelGGL(cells_hiz_kernel, dim3(ceil_div(ws.nbx * ws.nby, 256)), dim3(256), 0, stream,
-                       (const unsigned long long *)ws.keys, ws.zimg, W, H, ws.nbx, ws.nby, ws.hiz);
+                       (const unsigned long long *)ws.keys, ws.zimg, W, H, ws.nbx, ws.nby, ws.hiz, ks);
     READ_CHECK_LAUNCH();
     hipLaunchKernelGGL(pass_b, dim3(grid), dim3(256), 0, stream, cc, cam, W, H, ws.keys, ws.zimg,
-                       (const unsigned short *)ws.hiz, ws.nbx, ws.hdr, ws.prev[0], ws.prev[1], si, items, stats);
+                       (const unsigned short *)ws.hiz, ws.nbx, ws.hdr, ws.prev[0], ws.prev[1], si, items, stats, ks);
     READ_CHECK_LAUNCH();
-    return resolve_launch(ws.keys, 1, 0, W, H, levels, idx_levels, depth_levels, 0, ws, 2, stream);
+    return resolve_launch(ws.keys, 1, 0, W, H, levels, idx_levels, depth_levels, 0, ws, 2, stream, ks);
 }
 
 }  // namespace
@@ -1155,6 +1187,7 @@ void splat_set_cells_sub(int v) { g_splat_cells_sub = v < 0 ? 0 : v; }
 void splat_set_items(int v) { g_splat_items = v >= 4 ? 4 : (v >= 2 ? 2 : 1); }
 void splat_set_zl2(int v) { g_splat_zl2 = v != 0; }
 void splat_set_lds(int v) { g_splat_lds = v != 0; }
+void splat_set_kslot(int v) { g_splat_kslot = v < 0 ? 0 : (v > 2 ? 2 : v); }
 void splat_set_wgs(int v) { g_splat_wgs = v < 1 ? 1 : (v > 16 ? 16 : v); }
 void splat_set_strips(int v) { g_splat_strips = v >= 8 ? 8 : (v >= 4 ? 4 : (v >= 2 ? 2 : 1)); }
 int splat_get(const char *key, int *value)
@@ -1171,6 +1204,7 @@ int splat_get(const char *key, int *value)
     else if (!strcmp(key, "splat_wgs")) *value = g_splat_wgs;
     else if (!strcmp(key, "splat_zl2")) *value = g_splat_zl2;
     else if (!strcmp(key, "splat_lds")) *value = g_splat_lds;
+    else if (!strcmp(key, "splat_kslot")) *value = g_splat_kslot;
     else return 0;
     return 1;
 }

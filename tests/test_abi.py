@@ -46,8 +46,8 @@ def test_bad_arguments_fail_loudly():
     L = _lib.lib()
     # header + one key image + hi-z bounds + two seed images + the depth-bound image of the striped path
     px = 1216 * 352
-    assert L.read_splat_workspace_bytes(1, 1216, 352) == 4096 + px * 8 + 304 * 88 * 4 + 3 * px * 4
-    assert L.read_splat_workspace_bytes(3, 1216, 352) == 4096 + 3 * px * 8 + 304 * 88 * 4 + 3 * px * 4
+    assert L.read_splat_workspace_bytes(1, 1216, 352) == 4096 + 8 * px * 8 + 304 * 88 * 4 + 3 * px * 4
+    assert L.read_splat_workspace_bytes(9, 1216, 352) == 4096 + 8 * px * 8 + 304 * 88 * 4 + 3 * px * 4
     assert L.read_splat_workspace_bytes(0, 10, 10) == 0
     rc = L.read_splat_forward(None, 10, None, 1, 64, 64, 5, None, None, None, 0, None)
     assert rc == -22 and b"xyz" in L.read_last_error()
