@@ -225,9 +225,10 @@ struct SplatHeader {          // first bytes of the workspace
     int W, H;
     int parity;               // which of the two seed images the NEXT striped frame reads
 };
+constexpr int A_BANDS = 8;    // list A of a strip is kept in depth bands, nearest first
 struct StripCounters {        // 256 bytes per strip, at HEADER_STRIPS_OFFSET + 256 * strip
-    int nA, nB;               // list lengths, written by the classification blocks of the seed launch (agent-scope atomics)
-    int pad0[62];
+    int nA[A_BANDS], nB;      // list lengths, written by the classification blocks of the seed launch (agent-scope atomics)
+    int pad0[64 - A_BANDS - 1];
 };
 constexpr size_t HEADER_BYTES = 4096;
 constexpr size_t HEADER_STATS_OFFSET = 64;      // 16 x u64 debug counters (read_tuning_set("splat_stats", 1))
@@ -363,7 +364,7 @@ struct CellCloud {             // device pointers into the blob
     const float4 *pts;         // nchunks * 1024 records (x, y, z, bits of the original id), Morton order, tail padded
                                // with copies of the last point
     const float *aabb;         // nchunks * 8: min xyz, max xyz, 2 pad
-    int *list_a;               // scratch: MAX_STRIPS x nchunks chunk ids of this frame's lists A
+    int *list_a;               // scratch: MAX_STRIPS x A_BANDS x nchunks chunk ids of this frame's lists A (by depth band)
     CellEntryB *list_b;        // scratch: MAX_STRIPS x nchunks
     int nchunks;
 };
@@ -384,7 +385,7 @@ __device__ __forceinline__ int strip_of_column(const StripInfo &si, int x)
 
 // class of one chunk for camera M: 0 dropped, 1 list A, 2 list B (then e fills in); [cx0, cx1] = pixel columns
 __device__ __forceinline__ int classify_chunk(const float *bb, const float *M, int W, int H, float w_split, bool boot,
-                                              CellEntryB &e, int &cx0, int &cx1)
+                                              CellEntryB &e, int &cx0, int &cx1, float &wmin_out)
 {
     constexpr float GAMMA = 1e-6f;
     const float mn[3] = {bb[0], bb[1], bb[2]}, mx[3] = {bb[3], bb[4], bb[5]};
@@ -405,6 +406,7 @@ __device__ __forceinline__ int classify_chunk(const float *bb, const float *M, i
     }
     cx0 = 0;
     cx1 = W - 1;
+    wmin_out = wmin > 0.0f ? wmin : 0.0f;
     if (!(wmin > fmaxf(1e-3f, 1e-5f * S[3]))) return 1;           // a corner at / behind the camera plane: never culled
     float lo[3] = {3.0e38f, 3.0e38f, 3.0e38f}, hi[3] = {-3.0e38f, -3.0e38f, -3.0e38f};
 #pragma unroll
@@ -445,8 +447,11 @@ __device__ __forceinline__ int classify_chunk(const float *bb, const float *M, i
 __device__ __forceinline__ void classify_block(const CellCloud &cc, const float *M, int W, int H, int sub, float near_count,
                                                int block, void *hdr, const StripInfo &si)
 {
-    __shared__ int s_cnt[4][2 * MAX_STRIPS];
-    __shared__ int s_base[2 * MAX_STRIPS];
+    constexpr int PER_STRIP = A_BANDS + 1, LISTS = MAX_STRIPS * PER_STRIP;      // per strip: the bands of list A, then list B
+    __shared__ int s_cnt[LISTS];
+    __shared__ int s_base[LISTS];
+    if (threadIdx.x < LISTS) s_cnt[threadIdx.x] = 0;
+    __syncthreads();
     const int chunk = block * 256 + threadIdx.x;
     // list A takes the chunks nearer than the distance within which a pixel expects `near_count` points
     const float focal = sqrtf(M[0] * M[0] + M[1] * M[1] + M[2] * M[2]) * (float)W * 0.5f;
@@ -456,47 +461,33 @@ __device__ __forceinline__ void classify_block(const CellCloud &cc, const float 
     e.bx = e.by = 0;
     e.e_thr = 0.0f;
     int cls = 0, cx0 = 0, cx1 = 0;
-    if (chunk < cc.nchunks)
-        cls = classify_chunk(cc.aabb + (size_t)chunk * 8, M, W, H, w_split, sub > 0 && chunk % sub == 0, e, cx0, cx1);
+    float wmin = 0.0f;
+    const bool boot = sub > 0 && chunk % sub == 0;
+    if (chunk < cc.nchunks) cls = classify_chunk(cc.aabb + (size_t)chunk * 8, M, W, H, w_split, boot, e, cx0, cx1, wmin);
     // A chunk belongs to ONE strip — the one that holds the centre column of its rectangle — and all of its points are
     // processed there; the few that fall into a neighbouring strip read and write that strip's part of zimg from the "wrong"
     // XCD (a staler bound, never a wrong result).  Listing a chunk in every strip it touches kept the bounds exact but read
-    // near chunks twice: pass A fetched 287 MB per frame for 93 MB of records and ran at the HBM rate (4.5 TB/s).
-    const int s0 = strip_of_column(si, (cx0 + cx1) >> 1), s1 = s0;
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    for (int s = 0; s < si.ns; ++s) {
-        const bool in = cls != 0 && s >= s0 && s <= s1;
-        const unsigned long long ma = __ballot(in && cls == 1), mb = __ballot(in && cls == 2);
-        if (lane == 0) {
-            s_cnt[wave][s] = __popcll(ma);
-            s_cnt[wave][MAX_STRIPS + s] = __popcll(mb);
-        }
+    // near chunks twice (pass A fetched 287 MB per frame for 93 MB of records).
+    const int strip = strip_of_column(si, (cx0 + cx1) >> 1);
+    // Depth band of a list-A chunk: the waves of a strip walk the bands nearest first, so a pixel's nearest candidates
+    // arrive first and the farther ones fail the bound instead of each costing a memory-side atomic (pass A's time is the
+    // number of atomics).  Chunk counts grow with the cube of the distance: equal-population bands at t^3.
+    const float t = fminf(wmin / fmaxf(w_split, 1e-20f), 1.0f);
+    const int band = wmin >= w_split ? A_BANDS - 1 : min(A_BANDS - 1, (int)((float)A_BANDS * t * t * t));
+    const int l = strip * PER_STRIP + (cls == 1 ? band : A_BANDS);
+    const int mine = cls ? atomicAdd(&s_cnt[l], 1) : 0;            // position inside the block's share (LDS atomic)
+    __syncthreads();
+    if (threadIdx.x < LISTS) {
+        const int s = threadIdx.x / PER_STRIP, k = threadIdx.x % PER_STRIP;
+        const int tot = s_cnt[threadIdx.x];
+        StripCounters *sc = strip_counters(hdr, s);
+        s_base[threadIdx.x] = tot ? atomicAdd(k < A_BANDS ? &sc->nA[k] : &sc->nB, tot) : 0;     // one atomic per block and list
     }
     __syncthreads();
-    if (threadIdx.x < 2 * MAX_STRIPS) {
-        const int l = threadIdx.x, s = l & (MAX_STRIPS - 1);
-        int base = 0;
-        if (s < si.ns) {
-            const int tot = s_cnt[0][l] + s_cnt[1][l] + s_cnt[2][l] + s_cnt[3][l];
-            StripCounters *sc = strip_counters(hdr, s);
-            if (tot) base = atomicAdd(l < MAX_STRIPS ? &sc->nA : &sc->nB, tot);
-        }
-        s_base[l] = base;
-    }
-    __syncthreads();
-    const unsigned long long below = lane == 0 ? 0ull : (~0ull >> (64 - lane));
-    for (int s = 0; s < si.ns; ++s) {
-        const bool in = cls != 0 && s >= s0 && s <= s1;
-        const unsigned long long ma = __ballot(in && cls == 1), mb = __ballot(in && cls == 2);
-        if (!in) continue;
-        const int l = cls == 1 ? s : MAX_STRIPS + s;
-        int off = s_base[l] + __popcll((cls == 1 ? ma : mb) & below);
-        for (int w = 0; w < wave; ++w) off += s_cnt[w][l];
-        if (cls == 1)
-            cc.list_a[(size_t)s * cc.nchunks + off] = chunk;
-        else
-            cc.list_b[(size_t)s * cc.nchunks + off] = e;
-    }
+    if (cls == 1)
+        cc.list_a[((size_t)strip * A_BANDS + band) * cc.nchunks + s_base[l] + mine] = chunk;
+    else if (cls == 2)
+        cc.list_b[(size_t)strip * cc.nchunks + s_base[l] + mine] = e;
 }
 
 __global__ __launch_bounds__(256) void cells_seed_classify_kernel(CellCloud cc, Cam1 cam, int W, int H,
@@ -656,11 +647,19 @@ __global__ __launch_bounds__(256) void cells_pass_kernel(CellCloud cc, Cam1 cam,
     const StripCounters *sc = strip_counters(hdr_v, s);
     const int xlo = 0, xhi = W;                                     // a chunk is processed whole by the strip that lists it
     if (!PASS_B) {
-        const int *list_a = cc.list_a + (size_t)s * cc.nchunks;
-        const int n_items = sc->nA * sub_items, rounds = 4 / sub_items;
+        const int rounds = 4 / sub_items;
+        int n_items = 0;
+        for (int b = 0; b < A_BANDS; ++b) n_items += sc->nA[b] * sub_items;
+        int band = 0, band_first = 0, band_items = sc->nA[0] * sub_items;      // items [band_first, band_first + band_items)
         for (int t = wave; t < n_items; t += n_waves) {
-            const int li = t / sub_items, part = t - li * sub_items;
-            const int chunk = __builtin_amdgcn_readfirstlane(list_a[li]);
+            while (t >= band_first + band_items) {                               // t only grows: the cursor moves forward
+                band_first += band_items;
+                ++band;
+                band_items = sc->nA[band] * sub_items;
+            }
+            const int tl = t - band_first;
+            const int li = tl / sub_items, part = tl - li * sub_items;
+            const int chunk = __builtin_amdgcn_readfirstlane(cc.list_a[((size_t)s * A_BANDS + band) * cc.nchunks + li]);
             ++n_run;
             strip_points<STATS, ZL2, LDS>(cc, M, W, H, xlo, xhi, keys, zimg, next, chunk * CELL_CHUNK + part * rounds * 256, rounds,
                                           lane, st_in, st_atomics, tag, hkey, hpos, ks);
@@ -892,7 +891,8 @@ __global__ __launch_bounds__(256) void splat_resolve_kernel(unsigned long long *
         SplatHeader *hdr = (SplatHeader *)hdr_v;
         if (keep == 2 && t < MAX_STRIPS) {
             StripCounters *sc = strip_counters(hdr_v, t);
-            sc->nA = sc->nB = 0;
+            for (int b = 0; b < A_BANDS; ++b) sc->nA[b] = 0;
+            sc->nB = 0;
         }
         if (t == 0) {
             // any integer below the padded point count is the position of a real point, i.e. a valid seed, so the two
@@ -972,7 +972,8 @@ int g_splat_cells_sub = 32;    // list A also takes every n-th chunk (0: none): 
 int g_splat_seeds = 1;         // 0: no warm start from the previous frame's front points (A/B)
 int g_splat_items = 4;         // work items per chunk in the striped passes (1, 2 or 4): 0.101 / 0.101 / 0.097 ms per frame
 int g_splat_zl2 = 0;            // 1: early-z loads bypass the L1 (sc1); measured slower (0.107 vs 0.101 ms)
-int g_splat_kslot = 0;          // key-image layout of the striped path: 0 linear, 1 one key per 64 B, 2 scattered (key_slot)
+int g_splat_kslot = 0;          // key-image layout of the striped path: 0 linear, 1 one key per 64 B, 2 scattered (key_slot):
+                                // pass A 60.7 / 66.0 / 61.9 us — the atomics do not serialise on neighbouring lines, their NUMBER is the cost
 int g_splat_lds = 1;            // 1: per-wave LDS hash table in front of the memory-side atomics (strip_points)
 int g_splat_wgs = 8;            // workgroups per CU of the striped passes
 int g_splat_strips = MAX_STRIPS;   // column strips of the striped passes (1, 2, 4 or 8); pass A measured 61.5 / 75.5 / 70 us at
@@ -1288,7 +1289,7 @@ CellOffsets cell_offsets(int64_t n)
     o.pts = CELL_HEADER_BYTES;
     o.aabb = o.pts + nc * CELL_CHUNK * sizeof(float4);
     o.list_a = o.aabb + nc * 8 * sizeof(float);                      // per-frame scratch (written by the passes)
-    o.list_b = o.list_a + ((MAX_STRIPS * nc * sizeof(int) + 255) & ~(size_t)255);
+    o.list_b = o.list_a + ((MAX_STRIPS * A_BANDS * nc * sizeof(int) + 255) & ~(size_t)255);
     o.total = o.list_b + MAX_STRIPS * nc * sizeof(CellEntryB);
     return o;
 }
