@@ -385,7 +385,7 @@ __device__ __forceinline__ int strip_of_column(const StripInfo &si, int x)
 
 // class of one chunk for camera M: 0 dropped, 1 list A, 2 list B (then e fills in); [cx0, cx1] = pixel columns
 __device__ __forceinline__ int classify_chunk(const float *bb, const float *M, int W, int H, float w_split, bool boot,
-                                              CellEntryB &e, int &cx0, int &cx1, float &wmin_out)
+                                              CellEntryB &e, int &cx0, int &cx1, float &wmin_out, int &area_out)
 {
     constexpr float GAMMA = 1e-6f;
     const float mn[3] = {bb[0], bb[1], bb[2]}, mx[3] = {bb[3], bb[4], bb[5]};
@@ -406,6 +406,7 @@ __device__ __forceinline__ int classify_chunk(const float *bb, const float *M, i
     }
     cx0 = 0;
     cx1 = W - 1;
+    area_out = W * H;
     wmin_out = wmin > 0.0f ? wmin : 0.0f;
     if (!(wmin > fmaxf(1e-3f, 1e-5f * S[3]))) return 1;           // a corner at / behind the camera plane: never culled
     float lo[3] = {3.0e38f, 3.0e38f, 3.0e38f}, hi[3] = {-3.0e38f, -3.0e38f, -3.0e38f};
@@ -434,6 +435,7 @@ __device__ __forceinline__ int classify_chunk(const float *bb, const float *M, i
     const unsigned uy1 = (unsigned)fminf(fmaxf(py1, 0.0f), (float)(H - 1));
     cx0 = (int)ux0;
     cx1 = (int)ux1;
+    area_out = (int)((ux1 - ux0 + 1u) * (uy1 - uy0 + 1u));
     if (wmin < w_split || boot) return 1;
     const float dmin = (fmaxf(lo[2], -1.0f) + 1.0f) * 0.5f;
     e.e_thr = (1.0f - dmin) + 2.0f * (0.5f * ez + 2e-7f);
@@ -460,10 +462,13 @@ __device__ __forceinline__ void classify_block(const CellCloud &cc, const float 
     e.chunk = chunk;
     e.bx = e.by = 0;
     e.e_thr = 0.0f;
-    int cls = 0, cx0 = 0, cx1 = 0;
+    int cls = 0, cx0 = 0, cx1 = 0, area = 0;
     float wmin = 0.0f;
     const bool boot = sub > 0 && chunk % sub == 0;
-    if (chunk < cc.nchunks) cls = classify_chunk(cc.aabb + (size_t)chunk * 8, M, W, H, w_split, boot, e, cx0, cx1, wmin);
+    if (chunk < cc.nchunks) cls = classify_chunk(cc.aabb + (size_t)chunk * 8, M, W, H, w_split, boot, e, cx0, cx1, wmin, area);
+    // Dense chunk: more points than pixels in its rectangle — its points share pixels, so the passes fold them in the LDS
+    // table first (strip_points); a sparse chunk's candidates each own a pixel and go to memory directly.  Bit 31 of the entry.
+    const int dense_bit = area < CELL_CHUNK ? (int)0x80000000u : 0;
     // A chunk belongs to ONE strip — the one that holds the centre column of its rectangle — and all of its points are
     // processed there; the few that fall into a neighbouring strip read and write that strip's part of zimg from the "wrong"
     // XCD (a staler bound, never a wrong result).  Listing a chunk in every strip it touches kept the bounds exact but read
@@ -484,8 +489,9 @@ __device__ __forceinline__ void classify_block(const CellCloud &cc, const float 
         s_base[threadIdx.x] = tot ? atomicAdd(k < A_BANDS ? &sc->nA[k] : &sc->nB, tot) : 0;     // one atomic per block and list
     }
     __syncthreads();
+    e.chunk = chunk | dense_bit;
     if (cls == 1)
-        cc.list_a[((size_t)strip * A_BANDS + band) * cc.nchunks + s_base[l] + mine] = chunk;
+        cc.list_a[((size_t)strip * A_BANDS + band) * cc.nchunks + s_base[l] + mine] = chunk | dense_bit;
     else if (cls == 2)
         cc.list_b[(size_t)strip * cc.nchunks + s_base[l] + mine] = e;
 }
@@ -533,7 +539,7 @@ template <bool STATS, bool ZL2, bool LDS>
 __device__ __forceinline__ void strip_points(const CellCloud &cc, const float *M, int W, int H, int xlo, int xhi,
                                              unsigned long long *keys, unsigned *zimg, int *next, int first, int rounds,
                                              int lane, unsigned &st_in, unsigned &st_atomics, unsigned *tag,
-                                             unsigned long long *hkey, int *hpos, const KeySlots ks)
+                                             unsigned long long *hkey, int *hpos, const KeySlots ks, bool use_lds)
 {
     float4 q[4], qn[4];
 #pragma unroll
@@ -568,7 +574,7 @@ __device__ __forceinline__ void strip_points(const CellCloud &cc, const float *M
             const unsigned long long key = ((unsigned long long)dbits[k] << 32) | __float_as_uint(q[k].w);
             if (dbits[k] < bound[k]) zimg[pix[k]] = dbits[k];
             bool direct = true;
-            if (LDS) {
+            if (LDS && use_lds) {
                 unsigned h = ((unsigned)pix[k] * 2654435761u) >> 24;
 #pragma unroll
                 for (int probe = 0; probe < 2 && direct; ++probe, h = (h + 1) & (LDS_SLOTS - 1)) {
@@ -585,7 +591,7 @@ __device__ __forceinline__ void strip_points(const CellCloud &cc, const float *M
                 if (STATS) st_atomics++;
             }
         }
-        if (LDS) {
+        if (LDS && use_lds) {
             // the wave's own table: its LDS operations complete in program order, no barrier needed
             __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
 #pragma unroll
@@ -659,10 +665,11 @@ __global__ __launch_bounds__(256) void cells_pass_kernel(CellCloud cc, Cam1 cam,
             }
             const int tl = t - band_first;
             const int li = tl / sub_items, part = tl - li * sub_items;
-            const int chunk = __builtin_amdgcn_readfirstlane(cc.list_a[((size_t)s * A_BANDS + band) * cc.nchunks + li]);
+            const int entry = __builtin_amdgcn_readfirstlane(cc.list_a[((size_t)s * A_BANDS + band) * cc.nchunks + li]);
+            const int chunk = entry & 0x7fffffff;
             ++n_run;
             strip_points<STATS, ZL2, LDS>(cc, M, W, H, xlo, xhi, keys, zimg, next, chunk * CELL_CHUNK + part * rounds * 256, rounds,
-                                          lane, st_in, st_atomics, tag, hkey, hpos, ks);
+                                          lane, st_in, st_atomics, tag, hkey, hpos, ks, entry < 0);
         }
     } else {
         const CellEntryB *list_b = cc.list_b + (size_t)s * cc.nchunks;
@@ -701,10 +708,11 @@ __global__ __launch_bounds__(256) void cells_pass_kernel(CellCloud cc, Cam1 cam,
             while (todo) {
                 const int j = __builtin_ctz(todo);
                 todo &= todo - 1;
-                const int chunk = __builtin_amdgcn_readfirstlane(j == 0 ? e0.chunk : (j == 1 ? e1.chunk : e2.chunk));
+                const int entry = __builtin_amdgcn_readfirstlane(j == 0 ? e0.chunk : (j == 1 ? e1.chunk : e2.chunk));
+                const int chunk = entry & 0x7fffffff;
                 ++n_run;
                 strip_points<STATS, ZL2, LDS>(cc, M, W, H, xlo, xhi, keys, zimg, next, chunk * CELL_CHUNK, 4, lane, st_in, st_atomics,
-                                              tag, hkey, hpos, ks);
+                                              tag, hkey, hpos, ks, entry < 0);
             }
         }
     }
