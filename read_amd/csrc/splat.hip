@@ -983,7 +983,8 @@ int g_splat_zl2 = 0;            // 1: early-z loads bypass the L1 (sc1); measure
 int g_splat_kslot = 0;          // key-image layout of the striped path: 0 linear, 1 one key per 64 B, 2 scattered (key_slot):
                                 // pass A 60.7 / 66.0 / 61.9 us — the atomics do not serialise on neighbouring lines, their NUMBER is the cost
 int g_splat_lds = 1;            // 1: per-wave LDS hash table in front of the memory-side atomics (strip_points)
-int g_splat_wgs = 8;            // workgroups per CU of the striped passes
+int g_splat_wgs = 4;            // workgroups per CU of the striped passes: 0.0996 / 0.0936 / 0.0893 / 0.0927 / 0.0923 ms at 2 / 3 / 4 / 6 / 8
+                                // (fewer waves = more rounds per wave = finer front-to-back order over the depth bands)
 int g_splat_strips = MAX_STRIPS;   // column strips of the striped passes (1, 2, 4 or 8); pass A measured 61.5 / 75.5 / 70 us at
                                // 8 / 2 / 1 (with 4 items per chunk): its time follows the number of atomics (0.92 M / 1.16 M)
 
