@@ -985,8 +985,10 @@ int g_splat_kslot = 0;          // key-image layout of the striped path: 0 linea
 int g_splat_lds = 1;            // 1: per-wave LDS hash table in front of the memory-side atomics (strip_points)
 int g_splat_wgs = 4;            // workgroups per CU of the striped passes: 0.0996 / 0.0936 / 0.0893 / 0.0927 / 0.0923 ms at 2 / 3 / 4 / 6 / 8
                                 // (fewer waves = more rounds per wave = finer front-to-back order over the depth bands)
-int g_splat_strips = MAX_STRIPS;   // column strips of the striped passes (1, 2, 4 or 8); pass A measured 61.5 / 75.5 / 70 us at
-                               // 8 / 2 / 1 (with 4 items per chunk): its time follows the number of atomics (0.92 M / 1.16 M)
+int g_splat_strips = 1;         // column strips of the striped passes (1, 2, 4 or 8).  8 was best while a strip's list was walked in
+                               // Morton order (pass A 61.5 / 75.5 / 70 us at 8 / 2 / 1: fewer atomics with exact bounds); with the
+                               // depth bands ONE global list wins — global front-to-back order and perfect balance: bench
+                               // 0.0866 / 0.0867 / 0.0951 ms at 1 / 2 / 8 strips, street scene 0.099 vs 0.138 ms at 1 vs 8
 
 // Workspace layout (fixed by the (B, W, H) it was sized for; one workspace serves one such triple):
 //   [header 4096 B][key images: min(B,8) x W*H x 8 B][hi-z bounds: ceil(W/4)*ceil(H/4) x 4 B][seed image 0: W*H x 4 B]

@@ -63,7 +63,7 @@ def test_bad_arguments_fail_loudly():
     for bad_mode in (2, 4, 5, 6):
         assert L.read_tuning_set(b"splat_mode", bad_mode) == -22
     st = _lib.tuning_state()
-    assert st["splat_mode"] == 7 and st["splat_cells"] == 1 and st["splat_strips"] == 8 and st["splat_items"] == 4 and st["splat_lds"] == 1 and st["splat_kslot"] == 0 and st["conv_wino"] == 1 << 30 and "conv_ablate" not in st
+    assert st["splat_mode"] == 7 and st["splat_cells"] == 1 and st["splat_strips"] == 1 and st["splat_items"] == 4 and st["splat_lds"] == 1 and st["splat_kslot"] == 0 and st["conv_wino"] == 1 << 30 and "conv_ablate" not in st
 
 
 def test_weight_packing_layout():

@@ -196,7 +196,7 @@ def test_cell_ordered_passes_are_exact_for_hard_cameras(hip):
         _lib.check(L.read_tuning_set(b"splat_near", 12))
     # work-item granularity of the striped passes, no warm start, no every-n-th chunk in pass A
     try:
-        for key, val in ((b"splat_items", 2), (b"splat_items", 1), (b"splat_seeds", 0), (b"splat_cells_sub", 0), (b"splat_strips", 1),
+        for key, val in ((b"splat_items", 2), (b"splat_items", 1), (b"splat_seeds", 0), (b"splat_cells_sub", 0), (b"splat_strips", 8),
                          (b"splat_strips", 2), (b"splat_zl2", 1), (b"splat_lds", 0), (b"splat_kslot", 1), (b"splat_kslot", 2)):
             _lib.check(L.read_tuning_set(key, val))
             for k in (1, 2, 5):
@@ -206,10 +206,10 @@ def test_cell_ordered_passes_are_exact_for_hard_cameras(hip):
                 for l in range(5):
                     assert np.array_equal(idx[l][0].cpu().numpy(), oi[l]), f"{key} {val} pose {k} level {l}"
                     assert np.array_equal(dep[l][0].cpu().numpy().view(np.uint32), od[l].view(np.uint32))
-            for k_, v_ in ((b"splat_items", 4), (b"splat_seeds", 1), (b"splat_cells_sub", 32), (b"splat_strips", 8), (b"splat_zl2", 0), (b"splat_lds", 1), (b"splat_kslot", 0)):
+            for k_, v_ in ((b"splat_items", 4), (b"splat_seeds", 1), (b"splat_cells_sub", 32), (b"splat_strips", 1), (b"splat_zl2", 0), (b"splat_lds", 1), (b"splat_kslot", 0)):
                 _lib.check(L.read_tuning_set(k_, v_))
     finally:
-        for k_, v_ in ((b"splat_items", 4), (b"splat_seeds", 1), (b"splat_cells_sub", 32), (b"splat_strips", 8), (b"splat_zl2", 0), (b"splat_lds", 1), (b"splat_kslot", 0)):
+        for k_, v_ in ((b"splat_items", 4), (b"splat_seeds", 1), (b"splat_cells_sub", 32), (b"splat_strips", 1), (b"splat_zl2", 0), (b"splat_lds", 1), (b"splat_kslot", 0)):
             _lib.check(L.read_tuning_set(k_, v_))
     # large world coordinates: the same cloud and camera moved 5 km away (projection rounding grows ~100x)
     off = np.array([5000.0, -3000.0, 4000.0], np.float32)

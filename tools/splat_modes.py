@@ -15,7 +15,7 @@ from read_amd import _lib, camera, synthetic          # noqa: E402
 from read_amd.raster import PointCloudRasterizer      # noqa: E402
 
 DEFAULTS = {"splat_mode": 7, "splat_cells": 1, "splat_seeds": 1, "splat_near": 12, "splat_cells_sub": 32, "splat_items": 4,
-            "splat_subset": 8, "splat_strips": 8, "splat_zl2": 0, "splat_wgs": 4, "splat_lds": 1, "splat_kslot": 0}
+            "splat_subset": 8, "splat_strips": 1, "splat_zl2": 0, "splat_wgs": 4, "splat_lds": 1, "splat_kslot": 0}
 VARIANTS = [
     ("default: striped cell-ordered passes, zimg early-z, warm start", {}),
     ("no LDS table in front of the atomics", {"splat_lds": 0}),
@@ -24,9 +24,7 @@ VARIANTS = [
     ("early-z loads from L2 (sc1)", {"splat_zl2": 1}),
     ("4 strips", {"splat_strips": 4}),
     ("2 strips", {"splat_strips": 2}),
-    ("1 strip (no XCD affinity)", {"splat_strips": 1}),
-    ("1 strip, items per chunk 2", {"splat_strips": 1, "splat_items": 2}),
-    ("1 strip, items per chunk 4", {"splat_strips": 1, "splat_items": 4}),
+    ("8 strips (XCD affinity of the bound image)", {"splat_strips": 8}),
     ("items per chunk 2", {"splat_items": 2}),
     ("items per chunk 1", {"splat_items": 1}),
     ("near split 6 points/pixel", {"splat_near": 6}),
