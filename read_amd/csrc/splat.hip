@@ -349,6 +349,7 @@ struct CellHeader {            // first 256 bytes of the cell-ordered cloud (dev
     float density;             // points per unit volume of the bounding box
 };
 constexpr int CELL_CHUNK = 1024;
+constexpr int STICKY_FRAMES = 8;
 constexpr int CELL_VERSION = 2;
 constexpr size_t CELL_HEADER_BYTES = 256;
 
@@ -366,6 +367,7 @@ struct CellCloud {             // device pointers into the blob
     const float *aabb;         // nchunks * 8: min xyz, max xyz, 2 pad
     int *list_a;               // scratch: MAX_STRIPS x A_BANDS x nchunks chunk ids of this frame's lists A (by depth band)
     CellEntryB *list_b;        // scratch: MAX_STRIPS x nchunks
+    unsigned char *sticky;     // scratch: per chunk, frames for which a list-B chunk that survived the bounds stays in list A
     int nchunks;
 };
 
@@ -477,6 +479,13 @@ __device__ __forceinline__ void classify_block(const CellCloud &cc, const float 
     // Depth band of a list-A chunk: the waves of a strip walk the bands nearest first, so a pixel's nearest candidates
     // arrive first and the farther ones fail the bound instead of each costing a memory-side atomic (pass A's time is the
     // number of atomics).  Chunk counts grow with the cube of the distance: equal-population bands at t^3.
+    // A list-B chunk that survived the bound test is processed by ONE wave at the tail of pass B (the 26 survivors of the
+    // benchmark scene cost ~8 us that way).  Survivors are stable from frame to frame, so pass B marks them and the next
+    // STICKY_FRAMES classifications put them into list A, where they are spread over the whole grid; then they are tested again.
+    if (cls == 2 && cc.sticky[chunk]) {
+        cc.sticky[chunk] -= 1;
+        cls = 1;
+    }
     const float t = fminf(wmin / fmaxf(w_split, 1e-20f), 1.0f);
     const int band = wmin >= w_split ? A_BANDS - 1 : min(A_BANDS - 1, (int)((float)A_BANDS * t * t * t));
     const int l = strip * PER_STRIP + (cls == 1 ? band : A_BANDS);
@@ -710,6 +719,7 @@ __global__ __launch_bounds__(256) void cells_pass_kernel(CellCloud cc, Cam1 cam,
                 todo &= todo - 1;
                 const int entry = __builtin_amdgcn_readfirstlane(j == 0 ? e0.chunk : (j == 1 ? e1.chunk : e2.chunk));
                 const int chunk = entry & 0x7fffffff;
+                if (lane == 0) cc.sticky[chunk] = STICKY_FRAMES;
                 ++n_run;
                 strip_points<STATS, ZL2, LDS>(cc, M, W, H, xlo, xhi, keys, zimg, next, chunk * CELL_CHUNK, 4, lane, st_in, st_atomics,
                                               tag, hkey, hpos, ks, entry < 0);
@@ -1291,7 +1301,7 @@ namespace {
 size_t cells_chunks(int64_t n) { return (size_t)((n + CELL_CHUNK - 1) / CELL_CHUNK); }
 
 struct CellOffsets {
-    size_t pts, aabb, list_a, list_b, total;
+    size_t pts, aabb, list_a, list_b, sticky, total;
 };
 CellOffsets cell_offsets(int64_t n)
 {
@@ -1301,7 +1311,8 @@ CellOffsets cell_offsets(int64_t n)
     o.aabb = o.pts + nc * CELL_CHUNK * sizeof(float4);
     o.list_a = o.aabb + nc * 8 * sizeof(float);                      // per-frame scratch (written by the passes)
     o.list_b = o.list_a + ((MAX_STRIPS * A_BANDS * nc * sizeof(int) + 255) & ~(size_t)255);
-    o.total = o.list_b + MAX_STRIPS * nc * sizeof(CellEntryB);
+    o.sticky = o.list_b + MAX_STRIPS * nc * sizeof(CellEntryB);
+    o.total = o.sticky + ((nc + 255) & ~(size_t)255);
     return o;
 }
 
@@ -1420,6 +1431,7 @@ extern "C" int read_splat_cells_build_host(const float *xyz, int64_t n, void *bl
     // 4. records + boxes
     char *base = (char *)blob;
     memset(base, 0, CELL_HEADER_BYTES);
+    memset(base + o.sticky, 0, o.total - o.sticky);
     float *rec = (float *)(base + o.pts);
     float *bb = (float *)(base + o.aabb);
     const size_t nc = cells_chunks(n);
@@ -1484,6 +1496,7 @@ extern "C" int read_splat_forward_cells(const float *xyz, void *cells, int64_t n
     cc.aabb = (const float *)((const char *)cells + o.aabb);
     cc.list_a = (int *)((char *)cells + o.list_a);
     cc.list_b = (CellEntryB *)((char *)cells + o.list_b);
+    cc.sticky = (unsigned char *)cells + o.sticky;
     cc.nchunks = (int)cells_chunks(n);
     const WsLayout L = ws_layout(ws, B, W, H);
     return cells_frame(cc, M_host, W, H, levels, idx_levels, depth_levels, L, as_stream(stream));

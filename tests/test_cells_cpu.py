@@ -18,7 +18,7 @@ def _parse(blob, n):
     ids = np.ascontiguousarray(rec[:, 3]).view(np.uint32)
     o += nc * 1024 * 16
     aabb = np.frombuffer(blob[o:o + nc * 32].tobytes(), np.float32).reshape(-1, 8)
-    scratch = ((8 * 8 * nc * 4 + 255) // 256) * 256 + 8 * nc * 16   # per-frame chunk lists: 8 strips x (8 bands of A, B)
+    scratch = ((8 * 8 * nc * 4 + 255) // 256) * 256 + 8 * nc * 16 + ((nc + 255) // 256) * 256   # chunk lists: 8 strips x (8 bands of A, B); sticky flags
     assert o + nc * 32 + scratch == len(blob)
     return hdr_n, int(nchunks), int(version), bbox, density, xs, ids, aabb
 
