@@ -98,11 +98,6 @@ __device__ __forceinline__ void fold_key_agent(unsigned long long *k, unsigned l
 // Mode 2: slot (p * odd) mod 2^k, a bijection that scatters neighbouring pixels over the whole image — the memory-side atomic
 // units serialise atomics that hit the same line / channel, and the candidates of a round are Morton neighbours, i.e.
 // pixels of a few adjacent 128-byte lines (read_tuning_set("splat_kslot", m); measured in profiles/README.md).
-struct HizMips {
-    int off[5];              // element offset of level k in the bound image (level 0 = the 4x4-pixel blocks)
-    int nx[5], ny[5];
-};
-
 struct KeySlots {
     int mode;
     unsigned mask;           // 2^k - 1 >= W*H - 1 (mode 2)
@@ -635,7 +630,7 @@ __global__ __launch_bounds__(256) void cells_pass_kernel(CellCloud cc, Cam1 cam,
                                                          unsigned long long *keys, unsigned *zimg,
                                                          const unsigned short *__restrict__ hiz_g, int nbx, void *hdr_v,
                                                          int *pos0, int *pos1, StripInfo si, int sub_items,
-                                                         unsigned long long *stats, KeySlots ks, HizMips mp)
+                                                         unsigned long long *stats, KeySlots ks)
 {
     __shared__ unsigned s_tag[LDS ? 4 * LDS_SLOTS : 1];
     __shared__ unsigned long long s_key[LDS ? 4 * LDS_SLOTS : 1];
@@ -688,71 +683,51 @@ __global__ __launch_bounds__(256) void cells_pass_kernel(CellCloud cc, Cam1 cam,
     } else {
         const CellEntryB *list_b = cc.list_b + (size_t)s * cc.nchunks;
         const int n_list = sc->nB;
-        // Stage 1, one list entry per LANE: the coarsest level of the bound image at which the chunk's rectangle spans at
-        // most 2 x 2 texels gives a conservative far bound from four 2-byte loads; a texel covers more than the rectangle,
-        // so this can only fail to cull.  Stage 2, one undecided entry per WAVE: the exact minimum over the rectangle's blocks;
-        // chunks that survive it are processed like pass-A chunks (and stay in list A for the next frames, classify_block).
-        for (int t0 = wave * 64; t0 < n_list; t0 += n_waves * 64) {
-            const int t = t0 + lane;
-            CellEntryB e;
-            e.chunk = 0;
-            e.bx = e.by = 0;
-            e.e_thr = 0.0f;
-            bool undecided = false;
-            if (t < n_list) {
-                e = list_b[t];
-                const int bx0 = (int)(e.bx >> 16), bx1 = (int)(e.bx & 0xffffu), by0 = (int)(e.by >> 16), by1 = (int)(e.by & 0xffffu);
-                int k = 0;
-                while (k < 4 && (((bx1 >> k) - (bx0 >> k)) > 1 || ((by1 >> k) - (by0 >> k)) > 1)) ++k;
-                undecided = true;
-                if (((bx1 >> k) - (bx0 >> k)) <= 1 && ((by1 >> k) - (by0 >> k)) <= 1) {
-                    const unsigned short *lv = hiz_g + mp.off[k];
-                    const int x0 = bx0 >> k, x1 = min(bx1 >> k, mp.nx[k] - 1), y0 = by0 >> k, y1 = min(by1 >> k, mp.ny[k] - 1);
-                    const float e00 = __uint_as_float((unsigned)lv[y0 * mp.nx[k] + x0] << 16);
-                    const float e01 = __uint_as_float((unsigned)lv[y0 * mp.nx[k] + x1] << 16);
-                    const float e10 = __uint_as_float((unsigned)lv[y1 * mp.nx[k] + x0] << 16);
-                    const float e11 = __uint_as_float((unsigned)lv[y1 * mp.nx[k] + x1] << 16);
-                    if (e.e_thr < fminf(fminf(e00, e01), fminf(e10, e11))) undecided = false;     // behind every bound: culled
-                }
-                if (!undecided) ++n_cull;
-            }
-            unsigned long long todo = __ballot(undecided);
-            while (todo) {
-                const int src = __builtin_ctzll(todo);
-                todo &= todo - 1;
-                const int entry = __builtin_amdgcn_readfirstlane(__shfl(e.chunk, src));
-                const unsigned ebx = (unsigned)__builtin_amdgcn_readfirstlane((int)__shfl((int)e.bx, src));
-                const unsigned eby = (unsigned)__builtin_amdgcn_readfirstlane((int)__shfl((int)e.by, src));
-                const float thr = __shfl(e.e_thr, src);
-                const int bx0 = (int)(ebx >> 16), bx1 = (int)(ebx & 0xffffu), by0 = (int)(eby >> 16), by1 = (int)(eby & 0xffffu);
+        // up to three entries per wave (2.3 on the benchmark scene): their records are fetched together, then each
+        // rectangle's bounds (one 2-byte load per lane for rectangles of <= 64 blocks); survivors are queued in a bit mask
+        // so that the point loop exists once in the code
+        for (int t0 = wave; t0 < n_list; t0 += 3 * n_waves) {
+            const int t1 = t0 + n_waves, t2 = t0 + 2 * n_waves;
+            const CellEntryB e0 = list_b[t0], e1 = list_b[t1 < n_list ? t1 : t0], e2 = list_b[t2 < n_list ? t2 : t0];
+            unsigned todo = 0;
+#pragma unroll
+            for (int j = 0; j < 3; ++j) {
+                const CellEntryB e = j == 0 ? e0 : (j == 1 ? e1 : e2);
+                if (j > 0 && t0 + j * n_waves >= n_list) continue;
+                int bx0 = (int)(e.bx >> 16), bx1 = (int)(e.bx & 0xffffu);
+                const int by0 = (int)(e.by >> 16), by1 = (int)(e.by & 0xffffu);
                 const int rw = bx1 - bx0 + 1, nblk = rw * (by1 - by0 + 1);
-                bool run = true;
-                if (nblk <= 4096) {
+                bool run = rw > 0;
+                if (run && nblk <= 4096) {
                     float emin = 3.0e38f;                          // min over the rectangle of (1 - far bound)
                     const float inv_rw = 1.0f / (float)rw;
                     for (int i = lane; i < nblk; i += 64) {
-                        const int ry = (int)(((float)i + 0.5f) * inv_rw);   // i / rw for i < 4096 (exact: |error| << 0.5 / rw)
+                        int ry = (int)(((float)i + 0.5f) * inv_rw);   // i / rw for i < 4096 (exact: |error| << 0.5 / rw)
                         const int rx = i - ry * rw;
                         emin = fminf(emin, __uint_as_float((unsigned)hiz_g[(by0 + ry) * nbx + bx0 + rx] << 16));
                     }
 #pragma unroll
                     for (int o = 32; o > 0; o >>= 1) emin = fminf(emin, __shfl_xor(emin, o));
-                    run = !(thr < emin);                           // cull iff every point of the box is behind every bound
+                    run = !(e.e_thr < emin);                       // cull iff every point of the box is behind every bound
                 }
-                if (!run) {
-                    if (lane == 0) ++n_cull;
-                    continue;
-                }
+                if (run) todo |= 1u << j;
+                else ++n_cull;
+            }
+            todo = __builtin_amdgcn_readfirstlane(todo);
+            while (todo) {
+                const int j = __builtin_ctz(todo);
+                todo &= todo - 1;
+                const int entry = __builtin_amdgcn_readfirstlane(j == 0 ? e0.chunk : (j == 1 ? e1.chunk : e2.chunk));
                 const int chunk = entry & 0x7fffffff;
                 if (lane == 0) cc.sticky[chunk] = STICKY_FRAMES;
-                if (lane == 0) ++n_run;
+                ++n_run;
                 strip_points<STATS, ZL2, LDS>(cc, M, W, H, xlo, xhi, keys, zimg, next, chunk * CELL_CHUNK, 4, lane, st_in, st_atomics,
                                               tag, hkey, hpos, ks, entry < 0);
             }
         }
     }
     if (STATS) {
-        unsigned v[4] = {st_in, st_atomics, (PASS_B || lane == 0) ? n_run : 0u, (PASS_B || lane == 0) ? n_cull : 0u};
+        unsigned v[4] = {st_in, st_atomics, lane == 0 ? n_run : 0u, lane == 0 ? n_cull : 0u};
 #pragma unroll
         for (int i = 0; i < 4; ++i)
 #pragma unroll
@@ -767,67 +742,38 @@ __global__ __launch_bounds__(256) void cells_pass_kernel(CellCloud cc, Cam1 cam,
 }
 
 // After pass A: bound[block] = max over the block's pixels of the current depth (from the exact key image), "none" if a
-// pixel is still empty; zimg is set to the exact current depths (the racy stores of pass A may have left a larger value
-// than the minimum), so pass B's early-z is exact; and four coarser levels of the bound image (texel = 2^k x 2^k blocks,
-// value = the farthest = numerically smallest bound below it) let pass B reject most chunks with four 2-byte loads.
-// One workgroup = a tile of 16 x 16 blocks (64 x 64 pixels), reduced through LDS.
+// pixel is still empty; and zimg is set to the exact current depths (the racy stores of pass A may have left a larger
+// value than the minimum), so pass B's early-z is exact.
 __global__ __launch_bounds__(256) void cells_hiz_kernel(const unsigned long long *__restrict__ keys, unsigned *__restrict__ zimg,
-                                                        int W, int H, unsigned short *__restrict__ hiz, HizMips mp, KeySlots ks)
+                                                        int W, int H, int nbx, int nby, unsigned short *__restrict__ hiz,
+                                                        KeySlots ks)
 {
-    __shared__ float s_e[256];
-    const int tiles_x = (mp.nx[0] + 15) >> 4;
-    const int tx = blockIdx.x % tiles_x, ty = blockIdx.x / tiles_x;
-    const int lx = threadIdx.x & 15, ly = threadIdx.x >> 4;
-    const int bx = tx * 16 + lx, by = ty * 16 + ly;
-    float e = 3.0e38f;                                           // outside the image: neutral for the minimum
-    if (bx < mp.nx[0] && by < mp.ny[0]) {
-        unsigned m = 0;
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= nbx * nby) return;
+    const int bx = b % nbx, by = b / nbx;
+    unsigned m = 0;
 #pragma unroll
-        for (int dy = 0; dy < 4; ++dy)
-            if (by * 4 + dy < H) {                              // W % 16 == 0: the block's 4 columns exist
-                const long long off = (long long)(by * 4 + dy) * W + bx * 4;
-                uint4 z;
-                if (ks.mode == 0) {
-                    const ulonglong2 k01 = *reinterpret_cast<const ulonglong2 *>(keys + off);
-                    const ulonglong2 k23 = *reinterpret_cast<const ulonglong2 *>(keys + off + 2);
-                    z.x = (unsigned)(k01.x >> 32);              // EMPTY -> 0xffffffff = "none"
-                    z.y = (unsigned)(k01.y >> 32);
-                    z.z = (unsigned)(k23.x >> 32);
-                    z.w = (unsigned)(k23.y >> 32);
-                } else {
-                    z.x = (unsigned)(keys[key_slot(ks, (unsigned)off)] >> 32);
-                    z.y = (unsigned)(keys[key_slot(ks, (unsigned)off + 1)] >> 32);
-                    z.z = (unsigned)(keys[key_slot(ks, (unsigned)off + 2)] >> 32);
-                    z.w = (unsigned)(keys[key_slot(ks, (unsigned)off + 3)] >> 32);
-                }
-                *reinterpret_cast<uint4 *>(zimg + off) = z;
-                m = max(max(m, z.x), max(max(z.y, z.z), z.w));
+    for (int dy = 0; dy < 4; ++dy)
+        if (by * 4 + dy < H) {                                  // W % 16 == 0: the block's 4 columns exist
+            const long long off = (long long)(by * 4 + dy) * W + bx * 4;
+            uint4 z;
+            if (ks.mode == 0) {
+                const ulonglong2 k01 = *reinterpret_cast<const ulonglong2 *>(keys + off);
+                const ulonglong2 k23 = *reinterpret_cast<const ulonglong2 *>(keys + off + 2);
+                z.x = (unsigned)(k01.x >> 32);                  // EMPTY -> 0xffffffff = "none"
+                z.y = (unsigned)(k01.y >> 32);
+                z.z = (unsigned)(k23.x >> 32);
+                z.w = (unsigned)(k23.y >> 32);
+            } else {
+                z.x = (unsigned)(keys[key_slot(ks, (unsigned)off)] >> 32);
+                z.y = (unsigned)(keys[key_slot(ks, (unsigned)off + 1)] >> 32);
+                z.z = (unsigned)(keys[key_slot(ks, (unsigned)off + 2)] >> 32);
+                z.w = (unsigned)(keys[key_slot(ks, (unsigned)off + 3)] >> 32);
             }
-        const unsigned short enc = hiz_encode(m);
-        hiz[mp.off[0] + by * mp.nx[0] + bx] = enc;
-        e = __uint_as_float((unsigned)enc << 16);
-    }
-    s_e[threadIdx.x] = e;
-    __syncthreads();
-    // level k: texel (lx, ly) of the tile's 16 >> k grid = min over its 2 x 2 children of level k-1 (kept in s_e in place:
-    // level k-1 lives at stride 1 << (k-1) in the 16 x 16 array)
-#pragma unroll
-    for (int k = 1; k <= 4; ++k) {
-        const int n = 16 >> k, st = 1 << k, h = st >> 1;
-        float v = 3.0e38f;
-        const bool act = lx < n && ly < n;
-        if (act) {
-            const int bxy = (ly * st) * 16 + lx * st;
-            v = fminf(fminf(s_e[bxy], s_e[bxy + h]), fminf(s_e[bxy + h * 16], s_e[bxy + h * 16 + h]));
+            *reinterpret_cast<uint4 *>(zimg + off) = z;
+            m = max(max(m, z.x), max(max(z.y, z.z), z.w));
         }
-        __syncthreads();
-        if (act) {
-            s_e[(ly * st) * 16 + lx * st] = v;
-            const int gx = tx * n + lx, gy = ty * n + ly;
-            if (gx < mp.nx[k] && gy < mp.ny[k]) hiz[mp.off[k] + gy * mp.nx[k] + gx] = (unsigned short)(__float_as_uint(v) >> 16);
-        }
-        __syncthreads();
-    }
+    hiz[b] = hiz_encode(m);
 }
 
 // ---- GL twin features: point sizes, "ps" splats, discard, clip-space perturbation ------------------------------------
@@ -1215,13 +1161,6 @@ int cells_frame(const CellCloud &cc, const float *M_host, int W, int H, int leve
     READ_CHECK_LAUNCH();
     const unsigned grid = (unsigned)(device_cus() * g_splat_wgs);
     const int items = g_splat_items;
-    HizMips mp;
-    for (int k = 0, off = 0; k < 5; ++k) {
-        mp.nx[k] = ceil_div(ws.nbx, 1 << k);
-        mp.ny[k] = ceil_div(ws.nby, 1 << k);
-        mp.off[k] = off;
-        off += (mp.nx[k] * mp.ny[k] + 7) & ~7;                 // all levels fit the region's 4 bytes per level-0 block
-    }
     KeySlots ks;
     ks.mode = g_splat_kslot;
     ks.mask = 1;
@@ -1235,13 +1174,13 @@ int cells_frame(const CellCloud &cc, const float *M_host, int W, int H, int leve
                   : g_splat_zl2 ? cells_pass_kernel<true, false, true, false>
                   : g_splat_lds ? cells_pass_kernel<true, false, false, true> : cells_pass_kernel<true, false, false, false>;
     hipLaunchKernelGGL(pass_a, dim3(grid), dim3(256), 0, stream, cc, cam, W, H, ws.keys, ws.zimg,
-                       (const unsigned short *)ws.hiz, ws.nbx, ws.hdr, ws.prev[0], ws.prev[1], si, items, stats, ks, mp);
+                       (const unsigned short *)ws.hiz, ws.nbx, ws.hdr, ws.prev[0], ws.prev[1], si, items, stats, ks);
     READ_CHECK_LAUNCH();
-    hipLaunchKernelGGL(cells_hiz_kernel, dim3((unsigned)(ceil_div(ws.nbx, 16) * ceil_div(ws.nby, 16))), dim3(256), 0, stream,
-                       (const unsigned long long *)ws.keys, ws.zimg, W, H, ws.hiz, mp, ks);
+    hipLaunchKernelGGL(cells_hiz_kernel, dim3(ceil_div(ws.nbx * ws.nby, 256)), dim3(256), 0, stream,
+                       (const unsigned long long *)ws.keys, ws.zimg, W, H, ws.nbx, ws.nby, ws.hiz, ks);
     READ_CHECK_LAUNCH();
     hipLaunchKernelGGL(pass_b, dim3(grid), dim3(256), 0, stream, cc, cam, W, H, ws.keys, ws.zimg,
-                       (const unsigned short *)ws.hiz, ws.nbx, ws.hdr, ws.prev[0], ws.prev[1], si, items, stats, ks, mp);
+                       (const unsigned short *)ws.hiz, ws.nbx, ws.hdr, ws.prev[0], ws.prev[1], si, items, stats, ks);
     READ_CHECK_LAUNCH();
     return resolve_launch(ws.keys, 1, 0, W, H, levels, idx_levels, depth_levels, 0, ws, 2, stream, ks);
 }
