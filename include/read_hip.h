@@ -248,6 +248,11 @@ int read_conv_pack_params_device(int Cout, const float *bf, const float *bm, con
                                  const float *mean, const float *var, float eps, float *params, void *stream);
 int read_conv_pack_weights_device(int Cin, int Cout, int ksize, int kc, const float *wf, const float *wm, float *wpacked,
                                   void *stream);
+/* Winograd fragments (3x3 / stride 1, Cin % 16 == 0) of the layer's own weights and of its dgrad weights, produced on the
+ * device: with desc.wpacked_wino set, linear-mode launches of eligible layers take the Winograd kernel too. */
+int read_conv_pack_wino_device(int Cin, int Cout, const float *wf, const float *wm, float *wpacked_wino, void *stream);
+size_t read_conv_dgrad_wino_floats(int Cin, int Cout);
+int read_conv_pack_dgrad_wino_device(int Cin, int Cout, const float *wf, const float *wm, float *wpacked_wino, void *stream);
 size_t read_conv_dgrad_packed_floats(int Cin, int Cout, int ksize);
 int read_conv_pack_dgrad_device(int Cin, int Cout, int ksize, int kc, const float *wf, const float *wm, float *wpacked,
                                 void *stream);

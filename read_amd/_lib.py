@@ -76,6 +76,9 @@ SIGNATURES = {
     "read_bilinear_up4": (_i, [_vp, _i, _i, _i, _vp, _vp]),
     "read_conv_pack_params_device": (_i, [_i, _vp, _vp, _vp, _vp, _vp, _vp, _f, _vp, _vp]),
     "read_conv_pack_weights_device": (_i, [_i, _i, _i, _i, _vp, _vp, _vp, _vp]),
+    "read_conv_pack_wino_device": (_i, [_i, _i, _vp, _vp, _vp, _vp]),
+    "read_conv_dgrad_wino_floats": (_sz, [_i, _i]),
+    "read_conv_pack_dgrad_wino_device": (_i, [_i, _i, _vp, _vp, _vp, _vp]),
     "read_conv_dgrad_packed_floats": (_sz, [_i, _i, _i]),
     "read_conv_pack_dgrad_device": (_i, [_i, _i, _i, _i, _vp, _vp, _vp, _vp]),
     "read_gate_forward": (_i, [_vp, _i64, _i, _vp, _i, _vp, _vp, _i, _i, _i, _vp]),

@@ -928,6 +928,25 @@ __global__ __launch_bounds__(256, 2) void gated_conv_wino_kernel(const ConvKArgs
 #pragma unroll
                 for (int b = 0; b < 2; ++b) {
                     f32x4 f = Y[0][aa][b] + bf;
+                    if (a.linear) {
+                        // plain convolution (training path): conv_f + b_f at channel c, conv_m + b_m at channel Cout + c
+                        const f32x4 m = Y[1][aa][b] + bm;
+                        float *op = a.out + ((size_t)(oy + aa) * a.outW + ox + b) * a.out_cstride + c0;
+                        if (pix_in[aa][b]) {
+                            if (c0 + 3 < a.Cout && ((a.out_cstride | a.Cout) & 3) == 0) {
+                                *reinterpret_cast<f32x4 *>(op) = f;
+                                *reinterpret_cast<f32x4 *>(op + a.Cout) = m;
+                            } else {
+#pragma unroll
+                                for (int k = 0; k < 4; ++k)
+                                    if (c0 + k < a.Cout) {
+                                        op[k] = f[k];
+                                        op[a.Cout + k] = m[k];
+                                    }
+                            }
+                        }
+                        continue;
+                    }
                     const f32x4 mm = (Y[1][aa][b] + bm) * -LOG2E;
                     if (a.elu) {                                     // x > 0 ? x : exp(x) - 1
                         const f32x4 fe = f * LOG2E;
@@ -1340,9 +1359,12 @@ int launch_gated_conv(const read_conv_desc *d, hipStream_t stream)
     const int CoutPad = pad32(d->Cout), groups = CoutPad / 32;
     int cfg = d->config;
     if (d->linear) {
-        // the plain-convolution epilogue exists in the workgroup-tiled kernel only
-        READ_CHECK_ARG(cfg < 0 || (cfg < N_CONFIGS && !g_configs[cfg].wave && !g_configs[cfg].wino),
-                       "read_gated_conv_forward: linear mode needs a workgroup-tiled config");
+        // the plain-convolution epilogue exists in the workgroup-tiled kernels and in the Winograd kernel
+        READ_CHECK_ARG(cfg < 0 || (cfg < N_CONFIGS && !g_configs[cfg].wave),
+                       "read_gated_conv_forward: linear mode needs a workgroup-tiled or Winograd config");
+        if (cfg < 0 && conv_uses_wino(d))
+            for (int i = N_CONFIGS - 1; i >= 0; --i)
+                if (g_configs[i].wino) cfg = i;
         for (int i = 0; cfg < 0 && i < N_CONFIGS; ++i) {
             const ConvConfig &k = g_configs[i];
             if (!k.wave && !k.wino && k.KS == d->ksize && k.S == d->stride && k.KC == kc && groups % (k.WN * k.QG) == 0 &&

@@ -79,6 +79,42 @@ __global__ void pack_weights_kernel(int mode, int Cin, int Cout, int ksize, int 
     }
 }
 
+// Winograd F(2x2,3x3) fragment order of read_conv_pack_wino_host: U = G g G^T per (cout, cin) pair, packed
+// [group][k8 step][row i][j][f|m][lane][4], row 2 negated.  mode as in pack_weights_kernel (1 = dgrad's virtual weights).
+__global__ void pack_wino_kernel(int mode, int Cin, int Cout, int Cp, const float *wf, const float *wm, float *out, long long total)
+{
+    const float G[4][3] = {{1.f, 0.f, 0.f}, {.5f, .5f, .5f}, {.5f, -.5f, .5f}, {0.f, 0.f, 1.f}};
+    const int CinV = mode ? 2 * Cp : Cin, CoutV = mode ? Cin / 2 : Cout;
+    const int nsteps = CinV / 8;
+    for (long long o = (long long)blockIdx.x * blockDim.x + threadIdx.x; o < total; o += (long long)gridDim.x * blockDim.x) {
+        long long r = o;
+        const int e = (int)(r & 3); r >>= 2;
+        const int lane = (int)(r & 63); r >>= 6;
+        const int fm = (int)(r & 1); r >>= 1;
+        const int j = (int)(r & 3); r >>= 2;
+        const int i = (int)(r & 3); r >>= 2;
+        const int st = (int)(r % nsteps);
+        const int g = (int)(r / nsteps);
+        const int co = g * 32 + (lane & 31), ci = 8 * st + 4 * (lane >> 5) + e;
+        float u = 0.0f;
+        if (co < CoutV) {
+            const float *k = nullptr;
+            bool flip = false;
+            if (!mode) {
+                k = (fm ? wm : wf) + ((size_t)co * Cin + ci) * 9;
+            } else {
+                const int layer_co = ci % Cp, layer_ci = fm * (Cin / 2) + co;
+                if (layer_co < Cout) k = (ci < Cp ? wf : wm) + ((size_t)layer_co * Cin + layer_ci) * 9;
+                flip = true;
+            }
+            if (k)
+                for (int a = 0; a < 3; ++a)
+                    for (int b = 0; b < 3; ++b) u += G[i][a] * k[flip ? 8 - (a * 3 + b) : a * 3 + b] * G[j][b];
+        }
+        out[o] = i == 2 ? -u : u;
+    }
+}
+
 // weights for dgrad_generic_kernel: [tap][co' in 2*Cp][ci]  (ci contiguous)
 __global__ void pack_dgrad_generic_kernel(int Cin, int Cout, int taps, int Cp, const float *wf, const float *wm, float *out,
                                           long long total)
@@ -504,6 +540,36 @@ extern "C" int read_conv_pack_weights_device(int Cin, int Cout, int ksize, int k
     const long long total = (long long)read_conv_packed_floats(Cin, Cout, ksize);
     hipLaunchKernelGGL(pack_weights_kernel, dim3(grid_for(total)), dim3(256), 0, as_stream(stream), 0, Cin, Cout, ksize, kc, 0,
                        wf, wm, wpacked, total);
+    READ_CHECK_LAUNCH();
+    return READ_OK;
+}
+
+extern "C" int read_conv_pack_wino_device(int Cin, int Cout, const float *wf, const float *wm, float *wpacked_wino, void *stream)
+{
+    READ_CHECK_ARG(wf && wm && wpacked_wino, "read_conv_pack_wino_device: null pointer");
+    READ_CHECK_ARG(Cin >= 16 && Cin % 16 == 0 && Cout >= 1, "read_conv_pack_wino_device: needs Cin %% 16 == 0 (got %d)", Cin);
+    const long long total = (long long)read_conv_wino_floats(Cin, Cout);
+    hipLaunchKernelGGL(pack_wino_kernel, dim3(grid_for(total)), dim3(256), 0, as_stream(stream), 0, Cin, Cout, 0, wf, wm,
+                       wpacked_wino, total);
+    READ_CHECK_LAUNCH();
+    return READ_OK;
+}
+
+extern "C" size_t read_conv_dgrad_wino_floats(int Cin, int Cout)
+{
+    if (Cin < 2 || Cin % 2 || Cout < 1) return 0;
+    return read_conv_wino_floats(2 * ((Cout + 7) / 8 * 8), Cin / 2);
+}
+
+extern "C" int read_conv_pack_dgrad_wino_device(int Cin, int Cout, const float *wf, const float *wm, float *wpacked_wino,
+                                                void *stream)
+{
+    READ_CHECK_ARG(wf && wm && wpacked_wino, "read_conv_pack_dgrad_wino_device: null pointer");
+    READ_CHECK_ARG(Cin >= 2 && Cin % 2 == 0 && Cout >= 1, "read_conv_pack_dgrad_wino_device: Cin must be even");
+    const int Cp = (Cout + 7) / 8 * 8;
+    const long long total = (long long)read_conv_dgrad_wino_floats(Cin, Cout);
+    hipLaunchKernelGGL(pack_wino_kernel, dim3(grid_for(total)), dim3(256), 0, as_stream(stream), 1, Cin, Cout, Cp, wf, wm,
+                       wpacked_wino, total);
     READ_CHECK_LAUNCH();
     return READ_OK;
 }

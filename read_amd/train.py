@@ -38,8 +38,9 @@ def _kc_for(cin):
     return 16 if cin % 16 == 0 else 8
 
 
-def _linear_conv(x, cin, wpacked, params, cout, k, stride, out):
-    """x (H,W,cin) NHWC -> out (Ho,Wo,2*cout): [conv_f + b_f | conv_m + b_m] through the MFMA kernel (linear epilogue)."""
+def _linear_conv(x, cin, wpacked, params, cout, k, stride, out, wino=None):
+    """x (H,W,cin) NHWC -> out (Ho,Wo,2*cout): [conv_f + b_f | conv_m + b_m] through the MFMA kernel (linear epilogue);
+    with Winograd fragments (3x3 / stride 1, cin % 16 == 0) through the Winograd F(2x2,3x3) kernel."""
     H, W = int(x.shape[0]), int(x.shape[1])
     d = _lib.ConvDesc()
     d.n_src = 1
@@ -48,6 +49,8 @@ def _linear_conv(x, cin, wpacked, params, cout, k, stride, out):
     d.inH, d.inW, d.Cout, d.ksize, d.stride, d.elu = H, W, cout, k, stride, 0
     d.wpacked, d.params, d.out, d.out_cstride = wpacked.data_ptr(), params.data_ptr(), out.data_ptr(), 2 * cout
     d.config, d.linear = -1, 1
+    if wino is not None:
+        d.wpacked_wino = wino.data_ptr()
     _lib.check(_lib.lib().read_gated_conv_forward(C.byref(d), _lib.stream_ptr()), "read_gated_conv_forward(linear)")
     return out
 
@@ -55,6 +58,7 @@ def _linear_conv(x, cin, wpacked, params, cout, k, stride, out):
 # packed copies of a layer's weights, reused by every image of a batch (weights only change at optimizer steps, which bump
 # the parameters' _version): key = id of the conv_f weight -> (versions, params block, forward fragments, dgrad fragments)
 _PACK_CACHE = {}
+USE_WINOGRAD = True          # 3x3 / stride-1 layers with cin % 16 == 0: forward pre-activations and dgrad through the Winograd kernel
 
 
 def _packed_for(wf, bf, wm, bm, gamma, beta, mean, var, cin, cout, k):
@@ -67,6 +71,8 @@ def _packed_for(wf, bf, wm, bm, gamma, beta, mean, var, cin, cout, k):
         cur.wait_event(hit[4])                              # packed on another item's stream
         hit[1].record_stream(cur)
         hit[2].record_stream(cur)
+        if hit[5] is not None:
+            hit[5].record_stream(cur)
         return hit
     dev = wf.device
     params = torch.empty(L.read_conv_param_floats(cout), dtype=torch.float32, device=dev)
@@ -75,9 +81,13 @@ def _packed_for(wf, bf, wm, bm, gamma, beta, mean, var, cin, cout, k):
     wf_c, wm_c = wf.detach().contiguous(), wm.detach().contiguous()
     wp = torch.empty(L.read_conv_packed_floats(cin, cout, k), dtype=torch.float32, device=dev)
     _lib.check(L.read_conv_pack_weights_device(cin, cout, k, _kc_for(cin), wf_c.data_ptr(), wm_c.data_ptr(), wp.data_ptr(), st))
+    wino = None
+    if k == 3 and cin % 16 == 0 and USE_WINOGRAD:
+        wino = torch.empty(L.read_conv_wino_floats(cin, cout), dtype=torch.float32, device=dev)
+        _lib.check(L.read_conv_pack_wino_device(cin, cout, wf_c.data_ptr(), wm_c.data_ptr(), wino.data_ptr(), st))
     ev = torch.cuda.Event()
     ev.record()
-    entry = [ver, params, wp, None, ev]
+    entry = [ver, params, wp, None, ev, wino]
     _PACK_CACHE[id(wf)] = entry
     return entry
 
@@ -100,7 +110,7 @@ class GatedConvFn(torch.autograd.Function):
         params, wp = entry[1], entry[2]
         ctx.pack = entry
         fm = torch.empty((Ho, Wo, 2 * cout), dtype=torch.float32, device=dev)
-        _linear_conv(x, cin, wp, params, cout, k, stride, fm)
+        _linear_conv(x, cin, wp, params, cout, k, stride, fm, wino=entry[5] if stride == 1 else None)
         y = torch.empty((Ho, Wo, cout), dtype=torch.float32, device=dev)
         # a batch is one tall image of nb stacked items; separator rows (block geometry at THIS layer's output scale) stay zero
         bh = Ho // nb if nb > 1 else 0
@@ -136,15 +146,21 @@ class GatedConvFn(torch.autograd.Function):
                 if wd is None:
                     wd = torch.empty(L.read_conv_dgrad_packed_floats(cin, cout, k), dtype=torch.float32, device=dev)
                     _lib.check(L.read_conv_pack_dgrad_device(cin, cout, k, 16, wf.data_ptr(), wm.data_ptr(), wd.data_ptr(), st))
+                    wdw = None
+                    if k == 3 and USE_WINOGRAD:                      # the virtual input has 2 * cp channels: always % 16
+                        wdw = torch.empty(L.read_conv_dgrad_wino_floats(cin, cout), dtype=torch.float32, device=dev)
+                        _lib.check(L.read_conv_pack_dgrad_wino_device(cin, cout, wf.data_ptr(), wm.data_ptr(), wdw.data_ptr(), st))
                     ev = torch.cuda.Event()
                     ev.record()
-                    ctx.pack[3] = (wd, ev)
+                    ctx.pack[3] = (wd, ev, wdw)
                 else:
-                    wd, ev = wd
+                    wd, ev, wdw = wd
                     torch.cuda.current_stream().wait_event(ev)
                     wd.record_stream(torch.cuda.current_stream())
+                    if wdw is not None:
+                        wdw.record_stream(torch.cuda.current_stream())
                 zero = torch.zeros(L.read_conv_param_floats(cin // 2), dtype=torch.float32, device=dev)
-                _linear_conv(dfm, 2 * cp, wd, zero, cin // 2, k, 1, dx)
+                _linear_conv(dfm, 2 * cp, wd, zero, cin // 2, k, 1, dx, wino=wdw)
             else:
                 ws = torch.empty(L.read_conv_dgrad_generic_floats(cin, cout, k), dtype=torch.float32, device=dev)
                 _lib.check(L.read_conv_dgrad_generic(dfm.data_ptr(), Ho, Wo, cin, cout, k, stride, wf.data_ptr(), wm.data_ptr(),
