@@ -320,16 +320,27 @@ __global__ __launch_bounds__(64) void wgrad_mfma_kernel(const float *__restrict_
             a[t] = ok ? x[((long long)iy * inW + ix) * Cin + ci0 + i] : 0.0f;
         }
     };
-    float a_cur[NT], a_nxt[NT], b_cur, b_nxt;
-    fetch(0, a_cur, b_cur);
-    for (long long step = 0; step < total_steps; ++step) {
-        fetch(step + 1, a_nxt, b_nxt);
+    // operands two steps ahead (a ring of three register sets): one step of NT MFMAs (~0.25 us) does not cover an L2 round trip
+    float a0[NT], a1[NT], a2[NT], b0, b1, b2;
+    fetch(0, a0, b0);
+    fetch(1, a1, b1);
+    long long step = 0;
+    for (; step + 3 <= total_steps; step += 3) {
+        fetch(step + 2, a2, b2);
 #pragma unroll
-        for (int t = 0; t < NT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a_cur[t], b_cur, acc[t], 0, 0, 0);
+        for (int t = 0; t < NT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[t], b0, acc[t], 0, 0, 0);
+        fetch(step + 3, a0, b0);
 #pragma unroll
-        for (int t = 0; t < NT; ++t) a_cur[t] = a_nxt[t];
-        b_cur = b_nxt;
+        for (int t = 0; t < NT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[t], b1, acc[t], 0, 0, 0);
+        fetch(step + 4, a1, b1);
+#pragma unroll
+        for (int t = 0; t < NT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a2[t], b2, acc[t], 0, 0, 0);
     }
+    // tail: at most two steps left, already in (a0, b0), (a1, b1); fetch() returns zeros past the end
+#pragma unroll
+    for (int t = 0; t < NT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[t], b0, acc[t], 0, 0, 0);
+#pragma unroll
+    for (int t = 0; t < NT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[t], b1, acc[t], 0, 0, 0);
     // D[i][j] sits in lane (j + 32 * ((i >> 2) & 1)), register (i & 3) + 4 * (i >> 3): row i = ci, column j = co'
     float *dst = partial + (((long long)blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x) * (NT * 1024);
 #pragma unroll

@@ -232,7 +232,10 @@ def test_texture_pipeline_training_step(hip):
         loss_r.backward()
         opt_r.step(); opt_r.zero_grad(); ext_r.step(); ext_r.zero_grad()
         assert abs(float(loss) - float(loss_r)) <= 1e-4 * abs(float(loss_r)), (step, float(loss), float(loss_r))
-    _close(tex.state_dict()["texture_"].cpu(), tex_r.detach(), "descriptors after two steps", rtol=1e-3)
+    # RMSprop's first steps move a descriptor by lr * g / (sqrt(0.01 g^2) + 1e-8) ~ 10 lr sign(g): entries whose gradient is
+    # at round-off level (|g| ~ 1e-9) take updates that depend on the last bits of g — ill-conditioned by construction, so the
+    # comparison after two optimizer steps is at 5e-3 of the largest entry (the gradients themselves are held to 1e-4 above)
+    _close(tex.state_dict()["texture_"].cpu(), tex_r.detach(), "descriptors after two steps", rtol=5e-3)
     sd = pipe.net.state_dict()
     for name in ("feat_extract.0.block.conv_f.weight", "Encoder.3.layers.2.main.0.block.conv_m.weight", "feat_extract.5.block.norm.weight",
                  "AFFs.1.conv.0.block.conv_f.bias"):
