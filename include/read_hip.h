@@ -205,7 +205,14 @@ typedef struct read_conv_desc {
                                                Winograd F(2x2,3x3) kernel for 3x3/s1 single-source layers */
     int linear;                             /* 1: plain convolution (training path): out[..][c] = conv_f + b_f,
                                                out[..][Cout + c] = conv_m + b_m, out_cstride >= 2 * Cout; no gate /
-                                               BatchNorm / residual; always the workgroup-tiled kernel */
+                                               BatchNorm / residual; workgroup-tiled or Winograd kernel */
+    /* optional pre-activation addend, NHWC [preH][preW][pre_cstride]: before bias / activation / gate,
+     *   conv_f(y,x,c) += pre[y >> pre_shift][x >> pre_shift][pre_f_off + c],  conv_m likewise with pre_m_off.
+     * A 1x1 convolution commutes with nearest up-sampling, so the share of torch.cat([.., F.interpolate(coarse)]) -> 1x1 conv
+     * that comes from a coarser tensor is computed at the coarse resolution by a `linear` launch and enters here
+     * (READ/models/unet.py:239-254, the AFF inputs).  Not available with the Winograd kernel. */
+    const float *pre;
+    int pre_cstride, pre_f_off, pre_m_off, pre_shift, preH, preW;
 } read_conv_desc;
 
 /* Sizes (in floats) of the packed weight / parameter blocks of one BasicConv. */

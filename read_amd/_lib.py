@@ -29,6 +29,8 @@ class ConvDesc(C.Structure):
         ("elu", C.c_int), ("wpacked", C.c_void_p), ("params", C.c_void_p), ("residual", C.c_void_p),
         ("out", C.c_void_p), ("out_cstride", C.c_int), ("out_fill", C.c_float), ("fill_pad", C.c_int),
         ("config", C.c_int), ("wpacked_wino", C.c_void_p), ("linear", C.c_int),
+        ("pre", C.c_void_p), ("pre_cstride", C.c_int), ("pre_f_off", C.c_int), ("pre_m_off", C.c_int),
+        ("pre_shift", C.c_int), ("preH", C.c_int), ("preW", C.c_int),
     ]
 
 

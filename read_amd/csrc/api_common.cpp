@@ -53,6 +53,7 @@ void conv_set_wino(int max_cin);
 void conv_set_kc32(int v);
 int conv_get(const char *key, int *value);
 void unet_set_streams(int v);
+void unet_set_aff_split(int v);
 int unet_get(const char *key, int *value);
 }
 
@@ -69,7 +70,7 @@ extern "C" int read_debug_set_trace(void *buf, size_t bytes)
 // selects between implementations that produce the SAME results; the attribution probes whose results are invalid
 // ("conv_ablate") exist only in builds with -DREAD_DEBUG_KNOBS.
 static const char *const k_tuning_keys[] = {"splat_mode", "splat_stats", "splat_subset", "splat_near", "splat_cells",
-                                            "splat_cells_sub", "splat_seeds", "splat_items", "splat_strips", "splat_wgs", "splat_zl2", "splat_lds", "splat_kslot", "unet_streams", "conv_kc32",
+                                            "splat_cells_sub", "splat_seeds", "splat_items", "splat_strips", "splat_wgs", "splat_zl2", "splat_lds", "splat_kslot", "unet_streams", "unet_aff_split", "conv_kc32",
                                             "conv_wino", "conv_stagger", "conv_wave",
 #ifdef READ_DEBUG_KNOBS
                                             "conv_ablate",
@@ -98,6 +99,8 @@ extern "C" int read_tuning_set(const char *key, int value)
     if (!strcmp(key, "splat_wgs")) { readhip::splat_set_wgs(value); return READ_OK; }         // workgroups per CU of the passes
     if (!strcmp(key, "splat_strips")) { readhip::splat_set_strips(value); return READ_OK; }   // column strips: 1, 2, 4, 8
     if (!strcmp(key, "unet_streams")) { readhip::unet_set_streams(value); return READ_OK; }   // 0: SCM chains on the caller's stream
+    // 0: AFF first convs as single 480-channel launches (takes effect for plans created afterwards)
+    if (!strcmp(key, "unet_aff_split")) { readhip::unet_set_aff_split(value != 0); return READ_OK; }
     if (!strcmp(key, "conv_kc32")) { readhip::conv_set_kc32(value); return READ_OK; }
     if (!strcmp(key, "conv_wino")) { readhip::conv_set_wino(value); return READ_OK; }         // largest Cin on the Winograd kernel (0 = off)
     if (!strcmp(key, "conv_stagger")) { readhip::conv_set_stagger(value); return READ_OK; }

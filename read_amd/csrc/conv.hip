@@ -57,6 +57,10 @@ struct ConvKArgs {
     int linear;                    // 1: plain convolution — store conv_f + b_f at channel c and conv_m + b_m at channel Cout + c
                                    //    (no gate, no BatchNorm, no residual): the training path's pre-activations and dgrad
     float out_fill;
+    // optional pre-activation addend (read_conv_desc.pre): conv_f += pre[(oy >> s, ox >> s)][pre_foff + c], conv_m likewise
+    // with pre_moff — partial sums of the same layer computed at a coarser level (nearest up-sampling commutes with a 1x1 conv)
+    const float *pre;
+    int pre_cstride, pre_foff, pre_moff, pre_shift, pre_W, pre_bytes;
     unsigned long long *trace;     // optional timeline: 8 x u64 per workgroup (read_debug_set_trace)
 };
 
@@ -303,6 +307,8 @@ __global__ __launch_bounds__(256) void gated_conv_kernel(const ConvKArgs a)
         (void *)a.out, 0, a.outH * a.outW * a.out_cstride * 4, 0x00020000);
     const __amdgpu_buffer_rsrc_t rrsrc = __builtin_amdgcn_make_buffer_rsrc(
         (void *)(a.residual ? a.residual : a.out), 0, a.residual ? a.outH * a.outW * a.Cout * 4 : 0, 0x00020000);
+    const __amdgpu_buffer_rsrc_t prsrc = __builtin_amdgcn_make_buffer_rsrc(
+        (void *)(a.pre ? a.pre : a.out), 0, a.pre ? a.pre_bytes : 0, 0x00020000);
 #pragma unroll
     for (int g = 0; g < QG; ++g) {
         const int c = ((nt0 >> 1) + g) * 32 + (lane & 31);
@@ -316,7 +322,7 @@ __global__ __launch_bounds__(256) void gated_conv_kernel(const ConvKArgs a)
         for (int p = 0; p < P; ++p) {
             const int oy = oy0 + wm * P + p;
             int ooff[TL::NR];
-            float rv[TL::NR];
+            float rv[TL::NR], pf[TL::NR], pm[TL::NR];
 #pragma unroll
             for (int rr = 0; rr < TL::NR; ++rr) {
                 const int r = wk * TL::NR + rr;
@@ -327,6 +333,12 @@ __global__ __launch_bounds__(256) void gated_conv_kernel(const ConvKArgs a)
                 const int roff = (in & c_ok) ? (opix * a.Cout + c) * 4 : OOB;
                 rv[rr] = (a.ablate & 1) ? 0.0f : __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rrsrc, roff, 0, 0));
                 if ((a.ablate & 1) && !(in && oy == 0 && ox == 0)) ooff[rr] = OOB;      // one store per tile keeps the math live
+                pf[rr] = pm[rr] = 0.0f;
+                if (a.pre) {
+                    const int poff = (in & c_ok) ? (((oy >> a.pre_shift) * a.pre_W + (ox >> a.pre_shift)) * a.pre_cstride + c) * 4 : OOB;
+                    pf[rr] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(prsrc, poff, a.pre_foff * 4, 0));
+                    pm[rr] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(prsrc, poff, a.pre_moff * 4, 0));
+                }
             }
 #pragma unroll
             for (int rr = 0; rr < TL::NR; ++rr) {
@@ -343,8 +355,8 @@ __global__ __launch_bounds__(256) void gated_conv_kernel(const ConvKArgs a)
                     f = acc[p][2 * g][rr];            // WK == 1: r == rr
                     m = acc[p][2 * g + 1][rr];
                 }
-                f += bf;
-                m += bm;
+                f += bf + pf[rr];
+                m += bm + pm[rr];
                 if (a.linear) {
                     // ooff addresses channel c of the first half; the second half starts Cout channels later
                     const int o2 = (ooff[rr] != OOB && c_ok) ? ooff[rr] + a.Cout * 4 : OOB;
@@ -495,6 +507,8 @@ __global__ __launch_bounds__(256, (P * QG >= 2 ? 2 : 3)) void gated_conv_wave_ke
         (void *)a.out, 0, a.outH * a.outW * a.out_cstride * 4, 0x00020000);
     const __amdgpu_buffer_rsrc_t rrsrc = __builtin_amdgcn_make_buffer_rsrc(
         (void *)(a.residual ? a.residual : a.out), 0, a.residual ? a.outH * a.outW * a.Cout * 4 : 0, 0x00020000);
+    const __amdgpu_buffer_rsrc_t prsrc = __builtin_amdgcn_make_buffer_rsrc(
+        (void *)(a.pre ? a.pre : a.out), 0, a.pre ? a.pre_bytes : 0, 0x00020000);
 
     // ---- prologue: first item into LDS, second into registers, B ring of the first unit
     gload();
@@ -571,6 +585,16 @@ __global__ __launch_bounds__(256, (P * QG >= 2 ? 2 : 3)) void gated_conv_wave_ke
                     ooff[r] = (in & c_st) ? (opix * a.out_cstride + c) * 4 : OOB;
                     const int roff = (in & c_ok) ? (opix * a.Cout + c) * 4 : OOB;
                     rv[r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rrsrc, roff, 0, 0));
+                }
+                if (a.pre) {                               // pre-activation addend: straight into the accumulators
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const int ox = ox0 + (r & 3) + 8 * (r >> 2) + 4 * hi;
+                        const bool in = (oy < a.outH) & (ox < a.outW) & c_ok;
+                        const int poff = in ? (((oy >> a.pre_shift) * a.pre_W + (ox >> a.pre_shift)) * a.pre_cstride + c) * 4 : OOB;
+                        acc[p][2 * g][r] += __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(prsrc, poff, a.pre_foff * 4, 0));
+                        acc[p][2 * g + 1][r] += __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(prsrc, poff, a.pre_moff * 4, 0));
+                    }
                 }
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
@@ -1410,6 +1434,23 @@ int launch_gated_conv(const read_conv_desc *d, hipStream_t stream)
     a.ablate = g_ablate;
     a.fill_pad = d->fill_pad;
     a.out_fill = d->out_fill;
+    if (d->pre) {
+        READ_CHECK_ARG(!c.wino, "read_gated_conv_forward: the Winograd kernel takes no pre-activation addend");
+        READ_CHECK_ARG((uintptr_t)d->pre % 4 == 0 && d->pre_shift >= 0 && d->pre_shift <= 4 && d->pre_f_off >= 0 && d->pre_m_off >= 0 &&
+                           d->pre_cstride >= d->pre_f_off + d->Cout && d->pre_cstride >= d->pre_m_off + d->Cout,
+                       "read_gated_conv_forward: bad pre-activation addend layout");
+        READ_CHECK_ARG(d->preH >= ((outH - 1) >> d->pre_shift) + 1 && d->preW >= ((outW - 1) >> d->pre_shift) + 1 &&
+                           (long long)d->preH * d->preW * d->pre_cstride * 4 < OOB_LIMIT,
+                       "read_gated_conv_forward: pre-activation addend %dx%d does not cover the %dx%d output at shift %d", d->preH,
+                       d->preW, outH, outW, d->pre_shift);
+        a.pre = d->pre;
+        a.pre_cstride = d->pre_cstride;
+        a.pre_foff = d->pre_f_off;
+        a.pre_moff = d->pre_m_off;
+        a.pre_shift = d->pre_shift;
+        a.pre_W = d->preW;
+        a.pre_bytes = d->preH * d->preW * d->pre_cstride * 4;
+    }
     const int tiles_y = ceil_div(outH, c.WM * c.P);
     dim3 grid((unsigned)(a.tiles_x * tiles_y), (unsigned)(groups / (c.WN * c.QG)));
     a.trace = ((size_t)grid.x * grid.y <= g_trace_records) ? g_trace : nullptr;
@@ -1477,7 +1518,7 @@ int launch_gated_conv(const read_conv_desc *d, hipStream_t stream)
 // the automatic choice takes the Winograd kernel for every layer it can run (measured faster on all four levels)
 int conv_uses_wino(const read_conv_desc *d)
 {
-    return d->config < 0 && g_use_wino && d->ksize == 3 && d->stride == 1 && d->n_src == 1 &&
+    return d->config < 0 && g_use_wino && !d->pre && d->ksize == 3 && d->stride == 1 && d->n_src == 1 &&
            d->src[0].shift == 0 && d->src[0].C % 16 == 0 && d->wpacked_wino && d->src[0].C <= g_use_wino;
 }
 

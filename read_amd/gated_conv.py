@@ -43,15 +43,18 @@ class PackedGatedConv:
 
 
 def gated_conv(packed, sources, stride=1, elu=True, mul=None, residual=None, config=-1, out=None,
-               out_channels=None, fill=None):
-    """sources: list of (NHWC tensor (h,w,C), shift).  Returns the NHWC output (outH,outW,Cout)."""
+               out_channels=None, fill=None, linear=False, pre=None):
+    """sources: list of (NHWC tensor (h,w,C), shift).  Returns the NHWC output (outH,outW,Cout).
+
+    linear: plain convolution, output channels [conv_f + b_f | conv_m + b_m] (2*Cout).
+    pre: (NHWC tensor, f_off, m_off, shift) pre-activation addend sampled at (y >> shift, x >> shift)."""
     t0, s0 = sources[0]
     inH = (t0.shape[0] >> s0) if s0 >= 0 else (t0.shape[0] << -s0)
     inW = (t0.shape[1] >> s0) if s0 >= 0 else (t0.shape[1] << -s0)
     pad = (packed.k - 1) // 2
     outH = (inH + 2 * pad - packed.k) // stride + 1
     outW = (inW + 2 * pad - packed.k) // stride + 1
-    cs = out_channels if out_channels is not None else packed.cout
+    cs = out_channels if out_channels is not None else packed.cout * (2 if linear else 1)
     if out is None:
         out = torch.empty((outH, outW, cs), dtype=torch.float32, device=t0.device)
     d = _lib.ConvDesc()
@@ -73,6 +76,12 @@ def gated_conv(packed, sources, stride=1, elu=True, mul=None, residual=None, con
     d.out_fill = 0.0 if fill is None else float(fill)
     d.config = config
     d.wpacked_wino = packed.wpacked_wino.data_ptr() if packed.wpacked_wino is not None else None
+    d.linear = 1 if linear else 0
+    if pre is not None:
+        pt, f_off, m_off, psh = pre
+        assert pt.is_contiguous() and pt.dtype == torch.float32
+        d.pre, d.pre_cstride, d.pre_f_off, d.pre_m_off, d.pre_shift = pt.data_ptr(), pt.shape[2], f_off, m_off, psh
+        d.preH, d.preW = pt.shape[0], pt.shape[1]
     _lib.check(_lib.lib().read_gated_conv_forward(C.byref(d), _lib.stream_ptr()), "read_gated_conv_forward")
     return out
 

@@ -109,27 +109,41 @@ def test_param_packing_folds_batchnorm():
 
 
 def test_unet_blob_sizes_and_plan_flops():
-    """The launch plan can be built without a GPU (create only records pointers): 99 convs + 3
-    upsamples, algorithmic FLOPs as measured on the reference module."""
+    """The launch plan can be built without a GPU (create only records pointers).  As the reference wires the network
+    (read_tuning_set("unet_aff_split", 0)): 99 convs + 3 upsamples, algorithmic FLOPs as measured on the reference module
+    (BASELINE.md §2).  Default plan: the AFF inputs of coarser levels are multiplied at their own level (3 extra
+    launches, 46.0 -> 11.2 GFLOP at 1216x352)."""
     L = _lib.lib()
     raw = sum(2 * (co * ci * k * k + co) + 4 * co for (_, ci, co, k) in UNET_SPEC)
     assert L.read_unet_raw_floats() == raw
-    for (H, W, gflop) in [(352, 1216, 1221.73), (256, 256, 187.06)]:
-        need = L.read_unet_workspace_bytes(H, W)
-        ws = np.empty(need + 256, np.uint8)
-        base = (ws.ctypes.data + 255) // 256 * 256
-        pk = np.empty(64, np.float32)
-        h = C.c_void_p()
-        _lib.check(L.read_unet_create(C.byref(h), (pk.ctypes.data + 15) // 16 * 16, H, W, base, need))
-        n = L.read_unet_launch_count(h)
-        assert n == 102
-        tot = 0.0
-        for i in range(n):
-            fl = C.c_double()
-            L.read_unet_launch_info(h, i, C.byref(fl), None, None, None, None, None)
-            tot += fl.value
-        assert abs(tot / 1e9 - gflop) < 0.01
-        L.read_unet_destroy(h)
+
+    def aff_gflop(H, W, split):
+        px = [H * W >> (2 * l) for l in range(4)]
+        if not split:
+            return sum(4.0 * px[l] * 480 * (32 << l) for l in range(3)) / 1e9
+        q = 4.0 * (px[3] * 256 * 224 + px[2] * 128 * 96 + px[1] * 64 * 32)
+        r = 4.0 * (px[0] * 32 * 32 + px[1] * 96 * 64 + px[2] * 224 * 128)
+        return (q + r) / 1e9
+
+    for split, launches in ((0, 102), (1, 105)):
+        _lib.check(L.read_tuning_set(b"unet_aff_split", split))
+        for (H, W, gflop) in [(352, 1216, 1221.73), (256, 256, 187.06)]:
+            need = L.read_unet_workspace_bytes(H, W)
+            ws = np.empty(need + 256, np.uint8)
+            base = (ws.ctypes.data + 255) // 256 * 256
+            pk = np.empty(64, np.float32)
+            h = C.c_void_p()
+            _lib.check(L.read_unet_create(C.byref(h), (pk.ctypes.data + 15) // 16 * 16, H, W, base, need))
+            n = L.read_unet_launch_count(h)
+            assert n == launches
+            tot = 0.0
+            for i in range(n):
+                fl = C.c_double()
+                L.read_unet_launch_info(h, i, C.byref(fl), None, None, None, None, None)
+                tot += fl.value
+            want = gflop - aff_gflop(H, W, 0) + aff_gflop(H, W, split)
+            assert abs(tot / 1e9 - want) < 0.01, (split, tot / 1e9, want)
+            L.read_unet_destroy(h)
     assert kc_for([8, 56]) == 8 and kc_for([32, 64, 128, 256]) == 16
 
 

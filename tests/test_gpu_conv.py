@@ -150,6 +150,38 @@ def test_concat_and_nearest_resample_sources(hip):
     _close(got, ref, "SCM 1x1 over cat[8,56]")
 
 
+def test_coarse_sources_as_pre_activation_addends(hip):
+    """The AFF plan of read_unet: a 1x1 conv commutes with nearest up-sampling, so the inputs that live at coarser levels
+    are multiplied at their own level by `linear` launches and enter the layer as a pre-activation addend
+    (read_conv_desc.pre); same reference as the single 480-channel launch (unet.py:239-254)."""
+    torch.manual_seed(21)
+    H, W = 24, 64
+    chans = [32, 64, 128]
+    xs = [torch.randn(c, H >> i, W >> i) for i, c in enumerate(chans)]            # fine, 1/2, 1/4
+    cat = torch.cat([F.interpolate(x[None], size=(H, W), mode="nearest") for x in xs], 1)
+    for cout in (32, 64, 128):                                                      # wave kernel (1, 2 groups), workgroup kernel (4)
+        st = _state(sum(chans), cout, 1, seed=30 + cout)
+        ref = unet_torch.basic_conv(st, "L", cat, 1, elu=True)[0]
+        b = "L.block."
+
+        def part(c0, c1, own):
+            sub = dict(st)
+            for br in ("conv_f", "conv_m"):
+                sub[b + br + ".weight"] = np.ascontiguousarray(st[b + br + ".weight"][:, c0:c1])
+                if not own:
+                    sub[b + br + ".bias"] = np.zeros(cout, np.float32)
+            return _pack(sub, [c1 - c0])
+
+        q2 = gated_conv(part(96, 224, False), [(_nhwc(xs[2]), 0)], linear=True)                         # 1/4: [f | m]
+        q1 = gated_conv(part(32, 96, False), [(_nhwc(xs[1]), 0)], linear=True, pre=(q2, 0, cout, 1))    # 1/2, + up(q2)
+        assert q1.shape == (H // 2, W // 2, 2 * cout)
+        got = gated_conv(part(0, 32, True), [(_nhwc(xs[0]), 0)], elu=True, pre=(q1, 0, cout, 1))
+        _close(got, ref, f"AFF split over three levels, Cout={cout}")
+        # the linear partial sums themselves
+        lin = F.conv2d(xs[2][None], torch.as_tensor(np.ascontiguousarray(st[b + "conv_f.weight"][:, 96:224])))[0]
+        _close(q2[:, :, :cout].contiguous(), lin, "linear 1x1 partial sum")
+
+
 def test_fam_multiply_and_residual(hip):
     """FAM: x1 + BC(x1*x2) (unet.py:114-117) in one launch."""
     torch.manual_seed(3)
