@@ -19,6 +19,8 @@ SOURCES = ["api_common.cpp", "splat.hip", "gather.hip", "conv.hip", "train.hip",
 ARCH = "gfx950"
 FLAGS = ["-O3", "-std=c++17", "-fPIC", f"--offload-arch={ARCH}", "-x", "hip",
          "-I", os.path.join(ROOT, "include"), "-I", CSRC, "-Wall", "-Wno-unused-function"]
+if os.environ.get("READ_DEBUG_KNOBS"):      # attribution probes whose results are invalid (conv_ablate, splat_probe): never shipped
+    FLAGS.append("-DREAD_DEBUG_KNOBS")
 # the rasteriser's pixel assignment must be bit-exact fp32: no a*b+c contraction
 # gather / train: fp32 atomicAdd as the hardware global_atomic_add_f32 (the default lowers it to a compare-and-swap loop)
 PER_FILE = {"splat.hip": ["-ffp-contract=off"], "conv.hip": ["-fno-slp-vectorize"], "gather.hip": ["-munsafe-fp-atomics"],

@@ -43,6 +43,8 @@ void splat_set_strips(int v);
 void splat_set_wgs(int v);
 void splat_set_zl2(int v);
 void splat_set_lds(int v);
+void splat_set_bins(int v);
+void splat_set_probe(int v);
 void splat_set_kslot(int v);
 int splat_get(const char *key, int *value);
 void conv_set_trace(void *buf, size_t bytes);
@@ -51,6 +53,7 @@ void conv_set_stagger(int ticks);
 void conv_set_ablate(int bits);
 void conv_set_wino(int max_cin);
 void conv_set_kc32(int v);
+void conv_set_px(int v);
 int conv_get(const char *key, int *value);
 void unet_set_streams(int v);
 void unet_set_aff_split(int v);
@@ -70,7 +73,7 @@ extern "C" int read_debug_set_trace(void *buf, size_t bytes)
 // selects between implementations that produce the SAME results; the attribution probes whose results are invalid
 // ("conv_ablate") exist only in builds with -DREAD_DEBUG_KNOBS.
 static const char *const k_tuning_keys[] = {"splat_mode", "splat_stats", "splat_subset", "splat_near", "splat_cells",
-                                            "splat_cells_sub", "splat_seeds", "splat_items", "splat_strips", "splat_wgs", "splat_zl2", "splat_lds", "splat_kslot", "unet_streams", "unet_aff_split", "conv_kc32",
+                                            "splat_cells_sub", "splat_seeds", "splat_items", "splat_strips", "splat_wgs", "splat_zl2", "splat_lds", "splat_bins", "splat_kslot", "unet_streams", "unet_aff_split", "conv_kc32", "conv_px",
                                             "conv_wino", "conv_stagger", "conv_wave",
 #ifdef READ_DEBUG_KNOBS
                                             "conv_ablate",
@@ -95,18 +98,21 @@ extern "C" int read_tuning_set(const char *key, int value)
     if (!strcmp(key, "splat_items")) { readhip::splat_set_items(value); return READ_OK; }     // work items per chunk: 1, 2, 4
     if (!strcmp(key, "splat_kslot")) { readhip::splat_set_kslot(value); return READ_OK; }     // key-image layout: 0 linear, 1 strided, 2 scattered
     if (!strcmp(key, "splat_lds")) { readhip::splat_set_lds(value); return READ_OK; }         // 0: no LDS table in front of the atomics
+    if (!strcmp(key, "splat_bins")) { readhip::splat_set_bins(value); return READ_OK; }       // 0: pass A with one atomic per candidate
     if (!strcmp(key, "splat_zl2")) { readhip::splat_set_zl2(value); return READ_OK; }         // 1: early-z loads bypass the L1
     if (!strcmp(key, "splat_wgs")) { readhip::splat_set_wgs(value); return READ_OK; }         // workgroups per CU of the passes
     if (!strcmp(key, "splat_strips")) { readhip::splat_set_strips(value); return READ_OK; }   // column strips: 1, 2, 4, 8
     if (!strcmp(key, "unet_streams")) { readhip::unet_set_streams(value); return READ_OK; }   // 0: SCM chains on the caller's stream
     // 0: AFF first convs as single 480-channel launches (takes effect for plans created afterwards)
     if (!strcmp(key, "unet_aff_split")) { readhip::unet_set_aff_split(value != 0); return READ_OK; }
+    if (!strcmp(key, "conv_px")) { readhip::conv_set_px(value); return READ_OK; }             // pixel-lane kernel for 1x1 layers
     if (!strcmp(key, "conv_kc32")) { readhip::conv_set_kc32(value); return READ_OK; }
     if (!strcmp(key, "conv_wino")) { readhip::conv_set_wino(value); return READ_OK; }         // largest Cin on the Winograd kernel (0 = off)
     if (!strcmp(key, "conv_stagger")) { readhip::conv_set_stagger(value); return READ_OK; }
     if (!strcmp(key, "conv_wave")) { readhip::conv_set_prefer_wave(value != 0); return READ_OK; }
 #ifdef READ_DEBUG_KNOBS
     if (!strcmp(key, "conv_ablate")) { readhip::conv_set_ablate(value); return READ_OK; }
+    if (!strcmp(key, "splat_probe")) { readhip::splat_set_probe(value); return READ_OK; }
 #endif
     readhip::set_error("read_tuning_set: unknown key '%s'", key);
     return READ_EINVAL;

@@ -1013,6 +1013,182 @@ __global__ __launch_bounds__(256, 2) void gated_conv_wino_kernel(const ConvKArgs
 }
 
 // ------------------------------------------------------------------------------------------
+// 1x1 layers in the "pixel-lane" orientation: weights are the MFMA A operand, activations the B operand.
+//
+//   D[cout][pixel] = sum_k W[cout][k] * X[k][pixel]        (v_mfma_f32_32x32x2_f32: lane = pixel, registers = channels)
+//
+// With NHWC activations both sides of the product are then plain 128-bit global accesses and nothing is transposed:
+//   * B operand: lane (h = lane >> 5, j = lane & 31) supplies k = h (+2, +4, +6 inside a float4 step): the float4 at channel
+//     8s + 4h of pixel j — one global_load_dwordx4 per lane and k8 step, straight from the tensor (no LDS tile);
+//   * D: lane (h, j) ends up with channels 8q + 4h + {0..3} (q = register quad) of pixel j, for conv_f and conv_m alike:
+//     the epilogue is lane-local and loads / stores 4 consecutive channels at a time (residual, pre-activation addend,
+//     output), 4 + 4 memory instructions per 32x32 tile instead of the 16 + 16 dword accesses of the other orientation;
+//   * A operand = the layer's packed weights (same fragment order as everywhere else), copied ONCE per persistent
+//     workgroup into LDS and read from there with conflict-free ds_read_b128 — a wave then streams pixel tiles with no
+//     barrier and no LDS writes in its loop.
+// A wave's unit = PT tiles of 32 consecutive pixels (flattened y*W + x) x GW 32-channel groups; the activation ring holds
+// four k8 steps per tile and is refilled four steps ahead of the MFMAs, across unit boundaries.  Sources of other levels
+// (nearest resampling, unet.py:239-254) are addressed per lane.  Measured next to the LDS-tiled kernels in
+// profiles/README.md (the 1x1 layers are short-K: their time is the epilogue and HBM traffic, not MFMAs).
+template <int PT, int GW>
+__global__ __launch_bounds__(256, (PT * GW >= 4 ? 2 : 3)) void gated_conv_px_kernel(const ConvKArgs a)
+{
+    extern __shared__ __attribute__((aligned(16))) float4 wl[];      // [k8 step][2 GW tiles (f, m per group)][lane]
+    constexpr int T = 2 * GW;
+    typedef float f32x4 __attribute__((ext_vector_type(4)));
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int half = lane >> 5, lp = lane & 31;
+    const int nsteps = a.nchunks;                                    // k8 steps = Cin / 8
+    const int nquads = (nsteps + 3) >> 2;                            // the ring advances in quads; steps >= nsteps are empty
+    const int gsets = (a.CoutPad >> 5) / GW;
+    const int gs = blockIdx.x % gsets;                               // channel-group set of this workgroup
+    {
+        const int NT = a.CoutPad >> 4;
+        const float4 *wp4 = reinterpret_cast<const float4 *>(a.wp);
+        for (int i = threadIdx.x; i < nsteps * T * 64; i += 256) {
+            const int l = i & 63, t = (i >> 6) % T, st = (i >> 6) / T;
+            wl[i] = wp4[((size_t)st * NT + gs * T + t) * 64 + l];
+        }
+    }
+    __syncthreads();
+    const int npix = a.outH * a.outW;
+    const int wslots = (gridDim.x / gsets) * 4, w0 = (blockIdx.x / gsets) * 4 + wave;
+    if (w0 >= a.n_units) return;
+
+    // ---- load cursor: (unit, step) of the next activation fragment, four steps ahead of the MFMAs
+    int lu = w0, lstep = 0, lsrc = 0, lcoff = 0;
+    SrcDev lsd = a.src[0];
+    int ly[PT], lx[PT];
+    auto set_load_unit = [&]() {
+#pragma unroll
+        for (int pt = 0; pt < PT; ++pt) {
+            int p = (lu * PT + pt) * 32 + lp;
+            p = p < npix ? p : npix - 1;                             // past the image (and past the last unit): a valid pixel
+            ly[pt] = p / a.outW;
+            lx[pt] = p - ly[pt] * a.outW;
+        }
+    };
+    float4 ring[4][PT];
+    auto load_step = [&](int slot) {
+        if (lstep < nsteps) {
+#pragma unroll
+            for (int pt = 0; pt < PT; ++pt) {
+                const int sy = (ly[pt] << lsd.sl) >> lsd.sr, sx = (lx[pt] << lsd.sl) >> lsd.sr;
+                ring[slot][pt] = *reinterpret_cast<const float4 *>(lsd.p + (sy * lsd.W + sx) * lsd.C + lcoff + 4 * half);
+            }
+            lcoff += 8;
+            if (lcoff >= lsd.C && lsrc + 1 < a.n_src) {
+                ++lsrc;
+                lcoff = 0;
+                lsd = a.src[lsrc];
+            }
+        }
+        if (++lstep == 4 * nquads) {
+            lstep = 0;
+            lu += wslots;
+            lsrc = 0;
+            lcoff = 0;
+            lsd = a.src[0];
+            set_load_unit();
+        }
+    };
+    set_load_unit();
+#pragma unroll
+    for (int e = 0; e < 4; ++e) load_step(e);
+
+    const bool quad_res = a.residual != nullptr;
+    for (int u = w0; u < a.n_units; u += wslots) {
+        floatx16 acc[PT][GW][2];
+#pragma unroll
+        for (int pt = 0; pt < PT; ++pt)
+#pragma unroll
+            for (int g = 0; g < GW; ++g)
+#pragma unroll
+                for (int fm = 0; fm < 2; ++fm)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) acc[pt][g][fm][r] = 0.0f;
+
+        float4 w[2][T];
+#pragma unroll
+        for (int t = 0; t < T; ++t) w[0][t] = wl[t * 64 + lane];
+        for (int q = 0; q < nquads; ++q) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int st = 4 * q + e;
+                if (st < nsteps) {
+                    const int sn = st + 1 < nsteps ? st + 1 : 0;     // next step's weights (the unit's first again at the end)
+#pragma unroll
+                    for (int t = 0; t < T; ++t) w[(e + 1) & 1][t] = wl[(sn * T + t) * 64 + lane];
+#pragma unroll
+                    for (int j = 0; j < 4; ++j)
+#pragma unroll
+                        for (int pt = 0; pt < PT; ++pt)
+#pragma unroll
+                            for (int g = 0; g < GW; ++g)
+#pragma unroll
+                                for (int fm = 0; fm < 2; ++fm) {
+                                    const float4 wv = w[e & 1][2 * g + fm], xv = ring[e][pt];
+                                    const float av = j == 0 ? wv.x : j == 1 ? wv.y : j == 2 ? wv.z : wv.w;
+                                    const float bv = j == 0 ? xv.x : j == 1 ? xv.y : j == 2 ? xv.z : xv.w;
+                                    acc[pt][g][fm] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc[pt][g][fm], 0, 0, 0);
+                                }
+                }
+                load_step(e);                                        // slot e now takes step st + 4 of the stream
+            }
+        }
+        // (nsteps odd multiples of 1..3 leave w[] parity off by the skipped steps: reload at the next unit's start)
+
+        // ---- epilogue: lane = (pixel, channel quad), everything 128 bits wide
+#pragma unroll
+        for (int pt = 0; pt < PT; ++pt) {
+            const int p = (u * PT + pt) * 32 + lp;
+            const bool p_ok = p < npix;
+            const int y = p / a.outW, x = p - y * a.outW;
+            const size_t pre_pix = a.pre ? ((size_t)(y >> a.pre_shift) * a.pre_W + (x >> a.pre_shift)) * a.pre_cstride : 0;
+#pragma unroll
+            for (int g = 0; g < GW; ++g)
+#pragma unroll
+                for (int qd = 0; qd < 4; ++qd) {
+                    const int c0 = (gs * GW + g) * 32 + 8 * qd + 4 * half;
+                    if (!p_ok || c0 >= a.Cout) continue;
+                    f32x4 f, m;
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) {
+                        f[k] = acc[pt][g][0][4 * qd + k];
+                        m[k] = acc[pt][g][1][4 * qd + k];
+                    }
+                    f += *reinterpret_cast<const f32x4 *>(a.params + c0);
+                    m += *reinterpret_cast<const f32x4 *>(a.params + a.CoutPad + c0);
+                    if (a.pre) {
+                        f += *reinterpret_cast<const f32x4 *>(a.pre + pre_pix + a.pre_foff + c0);
+                        m += *reinterpret_cast<const f32x4 *>(a.pre + pre_pix + a.pre_moff + c0);
+                    }
+                    float *op = a.out + (size_t)p * a.out_cstride + c0;
+                    if (a.linear) {
+                        *reinterpret_cast<f32x4 *>(op) = f;
+                        *reinterpret_cast<f32x4 *>(op + a.Cout) = m;
+                        continue;
+                    }
+                    constexpr float LOG2E = 1.44269504088896341f;
+                    if (a.elu) {
+                        const f32x4 fe = f * LOG2E;
+#pragma unroll
+                        for (int k = 0; k < 4; ++k) f[k] = f[k] > 0.0f ? f[k] : __builtin_amdgcn_exp2f(fe[k]) - 1.0f;
+                    }
+                    const f32x4 mm = m * -LOG2E;
+                    f32x4 sg;
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) sg[k] = __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(mm[k]));
+                    f32x4 v = (f * sg) * *reinterpret_cast<const f32x4 *>(a.params + 2 * a.CoutPad + c0) +
+                              *reinterpret_cast<const f32x4 *>(a.params + 3 * a.CoutPad + c0);
+                    if (quad_res) v += *reinterpret_cast<const f32x4 *>(a.residual + (size_t)p * a.Cout + c0);
+                    *reinterpret_cast<f32x4 *>(op) = v;
+                }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------
 // configuration table
 // ------------------------------------------------------------------------------------------
 typedef void (*conv_fn)(const ConvKArgs);
@@ -1112,6 +1288,7 @@ int find_config(int ks, int s, int kc, int P, int QG, int WM, int WN, int PF, in
 }
 
 int g_prefer_wave = 1;   // read_tuning_set("conv_wave", 0): workgroup-tiled kernels only
+int g_conv_px = 1;         // read_tuning_set("conv_px", v): pixel-lane kernel for 1x1 layers (0 off, 1: 64 accumulator registers, 2: 128)
 int g_kc32 = 1;            // 32-channel chunks for 1x1 layers whose sources are all multiples of 32 (read_tuning_set("conv_kc32", 0): 16)
 int g_use_wino = 1 << 30;  // read_tuning_set("conv_wino", max Cin): Winograd kernel for eligible 3x3 layers (0 = off)
 int g_stagger_ticks = 0;   // read_tuning_set("conv_stagger", ticks of 10 ns)
@@ -1306,11 +1483,13 @@ void conv_set_stagger(int ticks) { g_stagger_ticks = ticks < 0 ? 0 : ticks; }
 void conv_set_ablate(int bits) { g_ablate = bits; }
 void conv_set_wino(int max_cin) { g_use_wino = max_cin; }
 void conv_set_kc32(int v) { g_kc32 = v; }
+void conv_set_px(int v) { g_conv_px = v < 0 ? 0 : v > 2 ? 2 : v; }
 int conv_get(const char *key, int *value)
 {
     if (!strcmp(key, "conv_wave")) *value = g_prefer_wave;
     else if (!strcmp(key, "conv_stagger")) *value = g_stagger_ticks;
     else if (!strcmp(key, "conv_kc32")) *value = g_kc32;
+    else if (!strcmp(key, "conv_px")) *value = g_conv_px;
     else if (!strcmp(key, "conv_wino")) *value = g_use_wino;
 #ifdef READ_DEBUG_KNOBS
     else if (!strcmp(key, "conv_ablate")) *value = g_ablate;
@@ -1382,6 +1561,85 @@ int launch_gated_conv(const read_conv_desc *d, hipStream_t stream)
     READ_CHECK_ARG((long long)outH * outW * d->out_cstride * 4 < OOB_LIMIT, "read_gated_conv_forward: output too large");
     const int CoutPad = pad32(d->Cout), groups = CoutPad / 32;
     int cfg = d->config;
+    if (d->pre) {
+        READ_CHECK_ARG((uintptr_t)d->pre % 4 == 0 && d->pre_shift >= 0 && d->pre_shift <= 4 && d->pre_f_off >= 0 && d->pre_m_off >= 0 &&
+                           d->pre_cstride >= d->pre_f_off + d->Cout && d->pre_cstride >= d->pre_m_off + d->Cout,
+                       "read_gated_conv_forward: bad pre-activation addend layout");
+        READ_CHECK_ARG(d->preH >= ((outH - 1) >> d->pre_shift) + 1 && d->preW >= ((outW - 1) >> d->pre_shift) + 1 &&
+                           (long long)d->preH * d->preW * d->pre_cstride * 4 < OOB_LIMIT,
+                       "read_gated_conv_forward: pre-activation addend %dx%d does not cover the %dx%d output at shift %d", d->preH,
+                       d->preW, outH, outW, d->pre_shift);
+        a.pre = d->pre;
+        a.pre_cstride = d->pre_cstride;
+        a.pre_foff = d->pre_f_off;
+        a.pre_moff = d->pre_m_off;
+        a.pre_shift = d->pre_shift;
+        a.pre_W = d->preW;
+        a.pre_bytes = d->preH * d->preW * d->pre_cstride * 4;
+    }
+    a.mul = d->mul;
+    a.wp = d->wpacked;
+    a.wp_wino = d->wpacked_wino;
+    a.params = d->params;
+    a.residual = d->residual;
+    a.out = d->out;
+    a.inH = d->inH;
+    a.inW = d->inW;
+    a.outH = outH;
+    a.outW = outW;
+    a.Cout = d->Cout;
+    a.CoutPad = CoutPad;
+    a.out_cstride = d->out_cstride;
+    a.elu = d->elu;
+    a.linear = d->linear;
+    a.ablate = g_ablate;
+    a.fill_pad = d->fill_pad;
+    a.out_fill = d->out_fill;
+
+    // ---- 1x1 layers: the pixel-lane kernel (config -2 forces it, -1 takes it whenever the layer qualifies)
+    {
+        const int nsteps = Cin / 8;
+        const int gw = (groups % 2 == 0 && nsteps <= 16) ? 2 : 1;
+        const bool fits = d->ksize == 1 && d->stride == 1 && !d->mul && !d->fill_pad && d->Cout % 4 == 0 && d->out_cstride % 4 == 0 &&
+                          (uintptr_t)d->out % 16 == 0 && (uintptr_t)d->params % 16 == 0 && nsteps <= 32 &&
+                          (!d->residual || (uintptr_t)d->residual % 16 == 0) &&
+                          (!d->pre || ((uintptr_t)d->pre % 16 == 0 && d->pre_cstride % 4 == 0 && d->pre_f_off % 4 == 0 && d->pre_m_off % 4 == 0));
+        READ_CHECK_ARG(d->config != -2 || fits, "read_gated_conv_forward: the pixel-lane kernel takes 1x1/s1 layers with Cin <= 256, "
+                       "Cout %% 4 == 0 and 16-byte aligned tensors");
+        if (d->config == -2 || (d->config == -1 && g_conv_px && fits)) {
+            static int n_cu_p = 0;
+            if (!n_cu_p) {
+                int dev = 0;
+                hipDeviceProp_t prop;
+                n_cu_p = (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess &&
+                          prop.multiProcessorCount > 0) ? prop.multiProcessorCount : 256;
+            }
+            const bool wide = g_conv_px >= 2;                       // 128 accumulator registers per wave instead of 64
+            const int pt = (gw == 2 ? 1 : 2) * (wide ? 2 : 1);
+            const size_t lds = (size_t)nsteps * 2 * gw * 1024;
+            int per_cu = (int)((160 * 1024) / (lds + 256));
+            const int reg_cap = wide ? 2 : 3;
+            per_cu = per_cu < 1 ? 1 : per_cu > reg_cap ? reg_cap : per_cu;
+            const int gsets = groups / gw;
+            a.nchunks = nsteps;
+            a.n_units = ceil_div(outH * outW, 32 * pt);
+            int per_set = (n_cu_p * per_cu) / gsets;
+            const int want = ceil_div(a.n_units, 4);
+            per_set = per_set < 1 ? 1 : per_set;
+            per_set = per_set < want ? per_set : want;
+            conv_fn fn = gw == 2 ? (wide ? gated_conv_px_kernel<2, 2> : gated_conv_px_kernel<1, 2>)
+                                 : (wide ? gated_conv_px_kernel<4, 1> : gated_conv_px_kernel<2, 1>);
+            static bool attr_set[4] = {false, false, false, false};
+            const int vi = (gw == 2 ? 2 : 0) + (wide ? 1 : 0);
+            if (!attr_set[vi]) {                                    // 64 KiB of dynamic LDS at Cin = 256
+                READ_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024));
+                attr_set[vi] = true;
+            }
+            hipLaunchKernelGGL(fn, dim3((unsigned)(per_set * gsets)), dim3(256), lds, stream, a);
+            READ_CHECK_LAUNCH();
+            return READ_OK;
+        }
+    }
     if (d->linear) {
         // the plain-convolution epilogue exists in the workgroup-tiled kernels and in the Winograd kernel
         READ_CHECK_ARG(cfg < 0 || (cfg < N_CONFIGS && !g_configs[cfg].wave),
@@ -1414,43 +1672,9 @@ int launch_gated_conv(const read_conv_desc *d, hipStream_t stream)
     READ_CHECK_ARG(c.KS == d->ksize && c.S == d->stride && c.KC == kc && groups % (c.WN * c.QG) == 0,
                    "read_gated_conv_forward: config %s does not fit k=%d s=%d kc=%d groups=%d", c.name, d->ksize,
                    d->stride, kc, groups);
-    a.mul = d->mul;
-    a.wp = d->wpacked;
-    a.wp_wino = d->wpacked_wino;
-    a.params = d->params;
-    a.residual = d->residual;
-    a.out = d->out;
-    a.inH = d->inH;
-    a.inW = d->inW;
-    a.outH = outH;
-    a.outW = outW;
-    a.Cout = d->Cout;
-    a.CoutPad = CoutPad;
-    a.out_cstride = d->out_cstride;
     a.nchunks = nchunks;
     a.tiles_x = ceil_div(outW, 32);
-    a.elu = d->elu;
-    a.linear = d->linear;
-    a.ablate = g_ablate;
-    a.fill_pad = d->fill_pad;
-    a.out_fill = d->out_fill;
-    if (d->pre) {
-        READ_CHECK_ARG(!c.wino, "read_gated_conv_forward: the Winograd kernel takes no pre-activation addend");
-        READ_CHECK_ARG((uintptr_t)d->pre % 4 == 0 && d->pre_shift >= 0 && d->pre_shift <= 4 && d->pre_f_off >= 0 && d->pre_m_off >= 0 &&
-                           d->pre_cstride >= d->pre_f_off + d->Cout && d->pre_cstride >= d->pre_m_off + d->Cout,
-                       "read_gated_conv_forward: bad pre-activation addend layout");
-        READ_CHECK_ARG(d->preH >= ((outH - 1) >> d->pre_shift) + 1 && d->preW >= ((outW - 1) >> d->pre_shift) + 1 &&
-                           (long long)d->preH * d->preW * d->pre_cstride * 4 < OOB_LIMIT,
-                       "read_gated_conv_forward: pre-activation addend %dx%d does not cover the %dx%d output at shift %d", d->preH,
-                       d->preW, outH, outW, d->pre_shift);
-        a.pre = d->pre;
-        a.pre_cstride = d->pre_cstride;
-        a.pre_foff = d->pre_f_off;
-        a.pre_moff = d->pre_m_off;
-        a.pre_shift = d->pre_shift;
-        a.pre_W = d->preW;
-        a.pre_bytes = d->preH * d->preW * d->pre_cstride * 4;
-    }
+    READ_CHECK_ARG(!d->pre || !c.wino, "read_gated_conv_forward: the Winograd kernel takes no pre-activation addend");
     const int tiles_y = ceil_div(outH, c.WM * c.P);
     dim3 grid((unsigned)(a.tiles_x * tiles_y), (unsigned)(groups / (c.WN * c.QG)));
     a.trace = ((size_t)grid.x * grid.y <= g_trace_records) ? g_trace : nullptr;

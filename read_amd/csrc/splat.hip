@@ -544,21 +544,138 @@ __global__ __launch_bounds__(256) void cells_seed_classify_kernel(CellCloud cc, 
 // overhead.  Candidates that find their probe slots taken by other pixels go to memory directly.
 constexpr int LDS_SLOTS = 256;       // per wave
 
-template <bool STATS, bool ZL2, bool LDS>
+// ---- pass A without data-path atomics: candidates are binned by 32x32-pixel screen tile ------------------------------
+// Pass A was bound by the NUMBER of memory-side atomics (0.75 M x ~65 ps = 49 of its 54 us, profiles/README.md).  With
+// bins a candidate (a point that beat the bound image) becomes a 16-byte record (pixel inside the tile, key) appended
+// to its tile's bin; cells_merge_hiz_kernel — one workgroup per tile, the tile's keys in LDS — then takes the minimum
+// per pixel with LDS atomics and writes the tile back with plain stores.  min() does not care about order or grouping, so
+// the key image after the merge is the one the atomics would have produced.  Slots are reserved per wave and tile: the
+// candidates of a wave's 256-point item fall into a handful of tiles, each (tile, count) pair costs ONE returning
+// atomic on the tile's counter, all of them issued together (one memory round trip per item).  A full bin (or more than
+// 64 distinct (pass, tile) pairs in one item) falls back to the atomic on the key image, which the merge reads first.
+// Counters are kept MINUS ONE: read_splat_workspace_init() fills the workspace with ones, which then means "empty".
+constexpr int BIN_TILE = 32;
+constexpr int BIN_SUB = 32;    // sub-bins per tile, chosen by the wave's index: same-address atomics serialise at ~30 ns each
+                               // (one counter per tile: pass A 96 us — near chunks of the same depth band hammer a few tiles)
+static_assert(BIN_SUB * 8 == 256, "cells_merge_hiz_kernel: 8 threads per sub-bin");
+struct BinInfo {
+    uint4 *recs;               // tiles x BIN_SUB x cap records {pixel inside the tile, 0, key lo, key hi}; null = pass A with atomics
+    unsigned *count;           // per (tile, sub-bin), minus one
+    int cap, tiles_x;
+    int probe;                 // -DREAD_DEBUG_KNOBS builds: attribution bits (results invalid): 1 no seed-position stores,
+                               //   2 no bound stores, 4 candidates dropped, 8 nothing after the projection
+    float inv_w;               // 1 / W (exact row of a pixel index: (pix + 0.5) * inv_w, W * H <= 2^20)
+};
+
+// NC candidates per lane (valid bit k of `valid`): records into the bins; pos[k] = position of the point (next frame's seed)
+template <int NC>
+__device__ __forceinline__ void emit_binned(const BinInfo &bi, int W, const int (&pix)[NC], const unsigned long long (&key)[NC],
+                                            unsigned valid, unsigned long long *keys, int lane, unsigned *wl_tile,
+                                            unsigned *wl_cnt, int sub)
+{
+    int tile[NC], inpix[NC], entry[NC], rank[NC];
+    int nd = 0;                                                     // wave-uniform: (pass, tile) pairs so far
+    const unsigned long long lt_mask = (1ull << lane) - 1ull;
+    // The candidates of an item are Morton neighbours: usually ONE tile.  Then the ranks are prefix counts over the NC
+    // ballots and the item costs a single reservation, with no lists.
+    {
+        unsigned long long mk[NC];
+        int t0 = -1;
+#pragma unroll
+        for (int k = 0; k < NC; ++k) {
+            const bool act = (valid >> k) & 1u;
+            const int y = (int)(((float)pix[k] + 0.5f) * bi.inv_w), x = pix[k] - y * W;
+            tile[k] = act ? ((y >> 5) * bi.tiles_x + (x >> 5)) * BIN_SUB + sub : -1;    // (tile, sub-bin of this wave)
+            inpix[k] = (y & 31) * BIN_TILE + (x & 31);
+            mk[k] = __ballot(act);
+            if (t0 < 0 && mk[k]) t0 = __builtin_amdgcn_readlane(tile[k], __builtin_ctzll(mk[k]));
+        }
+        bool same = true;
+#pragma unroll
+        for (int k = 0; k < NC; ++k) same = same && __ballot(tile[k] >= 0 && tile[k] != t0) == 0ull;
+        if (same) {
+            int total = 0;
+#pragma unroll
+            for (int k = 0; k < NC; ++k) {
+                rank[k] = total + __builtin_popcountll(mk[k] & lt_mask);
+                total += __builtin_popcountll(mk[k]);
+            }
+            unsigned base = 0;
+            if (lane == 0) base = atomicAdd(bi.count + t0, (unsigned)total) + 1u;        // counters are kept minus one
+            base = (unsigned)__builtin_amdgcn_readfirstlane((int)base);
+#pragma unroll
+            for (int k = 0; k < NC; ++k) {
+                if (!((valid >> k) & 1u)) continue;
+                const unsigned slot = base + (unsigned)rank[k];
+                if (slot < (unsigned)bi.cap)
+                    bi.recs[(size_t)t0 * bi.cap + slot] = make_uint4((unsigned)inpix[k], 0u, (unsigned)key[k], (unsigned)(key[k] >> 32));
+                else
+                    __hip_atomic_fetch_min(keys + pix[k], key[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+            return;
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < NC; ++k) {
+        const bool act = (valid >> k) & 1u;
+        entry[k] = -1;
+        rank[k] = 0;
+        unsigned long long todo = __ballot(act);
+        while (todo && nd < 64) {
+            const int leader = __builtin_ctzll(todo);
+            const int t = __builtin_amdgcn_readlane(tile[k], leader);
+            const unsigned long long m = __ballot(act && tile[k] == t);
+            if (act && tile[k] == t) {
+                entry[k] = nd;
+                rank[k] = __builtin_popcountll(m & lt_mask);
+            }
+            if (lane == 0) {
+                wl_tile[nd] = (unsigned)t;
+                wl_cnt[nd] = (unsigned)__builtin_popcountll(m);
+            }
+            ++nd;
+            todo &= ~m;
+        }
+    }
+    if (nd == 0) return;
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");          // the wave's own lists: LDS operations complete in order
+    if (lane < nd) {
+        const unsigned base = atomicAdd(bi.count + wl_tile[lane], wl_cnt[lane]) + 1u;     // counters are kept minus one
+        wl_cnt[lane] = base;
+    }
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+#pragma unroll
+    for (int k = 0; k < NC; ++k) {
+        if (!((valid >> k) & 1u)) continue;
+        const unsigned slot = entry[k] >= 0 ? wl_cnt[entry[k]] + (unsigned)rank[k] : 0xffffffffu;
+        if (slot < (unsigned)bi.cap)
+            bi.recs[(size_t)tile[k] * bi.cap + slot] = make_uint4((unsigned)inpix[k], 0u, (unsigned)key[k], (unsigned)(key[k] >> 32));
+        else
+            __hip_atomic_fetch_min(keys + pix[k], key[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");          // the lists are reused by the next batch
+}
+
+template <bool STATS, bool ZL2, bool LDS, bool BIN>
 __device__ __forceinline__ void strip_points(const CellCloud &cc, const float *M, int W, int H, int xlo, int xhi,
                                              unsigned long long *keys, unsigned *zimg, int *next, int first, int rounds,
                                              int lane, unsigned &st_in, unsigned &st_atomics, unsigned *tag,
-                                             unsigned long long *hkey, int *hpos, const KeySlots ks, bool use_lds)
+                                             unsigned long long *hkey, int *hpos, const KeySlots ks, bool use_lds,
+                                             const BinInfo &bi, unsigned *wl_tile, unsigned *wl_cnt, int sub,
+                                             float4 (&q)[4], int next_first)
 {
-    float4 q[4], qn[4];
-#pragma unroll
-    for (int k = 0; k < 4; ++k) q[k] = cc.pts[first + lane + 64 * k];
+    // q holds the first 256 records of this call (loaded by the caller: point_records); on return it holds the first 256 of
+    // the caller's NEXT call (next_first, -1 = none) — their loads run under this call's bound reads and slot reservations
+    float4 qn[4];
     for (int r = 0; r < rounds; ++r) {
         // 256 points: lane l takes records base + l + 64 k (each load instruction = 1 KiB contiguous)
         const int base = first + r * 256 + lane;
         if (r + 1 < rounds) {
 #pragma unroll
             for (int k = 0; k < 4; ++k) qn[k] = cc.pts[base + 256 + 64 * k];
+        } else if (next_first >= 0) {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) qn[k] = cc.pts[next_first + lane + 64 * k];
         }
         int pix[4];
         unsigned dbits[4], bound[4];
@@ -571,17 +688,35 @@ __device__ __forceinline__ void strip_points(const CellCloud &cc, const float *M
             dbits[k] = __float_as_uint(d);
             if (STATS && pix[k] >= 0) st_in++;
         }
+#ifdef READ_DEBUG_KNOBS
+        const int probe = bi.probe;
+        if (probe & 8) {
+#pragma unroll
+            for (int k = 0; k < 4; ++k)
+                if (pix[k] == -12345) zimg[0] = dbits[k];         // keeps the projection live
+#pragma unroll
+            for (int k = 0; k < 4; ++k) q[k] = qn[k];
+            continue;
+        }
+#else
+        constexpr int probe = 0;
+#endif
         // early-z against the bound image (L1 / this XCD's L2; a stale bound is only ever LARGER)
 #pragma unroll
         for (int k = 0; k < 4; ++k)
             bound[k] = pix[k] < 0 ? 0u
                        : ZL2 ? __hip_atomic_load(zimg + pix[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)   // sc1: L2, not L1
                              : zimg[pix[k]];
+        int cpix[4];                                               // BIN: candidates that go to memory directly
+        unsigned long long ckey[4];
+        unsigned cvalid = 0;
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
+            cpix[k] = 0;
+            ckey[k] = 0;
             if (pix[k] < 0 || dbits[k] > bound[k]) continue;       // ties pass: the atomic breaks them by id
             const unsigned long long key = ((unsigned long long)dbits[k] << 32) | __float_as_uint(q[k].w);
-            if (dbits[k] < bound[k]) zimg[pix[k]] = dbits[k];
+            if (dbits[k] < bound[k] && !(probe & 2)) zimg[pix[k]] = dbits[k];
             bool direct = true;
             if (LDS && use_lds) {
                 unsigned h = ((unsigned)pix[k] * 2654435761u) >> 24;
@@ -595,27 +730,46 @@ __device__ __forceinline__ void strip_points(const CellCloud &cc, const float *M
                 }
             }
             if (direct) {
-                __hip_atomic_fetch_min(keys + key_slot(ks, (unsigned)pix[k]), key, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                next[pix[k]] = base + 64 * k;                      // a front point of this pixel: next frame's seed
+                if (BIN) {
+                    cpix[k] = pix[k];
+                    ckey[k] = key;
+                    cvalid |= 1u << k;
+                } else {
+                    __hip_atomic_fetch_min(keys + key_slot(ks, (unsigned)pix[k]), key, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
+                if (!(probe & 1)) next[pix[k]] = base + 64 * k;    // a front point of this pixel: next frame's seed
                 if (STATS) st_atomics++;
             }
         }
+        if (probe & 4) cvalid = 0;
+        if (BIN && __ballot(cvalid != 0u)) emit_binned<4>(bi, W, cpix, ckey, cvalid, keys, lane, wl_tile, wl_cnt, sub);
         if (LDS && use_lds) {
             // the wave's own table: its LDS operations complete in program order, no barrier needed
             __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+            cvalid = 0;
 #pragma unroll
             for (int j = 0; j < LDS_SLOTS / 64; ++j) {
                 const int sl = lane + 64 * j;
                 const unsigned t = tag[sl];
+                cpix[j] = 0;
+                ckey[j] = 0;
                 if (t) {
-                    __hip_atomic_fetch_min(keys + key_slot(ks, t - 1u), hkey[sl], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    next[t - 1u] = hpos[sl];
+                    if (BIN) {
+                        cpix[j] = (int)(t - 1u);
+                        ckey[j] = hkey[sl];
+                        cvalid |= 1u << j;
+                    } else {
+                        __hip_atomic_fetch_min(keys + key_slot(ks, t - 1u), hkey[sl], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    }
+                    if (!(probe & 1)) next[t - 1u] = hpos[sl];
                     tag[sl] = 0u;
                     hkey[sl] = ~0ull;
                     if (STATS) st_atomics++;
                 }
             }
             __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+            if (probe & 4) cvalid = 0;
+            if (BIN && __ballot(cvalid != 0u)) emit_binned<4>(bi, W, cpix, ckey, cvalid, keys, lane, wl_tile, wl_cnt, sub);
         }
 #pragma unroll
         for (int k = 0; k < 4; ++k) q[k] = qn[k];
@@ -625,16 +779,18 @@ __device__ __forceinline__ void strip_points(const CellCloud &cc, const float *M
 // Pass A: an item = 1024 / sub_items consecutive points of one list-A chunk, for one wave and one strip.
 // Pass B: four list-B entries in flight per wave: the hi-Z bounds of their rectangles (inside the strip) are loaded together,
 // then reduced; chunks that survive are processed like pass-A chunks.
-template <bool PASS_B, bool STATS, bool ZL2, bool LDS>
+template <bool PASS_B, bool STATS, bool ZL2, bool LDS, bool BIN>
 __global__ __launch_bounds__(256) void cells_pass_kernel(CellCloud cc, Cam1 cam, int W, int H,
                                                          unsigned long long *keys, unsigned *zimg,
                                                          const unsigned short *__restrict__ hiz_g, int nbx, void *hdr_v,
                                                          int *pos0, int *pos1, StripInfo si, int sub_items,
-                                                         unsigned long long *stats, KeySlots ks)
+                                                         unsigned long long *stats, KeySlots ks, BinInfo bi)
 {
     __shared__ unsigned s_tag[LDS ? 4 * LDS_SLOTS : 1];
     __shared__ unsigned long long s_key[LDS ? 4 * LDS_SLOTS : 1];
     __shared__ int s_pos[LDS ? 4 * LDS_SLOTS : 1];
+    __shared__ unsigned s_wl[BIN ? 4 * 128 : 1];                     // per wave: 64 tiles + 64 counts / bases (emit_binned)
+    unsigned *wl_tile = s_wl + (BIN ? (threadIdx.x >> 6) * 128 : 0), *wl_cnt = wl_tile + (BIN ? 64 : 0);
     const SplatHeader *hdr = (const SplatHeader *)hdr_v;
     int *next = hdr->parity ? pos0 : pos1;
     const float *M = cam.m;
@@ -661,24 +817,47 @@ __global__ __launch_bounds__(256) void cells_pass_kernel(CellCloud cc, Cam1 cam,
     const int wave = __builtin_amdgcn_readfirstlane(wg_in_strip * (int)(blockDim.x >> 6) + (int)(threadIdx.x >> 6));
     const StripCounters *sc = strip_counters(hdr_v, s);
     const int xlo = 0, xhi = W;                                     // a chunk is processed whole by the strip that lists it
+    float4 q[4];
     if (!PASS_B) {
         const int rounds = 4 / sub_items;
         int n_items = 0;
         for (int b = 0; b < A_BANDS; ++b) n_items += sc->nA[b] * sub_items;
+        // Items are pipelined over three iterations of the walk: the list entry of item i+2 and the point records of item
+        // i+1 are in flight while item i is tested — a wave's item is otherwise a chain of four dependent memory round trips
+        // (entry, records, bounds, slot reservation) with nothing of its own to overlap them.
         int band = 0, band_first = 0, band_items = sc->nA[0] * sub_items;      // items [band_first, band_first + band_items)
-        for (int t = wave; t < n_items; t += n_waves) {
-            while (t >= band_first + band_items) {                               // t only grows: the cursor moves forward
+        auto entry_of = [&](int t, int &part) {                                  // t only grows: the cursor moves forward
+            while (t >= band_first + band_items) {
                 band_first += band_items;
                 ++band;
                 band_items = sc->nA[band] * sub_items;
             }
-            const int tl = t - band_first;
-            const int li = tl / sub_items, part = tl - li * sub_items;
-            const int entry = __builtin_amdgcn_readfirstlane(cc.list_a[((size_t)s * A_BANDS + band) * cc.nchunks + li]);
+            const int tl = t - band_first, li = tl / sub_items;
+            part = tl - li * sub_items;
+            return cc.list_a[((size_t)s * A_BANDS + band) * cc.nchunks + li];
+        };
+        int part0 = 0, part1 = 0, part2 = 0, e0 = 0, e1 = 0, e2 = 0;
+        if (wave < n_items) e0 = entry_of(wave, part0);
+        if (wave + n_waves < n_items) e1 = entry_of(wave + n_waves, part1);
+        if (wave < n_items) {
+            const int first0 = (__builtin_amdgcn_readfirstlane(e0) & 0x7fffffff) * CELL_CHUNK + part0 * rounds * 256;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) q[k] = cc.pts[first0 + lane + 64 * k];
+        }
+        for (int t = wave; t < n_items; t += n_waves) {
+            if (t + 2 * n_waves < n_items) e2 = entry_of(t + 2 * n_waves, part2);
+            const int entry = __builtin_amdgcn_readfirstlane(e0);
             const int chunk = entry & 0x7fffffff;
+            const int next_first = t + n_waves < n_items
+                                       ? (__builtin_amdgcn_readfirstlane(e1) & 0x7fffffff) * CELL_CHUNK + part1 * rounds * 256 : -1;
             ++n_run;
-            strip_points<STATS, ZL2, LDS>(cc, M, W, H, xlo, xhi, keys, zimg, next, chunk * CELL_CHUNK + part * rounds * 256, rounds,
-                                          lane, st_in, st_atomics, tag, hkey, hpos, ks, entry < 0);
+            strip_points<STATS, ZL2, LDS, BIN>(cc, M, W, H, xlo, xhi, keys, zimg, next, chunk * CELL_CHUNK + part0 * rounds * 256,
+                                               rounds, lane, st_in, st_atomics, tag, hkey, hpos, ks, entry < 0, bi, wl_tile, wl_cnt,
+                                               wave & (BIN_SUB - 1), q, next_first);
+            e0 = e1;
+            part0 = part1;
+            e1 = e2;
+            part1 = part2;
         }
     } else {
         const CellEntryB *list_b = cc.list_b + (size_t)s * cc.nchunks;
@@ -721,8 +900,11 @@ __global__ __launch_bounds__(256) void cells_pass_kernel(CellCloud cc, Cam1 cam,
                 const int chunk = entry & 0x7fffffff;
                 if (lane == 0) cc.sticky[chunk] = STICKY_FRAMES;
                 ++n_run;
-                strip_points<STATS, ZL2, LDS>(cc, M, W, H, xlo, xhi, keys, zimg, next, chunk * CELL_CHUNK, 4, lane, st_in, st_atomics,
-                                              tag, hkey, hpos, ks, entry < 0);
+#pragma unroll
+                for (int k = 0; k < 4; ++k) q[k] = cc.pts[chunk * CELL_CHUNK + lane + 64 * k];
+                strip_points<STATS, ZL2, LDS, BIN>(cc, M, W, H, xlo, xhi, keys, zimg, next, chunk * CELL_CHUNK, 4, lane, st_in,
+                                                   st_atomics, tag, hkey, hpos, ks, entry < 0, bi, wl_tile, wl_cnt, wave & (BIN_SUB - 1),
+                                                   q, -1);
             }
         }
     }
@@ -774,6 +956,73 @@ __global__ __launch_bounds__(256) void cells_hiz_kernel(const unsigned long long
             m = max(max(m, z.x), max(max(z.y, z.z), z.w));
         }
     hiz[b] = hiz_encode(m);
+}
+
+// Binned pass A (emit_binned): one workgroup per 32x32-pixel tile folds the tile's bin into its keys — LDS atomic min, then
+// plain coalesced stores — and does cells_hiz_kernel's work for the tile's 8x8 blocks on the way out (zimg := exact depths,
+// far bound per 4x4 block).  The tile's counter goes back to "empty" (minus one).
+__global__ __launch_bounds__(256) void cells_merge_hiz_kernel(unsigned long long *__restrict__ keys, unsigned *__restrict__ zimg,
+                                                              int W, int H, int nbx, unsigned short *__restrict__ hiz, BinInfo bi)
+{
+    __shared__ unsigned long long lk[BIN_TILE * BIN_TILE];
+    const int t = threadIdx.x, tile = blockIdx.x;
+    const int tx = tile % bi.tiles_x, ty = tile / bi.tiles_x;
+    const int r = t >> 3, c4 = (t & 7) * 4;                         // thread = 4 consecutive pixels of tile row r
+    const int y = ty * BIN_TILE + r, x = tx * BIN_TILE + c4;
+    const bool in = y < H && x < W;                                 // W % 16 == 0: the four columns exist together
+    const long long off = (long long)y * W + x;
+    ulonglong2 k01 = make_ulonglong2(EMPTY_KEY, EMPTY_KEY), k23 = k01;
+    if (in) {
+        k01 = *reinterpret_cast<const ulonglong2 *>(keys + off);
+        k23 = *reinterpret_cast<const ulonglong2 *>(keys + off + 2);
+    }
+    lk[r * BIN_TILE + c4] = k01.x;
+    lk[r * BIN_TILE + c4 + 1] = k01.y;
+    lk[r * BIN_TILE + c4 + 2] = k23.x;
+    lk[r * BIN_TILE + c4 + 3] = k23.y;
+    // 8 threads per sub-bin; the first four records of every thread are fetched before the tile is in LDS
+    const int sb = tile * BIN_SUB + (t >> 3);
+    unsigned n = bi.count[sb] + 1u;                                 // kept minus one
+    n = n < (unsigned)bi.cap ? n : (unsigned)bi.cap;
+    const uint4 *recs = bi.recs + (size_t)sb * bi.cap;
+    uint4 rec[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const unsigned i = (t & 7) + 8 * j;
+        rec[j] = recs[i < n ? i : 0];
+    }
+    __syncthreads();
+    for (unsigned i0 = t & 7; i0 < n; i0 += 32) {
+        uint4 nxt[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const unsigned i = i0 + 32 + 8 * j;
+            nxt[j] = recs[i < n ? i : 0];
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+            if (i0 + 8 * j < n) atomicMin(lk + rec[j].x, ((unsigned long long)rec[j].w << 32) | rec[j].z);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) rec[j] = nxt[j];
+    }
+    __syncthreads();
+    if ((t & 7) == 0) bi.count[sb] = 0xffffffffu;
+    uint4 z;
+    {
+        const unsigned long long a = lk[r * BIN_TILE + c4], b = lk[r * BIN_TILE + c4 + 1], c = lk[r * BIN_TILE + c4 + 2],
+                                 d = lk[r * BIN_TILE + c4 + 3];
+        if (in) {
+            *reinterpret_cast<ulonglong2 *>(keys + off) = make_ulonglong2(a, b);
+            *reinterpret_cast<ulonglong2 *>(keys + off + 2) = make_ulonglong2(c, d);
+        }
+        z = make_uint4((unsigned)(a >> 32), (unsigned)(b >> 32), (unsigned)(c >> 32), (unsigned)(d >> 32));   // EMPTY -> "none"
+    }
+    if (in) *reinterpret_cast<uint4 *>(zimg + off) = z;
+    // 4x4 block = this thread's 4 pixels in 4 consecutive rows: rows r, r^1, r^2, r^3 are lanes t, t^8, t^16, t^24
+    unsigned m = in ? max(max(z.x, z.y), max(z.z, z.w)) : 0u;       // rows below the image do not count
+    m = max(m, (unsigned)__shfl_xor((int)m, 8));
+    m = max(m, (unsigned)__shfl_xor((int)m, 16));
+    if ((r & 3) == 0 && in) hiz[((ty * BIN_TILE + r) >> 2) * nbx + ((tx * BIN_TILE + c4) >> 2)] = hiz_encode(m);
 }
 
 // ---- GL twin features: point sizes, "ps" splats, discard, clip-space perturbation ------------------------------------
@@ -995,6 +1244,8 @@ int g_splat_kslot = 0;          // key-image layout of the striped path: 0 linea
 int g_splat_lds = 1;            // 1: per-wave LDS hash table in front of the memory-side atomics (strip_points)
 int g_splat_wgs = 4;            // workgroups per CU of the striped passes: 0.0996 / 0.0936 / 0.0893 / 0.0927 / 0.0923 ms at 2 / 3 / 4 / 6 / 8
                                 // (fewer waves = more rounds per wave = finer front-to-back order over the depth bands)
+int g_splat_probe = 0;          // -DREAD_DEBUG_KNOBS builds only (BinInfo::probe)
+int g_splat_bins = 1;           // 1: pass A appends its candidates to per-tile bins, merged in LDS (emit_binned); 0: one memory-side atomic each
 int g_splat_strips = 1;         // column strips of the striped passes (1, 2, 4 or 8).  8 was best while a strip's list was walked in
                                // Morton order (pass A 61.5 / 75.5 / 70 us at 8 / 2 / 1: fewer atomics with exact bounds); with the
                                // depth bands ONE global list wins — global front-to-back order and perfect balance: bench
@@ -1009,6 +1260,9 @@ struct WsLayout {
     unsigned short *hiz;       // 16-bit far bounds (the region keeps its 4 bytes per block)
     int *prev[2];              // plain path: prev[0] = winners' ids; striped path: positions, double buffered
     unsigned *zimg;
+    unsigned *bin_count;       // striped path, binned pass A: per 32x32 tile, minus one
+    uint4 *bin_recs;           // tiles x bin_cap records
+    int bin_cap, bin_tiles_x, bin_tiles;
     size_t key_slots;
     int nbx, nby;
     size_t total;
@@ -1035,6 +1289,16 @@ WsLayout ws_layout(void *ws, int B, int W, int H)
     }
     L.zimg = (unsigned *)(p + off);
     off += ((size_t)W * H * sizeof(unsigned) + 255) / 256 * 256;
+    // bins of the striped path: BIN_SUB sub-bins per tile, <= 64 MiB of records, 32..256 per sub-bin (a full one falls back
+    // to the atomics)
+    L.bin_tiles_x = ceil_div(W, BIN_TILE);
+    L.bin_tiles = L.bin_tiles_x * ceil_div(H, BIN_TILE);
+    const size_t fit = ((size_t)64 << 20) / sizeof(uint4) / ((size_t)L.bin_tiles * BIN_SUB);
+    L.bin_cap = fit >= 256 ? 256 : (fit >= 32 ? (int)fit : 32);
+    L.bin_count = (unsigned *)(p + off);
+    off += ((size_t)L.bin_tiles * BIN_SUB * sizeof(unsigned) + 255) / 256 * 256;
+    L.bin_recs = (uint4 *)(p + off);
+    off += (size_t)L.bin_tiles * BIN_SUB * L.bin_cap * sizeof(uint4);
     L.total = off;
     return L;
 }
@@ -1167,20 +1431,40 @@ int cells_frame(const CellCloud &cc, const float *M_host, int W, int H, int leve
     while (ks.mask < (unsigned)(W * H)) ks.mask <<= 1;
     ks.mask -= 1;
     if (ks.mode == 2 && (size_t)ks.mask + 1 > ws.key_slots) ks.mode = 0;      // (a workspace of this size always has 8 W H slots)
-    auto pass_a = stats ? (g_splat_lds ? cells_pass_kernel<false, true, false, true> : cells_pass_kernel<false, true, false, false>)
-                  : g_splat_zl2 ? cells_pass_kernel<false, false, true, false>
-                  : g_splat_lds ? cells_pass_kernel<false, false, false, true> : cells_pass_kernel<false, false, false, false>;
-    auto pass_b = stats ? (g_splat_lds ? cells_pass_kernel<true, true, false, true> : cells_pass_kernel<true, true, false, false>)
-                  : g_splat_zl2 ? cells_pass_kernel<true, false, true, false>
-                  : g_splat_lds ? cells_pass_kernel<true, false, false, true> : cells_pass_kernel<true, false, false, false>;
+    // bins need the linear key layout and exact pixel rows from (pix + 0.5) / W in fp32
+    const bool bins = g_splat_bins && ks.mode == 0 && (long long)W * H <= (1ll << 20);
+    BinInfo bi;
+    memset(&bi, 0, sizeof(bi));
+    if (bins) {
+        bi.recs = ws.bin_recs;
+        bi.count = ws.bin_count;
+        bi.cap = ws.bin_cap;
+        bi.tiles_x = ws.bin_tiles_x;
+        bi.inv_w = 1.0f / (float)W;
+        bi.probe = g_splat_probe;
+    }
+    auto pass_a = bins ? (stats ? (g_splat_lds ? cells_pass_kernel<false, true, false, true, true> : cells_pass_kernel<false, true, false, false, true>)
+                          : g_splat_zl2 ? cells_pass_kernel<false, false, true, false, true>
+                          : g_splat_lds ? cells_pass_kernel<false, false, false, true, true> : cells_pass_kernel<false, false, false, false, true>)
+                  : stats ? (g_splat_lds ? cells_pass_kernel<false, true, false, true, false> : cells_pass_kernel<false, true, false, false, false>)
+                  : g_splat_zl2 ? cells_pass_kernel<false, false, true, false, false>
+                  : g_splat_lds ? cells_pass_kernel<false, false, false, true, false> : cells_pass_kernel<false, false, false, false, false>;
+    auto pass_b = stats ? (g_splat_lds ? cells_pass_kernel<true, true, false, true, false> : cells_pass_kernel<true, true, false, false, false>)
+                  : g_splat_zl2 ? cells_pass_kernel<true, false, true, false, false>
+                  : g_splat_lds ? cells_pass_kernel<true, false, false, true, false> : cells_pass_kernel<true, false, false, false, false>;
     hipLaunchKernelGGL(pass_a, dim3(grid), dim3(256), 0, stream, cc, cam, W, H, ws.keys, ws.zimg,
-                       (const unsigned short *)ws.hiz, ws.nbx, ws.hdr, ws.prev[0], ws.prev[1], si, items, stats, ks);
+                       (const unsigned short *)ws.hiz, ws.nbx, ws.hdr, ws.prev[0], ws.prev[1], si, items, stats, ks, bi);
     READ_CHECK_LAUNCH();
-    hipLaunchKernelGGL(cells_hiz_kernel, dim3(ceil_div(ws.nbx * ws.nby, 256)), dim3(256), 0, stream,
-                       (const unsigned long long *)ws.keys, ws.zimg, W, H, ws.nbx, ws.nby, ws.hiz, ks);
+    if (bins)
+        hipLaunchKernelGGL(cells_merge_hiz_kernel, dim3((unsigned)ws.bin_tiles), dim3(256), 0, stream, ws.keys, ws.zimg, W, H,
+                           ws.nbx, ws.hiz, bi);
+    else
+        hipLaunchKernelGGL(cells_hiz_kernel, dim3(ceil_div(ws.nbx * ws.nby, 256)), dim3(256), 0, stream,
+                           (const unsigned long long *)ws.keys, ws.zimg, W, H, ws.nbx, ws.nby, ws.hiz, ks);
     READ_CHECK_LAUNCH();
+    bi.recs = nullptr;
     hipLaunchKernelGGL(pass_b, dim3(grid), dim3(256), 0, stream, cc, cam, W, H, ws.keys, ws.zimg,
-                       (const unsigned short *)ws.hiz, ws.nbx, ws.hdr, ws.prev[0], ws.prev[1], si, items, stats, ks);
+                       (const unsigned short *)ws.hiz, ws.nbx, ws.hdr, ws.prev[0], ws.prev[1], si, items, stats, ks, bi);
     READ_CHECK_LAUNCH();
     return resolve_launch(ws.keys, 1, 0, W, H, levels, idx_levels, depth_levels, 0, ws, 2, stream, ks);
 }
@@ -1209,6 +1493,8 @@ void splat_set_cells_sub(int v) { g_splat_cells_sub = v < 0 ? 0 : v; }
 void splat_set_items(int v) { g_splat_items = v >= 4 ? 4 : (v >= 2 ? 2 : 1); }
 void splat_set_zl2(int v) { g_splat_zl2 = v != 0; }
 void splat_set_lds(int v) { g_splat_lds = v != 0; }
+void splat_set_bins(int v) { g_splat_bins = v != 0; }
+void splat_set_probe(int v) { g_splat_probe = v; }
 void splat_set_kslot(int v) { g_splat_kslot = v < 0 ? 0 : (v > 2 ? 2 : v); }
 void splat_set_wgs(int v) { g_splat_wgs = v < 1 ? 1 : (v > 16 ? 16 : v); }
 void splat_set_strips(int v) { g_splat_strips = v >= 8 ? 8 : (v >= 4 ? 4 : (v >= 2 ? 2 : 1)); }
@@ -1226,6 +1512,7 @@ int splat_get(const char *key, int *value)
     else if (!strcmp(key, "splat_wgs")) *value = g_splat_wgs;
     else if (!strcmp(key, "splat_zl2")) *value = g_splat_zl2;
     else if (!strcmp(key, "splat_lds")) *value = g_splat_lds;
+    else if (!strcmp(key, "splat_bins")) *value = g_splat_bins;
     else if (!strcmp(key, "splat_kslot")) *value = g_splat_kslot;
     else return 0;
     return 1;

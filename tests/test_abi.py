@@ -45,9 +45,12 @@ def test_layer_table_matches_independent_spec():
 def test_bad_arguments_fail_loudly():
     L = _lib.lib()
     # header + one key image + hi-z bounds + two seed images + the depth-bound image of the striped path
+    # + the bins of its pass A (38 x 11 tiles of 32x32 pixels x 32 sub-bins: a counter and 256 records of 16 bytes each)
     px = 1216 * 352
-    assert L.read_splat_workspace_bytes(1, 1216, 352) == 4096 + 8 * px * 8 + 304 * 88 * 4 + 3 * px * 4
-    assert L.read_splat_workspace_bytes(9, 1216, 352) == 4096 + 8 * px * 8 + 304 * 88 * 4 + 3 * px * 4
+    bins = 38 * 11 * 32
+    want = 4096 + 8 * px * 8 + 304 * 88 * 4 + 3 * px * 4 + (bins * 4 + 255) // 256 * 256 + bins * 256 * 16
+    assert L.read_splat_workspace_bytes(1, 1216, 352) == want
+    assert L.read_splat_workspace_bytes(9, 1216, 352) == want
     assert L.read_splat_workspace_bytes(0, 10, 10) == 0
     rc = L.read_splat_forward(None, 10, None, 1, 64, 64, 5, None, None, None, 0, None)
     assert rc == -22 and b"xyz" in L.read_last_error()

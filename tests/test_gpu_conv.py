@@ -153,33 +153,70 @@ def test_concat_and_nearest_resample_sources(hip):
 def test_coarse_sources_as_pre_activation_addends(hip):
     """The AFF plan of read_unet: a 1x1 conv commutes with nearest up-sampling, so the inputs that live at coarser levels
     are multiplied at their own level by `linear` launches and enter the layer as a pre-activation addend
-    (read_conv_desc.pre); same reference as the single 480-channel launch (unet.py:239-254)."""
+    (read_conv_desc.pre); same reference as the single 480-channel launch (unet.py:239-254).  Through the pixel-lane
+    kernel (default) and through the LDS-tiled kernels (conv_px = 0)."""
+    from read_amd import _lib
     torch.manual_seed(21)
     H, W = 24, 64
     chans = [32, 64, 128]
     xs = [torch.randn(c, H >> i, W >> i) for i, c in enumerate(chans)]            # fine, 1/2, 1/4
     cat = torch.cat([F.interpolate(x[None], size=(H, W), mode="nearest") for x in xs], 1)
-    for cout in (32, 64, 128):                                                      # wave kernel (1, 2 groups), workgroup kernel (4)
-        st = _state(sum(chans), cout, 1, seed=30 + cout)
-        ref = unet_torch.basic_conv(st, "L", cat, 1, elu=True)[0]
-        b = "L.block."
+    try:
+        for px in (1, 0):
+            _lib.check(_lib.lib().read_tuning_set(b"conv_px", px))
+            for cout in (32, 64, 128):                                              # one, two, four channel groups
+                st = _state(sum(chans), cout, 1, seed=30 + cout)
+                ref = unet_torch.basic_conv(st, "L", cat, 1, elu=True)[0]
+                b = "L.block."
 
-        def part(c0, c1, own):
-            sub = dict(st)
-            for br in ("conv_f", "conv_m"):
-                sub[b + br + ".weight"] = np.ascontiguousarray(st[b + br + ".weight"][:, c0:c1])
-                if not own:
-                    sub[b + br + ".bias"] = np.zeros(cout, np.float32)
-            return _pack(sub, [c1 - c0])
+                def part(c0, c1, own):
+                    sub = dict(st)
+                    for br in ("conv_f", "conv_m"):
+                        sub[b + br + ".weight"] = np.ascontiguousarray(st[b + br + ".weight"][:, c0:c1])
+                        if not own:
+                            sub[b + br + ".bias"] = np.zeros(cout, np.float32)
+                    return _pack(sub, [c1 - c0])
 
-        q2 = gated_conv(part(96, 224, False), [(_nhwc(xs[2]), 0)], linear=True)                         # 1/4: [f | m]
-        q1 = gated_conv(part(32, 96, False), [(_nhwc(xs[1]), 0)], linear=True, pre=(q2, 0, cout, 1))    # 1/2, + up(q2)
-        assert q1.shape == (H // 2, W // 2, 2 * cout)
-        got = gated_conv(part(0, 32, True), [(_nhwc(xs[0]), 0)], elu=True, pre=(q1, 0, cout, 1))
-        _close(got, ref, f"AFF split over three levels, Cout={cout}")
-        # the linear partial sums themselves
-        lin = F.conv2d(xs[2][None], torch.as_tensor(np.ascontiguousarray(st[b + "conv_f.weight"][:, 96:224])))[0]
-        _close(q2[:, :, :cout].contiguous(), lin, "linear 1x1 partial sum")
+                q2 = gated_conv(part(96, 224, False), [(_nhwc(xs[2]), 0)], linear=True)                       # 1/4: [f | m]
+                q1 = gated_conv(part(32, 96, False), [(_nhwc(xs[1]), 0)], linear=True, pre=(q2, 0, cout, 1))  # 1/2, + up(q2)
+                assert q1.shape == (H // 2, W // 2, 2 * cout)
+                got = gated_conv(part(0, 32, True), [(_nhwc(xs[0]), 0)], elu=True, pre=(q1, 0, cout, 1))
+                _close(got, ref, f"AFF split over three levels, Cout={cout}, conv_px={px}")
+                lin = F.conv2d(xs[2][None], torch.as_tensor(np.ascontiguousarray(st[b + "conv_f.weight"][:, 96:224])))[0]
+                _close(q2[:, :, :cout].contiguous(), lin, "linear 1x1 partial sum")
+    finally:
+        _lib.check(_lib.lib().read_tuning_set(b"conv_px", 1))
+
+
+def test_pixel_lane_kernel_for_1x1_layers(hip):
+    """config=-2 forces the pixel-lane 1x1 kernel (weights as the MFMA A operand, LDS-resident; activations straight
+    from NHWC memory): the 1x1 shapes of the network, ragged pixel counts, resampled / concatenated sources, residual,
+    padded channel groups (Cout = 56) and both accumulator widths."""
+    from read_amd import _lib
+    torch.manual_seed(31)
+    cases = [  # (source channels, shifts, Cout, elu, residual)
+        ([16], [0], 32, True, False), ([32], [0], 56, True, False), ([8, 56], [0, 0], 64, False, False),
+        ([128], [0], 248, True, False), ([8, 248], [0, 0], 256, False, True), ([128, 128], [0, 0], 128, True, True),
+        ([32, 64, 128], [2, 1, 0], 128, True, False), ([32, 64], [1, 0], 64, True, False), ([64, 64], [0, 0], 32, True, False),
+    ]
+    try:
+        for width in (1, 2):
+            _lib.check(_lib.lib().read_tuning_set(b"conv_px", width))
+            for chans, shifts, cout, elu, with_res in cases:
+                H, W = 12, 44                                           # 528 pixels: ragged last tile, rows not a multiple of 32
+                xs = [torch.randn(c, H << sh, W << sh) for c, sh in zip(chans, shifts)]
+                cat = torch.cat([F.interpolate(x[None], size=(H, W), mode="nearest") for x in xs], 1)
+                st = _state(sum(chans), cout, 1, seed=sum(chans) + cout)
+                ref = unet_torch.basic_conv(st, "L", cat, 1, elu=elu)[0]
+                res = torch.randn(cout, H, W) if with_res else None
+                got = gated_conv(_pack(st, chans), [(_nhwc(x), sh) for x, sh in zip(xs, shifts)], elu=elu, config=-2,
+                                 residual=_nhwc(res) if with_res else None)
+                _close(got, ref + (res if with_res else 0), f"px width {width}: {chans} -> {cout}")
+    finally:
+        _lib.check(_lib.lib().read_tuning_set(b"conv_px", 1))
+    with pytest.raises(_lib.ReadHipError):                               # 3x3 layers do not qualify
+        st = _state(32, 32, 3, seed=1)
+        gated_conv(_pack(st, [32]), [(_nhwc(torch.randn(32, 8, 32)), 0)], config=-2)
 
 
 def test_fam_multiply_and_residual(hip):
