@@ -1288,7 +1288,8 @@ int find_config(int ks, int s, int kc, int P, int QG, int WM, int WN, int PF, in
 }
 
 int g_prefer_wave = 1;   // read_tuning_set("conv_wave", 0): workgroup-tiled kernels only
-int g_conv_px = 1;         // read_tuning_set("conv_px", v): pixel-lane kernel for 1x1 layers (0 off, 1: 64 accumulator registers, 2: 128)
+int g_conv_px = 1;         // read_tuning_set("conv_px", v): pixel-lane kernel for 1x1 layers — 0 off; 1 / 2 where it measured faster
+                           // (64 / 128 accumulator registers per wave); 3 / 4 every layer it fits
 int g_kc32 = 1;            // 32-channel chunks for 1x1 layers whose sources are all multiples of 32 (read_tuning_set("conv_kc32", 0): 16)
 int g_use_wino = 1 << 30;  // read_tuning_set("conv_wino", max Cin): Winograd kernel for eligible 3x3 layers (0 = off)
 int g_stagger_ticks = 0;   // read_tuning_set("conv_stagger", ticks of 10 ns)
@@ -1483,7 +1484,7 @@ void conv_set_stagger(int ticks) { g_stagger_ticks = ticks < 0 ? 0 : ticks; }
 void conv_set_ablate(int bits) { g_ablate = bits; }
 void conv_set_wino(int max_cin) { g_use_wino = max_cin; }
 void conv_set_kc32(int v) { g_kc32 = v; }
-void conv_set_px(int v) { g_conv_px = v < 0 ? 0 : v > 2 ? 2 : v; }
+void conv_set_px(int v) { g_conv_px = v < 0 ? 0 : v > 4 ? 4 : v; }
 int conv_get(const char *key, int *value)
 {
     if (!strcmp(key, "conv_wave")) *value = g_prefer_wave;
@@ -1606,7 +1607,14 @@ int launch_gated_conv(const read_conv_desc *d, hipStream_t stream)
                           (!d->pre || ((uintptr_t)d->pre % 16 == 0 && d->pre_cstride % 4 == 0 && d->pre_f_off % 4 == 0 && d->pre_m_off % 4 == 0));
         READ_CHECK_ARG(d->config != -2 || fits, "read_gated_conv_forward: the pixel-lane kernel takes 1x1/s1 layers with Cin <= 256, "
                        "Cout %% 4 == 0 and 16-byte aligned tensors");
-        if (d->config == -2 || (d->config == -1 && g_conv_px && fits)) {
+        // Measured per layer at 1216x352 (profiles/README.md): the pixel-lane kernel wins where the LDS-tiled kernels fall to
+        // 8-channel chunks (SCM tails, cat[x(8), main]) or pad the last channel group (Cout = 56 / 120 / 248), 3-7 us per
+        // layer; on the other 1x1 layers it is level or up to 10 us slower (its four 32-byte segments per pixel line
+        // arrive as separate instructions) — conv_px = 1 takes it only for the former, 3 / 4 for every layer it fits.
+        bool px_pick = false;
+        for (int i = 0; i < d->n_src; ++i) px_pick = px_pick || d->src[i].C % 16 != 0;
+        px_pick = px_pick || d->Cout % 32 != 0 || g_conv_px >= 3;
+        if (d->config == -2 || (d->config == -1 && g_conv_px && fits && px_pick)) {
             static int n_cu_p = 0;
             if (!n_cu_p) {
                 int dev = 0;
@@ -1614,7 +1622,7 @@ int launch_gated_conv(const read_conv_desc *d, hipStream_t stream)
                 n_cu_p = (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess &&
                           prop.multiProcessorCount > 0) ? prop.multiProcessorCount : 256;
             }
-            const bool wide = g_conv_px >= 2;                       // 128 accumulator registers per wave instead of 64
+            const bool wide = g_conv_px == 2 || g_conv_px == 4;     // 128 accumulator registers per wave instead of 64
             const int pt = (gw == 2 ? 1 : 2) * (wide ? 2 : 1);
             const size_t lds = (size_t)nsteps * 2 * gw * 1024;
             int per_cu = (int)((160 * 1024) / (lds + 256));

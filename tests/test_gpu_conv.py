@@ -162,7 +162,7 @@ def test_coarse_sources_as_pre_activation_addends(hip):
     xs = [torch.randn(c, H >> i, W >> i) for i, c in enumerate(chans)]            # fine, 1/2, 1/4
     cat = torch.cat([F.interpolate(x[None], size=(H, W), mode="nearest") for x in xs], 1)
     try:
-        for px in (1, 0):
+        for px in (3, 0):
             _lib.check(_lib.lib().read_tuning_set(b"conv_px", px))
             for cout in (32, 64, 128):                                              # one, two, four channel groups
                 st = _state(sum(chans), cout, 1, seed=30 + cout)
@@ -200,7 +200,7 @@ def test_pixel_lane_kernel_for_1x1_layers(hip):
         ([32, 64, 128], [2, 1, 0], 128, True, False), ([32, 64], [1, 0], 64, True, False), ([64, 64], [0, 0], 32, True, False),
     ]
     try:
-        for width in (1, 2):
+        for width in (3, 4):
             _lib.check(_lib.lib().read_tuning_set(b"conv_px", width))
             for chans, shifts, cout, elu, with_res in cases:
                 H, W = 12, 44                                           # 528 pixels: ragged last tile, rows not a multiple of 32
