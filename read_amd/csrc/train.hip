@@ -303,44 +303,77 @@ __global__ __launch_bounds__(64) void wgrad_mfma_kernel(const float *__restrict_
     const int y_begin = (int)blockIdx.z * rows_per_split;
     const int y_end = min(outH, y_begin + rows_per_split);
     const int taps = ksize * ksize;
-    // One k-step = two output pixels (px = ox + kk).  The operands of step s+1 are fetched before the MFMAs of step s issue
-    // (an in-order wave would otherwise sit out the full load latency in front of every group of NT MFMAs), and the
-    // per-row part of every tap's address is hoisted out of the pixel loop.
+    // One k-step = two output pixels (px = 2 p + kk) of one row.  Operands run two steps ahead of the MFMAs (a ring of three
+    // register sets: one step of NT MFMAs, ~0.25 us, does not cover an L2 round trip).  The fetch cursor (row, pixel pair) is
+    // wave-uniform and advanced with scalar arithmetic; for a pair whose taps all fall inside the image — all but the first
+    // and last pair of a row and the first / last rows — a lane's NT loads share ONE 32-bit offset on NT scalar bases
+    // (tensor + tap offset), i.e. one VALU add per step instead of a bounds test and an address per tap.  (The first version
+    // derived (row, pair) from a 64-bit step index by division and tested every tap: the wave spent more issue slots on
+    // addresses than on MFMAs, 18 TF.)
     const int n_pairs = (outW + 1) >> 1;
-    const long long total_steps = (long long)(y_end - y_begin) * n_pairs;
-    auto fetch = [&](long long step, float (&a)[NT], float &b) {
-        const int oy = y_begin + (int)(step / n_pairs), px = 2 * (int)(step % n_pairs) + kk;
-        const bool p_ok = step < total_steps && px < outW;
-        b = (p_ok && co_ok) ? dfm[((long long)oy * outW + px) * C2 + co0 + i] : 0.0f;
+    const int cil = ci_ok ? ci0 + i : Cin - 1, col = co_ok ? co0 + i : C2 - 1;      // padded rows / columns are never stored
+    const char *xb[NT];
+    int tky[NT], tkx[NT];
 #pragma unroll
-        for (int t = 0; t < NT; ++t) {
-            const int tap = (int)blockIdx.y * NT + t, ky = tap / ksize, kx = tap - ky * ksize;
-            const int iy = oy * stride + ky - pad, ix = px * stride + kx - pad;
-            const bool ok = p_ok && ci_ok && tap < taps && iy >= 0 && iy < inH && ix >= 0 && ix < inW;
-            a[t] = ok ? x[((long long)iy * inW + ix) * Cin + ci0 + i] : 0.0f;
+    for (int t = 0; t < NT; ++t) {
+        const int tap = (int)blockIdx.y * NT + t;
+        tky[t] = tap / ksize;
+        tkx[t] = tap - tky[t] * ksize;
+        xb[t] = reinterpret_cast<const char *>(x) + ((long long)tky[t] * inW + tkx[t]) * Cin * 4;
+    }
+    const unsigned lane_x = (unsigned)(kk * stride * Cin + cil), lane_d = (unsigned)(kk * C2 + col);
+    int f_oy = y_begin, f_p = 0;
+    auto ld = [](const char *sbase, unsigned voff) {     // (scalar base) + (32-bit lane byte offset): global_load_dword v, voff, s[base]
+        asm volatile("" : "+v"(voff));
+        return *reinterpret_cast<const float *>(sbase + voff);
+    };
+    const char *const xc = reinterpret_cast<const char *>(x), *const dc = reinterpret_cast<const char *>(dfm);
+    auto fetch = [&](float (&a)[NT], float &b) {
+        const bool live = f_oy < y_end;
+        const int oy = live ? f_oy : y_begin, p = live ? f_p : 0;
+        const int iy0 = oy * stride - pad, ix0 = 2 * p * stride - pad;             // tap (0,0) of the pair's first pixel
+        const bool inside = live && iy0 >= 0 && iy0 + ksize - 1 < inH && ix0 >= 0 && ix0 + stride + ksize - 1 < inW &&
+                            2 * p + 1 < outW && taps == NT * (int)gridDim.y;
+        if (inside) {                                                            // wave-uniform
+            const unsigned off = ((unsigned)((iy0 * inW + ix0) * Cin) + lane_x) * 4u;
+#pragma unroll
+            for (int t = 0; t < NT; ++t) a[t] = ld(xb[t], off);
+            b = ld(dc, ((unsigned)((oy * outW + 2 * p) * C2) + lane_d) * 4u);
+        } else {
+            const int px = 2 * p + kk;
+            const bool p_ok = live && px < outW;
+            const float bv = ld(dc, p_ok ? (unsigned)((oy * outW + px) * C2 + col) * 4u : 0u);
+            b = (p_ok && co_ok) ? bv : 0.0f;
+#pragma unroll
+            for (int t = 0; t < NT; ++t) {
+                const int iy = iy0 + tky[t], ix = px * stride - pad + tkx[t];
+                const bool ok = p_ok && ci_ok && (int)blockIdx.y * NT + t < taps && iy >= 0 && iy < inH && ix >= 0 && ix < inW;
+                const float v = ld(xc, ok ? (unsigned)((iy * inW + ix) * Cin + cil) * 4u : 0u);
+                a[t] = ok ? v : 0.0f;
+            }
+        }
+        if (++f_p == n_pairs) {
+            f_p = 0;
+            ++f_oy;
         }
     };
-    // operands two steps ahead (a ring of three register sets): one step of NT MFMAs (~0.25 us) does not cover an L2 round trip
+    // one fetch site, operands two steps ahead: the ring rotates through register moves (2 NT + 2 per step, against NT MFMAs)
+    const long long total_steps = (long long)(y_end - y_begin) * n_pairs;
     float a0[NT], a1[NT], a2[NT], b0, b1, b2;
-    fetch(0, a0, b0);
-    fetch(1, a1, b1);
-    long long step = 0;
-    for (; step + 3 <= total_steps; step += 3) {
-        fetch(step + 2, a2, b2);
+    fetch(a0, b0);
+    fetch(a1, b1);
+    for (long long step = 0; step < total_steps; ++step) {
+        fetch(a2, b2);
 #pragma unroll
         for (int t = 0; t < NT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[t], b0, acc[t], 0, 0, 0);
-        fetch(step + 3, a0, b0);
 #pragma unroll
-        for (int t = 0; t < NT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[t], b1, acc[t], 0, 0, 0);
-        fetch(step + 4, a1, b1);
-#pragma unroll
-        for (int t = 0; t < NT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a2[t], b2, acc[t], 0, 0, 0);
+        for (int t = 0; t < NT; ++t) {
+            a0[t] = a1[t];
+            a1[t] = a2[t];
+        }
+        b0 = b1;
+        b1 = b2;
     }
-    // tail: at most two steps left, already in (a0, b0), (a1, b1); fetch() returns zeros past the end
-#pragma unroll
-    for (int t = 0; t < NT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[t], b0, acc[t], 0, 0, 0);
-#pragma unroll
-    for (int t = 0; t < NT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[t], b1, acc[t], 0, 0, 0);
     // D[i][j] sits in lane (j + 32 * ((i >> 2) & 1)), register (i & 3) + 4 * (i >> 3): row i = ci, column j = co'
     float *dst = partial + (((long long)blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x) * (NT * 1024);
 #pragma unroll
@@ -714,6 +747,9 @@ extern "C" int read_conv_wgrad(const float *x, int inH, int inW, int Cin, const 
     const int pad = (ksize - 1) / 2, Cp = (Cout + 7) / 8 * 8;
     const int outH = (inH + 2 * pad - ksize) / stride + 1, outW = (inW + 2 * pad - ksize) / stride + 1;
     READ_CHECK_ARG(outH >= 1 && outW >= 1, "read_conv_wgrad: empty output");
+    // the kernel addresses both tensors with 32-bit byte offsets (plus the largest tap offset)
+    READ_CHECK_ARG(((long long)inH + ksize) * inW * Cin * 4 < (1ll << 32) && (long long)outH * outW * 2 * Cp * 4 < (1ll << 32),
+                   "read_conv_wgrad: tensors of 4 GiB and more are not supported");
     const WgradPlan p = wgrad_plan(Cin, Cout, ksize, outH);
     READ_CHECK_ARG(scratch_floats >= p.partial_floats, "read_conv_wgrad: scratch %zu < %zu floats", scratch_floats, p.partial_floats);
     const dim3 grid((unsigned)(p.tiles_ci * p.tiles_co), (unsigned)p.tap_groups, (unsigned)p.splits);
