@@ -293,6 +293,13 @@ int read_huber_loss(const float *out, const float *target, int64_t n, float grad
  * (int32 per row, zero-initialised; step counts from 1).  rows / sq / grad are N x C. */
 int read_rmsprop_sparse(float *rows, float *sq, float *grad, int32_t *stamp, int C, int64_t n_rows, const int32_t *ids,
                         int64_t n_ids, int step, float lr, float alpha, float eps, void *stream);
+/* The same update without the N x C gradient table: the step's (id, gradient row) pairs sorted by id (sorted_ids ascending,
+ * perm[i] = row of g that sorted_ids[i] came from, e.g. torch.sort); runs of equal ids are summed in sorted order
+ * (deterministic) and applied once.  scratch: read_rmsprop_sorted_scratch_ints() int32 of device memory. */
+size_t read_rmsprop_sorted_scratch_ints(void);
+int read_rmsprop_sorted(float *rows, float *sq, int32_t *stamp, int C, int64_t n_rows, const int32_t *sorted_ids,
+                        const int64_t *perm, const float *g, int64_t n, int step, float lr, float alpha, float eps,
+                        int32_t *scratch, void *stream);
 
 /* ---------------------------------------------------------------- UNet */
 

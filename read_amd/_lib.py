@@ -94,6 +94,8 @@ SIGNATURES = {
     "read_bilinear_up4_backward": (_i, [_vp, _i, _i, _i, _vp, _i, _i, _vp]),
     "read_huber_loss": (_i, [_vp, _vp, _i64, _f, _vp, _vp, _vp]),
     "read_rmsprop_sparse": (_i, [_vp, _vp, _vp, _vp, _i, _i64, _vp, _i64, _i, _f, _f, _f, _vp]),
+    "read_rmsprop_sorted_scratch_ints": (_sz, []),
+    "read_rmsprop_sorted": (_i, [_vp, _vp, _vp, _i, _i64, _vp, _vp, _vp, _i64, _i, _f, _f, _f, _vp, _vp]),
     "read_unet_layer_count": (_i, []),
     "read_unet_layer_info": (_i, [_i, C.POINTER(C.c_char_p), C.POINTER(_i), C.POINTER(_i), C.POINTER(_i),
                                   C.POINTER(_i), C.POINTER(_i)]),

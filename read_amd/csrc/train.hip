@@ -799,6 +799,107 @@ extern "C" int read_huber_loss(const float *out, const float *target, int64_t n,
     return READ_OK;
 }
 
+// The same update from the step's (pixel id, gradient row) pairs SORTED by id (torch.sort): the head of every run of equal ids
+// sums the run's rows in sorted order — deterministic, no atomics, no N x C gradient table — and applies the update.  The run
+// length comes from a binary search; runs above LONG_RUN pairs (the background id 0 collects every empty pixel) are queued
+// for rmsprop_long_kernel, one workgroup each.  (Scatter-adding into the dense table first cost 10.5 ms per iteration:
+// 5.6 M random fp32 atomics into 320 MB.)
+constexpr int LONG_RUN = 512, MAX_LONG = 64;
+
+__device__ __forceinline__ void rmsprop_row(float *rows, float *sq, int *stamp, int C, long long id, const float *g, int step,
+                                            float lr, float alpha, float eps)
+{
+    const int last = stamp[id];
+    stamp[id] = step;
+    const float decay = powf(alpha, (float)(step - 1 - last));      // steps in which the dense optimizer saw g = 0
+    for (int c = 0; c < C; ++c) {
+        const float v = alpha * (sq[id * C + c] * decay) + (1.0f - alpha) * g[c] * g[c];
+        sq[id * C + c] = v;
+        rows[id * C + c] -= lr * g[c] / (sqrtf(v) + eps);
+    }
+}
+
+constexpr int RMS_MAX_C = 16;
+
+__global__ __launch_bounds__(256) void rmsprop_sorted_kernel(float *__restrict__ rows, float *__restrict__ sq, int *__restrict__ stamp,
+                                                             int C, long long n_rows, const int32_t *__restrict__ sorted_ids,
+                                                             const long long *__restrict__ perm, const float *__restrict__ g,
+                                                             long long n, int step, float lr, float alpha, float eps,
+                                                             int *__restrict__ long_list)
+{
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const long long id = sorted_ids[i];
+    if (i > 0 && sorted_ids[i - 1] == id) return;                   // not the head of its run
+    if (id < 0 || id >= n_rows) return;
+    long long lo = i + 1, hi = n;                                   // first index past the run
+    while (lo < hi) {
+        const long long mid = (lo + hi) >> 1;
+        if (sorted_ids[mid] == id) lo = mid + 1;
+        else hi = mid;
+    }
+    const long long len = lo - i;
+    if (len > LONG_RUN) {
+        const int slot = atomicAdd(long_list, 1);
+        if (slot < MAX_LONG) {
+            long_list[1 + 3 * slot] = (int)id;
+            long_list[2 + 3 * slot] = (int)i;
+            long_list[3 + 3 * slot] = (int)len;
+            return;
+        }
+    }
+    float acc[RMS_MAX_C];
+    for (int c = 0; c < C; ++c) acc[c] = 0.0f;
+    for (long long j = i; j < lo; ++j) {
+        const float *row = g + perm[j] * C;
+        for (int c = 0; c < C; ++c) acc[c] += row[c];
+    }
+    rmsprop_row(rows, sq, stamp, C, id, acc, step, lr, alpha, eps);
+}
+
+__global__ __launch_bounds__(256) void rmsprop_long_kernel(float *__restrict__ rows, float *__restrict__ sq, int *__restrict__ stamp,
+                                                           int C, const long long *__restrict__ perm, const float *__restrict__ g,
+                                                           int step, float lr, float alpha, float eps, const int *__restrict__ long_list)
+{
+    __shared__ float red[256];
+    __shared__ float total[RMS_MAX_C];
+    const int count = long_list[0] < MAX_LONG ? long_list[0] : MAX_LONG;
+    if ((int)blockIdx.x >= count) return;
+    const long long id = long_list[1 + 3 * blockIdx.x], start = long_list[2 + 3 * blockIdx.x], len = long_list[3 + 3 * blockIdx.x];
+    for (int c = 0; c < C; ++c) {
+        float s = 0.0f;
+        for (long long j = threadIdx.x; j < len; j += 256) s += g[perm[start + j] * C + c];
+        red[threadIdx.x] = s;
+        __syncthreads();
+        for (int o = 128; o > 0; o >>= 1) {
+            if ((int)threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o];
+            __syncthreads();
+        }
+        if (threadIdx.x == 0) total[c] = red[0];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) rmsprop_row(rows, sq, stamp, C, id, total, step, lr, alpha, eps);
+}
+
+extern "C" size_t read_rmsprop_sorted_scratch_ints(void) { return 1 + 3 * MAX_LONG; }
+
+extern "C" int read_rmsprop_sorted(float *rows, float *sq, int32_t *stamp, int C, int64_t n_rows, const int32_t *sorted_ids,
+                                   const int64_t *perm, const float *g, int64_t n, int step, float lr, float alpha, float eps,
+                                   int32_t *scratch, void *stream)
+{
+    READ_CHECK_ARG(rows && sq && stamp && sorted_ids && perm && g && scratch, "read_rmsprop_sorted: null pointer");
+    READ_CHECK_ARG(C >= 1 && C <= RMS_MAX_C && n_rows >= 1 && n >= 0 && step >= 1, "read_rmsprop_sorted: bad sizes / step");
+    if (n == 0) return READ_OK;
+    READ_CHECK_HIP(hipMemsetAsync(scratch, 0, sizeof(int), as_stream(stream)));
+    hipLaunchKernelGGL(rmsprop_sorted_kernel, dim3((unsigned)ceil_div64(n, 256)), dim3(256), 0, as_stream(stream), rows, sq, stamp, C,
+                       (long long)n_rows, sorted_ids, (const long long *)perm, g, (long long)n, step, lr, alpha, eps, scratch);
+    READ_CHECK_LAUNCH();
+    hipLaunchKernelGGL(rmsprop_long_kernel, dim3(MAX_LONG), dim3(256), 0, as_stream(stream), rows, sq, stamp, C,
+                       (const long long *)perm, g, step, lr, alpha, eps, (const int *)scratch);
+    READ_CHECK_LAUNCH();
+    return READ_OK;
+}
+
 extern "C" int read_rmsprop_sparse(float *rows, float *sq, float *grad, int32_t *stamp, int C, int64_t n_rows,
                                    const int32_t *ids, int64_t n_ids, int step, float lr, float alpha, float eps, void *stream)
 {

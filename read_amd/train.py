@@ -342,17 +342,33 @@ class SparseDescriptorRMSprop:
 
     def step(self, closure=None):
         g = self.param_groups[0]
+        L = _lib.lib()
         for tex in self.textures:
+            if tex._touched:                      # someone asked for the dense gradient rows: everything goes through them
+                tex.grad_rows()
+            pend = tex.take_pending()
             ids = tex.take_touched()
-            if ids is None:
+            if pend is None and ids is None:
                 continue
             s = self._state(tex)
             s['step'] += 1
-            rows, grad = tex.training_rows(), tex.grad_rows()
-            _lib.check(_lib.lib().read_rmsprop_sparse(rows.data_ptr(), s['sq'].data_ptr(), grad.data_ptr(), s['stamp'].data_ptr(),
-                                                      int(rows.shape[1]), int(rows.shape[0]), ids.data_ptr(), ids.numel(),
-                                                      s['step'], float(g['lr']), float(g['alpha']), float(g['eps']),
-                                                      _lib.stream_ptr()), "read_rmsprop_sparse")
+            rows = tex.training_rows()
+            if pend is not None:
+                # pairs sorted by id, runs summed in order, each row updated once (no gradient table, deterministic)
+                pids, pg = pend
+                sorted_ids, perm = torch.sort(pids, stable=True)
+                if 'scratch' not in s:
+                    s['scratch'] = torch.zeros(int(L.read_rmsprop_sorted_scratch_ints()), dtype=torch.int32, device=rows.device)
+                _lib.check(L.read_rmsprop_sorted(rows.data_ptr(), s['sq'].data_ptr(), s['stamp'].data_ptr(), int(rows.shape[1]),
+                                                 int(rows.shape[0]), sorted_ids.data_ptr(), perm.data_ptr(), pg.data_ptr(),
+                                                 int(pids.numel()), s['step'], float(g['lr']), float(g['alpha']), float(g['eps']),
+                                                 s['scratch'].data_ptr(), _lib.stream_ptr()), "read_rmsprop_sorted")
+            else:
+                grad = tex.grad_rows()
+                _lib.check(L.read_rmsprop_sparse(rows.data_ptr(), s['sq'].data_ptr(), grad.data_ptr(), s['stamp'].data_ptr(),
+                                                 int(rows.shape[1]), int(rows.shape[0]), ids.data_ptr(), ids.numel(),
+                                                 s['step'], float(g['lr']), float(g['alpha']), float(g['eps']),
+                                                 _lib.stream_ptr()), "read_rmsprop_sparse")
             tex.rows_changed()
 
     def zero_grad(self, set_to_none=True):
@@ -360,7 +376,8 @@ class SparseDescriptorRMSprop:
 
     def state_dict(self):
         return {'param_groups': [{k: v for k, v in self.param_groups[0].items() if k != 'params'}],
-                'state': [{k: (v.cpu() if torch.is_tensor(v) else v) for k, v in self._state(t).items()} for t in self.textures]}
+                'state': [{k: (v.cpu() if torch.is_tensor(v) else v) for k, v in self._state(t).items() if k != 'scratch'}
+                          for t in self.textures]}
 
     def load_state_dict(self, sd):
         self.param_groups[0].update(sd['param_groups'][0])

@@ -151,10 +151,17 @@ def test_sparse_rmsprop_equals_dense_torch_rmsprop(hip):
     opt = SparseDescriptorRMSprop([tex], lr=0.1)
     ref_p = torch.nn.Parameter(torch.from_numpy(init.copy()))
     ref_opt = torch.optim.RMSprop([ref_p], lr=0.1)
-    for step in range(5):
-        ids = torch.from_numpy(rng.integers(0, N if step != 2 else N // 10, (2, 1, 24, 32)).astype(np.float32))
+    for step in range(6):
+        ids_np = rng.integers(0, N if step != 2 else N // 10, (2, 1, 24, 32))
+        if step == 3:
+            ids_np.reshape(-1)[rng.permutation(ids_np.size)[:800]] = 0         # background: one run of > 512 equal ids
+        ids = torch.from_numpy(ids_np.astype(np.float32))
         w = torch.from_numpy(rng.standard_normal((2, Cc, 24, 32)).astype(np.float32))
         (tex(ids.cuda()) * w.cuda()).sum().backward()
+        if step == 4:       # the dense gradient rows on request (then the optimizer consumes them instead of the sorted pairs)
+            dense = torch.zeros(N, Cc).index_add_(0, ids.reshape(2, -1).long().reshape(-1),
+                                                  w.permute(0, 2, 3, 1).reshape(-1, Cc))
+            _close(tex.grad_rows(), dense, "dense gradient rows", rtol=1e-5)
         opt.step()
         opt.zero_grad()
         ref_opt.zero_grad()
@@ -162,7 +169,7 @@ def test_sparse_rmsprop_equals_dense_torch_rmsprop(hip):
         ref_opt.step()
         assert tex.texture_.grad is None
     got = tex.state_dict()["texture_"].cpu()                       # state_dict() writes the rows back into texture_
-    _close(got, ref_p.detach(), "descriptors after 5 sparse steps", rtol=1e-5)
+    _close(got, ref_p.detach(), "descriptors after 6 sparse steps", rtol=1e-5)
     assert float(tex.grad_rows().abs().max()) == 0.0               # gradient rows are clean again
     # forward after the steps serves the updated rows
     ids = torch.arange(64, dtype=torch.float32).view(1, 1, 8, 8)
