@@ -139,9 +139,17 @@ class GatedConvFn(torch.autograd.Function):
         dx = None
         if ctx.needs_input_grad[0]:
             dx = torch.empty((H, W, cin), dtype=torch.float32, device=dev)
-            if stride == 1:
+            dilated = stride == 2 and k == 3 and H % 2 == 0 and W % 2 == 0
+            if stride == 1 or dilated:
                 # dgrad = the same MFMA convolution over d[f|m] with flipped, transposed weights; the two "gate halves" of
-                # the kernel's output tile are simply the two halves of the input channels
+                # the kernel's output tile are simply the two halves of the input channels.  A 3x3 / stride-2 layer is the
+                # stride-1 layer sampled at the even positions, so its dgrad is the stride-1 dgrad of d[f|m] spread onto the
+                # even positions of a zero image — 4x the necessary MFMAs, still 7x faster than the generic VALU kernel
+                # (1.34 ms per layer) because it runs on the Winograd kernel.
+                d_in = dfm
+                if dilated:
+                    d_in = torch.zeros((H, W, 2 * cp), dtype=torch.float32, device=dev)
+                    d_in[::2, ::2] = dfm
                 wd = ctx.pack[3]
                 if wd is None:
                     wd = torch.empty(L.read_conv_dgrad_packed_floats(cin, cout, k), dtype=torch.float32, device=dev)
@@ -160,7 +168,7 @@ class GatedConvFn(torch.autograd.Function):
                     if wdw is not None:
                         wdw.record_stream(torch.cuda.current_stream())
                 zero = torch.zeros(L.read_conv_param_floats(cin // 2), dtype=torch.float32, device=dev)
-                _linear_conv(dfm, 2 * cp, wd, zero, cin // 2, k, 1, dx, wino=wdw)
+                _linear_conv(d_in, 2 * cp, wd, zero, cin // 2, k, 1, dx, wino=wdw)
             else:
                 ws = torch.empty(L.read_conv_dgrad_generic_floats(cin, cout, k), dtype=torch.float32, device=dev)
                 _lib.check(L.read_conv_dgrad_generic(dfm.data_ptr(), Ho, Wo, cin, cout, k, stride, wf.data_ptr(), wm.data_ptr(),
