@@ -284,14 +284,16 @@ __global__ __launch_bounds__(256) void dgrad_generic_kernel(const float *__restr
 // the taps.  The pixel range is split over grid.z (split-K); partial tiles go to a scratch buffer and
 // wgrad_reduce_kernel sums them into dW_f / dW_m in the PyTorch layout (Cout, Cin, k, k).
 // ---------------------------------------------------------------------------------------------------------------------
-template <int NT>
+// CIB (1x1 layers): the NT accumulators are NT consecutive 32-channel tiles of the INPUT channels instead of NT taps, so the
+// d[f|m] operand is loaded once for NT MFMAs (with NT = 1 a 1x1 layer issues two loads per MFMA: 362 us per layer on average).
+template <int NT, bool CIB>
 __global__ __launch_bounds__(64) void wgrad_mfma_kernel(const float *__restrict__ x, int inH, int inW, int Cin,
                                                         const float *__restrict__ dfm, int outH, int outW, int C2, int ksize,
                                                         int stride, int tiles_co, int rows_per_split,
                                                         float *__restrict__ partial)
 {
     const int lane = threadIdx.x;
-    const int ci0 = ((int)blockIdx.x / tiles_co) * 32, co0 = ((int)blockIdx.x % tiles_co) * 32;
+    const int ci0 = ((int)blockIdx.x / tiles_co) * 32 * (CIB ? NT : 1), co0 = ((int)blockIdx.x % tiles_co) * 32;
     const int pad = (ksize - 1) / 2;
     const int i = lane & 31, kk = lane >> 5;
     const bool ci_ok = ci0 + i < Cin, co_ok = co0 + i < C2;
@@ -316,10 +318,10 @@ __global__ __launch_bounds__(64) void wgrad_mfma_kernel(const float *__restrict_
     int tky[NT], tkx[NT];
 #pragma unroll
     for (int t = 0; t < NT; ++t) {
-        const int tap = (int)blockIdx.y * NT + t;
+        const int tap = CIB ? 0 : (int)blockIdx.y * NT + t;
         tky[t] = tap / ksize;
         tkx[t] = tap - tky[t] * ksize;
-        xb[t] = reinterpret_cast<const char *>(x) + ((long long)tky[t] * inW + tkx[t]) * Cin * 4;
+        xb[t] = reinterpret_cast<const char *>(x) + (((long long)tky[t] * inW + tkx[t]) * Cin + (CIB ? 32 * t : 0)) * 4;
     }
     const unsigned lane_x = (unsigned)(kk * stride * Cin + cil), lane_d = (unsigned)(kk * C2 + col);
     int f_oy = y_begin, f_p = 0;
@@ -333,7 +335,7 @@ __global__ __launch_bounds__(64) void wgrad_mfma_kernel(const float *__restrict_
         const int oy = live ? f_oy : y_begin, p = live ? f_p : 0;
         const int iy0 = oy * stride - pad, ix0 = 2 * p * stride - pad;             // tap (0,0) of the pair's first pixel
         const bool inside = live && iy0 >= 0 && iy0 + ksize - 1 < inH && ix0 >= 0 && ix0 + stride + ksize - 1 < inW &&
-                            2 * p + 1 < outW && taps == NT * (int)gridDim.y;
+                            2 * p + 1 < outW && (CIB || taps == NT * (int)gridDim.y);
         if (inside) {                                                            // wave-uniform
             const unsigned off = ((unsigned)((iy0 * inW + ix0) * Cin) + lane_x) * 4u;
 #pragma unroll
@@ -347,8 +349,8 @@ __global__ __launch_bounds__(64) void wgrad_mfma_kernel(const float *__restrict_
 #pragma unroll
             for (int t = 0; t < NT; ++t) {
                 const int iy = iy0 + tky[t], ix = px * stride - pad + tkx[t];
-                const bool ok = p_ok && ci_ok && (int)blockIdx.y * NT + t < taps && iy >= 0 && iy < inH && ix >= 0 && ix < inW;
-                const float v = ld(xc, ok ? (unsigned)((iy * inW + ix) * Cin + cil) * 4u : 0u);
+                const bool ok = p_ok && ci_ok && (CIB || (int)blockIdx.y * NT + t < taps) && iy >= 0 && iy < inH && ix >= 0 && ix < inW;
+                const float v = ld(xc, ok ? (unsigned)((iy * inW + ix) * Cin + cil + (CIB ? 32 * t : 0)) * 4u : 0u);
                 a[t] = ok ? v : 0.0f;
             }
         }
@@ -389,7 +391,8 @@ __global__ __launch_bounds__(64) void wgrad_mfma_kernel(const float *__restrict_
 // (co' fastest), so the `splits` reads of a thread's element are coalesced across the wave; the one scattered access is the
 // final store.  (Walking the output layout instead cost 94 us per layer: every read of every split was a 4-byte gather.)
 __global__ void wgrad_reduce_kernel(const float *__restrict__ partial, int splits, int tap_groups, int NT, int tiles_ci,
-                                    int tiles_co, int Cin, int Cout, int Cp, int taps, float *dwf, float *dwm, int accumulate)
+                                    int tiles_co, int Cin, int Cout, int Cp, int taps, float *dwf, float *dwm, int accumulate,
+                                    int cib)
 {
     const long long tile_stride = (long long)NT * 1024;
     const long long tiles = (long long)tiles_ci * tiles_co;
@@ -399,8 +402,8 @@ __global__ void wgrad_reduce_kernel(const float *__restrict__ partial, int split
         const int t = (int)((e >> 10) % NT);
         const long long tt = e / tile_stride;                      // tapgroup * tiles + tile
         const int tile = (int)(tt % tiles), tg = (int)(tt / tiles);
-        const int tap = tg * NT + t;
-        const int ci = (tile / tiles_co) * 32 + row, cp = (tile % tiles_co) * 32 + col;
+        const int tap = cib ? 0 : tg * NT + t;                       // cib: t = tile of input channels inside the block
+        const int ci = cib ? ((tile / tiles_co) * NT + t) * 32 + row : (tile / tiles_co) * 32 + row, cp = (tile % tiles_co) * 32 + col;
         const int half = cp >= Cp ? 1 : 0, co = cp - half * Cp;
         if (tap >= taps || ci >= Cin || co >= Cout || cp >= 2 * Cp) continue;
         float s = 0.0f;
@@ -711,6 +714,7 @@ extern "C" int read_conv_dgrad_generic(const float *dfm, int outH, int outW, int
 namespace {
 struct WgradPlan {
     int NT, tap_groups, tiles_ci, tiles_co, splits, rows_per_split;
+    int cib;                   // 1x1 layers: NT tiles of input channels per wave (tiles_ci then counts blocks of NT tiles)
     size_t partial_floats;
 };
 WgradPlan wgrad_plan(int Cin, int Cout, int ksize, int outH)
@@ -720,6 +724,12 @@ WgradPlan wgrad_plan(int Cin, int Cout, int ksize, int outH)
     p.NT = taps == 1 ? 1 : (taps == 9 ? 9 : 8);
     p.tap_groups = (taps + p.NT - 1) / p.NT;
     p.tiles_ci = (Cin + 31) / 32;
+    p.cib = 0;
+    if (taps == 1 && Cin % 32 == 0 && p.tiles_ci > 1) {
+        p.NT = p.tiles_ci % 5 == 0 ? 5 : (p.tiles_ci % 4 == 0 ? 4 : (p.tiles_ci % 2 == 0 ? 2 : 1));
+        p.cib = p.NT > 1;
+        p.tiles_ci /= p.NT;
+    }
     p.tiles_co = (2 * Cp + 31) / 32;
     const int waves = p.tiles_ci * p.tiles_co * p.tap_groups;
     int splits = (2048 + waves - 1) / waves;                    // ~2 waves per SIMD over the chip
@@ -753,13 +763,14 @@ extern "C" int read_conv_wgrad(const float *x, int inH, int inW, int Cin, const 
     const WgradPlan p = wgrad_plan(Cin, Cout, ksize, outH);
     READ_CHECK_ARG(scratch_floats >= p.partial_floats, "read_conv_wgrad: scratch %zu < %zu floats", scratch_floats, p.partial_floats);
     const dim3 grid((unsigned)(p.tiles_ci * p.tiles_co), (unsigned)p.tap_groups, (unsigned)p.splits);
-    auto kern = p.NT == 9 ? wgrad_mfma_kernel<9> : (p.NT == 8 ? wgrad_mfma_kernel<8> : wgrad_mfma_kernel<1>);
+    auto kern = p.cib ? (p.NT == 5 ? wgrad_mfma_kernel<5, true> : (p.NT == 4 ? wgrad_mfma_kernel<4, true> : wgrad_mfma_kernel<2, true>))
+                      : (p.NT == 9 ? wgrad_mfma_kernel<9, false> : (p.NT == 8 ? wgrad_mfma_kernel<8, false> : wgrad_mfma_kernel<1, false>));
     hipLaunchKernelGGL(kern, grid, dim3(64), 0, as_stream(stream), x, inH, inW, Cin, dfm, outH, outW, 2 * Cp, ksize, stride,
                        p.tiles_co, p.rows_per_split, scratch);
     READ_CHECK_LAUNCH();
     const long long total = (long long)p.tap_groups * p.tiles_ci * p.tiles_co * p.NT * 1024;
     hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(grid_for(total)), dim3(256), 0, as_stream(stream), (const float *)scratch,
-                       p.splits, p.tap_groups, p.NT, p.tiles_ci, p.tiles_co, Cin, Cout, Cp, ksize * ksize, dwf, dwm, accumulate);
+                       p.splits, p.tap_groups, p.NT, p.tiles_ci, p.tiles_co, Cin, Cout, Cp, ksize * ksize, dwf, dwm, accumulate, p.cib);
     READ_CHECK_LAUNCH();
     return READ_OK;
 }

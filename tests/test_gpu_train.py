@@ -30,7 +30,7 @@ def _close(got, ref, what, rtol=RTOL):
 
 @pytest.mark.parametrize("cin,cout,k,stride,elu,H,W", [
     (32, 32, 3, 1, True, 24, 40), (64, 64, 3, 1, False, 17, 33), (8, 32, 3, 1, True, 32, 48), (32, 3, 3, 1, False, 16, 32),
-    (480, 32, 1, 1, True, 16, 24), (64, 56, 1, 1, True, 12, 20), (16, 32, 1, 1, True, 9, 31),
+    (480, 32, 1, 1, True, 16, 24), (64, 56, 1, 1, True, 12, 20), (16, 32, 1, 1, True, 9, 31), (128, 64, 1, 1, False, 10, 18),
     (32, 64, 3, 2, True, 32, 48), (128, 256, 3, 2, True, 16, 16), (256, 128, 4, 2, True, 16, 24), (64, 32, 4, 2, True, 32, 32),
 ])
 def test_gated_conv_layer_gradients(hip, cin, cout, k, stride, elu, H, W):
