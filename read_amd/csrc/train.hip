@@ -359,7 +359,8 @@ __global__ __launch_bounds__(64) void wgrad_mfma_kernel(const float *__restrict_
             ++f_oy;
         }
     };
-    // one fetch site, operands two steps ahead: the ring rotates through register moves (2 NT + 2 per step, against NT MFMAs)
+    // one fetch site, operands two steps ahead: the ring rotates through register moves (2 NT + 2 per step, against NT MFMAs).
+    // (Four steps ahead was measured slower, 373 vs 290 us per 3x3 layer: the extra moves cost more than the latency they hide.)
     const long long total_steps = (long long)(y_end - y_begin) * n_pairs;
     float a0[NT], a1[NT], a2[NT], b0, b1, b2;
     fetch(a0, b0);
@@ -868,31 +869,56 @@ __global__ __launch_bounds__(256) void rmsprop_sorted_kernel(float *__restrict__
     rmsprop_row(rows, sq, stamp, C, id, acc, step, lr, alpha, eps);
 }
 
-__global__ __launch_bounds__(256) void rmsprop_long_kernel(float *__restrict__ rows, float *__restrict__ sq, int *__restrict__ stamp,
-                                                           int C, const long long *__restrict__ perm, const float *__restrict__ g,
-                                                           int step, float lr, float alpha, float eps, const int *__restrict__ long_list)
+// long runs: LONG_SUB workgroups each sum a slice of the run (whole rows, fixed tree), the final kernel adds the slices in order
+constexpr int LONG_SUB = 64;
+
+__global__ __launch_bounds__(256) void rmsprop_long_partial_kernel(int C, const long long *__restrict__ perm, const float *__restrict__ g,
+                                                                   const int *__restrict__ long_list, float *__restrict__ partial)
 {
     __shared__ float red[256];
-    __shared__ float total[RMS_MAX_C];
     const int count = long_list[0] < MAX_LONG ? long_list[0] : MAX_LONG;
-    if ((int)blockIdx.x >= count) return;
-    const long long id = long_list[1 + 3 * blockIdx.x], start = long_list[2 + 3 * blockIdx.x], len = long_list[3 + 3 * blockIdx.x];
+    const int seg = blockIdx.y, sub = blockIdx.x;
+    if (seg >= count) return;
+    const long long start = long_list[2 + 3 * seg], len = long_list[3 + 3 * seg];
+    const long long per = (len + LONG_SUB - 1) / LONG_SUB, lo = sub * per, hi = lo + per < len ? lo + per : len;
+    float acc[RMS_MAX_C];
+    for (int c = 0; c < C; ++c) acc[c] = 0.0f;
+    for (long long j = lo + threadIdx.x; j < hi; j += 256) {
+        const float *row = g + perm[start + j] * C;
+        for (int c = 0; c < C; ++c) acc[c] += row[c];
+    }
     for (int c = 0; c < C; ++c) {
-        float s = 0.0f;
-        for (long long j = threadIdx.x; j < len; j += 256) s += g[perm[start + j] * C + c];
-        red[threadIdx.x] = s;
+        red[threadIdx.x] = acc[c];
         __syncthreads();
         for (int o = 128; o > 0; o >>= 1) {
             if ((int)threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o];
             __syncthreads();
         }
-        if (threadIdx.x == 0) total[c] = red[0];
+        if (threadIdx.x == 0) partial[((size_t)seg * LONG_SUB + sub) * RMS_MAX_C + c] = red[0];
         __syncthreads();
     }
-    if (threadIdx.x == 0) rmsprop_row(rows, sq, stamp, C, id, total, step, lr, alpha, eps);
 }
 
-extern "C" size_t read_rmsprop_sorted_scratch_ints(void) { return 1 + 3 * MAX_LONG; }
+__global__ __launch_bounds__(64) void rmsprop_long_final_kernel(float *__restrict__ rows, float *__restrict__ sq, int *__restrict__ stamp,
+                                                                int C, int step, float lr, float alpha, float eps,
+                                                                const int *__restrict__ long_list, const float *__restrict__ partial)
+{
+    __shared__ float total[RMS_MAX_C];
+    const int count = long_list[0] < MAX_LONG ? long_list[0] : MAX_LONG;
+    if ((int)blockIdx.x >= count) return;
+    if ((int)threadIdx.x < C) {
+        float s = 0.0f;
+        for (int k = 0; k < LONG_SUB; ++k) s += partial[((size_t)blockIdx.x * LONG_SUB + k) * RMS_MAX_C + threadIdx.x];
+        total[threadIdx.x] = s;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) rmsprop_row(rows, sq, stamp, C, long_list[1 + 3 * blockIdx.x], total, step, lr, alpha, eps);
+}
+
+// scratch = [count, MAX_LONG x (id, start, length)] as int32, padded to 256 words, then MAX_LONG x LONG_SUB x RMS_MAX_C floats
+constexpr size_t LONG_LIST_WORDS = 256;
+static_assert(1 + 3 * MAX_LONG <= LONG_LIST_WORDS, "long-run list does not fit its scratch region");
+extern "C" size_t read_rmsprop_sorted_scratch_ints(void) { return LONG_LIST_WORDS + (size_t)MAX_LONG * LONG_SUB * RMS_MAX_C; }
 
 extern "C" int read_rmsprop_sorted(float *rows, float *sq, int32_t *stamp, int C, int64_t n_rows, const int32_t *sorted_ids,
                                    const int64_t *perm, const float *g, int64_t n, int step, float lr, float alpha, float eps,
@@ -905,8 +931,12 @@ extern "C" int read_rmsprop_sorted(float *rows, float *sq, int32_t *stamp, int C
     hipLaunchKernelGGL(rmsprop_sorted_kernel, dim3((unsigned)ceil_div64(n, 256)), dim3(256), 0, as_stream(stream), rows, sq, stamp, C,
                        (long long)n_rows, sorted_ids, (const long long *)perm, g, (long long)n, step, lr, alpha, eps, scratch);
     READ_CHECK_LAUNCH();
-    hipLaunchKernelGGL(rmsprop_long_kernel, dim3(MAX_LONG), dim3(256), 0, as_stream(stream), rows, sq, stamp, C,
-                       (const long long *)perm, g, step, lr, alpha, eps, (const int *)scratch);
+    float *partial = reinterpret_cast<float *>(scratch + LONG_LIST_WORDS);
+    hipLaunchKernelGGL(rmsprop_long_partial_kernel, dim3(LONG_SUB, MAX_LONG), dim3(256), 0, as_stream(stream), C,
+                       (const long long *)perm, g, (const int *)scratch, partial);
+    READ_CHECK_LAUNCH();
+    hipLaunchKernelGGL(rmsprop_long_final_kernel, dim3(MAX_LONG), dim3(64), 0, as_stream(stream), rows, sq, stamp, C, step, lr, alpha,
+                       eps, (const int *)scratch, (const float *)partial);
     READ_CHECK_LAUNCH();
     return READ_OK;
 }
