@@ -197,7 +197,7 @@ def test_cell_ordered_passes_are_exact_for_hard_cameras(hip):
     # work-item granularity of the striped passes, no warm start, no every-n-th chunk in pass A
     try:
         for key, val in ((b"splat_items", 2), (b"splat_items", 1), (b"splat_seeds", 0), (b"splat_cells_sub", 0), (b"splat_strips", 8),
-                         (b"splat_strips", 2), (b"splat_zl2", 1), (b"splat_lds", 0), (b"splat_kslot", 1), (b"splat_kslot", 2)):
+                         (b"splat_strips", 2), (b"splat_zl2", 1), (b"splat_lds", 0), (b"splat_kslot", 1), (b"splat_kslot", 2), (b"splat_bins", 0)):
             _lib.check(L.read_tuning_set(key, val))
             for k in (1, 2, 5):
                 M = camera.total_matrix(proj, poses[k])
@@ -206,10 +206,10 @@ def test_cell_ordered_passes_are_exact_for_hard_cameras(hip):
                 for l in range(5):
                     assert np.array_equal(idx[l][0].cpu().numpy(), oi[l]), f"{key} {val} pose {k} level {l}"
                     assert np.array_equal(dep[l][0].cpu().numpy().view(np.uint32), od[l].view(np.uint32))
-            for k_, v_ in ((b"splat_items", 4), (b"splat_seeds", 1), (b"splat_cells_sub", 32), (b"splat_strips", 1), (b"splat_zl2", 0), (b"splat_lds", 1), (b"splat_kslot", 0)):
+            for k_, v_ in ((b"splat_items", 4), (b"splat_seeds", 1), (b"splat_cells_sub", 32), (b"splat_strips", 1), (b"splat_zl2", 0), (b"splat_lds", 1), (b"splat_kslot", 0), (b"splat_bins", 1)):
                 _lib.check(L.read_tuning_set(k_, v_))
     finally:
-        for k_, v_ in ((b"splat_items", 4), (b"splat_seeds", 1), (b"splat_cells_sub", 32), (b"splat_strips", 1), (b"splat_zl2", 0), (b"splat_lds", 1), (b"splat_kslot", 0)):
+        for k_, v_ in ((b"splat_items", 4), (b"splat_seeds", 1), (b"splat_cells_sub", 32), (b"splat_strips", 1), (b"splat_zl2", 0), (b"splat_lds", 1), (b"splat_kslot", 0), (b"splat_bins", 1)):
             _lib.check(L.read_tuning_set(k_, v_))
     # large world coordinates: the same cloud and camera moved 5 km away (projection rounding grows ~100x)
     off = np.array([5000.0, -3000.0, 4000.0], np.float32)
@@ -229,6 +229,23 @@ def test_cell_ordered_passes_are_exact_for_hard_cameras(hip):
     finally:
         _lib.check(L.read_tuning_set(b"splat_cells", 1))
     assert all(torch.equal(a, b) for a, b in zip(idx, idx2)) and all(torch.equal(a, b) for a, b in zip(dep, dep2))
+
+
+def test_bins_overflow_falls_back_to_atomics(hip):
+    """2 M points on a 64x32 image: two 32x32 tiles, so every sub-bin of pass A (256 records) overflows many times over and
+    most candidates take the fallback atomic on the key image; the merge must combine both (bit-exact, cold and warm)."""
+    W, H = 64, 32
+    xyz = synthetic.make_cloud(1 << 21, 77)
+    proj = synthetic.make_proj(W, H)
+    r = PointCloudRasterizer(xyz)
+    assert r.cells is not None
+    for k in (0, 1, 1, 30):
+        M = camera.total_matrix(proj, synthetic.sweep_pose(k))
+        idx, dep = r.render(M, W, H, 5)
+        oi, od = oracle.raster_multiscale(xyz, M[0], W, H, 5, threads=8)
+        for l in range(5):
+            assert np.array_equal(idx[l][0].cpu().numpy(), oi[l]), f"pose {k} level {l}"
+            assert np.array_equal(dep[l][0].cpu().numpy().view(np.uint32), od[l].view(np.uint32))
 
 
 def _assert_frame(idx, dep, xyz, M, W, H, what, threads):
