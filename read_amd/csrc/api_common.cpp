@@ -44,7 +44,6 @@ void splat_set_wgs(int v);
 void splat_set_zl2(int v);
 void splat_set_lds(int v);
 void splat_set_bins(int v);
-void splat_set_probe(int v);
 void splat_set_kslot(int v);
 int splat_get(const char *key, int *value);
 void conv_set_trace(void *buf, size_t bytes);
@@ -112,7 +111,6 @@ extern "C" int read_tuning_set(const char *key, int value)
     if (!strcmp(key, "conv_wave")) { readhip::conv_set_prefer_wave(value != 0); return READ_OK; }
 #ifdef READ_DEBUG_KNOBS
     if (!strcmp(key, "conv_ablate")) { readhip::conv_set_ablate(value); return READ_OK; }
-    if (!strcmp(key, "splat_probe")) { readhip::splat_set_probe(value); return READ_OK; }
 #endif
     readhip::set_error("read_tuning_set: unknown key '%s'", key);
     return READ_EINVAL;

@@ -562,16 +562,14 @@ struct BinInfo {
     uint4 *recs;               // tiles x BIN_SUB x cap records {pixel inside the tile, 0, key lo, key hi}; null = pass A with atomics
     unsigned *count;           // per (tile, sub-bin), minus one
     int cap, tiles_x;
-    int probe;                 // -DREAD_DEBUG_KNOBS builds: attribution bits (results invalid): 1 no seed-position stores,
-                               //   2 no bound stores, 4 candidates dropped, 8 nothing after the projection
     float inv_w;               // 1 / W (exact row of a pixel index: (pix + 0.5) * inv_w, W * H <= 2^20)
 };
 
 // NC candidates per lane (valid bit k of `valid`): records into the bins; pos[k] = position of the point (next frame's seed)
 template <int NC>
-__device__ __forceinline__ void emit_binned(const BinInfo &bi, int W, const int (&pix)[NC], const unsigned long long (&key)[NC],
-                                            unsigned valid, unsigned long long *keys, int lane, unsigned *wl_tile,
-                                            unsigned *wl_cnt, int sub)
+__device__ __forceinline__ void emit_binned(const BinInfo &bi, const int (&pix)[NC], const int (&px)[NC], const int (&py)[NC],
+                                            const unsigned long long (&key)[NC], unsigned valid, unsigned long long *keys,
+                                            int lane, unsigned *wl_tile, unsigned *wl_cnt, int sub)
 {
     int tile[NC], inpix[NC], entry[NC], rank[NC];
     int nd = 0;                                                     // wave-uniform: (pass, tile) pairs so far
@@ -584,9 +582,8 @@ __device__ __forceinline__ void emit_binned(const BinInfo &bi, int W, const int 
 #pragma unroll
         for (int k = 0; k < NC; ++k) {
             const bool act = (valid >> k) & 1u;
-            const int y = (int)(((float)pix[k] + 0.5f) * bi.inv_w), x = pix[k] - y * W;
-            tile[k] = act ? ((y >> 5) * bi.tiles_x + (x >> 5)) * BIN_SUB + sub : -1;    // (tile, sub-bin of this wave)
-            inpix[k] = (y & 31) * BIN_TILE + (x & 31);
+            tile[k] = act ? ((py[k] >> 5) * bi.tiles_x + (px[k] >> 5)) * BIN_SUB + sub : -1;    // (tile, sub-bin of this wave)
+            inpix[k] = (py[k] & 31) * BIN_TILE + (px[k] & 31);
             mk[k] = __ballot(act);
             if (t0 < 0 && mk[k]) t0 = __builtin_amdgcn_readlane(tile[k], __builtin_ctzll(mk[k]));
         }
@@ -677,99 +674,85 @@ __device__ __forceinline__ void strip_points(const CellCloud &cc, const float *M
 #pragma unroll
             for (int k = 0; k < 4; ++k) qn[k] = cc.pts[next_first + lane + 64 * k];
         }
-        int pix[4];
+        int pix[4], px[4], py[4];
         unsigned dbits[4], bound[4];
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
-            int xx, yy;
             float d;
-            pix[k] = project_one(q[k].x, q[k].y, q[k].z, M, W, H, d, xx, yy);
-            if (xx < xlo || xx >= xhi) pix[k] = -1;
+            pix[k] = project_one(q[k].x, q[k].y, q[k].z, M, W, H, d, px[k], py[k]);
+            if (px[k] < xlo || px[k] >= xhi) pix[k] = -1;
             dbits[k] = __float_as_uint(d);
             if (STATS && pix[k] >= 0) st_in++;
         }
-#ifdef READ_DEBUG_KNOBS
-        const int probe = bi.probe;
-        if (probe & 8) {
-#pragma unroll
-            for (int k = 0; k < 4; ++k)
-                if (pix[k] == -12345) zimg[0] = dbits[k];         // keeps the projection live
-#pragma unroll
-            for (int k = 0; k < 4; ++k) q[k] = qn[k];
-            continue;
-        }
-#else
-        constexpr int probe = 0;
-#endif
         // early-z against the bound image (L1 / this XCD's L2; a stale bound is only ever LARGER)
 #pragma unroll
         for (int k = 0; k < 4; ++k)
             bound[k] = pix[k] < 0 ? 0u
                        : ZL2 ? __hip_atomic_load(zimg + pix[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)   // sc1: L2, not L1
                              : zimg[pix[k]];
-        int cpix[4];                                               // BIN: candidates that go to memory directly
-        unsigned long long ckey[4];
-        unsigned cvalid = 0;
+        // Candidates = points at or in front of their pixel's bound (ties pass: the key's id part breaks them).  Kept as
+        // bit masks over the four points of a lane and handled in straight-line stages — the first version walked a
+        // per-point if-chain through all of it and the compiler shuffled the four 64-bit keys between branch arms
+        // (385 of the loop's 1370 VALU instructions were moves; the pass is VALU-issue bound).
+        unsigned long long key[4];
+        unsigned cand = 0;
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
-            cpix[k] = 0;
-            ckey[k] = 0;
-            if (pix[k] < 0 || dbits[k] > bound[k]) continue;       // ties pass: the atomic breaks them by id
-            const unsigned long long key = ((unsigned long long)dbits[k] << 32) | __float_as_uint(q[k].w);
-            if (dbits[k] < bound[k] && !(probe & 2)) zimg[pix[k]] = dbits[k];
-            bool direct = true;
-            if (LDS && use_lds) {
-                unsigned h = ((unsigned)pix[k] * 2654435761u) >> 24;
+            key[k] = ((unsigned long long)dbits[k] << 32) | __float_as_uint(q[k].w);
+            cand |= (pix[k] >= 0 && dbits[k] <= bound[k] ? 1u : 0u) << k;
+        }
 #pragma unroll
-                for (int probe = 0; probe < 2 && direct; ++probe, h = (h + 1) & (LDS_SLOTS - 1)) {
+        for (int k = 0; k < 4; ++k)
+            if (((cand >> k) & 1u) && dbits[k] < bound[k]) zimg[pix[k]] = dbits[k];
+        unsigned direct = cand;                                    // candidates that go to memory (bins / atomics) themselves
+        if (LDS && use_lds) {                                      // wave-uniform: dense chunk, fold into the wave's table first
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                if (!((cand >> k) & 1u)) continue;
+                unsigned h = ((unsigned)pix[k] * 2654435761u) >> 24;
+                bool placed = false;
+#pragma unroll
+                for (int probe = 0; probe < 2 && !placed; ++probe, h = (h + 1) & (LDS_SLOTS - 1)) {
                     const unsigned old = atomicCAS(tag + h, 0u, (unsigned)pix[k] + 1u);
                     if (old == 0u || old == (unsigned)pix[k] + 1u) {
-                        if (key < atomicMin(hkey + h, key)) hpos[h] = base + 64 * k;
-                        direct = false;
+                        if (key[k] < atomicMin(hkey + h, key[k])) hpos[h] = base + 64 * k;
+                        placed = true;
                     }
                 }
-            }
-            if (direct) {
-                if (BIN) {
-                    cpix[k] = pix[k];
-                    ckey[k] = key;
-                    cvalid |= 1u << k;
-                } else {
-                    __hip_atomic_fetch_min(keys + key_slot(ks, (unsigned)pix[k]), key, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                }
-                if (!(probe & 1)) next[pix[k]] = base + 64 * k;    // a front point of this pixel: next frame's seed
-                if (STATS) st_atomics++;
+                if (placed) direct &= ~(1u << k);
             }
         }
-        if (probe & 4) cvalid = 0;
-        if (BIN && __ballot(cvalid != 0u)) emit_binned<4>(bi, W, cpix, ckey, cvalid, keys, lane, wl_tile, wl_cnt, sub);
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+            if ((direct >> k) & 1u) {
+                next[pix[k]] = base + 64 * k;                      // a front point of this pixel: next frame's seed
+                if (!BIN) __hip_atomic_fetch_min(keys + key_slot(ks, (unsigned)pix[k]), key[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (STATS) st_atomics++;
+            }
+        if (BIN && __ballot(direct != 0u)) emit_binned<4>(bi, pix, px, py, key, direct, keys, lane, wl_tile, wl_cnt, sub);
         if (LDS && use_lds) {
             // the wave's own table: its LDS operations complete in program order, no barrier needed
             __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
-            cvalid = 0;
+            unsigned flush = 0;
 #pragma unroll
             for (int j = 0; j < LDS_SLOTS / 64; ++j) {
                 const int sl = lane + 64 * j;
                 const unsigned t = tag[sl];
-                cpix[j] = 0;
-                ckey[j] = 0;
+                pix[j] = (int)t - 1;
+                key[j] = hkey[sl];
+                py[j] = (int)(((float)pix[j] + 0.5f) * bi.inv_w);  // exact for W * H <= 2^20 (BIN only; unused otherwise)
+                px[j] = pix[j] - py[j] * W;
                 if (t) {
-                    if (BIN) {
-                        cpix[j] = (int)(t - 1u);
-                        ckey[j] = hkey[sl];
-                        cvalid |= 1u << j;
-                    } else {
-                        __hip_atomic_fetch_min(keys + key_slot(ks, t - 1u), hkey[sl], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    }
-                    if (!(probe & 1)) next[t - 1u] = hpos[sl];
+                    flush |= 1u << j;
+                    if (!BIN) __hip_atomic_fetch_min(keys + key_slot(ks, t - 1u), key[j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    next[t - 1u] = hpos[sl];
                     tag[sl] = 0u;
                     hkey[sl] = ~0ull;
                     if (STATS) st_atomics++;
                 }
             }
             __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
-            if (probe & 4) cvalid = 0;
-            if (BIN && __ballot(cvalid != 0u)) emit_binned<4>(bi, W, cpix, ckey, cvalid, keys, lane, wl_tile, wl_cnt, sub);
+            if (BIN && __ballot(flush != 0u)) emit_binned<4>(bi, pix, px, py, key, flush, keys, lane, wl_tile, wl_cnt, sub);
         }
 #pragma unroll
         for (int k = 0; k < 4; ++k) q[k] = qn[k];
@@ -1244,7 +1227,6 @@ int g_splat_kslot = 0;          // key-image layout of the striped path: 0 linea
 int g_splat_lds = 1;            // 1: per-wave LDS hash table in front of the memory-side atomics (strip_points)
 int g_splat_wgs = 4;            // workgroups per CU of the striped passes: 0.0996 / 0.0936 / 0.0893 / 0.0927 / 0.0923 ms at 2 / 3 / 4 / 6 / 8
                                 // (fewer waves = more rounds per wave = finer front-to-back order over the depth bands)
-int g_splat_probe = 0;          // -DREAD_DEBUG_KNOBS builds only (BinInfo::probe)
 int g_splat_bins = 1;           // 1: pass A appends its candidates to per-tile bins, merged in LDS (emit_binned); 0: one memory-side atomic each
 int g_splat_strips = 1;         // column strips of the striped passes (1, 2, 4 or 8).  8 was best while a strip's list was walked in
                                // Morton order (pass A 61.5 / 75.5 / 70 us at 8 / 2 / 1: fewer atomics with exact bounds); with the
@@ -1441,7 +1423,6 @@ int cells_frame(const CellCloud &cc, const float *M_host, int W, int H, int leve
         bi.cap = ws.bin_cap;
         bi.tiles_x = ws.bin_tiles_x;
         bi.inv_w = 1.0f / (float)W;
-        bi.probe = g_splat_probe;
     }
     auto pass_a = bins ? (stats ? (g_splat_lds ? cells_pass_kernel<false, true, false, true, true> : cells_pass_kernel<false, true, false, false, true>)
                           : g_splat_zl2 ? cells_pass_kernel<false, false, true, false, true>
@@ -1494,7 +1475,6 @@ void splat_set_items(int v) { g_splat_items = v >= 4 ? 4 : (v >= 2 ? 2 : 1); }
 void splat_set_zl2(int v) { g_splat_zl2 = v != 0; }
 void splat_set_lds(int v) { g_splat_lds = v != 0; }
 void splat_set_bins(int v) { g_splat_bins = v != 0; }
-void splat_set_probe(int v) { g_splat_probe = v; }
 void splat_set_kslot(int v) { g_splat_kslot = v < 0 ? 0 : (v > 2 ? 2 : v); }
 void splat_set_wgs(int v) { g_splat_wgs = v < 1 ? 1 : (v > 16 ? 16 : v); }
 void splat_set_strips(int v) { g_splat_strips = v >= 8 ? 8 : (v >= 4 ? 4 : (v >= 2 ? 2 : 1)); }
