@@ -61,6 +61,17 @@ _PACK_CACHE = {}
 USE_WINOGRAD = True          # 3x3 / stride-1 layers with cin % 16 == 0: forward pre-activations and dgrad through the Winograd kernel
 
 
+_ZERO_PARAMS = {}
+
+
+def _zero_params(n, dev):
+    """An all-zero parameter block (bias / scale / shift of the dgrad's virtual layer): read-only, one per size and device."""
+    z = _ZERO_PARAMS.get((n, dev))
+    if z is None:
+        z = _ZERO_PARAMS[(n, dev)] = torch.zeros(n, dtype=torch.float32, device=dev)
+    return z
+
+
 def _packed_for(wf, bf, wm, bm, gamma, beta, mean, var, cin, cout, k):
     L = _lib.lib()
     st = _lib.stream_ptr()
@@ -133,7 +144,7 @@ class GatedConvFn(torch.autograd.Function):
         sums = torch.empty((4, cout), dtype=torch.float32, device=dev)
         _lib.check(L.read_gate_backward(dy.data_ptr(), fm.data_ptr(), Ho * Wo, cout, params.data_ptr(), elu, dfm.data_ptr(),
                                         sums.data_ptr(), Wo, bh, vh, st))
-        dbf, dbm, dgamma, dbeta = (torch.zeros(cout, dtype=torch.float32, device=dev) for _ in range(4))
+        dbf, dbm, dgamma, dbeta = torch.zeros((4, cout), dtype=torch.float32, device=dev).unbind(0)     # one fill, four rows
         _lib.check(L.read_bn_param_grads(cout, sums.data_ptr(), mean.data_ptr(), var.data_ptr(), BN_EPS, dbf.data_ptr(),
                                          dbm.data_ptr(), dgamma.data_ptr(), dbeta.data_ptr(), st))
         dx = None
@@ -167,7 +178,7 @@ class GatedConvFn(torch.autograd.Function):
                     wd.record_stream(torch.cuda.current_stream())
                     if wdw is not None:
                         wdw.record_stream(torch.cuda.current_stream())
-                zero = torch.zeros(L.read_conv_param_floats(cin // 2), dtype=torch.float32, device=dev)
+                zero = _zero_params(L.read_conv_param_floats(cin // 2), dev)
                 _linear_conv(d_in, 2 * cp, wd, zero, cin // 2, k, 1, dx, wino=wdw)
             else:
                 ws = torch.empty(L.read_conv_dgrad_generic_floats(cin, cout, k), dtype=torch.float32, device=dev)
