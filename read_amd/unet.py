@@ -164,8 +164,16 @@ class UNet(nn.Module):
 
     # ---- weights -> device blob --------------------------------------------------------------
     def _weights_key(self):
-        dev = next(self.parameters()).device
-        return (dev,) + tuple(t._version for t in list(self.parameters()) + list(self.buffers()))
+        # called once per frame (engine()): the flat tensor list is cached — walking the module tree for its ~700
+        # parameters and buffers costs 1.4 ms of host time per call, reading their version counters 0.05 ms
+        ts = self.__dict__.get('_flat_tensors')
+        if ts is None:
+            ts = self.__dict__['_flat_tensors'] = list(self.parameters()) + list(self.buffers())
+        return (ts[0].device,) + tuple(t._version for t in ts)
+
+    def _apply(self, fn, *args, **kwargs):
+        self.__dict__['_flat_tensors'] = None          # .cuda() / .to() may replace the tensors
+        return super()._apply(fn, *args, **kwargs)
 
     def packed_weights(self):
         key = self._weights_key()
@@ -183,6 +191,7 @@ class UNet(nn.Module):
         """Drop the packed weights (call after editing parameters through ``.data``, which does not bump ``_version``)."""
         self._packed = None
         self._engines = {}
+        self.__dict__['_flat_tensors'] = None
 
     def load_state_dict(self, *args, **kwargs):
         self.invalidate()
