@@ -213,6 +213,11 @@ typedef struct read_conv_desc {
      * (READ/models/unet.py:239-254, the AFF inputs).  Not available with the Winograd kernel. */
     const float *pre;
     int pre_cstride, pre_f_off, pre_m_off, pre_shift, preH, preW;
+    /* optional, linear launches that run on the Winograd kernel (3x3 / stride 1, Cin % 16 == 0): ALSO store the layer's output
+     * BN_eval(act(f) * sigmoid(m)), NHWC [outH][outW][Cout], in the same pass (what read_gate_forward would compute from
+     * `out`); rows r of a stacked batch with r % block_h >= valid_h are written as zeros (block_h = 0: one image). */
+    float *out_gated;
+    int block_h, valid_h;
 } read_conv_desc;
 
 /* Sizes (in floats) of the packed weight / parameter blocks of one BasicConv. */

@@ -61,6 +61,10 @@ struct ConvKArgs {
     // with pre_moff — partial sums of the same layer computed at a coarser level (nearest up-sampling commutes with a 1x1 conv)
     const float *pre;
     int pre_cstride, pre_foff, pre_moff, pre_shift, pre_W, pre_bytes;
+    // linear launches of the training path (Winograd kernel): also store the gated output BN(act(f) * sigmoid(m)) here, zero on
+    // the separator rows of a stacked batch (rows r with r % blk_h >= blk_valid)
+    float *out_gated;
+    int blk_h, blk_valid;
     unsigned long long *trace;     // optional timeline: 8 x u64 per workgroup (read_debug_set_trace)
 };
 
@@ -969,6 +973,27 @@ __global__ __launch_bounds__(256, 2) void gated_conv_wino_kernel(const ConvKArgs
                                     }
                             }
                         }
+                        if (a.out_gated && pix_in[aa][b]) {          // ... and the layer's output in the same pass (gate_forward_kernel)
+                            constexpr float L2E = 1.44269504088896341f;
+                            f32x4 g = f;
+                            if (a.elu) {
+                                const f32x4 fe = f * L2E;
+#pragma unroll
+                                for (int k = 0; k < 4; ++k) g[k] = f[k] > 0.0f ? f[k] : __builtin_amdgcn_exp2f(fe[k]) - 1.0f;
+                            }
+                            const f32x4 mn = m * -L2E;
+                            f32x4 v;
+#pragma unroll
+                            for (int k = 0; k < 4; ++k) v[k] = (g[k] * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(mn[k]))) * sc[k] + sh[k];
+                            if (a.blk_h > 0 && (oy + aa) % a.blk_h >= a.blk_valid) v = f32x4{0.f, 0.f, 0.f, 0.f};
+                            float *gp = a.out_gated + ((size_t)(oy + aa) * a.outW + ox + b) * a.Cout + c0;
+                            if (c0 + 3 < a.Cout && (a.Cout & 3) == 0) *reinterpret_cast<f32x4 *>(gp) = v;
+                            else {
+#pragma unroll
+                                for (int k = 0; k < 4; ++k)
+                                    if (c0 + k < a.Cout) gp[k] = v[k];
+                            }
+                        }
                         continue;
                     }
                     const f32x4 mm = (Y[1][aa][b] + bm) * -LOG2E;
@@ -1683,6 +1708,12 @@ int launch_gated_conv(const read_conv_desc *d, hipStream_t stream)
     a.nchunks = nchunks;
     a.tiles_x = ceil_div(outW, 32);
     READ_CHECK_ARG(!d->pre || !c.wino, "read_gated_conv_forward: the Winograd kernel takes no pre-activation addend");
+    READ_CHECK_ARG(!d->out_gated || (c.wino && d->linear && (uintptr_t)d->out_gated % 16 == 0 && d->block_h >= 0 &&
+                                     d->valid_h <= d->block_h),
+                   "read_gated_conv_forward: out_gated needs a linear launch on the Winograd kernel");
+    a.out_gated = d->out_gated;
+    a.blk_h = d->block_h;
+    a.blk_valid = d->valid_h;
     const int tiles_y = ceil_div(outH, c.WM * c.P);
     dim3 grid((unsigned)(a.tiles_x * tiles_y), (unsigned)(groups / (c.WN * c.QG)));
     a.trace = ((size_t)grid.x * grid.y <= g_trace_records) ? g_trace : nullptr;

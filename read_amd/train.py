@@ -38,9 +38,10 @@ def _kc_for(cin):
     return 16 if cin % 16 == 0 else 8
 
 
-def _linear_conv(x, cin, wpacked, params, cout, k, stride, out, wino=None):
+def _linear_conv(x, cin, wpacked, params, cout, k, stride, out, wino=None, gated=None):
     """x (H,W,cin) NHWC -> out (Ho,Wo,2*cout): [conv_f + b_f | conv_m + b_m] through the MFMA kernel (linear epilogue);
-    with Winograd fragments (3x3 / stride 1, cin % 16 == 0) through the Winograd F(2x2,3x3) kernel."""
+    with Winograd fragments (3x3 / stride 1, cin % 16 == 0) through the Winograd F(2x2,3x3) kernel — which can store the
+    layer's gated output in the same pass: gated = (y (Ho,Wo,cout), elu, block_h, valid_h)."""
     H, W = int(x.shape[0]), int(x.shape[1])
     d = _lib.ConvDesc()
     d.n_src = 1
@@ -51,6 +52,9 @@ def _linear_conv(x, cin, wpacked, params, cout, k, stride, out, wino=None):
     d.config, d.linear = -1, 1
     if wino is not None:
         d.wpacked_wino = wino.data_ptr()
+        if gated is not None:
+            y, elu, bh, vh = gated
+            d.out_gated, d.elu, d.block_h, d.valid_h = y.data_ptr(), int(elu), int(bh), int(vh)
     _lib.check(_lib.lib().read_gated_conv_forward(C.byref(d), _lib.stream_ptr()), "read_gated_conv_forward(linear)")
     return out
 
@@ -121,12 +125,15 @@ class GatedConvFn(torch.autograd.Function):
         params, wp = entry[1], entry[2]
         ctx.pack = entry
         fm = torch.empty((Ho, Wo, 2 * cout), dtype=torch.float32, device=dev)
-        _linear_conv(x, cin, wp, params, cout, k, stride, fm, wino=entry[5] if stride == 1 else None)
         y = torch.empty((Ho, Wo, cout), dtype=torch.float32, device=dev)
         # a batch is one tall image of nb stacked items; separator rows (block geometry at THIS layer's output scale) stay zero
         bh = Ho // nb if nb > 1 else 0
         vh = bh * v_num // v_den
-        _lib.check(L.read_gate_forward(fm.data_ptr(), Ho * Wo, cout, params.data_ptr(), int(elu), None, y.data_ptr(), Wo, bh, vh, st))
+        wino = entry[5] if stride == 1 else None
+        # the Winograd kernel writes the gated output next to the pre-activations; the other kernels leave it to the gate pass
+        _linear_conv(x, cin, wp, params, cout, k, stride, fm, wino=wino, gated=(y, elu, bh, vh))
+        if wino is None:
+            _lib.check(L.read_gate_forward(fm.data_ptr(), Ho * Wo, cout, params.data_ptr(), int(elu), None, y.data_ptr(), Wo, bh, vh, st))
         ctx.save_for_backward(x, fm, params, wf_c, wm_c, mean, var)
         ctx.cfg = (k, stride, int(elu), H, W, cin, cout, Ho, Wo, bh, vh)
         return y
