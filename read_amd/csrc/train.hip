@@ -359,24 +359,30 @@ __global__ __launch_bounds__(64) void wgrad_mfma_kernel(const float *__restrict_
             ++f_oy;
         }
     };
-    // one fetch site, operands two steps ahead: the ring rotates through register moves (2 NT + 2 per step, against NT MFMAs).
-    // (Four steps ahead was measured slower, 373 vs 290 us per 3x3 layer: the extra moves cost more than the latency they hide.)
+    // Operands RING - 1 steps ahead of the MFMAs in a ring of RING register sets with STATIC roles (the loop is unrolled RING
+    // times): one step of NT MFMAs is ~0.27 us per wave, and every step touches lines nobody has read yet (2 new pixels of x per
+    // tap row, 2 of d[f|m]) — an HBM round trip of ~2 us sits in front of every step's in-order vmcnt.  (A ring rotated
+    // through register moves was measured: two steps ahead 290 us per 3x3 layer, four steps ahead 373 — the moves cost more
+    // than the latency they hid.)
+    constexpr int RING = NT >= 8 ? 5 : 6;
     const long long total_steps = (long long)(y_end - y_begin) * n_pairs;
-    float a0[NT], a1[NT], a2[NT], b0, b1, b2;
-    fetch(a0, b0);
-    fetch(a1, b1);
-    for (long long step = 0; step < total_steps; ++step) {
-        fetch(a2, b2);
+    float a[RING][NT], b[RING];
 #pragma unroll
-        for (int t = 0; t < NT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[t], b0, acc[t], 0, 0, 0);
+    for (int r = 0; r + 1 < RING; ++r) fetch(a[r], b[r]);
+    long long step = 0;
+    for (; step + RING <= total_steps; step += RING) {
 #pragma unroll
-        for (int t = 0; t < NT; ++t) {
-            a0[t] = a1[t];
-            a1[t] = a2[t];
+        for (int r = 0; r < RING; ++r) {
+            fetch(a[(r + RING - 1) % RING], b[(r + RING - 1) % RING]);
+#pragma unroll
+            for (int t = 0; t < NT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[r][t], b[r], acc[t], 0, 0, 0);
         }
-        b0 = b1;
-        b1 = b2;
     }
+    // tail: at most RING - 1 steps left, already fetched (fetch() returns zeros past the end)
+#pragma unroll
+    for (int r = 0; r + 1 < RING; ++r)
+#pragma unroll
+        for (int t = 0; t < NT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[r][t], b[r], acc[t], 0, 0, 0);
     // D[i][j] sits in lane (j + 32 * ((i >> 2) & 1)), register (i & 3) + 4 * (i >> 3): row i = ci, column j = co'
     float *dst = partial + (((long long)blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x) * (NT * 1024);
 #pragma unroll
