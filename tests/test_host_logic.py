@@ -47,6 +47,40 @@ def test_unet_state_dict_names_and_blob():
         UNet(num_input_channels=3)
 
 
+def test_aff_weight_blocks_in_the_packed_blob():
+    """read_unet_pack_host appends, after the 104 layers, the weight blocks of the split AFF plan (csrc/unet.cpp DerivedInfo):
+    columns [ci0, ci0 + cin) of the AFF first convs' (cout, 480) matrices, output channels of the listed AFFs stacked, in the
+    usual 1x1 fragment order; the linear partial-sum layers carry zero biases."""
+    from read_amd import _lib
+    L = _lib.lib()
+    state = synthetic.make_unet_state(UNET_SPEC, 11)
+    packed = pack_state(state)
+    off = 0
+    for (path, cin, cout, k) in UNET_SPEC:                                 # the regular layers come first, in table order
+        off += L.read_conv_packed_floats(cin, cout, k) + L.read_conv_param_floats(cout)
+        if k == 3 and cin % 16 == 0 and not path.startswith("feat_extract.1") and not path.startswith("feat_extract.2") \
+                and not path.startswith("feat_extract.6"):
+            off += L.read_conv_wino_floats(cin, cout)                      # 3x3 / stride-1 layers carry G g G^T as well
+    derived = [("AFFq3", 224, 256, (0, 1, 2)), ("AFFq2", 96, 128, (0, 1)), ("AFFq1", 32, 64, (0,)),
+               ("AFFs.0.conv.0r", 0, 32, (0,)), ("AFFs.1.conv.0r", 0, 96, (1,)), ("AFFs.2.conv.0r", 0, 224, (2,))]
+    rng = np.random.default_rng(5)
+    for name, ci0, cin, affs in derived:
+        wf = np.concatenate([np.asarray(state[f"AFFs.{a}.conv.0.block.conv_f.weight"])[:, ci0:ci0 + cin, 0, 0] for a in affs])
+        wm = np.concatenate([np.asarray(state[f"AFFs.{a}.conv.0.block.conv_m.weight"])[:, ci0:ci0 + cin, 0, 0] for a in affs])
+        cout = wf.shape[0]
+        n = L.read_conv_packed_floats(cin, cout, 1)
+        blk = packed[off:off + n].reshape(cin // 8, (cout + 31) // 32 * 2, 64, 4)          # [k8 step][tile (f, m)][lane][4]
+        for _ in range(300):
+            s_, nt, lane, j = (int(rng.integers(0, d)) for d in blk.shape)
+            co, ci = (nt // 2) * 32 + lane % 32, 8 * s_ + 4 * (lane // 32) + j
+            want = (wm if nt % 2 else wf)[co, ci] if co < cout else 0.0
+            assert blk[s_, nt, lane, j] == want, (name, s_, nt, lane, j)
+        par = packed[off + n:off + n + L.read_conv_param_floats(cout)].reshape(4, -1)
+        assert not par[0].any() and not par[1].any()                         # zero biases (the gated finals use their AFF's own block)
+        off += n + L.read_conv_param_floats(cout)
+    assert off == L.read_unet_packed_floats()
+
+
 def test_input_format_tokens(golden_dir):
     """The whole DSL against the reference's own parse_input_string (tests/golden/make_tokens_golden.py executes its
     source text): every key and value equal."""
