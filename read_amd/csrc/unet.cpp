@@ -2,7 +2,7 @@
 //
 // The network is fixed by the reference (get_net(): UNet(8, 3, feature_scale=4, num_res=4),
 // READ/pipelines/ogl.py:19-27; base_channel 32, unet.py:141), so the plan is built once per
-// resolution: 99 fused gated-conv launches + 3 bilinear x4 upsamples, every torch.cat /
+// resolution: 99 fused gated-conv launches (+ 3 for the AFF inputs of coarser levels) + 3 bilinear x4 upsamples, every torch.cat /
 // F.interpolate(nearest) / FAM multiply / residual add folded into a conv's loader or epilogue.
 // Activations are NHWC fp32 in a caller-provided workspace; one C-ABI call enqueues a frame.
 #include <math.h>
