@@ -12,6 +12,12 @@ scaling: K frames per GPU); rank 0 builds the scene once and broadcasts it over 
 exchanged over RCCL — the only exchange the path has (§8e; read_amd/sweep.py is the one implementation of
 that loop).  Rank 0 prints ONE JSON line.
 
+Throughput mode (default --frames-in-flight 2, FrameRenderer(frames_in_flight=2)): the rasteriser + gather of the sweep run
+on one stream in pose order, the UNet of consecutive poses on two streams with their own plans — the workgroups of one
+frame's layer fill the CUs that the last, partly filled round of the other frame's layer leaves idle (a layer's units
+rarely divide by the 512 persistent workgroups).  Every frame is still rendered completely inside the timed region;
+--frames-in-flight 1 is the latency mode (one frame at a time).
+
 After the timed loop rank 0 re-renders pose 0 through the SAME warm renderer and compares it with the CPU
 oracle's frame (which the cpu_baseline leg computes anyway): raster index/depth bit-exact on all five levels,
 RGB PSNR / max|diff| — "verified" in the JSON line; a mismatch exits non-zero.
@@ -54,6 +60,8 @@ def parse():
     p.add_argument("--warmup", type=int, default=3)
     p.add_argument("--config", choices=("slab30m", "kitti6_like", "train"), default="slab30m")
     p.add_argument("--points", type=int, default=0, help="override the cloud size of the config")
+    p.add_argument("--frames-in-flight", type=int, default=2,
+                   help="UNet plans / streams the frames of the sweep rotate through (FrameRenderer(frames_in_flight=...))")
     p.add_argument("--exchange", choices=("all", "root", "none"), default="all",
                    help="N>1: all-gather finished frames to every rank / gather to rank 0 / keep them local")
     p.add_argument("--no-cpu-baseline", action="store_true", help="skip the CPU leg (then nothing is verified)")
@@ -117,7 +125,9 @@ class SlabWorkload:
                     torch.from_numpy(build_cells(self.xyz))]
         xyz_d, desc_d, packed_d, cells_d = sweep.broadcast_scene_from_rank0(make, dev)
         self.proj = synthetic.make_proj(self.W, self.H)
-        self.fr = FrameRenderer(xyz_d, desc_d, packed_d, self.W, self.H, proj_matrix=self.proj, device=dev, cells=cells_d)
+        self.fr = FrameRenderer(xyz_d, desc_d, packed_d, self.W, self.H, proj_matrix=self.proj, device=dev, cells=cells_d,
+                                frames_in_flight=a.frames_in_flight)
+        self.exchanging = False                      # set by main(): frames leave the GPU, so the caller's stream must see them
         del desc_d
         self.total = [camera.total_matrix(self.proj, synthetic.sweep_pose(k)) for k in range(N_POSES)]
         self.describe = (f"BASELINE configs[2]: synthetic {N}-point KITTI-like slab, 1216x352, 8-dim descriptors, "
@@ -125,8 +135,21 @@ class SlabWorkload:
 
     def render_into(self, k, out):
         self.fr.render_total(self.total[k], out=out)
+        if self.exchanging and self.fr.frame_done is not None:
+            torch.cuda.current_stream().wait_event(self.fr.frame_done)
+
+    def timed_frame(self, k):
+        """Pose k through render_into() — the call the timed loop makes — preceded by its sweep predecessor so that both
+        pipeline slots have been in flight; -> (index pyramid, depth pyramid, RGBA frame) of pose k."""
+        bufs = [torch.empty((self.H, self.W, 4), dtype=torch.float32, device=self.fr.device) for _ in range(2)]
+        self.render_into((k - 1) % N_POSES, bufs[0])
+        self.render_into(k, bufs[1])
+        self.fr.sync()
+        torch.cuda.synchronize()
+        return self.fr.idx, self.fr.depth, bufs[1]
 
     def rasterize(self, k):
+        self.fr.sync()
         self.fr.rasterize(self.total[k])
         return self.fr.idx, self.fr.depth
 
@@ -407,9 +430,14 @@ def verify(wl, first):
     """Pose 0 through the warm renderer against the oracle's pose-0 frame."""
     from oracle import unet_torch
     idx_o, dep_o, rgb_o = first
-    idx, depth = wl.rasterize(0)
-    wl.gather()
-    rgba = wl.refine()
+    if hasattr(wl, "timed_frame"):
+        # the frame comes out of the SAME call the timed loop makes (with frames in flight: two poses through the pipelined
+        # path, the second one is compared), the index / depth pyramids are what that call's rasteriser left behind
+        idx, depth, rgba = wl.timed_frame(0)
+    else:
+        idx, depth = wl.rasterize(0)
+        wl.gather()
+        rgba = wl.refine()
     torch.cuda.synchronize()
     exact = True
     for l in range(5):
@@ -448,6 +476,7 @@ def main():
     wl = (SlabWorkload if a.config == "slab30m" else Kitti6LikeWorkload)(a, dev, rank)
     W, H, N = wl.W, wl.H, wl.N
     ex = sweep.FrameExchange((H, W, 4), dev, torch.float32, None if a.exchange == "none" else a.exchange)
+    wl.exchanging = ex.mode is not None
 
     sweep.run_steps(wl.render_into, ex, 0, a.warmup, N_POSES)
     ex.drain()
@@ -504,7 +533,8 @@ def main():
             "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": 1e3 * dt / a.steps,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": wl.describe, "points": N, "width": W, "height": H,
-                       "parallelism": f"pose-sharded x{world}", "frame_exchange": ex.mode or "none"},
+                       "parallelism": f"pose-sharded x{world}", "frame_exchange": ex.mode or "none",
+                       "frames_in_flight": a.frames_in_flight},
             "roofline": {
                 "kernel": ("gated_conv_wino_kernel: 3x3/s1 C->C gated conv, Winograd F(2x2,3x3) on v_mfma_f32_32x32x2_f32"
                            if n_wino else "gated_conv_kernel 3x3/s1 C->C (v_mfma_f32_32x32x2_f32)"), "bound": "mfma",

@@ -18,10 +18,17 @@ LEVELS = 5          # the reference rasterises and gathers 5 scales; the UNet co
 
 
 class FrameRenderer:
-    def __init__(self, xyz, texture_cn, unet_state, W, H, proj_matrix=None, device=None, levels=LEVELS, cells=True):
+    def __init__(self, xyz, texture_cn, unet_state, W, H, proj_matrix=None, device=None, levels=LEVELS, cells=True,
+                 frames_in_flight=1):
         """xyz (N,3); texture_cn (C,N) descriptors (PointTexture.texture_[0]); unet_state: state dict (tensors or
         ndarrays) under the reference's names, or an already packed fp32 blob (1-D tensor, e.g. received from rank 0);
-        W,H multiples of 16; cells: see PointCloudRasterizer."""
+        W,H multiples of 16; cells: see PointCloudRasterizer.
+
+        frames_in_flight > 1 (throughput mode for pose sweeps): ``render_total`` rasterises and gathers on one stream, in
+        call order (the rasteriser warm-starts from the previous call), and runs the UNet of call i on stream i mod F with its
+        own plan and feature buffers — the launches of consecutive frames overlap, so the workgroups of one frame fill the
+        CUs that the last, partly filled round of the other frame's layer leaves idle.  The returned tensor is then
+        complete on ``frame_done`` (an event; ``sync()`` waits for everything), not on the caller's stream."""
         self.device = device if device is not None else _lib.require_gpu()
         if W % 16 or H % 16:
             raise ValueError(f"set width {16 * (W // 16)} / height {16 * (H // 16)}")    # READ/gl/nn.py:107-109
@@ -44,6 +51,16 @@ class FrameRenderer:
         self.feat = [torch.empty((1, h, w, self.rows.shape[1]), dtype=torch.float32, device=self.device)
                      for (w, h) in sizes]
         self.rgba = torch.empty((H, W, 4), dtype=torch.float32, device=self.device)
+        self.frame_done = None
+        self._slots = []
+        self._calls = 0
+        if frames_in_flight > 1:
+            self._raster_stream = torch.cuda.Stream(self.device)
+            for _ in range(int(frames_in_flight)):
+                slot = {"feat": [torch.empty_like(f) for f in self.feat], "unet": UNetEngine(self.packed, H, W),
+                        "stream": torch.cuda.Stream(self.device), "ready": torch.cuda.Event(), "done": torch.cuda.Event()}
+                slot["done"].record(torch.cuda.current_stream(self.device))
+                self._slots.append(slot)
 
     def rasterize(self, total_m):
         return self.raster.render(total_m, self.W, self.H, self.levels, out=(self.idx, self.depth))
@@ -58,9 +75,36 @@ class FrameRenderer:
 
     def render_total(self, total_m, out=None, channels=4):
         """total_m = proj @ inv(view) (4x4 fp32) -> (H,W,channels) fp32 frame on the device."""
-        self.rasterize(total_m)
-        self.gather()
-        return self.refine(out, channels)
+        if not self._slots:
+            self.rasterize(total_m)
+            self.gather()
+            return self.refine(out, channels)
+        slot = self._slots[self._calls % len(self._slots)]
+        self._calls += 1
+        if out is None:
+            out = torch.empty((self.H, self.W, channels), dtype=torch.float32, device=self.device)
+        rs = self._raster_stream
+        with torch.cuda.stream(rs):
+            rs.wait_event(slot["done"])                  # this slot's features were last read by the frame F calls ago
+            self.rasterize(total_m)
+            gather_pyramid(self.rows, self.idx, out=slot["feat"])
+            slot["ready"].record(rs)
+        us = slot["stream"]
+        with torch.cuda.stream(us):
+            us.wait_event(slot["ready"])
+            f = slot["feat"]
+            slot["unet"].forward(f[0][0], f[1][0], f[2][0], f[3][0], out=out, channels=channels)
+            slot["done"].record(us)
+        out.record_stream(us)
+        self.frame_done = slot["done"]
+        return out
+
+    def sync(self):
+        """Wait (on the host) for every frame in flight."""
+        if self._slots:
+            self._raster_stream.synchronize()
+            for slot in self._slots:
+                slot["stream"].synchronize()
 
     def render(self, view_matrix, proj_matrix=None, out=None, channels=4):
         """view_matrix: camera->world 4x4 (the reference's convention); -> H x W x 4 RGBA (alpha = 1)."""
