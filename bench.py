@@ -127,7 +127,6 @@ class SlabWorkload:
         self.proj = synthetic.make_proj(self.W, self.H)
         self.fr = FrameRenderer(xyz_d, desc_d, packed_d, self.W, self.H, proj_matrix=self.proj, device=dev, cells=cells_d,
                                 frames_in_flight=a.frames_in_flight)
-        self.exchanging = False                      # set by main(): frames leave the GPU, so the caller's stream must see them
         del desc_d
         self.total = [camera.total_matrix(self.proj, synthetic.sweep_pose(k)) for k in range(N_POSES)]
         self.describe = (f"BASELINE configs[2]: synthetic {N}-point KITTI-like slab, 1216x352, 8-dim descriptors, "
@@ -135,8 +134,7 @@ class SlabWorkload:
 
     def render_into(self, k, out):
         self.fr.render_total(self.total[k], out=out)
-        if self.exchanging and self.fr.frame_done is not None:
-            torch.cuda.current_stream().wait_event(self.fr.frame_done)
+        return self.fr.frame_done                  # None (one frame at a time) or the event of this frame's UNet stream
 
     def timed_frame(self, k):
         """Pose k through render_into() — the call the timed loop makes — preceded by its sweep predecessor so that both
@@ -476,7 +474,6 @@ def main():
     wl = (SlabWorkload if a.config == "slab30m" else Kitti6LikeWorkload)(a, dev, rank)
     W, H, N = wl.W, wl.H, wl.N
     ex = sweep.FrameExchange((H, W, 4), dev, torch.float32, None if a.exchange == "none" else a.exchange)
-    wl.exchanging = ex.mode is not None
 
     sweep.run_steps(wl.render_into, ex, 0, a.warmup, N_POSES)
     ex.drain()

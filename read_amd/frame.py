@@ -83,6 +83,9 @@ class FrameRenderer:
         self._calls += 1
         if out is None:
             out = torch.empty((self.H, self.W, channels), dtype=torch.float32, device=self.device)
+        # whatever the caller's stream has waited for (e.g. the exchange that last read `out`) the writer waits for too
+        entered = torch.cuda.Event()
+        entered.record(torch.cuda.current_stream(self.device))
         rs = self._raster_stream
         with torch.cuda.stream(rs):
             rs.wait_event(slot["done"])                  # this slot's features were last read by the frame F calls ago
@@ -92,6 +95,7 @@ class FrameRenderer:
         us = slot["stream"]
         with torch.cuda.stream(us):
             us.wait_event(slot["ready"])
+            us.wait_event(entered)
             f = slot["feat"]
             slot["unet"].forward(f[0][0], f[1][0], f[2][0], f[3][0], out=out, channels=channels)
             slot["done"].record(us)

@@ -53,12 +53,16 @@ class FrameExchange:
          'root'  only rank 0 receives them (gather): the viewer process displays, the others only render
          None    no exchange (frames stay where they were rendered)"""
 
-    def __init__(self, frame_shape, device, dtype=torch.float32, mode='all'):
+    def __init__(self, frame_shape, device, dtype=torch.float32, mode='all', force=False):
         if mode not in ('all', 'root', None):
             raise ValueError(mode)
-        self.world = dist.get_world_size() if _dist_on() else 1
-        self.rank = dist.get_rank() if _dist_on() else 0
-        self.mode = mode if self.world > 1 else None
+        on = _dist_on() or (force and dist.is_available() and dist.is_initialized())     # force: exchange even at world size 1
+        self.world = dist.get_world_size() if on else 1
+        self.rank = dist.get_rank() if on else 0
+        self.mode = mode if on else None
+        # device frames: the collectives are issued from a stream of their own, after the event that says the frame is
+        # complete — the caller's stream never waits for a frame, so a renderer with several frames in flight keeps them in flight
+        self.comm = torch.cuda.Stream(device) if (self.mode is not None and torch.device(device).type == 'cuda') else None
         self.send = [torch.zeros(tuple(frame_shape), dtype=dtype, device=device) for _ in range(2)]
         self.recv = [None, None]
         if self.mode == 'all' or (self.mode == 'root' and self.rank == 0):
@@ -73,13 +77,26 @@ class FrameExchange:
             self.pending[j] = None
         return self.send[j]
 
-    def post(self, i):
+    def post(self, i, done=None):
+        """Start the exchange of step i's frame.  done: event after which the frame is complete (a renderer that writes it
+        on a stream of its own); None = complete in the current stream's order."""
         j = i & 1
+        if self.mode is None:
+            return
+        if self.comm is not None:
+            self.comm.wait_stream(torch.cuda.current_stream(self.send[j].device))
+            if done is not None:
+                self.comm.wait_event(done)
+            with torch.cuda.stream(self.comm):
+                self.pending[j] = self._collective(j)
+        else:
+            self.pending[j] = self._collective(j)
+
+    def _collective(self, j):
         if self.mode == 'all':
-            self.pending[j] = dist.all_gather_into_tensor(self.recv[j], self.send[j][None], async_op=True)
-        elif self.mode == 'root':
-            out = list(self.recv[j].unbind(0)) if self.rank == 0 else None
-            self.pending[j] = dist.gather(self.send[j], out, dst=0, async_op=True)
+            return dist.all_gather_into_tensor(self.recv[j], self.send[j][None], async_op=True)
+        out = list(self.recv[j].unbind(0)) if self.rank == 0 else None
+        return dist.gather(self.send[j], out, dst=0, async_op=True)
 
     def frames(self, i):
         """(world, *frame_shape) frames of step i in rank order once its exchange has completed (None where not received)."""
@@ -100,12 +117,13 @@ class FrameExchange:
 
 def run_steps(render_into, exchange, first, count, n_poses):
     """Steps first .. first+count-1 of the sweep on this rank: step i renders pose ``(i * world + rank) % n_poses`` into
-    the exchange's buffer and posts the exchange.  ``render_into(pose_index, out_tensor)``."""
+    the exchange's buffer and posts the exchange.  ``render_into(pose_index, out_tensor)`` returns None, or the event that
+    marks the frame complete when the renderer writes it on its own stream (FrameRenderer(frames_in_flight=2))."""
     world, rank = exchange.world, exchange.rank
     for i in range(first, first + count):
         out = exchange.buffer(i)
-        render_into((i * world + rank) % n_poses, out)
-        exchange.post(i)
+        done = render_into((i * world + rank) % n_poses, out)      # an event if the frame completes on another stream
+        exchange.post(i, done)
 
 
 def render_sweep(render_fn, n_poses, frame_shape, device, dtype=torch.float32, gather=True):

@@ -139,6 +139,50 @@ def test_frames_in_flight_equal_sequential_frames(hip):
         assert torch.equal(g, w), f"pipelined frame {i} differs"
 
 
+def test_pipelined_frames_through_the_rccl_exchange(hip):
+    """The loop bench.py times at N > 1 — sweep.run_steps with a FrameExchange — on ONE GPU: a single-rank RCCL group with
+    the exchange forced on, FrameRenderer(frames_in_flight=2) writing the exchange's send buffers from its UNet streams and
+    handing the completion events to post().  Frames coming out of the all-gather must equal the one-at-a-time frames."""
+    import socket
+    import torch.distributed as dist
+    from read_amd import sweep
+    W, H = 256, 128
+    N = 200_000
+    xyz, desc = synthetic.make_cloud(N, 8), synthetic.make_descriptors(N)
+    state = synthetic.make_unet_state(UNET_SPEC, 4)
+    proj = synthetic.make_proj(W, H, f=200.0)
+    seq = FrameRenderer(xyz, desc, state, W, H, proj_matrix=proj)
+    pipe = FrameRenderer(xyz, desc, state, W, H, proj_matrix=proj, frames_in_flight=2)
+    n = 7
+    total = [camera.total_matrix(proj, synthetic.sweep_pose(k)) for k in range(n)]
+    want = [seq.render_total(total[k]).clone() for k in range(n)]
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    dist.init_process_group("nccl", init_method=f"tcp://127.0.0.1:{port}", rank=0, world_size=1,
+                            device_id=torch.device("cuda", 0))
+    try:
+        ex = sweep.FrameExchange((H, W, 4), torch.device("cuda", 0), torch.float32, 'all', force=True)
+        assert ex.mode == 'all' and ex.world == 1
+
+        def render_into(k, out):
+            pipe.render_total(total[k], out=out)
+            return pipe.frame_done
+
+        got = []
+        for i in range(n):
+            sweep.run_steps(render_into, ex, i, 1, n)
+            if i > 0:
+                got.append(ex.frames(i - 1)[0].clone())
+        got.append(ex.frames(n - 1)[0].clone())
+        ex.drain()
+        torch.cuda.synchronize()
+    finally:
+        dist.destroy_process_group()
+    for i, (g, w) in enumerate(zip(got, want)):
+        assert torch.equal(g, w), f"exchanged frame {i} differs"
+
+
 def test_winograd_and_direct_conv_paths_agree(hip):
     """The automatic plan runs the 3x3/s1 layers through the Winograd F(2x2,3x3) kernel; with the knob off the
     same layers run the direct implicit-GEMM kernel.  Both must meet the tolerance against the oracle, and they
