@@ -1313,6 +1313,7 @@ int find_config(int ks, int s, int kc, int P, int QG, int WM, int WN, int PF, in
 }
 
 int g_prefer_wave = 1;   // read_tuning_set("conv_wave", 0): workgroup-tiled kernels only
+int g_wino_wgs = 2;        // read_tuning_set("conv_wino_wgs", 1): one persistent Winograd workgroup per CU (A/B with frames in flight)
 int g_conv_px = 1;         // read_tuning_set("conv_px", v): pixel-lane kernel for 1x1 layers — 0 off; 1 / 2 where it measured faster
                            // (64 / 128 accumulator registers per wave); 3 / 4 every layer it fits
 int g_kc32 = 1;            // 32-channel chunks for 1x1 layers whose sources are all multiples of 32 (read_tuning_set("conv_kc32", 0): 16)
@@ -1509,6 +1510,7 @@ void conv_set_stagger(int ticks) { g_stagger_ticks = ticks < 0 ? 0 : ticks; }
 void conv_set_ablate(int bits) { g_ablate = bits; }
 void conv_set_wino(int max_cin) { g_use_wino = max_cin; }
 void conv_set_kc32(int v) { g_kc32 = v; }
+void conv_set_wino_wgs(int v) { g_wino_wgs = v <= 1 ? 1 : 2; }
 void conv_set_px(int v) { g_conv_px = v < 0 ? 0 : v > 4 ? 4 : v; }
 int conv_get(const char *key, int *value)
 {
@@ -1516,6 +1518,7 @@ int conv_get(const char *key, int *value)
     else if (!strcmp(key, "conv_stagger")) *value = g_stagger_ticks;
     else if (!strcmp(key, "conv_kc32")) *value = g_kc32;
     else if (!strcmp(key, "conv_px")) *value = g_conv_px;
+    else if (!strcmp(key, "conv_wino_wgs")) *value = g_wino_wgs;
     else if (!strcmp(key, "conv_wino")) *value = g_use_wino;
 #ifdef READ_DEBUG_KNOBS
     else if (!strcmp(key, "conv_ablate")) *value = g_ablate;
@@ -1730,7 +1733,7 @@ int launch_gated_conv(const read_conv_desc *d, hipStream_t stream)
             n_cu_w = (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess &&
                       prop.multiProcessorCount > 0) ? prop.multiProcessorCount : 256;
         }
-        int nwg = a.n_units < 2 * n_cu_w ? a.n_units : 2 * n_cu_w;    // persistent: two workgroups per CU
+        int nwg = a.n_units < g_wino_wgs * n_cu_w ? a.n_units : g_wino_wgs * n_cu_w;    // persistent: two workgroups per CU
         nwg -= nwg % groups;                                          // keeps the group fixed per workgroup
         if (nwg < groups) nwg = groups;
         grid = dim3((unsigned)nwg, 1);
