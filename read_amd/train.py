@@ -65,6 +65,29 @@ _PACK_CACHE = {}
 USE_WINOGRAD = True          # 3x3 / stride-1 layers with cin % 16 == 0: forward pre-activations and dgrad through the Winograd kernel
 
 
+WGRAD_SIDE_STREAM = True     # weight gradients on a side stream, joined at the end of the backward pass
+_SIDE = {}                   # device -> [stream, join queued for the running backward pass]
+
+
+def _side_stream(dev):
+    e = _SIDE.get(dev)
+    if e is None:
+        e = _SIDE[dev] = [torch.cuda.Stream(dev), False]
+    return e[0]
+
+
+def _queue_join(dev):
+    e = _SIDE[dev]
+    if e[1]:
+        return
+    e[1] = True
+
+    def join():
+        e[1] = False
+        torch.cuda.current_stream(dev).wait_stream(e[0])
+    torch.autograd.Variable._execution_engine.queue_callback(join)
+
+
 _ZERO_PARAMS = {}
 
 
@@ -151,6 +174,10 @@ class GatedConvFn(torch.autograd.Function):
         sums = torch.empty((4, cout), dtype=torch.float32, device=dev)
         _lib.check(L.read_gate_backward(dy.data_ptr(), fm.data_ptr(), Ho * Wo, cout, params.data_ptr(), elu, dfm.data_ptr(),
                                         sums.data_ptr(), Wo, bh, vh, st))
+        ev_dfm = None
+        if WGRAD_SIDE_STREAM:
+            ev_dfm = torch.cuda.Event()
+            ev_dfm.record(torch.cuda.current_stream(dev))              # d[f|m] (and everything before it) is complete here
         dbf, dbm, dgamma, dbeta = torch.zeros((4, cout), dtype=torch.float32, device=dev).unbind(0)     # one fill, four rows
         _lib.check(L.read_bn_param_grads(cout, sums.data_ptr(), mean.data_ptr(), var.data_ptr(), BN_EPS, dbf.data_ptr(),
                                          dbm.data_ptr(), dgamma.data_ptr(), dbeta.data_ptr(), st))
@@ -194,8 +221,21 @@ class GatedConvFn(torch.autograd.Function):
         dwf, dwm = torch.empty_like(wf), torch.empty_like(wm)
         n_scr = L.read_conv_wgrad_scratch_floats(cin, cout, k, Ho)
         scratch = torch.empty(n_scr, dtype=torch.float32, device=dev)
-        _lib.check(L.read_conv_wgrad(x.data_ptr(), H, W, cin, dfm.data_ptr(), cout, k, stride, dwf.data_ptr(), dwm.data_ptr(), 0,
-                                     scratch.data_ptr(), n_scr, st))
+        if WGRAD_SIDE_STREAM:
+            # nothing downstream of this layer needs its weight gradient before the optimizer step, so it is computed on a
+            # side stream while the main stream goes on with the dgrad chain of the layers below; the end of the backward
+            # pass joins the streams (_join_side_stream, queued once per pass on the autograd engine)
+            main, side = torch.cuda.current_stream(dev), _side_stream(dev)
+            side.wait_event(ev_dfm)
+            with torch.cuda.stream(side):
+                _lib.check(L.read_conv_wgrad(x.data_ptr(), H, W, cin, dfm.data_ptr(), cout, k, stride, dwf.data_ptr(), dwm.data_ptr(),
+                                             0, scratch.data_ptr(), n_scr, _lib.stream_ptr()))
+            for t in (x, dfm, dwf, dwm, scratch):
+                t.record_stream(side)
+            _queue_join(dev)
+        else:
+            _lib.check(L.read_conv_wgrad(x.data_ptr(), H, W, cin, dfm.data_ptr(), cout, k, stride, dwf.data_ptr(), dwm.data_ptr(), 0,
+                                         scratch.data_ptr(), n_scr, st))
         return dx, dwf, dbf, dwm, dbm, dgamma, dbeta, None, None, None, None, None, None, None, None
 
 
