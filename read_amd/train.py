@@ -147,6 +147,9 @@ class GatedConvFn(torch.autograd.Function):
         entry = _packed_for(wf, bf, wm, bm, gamma, beta, mean, var, cin, cout, k)
         params, wp = entry[1], entry[2]
         ctx.pack = entry
+        side = _SIDE.get(dev)
+        if side is not None:
+            side[1] = False          # a backward pass that died before its join callback ran must not mute the next one's
         fm = torch.empty((Ho, Wo, 2 * cout), dtype=torch.float32, device=dev)
         y = torch.empty((Ho, Wo, cout), dtype=torch.float32, device=dev)
         # a batch is one tall image of nb stacked items; separator rows (block geometry at THIS layer's output scale) stay zero
