@@ -130,6 +130,23 @@ def _packed_for(wf, bf, wm, bm, gamma, beta, mean, var, cin, cout, k):
     return entry
 
 
+def _pack_dgrad(entry, wf, wm, cin, cout, k):
+    """Flipped / transposed fragments of the layer for its dgrad (direct and, for 3x3, Winograd) on the current stream."""
+    L = _lib.lib()
+    st = _lib.stream_ptr()
+    dev = wf.device
+    wf_c, wm_c = wf.detach().contiguous(), wm.detach().contiguous()
+    wd = torch.empty(L.read_conv_dgrad_packed_floats(cin, cout, k), dtype=torch.float32, device=dev)
+    _lib.check(L.read_conv_pack_dgrad_device(cin, cout, k, 16, wf_c.data_ptr(), wm_c.data_ptr(), wd.data_ptr(), st))
+    wdw = None
+    if k == 3 and USE_WINOGRAD:                                      # the virtual input has 2 * cp channels: always % 16
+        wdw = torch.empty(L.read_conv_dgrad_wino_floats(cin, cout), dtype=torch.float32, device=dev)
+        _lib.check(L.read_conv_pack_dgrad_wino_device(cin, cout, wf_c.data_ptr(), wm_c.data_ptr(), wdw.data_ptr(), st))
+    ev = torch.cuda.Event()
+    ev.record()
+    entry[3] = (wd, ev, wdw)
+
+
 class GatedConvFn(torch.autograd.Function):
     """y = BN_eval(act(conv_f(x) + b_f) * sigmoid(conv_m(x) + b_m)) for ONE image, x (H,W,Cin) NHWC -> (Ho,Wo,Cout)."""
 
@@ -198,23 +215,13 @@ class GatedConvFn(torch.autograd.Function):
                 if dilated:
                     d_in = torch.zeros((H, W, 2 * cp), dtype=torch.float32, device=dev)
                     d_in[::2, ::2] = dfm
-                wd = ctx.pack[3]
-                if wd is None:
-                    wd = torch.empty(L.read_conv_dgrad_packed_floats(cin, cout, k), dtype=torch.float32, device=dev)
-                    _lib.check(L.read_conv_pack_dgrad_device(cin, cout, k, 16, wf.data_ptr(), wm.data_ptr(), wd.data_ptr(), st))
-                    wdw = None
-                    if k == 3 and USE_WINOGRAD:                      # the virtual input has 2 * cp channels: always % 16
-                        wdw = torch.empty(L.read_conv_dgrad_wino_floats(cin, cout), dtype=torch.float32, device=dev)
-                        _lib.check(L.read_conv_pack_dgrad_wino_device(cin, cout, wf.data_ptr(), wm.data_ptr(), wdw.data_ptr(), st))
-                    ev = torch.cuda.Event()
-                    ev.record()
-                    ctx.pack[3] = (wd, ev, wdw)
-                else:
-                    wd, ev, wdw = wd
-                    torch.cuda.current_stream().wait_event(ev)
-                    wd.record_stream(torch.cuda.current_stream())
-                    if wdw is not None:
-                        wdw.record_stream(torch.cuda.current_stream())
+                if ctx.pack[3] is None:
+                    _pack_dgrad(ctx.pack, wf, wm, cin, cout, k)
+                wd, ev, wdw = ctx.pack[3]
+                torch.cuda.current_stream().wait_event(ev)
+                wd.record_stream(torch.cuda.current_stream())
+                if wdw is not None:
+                    wdw.record_stream(torch.cuda.current_stream())
                 zero = _zero_params(L.read_conv_param_floats(cin // 2), dev)
                 _linear_conv(d_in, 2 * cp, wd, zero, cin // 2, k, 1, dx, wino=wdw)
             else:
