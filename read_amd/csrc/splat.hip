@@ -331,9 +331,11 @@ __global__ __launch_bounds__(256) void splat_seed_kernel(const float *__restrict
 //                        the rest -> list B with its screen rectangle and depth threshold.  A chunk is appended to the
 //                        list of the strip that holds the centre column of its rectangle (block-aggregated appends).
 //   cells_pass_kernel<A> workgroup b works on strip b % ns and walks that strip's list A statically: zimg early-z, LDS
-//                        table, then atomic min on the key + plain stores of the new bound and of the point's position
+//                        table for dense chunks, then the candidate goes to its screen tile's bin (emit_binned; or an atomic
+//                        min on the key with splat_bins = 0) + plain stores of the new bound and of the point's position
 //                        (next frame's seed).
-//   cells_hiz_kernel     far bound per 4x4 block from the (exact) key image; zimg := exact current depths.
+//   cells_merge_hiz_kernel  one workgroup per 32x32 tile: bins folded into the tile's keys in LDS, written back; far bound
+//                        per 4x4 block from the (now exact) keys; zimg := exact current depths.  (cells_hiz_kernel without bins.)
 //   cells_pass_kernel<B> same walk over list B: a chunk is skipped when its nearest possible depth is behind the bound
 //                        of EVERY block of its rectangle, otherwise its points run as in pass A.
 //   splat_resolve_kernel levels, keys back to EMPTY, zimg back to "no bound", counters to zero.
