@@ -174,6 +174,13 @@ int read_gather_backward(float *drows_nc, int64_t n, int C, int levels,
                          const int32_t *const *idx_levels, const int64_t *count_levels,
                          const float *const *dfeat_levels, void *stream);
 
+/* Bilinear down-scale by an integer factor ss (2..8) of `planes` NCHW planes [ss*h][ss*w] -> [h][w]: torch's
+ * F.interpolate(scale_factor = 1/ss, mode = 'bilinear', align_corners = False) as READ/models/compose.py:162-163 applies it to
+ * network inputs that mix non-uv tokens with texture samples (the all-uv case is fused into read_gather_forward_ss), and its
+ * adjoint (din is written, not accumulated). */
+int read_bilinear_down(const float *in, int64_t planes, int h, int w, int ss, float *out, void *stream);
+int read_bilinear_down_backward(const float *dout, int64_t planes, int h, int w, int ss, float *din, void *stream);
+
 /* ---------------------------------------------------------------- gated conv (BasicConv) */
 
 #define READ_CONV_MAX_SRC 4

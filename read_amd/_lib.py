@@ -67,6 +67,8 @@ SIGNATURES = {
     "read_gather_forward": (_i, [_vp, _i64, _i, _i, _pp, C.POINTER(_i64), _pp, _i, _vp]),
     "read_gather_forward_ss": (_i, [_vp, _i64, _i, _i, _i, _pp, C.POINTER(_i), C.POINTER(_i), _i, _pp, _i, _vp]),
     "read_gather_backward": (_i, [_vp, _i64, _i, _i, _pp, C.POINTER(_i64), _pp, _vp]),
+    "read_bilinear_down": (_i, [_vp, _i64, _i, _i, _i, _vp, _vp]),
+    "read_bilinear_down_backward": (_i, [_vp, _i64, _i, _i, _i, _vp, _vp]),
     "read_conv_packed_floats": (_sz, [_i, _i, _i]),
     "read_conv_param_floats": (_sz, [_i]),
     "read_conv_pack_weights_host": (_i, [_i, _i, _i, _i, _vp, _vp, _vp]),

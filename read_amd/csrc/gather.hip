@@ -120,6 +120,51 @@ __global__ __launch_bounds__(256) void gather_forward_ss_kernel(const float *__r
     }
 }
 
+// Bilinear down-scale by an integer factor of NCHW planes: torch's F.interpolate(scale_factor = 1 / ss, mode = 'bilinear',
+// align_corners = False) as READ/models/compose.py:162-163 applies it to the concatenated (non-uv extras + texture sample)
+// network inputs.  out[p][oy][ox] = blend of the 4 samples around ((o + 0.5) * ss - 0.5); lane = output pixel of a plane.
+__global__ __launch_bounds__(256) void bilinear_down_kernel(const float *__restrict__ in, long long planes, int h, int w, int ss,
+                                                            float *__restrict__ out)
+{
+    const long long total = planes * h * w;
+    const int sh = h * ss, sw = w * ss;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+        const int ox = (int)(i % w), oy = (int)((i / w) % h);
+        const long long p = i / ((long long)w * h);
+        const float sy = ((float)oy + 0.5f) * (float)ss - 0.5f, sx = ((float)ox + 0.5f) * (float)ss - 0.5f;
+        const int y0 = (int)sy, x0 = (int)sx;
+        const int y1 = y0 + (y0 < sh - 1 ? 1 : 0), x1 = x0 + (x0 < sw - 1 ? 1 : 0);
+        const float ly = sy - (float)y0, lx = sx - (float)x0, wy0 = 1.0f - ly, wx0 = 1.0f - lx;
+        const float *im = in + p * (long long)sh * sw;
+        out[i] = wy0 * (wx0 * im[(long long)y0 * sw + x0] + lx * im[(long long)y0 * sw + x1]) +
+                 ly * (wx0 * im[(long long)y1 * sw + x0] + lx * im[(long long)y1 * sw + x1]);
+    }
+}
+
+// Its adjoint.  For ss >= 2 the 2x2 footprints of different outputs are disjoint, so the gradient of an input sample comes
+// from at most one output: a gather, no atomics.  lane = input sample.
+__global__ __launch_bounds__(256) void bilinear_down_backward_kernel(const float *__restrict__ dout, long long planes, int h, int w,
+                                                                     int ss, float *__restrict__ din)
+{
+    const int sh = h * ss, sw = w * ss;
+    const long long total = planes * sh * sw;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+        const int x = (int)(i % sw), y = (int)((i / sw) % sh);
+        const long long p = i / ((long long)sw * sh);
+        const int oy = y / ss, ox = x / ss;
+        const float sy = ((float)oy + 0.5f) * (float)ss - 0.5f, sx = ((float)ox + 0.5f) * (float)ss - 0.5f;
+        const int y0 = (int)sy, x0 = (int)sx;
+        const int y1 = y0 + (y0 < sh - 1 ? 1 : 0), x1 = x0 + (x0 < sw - 1 ? 1 : 0);
+        const float ly = sy - (float)y0, lx = sx - (float)x0;
+        float wy = 0.0f, wx = 0.0f;
+        if (y == y0) wy += 1.0f - ly;
+        if (y == y1) wy += ly;
+        if (x == x0) wx += 1.0f - lx;
+        if (x == x1) wx += lx;
+        din[i] = wy * wx * dout[(p * h + oy) * w + ox];
+    }
+}
+
 struct LevelTableBwd {
     const int32_t *idx[READ_MAX_LEVELS];
     const float *dfeat[READ_MAX_LEVELS];
@@ -306,6 +351,30 @@ extern "C" int read_gather_backward(float *drows_nc, int64_t n, int C, int level
     if (blocks > 256 * 8) blocks = 256 * 8;
     hipLaunchKernelGGL(gather_backward_kernel, dim3((unsigned)blocks), dim3(256), 0, as_stream(stream), drows_nc,
                        (long long)n, C, tab);
+    READ_CHECK_LAUNCH();
+    return READ_OK;
+}
+
+extern "C" int read_bilinear_down(const float *in, int64_t planes, int h, int w, int ss, float *out, void *stream)
+{
+    READ_CHECK_ARG(in && out && planes >= 1 && h >= 1 && w >= 1, "read_bilinear_down: null pointer or empty tensor");
+    READ_CHECK_ARG(ss >= 2 && ss <= 8, "read_bilinear_down: the factor must be 2..8 (got %d)", ss);
+    int64_t blocks = ceil_div64(planes * h * w, 256);
+    if (blocks > 256 * 8) blocks = 256 * 8;
+    hipLaunchKernelGGL(bilinear_down_kernel, dim3((unsigned)blocks), dim3(256), 0, as_stream(stream), in, (long long)planes, h, w,
+                       ss, out);
+    READ_CHECK_LAUNCH();
+    return READ_OK;
+}
+
+extern "C" int read_bilinear_down_backward(const float *dout, int64_t planes, int h, int w, int ss, float *din, void *stream)
+{
+    READ_CHECK_ARG(dout && din && planes >= 1 && h >= 1 && w >= 1, "read_bilinear_down_backward: null pointer or empty tensor");
+    READ_CHECK_ARG(ss >= 2 && ss <= 8, "read_bilinear_down_backward: the factor must be 2..8 (got %d)", ss);
+    int64_t blocks = ceil_div64(planes * h * w * ss * ss, 256);
+    if (blocks > 256 * 8) blocks = 256 * 8;
+    hipLaunchKernelGGL(bilinear_down_backward_kernel, dim3((unsigned)blocks), dim3(256), 0, as_stream(stream), dout,
+                       (long long)planes, h, w, ss, din);
     READ_CHECK_LAUNCH();
     return READ_OK;
 }

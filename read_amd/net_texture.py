@@ -14,9 +14,7 @@ the UNet engine consumes without a copy.
 """
 import torch
 import torch.nn as nn
-import torch.nn.functional as F
-
-from .texture import gather_pyramid
+from .texture import _RangeCheck, bilinear_down, gather_pyramid
 
 
 def _as_id_list(ids):
@@ -39,7 +37,7 @@ class NetAndTexture(nn.Module):
                 textures = {0: textures}
         self._textures = {tid: tex.cpu() for tid, tex in textures.items()}
         self._loaded_textures = []
-
+        self._range_check = _RangeCheck()
 
     # ---- texture residency -------------------------------------------------------------------
     def load_textures(self, texture_ids):
@@ -52,6 +50,10 @@ class NetAndTexture(nn.Module):
         for tid in self._loaded_textures:
             self._modules.pop(str(tid)).cpu()
         self._loaded_textures = []
+
+    def check_ids(self):
+        """Block until every queued point-id range check has landed; raises IndexError if a lookup saw an id >= N."""
+        self._range_check.flush()
 
     def reg_loss(self):
         return sum((self._modules[str(tid)].reg_loss() for tid in self._loaded_textures), 0)
@@ -66,9 +68,10 @@ class NetAndTexture(nn.Module):
         needs_grad = torch.is_grad_enabled() and texture.texture_.requires_grad
         if only_uv and not needs_grad:
             ids = [texture._ids(item[t]).to(texture.texture_.device) for t in tokens]
-            if int(ids[0].max()) >= texture.texture_.shape[-1]:
-                raise IndexError(f"point id {int(ids[0].max())} out of range for a descriptor table of "
-                                 f"{texture.texture_.shape[-1]} points (wrong texture for this scene?)")
+            # out-of-range ids (wrong texture for this scene) raise IndexError without a device->host sync per frame:
+            # the check of THIS lookup is queued, the previous ones are polled (texture._RangeCheck); the gather clamps
+            self._range_check.poll()
+            self._range_check.queue(ids[0], texture.texture_.shape[-1])
             feats = gather_pyramid(texture.rows(), ids, texture.activation, ss=self.ss)     # ss > 1: fused bilinear reduce
             return [f.permute(0, 3, 1, 2) for f in feats]
         scales, extras = [], []
@@ -79,8 +82,8 @@ class NetAndTexture(nn.Module):
             else:
                 extras.insert(len(extras) - 1, item[t].to(texture.texture_.device))
         out = [torch.cat(parts, 1) if len(parts) > 1 else parts[0] for parts in scales]
-        if self.ss > 1:
-            out = [F.interpolate(x, scale_factor=1. / self.ss, mode='bilinear') for x in out]
+        if self.ss > 1:                         # compose.py:162-163, as a HIP node (differentiable)
+            out = [bilinear_down(x, self.ss) for x in out]
         return out
 
     def forward(self, inputs, **kwargs):

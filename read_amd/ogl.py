@@ -9,7 +9,7 @@ plan, no ToTensor / host copies (nn.py:115-117)."""
 import torch
 
 from . import _lib
-from .render import MultiscaleRender, parse_input_string
+from .render import MultiscaleRender, is_point_id_pyramid
 from .texture import gather_pyramid
 
 
@@ -55,13 +55,8 @@ class OGL:
         # the device-resident fast path of infer() serves exactly the layout TexturePipeline trains with: >= 4 tokens,
         # token i = 1-px point ids at downscale i; anything else goes through the checked dict path
         fmts = input_format.replace(' ', '').split(',')
-        try:
-            cfgs = [parse_input_string(t) for t in fmts]
-            self._fast_format = (len(cfgs) >= 4 and all(c['mode'] == 'uv_1d' and c['point_size'] == 1
-                                                        and not c['splat_mode'] and c.get('downscale', 0) == i
-                                                        for i, c in enumerate(cfgs)))
-        except (NotImplementedError, ValueError):
-            self._fast_format = False
+        self._fast_format = len(fmts) >= 4 and is_point_id_pyramid(input_format)
+        self.last_path = None                # 'fast' / 'dict': which branch the last infer() took (asserted by the tests)
 
     def infer(self, input_dict=None):
         """-> {'output': H x W x 4 float tensor (RGB + alpha 1), 'net_input': list of NCHW feature maps}."""
@@ -69,6 +64,7 @@ class OGL:
         texture = model._modules[str(model._loaded_textures[0])] if model._loaded_textures else model._modules['0']
         fast = (input_dict is None and not model.temporal_average and self._fast_format
                 and not self.renderer.scene.augmented() and hasattr(model.net, 'engine'))
+        self.last_path = 'fast' if fast else 'dict'
         with torch.set_grad_enabled(False):
             if fast:
                 scene = self.renderer.scene

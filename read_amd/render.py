@@ -67,7 +67,7 @@ def is_point_id_pyramid(input_format):
     cloud (pyramid identity)."""
     try:
         cfgs = [parse_input_string(t) for t in input_format.replace(' ', '').split(',')]
-    except ValueError:
+    except (ValueError, NotImplementedError):
         return False
     return all(c['mode'] == (MODE_UV, UV_TYPE_1D) and c['draw_points'] and c['point_size'] == 1 and not c['splat_mode']
                and c.get('downscale', 0) == i for i, c in enumerate(cfgs))
@@ -131,7 +131,13 @@ class Scene:
     per-point attributes the vertex shader reads, the discard / perturb augmentation buffers, the draw parameters
     ``set_params(**parse_input_string(token))`` sets."""
 
-    def __init__(self, xyz=None):
+    # the mode constants callers reach through the class (``NNScene.MODE_UV`` ..., READ/gl/programs.py:61-75)
+    MODE_COLOR, MODE_NORMALS, MODE_DEPTH, MODE_UV, MODE_XYZ, MODE_LABEL = (MODE_COLOR, MODE_NORMALS, MODE_DEPTH, MODE_UV,
+                                                                            MODE_XYZ, MODE_LABEL)
+    NORMALS_MODE_MODEL, NORMALS_MODE_REFLECTION, NORMALS_MODE_LOCAL, NORMALS_MODE_DIRECTION, NORMALS_MODE_RAW = 0, 1, 2, 3, 4
+    UV_TYPE_1D, UV_TYPE_2D = UV_TYPE_1D, UV_TYPE_2D
+
+    def __init__(self, xyz=None, flat_color=True):
         self.model_matrix = np.eye(4, dtype=np.float32)
         self.view_matrix = np.eye(4, dtype=np.float32)        # camera -> world
         self.proj_matrix = np.eye(4, dtype=np.float32)
@@ -200,6 +206,12 @@ class Scene:
         for k, v in kwargs.items():
             if k not in skip:
                 self.params[k] = v
+
+    def delete(self):
+        """NNScene.delete() (READ/gl/programs.py; DynamicDataset.unload, dynamic.py:181-183): drop the device copies."""
+        self._raster = None
+        self._dev = {}
+        self._dirty = True
 
     def augmented(self):
         return (self.point_discard is not None or self.point_perturb is not None or self.point_drop is not None

@@ -155,10 +155,17 @@ def write_ply(path, xyz, rgb=None, normals=None, fmt='binary_little_endian'):
 
 # ---------------------------------------------------------------------------------------------- model import
 def get_xyz_colors(xyz, r=8):
-    """READ/gl/utils.py:385-389."""
-    mmin, mmax = xyz.min(axis=0), xyz.max(axis=0)
-    color = (xyz - mmin) / (mmax - mmin)
-    return np.clip(color, 0., 1.).astype(np.float32)
+    """Position -> colour: every axis normalised to the cloud's bounding box (semantics of READ/gl/utils.py:385-389; ``r`` is
+    unused there too)."""
+    xyz = np.asarray(xyz)
+    lo = xyz.min(axis=0)
+    span = xyz.max(axis=0) - lo
+    return np.clip((xyz - lo) / span, 0., 1.).astype(np.float32)
+
+
+def get_normal_colors(normals):
+    """Unit normals [-1, 1] -> colours [0, 1] (READ/gl/utils.py:391-393)."""
+    return (0.5 * np.asarray(normals) + 0.5).astype(np.float32)
 
 
 def import_model3d(model_path, uv_order=None, is_mesh=False):
@@ -261,13 +268,9 @@ def extrinsics_from_xml(xml_file, verbose=False):
 
 
 def get_valid_matrices(mlist):
-    """READ/gl/utils.py:374-382."""
-    ilist, vmlist = [], []
-    for i, m in enumerate(mlist):
-        if np.isfinite(m).all():
-            ilist.append(i)
-            vmlist.append(m)
-    return vmlist, ilist
+    """-> (the matrices without NaN / inf entries, their positions in ``mlist``); contract of READ/gl/utils.py:374-382."""
+    keep = [i for i, m in enumerate(mlist) if bool(np.all(np.isfinite(m)))]
+    return [mlist[i] for i in keep], keep
 
 
 def extrinsics_from_view_matrix(path):
@@ -279,12 +282,12 @@ def extrinsics_from_view_matrix(path):
 
 
 def fix_relative_path(path, config_path):
-    """READ/gl/utils.py:365-371: a path that does not exist as given is tried relative to the scene file."""
-    if not os.path.exists(path) and not os.path.isabs(path):
-        abspath = os.path.join(os.path.dirname(config_path), path)
-        if os.path.exists(abspath):
-            return abspath
-    return path
+    """A relative path that does not resolve from the working directory is looked up next to the scene file; anything else
+    is returned unchanged (contract of READ/gl/utils.py:365-371)."""
+    if os.path.isabs(path) or os.path.exists(path):
+        return path
+    beside = os.path.join(os.path.dirname(config_path), path)
+    return beside if os.path.exists(beside) else path
 
 
 def load_scene_data(path):
@@ -353,3 +356,30 @@ def load_scene(config_path):
     scene = Scene()
     setup_scene(scene, scene_data)
     return scene, scene_data
+
+
+
+# ---------------------------------------------------------------------------------------------- small host-side helpers
+class FastRand:
+    """A bank of ``bank_size`` pre-drawn random arrays ``tform(rand(*shape))``; ``toss()`` hands out one of them (interface of
+    READ/gl/utils.py:40-52 — DynamicDataset draws its per-sample point perturbation from it, dynamic.py:176-179,238-239)."""
+
+    def __init__(self, shape, tform, bank_size):
+        self.bank = [tform(np.random.rand(*shape)) for _ in range(bank_size)]
+
+    def toss(self):
+        return self.bank[np.random.randint(0, len(self.bank))]
+
+
+def crop_proj_matrix(pm, old_w, old_h, new_w, new_h):
+    """Projection matrix of a centred crop / resize of the viewport, term by term as READ/gl/utils.py:94-106 (which notes
+    itself that it is approximate; its [1,2] entry is derived from pm[0,2], kept)."""
+    out = np.array(pm, copy=True)
+    rx, ry = old_w / new_w, old_h / new_h
+    ccx = (new_w / 2) / (old_w / 2)
+    ccy = (new_h / 2) / (old_h / 2)
+    out[0, 0] = pm[0, 0] * rx
+    out[0, 2] = (pm[0, 2] - 1) * rx * ccx + 1
+    out[1, 1] = pm[1, 1] * ry
+    out[1, 2] = (pm[0, 2] + 1) * ry * ccy - 1
+    return out

@@ -73,6 +73,73 @@ def scatter_pyramid(dfeat_levels, idx_levels, n):
     return drows
 
 
+class _BilinearDownFn(torch.autograd.Function):
+    """(B,C,ss*h,ss*w) -> (B,C,h,w): F.interpolate(scale_factor=1/ss, mode='bilinear') (READ/models/compose.py:162-163)."""
+
+    @staticmethod
+    def forward(ctx, x, ss):
+        x = x.contiguous()
+        B, c, H, W = (int(v) for v in x.shape)
+        if H % ss or W % ss:
+            raise ValueError(f"input {W}x{H} is not a multiple of supersampling {ss}")
+        out = torch.empty((B, c, H // ss, W // ss), dtype=torch.float32, device=x.device)
+        _lib.check(_lib.lib().read_bilinear_down(x.data_ptr(), B * c, H // ss, W // ss, int(ss), out.data_ptr(), _lib.stream_ptr()),
+                   "read_bilinear_down")
+        ctx.cfg = (B, c, H, W, int(ss))
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        B, c, H, W, ss = ctx.cfg
+        g = g.contiguous()
+        din = torch.empty((B, c, H, W), dtype=torch.float32, device=g.device)
+        _lib.check(_lib.lib().read_bilinear_down_backward(g.data_ptr(), B * c, H // ss, W // ss, ss, din.data_ptr(),
+                                                          _lib.stream_ptr()), "read_bilinear_down_backward")
+        return din, None
+
+
+def bilinear_down(x, ss):
+    """HIP replacement of ``F.interpolate(x, scale_factor=1/ss, mode='bilinear')`` for integer ss >= 2 (differentiable)."""
+    _lib.require_gpu()
+    if not x.is_cuda:
+        raise _lib.ReadHipError("bilinear_down runs on the GPU")
+    return _BilinearDownFn.apply(x.float(), int(ss))
+
+
+class _RangeCheck:
+    """Out-of-range point ids without a device->host sync per lookup.  The reference's index_select (texture.py:61) reports
+    them through an asynchronous device assert; here every lookup queues `max(ids) >= n` into pinned host memory and the
+    NEXT lookup (or ``flush()``) raises IndexError once that copy has landed — the gather itself clamps, so nothing reads
+    out of bounds in the meantime."""
+
+    def __init__(self):
+        self.pending = []          # (event, pinned flag tensor, n)
+
+    def queue(self, ids, n):
+        flag = torch.empty(1, dtype=torch.int32).pin_memory()
+        flag.copy_(torch.stack([ids.max()]).to(torch.int32), non_blocking=True)
+        ev = torch.cuda.Event()
+        ev.record()
+        self.pending.append((ev, flag, n))
+
+    def poll(self, wait=False):
+        keep = []
+        for ev, flag, n in self.pending:
+            if wait:
+                ev.synchronize()
+            if ev.query():
+                if int(flag[0]) >= n:
+                    self.pending = []
+                    raise IndexError(f"point id {int(flag[0])} out of range for a descriptor table of {n} points "
+                                     f"(wrong texture for this scene?)")
+            else:
+                keep.append((ev, flag, n))
+        self.pending = keep
+
+    def flush(self):
+        self.poll(wait=True)
+
+
 class _GatherFn(torch.autograd.Function):
     """texture_ (1,C,N) x int32 ids (B,H,W) -> NHWC (B,H,W,C); backward = HIP scatter-add."""
 
@@ -218,6 +285,19 @@ class PointTexture(Texture):
     def state_dict(self, *args, **kwargs):
         self.sync_texture()
         return super().state_dict(*args, **kwargs)
+
+    def _apply(self, fn, *args, **kwargs):
+        """``.cpu()`` / ``.cuda()`` / ``.to()`` (NetAndTexture.unload_textures, READ/models/compose.py:118-123; the train loop
+        moves the texture off the device between train and eval, train.py:271-305): rows stepped by the sparse optimizer are
+        written back into ``texture_`` BEFORE the parameter leaves the device, and the row cache is dropped — the next lookup
+        rebuilds it from the (now current) parameter wherever it lives."""
+        self.sync_texture()
+        out = super()._apply(fn, *args, **kwargs)
+        self._rows = None
+        self._rows_version = None
+        self._rows_newer = False
+        self._grad_rows = None
+        return out
 
     def invalidate(self):
         """Drop the cached rows (call after editing ``texture_`` through ``.data`` or other version-blind paths)."""

@@ -20,6 +20,7 @@ BatchNorm runs as the eval-mode affine map with trainable gamma/beta — the con
 BatchNorm (``model.train()``) raises.
 """
 import ctypes as C
+import weakref
 
 import torch
 
@@ -104,6 +105,8 @@ def _packed_for(wf, bf, wm, bm, gamma, beta, mean, var, cin, cout, k):
     st = _lib.stream_ptr()
     ver = tuple(t._version for t in (wf, bf, wm, bm, gamma, beta, mean, var)) + (wf.data_ptr(), wm.data_ptr())
     hit = _PACK_CACHE.get(id(wf))
+    if hit is not None and hit[6]() is not wf:              # the id was recycled by another tensor: not this layer's entry
+        hit = None
     if hit is not None and hit[0] == ver:
         cur = torch.cuda.current_stream()
         cur.wait_event(hit[4])                              # packed on another item's stream
@@ -125,9 +128,22 @@ def _packed_for(wf, bf, wm, bm, gamma, beta, mean, var, cin, cout, k):
         _lib.check(L.read_conv_pack_wino_device(cin, cout, wf_c.data_ptr(), wm_c.data_ptr(), wino.data_ptr(), st))
     ev = torch.cuda.Event()
     ev.record()
-    entry = [ver, params, wp, None, ev, wino]
-    _PACK_CACHE[id(wf)] = entry
+    key = id(wf)
+    old = _PACK_CACHE.get(key)
+    if old is not None and old[6]() is wf:
+        ref = old[6]                                          # same parameter, new version: keep its finalizer's handle
+    else:
+        ref = weakref.ref(wf)
+        weakref.finalize(wf, _drop_pack, key, ref)            # the entry dies with its parameter
+    entry = [ver, params, wp, None, ev, wino, ref]
+    _PACK_CACHE[key] = entry
     return entry
+
+
+def _drop_pack(key, ref):
+    e = _PACK_CACHE.get(key)
+    if e is not None and e[6] is ref:
+        del _PACK_CACHE[key]
 
 
 def _pack_dgrad(entry, wf, wm, cin, cout, k):
@@ -179,6 +195,7 @@ class GatedConvFn(torch.autograd.Function):
             _lib.check(L.read_gate_forward(fm.data_ptr(), Ho * Wo, cout, params.data_ptr(), int(elu), None, y.data_ptr(), Wo, bh, vh, st))
         ctx.save_for_backward(x, fm, params, wf_c, wm_c, mean, var)
         ctx.cfg = (k, stride, int(elu), H, W, cin, cout, Ho, Wo, bh, vh)
+        ctx.wrefs = (weakref.ref(wf), weakref.ref(wm))
         return y
 
     @staticmethod
@@ -228,6 +245,8 @@ class GatedConvFn(torch.autograd.Function):
                 ws = torch.empty(L.read_conv_dgrad_generic_floats(cin, cout, k), dtype=torch.float32, device=dev)
                 _lib.check(L.read_conv_dgrad_generic(dfm.data_ptr(), Ho, Wo, cin, cout, k, stride, wf.data_ptr(), wm.data_ptr(),
                                                      ws.data_ptr(), H, W, dx.data_ptr(), st))
+        if not (ctx.needs_input_grad[1] or ctx.needs_input_grad[3]):        # frozen net: nobody asked for weight gradients
+            return dx, None, dbf, None, dbm, dgamma, dbeta, None, None, None, None, None, None, None, None
         dwf, dwm = torch.empty_like(wf), torch.empty_like(wm)
         n_scr = L.read_conv_wgrad_scratch_floats(cin, cout, k, Ho)
         scratch = torch.empty(n_scr, dtype=torch.float32, device=dev)
@@ -242,7 +261,21 @@ class GatedConvFn(torch.autograd.Function):
                                              0, scratch.data_ptr(), n_scr, _lib.stream_ptr()))
             for t in (x, dfm, dwf, dwm, scratch):
                 t.record_stream(side)
-            _queue_join(dev)
+            # Returning dwf / dwm before the side stream has produced them is only safe when AccumulateGrad STEALS the
+            # tensors (``.grad`` is None, no hooks): otherwise ``grad += dwf`` runs on the main stream right away — gradient
+            # accumulation over several backward() calls, zero_grad(set_to_none=False), a layer used twice in one graph, a
+            # tensor hook.  Then the main stream waits for this layer's wgrad here.
+            stealable = True
+            for r in ctx.wrefs:
+                p = r()
+                if p is None or p.grad is not None or getattr(p, '_backward_hooks', None) or getattr(p, '_post_accumulate_grad_hooks', None):
+                    stealable = False
+            if stealable:
+                _queue_join(dev)
+            else:
+                ev_w = torch.cuda.Event()
+                ev_w.record(side)
+                main.wait_event(ev_w)
         else:
             _lib.check(L.read_conv_wgrad(x.data_ptr(), H, W, cin, dfm.data_ptr(), cout, k, stride, dwf.data_ptr(), dwm.data_ptr(), 0,
                                          scratch.data_ptr(), n_scr, st))

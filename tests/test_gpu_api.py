@@ -95,8 +95,10 @@ def test_multiscale_render_and_ogl_infer(hip):
 
     ogl = OGL.from_model(scene, model, FMT, (W, H))
     fast = ogl.infer()['output']
+    assert ogl.last_path == 'fast'                                         # the device-resident branch really ran
     assert fast.shape == (H, W, 4) and bool((fast[..., 3] == 1).all())
     slow = ogl.infer({k: v.permute(2, 0, 1)[None] for k, v in maps.items()})['output']
+    assert ogl.last_path == 'dict'
     torch.testing.assert_close(fast, slow, rtol=0, atol=1e-6)
     with torch.no_grad():
         ref = unet_torch.net_and_texture_forward(state, tex.texture_.detach().cpu().numpy(), oi)[0]

@@ -204,6 +204,7 @@ def test_ogl_supersampling_end_to_end(hip):
     scene.set_camera_view(synthetic.sweep_pose(4))
     ogl = OGL.from_model(scene, model, fmt, (W, H), supersampling=ss)
     fast = ogl.infer()["output"]
+    assert ogl.last_path == 'fast'                  # fused supersampling branch of the device-resident path
     M = camera.total_matrix(proj, synthetic.sweep_pose(4))[0]
     oi, _ = oracle.raster_multiscale(xyz, M, ss * W, ss * H, 5)
     desc = tex.texture_.detach().cpu().numpy()
@@ -216,4 +217,5 @@ def test_ogl_supersampling_end_to_end(hip):
     # the dict path (MultiscaleRender at ss x -> NetAndTexture) gives the same frame
     inputs = {k: v.permute(2, 0, 1)[None] for k, v in ogl.renderer.render().items()}
     slow = ogl.infer(inputs)["output"]
+    assert ogl.last_path == 'dict'
     torch.testing.assert_close(fast, slow, rtol=0, atol=1e-6)

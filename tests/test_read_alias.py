@@ -69,3 +69,56 @@ def test_alias_package_in_front_of_the_real_reference():
         print('ok')
     """, ref)
     assert r.returncode == 0, r.stderr
+
+
+_THIRD_PARTY_STUBS = """
+    import sys, types
+    # torchvision / cv2 are imported at the top of the reference's dataset modules and are not in this image
+    tv, tr = types.ModuleType('torchvision'), types.ModuleType('torchvision.transforms')
+    class Compose:
+        def __init__(self, ts): self.ts = ts
+        def __call__(self, x):
+            for t in self.ts: x = t(x)
+            return x
+    tr.Compose = Compose; tv.transforms = tr
+    sys.modules['torchvision'] = tv; sys.modules['torchvision.transforms'] = tr
+    sys.modules.setdefault('cv2', types.ModuleType('cv2'))
+"""
+
+
+def test_reference_datasets_use_the_hip_renderer():
+    """the reference's DynamicDataset resolves MultiscaleRender / NNScene / app.Window through ITS module globals —
+    those must be the HIP-backed classes, and ``get_datasets`` must be importable through the alias (TexturePipeline.create)."""
+    ref = "/root/reference"
+    if not os.path.isdir(os.path.join(ref, "READ")):
+        import pytest
+        pytest.skip("reference checkout not present")
+    scene = os.path.join(ROOT, "tests", "golden", "scene", "scene.yaml")
+    r = _run(_THIRD_PARTY_STUBS + f"""
+    import numpy as np
+    import READ.datasets.dynamic as dyn, read_amd.render
+    from READ.gl.utils import load_scene_data, FastRand, get_proj_matrix
+    from READ.gl.programs import NNScene
+    from READ.gl.dataset import parse_input_string
+    assert dyn._ref is not None, dyn.reference_origin
+    assert 'reference' in dyn.reference_origin
+    assert callable(dyn.get_datasets)
+    DD = dyn.DynamicDataset
+    g = DD.__init__.__globals__                                   # what the reference class sees at run time
+    assert g['MultiscaleRender'] is read_amd.render.MultiscaleRender
+    assert g['NNScene'] is read_amd.render.Scene and NNScene is read_amd.render.Scene
+    g['app'].Window(visible=False)                                # "creates GL context": a no-op here
+    assert NNScene.MODE_UV == 3 and NNScene.UV_TYPE_1D == 0
+    sd = load_scene_data({scene!r})
+    n = len(sd['view_matrix'])
+    ds = DD(sd, 'uv_1d_p1, uv_1d_p1_ds1', (64, 48), sd['view_matrix'], [''] * n, [''] * n, [''] * n, perturb_points=0.1)
+    ds.load()                                                     # NNScene() + setup_scene + FastRand, all without GL
+    assert isinstance(ds.scene, read_amd.render.Scene) and ds.scene.xyz.shape[1] == 3
+    assert ds.fastrand.toss().shape == (ds.scene.xyz.shape[0], 2)
+    K, proj = ds._get_intrinsics()
+    assert proj.shape == (4, 4)
+    ds.unload()
+    assert ds.scene is None
+    print('ok')
+    """, ref)
+    assert r.returncode == 0, r.stderr
