@@ -3,6 +3,11 @@
 
     python bench.py --gpus N --steps K --warmup W        (N>1: launched by torch.distributed.run)
     python bench.py --config kitti6_like                 (second line: BASELINE configs[1] stand-in, see below)
+    python bench.py --config train                       (third line: BASELINE configs[4], training iterations/s)
+
+The default (headline) run at N = 1 also carries compact sub-records of the other configurations in the same JSON line —
+``"also": {"latency_mode", "kitti6_like", "train"}`` — each measured and VERIFIED against the oracle inside this run (their
+CPU timing legs are skipped, the verification frames / iteration are kept); ``--no-also`` drops them.
 
 A "step" is one full frame of READ's render path on one GPU: rasterise 5 scales (one pass over the
 cloud) -> gather 8-channel descriptors -> 99-conv gated UNet -> RGBA frame.  Inputs (xyz, descriptors,
@@ -68,6 +73,10 @@ def parse():
     p.add_argument("--cpu-frames", type=int, default=3, help="timed CPU frames after one warm-up frame")
     p.add_argument("--detail", type=str, default="", help="write per-launch timings to this JSON file")
     p.add_argument("--tune", type=str, default="", help="comma list of key=value for read_tuning_set (A/B runs)")
+    p.add_argument("--no-also", action="store_true", help="headline run without the kitti6_like / train / latency sub-records")
+    p.add_argument("--train-mode", choices=("eval", "train"), default="eval",
+                   help="--config train: BatchNorm in eval mode (eval_in_train: True, configs/train_example.yaml) or with "
+                        "batch statistics (model.train(), the reference's default)")
     return p.parse_args()
 
 
@@ -127,6 +136,7 @@ class SlabWorkload:
         self.proj = synthetic.make_proj(self.W, self.H)
         self.fr = FrameRenderer(xyz_d, desc_d, packed_d, self.W, self.H, proj_matrix=self.proj, device=dev, cells=cells_d,
                                 frames_in_flight=a.frames_in_flight)
+        self.xyz_d = xyz_d
         del desc_d
         self.total = [camera.total_matrix(self.proj, synthetic.sweep_pose(k)) for k in range(N_POSES)]
         self.describe = (f"BASELINE configs[2]: synthetic {N}-point KITTI-like slab, 1216x352, 8-dim descriptors, "
@@ -162,6 +172,9 @@ class SlabWorkload:
         return self.fr.unet.profile(f[0][0], f[1][0], f[2][0], f[3][0], channels=4)
 
     def oracle_inputs(self):
+        if self.xyz is None:                     # ranks > 0 received the scene over the collective: copy it back to the host
+            self.xyz = self.xyz_d.cpu().numpy()
+            self.desc = self.fr.rows.t().contiguous().cpu().numpy()
         return self.xyz, self.desc, self.state
 
 
@@ -170,7 +183,7 @@ class Kitti6LikeWorkload:
     name = "kitti6_like"
     W, H = 1216, 368
 
-    def __init__(self, a, dev, rank):
+    def __init__(self, a, dev, rank, street=None):
         from read_amd import scene_io
         from read_amd.ogl import OGL
         from read_amd.pipeline import save_model
@@ -183,7 +196,7 @@ class Kitti6LikeWorkload:
         holder = [None]
         if rank == 0:
             d = tempfile.mkdtemp(prefix="read_kitti6_like_")
-            xyz = synthetic.make_street_cloud(N)
+            xyz = street if street is not None and len(street) == N else synthetic.make_street_cloud(N)
             scene_io.write_ply(os.path.join(d, "pointcloud.ply"), xyz)
             cams = []
             for k in range(N_POSES):
@@ -241,6 +254,15 @@ class Kitti6LikeWorkload:
         self.scene.set_camera_view(self.views[k])
         out.copy_(self.ogl.infer()["output"])
 
+    def timed_frame(self, k):
+        """Pose k through render_into() — the call the timed loop makes (OGL.infer(), device-resident branch)."""
+        out = torch.empty((self.H, self.W, 4), dtype=torch.float32, device=self.texture.texture_.device)
+        self.render_into(k, out)
+        torch.cuda.synchronize()
+        assert self.ogl.last_path == 'fast', "OGL.infer() left its device-resident branch"
+        idx, depth = self.rasterize(k)               # the same rasteriser call infer() made, with depth this time
+        return idx, depth, out
+
     def rasterize(self, k):
         self.scene.set_camera_view(self.views[k])
         self.idx, self.depth = self.scene.rasterizer().render(self.scene.total_matrix(), self.W, self.H, self.levels)
@@ -274,17 +296,30 @@ class Kitti6LikeWorkload:
 # ---------------------------------------------------------------------------------------------------------------------
 # BASELINE configs[4]: training iterations/s (train.py --crop_size 256x256, batch_size 2 x inner_batch 4 = 8 crops)
 # ---------------------------------------------------------------------------------------------------------------------
-def run_train(a, dev):
+def _grad_err(got, ref):
+    """(max|diff| / max|ref|,  smallest floor factor a such that |diff| <= a * max|ref| + 1e-3 * |ref| holds everywhere)."""
+    got, ref = got.detach().cpu().double(), ref.detach().cpu().double()
+    scale = max(float(ref.abs().max()), 1e-30)
+    diff = (got - ref).abs()
+    return float(diff.max()) / scale, float((diff - 1e-3 * ref.abs()).clamp_min(0).max()) / scale
+
+
+def run_train(a, dev, street=None, steps=None, warm=None, cpu_timing=True, do_verify=True):
     """One iteration = what src/train.py:150-265 does per batch with the headless renderer: rasterise 8 cameras x 5 scales
     (MyRender), look the descriptors up, UNet forward, loss, backward, Adam on the net, RMSprop on the descriptors.  The
-    criterion is the Huber term (x 1e4, train.py:549) only: the VGG term needs downloaded VGG weights (no network)."""
+    criterion is the Huber term (x 1e4, train.py:549) only: the VGG term needs downloaded VGG weights (no network).
+
+    verified: BEFORE the timed loop one iteration's forward/backward runs on fixed cameras and is compared with the oracle
+    on the host (oracle rasteriser -> torch-CPU gather + UNet + Huber under torch.autograd): index maps bit-exact, loss,
+    every parameter gradient and the descriptor gradient rows."""
     from types import SimpleNamespace
     from read_amd.pipeline import TexturePipeline
     from read_amd.render import MyRender
     from read_amd.train import huber_loss
     N, B, S = a.points or 10_000_000, 8, 256
-    xyz = synthetic.make_street_cloud(N)
+    xyz = street if street is not None and len(street) == N else synthetic.make_street_cloud(N)
     fmt = "uv_1d_p1, uv_1d_p1_ds1, uv_1d_p1_ds2, uv_1d_p1_ds3, uv_1d_p1_ds4"
+    bn_train = a.train_mode == "train"
 
     class DS:
         id, name, input_format, tgt_sh = 0, "kitti6_like", fmt, (S, S)
@@ -303,32 +338,129 @@ def run_train(a, dev):
     pipe.create(args)
     state = synthetic.make_unet_state(weight_spec())
     pipe.net.load_state_dict({k: torch.from_numpy(np.asarray(v)) for k, v in state.items()})
+    desc0 = synthetic.make_descriptors(N)
     with torch.no_grad():
-        pipe.textures[0].texture_.copy_(torch.from_numpy(synthetic.make_descriptors(N))[None])
+        pipe.textures[0].texture_.copy_(torch.from_numpy(desc0)[None])
     model = pipe.model
     pipe.dataset_load([DS()])
-    model.cuda().eval()                                           # eval_in_train: True (configs/train_example.yaml)
+    model.cuda()
+    if bn_train:
+        model.train()                                             # the reference's default (train.py:271-279, eval_in_train False)
+    else:
+        model.eval()                                              # eval_in_train: True (configs/train_example.yaml)
     extra = pipe.extra_optimizer([DS()])
     renderer = MyRender([DS()], device_outputs=True)
     rng = np.random.default_rng(2019)
     proj = synthetic.make_proj(S, S).astype(np.float32)
     targets = torch.from_numpy(rng.random((4, B, 3, S, S)).astype(np.float32)).to(dev)
+    tex = pipe.textures[0]
 
-    def step(i):
-        views = np.stack([synthetic.sweep_pose(int(k)) for k in rng.integers(0, N_POSES, B)])
+    def forward_backward(views, target):
         data = {'input': {'id': torch.zeros(B, dtype=torch.long)}, 'view_matrix': torch.from_numpy(views),
                 'proj_matrix': torch.from_numpy(np.repeat(proj[None], B, 0))}
         inputs, _ = renderer.render(data)
         out = model(inputs)
-        loss = pipe.criterion(out, targets[i % 4]) * 1e4
+        loss = pipe.criterion(out, target) * 1e4
         loss.backward()
+        return loss
+
+    def step(i):
+        views = np.stack([synthetic.sweep_pose(int(k)) for k in rng.integers(0, N_POSES, B)])
+        loss = forward_backward(views, targets[i % 4])
         pipe.optimizer.step()
         pipe.optimizer.zero_grad()
         extra.step()
         extra.zero_grad()
         return loss
 
-    steps, warm = (a.steps if a.steps != 256 else 10), max(a.warmup, 2)
+    # ---- verification iteration (no optimizer step: the weights the timed loop starts from are the seeded ones)
+    verified, base = None, None
+    if do_verify and not a.no_cpu_baseline:
+        import oracle
+        from oracle import unet_torch
+        import torch.nn.functional as Fnn
+        vviews = np.stack([synthetic.sweep_pose(int(k)) for k in (0, 37, 64, 101, 128, 165, 192, 229)])
+        bn_before = {k: v.detach().clone() for k, v in pipe.net.state_dict().items() if "running_" in k} if bn_train else None
+        loss_g = forward_backward(vviews, targets[0])
+        idx_g = [t.cpu().numpy() for t in renderer.last_index]
+        grads_g = {n: p.grad.detach().cpu() for n, p in pipe.net.named_parameters() if p.grad is not None}
+        drows_g = tex.grad_rows().detach().cpu()                       # dense descriptor gradient rows of this iteration (N, 8)
+        bn_after = {k: v.detach().cpu() for k, v in pipe.net.state_dict().items() if "running_" in k} if bn_train else None
+        pipe.optimizer.zero_grad()
+        tex.take_touched()
+        tex.grad_rows().zero_()
+        tex.null_grad()
+        if bn_train:                                                    # undo the running-statistics update of this iteration
+            pipe.net.load_state_dict({**pipe.net.state_dict(), **bn_before})
+        torch.cuda.synchronize()
+        torch.set_num_threads(min(os.cpu_count() or 1, 32))
+        r_threads = min(os.cpu_count() or 1, 64)
+
+        def oracle_iteration(views, target, st_r, tex_r):
+            tm = camera.total_matrix(proj, views)
+            maps = [[], [], [], [], []]
+            for b in range(B):
+                il, _ = oracle.raster_multiscale(xyz, tm[b], S, S, 5, threads=r_threads)
+                for l in range(5):
+                    maps[l].append(il[l])
+            maps = [np.stack(m) for m in maps]
+            feats = [tex_r[0][:, torch.from_numpy(m.astype(np.int64))].permute(1, 0, 2, 3) for m in maps]
+            out = unet_torch.unet_forward(st_r, *feats[:4], training=bn_train)
+            loss = Fnn.huber_loss(out, target) * 1e4
+            loss.backward()
+            return maps, loss
+
+        def fresh():
+            st = {k: torch.nn.Parameter(torch.from_numpy(np.asarray(v)).clone())
+                  if (np.asarray(v).dtype == np.float32 and "running" not in k) else torch.from_numpy(np.asarray(v)).clone()
+                  for k, v in state.items()}
+            return st, torch.nn.Parameter(torch.from_numpy(desc0.copy())[None])
+        st_r, tex_r = fresh()
+        t0 = time.perf_counter()
+        maps_o, loss_o = oracle_iteration(vviews, targets[0].cpu(), st_r, tex_r)
+        t_first = time.perf_counter() - t0
+        exact = all(bool(np.array_equal(idx_g[l], maps_o[l])) for l in range(5))
+        worst = worst_floor = 0.0
+        n_par = 0
+        for n, g in grads_g.items():
+            e, f = _grad_err(g, st_r[n].grad)
+            worst, worst_floor, n_par = max(worst, e), max(worst_floor, f), n_par + 1
+        touched = torch.from_numpy(np.unique(np.concatenate([m.reshape(-1) for m in maps_o])).astype(np.int64))
+        dref = tex_r.grad[0].t()[touched]
+        e_desc, f_desc = _grad_err(drows_g[touched], dref)
+        untouched_zero = bool(float(drows_g.abs().sum()) == float(drows_g[touched].abs().sum()))
+        loss_rel = abs(float(loss_g) - float(loss_o)) / max(abs(float(loss_o)), 1e-30)
+        verified = {"raster_bit_exact": exact, "loss": float(loss_g), "loss_oracle": float(loss_o), "loss_rel_err": loss_rel,
+                    "param_grads_compared": n_par, "worst_param_grad_err_of_max": worst,
+                    "worst_param_grad_floor_with_1e-3_rel": worst_floor,
+                    "descriptor_rows_compared": int(touched.numel()), "descriptor_grad_err_of_max": e_desc,
+                    "descriptor_grad_floor_with_1e-3_rel": f_desc, "untouched_rows_zero": untouched_zero,
+                    "batchnorm": "batch statistics" if bn_train else "eval (running statistics)"}
+        if bn_train:
+            e_bn = max(_grad_err(bn_after[k], st_r[k])[0] for k in bn_after)
+            verified["running_stats_err_of_max"] = e_bn
+        verified["ok"] = bool(exact and loss_rel <= 1e-4 and n_par >= 594 and worst <= 2e-4 and e_desc <= 2e-4 and untouched_zero
+                              and (not bn_train or verified["running_stats_err_of_max"] <= 1e-4))
+        if cpu_timing:
+            # CPU baseline: the first oracle iteration above was the warm-up; time 2 more complete iterations (oracle
+            # rasteriser for 8 cameras + gather + UNet forward/backward + Huber + Adam + dense RMSprop, as the reference does)
+            opt_r = torch.optim.Adam([p_ for p_ in st_r.values() if isinstance(p_, torch.nn.Parameter)], lr=1e-4)
+            ext_r = torch.optim.RMSprop([tex_r], lr=1e-1)
+            opt_r.zero_grad(); ext_r.zero_grad()
+            n_cpu = 2
+            t0 = time.perf_counter()
+            for i in range(n_cpu):
+                views = np.stack([synthetic.sweep_pose(int(k)) for k in rng.integers(0, N_POSES, B)])
+                oracle_iteration(views, targets[i % 4].cpu(), st_r, tex_r)
+                opt_r.step(); opt_r.zero_grad(); ext_r.step(); ext_r.zero_grad()
+            t_cpu = (time.perf_counter() - t0) / n_cpu
+            base = {"value": 1.0 / t_cpu, "unit": "iters/s", "cores": torch.get_num_threads(), "kind": "port",
+                    "sample": f"1 warm-up ({t_first:.1f} s, also the verification iteration) + {n_cpu} timed iterations of 8 crops: "
+                              f"oracle rasteriser (C/OpenMP, {r_threads} threads, 8 cameras x 5 scales over {N} points) + torch-CPU "
+                              "gather + UNet forward/backward + Huber through the oracle + torch Adam + dense torch RMSprop"}
+
+    steps = steps if steps is not None else (a.steps if a.steps != 256 else 10)
+    warm = warm if warm is not None else max(a.warmup, 2)
     for i in range(warm):
         step(i)
     torch.cuda.synchronize()
@@ -345,36 +477,24 @@ def run_train(a, dev):
            "config": {"workload": f"BASELINE configs[4] stand-in: TexturePipeline training step on a seeded {N}-point street scene, "
                                   "batch_size 2 x inner_batch 4 = 8 crops of 256x256: MyRender raster (8 cameras x 5 scales) + "
                                   "gather + UNet forward/backward (HIP autograd nodes) + Huber x 1e4 (no VGG term: weights are a "
-                                  "download) + Adam(net) + sparse RMSprop(descriptors), BatchNorm in eval mode (eval_in_train)",
+                                  "download) + Adam(net) + sparse RMSprop(descriptors), BatchNorm "
+                                  + ("with batch statistics (model.train())" if bn_train else "in eval mode (eval_in_train)"),
                       "points": N, "crop": S, "batch": B, "parallelism": "single GPU (DataParallel of the reference not rebuilt)"},
            "roofline": {"kernel": "whole step (MFMA convolutions forward + dgrad + wgrad)", "bound": "mfma",
                         "achieved": achieved, "peak": FP32_MFMA_PEAK_TFS, "unit": "TFLOP/s", "frac": achieved / FP32_MFMA_PEAK_TFS,
                         "traffic": None, "flops_per_step": 3.0 * fwd_flops,
                         "note": "3 x the forward convolution FLOPs of 8 crops / wall time of a step (host-side autograd "
                                 "bookkeeping included)"},
-           "final_loss": float(loss.detach()), "tuning": _lib.tuning_state(), "cpu_baseline": None, "verified": None}
-    if not a.no_cpu_baseline:
-        from oracle import unet_torch
-        import torch.nn.functional as Fnn
-        torch.set_num_threads(min(os.cpu_count() or 1, 32))
-        st_r = {k: torch.nn.Parameter(torch.from_numpy(np.asarray(v)).clone()) if (np.asarray(v).dtype == np.float32 and "running" not in k)
-                else torch.from_numpy(np.asarray(v)) for k, v in state.items()}
-        idx = [torch.from_numpy(rng.integers(0, N, (B, S >> l, S >> l))) for l in range(5)]
-        tex_r = torch.nn.Parameter(torch.from_numpy(synthetic.make_descriptors(N))[None])
-        t0 = time.perf_counter()
-        outs = [unet_torch.unet_forward(st_r, *[tex_r[:, :, i[b]] for i in idx[:4]]) for b in range(B)]
-        (Fnn.huber_loss(torch.cat(outs, 0), targets[0].cpu()) * 1e4).backward()
-        t_cpu = time.perf_counter() - t0
-        out["cpu_baseline"] = {"value": 1.0 / t_cpu, "unit": "iters/s", "cores": torch.get_num_threads(), "kind": "port",
-                               "sample": "1 iteration (8 crops): torch-CPU gather + UNet forward/backward + Huber through the oracle; "
-                                         "rasterisation and optimizer steps not included"}
-    print(json.dumps(out), flush=True)
+           "final_loss": float(loss.detach()), "tuning": _lib.tuning_state(), "cpu_baseline": base, "verified": verified}
+    pipe.dataset_unload([DS()])
+    return out
 
 
 # ---------------------------------------------------------------------------------------------------------------------
 # CPU leg: the oracle on this box's host cores (bounded sample) + the frame the GPU result is verified against
 # ---------------------------------------------------------------------------------------------------------------------
-def cpu_leg(wl, frames):
+def cpu_leg(wl, frames, pose0=0, probe_threads=True):
+    """-> (cpu_baseline record or None when frames == 0, the oracle's frame of pose `pose0`)."""
     import oracle
     from oracle import unet_torch
     xyz, desc, state = wl.oracle_inputs()
@@ -383,24 +503,26 @@ def cpu_leg(wl, frames):
     # thread count: torch's CPU convolutions get SLOWER with too many threads on the 256-thread GPU hosts (the UNet is
     # ~600 small ops; measured on a 128x128 frame: 0.18 s at 32 threads, 0.39 s at 64, 149 s at all 256 —
     # profiles/r2_bench.log), so probe {16, 32, 64, all if <= 128} on a small frame and run the sample with the best
-    cands = sorted({min(16, ncpu), min(32, ncpu), min(64, ncpu)} | ({ncpu} if ncpu <= 128 else set()))
-    xs = [torch.rand(1, 8, 128 >> l, 128 >> l) for l in range(4)]
     probe = {}
-    with torch.no_grad():
-        torch.set_num_threads(cands[0])
-        unet_torch.unet_forward(state, *xs)
-        for t in cands:
-            torch.set_num_threads(t)
-            t0 = time.perf_counter()
+    cores = min(32, ncpu)
+    if probe_threads and frames > 0:
+        cands = sorted({min(16, ncpu), min(32, ncpu), min(64, ncpu)} | ({ncpu} if ncpu <= 128 else set()))
+        xs = [torch.rand(1, 8, 128 >> l, 128 >> l) for l in range(4)]
+        with torch.no_grad():
+            torch.set_num_threads(cands[0])
             unet_torch.unet_forward(state, *xs)
-            probe[t] = time.perf_counter() - t0
-    cores = min(probe, key=probe.get)
+            for t in cands:
+                torch.set_num_threads(t)
+                t0 = time.perf_counter()
+                unet_torch.unet_forward(state, *xs)
+                probe[t] = time.perf_counter() - t0
+        cores = min(probe, key=probe.get)
     torch.set_num_threads(cores)
     r_threads = min(ncpu, 64)
     t_r = t_g = t_u = 0.0
     first = None
     for k in range(frames + 1):                              # frame 0 = warm-up (and the verification frame)
-        M = np.asarray(wl.total[k], np.float32).reshape(-1, 4, 4)[0]
+        M = np.asarray(wl.total[(pose0 + k) % N_POSES], np.float32).reshape(-1, 4, 4)[0]
         t0 = time.perf_counter()
         idx, dep = oracle.raster_multiscale(xyz, M, W, H, 5, threads=r_threads)
         t1 = time.perf_counter()
@@ -413,29 +535,25 @@ def cpu_leg(wl, frames):
             first = (idx, dep, rgb[0])
         else:
             t_r, t_g, t_u = t_r + (t1 - t0), t_g + (t2 - t1), t_u + (t3 - t2)
-    per = (t_r + t_g + t_u) / max(frames, 1)
+    if frames == 0:
+        return None, first
+    per = (t_r + t_g + t_u) / frames
     base = {"value": 1.0 / per, "unit": "frames/s", "cores": cores, "kind": "port",
             "sample": f"1 warm-up + {frames} timed full frames ({W}x{H}, {xyz.shape[0]} pts, sweep poses 1..{frames}): oracle "
                       f"raster C/OpenMP on {r_threads} threads + torch-CPU gather + torch-CPU fp32 UNet on {cores} threads "
                       f"(best of the probed thread counts) of {ncpu}",
             "thread_probe_s_128x128": {str(k): v for k, v in probe.items()},
-            "ms_raster": 1e3 * t_r / max(frames, 1), "ms_gather": 1e3 * t_g / max(frames, 1),
-            "ms_unet": 1e3 * t_u / max(frames, 1)}
+            "ms_raster": 1e3 * t_r / frames, "ms_gather": 1e3 * t_g / frames, "ms_unet": 1e3 * t_u / frames}
     return base, first
 
 
-def verify(wl, first):
-    """Pose 0 through the warm renderer against the oracle's pose-0 frame."""
+def verify(wl, first, pose=0):
+    """Pose `pose` through the warm renderer against the oracle's frame of that pose."""
     from oracle import unet_torch
     idx_o, dep_o, rgb_o = first
-    if hasattr(wl, "timed_frame"):
-        # the frame comes out of the SAME call the timed loop makes (with frames in flight: two poses through the pipelined
-        # path, the second one is compared), the index / depth pyramids are what that call's rasteriser left behind
-        idx, depth, rgba = wl.timed_frame(0)
-    else:
-        idx, depth = wl.rasterize(0)
-        wl.gather()
-        rgba = wl.refine()
+    # the frame comes out of the SAME call the timed loop makes (with frames in flight: two poses through the pipelined
+    # path, the second one is compared), the index / depth pyramids are what that call's rasteriser left behind
+    idx, depth, rgba = wl.timed_frame(pose)
     torch.cuda.synchronize()
     exact = True
     for l in range(5):
@@ -443,12 +561,94 @@ def verify(wl, first):
         exact &= bool(np.array_equal(depth[l][0].cpu().numpy().view(np.uint32), dep_o[l].view(np.uint32)))
     got = rgba[:, :, :3].permute(2, 0, 1).cpu()
     diff = (got.double() - rgb_o.double())
-    out = {"pose": 0, "raster_bit_exact": exact, "psnr_db": unet_torch.psnr(got, rgb_o),
+    out = {"pose": pose, "raster_bit_exact": exact, "psnr_db": unet_torch.psnr(got, rgb_o),
            "max_abs_diff": float(diff.abs().max()),
            "rel_rms": float(diff.pow(2).mean().sqrt() / rgb_o.double().std()),
            "alpha_is_one": bool((rgba[:, :, 3] == 1).all())}
     out["ok"] = bool(exact and out["psnr_db"] >= PSNR_FLOOR_DB and out["alpha_is_one"])
     return out
+
+
+def timed_sweep(wl, ex, warmup, steps, world, dev):
+    """The timed region of the contract: W untimed steps, then exactly K steps bracketed by barrier + synchronize; max over ranks."""
+    sweep.run_steps(wl.render_into, ex, 0, warmup, N_POSES)
+    ex.drain()
+    if hasattr(wl, "fr"):
+        wl.fr.sync()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    sweep.run_steps(wl.render_into, ex, warmup, steps, N_POSES)
+    ex.drain()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    return dt
+
+
+def stage_times(wl):
+    """Per-kernel durations, live, with HIP events on the launch stream."""
+    # the rasteriser warm-starts from the previous frame, so it is timed over consecutive poses of the sweep
+    # (as in the timed loop), not over one repeated pose
+    it = iter(range(1, 10 ** 6))
+    wl.rasterize(0)
+    ms_splat = hip_time_ms(lambda: wl.rasterize(next(it) % N_POSES), 32)
+    ms_gather = hip_time_ms(lambda: wl.gather(), 10)
+    ms_unet = hip_time_ms(lambda: wl.refine(), 5)
+    return ms_splat, ms_gather, ms_unet
+
+
+def also_records(a, dev, wl):
+    """Compact records of the configurations the headline line is not quoted on, measured and verified inside this run."""
+    import copy
+    rec = {}
+    # (1) latency mode: the same renderer, one frame at a time (the viewer's mode, OGL.infer / FrameRenderer.render)
+    try:
+        wl.fr.set_frames_in_flight(1)
+        ex = sweep.FrameExchange((wl.H, wl.W, 4), dev, torch.float32, None)
+        n = min(a.steps, 64)
+        dt = timed_sweep(wl, ex, a.warmup, n, 1, dev)
+        rec["latency_mode"] = {"value": n / dt, "unit": "frames/s", "ms_per_step": 1e3 * dt / n, "steps": n, "frames_in_flight": 1,
+                               "what": "headline workload, one frame at a time (every frame complete before the next starts)"}
+    finally:
+        wl.fr.set_frames_in_flight(a.frames_in_flight)
+    street = synthetic.make_street_cloud(10_000_000)
+    # (2) BASELINE configs[1] stand-in through the viewer API
+    ak = copy.copy(a)
+    ak.points = 0
+    kw = Kitti6LikeWorkload(ak, dev, 0, street=street)
+    try:
+        ex = sweep.FrameExchange((kw.H, kw.W, 4), dev, torch.float32, None)
+        n = min(a.steps, 64)
+        dt = timed_sweep(kw, ex, a.warmup, n, 1, dev)
+        ms_splat, ms_gather, ms_unet = stage_times(kw)
+        r = {"value": n / dt, "unit": "frames/s", "ms_per_step": 1e3 * dt / n, "steps": n, "splat_ms": ms_splat,
+             "gather_ms": ms_gather, "unet_ms": ms_unet, "infer_path": kw.ogl.last_path,
+             "splat_frac_hbm": (12.0 * kw.N + 8.0 * sum(w * h for (w, h) in camera.level_sizes(kw.W, kw.H, 5)))
+                               / (ms_splat * 1e-3) / 1e9 / HBM_PEAK_GBS,
+             "what": kw.describe, "verified": None}
+        if not a.no_cpu_baseline:
+            _, first = cpu_leg(kw, 0, probe_threads=False)
+            r["verified"] = verify(kw, first)
+        rec["kitti6_like"] = r
+    finally:
+        kw.close()
+        del kw
+    # (3) BASELINE configs[4]: the training step
+    at = copy.copy(a)
+    at.points = 0
+    t = run_train(at, dev, street=street, steps=10, warm=2, cpu_timing=False)
+    rec["train"] = {"value": t["value"], "unit": t["unit"], "ms_per_step": t["ms_per_step"], "steps": t["steps"],
+                    "frac": t["roofline"]["frac"], "final_loss": t["final_loss"], "verified": t["verified"],
+                    "what": t["config"]["workload"]}
+    return rec
 
 
 def main():
@@ -469,40 +669,28 @@ def main():
 
     if a.config == "train":
         assert world == 1, "the training step is single-GPU (the reference's nn.DataParallel is not rebuilt)"
-        run_train(a, dev)
+        out = run_train(a, dev)
+        print(json.dumps(out), flush=True)
+        if out["verified"] is not None and not out["verified"]["ok"]:
+            print("bench.py: the training iteration does NOT reproduce the oracle: %r" % (out["verified"],), file=sys.stderr, flush=True)
+            sys.exit(3)
         return
     wl = (SlabWorkload if a.config == "slab30m" else Kitti6LikeWorkload)(a, dev, rank)
     W, H, N = wl.W, wl.H, wl.N
     ex = sweep.FrameExchange((H, W, 4), dev, torch.float32, None if a.exchange == "none" else a.exchange)
+    dt = timed_sweep(wl, ex, a.warmup, a.steps, world, dev)
 
-    sweep.run_steps(wl.render_into, ex, 0, a.warmup, N_POSES)
-    ex.drain()
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    sweep.run_steps(wl.render_into, ex, a.warmup, a.steps, N_POSES)
-    ex.drain()
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    dt = time.perf_counter() - t0
-    if world > 1:
-        t = torch.tensor([dt], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
-
-    # ---- per-kernel durations, live, with HIP events on the launch stream (rank 0)
+    # ---- every rank checks one of ITS OWN frames (the first pose it rendered) against the oracle on its host cores
     rc = 0
+    my_verified = None
+    base = None
+    if not a.no_cpu_baseline:
+        base, first = cpu_leg(wl, a.cpu_frames if (rank == 0 and world == 1) else 0, pose0=rank % N_POSES)
+        my_verified = verify(wl, first, pose=rank % N_POSES)
+    verified_ranks = sweep.gather_objects(None if my_verified is None else bool(my_verified["ok"]))
+
     if rank == 0:
-        # the rasteriser warm-starts from the previous frame, so it is timed over consecutive poses of the sweep
-        # (as in the timed loop), not over one repeated pose
-        it = iter(range(1, 10 ** 6))
-        wl.rasterize(0)
-        ms_splat = hip_time_ms(lambda: wl.rasterize(next(it) % N_POSES), 32)
-        ms_gather = hip_time_ms(lambda: wl.gather(), 10)
-        ms_unet = hip_time_ms(lambda: wl.refine(), 5)
+        ms_splat, ms_gather, ms_unet = stage_times(wl)
         prof = None
         for _ in range(3):
             cur = wl.profile()
@@ -513,12 +701,14 @@ def main():
         n_c3 = sum(1 for (_, _, _, c) in prof if c)
         all_fl = sum(fl for (_, _, fl, _) in prof)
         algorithmic_tfs = c3_fl / (c3_ms * 1e-3) / 1e12
-        # launches that ran the Winograd F(2x2,3x3) kernel execute 2.25x fewer MFMA flops than the algorithmic count
-        wino_fl = sum(fl for (_, _, fl, c) in prof if c == 2)
+        # a launch that ran a Winograd kernel executes fewer MFMA flops than the algorithmic (direct-convolution) count:
+        # F(2x2,3x3) 1/2.25 (c == 2), F(4x4,3x3) 1/4 (c == 4)
+        gain = {0: 1.0, 1: 1.0, 2: 2.25, 4: 4.0}
+        c3_exec = sum(fl / gain.get(c, 1.0) for (_, _, fl, c) in prof if c)
         n_wino = sum(1 for (_, _, _, c) in prof if c == 2)
-        c3_exec = c3_fl - wino_fl + wino_fl / 2.25
+        n_wino4 = sum(1 for (_, _, _, c) in prof if c == 4)
         executed_tfs = c3_exec / (c3_ms * 1e-3) / 1e12
-        all_exec = all_fl - wino_fl + wino_fl / 2.25
+        all_exec = sum(fl / gain.get(c, 1.0) for (_, _, fl, c) in prof)
         sizes = camera.level_sizes(W, H, 5)
         splat_bytes = 12.0 * N + 8.0 * sum(w * h for (w, h) in sizes)
         gather_bytes = 68.0 * sum(w * h for (w, h) in sizes)
@@ -533,23 +723,26 @@ def main():
                        "parallelism": f"pose-sharded x{world}", "frame_exchange": ex.mode or "none",
                        "frames_in_flight": a.frames_in_flight},
             "roofline": {
-                "kernel": ("gated_conv_wino_kernel: 3x3/s1 C->C gated conv, Winograd F(2x2,3x3) on v_mfma_f32_32x32x2_f32"
-                           if n_wino else "gated_conv_kernel 3x3/s1 C->C (v_mfma_f32_32x32x2_f32)"), "bound": "mfma",
+                "kernel": "3x3/s1 C->C gated conv family: Winograd kernels on the fp32 matrix cores "
+                          f"({n_wino} launches F(2x2,3x3), {n_wino4} launches F(4x4,3x3), {n_c3 - n_wino - n_wino4} direct)",
+                "bound": "mfma",
                 "achieved": executed_tfs, "peak": FP32_MFMA_PEAK_TFS, "unit": "TFLOP/s",
                 "frac": executed_tfs / FP32_MFMA_PEAK_TFS, "traffic": traffic,
                 "traffic_unit": f"HBM bytes per launch (rocprofv3 FETCH_SIZE*2 + WRITE_SIZE, profiles/{traffic_src})",
                 "launches_per_frame": n_c3, "avg_launch_ms": c3_ms / max(n_c3, 1),
                 "executed_flops_per_frame": c3_exec, "algorithmic_flops_per_frame": c3_fl,
-                "algorithmic_TFLOPs": algorithmic_tfs, "winograd_launches": n_wino,
+                "algorithmic_TFLOPs": algorithmic_tfs, "winograd_f2_launches": n_wino, "winograd_f4_launches": n_wino4,
                 "winograd_gain": c3_fl / c3_exec,
-                "note": "achieved = MFMA flops the launches EXECUTE / time (a Winograd launch executes 1/2.25 of the "
-                        "direct-convolution count); algorithmic_TFLOPs = SURVEY 8d's direct-convolution flops / time"},
+                "note": "achieved = MFMA flops the launches EXECUTE / time (an F(2x2,3x3) launch executes 1/2.25 of the "
+                        "direct-convolution count, an F(4x4,3x3) launch 1/4); algorithmic_TFLOPs = SURVEY 8d's "
+                        "direct-convolution flops / time"},
             "stages": {
                 "splat_ms": ms_splat, "splat_GBps": splat_bytes / (ms_splat * 1e-3) / 1e9,
                 "splat_frac_hbm": splat_bytes / (ms_splat * 1e-3) / 1e9 / HBM_PEAK_GBS,
                 "splat_algorithmic_bytes": splat_bytes,
                 "gather_ms": ms_gather, "gather_GBps": gather_bytes / (ms_gather * 1e-3) / 1e9,
-                "unet_ms": ms_unet, "unet_executed_TFLOPs": all_exec / (ms_unet * 1e-3) / 1e12,
+                "gather_frac_hbm": gather_bytes / (ms_gather * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                "unet_ms": ms_unet, "unet_launches": len(prof), "unet_executed_TFLOPs": all_exec / (ms_unet * 1e-3) / 1e12,
                 "unet_frac_mfma": all_exec / (ms_unet * 1e-3) / 1e12 / FP32_MFMA_PEAK_TFS,
                 "unet_algorithmic_TFLOPs": all_fl / (ms_unet * 1e-3) / 1e12},
             "tuning": _lib.tuning_state(),
@@ -558,18 +751,21 @@ def main():
             os.makedirs(os.path.dirname(os.path.abspath(a.detail)), exist_ok=True)
             with open(a.detail, "w") as fh:
                 json.dump([{"label": l, "ms": m, "gflop": fl / 1e9, "c3s1": c} for (l, m, fl, c) in prof], fh, indent=0)
-        out["cpu_baseline"] = None
-        out["verified"] = None
-        if not a.no_cpu_baseline:
-            base, first = cpu_leg(wl, a.cpu_frames)
-            if world == 1:
-                out["cpu_baseline"] = base
-            out["verified"] = verify(wl, first)
-            if not out["verified"]["ok"]:
-                rc = 3
+        out["cpu_baseline"] = base if world == 1 else None
+        out["verified"] = my_verified
+        out["verified_ranks"] = verified_ranks
+        if my_verified is not None and not all(bool(v) for v in verified_ranks):
+            rc = 3
+        if a.config == "slab30m" and world == 1 and not a.no_also:
+            out["also"] = also_records(a, dev, wl)
+            for k, r in out["also"].items():
+                v = r.get("verified")
+                if v is not None and not v["ok"]:
+                    rc = 3
         print(json.dumps(out), flush=True)
         if rc:
-            print("bench.py: the timed configuration does NOT reproduce the oracle frame: %r" % (out["verified"],),
+            print("bench.py: the timed configuration does NOT reproduce the oracle: %r / ranks %r / also %r"
+                  % (out["verified"], verified_ranks, {k: r.get("verified") for k, r in out.get("also", {}).items()}),
                   file=sys.stderr, flush=True)
     if hasattr(wl, "close"):
         wl.close()

@@ -285,6 +285,22 @@ int read_gate_backward(const float *dy, const float *fm, int64_t pixels, int Cou
                        float *sums, int W, int block_h, int valid_h, void *stream);
 int read_bn_param_grads(int Cout, const float *sums, const float *mean, const float *var, float eps, float *dbf, float *dbm,
                         float *dgamma, float *dbeta, void *stream);
+/* Batch-statistics BatchNorm — nn.BatchNorm2d in .train() (READ/models/unet.py:40,51; the reference's default training mode,
+ * train.py:271-279,450).  read_bn_train_forward: g = act(f) * sigmoid(m) [pixels][C] (produced with an identity BatchNorm in the
+ * params block: scale 1, shift 0) is normalised IN PLACE with the per-channel mean / biased variance of the valid pixels
+ * (fp64 accumulation): y = (g - mean) / sqrt(var + eps) * gamma + beta; separator rows of a stacked batch stay zero and do
+ * not count.  stat[2][C] receives {mean, biased var} (kept for the backward pass), params (4 * pad32(C) floats) receives the
+ * scale / shift rows, running_mean / running_var (may be NULL) move by `momentum` (variance unbiased, n / (n - 1)), scratch
+ * = 2 * C doubles.
+ * read_gate_backward_bn: read_gate_backward through that BatchNorm: two passes (sums of dy and dy * g, then
+ * dg = gamma r (dy - mean(dy) - xhat mean(dy xhat))); sums as read_gate_backward, so read_bn_param_grads(sums, stat, stat + C)
+ * gives db_f, db_m, dgamma, dbeta; abc = 3 * Cout floats of scratch. */
+int read_bn_train_forward(float *g_to_y, int64_t pixels, int C, int W, int block_h, int valid_h, const float *gamma,
+                          const float *beta, float eps, float momentum, float *running_mean, float *running_var, float *stat,
+                          float *params, double *scratch, void *stream);
+int read_gate_backward_bn(const float *dy, const float *fm, int64_t pixels, int Cout, const float *params, int elu, float *dfm,
+                          float *sums, int W, int block_h, int valid_h, const float *stat, const float *gamma, float eps,
+                          float *abc, void *stream);
 size_t read_conv_dgrad_generic_floats(int Cin, int Cout, int ksize);
 int read_conv_dgrad_generic(const float *dfm, int outH, int outW, int Cin, int Cout, int ksize, int stride, const float *wf,
                             const float *wm, float *wscratch, int inH, int inW, float *dx, void *stream);

@@ -21,8 +21,13 @@ def _t(v):
     return v if torch.is_tensor(v) else torch.from_numpy(v)
 
 
+TRAINING = False      # True inside unet_forward(..., training=True): nn.BatchNorm2d in .train() (batch statistics, momentum 0.1)
+
+
 def basic_conv(st, path, x, k, stride=1, elu=True):
-    """BasicConv.forward, unet.py:44-53: BN_eval( act(conv_f x) * sigmoid(conv_m x) ); zero padding int((k-1)/2)."""
+    """BasicConv.forward, unet.py:44-53: BN( act(conv_f x) * sigmoid(conv_m x) ); zero padding int((k-1)/2).  BN = nn.BatchNorm2d
+    (unet.py:40,51): running statistics in .eval(); in .train() the batch statistics (biased variance) normalise and the
+    running buffers move by momentum 0.1 (unbiased variance) — torch's F.batch_norm(training=True) does both in place."""
     pad = int((k - 1) / 2)
     b = path + ".block."
     f = F.conv2d(x, _t(st[b + "conv_f.weight"]), _t(st[b + "conv_f.bias"]), stride=stride, padding=pad)
@@ -31,7 +36,7 @@ def basic_conv(st, path, x, k, stride=1, elu=True):
         f = F.elu(f)
     y = f * torch.sigmoid(m)
     return F.batch_norm(y, _t(st[b + "norm.running_mean"]), _t(st[b + "norm.running_var"]),
-                        _t(st[b + "norm.weight"]), _t(st[b + "norm.bias"]), training=False, eps=1e-5)
+                        _t(st[b + "norm.weight"]), _t(st[b + "norm.bias"]), training=TRAINING, momentum=0.1, eps=1e-5)
 
 
 def res_blocks(st, prefix, x):
@@ -62,8 +67,18 @@ def aff(st, name, xs):
     return basic_conv(st, name + ".conv.1", y, 3, elu=False)
 
 
-def unet_forward(st, x, x2, x4, x8, taps=None):
-    """UNet.forward, unet.py:202-285.  `taps` (dict) optionally receives named intermediates."""
+def unet_forward(st, x, x2, x4, x8, taps=None, training=False):
+    """UNet.forward, unet.py:202-285.  `taps` (dict) optionally receives named intermediates.  training=True: the module in
+    .train() — every BatchNorm uses batch statistics and updates st's running_mean / running_var tensors in place."""
+    global TRAINING
+    prev, TRAINING = TRAINING, bool(training)
+    try:
+        return _unet_forward(st, x, x2, x4, x8, taps)
+    finally:
+        TRAINING = prev
+
+
+def _unet_forward(st, x, x2, x4, x8, taps=None):
     def tap(name, v):
         if taps is not None:
             taps[name] = v

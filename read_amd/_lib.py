@@ -89,6 +89,8 @@ SIGNATURES = {
     "read_gate_forward": (_i, [_vp, _i64, _i, _vp, _i, _vp, _vp, _i, _i, _i, _vp]),
     "read_gate_backward": (_i, [_vp, _vp, _i64, _i, _vp, _i, _vp, _vp, _i, _i, _i, _vp]),
     "read_bn_param_grads": (_i, [_i, _vp, _vp, _vp, _f, _vp, _vp, _vp, _vp, _vp]),
+    "read_bn_train_forward": (_i, [_vp, _i64, _i, _i, _i, _i, _vp, _vp, _f, _f, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "read_gate_backward_bn": (_i, [_vp, _vp, _i64, _i, _vp, _i, _vp, _vp, _i, _i, _i, _vp, _vp, _f, _vp, _vp]),
     "read_conv_dgrad_generic_floats": (_sz, [_i, _i, _i]),
     "read_conv_dgrad_generic": (_i, [_vp, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp, _i, _i, _vp, _vp]),
     "read_conv_wgrad_scratch_floats": (_sz, [_i, _i, _i, _i]),

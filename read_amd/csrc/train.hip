@@ -167,12 +167,17 @@ __global__ __launch_bounds__(256) void gate_forward_kernel(const float *__restri
 // sums[4][Cout] += { sum df, sum dm, sum dy, sum dy * g }  with g = act(f) * sigmoid(m)   (db_f, db_m, dbeta, dgamma pieces)
 // One workgroup = 64 pixels x all channels (thread t: channel t % CW ... ), block-level partial sums in LDS, one
 // atomicAdd per channel and workgroup.
+// mode 0: BatchNorm as the eval-mode affine map, dg = dy * scale.
+// Batch-statistics BatchNorm (nn.BatchNorm2d in .train(), unet.py:40,51) needs the per-channel sums of dy and dy * g BEFORE any
+// dg can be formed (dg = gamma r (dy - mean(dy) - xhat mean(dy xhat))), so its backward is two passes of this kernel:
+// mode 1: only the sums {., ., sum dy, sum dy * g} (no dfm written);  mode 2: dg = A dy + B + C g with the per-channel constants
+// abc[3][Cout] that bn_bwd_coeff_kernel derives from the mode-1 sums.
 template <int CW>
 __global__ __launch_bounds__(256) void gate_backward_kernel(const float *__restrict__ dy, const float *__restrict__ fm,
                                                             long long pixels, int Cout, int CoutPad, int Cp,
                                                             const float *__restrict__ params, int elu,
                                                             float *__restrict__ dfm, float *__restrict__ sums, int W, int block_h,
-                                                            int valid_h)
+                                                            int valid_h, int mode, const float *__restrict__ abc)
 {
     constexpr int ROWS = 256 / CW;                       // pixels handled concurrently by a workgroup
     __shared__ float red[4][256];
@@ -181,6 +186,8 @@ __global__ __launch_bounds__(256) void gate_backward_kernel(const float *__restr
         const int c = cb + c0;
         const bool ok = c < Cout;
         const float sc = ok ? params[2 * CoutPad + c] : 0.0f;
+        const float cA = (ok && mode == 2) ? abc[c] : 0.0f, cB = (ok && mode == 2) ? abc[Cout + c] : 0.0f,
+                    cC = (ok && mode == 2) ? abc[2 * Cout + c] : 0.0f;
         float s_df = 0.f, s_dm = 0.f, s_dy = 0.f, s_dyg = 0.f;
         for (long long p = (long long)blockIdx.x * ROWS + r; p < pixels; p += (long long)gridDim.x * ROWS) {
             float df = 0.f, dm = 0.f;
@@ -190,7 +197,7 @@ __global__ __launch_bounds__(256) void gate_backward_kernel(const float *__restr
                 const float a = elu ? (f > 0.0f ? f : fast_exp(f) - 1.0f) : f;
                 const float da = elu ? (f > 0.0f ? 1.0f : a + 1.0f) : 1.0f;          // ELU'(f) = exp(f) = a + 1 for f <= 0
                 const float s = __builtin_amdgcn_rcpf(1.0f + fast_exp(-m));
-                const float gs = g * sc;                                             // through the BatchNorm scale
+                const float gs = mode == 2 ? cA * g + cB + cC * (a * s) : g * sc;   // through the BatchNorm (eval: its scale)
                 df = gs * s * da;
                 dm = gs * a * s * (1.0f - s);
                 s_df += df;
@@ -198,7 +205,7 @@ __global__ __launch_bounds__(256) void gate_backward_kernel(const float *__restr
                 s_dy += g;
                 s_dyg += g * (a * s);
             }
-            if (c < Cp) {
+            if (c < Cp && mode != 1) {
                 dfm[p * 2 * Cp + c] = df;
                 dfm[p * 2 * Cp + Cp + c] = dm;
             }
@@ -231,6 +238,93 @@ __global__ void bn_grads_kernel(int Cout, const float *sums, const float *mean, 
     if (dbm) dbm[c] += sums[Cout + c];
     if (dbeta) dbeta[c] += sums[2 * Cout + c];
     if (dgamma) dgamma[c] += (sums[3 * Cout + c] - mean[c] * sums[2 * Cout + c]) * rstd;
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Batch-statistics BatchNorm (model.train(): the reference's default, train.py:271-279,450 -> nn.BatchNorm2d of
+// unet.py:40,51 normalises with the statistics of the batch and moves its running buffers).
+//   forward : g = act(f) * sigmoid(m) is produced by the linear launch / gate pass with an identity BatchNorm (scale 1, shift 0);
+//             bn_stats_kernel   per-channel sum g, sum g^2 over the valid pixels, accumulated in fp64
+//             bn_finalize_kernel mean, biased variance -> scale = gamma r, shift = beta - mean scale; running buffers:
+//                               rm = (1 - mom) rm + mom mean, rv = (1 - mom) rv + mom var n / (n - 1)   (torch's update)
+//             bn_apply_kernel   y = g scale + shift in place (separator rows of a stacked batch stay zero)
+//   backward: gate_backward_kernel mode 1 (sums) -> bn_bwd_coeff_kernel -> gate_backward_kernel mode 2
+// ---------------------------------------------------------------------------------------------------------------------
+template <int CW>
+__global__ __launch_bounds__(256) void bn_stats_kernel(const float *__restrict__ g, long long pixels, int C, double *__restrict__ sums,
+                                                       int W, int block_h, int valid_h)
+{
+    constexpr int ROWS = 256 / CW;
+    __shared__ double red[2][256];
+    const int c0 = threadIdx.x % CW, r = threadIdx.x / CW;
+    for (int cb = 0; cb < C; cb += CW) {
+        const int c = cb + c0;
+        const bool ok = c < C;
+        double s1 = 0.0, s2 = 0.0;
+        if (ok)
+            for (long long p = (long long)blockIdx.x * ROWS + r; p < pixels; p += (long long)gridDim.x * ROWS) {
+                if (separator_row(p, W, block_h, valid_h)) continue;
+                const double v = (double)g[p * C + c];
+                s1 += v;
+                s2 += v * v;
+            }
+        red[0][threadIdx.x] = s1;
+        red[1][threadIdx.x] = s2;
+        __syncthreads();
+        if (threadIdx.x < CW && ok) {
+            double t0 = 0.0, t1 = 0.0;
+            for (int k = 0; k < ROWS; ++k) {
+                t0 += red[0][k * CW + threadIdx.x];
+                t1 += red[1][k * CW + threadIdx.x];
+            }
+            atomicAdd(sums + c, t0);
+            atomicAdd(sums + C + c, t1);
+        }
+        __syncthreads();
+    }
+}
+
+__global__ void bn_finalize_kernel(int C, int CoutPad, const double *sums, double count, const float *gamma, const float *beta,
+                                   float eps, float momentum, float *running_mean, float *running_var, float *stat, float *params)
+{
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    const double mean = sums[c] / count;
+    double var = sums[C + c] / count - mean * mean;
+    var = var > 0.0 ? var : 0.0;
+    const float mf = (float)mean, vf = (float)var;
+    stat[c] = mf;
+    stat[C + c] = vf;
+    const float sc = gamma[c] / sqrtf(vf + eps);
+    params[2 * CoutPad + c] = sc;
+    params[3 * CoutPad + c] = beta[c] - mf * sc;
+    if (running_mean) running_mean[c] = (1.0f - momentum) * running_mean[c] + momentum * mf;
+    if (running_var) running_var[c] = (1.0f - momentum) * running_var[c] + momentum * (float)(count > 1.0 ? var * count / (count - 1.0) : var);
+}
+
+__global__ __launch_bounds__(256) void bn_apply_kernel(float *__restrict__ y, long long pixels, int C, int CoutPad,
+                                                       const float *__restrict__ params, int W, int block_h, int valid_h)
+{
+    const long long total = pixels * C;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+        const long long p = i / C;
+        const int c = (int)(i - p * C);
+        y[i] = separator_row(p, W, block_h, valid_h) ? 0.0f : y[i] * params[2 * CoutPad + c] + params[3 * CoutPad + c];
+    }
+}
+
+// abc[3][C]: dg = A dy + B + C' g with A = gamma r, C' = -A r dgamma / n, B = -A dbeta / n - C' mean,
+// dbeta = sum dy, dgamma = (sum dy g - mean sum dy) r      (sums rows 2, 3 of gate_backward_kernel mode 1)
+__global__ void bn_bwd_coeff_kernel(int C, const float *sums, const float *stat, const float *gamma, float eps, float count, float *abc)
+{
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    const float mean = stat[c], r = 1.0f / sqrtf(stat[C + c] + eps);
+    const float dbeta = sums[2 * C + c], dgamma = (sums[3 * C + c] - mean * dbeta) * r;
+    const float A = gamma[c] * r, Cc = -A * r * dgamma / count;
+    abc[c] = A;
+    abc[C + c] = -A * dbeta / count - Cc * mean;
+    abc[2 * C + c] = Cc;
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
@@ -672,11 +766,70 @@ extern "C" int read_gate_backward(const float *dy, const float *fm, int64_t pixe
     if (Cp <= 8) {
         const int blocks = grid_for(pixels, 32, 2048);
         hipLaunchKernelGGL(gate_backward_kernel<8>, dim3(blocks), dim3(256), 0, as_stream(stream), dy, fm, (long long)pixels, Cout,
-                           CoutPad, Cp, params, elu, dfm, sums, W, block_h, valid_h);
+                           CoutPad, Cp, params, elu, dfm, sums, W, block_h, valid_h, 0, (const float *)nullptr);
     } else {
         const int blocks = grid_for(pixels, 8, 2048);
         hipLaunchKernelGGL(gate_backward_kernel<32>, dim3(blocks), dim3(256), 0, as_stream(stream), dy, fm, (long long)pixels, Cout,
-                           CoutPad, Cp, params, elu, dfm, sums, W, block_h, valid_h);
+                           CoutPad, Cp, params, elu, dfm, sums, W, block_h, valid_h, 0, (const float *)nullptr);
+    }
+    READ_CHECK_LAUNCH();
+    return READ_OK;
+}
+
+static long long valid_pixels(int64_t pixels, int W, int block_h, int valid_h)
+{
+    if (block_h <= 0) return pixels;
+    const long long rows = pixels / W, full = rows / block_h, rem = rows % block_h;
+    return (full * valid_h + (rem < valid_h ? rem : valid_h)) * W;
+}
+
+extern "C" int read_bn_train_forward(float *g_to_y, int64_t pixels, int C, int W, int block_h, int valid_h, const float *gamma,
+                                     const float *beta, float eps, float momentum, float *running_mean, float *running_var,
+                                     float *stat, float *params, double *scratch, void *stream)
+{
+    READ_CHECK_ARG(g_to_y && gamma && beta && stat && params && scratch && pixels >= 1 && C >= 1,
+                   "read_bn_train_forward: null pointer or empty tensor");
+    READ_CHECK_ARG(block_h == 0 || (W >= 1 && valid_h >= 1 && valid_h <= block_h), "read_bn_train_forward: bad block geometry");
+    if (W < 1) W = 1;
+    const long long n = valid_pixels(pixels, W, block_h, valid_h);
+    READ_CHECK_ARG(n >= 1, "read_bn_train_forward: no valid pixel");
+    const int CoutPad = (C + 31) / 32 * 32;
+    READ_CHECK_HIP(hipMemsetAsync(scratch, 0, sizeof(double) * 2 * (size_t)C, as_stream(stream)));
+    if (C <= 8)
+        hipLaunchKernelGGL(bn_stats_kernel<8>, dim3(grid_for(pixels, 32, 1024)), dim3(256), 0, as_stream(stream), g_to_y,
+                           (long long)pixels, C, scratch, W, block_h, valid_h);
+    else
+        hipLaunchKernelGGL(bn_stats_kernel<32>, dim3(grid_for(pixels, 8, 1024)), dim3(256), 0, as_stream(stream), g_to_y,
+                           (long long)pixels, C, scratch, W, block_h, valid_h);
+    hipLaunchKernelGGL(bn_finalize_kernel, dim3(ceil_div(C, 64)), dim3(64), 0, as_stream(stream), C, CoutPad, scratch, (double)n,
+                       gamma, beta, eps, momentum, running_mean, running_var, stat, params);
+    hipLaunchKernelGGL(bn_apply_kernel, dim3(grid_for(pixels * C)), dim3(256), 0, as_stream(stream), g_to_y, (long long)pixels, C,
+                       CoutPad, params, W, block_h, valid_h);
+    READ_CHECK_LAUNCH();
+    return READ_OK;
+}
+
+extern "C" int read_gate_backward_bn(const float *dy, const float *fm, int64_t pixels, int Cout, const float *params, int elu,
+                                     float *dfm, float *sums, int W, int block_h, int valid_h, const float *stat,
+                                     const float *gamma, float eps, float *abc, void *stream)
+{
+    READ_CHECK_ARG(dy && fm && params && dfm && sums && stat && gamma && abc && pixels >= 1 && Cout >= 1,
+                   "read_gate_backward_bn: null pointer or empty tensor");
+    READ_CHECK_ARG(block_h == 0 || (W >= 1 && valid_h >= 1 && valid_h <= block_h), "read_gate_backward_bn: bad block geometry");
+    if (W < 1) W = 1;
+    const int Cp = (Cout + 7) / 8 * 8, CoutPad = (Cout + 31) / 32 * 32;
+    const long long n = valid_pixels(pixels, W, block_h, valid_h);
+    for (int mode = 1; mode <= 2; ++mode) {
+        READ_CHECK_HIP(hipMemsetAsync(sums, 0, sizeof(float) * 4 * (size_t)Cout, as_stream(stream)));
+        if (Cp <= 8)
+            hipLaunchKernelGGL(gate_backward_kernel<8>, dim3(grid_for(pixels, 32, 2048)), dim3(256), 0, as_stream(stream), dy, fm,
+                               (long long)pixels, Cout, CoutPad, Cp, params, elu, dfm, sums, W, block_h, valid_h, mode, (const float *)abc);
+        else
+            hipLaunchKernelGGL(gate_backward_kernel<32>, dim3(grid_for(pixels, 8, 2048)), dim3(256), 0, as_stream(stream), dy, fm,
+                               (long long)pixels, Cout, CoutPad, Cp, params, elu, dfm, sums, W, block_h, valid_h, mode, (const float *)abc);
+        if (mode == 1)
+            hipLaunchKernelGGL(bn_bwd_coeff_kernel, dim3(ceil_div(Cout, 64)), dim3(64), 0, as_stream(stream), Cout, sums, stat, gamma,
+                               eps, (float)n, abc);
     }
     READ_CHECK_LAUNCH();
     return READ_OK;

@@ -2,8 +2,8 @@
 
 This is the hot loop of the reference's viewer (viewer.py:263-285 -> READ/gl/nn.py:113-129 ->
 READ/datasets/dynamic.py:66-99 -> READ/models/compose.py:125-181) with every stage resident on
-one MI355X: 2 rasteriser launches + 1 gather launch + 102 UNet launches, three C calls, no host
-round trips, no per-frame allocation.
+one MI355X: the rasteriser's launches + 1 gather launch + the UNet plan's launches (counts: DESIGN.md §3), three C calls,
+no host round trips, no per-frame allocation.
 """
 import numpy as np
 import torch
@@ -54,10 +54,21 @@ class FrameRenderer:
         self.frame_done = None
         self._slots = []
         self._calls = 0
+        self._raster_stream = None
+        self.set_frames_in_flight(frames_in_flight)
+
+    def set_frames_in_flight(self, frames_in_flight):
+        """1 = one frame at a time on the caller's stream (the viewer's mode); F > 1 = F UNet plans / streams (see __init__).
+        Waits for the frames in flight before switching."""
+        self.sync()
+        self._slots = []
+        self._calls = 0
+        self.frame_done = None
         if frames_in_flight > 1:
-            self._raster_stream = torch.cuda.Stream(self.device)
+            if self._raster_stream is None:
+                self._raster_stream = torch.cuda.Stream(self.device)
             for _ in range(int(frames_in_flight)):
-                slot = {"feat": [torch.empty_like(f) for f in self.feat], "unet": UNetEngine(self.packed, H, W),
+                slot = {"feat": [torch.empty_like(f) for f in self.feat], "unet": UNetEngine(self.packed, self.H, self.W),
                         "stream": torch.cuda.Stream(self.device), "ready": torch.cuda.Event(), "done": torch.cuda.Event()}
                 slot["done"].record(torch.cuda.current_stream(self.device))
                 self._slots.append(slot)

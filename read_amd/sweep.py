@@ -45,6 +45,16 @@ def broadcast_scene_from_rank0(make, device):
     return broadcast_scene(tensors, 0)
 
 
+def gather_objects(obj):
+    """One small Python object per rank -> the list in rank order on every rank (``[obj]`` without a process group).
+    bench.py uses it for ``verified_ranks``: every rank checks one of ITS OWN frames against the oracle."""
+    if not _dist_on():
+        return [obj]
+    out = [None] * dist.get_world_size()
+    dist.all_gather_object(out, obj)
+    return out
+
+
 class FrameExchange:
     """Double-buffered exchange of finished frames: while the frames of step i are on the wire (async collective),
     step i+1 is rendered into the other buffer.

@@ -114,10 +114,11 @@ class _RangeCheck:
 
     def __init__(self):
         self.pending = []          # (event, pinned flag tensor, n)
+        self.free = []             # pinned one-int buffers whose copy has landed
 
     def queue(self, ids, n):
-        flag = torch.empty(1, dtype=torch.int32).pin_memory()
-        flag.copy_(torch.stack([ids.max()]).to(torch.int32), non_blocking=True)
+        flag = self.free.pop() if self.free else torch.empty(1, dtype=torch.int32).pin_memory()
+        flag.copy_(ids.max().to(torch.int32).reshape(1), non_blocking=True)
         ev = torch.cuda.Event()
         ev.record()
         self.pending.append((ev, flag, n))
@@ -128,9 +129,11 @@ class _RangeCheck:
             if wait:
                 ev.synchronize()
             if ev.query():
-                if int(flag[0]) >= n:
+                worst = int(flag[0])
+                self.free.append(flag)
+                if worst >= n:
                     self.pending = []
-                    raise IndexError(f"point id {int(flag[0])} out of range for a descriptor table of {n} points "
+                    raise IndexError(f"point id {worst} out of range for a descriptor table of {n} points "
                                      f"(wrong texture for this scene?)")
             else:
                 keep.append((ev, flag, n))

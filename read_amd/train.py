@@ -15,9 +15,10 @@ HIP kernels of csrc/train.hip + csrc/conv.hip:
 
 The graph around the convolutions (torch.cat, nearest resampling, FAM's product, residual adds) is expressed with torch
 tensor ops on the device so that autograd does the bookkeeping of the 99-layer graph; every FLOP-carrying node is HIP.
-BatchNorm runs as the eval-mode affine map with trainable gamma/beta — the configuration the reference trains with
-(configs/train_example.yaml ``eval_in_train: True``; train.py:271-277 puts the model in ``.eval()``); batch-statistics
-BatchNorm (``model.train()``) raises.
+BatchNorm: with the net in ``.eval()`` (configs/train_example.yaml ``eval_in_train: True``; train.py:271-277) it is the
+eval-mode affine map with trainable gamma/beta; with the net in ``.train()`` (the reference's default, train.py:450) every
+layer normalises with the statistics of the batch and moves its running buffers (``read_bn_train_forward`` /
+``read_gate_backward_bn``), exactly what nn.BatchNorm2d does in the reference's BasicConv (unet.py:40,51).
 """
 import ctypes as C
 import weakref
@@ -27,6 +28,7 @@ import torch
 from . import _lib
 
 BN_EPS = 1e-5
+BN_MOMENTUM = 0.1          # nn.BatchNorm2d default (unet.py:40)
 
 
 def _ptr(t):
@@ -92,6 +94,25 @@ def _queue_join(dev):
 _ZERO_PARAMS = {}
 
 
+def _bump_version(*tensors):
+    inc = getattr(torch._C, '_increment_version', None)
+    if inc is not None:
+        inc(list(tensors))
+    else:
+        for t in tensors:
+            t.add_(0)
+
+
+_CONST_VECS = {}
+
+
+def _const_vec(n, value, dev):
+    v = _CONST_VECS.get((n, value, dev))
+    if v is None:
+        v = _CONST_VECS[(n, value, dev)] = torch.full((n,), value, dtype=torch.float32, device=dev)
+    return v
+
+
 def _zero_params(n, dev):
     """An all-zero parameter block (bias / scale / shift of the dgrad's virtual layer): read-only, one per size and device."""
     z = _ZERO_PARAMS.get((n, dev))
@@ -100,10 +121,15 @@ def _zero_params(n, dev):
     return z
 
 
-def _packed_for(wf, bf, wm, bm, gamma, beta, mean, var, cin, cout, k):
+def _packed_for(wf, bf, wm, bm, gamma, beta, mean, var, cin, cout, k, identity_bn=False):
+    """identity_bn (batch-statistics mode): the params block carries the two biases and scale 1 / shift 0 — the launch then
+    stores g = act(f) * sigmoid(m) itself and read_bn_train_forward normalises it."""
     L = _lib.lib()
     st = _lib.stream_ptr()
-    ver = tuple(t._version for t in (wf, bf, wm, bm, gamma, beta, mean, var)) + (wf.data_ptr(), wm.data_ptr())
+    if identity_bn:
+        ver = tuple(t._version for t in (wf, bf, wm, bm)) + (wf.data_ptr(), wm.data_ptr(), 'identity')
+    else:
+        ver = tuple(t._version for t in (wf, bf, wm, bm, gamma, beta, mean, var)) + (wf.data_ptr(), wm.data_ptr())
     hit = _PACK_CACHE.get(id(wf))
     if hit is not None and hit[6]() is not wf:              # the id was recycled by another tensor: not this layer's entry
         hit = None
@@ -117,8 +143,13 @@ def _packed_for(wf, bf, wm, bm, gamma, beta, mean, var, cin, cout, k):
         return hit
     dev = wf.device
     params = torch.empty(L.read_conv_param_floats(cout), dtype=torch.float32, device=dev)
-    _lib.check(L.read_conv_pack_params_device(cout, _ptr(bf.detach()), _ptr(bm.detach()), _ptr(gamma.detach()),
-                                              _ptr(beta.detach()), _ptr(mean), _ptr(var), BN_EPS, params.data_ptr(), st))
+    if identity_bn:
+        one, zero = _const_vec(cout, 1.0, dev), _const_vec(cout, 0.0, dev)
+        _lib.check(L.read_conv_pack_params_device(cout, _ptr(bf.detach()), _ptr(bm.detach()), one.data_ptr(), zero.data_ptr(),
+                                                  zero.data_ptr(), one.data_ptr(), 0.0, params.data_ptr(), st))      # 1 / sqrt(1 + 0) = 1
+    else:
+        _lib.check(L.read_conv_pack_params_device(cout, _ptr(bf.detach()), _ptr(bm.detach()), _ptr(gamma.detach()),
+                                                  _ptr(beta.detach()), _ptr(mean), _ptr(var), BN_EPS, params.data_ptr(), st))
     wf_c, wm_c = wf.detach().contiguous(), wm.detach().contiguous()
     wp = torch.empty(L.read_conv_packed_floats(cin, cout, k), dtype=torch.float32, device=dev)
     _lib.check(L.read_conv_pack_weights_device(cin, cout, k, _kc_for(cin), wf_c.data_ptr(), wm_c.data_ptr(), wp.data_ptr(), st))
@@ -167,7 +198,7 @@ class GatedConvFn(torch.autograd.Function):
     """y = BN_eval(act(conv_f(x) + b_f) * sigmoid(conv_m(x) + b_m)) for ONE image, x (H,W,Cin) NHWC -> (Ho,Wo,Cout)."""
 
     @staticmethod
-    def forward(ctx, x, wf, bf, wm, bm, gamma, beta, mean, var, k, stride, elu, nb=1, v_num=1, v_den=1):
+    def forward(ctx, x, wf, bf, wm, bm, gamma, beta, mean, var, k, stride, elu, nb=1, v_num=1, v_den=1, bn_train=False):
         L = _lib.lib()
         st = _lib.stream_ptr()
         x = x.contiguous()
@@ -177,7 +208,7 @@ class GatedConvFn(torch.autograd.Function):
         Ho, Wo = (H + 2 * pad - k) // stride + 1, (W + 2 * pad - k) // stride + 1
         dev = x.device
         wf_c, wm_c = wf.detach().contiguous(), wm.detach().contiguous()
-        entry = _packed_for(wf, bf, wm, bm, gamma, beta, mean, var, cin, cout, k)
+        entry = _packed_for(wf, bf, wm, bm, gamma, beta, mean, var, cin, cout, k, identity_bn=bn_train)
         params, wp = entry[1], entry[2]
         ctx.pack = entry
         side = _SIDE.get(dev)
@@ -193,7 +224,20 @@ class GatedConvFn(torch.autograd.Function):
         _linear_conv(x, cin, wp, params, cout, k, stride, fm, wino=wino, gated=(y, elu, bh, vh))
         if wino is None:
             _lib.check(L.read_gate_forward(fm.data_ptr(), Ho * Wo, cout, params.data_ptr(), int(elu), None, y.data_ptr(), Wo, bh, vh, st))
-        ctx.save_for_backward(x, fm, params, wf_c, wm_c, mean, var)
+        stat = None
+        if bn_train:
+            # y holds g = act(f) * sigmoid(m) so far: normalise it with the batch statistics, in place; the module's running
+            # buffers (mean, var ARE the buffers) move as nn.BatchNorm2d's do — no autograd through them
+            stat = torch.empty((2, cout), dtype=torch.float32, device=dev)
+            bn_params = torch.empty_like(params)
+            scratch = torch.empty(2 * cout, dtype=torch.float64, device=dev)
+            _lib.check(L.read_bn_train_forward(y.data_ptr(), Ho * Wo, cout, Wo, bh, vh, gamma.detach().data_ptr(),
+                                               beta.detach().data_ptr(), BN_EPS, BN_MOMENTUM, mean.data_ptr(), var.data_ptr(),
+                                               stat.data_ptr(), bn_params.data_ptr(), scratch.data_ptr(), st), "read_bn_train_forward")
+            _bump_version(mean, var)                 # written through raw pointers: caches keyed on ._version must see it
+            mean, var = stat[0], stat[1]
+        ctx.bn_train = bool(bn_train)
+        ctx.save_for_backward(x, fm, params, wf_c, wm_c, mean, var, gamma.detach() if bn_train else mean)
         ctx.cfg = (k, stride, int(elu), H, W, cin, cout, Ho, Wo, bh, vh)
         ctx.wrefs = (weakref.ref(wf), weakref.ref(wm))
         return y
@@ -202,15 +246,23 @@ class GatedConvFn(torch.autograd.Function):
     def backward(ctx, dy):
         L = _lib.lib()
         st = _lib.stream_ptr()
-        x, fm, params, wf, wm, mean, var = ctx.saved_tensors
+        x, fm, params, wf, wm, mean, var, gamma_d = ctx.saved_tensors
         k, stride, elu, H, W, cin, cout, Ho, Wo, bh, vh = ctx.cfg
         dev = x.device
         dy = dy.contiguous()
         cp = (cout + 7) // 8 * 8
         dfm = torch.empty((Ho, Wo, 2 * cp), dtype=torch.float32, device=dev)
         sums = torch.empty((4, cout), dtype=torch.float32, device=dev)
-        _lib.check(L.read_gate_backward(dy.data_ptr(), fm.data_ptr(), Ho * Wo, cout, params.data_ptr(), elu, dfm.data_ptr(),
-                                        sums.data_ptr(), Wo, bh, vh, st))
+        if ctx.bn_train:
+            stat = torch.stack([mean, var]).contiguous()              # batch mean / biased variance of the forward pass
+            abc = torch.empty((3, cout), dtype=torch.float32, device=dev)
+            _lib.check(L.read_gate_backward_bn(dy.data_ptr(), fm.data_ptr(), Ho * Wo, cout, params.data_ptr(), elu, dfm.data_ptr(),
+                                               sums.data_ptr(), Wo, bh, vh, stat.data_ptr(), gamma_d.data_ptr(), BN_EPS,
+                                               abc.data_ptr(), st), "read_gate_backward_bn")
+            mean, var = stat[0], stat[1]
+        else:
+            _lib.check(L.read_gate_backward(dy.data_ptr(), fm.data_ptr(), Ho * Wo, cout, params.data_ptr(), elu, dfm.data_ptr(),
+                                            sums.data_ptr(), Wo, bh, vh, st))
         ev_dfm = None
         if WGRAD_SIDE_STREAM:
             ev_dfm = torch.cuda.Event()
@@ -246,7 +298,7 @@ class GatedConvFn(torch.autograd.Function):
                 _lib.check(L.read_conv_dgrad_generic(dfm.data_ptr(), Ho, Wo, cin, cout, k, stride, wf.data_ptr(), wm.data_ptr(),
                                                      ws.data_ptr(), H, W, dx.data_ptr(), st))
         if not (ctx.needs_input_grad[1] or ctx.needs_input_grad[3]):        # frozen net: nobody asked for weight gradients
-            return dx, None, dbf, None, dbm, dgamma, dbeta, None, None, None, None, None, None, None, None
+            return dx, None, dbf, None, dbm, dgamma, dbeta, None, None, None, None, None, None, None, None, None
         dwf, dwm = torch.empty_like(wf), torch.empty_like(wm)
         n_scr = L.read_conv_wgrad_scratch_floats(cin, cout, k, Ho)
         scratch = torch.empty(n_scr, dtype=torch.float32, device=dev)
@@ -279,7 +331,7 @@ class GatedConvFn(torch.autograd.Function):
         else:
             _lib.check(L.read_conv_wgrad(x.data_ptr(), H, W, cin, dfm.data_ptr(), cout, k, stride, dwf.data_ptr(), dwm.data_ptr(), 0,
                                          scratch.data_ptr(), n_scr, st))
-        return dx, dwf, dbf, dwm, dbm, dgamma, dbeta, None, None, None, None, None, None, None, None
+        return dx, dwf, dbf, dwm, dbm, dgamma, dbeta, None, None, None, None, None, None, None, None, None
 
 
 class Up4Fn(torch.autograd.Function):
@@ -338,8 +390,11 @@ def _bc(net, path, x, k, stride=1, elu=True, blk=(1, 1, 1)):
         node = node._modules[p]
     b = node.block
     n = b['norm']
+    bn_train = bool(net.training)
+    if bn_train and n.num_batches_tracked is not None:
+        n.num_batches_tracked += 1                      # nn.BatchNorm2d bookkeeping (momentum is fixed, so only a counter)
     return GatedConvFn.apply(x, b['conv_f'].weight, b['conv_f'].bias, b['conv_m'].weight, b['conv_m'].bias, n.weight, n.bias,
-                             n.running_mean, n.running_var, k, stride, elu, *blk)
+                             n.running_mean, n.running_var, k, stride, elu, *blk, bn_train)
 
 
 def _res_blocks(net, prefix, x, blk):

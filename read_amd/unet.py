@@ -210,15 +210,13 @@ class UNet(nn.Module):
         inputs = list(inputs)
         if len(inputs) < 4:
             raise ValueError("UNet.forward needs the 1, 1/2, 1/4 and 1/8 scale inputs")
-        if self.training:
-            raise NotImplementedError(
-                "batch-statistics BatchNorm (model.train()) is not built: train with the model in .eval(), i.e. "
-                "eval_in_train: True as in the reference's configs/train_example.yaml (train.py:271-277)")
         _lib.require_gpu()
         dev = next(self.parameters()).device
         wants_grad = torch.is_grad_enabled() and (any(p.requires_grad for p in self.parameters())
                                                   or any(torch.is_tensor(x) and x.requires_grad for x in inputs[:4]))
-        if wants_grad:
+        if wants_grad or self.training:
+            # .train(): batch-statistics BatchNorm (the reference's default training mode, train.py:271-279,450) lives in
+            # the layer-by-layer graph, with or without gradients; the fused inference plan folds the RUNNING statistics
             # training step: every BasicConv is an autograd node backed by the HIP kernels of csrc/train.hip
             from .train import unet_forward_train_batch
             return unet_forward_train_batch(self, [x.to(dev, torch.float32) for x in inputs[:4]])

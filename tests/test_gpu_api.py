@@ -179,3 +179,48 @@ def test_scene_directory_and_checkpoints_to_frame(hip, tmp_path):
         with torch.no_grad():
             ref = unet_torch.net_and_texture_forward(state, tex.texture_.detach().cpu().numpy(), oi)[0]
         assert unet_torch.psnr(out[..., :3].permute(2, 0, 1).cpu(), ref) >= 120.0, f"camera {k}"
+
+
+def test_out_of_range_ids_raise_without_a_sync_per_frame(hip):
+    """NetAndTexture's all-uv path checks the point ids of a lookup asynchronously (the reference's index_select reports them
+    through an asynchronous device assert): the IndexError surfaces at the next lookup or at check_ids()."""
+    from read_amd.net_texture import NetAndTexture
+    from read_amd.texture import PointTexture
+    W, H, N = 64, 48, 500
+    net = UNet()
+    model = NetAndTexture(net, {0: PointTexture(8, N, init_method='rand')})
+    model.load_textures(0)
+    model.cuda().eval()
+    good = {'id': 0}
+    bad = {'id': 0}
+    for l, k in enumerate(FMT.replace(' ', '').split(',')):
+        good[k] = torch.randint(0, N, (1, 1, H >> l, W >> l)).float()
+        bad[k] = good[k].clone()
+    bad['uv_1d_p1'][0, 0, 3, 5] = float(N + 7)
+    with torch.no_grad():
+        model(dict(good))
+        model.check_ids()                                          # nothing wrong so far
+        model(dict(bad))                                           # the gather clamps; the verdict is queued
+        with pytest.raises(IndexError):
+            model.check_ids()
+        model(dict(good))
+        model.check_ids()
+
+
+def test_bilinear_down_equals_torch_interpolate(hip):
+    """compose.py:162-163 for network inputs that mix non-uv tokens with texture samples: the HIP node against
+    F.interpolate(scale_factor=1/ss, mode='bilinear'), forward and adjoint."""
+    import torch.nn.functional as F
+    from read_amd.texture import bilinear_down
+    rng = np.random.default_rng(9)
+    for ss, shape in ((2, (2, 5, 12, 20)), (3, (1, 3, 9, 15)), (4, (1, 11, 16, 8))):
+        x = torch.from_numpy(rng.standard_normal(shape).astype(np.float32))
+        xr = x.clone().requires_grad_(True)
+        yr = F.interpolate(xr, scale_factor=1. / ss, mode='bilinear')
+        g = torch.from_numpy(rng.standard_normal(tuple(yr.shape)).astype(np.float32))
+        yr.backward(g)
+        xd = x.cuda().requires_grad_(True)
+        y = bilinear_down(xd, ss)
+        torch.testing.assert_close(y.cpu(), yr.detach(), rtol=1e-5, atol=1e-6)
+        y.backward(g.cuda())
+        torch.testing.assert_close(xd.grad.cpu(), xr.grad, rtol=1e-5, atol=1e-6)

@@ -132,9 +132,105 @@ def test_unet_training_graph_vs_oracle_autograd(hip):
     with torch.no_grad():
         y2 = net(*[x.cuda() for x in xs])
     _close(y2, out_r, "fused forward after training forward", rtol=2e-5)
-    with pytest.raises(NotImplementedError):
-        net.train()(*xs_d)                                           # batch-statistics BatchNorm is not built
+
+
+@pytest.mark.parametrize("cin,cout,k,stride,elu,H,W,nb", [
+    (32, 32, 3, 1, True, 24, 40, 1), (64, 64, 3, 1, False, 2 * (16 + 4), 32, 2), (8, 32, 3, 1, True, 32, 48, 1),
+    (64, 56, 1, 1, True, 12, 20, 1), (32, 64, 3, 2, True, 32, 48, 1), (256, 128, 4, 2, True, 16, 24, 1), (32, 3, 3, 1, False, 16, 32, 1),
+])
+def test_gated_conv_layer_batch_statistics_batchnorm(hip, cin, cout, k, stride, elu, H, W, nb):
+    """One BasicConv with nn.BatchNorm2d in .train() (unet.py:40,51; the reference's default, train.py:271-279): output, every
+    gradient and the running-buffer update against torch's F.batch_norm(training=True).  nb = 2: two items stacked with
+    separator rows — the statistics count the items' pixels only."""
+    rng = np.random.default_rng(cin * 77 + cout + k)
+    b = 1.0 / np.sqrt(cin * k * k)
+    t = lambda a: torch.from_numpy(np.asarray(a, np.float32))
+    p = dict(wf=t(rng.uniform(-b, b, (cout, cin, k, k))), bf=t(rng.uniform(-b, b, cout)), wm=t(rng.uniform(-b, b, (cout, cin, k, k))),
+             bm=t(rng.uniform(-b, b, cout)), gamma=t(rng.uniform(0.5, 1.5, cout)), beta=t(0.1 * rng.standard_normal(cout)),
+             mean=t(0.1 * rng.standard_normal(cout)), var=t(rng.uniform(0.5, 1.5, cout)))
+    pad = (k - 1) // 2
+    if nb == 1:
+        x = t(rng.standard_normal((1, cin, H, W)))
+        xb = x
+    else:                                                     # items of 16 rows + 4 zero separator rows each
+        items = t(rng.standard_normal((nb, cin, 16, W)))
+        xb = items
+        x = torch.nn.functional.pad(items, (0, 0, 0, 4)).permute(1, 0, 2, 3).reshape(1, cin, nb * 20, W)
+    ref_in = {n: v.clone().requires_grad_(n not in ("mean", "var")) for n, v in p.items()}
+    xr = xb.clone().requires_grad_(True)
+    f = F.conv2d(xr, ref_in["wf"], ref_in["bf"], stride=stride, padding=pad)
+    m = F.conv2d(xr, ref_in["wm"], ref_in["bm"], stride=stride, padding=pad)
+    rm, rv = p["mean"].clone(), p["var"].clone()
+    yr = F.batch_norm((F.elu(f) if elu else f) * torch.sigmoid(m), rm, rv, ref_in["gamma"], ref_in["beta"], training=True,
+                      momentum=0.1, eps=1e-5)
+    g = t(rng.standard_normal(tuple(yr.shape)))
+    yr.backward(g)
+    dev = {n: v.cuda().requires_grad_(n not in ("mean", "var")) for n, v in p.items()}
+    xd = x[0].permute(1, 2, 0).contiguous().cuda().requires_grad_(True)
+    blk = (1, 1, 1) if nb == 1 else (nb, 16, 20)
+    y = GatedConvFn.apply(xd, dev["wf"], dev["bf"], dev["wm"], dev["bm"], dev["gamma"], dev["beta"], dev["mean"], dev["var"], k,
+                          stride, elu, *blk, True)
+    if nb == 1:
+        y_cmp, unstack = y.permute(2, 0, 1)[None], lambda a: a.permute(2, 0, 1)[None]
+        gd = g[0].permute(1, 2, 0).contiguous()
+    else:
+        unstack = lambda a: a.reshape(nb, 20, W, -1)[:, :16].permute(0, 3, 1, 2)
+        y_cmp = unstack(y)
+        assert float(y.reshape(nb, 20, W, -1)[:, 16:].abs().max()) == 0.0          # separators stay zero
+        gd = torch.nn.functional.pad(g.permute(0, 2, 3, 1), (0, 0, 0, 0, 0, 4)).reshape(nb * 20, W, cout).contiguous()
+    _close(y_cmp, yr, "forward", rtol=5e-5)
+    _close(dev["mean"], rm, "running_mean", rtol=1e-5)
+    _close(dev["var"], rv, "running_var", rtol=1e-5)
+    y.backward(gd.cuda())
+    _close(unstack(xd.grad), xr.grad, "dx")
+    for n in ("wf", "wm", "bf", "bm", "gamma", "beta"):
+        _close(dev[n].grad, ref_in[n].grad, "d" + n, rtol=2e-4)
+
+
+def test_unet_batch_statistics_mode_vs_oracle(hip):
+    """model.train() — the reference's DEFAULT training mode (train.py:271-279,450): the whole UNet on a stacked batch with
+    batch-statistics BatchNorm in every BasicConv against the oracle with training=True (itself pinned against the reference's
+    own UNet in .train(), tests/test_oracle_unet.py): output, input gradients, parameter gradients, running buffers; and
+    the eval-mode fused plan afterwards sees the moved running statistics."""
+    H, W, B = 48, 64, 3
+    state = synthetic.make_unet_state(UNET_SPEC, 17)
+    net = UNet()
+    net.load_state_dict({k: torch.from_numpy(np.asarray(v)) for k, v in state.items()})
+    net.cuda().train()
+    rng = np.random.default_rng(5)
+    xs = [torch.from_numpy(rng.random((B, 8, H >> l, W >> l)).astype(np.float32)) for l in range(4)]
+    st_r = {k: torch.from_numpy(np.asarray(v)).clone().requires_grad_(np.asarray(v).dtype == np.float32 and "running" not in k)
+            for k, v in state.items()}
+    xs_r = [x.clone().requires_grad_(True) for x in xs]
+    out_r = unet_torch.unet_forward(st_r, *xs_r, training=True)
+    g = torch.from_numpy(rng.standard_normal(tuple(out_r.shape)).astype(np.float32))
+    out_r.backward(g)
+    xs_d = [x.cuda().requires_grad_(True) for x in xs]
+    out = net(*xs_d)
+    _close(out, out_r, "forward (batch statistics)", rtol=1e-4)
+    out.backward(g.cuda())
+    for l in range(4):
+        _close(xs_d[l].grad, xs_r[l].grad, f"dx level {l}", rtol=5e-4)
+    worst, n = 0.0, 0
+    for name, p in net.named_parameters():
+        if name.startswith("ConvsOut."):
+            continue
+        worst = max(worst, _close(p.grad, st_r[name].grad, name, rtol=1e-3))
+        n += 1
+    print(f"{n} parameter gradients in batch-statistics mode, worst relative error {worst:.2e}")
+    assert n >= 594
+    sd = net.state_dict()
+    for k in sd:
+        if "running_" in k and not k.startswith("ConvsOut."):
+            _close(sd[k].cpu(), st_r[k], k, rtol=1e-4)
+        if k.endswith("num_batches_tracked") and not k.startswith("ConvsOut."):
+            assert int(sd[k]) == 1, k
+    # eval afterwards: the fused plan re-packs and uses the running statistics the training pass just moved
     net.eval()
+    with torch.no_grad():
+        y_eval = net(*[x.cuda() for x in xs])
+        ref_eval = unet_torch.unet_forward(st_r, *xs)
+    _close(y_eval, ref_eval, "fused eval forward after a train-mode pass", rtol=2e-5)
 
 
 def test_sparse_rmsprop_equals_dense_torch_rmsprop(hip):
@@ -247,3 +343,79 @@ def test_texture_pipeline_training_step(hip):
     for name in ("feat_extract.0.block.conv_f.weight", "Encoder.3.layers.2.main.0.block.conv_m.weight", "feat_extract.5.block.norm.weight",
                  "AFFs.1.conv.0.block.conv_f.bias"):
         _close(sd[name].cpu(), st_r[name].detach(), name, rtol=2e-3)   # Adam divides by sqrt(v): early steps amplify round-off
+
+
+def test_sparse_descriptors_survive_unload_and_load(hip):
+    """the train loop moves the texture off the device between train and eval (train.py:271-305 ->
+    dataset_unload -> unload_textures -> .cpu(), then dataset_load / model.cuda()).  Rows stepped by the sparse optimizer must
+    be written back into texture_ BEFORE it leaves the device, so eval, checkpoints and the next epoch see the trained rows."""
+    from read_amd.net_texture import NetAndTexture
+    from read_amd.texture import PointTexture
+    N, Cc = 3000, 8
+    rng = np.random.default_rng(11)
+    init = rng.random((1, Cc, N)).astype(np.float32)
+    tex = PointTexture(Cc, N, init_method='zeros')
+    with torch.no_grad():
+        tex.texture_.copy_(torch.from_numpy(init))
+    tex.sparse_training = True
+    model = NetAndTexture(UNet(), {0: tex})
+    model.load_textures(0)
+    model.cuda()
+    opt = SparseDescriptorRMSprop([tex], lr=0.1)
+    ref_p = torch.nn.Parameter(torch.from_numpy(init.copy()))
+    ref_opt = torch.optim.RMSprop([ref_p], lr=0.1)
+
+    def one_step():
+        ids = torch.from_numpy(rng.integers(0, N, (2, 1, 16, 24)).astype(np.float32))
+        w = torch.from_numpy(rng.standard_normal((2, Cc, 16, 24)).astype(np.float32))
+        (tex(ids.cuda()) * w.cuda()).sum().backward()
+        opt.step()
+        ref_opt.zero_grad()
+        (ref_p[0][:, ids[:, 0].long()].permute(1, 0, 2, 3) * w).sum().backward()
+        ref_opt.step()
+    one_step()
+    one_step()
+    model.unload_textures()                                        # epoch boundary: texture -> CPU
+    assert not tex.texture_.is_cuda
+    _close(tex.texture_.detach(), ref_p.detach(), "texture_ on the CPU after unload", rtol=1e-5)     # trained values, not the initial ones
+    _close(tex.state_dict()["texture_"], ref_p.detach(), "checkpoint after unload", rtol=1e-5)
+    model.load_textures(0)                                         # eval / next epoch: back to the device
+    model.cuda()
+    probe = torch.arange(128, dtype=torch.float32).view(1, 1, 8, 16)
+    with torch.no_grad():
+        _close(tex(probe.cuda()), ref_p.detach()[0][:, probe[0, 0].long()][None], "lookup after reload", rtol=1e-5)
+    one_step()                                                     # the optimizer state carried over (same trajectory as dense)
+    _close(tex.state_dict()["texture_"].cpu(), ref_p.detach(), "descriptors after unload / load / one more step", rtol=1e-5)
+
+
+def test_wgrad_when_gradients_accumulate_or_are_frozen(hip):
+    """weight gradients come from a side stream; with an existing .grad (gradient accumulation) autograd adds
+    on the main stream, which must wait for them; with frozen weights no wgrad is computed at all."""
+    rng = np.random.default_rng(21)
+    cin, cout, H, W = 32, 32, 40, 56
+    t = lambda a: torch.from_numpy(np.asarray(a, np.float32))
+    b = 1.0 / np.sqrt(cin * 9)
+    p = dict(wf=t(rng.uniform(-b, b, (cout, cin, 3, 3))), bf=t(rng.uniform(-b, b, cout)), wm=t(rng.uniform(-b, b, (cout, cin, 3, 3))),
+             bm=t(rng.uniform(-b, b, cout)), gamma=t(rng.uniform(0.5, 1.5, cout)), beta=t(0.1 * rng.standard_normal(cout)),
+             mean=t(0.1 * rng.standard_normal(cout)), var=t(rng.uniform(0.5, 1.5, cout)))
+    xs = [t(rng.standard_normal((1, cin, H, W))) for _ in range(3)]
+    gs = [t(rng.standard_normal((1, cout, H, W))) for _ in range(3)]
+    ref_in = {n: v.clone().requires_grad_(n not in ("mean", "var")) for n, v in p.items()}
+    for x, g in zip(xs, gs):
+        f = F.conv2d(x, ref_in["wf"], ref_in["bf"], padding=1)
+        m = F.conv2d(x, ref_in["wm"], ref_in["bm"], padding=1)
+        F.batch_norm(F.elu(f) * torch.sigmoid(m), ref_in["mean"], ref_in["var"], ref_in["gamma"], ref_in["beta"], training=False,
+                     eps=1e-5).backward(g)
+    dev = {n: v.cuda().requires_grad_(n not in ("mean", "var")) for n, v in p.items()}
+    for x, g in zip(xs, gs):                                       # three backward passes into the same .grad
+        y = GatedConvFn.apply(x[0].permute(1, 2, 0).contiguous().cuda(), dev["wf"], dev["bf"], dev["wm"], dev["bm"], dev["gamma"],
+                              dev["beta"], dev["mean"], dev["var"], 3, 1, True)
+        y.backward(g[0].permute(1, 2, 0).contiguous().cuda())
+    for n in ("wf", "wm", "bf", "bm", "gamma", "beta"):
+        _close(dev[n].grad, ref_in[n].grad, "accumulated d" + n)
+    frozen = {n: v.cuda() for n, v in p.items()}
+    xd = xs[0][0].permute(1, 2, 0).contiguous().cuda().requires_grad_(True)
+    y = GatedConvFn.apply(xd, frozen["wf"], frozen["bf"], frozen["wm"], frozen["bm"], frozen["gamma"], frozen["beta"], frozen["mean"],
+                          frozen["var"], 3, 1, True)
+    y.backward(gs[0][0].permute(1, 2, 0).contiguous().cuda())
+    assert xd.grad is not None and all(v.grad is None for v in frozen.values())

@@ -1,0 +1,130 @@
+"""The training step at the size BASELINE configs[4] benchmarks (src/configs/train_example.yaml:4,33: batch_size 2 x inner_batch 4
+= 8 crops of 256 x 256; src/train.py:132-266): 8 items through NetAndTexture -> ONE stacked 2160-row image -> UNet -> Huber x 1e4
+-> backward -> sparse descriptor RMSprop, against torch.autograd through the oracle on the host.
+
+What only this size exercises: the persistent Winograd scheduling at 512 workgroups with block_h / valid_h masking, the grid.z
+pixel split of wgrad_mfma_kernel + wgrad_reduce_kernel, the sorted RMSprop with a > 512-pair background run over 524 k pixels.
+
+Tolerances (stated): forward max|diff| <= 2e-5 max|ref|; every gradient tensor BOTH max-normalised (<= 1e-4 of its largest
+entry; 2e-4 for weights) AND per element |diff| <= 1e-4 max|ref| + 1e-3 |ref|; the smallest floor factor that would pass is
+printed so the bound can be tightened with evidence."""
+import os
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from oracle import unet_torch
+from read_amd import synthetic
+from read_amd.net_texture import NetAndTexture
+from read_amd.texture import PointTexture
+from read_amd.train import SparseDescriptorRMSprop, huber_loss
+from read_amd.unet import UNet
+from tests.unet_spec import UNET_SPEC
+
+pytestmark = pytest.mark.gpu
+
+KEYS = "uv_1d_p1, uv_1d_p1_ds1, uv_1d_p1_ds2, uv_1d_p1_ds3, uv_1d_p1_ds4".replace(' ', '').split(',')
+
+
+def _check(got, ref, what, rtol_max, stats):
+    got, ref = got.detach().cpu().double(), ref.detach().cpu().double()
+    assert got.shape == ref.shape, (what, got.shape, ref.shape)
+    scale = max(float(ref.abs().max()), 1e-30)
+    diff = (got - ref).abs()
+    e_max = float(diff.max()) / scale
+    floor = float((diff - 1e-3 * ref.abs()).clamp_min(0).max()) / scale       # smallest a with |diff| <= a max|ref| + 1e-3 |ref|
+    assert e_max <= rtol_max, f"{what}: max error {e_max:.3e} of the largest entry"
+    assert floor <= 1e-4, f"{what}: per-element bound needs floor {floor:.3e} (> 1e-4) of the largest entry"
+    stats["max"], stats["floor"] = max(stats["max"], e_max), max(stats["floor"], floor)
+
+
+@pytest.mark.parametrize("bn_mode", ["eval", "train"])
+def test_training_step_8_crops_of_256(hip, bn_mode):
+    B, S, N = 8, 256, 300_000
+    training = bn_mode == "train"
+    torch.set_num_threads(min(os.cpu_count() or 1, 32))           # torch's CPU convolutions collapse on all 256 host threads
+    rng = np.random.default_rng(2019)
+    state = synthetic.make_unet_state(UNET_SPEC, 23)
+    init = rng.random((1, 8, N)).astype(np.float32)
+    maps = [rng.integers(1, N, (B, 1, S >> l, S >> l)) for l in range(5)]
+    for m in maps:                                                 # ~35 % background (id 0): ONE run of > 10^5 equal ids
+        m[rng.random(m.shape) < 0.35] = 0
+    target = torch.from_numpy(rng.random((B, 3, S, S)).astype(np.float32))
+    sq0 = (0.5 + rng.random((N, 8))).astype(np.float32)            # a second-moment state as after many steps: update ~ lr g / sqrt(sq)
+
+    # ---- HIP: NetAndTexture training path (per-item lookups, one stacked network call), sparse RMSprop
+    net = UNet()
+    net.load_state_dict({k: torch.from_numpy(np.asarray(v)) for k, v in state.items()})
+    tex = PointTexture(8, N, init_method='zeros')
+    with torch.no_grad():
+        tex.texture_.copy_(torch.from_numpy(init))
+    tex.sparse_training = True
+    model = NetAndTexture(net, {0: tex})
+    model.load_textures(0)
+    model.cuda()
+    model.train() if training else model.eval()
+    opt = SparseDescriptorRMSprop([tex], lr=0.1)
+    st = opt._state(tex)
+    st['step'] = 1
+    st['sq'].copy_(torch.from_numpy(sq0))
+    st['stamp'].fill_(1)
+    inputs = {'id': torch.zeros(B, dtype=torch.long)}
+    inputs.update({k: torch.from_numpy(m).float().cuda() for k, m in zip(KEYS, maps)})
+    out, net_input = model(inputs, return_input=True)
+    assert out.shape == (B, 3, S, S)
+    for t in net_input:
+        t.retain_grad()
+    loss = huber_loss(out, target.cuda()) * 1e4
+    loss.backward()
+    model.check_ids()
+    opt.step()
+    torch.cuda.synchronize()
+
+    # ---- oracle: plain batch under torch.autograd on the host
+    st_r = {k: torch.from_numpy(np.asarray(v)).clone().requires_grad_(np.asarray(v).dtype == np.float32 and "running" not in k)
+            for k, v in state.items()}
+    tex_r = torch.nn.Parameter(torch.from_numpy(init.copy()))
+    feats = [tex_r[0][:, torch.from_numpy(m[:, 0])].permute(1, 0, 2, 3) for m in maps]
+    for f in feats:
+        f.retain_grad()
+    out_r = unet_torch.unet_forward(st_r, *feats[:4], training=training)
+    loss_r = F.huber_loss(out_r, target) * 1e4
+    loss_r.backward()
+    ref_opt = torch.optim.RMSprop([tex_r], lr=0.1)
+    ref_opt.state[tex_r]['step'] = torch.tensor(1.0)
+    ref_opt.state[tex_r]['square_avg'] = torch.from_numpy(sq0.T.copy())[None]
+    ref_opt.step()
+
+    stats = {"max": 0.0, "floor": 0.0}
+    _check(out, out_r, "forward", 1e-4 if training else 2e-5, stats)
+    assert abs(float(loss) - float(loss_r)) <= 1e-5 * abs(float(loss_r)), (float(loss), float(loss_r))
+    g_tol = 5e-4 if training else 1e-4
+    for l in range(4):
+        _check(net_input[l].grad, feats[l].grad, f"dx level {l}", g_tol, stats)
+    n = 0
+    for name, p in net.named_parameters():
+        if name.startswith("ConvsOut."):
+            assert p.grad is None
+            continue
+        _check(p.grad, st_r[name].grad, name, 1e-3 if training else 2e-4, stats)
+        n += 1
+    assert n >= 594
+    print(f"[{bn_mode}] {n} parameter gradients + 4 input gradients at 8 x 256 x 256: worst max-normalised error "
+          f"{stats['max']:.2e}, smallest passing per-element floor {stats['floor']:.2e} (bound 1e-4)")
+    # descriptors after the sorted sparse step == dense torch RMSprop (state seeded so that the update is ~ lr g / sqrt(sq))
+    got = tex.state_dict()["texture_"].cpu()
+    upd, upd_r = got - torch.from_numpy(init), tex_r.detach() - torch.from_numpy(init)
+    d_stats = {"max": 0.0, "floor": 0.0}
+    _check(upd, upd_r, "descriptor update (sorted sparse RMSprop vs dense torch RMSprop)", 5e-4 if training else 2e-4, d_stats)
+    touched = np.unique(np.concatenate([m.reshape(-1) for m in maps]))
+    mask = np.ones(N, bool)
+    mask[touched] = False
+    assert float(upd[0][:, torch.from_numpy(mask)].abs().max()) == 0.0            # untouched rows did not move
+    if training:
+        sd = net.state_dict()
+        for k in sd:
+            if "running_" in k and not k.startswith("ConvsOut."):
+                e = float((sd[k].cpu().double() - st_r[k].double()).abs().max()) / max(float(st_r[k].abs().max()), 1e-30)
+                assert e <= 1e-4, (k, e)

@@ -43,3 +43,48 @@ def test_psnr_definition():
     b = torch.full((3, 4, 4), 0.1)
     assert abs(unet_torch.psnr(a, b) - 20.0) < 1e-4
     assert unet_torch.psnr(a, a) == float("inf")
+
+
+def test_training_mode_equals_reference_module_in_train():
+    """Live pin (only where /root/reference exists): the oracle with training=True against the reference's own UNet in
+    .train() — batch-statistics BatchNorm output, its gradients and the running-buffer update (READ/models/unet.py:40,51;
+    train.py:271-279 puts the model in .train() unless eval_in_train)."""
+    import sys
+    import types
+    import pytest
+    ref = "/root/reference"
+    if not os.path.isdir(os.path.join(ref, "READ", "models")):
+        pytest.skip("reference checkout not present")
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("_ref_unet_for_pin", os.path.join(ref, "READ", "models", "unet.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    state = synthetic.make_unet_state(UNET_SPEC, 5)
+    net = mod.UNet()
+    net.load_state_dict({k: torch.from_numpy(np.asarray(v)).clone() for k, v in state.items()}, strict=True)
+    net.train()
+    rng = np.random.default_rng(8)
+    xs = [torch.from_numpy(rng.random((2, 8, 32 >> l, 48 >> l)).astype(np.float32)) for l in range(4)]
+    out_ref = net(*xs)
+    g = torch.from_numpy(rng.standard_normal(tuple(out_ref.shape)).astype(np.float32))
+    out_ref.backward(g)
+    st = {k: (torch.from_numpy(np.asarray(v)).clone().requires_grad_(True)
+              if (np.asarray(v).dtype == np.float32 and "running" not in k) else torch.from_numpy(np.asarray(v)).clone())
+          for k, v in state.items()}
+    out = unet_torch.unet_forward(st, *xs, training=True)
+    out.backward(g)
+    torch.testing.assert_close(out, out_ref, rtol=1e-5, atol=1e-5)
+    sd = net.state_dict()
+    for k in ("feat_extract.0.block.norm.running_mean", "Encoder.2.layers.1.main.0.block.norm.running_var",
+              "SCM0.conv.block.norm.running_var", "feat_extract.5.block.norm.running_mean"):
+        torch.testing.assert_close(st[k], sd[k], rtol=1e-5, atol=1e-6)
+        assert not torch.equal(st[k], torch.from_numpy(np.asarray(state[k])))          # the buffers did move
+    for name, p in net.named_parameters():
+        if name.startswith("ConvsOut."):
+            continue
+        torch.testing.assert_close(st[name].grad, p.grad, rtol=1e-3, atol=1e-5 * float(p.grad.abs().max()) + 1e-12)
+    # eval mode is untouched by the flag's plumbing
+    with torch.no_grad():
+        a = unet_torch.unet_forward(state, *xs)
+        b = unet_torch.unet_forward(state, *xs, training=False)
+    assert torch.equal(a, b)

@@ -101,6 +101,8 @@ def _bench_worker(rank, world, port, q, mode):
             if mode == 'all' or rank == 0:
                 seen[i] = fr.clone().numpy()
         ex.drain()
+        flags = sweep.gather_objects(rank == 0 or None)            # bench.py's verified_ranks: one verdict per rank
+        assert flags == [True, None]
         q.put((rank, log, seen))
     finally:
         dist.destroy_process_group()
@@ -142,3 +144,4 @@ def test_bench_loop_single_process_has_no_exchange():
     assert ex.mode is None and ex.world == 1
     sweep.run_steps(lambda k, out: out.fill_(k), ex, 0, 3, POSES)
     assert float(ex.frames(2)[0, 0, 0]) == 2.0
+    assert sweep.gather_objects(True) == [True]
