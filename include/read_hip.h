@@ -129,8 +129,13 @@ int read_splat_forward_cells(const float *xyz, void *cells, int64_t n, const flo
  *                                             threshold = p * (2^32 - 1)
  *   perturb                                   optional device array N x 2 added to clip.xy (set_point_perturb)
  *   perturb_amp, perturb_seed                 seeded perturbation amp * (u01(i, seed) - 0.5) per axis (0 = off)
+ * Coverage rule = OpenGL's basic point rasterisation with GL_PROGRAM_POINT_SIZE (READ/gl/render.py:55; GL 4.6 core spec
+ * section 14.4.1: "a fragment for each framebuffer pixel whose center lies inside a square centered at the point's (xw, yw), with
+ * side length equal to the current point size"): pixel column i is covered iff xw - s/2 <= i + 0.5 < xw + s/2, i.e.
+ * i in [floor(u - (s-1)/2), floor(u + (s-1)/2)] away from exact ties — for odd AND even s; points are clipped by their CENTRE
+ * (spec 13.7: a point outside the clip volume is discarded whole), sizes clamp to [1, 4096] (the aliased point size range).
  * Exact semantics: csrc/splat.hip (splat_project_gl_kernel) == oracle/raster.c (oracle_raster_level_gl).  With the default
- * options {1, 0, 1, NULL, 0, 0, NULL, 0, 0} the result equals read_splat_forward(levels = 1).  The workspace is the one of
+ * options {1, 0, 1, NULL, 0, 0, NULL, 0, 0, NULL} the result equals read_splat_forward(levels = 1).  The workspace is the one of
  * read_splat_workspace_bytes(1, W, H); it is left EMPTY. */
 typedef struct read_splat_gl_opts {
     float point_size;
@@ -141,6 +146,9 @@ typedef struct read_splat_gl_opts {
     const float *perturb;
     float perturb_amp;
     uint32_t perturb_seed;
+    const float *point_sizes;    /* optional device array of N per-point sizes (NNScene.set_point_sizes, the a_point_size vertex
+                                  * attribute): used instead of point_size when point_size == 0 (the shader's
+                                  * "if (point_size < 1) point_size = a_point_size", READ/gl/programs.py:183-187, :339-345) */
 } read_splat_gl_opts;
 int read_splat_forward_gl(const float *xyz, int64_t n, const float *M_host, int W, int H,
                           const read_splat_gl_opts *opts, int32_t *idx, float *depth, void *workspace,

@@ -194,6 +194,7 @@ typedef struct oracle_gl_opts {
     const float *perturb;        /* optional N x 2 clip-space offsets */
     float perturb_amp;           /* seeded perturbation amplitude (0 = off) */
     uint32_t perturb_seed;
+    const float *point_sizes;    /* optional per-point sizes (a_point_size), used when point_size < 1 (programs.py:183-187) */
 } oracle_gl_opts;
 
 void oracle_raster_level_gl(const float *xyz, int64_t n, const float *M, int W, int H, const oracle_gl_opts *o,
@@ -225,7 +226,8 @@ void oracle_raster_level_gl(const float *xyz, int64_t n, const float *M, int W, 
         const float d = (nz + 1.0f) * 0.5f;
         if ((int)u < 0 || (int)u >= W || (int)v < 0 || (int)v >= H) continue;
         float sz = o->point_size;
-        if (o->relative) { sz = o->point_size / c2; if (!(sz > o->min_point_size)) sz = o->min_point_size; }
+        if (sz < 1.0f && o->point_sizes) sz = o->point_sizes[i];
+        if (o->relative) { sz = sz / c2; if (!(sz > o->min_point_size)) sz = o->min_point_size; }
         if (!(sz > 1.0f)) sz = 1.0f;
         if (sz > 4096.0f) sz = 4096.0f;
         const float half = 0.5f * (sz - 1.0f);

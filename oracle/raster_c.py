@@ -12,7 +12,8 @@ _LIB = None
 class GLOpts(C.Structure):
     _fields_ = [("point_size", C.c_float), ("relative", C.c_int), ("min_point_size", C.c_float),
                 ("discard", C.c_void_p), ("drop_threshold", C.c_uint32), ("drop_seed", C.c_uint32),
-                ("perturb", C.c_void_p), ("perturb_amp", C.c_float), ("perturb_seed", C.c_uint32)]
+                ("perturb", C.c_void_p), ("perturb_amp", C.c_float), ("perturb_seed", C.c_uint32),
+                ("point_sizes", C.c_void_p)]
 
 
 def lib_path() -> str:
@@ -121,12 +122,17 @@ def drop_threshold(p):
 
 
 def raster_level_gl(xyz, M, W, H, point_size=1.0, relative=False, min_point_size=1.0, discard=None, drop=None,
-                    perturb=None, perturb_hash=None):
+                    perturb=None, perturb_hash=None, point_sizes=None):
     """GL-twin rasterisation of ONE level at its own size (see raster.c): point sizes / "ps" splats, discard mask or
     seeded drop=(p, seed), perturb array (N,2) or seeded perturb_hash=(amp, seed) -> (index int32 [H,W], depth [H,W])."""
     xyz, M = _f32(xyz), _f32(M).reshape(16)
-    o = GLOpts(float(point_size), int(bool(relative)), float(min_point_size), None, 0, 0, None, 0.0, 0)
+    o = GLOpts(float(point_size), int(bool(relative)), float(min_point_size), None, 0, 0, None, 0.0, 0, None)
     keep = []
+    if point_sizes is not None:                    # NNScene.set_point_sizes: the global size becomes 0, the attribute rules
+        psz = _f32(point_sizes).reshape(-1)
+        keep.append(psz)
+        o.point_sizes = psz.ctypes.data
+        o.point_size = 0.0
     if discard is not None:
         dm = np.ascontiguousarray(discard, dtype=np.uint8)
         keep.append(dm)

@@ -38,7 +38,8 @@ class ConvDesc(C.Structure):
 class SplatGlOpts(C.Structure):
     _fields_ = [("point_size", C.c_float), ("relative", C.c_int), ("min_point_size", C.c_float),
                 ("discard", C.c_void_p), ("drop_threshold", C.c_uint32), ("drop_seed", C.c_uint32),
-                ("perturb", C.c_void_p), ("perturb_amp", C.c_float), ("perturb_seed", C.c_uint32)]
+                ("perturb", C.c_void_p), ("perturb_amp", C.c_float), ("perturb_seed", C.c_uint32),
+                ("point_sizes", C.c_void_p)]
 
 
 _vp, _i, _i64, _sz, _f = C.c_void_p, C.c_int, C.c_int64, C.c_size_t, C.c_float

@@ -1026,6 +1026,7 @@ struct GlOpts {
     const float *perturb;
     float perturb_amp;
     unsigned perturb_seed;
+    const float *point_sizes;    // per-point sizes (a_point_size), used when point_size < 1 (programs.py:183-187)
 };
 
 __device__ __forceinline__ unsigned hash32(unsigned x)
@@ -1068,8 +1069,9 @@ __global__ __launch_bounds__(256) void splat_project_gl_kernel(const float *__re
         const float d = (nz + 1.0f) * 0.5f;
         if ((int)u < 0 || (int)u >= W || (int)v < 0 || (int)v >= H) continue;
         float sz = o.point_size;
+        if (sz < 1.0f && o.point_sizes) sz = o.point_sizes[i];      // global_point_size 0 -> the vertex attribute
         if (o.relative) {
-            sz = o.point_size / c2;
+            sz = sz / c2;
             if (!(sz > o.min_point_size)) sz = o.min_point_size;
         }
         if (!(sz > 1.0f)) sz = 1.0f;
@@ -1780,7 +1782,8 @@ extern "C" int read_splat_forward_gl(const float *xyz, int64_t n, const float *M
     READ_CHECK_ARG(M_host && opts, "read_splat_forward_gl: M_host / opts is null");
     READ_CHECK_ARG(W >= 1 && H >= 1 && (long long)W * H < (1ll << 31), "read_splat_forward_gl: bad size (%d,%d)", W, H);
     READ_CHECK_ARG(idx || depth, "read_splat_forward_gl: no outputs requested");
-    READ_CHECK_ARG(opts->point_size >= 1.0f && opts->min_point_size >= 0.0f, "read_splat_forward_gl: point_size must be >= 1");
+    READ_CHECK_ARG((opts->point_size >= 1.0f || (opts->point_size == 0.0f && opts->point_sizes)) && opts->min_point_size >= 0.0f,
+                   "read_splat_forward_gl: point_size must be >= 1, or 0 with a per-point size array");
     READ_CHECK_ARG(ws && (uintptr_t)ws % 256 == 0, "read_splat_forward_gl: workspace null or not 256-byte aligned");
     if (ws_bytes < read_splat_workspace_bytes(1, W, H)) {
         set_error("read_splat_forward_gl: workspace %zu < %zu bytes", ws_bytes, read_splat_workspace_bytes(1, W, H));
@@ -1801,6 +1804,7 @@ extern "C" int read_splat_forward_gl(const float *xyz, int64_t n, const float *M
         o.perturb = opts->perturb;
         o.perturb_amp = opts->perturb_amp;
         o.perturb_seed = opts->perturb_seed;
+        o.point_sizes = opts->point_sizes;
         int64_t blocks = ceil_div64(n, 256);
         if (blocks > (int64_t)device_cus() * 8) blocks = (int64_t)device_cus() * 8;
         hipLaunchKernelGGL(splat_project_gl_kernel, dim3((unsigned)blocks), dim3(256), 0, s, xyz, (long long)n, cam, W, H,

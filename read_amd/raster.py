@@ -80,17 +80,25 @@ class PointCloudRasterizer:
         return idx, dep
 
     def render_gl(self, total_m, W, H, point_size=1.0, relative=False, min_point_size=1.0, discard=None, drop=None,
-                  perturb=None, perturb_hash=None, want_depth=True):
+                  perturb=None, perturb_hash=None, want_depth=True, point_sizes=None):
         """ONE level of ONE camera at its own size with the GL twin's point options (read_splat_forward_gl):
         point_size / relative ("pN" / "psN" tokens, READ/gl/programs.py:183-192), discard = bool/uint8 (N,) array or
         tensor (set_point_discard), drop = (p, seed) seeded drop, perturb = (N,2) clip-space offsets
-        (set_point_perturb), perturb_hash = (amp, seed).  -> (idx (1,H,W) int32, depth (1,H,W) fp32 | None)."""
+        (set_point_perturb), perturb_hash = (amp, seed), point_sizes = (N,) per-point sizes (set_point_sizes; they replace
+        point_size as in the shader, programs.py:183-187).  -> (idx (1,H,W) int32, depth (1,H,W) fp32 | None)."""
         M = np.ascontiguousarray(total_m.detach().cpu().numpy() if torch.is_tensor(total_m) else total_m,
                                  dtype=np.float32).reshape(-1, 16)
         if M.shape[0] != 1:
             raise ValueError("render_gl renders one camera per call")
-        o = _lib.SplatGlOpts(float(point_size), int(bool(relative)), float(min_point_size), None, 0, 0, None, 0.0, 0)
+        o = _lib.SplatGlOpts(float(point_size), int(bool(relative)), float(min_point_size), None, 0, 0, None, 0.0, 0, None)
         keep = []
+        if point_sizes is not None:         # per-point sizes (NNScene.set_point_sizes): they replace the token's global size
+            ps = torch.as_tensor(point_sizes).to(self.device, torch.float32).contiguous().reshape(-1)
+            if ps.numel() != self.n:
+                raise ValueError(f"point_sizes has {ps.numel()} entries for {self.n} points")
+            keep.append(ps)
+            o.point_sizes = ps.data_ptr()
+            o.point_size = 0.0
         if discard is not None:
             d = torch.as_tensor(discard).to(self.device, torch.uint8).contiguous()
             if d.numel() != self.n:

@@ -148,6 +148,7 @@ class Scene:
         self._dev = {}
         self.point_discard = None         # bool (N,)  set_point_discard  (programs.py:347-351)
         self.point_perturb = None         # float (N,2) set_point_perturb (programs.py:353-357)
+        self.point_sizes = None           # float (N,) set_point_sizes (programs.py:339-345)
         self.point_drop = None            # (p, seed): seeded drop evaluated on the device
         self.point_perturb_seeded = None  # (amp, seed)
         self.params = {'mode': (MODE_UV, UV_TYPE_1D), 'draw_points': True, 'flat_color': True, 'point_size': 1,
@@ -165,12 +166,18 @@ class Scene:
         if uv1d is not None and not np.array_equal(np.asarray(uv1d).reshape(-1), np.arange(positions.shape[0])):
             raise NotImplementedError("uv1d other than the point index (import_model3d's arange) is not supported")
         self.xyz_min, self.xyz_max = self.xyz.min(axis=0), self.xyz.max(axis=0)          # programs.py:334-335
-        self.point_discard = self.point_perturb = None
+        self.point_discard = self.point_perturb = self.point_sizes = None
         self._dev = {}
         self._dirty = True
 
     def set_point_sizes(self, point_sizes):
-        raise NotImplementedError("per-point size arrays (scene 'point_sizes') are not rendered; use pN / psN tokens")
+        """Per-point sizes (READ/gl/programs.py:339-345, scene yaml 'point_sizes'): from now on every token is drawn with the
+        point's own size instead of the token's N — the reference sets global_point_size to 0 and set_params skips
+        'point_size' (programs.py:404-406); "ps" tokens still divide by clip z."""
+        ps = np.ascontiguousarray(point_sizes, dtype=np.float32).reshape(-1)
+        if self.xyz is not None and ps.shape[0] != self.xyz.shape[0]:
+            raise ValueError(f"point_sizes has {ps.shape[0]} entries for {self.xyz.shape[0]} points")
+        self.point_sizes = ps
 
     def set_point_discard(self, arr):
         self.point_discard = None if arr is None else np.ascontiguousarray(arr).astype(bool)
@@ -215,7 +222,7 @@ class Scene:
 
     def augmented(self):
         return (self.point_discard is not None or self.point_perturb is not None or self.point_drop is not None
-                or self.point_perturb_seeded is not None)
+                or self.point_perturb_seeded is not None or self.point_sizes is not None)
 
     def device_array(self, name):
         """colors / normals / xyz as (N,3) CUDA tensors, uploaded on first use."""
@@ -309,7 +316,8 @@ class MultiscaleRender:
         M = scene.total_matrix()
         idx, dep = scene.rasterizer().render_gl(M, w, h, point_size=cfg['point_size'], relative=cfg['splat_mode'],
                                                 min_point_size=1.0, discard=scene.point_discard, drop=scene.point_drop,
-                                                perturb=scene.point_perturb, perturb_hash=scene.point_perturb_seeded)
+                                                perturb=scene.point_perturb, perturb_hash=scene.point_perturb_seeded,
+                                                point_sizes=scene.point_sizes)
         self.last_index.append(idx)
         ids, covered = idx[0], (dep[0] != 0) | (idx[0] != 0)
         if mode0 == MODE_UV:

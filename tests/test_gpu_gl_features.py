@@ -44,6 +44,34 @@ def test_point_sizes_and_perspective_splats(hip):
         w, h = W >> l, H >> l
         i, d = r.render_gl(M, w, h, point_size=3)
         _same(i, d, oracle.raster_level_gl(xyz, M[0], w, h, point_size=3), f"p3 level {l}")
+    # even sizes and "ps" splats that really exceed a pixel; per-point size arrays (NNScene.set_point_sizes, programs.py:183-187)
+    for size in (6, 12):
+        i, d = r.render_gl(M, W, H, point_size=size)
+        _same(i, d, oracle.raster_level_gl(xyz, M[0], W, H, point_size=size), f"p{size}")
+    for size in (400, 1500):
+        i, d = r.render_gl(M, W, H, point_size=size, relative=True)
+        ref = oracle.raster_level_gl(xyz, M[0], W, H, point_size=size, relative=True)
+        assert (ref[0] != 0).sum() > 1.3 * (i1[0].cpu().numpy() != 0).sum()      # these splats are larger than one pixel
+        _same(i, d, ref, f"ps{size}")
+    rng = np.random.default_rng(12)
+    sizes = rng.uniform(0.5, 9.0, N).astype(np.float32)
+    i, d = r.render_gl(M, W, H, point_sizes=sizes)
+    _same(i, d, oracle.raster_level_gl(xyz, M[0], W, H, point_sizes=sizes), "per-point sizes")
+    i, d = r.render_gl(M, W, H, point_sizes=200.0 * sizes, relative=True, min_point_size=1.5)
+    _same(i, d, oracle.raster_level_gl(xyz, M[0], W, H, point_sizes=200.0 * sizes, relative=True, min_point_size=1.5),
+          "per-point sizes, perspective")
+    with pytest.raises(ValueError):
+        r.render_gl(M, W, H, point_sizes=sizes[:-1])
+    # through the scene API: set_point_sizes overrides the token's size for every token (programs.py:404-406)
+    scene = Scene(xyz)
+    scene.set_proj_matrix(proj)
+    scene.set_camera_view(synthetic.sweep_pose(6))
+    scene.set_point_sizes(sizes)
+    out = MultiscaleRender(scene, "uv_1d_p1, uv_1d_p3_ds1", (W, H), out_buffer_location='torch').render()
+    ref0 = oracle.raster_level_gl(xyz, M[0], W, H, point_sizes=sizes)[0]
+    ref1 = oracle.raster_level_gl(xyz, M[0], W // 2, H // 2, point_sizes=sizes)[0]
+    assert np.array_equal(out["uv_1d_p1"][..., 0].cpu().numpy(), oracle.index_to_float(ref0))
+    assert np.array_equal(out["uv_1d_p3_ds1"][..., 0].cpu().numpy(), oracle.index_to_float(ref1))
     # the workspace is left EMPTY: the plain path renders the same frame afterwards
     idx, dep = r.render(M, W, H, 1)
     _same(idx[0], dep[0], oracle.raster_level(xyz, M[0], W, H), "plain after gl")

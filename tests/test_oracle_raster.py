@@ -116,3 +116,37 @@ def test_gather_and_backward_oracle():
     for c in range(8):
         np.add.at(ref[c], idx.reshape(-1), g[c].reshape(-1))
     np.testing.assert_allclose(gt, ref, rtol=1e-6, atol=1e-6)
+
+
+def test_gl_coverage_rule_equals_the_opengl_specification_text():
+    """Pin of the GL twin's pixel coverage (round-2 verdict: "the pixel-coverage rule for sizes > 1 is the
+    builder's own convention"): oracle/raster.c's floor(u +- (s - 1) / 2) rule against oracle/raster_gl_spec.py, an
+    independent restatement written from the OpenGL 4.6 core specification's text (13.7 clipping of points by their centre,
+    14.4.1 "pixel whose center lies inside a square ... with side length equal to the current point size", 13.8.1 viewport,
+    17.3.6 GL_LESS) — odd, EVEN and fractional sizes, "ps" splats that actually exceed one pixel, per-point size arrays,
+    discard and perturbation.  Pixels whose centre lies within 1e-4 px of a square's edge are excluded (the spec does not say
+    which side owns the edge); everything else must agree bit for bit."""
+    from oracle.raster_gl_spec import raster_level_gl_spec
+    N, W, H = 2500, 96, 64
+    xyz = synthetic.make_cloud(N, seed=5)
+    M = camera.total_matrix(synthetic.make_proj(W, H, f=60.0), synthetic.sweep_pose(7))[0]
+    rng = np.random.default_rng(1)
+    cases = [dict(point_size=1), dict(point_size=2), dict(point_size=3), dict(point_size=4), dict(point_size=7),
+             dict(point_size=300, relative=True), dict(point_size=777, relative=True, min_point_size=2.5),
+             dict(point_sizes=rng.uniform(0.5, 6.0, N).astype(np.float32)),
+             dict(point_sizes=rng.uniform(1, 400, N).astype(np.float32), relative=True),
+             dict(point_size=5, discard=rng.random(N) < 0.3, perturb=(0.5 * (rng.random((N, 2)) - 0.5)).astype(np.float32))]
+    for kw in cases:
+        a_i, a_d = oracle.raster_level_gl(xyz, M, W, H, **kw)
+        b_i, b_d, amb = raster_level_gl_spec(xyz, M, W, H, **kw)
+        ok = ~amb
+        assert amb.mean() < 0.02, kw
+        assert ((a_i != 0) | (a_d != 0)).sum() > 1000, kw                    # the case draws something
+        assert np.array_equal(a_i[ok], b_i[ok]), kw
+        assert np.array_equal(_bits(a_d)[ok], _bits(b_d)[ok]), kw
+    # sizes > 1 really cover more than the 1-px rule (the test above is not vacuous), and p1 reduces to the pinned rasteriser
+    i1, d1 = oracle.raster_level_gl(xyz, M, W, H, point_size=1)
+    i0, d0 = oracle.raster_level(xyz, M, W, H)
+    assert np.array_equal(i1, i0) and np.array_equal(_bits(d1), _bits(d0))
+    i2, _ = oracle.raster_level_gl(xyz, M, W, H, point_size=2)
+    assert (i2 != 0).sum() > 1.5 * (i1 != 0).sum()
