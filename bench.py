@@ -428,7 +428,9 @@ def run_train(a, dev, street=None, steps=None, warm=None, cpu_timing=True, do_ve
         touched = torch.from_numpy(np.unique(np.concatenate([m.reshape(-1) for m in maps_o])).astype(np.int64))
         dref = tex_r.grad[0].t()[touched]
         e_desc, f_desc = _grad_err(drows_g[touched], dref)
-        untouched_zero = bool(float(drows_g.abs().sum()) == float(drows_g[touched].abs().sum()))
+        rest = torch.ones(drows_g.shape[0], dtype=torch.bool)
+        rest[touched] = False
+        untouched_zero = bool(float(drows_g[rest].abs().max()) == 0.0) if bool(rest.any()) else True
         loss_rel = abs(float(loss_g) - float(loss_o)) / max(abs(float(loss_o)), 1e-30)
         verified = {"raster_bit_exact": exact, "loss": float(loss_g), "loss_oracle": float(loss_o), "loss_rel_err": loss_rel,
                     "param_grads_compared": n_par, "worst_param_grad_err_of_max": worst,
@@ -439,7 +441,9 @@ def run_train(a, dev, street=None, steps=None, warm=None, cpu_timing=True, do_ve
         if bn_train:
             e_bn = max(_grad_err(bn_after[k], st_r[k])[0] for k in bn_after)
             verified["running_stats_err_of_max"] = e_bn
-        verified["ok"] = bool(exact and loss_rel <= 1e-4 and n_par >= 594 and worst <= 2e-4 and e_desc <= 2e-4 and untouched_zero
+        g_tol = 1e-3 if bn_train else 2e-4              # batch statistics couple every pixel of a channel: round-off is amplified
+        verified["grad_tolerance_of_max"] = g_tol
+        verified["ok"] = bool(exact and loss_rel <= 1e-4 and n_par >= 594 and worst <= g_tol and e_desc <= g_tol and untouched_zero
                               and (not bn_train or verified["running_stats_err_of_max"] <= 1e-4))
         if cpu_timing:
             # CPU baseline: the first oracle iteration above was the warm-up; time 2 more complete iterations (oracle

@@ -5,9 +5,11 @@
 What only this size exercises: the persistent Winograd scheduling at 512 workgroups with block_h / valid_h masking, the grid.z
 pixel split of wgrad_mfma_kernel + wgrad_reduce_kernel, the sorted RMSprop with a > 512-pair background run over 524 k pixels.
 
-Tolerances (stated): forward max|diff| <= 2e-5 max|ref|; every gradient tensor BOTH max-normalised (<= 1e-4 of its largest
-entry; 2e-4 for weights) AND per element |diff| <= 1e-4 max|ref| + 1e-3 |ref|; the smallest floor factor that would pass is
-printed so the bound can be tightened with evidence."""
+Tolerances (stated).  Eval-mode BatchNorm (the benchmarked configuration): forward max|diff| <= 2e-5 max|ref|; every gradient
+tensor BOTH max-normalised (<= 2e-5 of its largest entry; measured 3.4e-6) AND per element |diff| <= 1e-5 max|ref| + 1e-3 |ref|
+(measured floor 8.9e-7: entries 10^5 x smaller than the tensor's largest are still checked to 1 %).  Batch-statistics
+BatchNorm couples every pixel of a channel through mean / variance, which amplifies fp32 round-off of the 524 k-pixel sums:
+max-normalised <= 1e-3 (measured 1.2e-4), per-element floor 5e-4 (measured 8.9e-5).  The measured values are printed."""
 import os
 
 import numpy as np
@@ -28,7 +30,7 @@ pytestmark = pytest.mark.gpu
 KEYS = "uv_1d_p1, uv_1d_p1_ds1, uv_1d_p1_ds2, uv_1d_p1_ds3, uv_1d_p1_ds4".replace(' ', '').split(',')
 
 
-def _check(got, ref, what, rtol_max, stats):
+def _check(got, ref, what, rtol_max, stats, floor_max=1e-5):
     got, ref = got.detach().cpu().double(), ref.detach().cpu().double()
     assert got.shape == ref.shape, (what, got.shape, ref.shape)
     scale = max(float(ref.abs().max()), 1e-30)
@@ -36,7 +38,7 @@ def _check(got, ref, what, rtol_max, stats):
     e_max = float(diff.max()) / scale
     floor = float((diff - 1e-3 * ref.abs()).clamp_min(0).max()) / scale       # smallest a with |diff| <= a max|ref| + 1e-3 |ref|
     assert e_max <= rtol_max, f"{what}: max error {e_max:.3e} of the largest entry"
-    assert floor <= 1e-4, f"{what}: per-element bound needs floor {floor:.3e} (> 1e-4) of the largest entry"
+    assert floor <= floor_max, f"{what}: per-element bound needs floor {floor:.3e} (> {floor_max:.0e}) of the largest entry"
     stats["max"], stats["floor"] = max(stats["max"], e_max), max(stats["floor"], floor)
 
 
@@ -98,26 +100,29 @@ def test_training_step_8_crops_of_256(hip, bn_mode):
     ref_opt.step()
 
     stats = {"max": 0.0, "floor": 0.0}
-    _check(out, out_r, "forward", 1e-4 if training else 2e-5, stats)
+    fl = 5e-4 if training else 1e-5
+    _check(out, out_r, "forward", 1e-4 if training else 2e-5, stats, fl)
     assert abs(float(loss) - float(loss_r)) <= 1e-5 * abs(float(loss_r)), (float(loss), float(loss_r))
-    g_tol = 5e-4 if training else 1e-4
+    g_tol = 1e-3 if training else 2e-5
     for l in range(4):
-        _check(net_input[l].grad, feats[l].grad, f"dx level {l}", g_tol, stats)
+        _check(net_input[l].grad, feats[l].grad, f"dx level {l}", g_tol, stats, fl)
     n = 0
     for name, p in net.named_parameters():
         if name.startswith("ConvsOut."):
             assert p.grad is None
             continue
-        _check(p.grad, st_r[name].grad, name, 1e-3 if training else 2e-4, stats)
+        _check(p.grad, st_r[name].grad, name, g_tol, stats, fl)
         n += 1
     assert n >= 594
     print(f"[{bn_mode}] {n} parameter gradients + 4 input gradients at 8 x 256 x 256: worst max-normalised error "
-          f"{stats['max']:.2e}, smallest passing per-element floor {stats['floor']:.2e} (bound 1e-4)")
+          f"{stats['max']:.2e} (bound {g_tol:.0e}), smallest passing per-element floor {stats['floor']:.2e} (bound {fl:.0e})")
     # descriptors after the sorted sparse step == dense torch RMSprop (state seeded so that the update is ~ lr g / sqrt(sq))
     got = tex.state_dict()["texture_"].cpu()
     upd, upd_r = got - torch.from_numpy(init), tex_r.detach() - torch.from_numpy(init)
     d_stats = {"max": 0.0, "floor": 0.0}
-    _check(upd, upd_r, "descriptor update (sorted sparse RMSprop vs dense torch RMSprop)", 5e-4 if training else 2e-4, d_stats)
+    _check(upd, upd_r, "descriptor update (sorted sparse RMSprop vs dense torch RMSprop)", 1e-3 if training else 1e-4, d_stats,
+           5e-4 if training else 1e-4)
+    print(f"[{bn_mode}] descriptor update: max-normalised {d_stats['max']:.2e}, floor {d_stats['floor']:.2e}")
     touched = np.unique(np.concatenate([m.reshape(-1) for m in maps]))
     mask = np.ones(N, bool)
     mask[touched] = False
