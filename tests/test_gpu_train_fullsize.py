@@ -120,7 +120,7 @@ def test_training_step_8_crops_of_256(hip, bn_mode):
     got = tex.state_dict()["texture_"].cpu()
     upd, upd_r = got - torch.from_numpy(init), tex_r.detach() - torch.from_numpy(init)
     d_stats = {"max": 0.0, "floor": 0.0}
-    _check(upd, upd_r, "descriptor update (sorted sparse RMSprop vs dense torch RMSprop)", 1e-3 if training else 1e-4, d_stats,
+    _check(upd, upd_r, "descriptor update (sorted sparse RMSprop vs dense torch RMSprop)", 1e-3 if training else 2e-4, d_stats,
            5e-4 if training else 1e-4)
     print(f"[{bn_mode}] descriptor update: max-normalised {d_stats['max']:.2e}, floor {d_stats['floor']:.2e}")
     touched = np.unique(np.concatenate([m.reshape(-1) for m in maps]))
