@@ -218,6 +218,11 @@ typedef struct read_conv_desc {
     int config;                             /* tile configuration id, -1 = pick automatically */
     const float *wpacked_wino;              /* optional: read_conv_pack_wino_host() output (device); enables the
                                                Winograd F(2x2,3x3) kernel for 3x3/s1 single-source layers */
+    const float *wpacked_w16;               /* optional: read_conv_pack_w16_host() output (device): the same Winograd operand in the
+                                               order of the wave-autonomous kernel (all 16 frequencies of a tile in one wave,
+                                               v_mfma_f32_16x16x4_f32); taken for non-linear launches when present
+                                               (read_tuning_set("conv_w16", 0) or config >= 0 keep the row-per-wave kernel,
+                                               config = -3 forces it) */
     int linear;                             /* 1: plain convolution (training path): out[..][c] = conv_f + b_f,
                                                out[..][Cout + c] = conv_m + b_m, out_cstride >= 2 * Cout; no gate /
                                                BatchNorm / residual; workgroup-tiled or Winograd kernel */
@@ -247,6 +252,8 @@ int read_conv_pack_weights_host(int Cin, int Cout, int ksize, int kc, const floa
 /* Winograd F(2x2,3x3): transformed weights G g G^T in fragment order, Cin % 16 == 0 (16/9 the plain size). */
 size_t read_conv_wino_floats(int Cin, int Cout);
 int read_conv_pack_wino_host(int Cin, int Cout, const float *wf, const float *wm, float *wpacked_wino_host);
+/* same size (read_conv_wino_floats), order of the wave-autonomous Winograd kernel: [group][wave][chunk][row][col][lane][4] */
+int read_conv_pack_w16_host(int Cin, int Cout, const float *wf, const float *wm, float *wpacked_w16_host);
 int read_conv_pack_params_host(int Cout, const float *bf, const float *bm, const float *gamma,
                                const float *beta, const float *mean, const float *var, float eps,
                                float *params_host);

@@ -40,6 +40,7 @@ struct ConvKArgs {
     const float *mul;
     const float *wp;
     const float *wp_wino;          // Winograd-transformed weights (read_conv_pack_wino_host) or null
+    const float *wp_w16;           // the same weights in the order of the wave-autonomous kernel (read_conv_pack_w16_host) or null
     const float *params;
     const float *residual;
     float *out;
@@ -1038,6 +1039,343 @@ __global__ __launch_bounds__(256, 2) void gated_conv_wino_kernel(const ConvKArgs
 }
 
 // ------------------------------------------------------------------------------------------
+// Winograd F(2x2,3x3), wave-autonomous form on v_mfma_f32_16x16x4_f32 (round 3; index maps mirrored in tests/wino16_ref.py).
+//
+// The kernel above gives a wave one frequency ROW of a 32-tile x 32-channel unit, so the output transform
+// Y = A^T M A needs the other three waves: two passes through 32 KiB of LDS and three barriers per unit — at C = 32 / 64 as
+// long as the unit's MFMA loop (MFMA pipe busy 50-55 %, profiles/r2_pmc_mfma_busy.md).  Here the unit is cut the other way:
+//   * wave w of the workgroup owns output channels 8w .. 8w+7 of the 32-channel group and ALL 16 frequencies of all 32 tiles:
+//     the MFMA is 16x16x4 with  A operand = transformed weights, rows 0..7 = conv_f, rows 8..15 = conv_m of those 8 channels
+//                               B operand = transformed input of 16 tiles (block b = tile rows 2b, 2b+1; both blocks share A)
+//     -> 16 frequencies x 2 blocks x 4 registers = 128 accumulators; a lane ends up with every frequency of its
+//     (tile, 4 channels), so A^T M A is 24 lane-local additions per value: no LDS, no barrier, no other wave;
+//   * conv_f sits in lanes 0..31 and conv_m of the same (tile, channels) in lane + 32: one v_permlane32_swap per register pair
+//     puts f and m of block 0 into the lower and of block 1 into the upper half-wave; the gate is then lane-local and a lane
+//     loads / stores 4 consecutive channels of a pixel (128-bit residual loads and stores);
+//   * input patches are shared by the four waves exactly as before (10 x 18 pixels x 16 channels per chunk, three LDS
+//     buffers, fetched two chunks ahead; rows padded to 384 floats: the B-operand ds_read_b128 of lanes (tile, 4 cin) are
+//     bank-conflict free); weights come straight from L2, [group][wave][chunk][row a][j][lane][4 k-steps]: one
+//     global_load_dwordx4 per frequency and chunk;
+//   * a chunk = 8 groups (frequency row a, block b) of 16 MFMAs; every other instruction is an item pinned in the shadow of one
+//     MFMA of the group BEFORE the one that consumes it (LDS reads of the two patch rows, the row / column combinations of
+//     B^T d B in place, the next row's weights, patch staging), across chunk and unit boundaries;
+//   * no cross-wave traffic is left except the patch barrier per chunk; two workgroups per CU: the epilogue of one (VALU +
+//     memory) runs beside the MFMA stream of the other on the same SIMDs.
+struct Wino16Geom {
+    static constexpr int TR = 4, TC = 8;                       // tiles per block (rows, cols): two 16-tile MFMA blocks
+    static constexpr int IH = 2 * TR + 2, IW = 2 * TC + 2;     // 10 x 18 input pixels
+    static constexpr int KC = 16, PS = KC + 4;                 // floats per staged pixel
+    static constexpr int RS = IW * PS + 24;                    // floats per patch row (384): conflict-free B-operand reads
+    static constexpr int BUF = IH * RS;
+    static constexpr int NE = IH * IW * (KC / 4), NI = (NE + 255) / 256;
+    static constexpr int LDS_FLOATS = 3 * BUF + 4;             // three patch buffers + a dummy float4 slot
+};
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+
+template <bool MUL>
+__global__ __launch_bounds__(256, 2) void gated_conv_wino16_kernel(const ConvKArgs a)
+{
+    using WG = Wino16Geom;
+    __shared__ __attribute__((aligned(16))) float lds[WG::LDS_FLOATS];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);           // channel octet of this wave
+    const SrcDev s = a.src[0];
+    const int groups = a.CoutPad >> 5, G = gridDim.x;                  // G % groups == 0: g is fixed per workgroup
+    const int g = blockIdx.x % groups;
+    const int n = a.nchunks;
+
+    // ---- units: u = blockIdx.x + k G  ->  tile block u / groups = (by, bx), advanced by (wino_dby, wino_dbx) per step
+    int by = (blockIdx.x / groups) / a.tiles_x, bx = (blockIdx.x / groups) % a.tiles_x;      // running unit
+    int pby = by, pbx = bx, pu = blockIdx.x, pchunk = 0;                                     // prefetch cursor
+    auto step_tile = [&](int &ty_, int &tx_) {
+        ty_ += a.wino_dby;
+        tx_ += a.wino_dbx;
+        if (tx_ >= a.tiles_x) {
+            tx_ -= a.tiles_x;
+            ++ty_;
+        }
+    };
+
+    // ---- input patch staging (as in gated_conv_wino_kernel; LDS rows padded to RS floats)
+    int loff[WG::NI];
+    unsigned rel[WG::NI], aoff[WG::NI];
+    unsigned okmask = 0;
+#pragma unroll
+    for (int i = 0; i < WG::NI; ++i) {
+        const int e = tid + i * 256, q = e % 4, pix = e / 4;
+        loff[i] = e < WG::NE ? (pix / WG::IW) * WG::RS + (pix % WG::IW) * WG::PS + 4 * q : -1;
+        rel[i] = (unsigned)(((pix / WG::IW) * s.W + pix % WG::IW) * s.C + 4 * q) * 4u;
+    }
+    const unsigned safe_rel = (unsigned)((s.W + 1) * s.C) * 4u;
+    const char *pbase = nullptr;
+    long pdelta = 0;
+    if constexpr (MUL) pdelta = reinterpret_cast<const char *>(a.mul) - reinterpret_cast<const char *>(s.p);
+    auto set_patch = [&]() {
+        const int y0 = pby * (2 * WG::TR) - 1, x0 = pbx * (2 * WG::TC) - 1;
+        pbase = reinterpret_cast<const char *>(s.p) + ((long)y0 * s.W + x0) * (long)(s.C * 4);
+        okmask = 0;
+#pragma unroll
+        for (int i = 0; i < WG::NI; ++i) {
+            const int e = tid + i * 256, pix = e / 4, ppy = pix / WG::IW, ppx = pix % WG::IW;
+            const bool ok = (e < WG::NE) & (ppy >= -y0) & (ppy < a.inH - y0) & (ppx >= -x0) & (ppx < a.inW - x0);
+            okmask |= (ok ? 1u : 0u) << i;
+            aoff[i] = ok ? rel[i] : safe_rel;
+        }
+    };
+    auto advance = [&]() {
+        if (++pchunk == n) {
+            pchunk = 0;
+            if (pu + G < a.n_units) {
+                pu += G;
+                step_tile(pby, pbx);
+            }
+            set_patch();
+        }
+    };
+    float4 st[WG::NI], stm[MUL ? WG::NI : 1];
+    auto gload1 = [&](int i) {
+        st[i] = load_f4(pbase + pchunk * (WG::KC * 4), aoff[i]);
+        if constexpr (MUL) stm[i] = load_f4(pbase + pdelta + pchunk * (WG::KC * 4), aoff[i]);
+    };
+    auto staged = [&](int i, unsigned mask, const float4 &x, const float4 *y) {
+        float4 v = x;
+        if constexpr (MUL) v = make_float4(x.x * y[i].x, x.y * y[i].y, x.z * y[i].z, x.w * y[i].w);
+        return ((mask >> i) & 1u) ? v : make_float4(0.f, 0.f, 0.f, 0.f);
+    };
+    auto lwrite1 = [&](int i, int obuf) {
+        const float4 v = staged(i, okmask, st[i], stm);
+        *reinterpret_cast<float4 *>(lds + (loff[i] >= 0 ? obuf + loff[i] : 3 * WG::BUF)) = v;
+    };
+
+    // ---- B operand (transformed input): lane (t = tile of the block, kl) reads the float4 of input channels 4 kl .. 4 kl + 3
+    // (= the lane's k of MFMA steps 0..3) of patch pixel (2 (2b + t/8) + r, 2 (t%8) + c)
+    const int t16 = lane & 15, kl = lane >> 4;
+    const int lbase = (2 * (t16 >> 3)) * WG::RS + (2 * (t16 & 7)) * WG::PS + 4 * kl;
+    // frequency row a: T = d[ra] + sgn d[rb]   (B^T rows: d0 - d2, d1 + d2, d2 - d1, d1 - d3)
+    float4 V[2][4], dB[4];                                             // V[x]: B operands of the running / the next group
+    auto rd1 = [&](const float *buf, int vb, int na, int nb, int r) {  // LDS read r = 2c + {0: row ra, 1: row rb}
+        const int c = r >> 1;
+        const int ra = na == 0 ? 0 : na == 2 ? 2 : 1, rb = na == 0 ? 2 : na == 1 ? 2 : na == 2 ? 1 : 3;
+        const float *p = buf + lbase + (4 * nb) * WG::RS + c * WG::PS;
+        if (r & 1) dB[c] = *reinterpret_cast<const float4 *>(p + rb * WG::RS);
+        else V[vb][c] = *reinterpret_cast<const float4 *>(p + ra * WG::RS);
+    };
+    auto tt1 = [&](int vb, int na, int c) {                            // T[c] in place of d[ra][c]
+        float4 &x = V[vb][c];
+        const float4 y = dB[c];
+        if (na == 1) x = make_float4(x.x + y.x, x.y + y.y, x.z + y.z, x.w + y.w);
+        else x = make_float4(x.x - y.x, x.y - y.y, x.z - y.z, x.w - y.w);
+    };
+    // column combinations in place: V0 = T0 - T2, V3 = T1 - T3, (V1, V2) = (T1 + T2, T2 - T1)
+    auto vv1 = [&](int vb, int step) {
+        float4(&T)[4] = V[vb];
+        auto sub = [](const float4 &x, const float4 &y) { return make_float4(x.x - y.x, x.y - y.y, x.z - y.z, x.w - y.w); };
+        auto add = [](const float4 &x, const float4 &y) { return make_float4(x.x + y.x, x.y + y.y, x.z + y.z, x.w + y.w); };
+        if (step == 0) T[0] = sub(T[0], T[2]);
+        else if (step == 1) T[3] = sub(T[1], T[3]);
+        else if (step == 2) dB[0] = add(T[1], T[2]);                   // dB[0] is free by now: temporary for V1
+        else {
+            T[2] = sub(T[2], T[1]);
+            T[1] = dB[0];
+        }
+    };
+
+    // ---- A operand (weights): wave (g, wv): [chunk][a][j][lane][4]; one dwordx4 per (chunk, a, j) and lane
+    const char *const wbase = reinterpret_cast<const char *>(a.wp_w16) + ((size_t)(g * 4 + wv) * n) * (16 * 1024);
+    const unsigned wvoff = lane * 16;
+    float4 Wr[2][4];                                                   // ring by row parity
+    auto wload1 = [&](int slot, int j, int chunk, int row) {
+        Wr[slot][j] = load_f4(wbase + (size_t)((chunk * 4 + row) * 4 + j) * 1024, wvoff);
+    };
+
+    f32x4 acc[2][4][4];                                                // [block][a][j], written (C = 0) by the first chunk of a unit
+
+    // ---- prologue: two chunks of the stream into LDS, the weights of (chunk 0, row 0), B operands of group (0, 0, 0)
+    set_patch();
+    {
+        float4 st1[WG::NI], stm1[MUL ? WG::NI : 1];
+#pragma unroll
+        for (int i = 0; i < WG::NI; ++i) gload1(i);
+        const unsigned ok0 = okmask;
+        advance();
+#pragma unroll
+        for (int i = 0; i < WG::NI; ++i) {
+            st1[i] = load_f4(pbase + pchunk * (WG::KC * 4), aoff[i]);
+            if constexpr (MUL) stm1[i] = load_f4(pbase + pdelta + pchunk * (WG::KC * 4), aoff[i]);
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) wload1(0, j, 0, 0);
+#pragma unroll
+        for (int i = 0; i < WG::NI; ++i) {
+            const float4 v0 = staged(i, ok0, st[i], stm);
+            const float4 v1 = staged(i, okmask, st1[i], stm1);
+            if (loff[i] >= 0) {
+                *reinterpret_cast<float4 *>(lds + loff[i]) = v0;
+                *reinterpret_cast<float4 *>(lds + WG::BUF + loff[i]) = v1;
+            }
+        }
+        advance();
+    }
+    __syncthreads();
+#pragma unroll
+    for (int r = 0; r < 8; ++r) rd1(lds, 0, 0, 0, r);
+#pragma unroll
+    for (int c = 0; c < 4; ++c) tt1(0, 0, c);
+#pragma unroll
+    for (int st_ = 0; st_ < 4; ++st_) vv1(0, st_);
+
+    int o_cur = 0, o_nxt = WG::BUF, o_nn = 2 * WG::BUF;
+
+    auto chunk_body = [&](auto first_tag, int chunk) {
+        constexpr bool FIRST = decltype(first_tag)::value;
+        const float *buf = lds + o_cur, *bufn = lds + o_nxt;
+        int cnext = chunk + 1;                                         // chunk of the row after (chunk, 3): wraps into the next unit
+        cnext = cnext == n ? 0 : cnext;
+#pragma unroll
+        for (int ab = 0; ab < 8; ++ab) {
+            const int ra_ = ab >> 1, b = ab & 1;                      // this group: frequency row ra_, block b
+            const int vc = ab & 1, vn = vc ^ 1;                       // V slots: running / next group
+            const int na = ab == 7 ? 0 : (ab + 1) >> 1, nb = (ab + 1) & 1;
+            const float *tb = ab == 7 ? bufn : buf;                   // the next group's patch buffer
+            const int wc = ra_ & 1, wn = wc ^ 1;                      // weight slots: this row / next row
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int m = e * 4 + j;
+                    const float4 wv4 = Wr[wc][j], vv4 = V[vc][j];
+                    const float we = e == 0 ? wv4.x : e == 1 ? wv4.y : e == 2 ? wv4.z : wv4.w;
+                    const float ve = e == 0 ? vv4.x : e == 1 ? vv4.y : e == 2 ? vv4.z : vv4.w;
+                    if (FIRST && e == 0) {
+                        const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+                        acc[b][ra_][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(we, ve, zero, 0, 0, 0);
+                    } else
+                        acc[b][ra_][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(we, ve, acc[b][ra_][j], 0, 0, 0);
+                    // ---- items in the shadow of MFMA m: everything the NEXT group needs
+                    if (m < 8) rd1(tb, vn, na, nb, m);
+                    if (m < 4 && b == 0) {                                           // weights of the NEXT row: two groups
+                        if (ra_ < 3) wload1(wn, m, chunk, ra_ + 1);                  // (32 MFMAs) ahead of their first use
+                        else wload1(wn, m, cnext, 0);
+                    }
+                    if (m >= 8 && m < 12) tt1(vn, na, m - 8);
+                    if (m >= 12) vv1(vn, m - 12);
+                    if (ab == 0 && m >= 4 && m - 4 < WG::NI) gload1(m - 4);          // patch at the cursor -> registers
+                    if (ab == 4 && m >= 4 && m - 4 < WG::NI) lwrite1(m - 4, o_nn);   // ... -> LDS, half a chunk later
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+        }
+        advance();
+        __syncthreads();
+        const int o = o_cur;
+        o_cur = o_nxt;
+        o_nxt = o_nn;
+        o_nn = o;
+    };
+
+    for (int u = blockIdx.x; u < a.n_units; u += G) {
+        chunk_body(std::true_type{}, 0);
+        for (int chunk = 1; chunk < n; ++chunk) chunk_body(std::false_type{}, chunk);
+
+        // ================= unit epilogue (lane-local) =================
+        // D layout of v_mfma_f32_16x16x4_f32: lane (t = lane & 15, q = lane >> 4), register r = MFMA row 4q + r:
+        // q = 0, 1 -> conv_f of channels 4q + r; q = 2, 3 -> conv_m of channels 4 (q - 2) + r; column = tile t of block b.
+        __builtin_amdgcn_s_setprio(1);
+        const int cq = (lane >> 4) & 1, eb = lane >> 5;                                    // channel quad, block finished by this lane
+        const int c0 = g * 32 + wv * 8 + 4 * cq;
+        const int oy = by * (2 * WG::TR) + 2 * (2 * eb + (t16 >> 3)), ox = bx * (2 * WG::TC) + 2 * (t16 & 7);
+        const int c_lim = a.fill_pad ? a.out_cstride : a.Cout;
+        const bool quad_st = c0 + 3 < c_lim && (a.out_cstride & 3) == 0;
+        const bool quad_ld = a.residual && c0 + 3 < a.Cout && (a.Cout & 3) == 0;
+        const f32x4 bf = *reinterpret_cast<const f32x4 *>(a.params + c0);
+        const f32x4 bm = *reinterpret_cast<const f32x4 *>(a.params + a.CoutPad + c0);
+        const f32x4 sc = *reinterpret_cast<const f32x4 *>(a.params + 2 * a.CoutPad + c0);
+        const f32x4 sh = *reinterpret_cast<const f32x4 *>(a.params + 3 * a.CoutPad + c0);
+        bool pix_in[2][2];
+        f32x4 rv[2][2];
+#pragma unroll
+        for (int pa = 0; pa < 2; ++pa)
+#pragma unroll
+            for (int pb = 0; pb < 2; ++pb) {
+                pix_in[pa][pb] = (oy + pa < a.outH) & (ox + pb < a.outW);
+                rv[pa][pb] = f32x4{0.f, 0.f, 0.f, 0.f};
+                const float *rp = a.residual + ((size_t)(oy + pa) * a.outW + ox + pb) * a.Cout + c0;
+                if (pix_in[pa][pb] && quad_ld) rv[pa][pb] = *reinterpret_cast<const f32x4 *>(rp);
+                else if (pix_in[pa][pb] && a.residual) {
+#pragma unroll
+                    for (int k = 0; k < 4; ++k)
+                        if (c0 + k < a.Cout) rv[pa][pb][k] = rp[k];
+                }
+            }
+        // Y[pa][pb] = sum_a sum_j A^T[pa][a] M[a][j] A^T[pb][j],  A^T = [1 1 1 0; 0 1 -1 -1]
+        f32x4 Yf[2][2], Ym[2][2];
+#pragma unroll
+        for (int pa = 0; pa < 2; ++pa)
+#pragma unroll
+            for (int pb = 0; pb < 2; ++pb) {
+                f32x4 yb[2];
+#pragma unroll
+                for (int b = 0; b < 2; ++b) {
+                    f32x4 rr[3];                                       // rows a = pa, pa + 1, pa + 2 combined over j
+#pragma unroll
+                    for (int k = 0; k < 3; ++k) {
+                        const int ar = pa + k;
+                        rr[k] = pb == 0 ? acc[b][ar][0] + acc[b][ar][1] + acc[b][ar][2] : acc[b][ar][1] - acc[b][ar][2] - acc[b][ar][3];
+                    }
+                    yb[b] = pa == 0 ? rr[0] + rr[1] + rr[2] : rr[0] - rr[1] - rr[2];
+                }
+                // lanes 0..31 hold conv_f, lanes 32..63 conv_m of (block 0 | block 1): after the half exchange the lower
+                // half-wave owns block 0 and the upper half block 1, f in one register and m in the other
+                // (whole-vector bit casts: with __builtin_bit_cast of single vector ELEMENTS this hipcc folds the four swaps
+                //  into one — seen in the ISA)
+                u32x4 u0 = __builtin_bit_cast(u32x4, yb[0]), u1 = __builtin_bit_cast(u32x4, yb[1]);
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const auto sw = __builtin_amdgcn_permlane32_swap(u0[k], u1[k], false, false);
+                    u0[k] = sw[0];
+                    u1[k] = sw[1];
+                }
+                Yf[pa][pb] = __builtin_bit_cast(f32x4, u0);
+                Ym[pa][pb] = __builtin_bit_cast(f32x4, u1);
+            }
+        {
+            constexpr float LOG2E = 1.44269504088896341f;
+#pragma unroll
+            for (int pa = 0; pa < 2; ++pa)
+#pragma unroll
+                for (int pb = 0; pb < 2; ++pb) {
+                    f32x4 f = Yf[pa][pb] + bf;
+                    const f32x4 mm = (Ym[pa][pb] + bm) * -LOG2E;
+                    if (a.elu) {
+                        const f32x4 fe = f * LOG2E;
+#pragma unroll
+                        for (int k = 0; k < 4; ++k) f[k] = f[k] > 0.0f ? f[k] : __builtin_amdgcn_exp2f(fe[k]) - 1.0f;
+                    }
+                    f32x4 sg;
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) sg[k] = __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(mm[k]));
+                    f32x4 v = (f * sg) * sc + sh + rv[pa][pb];
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) v[k] = c0 + k < a.Cout ? v[k] : a.out_fill;
+                    float *op = a.out + ((size_t)(oy + pa) * a.outW + ox + pb) * a.out_cstride + c0;
+                    if (pix_in[pa][pb]) {
+                        if (quad_st) *reinterpret_cast<f32x4 *>(op) = v;
+                        else {
+#pragma unroll
+                            for (int k = 0; k < 4; ++k)
+                                if (c0 + k < c_lim) op[k] = v[k];
+                        }
+                    }
+                }
+        }
+        step_tile(by, bx);
+        __builtin_amdgcn_s_setprio(0);
+    }
+}
+
+// ------------------------------------------------------------------------------------------
 // 1x1 layers in the "pixel-lane" orientation: weights are the MFMA A operand, activations the B operand.
 //
 //   D[cout][pixel] = sum_k W[cout][k] * X[k][pixel]        (v_mfma_f32_32x32x2_f32: lane = pixel, registers = channels)
@@ -1318,6 +1656,7 @@ int g_conv_px = 1;         // read_tuning_set("conv_px", v): pixel-lane kernel f
                            // (64 / 128 accumulator registers per wave); 3 / 4 every layer it fits
 int g_kc32 = 1;            // 32-channel chunks for 1x1 layers whose sources are all multiples of 32 (read_tuning_set("conv_kc32", 0): 16)
 int g_use_wino = 1 << 30;  // read_tuning_set("conv_wino", max Cin): Winograd kernel for eligible 3x3 layers (0 = off)
+int g_w16 = 1;             // read_tuning_set("conv_w16", 0): the row-per-wave Winograd kernel instead of the wave-autonomous one
 int g_stagger_ticks = 0;   // read_tuning_set("conv_stagger", ticks of 10 ns)
 int g_ablate = 0;          // read_tuning_set("conv_ablate", bits): attribution probe, results invalid; -DREAD_DEBUG_KNOBS builds only
 
@@ -1484,6 +1823,34 @@ extern "C" int read_conv_pack_wino_host(int Cin, int Cout, const float *wf, cons
     return READ_OK;
 }
 
+// The wave-autonomous Winograd kernel's order (tests/wino16_ref.py): [group][wave 4][chunk of 16 cin][a][j][lane][e]; lane
+// (i = lane & 15, kl = lane >> 4) holds U_{i < 8 ? f : m}[a][j][cin = 16 chunk + 4 kl + e][cout = 32 group + 8 wave + (i & 7)].
+extern "C" int read_conv_pack_w16_host(int Cin, int Cout, const float *wf, const float *wm, float *out)
+{
+    READ_CHECK_ARG(wf && wm && out, "read_conv_pack_w16_host: null pointer");
+    READ_CHECK_ARG(Cin >= 16 && Cin % 16 == 0 && Cout >= 1, "read_conv_pack_w16_host: needs Cin %% 16 == 0 (got %d)", Cin);
+    static const float G[4][3] = {{1.f, 0.f, 0.f}, {.5f, .5f, .5f}, {.5f, -.5f, .5f}, {0.f, 0.f, 1.f}};
+    const int CoutPad = pad32(Cout), groups = CoutPad / 32, nchunks = Cin / 16;
+    size_t o = 0;
+    for (int g = 0; g < groups; ++g)
+        for (int w = 0; w < 4; ++w)
+            for (int c = 0; c < nchunks; ++c)
+                for (int i = 0; i < 4; ++i)
+                    for (int j = 0; j < 4; ++j)
+                        for (int lane = 0; lane < 64; ++lane)
+                            for (int e = 0; e < 4; ++e, ++o) {
+                                const int slot = lane & 15, co = g * 32 + w * 8 + (slot & 7), ci = 16 * c + 4 * (lane >> 4) + e;
+                                float u = 0.0f;
+                                if (co < Cout) {
+                                    const float *k = ((slot >> 3) ? wm : wf) + ((size_t)co * Cin + ci) * 9;
+                                    for (int a = 0; a < 3; ++a)
+                                        for (int b = 0; b < 3; ++b) u += G[i][a] * k[a * 3 + b] * G[j][b];
+                                }
+                                out[o] = u;
+                            }
+    return READ_OK;
+}
+
 extern "C" int read_conv_pack_params_host(int Cout, const float *bf, const float *bm, const float *gamma,
                                           const float *beta, const float *mean, const float *var, float eps,
                                           float *params_host)
@@ -1510,6 +1877,7 @@ void conv_set_stagger(int ticks) { g_stagger_ticks = ticks < 0 ? 0 : ticks; }
 void conv_set_ablate(int bits) { g_ablate = bits; }
 void conv_set_wino(int max_cin) { g_use_wino = max_cin; }
 void conv_set_kc32(int v) { g_kc32 = v; }
+void conv_set_w16(int v) { g_w16 = v ? 1 : 0; }
 void conv_set_wino_wgs(int v) { g_wino_wgs = v <= 1 ? 1 : 2; }
 void conv_set_px(int v) { g_conv_px = v < 0 ? 0 : v > 4 ? 4 : v; }
 int conv_get(const char *key, int *value)
@@ -1520,6 +1888,7 @@ int conv_get(const char *key, int *value)
     else if (!strcmp(key, "conv_px")) *value = g_conv_px;
     else if (!strcmp(key, "conv_wino_wgs")) *value = g_wino_wgs;
     else if (!strcmp(key, "conv_wino")) *value = g_use_wino;
+    else if (!strcmp(key, "conv_w16")) *value = g_w16;
 #ifdef READ_DEBUG_KNOBS
     else if (!strcmp(key, "conv_ablate")) *value = g_ablate;
 #endif
@@ -1609,6 +1978,7 @@ int launch_gated_conv(const read_conv_desc *d, hipStream_t stream)
     a.mul = d->mul;
     a.wp = d->wpacked;
     a.wp_wino = d->wpacked_wino;
+    a.wp_w16 = d->wpacked_w16;
     a.params = d->params;
     a.residual = d->residual;
     a.out = d->out;
@@ -1775,6 +2145,12 @@ int launch_gated_conv(const read_conv_desc *d, hipStream_t stream)
         READ_CHECK_ARG(c.fn_mul, "read_gated_conv_forward: config %s has no multiply variant", c.name);
         READ_CHECK_ARG((uintptr_t)d->mul % 16 == 0, "read_gated_conv_forward: mul misaligned");
         fn = c.fn_mul;
+    }
+    // the wave-autonomous Winograd kernel (same units, same grid) whenever its weight order was supplied; linear launches
+    // (training path) stay on the row-per-wave kernel, which carries the plain-convolution epilogue
+    if (c.wino && !d->linear && !a.trace && d->wpacked_w16 && (d->config == -3 || (d->config < 0 && g_w16))) {
+        READ_CHECK_ARG((uintptr_t)d->wpacked_w16 % 16 == 0, "read_gated_conv_forward: wpacked_w16 misaligned");
+        fn = d->mul ? gated_conv_wino16_kernel<true> : gated_conv_wino16_kernel<false>;
     }
     hipLaunchKernelGGL(fn, grid, dim3(256), 0, stream, a);
     READ_CHECK_LAUNCH();

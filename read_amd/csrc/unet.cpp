@@ -29,6 +29,7 @@ struct LayerInfo {
     int cin, cout, k, stride, elu, kc;
     size_t raw_off, w_off, p_off;   // float offsets into the raw / packed blobs
     size_t wino_off;                // Winograd-transformed weights of 3x3/s1 layers with Cin % 16 == 0, else NO_WINO
+    size_t w16_off;                 // ... in the order of the wave-autonomous Winograd kernel (read_conv_pack_w16_host)
 };
 constexpr size_t NO_WINO = ~(size_t)0;
 
@@ -67,7 +68,7 @@ const Arch &arch()
     static Arch A = [] {
         Arch a;
         auto add = [&](const std::string &path, int cin, int cout, int k, int s, int elu, int kc) {
-            LayerInfo L{path, cin, cout, k, s, elu, kc, 0, 0, 0, NO_WINO};
+            LayerInfo L{path, cin, cout, k, s, elu, kc, 0, 0, 0, NO_WINO, NO_WINO};
             L.raw_off = a.raw_floats;
             a.raw_floats += raw_layer_floats(cin, cout, k);
             L.w_off = a.packed_floats;
@@ -76,6 +77,8 @@ const Arch &arch()
             a.packed_floats += read_conv_param_floats(cout);
             if (k == 3 && s == 1 && kc == 16 && cin % 16 == 0) {
                 L.wino_off = a.packed_floats;
+                a.packed_floats += read_conv_wino_floats(cin, cout);
+                L.w16_off = a.packed_floats;
                 a.packed_floats += read_conv_wino_floats(cin, cout);
             }
             a.layers.push_back(L);
@@ -234,7 +237,7 @@ struct Builder {
     };
     struct LayerRef {
         int cin, cout, k, stride, elu;
-        size_t w_off, p_off, wino_off;
+        size_t w_off, p_off, wino_off, w16_off;
     };
 
     // One BasicConv.  srcs = {tensor id, shift}; out tensor must already exist.
@@ -243,7 +246,7 @@ struct Builder {
     {
         const Arch &A = arch();
         const LayerInfo &L = A.layers[A.find(path)];
-        emit(path, LayerRef{L.cin, L.cout, L.k, L.stride, L.elu, L.w_off, L.p_off, L.wino_off}, srcs, out_t, mul_t, res_t, 0,
+        emit(path, LayerRef{L.cin, L.cout, L.k, L.stride, L.elu, L.w_off, L.p_off, L.wino_off, L.w16_off}, srcs, out_t, mul_t, res_t, 0,
              PreRef());
     }
     // A derived 1x1 layer (DerivedInfo): `linear` ones store the pre-activations [f | m] for a finer level to add,
@@ -253,7 +256,7 @@ struct Builder {
         const Arch &A = arch();
         const DerivedInfo &D = A.derived[A.find_derived(name)];
         const LayerInfo &P0 = A.layers[D.parts[0]];
-        emit(name, LayerRef{D.cin, D.cout, 1, 1, P0.elu, D.w_off, linear ? D.p_off : P0.p_off, NO_WINO}, srcs, out_t, -1, -1,
+        emit(name, LayerRef{D.cin, D.cout, 1, 1, P0.elu, D.w_off, linear ? D.p_off : P0.p_off, NO_WINO, NO_WINO}, srcs, out_t, -1, -1,
              linear, pre);
     }
 
@@ -292,6 +295,7 @@ struct Builder {
         op.d.wpacked = u->packed + L.w_off;
         op.d.params = u->packed + L.p_off;
         op.d.wpacked_wino = L.wino_off != NO_WINO ? u->packed + L.wino_off : nullptr;
+        op.d.wpacked_w16 = L.w16_off != NO_WINO ? u->packed + L.w16_off : nullptr;
         op.d.mul = mul_t >= 0 ? u->tensors[mul_t].p : nullptr;
         op.d.residual = res_t >= 0 ? u->tensors[res_t].p : nullptr;
         op.d.out = o.p;
@@ -563,6 +567,8 @@ extern "C" int read_unet_pack_host(const float *raw, float bn_eps, float *packed
         if (rc) return rc;
         if (L.wino_off != NO_WINO) {
             rc = read_conv_pack_wino_host(L.cin, L.cout, wf, wm, packed + L.wino_off);
+            if (rc) return rc;
+            rc = read_conv_pack_w16_host(L.cin, L.cout, wf, wm, packed + L.w16_off);
             if (rc) return rc;
         }
     }

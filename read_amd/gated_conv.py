@@ -34,12 +34,16 @@ class PackedGatedConv:
                                                 pp.ctypes.data), "read_conv_pack_params_host")
         self.wpacked = torch.from_numpy(wp).to(device)
         self.params = torch.from_numpy(pp).to(device)
-        self.wpacked_wino = None
+        self.wpacked_wino = self.wpacked_w16 = None
         if self.k == 3 and self.cin % 16 == 0:        # Winograd F(2x2,3x3) operand for the 3x3/s1 kernel variant
             ww = np.empty(L.read_conv_wino_floats(self.cin, self.cout), np.float32)
             _lib.check(L.read_conv_pack_wino_host(self.cin, self.cout, wf.ctypes.data, wm.ctypes.data, ww.ctypes.data),
                        "read_conv_pack_wino_host")
             self.wpacked_wino = torch.from_numpy(ww).to(device)
+            w16 = np.empty(L.read_conv_wino_floats(self.cin, self.cout), np.float32)
+            _lib.check(L.read_conv_pack_w16_host(self.cin, self.cout, wf.ctypes.data, wm.ctypes.data, w16.ctypes.data),
+                       "read_conv_pack_w16_host")
+            self.wpacked_w16 = torch.from_numpy(w16).to(device)
 
 
 def gated_conv(packed, sources, stride=1, elu=True, mul=None, residual=None, config=-1, out=None,
@@ -76,6 +80,7 @@ def gated_conv(packed, sources, stride=1, elu=True, mul=None, residual=None, con
     d.out_fill = 0.0 if fill is None else float(fill)
     d.config = config
     d.wpacked_wino = packed.wpacked_wino.data_ptr() if packed.wpacked_wino is not None else None
+    d.wpacked_w16 = packed.wpacked_w16.data_ptr() if packed.wpacked_w16 is not None else None
     d.linear = 1 if linear else 0
     if pre is not None:
         pt, f_off, m_off, psh = pre

@@ -79,7 +79,7 @@ def test_winograd_kernel_on_unet_shapes(hip):
         x = torch.randn(c, H, W)
         res = torch.randn(c, H, W)
         ref = unet_torch.basic_conv(st, "L", x[None], 3, elu=j % 2 == 0)[0] + res
-        for cfg in ci:           # one and two unit streams per workgroup; the last shape gives every stream several units
+        for cfg in ci + [-3]:    # row-per-wave kernel(s); -3 = the wave-autonomous 16x16x4 kernel (tests/wino16_ref.py)
             got = gated_conv(_pack(st, [c]), [(_nhwc(x), 0)], elu=j % 2 == 0, residual=_nhwc(res), config=cfg)
             _close(got, ref, f"winograd config {cfg} {c}->{c} {H}x{W}", scale=5.0)
 
@@ -100,14 +100,15 @@ def test_winograd_kernel_odd_channel_counts_and_strides(hip):
         if res is not None:
             ref = ref + res
         width = cs if cs is not None else cout
-        out = torch.full((H, W, width), -7.0, device="cuda")           # sentinel: untouched channels must stay
-        got = gated_conv(_pack(st, [cin]), [(_nhwc(x), 0)], elu=j % 2 == 1, config=ci, out=out, out_channels=width,
-                         residual=_nhwc(res) if res is not None else None, fill=fill)
-        _close(got[:, :, :cout].contiguous(), ref, f"winograd edge case {j}: {cin}->{cout} {H}x{W} cs={cs}", scale=5.0)
-        if width > cout:
-            pad = got[:, :, cout:].cpu()
-            want = fill if fill is not None else -7.0
-            assert bool((pad == want).all()), f"case {j}: padded channels hold {pad.unique().tolist()}, want {want}"
+        for cfg in (ci, -3):                                           # both Winograd kernels
+            out = torch.full((H, W, width), -7.0, device="cuda")       # sentinel: untouched channels must stay
+            got = gated_conv(_pack(st, [cin]), [(_nhwc(x), 0)], elu=j % 2 == 1, config=cfg, out=out, out_channels=width,
+                             residual=_nhwc(res) if res is not None else None, fill=fill)
+            _close(got[:, :, :cout].contiguous(), ref, f"winograd edge case {j} (config {cfg}): {cin}->{cout} {H}x{W} cs={cs}", scale=5.0)
+            if width > cout:
+                pad = got[:, :, cout:].cpu()
+                want = fill if fill is not None else -7.0
+                assert bool((pad == want).all()), f"case {j}: padded channels hold {pad.unique().tolist()}, want {want}"
 
 
 def test_unet_layer_shapes_auto_config(hip):

@@ -25,3 +25,38 @@ def test_filter_transform_shape_and_dc():
     U = filter_transform(w)
     assert U.shape == (4, 4, 1, 1)
     assert abs(float(U[0, 0, 0, 0]) - 1.0) < 1e-6 and abs(float(U[1, 1, 0, 0]) - 2.25) < 1e-6
+
+
+def test_wave_autonomous_model_matches_conv2d():
+    """The 16x16x4-MFMA kernel's lane maps (tests/wino16_ref.py): weights as the A operand with conv_f | conv_m stacked in the
+    MFMA rows, tiles as columns, both 16-tile blocks, in-lane output transform."""
+    from tests.wino16_ref import pack_w16, wino16_conv_model
+    rng = np.random.default_rng(0)
+    cin, cout, H, W = 32, 40, 10, 20                      # two chunks, padded cout, partial tile blocks
+    wf = rng.standard_normal((cout, cin, 3, 3)).astype(np.float32) * 0.2
+    wm = rng.standard_normal((cout, cin, 3, 3)).astype(np.float32) * 0.2
+    x = rng.standard_normal((H, W, cin)).astype(np.float32)
+    f, m = wino16_conv_model(x, pack_w16(wf, wm), cin, cout)
+    xt = torch.from_numpy(x).permute(2, 0, 1)[None]
+    rf = F.conv2d(xt, torch.from_numpy(wf), padding=1)[0].permute(1, 2, 0).numpy()
+    rm = F.conv2d(xt, torch.from_numpy(wm), padding=1)[0].permute(1, 2, 0).numpy()
+    np.testing.assert_allclose(f, rf, rtol=1e-4, atol=1e-4)
+    np.testing.assert_allclose(m, rm, rtol=1e-4, atol=1e-4)
+
+
+def test_library_packers_equal_the_models():
+    """read_conv_pack_wino_host / read_conv_pack_w16_host (host code of libreadhip.so, no GPU needed) produce exactly the
+    fragment orders of the NumPy models the kernels were checked against."""
+    from read_amd import _lib
+    from tests.wino16_ref import pack_w16
+    L = _lib.lib()
+    rng = np.random.default_rng(1)
+    for cin, cout in ((16, 3), (32, 40), (48, 64)):
+        wf = rng.standard_normal((cout, cin, 3, 3)).astype(np.float32)
+        wm = rng.standard_normal((cout, cin, 3, 3)).astype(np.float32)
+        n = L.read_conv_wino_floats(cin, cout)
+        a, b = np.empty(n, np.float32), np.empty(n, np.float32)
+        assert L.read_conv_pack_wino_host(cin, cout, wf.ctypes.data, wm.ctypes.data, a.ctypes.data) == 0
+        assert L.read_conv_pack_w16_host(cin, cout, wf.ctypes.data, wm.ctypes.data, b.ctypes.data) == 0
+        np.testing.assert_allclose(a, pack_wino(wf, wm), rtol=1e-6, atol=1e-6)
+        np.testing.assert_allclose(b, pack_w16(wf, wm), rtol=1e-6, atol=1e-6)
