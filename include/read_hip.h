@@ -78,6 +78,11 @@ int read_debug_set_trace(void *buf, size_t bytes);
  * (4096 FLOP each) from registers — the sustained matrix-core ceiling for the conv kernels.
  * scratch: >= blocks*256 floats (never written in practice). */
 int read_debug_mfma_probe(int blocks, int iters, int nacc, float *scratch, void *stream);
+/* Issue-model probe (debug): every wave runs `iters` rounds of 16 fp32 MFMAs (kind 0: v_mfma_f32_32x32x2_f32, 1:
+ * v_mfma_f32_16x16x4_f32), each followed by K filler instructions of type `filler` (0 independent v_add_f32, 1 ds_read_b128,
+ * 2 s_add_u32, 3 dependent v_add_f32 chain, 4 global_load_dwordx4 from gsrc); cycles[blocks * 4] = s_memtime span per wave. */
+int read_debug_issue_probe(int kind, int filler, int K, int blocks, int iters, float *scratch, unsigned long long *cycles,
+                           const float *gsrc, void *stream);
 
 /* ---------------------------------------------------------------- rasteriser (z-buffer splat) */
 

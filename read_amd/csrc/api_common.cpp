@@ -53,6 +53,7 @@ void conv_set_ablate(int bits);
 void conv_set_wino(int max_cin);
 void conv_set_kc32(int v);
 void conv_set_w16(int v);
+void conv_set_w16_abl(int v);
 void conv_set_px(int v);
 void conv_set_wino_wgs(int v);
 int conv_get(const char *key, int *value);
@@ -109,6 +110,7 @@ extern "C" int read_tuning_set(const char *key, int value)
     if (!strcmp(key, "conv_wino_wgs")) { readhip::conv_set_wino_wgs(value); return READ_OK; } // persistent Winograd workgroups per CU: 1 or 2
     if (!strcmp(key, "conv_px")) { readhip::conv_set_px(value); return READ_OK; }             // pixel-lane kernel for 1x1 layers
     if (!strcmp(key, "conv_kc32")) { readhip::conv_set_kc32(value); return READ_OK; }
+    if (!strcmp(key, "conv_w16_abl")) { readhip::conv_set_w16_abl(value); return READ_OK; }   // attribution probes (results invalid)
     if (!strcmp(key, "conv_w16")) { readhip::conv_set_w16(value); return READ_OK; }           // wave-autonomous Winograd kernel (0 = row-per-wave)
     if (!strcmp(key, "conv_wino")) { readhip::conv_set_wino(value); return READ_OK; }         // largest Cin on the Winograd kernel (0 = off)
     if (!strcmp(key, "conv_stagger")) { readhip::conv_set_stagger(value); return READ_OK; }

@@ -1074,7 +1074,9 @@ struct Wino16Geom {
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 
-template <bool MUL>
+// ABL (attribution probes, results invalid, selected only by read_tuning_set("conv_w16_abl")): 1 no epilogue, 2 weights loaded
+// once, 4 B operands formed once (no LDS reads / transforms in the loop), 8 no patch staging, 16 no barrier
+template <bool MUL, int ABL = 0>
 __global__ __launch_bounds__(256, 2) void gated_conv_wino16_kernel(const ConvKArgs a)
 {
     using WG = Wino16Geom;
@@ -1246,7 +1248,7 @@ __global__ __launch_bounds__(256, 2) void gated_conv_wino16_kernel(const ConvKAr
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
                     const int m = e * 4 + j;
-                    const float4 wv4 = Wr[wc][j], vv4 = V[vc][j];
+                    const float4 wv4 = Wr[(ABL & 2) ? 0 : wc][j], vv4 = V[(ABL & 4) ? 0 : vc][j];
                     const float we = e == 0 ? wv4.x : e == 1 ? wv4.y : e == 2 ? wv4.z : wv4.w;
                     const float ve = e == 0 ? vv4.x : e == 1 ? vv4.y : e == 2 ? vv4.z : vv4.w;
                     if (FIRST && e == 0) {
@@ -1255,30 +1257,64 @@ __global__ __launch_bounds__(256, 2) void gated_conv_wino16_kernel(const ConvKAr
                     } else
                         acc[b][ra_][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(we, ve, acc[b][ra_][j], 0, 0, 0);
                     // ---- items in the shadow of MFMA m: everything the NEXT group needs
-                    if (m < 8) rd1(tb, vn, na, nb, m);
-                    if (m < 4 && b == 0) {                                           // weights of the NEXT row: two groups
+                    if (!(ABL & 4)) {
+                        if (m < 8) rd1(tb, vn, na, nb, m);
+                        if (m >= 8 && m < 12) tt1(vn, na, m - 8);
+                        if (m >= 12) vv1(vn, m - 12);
+                    }
+                    if (m < 4 && b == 0 && !(ABL & 2)) {                             // weights of the NEXT row: two groups
                         if (ra_ < 3) wload1(wn, m, chunk, ra_ + 1);                  // (32 MFMAs) ahead of their first use
                         else wload1(wn, m, cnext, 0);
                     }
-                    if (m >= 8 && m < 12) tt1(vn, na, m - 8);
-                    if (m >= 12) vv1(vn, m - 12);
-                    if (ab == 0 && m >= 4 && m - 4 < WG::NI) gload1(m - 4);          // patch at the cursor -> registers
-                    if (ab == 4 && m >= 4 && m - 4 < WG::NI) lwrite1(m - 4, o_nn);   // ... -> LDS, half a chunk later
+                    if (!(ABL & 8)) {
+                        if (ab == 0 && m >= 4 && m - 4 < WG::NI) gload1(m - 4);      // patch at the cursor -> registers
+                        if (ab == 4 && m >= 4 && m - 4 < WG::NI) lwrite1(m - 4, o_nn);   // ... -> LDS, half a chunk later
+                    }
                     __builtin_amdgcn_sched_barrier(0);
                 }
         }
         advance();
-        __syncthreads();
+        if (!(ABL & 16)) __syncthreads();
         const int o = o_cur;
         o_cur = o_nxt;
         o_nxt = o_nn;
         o_nn = o;
     };
 
+    // A wave whose 8 channels are all padding (Cout = 3: the output layer) only helps with the patch staging: the unit then
+    // costs one wave's MFMAs instead of four
+    if (g * 32 + wv * 8 >= a.Cout) {
+        for (int u = blockIdx.x; u < a.n_units; u += G)
+            for (int chunk = 0; chunk < n; ++chunk) {
+#pragma unroll
+                for (int i = 0; i < WG::NI; ++i) gload1(i);
+#pragma unroll
+                for (int i = 0; i < WG::NI; ++i) lwrite1(i, o_nn);
+                advance();
+                __syncthreads();
+                const int o = o_cur;
+                o_cur = o_nxt;
+                o_nxt = o_nn;
+                o_nn = o;
+            }
+        return;
+    }
     for (int u = blockIdx.x; u < a.n_units; u += G) {
         chunk_body(std::true_type{}, 0);
         for (int chunk = 1; chunk < n; ++chunk) chunk_body(std::false_type{}, chunk);
 
+        if (ABL & 1) {                                                 // keep the accumulators live with one store per wave
+            f32x4 ssum = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int b = 0; b < 2; ++b)
+#pragma unroll
+                for (int aa = 0; aa < 4; ++aa)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) ssum += acc[b][aa][j];
+            if (ssum[0] + ssum[1] + ssum[2] + ssum[3] == 12345.678f) a.out[lane] = ssum[0];
+            step_tile(by, bx);
+            continue;
+        }
         // ================= unit epilogue (lane-local) =================
         // D layout of v_mfma_f32_16x16x4_f32: lane (t = lane & 15, q = lane >> 4), register r = MFMA row 4q + r:
         // q = 0, 1 -> conv_f of channels 4q + r; q = 2, 3 -> conv_m of channels 4 (q - 2) + r; column = tile t of block b.
@@ -1656,6 +1692,7 @@ int g_conv_px = 1;         // read_tuning_set("conv_px", v): pixel-lane kernel f
                            // (64 / 128 accumulator registers per wave); 3 / 4 every layer it fits
 int g_kc32 = 1;            // 32-channel chunks for 1x1 layers whose sources are all multiples of 32 (read_tuning_set("conv_kc32", 0): 16)
 int g_use_wino = 1 << 30;  // read_tuning_set("conv_wino", max Cin): Winograd kernel for eligible 3x3 layers (0 = off)
+int g_w16_abl = 0;         // read_tuning_set("conv_w16_abl", bits): attribution probes of the wave-autonomous kernel (results invalid)
 int g_w16 = 1;             // read_tuning_set("conv_w16", 0): the row-per-wave Winograd kernel instead of the wave-autonomous one
 int g_stagger_ticks = 0;   // read_tuning_set("conv_stagger", ticks of 10 ns)
 int g_ablate = 0;          // read_tuning_set("conv_ablate", bits): attribution probe, results invalid; -DREAD_DEBUG_KNOBS builds only
@@ -1878,6 +1915,7 @@ void conv_set_ablate(int bits) { g_ablate = bits; }
 void conv_set_wino(int max_cin) { g_use_wino = max_cin; }
 void conv_set_kc32(int v) { g_kc32 = v; }
 void conv_set_w16(int v) { g_w16 = v ? 1 : 0; }
+void conv_set_w16_abl(int v) { g_w16_abl = v; }
 void conv_set_wino_wgs(int v) { g_wino_wgs = v <= 1 ? 1 : 2; }
 void conv_set_px(int v) { g_conv_px = v < 0 ? 0 : v > 4 ? 4 : v; }
 int conv_get(const char *key, int *value)
@@ -2151,6 +2189,19 @@ int launch_gated_conv(const read_conv_desc *d, hipStream_t stream)
     if (c.wino && !d->linear && !a.trace && d->wpacked_w16 && (d->config == -3 || (d->config < 0 && g_w16))) {
         READ_CHECK_ARG((uintptr_t)d->wpacked_w16 % 16 == 0, "read_gated_conv_forward: wpacked_w16 misaligned");
         fn = d->mul ? gated_conv_wino16_kernel<true> : gated_conv_wino16_kernel<false>;
+        if (!d->mul && g_w16_abl) {
+            switch (g_w16_abl) {
+            case 1: fn = gated_conv_wino16_kernel<false, 1>; break;
+            case 2: fn = gated_conv_wino16_kernel<false, 2>; break;
+            case 4: fn = gated_conv_wino16_kernel<false, 4>; break;
+            case 8: fn = gated_conv_wino16_kernel<false, 8>; break;
+            case 16: fn = gated_conv_wino16_kernel<false, 16>; break;
+            case 6: fn = gated_conv_wino16_kernel<false, 6>; break;
+            case 14: fn = gated_conv_wino16_kernel<false, 14>; break;
+            case 31: fn = gated_conv_wino16_kernel<false, 31>; break;
+            default: break;
+            }
+        }
     }
     hipLaunchKernelGGL(fn, grid, dim3(256), 0, stream, a);
     READ_CHECK_LAUNCH();

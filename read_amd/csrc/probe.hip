@@ -46,7 +46,112 @@ __global__ __launch_bounds__(256) void mfma_f32_probe_kernel(float *out, int ite
         for (int r = 0; r < 16; ++r) s += acc[i][r];
     if (s == 1234.5678f) out[blockIdx.x * blockDim.x + threadIdx.x] = s;   // keeps everything live
 }
+
+// ---- issue-model probe: what does ONE filler instruction in the shadow of an fp32 MFMA cost, alone on a SIMD and beside a
+// second wave?  Each wave runs `iters` rounds of 16 MFMAs on independent accumulators; after every MFMA come K fillers
+// (pinned with sched_barrier): FT 0 independent v_add_f32, 1 ds_read_b128 (waited once per round), 2 s_add_u32, 3 v_add_f32 in
+// one dependent chain, 4 global_load_dwordx4 (L2-resident line, waited once per round).  KIND 0: v_mfma_f32_32x32x2_f32
+// (8 accumulators, 2 MFMAs each per round), 1: v_mfma_f32_16x16x4_f32 (16 accumulators).  Lane 0 of every wave stores its
+// s_memtime span.
+typedef float floatx4 __attribute__((ext_vector_type(4)));
+template <int KIND, int FT, int K>
+__global__ __launch_bounds__(256, 2) void issue_probe_kernel(float *out, unsigned long long *cycles, int iters, const float4 *gsrc)
+{
+    __shared__ float4 lbuf[256];
+    lbuf[threadIdx.x] = make_float4(1.f, 2.f, 3.f, 4.f);
+    __syncthreads();
+    floatx16 acc32[KIND == 0 ? 8 : 1];
+    floatx4 acc16[KIND == 1 ? 16 : 1];
+#pragma unroll
+    for (int i = 0; i < (KIND == 0 ? 8 : 1); ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc32[i][r] = 0.0f;
+#pragma unroll
+    for (int i = 0; i < (KIND == 1 ? 16 : 1); ++i) acc16[i] = floatx4{0.f, 0.f, 0.f, 0.f};
+    float a0 = 0.37f + 0.001f * threadIdx.x, b0 = 1.0f - 0.002f * threadIdx.x;
+    float x[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) x[i] = 0.01f * (i + 1) + threadIdx.x;
+    float4 ld[4] = {};
+    unsigned sacc = 0;
+    const unsigned laddr = (threadIdx.x & 63) * 16;
+    const float4 *gp = gsrc + (threadIdx.x & 63);
+    const unsigned long long t0 = __builtin_amdgcn_s_memtime();
+    for (int it = 0; it < iters; ++it) {
+#pragma unroll
+        for (int m = 0; m < 16; ++m) {
+            if (KIND == 0) acc32[m & 7] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc32[m & 7], 0, 0, 0);
+            else acc16[m] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0, b0, acc16[m], 0, 0, 0);
+#pragma unroll
+            for (int k = 0; k < K; ++k) {
+                const int q = (m * K + k) & 7;
+                if (FT == 0) asm volatile("v_add_f32 %0, %0, %1" : "+v"(x[q]) : "v"(b0));
+                else if (FT == 1) asm volatile("ds_read_b128 %0, %1" : "=v"(ld[q & 3]) : "v"(laddr) : "memory");
+                else if (FT == 2) asm volatile("s_add_u32 %0, %0, 3" : "+s"(sacc));
+                else if (FT == 3) asm volatile("v_add_f32 %0, %0, %1" : "+v"(x[0]) : "v"(b0));
+                else asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(ld[q & 3]) : "v"(gp) : "memory");
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        if (FT == 1) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        if (FT == 4) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        a0 = a0 * 0.999f + 0.0007f;
+        b0 = b0 * 1.0001f - 0.0001f;
+    }
+    const unsigned long long t1 = __builtin_amdgcn_s_memtime();
+    float ssum = (float)sacc;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) ssum += x[i];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) ssum += ld[i].x + ld[i].w;
+#pragma unroll
+    for (int i = 0; i < (KIND == 0 ? 8 : 1); ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) ssum += acc32[i][r];
+#pragma unroll
+    for (int i = 0; i < (KIND == 1 ? 16 : 1); ++i) ssum += acc16[i][0] + acc16[i][3];
+    if (ssum == 1234.5678f) out[blockIdx.x * blockDim.x + threadIdx.x] = ssum;
+    if ((threadIdx.x & 63) == 0) cycles[blockIdx.x * 4 + (threadIdx.x >> 6)] = t1 - t0;
+}
+
+template <int KIND, int FT>
+int issue_probe_launch(int K, int blocks, float *out, unsigned long long *cycles, int iters, const float4 *gsrc, hipStream_t s)
+{
+#define IP_CASE(k) case k: hipLaunchKernelGGL((issue_probe_kernel<KIND, FT, k>), dim3(blocks), dim3(256), 0, s, out, cycles, iters, gsrc); return 0;
+    switch (K) {
+        IP_CASE(0) IP_CASE(1) IP_CASE(2) IP_CASE(3) IP_CASE(4) IP_CASE(6) IP_CASE(8) IP_CASE(12)
+    default: return 1;
+    }
+#undef IP_CASE
+}
 }  // namespace
+
+// kind 0 / 1 = v_mfma_f32_32x32x2_f32 / v_mfma_f32_16x16x4_f32; filler type 0..4 (see issue_probe_kernel); K fillers per MFMA in
+// {0,1,2,3,4,6,8,12}; `blocks` workgroups of 4 waves; cycles[blocks * 4] receives every wave's s_memtime span; gsrc: 1 KiB.
+extern "C" int read_debug_issue_probe(int kind, int filler, int K, int blocks, int iters, float *scratch, unsigned long long *cycles,
+                                      const float *gsrc, void *stream)
+{
+    READ_CHECK_ARG(blocks > 0 && iters > 0 && scratch && cycles && gsrc, "read_debug_issue_probe: bad arguments");
+    const float4 *g = reinterpret_cast<const float4 *>(gsrc);
+    hipStream_t s = as_stream(stream);
+    int rc = 1;
+    if (kind == 0) {
+        if (filler == 0) rc = issue_probe_launch<0, 0>(K, blocks, scratch, cycles, iters, g, s);
+        else if (filler == 1) rc = issue_probe_launch<0, 1>(K, blocks, scratch, cycles, iters, g, s);
+        else if (filler == 2) rc = issue_probe_launch<0, 2>(K, blocks, scratch, cycles, iters, g, s);
+        else if (filler == 3) rc = issue_probe_launch<0, 3>(K, blocks, scratch, cycles, iters, g, s);
+        else if (filler == 4) rc = issue_probe_launch<0, 4>(K, blocks, scratch, cycles, iters, g, s);
+    } else if (kind == 1) {
+        if (filler == 0) rc = issue_probe_launch<1, 0>(K, blocks, scratch, cycles, iters, g, s);
+        else if (filler == 1) rc = issue_probe_launch<1, 1>(K, blocks, scratch, cycles, iters, g, s);
+        else if (filler == 2) rc = issue_probe_launch<1, 2>(K, blocks, scratch, cycles, iters, g, s);
+        else if (filler == 3) rc = issue_probe_launch<1, 3>(K, blocks, scratch, cycles, iters, g, s);
+        else if (filler == 4) rc = issue_probe_launch<1, 4>(K, blocks, scratch, cycles, iters, g, s);
+    }
+    if (rc) { set_error("read_debug_issue_probe: unsupported kind / filler / K"); return READ_EINVAL; }
+    READ_CHECK_LAUNCH();
+    return READ_OK;
+}
 
 // Launches `blocks` workgroups of 4 waves, each wave issuing iters*nacc*4 MFMAs (4096 FLOP each).
 extern "C" int read_debug_mfma_probe(int blocks, int iters, int nacc, float *scratch, void *stream)

@@ -1,0 +1,44 @@
+"""Issue model of gfx950 around fp32 MFMAs (run on the GPU box): cycles per MFMA slot as a function of the MFMA shape, the
+number / kind of filler instructions in its shadow, and the number of waves per SIMD.
+
+    python tools/issue_probe.py [out.json]
+"""
+import json
+import os
+import sys
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from read_amd import _lib  # noqa: E402
+
+L = _lib.lib()
+scratch = torch.zeros(256 * 8192, device="cuda")
+gsrc = torch.ones(4096, device="cuda")
+cycles = torch.zeros(4096, dtype=torch.int64, device="cuda")
+FT = {0: "v_add indep", 1: "ds_read_b128", 2: "s_add", 3: "v_add chain", 4: "global_load_dwordx4"}
+res = []
+iters = 2000
+for kind in (0, 1):
+    for wps in (1, 2):                      # waves per SIMD = workgroups per CU
+        blocks = 256 * wps
+        for ft in (0, 1, 2, 3, 4):
+            for K in (0, 1, 2, 3, 4, 6, 8, 12):
+                if K == 0 and ft != 0:
+                    continue
+                for rep in range(2):
+                    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                    e0.record()
+                    _lib.check(L.read_debug_issue_probe(kind, ft, K, blocks, iters, scratch.data_ptr(), cycles.data_ptr(), gsrc.data_ptr(),
+                                                        _lib.stream_ptr()))
+                    e1.record()
+                    e1.synchronize()
+                ms = e0.elapsed_time(e1)
+                cyc = cycles[:blocks * 4].double()
+                per = float(cyc.mean()) / (iters * 16)          # s_memtime ticks per MFMA slot of ONE wave
+                row = {"mfma": "32x32x2" if kind == 0 else "16x16x4", "waves_per_simd": wps, "filler": FT[ft], "K": K, "ms": ms,
+                       "ticks_per_mfma_per_wave": per, "ticks_per_mfma_per_simd": per / wps,
+                       "ns_per_mfma_per_simd": 1e6 * ms / (iters * 16 * wps)}
+                print(row, flush=True)
+                res.append(row)
+json.dump(res, open(sys.argv[1] if len(sys.argv) > 1 else "gpurun_out/issue_probe.json", "w"), indent=1)
