@@ -1412,6 +1412,399 @@ __global__ __launch_bounds__(256, 2) void gated_conv_wino16_kernel(const ConvKAr
 }
 
 // ------------------------------------------------------------------------------------------
+// Version 2 of the wave-autonomous Winograd kernel: the INPUT TRANSFORM is shared by the four waves through LDS.
+//
+// tools/issue_probe.py (profiles/r3_issue_probe.json): the fp32 MFMA runs on the FP32 vector pipe itself — a v_add_f32 behind a
+// v_mfma_f32_* costs its full issue time whether it is "in the shadow" or not (16x16x4: 33 cycles alone, +2.5..3 per VALU
+// instruction with two waves per SIMD; LDS reads, SALU and global loads DO overlap).  So every VALU instruction competes with the
+// MFMAs for the same cycles, and version 1 — each wave forming B^T d B of all 32 tiles for itself — spends 19 % of its loop
+// there (attribution runs: profiles/r3_w16_ablation.md).  Here a chunk is processed in two PARTS (frequency rows 2p, 2p + 1):
+//   * transform role: wave w forms row a = 2p + (w & 1) of block tb = w >> 1 (lane = tile x 4 input channels): 8 ds_read_b128 of the
+//     raw patch, 32 VALU, 4 ds_write_b128 into Vbuf[p][8 frequencies][32 tiles][16 channels] (16 KiB, XOR-swizzled float4 slots:
+//     stores and loads are bank-conflict free) — a quarter of version 1's VALU work per wave;
+//   * MFMA role: as version 1 (A = weights of the wave's 8 channels, f | m in the 16 rows; B = a 16-tile block), B operands read
+//     from Vbuf with one ds_read_b128 per (frequency, block) = 4 k-steps; 64 MFMAs per part, order (frequency, k-step, block) so
+//     that an accumulator is touched every second MFMA;
+//   * pipeline: during the MFMAs of part s the wave transforms part s + 1 into the other V buffer, fetches the weights three
+//     frequencies ahead and stages the raw patch of the next chunk (two raw buffers); one barrier per part.
+// Epilogue, units, weight order: version 1.  LDS: 2 x 15 KiB raw + 2 x 16 KiB V.  Index maps: tests/wino16_ref.py (v2 model).
+struct Wino16sGeom {
+    static constexpr int IH = 10, IW = 18, KC = 16, PS = KC + 4;
+    static constexpr int RS = IW * PS + 24;                    // floats per raw patch row (384)
+    static constexpr int BUF = IH * RS;                        // raw patch buffer (3840 floats)
+    static constexpr int VBUF = 8 * 32 * 16;                   // one part of the transformed chunk (4096 floats)
+    static constexpr int NE = IH * IW * (KC / 4), NI = (NE + 255) / 256;
+    static constexpr int V0 = 2 * BUF;                         // float offset of Vbuf[0]
+    static constexpr int LDS_FLOATS = 2 * BUF + 2 * VBUF + 4;  // + a dummy float4 slot
+};
+
+template <bool MUL, int ABL = 0>
+__global__ __launch_bounds__(256, 2) void gated_conv_wino16s_kernel(const ConvKArgs a)
+{
+    using WG = Wino16sGeom;
+    __shared__ __attribute__((aligned(16))) float lds[WG::LDS_FLOATS];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const SrcDev s = a.src[0];
+    const int groups = a.CoutPad >> 5, G = gridDim.x;
+    const int g = blockIdx.x % groups;
+    const int n = a.nchunks;
+
+    int by = (blockIdx.x / groups) / a.tiles_x, bx = (blockIdx.x / groups) % a.tiles_x;      // running unit
+    int pby = by, pbx = bx, pu = blockIdx.x, pchunk = 0;                                     // prefetch cursor (raw patches)
+    auto step_tile = [&](int &ty_, int &tx_) {
+        ty_ += a.wino_dby;
+        tx_ += a.wino_dbx;
+        if (tx_ >= a.tiles_x) {
+            tx_ -= a.tiles_x;
+            ++ty_;
+        }
+    };
+
+    // ---- raw patch staging (global -> registers -> LDS), two buffers
+    int loff[WG::NI];
+    unsigned rel[WG::NI], aoff[WG::NI];
+    unsigned okmask = 0;
+#pragma unroll
+    for (int i = 0; i < WG::NI; ++i) {
+        const int e = tid + i * 256, q = e % 4, pix = e / 4;
+        loff[i] = e < WG::NE ? (pix / WG::IW) * WG::RS + (pix % WG::IW) * WG::PS + 4 * q : -1;
+        rel[i] = (unsigned)(((pix / WG::IW) * s.W + pix % WG::IW) * s.C + 4 * q) * 4u;
+    }
+    const unsigned safe_rel = (unsigned)((s.W + 1) * s.C) * 4u;
+    const char *pbase = nullptr;
+    long pdelta = 0;
+    if constexpr (MUL) pdelta = reinterpret_cast<const char *>(a.mul) - reinterpret_cast<const char *>(s.p);
+    auto set_patch = [&]() {
+        const int y0 = pby * 8 - 1, x0 = pbx * 16 - 1;
+        pbase = reinterpret_cast<const char *>(s.p) + ((long)y0 * s.W + x0) * (long)(s.C * 4);
+        okmask = 0;
+#pragma unroll
+        for (int i = 0; i < WG::NI; ++i) {
+            const int e = tid + i * 256, pix = e / 4, ppy = pix / WG::IW, ppx = pix % WG::IW;
+            const bool ok = (e < WG::NE) & (ppy >= -y0) & (ppy < a.inH - y0) & (ppx >= -x0) & (ppx < a.inW - x0);
+            okmask |= (ok ? 1u : 0u) << i;
+            aoff[i] = ok ? rel[i] : safe_rel;
+        }
+    };
+    auto advance = [&]() {                                   // the cursor crosses unit boundaries (past the last unit it repeats it)
+        if (++pchunk == n) {
+            pchunk = 0;
+            if (pu + G < a.n_units) {
+                pu += G;
+                step_tile(pby, pbx);
+            }
+            set_patch();
+        }
+    };
+    float4 st[WG::NI], stm[MUL ? WG::NI : 1];
+    unsigned st_ok = 0;                                      // in-image mask of the chunk held in st[]
+    auto gload1 = [&](int i) {
+        st[i] = load_f4(pbase + pchunk * (WG::KC * 4), aoff[i]);
+        if constexpr (MUL) stm[i] = load_f4(pbase + pdelta + pchunk * (WG::KC * 4), aoff[i]);
+    };
+    auto lwrite1 = [&](int i, int obuf) {
+        float4 v = st[i];
+        if constexpr (MUL) v = make_float4(v.x * stm[i].x, v.y * stm[i].y, v.z * stm[i].z, v.w * stm[i].w);
+        if (!((st_ok >> i) & 1u)) v = make_float4(0.f, 0.f, 0.f, 0.f);
+        *reinterpret_cast<float4 *>(lds + (loff[i] >= 0 ? obuf + loff[i] : WG::LDS_FLOATS - 4)) = v;
+    };
+
+    // ---- lane constants.  t16 = tile within a 16-tile block (MFMA column / transform item), kl = channel quad
+    const int t16 = lane & 15, kl = lane >> 4;
+    const int lbase = (2 * (t16 >> 3)) * WG::RS + (2 * (t16 & 7)) * WG::PS + 4 * kl;               // raw patch (floats)
+    const int vlane = t16 * 16 + 4 * (kl ^ ((t16 >> 1) & 3));                                       // swizzled float4 slot of a V row
+    const int t_blk = wv >> 1, t_row = wv & 1;                                                      // transform role of this wave
+    const int vwbase = WG::V0 + ((t_row * 4) * 32 + 16 * t_blk) * 16 + vlane;                       // + part * VBUF + j * 512
+    const int rbase = lbase + (4 * t_blk) * WG::RS;                                                 // + raw buffer
+
+    // transform scratch: T[c] ends up as V[j] in place
+    float4 tA[4], tB[4];
+    auto t_rd = [&](const float *raw, int arow, int r) {          // r = 2c + {0: row ra, 1: row rb}
+        const int c = r >> 1;
+        const int ra = arow == 0 ? 0 : arow == 2 ? 2 : 1, rb = arow == 0 ? 2 : arow == 1 ? 2 : arow == 2 ? 1 : 3;
+        const float *p = raw + rbase + c * WG::PS;
+        if (r & 1) tB[c] = *reinterpret_cast<const float4 *>(p + rb * WG::RS);
+        else tA[c] = *reinterpret_cast<const float4 *>(p + ra * WG::RS);
+    };
+    auto t_row1 = [&](int arow, int c) {
+        float4 &x = tA[c];
+        const float4 y = tB[c];
+        if (arow == 1) x = make_float4(x.x + y.x, x.y + y.y, x.z + y.z, x.w + y.w);
+        else x = make_float4(x.x - y.x, x.y - y.y, x.z - y.z, x.w - y.w);
+    };
+    auto t_col1 = [&](int step) {                                 // V0 = T0 - T2, V3 = T1 - T3, V1 = T1 + T2, V2 = T2 - T1
+        auto sub = [](const float4 &x, const float4 &y) { return make_float4(x.x - y.x, x.y - y.y, x.z - y.z, x.w - y.w); };
+        auto add = [](const float4 &x, const float4 &y) { return make_float4(x.x + y.x, x.y + y.y, x.z + y.z, x.w + y.w); };
+        if (step == 0) tA[0] = sub(tA[0], tA[2]);
+        else if (step == 1) tA[3] = sub(tA[1], tA[3]);
+        else if (step == 2) tB[0] = add(tA[1], tA[2]);
+        else {
+            tA[2] = sub(tA[2], tA[1]);
+            tA[1] = tB[0];
+        }
+    };
+    auto t_wr = [&](int part, int j) {
+        *reinterpret_cast<float4 *>(lds + vwbase + part * WG::VBUF + j * 512) = tA[j];
+    };
+
+    // ---- A operand (weights): [group][wave][stage = 2 chunk + part][fl][lane][4]; ring of 4 frequencies, fetched 3 ahead
+    const char *const wbase = reinterpret_cast<const char *>(a.wp_w16) + ((size_t)(g * 4 + wv) * n) * (16 * 1024);
+    const unsigned wvoff = lane * 16;
+    float4 Wq[4];
+    auto wload1 = [&](int slot, int stage, int fl) { Wq[slot] = load_f4(wbase + (size_t)(stage * 8 + fl) * 1024, wvoff); };
+    // ---- B operand: Vbuf[part][fl][16 b + t16][slot]
+    float4 Bq[2][2];
+    auto bload1 = [&](int slot, int part, int fl, int b) {
+        Bq[slot][b] = *reinterpret_cast<const float4 *>(lds + WG::V0 + part * WG::VBUF + (fl * 32 + 16 * b) * 16 + vlane);
+    };
+
+    f32x4 acc[2][4][4];
+
+    // ---- prologue: raw(0) -> LDS, raw(1) -> registers, V(0, part 0), the first three weight fragments
+    const int nstages = 2 * n;
+    set_patch();
+#pragma unroll
+    for (int i = 0; i < WG::NI; ++i) gload1(i);
+    st_ok = okmask;
+#pragma unroll
+    for (int j = 0; j < 3; ++j) wload1(j, 0, j);
+#pragma unroll
+    for (int i = 0; i < WG::NI; ++i) lwrite1(i, 0);
+    advance();
+#pragma unroll
+    for (int i = 0; i < WG::NI; ++i) gload1(i);
+    st_ok = okmask;
+    advance();
+    __syncthreads();
+#pragma unroll
+    for (int r = 0; r < 8; ++r) t_rd(lds, t_row, r);
+#pragma unroll
+    for (int c = 0; c < 4; ++c) t_row1(t_row, c);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) t_col1(k);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) t_wr(0, j);
+    __syncthreads();
+    bload1(0, 0, 0, 0);
+    bload1(0, 0, 0, 1);
+
+    int raw_cur = 0, raw_nxt = WG::BUF;                        // raw buffers of this stage's chunk / the next chunk
+
+    // One stage = part P of a chunk: 64 MFMAs; shadow items prepare the NEXT stage.
+    auto stage_body = [&](auto first_tag, auto part_tag, int chunk) {
+        constexpr bool FIRST = decltype(first_tag)::value;
+        constexpr int P = decltype(part_tag)::value;
+        const int stage = 2 * chunk + P;
+        int nstage = stage + 1;                                       // wraps into the next unit (same weights)
+        nstage = nstage == nstages ? 0 : nstage;
+        // the next stage's transform: part 1 of this chunk (raw_cur) or part 0 of the next chunk (raw_nxt)
+        const float *traw = lds + (P == 0 ? raw_cur : raw_nxt);
+        const int narow = 2 * (1 - P) + t_row;                        // frequency row this wave forms for the next stage
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int fl = 0; fl < 8; ++fl) {
+            const int arow = 2 * P + (fl >> 2), j = fl & 3;
+            const int bs = fl & 1, bn = bs ^ 1;
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+#pragma unroll
+                for (int b = 0; b < 2; ++b) {
+                    const int m = fl * 8 + e * 2 + b;
+                    const float4 wv4 = Wq[(ABL & 2) ? 0 : (fl & 3)], vv4 = Bq[(ABL & 4) ? 0 : bs][(ABL & 4) ? 0 : b];
+                    const float we = e == 0 ? wv4.x : e == 1 ? wv4.y : e == 2 ? wv4.z : wv4.w;
+                    const float ve = e == 0 ? vv4.x : e == 1 ? vv4.y : e == 2 ? vv4.z : vv4.w;
+                    if (FIRST && e == 0) {
+                        const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+                        acc[b][arow][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(we, ve, zero, 0, 0, 0);
+                    } else
+                        acc[b][arow][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(we, ve, acc[b][arow][j], 0, 0, 0);
+                    // ---- shadow items
+                    const int mm = e * 2 + b;                                        // position inside this frequency's 8 MFMAs
+                    if (!(ABL & 4) && fl < 7 && mm < 2) bload1(bn, P, fl + 1, mm);   // B operands of the next frequency
+                    if (!(ABL & 2) && mm == 2) {                                     // weights three frequencies ahead
+                        if (fl + 3 < 8) wload1((fl + 3) & 3, stage, fl + 3);
+                        else wload1((fl + 3) & 3, nstage, fl + 3 - 8);
+                    }
+                    if (!(ABL & 32)) {                                               // the next stage's share of B^T d B
+                        if (m >= 4 && m < 12) t_rd(traw, narow, m - 4);
+                        if (m >= 20 && m < 24) t_row1(narow, m - 20);
+                        if (m >= 24 && m < 28) t_col1(m - 24);
+                        if (m >= 28 && m < 32) t_wr(1 - P, m - 28);
+                    }
+                    if (!(ABL & 8)) {
+                        if (P == 0 && m >= 40 && m - 40 < WG::NI) lwrite1(m - 40, raw_nxt);        // raw(chunk + 1): registers -> LDS
+                        if (P == 1 && m >= 40 && m - 40 < WG::NI) gload1(m - 40);                  // raw(chunk + 2) -> registers
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+        }
+        if (P == 1) {
+            if (!(ABL & 8)) st_ok = okmask;
+            advance();
+        }
+        if (!(ABL & 16)) __syncthreads();
+        if (!(ABL & 4)) {                                              // first B operands of the next stage (written by all waves)
+            bload1(0, 1 - P, 0, 0);
+            bload1(0, 1 - P, 0, 1);
+        }
+        if (P == 1) {
+            const int o = raw_cur;
+            raw_cur = raw_nxt;
+            raw_nxt = o;
+        }
+    };
+
+    if (g * 32 + wv * 8 >= a.Cout) {
+        // a wave whose 8 channels are all padding (Cout = 3) takes part in staging and transforming only
+        for (int u = blockIdx.x; u < a.n_units; u += G)
+            for (int chunk = 0; chunk < n; ++chunk)
+                for (int P = 0; P < 2; ++P) {
+                    const float *traw = lds + (P == 0 ? raw_cur : raw_nxt);
+                    const int narow = 2 * (1 - P) + t_row;
+#pragma unroll
+                    for (int r = 0; r < 8; ++r) t_rd(traw, narow, r);
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) t_row1(narow, c);
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) t_col1(k);
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) t_wr(1 - P, j);
+                    if (P == 0) {
+#pragma unroll
+                        for (int i = 0; i < WG::NI; ++i) lwrite1(i, raw_nxt);
+                    } else {
+#pragma unroll
+                        for (int i = 0; i < WG::NI; ++i) gload1(i);
+                        st_ok = okmask;
+                        advance();
+                    }
+                    __syncthreads();
+                    if (P == 1) {
+                        const int o = raw_cur;
+                        raw_cur = raw_nxt;
+                        raw_nxt = o;
+                    }
+                }
+        return;
+    }
+
+    for (int u = blockIdx.x; u < a.n_units; u += G) {
+        stage_body(std::true_type{}, std::integral_constant<int, 0>{}, 0);
+        stage_body(std::true_type{}, std::integral_constant<int, 1>{}, 0);
+        for (int chunk = 1; chunk < n; ++chunk) {
+            stage_body(std::false_type{}, std::integral_constant<int, 0>{}, chunk);
+            stage_body(std::false_type{}, std::integral_constant<int, 1>{}, chunk);
+        }
+        if (ABL & 1) {                                                 // keep the accumulators live with one store per wave
+            f32x4 ssum = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int b = 0; b < 2; ++b)
+#pragma unroll
+                for (int aa = 0; aa < 4; ++aa)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) ssum += acc[b][aa][j];
+            if (ssum[0] + ssum[1] + ssum[2] + ssum[3] == 12345.678f) a.out[lane] = ssum[0];
+            step_tile(by, bx);
+            continue;
+        }
+        // ================= unit epilogue (lane-local) =================
+        // D layout of v_mfma_f32_16x16x4_f32: lane (t = lane & 15, q = lane >> 4), register r = MFMA row 4q + r:
+        // q = 0, 1 -> conv_f of channels 4q + r; q = 2, 3 -> conv_m of channels 4 (q - 2) + r; column = tile t of block b.
+        __builtin_amdgcn_s_setprio(1);
+        const int cq = (lane >> 4) & 1, eb = lane >> 5;                                    // channel quad, block finished by this lane
+        const int c0 = g * 32 + wv * 8 + 4 * cq;
+        const int oy = by * (2 * 4) + 2 * (2 * eb + (t16 >> 3)), ox = bx * (2 * 8) + 2 * (t16 & 7);
+        const int c_lim = a.fill_pad ? a.out_cstride : a.Cout;
+        const bool quad_st = c0 + 3 < c_lim && (a.out_cstride & 3) == 0;
+        const bool quad_ld = a.residual && c0 + 3 < a.Cout && (a.Cout & 3) == 0;
+        const f32x4 bf = *reinterpret_cast<const f32x4 *>(a.params + c0);
+        const f32x4 bm = *reinterpret_cast<const f32x4 *>(a.params + a.CoutPad + c0);
+        const f32x4 sc = *reinterpret_cast<const f32x4 *>(a.params + 2 * a.CoutPad + c0);
+        const f32x4 sh = *reinterpret_cast<const f32x4 *>(a.params + 3 * a.CoutPad + c0);
+        bool pix_in[2][2];
+        f32x4 rv[2][2];
+#pragma unroll
+        for (int pa = 0; pa < 2; ++pa)
+#pragma unroll
+            for (int pb = 0; pb < 2; ++pb) {
+                pix_in[pa][pb] = (oy + pa < a.outH) & (ox + pb < a.outW);
+                rv[pa][pb] = f32x4{0.f, 0.f, 0.f, 0.f};
+                const float *rp = a.residual + ((size_t)(oy + pa) * a.outW + ox + pb) * a.Cout + c0;
+                if (pix_in[pa][pb] && quad_ld) rv[pa][pb] = *reinterpret_cast<const f32x4 *>(rp);
+                else if (pix_in[pa][pb] && a.residual) {
+#pragma unroll
+                    for (int k = 0; k < 4; ++k)
+                        if (c0 + k < a.Cout) rv[pa][pb][k] = rp[k];
+                }
+            }
+        // Y[pa][pb] = sum_a sum_j A^T[pa][a] M[a][j] A^T[pb][j],  A^T = [1 1 1 0; 0 1 -1 -1]
+        f32x4 Yf[2][2], Ym[2][2];
+#pragma unroll
+        for (int pa = 0; pa < 2; ++pa)
+#pragma unroll
+            for (int pb = 0; pb < 2; ++pb) {
+                f32x4 yb[2];
+#pragma unroll
+                for (int b = 0; b < 2; ++b) {
+                    f32x4 rr[3];                                       // rows a = pa, pa + 1, pa + 2 combined over j
+#pragma unroll
+                    for (int k = 0; k < 3; ++k) {
+                        const int ar = pa + k;
+                        rr[k] = pb == 0 ? acc[b][ar][0] + acc[b][ar][1] + acc[b][ar][2] : acc[b][ar][1] - acc[b][ar][2] - acc[b][ar][3];
+                    }
+                    yb[b] = pa == 0 ? rr[0] + rr[1] + rr[2] : rr[0] - rr[1] - rr[2];
+                }
+                // lanes 0..31 hold conv_f, lanes 32..63 conv_m of (block 0 | block 1): after the half exchange the lower
+                // half-wave owns block 0 and the upper half block 1, f in one register and m in the other
+                // (whole-vector bit casts: with __builtin_bit_cast of single vector ELEMENTS this hipcc folds the four swaps
+                //  into one — seen in the ISA)
+                u32x4 u0 = __builtin_bit_cast(u32x4, yb[0]), u1 = __builtin_bit_cast(u32x4, yb[1]);
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const auto sw = __builtin_amdgcn_permlane32_swap(u0[k], u1[k], false, false);
+                    u0[k] = sw[0];
+                    u1[k] = sw[1];
+                }
+                Yf[pa][pb] = __builtin_bit_cast(f32x4, u0);
+                Ym[pa][pb] = __builtin_bit_cast(f32x4, u1);
+            }
+        {
+            constexpr float LOG2E = 1.44269504088896341f;
+#pragma unroll
+            for (int pa = 0; pa < 2; ++pa)
+#pragma unroll
+                for (int pb = 0; pb < 2; ++pb) {
+                    f32x4 f = Yf[pa][pb] + bf;
+                    const f32x4 mm = (Ym[pa][pb] + bm) * -LOG2E;
+                    if (a.elu) {
+                        const f32x4 fe = f * LOG2E;
+#pragma unroll
+                        for (int k = 0; k < 4; ++k) f[k] = f[k] > 0.0f ? f[k] : __builtin_amdgcn_exp2f(fe[k]) - 1.0f;
+                    }
+                    f32x4 sg;
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) sg[k] = __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(mm[k]));
+                    f32x4 v = (f * sg) * sc + sh + rv[pa][pb];
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) v[k] = c0 + k < a.Cout ? v[k] : a.out_fill;
+                    float *op = a.out + ((size_t)(oy + pa) * a.outW + ox + pb) * a.out_cstride + c0;
+                    if (pix_in[pa][pb]) {
+                        if (quad_st) *reinterpret_cast<f32x4 *>(op) = v;
+                        else {
+#pragma unroll
+                            for (int k = 0; k < 4; ++k)
+                                if (c0 + k < c_lim) op[k] = v[k];
+                        }
+                    }
+                }
+        }
+        step_tile(by, bx);
+        __builtin_amdgcn_s_setprio(0);
+    }
+}
+
+// ------------------------------------------------------------------------------------------
 // 1x1 layers in the "pixel-lane" orientation: weights are the MFMA A operand, activations the B operand.
 //
 //   D[cout][pixel] = sum_k W[cout][k] * X[k][pixel]        (v_mfma_f32_32x32x2_f32: lane = pixel, registers = channels)
@@ -1693,7 +2086,8 @@ int g_conv_px = 1;         // read_tuning_set("conv_px", v): pixel-lane kernel f
 int g_kc32 = 1;            // 32-channel chunks for 1x1 layers whose sources are all multiples of 32 (read_tuning_set("conv_kc32", 0): 16)
 int g_use_wino = 1 << 30;  // read_tuning_set("conv_wino", max Cin): Winograd kernel for eligible 3x3 layers (0 = off)
 int g_w16_abl = 0;         // read_tuning_set("conv_w16_abl", bits): attribution probes of the wave-autonomous kernel (results invalid)
-int g_w16 = 1;             // read_tuning_set("conv_w16", 0): the row-per-wave Winograd kernel instead of the wave-autonomous one
+int g_w16 = 1;             // read_tuning_set("conv_w16", v): 0 the row-per-wave Winograd kernel, 1 the wave-autonomous kernel with the shared
+                           // input transform (default), 2 its first version (every wave transforms for itself)
 int g_stagger_ticks = 0;   // read_tuning_set("conv_stagger", ticks of 10 ns)
 int g_ablate = 0;          // read_tuning_set("conv_ablate", bits): attribution probe, results invalid; -DREAD_DEBUG_KNOBS builds only
 
@@ -1914,7 +2308,7 @@ void conv_set_stagger(int ticks) { g_stagger_ticks = ticks < 0 ? 0 : ticks; }
 void conv_set_ablate(int bits) { g_ablate = bits; }
 void conv_set_wino(int max_cin) { g_use_wino = max_cin; }
 void conv_set_kc32(int v) { g_kc32 = v; }
-void conv_set_w16(int v) { g_w16 = v ? 1 : 0; }
+void conv_set_w16(int v) { g_w16 = v < 0 ? 0 : v > 2 ? 2 : v; }
 void conv_set_w16_abl(int v) { g_w16_abl = v; }
 void conv_set_wino_wgs(int v) { g_wino_wgs = v <= 1 ? 1 : 2; }
 void conv_set_px(int v) { g_conv_px = v < 0 ? 0 : v > 4 ? 4 : v; }
@@ -2186,10 +2580,23 @@ int launch_gated_conv(const read_conv_desc *d, hipStream_t stream)
     }
     // the wave-autonomous Winograd kernel (same units, same grid) whenever its weight order was supplied; linear launches
     // (training path) stay on the row-per-wave kernel, which carries the plain-convolution epilogue
-    if (c.wino && !d->linear && !a.trace && d->wpacked_w16 && (d->config == -3 || (d->config < 0 && g_w16))) {
+    if (c.wino && !d->linear && !a.trace && d->wpacked_w16 && (d->config == -3 || d->config == -4 || (d->config < 0 && g_w16))) {
         READ_CHECK_ARG((uintptr_t)d->wpacked_w16 % 16 == 0, "read_gated_conv_forward: wpacked_w16 misaligned");
-        fn = d->mul ? gated_conv_wino16_kernel<true> : gated_conv_wino16_kernel<false>;
-        if (!d->mul && g_w16_abl) {
+        const bool v1 = g_w16 == 2 || d->config == -4;
+        fn = v1 ? (d->mul ? gated_conv_wino16_kernel<true> : gated_conv_wino16_kernel<false>)
+                : (d->mul ? gated_conv_wino16s_kernel<true> : gated_conv_wino16s_kernel<false>);
+        if (!v1 && !d->mul && g_w16_abl) {
+            switch (g_w16_abl) {
+            case 1: fn = gated_conv_wino16s_kernel<false, 1>; break;
+            case 2: fn = gated_conv_wino16s_kernel<false, 2>; break;
+            case 4: fn = gated_conv_wino16s_kernel<false, 4>; break;
+            case 8: fn = gated_conv_wino16s_kernel<false, 8>; break;
+            case 16: fn = gated_conv_wino16s_kernel<false, 16>; break;
+            case 32: fn = gated_conv_wino16s_kernel<false, 32>; break;
+            case 63: fn = gated_conv_wino16s_kernel<false, 63>; break;
+            default: break;
+            }
+        } else if (v1 && !d->mul && g_w16_abl) {
             switch (g_w16_abl) {
             case 1: fn = gated_conv_wino16_kernel<false, 1>; break;
             case 2: fn = gated_conv_wino16_kernel<false, 2>; break;

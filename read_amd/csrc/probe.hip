@@ -72,7 +72,11 @@ __global__ __launch_bounds__(256, 2) void issue_probe_kernel(float *out, unsigne
     float x[8];
 #pragma unroll
     for (int i = 0; i < 8; ++i) x[i] = 0.01f * (i + 1) + threadIdx.x;
-    float4 ld[4] = {};
+    floatx4 ld[4] = {};
+    typedef float floatx2 __attribute__((ext_vector_type(2)));
+    floatx2 pk[4], pkb = {0.5f, 0.25f};
+#pragma unroll
+    for (int i = 0; i < 4; ++i) pk[i] = floatx2{0.1f * i, 1.0f + threadIdx.x};
     unsigned sacc = 0;
     const unsigned laddr = (threadIdx.x & 63) * 16;
     const float4 *gp = gsrc + (threadIdx.x & 63);
@@ -89,11 +93,15 @@ __global__ __launch_bounds__(256, 2) void issue_probe_kernel(float *out, unsigne
                 else if (FT == 1) asm volatile("ds_read_b128 %0, %1" : "=v"(ld[q & 3]) : "v"(laddr) : "memory");
                 else if (FT == 2) asm volatile("s_add_u32 %0, %0, 3" : "+s"(sacc));
                 else if (FT == 3) asm volatile("v_add_f32 %0, %0, %1" : "+v"(x[0]) : "v"(b0));
-                else asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(ld[q & 3]) : "v"(gp) : "memory");
+                else if (FT == 4) asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(ld[q & 3]) : "v"(gp) : "memory");
+                else if (FT == 5) asm volatile("v_pk_add_f32 %0, %0, %1" : "+v"(pk[q & 3]) : "v"(pkb));
+                else if (FT == 6) asm volatile("v_exp_f32 %0, %0" : "+v"(x[q]));
+                else if (FT == 7) asm volatile("ds_write_b128 %0, %1" : : "v"(laddr), "v"(ld[q & 3]) : "memory");
+                else asm volatile("v_fma_f32 %0, %0, %1, %1" : "+v"(x[q]) : "v"(b0));
             }
             __builtin_amdgcn_sched_barrier(0);
         }
-        if (FT == 1) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        if (FT == 1 || FT == 7) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         if (FT == 4) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         a0 = a0 * 0.999f + 0.0007f;
         b0 = b0 * 1.0001f - 0.0001f;
@@ -103,7 +111,7 @@ __global__ __launch_bounds__(256, 2) void issue_probe_kernel(float *out, unsigne
 #pragma unroll
     for (int i = 0; i < 8; ++i) ssum += x[i];
 #pragma unroll
-    for (int i = 0; i < 4; ++i) ssum += ld[i].x + ld[i].w;
+    for (int i = 0; i < 4; ++i) ssum += ld[i][0] + ld[i][3] + pk[i][0] + pk[i][1];
 #pragma unroll
     for (int i = 0; i < (KIND == 0 ? 8 : 1); ++i)
 #pragma unroll
@@ -141,12 +149,20 @@ extern "C" int read_debug_issue_probe(int kind, int filler, int K, int blocks, i
         else if (filler == 2) rc = issue_probe_launch<0, 2>(K, blocks, scratch, cycles, iters, g, s);
         else if (filler == 3) rc = issue_probe_launch<0, 3>(K, blocks, scratch, cycles, iters, g, s);
         else if (filler == 4) rc = issue_probe_launch<0, 4>(K, blocks, scratch, cycles, iters, g, s);
+        else if (filler == 5) rc = issue_probe_launch<0, 5>(K, blocks, scratch, cycles, iters, g, s);
+        else if (filler == 6) rc = issue_probe_launch<0, 6>(K, blocks, scratch, cycles, iters, g, s);
+        else if (filler == 7) rc = issue_probe_launch<0, 7>(K, blocks, scratch, cycles, iters, g, s);
+        else if (filler == 8) rc = issue_probe_launch<0, 8>(K, blocks, scratch, cycles, iters, g, s);
     } else if (kind == 1) {
         if (filler == 0) rc = issue_probe_launch<1, 0>(K, blocks, scratch, cycles, iters, g, s);
         else if (filler == 1) rc = issue_probe_launch<1, 1>(K, blocks, scratch, cycles, iters, g, s);
         else if (filler == 2) rc = issue_probe_launch<1, 2>(K, blocks, scratch, cycles, iters, g, s);
         else if (filler == 3) rc = issue_probe_launch<1, 3>(K, blocks, scratch, cycles, iters, g, s);
         else if (filler == 4) rc = issue_probe_launch<1, 4>(K, blocks, scratch, cycles, iters, g, s);
+        else if (filler == 5) rc = issue_probe_launch<1, 5>(K, blocks, scratch, cycles, iters, g, s);
+        else if (filler == 6) rc = issue_probe_launch<1, 6>(K, blocks, scratch, cycles, iters, g, s);
+        else if (filler == 7) rc = issue_probe_launch<1, 7>(K, blocks, scratch, cycles, iters, g, s);
+        else if (filler == 8) rc = issue_probe_launch<1, 8>(K, blocks, scratch, cycles, iters, g, s);
     }
     if (rc) { set_error("read_debug_issue_probe: unsupported kind / filler / K"); return READ_EINVAL; }
     READ_CHECK_LAUNCH();

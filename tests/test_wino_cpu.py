@@ -30,7 +30,7 @@ def test_filter_transform_shape_and_dc():
 def test_wave_autonomous_model_matches_conv2d():
     """The 16x16x4-MFMA kernel's lane maps (tests/wino16_ref.py): weights as the A operand with conv_f | conv_m stacked in the
     MFMA rows, tiles as columns, both 16-tile blocks, in-lane output transform."""
-    from tests.wino16_ref import pack_w16, wino16_conv_model
+    from tests.wino16_ref import pack_w16, wino16_conv_model, wino16v2_conv_model
     rng = np.random.default_rng(0)
     cin, cout, H, W = 32, 40, 10, 20                      # two chunks, padded cout, partial tile blocks
     wf = rng.standard_normal((cout, cin, 3, 3)).astype(np.float32) * 0.2
@@ -42,6 +42,10 @@ def test_wave_autonomous_model_matches_conv2d():
     rm = F.conv2d(xt, torch.from_numpy(wm), padding=1)[0].permute(1, 2, 0).numpy()
     np.testing.assert_allclose(f, rf, rtol=1e-4, atol=1e-4)
     np.testing.assert_allclose(m, rm, rtol=1e-4, atol=1e-4)
+    # version 2: the input transform shared through a swizzled LDS buffer (every slot written once, read where expected)
+    f2, m2 = wino16v2_conv_model(x, pack_w16(wf, wm), cin, cout)
+    np.testing.assert_allclose(f2, rf, rtol=1e-4, atol=1e-4)
+    np.testing.assert_allclose(m2, rm, rtol=1e-4, atol=1e-4)
 
 
 def test_library_packers_equal_the_models():

@@ -108,3 +108,67 @@ def wino16_conv_model(x_hwc, packed, cin, cout):
                                         if oy < H and ox < W:
                                             (m if is_m[l] else f)[oy, ox, ch[l]] = Y[pa, pb, l]
     return f[:, :, :cout], m[:, :, :cout]
+
+
+# ---- version 2 of the kernel: the input transform is SHARED by the four waves through LDS -------------------------------------
+# (the fp32 MFMA runs on the same FP pipe as the VALU — tools/issue_probe.py — so transform instructions are not hidden
+# behind MFMAs; version 1 let every wave transform all 32 tiles for itself, 4x the necessary VALU work)
+#   part p of a chunk = frequency rows a = 2p, 2p + 1;  transform role of wave w: block tb = w >> 1, row a = 2p + (w & 1);
+#   lane (t = lane & 15, quad = lane >> 4) forms V[a][0..3] of tile 16 tb + t for input channels 4 quad .. 4 quad + 3 and stores
+#   them at  Vbuf[p][fl = 4 (w & 1) + j][tile][slot (quad ^ ((t >> 1) & 3))]   (float4 slots; the XOR keeps both the stores and
+#   the MFMA-side ds_read_b128 of lanes (t, kl) bank-conflict free);  MFMA role as before, B operand = Vbuf[p][fl][16 b + t][slot].
+def wino16v2_conv_model(x_hwc, packed, cin, cout):
+    H, W, _ = x_hwc.shape
+    cp = (cout + 31) // 32 * 32
+    P = packed.reshape(cp // 32, 4, cin // 16, 4, 4, 64, 4)
+    xp = np.zeros((H + 18, W + 34, cin), np.float32)
+    xp[1:H + 1, 1:W + 1] = x_hwc
+    f = np.zeros((H, W, cp), np.float32)
+    m = np.zeros((H, W, cp), np.float32)
+    t, kl = LANE & 15, LANE >> 4
+    slot = kl ^ ((t >> 1) & 3)
+    rows = {0: (0, 2, 1.0, -1.0), 1: (1, 2, 1.0, 1.0), 2: (2, 1, 1.0, -1.0), 3: (1, 3, 1.0, -1.0)}
+    for by in range((H + 7) // 8):
+        for bx in range((W + 15) // 16):
+            oy0, ox0 = 8 * by, 16 * bx
+            for g in range(cp // 32):
+                acc = np.zeros((4, 2, 4, 4, 64, 4), np.float32)              # [wave][block][a][j][lane][register]
+                for c in range(cin // 16):
+                    for part in range(2):
+                        vbuf = np.full((8, 32, 4, 4), np.nan, np.float32)     # [fl][tile][slot][e]
+                        for w in range(4):                                    # transform role
+                            tb, a = w >> 1, 2 * part + (w & 1)
+                            ra, rb, sa, sb = rows[a]
+                            tr, tcc = 2 * tb + (t >> 3), t & 7
+                            T = np.zeros((4, 64, 4), np.float32)
+                            for cc in range(4):
+                                for e in range(4):
+                                    ci = 16 * c + 4 * kl + e
+                                    T[cc, :, e] = sa * xp[oy0 + 2 * tr + ra, ox0 + 2 * tcc + cc, ci] + \
+                                                  sb * xp[oy0 + 2 * tr + rb, ox0 + 2 * tcc + cc, ci]
+                            V = [T[0] - T[2], T[1] + T[2], T[2] - T[1], T[1] - T[3]]
+                            for j in range(4):
+                                vbuf[4 * (w & 1) + j, 16 * tb + t, slot] = V[j]
+                        assert not np.isnan(vbuf).any()                       # every slot written exactly by someone
+                        for w in range(4):                                    # MFMA role
+                            for fl in range(8):
+                                a, j = 2 * part + (fl >> 2), fl & 3
+                                for b in range(2):
+                                    Bop = vbuf[fl, 16 * b + t, slot]          # (64, 4)
+                                    for e in range(4):
+                                        acc[w, b, a, j] += mfma_16x16x4(P[g, w, c, a, j][:, e], Bop[:, e])
+                q = LANE >> 4
+                for w in range(4):
+                    for b in range(2):
+                        for r in range(4):
+                            Y = np.einsum("pa,ajl,qj->pql", AT, acc[w, b, :, :, :, r], AT)
+                            i_row = 4 * q + r
+                            ch = 32 * g + 8 * w + (i_row & 7)
+                            for l in range(64):
+                                tr_l, tc_l = 2 * b + (l & 15) // 8, (l & 15) % 8
+                                for pa in range(2):
+                                    for pb in range(2):
+                                        oy, ox = oy0 + 2 * tr_l + pa, ox0 + 2 * tc_l + pb
+                                        if oy < H and ox < W:
+                                            (m if i_row[l] >= 8 else f)[oy, ox, ch[l]] = Y[pa, pb, l]
+    return f[:, :, :cout], m[:, :, :cout]

@@ -16,15 +16,17 @@ L = _lib.lib()
 scratch = torch.zeros(256 * 8192, device="cuda")
 gsrc = torch.ones(4096, device="cuda")
 cycles = torch.zeros(4096, dtype=torch.int64, device="cuda")
-FT = {0: "v_add indep", 1: "ds_read_b128", 2: "s_add", 3: "v_add chain", 4: "global_load_dwordx4"}
+FT = {0: "v_add indep", 1: "ds_read_b128", 2: "s_add", 3: "v_add chain", 4: "global_load_dwordx4", 5: "v_pk_add_f32", 6: "v_exp_f32",
+      7: "ds_write_b128", 8: "v_fma_f32"}
+ONLY = [int(v) for v in os.environ.get("PROBE_FILLERS", "0,1,2,3,4,5,6,7,8").split(",")]
 res = []
 iters = 2000
 for kind in (0, 1):
     for wps in (1, 2):                      # waves per SIMD = workgroups per CU
         blocks = 256 * wps
-        for ft in (0, 1, 2, 3, 4):
+        for ft in ONLY:
             for K in (0, 1, 2, 3, 4, 6, 8, 12):
-                if K == 0 and ft != 0:
+                if K == 0 and ft != ONLY[0]:
                     continue
                 for rep in range(2):
                     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
