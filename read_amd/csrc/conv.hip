@@ -1435,7 +1435,7 @@ struct Wino16sGeom {
     static constexpr int VBUF = 8 * 32 * 16;                   // one part of the transformed chunk (4096 floats)
     static constexpr int NE = IH * IW * (KC / 4), NI = (NE + 255) / 256;
     static constexpr int V0 = 2 * BUF;                         // float offset of Vbuf[0]
-    static constexpr int LDS_FLOATS = 2 * BUF + 2 * VBUF + 4;  // + a dummy float4 slot
+    static constexpr int LDS_FLOATS = 2 * BUF + 3 * VBUF + 4;  // two raw buffers, three V buffers, a dummy float4 slot
 };
 
 template <bool MUL, int ABL = 0>
@@ -1507,7 +1507,7 @@ __global__ __launch_bounds__(256, 2) void gated_conv_wino16s_kernel(const ConvKA
         float4 v = st[i];
         if constexpr (MUL) v = make_float4(v.x * stm[i].x, v.y * stm[i].y, v.z * stm[i].z, v.w * stm[i].w);
         if (!((st_ok >> i) & 1u)) v = make_float4(0.f, 0.f, 0.f, 0.f);
-        *reinterpret_cast<float4 *>(lds + (loff[i] >= 0 ? obuf + loff[i] : WG::LDS_FLOATS - 4)) = v;
+        *reinterpret_cast<float4 *>(__builtin_assume_aligned(lds + (loff[i] >= 0 ? obuf + loff[i] : WG::LDS_FLOATS - 4), 16)) = v;
     };
 
     // ---- lane constants.  t16 = tile within a 16-tile block (MFMA column / transform item), kl = channel quad
@@ -1515,48 +1515,57 @@ __global__ __launch_bounds__(256, 2) void gated_conv_wino16s_kernel(const ConvKA
     const int lbase = (2 * (t16 >> 3)) * WG::RS + (2 * (t16 & 7)) * WG::PS + 4 * kl;               // raw patch (floats)
     const int vlane = t16 * 16 + 4 * (kl ^ ((t16 >> 1) & 3));                                       // swizzled float4 slot of a V row
     const int t_blk = wv >> 1, t_row = wv & 1;                                                      // transform role of this wave
-    const int vwbase = WG::V0 + ((t_row * 4) * 32 + 16 * t_blk) * 16 + vlane;                       // + part * VBUF + j * 512
+    const int vwbase = WG::V0 + ((t_row * 4) * 32 + 16 * t_blk) * 16 + vlane;                       // + V buffer + j * 512
     const int rbase = lbase + (4 * t_blk) * WG::RS;                                                 // + raw buffer
 
-    // transform scratch: T[c] ends up as V[j] in place
-    float4 tA[4], tB[4];
-    auto t_rd = [&](const float *raw, int arow, int r) {          // r = 2c + {0: row ra, 1: row rb}
-        const int c = r >> 1;
+    // This wave's share of B^T d B for the next stage as 18 small steps (columns in the order 0, 2, 1, 3 so that every V[j] is
+    // stored as soon as it exists: at most five float4 are live).  T(c) = d[ra][c] +- d[rb][c];  V0 = T0 - T2, V1 = T1 + T2,
+    // V2 = T2 - T1, V3 = T1 - T3.
+    float4 T0, T1, T2, T3, tq;
+    auto sub4 = [](const float4 &x, const float4 &y) { return make_float4(x.x - y.x, x.y - y.y, x.z - y.z, x.w - y.w); };
+    auto add4 = [](const float4 &x, const float4 &y) { return make_float4(x.x + y.x, x.y + y.y, x.z + y.z, x.w + y.w); };
+    auto t_step = [&](const float *raw, int arow, int vb, int k) {
         const int ra = arow == 0 ? 0 : arow == 2 ? 2 : 1, rb = arow == 0 ? 2 : arow == 1 ? 2 : arow == 2 ? 1 : 3;
-        const float *p = raw + rbase + c * WG::PS;
-        if (r & 1) tB[c] = *reinterpret_cast<const float4 *>(p + rb * WG::RS);
-        else tA[c] = *reinterpret_cast<const float4 *>(p + ra * WG::RS);
-    };
-    auto t_row1 = [&](int arow, int c) {
-        float4 &x = tA[c];
-        const float4 y = tB[c];
-        if (arow == 1) x = make_float4(x.x + y.x, x.y + y.y, x.z + y.z, x.w + y.w);
-        else x = make_float4(x.x - y.x, x.y - y.y, x.z - y.z, x.w - y.w);
-    };
-    auto t_col1 = [&](int step) {                                 // V0 = T0 - T2, V3 = T1 - T3, V1 = T1 + T2, V2 = T2 - T1
-        auto sub = [](const float4 &x, const float4 &y) { return make_float4(x.x - y.x, x.y - y.y, x.z - y.z, x.w - y.w); };
-        auto add = [](const float4 &x, const float4 &y) { return make_float4(x.x + y.x, x.y + y.y, x.z + y.z, x.w + y.w); };
-        if (step == 0) tA[0] = sub(tA[0], tA[2]);
-        else if (step == 1) tA[3] = sub(tA[1], tA[3]);
-        else if (step == 2) tB[0] = add(tA[1], tA[2]);
-        else {
-            tA[2] = sub(tA[2], tA[1]);
-            tA[1] = tB[0];
+        auto rdA = [&](int c) { return *reinterpret_cast<const float4 *>(__builtin_assume_aligned(raw + rbase + c * WG::PS + ra * WG::RS, 16)); };
+        auto rdB = [&](int c) { return *reinterpret_cast<const float4 *>(__builtin_assume_aligned(raw + rbase + c * WG::PS + rb * WG::RS, 16)); };
+        auto row = [&](const float4 &x, const float4 &y) { return arow == 1 ? add4(x, y) : sub4(x, y); };
+        auto wr = [&](int j, const float4 &v) {
+            *reinterpret_cast<float4 *>(__builtin_assume_aligned(lds + vwbase + vb + j * 512, 16)) = v;
+        };
+        switch (k) {
+        case 0: T0 = rdA(0); break;
+        case 1: tq = rdB(0); break;
+        case 2: T2 = rdA(2); break;
+        case 3: T1 = rdB(2); break;                 // (T1 is free until column 1 arrives)
+        case 4: T0 = row(T0, tq); break;
+        case 5: T2 = row(T2, T1); break;
+        case 6: T1 = rdA(1); break;
+        case 7: tq = rdB(1); break;
+        case 8: T0 = sub4(T0, T2); break;           // V0
+        case 9: wr(0, T0); break;
+        case 10: T3 = rdA(3); break;
+        case 11: T0 = rdB(3); break;                // (T0 is free after its store)
+        case 12: T1 = row(T1, tq); break;
+        case 13: tq = add4(T1, T2); break;          // V1
+        case 14: T2 = sub4(T2, T1); break;          // V2
+        case 15: wr(1, tq); break;
+        case 16: wr(2, T2); break;
+        case 17: T3 = row(T3, T0); break;
+        case 18: T3 = sub4(T1, T3); break;          // V3
+        case 19: wr(3, T3); break;
+        default: break;
         }
     };
-    auto t_wr = [&](int part, int j) {
-        *reinterpret_cast<float4 *>(lds + vwbase + part * WG::VBUF + j * 512) = tA[j];
-    };
-
+    constexpr int T_STEPS = 20;
     // ---- A operand (weights): [group][wave][stage = 2 chunk + part][fl][lane][4]; ring of 4 frequencies, fetched 3 ahead
     const char *const wbase = reinterpret_cast<const char *>(a.wp_w16) + ((size_t)(g * 4 + wv) * n) * (16 * 1024);
     const unsigned wvoff = lane * 16;
     float4 Wq[4];
     auto wload1 = [&](int slot, int stage, int fl) { Wq[slot] = load_f4(wbase + (size_t)(stage * 8 + fl) * 1024, wvoff); };
     // ---- B operand: Vbuf[part][fl][16 b + t16][slot]
-    float4 Bq[2][2];
-    auto bload1 = [&](int slot, int part, int fl, int b) {
-        Bq[slot][b] = *reinterpret_cast<const float4 *>(lds + WG::V0 + part * WG::VBUF + (fl * 32 + 16 * b) * 16 + vlane);
+    float4 Bq[4][2];                                             // ring of four frequencies: fetched two ahead
+    auto bload1 = [&](int slot, int vb, int fl, int b) {
+        Bq[slot][b] = *reinterpret_cast<const float4 *>(__builtin_assume_aligned(lds + WG::V0 + vb + (fl * 32 + 16 * b) * 16 + vlane, 16));
     };
 
     f32x4 acc[2][4][4];
@@ -1578,34 +1587,33 @@ __global__ __launch_bounds__(256, 2) void gated_conv_wino16s_kernel(const ConvKA
     advance();
     __syncthreads();
 #pragma unroll
-    for (int r = 0; r < 8; ++r) t_rd(lds, t_row, r);
-#pragma unroll
-    for (int c = 0; c < 4; ++c) t_row1(t_row, c);
-#pragma unroll
-    for (int k = 0; k < 4; ++k) t_col1(k);
-#pragma unroll
-    for (int j = 0; j < 4; ++j) t_wr(0, j);
+    for (int k2 = 0; k2 < T_STEPS; ++k2) t_step(lds, t_row, 0, k2);
     __syncthreads();
     bload1(0, 0, 0, 0);
     bload1(0, 0, 0, 1);
+    bload1(1, 0, 1, 0);
+    bload1(1, 0, 1, 1);
 
     int raw_cur = 0, raw_nxt = WG::BUF;                        // raw buffers of this stage's chunk / the next chunk
+    int v_cur = 0, v_nxt = WG::VBUF, v_nn = 2 * WG::VBUF;       // V buffers (float offsets): this stage, the next, the free one
 
-    // One stage = part P of a chunk: 64 MFMAs; shadow items prepare the NEXT stage.
+    // One stage = part P of a chunk: 64 MFMAs; shadow items prepare the NEXT stage.  The barrier sits in the MIDDLE of a stage,
+    // right after this wave's share of the next stage's V has been stored: the second half of the stage can then already
+    // fetch the next stage's first B operands, so no wave waits on LDS behind a barrier.  Three V buffers make that safe
+    // (the buffer written in stage s was last read in stage s - 2, which every wave has left before the barrier of s - 1).
     auto stage_body = [&](auto first_tag, auto part_tag, int chunk) {
         constexpr bool FIRST = decltype(first_tag)::value;
         constexpr int P = decltype(part_tag)::value;
         const int stage = 2 * chunk + P;
         int nstage = stage + 1;                                       // wraps into the next unit (same weights)
         nstage = nstage == nstages ? 0 : nstage;
-        // the next stage's transform: part 1 of this chunk (raw_cur) or part 0 of the next chunk (raw_nxt)
-        const float *traw = lds + (P == 0 ? raw_cur : raw_nxt);
+        const float *traw = lds + (P == 0 ? raw_cur : raw_nxt);       // raw patch of the next stage's chunk
         const int narow = 2 * (1 - P) + t_row;                        // frequency row this wave forms for the next stage
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int fl = 0; fl < 8; ++fl) {
             const int arow = 2 * P + (fl >> 2), j = fl & 3;
-            const int bs = fl & 1, bn = bs ^ 1;
+            const int bs = fl & 3;
 #pragma unroll
             for (int e = 0; e < 4; ++e)
 #pragma unroll
@@ -1621,38 +1629,41 @@ __global__ __launch_bounds__(256, 2) void gated_conv_wino16s_kernel(const ConvKA
                         acc[b][arow][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(we, ve, acc[b][arow][j], 0, 0, 0);
                     // ---- shadow items
                     const int mm = e * 2 + b;                                        // position inside this frequency's 8 MFMAs
-                    if (!(ABL & 4) && fl < 7 && mm < 2) bload1(bn, P, fl + 1, mm);   // B operands of the next frequency
+                    if (!(ABL & 4) && mm < 2) {                                      // B operands two frequencies ahead
+                        if (fl + 2 < 8) bload1((fl + 2) & 3, v_cur, fl + 2, mm);
+                        else bload1((fl + 2) & 3, v_nxt, fl + 2 - 8, mm);           // next stage (stored before this stage's barrier)
+                    }
                     if (!(ABL & 2) && mm == 2) {                                     // weights three frequencies ahead
                         if (fl + 3 < 8) wload1((fl + 3) & 3, stage, fl + 3);
                         else wload1((fl + 3) & 3, nstage, fl + 3 - 8);
                     }
                     if (!(ABL & 32)) {                                               // the next stage's share of B^T d B
-                        if (m >= 4 && m < 12) t_rd(traw, narow, m - 4);
-                        if (m >= 20 && m < 24) t_row1(narow, m - 20);
-                        if (m >= 24 && m < 28) t_col1(m - 24);
-                        if (m >= 28 && m < 32) t_wr(1 - P, m - 28);
+                        // program order = step order (the steps recycle registers); every arithmetic step sits at least 8 MFMAs
+                        // behind the LDS reads it consumes, everything is stored before the barrier at m = 39
+                        constexpr int at[T_STEPS] = {2, 3, 4, 5, 12, 13, 14, 15, 15, 16, 16, 17, 23, 24, 24, 25, 26, 27, 28, 29};
+#pragma unroll
+                        for (int k2 = 0; k2 < T_STEPS; ++k2)
+                            if (at[k2] == m) t_step(traw, narow, v_nxt, k2);
                     }
                     if (!(ABL & 8)) {
-                        if (P == 0 && m >= 40 && m - 40 < WG::NI) lwrite1(m - 40, raw_nxt);        // raw(chunk + 1): registers -> LDS
-                        if (P == 1 && m >= 40 && m - 40 < WG::NI) gload1(m - 40);                  // raw(chunk + 2) -> registers
+                        if (P == 0 && m >= 28 && m - 28 < WG::NI) lwrite1(m - 28, raw_nxt);        // raw(chunk + 1): registers -> LDS
+                        if (P == 1 && m >= 50 && m - 50 < WG::NI) gload1(m - 50);                  // raw(chunk + 2) -> registers
                     }
+                    if (m == 39 && !(ABL & 16)) __syncthreads();                     // V of the next stage (and raw(chunk + 1)) complete
                     __builtin_amdgcn_sched_barrier(0);
                 }
         }
         if (P == 1) {
             if (!(ABL & 8)) st_ok = okmask;
             advance();
-        }
-        if (!(ABL & 16)) __syncthreads();
-        if (!(ABL & 4)) {                                              // first B operands of the next stage (written by all waves)
-            bload1(0, 1 - P, 0, 0);
-            bload1(0, 1 - P, 0, 1);
-        }
-        if (P == 1) {
             const int o = raw_cur;
             raw_cur = raw_nxt;
             raw_nxt = o;
         }
+        const int v = v_cur;
+        v_cur = v_nxt;
+        v_nxt = v_nn;
+        v_nn = v;
     };
 
     if (g * 32 + wv * 8 >= a.Cout) {
@@ -1663,28 +1674,25 @@ __global__ __launch_bounds__(256, 2) void gated_conv_wino16s_kernel(const ConvKA
                     const float *traw = lds + (P == 0 ? raw_cur : raw_nxt);
                     const int narow = 2 * (1 - P) + t_row;
 #pragma unroll
-                    for (int r = 0; r < 8; ++r) t_rd(traw, narow, r);
-#pragma unroll
-                    for (int c = 0; c < 4; ++c) t_row1(narow, c);
-#pragma unroll
-                    for (int k = 0; k < 4; ++k) t_col1(k);
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) t_wr(1 - P, j);
+                    for (int k2 = 0; k2 < T_STEPS; ++k2) t_step(traw, narow, v_nxt, k2);
                     if (P == 0) {
 #pragma unroll
                         for (int i = 0; i < WG::NI; ++i) lwrite1(i, raw_nxt);
-                    } else {
+                    }
+                    __syncthreads();
+                    if (P == 1) {
 #pragma unroll
                         for (int i = 0; i < WG::NI; ++i) gload1(i);
                         st_ok = okmask;
                         advance();
-                    }
-                    __syncthreads();
-                    if (P == 1) {
                         const int o = raw_cur;
                         raw_cur = raw_nxt;
                         raw_nxt = o;
                     }
+                    const int v = v_cur;
+                    v_cur = v_nxt;
+                    v_nxt = v_nn;
+                    v_nn = v;
                 }
         return;
     }
