@@ -1528,7 +1528,13 @@ __global__ __launch_bounds__(256, 2) void gated_conv_wino16s_kernel(const ConvKA
         const int ra = arow == 0 ? 0 : arow == 2 ? 2 : 1, rb = arow == 0 ? 2 : arow == 1 ? 2 : arow == 2 ? 1 : 3;
         auto rdA = [&](int c) { return *reinterpret_cast<const float4 *>(__builtin_assume_aligned(raw + rbase + c * WG::PS + ra * WG::RS, 16)); };
         auto rdB = [&](int c) { return *reinterpret_cast<const float4 *>(__builtin_assume_aligned(raw + rbase + c * WG::PS + rb * WG::RS, 16)); };
-        auto row = [&](const float4 &x, const float4 &y) { return arow == 1 ? add4(x, y) : sub4(x, y); };
+        // d[ra] + sgn d[rb] as one FMA per component: arow depends on the wave (t_row), a select between add and sub would be
+        // a BRANCH in the middle of the MFMA stream (seen in the ISA of the first build)
+        const float sgn = arow == 1 ? 1.0f : -1.0f;
+        auto row = [&](const float4 &x, const float4 &y) {
+            return make_float4(__builtin_fmaf(y.x, sgn, x.x), __builtin_fmaf(y.y, sgn, x.y), __builtin_fmaf(y.z, sgn, x.z),
+                               __builtin_fmaf(y.w, sgn, x.w));
+        };
         auto wr = [&](int j, const float4 &v) {
             *reinterpret_cast<float4 *>(__builtin_assume_aligned(lds + vwbase + vb + j * 512, 16)) = v;
         };
