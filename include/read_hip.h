@@ -81,6 +81,9 @@ int read_debug_mfma_probe(int blocks, int iters, int nacc, float *scratch, void 
 /* Issue-model probe (debug): every wave runs `iters` rounds of 16 fp32 MFMAs (kind 0: v_mfma_f32_32x32x2_f32, 1:
  * v_mfma_f32_16x16x4_f32), each followed by K filler instructions of type `filler` (0 independent v_add_f32, 1 ds_read_b128,
  * 2 s_add_u32, 3 dependent v_add_f32 chain, 4 global_load_dwordx4 from gsrc); cycles[blocks * 4] = s_memtime span per wave. */
+/* Operand probe (debug): v_mfma_f32_16x16x4_f32 rate by operand register pattern (mode 0 one A/B pair, 1 a pair per MFMA, 2 the
+ * Winograd kernel's float4-component pattern, 3 as 2 with the B operands re-read from LDS every round). */
+int read_debug_operand_probe(int mode, int blocks, int iters, float *scratch, unsigned long long *cycles, void *stream);
 int read_debug_issue_probe(int kind, int filler, int K, int blocks, int iters, float *scratch, unsigned long long *cycles,
                            const float *gsrc, void *stream);
 

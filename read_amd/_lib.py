@@ -55,6 +55,7 @@ SIGNATURES = {
     "read_tuning_key": (C.c_char_p, [_i]),
     "read_debug_set_trace": (_i, [_vp, _sz]),
     "read_debug_mfma_probe": (_i, [_i, _i, _i, _vp, _vp]),
+    "read_debug_operand_probe": (_i, [_i, _i, _i, _vp, _vp, _vp]),
     "read_debug_issue_probe": (_i, [_i, _i, _i, _i, _i, _vp, _vp, _vp, _vp]),
     "read_splat_workspace_bytes": (_sz, [_i, _i, _i]),
     "read_splat_workspace_init": (_i, [_vp, _sz, _vp]),

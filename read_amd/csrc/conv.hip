@@ -1575,6 +1575,8 @@ __global__ __launch_bounds__(256, 2) void gated_conv_wino16s_kernel(const ConvKA
     };
 
     f32x4 acc[2][4][4];
+    // the wave's 8 channels exist, rows are quad aligned, no padded-channel fill: the epilogue of interior units needs no masks
+    const bool chan_full = (g * 32 + wv * 8 + 8 <= a.Cout) & ((a.out_cstride & 3) == 0) & ((a.Cout & 3) == 0) & !a.fill_pad;
 
     // ---- prologue: raw(0) -> LDS, raw(1) -> registers, V(0, part 0), the first three weight fragments
     const int nstages = 2 * n;
@@ -1728,22 +1730,33 @@ __global__ __launch_bounds__(256, 2) void gated_conv_wino16s_kernel(const ConvKA
         __builtin_amdgcn_s_setprio(1);
         const int cq = (lane >> 4) & 1, eb = lane >> 5;                                    // channel quad, block finished by this lane
         const int c0 = g * 32 + wv * 8 + 4 * cq;
-        const int oy = by * (2 * 4) + 2 * (2 * eb + (t16 >> 3)), ox = bx * (2 * 8) + 2 * (t16 & 7);
-        const int c_lim = a.fill_pad ? a.out_cstride : a.Cout;
-        const bool quad_st = c0 + 3 < c_lim && (a.out_cstride & 3) == 0;
-        const bool quad_ld = a.residual && c0 + 3 < a.Cout && (a.Cout & 3) == 0;
+        const int oy = by * 8 + 2 * (2 * eb + (t16 >> 3)), ox = bx * 16 + 2 * (t16 & 7);
+        // interior unit with 8 real channels and quad-aligned tensors: no masks at all (every unit of a C -> C layer but the
+        // ragged bottom / right blocks)
+        const bool full = (by * 8 + 8 <= a.outH) & (bx * 16 + 16 <= a.outW) & chan_full;
         const f32x4 bf = *reinterpret_cast<const f32x4 *>(a.params + c0);
         const f32x4 bm = *reinterpret_cast<const f32x4 *>(a.params + a.CoutPad + c0);
         const f32x4 sc = *reinterpret_cast<const f32x4 *>(a.params + 2 * a.CoutPad + c0);
         const f32x4 sh = *reinterpret_cast<const f32x4 *>(a.params + 3 * a.CoutPad + c0);
+        const int c_lim = a.fill_pad ? a.out_cstride : a.Cout;
+        const bool quad_st = c0 + 3 < c_lim && (a.out_cstride & 3) == 0;
+        const bool quad_ld = a.residual && c0 + 3 < a.Cout && (a.Cout & 3) == 0;
         bool pix_in[2][2];
         f32x4 rv[2][2];
+        const unsigned ro = (unsigned)((oy * a.outW + ox) * a.Cout + c0) * 4u;              // byte offsets of pixel (0, 0)
+        const unsigned oo = (unsigned)((oy * a.outW + ox) * a.out_cstride + c0) * 4u;
 #pragma unroll
         for (int pa = 0; pa < 2; ++pa)
 #pragma unroll
             for (int pb = 0; pb < 2; ++pb) {
-                pix_in[pa][pb] = (oy + pa < a.outH) & (ox + pb < a.outW);
                 rv[pa][pb] = f32x4{0.f, 0.f, 0.f, 0.f};
+                if (full) {
+                    if (a.residual)
+                        rv[pa][pb] = *reinterpret_cast<const f32x4 *>(reinterpret_cast<const char *>(a.residual) + ro +
+                                                                      (unsigned)((pa * a.outW + pb) * a.Cout) * 4u);
+                    continue;
+                }
+                pix_in[pa][pb] = (oy + pa < a.outH) & (ox + pb < a.outW);
                 const float *rp = a.residual + ((size_t)(oy + pa) * a.outW + ox + pb) * a.Cout + c0;
                 if (pix_in[pa][pb] && quad_ld) rv[pa][pb] = *reinterpret_cast<const f32x4 *>(rp);
                 else if (pix_in[pa][pb] && a.residual) {
@@ -1752,37 +1765,45 @@ __global__ __launch_bounds__(256, 2) void gated_conv_wino16s_kernel(const ConvKA
                         if (c0 + k < a.Cout) rv[pa][pb][k] = rp[k];
                 }
             }
-        // Y[pa][pb] = sum_a sum_j A^T[pa][a] M[a][j] A^T[pb][j],  A^T = [1 1 1 0; 0 1 -1 -1]
+        // Y[pa][pb] = sum_a sum_j A^T[pa][a] M[a][j] A^T[pb][j],  A^T = [1 1 1 0; 0 1 -1 -1]: first over j (R[a][pb], 4 additions per
+        // row), then over a (4 per column) = 24 vector additions per block
         f32x4 Yf[2][2], Ym[2][2];
+        {
+            f32x4 yb[2][2][2];                                         // [block][pa][pb]
 #pragma unroll
-        for (int pa = 0; pa < 2; ++pa)
+            for (int b = 0; b < 2; ++b) {
+                f32x4 R[4][2];
 #pragma unroll
-            for (int pb = 0; pb < 2; ++pb) {
-                f32x4 yb[2];
-#pragma unroll
-                for (int b = 0; b < 2; ++b) {
-                    f32x4 rr[3];                                       // rows a = pa, pa + 1, pa + 2 combined over j
-#pragma unroll
-                    for (int k = 0; k < 3; ++k) {
-                        const int ar = pa + k;
-                        rr[k] = pb == 0 ? acc[b][ar][0] + acc[b][ar][1] + acc[b][ar][2] : acc[b][ar][1] - acc[b][ar][2] - acc[b][ar][3];
-                    }
-                    yb[b] = pa == 0 ? rr[0] + rr[1] + rr[2] : rr[0] - rr[1] - rr[2];
+                for (int ar = 0; ar < 4; ++ar) {
+                    const f32x4 s12 = acc[b][ar][1] + acc[b][ar][2], d12 = acc[b][ar][1] - acc[b][ar][2];
+                    R[ar][0] = acc[b][ar][0] + s12;
+                    R[ar][1] = d12 - acc[b][ar][3];
                 }
-                // lanes 0..31 hold conv_f, lanes 32..63 conv_m of (block 0 | block 1): after the half exchange the lower
-                // half-wave owns block 0 and the upper half block 1, f in one register and m in the other
-                // (whole-vector bit casts: with __builtin_bit_cast of single vector ELEMENTS this hipcc folds the four swaps
-                //  into one — seen in the ISA)
-                u32x4 u0 = __builtin_bit_cast(u32x4, yb[0]), u1 = __builtin_bit_cast(u32x4, yb[1]);
 #pragma unroll
-                for (int k = 0; k < 4; ++k) {
-                    const auto sw = __builtin_amdgcn_permlane32_swap(u0[k], u1[k], false, false);
-                    u0[k] = sw[0];
-                    u1[k] = sw[1];
+                for (int pb = 0; pb < 2; ++pb) {
+                    const f32x4 s12 = R[1][pb] + R[2][pb], d12 = R[1][pb] - R[2][pb];
+                    yb[b][0][pb] = R[0][pb] + s12;
+                    yb[b][1][pb] = d12 - R[3][pb];
                 }
-                Yf[pa][pb] = __builtin_bit_cast(f32x4, u0);
-                Ym[pa][pb] = __builtin_bit_cast(f32x4, u1);
             }
+            // lanes 0..31 hold conv_f, lanes 32..63 conv_m of (block 0 | block 1): after the half exchange the lower half-wave
+            // owns block 0 and the upper half block 1, f in one register and m in the other (whole-vector bit casts: with
+            // __builtin_bit_cast of single vector ELEMENTS this hipcc folds the four swaps into one — seen in the ISA)
+#pragma unroll
+            for (int pa = 0; pa < 2; ++pa)
+#pragma unroll
+                for (int pb = 0; pb < 2; ++pb) {
+                    u32x4 u0 = __builtin_bit_cast(u32x4, yb[0][pa][pb]), u1 = __builtin_bit_cast(u32x4, yb[1][pa][pb]);
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) {
+                        const auto sw = __builtin_amdgcn_permlane32_swap(u0[k], u1[k], false, false);
+                        u0[k] = sw[0];
+                        u1[k] = sw[1];
+                    }
+                    Yf[pa][pb] = __builtin_bit_cast(f32x4, u0);
+                    Ym[pa][pb] = __builtin_bit_cast(f32x4, u1);
+                }
+        }
         {
             constexpr float LOG2E = 1.44269504088896341f;
 #pragma unroll
@@ -1800,6 +1821,10 @@ __global__ __launch_bounds__(256, 2) void gated_conv_wino16s_kernel(const ConvKA
 #pragma unroll
                     for (int k = 0; k < 4; ++k) sg[k] = __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(mm[k]));
                     f32x4 v = (f * sg) * sc + sh + rv[pa][pb];
+                    if (full) {
+                        *reinterpret_cast<f32x4 *>(reinterpret_cast<char *>(a.out) + oo + (unsigned)((pa * a.outW + pb) * a.out_cstride) * 4u) = v;
+                        continue;
+                    }
 #pragma unroll
                     for (int k = 0; k < 4; ++k) v[k] = c0 + k < a.Cout ? v[k] : a.out_fill;
                     float *op = a.out + ((size_t)(oy + pa) * a.outW + ox + pb) * a.out_cstride + c0;

@@ -122,6 +122,61 @@ __global__ __launch_bounds__(256, 2) void issue_probe_kernel(float *out, unsigne
     if ((threadIdx.x & 63) == 0) cycles[blockIdx.x * 4 + (threadIdx.x >> 6)] = t1 - t0;
 }
 
+// ---- operand probe: does the fp32 MFMA rate depend on WHICH registers feed it?  MODE 0: every MFMA of a round reads the same A / B
+// register; 1: 16 distinct A and 16 distinct B registers (one pair per MFMA); 2: the kernel's pattern — A = component e of four
+// float4 "weight" registers, B = component e of eight float4 "operand" registers (order frequency, k-step, block); 3: as 2 with
+// the operand registers rewritten by ds_read_b128 every round (values identical) and waited with s_waitcnt lgkmcnt(0) once per round.
+template <int MODE>
+__global__ __launch_bounds__(256, 2) void operand_probe_kernel(float *out, unsigned long long *cycles, int iters)
+{
+    __shared__ float4 lbuf[512];
+    lbuf[threadIdx.x] = make_float4(0.001f * threadIdx.x, 0.5f, 0.25f, 0.125f);
+    lbuf[256 + threadIdx.x] = make_float4(0.002f * threadIdx.x, 0.3f, 0.2f, 0.1f);
+    __syncthreads();
+    floatx4 acc[16];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc[i] = floatx4{0.f, 0.f, 0.f, 0.f};
+    float a[16], b[16];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+        a[i] = 0.37f + 0.001f * threadIdx.x + 0.01f * i;
+        b[i] = 1.0f - 0.002f * threadIdx.x - 0.02f * i;
+    }
+    floatx4 W4[4], V4[8];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) W4[i] = floatx4{a[i], a[i + 4], a[i + 8], a[i + 12]};
+#pragma unroll
+    for (int i = 0; i < 8; ++i) V4[i] = floatx4{b[i], b[i + 8], b[(i + 3) & 15], b[(i + 5) & 15]};
+    const unsigned laddr = (threadIdx.x & 63) * 16;
+    const unsigned long long t0 = __builtin_amdgcn_s_memtime();
+    for (int it = 0; it < iters; ++it) {
+        if (MODE == 3) {
+#pragma unroll
+            for (int i = 0; i < 8; ++i) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(V4[i]) : "v"(laddr), "n"(0) : "memory");
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        }
+#pragma unroll
+        for (int m = 0; m < 16; ++m) {
+            float av, bv;
+            if (MODE == 0) { av = a[0]; bv = b[0]; }
+            else if (MODE == 1) { av = a[m]; bv = b[m]; }
+            else {
+                const int fl = m >> 3, e = (m >> 1) & 3, blk = m & 1;          // (frequency pair, k-step, block)
+                av = W4[fl][e];
+                bv = V4[fl * 2 + blk][e];
+            }
+            acc[m] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bv, acc[m], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+    const unsigned long long t1 = __builtin_amdgcn_s_memtime();
+    float ssum = 0.f;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) ssum += acc[i][0] + acc[i][3];
+    if (ssum == 1234.5678f) out[blockIdx.x * blockDim.x + threadIdx.x] = ssum;
+    if ((threadIdx.x & 63) == 0) cycles[blockIdx.x * 4 + (threadIdx.x >> 6)] = t1 - t0;
+}
+
 template <int KIND, int FT>
 int issue_probe_launch(int K, int blocks, float *out, unsigned long long *cycles, int iters, const float4 *gsrc, hipStream_t s)
 {
@@ -133,6 +188,18 @@ int issue_probe_launch(int K, int blocks, float *out, unsigned long long *cycles
 #undef IP_CASE
 }
 }  // namespace
+
+extern "C" int read_debug_operand_probe(int mode, int blocks, int iters, float *scratch, unsigned long long *cycles, void *stream)
+{
+    READ_CHECK_ARG(blocks > 0 && iters > 0 && scratch && cycles && mode >= 0 && mode <= 3, "read_debug_operand_probe: bad arguments");
+    hipStream_t s = as_stream(stream);
+    if (mode == 0) hipLaunchKernelGGL(operand_probe_kernel<0>, dim3(blocks), dim3(256), 0, s, scratch, cycles, iters);
+    else if (mode == 1) hipLaunchKernelGGL(operand_probe_kernel<1>, dim3(blocks), dim3(256), 0, s, scratch, cycles, iters);
+    else if (mode == 2) hipLaunchKernelGGL(operand_probe_kernel<2>, dim3(blocks), dim3(256), 0, s, scratch, cycles, iters);
+    else hipLaunchKernelGGL(operand_probe_kernel<3>, dim3(blocks), dim3(256), 0, s, scratch, cycles, iters);
+    READ_CHECK_LAUNCH();
+    return READ_OK;
+}
 
 // kind 0 / 1 = v_mfma_f32_32x32x2_f32 / v_mfma_f32_16x16x4_f32; filler type 0..4 (see issue_probe_kernel); K fillers per MFMA in
 // {0,1,2,3,4,6,8,12}; `blocks` workgroups of 4 waves; cycles[blocks * 4] receives every wave's s_memtime span; gsrc: 1 KiB.
