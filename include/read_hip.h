@@ -231,6 +231,9 @@ typedef struct read_conv_desc {
                                                v_mfma_f32_16x16x4_f32); taken for non-linear launches when present
                                                (read_tuning_set("conv_w16", 0) or config >= 0 keep the row-per-wave kernel,
                                                config = -3 forces it) */
+    const float *wpacked_w4;                /* optional: read_conv_pack_w4_host() output (device): Winograd F(4x4,3x3) operand; taken by
+                                               non-linear 3x3 / stride-1 launches with Cout % 32 == 0 and Cin >= read_tuning("conv_w4")
+                                               (default 128; config = -5 forces it) */
     int linear;                             /* 1: plain convolution (training path): out[..][c] = conv_f + b_f,
                                                out[..][Cout + c] = conv_m + b_m, out_cstride >= 2 * Cout; no gate /
                                                BatchNorm / residual; workgroup-tiled or Winograd kernel */
@@ -262,6 +265,10 @@ size_t read_conv_wino_floats(int Cin, int Cout);
 int read_conv_pack_wino_host(int Cin, int Cout, const float *wf, const float *wm, float *wpacked_wino_host);
 /* same size (read_conv_wino_floats), order of the wave-autonomous Winograd kernel: [group][wave][chunk][row][col][lane][4] */
 int read_conv_pack_w16_host(int Cin, int Cout, const float *wf, const float *wm, float *wpacked_w16_host);
+/* Winograd F(4x4,3x3) operand: read_conv_w4_floats(Cin, Cout) = Cin * 36 * 2 * pad32(Cout) floats,
+ * [group][wave][chunk of 16 cin][frequency 36][lane][4] */
+size_t read_conv_w4_floats(int Cin, int Cout);
+int read_conv_pack_w4_host(int Cin, int Cout, const float *wf, const float *wm, float *wpacked_w4_host);
 int read_conv_pack_params_host(int Cout, const float *bf, const float *bm, const float *gamma,
                                const float *beta, const float *mean, const float *var, float eps,
                                float *params_host);

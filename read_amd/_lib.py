@@ -28,7 +28,8 @@ class ConvDesc(C.Structure):
         ("inH", C.c_int), ("inW", C.c_int), ("Cout", C.c_int), ("ksize", C.c_int), ("stride", C.c_int),
         ("elu", C.c_int), ("wpacked", C.c_void_p), ("params", C.c_void_p), ("residual", C.c_void_p),
         ("out", C.c_void_p), ("out_cstride", C.c_int), ("out_fill", C.c_float), ("fill_pad", C.c_int),
-        ("config", C.c_int), ("wpacked_wino", C.c_void_p), ("wpacked_w16", C.c_void_p), ("linear", C.c_int),
+        ("config", C.c_int), ("wpacked_wino", C.c_void_p), ("wpacked_w16", C.c_void_p), ("wpacked_w4", C.c_void_p),
+        ("linear", C.c_int),
         ("pre", C.c_void_p), ("pre_cstride", C.c_int), ("pre_f_off", C.c_int), ("pre_m_off", C.c_int),
         ("pre_shift", C.c_int), ("preH", C.c_int), ("preW", C.c_int),
         ("out_gated", C.c_void_p), ("block_h", C.c_int), ("valid_h", C.c_int),
@@ -79,6 +80,8 @@ SIGNATURES = {
     "read_conv_wino_floats": (_sz, [_i, _i]),
     "read_conv_pack_wino_host": (_i, [_i, _i, _vp, _vp, _vp]),
     "read_conv_pack_w16_host": (_i, [_i, _i, _vp, _vp, _vp]),
+    "read_conv_w4_floats": (_sz, [_i, _i]),
+    "read_conv_pack_w4_host": (_i, [_i, _i, _vp, _vp, _vp]),
     "read_gated_conv_forward": (_i, [C.POINTER(ConvDesc), _vp]),
     "read_conv_config_count": (_i, []),
     "read_conv_config_name": (C.c_char_p, [_i]),

@@ -41,6 +41,7 @@ struct ConvKArgs {
     const float *wp;
     const float *wp_wino;          // Winograd-transformed weights (read_conv_pack_wino_host) or null
     const float *wp_w16;           // the same weights in the order of the wave-autonomous kernel (read_conv_pack_w16_host) or null
+    const float *wp_w4;            // Winograd F(4x4,3x3) weights (read_conv_pack_w4_host) or null
     const float *params;
     const float *residual;
     float *out;
@@ -1844,6 +1845,350 @@ __global__ __launch_bounds__(256, 2) void gated_conv_wino16s_kernel(const ConvKA
 }
 
 // ------------------------------------------------------------------------------------------
+// Winograd F(4x4,3x3) on v_mfma_f32_16x16x4_f32 for the layers with C >= 128 (round 3; index maps: tests/wino4_ref.py).
+//
+// 4x fewer multiplications than the direct form (F(2x2,3x3): 2.25x), paid with more additions — and on this machine every VALU
+// instruction costs FP-pipe time next to the fp32 MFMAs (tools/issue_probe.py), so the design minimises VALU work per MFMA:
+//   * unit = 2 x 8 tiles of 4 x 4 output pixels (8 x 32 pixels) x 32 output channels; a workgroup of four waves, ONE per SIMD
+//     (144 accumulators + deep operand rings per wave; one wave per SIMD also keeps the weight stream — one 1 KiB fragment per
+//     four MFMAs — at half of what a SIMD's vector-memory path issues);
+//   * the input transform B^T d B (36 frequencies of a 6 x 6 patch, 168 VALU) is computed ONCE per (tile, input channel): thread
+//     = (channel of the 16-channel chunk, tile), 36 ds_read_b32 of the raw patch, 36 ds_write_b32 into a V buffer
+//     [frequency][tile][swizzled channel] that all four waves read their B operands from (one ds_read_b128 = 4 k-steps);
+//   * wave w owns output channels 8w .. 8w+7: A operand = G g G^T of conv_f (rows 0..7) and conv_m (rows 8..15), straight from L2
+//     ([group][wave][chunk][frequency][lane][4 k-steps], twelve frequencies in flight); a lane ends up with all 36 frequencies
+//     of its (tile, 4 channels): the output transform A^T M A is lane-local, one v_permlane32_swap per register pair brings conv_f
+//     and conv_m of half of the pixels together, then the usual gate / BatchNorm / residual epilogue with 128-bit accesses;
+//   * per 16-channel chunk: 144 MFMAs (frequencies in pairs, so an accumulator is touched every second MFMA), beside them the
+//     transform of the NEXT chunk into the other V buffer and the staging of the raw patch two chunks ahead; one barrier.
+struct Wino4Geom {
+    static constexpr int IH = 10, IW = 34, KC = 16, PS = KC + 4;
+    static constexpr int RS = IW * PS;                         // floats per raw patch row (680)
+    static constexpr int BUF = IH * RS;                        // raw patch buffer (6800 floats)
+    static constexpr int VBUF = 36 * 16 * 16;                  // transformed chunk (9216 floats)
+    static constexpr int NE = IH * IW * (KC / 4), NI = (NE + 255) / 256;    // 1360 float4 -> 6 per thread
+    static constexpr int V0 = 2 * BUF;
+    static constexpr int LDS_FLOATS = 2 * BUF + 2 * VBUF + 4;  // two raw buffers, two V buffers, a dummy float4 slot (128 KiB)
+};
+
+template <bool MUL>
+__global__ __launch_bounds__(256, 1) void gated_conv_wino4_kernel(const ConvKArgs a)
+{
+    using WG = Wino4Geom;
+    __shared__ __attribute__((aligned(16))) float lds[WG::LDS_FLOATS];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const SrcDev s = a.src[0];
+    const int groups = a.CoutPad >> 5, G = gridDim.x;
+    const int g = blockIdx.x % groups;
+    const int n = a.nchunks;
+
+    int by = (blockIdx.x / groups) / a.tiles_x, bx = (blockIdx.x / groups) % a.tiles_x;      // running unit (8 x 32 pixel block)
+    int pby = by, pbx = bx, pu = blockIdx.x, pchunk = 0;                                     // prefetch cursor (raw patches)
+    auto step_tile = [&](int &ty_, int &tx_) {
+        ty_ += a.wino_dby;
+        tx_ += a.wino_dbx;
+        if (tx_ >= a.tiles_x) {
+            tx_ -= a.tiles_x;
+            ++ty_;
+        }
+    };
+
+    // ---- raw patch staging (global -> registers -> LDS), two buffers
+    int loff[WG::NI];
+    unsigned rel[WG::NI], aoff[WG::NI];
+    unsigned okmask = 0;
+#pragma unroll
+    for (int i = 0; i < WG::NI; ++i) {
+        const int e = tid + i * 256, q = e % 4, pix = e / 4;
+        loff[i] = e < WG::NE ? (pix / WG::IW) * WG::RS + (pix % WG::IW) * WG::PS + 4 * q : -1;
+        rel[i] = (unsigned)(((pix / WG::IW) * s.W + pix % WG::IW) * s.C + 4 * q) * 4u;
+    }
+    const unsigned safe_rel = (unsigned)((s.W + 1) * s.C) * 4u;
+    const char *pbase = nullptr;
+    long pdelta = 0;
+    if constexpr (MUL) pdelta = reinterpret_cast<const char *>(a.mul) - reinterpret_cast<const char *>(s.p);
+    auto set_patch = [&]() {
+        const int y0 = pby * 8 - 1, x0 = pbx * 32 - 1;
+        pbase = reinterpret_cast<const char *>(s.p) + ((long)y0 * s.W + x0) * (long)(s.C * 4);
+        okmask = 0;
+#pragma unroll
+        for (int i = 0; i < WG::NI; ++i) {
+            const int e = tid + i * 256, pix = e / 4, ppy = pix / WG::IW, ppx = pix % WG::IW;
+            const bool ok = (e < WG::NE) & (ppy >= -y0) & (ppy < a.inH - y0) & (ppx >= -x0) & (ppx < a.inW - x0);
+            okmask |= (ok ? 1u : 0u) << i;
+            aoff[i] = ok ? rel[i] : safe_rel;
+        }
+    };
+    auto advance = [&]() {
+        if (++pchunk == n) {
+            pchunk = 0;
+            if (pu + G < a.n_units) {
+                pu += G;
+                step_tile(pby, pbx);
+            }
+            set_patch();
+        }
+    };
+    float4 st[WG::NI], stm[MUL ? WG::NI : 1];
+    unsigned st_ok = 0;
+    auto gload1 = [&](int i) {
+        st[i] = load_f4(pbase + pchunk * (WG::KC * 4), aoff[i]);
+        if constexpr (MUL) stm[i] = load_f4(pbase + pdelta + pchunk * (WG::KC * 4), aoff[i]);
+    };
+    auto lwrite1 = [&](int i, int obuf) {
+        float4 v = st[i];
+        if constexpr (MUL) v = make_float4(v.x * stm[i].x, v.y * stm[i].y, v.z * stm[i].z, v.w * stm[i].w);
+        if (!((st_ok >> i) & 1u)) v = make_float4(0.f, 0.f, 0.f, 0.f);
+        *reinterpret_cast<float4 *>(__builtin_assume_aligned(lds + (loff[i] >= 0 ? obuf + loff[i] : WG::LDS_FLOATS - 4), 16)) = v;
+    };
+
+    // ---- transform role: thread = (input channel c16 of the chunk, tile tl): one 6 x 6 patch -> 36 frequencies
+    const int c16 = tid & 15, tl = tid >> 4;
+    const int rbase = ((4 * (tl >> 3)) * WG::IW + 4 * (tl & 7)) * WG::PS + c16;                    // raw patch (floats)
+    const int vwoff = WG::V0 + tl * 16 + ((c16 >> 2) ^ ((tl >> 1) & 3)) * 4 + (c16 & 3);           // + V buffer + frequency * 256
+    float d[6][6];
+    // 1-D transform with B^T = [4 0 -5 0 1 0; 0 -4 -4 1 1 0; 0 4 -4 -1 1 0; 0 -2 -1 2 1 0; 0 2 -1 -2 1 0; 0 4 0 -5 0 1], 14 operations
+    auto bt6 = [](float &x0, float &x1, float &x2, float &x3, float &x4, float &x5) {
+        const float p = x3 + x4, q = x1 + x2, r = x4 - x3, u = x1 - x2, f = x3 - x1, h = x4 - x2;
+        const float y0 = __builtin_fmaf(x2, -5.0f, __builtin_fmaf(x0, 4.0f, x4));
+        const float y5 = __builtin_fmaf(x3, -5.0f, __builtin_fmaf(x1, 4.0f, x5));
+        x0 = y0;
+        x1 = __builtin_fmaf(q, -4.0f, p);
+        x2 = __builtin_fmaf(u, 4.0f, r);
+        x3 = __builtin_fmaf(f, 2.0f, h);
+        x4 = __builtin_fmaf(f, -2.0f, h);
+        x5 = y5;
+    };
+    // step k of the next chunk's transform: 0..35 reads, 36..41 columns, 42..47 rows, 48..83 stores
+    auto t_step = [&](const float *raw, int vb, int k) {
+        if (k < 36) {
+            d[k / 6][k % 6] = raw[rbase + ((k / 6) * WG::IW + (k % 6)) * WG::PS];
+        } else if (k < 42) {
+            const int c = k - 36;
+            bt6(d[0][c], d[1][c], d[2][c], d[3][c], d[4][c], d[5][c]);
+        } else if (k < 48) {
+            const int r = k - 42;
+            bt6(d[r][0], d[r][1], d[r][2], d[r][3], d[r][4], d[r][5]);
+        } else {
+            const int fq = k - 48;
+            lds[vwoff + vb + fq * 256] = d[fq / 6][fq % 6];
+        }
+    };
+    constexpr int T_STEPS = 84;
+
+    // ---- A operand (weights): [group][wave][chunk][frequency][lane][4]; ring of 12 frequencies, fetched 10 ahead
+    const char *const wbase = reinterpret_cast<const char *>(a.wp_w4) + ((size_t)(g * 4 + wv) * n) * (36 * 1024);
+    const unsigned wvoff = lane * 16;
+    float4 Wq[12];
+    auto wload1 = [&](int slot, int chunk, int fq) { Wq[slot] = load_f4(wbase + (size_t)(chunk * 36 + fq) * 1024, wvoff); };
+    // ---- B operand: Vbuf[frequency][tile t16][slot]; ring of 6 frequencies, fetched 4 ahead
+    const int t16 = lane & 15, kl = lane >> 4;
+    const int vlane = t16 * 16 + 4 * (kl ^ ((t16 >> 1) & 3));
+    float4 Bq[6];
+    auto bload1 = [&](int slot, int vb, int fq) {
+        Bq[slot] = *reinterpret_cast<const float4 *>(__builtin_assume_aligned(lds + WG::V0 + vb + fq * 256 + vlane, 16));
+    };
+
+    f32x4 acc[36];
+    const bool chan_full = (g * 32 + wv * 8 + 8 <= a.Cout) & ((a.out_cstride & 3) == 0) & ((a.Cout & 3) == 0) & !a.fill_pad;
+
+    // ---- prologue: raw(0), raw(1) -> LDS, raw(2) -> registers, V(0), the first ten weight fragments, the first four B operands
+    set_patch();
+#pragma unroll
+    for (int i = 0; i < WG::NI; ++i) gload1(i);
+    st_ok = okmask;
+#pragma unroll
+    for (int j = 0; j < 10; ++j) wload1(j, 0, j);
+#pragma unroll
+    for (int i = 0; i < WG::NI; ++i) lwrite1(i, 0);
+    advance();
+#pragma unroll
+    for (int i = 0; i < WG::NI; ++i) gload1(i);
+    st_ok = okmask;
+#pragma unroll
+    for (int i = 0; i < WG::NI; ++i) lwrite1(i, WG::BUF);
+    advance();
+#pragma unroll
+    for (int i = 0; i < WG::NI; ++i) gload1(i);
+    st_ok = okmask;
+    advance();
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < T_STEPS; ++k) t_step(lds, 0, k);
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < 4; ++j) bload1(j, 0, j);
+
+    int raw_cur = 0, raw_nxt = WG::BUF;                        // raw buffers: this chunk's (already transformed: free) / the next chunk's
+    int v_cur = 0, v_nxt = WG::VBUF;
+
+    // One stage = one 16-channel chunk: 144 MFMAs; beside them: the transform of chunk + 1 (raw_nxt -> v_nxt), raw(chunk + 2)
+    // registers -> LDS (into raw_cur, whose chunk was transformed during the previous stage) and raw(chunk + 3) -> registers.
+    auto stage_body = [&](auto first_tag, int chunk) {
+        constexpr bool FIRST = decltype(first_tag)::value;
+        int nchunk = chunk + 1;                                       // wraps into the next unit (same weights)
+        nchunk = nchunk == n ? 0 : nchunk;
+        const float *traw = lds + raw_nxt;
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int pr = 0; pr < 18; ++pr)
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+#pragma unroll
+                for (int sidx = 0; sidx < 2; ++sidx) {
+                    const int fq = 2 * pr + sidx, m = pr * 8 + e * 2 + sidx;
+                    const float4 wv4 = Wq[fq % 12], vv4 = Bq[fq % 6];
+                    const float we = e == 0 ? wv4.x : e == 1 ? wv4.y : e == 2 ? wv4.z : wv4.w;
+                    const float ve = e == 0 ? vv4.x : e == 1 ? vv4.y : e == 2 ? vv4.z : vv4.w;
+                    if (FIRST && e == 0) {
+                        const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+                        acc[fq] = __builtin_amdgcn_mfma_f32_16x16x4f32(we, ve, zero, 0, 0, 0);
+                    } else
+                        acc[fq] = __builtin_amdgcn_mfma_f32_16x16x4f32(we, ve, acc[fq], 0, 0, 0);
+                    // ---- shadow items
+                    const int mm = e * 2 + sidx;                                     // position inside this pair's 8 MFMAs
+                    if (mm < 2 && 2 * pr + 4 + mm < 36) bload1((2 * pr + 4 + mm) % 6, v_cur, 2 * pr + 4 + mm);   // B operands 4 ahead
+                    if (mm >= 2 && mm < 4) {                                         // weights 10 frequencies ahead
+                        const int wf = 2 * pr + 10 + (mm - 2);
+                        if (wf < 36) wload1(wf % 12, chunk, wf);
+                        else wload1(wf % 12, nchunk, wf - 36);
+                    }
+                    // the next chunk's transform: reads first (one per MFMA), arithmetic, stores; then the raw patch traffic
+                    if (m < 36) t_step(traw, v_nxt, m);
+                    if (m >= 44 && m < 56) t_step(traw, v_nxt, 36 + (m - 44));
+                    if (m >= 58 && m < 94) t_step(traw, v_nxt, 48 + (m - 58));
+                    if (m >= 96 && m - 96 < WG::NI) lwrite1(m - 96, raw_cur);        // raw(chunk + 2): registers -> LDS
+                    if (m >= 104 && m - 104 < WG::NI) gload1(m - 104);               // raw(chunk + 3) -> registers
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+        st_ok = okmask;
+        advance();
+        __syncthreads();
+#pragma unroll
+        for (int j = 0; j < 4; ++j) bload1(j, v_nxt, j);                              // first B operands of the next chunk
+        const int o = raw_cur;
+        raw_cur = raw_nxt;
+        raw_nxt = o;
+        const int v = v_cur;
+        v_cur = v_nxt;
+        v_nxt = v;
+    };
+
+    for (int u = blockIdx.x; u < a.n_units; u += G) {
+        stage_body(std::true_type{}, 0);
+        for (int chunk = 1; chunk < n; ++chunk) stage_body(std::false_type{}, chunk);
+
+        // ================= unit epilogue (lane-local) =================
+        // D layout: lane (t16, q = lane >> 4), register r = MFMA row 4q + r: q = 0, 1 -> conv_f of channels 4q + r, q = 2, 3 -> conv_m
+        // of channels 4 (q - 2) + r; column = tile t16.  Y = A^T M A with A^T = [1 1 1 1 1 0; 0 1 -1 2 -2 0; 0 1 1 4 4 0; 0 1 -1 8 -8 1].
+        __builtin_amdgcn_s_setprio(1);
+        const int cq = (lane >> 4) & 1, hf = lane >> 5;
+        const int c0 = g * 32 + wv * 8 + 4 * cq;
+        const int oy = by * 8 + 4 * (t16 >> 3) + 2 * hf, ox = bx * 32 + 4 * (t16 & 7);           // this lane finishes rows oy, oy + 1
+        const bool full = (by * 8 + 8 <= a.outH) & (bx * 32 + 32 <= a.outW) & chan_full;
+        const f32x4 bf = *reinterpret_cast<const f32x4 *>(a.params + c0);
+        const f32x4 bm = *reinterpret_cast<const f32x4 *>(a.params + a.CoutPad + c0);
+        const f32x4 sc = *reinterpret_cast<const f32x4 *>(a.params + 2 * a.CoutPad + c0);
+        const f32x4 sh = *reinterpret_cast<const f32x4 *>(a.params + 3 * a.CoutPad + c0);
+        const int c_lim = a.fill_pad ? a.out_cstride : a.Cout;
+        const bool quad_st = c0 + 3 < c_lim && (a.out_cstride & 3) == 0;
+        const bool quad_ld = a.residual && c0 + 3 < a.Cout && (a.Cout & 3) == 0;
+        f32x4 rv[2][4];
+#pragma unroll
+        for (int py = 0; py < 2; ++py)
+#pragma unroll
+            for (int px = 0; px < 4; ++px) {
+                rv[py][px] = f32x4{0.f, 0.f, 0.f, 0.f};
+                const bool in = (oy + py < a.outH) & (ox + px < a.outW);
+                const float *rp = a.residual + ((size_t)(oy + py) * a.outW + ox + px) * a.Cout + c0;
+                if (in && quad_ld) rv[py][px] = *reinterpret_cast<const f32x4 *>(rp);
+                else if (in && a.residual) {
+#pragma unroll
+                    for (int k = 0; k < 4; ++k)
+                        if (c0 + k < a.Cout) rv[py][px][k] = rp[k];
+                }
+            }
+        // rows: R[p][nu] from M[0..5][nu]; then columns: Y[p][0..3] from R[p][0..5]
+        f32x4 Y[4][4];
+        {
+            f32x4 R[4][6];
+#pragma unroll
+            for (int nu = 0; nu < 6; ++nu) {
+                const f32x4 s1 = acc[6 + nu] + acc[12 + nu], d1 = acc[6 + nu] - acc[12 + nu];
+                const f32x4 s2 = acc[18 + nu] + acc[24 + nu], d2 = acc[18 + nu] - acc[24 + nu];
+                R[0][nu] = acc[nu] + s1 + s2;
+                R[1][nu] = d1 + 2.0f * d2;
+                R[2][nu] = s1 + 4.0f * s2;
+                R[3][nu] = d1 + 8.0f * d2 + acc[30 + nu];
+            }
+#pragma unroll
+            for (int p = 0; p < 4; ++p) {
+                const f32x4 s1 = R[p][1] + R[p][2], d1 = R[p][1] - R[p][2];
+                const f32x4 s2 = R[p][3] + R[p][4], d2 = R[p][3] - R[p][4];
+                Y[p][0] = R[p][0] + s1 + s2;
+                Y[p][1] = d1 + 2.0f * d2;
+                Y[p][2] = s1 + 4.0f * s2;
+                Y[p][3] = d1 + 8.0f * d2 + R[p][5];
+            }
+        }
+        // lanes 0..31 hold conv_f, lanes 32..63 conv_m: exchange rows (py, py + 2) so that the lower half-wave owns rows 0, 1 and
+        // the upper half rows 2, 3 of the tile, f in one register and m in the other
+        f32x4 Yf[2][4], Ym[2][4];
+#pragma unroll
+        for (int py = 0; py < 2; ++py)
+#pragma unroll
+            for (int px = 0; px < 4; ++px) {
+                u32x4 u0 = __builtin_bit_cast(u32x4, Y[py][px]), u1 = __builtin_bit_cast(u32x4, Y[py + 2][px]);
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const auto sw = __builtin_amdgcn_permlane32_swap(u0[k], u1[k], false, false);
+                    u0[k] = sw[0];
+                    u1[k] = sw[1];
+                }
+                Yf[py][px] = __builtin_bit_cast(f32x4, u0);
+                Ym[py][px] = __builtin_bit_cast(f32x4, u1);
+            }
+        {
+            constexpr float LOG2E = 1.44269504088896341f;
+#pragma unroll
+            for (int py = 0; py < 2; ++py)
+#pragma unroll
+                for (int px = 0; px < 4; ++px) {
+                    f32x4 f = Yf[py][px] + bf;
+                    const f32x4 mm = (Ym[py][px] + bm) * -LOG2E;
+                    if (a.elu) {
+                        const f32x4 fe = f * LOG2E;
+#pragma unroll
+                        for (int k = 0; k < 4; ++k) f[k] = f[k] > 0.0f ? f[k] : __builtin_amdgcn_exp2f(fe[k]) - 1.0f;
+                    }
+                    f32x4 sg;
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) sg[k] = __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(mm[k]));
+                    f32x4 v = (f * sg) * sc + sh + rv[py][px];
+                    float *op = a.out + ((size_t)(oy + py) * a.outW + ox + px) * a.out_cstride + c0;
+                    if (full) {
+                        *reinterpret_cast<f32x4 *>(op) = v;
+                        continue;
+                    }
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) v[k] = c0 + k < a.Cout ? v[k] : a.out_fill;
+                    if ((oy + py < a.outH) & (ox + px < a.outW)) {
+                        if (quad_st) *reinterpret_cast<f32x4 *>(op) = v;
+                        else {
+#pragma unroll
+                            for (int k = 0; k < 4; ++k)
+                                if (c0 + k < c_lim) op[k] = v[k];
+                        }
+                    }
+                }
+        }
+        step_tile(by, bx);
+        __builtin_amdgcn_s_setprio(0);
+    }
+}
+
+// ------------------------------------------------------------------------------------------
 // 1x1 layers in the "pixel-lane" orientation: weights are the MFMA A operand, activations the B operand.
 //
 //   D[cout][pixel] = sum_k W[cout][k] * X[k][pixel]        (v_mfma_f32_32x32x2_f32: lane = pixel, registers = channels)
@@ -2124,6 +2469,8 @@ int g_conv_px = 1;         // read_tuning_set("conv_px", v): pixel-lane kernel f
                            // (64 / 128 accumulator registers per wave); 3 / 4 every layer it fits
 int g_kc32 = 1;            // 32-channel chunks for 1x1 layers whose sources are all multiples of 32 (read_tuning_set("conv_kc32", 0): 16)
 int g_use_wino = 1 << 30;  // read_tuning_set("conv_wino", max Cin): Winograd kernel for eligible 3x3 layers (0 = off)
+int g_w4 = 128;            // read_tuning_set("conv_w4", min Cin): layers with at least this many channels take the Winograd F(4x4,3x3)
+                           // kernel when its weights were supplied (0 = never)
 int g_w16_abl = 0;         // read_tuning_set("conv_w16_abl", bits): attribution probes of the wave-autonomous kernel (results invalid)
 int g_w16 = 1;             // read_tuning_set("conv_w16", v): 0 the row-per-wave Winograd kernel, 1 the wave-autonomous kernel with the shared
                            // input transform (default), 2 its first version (every wave transforms for itself)
@@ -2321,6 +2668,41 @@ extern "C" int read_conv_pack_w16_host(int Cin, int Cout, const float *wf, const
     return READ_OK;
 }
 
+extern "C" size_t read_conv_w4_floats(int Cin, int Cout)
+{
+    if (Cin < 16 || Cin % 16 || Cout < 1) return 0;
+    return (size_t)Cin * 36 * 2 * pad32(Cout);
+}
+
+// F(4x4,3x3): U = G g G^T (6 x 6) per (cout, cin) pair, G = [1/4 0 0; -1/6 -1/6 -1/6; -1/6 1/6 -1/6; 1/24 1/12 1/6; 1/24 -1/12 1/6; 0 0 1],
+// evaluated in double and rounded once; order [group][wave 4][chunk of 16 cin][frequency 6 xi + nu][lane][e] with lane
+// (i = lane & 15, kl = lane >> 4) = U_{i < 8 ? f : m}[xi][nu][cin = 16 chunk + 4 kl + e][cout = 32 group + 8 wave + (i & 7)]   (tests/wino4_ref.py)
+extern "C" int read_conv_pack_w4_host(int Cin, int Cout, const float *wf, const float *wm, float *out)
+{
+    READ_CHECK_ARG(wf && wm && out, "read_conv_pack_w4_host: null pointer");
+    READ_CHECK_ARG(Cin >= 16 && Cin % 16 == 0 && Cout >= 1, "read_conv_pack_w4_host: needs Cin %% 16 == 0 (got %d)", Cin);
+    static const double G[6][3] = {{0.25, 0.0, 0.0}, {-1.0 / 6, -1.0 / 6, -1.0 / 6}, {-1.0 / 6, 1.0 / 6, -1.0 / 6},
+                                   {1.0 / 24, 1.0 / 12, 1.0 / 6}, {1.0 / 24, -1.0 / 12, 1.0 / 6}, {0.0, 0.0, 1.0}};
+    const int CoutPad = pad32(Cout), groups = CoutPad / 32, nchunks = Cin / 16;
+    size_t o = 0;
+    for (int g = 0; g < groups; ++g)
+        for (int w = 0; w < 4; ++w)
+            for (int c = 0; c < nchunks; ++c)
+                for (int fq = 0; fq < 36; ++fq)
+                    for (int lane = 0; lane < 64; ++lane)
+                        for (int e = 0; e < 4; ++e, ++o) {
+                            const int slot = lane & 15, co = g * 32 + w * 8 + (slot & 7), ci = 16 * c + 4 * (lane >> 4) + e;
+                            double u = 0.0;
+                            if (co < Cout) {
+                                const float *k = ((slot >> 3) ? wm : wf) + ((size_t)co * Cin + ci) * 9;
+                                for (int a = 0; a < 3; ++a)
+                                    for (int b = 0; b < 3; ++b) u += G[fq / 6][a] * (double)k[a * 3 + b] * G[fq % 6][b];
+                            }
+                            out[o] = (float)u;
+                        }
+    return READ_OK;
+}
+
 extern "C" int read_conv_pack_params_host(int Cout, const float *bf, const float *bm, const float *gamma,
                                           const float *beta, const float *mean, const float *var, float eps,
                                           float *params_host)
@@ -2349,6 +2731,7 @@ void conv_set_wino(int max_cin) { g_use_wino = max_cin; }
 void conv_set_kc32(int v) { g_kc32 = v; }
 void conv_set_w16(int v) { g_w16 = v < 0 ? 0 : v > 2 ? 2 : v; }
 void conv_set_w16_abl(int v) { g_w16_abl = v; }
+void conv_set_w4(int v) { g_w4 = v < 0 ? 0 : v; }
 void conv_set_wino_wgs(int v) { g_wino_wgs = v <= 1 ? 1 : 2; }
 void conv_set_px(int v) { g_conv_px = v < 0 ? 0 : v > 4 ? 4 : v; }
 int conv_get(const char *key, int *value)
@@ -2360,6 +2743,7 @@ int conv_get(const char *key, int *value)
     else if (!strcmp(key, "conv_wino_wgs")) *value = g_wino_wgs;
     else if (!strcmp(key, "conv_wino")) *value = g_use_wino;
     else if (!strcmp(key, "conv_w16")) *value = g_w16;
+    else if (!strcmp(key, "conv_w4")) *value = g_w4;
 #ifdef READ_DEBUG_KNOBS
     else if (!strcmp(key, "conv_ablate")) *value = g_ablate;
 #endif
@@ -2378,6 +2762,7 @@ void conv_set_trace(void *buf, size_t bytes)
 // Validates a descriptor, builds kernel arguments and launches.  Shared by the single-layer
 // entry point and the UNet executor.
 int conv_uses_wino(const read_conv_desc *d);
+int conv_uses_w4(const read_conv_desc *d);
 
 int launch_gated_conv(const read_conv_desc *d, hipStream_t stream)
 {
@@ -2450,6 +2835,7 @@ int launch_gated_conv(const read_conv_desc *d, hipStream_t stream)
     a.wp = d->wpacked;
     a.wp_wino = d->wpacked_wino;
     a.wp_w16 = d->wpacked_w16;
+    a.wp_w4 = d->wpacked_w4;
     a.params = d->params;
     a.residual = d->residual;
     a.out = d->out;
@@ -2611,6 +2997,30 @@ int launch_gated_conv(const read_conv_desc *d, hipStream_t stream)
         grid = dim3((unsigned)(want < cap ? want : cap), 1);
     }
     conv_fn fn = c.fn;
+    // Winograd F(4x4,3x3): units of 8 x 32 pixels x 32 channels, one persistent workgroup per CU
+    if (conv_uses_w4(d)) {
+        READ_CHECK_ARG((uintptr_t)d->wpacked_w4 % 16 == 0, "read_gated_conv_forward: wpacked_w4 misaligned");
+        READ_CHECK_ARG(!d->mul || (uintptr_t)d->mul % 16 == 0, "read_gated_conv_forward: mul misaligned");
+        a.tiles_x = ceil_div(outW, 32);
+        a.n_units = a.tiles_x * ceil_div(outH, 8) * groups;
+        static int n_cu_4 = 0;
+        if (!n_cu_4) {
+            int dev = 0;
+            hipDeviceProp_t prop;
+            n_cu_4 = (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess &&
+                      prop.multiProcessorCount > 0) ? prop.multiProcessorCount : 256;
+        }
+        int nwg = a.n_units < n_cu_4 ? a.n_units : n_cu_4;
+        nwg -= nwg % groups;
+        if (nwg < groups) nwg = groups;
+        a.wino_dby = (nwg / groups) / a.tiles_x;
+        a.wino_dbx = (nwg / groups) % a.tiles_x;
+        a.trace = nullptr;
+        hipLaunchKernelGGL(d->mul ? gated_conv_wino4_kernel<true> : gated_conv_wino4_kernel<false>, dim3((unsigned)nwg), dim3(256), 0,
+                           stream, a);
+        READ_CHECK_LAUNCH();
+        return READ_OK;
+    }
     if (c.wino && a.trace && !d->mul) fn = gated_conv_wino_kernel<true, false>;
     if (d->mul) {
         READ_CHECK_ARG(c.fn_mul, "read_gated_conv_forward: config %s has no multiply variant", c.name);
@@ -2659,6 +3069,14 @@ int conv_uses_wino(const read_conv_desc *d)
 {
     return d->config < 0 && g_use_wino && !d->pre && d->ksize == 3 && d->stride == 1 && d->n_src == 1 &&
            d->src[0].shift == 0 && d->src[0].C % 16 == 0 && d->wpacked_wino && d->src[0].C <= g_use_wino;
+}
+
+// F(4x4,3x3): non-linear 3x3 / stride-1 launches with full 32-channel groups and at least conv_w4 input channels (config -5 forces it)
+int conv_uses_w4(const read_conv_desc *d)
+{
+    const bool shape = !d->pre && !d->linear && d->ksize == 3 && d->stride == 1 && d->n_src == 1 && d->src[0].shift == 0 &&
+                       d->src[0].C % 16 == 0 && d->src[0].C >= 32 && d->Cout % 32 == 0 && !d->fill_pad && d->wpacked_w4;
+    return shape && (d->config == -5 || (d->config == -1 && g_w4 > 0 && d->src[0].C >= g_w4));
 }
 
 int conv_kc_for(const read_conv_desc *d)

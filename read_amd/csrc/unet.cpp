@@ -15,6 +15,7 @@
 namespace readhip {
 int launch_gated_conv(const read_conv_desc *d, hipStream_t stream);
 int conv_uses_wino(const read_conv_desc *d);
+int conv_uses_w4(const read_conv_desc *d);
 }
 using namespace readhip;
 
@@ -30,6 +31,7 @@ struct LayerInfo {
     size_t raw_off, w_off, p_off;   // float offsets into the raw / packed blobs
     size_t wino_off;                // Winograd-transformed weights of 3x3/s1 layers with Cin % 16 == 0, else NO_WINO
     size_t w16_off;                 // ... in the order of the wave-autonomous Winograd kernel (read_conv_pack_w16_host)
+    size_t w4_off;                  // Winograd F(4x4,3x3) weights of the C -> C layers with C >= 128, else NO_WINO
 };
 constexpr size_t NO_WINO = ~(size_t)0;
 
@@ -68,7 +70,7 @@ const Arch &arch()
     static Arch A = [] {
         Arch a;
         auto add = [&](const std::string &path, int cin, int cout, int k, int s, int elu, int kc) {
-            LayerInfo L{path, cin, cout, k, s, elu, kc, 0, 0, 0, NO_WINO, NO_WINO};
+            LayerInfo L{path, cin, cout, k, s, elu, kc, 0, 0, 0, NO_WINO, NO_WINO, NO_WINO};
             L.raw_off = a.raw_floats;
             a.raw_floats += raw_layer_floats(cin, cout, k);
             L.w_off = a.packed_floats;
@@ -80,6 +82,10 @@ const Arch &arch()
                 a.packed_floats += read_conv_wino_floats(cin, cout);
                 L.w16_off = a.packed_floats;
                 a.packed_floats += read_conv_wino_floats(cin, cout);
+                if (cin >= 128 && cout % 32 == 0) {
+                    L.w4_off = a.packed_floats;
+                    a.packed_floats += read_conv_w4_floats(cin, cout);
+                }
             }
             a.layers.push_back(L);
         };
@@ -237,7 +243,7 @@ struct Builder {
     };
     struct LayerRef {
         int cin, cout, k, stride, elu;
-        size_t w_off, p_off, wino_off, w16_off;
+        size_t w_off, p_off, wino_off, w16_off, w4_off;
     };
 
     // One BasicConv.  srcs = {tensor id, shift}; out tensor must already exist.
@@ -246,7 +252,7 @@ struct Builder {
     {
         const Arch &A = arch();
         const LayerInfo &L = A.layers[A.find(path)];
-        emit(path, LayerRef{L.cin, L.cout, L.k, L.stride, L.elu, L.w_off, L.p_off, L.wino_off, L.w16_off}, srcs, out_t, mul_t, res_t, 0,
+        emit(path, LayerRef{L.cin, L.cout, L.k, L.stride, L.elu, L.w_off, L.p_off, L.wino_off, L.w16_off, L.w4_off}, srcs, out_t, mul_t, res_t, 0,
              PreRef());
     }
     // A derived 1x1 layer (DerivedInfo): `linear` ones store the pre-activations [f | m] for a finer level to add,
@@ -256,7 +262,7 @@ struct Builder {
         const Arch &A = arch();
         const DerivedInfo &D = A.derived[A.find_derived(name)];
         const LayerInfo &P0 = A.layers[D.parts[0]];
-        emit(name, LayerRef{D.cin, D.cout, 1, 1, P0.elu, D.w_off, linear ? D.p_off : P0.p_off, NO_WINO, NO_WINO}, srcs, out_t, -1, -1,
+        emit(name, LayerRef{D.cin, D.cout, 1, 1, P0.elu, D.w_off, linear ? D.p_off : P0.p_off, NO_WINO, NO_WINO, NO_WINO}, srcs, out_t, -1, -1,
              linear, pre);
     }
 
@@ -296,6 +302,7 @@ struct Builder {
         op.d.params = u->packed + L.p_off;
         op.d.wpacked_wino = L.wino_off != NO_WINO ? u->packed + L.wino_off : nullptr;
         op.d.wpacked_w16 = L.w16_off != NO_WINO ? u->packed + L.w16_off : nullptr;
+        op.d.wpacked_w4 = L.w4_off != NO_WINO ? u->packed + L.w4_off : nullptr;
         op.d.mul = mul_t >= 0 ? u->tensors[mul_t].p : nullptr;
         op.d.residual = res_t >= 0 ? u->tensors[res_t].p : nullptr;
         op.d.out = o.p;
@@ -570,6 +577,10 @@ extern "C" int read_unet_pack_host(const float *raw, float bn_eps, float *packed
             if (rc) return rc;
             rc = read_conv_pack_w16_host(L.cin, L.cout, wf, wm, packed + L.w16_off);
             if (rc) return rc;
+            if (L.w4_off != NO_WINO) {
+                rc = read_conv_pack_w4_host(L.cin, L.cout, wf, wm, packed + L.w4_off);
+                if (rc) return rc;
+            }
         }
     }
     const Arch &A = arch();
@@ -685,7 +696,9 @@ extern "C" int read_unet_profile(read_unet_t *u, const float *x0, const float *x
         if (flops) flops[i] = u->ops[i].flops;
         // 0: other, 1: 3x3/s1 C->C direct, 2: the same through the Winograd kernel (2.25x fewer MFMA flops than `flops`)
         if (is_conv3x3_s1)
-            is_conv3x3_s1[i] = u->ops[i].is_c3s1 ? (u->ops[i].kind == Op::CONV && conv_uses_wino(&u->ops[i].d) ? 2 : 1) : 0;
+            // 0: not in the 3x3/s1 C->C family; 1: direct kernel; 2: Winograd F(2x2,3x3); 4: Winograd F(4x4,3x3)
+            is_conv3x3_s1[i] = u->ops[i].is_c3s1 ? (u->ops[i].kind != Op::CONV ? 1 : conv_uses_w4(&u->ops[i].d) ? 4 :
+                                                     conv_uses_wino(&u->ops[i].d) ? 2 : 1) : 0;
     }
     return READ_OK;
 }

@@ -34,7 +34,7 @@ class PackedGatedConv:
                                                 pp.ctypes.data), "read_conv_pack_params_host")
         self.wpacked = torch.from_numpy(wp).to(device)
         self.params = torch.from_numpy(pp).to(device)
-        self.wpacked_wino = self.wpacked_w16 = None
+        self.wpacked_wino = self.wpacked_w16 = self.wpacked_w4 = None
         if self.k == 3 and self.cin % 16 == 0:        # Winograd F(2x2,3x3) operand for the 3x3/s1 kernel variant
             ww = np.empty(L.read_conv_wino_floats(self.cin, self.cout), np.float32)
             _lib.check(L.read_conv_pack_wino_host(self.cin, self.cout, wf.ctypes.data, wm.ctypes.data, ww.ctypes.data),
@@ -44,6 +44,11 @@ class PackedGatedConv:
             _lib.check(L.read_conv_pack_w16_host(self.cin, self.cout, wf.ctypes.data, wm.ctypes.data, w16.ctypes.data),
                        "read_conv_pack_w16_host")
             self.wpacked_w16 = torch.from_numpy(w16).to(device)
+            if self.cout % 32 == 0 and self.cin >= 32:
+                w4 = np.empty(L.read_conv_w4_floats(self.cin, self.cout), np.float32)
+                _lib.check(L.read_conv_pack_w4_host(self.cin, self.cout, wf.ctypes.data, wm.ctypes.data, w4.ctypes.data),
+                           "read_conv_pack_w4_host")
+                self.wpacked_w4 = torch.from_numpy(w4).to(device)
 
 
 def gated_conv(packed, sources, stride=1, elu=True, mul=None, residual=None, config=-1, out=None,
@@ -81,6 +86,7 @@ def gated_conv(packed, sources, stride=1, elu=True, mul=None, residual=None, con
     d.config = config
     d.wpacked_wino = packed.wpacked_wino.data_ptr() if packed.wpacked_wino is not None else None
     d.wpacked_w16 = packed.wpacked_w16.data_ptr() if packed.wpacked_w16 is not None else None
+    d.wpacked_w4 = packed.wpacked_w4.data_ptr() if packed.wpacked_w4 is not None else None
     d.linear = 1 if linear else 0
     if pre is not None:
         pt, f_off, m_off, psh = pre

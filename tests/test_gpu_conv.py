@@ -84,6 +84,26 @@ def test_winograd_kernel_on_unet_shapes(hip):
             _close(got, ref, f"winograd config {cfg} {c}->{c} {H}x{W}", scale=5.0)
 
 
+def test_winograd_f4_kernel(hip):
+    """Winograd F(4x4,3x3) (config -5; the automatic choice for C >= 128): the UNet's 128- and 256-channel shapes, ragged sizes
+    (partial 8 x 32 blocks, one-pixel images), residual, ELU on / off, the FAM multiply, several units per workgroup.  Stated
+    tolerance: 10x the direct kernels' (|diff| <= 2e-4 (1 + |ref|)): the F(4x4) transforms multiply by up to 8 and sum mixed signs."""
+    torch.manual_seed(21)
+    for j, (c, H, W) in enumerate([(128, 9, 17), (256, 8, 32), (128, 23, 70), (32, 5, 3), (64, 40, 100), (128, 88, 304), (256, 44, 152)]):
+        st = _state(c, c, 3, seed=500 + j)
+        x = torch.randn(c, H, W)
+        res = torch.randn(c, H, W)
+        ref = unet_torch.basic_conv(st, "L", x[None], 3, elu=j % 2 == 0)[0] + res
+        got = gated_conv(_pack(st, [c]), [(_nhwc(x), 0)], elu=j % 2 == 0, residual=_nhwc(res), config=-5)
+        _close(got, ref, f"winograd F(4x4) {c}->{c} {H}x{W}", scale=10.0)
+    for c in (128, 256):                                   # FAM: x1 + BC(x1 * x2), automatic choice (C >= 128 -> F(4x4))
+        x1, x2 = torch.randn(c, 12, 40), torch.randn(c, 12, 40)
+        st = _state(c, c, 3, seed=c + 7)
+        ref = x1 + unet_torch.basic_conv(st, "L", (x1 * x2)[None], 3, elu=False)[0]
+        got = gated_conv(_pack(st, [c]), [(_nhwc(x1), 0)], elu=False, mul=_nhwc(x2), residual=_nhwc(x1))
+        _close(got, ref, f"FAM through F(4x4) C={c}", scale=10.0)
+
+
 def test_winograd_kernel_odd_channel_counts_and_strides(hip):
     """Edge cases of the Winograd kernel's transposed epilogue: Cout that is not a multiple of 4 (scalar store
     fallback, partial last channel quad), padded output rows (out_cstride > Cout, with and without fill), a
@@ -127,7 +147,9 @@ def test_unet_layer_shapes_auto_config(hip):
         res = torch.randn_like(ref) if (s == 1 and cin == cout) else None
         got = gated_conv(_pack(st, [cin]), [(_nhwc(x), 0)], stride=s, elu=elu,
                          residual=_nhwc(res) if res is not None else None)
-        _close(got, ref + (res if res is not None else 0), f"shape {cin}->{cout} k{k} s{s}")
+        # C >= 128 3x3/s1 layers take Winograd F(4x4,3x3) by default: its stated tolerance (test_winograd_f4_kernel)
+        _close(got, ref + (res if res is not None else 0), f"shape {cin}->{cout} k{k} s{s}",
+               scale=10.0 if (k == 3 and s == 1 and cin >= 128) else 1.0)
 
 
 def test_concat_and_nearest_resample_sources(hip):
@@ -228,7 +250,7 @@ def test_fam_multiply_and_residual(hip):
         st = _state(c, c, 3, seed=c)
         ref = x1 + unet_torch.basic_conv(st, "L", (x1 * x2)[None], 3, elu=False)[0]
         got = gated_conv(_pack(st, [c]), [(_nhwc(x1), 0)], elu=False, mul=_nhwc(x2), residual=_nhwc(x1))
-        _close(got, ref, f"FAM C={c}")
+        _close(got, ref, f"FAM C={c}", scale=10.0 if c >= 128 else 5.0)
 
 
 def test_rgba_output_fill(hip):

@@ -64,3 +64,27 @@ def test_library_packers_equal_the_models():
         assert L.read_conv_pack_w16_host(cin, cout, wf.ctypes.data, wm.ctypes.data, b.ctypes.data) == 0
         np.testing.assert_allclose(a, pack_wino(wf, wm), rtol=1e-6, atol=1e-6)
         np.testing.assert_allclose(b, pack_w16(wf, wm), rtol=1e-6, atol=1e-6)
+
+
+def test_winograd_f4_model_and_packer():
+    """F(4x4,3x3): the kernel's lane maps (tests/wino4_ref.py) against conv2d, and the library's host packer against the model's."""
+    from read_amd import _lib
+    from tests.wino4_ref import pack_w4, wino4_conv_model
+    rng = np.random.default_rng(2)
+    cin, cout, H, W = 32, 40, 11, 40                      # two chunks, padded cout, ragged 8 x 32 blocks
+    wf = rng.standard_normal((cout, cin, 3, 3)).astype(np.float32) * 0.2
+    wm = rng.standard_normal((cout, cin, 3, 3)).astype(np.float32) * 0.2
+    x = rng.standard_normal((H, W, cin)).astype(np.float32)
+    packed = pack_w4(wf, wm)
+    f, m = wino4_conv_model(x, packed, cin, cout)
+    xt = torch.from_numpy(x).permute(2, 0, 1)[None]
+    rf = F.conv2d(xt, torch.from_numpy(wf), padding=1)[0].permute(1, 2, 0).numpy()
+    rm = F.conv2d(xt, torch.from_numpy(wm), padding=1)[0].permute(1, 2, 0).numpy()
+    np.testing.assert_allclose(f, rf, rtol=2e-4, atol=2e-4)
+    np.testing.assert_allclose(m, rm, rtol=2e-4, atol=2e-4)
+    L = _lib.lib()
+    n = L.read_conv_w4_floats(cin, cout)
+    assert n == packed.size
+    got = np.empty(n, np.float32)
+    assert L.read_conv_pack_w4_host(cin, cout, wf.ctypes.data, wm.ctypes.data, got.ctypes.data) == 0
+    np.testing.assert_allclose(got, packed, rtol=1e-6, atol=1e-7)

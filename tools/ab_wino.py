@@ -23,7 +23,7 @@ def main():
     ap.add_argument("--iters", type=int, default=20)
     ap.add_argument("--tune", default="")
     ap.add_argument("--out", default="gpurun_out/ab_wino.json")
-    ap.add_argument("--kernels", default="old,new")
+    ap.add_argument("--kernels", default="old,new,f4")
     a = ap.parse_args()
     if a.tune:
         for kv in a.tune.split(","):
@@ -40,7 +40,7 @@ def main():
         x = torch.randn(h, w, c, device="cuda")
         r = torch.randn(h, w, c, device="cuda")
         outs = {}
-        for name, cfg in (("old", old), ("v1", -4), ("new", -3)):
+        for name, cfg in (("old", old), ("v1", -4), ("new", -3), ("f4", -5)):
             if name not in a.kernels.split(","):
                 continue
             out = torch.empty(h, w, c, device="cuda")
@@ -55,13 +55,15 @@ def main():
             ms = e0.elapsed_time(e1) / a.iters
             fl = 4.0 * h * w * c * c * 9
             outs[name] = out
-            rec = {"shape": label, "kernel": name, "us": 1e3 * ms, "algorithmic_TF": fl / ms / 1e9, "executed_TF": fl / 2.25 / ms / 1e9,
-                   "frac_of_157.3": fl / 2.25 / ms / 1e9 / 157.3}
+            gain = 4.0 if name == "f4" else 2.25
+            rec = {"shape": label, "kernel": name, "us": 1e3 * ms, "algorithmic_TF": fl / ms / 1e9, "executed_TF": fl / gain / ms / 1e9,
+                   "frac_of_157.3": fl / gain / ms / 1e9 / 157.3}
             print(rec, flush=True)
             res.append(rec)
-        if "old" in outs and "new" in outs:
-            d = (outs["old"] - outs["new"]).abs().max().item()
-            print({"shape": label, "max_abs_diff_old_vs_new": d}, flush=True)
+        for other in ("new", "f4"):
+            if "old" in outs and other in outs:
+                d = (outs["old"] - outs[other]).abs().max().item()
+                print({"shape": label, f"max_abs_diff_old_vs_{other}": d}, flush=True)
     os.makedirs(os.path.dirname(os.path.abspath(a.out)), exist_ok=True)
     json.dump(res, open(a.out, "w"), indent=1)
 
