@@ -2095,20 +2095,31 @@ __global__ __launch_bounds__(256, 1) void gated_conv_wino4_kernel(const ConvKArg
         const bool quad_st = c0 + 3 < c_lim && (a.out_cstride & 3) == 0;
         const bool quad_ld = a.residual && c0 + 3 < a.Cout && (a.Cout & 3) == 0;
         f32x4 rv[2][4];
+        if (full) {                                                    // interior unit: no masks anywhere
 #pragma unroll
-        for (int py = 0; py < 2; ++py)
+            for (int py = 0; py < 2; ++py)
 #pragma unroll
-            for (int px = 0; px < 4; ++px) {
-                rv[py][px] = f32x4{0.f, 0.f, 0.f, 0.f};
-                const bool in = (oy + py < a.outH) & (ox + px < a.outW);
-                const float *rp = a.residual + ((size_t)(oy + py) * a.outW + ox + px) * a.Cout + c0;
-                if (in && quad_ld) rv[py][px] = *reinterpret_cast<const f32x4 *>(rp);
-                else if (in && a.residual) {
-#pragma unroll
-                    for (int k = 0; k < 4; ++k)
-                        if (c0 + k < a.Cout) rv[py][px][k] = rp[k];
+                for (int px = 0; px < 4; ++px) {
+                    rv[py][px] = f32x4{0.f, 0.f, 0.f, 0.f};
+                    if (a.residual)
+                        rv[py][px] = *reinterpret_cast<const f32x4 *>(a.residual + ((size_t)(oy + py) * a.outW + ox + px) * a.Cout + c0);
                 }
-            }
+        } else {
+#pragma unroll
+            for (int py = 0; py < 2; ++py)
+#pragma unroll
+                for (int px = 0; px < 4; ++px) {
+                    rv[py][px] = f32x4{0.f, 0.f, 0.f, 0.f};
+                    const bool in = (oy + py < a.outH) & (ox + px < a.outW);
+                    const float *rp = a.residual + ((size_t)(oy + py) * a.outW + ox + px) * a.Cout + c0;
+                    if (in && quad_ld) rv[py][px] = *reinterpret_cast<const f32x4 *>(rp);
+                    else if (in && a.residual) {
+#pragma unroll
+                        for (int k2 = 0; k2 < 4; ++k2)
+                            if (c0 + k2 < a.Cout) rv[py][px][k2] = rp[k2];
+                    }
+                }
+        }
         // rows: R[p][nu] from M[0..5][nu]; then columns: Y[p][0..3] from R[p][0..5]
         f32x4 Y[4][4];
         {
@@ -2469,11 +2480,11 @@ int g_conv_px = 1;         // read_tuning_set("conv_px", v): pixel-lane kernel f
                            // (64 / 128 accumulator registers per wave); 3 / 4 every layer it fits
 int g_kc32 = 1;            // 32-channel chunks for 1x1 layers whose sources are all multiples of 32 (read_tuning_set("conv_kc32", 0): 16)
 int g_use_wino = 1 << 30;  // read_tuning_set("conv_wino", max Cin): Winograd kernel for eligible 3x3 layers (0 = off)
-int g_w4 = 128;            // read_tuning_set("conv_w4", min Cin): layers with at least this many channels take the Winograd F(4x4,3x3)
+int g_w4 = 32;             // read_tuning_set("conv_w4", min Cin): layers with at least this many channels take the Winograd F(4x4,3x3)
                            // kernel when its weights were supplied (0 = never)
 int g_w16_abl = 0;         // read_tuning_set("conv_w16_abl", bits): attribution probes of the wave-autonomous kernel (results invalid)
-int g_w16 = 1;             // read_tuning_set("conv_w16", v): 0 the row-per-wave Winograd kernel, 1 the wave-autonomous kernel with the shared
-                           // input transform (default), 2 its first version (every wave transforms for itself)
+int g_w16 = 0;             // read_tuning_set("conv_w16", v): F(2x2,3x3) launches: 0 the row-per-wave kernel (default: measured equal or faster),
+                           // 1 the wave-autonomous kernel with the shared input transform, 2 its first version
 int g_stagger_ticks = 0;   // read_tuning_set("conv_stagger", ticks of 10 ns)
 int g_ablate = 0;          // read_tuning_set("conv_ablate", bits): attribution probe, results invalid; -DREAD_DEBUG_KNOBS builds only
 

@@ -31,7 +31,7 @@ struct LayerInfo {
     size_t raw_off, w_off, p_off;   // float offsets into the raw / packed blobs
     size_t wino_off;                // Winograd-transformed weights of 3x3/s1 layers with Cin % 16 == 0, else NO_WINO
     size_t w16_off;                 // ... in the order of the wave-autonomous Winograd kernel (read_conv_pack_w16_host)
-    size_t w4_off;                  // Winograd F(4x4,3x3) weights of the C -> C layers with C >= 128, else NO_WINO
+    size_t w4_off;                  // Winograd F(4x4,3x3) weights of the 3x3/s1 layers with Cin >= 32 and Cout % 32 == 0, else NO_WINO
 };
 constexpr size_t NO_WINO = ~(size_t)0;
 
@@ -82,7 +82,7 @@ const Arch &arch()
                 a.packed_floats += read_conv_wino_floats(cin, cout);
                 L.w16_off = a.packed_floats;
                 a.packed_floats += read_conv_wino_floats(cin, cout);
-                if (cin >= 128 && cout % 32 == 0) {
+                if (cin >= 32 && cout % 32 == 0) {
                     L.w4_off = a.packed_floats;
                     a.packed_floats += read_conv_w4_floats(cin, cout);
                 }
