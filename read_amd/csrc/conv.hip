@@ -659,6 +659,16 @@ __device__ __forceinline__ float4 load_f4(const char *sbase, unsigned voff)
     return *reinterpret_cast<const float4 *>(sbase + voff);
 }
 
+// The same with the SCALAR base made opaque instead of the lane offset: no v_mov per load (a VALU instruction behind an fp32 MFMA
+// costs 12 cycles on a SIMD that runs one wave, tools/issue_probe.py); hipcc cannot re-associate base + k * const into a 64-bit VGPR.
+__device__ __forceinline__ float4 load_f4s(const char *sbase, unsigned voff)
+{
+    typedef __attribute__((address_space(1))) const char *gptr;          // keep the address space: a generic pointer would be a flat load
+    gptr g = (gptr)sbase;
+    asm volatile("" : "+s"(g));
+    return *reinterpret_cast<__attribute__((address_space(1))) const float4 *>(g + voff);
+}
+
 template <bool TRACE, bool MUL>
 __global__ __launch_bounds__(256, 2) void gated_conv_wino_kernel(const ConvKArgs a)
 {
@@ -1982,6 +1992,15 @@ __global__ __launch_bounds__(256, 1) void gated_conv_wino4_kernel(const ConvKArg
     const unsigned wvoff = lane * 16;
     float4 Wq[12];
     auto wload1 = [&](int slot, int chunk, int fq) { Wq[slot] = load_f4(wbase + (size_t)(chunk * 36 + fq) * 1024, wvoff); };
+    // two consecutive frequencies with ONE opaque lane offset (one v_mov instead of two: a lone VALU instruction behind an fp32
+    // MFMA costs 12 cycles on a SIMD that runs a single wave, tools/issue_probe.py)
+    auto wload2 = [&](int slot, int chunk, int fq) {
+        const char *b = wbase + (size_t)(chunk * 36 + fq) * 1024;
+        unsigned vo = wvoff;
+        asm volatile("" : "+v"(vo));
+        Wq[slot] = *reinterpret_cast<const float4 *>(b + vo);
+        Wq[slot + 1] = *reinterpret_cast<const float4 *>(b + vo + 1024);
+    };
     // ---- B operand: Vbuf[frequency][tile t16][slot]; ring of 6 frequencies, fetched 4 ahead
     const int t16 = lane & 15, kl = lane >> 4;
     const int vlane = t16 * 16 + 4 * (kl ^ ((t16 >> 1) & 3));
@@ -2049,10 +2068,10 @@ __global__ __launch_bounds__(256, 1) void gated_conv_wino4_kernel(const ConvKArg
                     // ---- shadow items
                     const int mm = e * 2 + sidx;                                     // position inside this pair's 8 MFMAs
                     if (mm < 2 && 2 * pr + 4 + mm < 36) bload1((2 * pr + 4 + mm) % 6, v_cur, 2 * pr + 4 + mm);   // B operands 4 ahead
-                    if (mm >= 2 && mm < 4) {                                         // weights 10 frequencies ahead
-                        const int wf = 2 * pr + 10 + (mm - 2);
-                        if (wf < 36) wload1(wf % 12, chunk, wf);
-                        else wload1(wf % 12, nchunk, wf - 36);
+                    if (mm == 2) {                                                   // weights 10 frequencies ahead, two at a time
+                        const int wf = 2 * pr + 10;
+                        if (wf < 36) wload2(wf % 12, chunk, wf);
+                        else wload2(wf % 12, nchunk, wf - 36);
                     }
                     // the next chunk's transform: reads first (one per MFMA), arithmetic, stores; then the raw patch traffic
                     if (m < 36) t_step(traw, v_nxt, m);
