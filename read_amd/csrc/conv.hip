@@ -659,16 +659,6 @@ __device__ __forceinline__ float4 load_f4(const char *sbase, unsigned voff)
     return *reinterpret_cast<const float4 *>(sbase + voff);
 }
 
-// The same with the SCALAR base made opaque instead of the lane offset: no v_mov per load (a VALU instruction behind an fp32 MFMA
-// costs 12 cycles on a SIMD that runs one wave, tools/issue_probe.py); hipcc cannot re-associate base + k * const into a 64-bit VGPR.
-__device__ __forceinline__ float4 load_f4s(const char *sbase, unsigned voff)
-{
-    typedef __attribute__((address_space(1))) const char *gptr;          // keep the address space: a generic pointer would be a flat load
-    gptr g = (gptr)sbase;
-    asm volatile("" : "+s"(g));
-    return *reinterpret_cast<__attribute__((address_space(1))) const float4 *>(g + voff);
-}
-
 template <bool TRACE, bool MUL>
 __global__ __launch_bounds__(256, 2) void gated_conv_wino_kernel(const ConvKArgs a)
 {
