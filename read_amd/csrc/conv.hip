@@ -3049,7 +3049,11 @@ int launch_gated_conv(const read_conv_desc *d, hipStream_t stream)
     }
     // the wave-autonomous Winograd kernel (same units, same grid) whenever its weight order was supplied; linear launches
     // (training path) stay on the row-per-wave kernel, which carries the plain-convolution epilogue
-    if (c.wino && !d->linear && !a.trace && d->wpacked_w16 && (d->config == -3 || d->config == -4 || (d->config < 0 && g_w16))) {
+    // ... and, by default, for layers whose last channel group is mostly padding (the 32 -> 3 output layer): its waves without a real
+    // channel skip their MFMAs, the row-per-wave kernel pays for all 32 padded channels
+    const bool mostly_padding = d->Cout <= 8;
+    if (c.wino && !d->linear && !a.trace && d->wpacked_w16 &&
+        (d->config == -3 || d->config == -4 || (d->config < 0 && (g_w16 || mostly_padding)))) {
         READ_CHECK_ARG((uintptr_t)d->wpacked_w16 % 16 == 0, "read_gated_conv_forward: wpacked_w16 misaligned");
         const bool v1 = g_w16 == 2 || d->config == -4;
         fn = v1 ? (d->mul ? gated_conv_wino16_kernel<true> : gated_conv_wino16_kernel<false>)

@@ -161,26 +161,30 @@ def test_pipelined_frames_through_the_rccl_exchange(hip):
         port = sk.getsockname()[1]
     dist.init_process_group("nccl", init_method=f"tcp://127.0.0.1:{port}", rank=0, world_size=1,
                             device_id=torch.device("cuda", 0))
+    def render_into(k, out):
+        pipe.render_total(total[k], out=out)
+        return pipe.frame_done
+
+    results = {}
     try:
-        ex = sweep.FrameExchange((H, W, 4), torch.device("cuda", 0), torch.float32, 'all', force=True)
-        assert ex.mode == 'all' and ex.world == 1
-
-        def render_into(k, out):
-            pipe.render_total(total[k], out=out)
-            return pipe.frame_done
-
-        got = []
-        for i in range(n):
-            sweep.run_steps(render_into, ex, i, 1, n)
-            if i > 0:
-                got.append(ex.frames(i - 1)[0].clone())
-        got.append(ex.frames(n - 1)[0].clone())
-        ex.drain()
-        torch.cuda.synchronize()
+        for mode in ('all', 'root'):                       # all-gather to every rank / gather to rank 0 (the viewer process)
+            ex = sweep.FrameExchange((H, W, 4), torch.device("cuda", 0), torch.float32, mode, force=True)
+            assert ex.mode == mode and ex.world == 1
+            got = []
+            for i in range(n):
+                sweep.run_steps(render_into, ex, i, 1, n)
+                if i > 0:
+                    got.append(ex.frames(i - 1)[0].clone())
+            got.append(ex.frames(n - 1)[0].clone())
+            ex.drain()
+            torch.cuda.synchronize()
+            results[mode] = got
+        assert sweep.gather_objects(True) == [True]        # bench.py's verified_ranks at world size 1 with a live process group
     finally:
         dist.destroy_process_group()
-    for i, (g, w) in enumerate(zip(got, want)):
-        assert torch.equal(g, w), f"exchanged frame {i} differs"
+    for mode, got in results.items():
+        for i, (g, w) in enumerate(zip(got, want)):
+            assert torch.equal(g, w), f"exchange mode {mode!r}: frame {i} differs"
 
 
 def test_winograd_and_direct_conv_paths_agree(hip):
