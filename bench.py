@@ -95,7 +95,7 @@ def profiled_traffic():
     """HBM bytes per launch of the dominant kernel family from the committed rocprofv3 PMC passes (separate FETCH_SIZE /
     WRITE_SIZE runs of this same command, FETCH_SIZE x2 as MI355X_MICROARCH.md prescribes for gfx950, factor re-derived
     there from a kernel of known byte count).  Launch-weighted mean over every launch of the 3x3/s1 kernels."""
-    for name in ("r2_traffic.json", "r1_traffic.json"):
+    for name in ("r3_traffic.json", "r2_traffic.json", "r1_traffic.json"):
         path = os.path.join(ROOT, "profiles", name)
         try:
             ks = json.load(open(path))["kernels"]
@@ -103,7 +103,7 @@ def profiled_traffic():
             continue
         n = tot = 0
         for kname, v in ks.items():
-            if kname.startswith("gated_conv_wino_kernel") or (kname.startswith("gated_conv") and "<3, 1, 16" in kname):
+            if kname.startswith("gated_conv_wino") or (kname.startswith("gated_conv") and "<3, 1, 16" in kname):
                 n += v["launches"]
                 tot += (v["read_bytes"] + v["write_bytes"]) * v["launches"]
         if n:

@@ -7,7 +7,8 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libreadhip.so")
+# READ_HIP_DEBUG=1: the -DREAD_DEBUG_KNOBS build (attribution probes for tools/; python -m read_amd.build --debug)
+LIB_PATH = os.path.join(_HERE, "libreadhip_debug.so" if os.environ.get("READ_HIP_DEBUG") else "libreadhip.so")
 
 READ_MAX_LEVELS = 5
 READ_CONV_MAX_SRC = 4

@@ -1,6 +1,9 @@
 """Build libreadhip.so (the C-ABI HIP library) in-tree for gfx950.
 
-    python -m read_amd.build [--force]
+    python -m read_amd.build [--force] [--debug]
+
+--debug builds read_amd/libreadhip_debug.so with -DREAD_DEBUG_KNOBS: the same library plus the attribution probes whose results
+are invalid (read_tuning_set "conv_ablate", "conv_abl").  Only tools/ load it (READ_HIP_DEBUG=1); it is never the product.
 
 hipcc cross-compiles without a GPU; the resulting read_amd/libreadhip.so travels with the
 tree to the GPU box (it is git-ignored, never pip-installed).
@@ -19,8 +22,6 @@ SOURCES = ["api_common.cpp", "splat.hip", "gather.hip", "conv.hip", "train.hip",
 ARCH = "gfx950"
 FLAGS = ["-O3", "-std=c++17", "-fPIC", f"--offload-arch={ARCH}", "-x", "hip",
          "-I", os.path.join(ROOT, "include"), "-I", CSRC, "-Wall", "-Wno-unused-function"]
-if os.environ.get("READ_DEBUG_KNOBS"):      # attribution probes whose results are invalid (conv_ablate, splat_probe): never shipped
-    FLAGS.append("-DREAD_DEBUG_KNOBS")
 # the rasteriser's pixel assignment must be bit-exact fp32: no a*b+c contraction
 # gather / train: fp32 atomicAdd as the hardware global_atomic_add_f32 (the default lowers it to a compare-and-swap loop)
 PER_FILE = {"splat.hip": ["-ffp-contract=off"], "conv.hip": ["-fno-slp-vectorize"], "gather.hip": ["-munsafe-fp-atomics"],
@@ -41,7 +42,10 @@ def _stale(target, deps):
     return any(os.path.getmtime(d) > t for d in deps)
 
 
-def build(force: bool = False, verbose: bool = False) -> str:
+def build(force: bool = False, verbose: bool = False, debug: bool = False) -> str:
+    OBJ = os.path.join(HERE, "csrc", "_obj_debug" if debug else "_obj")
+    LIB = os.path.join(HERE, "libreadhip_debug.so" if debug else "libreadhip.so")
+    FLAGS = globals()["FLAGS"] + (["-DREAD_DEBUG_KNOBS"] if debug else [])
     os.makedirs(OBJ, exist_ok=True)
     headers = [os.path.join(ROOT, "include", "read_hip.h"), os.path.join(CSRC, "common.h")]
     hipcc = _hipcc()
@@ -66,4 +70,4 @@ def build(force: bool = False, verbose: bool = False) -> str:
 
 
 if __name__ == "__main__":
-    print(build(force="--force" in sys.argv, verbose=True))
+    print(build(force="--force" in sys.argv, verbose=True, debug="--debug" in sys.argv))

@@ -53,7 +53,7 @@ void conv_set_ablate(int bits);
 void conv_set_wino(int max_cin);
 void conv_set_kc32(int v);
 void conv_set_w16(int v);
-void conv_set_w16_abl(int v);
+void conv_set_abl(int v);
 void conv_set_w4(int v);
 void conv_set_px(int v);
 void conv_set_wino_wgs(int v);
@@ -79,7 +79,7 @@ static const char *const k_tuning_keys[] = {"splat_mode", "splat_stats", "splat_
                                             "splat_cells_sub", "splat_seeds", "splat_items", "splat_strips", "splat_wgs", "splat_zl2", "splat_lds", "splat_bins", "splat_kslot", "unet_streams", "unet_aff_split", "conv_kc32", "conv_px", "conv_wino_wgs",
                                             "conv_wino", "conv_w16", "conv_w4", "conv_stagger", "conv_wave",
 #ifdef READ_DEBUG_KNOBS
-                                            "conv_ablate",
+                                            "conv_ablate", "conv_abl",
 #endif
                                             nullptr};
 
@@ -111,7 +111,6 @@ extern "C" int read_tuning_set(const char *key, int value)
     if (!strcmp(key, "conv_wino_wgs")) { readhip::conv_set_wino_wgs(value); return READ_OK; } // persistent Winograd workgroups per CU: 1 or 2
     if (!strcmp(key, "conv_px")) { readhip::conv_set_px(value); return READ_OK; }             // pixel-lane kernel for 1x1 layers
     if (!strcmp(key, "conv_kc32")) { readhip::conv_set_kc32(value); return READ_OK; }
-    if (!strcmp(key, "conv_w16_abl")) { readhip::conv_set_w16_abl(value); return READ_OK; }   // attribution probes (results invalid)
     if (!strcmp(key, "conv_w4")) { readhip::conv_set_w4(value); return READ_OK; }             // min Cin on the Winograd F(4x4,3x3) kernel (0 = off)
     if (!strcmp(key, "conv_w16")) { readhip::conv_set_w16(value); return READ_OK; }           // wave-autonomous Winograd kernel (0 = row-per-wave)
     if (!strcmp(key, "conv_wino")) { readhip::conv_set_wino(value); return READ_OK; }         // largest Cin on the Winograd kernel (0 = off)
@@ -119,6 +118,7 @@ extern "C" int read_tuning_set(const char *key, int value)
     if (!strcmp(key, "conv_wave")) { readhip::conv_set_prefer_wave(value != 0); return READ_OK; }
 #ifdef READ_DEBUG_KNOBS
     if (!strcmp(key, "conv_ablate")) { readhip::conv_set_ablate(value); return READ_OK; }
+    if (!strcmp(key, "conv_abl")) { readhip::conv_set_abl(value); return READ_OK; }          // probes of the 16x16x4 Winograd kernels
 #endif
     readhip::set_error("read_tuning_set: unknown key '%s'", key);
     return READ_EINVAL;

@@ -1039,396 +1039,34 @@ __global__ __launch_bounds__(256, 2) void gated_conv_wino_kernel(const ConvKArgs
     }
 }
 
-// ------------------------------------------------------------------------------------------
-// Winograd F(2x2,3x3), wave-autonomous form on v_mfma_f32_16x16x4_f32 (round 3; index maps mirrored in tests/wino16_ref.py).
-//
-// The kernel above gives a wave one frequency ROW of a 32-tile x 32-channel unit, so the output transform
-// Y = A^T M A needs the other three waves: two passes through 32 KiB of LDS and three barriers per unit — at C = 32 / 64 as
-// long as the unit's MFMA loop (MFMA pipe busy 50-55 %, profiles/r2_pmc_mfma_busy.md).  Here the unit is cut the other way:
-//   * wave w of the workgroup owns output channels 8w .. 8w+7 of the 32-channel group and ALL 16 frequencies of all 32 tiles:
-//     the MFMA is 16x16x4 with  A operand = transformed weights, rows 0..7 = conv_f, rows 8..15 = conv_m of those 8 channels
-//                               B operand = transformed input of 16 tiles (block b = tile rows 2b, 2b+1; both blocks share A)
-//     -> 16 frequencies x 2 blocks x 4 registers = 128 accumulators; a lane ends up with every frequency of its
-//     (tile, 4 channels), so A^T M A is 24 lane-local additions per value: no LDS, no barrier, no other wave;
-//   * conv_f sits in lanes 0..31 and conv_m of the same (tile, channels) in lane + 32: one v_permlane32_swap per register pair
-//     puts f and m of block 0 into the lower and of block 1 into the upper half-wave; the gate is then lane-local and a lane
-//     loads / stores 4 consecutive channels of a pixel (128-bit residual loads and stores);
-//   * input patches are shared by the four waves exactly as before (10 x 18 pixels x 16 channels per chunk, three LDS
-//     buffers, fetched two chunks ahead; rows padded to 384 floats: the B-operand ds_read_b128 of lanes (tile, 4 cin) are
-//     bank-conflict free); weights come straight from L2, [group][wave][chunk][row a][j][lane][4 k-steps]: one
-//     global_load_dwordx4 per frequency and chunk;
-//   * a chunk = 8 groups (frequency row a, block b) of 16 MFMAs; every other instruction is an item pinned in the shadow of one
-//     MFMA of the group BEFORE the one that consumes it (LDS reads of the two patch rows, the row / column combinations of
-//     B^T d B in place, the next row's weights, patch staging), across chunk and unit boundaries;
-//   * no cross-wave traffic is left except the patch barrier per chunk; two workgroups per CU: the epilogue of one (VALU +
-//     memory) runs beside the MFMA stream of the other on the same SIMDs.
-struct Wino16Geom {
-    static constexpr int TR = 4, TC = 8;                       // tiles per block (rows, cols): two 16-tile MFMA blocks
-    static constexpr int IH = 2 * TR + 2, IW = 2 * TC + 2;     // 10 x 18 input pixels
-    static constexpr int KC = 16, PS = KC + 4;                 // floats per staged pixel
-    static constexpr int RS = IW * PS + 24;                    // floats per patch row (384): conflict-free B-operand reads
-    static constexpr int BUF = IH * RS;
-    static constexpr int NE = IH * IW * (KC / 4), NI = (NE + 255) / 256;
-    static constexpr int LDS_FLOATS = 3 * BUF + 4;             // three patch buffers + a dummy float4 slot
-};
-
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 
-// ABL (attribution probes, results invalid, selected only by read_tuning_set("conv_w16_abl")): 1 no epilogue, 2 weights loaded
-// once, 4 B operands formed once (no LDS reads / transforms in the loop), 8 no patch staging, 16 no barrier
-template <bool MUL, int ABL = 0>
-__global__ __launch_bounds__(256, 2) void gated_conv_wino16_kernel(const ConvKArgs a)
-{
-    using WG = Wino16Geom;
-    __shared__ __attribute__((aligned(16))) float lds[WG::LDS_FLOATS];
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);           // channel octet of this wave
-    const SrcDev s = a.src[0];
-    const int groups = a.CoutPad >> 5, G = gridDim.x;                  // G % groups == 0: g is fixed per workgroup
-    const int g = blockIdx.x % groups;
-    const int n = a.nchunks;
-
-    // ---- units: u = blockIdx.x + k G  ->  tile block u / groups = (by, bx), advanced by (wino_dby, wino_dbx) per step
-    int by = (blockIdx.x / groups) / a.tiles_x, bx = (blockIdx.x / groups) % a.tiles_x;      // running unit
-    int pby = by, pbx = bx, pu = blockIdx.x, pchunk = 0;                                     // prefetch cursor
-    auto step_tile = [&](int &ty_, int &tx_) {
-        ty_ += a.wino_dby;
-        tx_ += a.wino_dbx;
-        if (tx_ >= a.tiles_x) {
-            tx_ -= a.tiles_x;
-            ++ty_;
-        }
-    };
-
-    // ---- input patch staging (as in gated_conv_wino_kernel; LDS rows padded to RS floats)
-    int loff[WG::NI];
-    unsigned rel[WG::NI], aoff[WG::NI];
-    unsigned okmask = 0;
-#pragma unroll
-    for (int i = 0; i < WG::NI; ++i) {
-        const int e = tid + i * 256, q = e % 4, pix = e / 4;
-        loff[i] = e < WG::NE ? (pix / WG::IW) * WG::RS + (pix % WG::IW) * WG::PS + 4 * q : -1;
-        rel[i] = (unsigned)(((pix / WG::IW) * s.W + pix % WG::IW) * s.C + 4 * q) * 4u;
-    }
-    const unsigned safe_rel = (unsigned)((s.W + 1) * s.C) * 4u;
-    const char *pbase = nullptr;
-    long pdelta = 0;
-    if constexpr (MUL) pdelta = reinterpret_cast<const char *>(a.mul) - reinterpret_cast<const char *>(s.p);
-    auto set_patch = [&]() {
-        const int y0 = pby * (2 * WG::TR) - 1, x0 = pbx * (2 * WG::TC) - 1;
-        pbase = reinterpret_cast<const char *>(s.p) + ((long)y0 * s.W + x0) * (long)(s.C * 4);
-        okmask = 0;
-#pragma unroll
-        for (int i = 0; i < WG::NI; ++i) {
-            const int e = tid + i * 256, pix = e / 4, ppy = pix / WG::IW, ppx = pix % WG::IW;
-            const bool ok = (e < WG::NE) & (ppy >= -y0) & (ppy < a.inH - y0) & (ppx >= -x0) & (ppx < a.inW - x0);
-            okmask |= (ok ? 1u : 0u) << i;
-            aoff[i] = ok ? rel[i] : safe_rel;
-        }
-    };
-    auto advance = [&]() {
-        if (++pchunk == n) {
-            pchunk = 0;
-            if (pu + G < a.n_units) {
-                pu += G;
-                step_tile(pby, pbx);
-            }
-            set_patch();
-        }
-    };
-    float4 st[WG::NI], stm[MUL ? WG::NI : 1];
-    auto gload1 = [&](int i) {
-        st[i] = load_f4(pbase + pchunk * (WG::KC * 4), aoff[i]);
-        if constexpr (MUL) stm[i] = load_f4(pbase + pdelta + pchunk * (WG::KC * 4), aoff[i]);
-    };
-    auto staged = [&](int i, unsigned mask, const float4 &x, const float4 *y) {
-        float4 v = x;
-        if constexpr (MUL) v = make_float4(x.x * y[i].x, x.y * y[i].y, x.z * y[i].z, x.w * y[i].w);
-        return ((mask >> i) & 1u) ? v : make_float4(0.f, 0.f, 0.f, 0.f);
-    };
-    auto lwrite1 = [&](int i, int obuf) {
-        const float4 v = staged(i, okmask, st[i], stm);
-        *reinterpret_cast<float4 *>(lds + (loff[i] >= 0 ? obuf + loff[i] : 3 * WG::BUF)) = v;
-    };
-
-    // ---- B operand (transformed input): lane (t = tile of the block, kl) reads the float4 of input channels 4 kl .. 4 kl + 3
-    // (= the lane's k of MFMA steps 0..3) of patch pixel (2 (2b + t/8) + r, 2 (t%8) + c)
-    const int t16 = lane & 15, kl = lane >> 4;
-    const int lbase = (2 * (t16 >> 3)) * WG::RS + (2 * (t16 & 7)) * WG::PS + 4 * kl;
-    // frequency row a: T = d[ra] + sgn d[rb]   (B^T rows: d0 - d2, d1 + d2, d2 - d1, d1 - d3)
-    float4 V[2][4], dB[4];                                             // V[x]: B operands of the running / the next group
-    auto rd1 = [&](const float *buf, int vb, int na, int nb, int r) {  // LDS read r = 2c + {0: row ra, 1: row rb}
-        const int c = r >> 1;
-        const int ra = na == 0 ? 0 : na == 2 ? 2 : 1, rb = na == 0 ? 2 : na == 1 ? 2 : na == 2 ? 1 : 3;
-        const float *p = buf + lbase + (4 * nb) * WG::RS + c * WG::PS;
-        if (r & 1) dB[c] = *reinterpret_cast<const float4 *>(p + rb * WG::RS);
-        else V[vb][c] = *reinterpret_cast<const float4 *>(p + ra * WG::RS);
-    };
-    auto tt1 = [&](int vb, int na, int c) {                            // T[c] in place of d[ra][c]
-        float4 &x = V[vb][c];
-        const float4 y = dB[c];
-        if (na == 1) x = make_float4(x.x + y.x, x.y + y.y, x.z + y.z, x.w + y.w);
-        else x = make_float4(x.x - y.x, x.y - y.y, x.z - y.z, x.w - y.w);
-    };
-    // column combinations in place: V0 = T0 - T2, V3 = T1 - T3, (V1, V2) = (T1 + T2, T2 - T1)
-    auto vv1 = [&](int vb, int step) {
-        float4(&T)[4] = V[vb];
-        auto sub = [](const float4 &x, const float4 &y) { return make_float4(x.x - y.x, x.y - y.y, x.z - y.z, x.w - y.w); };
-        auto add = [](const float4 &x, const float4 &y) { return make_float4(x.x + y.x, x.y + y.y, x.z + y.z, x.w + y.w); };
-        if (step == 0) T[0] = sub(T[0], T[2]);
-        else if (step == 1) T[3] = sub(T[1], T[3]);
-        else if (step == 2) dB[0] = add(T[1], T[2]);                   // dB[0] is free by now: temporary for V1
-        else {
-            T[2] = sub(T[2], T[1]);
-            T[1] = dB[0];
-        }
-    };
-
-    // ---- A operand (weights): wave (g, wv): [chunk][a][j][lane][4]; one dwordx4 per (chunk, a, j) and lane
-    const char *const wbase = reinterpret_cast<const char *>(a.wp_w16) + ((size_t)(g * 4 + wv) * n) * (16 * 1024);
-    const unsigned wvoff = lane * 16;
-    float4 Wr[2][4];                                                   // ring by row parity
-    auto wload1 = [&](int slot, int j, int chunk, int row) {
-        Wr[slot][j] = load_f4(wbase + (size_t)((chunk * 4 + row) * 4 + j) * 1024, wvoff);
-    };
-
-    f32x4 acc[2][4][4];                                                // [block][a][j], written (C = 0) by the first chunk of a unit
-
-    // ---- prologue: two chunks of the stream into LDS, the weights of (chunk 0, row 0), B operands of group (0, 0, 0)
-    set_patch();
-    {
-        float4 st1[WG::NI], stm1[MUL ? WG::NI : 1];
-#pragma unroll
-        for (int i = 0; i < WG::NI; ++i) gload1(i);
-        const unsigned ok0 = okmask;
-        advance();
-#pragma unroll
-        for (int i = 0; i < WG::NI; ++i) {
-            st1[i] = load_f4(pbase + pchunk * (WG::KC * 4), aoff[i]);
-            if constexpr (MUL) stm1[i] = load_f4(pbase + pdelta + pchunk * (WG::KC * 4), aoff[i]);
-        }
-#pragma unroll
-        for (int j = 0; j < 4; ++j) wload1(0, j, 0, 0);
-#pragma unroll
-        for (int i = 0; i < WG::NI; ++i) {
-            const float4 v0 = staged(i, ok0, st[i], stm);
-            const float4 v1 = staged(i, okmask, st1[i], stm1);
-            if (loff[i] >= 0) {
-                *reinterpret_cast<float4 *>(lds + loff[i]) = v0;
-                *reinterpret_cast<float4 *>(lds + WG::BUF + loff[i]) = v1;
-            }
-        }
-        advance();
-    }
-    __syncthreads();
-#pragma unroll
-    for (int r = 0; r < 8; ++r) rd1(lds, 0, 0, 0, r);
-#pragma unroll
-    for (int c = 0; c < 4; ++c) tt1(0, 0, c);
-#pragma unroll
-    for (int st_ = 0; st_ < 4; ++st_) vv1(0, st_);
-
-    int o_cur = 0, o_nxt = WG::BUF, o_nn = 2 * WG::BUF;
-
-    auto chunk_body = [&](auto first_tag, int chunk) {
-        constexpr bool FIRST = decltype(first_tag)::value;
-        const float *buf = lds + o_cur, *bufn = lds + o_nxt;
-        int cnext = chunk + 1;                                         // chunk of the row after (chunk, 3): wraps into the next unit
-        cnext = cnext == n ? 0 : cnext;
-#pragma unroll
-        for (int ab = 0; ab < 8; ++ab) {
-            const int ra_ = ab >> 1, b = ab & 1;                      // this group: frequency row ra_, block b
-            const int vc = ab & 1, vn = vc ^ 1;                       // V slots: running / next group
-            const int na = ab == 7 ? 0 : (ab + 1) >> 1, nb = (ab + 1) & 1;
-            const float *tb = ab == 7 ? bufn : buf;                   // the next group's patch buffer
-            const int wc = ra_ & 1, wn = wc ^ 1;                      // weight slots: this row / next row
-            __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-            for (int e = 0; e < 4; ++e)
-#pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    const int m = e * 4 + j;
-                    const float4 wv4 = Wr[(ABL & 2) ? 0 : wc][j], vv4 = V[(ABL & 4) ? 0 : vc][j];
-                    const float we = e == 0 ? wv4.x : e == 1 ? wv4.y : e == 2 ? wv4.z : wv4.w;
-                    const float ve = e == 0 ? vv4.x : e == 1 ? vv4.y : e == 2 ? vv4.z : vv4.w;
-                    if (FIRST && e == 0) {
-                        const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
-                        acc[b][ra_][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(we, ve, zero, 0, 0, 0);
-                    } else
-                        acc[b][ra_][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(we, ve, acc[b][ra_][j], 0, 0, 0);
-                    // ---- items in the shadow of MFMA m: everything the NEXT group needs
-                    if (!(ABL & 4)) {
-                        if (m < 8) rd1(tb, vn, na, nb, m);
-                        if (m >= 8 && m < 12) tt1(vn, na, m - 8);
-                        if (m >= 12) vv1(vn, m - 12);
-                    }
-                    if (m < 4 && b == 0 && !(ABL & 2)) {                             // weights of the NEXT row: two groups
-                        if (ra_ < 3) wload1(wn, m, chunk, ra_ + 1);                  // (32 MFMAs) ahead of their first use
-                        else wload1(wn, m, cnext, 0);
-                    }
-                    if (!(ABL & 8)) {
-                        if (ab == 0 && m >= 4 && m - 4 < WG::NI) gload1(m - 4);      // patch at the cursor -> registers
-                        if (ab == 4 && m >= 4 && m - 4 < WG::NI) lwrite1(m - 4, o_nn);   // ... -> LDS, half a chunk later
-                    }
-                    __builtin_amdgcn_sched_barrier(0);
-                }
-        }
-        advance();
-        if (!(ABL & 16)) __syncthreads();
-        const int o = o_cur;
-        o_cur = o_nxt;
-        o_nxt = o_nn;
-        o_nn = o;
-    };
-
-    // A wave whose 8 channels are all padding (Cout = 3: the output layer) only helps with the patch staging: the unit then
-    // costs one wave's MFMAs instead of four
-    if (g * 32 + wv * 8 >= a.Cout) {
-        for (int u = blockIdx.x; u < a.n_units; u += G)
-            for (int chunk = 0; chunk < n; ++chunk) {
-#pragma unroll
-                for (int i = 0; i < WG::NI; ++i) gload1(i);
-#pragma unroll
-                for (int i = 0; i < WG::NI; ++i) lwrite1(i, o_nn);
-                advance();
-                __syncthreads();
-                const int o = o_cur;
-                o_cur = o_nxt;
-                o_nxt = o_nn;
-                o_nn = o;
-            }
-        return;
-    }
-    for (int u = blockIdx.x; u < a.n_units; u += G) {
-        chunk_body(std::true_type{}, 0);
-        for (int chunk = 1; chunk < n; ++chunk) chunk_body(std::false_type{}, chunk);
-
-        if (ABL & 1) {                                                 // keep the accumulators live with one store per wave
-            f32x4 ssum = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-            for (int b = 0; b < 2; ++b)
-#pragma unroll
-                for (int aa = 0; aa < 4; ++aa)
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) ssum += acc[b][aa][j];
-            if (ssum[0] + ssum[1] + ssum[2] + ssum[3] == 12345.678f) a.out[lane] = ssum[0];
-            step_tile(by, bx);
-            continue;
-        }
-        // ================= unit epilogue (lane-local) =================
-        // D layout of v_mfma_f32_16x16x4_f32: lane (t = lane & 15, q = lane >> 4), register r = MFMA row 4q + r:
-        // q = 0, 1 -> conv_f of channels 4q + r; q = 2, 3 -> conv_m of channels 4 (q - 2) + r; column = tile t of block b.
-        __builtin_amdgcn_s_setprio(1);
-        const int cq = (lane >> 4) & 1, eb = lane >> 5;                                    // channel quad, block finished by this lane
-        const int c0 = g * 32 + wv * 8 + 4 * cq;
-        const int oy = by * (2 * WG::TR) + 2 * (2 * eb + (t16 >> 3)), ox = bx * (2 * WG::TC) + 2 * (t16 & 7);
-        const int c_lim = a.fill_pad ? a.out_cstride : a.Cout;
-        const bool quad_st = c0 + 3 < c_lim && (a.out_cstride & 3) == 0;
-        const bool quad_ld = a.residual && c0 + 3 < a.Cout && (a.Cout & 3) == 0;
-        const f32x4 bf = *reinterpret_cast<const f32x4 *>(a.params + c0);
-        const f32x4 bm = *reinterpret_cast<const f32x4 *>(a.params + a.CoutPad + c0);
-        const f32x4 sc = *reinterpret_cast<const f32x4 *>(a.params + 2 * a.CoutPad + c0);
-        const f32x4 sh = *reinterpret_cast<const f32x4 *>(a.params + 3 * a.CoutPad + c0);
-        bool pix_in[2][2];
-        f32x4 rv[2][2];
-#pragma unroll
-        for (int pa = 0; pa < 2; ++pa)
-#pragma unroll
-            for (int pb = 0; pb < 2; ++pb) {
-                pix_in[pa][pb] = (oy + pa < a.outH) & (ox + pb < a.outW);
-                rv[pa][pb] = f32x4{0.f, 0.f, 0.f, 0.f};
-                const float *rp = a.residual + ((size_t)(oy + pa) * a.outW + ox + pb) * a.Cout + c0;
-                if (pix_in[pa][pb] && quad_ld) rv[pa][pb] = *reinterpret_cast<const f32x4 *>(rp);
-                else if (pix_in[pa][pb] && a.residual) {
-#pragma unroll
-                    for (int k = 0; k < 4; ++k)
-                        if (c0 + k < a.Cout) rv[pa][pb][k] = rp[k];
-                }
-            }
-        // Y[pa][pb] = sum_a sum_j A^T[pa][a] M[a][j] A^T[pb][j],  A^T = [1 1 1 0; 0 1 -1 -1]
-        f32x4 Yf[2][2], Ym[2][2];
-#pragma unroll
-        for (int pa = 0; pa < 2; ++pa)
-#pragma unroll
-            for (int pb = 0; pb < 2; ++pb) {
-                f32x4 yb[2];
-#pragma unroll
-                for (int b = 0; b < 2; ++b) {
-                    f32x4 rr[3];                                       // rows a = pa, pa + 1, pa + 2 combined over j
-#pragma unroll
-                    for (int k = 0; k < 3; ++k) {
-                        const int ar = pa + k;
-                        rr[k] = pb == 0 ? acc[b][ar][0] + acc[b][ar][1] + acc[b][ar][2] : acc[b][ar][1] - acc[b][ar][2] - acc[b][ar][3];
-                    }
-                    yb[b] = pa == 0 ? rr[0] + rr[1] + rr[2] : rr[0] - rr[1] - rr[2];
-                }
-                // lanes 0..31 hold conv_f, lanes 32..63 conv_m of (block 0 | block 1): after the half exchange the lower
-                // half-wave owns block 0 and the upper half block 1, f in one register and m in the other
-                // (whole-vector bit casts: with __builtin_bit_cast of single vector ELEMENTS this hipcc folds the four swaps
-                //  into one — seen in the ISA)
-                u32x4 u0 = __builtin_bit_cast(u32x4, yb[0]), u1 = __builtin_bit_cast(u32x4, yb[1]);
-#pragma unroll
-                for (int k = 0; k < 4; ++k) {
-                    const auto sw = __builtin_amdgcn_permlane32_swap(u0[k], u1[k], false, false);
-                    u0[k] = sw[0];
-                    u1[k] = sw[1];
-                }
-                Yf[pa][pb] = __builtin_bit_cast(f32x4, u0);
-                Ym[pa][pb] = __builtin_bit_cast(f32x4, u1);
-            }
-        {
-            constexpr float LOG2E = 1.44269504088896341f;
-#pragma unroll
-            for (int pa = 0; pa < 2; ++pa)
-#pragma unroll
-                for (int pb = 0; pb < 2; ++pb) {
-                    f32x4 f = Yf[pa][pb] + bf;
-                    const f32x4 mm = (Ym[pa][pb] + bm) * -LOG2E;
-                    if (a.elu) {
-                        const f32x4 fe = f * LOG2E;
-#pragma unroll
-                        for (int k = 0; k < 4; ++k) f[k] = f[k] > 0.0f ? f[k] : __builtin_amdgcn_exp2f(fe[k]) - 1.0f;
-                    }
-                    f32x4 sg;
-#pragma unroll
-                    for (int k = 0; k < 4; ++k) sg[k] = __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(mm[k]));
-                    f32x4 v = (f * sg) * sc + sh + rv[pa][pb];
-#pragma unroll
-                    for (int k = 0; k < 4; ++k) v[k] = c0 + k < a.Cout ? v[k] : a.out_fill;
-                    float *op = a.out + ((size_t)(oy + pa) * a.outW + ox + pb) * a.out_cstride + c0;
-                    if (pix_in[pa][pb]) {
-                        if (quad_st) *reinterpret_cast<f32x4 *>(op) = v;
-                        else {
-#pragma unroll
-                            for (int k = 0; k < 4; ++k)
-                                if (c0 + k < c_lim) op[k] = v[k];
-                        }
-                    }
-                }
-        }
-        step_tile(by, bx);
-        __builtin_amdgcn_s_setprio(0);
-    }
-}
-
 // ------------------------------------------------------------------------------------------
-// Version 2 of the wave-autonomous Winograd kernel: the INPUT TRANSFORM is shared by the four waves through LDS.
+// Winograd F(2x2,3x3), wave-autonomous form on v_mfma_f32_16x16x4_f32 (round 3; index maps mirrored in tests/wino16_ref.py).
 //
-// tools/issue_probe.py (profiles/r3_issue_probe.json): the fp32 MFMA runs on the FP32 vector pipe itself — a v_add_f32 behind a
-// v_mfma_f32_* costs its full issue time whether it is "in the shadow" or not (16x16x4: 33 cycles alone, +2.5..3 per VALU
-// instruction with two waves per SIMD; LDS reads, SALU and global loads DO overlap).  So every VALU instruction competes with the
-// MFMAs for the same cycles, and version 1 — each wave forming B^T d B of all 32 tiles for itself — spends 19 % of its loop
-// there (attribution runs: profiles/r3_w16_ablation.md).  Here a chunk is processed in two PARTS (frequency rows 2p, 2p + 1):
-//   * transform role: wave w forms row a = 2p + (w & 1) of block tb = w >> 1 (lane = tile x 4 input channels): 8 ds_read_b128 of the
-//     raw patch, 32 VALU, 4 ds_write_b128 into Vbuf[p][8 frequencies][32 tiles][16 channels] (16 KiB, XOR-swizzled float4 slots:
-//     stores and loads are bank-conflict free) — a quarter of version 1's VALU work per wave;
-//   * MFMA role: as version 1 (A = weights of the wave's 8 channels, f | m in the 16 rows; B = a 16-tile block), B operands read
-//     from Vbuf with one ds_read_b128 per (frequency, block) = 4 k-steps; 64 MFMAs per part, order (frequency, k-step, block) so
-//     that an accumulator is touched every second MFMA;
+// The kernel above gives a wave one frequency ROW of a 32-tile x 32-channel unit, so the output transform Y = A^T M A needs the
+// other three waves: two passes through 32 KiB of LDS and three barriers per unit.  Here the unit is cut the other way:
+//   * wave w owns output channels 8w .. 8w+7 of the 32-channel group and ALL 16 frequencies of all 32 tiles: 16x16x4 MFMAs with
+//     A operand = transformed weights (rows 0..7 = conv_f, rows 8..15 = conv_m of those 8 channels, straight from L2,
+//     [group][wave][chunk][row a][j][lane][4 k-steps]), B operand = transformed input of 16 tiles (block b = tile rows 2b, 2b+1);
+//     16 frequencies x 2 blocks x 4 registers = 128 accumulators; a lane ends up with every frequency of its (tile, 4 channels),
+//     so A^T M A is lane-local; one v_permlane32_swap per register pair brings conv_f (lanes 0..31) and conv_m (lanes 32..63)
+//     together, the gate is lane-local and a lane loads / stores 4 consecutive channels of a pixel;
+//   * the INPUT TRANSFORM is shared by the four waves through LDS.  tools/issue_probe.py (profiles/r3_issue_probe.json): the fp32
+//     MFMA runs on the FP32 vector pipe itself — a v_add_f32 behind a v_mfma_f32_* costs its full issue time whether it is "in the
+//     shadow" or not (LDS reads, SALU and global loads DO overlap) — so a first version in which every wave formed B^T d B of all
+//     32 tiles for itself spent 19 % of its loop there (profiles/r3_w16_ablation.md; that kernel is in the history, 9e4c1b0).
+//     A chunk is processed in two PARTS (frequency rows 2p, 2p + 1): wave w forms row a = 2p + (w & 1) of block tb = w >> 1 (lane =
+//     tile x 4 input channels): 8 ds_read_b128 of the raw patch, 32 VALU, 4 ds_write_b128 into Vbuf[p][8 frequencies][32 tiles]
+//     [16 channels] (16 KiB, XOR-swizzled float4 slots: stores and loads are bank-conflict free);
+//   * B operands are read from Vbuf with one ds_read_b128 per (frequency, block) = 4 k-steps; 64 MFMAs per part, order (frequency,
+//     k-step, block) so that an accumulator is touched every second MFMA;
 //   * pipeline: during the MFMAs of part s the wave transforms part s + 1 into the other V buffer, fetches the weights three
 //     frequencies ahead and stages the raw patch of the next chunk (two raw buffers); one barrier per part.
-// Epilogue, units, weight order: version 1.  LDS: 2 x 15 KiB raw + 2 x 16 KiB V.  Index maps: tests/wino16_ref.py (v2 model).
+// Measured equal to or slower than the row-per-wave kernel on the full C -> C layers (profiles/README.md), so it is the default only
+// where most of a 32-channel group is padding (the 32 -> 3 output layer: waves without a real channel skip their MFMAs).
+// LDS: 2 x 15 KiB raw + 3 x 16 KiB V.
 struct Wino16sGeom {
     static constexpr int IH = 10, IW = 18, KC = 16, PS = KC + 4;
     static constexpr int RS = IW * PS + 24;                    // floats per raw patch row (384)
@@ -1871,7 +1509,10 @@ struct Wino4Geom {
     static constexpr int LDS_FLOATS = 2 * BUF + 2 * VBUF + 4;  // two raw buffers, two V buffers, a dummy float4 slot (128 KiB)
 };
 
-template <bool MUL>
+// ABL (attribution probes, results invalid; -DREAD_DEBUG_KNOBS builds only, read_tuning_set("conv_abl")): 1 no transform
+// arithmetic, 2 no transform LDS reads, 4 no transform LDS writes, 8 no raw-patch global loads, 16 no raw-patch LDS writes,
+// 32 weights loaded once, 64 B operands loaded once, 128 no epilogue, 256 no barrier
+template <bool MUL, int ABL = 0>
 __global__ __launch_bounds__(256, 1) void gated_conv_wino4_kernel(const ConvKArgs a)
 {
     using WG = Wino4Geom;
@@ -1894,30 +1535,29 @@ __global__ __launch_bounds__(256, 1) void gated_conv_wino4_kernel(const ConvKArg
         }
     };
 
-    // ---- raw patch staging (global -> registers -> LDS), two buffers
+    // ---- raw patch staging (global -> registers -> LDS), two buffers.  Buffer loads: a lane whose pixel lies outside the image
+    // (or whose element does not exist: 1360 float4 over 6 x 256 lanes) carries an out-of-range offset and the hardware returns
+    // zeros — no masks, no selects beside the MFMAs (every VALU instruction there costs FP-pipe time)
     int loff[WG::NI];
     unsigned rel[WG::NI], aoff[WG::NI];
-    unsigned okmask = 0;
+    constexpr unsigned OOR = 0x80000000u;                      // >= the tensor's size (conv_uses_w4), no 32-bit wrap with the chunk offset
 #pragma unroll
     for (int i = 0; i < WG::NI; ++i) {
         const int e = tid + i * 256, q = e % 4, pix = e / 4;
-        loff[i] = e < WG::NE ? (pix / WG::IW) * WG::RS + (pix % WG::IW) * WG::PS + 4 * q : -1;
+        loff[i] = e < WG::NE ? (pix / WG::IW) * WG::RS + (pix % WG::IW) * WG::PS + 4 * q : WG::KC;   // else: pixel 0's pad floats
         rel[i] = (unsigned)(((pix / WG::IW) * s.W + pix % WG::IW) * s.C + 4 * q) * 4u;
     }
-    const unsigned safe_rel = (unsigned)((s.W + 1) * s.C) * 4u;
-    const char *pbase = nullptr;
-    long pdelta = 0;
-    if constexpr (MUL) pdelta = reinterpret_cast<const char *>(a.mul) - reinterpret_cast<const char *>(s.p);
+    const unsigned src_bytes = (unsigned)(a.inH * s.W * s.C) * 4u;
+    const auto rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(s.p), 0, src_bytes, 0x00020000);
+    const auto rsrc_mul = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(MUL ? a.mul : s.p), 0, src_bytes, 0x00020000);
     auto set_patch = [&]() {
         const int y0 = pby * 8 - 1, x0 = pbx * 32 - 1;
-        pbase = reinterpret_cast<const char *>(s.p) + ((long)y0 * s.W + x0) * (long)(s.C * 4);
-        okmask = 0;
+        const unsigned base = (unsigned)((y0 * s.W + x0) * s.C) * 4u;          // may wrap: only lanes inside the image use it
 #pragma unroll
         for (int i = 0; i < WG::NI; ++i) {
             const int e = tid + i * 256, pix = e / 4, ppy = pix / WG::IW, ppx = pix % WG::IW;
             const bool ok = (e < WG::NE) & (ppy >= -y0) & (ppy < a.inH - y0) & (ppx >= -x0) & (ppx < a.inW - x0);
-            okmask |= (ok ? 1u : 0u) << i;
-            aoff[i] = ok ? rel[i] : safe_rel;
+            aoff[i] = ok ? base + rel[i] : OOR;
         }
     };
     auto advance = [&]() {
@@ -1931,16 +1571,14 @@ __global__ __launch_bounds__(256, 1) void gated_conv_wino4_kernel(const ConvKArg
         }
     };
     float4 st[WG::NI], stm[MUL ? WG::NI : 1];
-    unsigned st_ok = 0;
     auto gload1 = [&](int i) {
-        st[i] = load_f4(pbase + pchunk * (WG::KC * 4), aoff[i]);
-        if constexpr (MUL) stm[i] = load_f4(pbase + pdelta + pchunk * (WG::KC * 4), aoff[i]);
+        st[i] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, aoff[i], pchunk * (WG::KC * 4), 0));
+        if constexpr (MUL) stm[i] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rsrc_mul, aoff[i], pchunk * (WG::KC * 4), 0));
     };
     auto lwrite1 = [&](int i, int obuf) {
         float4 v = st[i];
         if constexpr (MUL) v = make_float4(v.x * stm[i].x, v.y * stm[i].y, v.z * stm[i].z, v.w * stm[i].w);
-        if (!((st_ok >> i) & 1u)) v = make_float4(0.f, 0.f, 0.f, 0.f);
-        *reinterpret_cast<float4 *>(__builtin_assume_aligned(lds + (loff[i] >= 0 ? obuf + loff[i] : WG::LDS_FLOATS - 4), 16)) = v;
+        *reinterpret_cast<float4 *>(__builtin_assume_aligned(lds + obuf + loff[i], 16)) = v;
     };
 
     // ---- transform role: thread = (input channel c16 of the chunk, tile tl): one 6 x 6 patch -> 36 frequencies
@@ -1948,6 +1586,10 @@ __global__ __launch_bounds__(256, 1) void gated_conv_wino4_kernel(const ConvKArg
     const int rbase = ((4 * (tl >> 3)) * WG::IW + 4 * (tl & 7)) * WG::PS + c16;                    // raw patch (floats)
     const int vwoff = WG::V0 + tl * 16 + ((c16 >> 2) ^ ((tl >> 1) & 3)) * 4 + (c16 & 3);           // + V buffer + frequency * 256
     float d[6][6];
+    if (ABL) {
+#pragma unroll
+        for (int i = 0; i < 36; ++i) d[i / 6][i % 6] = 1.0f + tid;
+    }
     // 1-D transform with B^T = [4 0 -5 0 1 0; 0 -4 -4 1 1 0; 0 4 -4 -1 1 0; 0 -2 -1 2 1 0; 0 2 -1 -2 1 0; 0 4 0 -5 0 1], 14 operations
     auto bt6 = [](float &x0, float &x1, float &x2, float &x3, float &x4, float &x5) {
         const float p = x3 + x4, q = x1 + x2, r = x4 - x3, u = x1 - x2, f = x3 - x1, h = x4 - x2;
@@ -1963,33 +1605,30 @@ __global__ __launch_bounds__(256, 1) void gated_conv_wino4_kernel(const ConvKArg
     // step k of the next chunk's transform: 0..35 reads, 36..41 columns, 42..47 rows, 48..83 stores
     auto t_step = [&](const float *raw, int vb, int k) {
         if (k < 36) {
-            d[k / 6][k % 6] = raw[rbase + ((k / 6) * WG::IW + (k % 6)) * WG::PS];
+            if (!(ABL & 2)) d[k / 6][k % 6] = raw[rbase + ((k / 6) * WG::IW + (k % 6)) * WG::PS];
         } else if (k < 42) {
             const int c = k - 36;
-            bt6(d[0][c], d[1][c], d[2][c], d[3][c], d[4][c], d[5][c]);
+            if (!(ABL & 1)) bt6(d[0][c], d[1][c], d[2][c], d[3][c], d[4][c], d[5][c]);
         } else if (k < 48) {
             const int r = k - 42;
-            bt6(d[r][0], d[r][1], d[r][2], d[r][3], d[r][4], d[r][5]);
+            if (!(ABL & 1)) bt6(d[r][0], d[r][1], d[r][2], d[r][3], d[r][4], d[r][5]);
         } else {
             const int fq = k - 48;
-            lds[vwoff + vb + fq * 256] = d[fq / 6][fq % 6];
+            if (!(ABL & 4)) lds[vwoff + vb + fq * 256] = d[fq / 6][fq % 6];
         }
     };
     constexpr int T_STEPS = 84;
 
-    // ---- A operand (weights): [group][wave][chunk][frequency][lane][4]; ring of 12 frequencies, fetched 10 ahead
-    const char *const wbase = reinterpret_cast<const char *>(a.wp_w4) + ((size_t)(g * 4 + wv) * n) * (36 * 1024);
+    // ---- A operand (weights): [group][wave][chunk][frequency][lane][4]; ring of 12 frequencies, fetched 10 ahead, one fragment per
+    // four MFMAs.  Buffer loads: the lane offset is one constant VGPR and the fragment offset an SGPR — no address arithmetic on
+    // the vector pipe (the global_load form needed a v_mov per load to stay in its saddr form, 12 cycles each beside the MFMAs)
+    const float *const wbase = a.wp_w4 + ((size_t)(g * 4 + wv) * n) * (36 * 256);
+    const auto wrsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(wbase), 0, (unsigned)n * (36 * 1024), 0x00020000);
     const unsigned wvoff = lane * 16;
     float4 Wq[12];
-    auto wload1 = [&](int slot, int chunk, int fq) { Wq[slot] = load_f4(wbase + (size_t)(chunk * 36 + fq) * 1024, wvoff); };
-    // two consecutive frequencies with ONE opaque lane offset (one v_mov instead of two: a lone VALU instruction behind an fp32
-    // MFMA costs 12 cycles on a SIMD that runs a single wave, tools/issue_probe.py)
-    auto wload2 = [&](int slot, int chunk, int fq) {
-        const char *b = wbase + (size_t)(chunk * 36 + fq) * 1024;
-        unsigned vo = wvoff;
-        asm volatile("" : "+v"(vo));
-        Wq[slot] = *reinterpret_cast<const float4 *>(b + vo);
-        Wq[slot + 1] = *reinterpret_cast<const float4 *>(b + vo + 1024);
+    constexpr int WLEAD = (ABL & 512) ? 6 : 10;                // frequencies ahead (probe 512: the sensitivity to that distance)
+    auto wload1 = [&](int slot, int chunk, int fq) {
+        Wq[slot] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(wrsrc, wvoff, (chunk * 36 + fq) * 1024, 0));
     };
     // ---- B operand: Vbuf[frequency][tile t16][slot]; ring of 6 frequencies, fetched 4 ahead
     const int t16 = lane & 15, kl = lane >> 4;
@@ -2006,21 +1645,18 @@ __global__ __launch_bounds__(256, 1) void gated_conv_wino4_kernel(const ConvKArg
     set_patch();
 #pragma unroll
     for (int i = 0; i < WG::NI; ++i) gload1(i);
-    st_ok = okmask;
 #pragma unroll
-    for (int j = 0; j < 10; ++j) wload1(j, 0, j);
+    for (int j = 0; j < WLEAD; ++j) wload1(j, 0, j);
 #pragma unroll
     for (int i = 0; i < WG::NI; ++i) lwrite1(i, 0);
     advance();
 #pragma unroll
     for (int i = 0; i < WG::NI; ++i) gload1(i);
-    st_ok = okmask;
 #pragma unroll
     for (int i = 0; i < WG::NI; ++i) lwrite1(i, WG::BUF);
     advance();
 #pragma unroll
     for (int i = 0; i < WG::NI; ++i) gload1(i);
-    st_ok = okmask;
     advance();
     __syncthreads();
 #pragma unroll
@@ -2057,25 +1693,26 @@ __global__ __launch_bounds__(256, 1) void gated_conv_wino4_kernel(const ConvKArg
                         acc[fq] = __builtin_amdgcn_mfma_f32_16x16x4f32(we, ve, acc[fq], 0, 0, 0);
                     // ---- shadow items
                     const int mm = e * 2 + sidx;                                     // position inside this pair's 8 MFMAs
-                    if (mm < 2 && 2 * pr + 4 + mm < 36) bload1((2 * pr + 4 + mm) % 6, v_cur, 2 * pr + 4 + mm);   // B operands 4 ahead
-                    if (mm == 2) {                                                   // weights 10 frequencies ahead, two at a time
-                        const int wf = 2 * pr + 10;
-                        if (wf < 36) wload2(wf % 12, chunk, wf);
-                        else wload2(wf % 12, nchunk, wf - 36);
+                    if (!(ABL & 64) && mm < 2 && 2 * pr + 4 + mm < 36) bload1((2 * pr + 4 + mm) % 6, v_cur, 2 * pr + 4 + mm);   // B operands 4 ahead
+                    if (!(ABL & 32) && (mm == 2 || mm == 6)) {                       // weights 10 frequencies ahead
+                        const int wf = 2 * pr + WLEAD + (mm == 6);
+                        if (wf < 36) wload1(wf % 12, chunk, wf);
+                        else wload1(wf % 12, nchunk, wf - 36);
                     }
                     // the next chunk's transform: reads first (one per MFMA), arithmetic, stores; then the raw patch traffic
                     if (m < 36) t_step(traw, v_nxt, m);
                     if (m >= 44 && m < 56) t_step(traw, v_nxt, 36 + (m - 44));
                     if (m >= 58 && m < 94) t_step(traw, v_nxt, 48 + (m - 58));
-                    if (m >= 96 && m - 96 < WG::NI) lwrite1(m - 96, raw_cur);        // raw(chunk + 2): registers -> LDS
-                    if (m >= 104 && m - 104 < WG::NI) gload1(m - 104);               // raw(chunk + 3) -> registers
+                    if (!(ABL & 16) && m >= 96 && m - 96 < WG::NI) lwrite1(m - 96, raw_cur);        // raw(chunk + 2): registers -> LDS
+                    if (!(ABL & 8) && m >= 104 && m - 104 < WG::NI) gload1(m - 104);               // raw(chunk + 3) -> registers
                     __builtin_amdgcn_sched_barrier(0);
                 }
-        st_ok = okmask;
-        advance();
-        __syncthreads();
+            advance();
+        if (!(ABL & 256)) __syncthreads();
+        if (!(ABL & 64)) {
 #pragma unroll
-        for (int j = 0; j < 4; ++j) bload1(j, v_nxt, j);                              // first B operands of the next chunk
+            for (int j = 0; j < 4; ++j) bload1(j, v_nxt, j);                          // first B operands of the next chunk
+        }
         const int o = raw_cur;
         raw_cur = raw_nxt;
         raw_nxt = o;
@@ -2095,6 +1732,15 @@ __global__ __launch_bounds__(256, 1) void gated_conv_wino4_kernel(const ConvKArg
         const int cq = (lane >> 4) & 1, hf = lane >> 5;
         const int c0 = g * 32 + wv * 8 + 4 * cq;
         const int oy = by * 8 + 4 * (t16 >> 3) + 2 * hf, ox = bx * 32 + 4 * (t16 & 7);           // this lane finishes rows oy, oy + 1
+        if (ABL & 128) {                                               // keep the accumulators live with one store per lane
+            f32x4 sum = acc[0];
+#pragma unroll
+            for (int i = 1; i < 36; ++i) sum += acc[i];
+            if (oy < a.outH && ox < a.outW) *reinterpret_cast<f32x4 *>(a.out + ((size_t)oy * a.outW + ox) * a.out_cstride + c0) = sum;
+            step_tile(by, bx);
+            __builtin_amdgcn_s_setprio(0);
+            continue;
+        }
         const bool full = (by * 8 + 8 <= a.outH) & (bx * 32 + 32 <= a.outW) & chan_full;
         const f32x4 bf = *reinterpret_cast<const f32x4 *>(a.params + c0);
         const f32x4 bm = *reinterpret_cast<const f32x4 *>(a.params + a.CoutPad + c0);
@@ -2205,6 +1851,14 @@ __global__ __launch_bounds__(256, 1) void gated_conv_wino4_kernel(const ConvKArg
         }
         step_tile(by, bx);
         __builtin_amdgcn_s_setprio(0);
+    }
+    if (ABL && a.nchunks == -12345) {                                  // never true: keeps the probes' dead values alive
+        float sink = 0.f;
+#pragma unroll
+        for (int i = 0; i < 36; ++i) sink += d[i / 6][i % 6];
+#pragma unroll
+        for (int i = 0; i < WG::NI; ++i) sink += st[i].x + st[i].y + st[i].z + st[i].w;
+        a.out[tid] = sink;
     }
 }
 
@@ -2491,9 +2145,9 @@ int g_kc32 = 1;            // 32-channel chunks for 1x1 layers whose sources are
 int g_use_wino = 1 << 30;  // read_tuning_set("conv_wino", max Cin): Winograd kernel for eligible 3x3 layers (0 = off)
 int g_w4 = 32;             // read_tuning_set("conv_w4", min Cin): layers with at least this many channels take the Winograd F(4x4,3x3)
                            // kernel when its weights were supplied (0 = never)
-int g_w16_abl = 0;         // read_tuning_set("conv_w16_abl", bits): attribution probes of the wave-autonomous kernel (results invalid)
+int g_abl = 0;             // read_tuning_set("conv_abl", bits): attribution probes of the 16x16x4 Winograd kernels (results invalid); -DREAD_DEBUG_KNOBS builds only
 int g_w16 = 0;             // read_tuning_set("conv_w16", v): F(2x2,3x3) launches: 0 the row-per-wave kernel (default: measured equal or faster),
-                           // 1 the wave-autonomous kernel with the shared input transform, 2 its first version
+                           // 1 the wave-autonomous kernel with the shared input transform
 int g_stagger_ticks = 0;   // read_tuning_set("conv_stagger", ticks of 10 ns)
 int g_ablate = 0;          // read_tuning_set("conv_ablate", bits): attribution probe, results invalid; -DREAD_DEBUG_KNOBS builds only
 
@@ -2749,8 +2403,8 @@ void conv_set_stagger(int ticks) { g_stagger_ticks = ticks < 0 ? 0 : ticks; }
 void conv_set_ablate(int bits) { g_ablate = bits; }
 void conv_set_wino(int max_cin) { g_use_wino = max_cin; }
 void conv_set_kc32(int v) { g_kc32 = v; }
-void conv_set_w16(int v) { g_w16 = v < 0 ? 0 : v > 2 ? 2 : v; }
-void conv_set_w16_abl(int v) { g_w16_abl = v; }
+void conv_set_w16(int v) { g_w16 = v != 0; }
+void conv_set_abl(int v) { g_abl = v; }
 void conv_set_w4(int v) { g_w4 = v < 0 ? 0 : v; }
 void conv_set_wino_wgs(int v) { g_wino_wgs = v <= 1 ? 1 : 2; }
 void conv_set_px(int v) { g_conv_px = v < 0 ? 0 : v > 4 ? 4 : v; }
@@ -3036,8 +2690,19 @@ int launch_gated_conv(const read_conv_desc *d, hipStream_t stream)
         a.wino_dby = (nwg / groups) / a.tiles_x;
         a.wino_dbx = (nwg / groups) % a.tiles_x;
         a.trace = nullptr;
-        hipLaunchKernelGGL(d->mul ? gated_conv_wino4_kernel<true> : gated_conv_wino4_kernel<false>, dim3((unsigned)nwg), dim3(256), 0,
-                           stream, a);
+        conv_fn fn4 = d->mul ? gated_conv_wino4_kernel<true> : gated_conv_wino4_kernel<false>;
+#ifdef READ_DEBUG_KNOBS
+        if (!d->mul && g_abl) {
+            switch (g_abl) {
+#define READ_ABL_CASE(n) case n: fn4 = gated_conv_wino4_kernel<false, n>; break;
+            READ_ABL_CASE(1) READ_ABL_CASE(7) READ_ABL_CASE(8) READ_ABL_CASE(24) READ_ABL_CASE(31) READ_ABL_CASE(32) READ_ABL_CASE(64)
+            READ_ABL_CASE(128) READ_ABL_CASE(256) READ_ABL_CASE(511) READ_ABL_CASE(383) READ_ABL_CASE(512)
+#undef READ_ABL_CASE
+            default: break;
+            }
+        }
+#endif
+        hipLaunchKernelGGL(fn4, dim3((unsigned)nwg), dim3(256), 0, stream, a);
         READ_CHECK_LAUNCH();
         return READ_OK;
     }
@@ -3052,36 +2717,19 @@ int launch_gated_conv(const read_conv_desc *d, hipStream_t stream)
     // ... and, by default, for layers whose last channel group is mostly padding (the 32 -> 3 output layer): its waves without a real
     // channel skip their MFMAs, the row-per-wave kernel pays for all 32 padded channels
     const bool mostly_padding = d->Cout <= 8;
-    if (c.wino && !d->linear && !a.trace && d->wpacked_w16 &&
-        (d->config == -3 || d->config == -4 || (d->config < 0 && (g_w16 || mostly_padding)))) {
+    if (c.wino && !d->linear && !a.trace && d->wpacked_w16 && (d->config == -3 || (d->config < 0 && (g_w16 || mostly_padding)))) {
         READ_CHECK_ARG((uintptr_t)d->wpacked_w16 % 16 == 0, "read_gated_conv_forward: wpacked_w16 misaligned");
-        const bool v1 = g_w16 == 2 || d->config == -4;
-        fn = v1 ? (d->mul ? gated_conv_wino16_kernel<true> : gated_conv_wino16_kernel<false>)
-                : (d->mul ? gated_conv_wino16s_kernel<true> : gated_conv_wino16s_kernel<false>);
-        if (!v1 && !d->mul && g_w16_abl) {
-            switch (g_w16_abl) {
-            case 1: fn = gated_conv_wino16s_kernel<false, 1>; break;
-            case 2: fn = gated_conv_wino16s_kernel<false, 2>; break;
-            case 4: fn = gated_conv_wino16s_kernel<false, 4>; break;
-            case 8: fn = gated_conv_wino16s_kernel<false, 8>; break;
-            case 16: fn = gated_conv_wino16s_kernel<false, 16>; break;
-            case 32: fn = gated_conv_wino16s_kernel<false, 32>; break;
-            case 63: fn = gated_conv_wino16s_kernel<false, 63>; break;
-            default: break;
-            }
-        } else if (v1 && !d->mul && g_w16_abl) {
-            switch (g_w16_abl) {
-            case 1: fn = gated_conv_wino16_kernel<false, 1>; break;
-            case 2: fn = gated_conv_wino16_kernel<false, 2>; break;
-            case 4: fn = gated_conv_wino16_kernel<false, 4>; break;
-            case 8: fn = gated_conv_wino16_kernel<false, 8>; break;
-            case 16: fn = gated_conv_wino16_kernel<false, 16>; break;
-            case 6: fn = gated_conv_wino16_kernel<false, 6>; break;
-            case 14: fn = gated_conv_wino16_kernel<false, 14>; break;
-            case 31: fn = gated_conv_wino16_kernel<false, 31>; break;
+        fn = d->mul ? gated_conv_wino16s_kernel<true> : gated_conv_wino16s_kernel<false>;
+#ifdef READ_DEBUG_KNOBS
+        if (!d->mul && g_abl) {
+            switch (g_abl) {
+#define READ_ABL_CASE(n) case n: fn = gated_conv_wino16s_kernel<false, n>; break;
+            READ_ABL_CASE(1) READ_ABL_CASE(2) READ_ABL_CASE(4) READ_ABL_CASE(8) READ_ABL_CASE(16) READ_ABL_CASE(32) READ_ABL_CASE(63)
+#undef READ_ABL_CASE
             default: break;
             }
         }
+#endif
     }
     hipLaunchKernelGGL(fn, grid, dim3(256), 0, stream, a);
     READ_CHECK_LAUNCH();
@@ -3099,7 +2747,8 @@ int conv_uses_wino(const read_conv_desc *d)
 int conv_uses_w4(const read_conv_desc *d)
 {
     const bool shape = !d->pre && !d->linear && d->ksize == 3 && d->stride == 1 && d->n_src == 1 && d->src[0].shift == 0 &&
-                       d->src[0].C % 16 == 0 && d->src[0].C >= 32 && d->Cout % 32 == 0 && !d->fill_pad && d->wpacked_w4;
+                       d->src[0].C % 16 == 0 && d->src[0].C >= 32 && d->Cout % 32 == 0 && !d->fill_pad && d->wpacked_w4 &&
+                       (long long)d->src[0].srcH * d->src[0].srcW * d->src[0].C * 4 < (1ll << 31);    // 32-bit buffer offsets
     return shape && (d->config == -5 || (d->config == -1 && g_w4 > 0 && d->src[0].C >= g_w4));
 }
 

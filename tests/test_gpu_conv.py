@@ -79,7 +79,7 @@ def test_winograd_kernel_on_unet_shapes(hip):
         x = torch.randn(c, H, W)
         res = torch.randn(c, H, W)
         ref = unet_torch.basic_conv(st, "L", x[None], 3, elu=j % 2 == 0)[0] + res
-        for cfg in ci + [-3, -4]:    # row-per-wave kernel(s); -3 / -4 = the wave-autonomous 16x16x4 kernels v2 / v1 (tests/wino16_ref.py)
+        for cfg in ci + [-3]:        # row-per-wave kernel(s); -3 = the wave-autonomous 16x16x4 kernel (tests/wino16_ref.py)
             got = gated_conv(_pack(st, [c]), [(_nhwc(x), 0)], elu=j % 2 == 0, residual=_nhwc(res), config=cfg)
             _close(got, ref, f"winograd config {cfg} {c}->{c} {H}x{W}", scale=5.0)
 
@@ -120,7 +120,7 @@ def test_winograd_kernel_odd_channel_counts_and_strides(hip):
         if res is not None:
             ref = ref + res
         width = cs if cs is not None else cout
-        for cfg in (ci, -3, -4):                                       # all three Winograd kernels
+        for cfg in (ci, -3):                                           # both F(2x2) Winograd kernels
             out = torch.full((H, W, width), -7.0, device="cuda")       # sentinel: untouched channels must stay
             got = gated_conv(_pack(st, [cin]), [(_nhwc(x), 0)], elu=j % 2 == 1, config=cfg, out=out, out_channels=width,
                              residual=_nhwc(res) if res is not None else None, fill=fill)

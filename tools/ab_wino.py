@@ -24,6 +24,7 @@ def main():
     ap.add_argument("--tune", default="")
     ap.add_argument("--out", default="gpurun_out/ab_wino.json")
     ap.add_argument("--kernels", default="old,new,f4")
+    ap.add_argument("--abl", default="", help="attribution probes of the f4 / new kernels (READ_HIP_DEBUG=1 library): comma list of bit sets")
     a = ap.parse_args()
     if a.tune:
         for kv in a.tune.split(","):
@@ -40,7 +41,7 @@ def main():
         x = torch.randn(h, w, c, device="cuda")
         r = torch.randn(h, w, c, device="cuda")
         outs = {}
-        for name, cfg in (("old", old), ("v1", -4), ("new", -3), ("f4", -5)):
+        for name, cfg in (("old", old), ("new", -3), ("f4", -5)):
             if name not in a.kernels.split(","):
                 continue
             out = torch.empty(h, w, c, device="cuda")
@@ -60,6 +61,20 @@ def main():
                    "frac_of_157.3": fl / gain / ms / 1e9 / 157.3}
             print(rec, flush=True)
             res.append(rec)
+            for bits in [int(v) for v in a.abl.split(",") if v] if name in ("f4", "new") else []:
+                _lib.check(_lib.lib().read_tuning_set(b"conv_abl", bits))
+                for _ in range(2):
+                    gated_conv(pk, [(x, 0)], elu=True, residual=r, config=cfg, out=out)
+                e0.record()
+                for _ in range(a.iters):
+                    gated_conv(pk, [(x, 0)], elu=True, residual=r, config=cfg, out=out)
+                e1.record()
+                e1.synchronize()
+                _lib.check(_lib.lib().read_tuning_set(b"conv_abl", 0))
+                rec = {"shape": label, "kernel": name, "abl": bits, "us": 1e3 * e0.elapsed_time(e1) / a.iters}
+                print(rec, flush=True)
+                res.append(rec)
+            gated_conv(pk, [(x, 0)], elu=True, residual=r, config=cfg, out=out)
         for other in ("new", "f4"):
             if "old" in outs and other in outs:
                 d = (outs["old"] - outs[other]).abs().max().item()
