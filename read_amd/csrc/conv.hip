@@ -1639,7 +1639,9 @@ __global__ __launch_bounds__(256, 1) void gated_conv_wino4_kernel(const ConvKArg
     };
 
     f32x4 acc[36];
-    const bool chan_full = (g * 32 + wv * 8 + 8 <= a.Cout) & ((a.out_cstride & 3) == 0) & ((a.Cout & 3) == 0) & !a.fill_pad;
+    const auto out_rsrc = __builtin_amdgcn_make_buffer_rsrc(a.out, 0, (unsigned)(a.outH * a.outW * a.out_cstride) * 4u, 0x00020000);
+    const auto res_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(a.residual ? a.residual : a.out), 0,
+                                                            (unsigned)(a.outH * a.outW * a.Cout) * 4u, 0x00020000);
 
     // ---- prologue: raw(0), raw(1) -> LDS, raw(2) -> registers, V(0), the first ten weight fragments, the first four B operands
     set_patch();
@@ -1741,40 +1743,32 @@ __global__ __launch_bounds__(256, 1) void gated_conv_wino4_kernel(const ConvKArg
             __builtin_amdgcn_s_setprio(0);
             continue;
         }
-        const bool full = (by * 8 + 8 <= a.outH) & (bx * 32 + 32 <= a.outW) & chan_full;
         const f32x4 bf = *reinterpret_cast<const f32x4 *>(a.params + c0);
         const f32x4 bm = *reinterpret_cast<const f32x4 *>(a.params + a.CoutPad + c0);
         const f32x4 sc = *reinterpret_cast<const f32x4 *>(a.params + 2 * a.CoutPad + c0);
         const f32x4 sh = *reinterpret_cast<const f32x4 *>(a.params + 3 * a.CoutPad + c0);
-        const int c_lim = a.fill_pad ? a.out_cstride : a.Cout;
-        const bool quad_st = c0 + 3 < c_lim && (a.out_cstride & 3) == 0;
-        const bool quad_ld = a.residual && c0 + 3 < a.Cout && (a.Cout & 3) == 0;
+        // residual loads and output stores through buffer descriptors: a 32-bit lane offset per pixel, out of range for pixels
+        // outside the image (loads return zeros, stores are dropped): no 64-bit address arithmetic, no masks, no separate path for
+        // partial blocks (Cout % 32 == 0: conv_uses_w4)
+        unsigned rvoff[2][4], ovoff[2][4];
+#pragma unroll
+        for (int py = 0; py < 2; ++py)
+#pragma unroll
+            for (int px = 0; px < 4; ++px) {
+                const bool in = (oy + py < a.outH) & (ox + px < a.outW);
+                const int pix = (oy + py) * a.outW + ox + px;
+                rvoff[py][px] = in ? (unsigned)((pix * a.Cout + c0) * 4) : OOR;
+                ovoff[py][px] = in ? (unsigned)((pix * a.out_cstride + c0) * 4) : OOR;
+            }
         f32x4 rv[2][4];
-        if (full) {                                                    // interior unit: no masks anywhere
 #pragma unroll
-            for (int py = 0; py < 2; ++py)
+        for (int py = 0; py < 2; ++py)
 #pragma unroll
-                for (int px = 0; px < 4; ++px) {
-                    rv[py][px] = f32x4{0.f, 0.f, 0.f, 0.f};
-                    if (a.residual)
-                        rv[py][px] = *reinterpret_cast<const f32x4 *>(a.residual + ((size_t)(oy + py) * a.outW + ox + px) * a.Cout + c0);
-                }
-        } else {
-#pragma unroll
-            for (int py = 0; py < 2; ++py)
-#pragma unroll
-                for (int px = 0; px < 4; ++px) {
-                    rv[py][px] = f32x4{0.f, 0.f, 0.f, 0.f};
-                    const bool in = (oy + py < a.outH) & (ox + px < a.outW);
-                    const float *rp = a.residual + ((size_t)(oy + py) * a.outW + ox + px) * a.Cout + c0;
-                    if (in && quad_ld) rv[py][px] = *reinterpret_cast<const f32x4 *>(rp);
-                    else if (in && a.residual) {
-#pragma unroll
-                        for (int k2 = 0; k2 < 4; ++k2)
-                            if (c0 + k2 < a.Cout) rv[py][px][k2] = rp[k2];
-                    }
-                }
-        }
+            for (int px = 0; px < 4; ++px) {
+                rv[py][px] = f32x4{0.f, 0.f, 0.f, 0.f};
+                if (a.residual)
+                    rv[py][px] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(res_rsrc, rvoff[py][px], 0, 0));
+            }
         // rows: R[p][nu] from M[0..5][nu]; then columns: Y[p][0..3] from R[p][0..5]
         f32x4 Y[4][4];
         {
@@ -1831,22 +1825,8 @@ __global__ __launch_bounds__(256, 1) void gated_conv_wino4_kernel(const ConvKArg
                     f32x4 sg;
 #pragma unroll
                     for (int k = 0; k < 4; ++k) sg[k] = __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(mm[k]));
-                    f32x4 v = (f * sg) * sc + sh + rv[py][px];
-                    float *op = a.out + ((size_t)(oy + py) * a.outW + ox + px) * a.out_cstride + c0;
-                    if (full) {
-                        *reinterpret_cast<f32x4 *>(op) = v;
-                        continue;
-                    }
-#pragma unroll
-                    for (int k = 0; k < 4; ++k) v[k] = c0 + k < a.Cout ? v[k] : a.out_fill;
-                    if ((oy + py < a.outH) & (ox + px < a.outW)) {
-                        if (quad_st) *reinterpret_cast<f32x4 *>(op) = v;
-                        else {
-#pragma unroll
-                            for (int k = 0; k < 4; ++k)
-                                if (c0 + k < c_lim) op[k] = v[k];
-                        }
-                    }
+                    const f32x4 v = (f * sg) * sc + sh + rv[py][px];
+                    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), out_rsrc, ovoff[py][px], 0, 0);
                 }
         }
         step_tile(by, bx);
@@ -2748,7 +2728,9 @@ int conv_uses_w4(const read_conv_desc *d)
 {
     const bool shape = !d->pre && !d->linear && d->ksize == 3 && d->stride == 1 && d->n_src == 1 && d->src[0].shift == 0 &&
                        d->src[0].C % 16 == 0 && d->src[0].C >= 32 && d->Cout % 32 == 0 && !d->fill_pad && d->wpacked_w4 &&
-                       (long long)d->src[0].srcH * d->src[0].srcW * d->src[0].C * 4 < (1ll << 31);    // 32-bit buffer offsets
+                       d->out_cstride % 4 == 0 &&                                                     // 128-bit stores
+                       (long long)d->src[0].srcH * d->src[0].srcW * d->src[0].C * 4 < (1ll << 31) &&  // 32-bit buffer offsets
+                       (long long)d->inH * d->inW * d->out_cstride * 4 < (1ll << 31);
     return shape && (d->config == -5 || (d->config == -1 && g_w4 > 0 && d->src[0].C >= g_w4));
 }
 
