@@ -1039,6 +1039,7 @@ __global__ __launch_bounds__(256, 2) void gated_conv_wino_kernel(const ConvKArgs
     }
 }
 
+typedef float f32x2 __attribute__((ext_vector_type(2)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 
@@ -1585,39 +1586,68 @@ __global__ __launch_bounds__(256, 1) void gated_conv_wino4_kernel(const ConvKArg
     const int c16 = tid & 15, tl = tid >> 4;
     const int rbase = ((4 * (tl >> 3)) * WG::IW + 4 * (tl & 7)) * WG::PS + c16;                    // raw patch (floats)
     const int vwoff = WG::V0 + tl * 16 + ((c16 >> 2) ^ ((tl >> 1) & 3)) * 4 + (c16 & 3);           // + V buffer + frequency * 256
-    float d[6][6];
+    // The patch lives in registers as column PAIRS d2[r][cp] = (d[r][2cp], d[r][2cp + 1]): packed fp32 instructions cost the issue
+    // time of scalar ones beside the MFMAs (tools/issue_probe.py), so the transform is written for v_pk_*: 96 instructions instead
+    // of 168 on the pipe the MFMAs run on.
+    f32x2 d2[6][3];
     if (ABL) {
 #pragma unroll
-        for (int i = 0; i < 36; ++i) d[i / 6][i % 6] = 1.0f + tid;
+        for (int i = 0; i < 18; ++i) d2[i / 3][i % 3] = f32x2{1.0f + tid, 2.0f + tid};
     }
-    // 1-D transform with B^T = [4 0 -5 0 1 0; 0 -4 -4 1 1 0; 0 4 -4 -1 1 0; 0 -2 -1 2 1 0; 0 2 -1 -2 1 0; 0 4 0 -5 0 1], 14 operations
-    auto bt6 = [](float &x0, float &x1, float &x2, float &x3, float &x4, float &x5) {
-        const float p = x3 + x4, q = x1 + x2, r = x4 - x3, u = x1 - x2, f = x3 - x1, h = x4 - x2;
-        const float y0 = __builtin_fmaf(x2, -5.0f, __builtin_fmaf(x0, 4.0f, x4));
-        const float y5 = __builtin_fmaf(x3, -5.0f, __builtin_fmaf(x1, 4.0f, x5));
+    // 1-D transform with B^T = [4 0 -5 0 1 0; 0 -4 -4 1 1 0; 0 4 -4 -1 1 0; 0 -2 -1 2 1 0; 0 2 -1 -2 1 0; 0 4 0 -5 0 1]:
+    // down the rows, two columns at a time: 14 packed operations
+    auto bt6v = [](f32x2 &x0, f32x2 &x1, f32x2 &x2, f32x2 &x3, f32x2 &x4, f32x2 &x5) {
+        const f32x2 p = x3 + x4, q = x1 + x2, r = x4 - x3, u = x1 - x2, f = x3 - x1, h = x4 - x2;
+        const f32x2 y0 = __builtin_elementwise_fma(x2, f32x2{-5.0f, -5.0f}, __builtin_elementwise_fma(x0, f32x2{4.0f, 4.0f}, x4));
+        const f32x2 y5 = __builtin_elementwise_fma(x3, f32x2{-5.0f, -5.0f}, __builtin_elementwise_fma(x1, f32x2{4.0f, 4.0f}, x5));
         x0 = y0;
-        x1 = __builtin_fmaf(q, -4.0f, p);
-        x2 = __builtin_fmaf(u, 4.0f, r);
-        x3 = __builtin_fmaf(f, 2.0f, h);
-        x4 = __builtin_fmaf(f, -2.0f, h);
+        x1 = __builtin_elementwise_fma(q, f32x2{-4.0f, -4.0f}, p);
+        x2 = __builtin_elementwise_fma(u, f32x2{4.0f, 4.0f}, r);
+        x3 = __builtin_elementwise_fma(f, f32x2{2.0f, 2.0f}, h);
+        x4 = __builtin_elementwise_fma(f, f32x2{-2.0f, -2.0f}, h);
         x5 = y5;
     };
-    // step k of the next chunk's transform: 0..35 reads, 36..41 columns, 42..47 rows, 48..83 stores
+    // ... and along a row whose six values x0..x5 sit in three pairs P0 = (x0, x1), P1 = (x2, x3), P2 = (x4, x5): the half selects
+    // (op_sel) and per-half negations of the packed instructions do the shuffling, 9 instructions; results
+    // P0 = (y0, y5), P1 = (y1, y2), P2 = (y3, y4)
+    const f32x2 KA = {4.0f, -5.0f}, KB = {2.0f, 0.0f};
+    auto bt6row = [&](f32x2 &P0, f32x2 &P1, f32x2 &P2) {
+        f32x2 T, Y05, QU, PR, Y12, Y34;
+        asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[0,0,0] op_sel_hi:[1,0,1]" : "=v"(T) : "v"(P0), "v"(KA), "v"(P2));                  // 4 x0 + x4 | 4 x1 + x5
+        asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[0,1,0] op_sel_hi:[1,1,1]" : "=v"(Y05) : "v"(P1), "v"(KA), "v"(T));                 // - 5 x2 | - 5 x3
+        asm("v_pk_add_f32 %0, %1, %2 op_sel:[1,0] op_sel_hi:[1,0] neg_hi:[0,1]" : "=v"(QU) : "v"(P0), "v"(P1));                     // x1 + x2 | x1 - x2
+        asm("v_pk_add_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[0,1] neg_hi:[0,1]" : "=v"(PR) : "v"(P2), "v"(P1));                     // x4 + x3 | x4 - x3
+        f32x2 F2, H2;
+        asm("v_pk_add_f32 %0, %1, %2 op_sel:[1,1] op_sel_hi:[1,1] neg_lo:[0,1] neg_hi:[1,0]" : "=v"(F2) : "v"(P1), "v"(P0));       // x3 - x1 | x1 - x3
+        asm("v_pk_add_f32 %0, %1, %2 op_sel:[0,0] op_sel_hi:[0,0] neg_lo:[0,1] neg_hi:[0,1]" : "=v"(H2) : "v"(P2), "v"(P1));       // x4 - x2 | x4 - x2
+        asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[0,0,0] op_sel_hi:[1,0,1] neg_lo:[1,0,0]" : "=v"(Y12) : "v"(QU), "v"(KA), "v"(PR));  // p - 4 q | r + 4 u
+        asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[0,0,0] op_sel_hi:[1,0,1]" : "=v"(Y34) : "v"(F2), "v"(KB), "v"(H2));                // h + 2 f | h - 2 f
+        P0 = Y05;
+        P1 = Y12;
+        P2 = Y34;
+    };
+    // step k of the next chunk's transform: -36..-1 reads (one ds_read_b32 with an immediate offset each — in pairs they would
+    // become ds_read2_b32, whose 8-bit offsets need a VALU add per pair), 18..20 columns, 21..26 rows, 27..44 stores (two each)
     auto t_step = [&](const float *raw, int vb, int k) {
-        if (k < 36) {
-            if (!(ABL & 2)) d[k / 6][k % 6] = raw[rbase + ((k / 6) * WG::IW + (k % 6)) * WG::PS];
-        } else if (k < 42) {
-            const int c = k - 36;
-            if (!(ABL & 1)) bt6(d[0][c], d[1][c], d[2][c], d[3][c], d[4][c], d[5][c]);
-        } else if (k < 48) {
-            const int r = k - 42;
-            if (!(ABL & 1)) bt6(d[r][0], d[r][1], d[r][2], d[r][3], d[r][4], d[r][5]);
+        if (k < 0) {
+            const int e = k + 36, r = e / 6, c = e % 6;
+            if (!(ABL & 2)) d2[r][c >> 1][c & 1] = raw[rbase + (r * WG::IW + c) * WG::PS];
+        } else if (k < 21) {
+            const int c = k - 18;
+            if (!(ABL & 1)) bt6v(d2[0][c], d2[1][c], d2[2][c], d2[3][c], d2[4][c], d2[5][c]);
+        } else if (k < 27) {
+            const int r = k - 21;
+            if (!(ABL & 1)) bt6row(d2[r][0], d2[r][1], d2[r][2]);
         } else {
-            const int fq = k - 48;
-            if (!(ABL & 4)) lds[vwoff + vb + fq * 256] = d[fq / 6][fq % 6];
+            const int r = (k - 27) / 3, j = (k - 27) % 3;             // pair j of row r holds frequencies (0, 5), (1, 2), (3, 4) of that row
+            const int f0 = r * 6 + (j == 0 ? 0 : j == 1 ? 1 : 3), f1 = r * 6 + (j == 0 ? 5 : j == 1 ? 2 : 4);
+            if (!(ABL & 4)) {
+                lds[vwoff + vb + f0 * 256] = d2[r][j].x;
+                lds[vwoff + vb + f1 * 256] = d2[r][j].y;
+            }
         }
     };
-    constexpr int T_STEPS = 84;
+    constexpr int T_FIRST = -36, T_STEPS = 45;
 
     // ---- A operand (weights): [group][wave][chunk][frequency][lane][4]; ring of 12 frequencies, fetched 10 ahead, one fragment per
     // four MFMAs.  Buffer loads: the lane offset is one constant VGPR and the fragment offset an SGPR — no address arithmetic on
@@ -1662,7 +1692,8 @@ __global__ __launch_bounds__(256, 1) void gated_conv_wino4_kernel(const ConvKArg
     advance();
     __syncthreads();
 #pragma unroll
-    for (int k = 0; k < T_STEPS; ++k) t_step(lds, 0, k);
+    for (int k = T_FIRST; k < T_STEPS; ++k)
+        if (k < 0 || k >= 18) t_step(lds, 0, k);
     __syncthreads();
 #pragma unroll
     for (int j = 0; j < 4; ++j) bload1(j, 0, j);
@@ -1702,9 +1733,9 @@ __global__ __launch_bounds__(256, 1) void gated_conv_wino4_kernel(const ConvKArg
                         else wload1(wf % 12, nchunk, wf - 36);
                     }
                     // the next chunk's transform: reads first (one per MFMA), arithmetic, stores; then the raw patch traffic
-                    if (m < 36) t_step(traw, v_nxt, m);
-                    if (m >= 44 && m < 56) t_step(traw, v_nxt, 36 + (m - 44));
-                    if (m >= 58 && m < 94) t_step(traw, v_nxt, 48 + (m - 58));
+                    if (m < 36) t_step(traw, v_nxt, m - 36);
+                    if (m >= 44 && m < 53) t_step(traw, v_nxt, 18 + (m - 44));
+                    if (m >= 58 && m < 94 && !(m & 1)) t_step(traw, v_nxt, 27 + ((m - 58) >> 1));
                     if (!(ABL & 16) && m >= 96 && m - 96 < WG::NI) lwrite1(m - 96, raw_cur);        // raw(chunk + 2): registers -> LDS
                     if (!(ABL & 8) && m >= 104 && m - 104 < WG::NI) gload1(m - 104);               // raw(chunk + 3) -> registers
                     __builtin_amdgcn_sched_barrier(0);
@@ -1835,7 +1866,7 @@ __global__ __launch_bounds__(256, 1) void gated_conv_wino4_kernel(const ConvKArg
     if (ABL && a.nchunks == -12345) {                                  // never true: keeps the probes' dead values alive
         float sink = 0.f;
 #pragma unroll
-        for (int i = 0; i < 36; ++i) sink += d[i / 6][i % 6];
+        for (int i = 0; i < 18; ++i) sink += d2[i / 3][i % 3].x + d2[i / 3][i % 3].y;
 #pragma unroll
         for (int i = 0; i < WG::NI; ++i) sink += st[i].x + st[i].y + st[i].z + st[i].w;
         a.out[tid] = sink;
