@@ -1040,8 +1040,27 @@ __global__ __launch_bounds__(256, 2) void gated_conv_wino_kernel(const ConvKArgs
 }
 
 typedef float f32x2 __attribute__((ext_vector_type(2)));
+// packed fp32 subtraction: hipcc scalarises `a - b` on float vectors (two v_sub_f32 per pair); the packed add with both halves of
+// the second operand negated is one instruction
+__device__ __forceinline__ f32x2 pk_add(f32x2 a, f32x2 b)      // (... and now and then an addition too)
+{
+    f32x2 d;
+    asm("v_pk_add_f32 %0, %1, %2" : "=v"(d) : "v"(a), "v"(b));
+    return d;
+}
+__device__ __forceinline__ f32x2 pk_sub(f32x2 a, f32x2 b)
+{
+    f32x2 d;
+    asm("v_pk_add_f32 %0, %1, %2 neg_lo:[0,1] neg_hi:[0,1]" : "=v"(d) : "v"(a), "v"(b));
+    return d;
+}
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ f32x4 pk_sub4(f32x4 a, f32x4 b)
+{
+    const f32x2 lo = pk_sub(a.lo, b.lo), hi = pk_sub(a.hi, b.hi);
+    return f32x4{lo.x, lo.y, hi.x, hi.y};
+}
 
 // ------------------------------------------------------------------------------------------
 // Winograd F(2x2,3x3), wave-autonomous form on v_mfma_f32_16x16x4_f32 (round 3; index maps mirrored in tests/wino16_ref.py).
@@ -1597,7 +1616,7 @@ __global__ __launch_bounds__(256, 1) void gated_conv_wino4_kernel(const ConvKArg
     // 1-D transform with B^T = [4 0 -5 0 1 0; 0 -4 -4 1 1 0; 0 4 -4 -1 1 0; 0 -2 -1 2 1 0; 0 2 -1 -2 1 0; 0 4 0 -5 0 1]:
     // down the rows, two columns at a time: 14 packed operations
     auto bt6v = [](f32x2 &x0, f32x2 &x1, f32x2 &x2, f32x2 &x3, f32x2 &x4, f32x2 &x5) {
-        const f32x2 p = x3 + x4, q = x1 + x2, r = x4 - x3, u = x1 - x2, f = x3 - x1, h = x4 - x2;
+        const f32x2 p = pk_add(x3, x4), q = pk_add(x1, x2), r = pk_sub(x4, x3), u = pk_sub(x1, x2), f = pk_sub(x3, x1), h = pk_sub(x4, x2);
         const f32x2 y0 = __builtin_elementwise_fma(x2, f32x2{-5.0f, -5.0f}, __builtin_elementwise_fma(x0, f32x2{4.0f, 4.0f}, x4));
         const f32x2 y5 = __builtin_elementwise_fma(x3, f32x2{-5.0f, -5.0f}, __builtin_elementwise_fma(x1, f32x2{4.0f, 4.0f}, x5));
         x0 = y0;
@@ -1806,8 +1825,8 @@ __global__ __launch_bounds__(256, 1) void gated_conv_wino4_kernel(const ConvKArg
             f32x4 R[4][6];
 #pragma unroll
             for (int nu = 0; nu < 6; ++nu) {
-                const f32x4 s1 = acc[6 + nu] + acc[12 + nu], d1 = acc[6 + nu] - acc[12 + nu];
-                const f32x4 s2 = acc[18 + nu] + acc[24 + nu], d2 = acc[18 + nu] - acc[24 + nu];
+                const f32x4 s1 = acc[6 + nu] + acc[12 + nu], d1 = pk_sub4(acc[6 + nu], acc[12 + nu]);
+                const f32x4 s2 = acc[18 + nu] + acc[24 + nu], d2 = pk_sub4(acc[18 + nu], acc[24 + nu]);
                 R[0][nu] = acc[nu] + s1 + s2;
                 R[1][nu] = d1 + 2.0f * d2;
                 R[2][nu] = s1 + 4.0f * s2;
@@ -1815,8 +1834,8 @@ __global__ __launch_bounds__(256, 1) void gated_conv_wino4_kernel(const ConvKArg
             }
 #pragma unroll
             for (int p = 0; p < 4; ++p) {
-                const f32x4 s1 = R[p][1] + R[p][2], d1 = R[p][1] - R[p][2];
-                const f32x4 s2 = R[p][3] + R[p][4], d2 = R[p][3] - R[p][4];
+                const f32x4 s1 = R[p][1] + R[p][2], d1 = pk_sub4(R[p][1], R[p][2]);
+                const f32x4 s2 = R[p][3] + R[p][4], d2 = pk_sub4(R[p][3], R[p][4]);
                 Y[p][0] = R[p][0] + s1 + s2;
                 Y[p][1] = d1 + 2.0f * d2;
                 Y[p][2] = s1 + 4.0f * s2;
@@ -1848,14 +1867,21 @@ __global__ __launch_bounds__(256, 1) void gated_conv_wino4_kernel(const ConvKArg
                 for (int px = 0; px < 4; ++px) {
                     f32x4 f = Yf[py][px] + bf;
                     const f32x4 mm = (Ym[py][px] + bm) * -LOG2E;
-                    if (a.elu) {
+                    if (a.elu) {                                   // vector forms wherever an operation has one: they become v_pk_*
                         const f32x4 fe = f * LOG2E;
+                        f32x4 e;
 #pragma unroll
-                        for (int k = 0; k < 4; ++k) f[k] = f[k] > 0.0f ? f[k] : __builtin_amdgcn_exp2f(fe[k]) - 1.0f;
+                        for (int k = 0; k < 4; ++k) e[k] = __builtin_amdgcn_exp2f(fe[k]);
+                        e = e + f32x4{-1.0f, -1.0f, -1.0f, -1.0f};
+#pragma unroll
+                        for (int k = 0; k < 4; ++k) f[k] = f[k] > 0.0f ? f[k] : e[k];
                     }
-                    f32x4 sg;
+                    f32x4 sg, t;
 #pragma unroll
-                    for (int k = 0; k < 4; ++k) sg[k] = __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(mm[k]));
+                    for (int k = 0; k < 4; ++k) t[k] = __builtin_amdgcn_exp2f(mm[k]);
+                    t = t + f32x4{1.0f, 1.0f, 1.0f, 1.0f};
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) sg[k] = __builtin_amdgcn_rcpf(t[k]);
                     const f32x4 v = (f * sg) * sc + sh + rv[py][px];
                     __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), out_rsrc, ovoff[py][px], 0, 0);
                 }
