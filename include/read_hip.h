@@ -302,6 +302,12 @@ int read_conv_pack_weights_device(int Cin, int Cout, int ksize, int kc, const fl
 int read_conv_pack_wino_device(int Cin, int Cout, const float *wf, const float *wm, float *wpacked_wino, void *stream);
 size_t read_conv_dgrad_wino_floats(int Cin, int Cout);
 int read_conv_pack_dgrad_wino_device(int Cin, int Cout, const float *wf, const float *wm, float *wpacked_wino, void *stream);
+/* ... and the Winograd F(4x4,3x3) fragments (read_conv_pack_w4_host's order; desc.wpacked_w4): linear-mode launches of layers
+ * with Cin >= 32 and Cout % 32 == 0 (the dgrad's virtual layer: 2 * pad8(Cout) input and Cin / 2 gated output channels) then run
+ * on the F(4x4) kernel, which stores the pre-activations and — with desc.out_gated — the gated output in the same pass. */
+int read_conv_pack_w4_device(int Cin, int Cout, const float *wf, const float *wm, float *wpacked_w4, void *stream);
+size_t read_conv_dgrad_w4_floats(int Cin, int Cout);
+int read_conv_pack_dgrad_w4_device(int Cin, int Cout, const float *wf, const float *wm, float *wpacked_w4, void *stream);
 size_t read_conv_dgrad_packed_floats(int Cin, int Cout, int ksize);
 int read_conv_pack_dgrad_device(int Cin, int Cout, int ksize, int kc, const float *wf, const float *wm, float *wpacked,
                                 void *stream);

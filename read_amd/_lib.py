@@ -92,6 +92,9 @@ SIGNATURES = {
     "read_conv_pack_wino_device": (_i, [_i, _i, _vp, _vp, _vp, _vp]),
     "read_conv_dgrad_wino_floats": (_sz, [_i, _i]),
     "read_conv_pack_dgrad_wino_device": (_i, [_i, _i, _vp, _vp, _vp, _vp]),
+    "read_conv_pack_w4_device": (_i, [_i, _i, _vp, _vp, _vp, _vp]),
+    "read_conv_dgrad_w4_floats": (_sz, [_i, _i]),
+    "read_conv_pack_dgrad_w4_device": (_i, [_i, _i, _vp, _vp, _vp, _vp]),
     "read_conv_dgrad_packed_floats": (_sz, [_i, _i, _i]),
     "read_conv_pack_dgrad_device": (_i, [_i, _i, _i, _i, _vp, _vp, _vp, _vp]),
     "read_gate_forward": (_i, [_vp, _i64, _i, _vp, _i, _vp, _vp, _i, _i, _i, _vp]),

@@ -1689,8 +1689,10 @@ __global__ __launch_bounds__(256, 1) void gated_conv_wino4_kernel(const ConvKArg
 
     f32x4 acc[36];
     const auto out_rsrc = __builtin_amdgcn_make_buffer_rsrc(a.out, 0, (unsigned)(a.outH * a.outW * a.out_cstride) * 4u, 0x00020000);
-    const auto res_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(a.residual ? a.residual : a.out), 0,
-                                                            (unsigned)(a.outH * a.outW * a.Cout) * 4u, 0x00020000);
+    // the second [outH][outW][Cout] tensor of a launch: the residual (read) or, for the training path's linear launches, the
+    // gated output (written)
+    float *const aux = a.linear ? a.out_gated : const_cast<float *>(a.residual);
+    const auto res_rsrc = __builtin_amdgcn_make_buffer_rsrc(aux ? aux : a.out, 0, (unsigned)(a.outH * a.outW * a.Cout) * 4u, 0x00020000);
 
     // ---- prologue: raw(0), raw(1) -> LDS, raw(2) -> registers, V(0), the first ten weight fragments, the first four B operands
     set_patch();
@@ -1842,6 +1844,25 @@ __global__ __launch_bounds__(256, 1) void gated_conv_wino4_kernel(const ConvKArg
                 Y[p][3] = d1 + 8.0f * d2 + R[p][5];
             }
         }
+        if (a.linear) {
+            // training path: the pre-activations conv_f + b_f (channel c) and conv_m + b_m (channel Cout + c) of all four rows of
+            // the tile — lanes 0..31 hold f, lanes 32..63 m — before anything is gated
+            const f32x4 bb = hf ? bm : bf;
+            const int oyt = by * 8 + 4 * (t16 >> 3), chan = (hf ? a.Cout : 0) + c0;
+#pragma unroll
+            for (int p = 0; p < 4; ++p)
+#pragma unroll
+                for (int px = 0; px < 4; ++px) {
+                    const bool in = (oyt + p < a.outH) & (ox + px < a.outW);
+                    const unsigned vo = in ? (unsigned)((((oyt + p) * a.outW + ox + px) * a.out_cstride + chan) * 4) : OOR;
+                    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, Y[p][px] + bb), out_rsrc, vo, 0, 0);
+                }
+            if (!a.out_gated) {                                        // dgrad: nothing to gate
+                step_tile(by, bx);
+                __builtin_amdgcn_s_setprio(0);
+                continue;
+            }
+        }
         // lanes 0..31 hold conv_f, lanes 32..63 conv_m: exchange rows (py, py + 2) so that the lower half-wave owns rows 0, 1 and
         // the upper half rows 2, 3 of the tile, f in one register and m in the other
         f32x4 Yf[2][4], Ym[2][4];
@@ -1882,7 +1903,12 @@ __global__ __launch_bounds__(256, 1) void gated_conv_wino4_kernel(const ConvKArg
                     t = t + f32x4{1.0f, 1.0f, 1.0f, 1.0f};
 #pragma unroll
                     for (int k = 0; k < 4; ++k) sg[k] = __builtin_amdgcn_rcpf(t[k]);
-                    const f32x4 v = (f * sg) * sc + sh + rv[py][px];
+                    f32x4 v = (f * sg) * sc + sh + rv[py][px];
+                    if (a.linear) {                                    // the gated output, zero on the separator rows of a stacked batch
+                        if (a.blk_h > 0 && (oy + py) % a.blk_h >= a.blk_valid) v = f32x4{0.f, 0.f, 0.f, 0.f};
+                        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), res_rsrc, rvoff[py][px], 0, 0);
+                        continue;
+                    }
                     __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), out_rsrc, ovoff[py][px], 0, 0);
                 }
         }
@@ -2649,7 +2675,7 @@ int launch_gated_conv(const read_conv_desc *d, hipStream_t stream)
     a.nchunks = nchunks;
     a.tiles_x = ceil_div(outW, 32);
     READ_CHECK_ARG(!d->pre || !c.wino, "read_gated_conv_forward: the Winograd kernel takes no pre-activation addend");
-    READ_CHECK_ARG(!d->out_gated || (c.wino && d->linear && (uintptr_t)d->out_gated % 16 == 0 && d->block_h >= 0 &&
+    READ_CHECK_ARG(!d->out_gated || ((c.wino || conv_uses_w4(d)) && d->linear && (uintptr_t)d->out_gated % 16 == 0 && d->block_h >= 0 &&
                                      d->valid_h <= d->block_h),
                    "read_gated_conv_forward: out_gated needs a linear launch on the Winograd kernel");
     a.out_gated = d->out_gated;
@@ -2783,7 +2809,7 @@ int conv_uses_wino(const read_conv_desc *d)
 // F(4x4,3x3): non-linear 3x3 / stride-1 launches with full 32-channel groups and at least conv_w4 input channels (config -5 forces it)
 int conv_uses_w4(const read_conv_desc *d)
 {
-    const bool shape = !d->pre && !d->linear && d->ksize == 3 && d->stride == 1 && d->n_src == 1 && d->src[0].shift == 0 &&
+    const bool shape = !d->pre && (!d->linear || !d->residual) && d->ksize == 3 && d->stride == 1 && d->n_src == 1 && d->src[0].shift == 0 &&
                        d->src[0].C % 16 == 0 && d->src[0].C >= 32 && d->Cout % 32 == 0 && !d->fill_pad && d->wpacked_w4 &&
                        d->out_cstride % 4 == 0 &&                                                     // 128-bit stores
                        (long long)d->src[0].srcH * d->src[0].srcW * d->src[0].C * 4 < (1ll << 31) &&  // 32-bit buffer offsets

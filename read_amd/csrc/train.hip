@@ -115,6 +115,44 @@ __global__ void pack_wino_kernel(int mode, int Cin, int Cout, int Cp, const floa
     }
 }
 
+// Winograd F(4x4,3x3) fragment order of read_conv_pack_w4_host: U = G g G^T (6 x 6, evaluated in double, rounded once) per
+// (cout, cin) pair, [group][wave 4][chunk of 16 cin][frequency 6 xi + nu][lane][e]; lane (i = lane & 15, kl = lane >> 4) =
+// U_{i < 8 ? f : m}[xi][nu][cin = 16 chunk + 4 kl + e][cout = 32 group + 8 wave + (i & 7)].  mode as in pack_weights_kernel.
+__global__ void pack_w4_kernel(int mode, int Cin, int Cout, int Cp, const float *wf, const float *wm, float *out, long long total)
+{
+    const double G[6][3] = {{0.25, 0.0, 0.0}, {-1.0 / 6, -1.0 / 6, -1.0 / 6}, {-1.0 / 6, 1.0 / 6, -1.0 / 6},
+                            {1.0 / 24, 1.0 / 12, 1.0 / 6}, {1.0 / 24, -1.0 / 12, 1.0 / 6}, {0.0, 0.0, 1.0}};
+    const int CinV = mode ? 2 * Cp : Cin, CoutV = mode ? Cin / 2 : Cout;
+    const int nchunks = CinV / 16;
+    for (long long o = (long long)blockIdx.x * blockDim.x + threadIdx.x; o < total; o += (long long)gridDim.x * blockDim.x) {
+        long long r = o;
+        const int e = (int)(r & 3); r >>= 2;
+        const int lane = (int)(r & 63); r >>= 6;
+        const int fq = (int)(r % 36); r /= 36;
+        const int chunk = (int)(r % nchunks); r /= nchunks;
+        const int w = (int)(r & 3);
+        const int g = (int)(r >> 2);
+        const int slot = lane & 15, fm = slot >> 3;
+        const int co = g * 32 + w * 8 + (slot & 7), ci = 16 * chunk + 4 * (lane >> 4) + e;
+        double u = 0.0;
+        if (co < CoutV) {
+            const float *k = nullptr;
+            bool flip = false;
+            if (!mode) {
+                k = (fm ? wm : wf) + ((size_t)co * Cin + ci) * 9;
+            } else {
+                const int layer_co = ci % Cp, layer_ci = fm * (Cin / 2) + co;
+                if (layer_co < Cout) k = (ci < Cp ? wf : wm) + ((size_t)layer_co * Cin + layer_ci) * 9;
+                flip = true;
+            }
+            if (k)
+                for (int a = 0; a < 3; ++a)
+                    for (int b = 0; b < 3; ++b) u += G[fq / 6][a] * (double)k[flip ? 8 - (a * 3 + b) : a * 3 + b] * G[fq % 6][b];
+        }
+        out[o] = (float)u;
+    }
+}
+
 // weights for dgrad_generic_kernel: [tap][co' in 2*Cp][ci]  (ci contiguous)
 __global__ void pack_dgrad_generic_kernel(int Cin, int Cout, int taps, int Cp, const float *wf, const float *wm, float *out,
                                           long long total)
@@ -718,6 +756,33 @@ extern "C" int read_conv_pack_dgrad_wino_device(int Cin, int Cout, const float *
     const long long total = (long long)read_conv_dgrad_wino_floats(Cin, Cout);
     hipLaunchKernelGGL(pack_wino_kernel, dim3(grid_for(total)), dim3(256), 0, as_stream(stream), 1, Cin, Cout, Cp, wf, wm,
                        wpacked_wino, total);
+    READ_CHECK_LAUNCH();
+    return READ_OK;
+}
+
+extern "C" int read_conv_pack_w4_device(int Cin, int Cout, const float *wf, const float *wm, float *wpacked_w4, void *stream)
+{
+    READ_CHECK_ARG(wf && wm && wpacked_w4, "read_conv_pack_w4_device: null pointer");
+    READ_CHECK_ARG(Cin >= 16 && Cin % 16 == 0 && Cout >= 1, "read_conv_pack_w4_device: needs Cin %% 16 == 0 (got %d)", Cin);
+    const long long total = (long long)read_conv_w4_floats(Cin, Cout);
+    hipLaunchKernelGGL(pack_w4_kernel, dim3(grid_for(total)), dim3(256), 0, as_stream(stream), 0, Cin, Cout, 0, wf, wm, wpacked_w4, total);
+    READ_CHECK_LAUNCH();
+    return READ_OK;
+}
+
+extern "C" size_t read_conv_dgrad_w4_floats(int Cin, int Cout)
+{
+    if (Cin < 2 || Cin % 2 || Cout < 1) return 0;
+    return read_conv_w4_floats(2 * ((Cout + 7) / 8 * 8), Cin / 2);
+}
+
+extern "C" int read_conv_pack_dgrad_w4_device(int Cin, int Cout, const float *wf, const float *wm, float *wpacked_w4, void *stream)
+{
+    READ_CHECK_ARG(wf && wm && wpacked_w4, "read_conv_pack_dgrad_w4_device: null pointer");
+    READ_CHECK_ARG(Cin >= 2 && Cin % 2 == 0 && Cout >= 1, "read_conv_pack_dgrad_w4_device: Cin must be even");
+    const int Cp = (Cout + 7) / 8 * 8;
+    const long long total = (long long)read_conv_dgrad_w4_floats(Cin, Cout);
+    hipLaunchKernelGGL(pack_w4_kernel, dim3(grid_for(total)), dim3(256), 0, as_stream(stream), 1, Cin, Cout, Cp, wf, wm, wpacked_w4, total);
     READ_CHECK_LAUNCH();
     return READ_OK;
 }

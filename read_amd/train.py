@@ -41,7 +41,12 @@ def _kc_for(cin):
     return 16 if cin % 16 == 0 else 8
 
 
-def _linear_conv(x, cin, wpacked, params, cout, k, stride, out, wino=None, gated=None):
+def _w4_fits(cin, cout):
+    """Layers the Winograd F(4x4,3x3) kernel takes (csrc/conv.hip conv_uses_w4): full 32-channel groups, at least two chunks."""
+    return USE_W4 and cin % 16 == 0 and cin >= 32 and cout % 32 == 0
+
+
+def _linear_conv(x, cin, wpacked, params, cout, k, stride, out, wino=None, gated=None, w4=False):
     """x (H,W,cin) NHWC -> out (Ho,Wo,2*cout): [conv_f + b_f | conv_m + b_m] through the MFMA kernel (linear epilogue);
     with Winograd fragments (3x3 / stride 1, cin % 16 == 0) through the Winograd F(2x2,3x3) kernel — which can store the
     layer's gated output in the same pass: gated = (y (Ho,Wo,cout), elu, block_h, valid_h)."""
@@ -54,7 +59,10 @@ def _linear_conv(x, cin, wpacked, params, cout, k, stride, out, wino=None, gated
     d.wpacked, d.params, d.out, d.out_cstride = wpacked.data_ptr(), params.data_ptr(), out.data_ptr(), 2 * cout
     d.config, d.linear = -1, 1
     if wino is not None:
-        d.wpacked_wino = wino.data_ptr()
+        if w4:
+            d.wpacked_w4 = wino.data_ptr()
+        else:
+            d.wpacked_wino = wino.data_ptr()
         if gated is not None:
             y, elu, bh, vh = gated
             d.out_gated, d.elu, d.block_h, d.valid_h = y.data_ptr(), int(elu), int(bh), int(vh)
@@ -65,6 +73,7 @@ def _linear_conv(x, cin, wpacked, params, cout, k, stride, out, wino=None, gated
 # packed copies of a layer's weights, reused by every image of a batch (weights only change at optimizer steps, which bump
 # the parameters' _version): key = id of the conv_f weight -> (versions, params block, forward fragments, dgrad fragments)
 _PACK_CACHE = {}
+USE_W4 = True                # ... and through the F(4x4,3x3) kernel where its units fit (cin >= 32, cout % 32 == 0)
 USE_WINOGRAD = True          # 3x3 / stride-1 layers with cin % 16 == 0: forward pre-activations and dgrad through the Winograd kernel
 
 
@@ -121,7 +130,7 @@ def _zero_params(n, dev):
     return z
 
 
-def _packed_for(wf, bf, wm, bm, gamma, beta, mean, var, cin, cout, k, identity_bn=False):
+def _packed_for(wf, bf, wm, bm, gamma, beta, mean, var, cin, cout, k, identity_bn=False, stride=1):
     """identity_bn (batch-statistics mode): the params block carries the two biases and scale 1 / shift 0 — the launch then
     stores g = act(f) * sigmoid(m) itself and read_bn_train_forward normalises it."""
     L = _lib.lib()
@@ -151,12 +160,20 @@ def _packed_for(wf, bf, wm, bm, gamma, beta, mean, var, cin, cout, k, identity_b
         _lib.check(L.read_conv_pack_params_device(cout, _ptr(bf.detach()), _ptr(bm.detach()), _ptr(gamma.detach()),
                                                   _ptr(beta.detach()), _ptr(mean), _ptr(var), BN_EPS, params.data_ptr(), st))
     wf_c, wm_c = wf.detach().contiguous(), wm.detach().contiguous()
-    wp = torch.empty(L.read_conv_packed_floats(cin, cout, k), dtype=torch.float32, device=dev)
-    _lib.check(L.read_conv_pack_weights_device(cin, cout, k, _kc_for(cin), wf_c.data_ptr(), wm_c.data_ptr(), wp.data_ptr(), st))
-    wino = None
-    if k == 3 and cin % 16 == 0 and USE_WINOGRAD:
-        wino = torch.empty(L.read_conv_wino_floats(cin, cout), dtype=torch.float32, device=dev)
-        _lib.check(L.read_conv_pack_wino_device(cin, cout, wf_c.data_ptr(), wm_c.data_ptr(), wino.data_ptr(), st))
+    # ONE fragment order per layer and step: the Winograd order where that kernel runs the layer (3x3 / stride 1), the direct
+    # order everywhere else — packing both cost 64 us per layer and step for fragments nobody read
+    wp = wino = None
+    if k == 3 and stride == 1 and cin % 16 == 0 and USE_WINOGRAD:
+        if _w4_fits(cin, cout):
+            wino = torch.empty(L.read_conv_w4_floats(cin, cout), dtype=torch.float32, device=dev)
+            _lib.check(L.read_conv_pack_w4_device(cin, cout, wf_c.data_ptr(), wm_c.data_ptr(), wino.data_ptr(), st))
+        else:
+            wino = torch.empty(L.read_conv_wino_floats(cin, cout), dtype=torch.float32, device=dev)
+            _lib.check(L.read_conv_pack_wino_device(cin, cout, wf_c.data_ptr(), wm_c.data_ptr(), wino.data_ptr(), st))
+        wp = wino                                             # read_conv_desc.wpacked must point somewhere; it is not read
+    else:
+        wp = torch.empty(L.read_conv_packed_floats(cin, cout, k), dtype=torch.float32, device=dev)
+        _lib.check(L.read_conv_pack_weights_device(cin, cout, k, _kc_for(cin), wf_c.data_ptr(), wm_c.data_ptr(), wp.data_ptr(), st))
     ev = torch.cuda.Event()
     ev.record()
     key = id(wf)
@@ -183,12 +200,18 @@ def _pack_dgrad(entry, wf, wm, cin, cout, k):
     st = _lib.stream_ptr()
     dev = wf.device
     wf_c, wm_c = wf.detach().contiguous(), wm.detach().contiguous()
-    wd = torch.empty(L.read_conv_dgrad_packed_floats(cin, cout, k), dtype=torch.float32, device=dev)
-    _lib.check(L.read_conv_pack_dgrad_device(cin, cout, k, 16, wf_c.data_ptr(), wm_c.data_ptr(), wd.data_ptr(), st))
     wdw = None
     if k == 3 and USE_WINOGRAD:                                      # the virtual input has 2 * cp channels: always % 16
-        wdw = torch.empty(L.read_conv_dgrad_wino_floats(cin, cout), dtype=torch.float32, device=dev)
-        _lib.check(L.read_conv_pack_dgrad_wino_device(cin, cout, wf_c.data_ptr(), wm_c.data_ptr(), wdw.data_ptr(), st))
+        if _w4_fits(2 * ((cout + 7) // 8 * 8), cin // 2):            # the virtual layer: 2 * cp -> cin / 2 gated channels
+            wdw = torch.empty(L.read_conv_dgrad_w4_floats(cin, cout), dtype=torch.float32, device=dev)
+            _lib.check(L.read_conv_pack_dgrad_w4_device(cin, cout, wf_c.data_ptr(), wm_c.data_ptr(), wdw.data_ptr(), st))
+        else:
+            wdw = torch.empty(L.read_conv_dgrad_wino_floats(cin, cout), dtype=torch.float32, device=dev)
+            _lib.check(L.read_conv_pack_dgrad_wino_device(cin, cout, wf_c.data_ptr(), wm_c.data_ptr(), wdw.data_ptr(), st))
+        wd = wdw                                                     # the stride-1 dgrad of a 3x3 layer always runs on that kernel
+    else:
+        wd = torch.empty(L.read_conv_dgrad_packed_floats(cin, cout, k), dtype=torch.float32, device=dev)
+        _lib.check(L.read_conv_pack_dgrad_device(cin, cout, k, 16, wf_c.data_ptr(), wm_c.data_ptr(), wd.data_ptr(), st))
     ev = torch.cuda.Event()
     ev.record()
     entry[3] = (wd, ev, wdw)
@@ -208,7 +231,7 @@ class GatedConvFn(torch.autograd.Function):
         Ho, Wo = (H + 2 * pad - k) // stride + 1, (W + 2 * pad - k) // stride + 1
         dev = x.device
         wf_c, wm_c = wf.detach().contiguous(), wm.detach().contiguous()
-        entry = _packed_for(wf, bf, wm, bm, gamma, beta, mean, var, cin, cout, k, identity_bn=bn_train)
+        entry = _packed_for(wf, bf, wm, bm, gamma, beta, mean, var, cin, cout, k, identity_bn=bn_train, stride=stride)
         params, wp = entry[1], entry[2]
         ctx.pack = entry
         side = _SIDE.get(dev)
@@ -219,9 +242,9 @@ class GatedConvFn(torch.autograd.Function):
         # a batch is one tall image of nb stacked items; separator rows (block geometry at THIS layer's output scale) stay zero
         bh = Ho // nb if nb > 1 else 0
         vh = bh * v_num // v_den
-        wino = entry[5] if stride == 1 else None
+        wino = entry[5]
         # the Winograd kernel writes the gated output next to the pre-activations; the other kernels leave it to the gate pass
-        _linear_conv(x, cin, wp, params, cout, k, stride, fm, wino=wino, gated=(y, elu, bh, vh))
+        _linear_conv(x, cin, wp, params, cout, k, stride, fm, wino=wino, gated=(y, elu, bh, vh), w4=_w4_fits(cin, cout))
         if wino is None:
             _lib.check(L.read_gate_forward(fm.data_ptr(), Ho * Wo, cout, params.data_ptr(), int(elu), None, y.data_ptr(), Wo, bh, vh, st))
         stat = None
@@ -292,7 +315,7 @@ class GatedConvFn(torch.autograd.Function):
                 if wdw is not None:
                     wdw.record_stream(torch.cuda.current_stream())
                 zero = _zero_params(L.read_conv_param_floats(cin // 2), dev)
-                _linear_conv(d_in, 2 * cp, wd, zero, cin // 2, k, 1, dx, wino=wdw)
+                _linear_conv(d_in, 2 * cp, wd, zero, cin // 2, k, 1, dx, wino=wdw, w4=_w4_fits(2 * cp, cin // 2))
             else:
                 ws = torch.empty(L.read_conv_dgrad_generic_floats(cin, cout, k), dtype=torch.float32, device=dev)
                 _lib.check(L.read_conv_dgrad_generic(dfm.data_ptr(), Ho, Wo, cin, cout, k, stride, wf.data_ptr(), wm.data_ptr(),

@@ -60,7 +60,9 @@ def test_aff_weight_blocks_in_the_packed_blob():
         off += L.read_conv_packed_floats(cin, cout, k) + L.read_conv_param_floats(cout)
         if k == 3 and cin % 16 == 0 and not path.startswith("feat_extract.1") and not path.startswith("feat_extract.2") \
                 and not path.startswith("feat_extract.6"):
-            off += L.read_conv_wino_floats(cin, cout)                      # 3x3 / stride-1 layers carry G g G^T as well
+            off += 2 * L.read_conv_wino_floats(cin, cout)                  # 3x3 / stride-1 layers carry G g G^T as well, in the
+            if cin >= 32 and cout % 32 == 0:                               # orders of both F(2x2) kernels, and the F(4x4) fragments
+                off += L.read_conv_w4_floats(cin, cout)
     derived = [("AFFq3", 224, 256, (0, 1, 2)), ("AFFq2", 96, 128, (0, 1)), ("AFFq1", 32, 64, (0,)),
                ("AFFs.0.conv.0r", 0, 32, (0,)), ("AFFs.1.conv.0r", 0, 96, (1,)), ("AFFs.2.conv.0r", 0, 224, (2,))]
     rng = np.random.default_rng(5)
@@ -117,8 +119,10 @@ def test_scene_setters_and_refusals():
     assert s.point_drop == (0.25, 3) and s.point_perturb_seeded == (0.1, 4)
     s.set_params(**parse_input_string("colors_ps7_ds1"))
     assert s.params["point_size"] == 7 and s.params["splat_mode"] and s.params["mode"] == (0, None)
-    with pytest.raises(NotImplementedError):
-        s.set_point_sizes(np.ones(50))
+    s.set_point_sizes(np.full(50, 3.0))                    # per-point sizes (programs.py:339-345): accepted, make the scene "augmented"
+    assert s.point_sizes.dtype == np.float32 and s.augmented()
+    with pytest.raises(ValueError):
+        s.set_point_sizes(np.ones(49))
     with pytest.raises(NotImplementedError):
         s.set_vertices(xyz, uv1d=np.arange(50)[::-1])
     with pytest.raises(AssertionError):
