@@ -1801,13 +1801,13 @@ __global__ __launch_bounds__(256, 1) void gated_conv_wino4_kernel(const ConvKArg
         const f32x4 sh = *reinterpret_cast<const f32x4 *>(a.params + 3 * a.CoutPad + c0);
         // residual loads and output stores through buffer descriptors: a 32-bit lane offset per pixel, out of range for pixels
         // outside the image (loads return zeros, stores are dropped): no 64-bit address arithmetic, no masks, no separate path for
-        // partial blocks (Cout % 32 == 0: conv_uses_w4)
+        // partial blocks or a padded last channel group
         unsigned rvoff[2][4], ovoff[2][4];
 #pragma unroll
         for (int py = 0; py < 2; ++py)
 #pragma unroll
             for (int px = 0; px < 4; ++px) {
-                const bool in = (oy + py < a.outH) & (ox + px < a.outW);
+                const bool in = (oy + py < a.outH) & (ox + px < a.outW) & (c0 < a.Cout);      // Cout % 8 == 0: a lane's quad is real or padding
                 const int pix = (oy + py) * a.outW + ox + px;
                 rvoff[py][px] = in ? (unsigned)((pix * a.Cout + c0) * 4) : OOR;
                 ovoff[py][px] = in ? (unsigned)((pix * a.out_cstride + c0) * 4) : OOR;
@@ -1853,7 +1853,7 @@ __global__ __launch_bounds__(256, 1) void gated_conv_wino4_kernel(const ConvKArg
             for (int p = 0; p < 4; ++p)
 #pragma unroll
                 for (int px = 0; px < 4; ++px) {
-                    const bool in = (oyt + p < a.outH) & (ox + px < a.outW);
+                    const bool in = (oyt + p < a.outH) & (ox + px < a.outW) & (c0 < a.Cout);
                     const unsigned vo = in ? (unsigned)((((oyt + p) * a.outW + ox + px) * a.out_cstride + chan) * 4) : OOR;
                     __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, Y[p][px] + bb), out_rsrc, vo, 0, 0);
                 }
@@ -2810,7 +2810,7 @@ int conv_uses_wino(const read_conv_desc *d)
 int conv_uses_w4(const read_conv_desc *d)
 {
     const bool shape = !d->pre && (!d->linear || !d->residual) && d->ksize == 3 && d->stride == 1 && d->n_src == 1 && d->src[0].shift == 0 &&
-                       d->src[0].C % 16 == 0 && d->src[0].C >= 32 && d->Cout % 32 == 0 && !d->fill_pad && d->wpacked_w4 &&
+                       d->src[0].C % 16 == 0 && d->src[0].C >= 32 && (d->Cout % 32 == 0 || (d->linear && d->Cout % 8 == 0)) && !d->fill_pad && d->wpacked_w4 &&
                        d->out_cstride % 4 == 0 &&                                                     // 128-bit stores
                        (long long)d->src[0].srcH * d->src[0].srcW * d->src[0].C * 4 < (1ll << 31) &&  // 32-bit buffer offsets
                        (long long)d->inH * d->inW * d->out_cstride * 4 < (1ll << 31);

@@ -79,77 +79,88 @@ __global__ void pack_weights_kernel(int mode, int Cin, int Cout, int ksize, int 
     }
 }
 
-// Winograd F(2x2,3x3) fragment order of read_conv_pack_wino_host: U = G g G^T per (cout, cin) pair, packed
-// [group][k8 step][row i][j][f|m][lane][4], row 2 negated.  mode as in pack_weights_kernel (1 = dgrad's virtual weights).
-__global__ void pack_wino_kernel(int mode, int Cin, int Cout, int Cp, const float *wf, const float *wm, float *out, long long total)
+// The 3x3 kernel of the (virtual) layer's (cout, cin) pair, or null where the pair does not exist.  mode 0: the layer's own weights;
+// mode 1: dgrad as a convolution over d[f|m] (pack_weights_kernel): flipped, transposed.
+__device__ __forceinline__ const float *w3x3_of(int mode, int Cin, int Cout, int Cp, const float *wf, const float *wm, int fm, int co,
+                                                int ci, int CoutV)
 {
-    const float G[4][3] = {{1.f, 0.f, 0.f}, {.5f, .5f, .5f}, {.5f, -.5f, .5f}, {0.f, 0.f, 1.f}};
+    if (co >= CoutV) return nullptr;
+    if (!mode) return (fm ? wm : wf) + ((size_t)co * Cin + ci) * 9;
+    const int layer_co = ci % Cp, layer_ci = fm * (Cin / 2) + co;
+    return layer_co < Cout ? (ci < Cp ? wf : wm) + ((size_t)layer_co * Cin + layer_ci) * 9 : nullptr;
+}
+
+// Winograd F(2x2,3x3) fragment order of read_conv_pack_wino_host: U = G g G^T per (cout, cin) pair, packed
+// [group][k8 step][row i][j][f|m][lane][4], row 2 negated.  One workgroup per (group, k8 step): thread (lane, e) forms the 4 x 4
+// transform of its pair ONCE (constant indices: the first version looked G up per output element and spent 114 us per layer in
+// scratch traffic) and writes its 2 x 16 outputs, 1 KiB per instruction and workgroup.
+__global__ __launch_bounds__(256) void pack_wino_kernel(int mode, int Cin, int Cout, int Cp, const float *wf, const float *wm, float *out)
+{
     const int CinV = mode ? 2 * Cp : Cin, CoutV = mode ? Cin / 2 : Cout;
     const int nsteps = CinV / 8;
-    for (long long o = (long long)blockIdx.x * blockDim.x + threadIdx.x; o < total; o += (long long)gridDim.x * blockDim.x) {
-        long long r = o;
-        const int e = (int)(r & 3); r >>= 2;
-        const int lane = (int)(r & 63); r >>= 6;
-        const int fm = (int)(r & 1); r >>= 1;
-        const int j = (int)(r & 3); r >>= 2;
-        const int i = (int)(r & 3); r >>= 2;
-        const int st = (int)(r % nsteps);
-        const int g = (int)(r / nsteps);
-        const int co = g * 32 + (lane & 31), ci = 8 * st + 4 * (lane >> 5) + e;
-        float u = 0.0f;
-        if (co < CoutV) {
-            const float *k = nullptr;
-            bool flip = false;
-            if (!mode) {
-                k = (fm ? wm : wf) + ((size_t)co * Cin + ci) * 9;
-            } else {
-                const int layer_co = ci % Cp, layer_ci = fm * (Cin / 2) + co;
-                if (layer_co < Cout) k = (ci < Cp ? wf : wm) + ((size_t)layer_co * Cin + layer_ci) * 9;
-                flip = true;
-            }
-            if (k)
-                for (int a = 0; a < 3; ++a)
-                    for (int b = 0; b < 3; ++b) u += G[i][a] * k[flip ? 8 - (a * 3 + b) : a * 3 + b] * G[j][b];
+    const int st = blockIdx.x % nsteps, g = blockIdx.x / nsteps;
+    const int lane = threadIdx.x >> 2, e = threadIdx.x & 3;
+    const int co = g * 32 + (lane & 31), ci = 8 * st + 4 * (lane >> 5) + e;
+    float *o = out + (size_t)blockIdx.x * (16 * 2 * 256) + threadIdx.x;
+#pragma unroll
+    for (int fm = 0; fm < 2; ++fm) {
+        const float *k = w3x3_of(mode, Cin, Cout, Cp, wf, wm, fm, co, ci, CoutV);
+        float w[3][3];
+#pragma unroll
+        for (int t = 0; t < 9; ++t) w[t / 3][t % 3] = k ? k[mode ? 8 - t : t] : 0.0f;
+        float h[4][3];                                         // G g: rows g0, (g0 + g1 + g2) / 2, (g0 - g1 + g2) / 2, g2
+#pragma unroll
+        for (int b2 = 0; b2 < 3; ++b2) {
+            h[0][b2] = w[0][b2];
+            h[1][b2] = 0.5f * w[0][b2] + 0.5f * w[1][b2] + 0.5f * w[2][b2];
+            h[2][b2] = 0.5f * w[0][b2] - 0.5f * w[1][b2] + 0.5f * w[2][b2];
+            h[3][b2] = w[2][b2];
         }
-        out[o] = i == 2 ? -u : u;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const float u[4] = {h[i][0], 0.5f * h[i][0] + 0.5f * h[i][1] + 0.5f * h[i][2], 0.5f * h[i][0] - 0.5f * h[i][1] + 0.5f * h[i][2],
+                                h[i][2]};
+#pragma unroll
+            for (int j = 0; j < 4; ++j) o[((i * 4 + j) * 2 + fm) * 256] = i == 2 ? -u[j] : u[j];
+        }
     }
 }
 
 // Winograd F(4x4,3x3) fragment order of read_conv_pack_w4_host: U = G g G^T (6 x 6, evaluated in double, rounded once) per
 // (cout, cin) pair, [group][wave 4][chunk of 16 cin][frequency 6 xi + nu][lane][e]; lane (i = lane & 15, kl = lane >> 4) =
-// U_{i < 8 ? f : m}[xi][nu][cin = 16 chunk + 4 kl + e][cout = 32 group + 8 wave + (i & 7)].  mode as in pack_weights_kernel.
-__global__ void pack_w4_kernel(int mode, int Cin, int Cout, int Cp, const float *wf, const float *wm, float *out, long long total)
+// U_{i < 8 ? f : m}[xi][nu][cin = 16 chunk + 4 kl + e][cout = 32 group + 8 wave + (i & 7)].  One workgroup per (group, wave, chunk):
+// thread (lane, e) forms the 36 values of its pair and writes them 1 KiB per instruction and workgroup.
+__global__ __launch_bounds__(256) void pack_w4_kernel(int mode, int Cin, int Cout, int Cp, const float *wf, const float *wm, float *out)
 {
-    const double G[6][3] = {{0.25, 0.0, 0.0}, {-1.0 / 6, -1.0 / 6, -1.0 / 6}, {-1.0 / 6, 1.0 / 6, -1.0 / 6},
-                            {1.0 / 24, 1.0 / 12, 1.0 / 6}, {1.0 / 24, -1.0 / 12, 1.0 / 6}, {0.0, 0.0, 1.0}};
     const int CinV = mode ? 2 * Cp : Cin, CoutV = mode ? Cin / 2 : Cout;
     const int nchunks = CinV / 16;
-    for (long long o = (long long)blockIdx.x * blockDim.x + threadIdx.x; o < total; o += (long long)gridDim.x * blockDim.x) {
-        long long r = o;
-        const int e = (int)(r & 3); r >>= 2;
-        const int lane = (int)(r & 63); r >>= 6;
-        const int fq = (int)(r % 36); r /= 36;
-        const int chunk = (int)(r % nchunks); r /= nchunks;
-        const int w = (int)(r & 3);
-        const int g = (int)(r >> 2);
-        const int slot = lane & 15, fm = slot >> 3;
-        const int co = g * 32 + w * 8 + (slot & 7), ci = 16 * chunk + 4 * (lane >> 4) + e;
-        double u = 0.0;
-        if (co < CoutV) {
-            const float *k = nullptr;
-            bool flip = false;
-            if (!mode) {
-                k = (fm ? wm : wf) + ((size_t)co * Cin + ci) * 9;
-            } else {
-                const int layer_co = ci % Cp, layer_ci = fm * (Cin / 2) + co;
-                if (layer_co < Cout) k = (ci < Cp ? wf : wm) + ((size_t)layer_co * Cin + layer_ci) * 9;
-                flip = true;
-            }
-            if (k)
-                for (int a = 0; a < 3; ++a)
-                    for (int b = 0; b < 3; ++b) u += G[fq / 6][a] * (double)k[flip ? 8 - (a * 3 + b) : a * 3 + b] * G[fq % 6][b];
-        }
-        out[o] = (float)u;
+    const int chunk = blockIdx.x % nchunks, w = (blockIdx.x / nchunks) & 3, g = blockIdx.x / (4 * nchunks);
+    const int lane = threadIdx.x >> 2, e = threadIdx.x & 3;
+    const int slot = lane & 15, fm = slot >> 3;
+    const int co = g * 32 + w * 8 + (slot & 7), ci = 16 * chunk + 4 * (lane >> 4) + e;
+    const float *k = w3x3_of(mode, Cin, Cout, Cp, wf, wm, fm, co, ci, CoutV);
+    double wk[3][3];
+#pragma unroll
+    for (int t = 0; t < 9; ++t) wk[t / 3][t % 3] = k ? (double)k[mode ? 8 - t : t] : 0.0;
+    // G = [1/4 0 0; -1/6 -1/6 -1/6; -1/6 1/6 -1/6; 1/24 1/12 1/6; 1/24 -1/12 1/6; 0 0 1], the same sums in the same order as the host packer
+    auto gmul = [](double x0, double x1, double x2, double (&r)[6]) {
+        r[0] = 0.25 * x0 + 0.0 * x1 + 0.0 * x2;
+        r[1] = (-1.0 / 6) * x0 + (-1.0 / 6) * x1 + (-1.0 / 6) * x2;
+        r[2] = (-1.0 / 6) * x0 + (1.0 / 6) * x1 + (-1.0 / 6) * x2;
+        r[3] = (1.0 / 24) * x0 + (1.0 / 12) * x1 + (1.0 / 6) * x2;
+        r[4] = (1.0 / 24) * x0 + (-1.0 / 12) * x1 + (1.0 / 6) * x2;
+        r[5] = 0.0 * x0 + 0.0 * x1 + 1.0 * x2;
+    };
+    double h[3][6];                                            // h[b][xi] = sum_a G[xi][a] g[a][b]
+#pragma unroll
+    for (int b2 = 0; b2 < 3; ++b2) gmul(wk[0][b2], wk[1][b2], wk[2][b2], h[b2]);
+    float *o = out + (size_t)blockIdx.x * (36 * 256) + threadIdx.x;
+#pragma unroll
+    for (int xi = 0; xi < 6; ++xi) {
+        double u[6];
+        gmul(h[0][xi], h[1][xi], h[2][xi], u);
+#pragma unroll
+        for (int nu = 0; nu < 6; ++nu) o[(xi * 6 + nu) * 256] = (float)u[nu];
     }
 }
 
@@ -735,8 +746,8 @@ extern "C" int read_conv_pack_wino_device(int Cin, int Cout, const float *wf, co
     READ_CHECK_ARG(wf && wm && wpacked_wino, "read_conv_pack_wino_device: null pointer");
     READ_CHECK_ARG(Cin >= 16 && Cin % 16 == 0 && Cout >= 1, "read_conv_pack_wino_device: needs Cin %% 16 == 0 (got %d)", Cin);
     const long long total = (long long)read_conv_wino_floats(Cin, Cout);
-    hipLaunchKernelGGL(pack_wino_kernel, dim3(grid_for(total)), dim3(256), 0, as_stream(stream), 0, Cin, Cout, 0, wf, wm,
-                       wpacked_wino, total);
+    hipLaunchKernelGGL(pack_wino_kernel, dim3((unsigned)(total / (32 * 256))), dim3(256), 0, as_stream(stream), 0, Cin, Cout, 0, wf, wm,
+                       wpacked_wino);
     READ_CHECK_LAUNCH();
     return READ_OK;
 }
@@ -754,8 +765,8 @@ extern "C" int read_conv_pack_dgrad_wino_device(int Cin, int Cout, const float *
     READ_CHECK_ARG(Cin >= 2 && Cin % 2 == 0 && Cout >= 1, "read_conv_pack_dgrad_wino_device: Cin must be even");
     const int Cp = (Cout + 7) / 8 * 8;
     const long long total = (long long)read_conv_dgrad_wino_floats(Cin, Cout);
-    hipLaunchKernelGGL(pack_wino_kernel, dim3(grid_for(total)), dim3(256), 0, as_stream(stream), 1, Cin, Cout, Cp, wf, wm,
-                       wpacked_wino, total);
+    hipLaunchKernelGGL(pack_wino_kernel, dim3((unsigned)(total / (32 * 256))), dim3(256), 0, as_stream(stream), 1, Cin, Cout, Cp, wf, wm,
+                       wpacked_wino);
     READ_CHECK_LAUNCH();
     return READ_OK;
 }
@@ -765,7 +776,7 @@ extern "C" int read_conv_pack_w4_device(int Cin, int Cout, const float *wf, cons
     READ_CHECK_ARG(wf && wm && wpacked_w4, "read_conv_pack_w4_device: null pointer");
     READ_CHECK_ARG(Cin >= 16 && Cin % 16 == 0 && Cout >= 1, "read_conv_pack_w4_device: needs Cin %% 16 == 0 (got %d)", Cin);
     const long long total = (long long)read_conv_w4_floats(Cin, Cout);
-    hipLaunchKernelGGL(pack_w4_kernel, dim3(grid_for(total)), dim3(256), 0, as_stream(stream), 0, Cin, Cout, 0, wf, wm, wpacked_w4, total);
+    hipLaunchKernelGGL(pack_w4_kernel, dim3((unsigned)(total / (36 * 256))), dim3(256), 0, as_stream(stream), 0, Cin, Cout, 0, wf, wm, wpacked_w4);
     READ_CHECK_LAUNCH();
     return READ_OK;
 }
@@ -782,7 +793,7 @@ extern "C" int read_conv_pack_dgrad_w4_device(int Cin, int Cout, const float *wf
     READ_CHECK_ARG(Cin >= 2 && Cin % 2 == 0 && Cout >= 1, "read_conv_pack_dgrad_w4_device: Cin must be even");
     const int Cp = (Cout + 7) / 8 * 8;
     const long long total = (long long)read_conv_dgrad_w4_floats(Cin, Cout);
-    hipLaunchKernelGGL(pack_w4_kernel, dim3(grid_for(total)), dim3(256), 0, as_stream(stream), 1, Cin, Cout, Cp, wf, wm, wpacked_w4, total);
+    hipLaunchKernelGGL(pack_w4_kernel, dim3((unsigned)(total / (36 * 256))), dim3(256), 0, as_stream(stream), 1, Cin, Cout, Cp, wf, wm, wpacked_w4);
     READ_CHECK_LAUNCH();
     return READ_OK;
 }

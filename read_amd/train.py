@@ -42,8 +42,9 @@ def _kc_for(cin):
 
 
 def _w4_fits(cin, cout):
-    """Layers the Winograd F(4x4,3x3) kernel takes (csrc/conv.hip conv_uses_w4): full 32-channel groups, at least two chunks."""
-    return USE_W4 and cin % 16 == 0 and cin >= 32 and cout % 32 == 0
+    """Layers the Winograd F(4x4,3x3) kernel takes in linear mode (csrc/conv.hip conv_uses_w4): at least two 16-channel chunks,
+    output channels in multiples of 8 (the dgrad of a 32-channel layer is a 64 -> 16 + 16 virtual layer: half a group)."""
+    return USE_W4 and cin % 16 == 0 and cin >= 32 and cout % 8 == 0       # linear launches: a padded last group is masked
 
 
 def _linear_conv(x, cin, wpacked, params, cout, k, stride, out, wino=None, gated=None, w4=False):
@@ -234,6 +235,10 @@ class GatedConvFn(torch.autograd.Function):
         entry = _packed_for(wf, bf, wm, bm, gamma, beta, mean, var, cin, cout, k, identity_bn=bn_train, stride=stride)
         params, wp = entry[1], entry[2]
         ctx.pack = entry
+        # the dgrad's fragments too, now: in the backward pass the wgrad kernels of the layers above fill the chip from their side
+        # stream and a small packing launch between two dgrads waits 200 us for its turn (10 us here)
+        if entry[3] is None and x.requires_grad and (stride == 1 or (stride == 2 and k == 3 and H % 2 == 0 and W % 2 == 0)):
+            _pack_dgrad(entry, wf, wm, cin, cout, k)
         side = _SIDE.get(dev)
         if side is not None:
             side[1] = False          # a backward pass that died before its join callback ran must not mute the next one's

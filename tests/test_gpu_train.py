@@ -315,6 +315,7 @@ def test_texture_pipeline_training_step(hip):
     opt_r = torch.optim.Adam([p for p in st_r.values() if isinstance(p, torch.nn.Parameter)], lr=1e-3)
     ext_r = torch.optim.RMSprop([tex_r], lr=1e-1)
     keys = "uv_1d_p1, uv_1d_p1_ds1, uv_1d_p1_ds2, uv_1d_p1_ds3, uv_1d_p1_ds4".replace(' ', '').split(',')
+    g_ref = []
     for step in range(2):
         maps = [rng.integers(0, N, (2, 1, H >> l, W >> l)) for l in range(5)]
         target = torch.from_numpy(rng.random((2, 3, H, W)).astype(np.float32))
@@ -333,12 +334,24 @@ def test_texture_pipeline_training_step(hip):
             outs.append(unet_torch.unet_forward(st_r, *feats[:4]))
         loss_r = F.huber_loss(torch.cat(outs, 0), target) * 1e4
         loss_r.backward()
+        g_ref.append(tex_r.grad.detach().clone())
         opt_r.step(); opt_r.zero_grad(); ext_r.step(); ext_r.zero_grad()
         assert abs(float(loss) - float(loss_r)) <= 1e-4 * abs(float(loss_r)), (step, float(loss), float(loss_r))
-    # RMSprop's first steps move a descriptor by lr * g / (sqrt(0.01 g^2) + 1e-8) ~ 10 lr sign(g): entries whose gradient is
-    # at round-off level (|g| ~ 1e-9) take updates that depend on the last bits of g — ill-conditioned by construction, so the
-    # comparison after two optimizer steps is at 5e-3 of the largest entry (the gradients themselves are held to 1e-4 above)
-    _close(tex.state_dict()["texture_"].cpu(), tex_r.detach(), "descriptors after two steps", rtol=5e-3)
+    # RMSprop's first steps move a descriptor by lr * g / (sqrt(0.01 g^2) + 1e-8) ~ 10 lr sign(g): an entry whose gradient is at
+    # round-off level takes an update that depends on the last bits of g — ill-conditioned by construction.  So: entries whose
+    # reference gradient is above 1e-4 of the largest one in both steps (or exactly zero: untouched rows) are compared at 2e-3 of
+    # the largest entry; the others only against the size of the steps themselves (2 steps x 10 lr).  The gradients themselves are
+    # held to 1e-4 by the tests above.
+    got, ref = tex.state_dict()["texture_"].cpu().double(), tex_r.detach().double()
+    gmax = max(float(g.abs().max()) for g in g_ref)
+    well = torch.ones_like(ref, dtype=torch.bool)
+    for g in g_ref:
+        well &= (g.abs() > 1e-4 * gmax) | (g == 0)
+    assert float(well.double().mean()) > 0.5, "the well-conditioned set must be most of the table"
+    scale = float(ref.abs().max())
+    err_well = float(((got - ref).abs() * well).max()) / scale
+    assert err_well <= 2e-3, f"descriptors after two steps (well-conditioned entries): {err_well:.3e} of the largest entry"
+    assert float((got - ref).abs().max()) <= 2 * 10 * 1e-1 + 1e-6, "an ill-conditioned entry moved by more than the two steps can"
     sd = pipe.net.state_dict()
     for name in ("feat_extract.0.block.conv_f.weight", "Encoder.3.layers.2.main.0.block.conv_m.weight", "feat_extract.5.block.norm.weight",
                  "AFFs.1.conv.0.block.conv_f.bias"):
