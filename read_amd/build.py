@@ -45,7 +45,7 @@ def _stale(target, deps):
 def build(force: bool = False, verbose: bool = False, debug: bool = False) -> str:
     OBJ = os.path.join(HERE, "csrc", "_obj_debug" if debug else "_obj")
     LIB = os.path.join(HERE, "libreadhip_debug.so" if debug else "libreadhip.so")
-    FLAGS = globals()["FLAGS"] + (["-DREAD_DEBUG_KNOBS"] if debug else [])
+    FLAGS = globals()["FLAGS"] + (["-DREAD_DEBUG_KNOBS"] if debug else []) + [f"-D{d}" for d in os.environ.get("READ_EXTRA_DEFINES", "").split()]
     os.makedirs(OBJ, exist_ok=True)
     headers = [os.path.join(ROOT, "include", "read_hip.h"), os.path.join(CSRC, "common.h")]
     hipcc = _hipcc()

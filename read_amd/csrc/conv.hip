@@ -1518,7 +1518,8 @@ __global__ __launch_bounds__(256, 2) void gated_conv_wino16s_kernel(const ConvKA
 //     of its (tile, 4 channels): the output transform A^T M A is lane-local, one v_permlane32_swap per register pair brings conv_f
 //     and conv_m of half of the pixels together, then the usual gate / BatchNorm / residual epilogue with 128-bit accesses;
 //   * per 16-channel chunk: 144 MFMAs (frequencies in pairs, so an accumulator is touched every second MFMA), beside them the
-//     transform of the NEXT chunk into the other V buffer and the staging of the raw patch two chunks ahead; one barrier.
+//     transform of the NEXT chunk into the other V buffer and the staging of the raw patch two chunks ahead; one barrier, eight
+//     MFMAs before the end of the chunk.
 struct Wino4Geom {
     static constexpr int IH = 10, IW = 34, KC = 16, PS = KC + 4;
     static constexpr int RS = IW * PS;                         // floats per raw patch row (680)
@@ -1667,6 +1668,7 @@ __global__ __launch_bounds__(256, 1) void gated_conv_wino4_kernel(const ConvKArg
         }
     };
     constexpr int T_FIRST = -36, T_STEPS = 45;
+    constexpr int BAR_M = 135;                                 // MFMA slot of the per-stage barrier (stage_body); 143 = after the last MFMA
 
     // ---- A operand (weights): [group][wave][chunk][frequency][lane][4]; ring of 12 frequencies, fetched 10 ahead, one fragment per
     // four MFMAs.  Buffer loads: the lane offset is one constant VGPR and the fragment offset an SGPR — no address arithmetic on
@@ -1759,14 +1761,20 @@ __global__ __launch_bounds__(256, 1) void gated_conv_wino4_kernel(const ConvKArg
                     if (m >= 58 && m < 94 && !(m & 1)) t_step(traw, v_nxt, 27 + ((m - 58) >> 1));
                     if (!(ABL & 16) && m >= 96 && m - 96 < WG::NI) lwrite1(m - 96, raw_cur);        // raw(chunk + 2): registers -> LDS
                     if (!(ABL & 8) && m >= 104 && m - 104 < WG::NI) gload1(m - 104);               // raw(chunk + 3) -> registers
+                    // The stage's barrier, eight MFMAs BEFORE its end: V(chunk + 1) and raw(chunk + 2) are complete in every
+                    // wave (last LDS write at m = 101), every wave has fetched its last B operand of this chunk (m = 121), and
+                    // the first B operands of the next chunk travel under the remaining MFMAs (frequencies 34, 35: ring slots
+                    // 4, 5) instead of behind the barrier
+                    if (m == BAR_M) {
+                        if (!(ABL & 256)) __syncthreads();
+                        if (!(ABL & 64)) {
+#pragma unroll
+                            for (int j = 0; j < 4; ++j) bload1(j, v_nxt, j);
+                        }
+                    }
                     __builtin_amdgcn_sched_barrier(0);
                 }
             advance();
-        if (!(ABL & 256)) __syncthreads();
-        if (!(ABL & 64)) {
-#pragma unroll
-            for (int j = 0; j < 4; ++j) bload1(j, v_nxt, j);                          // first B operands of the next chunk
-        }
         const int o = raw_cur;
         raw_cur = raw_nxt;
         raw_nxt = o;
@@ -2206,6 +2214,7 @@ int g_conv_px = 1;         // read_tuning_set("conv_px", v): pixel-lane kernel f
                            // (64 / 128 accumulator registers per wave); 3 / 4 every layer it fits
 int g_kc32 = 1;            // 32-channel chunks for 1x1 layers whose sources are all multiples of 32 (read_tuning_set("conv_kc32", 0): 16)
 int g_use_wino = 1 << 30;  // read_tuning_set("conv_wino", max Cin): Winograd kernel for eligible 3x3 layers (0 = off)
+int g_w4_grid = 0;        // read_tuning_set("conv_w4_grid", 1): F(4x4) launches with the same number of units per workgroup (measured: see profiles)
 int g_w4 = 32;             // read_tuning_set("conv_w4", min Cin): layers with at least this many channels take the Winograd F(4x4,3x3)
                            // kernel when its weights were supplied (0 = never)
 int g_abl = 0;             // read_tuning_set("conv_abl", bits): attribution probes of the 16x16x4 Winograd kernels (results invalid); -DREAD_DEBUG_KNOBS builds only
@@ -2469,6 +2478,7 @@ void conv_set_kc32(int v) { g_kc32 = v; }
 void conv_set_w16(int v) { g_w16 = v != 0; }
 void conv_set_abl(int v) { g_abl = v; }
 void conv_set_w4(int v) { g_w4 = v < 0 ? 0 : v; }
+void conv_set_w4_grid(int v) { g_w4_grid = v != 0; }
 void conv_set_wino_wgs(int v) { g_wino_wgs = v <= 1 ? 1 : 2; }
 void conv_set_px(int v) { g_conv_px = v < 0 ? 0 : v > 4 ? 4 : v; }
 int conv_get(const char *key, int *value)
@@ -2481,8 +2491,10 @@ int conv_get(const char *key, int *value)
     else if (!strcmp(key, "conv_wino")) *value = g_use_wino;
     else if (!strcmp(key, "conv_w16")) *value = g_w16;
     else if (!strcmp(key, "conv_w4")) *value = g_w4;
+    else if (!strcmp(key, "conv_w4_grid")) *value = g_w4_grid;
 #ifdef READ_DEBUG_KNOBS
     else if (!strcmp(key, "conv_ablate")) *value = g_ablate;
+    else if (!strcmp(key, "conv_abl")) *value = g_abl;
 #endif
     else return 0;
     return 1;
@@ -2749,6 +2761,11 @@ int launch_gated_conv(const read_conv_desc *d, hipStream_t stream)
         }
         int nwg = a.n_units < n_cu_4 ? a.n_units : n_cu_4;
         nwg -= nwg % groups;
+        if (g_w4_grid) {                                               // A/B: every workgroup the same number of units
+            const int cap = n_cu_4 - n_cu_4 % groups > 0 ? n_cu_4 - n_cu_4 % groups : groups;
+            nwg = ceil_div(ceil_div(a.n_units, ceil_div(a.n_units, cap)), groups) * groups;
+            if (nwg > n_cu_4) nwg -= groups;
+        }
         if (nwg < groups) nwg = groups;
         a.wino_dby = (nwg / groups) / a.tiles_x;
         a.wino_dbx = (nwg / groups) % a.tiles_x;
