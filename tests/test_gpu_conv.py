@@ -86,10 +86,10 @@ def test_winograd_kernel_on_unet_shapes(hip):
 
 def test_winograd_f4_kernel(hip):
     """Winograd F(4x4,3x3) (config -5; the automatic choice for C >= 128): the UNet's 128- and 256-channel shapes, ragged sizes
-    (partial 8 x 32 blocks, one-pixel images), residual, ELU on / off, the FAM multiply, several units per workgroup.  Stated
+    (partial 8 x 32 blocks, tiny images, three and five channel groups), residual, ELU on / off, the FAM multiply, several units per workgroup.  Stated
     tolerance: 10x the direct kernels' (|diff| <= 2e-4 (1 + |ref|)): the F(4x4) transforms multiply by up to 8 and sum mixed signs."""
     torch.manual_seed(21)
-    for j, (c, H, W) in enumerate([(128, 9, 17), (256, 8, 32), (128, 23, 70), (32, 5, 3), (64, 40, 100), (128, 88, 304), (256, 44, 152)]):
+    for j, (c, H, W) in enumerate([(128, 9, 17), (256, 8, 32), (128, 23, 70), (32, 5, 3), (64, 40, 100), (128, 88, 304), (256, 44, 152), (96, 14, 37), (160, 3, 65)]):
         st = _state(c, c, 3, seed=500 + j)
         x = torch.randn(c, H, W)
         res = torch.randn(c, H, W)
