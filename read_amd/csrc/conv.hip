@@ -1503,18 +1503,21 @@ __global__ __launch_bounds__(256, 2) void gated_conv_wino16s_kernel(const ConvKA
 }
 
 // ------------------------------------------------------------------------------------------
-// Winograd F(4x4,3x3) on v_mfma_f32_16x16x4_f32 for the layers with C >= 128 (round 3; index maps: tests/wino4_ref.py).
+// Winograd F(4x4,3x3) on v_mfma_f32_16x16x4_f32: every 3x3 / stride-1 layer with Cin >= 32 (round 3; index maps: tests/wino4_ref.py).
 //
 // 4x fewer multiplications than the direct form (F(2x2,3x3): 2.25x), paid with more additions — and on this machine every VALU
 // instruction costs FP-pipe time next to the fp32 MFMAs (tools/issue_probe.py), so the design minimises VALU work per MFMA:
 //   * unit = 2 x 8 tiles of 4 x 4 output pixels (8 x 32 pixels) x 32 output channels; a workgroup of four waves, ONE per SIMD
 //     (144 accumulators + deep operand rings per wave; one wave per SIMD also keeps the weight stream — one 1 KiB fragment per
 //     four MFMAs — at half of what a SIMD's vector-memory path issues);
-//   * the input transform B^T d B (36 frequencies of a 6 x 6 patch, 168 VALU) is computed ONCE per (tile, input channel): thread
-//     = (channel of the 16-channel chunk, tile), 36 ds_read_b32 of the raw patch, 36 ds_write_b32 into a V buffer
-//     [frequency][tile][swizzled channel] that all four waves read their B operands from (one ds_read_b128 = 4 k-steps);
+//   * the input transform B^T d B (36 frequencies of a 6 x 6 patch) is computed ONCE per (tile, input channel): thread = (channel
+//     of the 16-channel chunk, tile), 36 ds_read_b32 of the raw patch, 95 VALU in packed fp32 (columns in pairs, the row pass with
+//     op_sel half-selects), 18 ds_write2st64_b32 into a V buffer [frequency][tile][swizzled channel] that all four waves read
+//     their B operands from (one ds_read_b128 = 4 k-steps);
+//   * no per-lane address arithmetic or masks beside the MFMAs: raw patches, weights, residual and output go through buffer
+//     descriptors (SGPR offsets; out-of-image lanes carry an out-of-range offset: loads return zeros, stores are dropped);
 //   * wave w owns output channels 8w .. 8w+7: A operand = G g G^T of conv_f (rows 0..7) and conv_m (rows 8..15), straight from L2
-//     ([group][wave][chunk][frequency][lane][4 k-steps], twelve frequencies in flight); a lane ends up with all 36 frequencies
+//     ([group][wave][chunk][frequency][lane][4 k-steps], ten frequencies ahead); a lane ends up with all 36 frequencies
 //     of its (tile, 4 channels): the output transform A^T M A is lane-local, one v_permlane32_swap per register pair brings conv_f
 //     and conv_m of half of the pixels together, then the usual gate / BatchNorm / residual epilogue with 128-bit accesses;
 //   * per 16-channel chunk: 144 MFMAs (frequencies in pairs, so an accumulator is touched every second MFMA), beside them the
