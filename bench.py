@@ -609,7 +609,7 @@ def stage_times(wl):
     return ms_splat, ms_gather, ms_unet
 
 
-def also_records(a, dev, wl):
+def also_records(a, dev, wl, first=None):
     """Compact records of the configurations the headline line is not quoted on, measured and verified inside this run."""
     import copy
     rec = {}
@@ -620,7 +620,9 @@ def also_records(a, dev, wl):
         n = min(a.steps, 64)
         dt = timed_sweep(wl, ex, a.warmup, n, 1, dev)
         rec["latency_mode"] = {"value": n / dt, "unit": "frames/s", "ms_per_step": 1e3 * dt / n, "steps": n, "frames_in_flight": 1,
-                               "what": "headline workload, one frame at a time (every frame complete before the next starts)"}
+                               "what": "headline workload, one frame at a time (every frame complete before the next starts)",
+                               # the oracle's frame of pose 0 (computed for the headline) against THIS mode's frame of pose 0
+                               "verified": verify(wl, first, pose=0) if first is not None else None}
     finally:
         wl.fr.set_frames_in_flight(a.frames_in_flight)
     street = synthetic.make_street_cloud(10_000_000)
@@ -761,7 +763,7 @@ def main():
         if my_verified is not None and not all(bool(v) for v in verified_ranks):
             rc = 3
         if a.config == "slab30m" and world == 1 and not a.no_also:
-            out["also"] = also_records(a, dev, wl)
+            out["also"] = also_records(a, dev, wl, first if not a.no_cpu_baseline else None)
             for k, r in out["also"].items():
                 v = r.get("verified")
                 if v is not None and not v["ok"]:
