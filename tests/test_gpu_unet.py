@@ -234,3 +234,10 @@ def test_headline_frame_1216x352_vs_oracle(hip):
             ref = unet_torch.net_and_texture_forward(state, desc[None], idx)[0]
         _check_rgb(rgba[:, :, :3].permute(2, 0, 1), ref, f"frame {W}x{H}")
         assert bool((rgba[:, :, 3] == 1).all())
+        # ... and the frame above came out of the kernels the documents describe: the 73 C -> C 3x3 / stride-1 launches (and the
+        # three 3x3 layers of the SCM chains) of the plan run on the Winograd F(4x4,3x3) kernel, none on a silent fallback
+        f = fr.feat
+        prof = fr.unet.profile(f[0][0], f[1][0], f[2][0], f[3][0], channels=4)
+        kinds = [k for (_, _, _, k) in prof]
+        assert len(prof) == 105 and kinds.count(4) >= 73, (len(prof), kinds.count(4), kinds.count(2))
+        assert sum(1 for (lbl, _, fl, k) in prof if abs(fl - 15.778971648e9 * (H / 352)) < 1e6 and k != 4) == 0
