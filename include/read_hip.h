@@ -227,13 +227,13 @@ typedef struct read_conv_desc {
     const float *wpacked_wino;              /* optional: read_conv_pack_wino_host() output (device); enables the
                                                Winograd F(2x2,3x3) kernel for 3x3/s1 single-source layers */
     const float *wpacked_w16;               /* optional: read_conv_pack_w16_host() output (device): the same Winograd operand in the
-                                               order of the wave-autonomous kernel (all 16 frequencies of a tile in one wave,
-                                               v_mfma_f32_16x16x4_f32); taken for non-linear launches when present
-                                               (read_tuning_set("conv_w16", 0) or config >= 0 keep the row-per-wave kernel,
-                                               config = -3 forces it) */
+                                               order of the wave-autonomous F(2x2) kernel (all 16 frequencies of a tile in one wave,
+                                               v_mfma_f32_16x16x4_f32); taken by non-linear launches with Cout <= 8 (the 32 -> 3
+                                               output layer), with read_tuning_set("conv_w16", 1), or with config = -3 */
     const float *wpacked_w4;                /* optional: read_conv_pack_w4_host() output (device): Winograd F(4x4,3x3) operand; taken by
-                                               non-linear 3x3 / stride-1 launches with Cout % 32 == 0 and Cin >= read_tuning("conv_w4")
-                                               (default 128; config = -5 forces it) */
+                                               3x3 / stride-1 single-source launches with Cin % 16 == 0, Cin >= read_tuning("conv_w4")
+                                               (default 32) and Cout % 32 == 0 (linear launches: Cout % 8 == 0); config = -5
+                                               forces it where the shape fits */
     int linear;                             /* 1: plain convolution (training path): out[..][c] = conv_f + b_f,
                                                out[..][Cout + c] = conv_m + b_m, out_cstride >= 2 * Cout; no gate /
                                                BatchNorm / residual; workgroup-tiled or Winograd kernel */

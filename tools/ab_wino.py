@@ -1,7 +1,9 @@
-"""A/B of the two Winograd F(2x2,3x3) kernels on the four dominant UNet shapes (run on the GPU box):
-the row-per-wave kernel (32x32x2 MFMA, cross-wave LDS epilogue) against the wave-autonomous one (16x16x4 MFMA, in-lane epilogue).
+"""A/B of the Winograd kernels on the four dominant UNet shapes (run on the GPU box): "old" = F(2x2,3x3) row-per-wave kernel
+(32x32x2 MFMA, cross-wave LDS epilogue), "new" = F(2x2,3x3) wave-autonomous kernel with the shared input transform (16x16x4 MFMA,
+in-lane epilogue), "f4" = F(4x4,3x3).  --abl lists attribution variants of the f4 / new kernels (the -DREAD_DEBUG_KNOBS library:
+python -m read_amd.build --debug, then READ_HIP_DEBUG=1).
 
-    python tools/ab_wino.py [--iters 20] [--tune key=value,...]
+    python tools/ab_wino.py [--iters 20] [--kernels old,new,f4] [--abl 1,7,24,...] [--tune key=value,...]
 """
 import argparse
 import json
