@@ -1536,7 +1536,10 @@ struct Wino4Geom {
 // ABL (attribution probes, results invalid; -DREAD_DEBUG_KNOBS builds only, read_tuning_set("conv_abl")): 1 no transform
 // arithmetic, 2 no transform LDS reads, 4 no transform LDS writes, 8 no raw-patch global loads, 16 no raw-patch LDS writes,
 // 32 weights loaded once, 64 B operands loaded once, 128 no epilogue, 256 no barrier
-template <bool MUL, int ABL = 0>
+// LIN: the training path's linear launches — 1: pre-activations + gated output (forward), 2: pre-activations only (dgrad) —
+// separate instantiations, so that every kernel's unit loop keeps ONE path through its epilogue (the waitcnt bookkeeping of hipcc merges every path at the loop
+// header: with the dgrad's early `continue` in the same function every unit started with s_waitcnt vmcnt(0))
+template <bool MUL, int ABL = 0, int LIN = 0>
 __global__ __launch_bounds__(256, 1) void gated_conv_wino4_kernel(const ConvKArgs a)
 {
     using WG = Wino4Geom;
@@ -1696,7 +1699,7 @@ __global__ __launch_bounds__(256, 1) void gated_conv_wino4_kernel(const ConvKArg
     const auto out_rsrc = __builtin_amdgcn_make_buffer_rsrc(a.out, 0, (unsigned)(a.outH * a.outW * a.out_cstride) * 4u, 0x00020000);
     // the second [outH][outW][Cout] tensor of a launch: the residual (read) or, for the training path's linear launches, the
     // gated output (written)
-    float *const aux = a.linear ? a.out_gated : const_cast<float *>(a.residual);
+    float *const aux = LIN ? a.out_gated : const_cast<float *>(a.residual);
     const auto res_rsrc = __builtin_amdgcn_make_buffer_rsrc(aux ? aux : a.out, 0, (unsigned)(a.outH * a.outW * a.Cout) * 4u, 0x00020000);
 
     // ---- prologue: raw(0), raw(1) -> LDS, raw(2) -> registers, V(0), the first ten weight fragments, the first four B operands
@@ -1855,7 +1858,7 @@ __global__ __launch_bounds__(256, 1) void gated_conv_wino4_kernel(const ConvKArg
                 Y[p][3] = d1 + 8.0f * d2 + R[p][5];
             }
         }
-        if (a.linear) {
+        if constexpr (LIN) {
             // training path: the pre-activations conv_f + b_f (channel c) and conv_m + b_m (channel Cout + c) of all four rows of
             // the tile — lanes 0..31 hold f, lanes 32..63 m — before anything is gated
             const f32x4 bb = hf ? bm : bf;
@@ -1868,11 +1871,11 @@ __global__ __launch_bounds__(256, 1) void gated_conv_wino4_kernel(const ConvKArg
                     const unsigned vo = in ? (unsigned)((((oyt + p) * a.outW + ox + px) * a.out_cstride + chan) * 4) : OOR;
                     __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, Y[p][px] + bb), out_rsrc, vo, 0, 0);
                 }
-            if (!a.out_gated) {                                        // dgrad: nothing to gate
-                step_tile(by, bx);
-                __builtin_amdgcn_s_setprio(0);
-                continue;
-            }
+        }
+        if constexpr (LIN == 2) {                                      // dgrad: nothing to gate
+            step_tile(by, bx);
+            __builtin_amdgcn_s_setprio(0);
+            continue;
         }
         // lanes 0..31 hold conv_f, lanes 32..63 conv_m: exchange rows (py, py + 2) so that the lower half-wave owns rows 0, 1 and
         // the upper half rows 2, 3 of the tile, f in one register and m in the other
@@ -1915,7 +1918,7 @@ __global__ __launch_bounds__(256, 1) void gated_conv_wino4_kernel(const ConvKArg
 #pragma unroll
                     for (int k = 0; k < 4; ++k) sg[k] = __builtin_amdgcn_rcpf(t[k]);
                     f32x4 v = (f * sg) * sc + sh + rv[py][px];
-                    if (a.linear) {                                    // the gated output, zero on the separator rows of a stacked batch
+                    if constexpr (LIN) {                               // the gated output, zero on the separator rows of a stacked batch
                         if (a.blk_h > 0 && (oy + py) % a.blk_h >= a.blk_valid) v = f32x4{0.f, 0.f, 0.f, 0.f};
                         __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), res_rsrc, rvoff[py][px], 0, 0);
                         continue;
@@ -2773,7 +2776,8 @@ int launch_gated_conv(const read_conv_desc *d, hipStream_t stream)
         a.wino_dby = (nwg / groups) / a.tiles_x;
         a.wino_dbx = (nwg / groups) % a.tiles_x;
         a.trace = nullptr;
-        conv_fn fn4 = d->mul ? gated_conv_wino4_kernel<true> : gated_conv_wino4_kernel<false>;
+        conv_fn fn4 = d->linear ? (d->out_gated ? gated_conv_wino4_kernel<false, 0, 1> : gated_conv_wino4_kernel<false, 0, 2>) : d->mul ? gated_conv_wino4_kernel<true> : gated_conv_wino4_kernel<false>;
+        READ_CHECK_ARG(!d->linear || !d->mul, "read_gated_conv_forward: linear launches take no multiplier");
 #ifdef READ_DEBUG_KNOBS
         if (!d->mul && g_abl) {
             switch (g_abl) {
