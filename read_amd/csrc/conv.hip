@@ -1957,7 +1957,10 @@ __global__ __launch_bounds__(256, 1) void gated_conv_wino4_kernel(const ConvKArg
 // four k8 steps per tile and is refilled four steps ahead of the MFMAs, across unit boundaries.  Sources of other levels
 // (nearest resampling, unet.py:239-254) are addressed per lane.  Measured next to the LDS-tiled kernels in
 // profiles/README.md (the 1x1 layers are short-K: their time is the epilogue and HBM traffic, not MFMAs).
-template <int PT, int GW>
+// FULLQ: Cin % 32 == 0 (whole quads of k8 steps): the ring refill and the MFMA group of a step then sit in straight-line code.
+// With the `step < nsteps` tests in the loop hipcc's waitcnt pass loses count of the loads in flight and puts s_waitcnt vmcnt(0)
+// in front of every MFMA group AND behind every refill (seen in the ISA): the four-steps-ahead ring then prefetches nothing.
+template <int PT, int GW, bool FULLQ = false>
 __global__ __launch_bounds__(256, (PT * GW >= 4 ? 2 : 3)) void gated_conv_px_kernel(const ConvKArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) float4 wl[];      // [k8 step][2 GW tiles (f, m per group)][lane]
@@ -1997,7 +2000,7 @@ __global__ __launch_bounds__(256, (PT * GW >= 4 ? 2 : 3)) void gated_conv_px_ker
     };
     float4 ring[4][PT];
     auto load_step = [&](int slot) {
-        if (lstep < nsteps) {
+        if (FULLQ || lstep < nsteps) {
 #pragma unroll
             for (int pt = 0; pt < PT; ++pt) {
                 const int sy = (ly[pt] << lsd.sl) >> lsd.sr, sx = (lx[pt] << lsd.sl) >> lsd.sr;
@@ -2042,7 +2045,7 @@ __global__ __launch_bounds__(256, (PT * GW >= 4 ? 2 : 3)) void gated_conv_px_ker
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
                 const int st = 4 * q + e;
-                if (st < nsteps) {
+                if (FULLQ || st < nsteps) {
                     const int sn = st + 1 < nsteps ? st + 1 : 0;     // next step's weights (the unit's first again at the end)
 #pragma unroll
                     for (int t = 0; t < T; ++t) w[(e + 1) & 1][t] = wl[(sn * T + t) * 64 + lane];
@@ -2645,10 +2648,13 @@ int launch_gated_conv(const read_conv_desc *d, hipStream_t stream)
             const int want = ceil_div(a.n_units, 4);
             per_set = per_set < 1 ? 1 : per_set;
             per_set = per_set < want ? per_set : want;
-            conv_fn fn = gw == 2 ? (wide ? gated_conv_px_kernel<2, 2> : gated_conv_px_kernel<1, 2>)
-                                 : (wide ? gated_conv_px_kernel<4, 1> : gated_conv_px_kernel<2, 1>);
-            static bool attr_set[4] = {false, false, false, false};
-            const int vi = (gw == 2 ? 2 : 0) + (wide ? 1 : 0);
+            const bool fullq = nsteps % 4 == 0;
+            conv_fn fn = gw == 2 ? (wide ? (fullq ? gated_conv_px_kernel<2, 2, true> : gated_conv_px_kernel<2, 2>)
+                                         : (fullq ? gated_conv_px_kernel<1, 2, true> : gated_conv_px_kernel<1, 2>))
+                                 : (wide ? (fullq ? gated_conv_px_kernel<4, 1, true> : gated_conv_px_kernel<4, 1>)
+                                         : (fullq ? gated_conv_px_kernel<2, 1, true> : gated_conv_px_kernel<2, 1>));
+            static bool attr_set[8] = {false, false, false, false, false, false, false, false};
+            const int vi = (gw == 2 ? 2 : 0) + (wide ? 1 : 0) + (fullq ? 4 : 0);
             if (!attr_set[vi]) {                                    // 64 KiB of dynamic LDS at Cin = 256
                 READ_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024));
                 attr_set[vi] = true;
