@@ -471,6 +471,7 @@ def run_train(a, dev, street=None, steps=None, warm=None, cpu_timing=True, do_ve
     t0 = time.perf_counter()
     for i in range(steps):
         loss = step(warm + i)
+    dt_host = time.perf_counter() - t0                             # the host has enqueued everything; the device may still be busy
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
     fwd_flops = 187.06e9 * B                                      # conv MACs x 2 at 256x256, measured on the reference module
@@ -489,6 +490,7 @@ def run_train(a, dev, street=None, steps=None, warm=None, cpu_timing=True, do_ve
                         "traffic": None, "flops_per_step": 3.0 * fwd_flops,
                         "note": "3 x the forward convolution FLOPs of 8 crops / wall time of a step (host-side autograd "
                                 "bookkeeping included)"},
+           "host_enqueue_ms_per_step": 1e3 * dt_host / steps,      # close to ms_per_step = the step is bound by the host side
            "final_loss": float(loss.detach()), "tuning": _lib.tuning_state(), "cpu_baseline": base, "verified": verified}
     pipe.dataset_unload([DS()])
     return out

@@ -451,52 +451,63 @@ __global__ __launch_bounds__(64) void wgrad_mfma_kernel(const float *__restrict_
     // One k-step = two output pixels (px = 2 p + kk) of one row.  Operands run two steps ahead of the MFMAs (a ring of three
     // register sets: one step of NT MFMAs, ~0.25 us, does not cover an L2 round trip).  The fetch cursor (row, pixel pair) is
     // wave-uniform and advanced with scalar arithmetic; for a pair whose taps all fall inside the image — all but the first
-    // and last pair of a row and the first / last rows — a lane's NT loads share ONE 32-bit offset on NT scalar bases
-    // (tensor + tap offset), i.e. one VALU add per step instead of a bounds test and an address per tap.  (The first version
+    // and last pair of a row and the first / last rows — a lane's NT loads share ONE 32-bit offset, the tap offsets are scalar
+    // (buffer_load ... offen with an SGPR offset), i.e. one VALU add per step instead of a bounds test and an address per tap.  (The first version
     // derived (row, pair) from a 64-bit step index by division and tested every tap: the wave spent more issue slots on
     // addresses than on MFMAs, 18 TF.)
     const int n_pairs = (outW + 1) >> 1;
     const int cil = ci_ok ? ci0 + i : Cin - 1, col = co_ok ? co0 + i : C2 - 1;      // padded rows / columns are never stored
-    const char *xb[NT];
     int tky[NT], tkx[NT];
 #pragma unroll
     for (int t = 0; t < NT; ++t) {
         const int tap = CIB ? 0 : (int)blockIdx.y * NT + t;
         tky[t] = tap / ksize;
         tkx[t] = tap - tky[t] * ksize;
-        xb[t] = reinterpret_cast<const char *>(x) + (((long long)tky[t] * inW + tkx[t]) * Cin + (CIB ? 32 * t : 0)) * 4;
     }
     const unsigned lane_x = (unsigned)(kk * stride * Cin + cil), lane_d = (unsigned)(kk * C2 + col);
     int f_oy = y_begin, f_p = 0;
-    auto ld = [](const char *sbase, unsigned voff) {     // (scalar base) + (32-bit lane byte offset): global_load_dword v, voff, s[base]
-        asm volatile("" : "+v"(voff));
-        return *reinterpret_cast<const float *>(sbase + voff);
-    };
-    const char *const xc = reinterpret_cast<const char *>(x), *const dc = reinterpret_cast<const char *>(dfm);
+    // Both operands through buffer descriptors, and ONE set of load instructions for interior and border steps alike: the two
+    // cases only differ in the offsets they compute (a border lane that has nothing to read carries an out-of-range offset and
+    // gets zeros).  With the loads inside the two branches hipcc's waitcnt pass could not count them across the merge and drained
+    // every load in flight once per RING steps (s_waitcnt vmcnt(0) in front of the first MFMA group of each unrolled iteration,
+    // right behind the fetch it had just issued) — the ring hid one step of latency in five.
+    constexpr unsigned OOR = 0x80000000u;                                          // tensors are below 2 GiB (read_conv_wgrad)
+    const auto xrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(x), 0, (unsigned)(inH * inW * Cin) * 4u, 0x00020000);
+    const auto drs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(dfm), 0, (unsigned)(outH * outW * C2) * 4u, 0x00020000);
+    int tapoff[NT];
+#pragma unroll
+    for (int t = 0; t < NT; ++t) tapoff[t] = ((tky[t] * inW + tkx[t]) * Cin + (CIB ? 32 * t : 0)) * 4;
     auto fetch = [&](float (&a)[NT], float &b) {
         const bool live = f_oy < y_end;
         const int oy = live ? f_oy : y_begin, p = live ? f_p : 0;
         const int iy0 = oy * stride - pad, ix0 = 2 * p * stride - pad;             // tap (0,0) of the pair's first pixel
         const bool inside = live && iy0 >= 0 && iy0 + ksize - 1 < inH && ix0 >= 0 && ix0 + stride + ksize - 1 < inW &&
                             2 * p + 1 < outW && (CIB || taps == NT * (int)gridDim.y);
-        if (inside) {                                                            // wave-uniform
+        unsigned vo[NT], vob;
+        int so[NT];
+        if (inside) {                                                            // wave-uniform: one lane offset, scalar tap offsets
             const unsigned off = ((unsigned)((iy0 * inW + ix0) * Cin) + lane_x) * 4u;
 #pragma unroll
-            for (int t = 0; t < NT; ++t) a[t] = ld(xb[t], off);
-            b = ld(dc, ((unsigned)((oy * outW + 2 * p) * C2) + lane_d) * 4u);
+            for (int t = 0; t < NT; ++t) {
+                vo[t] = off;
+                so[t] = tapoff[t];
+            }
+            vob = ((unsigned)((oy * outW + 2 * p) * C2) + lane_d) * 4u;
         } else {
             const int px = 2 * p + kk;
             const bool p_ok = live && px < outW;
-            const float bv = ld(dc, p_ok ? (unsigned)((oy * outW + px) * C2 + col) * 4u : 0u);
-            b = (p_ok && co_ok) ? bv : 0.0f;
+            vob = (p_ok && co_ok) ? (unsigned)((oy * outW + px) * C2 + col) * 4u : OOR;
 #pragma unroll
             for (int t = 0; t < NT; ++t) {
                 const int iy = iy0 + tky[t], ix = px * stride - pad + tkx[t];
                 const bool ok = p_ok && ci_ok && (CIB || (int)blockIdx.y * NT + t < taps) && iy >= 0 && iy < inH && ix >= 0 && ix < inW;
-                const float v = ld(xc, ok ? (unsigned)((iy * inW + ix) * Cin + cil + (CIB ? 32 * t : 0)) * 4u : 0u);
-                a[t] = ok ? v : 0.0f;
+                vo[t] = ok ? (unsigned)((iy * inW + ix) * Cin + cil + (CIB ? 32 * t : 0)) * 4u : OOR;
+                so[t] = 0;
             }
         }
+#pragma unroll
+        for (int t = 0; t < NT; ++t) a[t] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(xrs, vo[t], so[t], 0));
+        b = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(drs, vob, 0, 0));
         if (++f_p == n_pairs) {
             f_p = 0;
             ++f_oy;
@@ -994,8 +1005,8 @@ extern "C" int read_conv_wgrad(const float *x, int inH, int inW, int Cin, const 
     const int outH = (inH + 2 * pad - ksize) / stride + 1, outW = (inW + 2 * pad - ksize) / stride + 1;
     READ_CHECK_ARG(outH >= 1 && outW >= 1, "read_conv_wgrad: empty output");
     // the kernel addresses both tensors with 32-bit byte offsets (plus the largest tap offset)
-    READ_CHECK_ARG(((long long)inH + ksize) * inW * Cin * 4 < (1ll << 32) && (long long)outH * outW * 2 * Cp * 4 < (1ll << 32),
-                   "read_conv_wgrad: tensors of 4 GiB and more are not supported");
+    READ_CHECK_ARG(((long long)inH + ksize) * inW * Cin * 4 < (1ll << 31) && (long long)outH * outW * 2 * Cp * 4 < (1ll << 31),
+                   "read_conv_wgrad: tensors of 2 GiB and more are not supported");
     const WgradPlan p = wgrad_plan(Cin, Cout, ksize, outH);
     READ_CHECK_ARG(scratch_floats >= p.partial_floats, "read_conv_wgrad: scratch %zu < %zu floats", scratch_floats, p.partial_floats);
     const dim3 grid((unsigned)(p.tiles_ci * p.tiles_co), (unsigned)p.tap_groups, (unsigned)p.splits);

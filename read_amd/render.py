@@ -106,16 +106,24 @@ class MyRender:
         tm = total_matrix(proj, view)                                          # myrender.py:28-30
         dev = _lib.require_gpu()
         sizes = level_sizes(W, H, levels)
-        index = [torch.zeros((B, h, w), dtype=torch.int32, device=dev) for (w, h) in sizes]
-        depth = [torch.zeros((B, h, w), dtype=torch.float32, device=dev) for (w, h) in sizes]
-        for ds_id in self.ds_ids:
-            sel = torch.where(ids_t == ds_id)[0]
-            if sel.numel() == 0:
-                continue
-            i_l, d_l = self.rasterizers[ds_id].render(tm[sel.numpy()], W, H, levels)
-            for l in range(levels):
-                index[l][sel.to(dev)] = i_l[l]
-                depth[l][sel.to(dev)] = d_l[l]
+        if len(self.ds_ids) == 1 and bool((ids_t == self.ds_ids[0]).all()):
+            # one scene (the usual batch): the rasteriser's outputs ARE the batch — no index tensors on the device, no copies
+            # (a host -> device copy of a pageable tensor blocks the host until the stream has drained: ten of them per call
+            # serialised the training loop's host and device sides)
+            index, depth = self.rasterizers[self.ds_ids[0]].render(tm, W, H, levels)
+            index, depth = list(index), list(depth)
+        else:
+            index = [torch.zeros((B, h, w), dtype=torch.int32, device=dev) for (w, h) in sizes]
+            depth = [torch.zeros((B, h, w), dtype=torch.float32, device=dev) for (w, h) in sizes]
+            for ds_id in self.ds_ids:
+                sel = torch.where(ids_t == ds_id)[0]
+                if sel.numel() == 0:
+                    continue
+                i_l, d_l = self.rasterizers[ds_id].render(tm[sel.numpy()], W, H, levels)
+                sel_d = sel.to(dev)
+                for l in range(levels):
+                    index[l][sel_d] = i_l[l]
+                    depth[l][sel_d] = d_l[l]
         self.last_index = index
         out_dict, depth_dict = {'id': ids}, {}
         for l, k in enumerate(input_format):

@@ -116,9 +116,11 @@ class _RangeCheck:
         self.pending = []          # (event, pinned flag tensor, n)
         self.free = []             # pinned one-int buffers whose copy has landed
 
-    def queue(self, ids, n):
+    def queue(self, ids, n, signed=False):
+        """signed: ids may also be negative (ids that did not come from the rasteriser) — a negative id counts as id n."""
         flag = self.free.pop() if self.free else torch.empty(1, dtype=torch.int32).pin_memory()
-        flag.copy_(ids.max().to(torch.int32).reshape(1), non_blocking=True)
+        worst = (torch.where(ids < 0, n, ids) if signed else ids).max()
+        flag.copy_(worst.to(torch.int32).reshape(1), non_blocking=True)
         ev = torch.cuda.Event()
         ev.record()
         self.pending.append((ev, flag, n))
@@ -218,6 +220,7 @@ class PointTexture(Texture):
         self._rows = None
         self._rows_version = None
         self.sparse_training = False        # True: gradients go to grad_rows() + touched ids (SparseDescriptorRMSprop)
+        self._range_check = _RangeCheck()   # asynchronous id range check of forward() (raises at the next lookup / check_ids())
         self._grad_rows = None
         self._touched = []
         self._pending = []                  # (ids, gradient rows) pairs of backward passes the optimizer has not consumed
@@ -342,8 +345,10 @@ class PointTexture(Texture):
         if not self.texture_.is_cuda:
             raise _lib.ReadHipError("PointTexture lookups run on the GPU: move the module with .cuda()")
         ids = ids.to(self.texture_.device)
-        if int(ids.max()) >= self.texture_.shape[-1] or int(ids.min()) < 0:
-            raise IndexError(f"point id out of range for a descriptor table of {self.texture_.shape[-1]} points")
+        # out-of-range ids are reported one lookup late (or at check_ids()): two int(ids.max()) / int(ids.min()) round trips per
+        # lookup were 80 device -> host synchronisations per training iteration (8 items x 5 levels); the kernels clamp
+        self._range_check.poll()
+        self._range_check.queue(ids, self.texture_.shape[-1], signed=True)
         if torch.is_grad_enabled() and self.texture_.requires_grad:
             sample = (_GatherRowsFn.apply(self.texture_, ids, self) if self.sparse_training
                       else _GatherFn.apply(self.texture_, ids))
@@ -358,3 +363,7 @@ class PointTexture(Texture):
     def forward_pyramid(self, idx_levels):
         """Fast path: int32 index maps of all scales -> NHWC feature maps, one launch."""
         return gather_pyramid(self.rows(), idx_levels, self.activation)
+
+    def check_ids(self):
+        """Wait for the queued id range checks of forward() and raise IndexError if one of them failed."""
+        self._range_check.flush()

@@ -188,7 +188,8 @@ def test_out_of_range_ids_raise_without_a_sync_per_frame(hip):
     from read_amd.texture import PointTexture
     W, H, N = 64, 48, 500
     net = UNet()
-    model = NetAndTexture(net, {0: PointTexture(8, N, init_method='rand')})
+    tex = PointTexture(8, N, init_method='rand')
+    model = NetAndTexture(net, {0: tex})
     model.load_textures(0)
     model.cuda().eval()
     good = {'id': 0}
@@ -205,6 +206,18 @@ def test_out_of_range_ids_raise_without_a_sync_per_frame(hip):
             model.check_ids()
         model(dict(good))
         model.check_ids()
+    # ... and the module-level lookup (the per-item training path: PointTexture.forward) queues its verdict the same way
+    ids_ok = torch.randint(0, N, (1, 1, 12, 20), device="cuda").float()
+    ids_bad = ids_ok.clone()
+    ids_bad[0, 0, 2, 3] = -1.0
+    with torch.no_grad():
+        tex(ids_ok)
+        tex.check_ids()
+        tex(ids_bad)
+        with pytest.raises(IndexError):
+            tex.check_ids()
+        tex(ids_ok)
+        tex.check_ids()
 
 
 def test_bilinear_down_equals_torch_interpolate(hip):
