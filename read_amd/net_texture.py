@@ -93,9 +93,14 @@ class NetAndTexture(nn.Module):
             # training: sample every item (each may use its own texture), then ONE network call for the batch — the HIP
             # training graph stacks the items into a single tall image (read_amd/train.py), so a 256x256 crop does not
             # leave most of the chip idle; the per-item results are the same as item-by-item calls
-            per_item = [self._sample_item(self._modules[str(tid)], {k: v[b][None] for k, v in inputs.items()})
-                        for b, tid in enumerate(texture_ids)]
-            net_input = [torch.cat([it[l] for it in per_item], 0) for l in range(len(per_item[0]))]
+            if len(set(texture_ids)) == 1:
+                # one scene for the whole batch (the usual case): one lookup per scale instead of one per item and scale —
+                # the same values, a fifth of a training step's host time less (8 items x 5 scales of Python per step)
+                net_input = self._sample_item(self._modules[str(texture_ids[0])], inputs)
+            else:
+                per_item = [self._sample_item(self._modules[str(tid)], {k: v[b][None] for k, v in inputs.items()})
+                            for b, tid in enumerate(texture_ids)]
+                net_input = [torch.cat([it[l] for it in per_item], 0) for l in range(len(per_item[0]))]
             out = self.net(*net_input, **kwargs)
             return (out, net_input) if kwargs.get('return_input') else out
         for b, tid in enumerate(texture_ids):

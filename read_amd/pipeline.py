@@ -83,6 +83,34 @@ class Pipeline:
         return None
 
 
+class _DeviceAdam(optim.Adam):
+    """torch.optim.Adam (READ/pipelines/ogl.py:99) that switches to torch's fused implementation at its first step when every
+    parameter lives on the GPU by then.  The pipeline creates its optimizer before `model.cuda()` (as the reference does), where
+    `fused=True` is refused; the per-step Python of the multi-tensor implementation over the UNet's 594 tensors was 15 ms of a
+    60 ms training step.  Same update rule, same hyper-parameters, same state_dict.
+    The fused kernel writes the parameters WITHOUT advancing their version counters (seen on torch 2.10: `_version` stays put,
+    the foreach implementation bumps it) — every cache keyed on `_version` (the packed fragments of read_amd/train.py, the
+    inference plan's weights key) would go stale, so the stepped parameters are bumped here."""
+
+    def step(self, closure=None):
+        if not self.state:                                        # nothing has been stepped yet: the state is created below
+            on_gpu = all(p.is_cuda for g in self.param_groups for p in g['params'])
+            for g in self.param_groups:
+                if g.get('fused') is None and not g.get('foreach'):
+                    g['fused'] = True if on_gpu else None
+        stepped = [p for g in self.param_groups if g.get('fused') for p in g['params'] if p.grad is not None]
+        out = super().step(closure)
+        if stepped:
+            inc = getattr(torch._C, '_increment_version', None)
+            if inc is not None:
+                inc(stepped)
+            else:
+                with torch.no_grad():
+                    for p in stepped:
+                        p.add_(0)
+        return out
+
+
 class TexturePipeline(Pipeline):
     def export_args(self, parser):
         add = getattr(parser, 'add', parser.add_argument)
@@ -126,7 +154,7 @@ class TexturePipeline(Pipeline):
             for ds in self.ds_train:
                 assert ds.scene_data['pointcloud'] is not None, 'set pointcloud'
                 textures[ds.id] = self._texture(args, ds.scene_data['pointcloud']['xyz'].shape[0])
-            self.optimizer = optim.Adam(net.parameters(), lr=args.lr)
+            self.optimizer = _DeviceAdam(net.parameters(), lr=args.lr)
             self.sparse_textures = bool(getattr(args, 'sparse_texture_optimizer', True)) and not getattr(args, 'reg_weight', 0.)
             for tex in textures.values():
                 tex.sparse_training = self.sparse_textures
