@@ -171,3 +171,23 @@ def test_pipeline_inference_create_and_netandtexture_bookkeeping():
         pcpr.forward(torch.zeros(4, 3), torch.zeros(4, 4), 8, 8, 512)     # "batch_size check": total_m must be 3-D
     with pytest.raises(RuntimeError):
         pcpr.forward(torch.zeros(4, 3, dtype=torch.float64), torch.zeros(1, 4, 4), 8, 8, 512)
+
+
+def test_pipeline_optimizer_is_adam_on_the_cpu():
+    """TexturePipeline's optimizer (read_amd.pipeline._DeviceAdam) only switches to torch's fused kernel when every parameter is
+    on the GPU at its first step; on the CPU it is torch.optim.Adam step for step (same state_dict keys, same trajectory)."""
+    from read_amd.pipeline import _DeviceAdam
+    torch.manual_seed(3)
+    a = [torch.nn.Parameter(torch.randn(7)), torch.nn.Parameter(torch.randn(3, 4))]
+    b = [torch.nn.Parameter(p.detach().clone()) for p in a]
+    oa, ob = _DeviceAdam(a, lr=1e-2), torch.optim.Adam(b, lr=1e-2)
+    for _ in range(3):
+        for p, q in zip(a, b):
+            g = torch.randn_like(p)
+            p.grad, q.grad = g.clone(), g.clone()
+        oa.step()
+        ob.step()
+    assert not oa.param_groups[0].get('fused')
+    for p, q in zip(a, b):
+        assert torch.equal(p, q)
+    assert oa.state_dict()['param_groups'][0].keys() == ob.state_dict()['param_groups'][0].keys()
