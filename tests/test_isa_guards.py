@@ -1,0 +1,75 @@
+"""CPU (hipcc cross-compiles): properties of the generated gfx950 code that round 3's measurements depend on and that a source
+change can silently lose — found in the ISA, not in any test result (profiles/README.md):
+
+  * the Winograd F(4x4,3x3) inference kernels keep their cross-unit pipeline: no `s_waitcnt vmcnt(0)` at the head of the unit
+    loop (a second path through the epilogue once put one there: -1.8 % frames/s), no scratch, one wave per SIMD's registers;
+  * the wgrad kernel's ring of five is counted by the compiler: `vmcnt(40)` in front of its MFMA groups, not a drain;
+  * the whole-quad 1x1 pixel-lane kernel waits for `vmcnt(3)` in front of its MFMA groups.
+"""
+import os
+import re
+import subprocess
+
+import pytest
+
+from read_amd import build as hip_build
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _asm(src, tmp_path_factory):
+    out = tmp_path_factory.getbasetemp() / (src + ".s")
+    if not out.exists():
+        cmd = [hip_build._hipcc()] + hip_build.FLAGS + hip_build.PER_FILE.get(src, []) + \
+              ["-S", "--cuda-device-only", os.path.join(hip_build.CSRC, src), "-o", str(out)]
+        subprocess.check_call(cmd, stderr=subprocess.DEVNULL)
+    return out.read_text()
+
+
+def _function(asm, mangled_part):
+    m = re.search(r"^(_Z\S*" + re.escape(mangled_part) + r"\S*):\s*;", asm, flags=re.M)
+    assert m, mangled_part
+    body = asm[m.start():]
+    return m.group(1), body[:body.index(".Lfunc_end")]
+
+
+def _meta(asm, name, key):
+    m = re.search(r"\.set " + re.escape(name) + r"\." + key + r", (\d+)", asm)
+    assert m, (name, key)
+    return int(m.group(1))
+
+
+@pytest.fixture(scope="module")
+def conv_asm(tmp_path_factory):
+    return _asm("conv.hip", tmp_path_factory)
+
+
+def test_f4_inference_kernels_keep_the_cross_unit_pipeline(conv_asm):
+    for variant in ("gated_conv_wino4_kernelILb0ELi0ELi0E", "gated_conv_wino4_kernelILb1ELi0ELi0E"):
+        name, body = _function(conv_asm, variant)
+        assert _meta(conv_asm, name, "private_seg_size") == 0, "scratch in the F(4x4) kernel"
+        assert _meta(conv_asm, name, "num_vgpr") == 256 and _meta(conv_asm, name, "num_agpr") >= 144
+        lines = body.split("\n")
+        heads = [i for i, l in enumerate(lines) if "Loop Header: Depth=1" in l]
+        assert heads, "unit loop not found"
+        head = "\n".join(lines[heads[0]:heads[0] + 12])
+        assert "v_mfma_f32_16x16x4_f32" in head                                  # the loop starts with the first stage's MFMAs
+        assert "vmcnt(0)" not in head, "the unit loop drains the previous unit's stores and loads:\n" + head
+        assert body.count("v_mfma_f32_16x16x4_f32") == 288                        # first + steady stage, 144 each, nothing duplicated
+
+
+def test_training_kernels_count_their_loads(conv_asm, tmp_path_factory):
+    for variant in ("gated_conv_wino4_kernelILb0ELi0ELi1E", "gated_conv_wino4_kernelILb0ELi0ELi2E"):
+        name, body = _function(conv_asm, variant)
+        lines = body.split("\n")
+        head = "\n".join(lines[[i for i, l in enumerate(lines) if "Loop Header: Depth=1" in l][0]:][:12])
+        assert "vmcnt(0)" not in head and _meta(conv_asm, name, "private_seg_size") == 0
+    train = _asm("train.hip", tmp_path_factory)
+    _, body = _function(train, "wgrad_mfma_kernelILi9ELb0E")
+    assert len(re.findall(r"s_waitcnt vmcnt\(40\)\s*\n\s*v_mfma_f32_32x32x2_f32", body)) >= 5, \
+        "the wgrad ring is no longer four steps of ten loads ahead of its MFMAs"
+
+
+def test_pixel_lane_kernel_prefetches(conv_asm):
+    _, body = _function(conv_asm, "gated_conv_px_kernelILi1ELi2ELb1E")
+    assert len(re.findall(r"s_waitcnt vmcnt\(3\)[^\n]*\n\s*v_mfma_f32_32x32x2_f32", body)) >= 4
