@@ -405,7 +405,9 @@ def run_train(a, dev, street=None, steps=None, warm=None, cpu_timing=True, do_ve
                     maps[l].append(il[l])
             maps = [np.stack(m) for m in maps]
             feats = [tex_r[0][:, torch.from_numpy(m.astype(np.int64))].permute(1, 0, 2, 3) for m in maps]
-            out = unet_torch.unet_forward(st_r, *feats[:4], training=bn_train)
+            # .train(): the reference runs the net once per batch item (READ/models/compose.py:137-176): per-item statistics
+            out = (unet_torch.unet_forward_per_item(st_r, *feats[:4], training=True) if bn_train
+                   else unet_torch.unet_forward(st_r, *feats[:4]))
             loss = Fnn.huber_loss(out, target) * 1e4
             loss.backward()
             return maps, loss

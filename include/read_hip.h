@@ -164,6 +164,12 @@ int read_splat_forward_gl(const float *xyz, int64_t n, const float *M_host, int 
 
 /* out[i] = (float)idx[i] — the reference's index image dtype (ids >= 2^24 round). */
 int read_index_to_float(const int32_t *idx, int64_t count, float *out, void *stream);
+/* Projection alone (point_render.cu:110-147 without the z-test of :149-166): pixel[i] = yy * W + xx of point i under the
+ * row-major 4x4 matrix M_host, or -1 when the point is clipped or falls outside the image; depth[i] (may be NULL) = (nz + 1) / 2
+ * as the rasteriser computes it, also for rejected points.  The same device function as every rasteriser pass — per-point
+ * visibility for a host, and the entry the division test drives (tests/test_gpu_splat.py). */
+int read_splat_project_points(const float *xyz, int64_t n, const float *M_host, int W, int H, int32_t *pixel, float *depth,
+                              void *stream);
 
 /* ---------------------------------------------------------------- descriptor gather / scatter */
 
@@ -325,18 +331,25 @@ int read_bn_param_grads(int Cout, const float *sums, const float *mean, const fl
  * train.py:271-279,450).  read_bn_train_forward: g = act(f) * sigmoid(m) [pixels][C] (produced with an identity BatchNorm in the
  * params block: scale 1, shift 0) is normalised IN PLACE with the per-channel mean / biased variance of the valid pixels
  * (fp64 accumulation): y = (g - mean) / sqrt(var + eps) * gamma + beta; separator rows of a stacked batch stay zero and do
- * not count.  stat[2][C] receives {mean, biased var} (kept for the backward pass), params (4 * pad32(C) floats) receives the
- * scale / shift rows, running_mean / running_var (may be NULL) move by `momentum` (variance unbiased, n / (n - 1)), scratch
- * = 2 * C doubles.
+ * not count.
+ * `groups` = number of statistic groups: 1 — the whole stacked batch is ONE BatchNorm batch (what nn.BatchNorm2d does with a
+ * (B,C,h,w) tensor: UNet.forward on a batch); B = the number of stacked items — every item is normalised with ITS OWN statistics
+ * and the running buffers move B times, in item order: the reference's NetAndTexture.forward calls the net once per batch item
+ * (READ/models/compose.py:137-176), so its BatchNorm layers see N = 1.  stat[groups][2][C] receives {mean, biased var} per group
+ * (kept for the backward pass), scale_shift (groups * 2 * pad32(C) floats) the scale / shift rows, running_mean / running_var
+ * (may be NULL) move by `momentum` once per group (variance unbiased, n / (n - 1)), scratch = groups * 2 * C doubles.
  * read_gate_backward_bn: read_gate_backward through that BatchNorm: two passes (sums of dy and dy * g, then
- * dg = gamma r (dy - mean(dy) - xhat mean(dy xhat))); sums as read_gate_backward, so read_bn_param_grads(sums, stat, stat + C)
- * gives db_f, db_m, dgamma, dbeta; abc = 3 * Cout floats of scratch. */
-int read_bn_train_forward(float *g_to_y, int64_t pixels, int C, int W, int block_h, int valid_h, const float *gamma,
+ * dg = gamma r (dy - mean(dy) - xhat mean(dy xhat))) per group; sums[groups][4][Cout] as read_gate_backward per group, so
+ * read_bn_param_grads_groups(Cout, groups, sums, stat, ...) gives db_f, db_m, dgamma, dbeta (accumulating, summed over the
+ * groups); abc = groups * 3 * Cout floats of scratch. */
+int read_bn_train_forward(float *g_to_y, int64_t pixels, int C, int W, int block_h, int valid_h, int groups, const float *gamma,
                           const float *beta, float eps, float momentum, float *running_mean, float *running_var, float *stat,
-                          float *params, double *scratch, void *stream);
+                          float *scale_shift, double *scratch, void *stream);
 int read_gate_backward_bn(const float *dy, const float *fm, int64_t pixels, int Cout, const float *params, int elu, float *dfm,
-                          float *sums, int W, int block_h, int valid_h, const float *stat, const float *gamma, float eps,
-                          float *abc, void *stream);
+                          float *sums, int W, int block_h, int valid_h, int groups, const float *stat, const float *gamma,
+                          float eps, float *abc, void *stream);
+int read_bn_param_grads_groups(int Cout, int groups, const float *sums, const float *stat, float eps, float *dbf, float *dbm,
+                               float *dgamma, float *dbeta, void *stream);
 size_t read_conv_dgrad_generic_floats(int Cin, int Cout, int ksize);
 int read_conv_dgrad_generic(const float *dfm, int outH, int outW, int Cin, int Cout, int ksize, int stride, const float *wf,
                             const float *wm, float *wscratch, int inH, int inW, float *dx, void *stream);

@@ -15,5 +15,5 @@ build_ref.sh    compiles the reference's own DepthProject source for the CPU -> 
 """
 from .raster_c import (  # noqa: F401
     raster_level, raster_multiscale, index_to_float, gather_chw, gather_backward_chw, lib_path,
-    raster_level_gl, drop_mask, perturb_array, drop_threshold,
+    raster_level_gl, drop_mask, perturb_array, drop_threshold, project_points,
 )

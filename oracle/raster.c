@@ -66,6 +66,25 @@ static inline int project_point(const float *p, const float *M, int W, int H,
     return 1;
 }
 
+/* The projection alone for every point: pixel[i] = yy * W + xx or -1 (rejected), depth[i] (accepted points only; 0 otherwise).
+ * The checker of read_splat_project_points — in particular of the shared-reciprocal form of the three divisions on the device. */
+void oracle_project_points(const float *xyz, int64_t n, const float *M, int W, int H, int32_t *pixel, float *depth, int threads)
+{
+#ifdef _OPENMP
+#pragma omp parallel for num_threads(threads > 0 ? threads : 1) schedule(static)
+#endif
+    for (int64_t i = 0; i < n; ++i) {
+        int pix = -1;
+        float d = 0.0f;
+        if (!project_point(xyz + 3 * i, M, W, H, &pix, &d)) {
+            pix = -1;
+            d = 0.0f;
+        }
+        pixel[i] = pix;
+        depth[i] = d;
+    }
+}
+
 /* Single level, single camera; serial in point order == canonical semantics.
  * out_index is int32 (the reference stores float(i); see raster_index_to_float). */
 void oracle_raster_level(const float *xyz, int64_t n, const float *M, int W, int H,

@@ -30,6 +30,8 @@ def _lib():
         L.oracle_raster_level_mt.argtypes = [f32p, C.c_int64, f32p, C.c_int, C.c_int, i32p, f32p, C.c_int]
         L.oracle_raster_multiscale.argtypes = [f32p, C.c_int64, f32p, C.c_int, C.c_int, C.c_int,
                                                i32p, f32p, C.c_int]
+        L.oracle_project_points.argtypes = [f32p, C.c_int64, f32p, C.c_int, C.c_int, i32p, f32p, C.c_int]
+        L.oracle_project_points.restype = None
         L.oracle_index_to_float.argtypes = [i32p, C.c_size_t, f32p]
         L.oracle_gather_chw.argtypes = [f32p, C.c_int64, C.c_int, i32p, C.c_size_t, f32p]
         L.oracle_gather_backward_chw.argtypes = [f32p, i32p, C.c_size_t, C.c_int, C.c_int64, f32p]
@@ -70,6 +72,17 @@ def raster_level(xyz, M, W, H, threads=1):
         _lib().oracle_raster_level(_p(xyz, C.c_float), xyz.shape[0], _p(M, C.c_float), W, H,
                                    _p(idx, C.c_int32), _p(dep, C.c_float))
     return idx, dep
+
+
+def project_points(xyz, M, W, H, threads=1):
+    """Projection alone (point_render.cu:110-147): per point the pixel index yy * W + xx (or -1: rejected) and the depth
+    (0 for rejected points)."""
+    xyz, M = _f32(xyz), _f32(M).reshape(16)
+    pix = np.empty(xyz.shape[0], np.int32)
+    dep = np.empty(xyz.shape[0], np.float32)
+    _lib().oracle_project_points(_p(xyz, C.c_float), xyz.shape[0], _p(M, C.c_float), W, H, _p(pix, C.c_int32),
+                                 _p(dep, C.c_float), threads)
+    return pix, dep
 
 
 def raster_multiscale(xyz, M, W, H, levels=5, threads=1):

@@ -130,6 +130,24 @@ def net_and_texture_forward(st, texture_1cn, index_maps):
     return unet_forward(st, *feats[:4])
 
 
+def net_and_texture_forward_batch(st, texture_1cn, index_maps, training=False):
+    """NetAndTexture.forward for a batch (compose.py:137-178): the net is called ONCE PER ITEM, in item order, and the results
+    are concatenated — so in .train() every BatchNorm layer normalises each item with that item's own statistics (a batch of
+    one) and its running buffers in `st` move once per item.  index_maps: per scale a (B,h,w) array / tensor of point ids."""
+    maps = [_t(m) for m in index_maps]
+    outs = []
+    for b in range(maps[0].shape[0]):
+        feats = [point_texture_forward(texture_1cn, m[b][None]) for m in maps[:4]]
+        outs.append(unet_forward(st, *feats, training=training))
+    return torch.cat(outs, 0)
+
+
+def unet_forward_per_item(st, x, x2, x4, x8, training=False):
+    """The same per-item loop over ready-made feature pyramids (B,8,h,w)."""
+    return torch.cat([unet_forward(st, x[b:b + 1], x2[b:b + 1], x4[b:b + 1], x8[b:b + 1], training=training)
+                      for b in range(x.shape[0])], 0)
+
+
 def psnr(a, b):
     """src/train.py:39-48: -10*log10(mean((a-b)^2))."""
     mse = torch.mean((_t(a).double() - _t(b).double()) ** 2).item()

@@ -67,6 +67,7 @@ SIGNATURES = {
     "read_splat_forward_cells": (_i, [_vp, _vp, _i64, C.POINTER(_f), _i, _i, _i, _i, _pp, _pp, _vp, _sz, _vp]),
     "read_splat_forward_gl": (_i, [_vp, _i64, C.POINTER(_f), _i, _i, _vp, _vp, _vp, _vp, _sz, _vp]),
     "read_index_to_float": (_i, [_vp, _i64, _vp, _vp]),
+    "read_splat_project_points": (_i, [_vp, _i64, C.POINTER(_f), _i, _i, _vp, _vp, _vp]),
     "read_texture_to_rows": (_i, [_vp, _i64, _i, _vp, _vp]),
     "read_rows_to_texture": (_i, [_vp, _i64, _i, _vp, _vp]),
     "read_gather_forward": (_i, [_vp, _i64, _i, _i, _pp, C.POINTER(_i64), _pp, _i, _vp]),
@@ -100,8 +101,9 @@ SIGNATURES = {
     "read_gate_forward": (_i, [_vp, _i64, _i, _vp, _i, _vp, _vp, _i, _i, _i, _vp]),
     "read_gate_backward": (_i, [_vp, _vp, _i64, _i, _vp, _i, _vp, _vp, _i, _i, _i, _vp]),
     "read_bn_param_grads": (_i, [_i, _vp, _vp, _vp, _f, _vp, _vp, _vp, _vp, _vp]),
-    "read_bn_train_forward": (_i, [_vp, _i64, _i, _i, _i, _i, _vp, _vp, _f, _f, _vp, _vp, _vp, _vp, _vp, _vp]),
-    "read_gate_backward_bn": (_i, [_vp, _vp, _i64, _i, _vp, _i, _vp, _vp, _i, _i, _i, _vp, _vp, _f, _vp, _vp]),
+    "read_bn_train_forward": (_i, [_vp, _i64, _i, _i, _i, _i, _i, _vp, _vp, _f, _f, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "read_gate_backward_bn": (_i, [_vp, _vp, _i64, _i, _vp, _i, _vp, _vp, _i, _i, _i, _i, _vp, _vp, _f, _vp, _vp]),
+    "read_bn_param_grads_groups": (_i, [_i, _i, _vp, _vp, _f, _vp, _vp, _vp, _vp, _vp]),
     "read_conv_dgrad_generic_floats": (_sz, [_i, _i, _i]),
     "read_conv_dgrad_generic": (_i, [_vp, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp, _i, _i, _vp, _vp]),
     "read_conv_wgrad_scratch_floats": (_sz, [_i, _i, _i, _i]),

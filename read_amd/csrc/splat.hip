@@ -53,6 +53,49 @@ struct Cam1 {
     float m[16];
 };
 
+// The three IEEE divisions of point_render.cu:119 (c0 / c3, c1 / c3, c2 / c3) with ONE reciprocal.
+// hipcc expands a correctly rounded fp32 a / b into  sb = v_div_scale(b), sa = v_div_scale(a), r = v_rcp(sb), e = fma(-sb, r, 1),
+// r = fma(e, r, r), q = sa r, t = fma(-sb, q, sa), q = fma(t, r, q), t = fma(-sb, q, sa), v_div_fmas(t, r, q), v_div_fixup — 11
+// instructions, 33 for a point (a quarter of pass A's vector instructions, and pass A is issue-bound).  v_div_scale only scales
+// when an exponent is extreme: for 2^-40 <= |b| <= 2^40 it returns b itself, and it returns a itself unless |a| < 2^-103 (then
+// |a / b| < 2^-63: n + 1 rounds to 1 whichever way the quotient was rounded — pixel and depth come out the same) or
+// |a| >= 2^56 |b| (then |a / b| > 1 on both paths, or inf / NaN: the point is rejected either way).  With nothing scaled
+// v_div_fmas is a plain fma and v_div_fixup returns its input, so the reciprocal and its Newton step (they depend on b alone)
+// can be shared and each quotient is the same five instructions on the same operands as in the compiler's expansion — the
+// same bits.  Outside the window the whole wave takes the compiler's divisions.  18 instead of 33 instructions per point;
+// tests/test_gpu_splat.py::test_shared_reciprocal_projection_is_ieee_division compares > 10^8 device points with the host's
+// IEEE divisions (random, window-edge, tiny, huge, zero and non-finite operands).
+__device__ __forceinline__ void div3_ieee(float a0, float a1, float a2, float b, float &q0, float &q1, float &q2)
+{
+    const float ab = fabsf(b);
+    const bool window = (ab >= 0x1p-40f) & (ab <= 0x1p40f);
+    if (__builtin_expect(__ballot(!window) == 0ull, 1)) {
+        float r = __builtin_amdgcn_rcpf(b);
+        const float e = __builtin_fmaf(-b, r, 1.0f);
+        r = __builtin_fmaf(e, r, r);
+        float t;
+        q0 = a0 * r;
+        q1 = a1 * r;
+        q2 = a2 * r;
+        t = __builtin_fmaf(-b, q0, a0);
+        q0 = __builtin_fmaf(t, r, q0);
+        t = __builtin_fmaf(-b, q1, a1);
+        q1 = __builtin_fmaf(t, r, q1);
+        t = __builtin_fmaf(-b, q2, a2);
+        q2 = __builtin_fmaf(t, r, q2);
+        t = __builtin_fmaf(-b, q0, a0);
+        q0 = __builtin_fmaf(t, r, q0);
+        t = __builtin_fmaf(-b, q1, a1);
+        q1 = __builtin_fmaf(t, r, q1);
+        t = __builtin_fmaf(-b, q2, a2);
+        q2 = __builtin_fmaf(t, r, q2);
+    } else {
+        q0 = a0 / b;
+        q1 = a1 / b;
+        q2 = a2 / b;
+    }
+}
+
 // point_render.cu:135-147 for one point and one camera; returns the pixel or -1.
 __device__ __forceinline__ int project_one(float x, float y, float z, const float *M, int W, int H,
                                            float &depth, int &xx_out, int &yy_out)
@@ -61,7 +104,8 @@ __device__ __forceinline__ int project_one(float x, float y, float z, const floa
     const float c1 = M[4] * x + M[5] * y + M[6] * z + M[7] * 1.0f;
     const float c2 = M[8] * x + M[9] * y + M[10] * z + M[11] * 1.0f;
     const float c3 = M[12] * x + M[13] * y + M[14] * z + M[15] * 1.0f;
-    const float nx = c0 / c3, ny = c1 / c3, nz = c2 / c3;
+    float nx, ny, nz;
+    div3_ieee(c0, c1, c2, c3, nx, ny, nz);
     // NaN compares false everywhere: written so that NaN is rejected (canonical semantics).
     const bool inside = (nx >= -1.0f) & (nx <= 1.0f) & (ny >= -1.0f) & (ny <= 1.0f) &
                         (nz >= -1.0f) & (nz <= 1.0f);
@@ -1814,6 +1858,38 @@ extern "C" int read_splat_forward_gl(const float *xyz, int64_t n, const float *M
     int32_t *idx_l[1] = {idx};
     float *dep_l[1] = {depth};
     return resolve_launch(L.keys, 1, 0, W, H, 1, idx ? idx_l : nullptr, depth ? dep_l : nullptr, 0, L, 0, s);
+}
+
+namespace {
+// One thread per point: the pixel it projects to (or -1) and its depth — project_one as every pass uses it, without the z-test.
+__global__ __launch_bounds__(256) void project_points_kernel(const float *__restrict__ xyz, long long n, Cam1 cam, int W, int H,
+                                                             int32_t *__restrict__ pixel, float *__restrict__ depth)
+{
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+        float d;
+        int xx, yy;
+        const int pix = project_one(xyz[3 * i], xyz[3 * i + 1], xyz[3 * i + 2], cam.m, W, H, d, xx, yy);
+        pixel[i] = pix;
+        if (depth) depth[i] = d;
+    }
+}
+}  // namespace
+
+extern "C" int read_splat_project_points(const float *xyz, int64_t n, const float *M_host, int W, int H, int32_t *pixel,
+                                         float *depth, void *stream)
+{
+    READ_CHECK_ARG(n >= 0 && (n == 0 || (xyz && pixel)), "read_splat_project_points: null pointer");
+    READ_CHECK_ARG(M_host, "read_splat_project_points: M_host is null");
+    READ_CHECK_ARG(W >= 1 && H >= 1 && (long long)W * H < (1ll << 31), "read_splat_project_points: bad W/H (%d,%d)", W, H);
+    if (n == 0) return READ_OK;
+    Cam1 cam;
+    for (int i = 0; i < 16; ++i) cam.m[i] = M_host[i];
+    long long blocks = ceil_div64(n, 256);
+    if (blocks > 65536) blocks = 65536;
+    hipLaunchKernelGGL(project_points_kernel, dim3((unsigned)blocks), dim3(256), 0, as_stream(stream), xyz, (long long)n, cam, W,
+                       H, pixel, depth);
+    READ_CHECK_LAUNCH();
+    return READ_OK;
 }
 
 extern "C" int read_index_to_float(const int32_t *idx, int64_t count, float *out, void *stream)

@@ -221,6 +221,9 @@ __global__ __launch_bounds__(256) void gate_forward_kernel(const float *__restri
 // dg can be formed (dg = gamma r (dy - mean(dy) - xhat mean(dy xhat))), so its backward is two passes of this kernel:
 // mode 1: only the sums {., ., sum dy, sum dy * g} (no dfm written);  mode 2: dg = A dy + B + C g with the per-channel constants
 // abc[3][Cout] that bn_bwd_coeff_kernel derives from the mode-1 sums.
+// Statistic groups (gridDim.y > 1, modes 1 and 2): one group per item of the stacked batch — the reference runs its net once per
+// batch item (READ/models/compose.py:137-176), so nn.BatchNorm2d sees N = 1 there; group j covers the rows of block j and uses
+// sums + j * 4 * Cout, abc + j * 3 * Cout.
 template <int CW>
 __global__ __launch_bounds__(256) void gate_backward_kernel(const float *__restrict__ dy, const float *__restrict__ fm,
                                                             long long pixels, int Cout, int CoutPad, int Cp,
@@ -231,6 +234,13 @@ __global__ __launch_bounds__(256) void gate_backward_kernel(const float *__restr
     constexpr int ROWS = 256 / CW;                       // pixels handled concurrently by a workgroup
     __shared__ float red[4][256];
     const int c0 = threadIdx.x % CW, r = threadIdx.x / CW;
+    long long p_begin = 0, p_end = pixels;
+    if (gridDim.y > 1) {
+        p_begin = (long long)blockIdx.y * block_h * W;
+        p_end = p_begin + (long long)block_h * W < pixels ? p_begin + (long long)block_h * W : pixels;
+        sums += (size_t)blockIdx.y * 4 * Cout;
+        if (abc) abc += (size_t)blockIdx.y * 3 * Cout;
+    }
     for (int cb = 0; cb < Cp; cb += CW) {                // channel blocks of CW
         const int c = cb + c0;
         const bool ok = c < Cout;
@@ -238,7 +248,7 @@ __global__ __launch_bounds__(256) void gate_backward_kernel(const float *__restr
         const float cA = (ok && mode == 2) ? abc[c] : 0.0f, cB = (ok && mode == 2) ? abc[Cout + c] : 0.0f,
                     cC = (ok && mode == 2) ? abc[2 * Cout + c] : 0.0f;
         float s_df = 0.f, s_dm = 0.f, s_dy = 0.f, s_dyg = 0.f;
-        for (long long p = (long long)blockIdx.x * ROWS + r; p < pixels; p += (long long)gridDim.x * ROWS) {
+        for (long long p = p_begin + (long long)blockIdx.x * ROWS + r; p < p_end; p += (long long)gridDim.x * ROWS) {
             float df = 0.f, dm = 0.f;
             if (ok && !separator_row(p, W, block_h, valid_h)) {
                 const float f = fm[p * 2 * Cout + c], m = fm[p * 2 * Cout + Cout + c];
@@ -289,6 +299,28 @@ __global__ void bn_grads_kernel(int Cout, const float *sums, const float *mean, 
     if (dgamma) dgamma[c] += (sums[3 * Cout + c] - mean[c] * sums[2 * Cout + c]) * rstd;
 }
 
+// The same over statistic groups (one per batch item): sums[groups][4][Cout], stat[groups][2][Cout] = {mean, biased var} of each
+// group; every parameter gradient is the sum of the groups' contributions.
+__global__ void bn_grads_groups_kernel(int Cout, int groups, const float *sums, const float *stat, float eps, float *dbf, float *dbm,
+                                       float *dgamma, float *dbeta)
+{
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= Cout) return;
+    float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+    for (int j = 0; j < groups; ++j) {
+        const float *S = sums + (size_t)j * 4 * Cout, *st = stat + (size_t)j * 2 * Cout;
+        const float rstd = 1.0f / sqrtf(st[Cout + c] + eps);
+        a0 += S[c];
+        a1 += S[Cout + c];
+        a2 += S[2 * Cout + c];
+        a3 += (S[3 * Cout + c] - st[c] * S[2 * Cout + c]) * rstd;
+    }
+    if (dbf) dbf[c] += a0;
+    if (dbm) dbm[c] += a1;
+    if (dbeta) dbeta[c] += a2;
+    if (dgamma) dgamma[c] += a3;
+}
+
 // ---------------------------------------------------------------------------------------------------------------------
 // Batch-statistics BatchNorm (model.train(): the reference's default, train.py:271-279,450 -> nn.BatchNorm2d of
 // unet.py:40,51 normalises with the statistics of the batch and moves its running buffers).
@@ -298,6 +330,9 @@ __global__ void bn_grads_kernel(int Cout, const float *sums, const float *mean, 
 //                               rm = (1 - mom) rm + mom mean, rv = (1 - mom) rv + mom var n / (n - 1)   (torch's update)
 //             bn_apply_kernel   y = g scale + shift in place (separator rows of a stacked batch stay zero)
 //   backward: gate_backward_kernel mode 1 (sums) -> bn_bwd_coeff_kernel -> gate_backward_kernel mode 2
+// Statistic groups: 1 = the whole stacked batch is one nn.BatchNorm2d batch (UNet.forward on a (B,8,h,w) tensor); B = every item
+// is its own batch of one and the running buffers move B times, in item order (NetAndTexture.forward calls the net once per item,
+// READ/models/compose.py:137-176).  Group j = block j of the stacked image: sums[j][2][C], stat[j][2][C], scale_shift[j][2][CoutPad].
 // ---------------------------------------------------------------------------------------------------------------------
 template <int CW>
 __global__ __launch_bounds__(256) void bn_stats_kernel(const float *__restrict__ g, long long pixels, int C, double *__restrict__ sums,
@@ -306,12 +341,18 @@ __global__ __launch_bounds__(256) void bn_stats_kernel(const float *__restrict__
     constexpr int ROWS = 256 / CW;
     __shared__ double red[2][256];
     const int c0 = threadIdx.x % CW, r = threadIdx.x / CW;
+    long long p_begin = 0, p_end = pixels;
+    if (gridDim.y > 1) {
+        p_begin = (long long)blockIdx.y * block_h * W;
+        p_end = p_begin + (long long)valid_h * W < pixels ? p_begin + (long long)valid_h * W : pixels;
+        sums += (size_t)blockIdx.y * 2 * C;
+    }
     for (int cb = 0; cb < C; cb += CW) {
         const int c = cb + c0;
         const bool ok = c < C;
         double s1 = 0.0, s2 = 0.0;
         if (ok)
-            for (long long p = (long long)blockIdx.x * ROWS + r; p < pixels; p += (long long)gridDim.x * ROWS) {
+            for (long long p = p_begin + (long long)blockIdx.x * ROWS + r; p < p_end; p += (long long)gridDim.x * ROWS) {
                 if (separator_row(p, W, block_h, valid_h)) continue;
                 const double v = (double)g[p * C + c];
                 s1 += v;
@@ -333,32 +374,39 @@ __global__ __launch_bounds__(256) void bn_stats_kernel(const float *__restrict__
     }
 }
 
-__global__ void bn_finalize_kernel(int C, int CoutPad, const double *sums, double count, const float *gamma, const float *beta,
-                                   float eps, float momentum, float *running_mean, float *running_var, float *stat, float *params)
+__global__ void bn_finalize_kernel(int C, int CoutPad, int groups, const double *sums, double count, const float *gamma,
+                                   const float *beta, float eps, float momentum, float *running_mean, float *running_var,
+                                   float *stat, float *scale_shift)
 {
     const int c = blockIdx.x * blockDim.x + threadIdx.x;
     if (c >= C) return;
-    const double mean = sums[c] / count;
-    double var = sums[C + c] / count - mean * mean;
-    var = var > 0.0 ? var : 0.0;
-    const float mf = (float)mean, vf = (float)var;
-    stat[c] = mf;
-    stat[C + c] = vf;
-    const float sc = gamma[c] / sqrtf(vf + eps);
-    params[2 * CoutPad + c] = sc;
-    params[3 * CoutPad + c] = beta[c] - mf * sc;
-    if (running_mean) running_mean[c] = (1.0f - momentum) * running_mean[c] + momentum * mf;
-    if (running_var) running_var[c] = (1.0f - momentum) * running_var[c] + momentum * (float)(count > 1.0 ? var * count / (count - 1.0) : var);
+    float rm = running_mean ? running_mean[c] : 0.0f, rv = running_var ? running_var[c] : 0.0f;
+    for (int j = 0; j < groups; ++j) {                   // the running buffers move once per group, in item order
+        const double mean = sums[(size_t)j * 2 * C + c] / count;
+        double var = sums[(size_t)j * 2 * C + C + c] / count - mean * mean;
+        var = var > 0.0 ? var : 0.0;
+        const float mf = (float)mean, vf = (float)var;
+        stat[(size_t)j * 2 * C + c] = mf;
+        stat[(size_t)j * 2 * C + C + c] = vf;
+        const float sc = gamma[c] / sqrtf(vf + eps);
+        scale_shift[(size_t)j * 2 * CoutPad + c] = sc;
+        scale_shift[(size_t)j * 2 * CoutPad + CoutPad + c] = beta[c] - mf * sc;
+        rm = (1.0f - momentum) * rm + momentum * mf;
+        rv = (1.0f - momentum) * rv + momentum * (float)(count > 1.0 ? var * count / (count - 1.0) : var);
+    }
+    if (running_mean) running_mean[c] = rm;
+    if (running_var) running_var[c] = rv;
 }
 
-__global__ __launch_bounds__(256) void bn_apply_kernel(float *__restrict__ y, long long pixels, int C, int CoutPad,
-                                                       const float *__restrict__ params, int W, int block_h, int valid_h)
+__global__ __launch_bounds__(256) void bn_apply_kernel(float *__restrict__ y, long long pixels, int C, int CoutPad, int groups,
+                                                       const float *__restrict__ scale_shift, int W, int block_h, int valid_h)
 {
     const long long total = pixels * C;
     for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
         const long long p = i / C;
         const int c = (int)(i - p * C);
-        y[i] = separator_row(p, W, block_h, valid_h) ? 0.0f : y[i] * params[2 * CoutPad + c] + params[3 * CoutPad + c];
+        const float *ss = scale_shift + (groups > 1 ? (size_t)((p / W) / block_h) * 2 * CoutPad : 0);
+        y[i] = separator_row(p, W, block_h, valid_h) ? 0.0f : y[i] * ss[c] + ss[CoutPad + c];
     }
 }
 
@@ -368,6 +416,9 @@ __global__ void bn_bwd_coeff_kernel(int C, const float *sums, const float *stat,
 {
     const int c = blockIdx.x * blockDim.x + threadIdx.x;
     if (c >= C) return;
+    sums += (size_t)blockIdx.y * 4 * C;                  // statistic group
+    stat += (size_t)blockIdx.y * 2 * C;
+    abc += (size_t)blockIdx.y * 3 * C;
     const float mean = stat[c], r = 1.0f / sqrtf(stat[C + c] + eps);
     const float dbeta = sums[2 * C + c], dgamma = (sums[3 * C + c] - mean * dbeta) * r;
     const float A = gamma[c] * r, Cc = -A * r * dgamma / count;
@@ -870,54 +921,74 @@ static long long valid_pixels(int64_t pixels, int W, int block_h, int valid_h)
     return (full * valid_h + (rem < valid_h ? rem : valid_h)) * W;
 }
 
-extern "C" int read_bn_train_forward(float *g_to_y, int64_t pixels, int C, int W, int block_h, int valid_h, const float *gamma,
-                                     const float *beta, float eps, float momentum, float *running_mean, float *running_var,
-                                     float *stat, float *params, double *scratch, void *stream)
+// groups: 1, or the number of stacked items (then pixels == groups * block_h * W and every item has valid_h * W valid pixels)
+static bool groups_fit(int groups, int64_t pixels, int W, int block_h)
 {
-    READ_CHECK_ARG(g_to_y && gamma && beta && stat && params && scratch && pixels >= 1 && C >= 1,
+    return groups == 1 || (groups > 1 && block_h > 0 && pixels == (int64_t)groups * block_h * W);
+}
+
+extern "C" int read_bn_train_forward(float *g_to_y, int64_t pixels, int C, int W, int block_h, int valid_h, int groups,
+                                     const float *gamma, const float *beta, float eps, float momentum, float *running_mean,
+                                     float *running_var, float *stat, float *scale_shift, double *scratch, void *stream)
+{
+    READ_CHECK_ARG(g_to_y && gamma && beta && stat && scale_shift && scratch && pixels >= 1 && C >= 1,
                    "read_bn_train_forward: null pointer or empty tensor");
     READ_CHECK_ARG(block_h == 0 || (W >= 1 && valid_h >= 1 && valid_h <= block_h), "read_bn_train_forward: bad block geometry");
     if (W < 1) W = 1;
-    const long long n = valid_pixels(pixels, W, block_h, valid_h);
+    READ_CHECK_ARG(groups_fit(groups, pixels, W, block_h), "read_bn_train_forward: statistic groups must be 1 or the number of stacked blocks");
+    const long long n = groups > 1 ? (long long)valid_h * W : valid_pixels(pixels, W, block_h, valid_h);
     READ_CHECK_ARG(n >= 1, "read_bn_train_forward: no valid pixel");
     const int CoutPad = (C + 31) / 32 * 32;
-    READ_CHECK_HIP(hipMemsetAsync(scratch, 0, sizeof(double) * 2 * (size_t)C, as_stream(stream)));
+    const long long span = groups > 1 ? (long long)valid_h * W : (long long)pixels;      // pixels one statistic group walks
+    READ_CHECK_HIP(hipMemsetAsync(scratch, 0, sizeof(double) * 2 * (size_t)C * groups, as_stream(stream)));
     if (C <= 8)
-        hipLaunchKernelGGL(bn_stats_kernel<8>, dim3(grid_for(pixels, 32, 1024)), dim3(256), 0, as_stream(stream), g_to_y,
+        hipLaunchKernelGGL(bn_stats_kernel<8>, dim3(grid_for(span, 32, 1024), groups), dim3(256), 0, as_stream(stream), g_to_y,
                            (long long)pixels, C, scratch, W, block_h, valid_h);
     else
-        hipLaunchKernelGGL(bn_stats_kernel<32>, dim3(grid_for(pixels, 8, 1024)), dim3(256), 0, as_stream(stream), g_to_y,
+        hipLaunchKernelGGL(bn_stats_kernel<32>, dim3(grid_for(span, 8, 1024), groups), dim3(256), 0, as_stream(stream), g_to_y,
                            (long long)pixels, C, scratch, W, block_h, valid_h);
-    hipLaunchKernelGGL(bn_finalize_kernel, dim3(ceil_div(C, 64)), dim3(64), 0, as_stream(stream), C, CoutPad, scratch, (double)n,
-                       gamma, beta, eps, momentum, running_mean, running_var, stat, params);
+    hipLaunchKernelGGL(bn_finalize_kernel, dim3(ceil_div(C, 64)), dim3(64), 0, as_stream(stream), C, CoutPad, groups, scratch,
+                       (double)n, gamma, beta, eps, momentum, running_mean, running_var, stat, scale_shift);
     hipLaunchKernelGGL(bn_apply_kernel, dim3(grid_for(pixels * C)), dim3(256), 0, as_stream(stream), g_to_y, (long long)pixels, C,
-                       CoutPad, params, W, block_h, valid_h);
+                       CoutPad, groups, scale_shift, W, block_h, valid_h);
     READ_CHECK_LAUNCH();
     return READ_OK;
 }
 
 extern "C" int read_gate_backward_bn(const float *dy, const float *fm, int64_t pixels, int Cout, const float *params, int elu,
-                                     float *dfm, float *sums, int W, int block_h, int valid_h, const float *stat,
+                                     float *dfm, float *sums, int W, int block_h, int valid_h, int groups, const float *stat,
                                      const float *gamma, float eps, float *abc, void *stream)
 {
     READ_CHECK_ARG(dy && fm && params && dfm && sums && stat && gamma && abc && pixels >= 1 && Cout >= 1,
                    "read_gate_backward_bn: null pointer or empty tensor");
     READ_CHECK_ARG(block_h == 0 || (W >= 1 && valid_h >= 1 && valid_h <= block_h), "read_gate_backward_bn: bad block geometry");
     if (W < 1) W = 1;
+    READ_CHECK_ARG(groups_fit(groups, pixels, W, block_h), "read_gate_backward_bn: statistic groups must be 1 or the number of stacked blocks");
     const int Cp = (Cout + 7) / 8 * 8, CoutPad = (Cout + 31) / 32 * 32;
-    const long long n = valid_pixels(pixels, W, block_h, valid_h);
+    const long long n = groups > 1 ? (long long)valid_h * W : valid_pixels(pixels, W, block_h, valid_h);
+    const long long span = groups > 1 ? (long long)block_h * W : (long long)pixels;
     for (int mode = 1; mode <= 2; ++mode) {
-        READ_CHECK_HIP(hipMemsetAsync(sums, 0, sizeof(float) * 4 * (size_t)Cout, as_stream(stream)));
+        READ_CHECK_HIP(hipMemsetAsync(sums, 0, sizeof(float) * 4 * (size_t)Cout * groups, as_stream(stream)));
         if (Cp <= 8)
-            hipLaunchKernelGGL(gate_backward_kernel<8>, dim3(grid_for(pixels, 32, 2048)), dim3(256), 0, as_stream(stream), dy, fm,
+            hipLaunchKernelGGL(gate_backward_kernel<8>, dim3(grid_for(span, 32, 2048), groups), dim3(256), 0, as_stream(stream), dy, fm,
                                (long long)pixels, Cout, CoutPad, Cp, params, elu, dfm, sums, W, block_h, valid_h, mode, (const float *)abc);
         else
-            hipLaunchKernelGGL(gate_backward_kernel<32>, dim3(grid_for(pixels, 8, 2048)), dim3(256), 0, as_stream(stream), dy, fm,
+            hipLaunchKernelGGL(gate_backward_kernel<32>, dim3(grid_for(span, 8, 2048), groups), dim3(256), 0, as_stream(stream), dy, fm,
                                (long long)pixels, Cout, CoutPad, Cp, params, elu, dfm, sums, W, block_h, valid_h, mode, (const float *)abc);
         if (mode == 1)
-            hipLaunchKernelGGL(bn_bwd_coeff_kernel, dim3(ceil_div(Cout, 64)), dim3(64), 0, as_stream(stream), Cout, sums, stat, gamma,
-                               eps, (float)n, abc);
+            hipLaunchKernelGGL(bn_bwd_coeff_kernel, dim3(ceil_div(Cout, 64), groups), dim3(64), 0, as_stream(stream), Cout, sums, stat,
+                               gamma, eps, (float)n, abc);
     }
+    READ_CHECK_LAUNCH();
+    return READ_OK;
+}
+
+extern "C" int read_bn_param_grads_groups(int Cout, int groups, const float *sums, const float *stat, float eps, float *dbf,
+                                          float *dbm, float *dgamma, float *dbeta, void *stream)
+{
+    READ_CHECK_ARG(Cout >= 1 && groups >= 1 && sums && stat, "read_bn_param_grads_groups: null pointer");
+    hipLaunchKernelGGL(bn_grads_groups_kernel, dim3(ceil_div(Cout, 64)), dim3(64), 0, as_stream(stream), Cout, groups, sums, stat,
+                       eps, dbf, dbm, dgamma, dbeta);
     READ_CHECK_LAUNCH();
     return READ_OK;
 }

@@ -6,7 +6,10 @@ temporal_average=False)``; textures live on the CPU until ``load_textures(ids)``
 sub-modules named ``str(id)`` (so ``.cuda()``, ``state_dict()`` and optimizers see them);
 ``forward(inputs)`` consumes a dict ``{'id': ids, <token>: (B,1|3,h,w) index maps, ...}``, REMOVES
 ``'id'`` from it, processes the batch item by item (each item may use a different texture) and
-returns ``(B,3,H,W)`` — plus the last item's network inputs when ``return_input=True``.
+returns ``(B,3,H,W)`` — plus the last item's network inputs when ``return_input=True``.  A net that follows the reference's
+``src`` tree and returns ``{'im_out': image[, 'seg_out': logits]}`` (src/READ/models/unet.py:280) gives a dict of batched
+tensors here, as src/READ/models/compose.py:134-192 does.  ``ModelAndLoss`` (compose.py:12-32 / src compose.py:14-42),
+``MultiscaleNet`` and ``RGBTexture`` complete the module ``READ.models.compose`` that ``train.py:26`` imports from.
 
 MI355X specifics: an item whose inputs are all ``uv*`` index maps (the only layout
 TexturePipeline produces) is gathered at every scale by ONE HIP launch into NHWC feature maps that
@@ -14,7 +17,21 @@ the UNet engine consumes without a copy.
 """
 import torch
 import torch.nn as nn
+import torch.nn.functional as F
 from .texture import _RangeCheck, bilinear_down, gather_pyramid
+from .unet import UNet
+
+
+def _join_items(results):
+    """Per-item net results -> one batched result, in the convention the net used (tensor, or dict of tensors)."""
+    if isinstance(results[0], dict):
+        out = {'im_out': torch.cat([r['im_out'] for r in results], 0)}
+        extra = [k for k in results[0] if k != 'im_out']
+        for k in extra:                                        # src compose.py:176-183: seg_out only when every item has one
+            if all(k in r for r in results):
+                out[k] = torch.cat([r[k] for r in results], 0)
+        return out
+    return torch.cat(results, 0)
 
 
 def _as_id_list(ids):
@@ -47,13 +64,19 @@ class NetAndTexture(nn.Module):
         self._loaded_textures = ids
 
     def unload_textures(self):
+        self.check_ids()                                   # a wrong-texture / out-of-range id must not outlive its epoch unreported
         for tid in self._loaded_textures:
             self._modules.pop(str(tid)).cpu()
         self._loaded_textures = []
 
     def check_ids(self):
-        """Block until every queued point-id range check has landed; raises IndexError if a lookup saw an id >= N."""
+        """Block until every queued point-id range check has landed; raises IndexError if a lookup saw an id >= N.
+        Covers the checks the training path queues on the textures themselves (PointTexture._range_check)."""
         self._range_check.flush()
+        for tex in self._textures.values():
+            check = getattr(tex, 'check_ids', None)
+            if check is not None:
+                check()
 
     def reg_loss(self):
         return sum((self._modules[str(tid)].reg_loss() for tid in self._loaded_textures), 0)
@@ -92,7 +115,11 @@ class NetAndTexture(nn.Module):
         if torch.is_grad_enabled() and len(texture_ids) > 1 and not self.temporal_average:
             # training: sample every item (each may use its own texture), then ONE network call for the batch — the HIP
             # training graph stacks the items into a single tall image (read_amd/train.py), so a 256x256 crop does not
-            # leave most of the chip idle; the per-item results are the same as item-by-item calls
+            # leave most of the chip idle; the per-item results are the same as item-by-item calls — in .train() too: the
+            # reference's item-by-item calls give every BatchNorm layer a batch of ONE item and move its running buffers once
+            # per item (compose.py:137-176), which the stacked call reproduces with per-item statistic groups
+            if isinstance(self.net, UNet):
+                kwargs = dict(kwargs, per_item_statistics=True)
             if len(set(texture_ids)) == 1:
                 # one scene for the whole batch (the usual case): one lookup per scale instead of one per item and scale —
                 # the same values, a fifth of a training step's host time less (8 items x 5 scales of Python per step)
@@ -111,5 +138,81 @@ class NetAndTexture(nn.Module):
                     net_input = [(cur + prev) / 2 for cur, prev in zip(net_input, self.last_input)]
                 self.last_input = list(net_input)
             frames.append(self.net(*net_input, **kwargs))
-        out = torch.cat(frames, 0)
+        out = _join_items(frames)
         return (out, net_input) if kwargs.get('return_input') else out
+
+
+class ModelAndLoss(nn.Module):
+    """``ModelAndLoss(model, loss, use_mask=False)``: model and criterion in one module, so ``nn.DataParallel`` scatters both
+    (train.py:136, src/train.py:145).  ``forward(*inputs, target, **kwargs) -> (output, loss)``.
+
+    Root-tree convention (READ/models/compose.py:19-32): the model returns the image, ``loss = criterion(output[* mask], target)``.
+    ``src``-tree convention (src/READ/models/compose.py:21-42): the model returns ``{'im_out': image[, 'seg_out': logits]}`` and
+    the loss is a dict — ``vgg_loss`` = the criterion, ``huber_loss`` = ``F.huber_loss`` (delta 1, mean) on the (masked) image,
+    ``seg_loss`` = cross entropy ignoring class 0 when the output carries ``seg_out`` and a ``label`` was passed.  The
+    convention is read off the model's result, so one class serves both trees."""
+
+    def __init__(self, model, loss, use_mask=False):
+        super().__init__()
+        self.model = model
+        self.loss = loss
+        self.use_mask = use_mask
+
+    def forward(self, *args, **kwargs):
+        *inputs, target = args
+        output = self.model(*inputs, **kwargs)
+        mask = kwargs.get('mask') if self.use_mask else None
+        if not isinstance(output, dict):
+            return output, self.loss(output if mask is None else output * mask, target)
+        image = output['im_out'] if mask is None else output['im_out'] * mask
+        losses = {'vgg_loss': self.loss(image, target), 'huber_loss': self._huber(image, target)}
+        if 'seg_out' in output and kwargs.get('label') is not None:
+            losses['seg_loss'] = F.cross_entropy(output['seg_out'], kwargs['label'], ignore_index=0)
+        return output, losses
+
+    @staticmethod
+    def _huber(image, target):
+        if image.is_cuda:                                  # value and gradient in one HIP launch (csrc/train.hip)
+            from .train import huber_loss
+            return huber_loss(image, target)
+        return F.huber_loss(image, target)
+
+
+def _reduce_ss(x, ss):
+    return x if ss <= 1 else F.interpolate(x, scale_factor=1. / ss, mode='bilinear')
+
+
+class MultiscaleNet(nn.Module):
+    """Image-to-image wrapper of Pix2PixPipeline (compose.py:184-212): consecutive groups of ``input_modality`` inputs are
+    concatenated into one scale each.  Pure torch — no descriptor lookup, nothing of the HIP path."""
+
+    def __init__(self, net, input_modality, supersampling=1):
+        super().__init__()
+        self.net = net
+        self.input_modality = input_modality
+        self.ss = supersampling
+
+    def forward(self, inputs, **kwargs):
+        inputs.pop('id')
+        values = list(inputs.values())
+        assert len(values) % self.input_modality == 0
+        scales = [_reduce_ss(torch.cat(values[i:i + self.input_modality], 1), self.ss)
+                  for i in range(0, len(values), self.input_modality)]
+        out = self.net(*scales, **kwargs)
+        return (out, scales) if kwargs.get('return_input') else out
+
+
+class RGBTexture(nn.Module):
+    """Mesh-texture lookup of RGBTexturePipeline (compose.py:215-235): the only input is ``uv_2d``."""
+
+    def __init__(self, texture, supersampling=1):
+        super().__init__()
+        self.texture = texture
+        self.ss = supersampling
+
+    def forward(self, inputs, **kwargs):
+        inputs.pop('id')
+        assert list(inputs) == ['uv_2d'], 'check input format'
+        uv = inputs['uv_2d']
+        out = self.texture(uv)
+        return (out, uv) if kwargs.get('return_input') else out

@@ -59,7 +59,9 @@ class OGL:
         self.last_path = None                # 'fast' / 'dict': which branch the last infer() took (asserted by the tests)
 
     def infer(self, input_dict=None):
-        """-> {'output': H x W x 4 float tensor (RGB + alpha 1), 'net_input': list of NCHW feature maps}."""
+        """-> {'output': H x W x 4 float tensor (RGB + alpha 1), 'net_input': list of NCHW feature maps}; a caller-supplied
+        ``input_dict`` (it must carry its own 'id') is rendered as it is and echoed under 'input', as the src tree's
+        ``OGL.infer(input_dict)`` does (src/READ/gl/nn.py:115-137)."""
         model = self.model
         texture = model._modules[str(model._loaded_textures[0])] if model._loaded_textures else model._modules['0']
         fast = (input_dict is None and not model.temporal_average and self._fast_format
@@ -79,11 +81,18 @@ class OGL:
                 out = model.net.engine(H, W).forward(feats[0][0], feats[1][0], feats[2][0], feats[3][0], channels=4)
                 net_input = [f.permute(0, 3, 1, 2) for f in feats]
             else:
-                if input_dict is None:
+                given = input_dict is not None
+                if not given:
                     input_dict = {k: v.permute(2, 0, 1)[None] for k, v in self.renderer.render().items()}
-                input_dict = dict(input_dict)
-                input_dict['id'] = 0
-                o, net_input = model(input_dict, return_input=True)
+                feed = dict(input_dict)                          # the model removes 'id' from the dict it is handed
+                if not given or 'id' not in feed:
+                    feed['id'] = 0
+                o, net_input = model(feed, return_input=True)
+                if isinstance(o, dict):                          # src tree: the net returns {'im_out': image}
+                    o = o['im_out']
                 o = o[0].detach().permute(1, 2, 0)
                 out = torch.cat([o, torch.ones_like(o[:, :, :1])], 2).contiguous()
-        return {'output': out, 'net_input': net_input}
+        res = {'output': out, 'net_input': net_input}
+        if input_dict is not None:
+            res['input'] = input_dict
+        return res

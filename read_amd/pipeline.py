@@ -122,13 +122,16 @@ class TexturePipeline(Pipeline):
         add('--n_points', type=int, default=0, help='this is for inference')
 
     @staticmethod
-    def _texture(args, size):
+    def _texture(args, size, texture_ckpt=None):
+        """``get_texture`` of READ/pipelines/ogl.py:30-42; the src tree passes the checkpoint per dataset
+        (src/READ/pipelines/ogl.py:38-48) instead of reading ``args.texture_ckpt``."""
         if getattr(args, 'use_mesh', False):
             raise NotImplementedError("MeshTexture (use_mesh) is outside the point-cloud render path")
         tex = PointTexture(args.descriptor_size, size, activation=getattr(args, 'texture_activation', 'none'),
                            reg_weight=getattr(args, 'reg_weight', 0.))
-        if getattr(args, 'texture_ckpt', None):
-            tex = load_model_checkpoint(args.texture_ckpt, tex)
+        ckpt = texture_ckpt if texture_ckpt is not None else getattr(args, 'texture_ckpt', None)
+        if ckpt:
+            tex = load_model_checkpoint(ckpt, tex)
         return tex
 
     def create(self, args):
@@ -150,10 +153,15 @@ class TexturePipeline(Pipeline):
                 except (ImportError, AttributeError) as e:
                     raise RuntimeError("training mode needs READ.datasets.dynamic.get_datasets (put the reference checkout "
                                        "behind this repo on PYTHONPATH, INTEGRATION.md) or args.get_datasets(args)") from e
-            self.ds_train, self.ds_val = get_datasets(args)
+            got = get_datasets(args)
+            # root tree: (ds_train, ds_val) (READ/pipelines/ogl.py:86); src tree: + {ds.id: texture checkpoint or None}
+            # (src/READ/pipelines/ogl.py:94,104)
+            self.ds_train, self.ds_val = got[0], got[1]
+            self.texture_ckpts = dict(got[2]) if len(got) > 2 and got[2] else {}
             for ds in self.ds_train:
                 assert ds.scene_data['pointcloud'] is not None, 'set pointcloud'
-                textures[ds.id] = self._texture(args, ds.scene_data['pointcloud']['xyz'].shape[0])
+                textures[ds.id] = self._texture(args, ds.scene_data['pointcloud']['xyz'].shape[0],
+                                                self.texture_ckpts.get(ds.id))
             self.optimizer = _DeviceAdam(net.parameters(), lr=args.lr)
             self.sparse_textures = bool(getattr(args, 'sparse_texture_optimizer', True)) and not getattr(args, 'reg_weight', 0.)
             for tex in textures.values():

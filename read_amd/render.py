@@ -62,6 +62,30 @@ def parse_input_string(string):
     return config
 
 
+_WHAT = {MODE_COLOR: 'colors', MODE_UV: 'uv', MODE_NORMALS: 'normals', MODE_XYZ: 'xyz', MODE_DEPTH: 'depth', MODE_LABEL: 'labels'}
+_VARIANT = {MODE_UV: ('_1d', '_2d'), MODE_NORMALS: ('_m', '_r', '_l', '_d')}
+
+
+def generate_input_string(config):
+    """Inverse of ``parse_input_string`` (READ/gl/dataset.py:85-122): a draw configuration -> its token,
+    ``<what>[_<variant>][_p<N>|_ps<N>][_ds<K>]``.  An unknown uv type raises ValueError like the reference; an unknown normals
+    variant is left out like the reference.  ``MODE_LABEL`` gives ``labels`` (the reference function has no branch for it and
+    returns a token that does not parse), so ``parse(generate(c)) == c`` holds for every mode ``parse_input_string`` knows."""
+    m0, m1 = config['mode']
+    s = _WHAT.get(m0, '')
+    if m0 == MODE_UV:
+        if m1 not in (UV_TYPE_1D, UV_TYPE_2D):
+            raise ValueError
+        s += _VARIANT[MODE_UV][m1]
+    elif m0 == MODE_NORMALS and m1 in (0, 1, 2, 3):
+        s += _VARIANT[MODE_NORMALS][m1]
+    if config['draw_points']:
+        s += ('_ps' if config['splat_mode'] else '_p') + str(config['point_size'])
+    if 'downscale' in config:
+        s += f"_ds{config['downscale']}"
+    return s
+
+
 def is_point_id_pyramid(input_format):
     """True when the tokens are exactly ``uv_1d_p1`` at downscale 0, 1, 2, ... — the layout served by ONE pass over the
     cloud (pyramid identity)."""

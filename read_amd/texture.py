@@ -118,6 +118,8 @@ class _RangeCheck:
 
     def queue(self, ids, n, signed=False):
         """signed: ids may also be negative (ids that did not come from the rasteriser) — a negative id counts as id n."""
+        if ids.numel() == 0:                               # an empty lookup has nothing out of range (and no .max())
+            return
         flag = self.free.pop() if self.free else torch.empty(1, dtype=torch.int32).pin_memory()
         worst = (torch.where(ids < 0, n, ids) if signed else ids).max()
         flag.copy_(worst.to(torch.int32).reshape(1), non_blocking=True)

@@ -29,6 +29,7 @@ from . import _lib
 
 BN_EPS = 1e-5
 BN_MOMENTUM = 0.1          # nn.BatchNorm2d default (unet.py:40)
+BN_PER_ITEM = 2            # GatedConvFn's bn_train: 0 eval, 1 batch statistics over the stacked batch, 2 per stacked item
 
 
 def _ptr(t):
@@ -252,19 +253,23 @@ class GatedConvFn(torch.autograd.Function):
         _linear_conv(x, cin, wp, params, cout, k, stride, fm, wino=wino, gated=(y, elu, bh, vh), w4=_w4_fits(cin, cout))
         if wino is None:
             _lib.check(L.read_gate_forward(fm.data_ptr(), Ho * Wo, cout, params.data_ptr(), int(elu), None, y.data_ptr(), Wo, bh, vh, st))
-        stat = None
+        stat, groups = None, 1
         if bn_train:
             # y holds g = act(f) * sigmoid(m) so far: normalise it with the batch statistics, in place; the module's running
-            # buffers (mean, var ARE the buffers) move as nn.BatchNorm2d's do — no autograd through them
-            stat = torch.empty((2, cout), dtype=torch.float32, device=dev)
-            bn_params = torch.empty_like(params)
-            scratch = torch.empty(2 * cout, dtype=torch.float64, device=dev)
-            _lib.check(L.read_bn_train_forward(y.data_ptr(), Ho * Wo, cout, Wo, bh, vh, gamma.detach().data_ptr(),
+            # buffers (mean, var ARE the buffers) move as nn.BatchNorm2d's do — no autograd through them.
+            # bn_train == 2 (BN_PER_ITEM): every stacked item is its own BatchNorm batch (the net called once per item,
+            # READ/models/compose.py:137-176) — per-item statistics, the buffers move nb times in item order
+            groups = nb if (int(bn_train) == BN_PER_ITEM and nb > 1) else 1
+            stat = torch.empty((groups, 2, cout), dtype=torch.float32, device=dev)
+            scale_shift = torch.empty((groups, 2, (cout + 31) // 32 * 32), dtype=torch.float32, device=dev)
+            scratch = torch.empty(groups * 2 * cout, dtype=torch.float64, device=dev)
+            _lib.check(L.read_bn_train_forward(y.data_ptr(), Ho * Wo, cout, Wo, bh, vh, groups, gamma.detach().data_ptr(),
                                                beta.detach().data_ptr(), BN_EPS, BN_MOMENTUM, mean.data_ptr(), var.data_ptr(),
-                                               stat.data_ptr(), bn_params.data_ptr(), scratch.data_ptr(), st), "read_bn_train_forward")
+                                               stat.data_ptr(), scale_shift.data_ptr(), scratch.data_ptr(), st), "read_bn_train_forward")
             _bump_version(mean, var)                 # written through raw pointers: caches keyed on ._version must see it
-            mean, var = stat[0], stat[1]
+            mean = var = stat                        # the backward pass needs the groups' {mean, biased var}, not the buffers
         ctx.bn_train = bool(bn_train)
+        ctx.bn_groups = groups
         ctx.save_for_backward(x, fm, params, wf_c, wm_c, mean, var, gamma.detach() if bn_train else mean)
         ctx.cfg = (k, stride, int(elu), H, W, cin, cout, Ho, Wo, bh, vh)
         ctx.wrefs = (weakref.ref(wf), weakref.ref(wm))
@@ -280,14 +285,14 @@ class GatedConvFn(torch.autograd.Function):
         dy = dy.contiguous()
         cp = (cout + 7) // 8 * 8
         dfm = torch.empty((Ho, Wo, 2 * cp), dtype=torch.float32, device=dev)
-        sums = torch.empty((4, cout), dtype=torch.float32, device=dev)
+        groups = ctx.bn_groups
+        sums = torch.empty((groups, 4, cout), dtype=torch.float32, device=dev)
         if ctx.bn_train:
-            stat = torch.stack([mean, var]).contiguous()              # batch mean / biased variance of the forward pass
-            abc = torch.empty((3, cout), dtype=torch.float32, device=dev)
+            stat = mean                                               # [groups][2][cout]: batch mean / biased variance of the forward pass
+            abc = torch.empty((groups, 3, cout), dtype=torch.float32, device=dev)
             _lib.check(L.read_gate_backward_bn(dy.data_ptr(), fm.data_ptr(), Ho * Wo, cout, params.data_ptr(), elu, dfm.data_ptr(),
-                                               sums.data_ptr(), Wo, bh, vh, stat.data_ptr(), gamma_d.data_ptr(), BN_EPS,
+                                               sums.data_ptr(), Wo, bh, vh, groups, stat.data_ptr(), gamma_d.data_ptr(), BN_EPS,
                                                abc.data_ptr(), st), "read_gate_backward_bn")
-            mean, var = stat[0], stat[1]
         else:
             _lib.check(L.read_gate_backward(dy.data_ptr(), fm.data_ptr(), Ho * Wo, cout, params.data_ptr(), elu, dfm.data_ptr(),
                                             sums.data_ptr(), Wo, bh, vh, st))
@@ -296,8 +301,12 @@ class GatedConvFn(torch.autograd.Function):
             ev_dfm = torch.cuda.Event()
             ev_dfm.record(torch.cuda.current_stream(dev))              # d[f|m] (and everything before it) is complete here
         dbf, dbm, dgamma, dbeta = torch.zeros((4, cout), dtype=torch.float32, device=dev).unbind(0)     # one fill, four rows
-        _lib.check(L.read_bn_param_grads(cout, sums.data_ptr(), mean.data_ptr(), var.data_ptr(), BN_EPS, dbf.data_ptr(),
-                                         dbm.data_ptr(), dgamma.data_ptr(), dbeta.data_ptr(), st))
+        if ctx.bn_train:
+            _lib.check(L.read_bn_param_grads_groups(cout, groups, sums.data_ptr(), stat.data_ptr(), BN_EPS, dbf.data_ptr(),
+                                                    dbm.data_ptr(), dgamma.data_ptr(), dbeta.data_ptr(), st))
+        else:
+            _lib.check(L.read_bn_param_grads(cout, sums.data_ptr(), mean.data_ptr(), var.data_ptr(), BN_EPS, dbf.data_ptr(),
+                                             dbm.data_ptr(), dgamma.data_ptr(), dbeta.data_ptr(), st))
         dx = None
         if ctx.needs_input_grad[0]:
             dx = torch.empty((H, W, cin), dtype=torch.float32, device=dev)
@@ -418,9 +427,12 @@ def _bc(net, path, x, k, stride=1, elu=True, blk=(1, 1, 1)):
         node = node._modules[p]
     b = node.block
     n = b['norm']
-    bn_train = bool(net.training)
+    bn_train = int(bool(net.training))
+    if bn_train and net.__dict__.get('_bn_per_item') and blk[0] > 1:
+        bn_train = BN_PER_ITEM
     if bn_train and n.num_batches_tracked is not None:
-        n.num_batches_tracked += 1                      # nn.BatchNorm2d bookkeeping (momentum is fixed, so only a counter)
+        # nn.BatchNorm2d bookkeeping (momentum is fixed, so only a counter): one forward call per statistic group
+        n.num_batches_tracked += blk[0] if bn_train == BN_PER_ITEM else 1
     return GatedConvFn.apply(x, b['conv_f'].weight, b['conv_f'].bias, b['conv_m'].weight, b['conv_m'].bias, n.weight, n.bias,
                              n.running_mean, n.running_var, k, stride, elu, *blk, bn_train)
 
@@ -496,13 +508,20 @@ def stack_batch(x_nchw, level):
     return x.reshape(-1, w, c).contiguous()
 
 
-def unet_forward_train_batch(net, xs):
-    """xs: four (B,8,h,w) pyramids -> (B,3,H,W) through ONE stacked image."""
+def unet_forward_train_batch(net, xs, per_item_statistics=False):
+    """xs: four (B,8,h,w) pyramids -> (B,3,H,W) through ONE stacked image.  In ``.train()`` the BatchNorm layers normalise with
+    the statistics of the whole batch — ``nn.BatchNorm2d`` on a (B,C,h,w) tensor — unless ``per_item_statistics``: then every item
+    is its own batch of one and the running buffers move B times in item order, which is what B separate calls of the net do
+    (``NetAndTexture.forward``, READ/models/compose.py:137-176)."""
     B, _, H, W = xs[0].shape
     if H % 16 or W % 16:
         raise ValueError(f"training crops must be multiples of 16, got {W}x{H}")
     blk = (B, H, H + SEPARATOR_ROWS) if B > 1 else (1, 1, 1)
-    out = unet_forward_train(net, *[stack_batch(x, l) for l, x in enumerate(xs)], blk=blk)
+    net.__dict__['_bn_per_item'] = bool(per_item_statistics)
+    try:
+        out = unet_forward_train(net, *[stack_batch(x, l) for l, x in enumerate(xs)], blk=blk)
+    finally:
+        net.__dict__['_bn_per_item'] = False
     out = out.reshape(B, -1, W, 3)[:, :H]
     return out.permute(0, 3, 1, 2)
 

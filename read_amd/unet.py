@@ -13,7 +13,7 @@ import numpy as np
 import torch
 import torch.nn as nn
 
-from . import _lib
+from . import _alias, _lib
 
 BN_EPS = 1e-5
 
@@ -156,6 +156,9 @@ class UNet(nn.Module):
         if num_input_channels != 8 or num_output_channels != 3 or num_res != 4:
             raise ValueError("the HIP UNet is built for READ's fixed configuration: 8 -> 3 channels, num_res=4")
         self.feature_scale = feature_scale
+        # None: follow the tree behind the READ alias package (read_amd/_alias.py) — the reference's root tree returns the image
+        # tensor (READ/models/unet.py:285), its src tree {'im_out': tensor} (src/READ/models/unet.py:280); 'tensor' / 'dict' pin it
+        self.result_convention = None
         for (path, cin, cout, k, stride, _elu) in layer_table():
             _attach(self, path, _GatedConvParams(cin, cout, k, stride))
         self._engines = {}
@@ -206,7 +209,13 @@ class UNet(nn.Module):
 
     # ---- forward -----------------------------------------------------------------------------
     def forward(self, *inputs, **kwargs):
-        """inputs: x, x_2, x_4, x_8 [, x_16 ignored] as (B,8,h,w) -> (B,3,H,W)  (unet.py:202-285)."""
+        """inputs: x, x_2, x_4, x_8 [, x_16 ignored] as (B,8,h,w) -> (B,3,H,W)  (unet.py:202-285), wrapped as
+        ``{'im_out': ...}`` under the src tree's convention (src/READ/models/unet.py:280)."""
+        z = self._forward_image(*inputs, **kwargs)
+        convention = self.result_convention or _alias.result_convention()
+        return {'im_out': z} if convention == 'dict' else z
+
+    def _forward_image(self, *inputs, **kwargs):
         inputs = list(inputs)
         if len(inputs) < 4:
             raise ValueError("UNet.forward needs the 1, 1/2, 1/4 and 1/8 scale inputs")
@@ -219,7 +228,8 @@ class UNet(nn.Module):
             # the layer-by-layer graph, with or without gradients; the fused inference plan folds the RUNNING statistics
             # training step: every BasicConv is an autograd node backed by the HIP kernels of csrc/train.hip
             from .train import unet_forward_train_batch
-            return unet_forward_train_batch(self, [x.to(dev, torch.float32) for x in inputs[:4]])
+            return unet_forward_train_batch(self, [x.to(dev, torch.float32) for x in inputs[:4]],
+                                            per_item_statistics=bool(kwargs.get('per_item_statistics')))
         xs = [x.to(dev, torch.float32).permute(0, 2, 3, 1).contiguous() for x in inputs[:4]]
         B, H, W, _ = xs[0].shape
         eng = self.engine(H, W)

@@ -288,3 +288,90 @@ def test_full_size_30M_warm_started_sweep_vs_oracle(hip):
         M = camera.total_matrix(proj, synthetic.sweep_pose(k))
         idx, dep = r.render(M, W, H, 5)
         _assert_frame(idx, dep, xyz, M[0], W, H, f"30M pose {k}", threads=threads)
+
+
+def _project_on_device(xyz, M, W, H):
+    import ctypes as C
+    from read_amd import _lib
+    pts = torch.from_numpy(np.ascontiguousarray(xyz, np.float32)).cuda()
+    pix = torch.empty(pts.shape[0], dtype=torch.int32, device="cuda")
+    dep = torch.empty(pts.shape[0], dtype=torch.float32, device="cuda")
+    Mh = np.ascontiguousarray(M, np.float32).reshape(16)
+    _lib.check(_lib.lib().read_splat_project_points(pts.data_ptr(), pts.shape[0], Mh.ctypes.data_as(C.POINTER(C.c_float)), W, H,
+                                                    pix.data_ptr(), dep.data_ptr(), _lib.stream_ptr()), "read_splat_project_points")
+    torch.cuda.synchronize()
+    return pix.cpu().numpy(), dep.cpu().numpy()
+
+
+def test_shared_reciprocal_projection_is_ieee_division(hip):
+    """the rasteriser computes c0/c3, c1/c3, c2/c3 with ONE reciprocal (csrc/splat.hip div3_ieee) instead of three
+    IEEE divisions.  More than 10^8 points, device against the oracle's IEEE divisions (oracle/raster.c project_point, the
+    restatement pinned to the reference's own source): the accept / reject decision and the pixel of EVERY point, the depth bits
+    of every accepted point.  Operands are adversarial on purpose: a matrix that hands (x, y, z) straight to the divisions
+    (numerators and divisor chosen bit by bit: divisors across and exactly on the edges 2^-40 / 2^40 of the fast path's window,
+    zero, denormal, inf, NaN; numerators zero, denormal, around 2^-103, 2^56 |b| and beyond, equal to the divisor and one ulp
+    off it, quotients within an ulp of +-1), real cameras, and real cameras scaled by 2^k so that whole clouds sit on the
+    window's edges (the projection is invariant under the scale, the instruction path is not)."""
+    W, H = 1216, 352
+    cpu = min(os.cpu_count() or 1, 32)
+    rng = np.random.default_rng(2024)
+    total = 0
+
+    def compare(xyz, M, what):
+        nonlocal total
+        got_p, got_d = _project_on_device(xyz, M, W, H)
+        with np.errstate(all="ignore"):
+            ref_p, ref_d = oracle.project_points(xyz, M, W, H, threads=cpu)
+        bad = np.flatnonzero(got_p != ref_p)
+        assert bad.size == 0, (what, bad.size, xyz[bad[:4]], got_p[bad[:4]], ref_p[bad[:4]])
+        acc = ref_p >= 0
+        badd = np.flatnonzero(acc & (got_d.view(np.uint32) != ref_d.view(np.uint32)))
+        assert badd.size == 0, (what, badd.size, xyz[badd[:4]], got_d[badd[:4]], ref_d[badd[:4]])
+        total += xyz.shape[0]
+        return float(acc.mean())
+
+    # ---- (x, y, z) -> numerators x, y, 0.5 x + 0.25 y over the divisor z
+    direct = np.array([[1, 0, 0, 0], [0, 1, 0, 0], [0.5, 0.25, 0, 0], [0, 0, 1, 0]], np.float32)
+    n = 1 << 25
+    edges = np.array([2.0 ** -40, 2.0 ** 40, 2.0 ** -126, 2.0 ** 126, 2.0 ** -103, 2.0 ** -41, 2.0 ** 41], np.float32)
+    edges = np.concatenate([edges, np.nextafter(edges, np.float32(0)), np.nextafter(edges, np.float32(np.inf))])
+    specials = np.concatenate([edges, -edges, np.array([0.0, -0.0, np.inf, -np.inf, np.nan, 1e-45, -1e-45, 1e-39, 3.4e38], np.float32)])
+    for batch in range(3):
+        # divisor: sign * mantissa * 2^e, e across the window edges; a slice of exact special values
+        e = rng.integers(-46, 47, n) if batch < 2 else rng.integers(-8, 12, n)
+        b = (np.ldexp(1.0 + rng.random(n), e) * rng.choice([-1.0, 1.0], n)).astype(np.float32)
+        sl = rng.random(n) < 0.02
+        b[sl] = rng.choice(specials, int(sl.sum()))
+        # numerators: quotient uniform a little beyond [-1, 1] ...
+        u = rng.uniform(-1.0005, 1.0005, (2, n))
+        with np.errstate(all="ignore"):
+            a = (u * b.astype(np.float64)).astype(np.float32)
+            # ... within a few ulps of +-1 (the clip edge), exactly the divisor, special values, far too small / large
+            k = rng.random(n)
+            near1 = (k < 0.05)
+            steps = rng.integers(-3, 4, int(near1.sum()))
+            a1 = b[near1] * rng.choice([-1.0, 1.0], int(near1.sum())).astype(np.float32)
+            for _ in range(3):
+                a1 = np.where(steps > 0, np.nextafter(a1, np.float32(np.inf)), np.where(steps < 0, np.nextafter(a1, np.float32(-np.inf)), a1))
+                steps = steps - np.sign(steps)
+            a[1, near1] = a1
+            sp = (k >= 0.05) & (k < 0.08)
+            a[1, sp] = rng.choice(specials, int(sp.sum()))
+            tiny = (k >= 0.08) & (k < 0.10)
+            a[1, tiny] = (b[tiny].astype(np.float64) * np.ldexp(1.0, -rng.integers(50, 140, int(tiny.sum())))).astype(np.float32)
+            huge = (k >= 0.10) & (k < 0.12)
+            a[0, huge] = (b[huge].astype(np.float64) * np.ldexp(1.0, rng.integers(1, 100, int(huge.sum())))).astype(np.float32)
+        xyz = np.stack([a[0], a[1], b], 1)
+        frac = compare(xyz, direct, f"direct operands, batch {batch}")
+        assert frac > 0.2, frac                                     # most quotient triples really are accepted points
+    # ---- real cameras, and the same cameras scaled onto the window's edges
+    cloud = synthetic.make_cloud(1 << 23)
+    proj = synthetic.make_proj(W, H)
+    for pose in (0, 17, 100):
+        M = camera.total_matrix(proj, synthetic.sweep_pose(pose))[0]
+        assert compare(cloud, M, f"camera pose {pose}") > 0.3
+        for k in (-46, -41, -40, -39, -36, 34, 38, 39, 40, 41):
+            # c3 is ~1 .. 120 for visible points: these scales put the cloud's divisors below, across and above both edges
+            compare(cloud[: 1 << 21], (M.astype(np.float64) * 2.0 ** k).astype(np.float32), f"camera pose {pose} scaled by 2^{k}")
+    assert total > 100_000_000, total
+    print(f"shared-reciprocal projection == IEEE division on {total} points")

@@ -138,6 +138,8 @@ def test_unet_training_graph_vs_oracle_autograd(hip):
 @pytest.mark.parametrize("cin,cout,k,stride,elu,H,W,nb", [
     (32, 32, 3, 1, True, 24, 40, 1), (64, 64, 3, 1, False, 2 * (16 + 4), 32, 2), (8, 32, 3, 1, True, 32, 48, 1),
     (64, 56, 1, 1, True, 12, 20, 1), (32, 64, 3, 2, True, 32, 48, 1), (256, 128, 4, 2, True, 16, 24, 1), (32, 3, 3, 1, False, 16, 32, 1),
+    # negative nb: |nb| stacked items, each its OWN BatchNorm batch (the net called once per item, compose.py:137-176)
+    (32, 32, 3, 1, True, 16, 24, -3), (8, 32, 3, 1, True, 16, 40, -2), (64, 56, 1, 1, False, 16, 20, -4),
 ])
 def test_gated_conv_layer_batch_statistics_batchnorm(hip, cin, cout, k, stride, elu, H, W, nb):
     """One BasicConv with nn.BatchNorm2d in .train() (unet.py:40,51; the reference's default, train.py:271-279): output, every
@@ -150,6 +152,7 @@ def test_gated_conv_layer_batch_statistics_batchnorm(hip, cin, cout, k, stride, 
              bm=t(rng.uniform(-b, b, cout)), gamma=t(rng.uniform(0.5, 1.5, cout)), beta=t(0.1 * rng.standard_normal(cout)),
              mean=t(0.1 * rng.standard_normal(cout)), var=t(rng.uniform(0.5, 1.5, cout)))
     pad = (k - 1) // 2
+    per_item, nb = nb < 0, abs(nb)
     if nb == 1:
         x = t(rng.standard_normal((1, cin, H, W)))
         xb = x
@@ -162,15 +165,19 @@ def test_gated_conv_layer_batch_statistics_batchnorm(hip, cin, cout, k, stride, 
     f = F.conv2d(xr, ref_in["wf"], ref_in["bf"], stride=stride, padding=pad)
     m = F.conv2d(xr, ref_in["wm"], ref_in["bm"], stride=stride, padding=pad)
     rm, rv = p["mean"].clone(), p["var"].clone()
-    yr = F.batch_norm((F.elu(f) if elu else f) * torch.sigmoid(m), rm, rv, ref_in["gamma"], ref_in["beta"], training=True,
-                      momentum=0.1, eps=1e-5)
+    gated = (F.elu(f) if elu else f) * torch.sigmoid(m)
+    if per_item:      # one F.batch_norm call per item, in order: own statistics, the running buffers move nb times
+        yr = torch.cat([F.batch_norm(gated[b:b + 1], rm, rv, ref_in["gamma"], ref_in["beta"], training=True, momentum=0.1, eps=1e-5)
+                        for b in range(nb)], 0)
+    else:
+        yr = F.batch_norm(gated, rm, rv, ref_in["gamma"], ref_in["beta"], training=True, momentum=0.1, eps=1e-5)
     g = t(rng.standard_normal(tuple(yr.shape)))
     yr.backward(g)
     dev = {n: v.cuda().requires_grad_(n not in ("mean", "var")) for n, v in p.items()}
     xd = x[0].permute(1, 2, 0).contiguous().cuda().requires_grad_(True)
     blk = (1, 1, 1) if nb == 1 else (nb, 16, 20)
     y = GatedConvFn.apply(xd, dev["wf"], dev["bf"], dev["wm"], dev["bm"], dev["gamma"], dev["beta"], dev["mean"], dev["var"], k,
-                          stride, elu, *blk, True)
+                          stride, elu, *blk, 2 if per_item else True)
     if nb == 1:
         y_cmp, unstack = y.permute(2, 0, 1)[None], lambda a: a.permute(2, 0, 1)[None]
         gd = g[0].permute(1, 2, 0).contiguous()
@@ -433,3 +440,121 @@ def test_wgrad_when_gradients_accumulate_or_are_frozen(hip):
                           frozen["var"], 3, 1, True)
     y.backward(gs[0][0].permute(1, 2, 0).contiguous().cuda())
     assert xd.grad is not None and all(v.grad is None for v in frozen.values())
+
+
+def test_src_train_py_loop_body_with_dict_results(hip):
+    """the body of the reference's headless loop (src/train.py:150-266) with its own names and call order —
+    ``renderer = MyRender(); renderer.update_ds(ds_list)``, ``ModelAndLoss(pipeline.model, criterion)``,
+    ``data['input'], depths = renderer.render(data)``, ``out, loss_dict = model(data_input, target, label=label, mask=mask)``,
+    ``out['im_out']``, ``loss = vgg + huber * 1e4 (+ reg_loss)``, backward, both optimizers — under the src tree's result
+    convention ({'im_out'}, loss dict; src/READ/models/unet.py:280, src/READ/models/compose.py:29-40), against the oracle:
+    raster bit-exact, image, both loss entries, the updated net weights and descriptors."""
+    from types import SimpleNamespace
+    import oracle
+    from read_amd import _alias, camera
+    from READ.gl.myrender import MyRender                                     # the names src/train.py imports (:29, :596)
+    from READ.models.compose import ModelAndLoss
+    from READ.pipelines.ogl import TexturePipeline
+    W, H, N, B = 64, 48, 20_000, 2
+    FMT = "uv_1d_p1, uv_1d_p1_ds1, uv_1d_p1_ds2, uv_1d_p1_ds3, uv_1d_p1_ds4"
+    keys = FMT.replace(' ', '').split(',')
+    rng = np.random.default_rng(12)
+    xyz = synthetic.make_cloud(N)
+
+    class DS:
+        id, name, tgt_sh, input_format = 0, "scene0", (W, H), FMT
+        scene_data = {'pointcloud': {'xyz': xyz}}
+        def load(self): pass
+        def unload(self): pass
+
+    class Crit(torch.nn.Module):                       # stands in for the VGG criterion (its weights are a download)
+        def forward(self, out, target):
+            return (out - target).abs().mean()
+
+    huber_ratio = 1e4                                  # src/train.py:550
+    args = SimpleNamespace(inference=False, descriptor_size=8, texture_activation='none', use_mesh=False, supersampling=1,
+                           lr=1e-3, texture_lr=1e-1, texture_ckpt=None, merge_loss=True, use_mask=False, headless=True,
+                           # src/READ/pipelines/ogl.py:94: get_datasets returns (train, val, {id: texture checkpoint})
+                           get_datasets=lambda a: ([DS()], [DS()], {0: None}),
+                           criterion_module=Crit, criterion_args={}, pipeline='READ.pipelines.ogl.TexturePipeline')
+    _alias.set_result_convention('dict')
+    try:
+        pipeline = TexturePipeline()
+        pipeline.create(args)
+        assert pipeline.texture_ckpts == {0: None}
+        state = synthetic.make_unet_state(UNET_SPEC, 5)
+        pipeline.get_net().load_state_dict({k: torch.from_numpy(np.asarray(v)) for k, v in state.items()})
+        init = rng.random((1, 8, N)).astype(np.float32)
+        with torch.no_grad():
+            pipeline.textures[0].texture_.copy_(torch.from_numpy(init))
+        # ---- run_epoch (src/train.py:130-152)
+        model = ModelAndLoss(pipeline.model, pipeline.criterion, use_mask=args.use_mask)
+        ds_list = pipeline.ds_train
+        renderer = MyRender()
+        renderer.update_ds(ds_list)
+        pipeline.dataset_load(ds_list)
+        extra_optimizer = pipeline.extra_optimizer(ds_list)
+        model.cuda()
+        pipeline.model.eval()                          # eval_in_train (src/train.py:311-314)
+        # oracle twin
+        st_r = {k: torch.nn.Parameter(torch.from_numpy(np.asarray(v)).clone()) if (np.asarray(v).dtype == np.float32 and "running" not in k)
+                else torch.from_numpy(np.asarray(v)).clone() for k, v in state.items()}
+        tex_r = torch.nn.Parameter(torch.from_numpy(init.copy()))
+        opt_r = torch.optim.Adam([p for p in st_r.values() if isinstance(p, torch.nn.Parameter)], lr=1e-3)
+        ext_r = torch.optim.RMSprop([tex_r], lr=1e-1)
+        for it in range(2):
+            proj = np.stack([synthetic.make_proj(W, H, f=60.0)] * B)
+            view = np.stack([synthetic.sweep_pose(3 + 7 * it), synthetic.sweep_pose(21 + 5 * it)])
+            data = {'input': {'id': torch.tensor([0] * B)}, 'view_matrix': torch.from_numpy(view),
+                    'proj_matrix': torch.from_numpy(proj), 'target': torch.from_numpy(rng.random((B, 3, H, W)).astype(np.float32))}
+            # ---- run_sub (src/train.py:153-266)
+            data['input'], depths = renderer.render(data)
+            inputs = data['input']
+            data_input = {k: (v.cuda() if torch.is_tensor(v) else v) for k, v in inputs.items()}      # to_device
+            target = data['target'].cuda()
+            label, mask = None, None
+            out, loss_dict = model(data_input, target, label=label, mask=mask)
+            im_out = out['im_out']
+            assert set(out) == {'im_out'} and set(loss_dict) == {'vgg_loss', 'huber_loss'}
+            assert depths['uv_1d_p1'].shape == (B, 1, H, W)
+            loss = loss_dict['vgg_loss'] + loss_dict['huber_loss'] * huber_ratio
+            if hasattr(pipeline.model, 'reg_loss'):
+                loss = loss + pipeline.model.reg_loss()
+            loss.backward(create_graph=False)
+            pipeline.optimizer.step()
+            pipeline.optimizer.zero_grad()
+            extra_optimizer.step()
+            extra_optimizer.zero_grad()
+            # ---- the same iteration on the host
+            tm = camera.total_matrix(proj, view)
+            outs = []
+            for b in range(B):
+                oi, od = oracle.raster_multiscale(xyz, tm[b], W, H, 5)
+                for l, k in enumerate(keys):
+                    assert np.array_equal(inputs[k][b, 0].cpu().numpy(), oracle.index_to_float(oi[l])), (it, b, k)
+                    assert np.array_equal(depths[k][b, 0].cpu().numpy().view(np.uint32), od[l].view(np.uint32))
+                feats = [tex_r[:, :, torch.from_numpy(oi[l].astype(np.int64))] for l in range(4)]
+                outs.append(unet_torch.unet_forward(st_r, *feats))
+            im_r = torch.cat(outs, 0)
+            vgg_r, hub_r = (im_r - data['target']).abs().mean(), F.huber_loss(im_r, data['target'])
+            (vgg_r + hub_r * huber_ratio).backward()
+            opt_r.step(); opt_r.zero_grad(); ext_r.step(); ext_r.zero_grad()
+            _close(im_out, im_r, f"im_out, iteration {it}", rtol=2e-3 if it else 2e-5)    # Adam's first step amplifies round-off
+            for name, got, ref in (("vgg_loss", loss_dict['vgg_loss'], vgg_r), ("huber_loss", loss_dict['huber_loss'], hub_r)):
+                assert abs(float(got) - float(ref)) <= (1e-3 if it else 1e-5) * abs(float(ref)), (it, name, float(got), float(ref))
+        pipeline.model.check_ids()
+        sd = pipeline.get_net().state_dict()
+        for name in ("feat_extract.0.block.conv_f.weight", "Decoder.3.layers.3.main.1.block.conv_m.weight",
+                     "feat_extract.5.block.norm.bias", "SCM1.conv.block.conv_f.bias"):
+            _close(sd[name].cpu(), st_r[name].detach(), name, rtol=2e-3)
+        pipeline.dataset_unload(ds_list)
+        assert not pipeline.textures[0].texture_.is_cuda
+        # eval through the same model object, as EvalIterCb / OGL.infer(input_dict) read it (src/READ/gl/nn.py:130)
+        pipeline.dataset_load(ds_list)
+        model.cuda()
+        with torch.no_grad():
+            probe = {k: (v.cuda() if torch.is_tensor(v) else v) for k, v in renderer.render(data)[0].items()}
+            res = pipeline.model(probe)
+        assert isinstance(res, dict) and res['im_out'].shape == (B, 3, H, W)
+    finally:
+        _alias.set_result_convention(None)

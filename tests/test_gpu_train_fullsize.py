@@ -91,7 +91,10 @@ def test_training_step_8_crops_of_256(hip, bn_mode):
     feats = [tex_r[0][:, torch.from_numpy(m[:, 0])].permute(1, 0, 2, 3) for m in maps]
     for f in feats:
         f.retain_grad()
-    out_r = unet_torch.unet_forward(st_r, *feats[:4], training=training)
+    # eval-mode BatchNorm: a plain batch equals the reference's per-item calls; .train(): the reference calls the net once per
+    # item (READ/models/compose.py:137-176 — per-item statistics, running buffers moved B times), pinned in tests/test_oracle_unet.py
+    out_r = (unet_torch.unet_forward_per_item(st_r, *feats[:4], training=True) if training
+             else unet_torch.unet_forward(st_r, *feats[:4]))
     loss_r = F.huber_loss(out_r, target) * 1e4
     loss_r.backward()
     ref_opt = torch.optim.RMSprop([tex_r], lr=0.1)
@@ -133,3 +136,5 @@ def test_training_step_8_crops_of_256(hip, bn_mode):
             if "running_" in k and not k.startswith("ConvsOut."):
                 e = float((sd[k].cpu().double() - st_r[k].double()).abs().max()) / max(float(st_r[k].abs().max()), 1e-30)
                 assert e <= 1e-4, (k, e)
+            if k.endswith("num_batches_tracked") and not k.startswith("ConvsOut."):
+                assert int(sd[k]) == B, (k, int(sd[k]))                 # one BatchNorm call per item, as the reference's loop

@@ -97,6 +97,22 @@ def test_input_format_tokens(golden_dir):
     for bad in g["value_error"]:
         with pytest.raises(ValueError):
             parse_input_string(bad)
+    # the other direction (READ/gl/dataset.py:85-122): the reference's generate_input_string on every parsed configuration and
+    # on the configurations of its own test_generate_parse (:124-200)
+    from read_amd.render import generate_input_string
+    for tok, want in g["generated"].items():
+        got = generate_input_string(parse_input_string(tok))
+        if tok.startswith("labels"):
+            assert want == "_p1" and got == tok      # the reference has no branch for MODE_LABEL; here the round trip holds
+        else:
+            assert got == want == tok, (tok, got, want)
+    assert len(g["reference_test_generate_parse"]) == 6
+    for case in g["reference_test_generate_parse"]:
+        cfg = dict(case["config"], mode=tuple(case["config"]["mode"]))
+        assert generate_input_string(cfg) == case["string"], case
+        assert parse_input_string(case["string"]) == cfg
+    with pytest.raises(ValueError):
+        generate_input_string({"mode": (3, 7), "draw_points": False})
     assert is_point_id_pyramid("uv_1d_p1, uv_1d_p1_ds1, uv_1d_p1_ds2, uv_1d_p1_ds3, uv_1d_p1_ds4")
     for fmt in ("uv_1d_p1, uv_1d_p2_ds1", "uv_1d_p1_ds1", "colors_p1", "uv_1d_ps4", "uv_1d_p1, uv_1d_p1_ds2"):
         assert not is_point_id_pyramid(fmt)

@@ -122,3 +122,139 @@ def test_reference_datasets_use_the_hip_renderer():
     print('ok')
     """, ref)
     assert r.returncode == 0, r.stderr
+
+
+_TRAIN_PY_DRIVER = """
+    import sys, types, importlib
+    def stub(name, **attrs):
+        m = types.ModuleType(name); m.__dict__.update(attrs); sys.modules[name] = m; return m
+    # third-party packages train.py imports at its top that are not in this image (no network): inert modules.  Nothing of
+    # READ itself is stubbed — READ.utils.*, READ.models.compose, READ.pipelines come through the alias package.
+    for pkg in ("cv2", "torchvision", "tensorboardX", "munch", "matplotlib", "tqdm"):
+        try:
+            importlib.import_module(pkg)
+        except ImportError:
+            if pkg == "torchvision":
+                tv = stub(pkg); tv.transforms = stub(pkg + ".transforms"); tv.utils = stub(pkg + ".utils")
+            elif pkg == "matplotlib":
+                stub(pkg).cm = stub(pkg + ".cm")
+            elif pkg == "tensorboardX":
+                stub(pkg, SummaryWriter=object)
+            elif pkg == "tqdm":
+                stub(pkg, tqdm=lambda it, **k: it)
+            else:
+                stub(pkg)
+    path, last_line, want = sys.argv[1], int(sys.argv[2]), sys.argv[3]
+    block = "\\n".join(open(path).read().splitlines()[:last_line])
+    assert "from READ.models.compose import ModelAndLoss" in block and "from READ.pipelines import save_pipeline" in block
+    g = {"__name__": "train_import_block"}
+    exec(compile(block, path, "exec"), g)                          # the reference's own import block, verbatim
+    import read_amd.net_texture, read_amd.pipeline, read_amd._alias, read_amd.unet
+    assert g["ModelAndLoss"] is read_amd.net_texture.ModelAndLoss
+    assert g["save_pipeline"] is read_amd.pipeline.save_pipeline
+    assert "reference" in sys.modules[g["TicToc"].__module__].__file__      # READ.utils.* still the reference's
+    assert "reference" in sys.modules[g["to_device"].__module__].__file__
+    assert read_amd._alias.result_convention() == want, read_amd._alias.result_convention()
+    # what train.py does next with these names (train.py:405-420 / src/train.py:571-575): the pipeline by dotted path
+    pipeline = g["get_module"]("READ.pipelines.ogl.TexturePipeline")()
+    assert isinstance(pipeline, read_amd.pipeline.TexturePipeline)
+    # the rest of the aliased modules keeps every name of the reference's
+    from READ.models.compose import NetAndTexture, MultiscaleNet, RGBTexture, BoxFilter, GaussianLayer
+    assert NetAndTexture is read_amd.net_texture.NetAndTexture
+    assert "_reference" in BoxFilter.__module__ and BoxFilter(3, 3)(__import__("torch").zeros(1, 3, 8, 8)).shape == (1, 3, 8, 8)
+    from READ.models.texture import PointTexture, MeshTexture
+    try:
+        MeshTexture(3, 64)
+        raise SystemExit("MeshTexture must refuse")
+    except NotImplementedError:
+        pass
+    from READ.gl.dataset import generate_input_string, parse_input_string
+    assert generate_input_string(parse_input_string("uv_1d_p1_ds2")) == "uv_1d_p1_ds2"
+    from READ.models.unet import UNet
+    assert UNet is read_amd.unet.UNet
+    print("ok")
+"""
+
+
+def _train_py_block(tree, last_line, convention):
+    ref = "/root/reference" + ("/src" if tree == "src" else "")
+    if not os.path.isfile(os.path.join(ref, "train.py")):
+        import pytest
+        pytest.skip("reference checkout not present")
+    env = dict(os.environ, PYTHONPATH=os.pathsep.join([ROOT, ref]))
+    env.pop("READ_AMD_RESULT", None)
+    r = subprocess.run([sys.executable, "-c", textwrap.dedent(_TRAIN_PY_DRIVER), os.path.join(ref, "train.py"), str(last_line),
+                        convention], env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-3000:]
+    assert r.stdout.strip().endswith("ok")
+
+
+def test_root_train_py_import_block_runs_through_the_alias():
+    """/root/reference/train.py:1-28 executed verbatim under PYTHONPATH=repo:reference (INTEGRATION level 1) —
+    ``from READ.models.compose import ModelAndLoss`` (:26) used to raise ImportError.  Root tree => tensor results."""
+    _train_py_block("root", 28, "tensor")
+
+
+def test_src_train_py_import_block_runs_through_the_alias():
+    """/root/reference/src/train.py:1-33 under PYTHONPATH=repo:reference/src; the src tree behind => {'im_out'} results."""
+    _train_py_block("src", 33, "dict")
+
+
+def test_model_and_loss_equals_both_reference_classes():
+    """``ModelAndLoss`` against the reference's two classes (READ/models/compose.py:12-32 root, src/READ/models/compose.py:14-42)
+    on the same model, criterion, inputs, mask and label: outputs and every loss entry identical."""
+    import importlib.util
+    import types
+    import pytest
+    import torch
+    from read_amd.net_texture import ModelAndLoss
+    if not os.path.isdir("/root/reference/READ"):
+        pytest.skip("reference checkout not present")
+
+    def load(path, name):
+        added = [m for m in ("imageio", "cv2") if m not in sys.modules]
+        for m in added:
+            sys.modules[m] = types.ModuleType(m)
+        try:
+            spec = importlib.util.spec_from_file_location(name, path)
+            mod = importlib.util.module_from_spec(spec)
+            spec.loader.exec_module(mod)
+        finally:
+            for m in added:
+                sys.modules.pop(m, None)
+        return mod
+    root = load("/root/reference/READ/models/compose.py", "_ref_compose_root")
+    src = load("/root/reference/src/READ/models/compose.py", "_ref_compose_src")
+    torch.manual_seed(3)
+    conv, seg = torch.nn.Conv2d(4, 3, 3, padding=1), torch.nn.Conv2d(4, 5, 1)
+
+    class TensorNet(torch.nn.Module):
+        def forward(self, x, **kw):
+            return conv(x)
+
+    class DictNet(torch.nn.Module):
+        def forward(self, x, **kw):
+            return {'im_out': conv(x), 'seg_out': seg(x)}
+    crit = torch.nn.L1Loss()
+    x, target = torch.randn(2, 4, 16, 16), torch.rand(2, 3, 16, 16)
+    mask = (torch.rand(2, 1, 16, 16) > 0.3).float()
+    label = torch.randint(0, 5, (2, 16, 16))
+    for use_mask in (False, True):
+        o_r, l_r = root.ModelAndLoss(TensorNet(), crit, use_mask=use_mask)(x, target, mask=mask)
+        o, l = ModelAndLoss(TensorNet(), crit, use_mask=use_mask)(x, target, mask=mask)
+        assert torch.equal(o, o_r) and torch.equal(l, l_r)
+        for lab in (None, label):
+            o_r, l_r = src.ModelAndLoss(DictNet(), crit, use_mask=use_mask)(x, target, mask=mask, label=lab)
+            o, l = ModelAndLoss(DictNet(), crit, use_mask=use_mask)(x, target, mask=mask, label=lab)
+            assert set(o) == set(o_r) and all(torch.equal(o[k], o_r[k]) for k in o)
+            assert set(l) == set(l_r) == ({'vgg_loss', 'huber_loss'} | ({'seg_loss'} if lab is not None else set()))
+            assert all(torch.equal(l[k], l_r[k]) for k in l), {k: (float(l[k]), float(l_r[k])) for k in l}
+    # MultiscaleNet (compose.py:184-212), same check
+    from read_amd.net_texture import MultiscaleNet
+    ins = lambda: {'id': 0, 'a': torch.ones(1, 2, 8, 8), 'b': torch.zeros(1, 2, 8, 8), 'c': torch.ones(1, 2, 4, 4), 'd': torch.ones(1, 2, 4, 4)}
+
+    class Cat(torch.nn.Module):
+        def forward(self, *xs, **kw):
+            return sum(float(x.sum()) for x in xs), [tuple(x.shape) for x in xs]
+    for ss in (1, 2):
+        assert MultiscaleNet(Cat(), 2, ss)(ins()) == root.MultiscaleNet(Cat(), 2, ss)(ins())
