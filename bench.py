@@ -460,7 +460,8 @@ def run_train(a, dev, street=None, steps=None, warm=None, cpu_timing=True, do_ve
                 oracle_iteration(views, targets[i % 4].cpu(), st_r, tex_r)
                 opt_r.step(); opt_r.zero_grad(); ext_r.step(); ext_r.zero_grad()
             t_cpu = (time.perf_counter() - t0) / n_cpu
-            base = {"value": 1.0 / t_cpu, "unit": "iters/s", "cores": torch.get_num_threads(), "kind": "port",
+            base = {"value": 1.0 / t_cpu, "unit": "iters/s", "cores": os.cpu_count() or 1, "threads_used": torch.get_num_threads(),
+                    "kind": "port",
                     "sample": f"1 warm-up ({t_first:.1f} s, also the verification iteration) + {n_cpu} timed iterations of 8 crops: "
                               f"oracle rasteriser (C/OpenMP, {r_threads} threads, 8 cameras x 5 scales over {N} points) + torch-CPU "
                               "gather + UNet forward/backward + Huber through the oracle + torch Adam + dense torch RMSprop"}
@@ -477,7 +478,23 @@ def run_train(a, dev, street=None, steps=None, warm=None, cpu_timing=True, do_ve
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
     fwd_flops = 187.06e9 * B                                      # conv MACs x 2 at 256x256, measured on the reference module
-    achieved = 3.0 * fwd_flops / (dt / steps) / 1e12               # forward + dgrad + wgrad
+    algorithmic = 3.0 * fwd_flops / (dt / steps) / 1e12            # forward + dgrad + wgrad, direct-convolution count
+    # the flops the step's launches EXECUTE (the convention of the headline's roofline.frac): one instrumented step logs every
+    # convolution launch with the kernel family the library takes for it (read_conv_kernel_family) — F(4x4,3x3) executes 1/4
+    # of the direct count, F(2x2,3x3) 1/2.25, direct kernels / wgrad all of it (padded channels and dilated dgrads included)
+    from read_amd import train as _train
+    step_path = _train.LAST_STEP_PATH                              # 'graph': the timed steps replayed the captured HIP graphs
+    _train.FLOP_LOG, graph_was = [], _train.GRAPH_TRAIN
+    _train.GRAPH_TRAIN = False                                     # the instrumented step runs the per-layer Python (same launches)
+    try:
+        step(warm + steps)
+        torch.cuda.synchronize()
+        log = list(_train.FLOP_LOG)
+    finally:
+        _train.FLOP_LOG, _train.GRAPH_TRAIN = None, graph_was
+    gain = {4: 4.0, 2: 2.25}
+    executed_flops = sum(fl / gain.get(fam, 1.0) for (_, fl, fam) in log)
+    achieved = executed_flops / (dt / steps) / 1e12 if log else algorithmic
     out = {"metric": "training iterations/sec (8 crops of 256x256 per iteration)", "value": steps / dt, "unit": "iters/s",
            "n_gpus": 1, "steps": steps, "warmup": warm, "ms_per_step": 1e3 * dt / steps, "higher_is_better": True,
            "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
@@ -489,10 +506,17 @@ def run_train(a, dev, street=None, steps=None, warm=None, cpu_timing=True, do_ve
                       "points": N, "crop": S, "batch": B, "parallelism": "single GPU (DataParallel of the reference not rebuilt)"},
            "roofline": {"kernel": "whole step (MFMA convolutions forward + dgrad + wgrad)", "bound": "mfma",
                         "achieved": achieved, "peak": FP32_MFMA_PEAK_TFS, "unit": "TFLOP/s", "frac": achieved / FP32_MFMA_PEAK_TFS,
-                        "traffic": None, "flops_per_step": 3.0 * fwd_flops,
-                        "note": "3 x the forward convolution FLOPs of 8 crops / wall time of a step (host-side autograd "
-                                "bookkeeping included)"},
+                        "traffic": None, "flops_per_step": executed_flops if log else 3.0 * fwd_flops,
+                        "algorithmic_flops_per_step": 3.0 * fwd_flops, "algorithmic_TFLOPs": algorithmic,
+                        "frac_algorithmic": algorithmic / FP32_MFMA_PEAK_TFS,
+                        "launches_logged": {k_: sum(1 for (kk, _, _) in log if kk == k_) for k_ in ("conv", "wgrad", "dgrad_valu")},
+                        "winograd_f4_launches": sum(1 for (_, _, f_) in log if f_ == 4),
+                        "winograd_f2_launches": sum(1 for (_, _, f_) in log if f_ == 2),
+                        "note": "achieved = MFMA flops the step's convolution launches EXECUTE (forward pre-activations and "
+                                "dgrad on the Winograd kernels at 1/4 or 1/2.25 of the direct count, wgrad direct) / wall time of "
+                                "a step, the headline's convention; frac_algorithmic = 3 x SURVEY 8d's forward count / wall time"},
            "host_enqueue_ms_per_step": 1e3 * dt_host / steps,      # close to ms_per_step = the step is bound by the host side
+           "step_path": step_path,
            "final_loss": float(loss.detach()), "tuning": _lib.tuning_state(), "cpu_baseline": base, "verified": verified}
     pipe.dataset_unload([DS()])
     return out
@@ -546,7 +570,7 @@ def cpu_leg(wl, frames, pose0=0, probe_threads=True):
     if frames == 0:
         return None, first
     per = (t_r + t_g + t_u) / frames
-    base = {"value": 1.0 / per, "unit": "frames/s", "cores": cores, "kind": "port",
+    base = {"value": 1.0 / per, "unit": "frames/s", "cores": ncpu, "threads_used": cores, "raster_threads_used": r_threads, "kind": "port",
             "sample": f"1 warm-up + {frames} timed full frames ({W}x{H}, {xyz.shape[0]} pts, sweep poses 1..{frames}): oracle "
                       f"raster C/OpenMP on {r_threads} threads + torch-CPU gather + torch-CPU fp32 UNet on {cores} threads "
                       f"(best of the probed thread counts) of {ncpu}",
@@ -601,6 +625,23 @@ def timed_sweep(wl, ex, warmup, steps, world, dev):
     return dt
 
 
+def frame_latencies(wl, ex, n, first_step):
+    """One frame at a time, each frame timed on its own from the call to its completion (host clock around render + sync):
+    what a viewer sees per frame.  -> percentiles in ms."""
+    ts = []
+    for i in range(first_step, first_step + n):
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        sweep.run_steps(wl.render_into, ex, i, 1, N_POSES)
+        if hasattr(wl, "fr"):
+            wl.fr.sync()
+        torch.cuda.synchronize()
+        ts.append(1e3 * (time.perf_counter() - t0))
+    q = np.percentile(np.asarray(ts), [50, 90, 99])
+    return {"p50_ms": float(q[0]), "p90_ms": float(q[1]), "p99_ms": float(q[2]), "min_ms": float(min(ts)), "max_ms": float(max(ts)),
+            "frames": n}
+
+
 def stage_times(wl):
     """Per-kernel durations, live, with HIP events on the launch stream."""
     # the rasteriser warm-starts from the previous frame, so it is timed over consecutive poses of the sweep
@@ -623,7 +664,9 @@ def also_records(a, dev, wl, first=None):
         ex = sweep.FrameExchange((wl.H, wl.W, 4), dev, torch.float32, None)
         n = min(a.steps, 64)
         dt = timed_sweep(wl, ex, a.warmup, n, 1, dev)
+        lat = frame_latencies(wl, ex, max(n, 100), a.warmup + n)
         rec["latency_mode"] = {"value": n / dt, "unit": "frames/s", "ms_per_step": 1e3 * dt / n, "steps": n, "frames_in_flight": 1,
+                               "frame_latency": lat,
                                "what": "headline workload, one frame at a time (every frame complete before the next starts)",
                                # the oracle's frame of pose 0 (computed for the headline) against THIS mode's frame of pose 0
                                "verified": verify(wl, first, pose=0) if first is not None else None}
@@ -656,7 +699,10 @@ def also_records(a, dev, wl, first=None):
     at.points = 0
     t = run_train(at, dev, street=street, steps=10, warm=2, cpu_timing=False)
     rec["train"] = {"value": t["value"], "unit": t["unit"], "ms_per_step": t["ms_per_step"], "steps": t["steps"],
-                    "frac": t["roofline"]["frac"], "final_loss": t["final_loss"], "verified": t["verified"],
+                    "frac": t["roofline"]["frac"], "frac_algorithmic": t["roofline"]["frac_algorithmic"],
+                    "frac_convention": "executed MFMA flops / wall time (as roofline.frac of the headline)",
+                    "host_enqueue_ms_per_step": t["host_enqueue_ms_per_step"], "step_path": t.get("step_path"),
+                    "final_loss": t["final_loss"], "verified": t["verified"],
                     "what": t["config"]["workload"]}
     return rec
 
@@ -738,7 +784,10 @@ def main():
                 "bound": "mfma",
                 "achieved": executed_tfs, "peak": FP32_MFMA_PEAK_TFS, "unit": "TFLOP/s",
                 "frac": executed_tfs / FP32_MFMA_PEAK_TFS, "traffic": traffic,
-                "traffic_unit": f"HBM bytes per launch (rocprofv3 FETCH_SIZE*2 + WRITE_SIZE, profiles/{traffic_src})",
+                "traffic_unit": "HBM bytes per launch (rocprofv3 FETCH_SIZE*2 + WRITE_SIZE)",
+                "traffic_source": f"static: profiles/{traffic_src} — separate --pmc passes of this command, committed; NOT measured "
+                                  "in this run (counters need rocprofv3 around the process)" if traffic_src else None,
+                "frac_algorithmic": algorithmic_tfs / FP32_MFMA_PEAK_TFS,
                 "launches_per_frame": n_c3, "avg_launch_ms": c3_ms / max(n_c3, 1),
                 "executed_flops_per_frame": c3_exec, "algorithmic_flops_per_frame": c3_fl,
                 "algorithmic_TFLOPs": algorithmic_tfs, "winograd_f2_launches": n_wino, "winograd_f4_launches": n_wino4,

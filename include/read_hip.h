@@ -279,6 +279,11 @@ int read_conv_pack_params_host(int Cout, const float *bf, const float *bm, const
                                const float *beta, const float *mean, const float *var, float eps,
                                float *params_host);
 int read_gated_conv_forward(const read_conv_desc *desc, void *stream);
+/* Which kernel family read_gated_conv_forward takes for this (filled) descriptor under the current tuning knobs: 4 = Winograd
+ * F(4x4,3x3) (reads wpacked_w4), 2 = Winograd F(2x2,3x3) (reads wpacked_wino), 0 = direct implicit GEMM (reads wpacked); -1 =
+ * NULL.  A host that packs ONE fragment order per layer asks this before packing (set the pointer it intends to fill to any
+ * non-NULL value); a launch whose wpacked aliases Winograd fragments it would not read is refused with READ_EINVAL. */
+int read_conv_kernel_family(const read_conv_desc *desc);
 /* Number of compiled tile configurations and a printable name for each (for tuning sweeps). */
 int read_conv_config_count(void);
 const char *read_conv_config_name(int config);

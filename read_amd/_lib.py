@@ -85,6 +85,7 @@ SIGNATURES = {
     "read_conv_w4_floats": (_sz, [_i, _i]),
     "read_conv_pack_w4_host": (_i, [_i, _i, _vp, _vp, _vp]),
     "read_gated_conv_forward": (_i, [C.POINTER(ConvDesc), _vp]),
+    "read_conv_kernel_family": (_i, [_vp]),
     "read_conv_config_count": (_i, []),
     "read_conv_config_name": (C.c_char_p, [_i]),
     "read_bilinear_up4": (_i, [_vp, _i, _i, _i, _vp, _vp]),

@@ -2857,8 +2857,27 @@ int conv_kc_for(const read_conv_desc *d)
 
 }  // namespace readhip
 
+extern "C" int read_conv_kernel_family(const read_conv_desc *desc)
+{
+    if (!desc) return -1;
+    if (readhip::conv_uses_w4(desc)) return 4;
+    if (readhip::conv_uses_wino(desc)) return 2;
+    return 0;
+}
+
 extern "C" int read_gated_conv_forward(const read_conv_desc *desc, void *stream)
 {
+    // One fragment order per layer is enough for a host that asked read_conv_kernel_family first; a host that aliases
+    // wpacked to its Winograd fragments (training: read_amd/train.py packs ONE order per layer and step) must never reach a
+    // kernel that reads wpacked as the direct order — a tuning knob, a 2 GiB tensor or an odd out_cstride can decline the
+    // Winograd kernels after the host has packed for them.
+    if (desc && desc->wpacked) {
+        const int family = read_conv_kernel_family(desc);
+        READ_CHECK_ARG(!((const void *)desc->wpacked == (const void *)desc->wpacked_w4 && family != 4) &&
+                           !((const void *)desc->wpacked == (const void *)desc->wpacked_wino && family != 2),
+                       "read_gated_conv_forward: wpacked aliases Winograd fragments but the launch takes kernel family %d "
+                       "(ask read_conv_kernel_family before packing)", family);
+    }
     return readhip::launch_gated_conv(desc, as_stream(stream));
 }
 

@@ -125,6 +125,17 @@ class FrameExchange:
                 self.pending[j] = None
 
 
+def sweep_steps(n_poses, world):
+    """Steps that cover every pose of the sweep once: ceil(n_poses / world).  When ``n_poses % world != 0`` the ranks past the
+    end of the last step wrap around to the head of the sweep (``pose_of_step``) — every rank renders and exchanges in every
+    step, so the collectives stay matched; a consumer drops the wrapped frames (``pose_of_step(...) < step * world``)."""
+    return (n_poses + world - 1) // world
+
+
+def pose_of_step(step, rank, world, n_poses):
+    return (step * world + rank) % n_poses
+
+
 def run_steps(render_into, exchange, first, count, n_poses):
     """Steps first .. first+count-1 of the sweep on this rank: step i renders pose ``(i * world + rank) % n_poses`` into
     the exchange's buffer and posts the exchange.  ``render_into(pose_index, out_tensor)`` returns None, or the event that
@@ -132,7 +143,7 @@ def run_steps(render_into, exchange, first, count, n_poses):
     world, rank = exchange.world, exchange.rank
     for i in range(first, first + count):
         out = exchange.buffer(i)
-        done = render_into((i * world + rank) % n_poses, out)      # an event if the frame completes on another stream
+        done = render_into(pose_of_step(i, rank, world, n_poses), out)   # an event if the frame completes on another stream
         exchange.post(i, done)
 
 

@@ -21,6 +21,7 @@ layer normalises with the statistics of the batch and moves its running buffers 
 ``read_gate_backward_bn``), exactly what nn.BatchNorm2d does in the reference's BasicConv (unet.py:40,51).
 """
 import ctypes as C
+import os
 import weakref
 
 import torch
@@ -68,8 +69,17 @@ def _linear_conv(x, cin, wpacked, params, cout, k, stride, out, wino=None, gated
         if gated is not None:
             y, elu, bh, vh = gated
             d.out_gated, d.elu, d.block_h, d.valid_h = y.data_ptr(), int(elu), int(bh), int(vh)
+    if FLOP_LOG is not None:                                 # bench.py: MFMA flops this launch EXECUTES (Winograd gains counted)
+        pad = (k - 1) // 2
+        Ho, Wo = (H + 2 * pad - k) // stride + 1, (W + 2 * pad - k) // stride + 1
+        FLOP_LOG.append(("conv", 2.0 * Ho * Wo * cin * 2 * cout * k * k, int(_lib.lib().read_conv_kernel_family(C.byref(d)))))
     _lib.check(_lib.lib().read_gated_conv_forward(C.byref(d), _lib.stream_ptr()), "read_gated_conv_forward(linear)")
     return out
+
+
+# bench.py sets this to a list for one instrumented step: (kind, direct-convolution flops of the launch as issued — padded /
+# dilated operands included —, kernel family 4 = F(4x4,3x3) executes 1/4 of them, 2 = F(2x2,3x3) 1/2.25, 0 = all)
+FLOP_LOG = None
 
 
 # packed copies of a layer's weights, reused by every image of a batch (weights only change at optimizer steps, which bump
@@ -141,7 +151,10 @@ def _packed_for(wf, bf, wm, bm, gamma, beta, mean, var, cin, cout, k, identity_b
         ver = tuple(t._version for t in (wf, bf, wm, bm)) + (wf.data_ptr(), wm.data_ptr(), 'identity')
     else:
         ver = tuple(t._version for t in (wf, bf, wm, bm, gamma, beta, mean, var)) + (wf.data_ptr(), wm.data_ptr())
-    hit = _PACK_CACHE.get(id(wf))
+    # While a HIP graph is being captured (GraphedTrainStep) every layer packs afresh: the packing launches must be PART of
+    # the graph — it is replayed after every optimizer step — and a cache hit would freeze the fragments of the capture step in.
+    capturing = torch.cuda.is_current_stream_capturing()
+    hit = None if capturing else _PACK_CACHE.get(id(wf))
     if hit is not None and hit[6]() is not wf:              # the id was recycled by another tensor: not this layer's entry
         hit = None
     if hit is not None and hit[0] == ver:
@@ -186,7 +199,8 @@ def _packed_for(wf, bf, wm, bm, gamma, beta, mean, var, cin, cout, k, identity_b
         ref = weakref.ref(wf)
         weakref.finalize(wf, _drop_pack, key, ref)            # the entry dies with its parameter
     entry = [ver, params, wp, None, ev, wino, ref]
-    _PACK_CACHE[key] = entry
+    if not capturing:                                         # a captured entry lives in the graph's memory pool, not in the cache
+        _PACK_CACHE[key] = entry
     return entry
 
 
@@ -331,11 +345,15 @@ class GatedConvFn(torch.autograd.Function):
                 zero = _zero_params(L.read_conv_param_floats(cin // 2), dev)
                 _linear_conv(d_in, 2 * cp, wd, zero, cin // 2, k, 1, dx, wino=wdw, w4=_w4_fits(2 * cp, cin // 2))
             else:
+                if FLOP_LOG is not None:
+                    FLOP_LOG.append(("dgrad_valu", 2.0 * Ho * Wo * cin * 2 * cout * k * k, 0))
                 ws = torch.empty(L.read_conv_dgrad_generic_floats(cin, cout, k), dtype=torch.float32, device=dev)
                 _lib.check(L.read_conv_dgrad_generic(dfm.data_ptr(), Ho, Wo, cin, cout, k, stride, wf.data_ptr(), wm.data_ptr(),
                                                      ws.data_ptr(), H, W, dx.data_ptr(), st))
         if not (ctx.needs_input_grad[1] or ctx.needs_input_grad[3]):        # frozen net: nobody asked for weight gradients
             return dx, None, dbf, None, dbm, dgamma, dbeta, None, None, None, None, None, None, None, None, None
+        if FLOP_LOG is not None:
+            FLOP_LOG.append(("wgrad", 2.0 * Ho * Wo * cin * 2 * cout * k * k, 0))
         dwf, dwm = torch.empty_like(wf), torch.empty_like(wm)
         n_scr = L.read_conv_wgrad_scratch_floats(cin, cout, k, Ho)
         scratch = torch.empty(n_scr, dtype=torch.float32, device=dev)
@@ -508,11 +526,128 @@ def stack_batch(x_nchw, level):
     return x.reshape(-1, w, c).contiguous()
 
 
+# -----------------------------------------------------------------------------------------------------------------------
+# The training forward and backward of the UNet as two HIP graphs
+# -----------------------------------------------------------------------------------------------------------------------
+# Round 3 measured the training step host-bound: 48 of 58 ms were Python around 99 autograd nodes (allocation, cache lookups,
+# ctypes, stream bookkeeping; bench.py host_enqueue_ms_per_step).  The launch sequence of a step is the same every iteration —
+# same shapes, same weights at the same addresses — so it is captured ONCE per batch geometry into a forward and a backward HIP
+# graph (torch.cuda.make_graphed_callables: the autograd-aware wrapper around hipGraph capture of both passes, static input /
+# output / gradient buffers) and replayed: two graph launches per step instead of ~1500 Python-driven ones.  Everything the
+# eager path does per step is inside the graphs — packing the weights' fragment orders (they change with every optimizer
+# step), batch-statistics BatchNorm with its running-buffer updates, the wgrad side stream and its join.
+# What a graph cannot tolerate falls back to the eager path on its own: a second forward before the first one's backward
+# (gradient accumulation over several forwards: the graphs share ONE set of saved activations), parameters moved to other
+# addresses (.cuda() / .to(): the key changes and a new pair is captured), hooks, anomaly mode, a failed capture.
+GRAPH_TRAIN = os.environ.get("READ_AMD_GRAPH_TRAIN", "1") != "0"
+_GRAPH_CACHE_MAX = 4         # (geometry, mode) pairs kept per net: a graph pair holds every activation of its step
+
+
+class _TrainCore(torch.nn.Module):
+    """The callable make_graphed_callables captures: its parameters are the net's parameters."""
+
+    def __init__(self, net, per_item):
+        super().__init__()
+        self.net = net
+        self.per_item = bool(per_item)
+
+    def forward(self, x0, x1, x2, x3):
+        return _unet_forward_train_batch_eager(self.net, [x0, x1, x2, x3], self.per_item)
+
+
+class _GraphedStep:
+    def __init__(self, fn):
+        self.fn = fn
+        self.pending = False         # a forward whose backward has not run yet: its saved activations are still needed
+
+    def __call__(self, xs):
+        out = self.fn(*xs)
+        self.pending = True
+        out.register_hook(self._done)
+        return out
+
+    def _done(self, grad):
+        self.pending = False
+        return grad
+
+
+def _graph_key(net, xs, per_item):
+    ts = net.__dict__.get('_flat_tensors')
+    if ts is None:
+        ts = net.__dict__['_flat_tensors'] = list(net.parameters()) + list(net.buffers())
+    return (tuple(tuple(x.shape) for x in xs), tuple(bool(x.requires_grad) for x in xs), bool(net.training), bool(per_item),
+            hash(tuple(t.data_ptr() for t in ts)), hash(tuple(bool(t.requires_grad) for t in ts)))
+
+
+def _graphed_step(net, xs, per_item):
+    """-> the captured step for this geometry, or None (then the caller runs eagerly)."""
+    if not (GRAPH_TRAIN and torch.is_grad_enabled() and all(x.is_cuda and x.dtype == torch.float32 for x in xs)):
+        return None
+    if torch.cuda.is_current_stream_capturing() or torch.is_anomaly_enabled():
+        return None
+    if not any(p.requires_grad for p in net.parameters()) and not any(x.requires_grad for x in xs):
+        return None
+    if net._forward_hooks or net._backward_hooks or net._forward_pre_hooks:
+        return None
+    cache = net.__dict__.setdefault('_train_graphs', {})
+    key = _graph_key(net, xs, per_item)
+    g = cache.get(key)
+    if g is None:
+        if len(cache) >= _GRAPH_CACHE_MAX:
+            cache.pop(next(iter(cache)))
+        g = cache[key] = _capture_step(net, xs, per_item)
+    if g is False or g.pending:
+        return None
+    return g
+
+
+def _capture_step(net, xs, per_item):
+    core = _TrainCore(net, per_item)
+    if not net.training:
+        core.eval()
+    # make_graphed_callables runs three eager warm-up iterations before it captures: in .train() they would move the BatchNorm
+    # running buffers and num_batches_tracked — restored below (capture itself executes nothing)
+    saved = [b.detach().clone() for b in net.buffers()] if net.training else None
+    sample = tuple(x.detach().clone().requires_grad_(x.requires_grad) for x in xs)
+    try:
+        fn = torch.cuda.make_graphed_callables(core, sample, num_warmup_iters=2, allow_unused_input=True)
+    except Exception as e:                                   # capture refused (an API the graph cannot hold, out of memory ...)
+        try:
+            torch.cuda.synchronize()
+        except Exception:
+            pass
+        import warnings
+        warnings.warn(f"read_amd: HIP-graph capture of the UNet training step failed ({type(e).__name__}: {e}); "
+                      "this geometry runs eagerly")
+        return False
+    finally:
+        if saved is not None:
+            with torch.no_grad():
+                for b, v in zip(net.buffers(), saved):
+                    b.copy_(v)
+    return _GraphedStep(fn)
+
+
 def unet_forward_train_batch(net, xs, per_item_statistics=False):
     """xs: four (B,8,h,w) pyramids -> (B,3,H,W) through ONE stacked image.  In ``.train()`` the BatchNorm layers normalise with
     the statistics of the whole batch — ``nn.BatchNorm2d`` on a (B,C,h,w) tensor — unless ``per_item_statistics``: then every item
     is its own batch of one and the running buffers move B times in item order, which is what B separate calls of the net do
-    (``NetAndTexture.forward``, READ/models/compose.py:137-176)."""
+    (``NetAndTexture.forward``, READ/models/compose.py:137-176).  The launches of the step come out of a pair of HIP graphs
+    when the step can be captured (``_graphed_step``), else from the per-layer autograd nodes directly; ``LAST_STEP_PATH`` says
+    which ('graph' / 'eager')."""
+    global LAST_STEP_PATH
+    g = _graphed_step(net, xs, per_item_statistics)
+    if g is not None:
+        LAST_STEP_PATH = 'graph'
+        return g(xs)
+    LAST_STEP_PATH = 'eager'
+    return _unet_forward_train_batch_eager(net, xs, per_item_statistics)
+
+
+LAST_STEP_PATH = None
+
+
+def _unet_forward_train_batch_eager(net, xs, per_item_statistics=False):
     B, _, H, W = xs[0].shape
     if H % 16 or W % 16:
         raise ValueError(f"training crops must be multiples of 16, got {W}x{H}")

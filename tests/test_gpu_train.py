@@ -558,3 +558,80 @@ def test_src_train_py_loop_body_with_dict_results(hip):
         assert isinstance(res, dict) and res['im_out'].shape == (B, 3, H, W)
     finally:
         _alias.set_result_convention(None)
+
+
+def test_training_step_from_hip_graphs_equals_the_eager_step(hip):
+    """The UNet's training forward / backward captured into a pair of HIP graphs (read_amd/train.py _graphed_step) against the
+    same step driven layer by layer from Python: outputs, input and parameter gradients — at the capture step AND after the
+    weights have changed (the fragment packing is part of the graph, so a replay must see the new weights), in eval-mode and
+    batch-statistics BatchNorm (running buffers: the capture's warm-up iterations must leave no trace); a second forward before
+    the first one's backward must not reuse the graphs' single set of saved activations."""
+    from read_amd import train as T
+    H, W, B = 32, 48, 2
+    state = synthetic.make_unet_state(UNET_SPEC, 23)
+    rng = np.random.default_rng(31)
+    xs = [torch.from_numpy(rng.random((B, 8, H >> l, W >> l)).astype(np.float32)).cuda() for l in range(4)]
+    g = torch.from_numpy(rng.standard_normal((B, 3, H, W)).astype(np.float32)).cuda()
+
+    def run(net, graph, n_steps, bn_train):
+        net.train() if bn_train else net.eval()
+        opt = torch.optim.SGD([p for p in net.parameters()], lr=1e-2)
+        was = T.GRAPH_TRAIN
+        T.GRAPH_TRAIN = graph
+        res = []
+        try:
+            for _ in range(n_steps):
+                ins = [x.clone().requires_grad_(True) for x in xs]
+                out = net(*ins, per_item_statistics=True)
+                path = T.LAST_STEP_PATH
+                opt.zero_grad()
+                out.backward(g)
+                res.append((path, out.detach().clone(), [i.grad.clone() for i in ins],
+                            {n: p.grad.clone() for n, p in net.named_parameters() if p.grad is not None},
+                            {n: b.clone() for n, b in net.named_buffers()}))
+                opt.step()
+        finally:
+            T.GRAPH_TRAIN = was
+        return res
+
+    for bn_train in (False, True):
+        nets = []
+        for _ in range(2):
+            net = UNet()
+            net.load_state_dict({k: torch.from_numpy(np.asarray(v)) for k, v in state.items()})
+            nets.append(net.cuda())
+        eager, graph = run(nets[0], False, 3, bn_train), run(nets[1], True, 3, bn_train)
+        for step, (e, gr) in enumerate(zip(eager, graph)):
+            assert e[0] == 'eager' and gr[0] == 'graph', (e[0], gr[0])
+            tol = 1e-5 * (10 ** step)                 # atomics reorder fp32 sums; SGD feeds the differences back into the weights
+            _close(gr[1], e[1], f"bn_train={bn_train} step {step}: output", rtol=tol)
+            for l in range(4):
+                _close(gr[2][l], e[2][l], f"bn_train={bn_train} step {step}: dx level {l}", rtol=max(tol, 1e-4))
+            assert set(gr[3]) == set(e[3]) and len(e[3]) >= 594
+            for n in e[3]:
+                _close(gr[3][n], e[3][n], f"bn_train={bn_train} step {step}: d{n}", rtol=max(tol, 1e-4))
+            for n in e[4]:
+                if "ConvsOut" not in n:
+                    _close(gr[4][n].float(), e[4][n].float(), f"bn_train={bn_train} step {step}: buffer {n}", rtol=max(tol, 1e-5))
+        assert not torch.equal(graph[0][1], graph[2][1])          # the replays did see the stepped weights
+    # two forwards before a backward: the second one must not overwrite the first one's saved activations
+    net = nets[1].eval()
+    ins_a = [x.clone().requires_grad_(True) for x in xs]
+    ins_b = [(x * 0.5).clone().requires_grad_(True) for x in xs]
+    out_a = net(*ins_a)
+    assert T.LAST_STEP_PATH == 'graph'
+    out_b = net(*ins_b)
+    assert T.LAST_STEP_PATH == 'eager'
+    net.zero_grad()
+    (out_a * g).sum().backward()
+    ga = [i.grad.clone() for i in ins_a]
+    T_was, T.GRAPH_TRAIN = T.GRAPH_TRAIN, False
+    try:
+        ins_c = [x.clone().requires_grad_(True) for x in xs]
+        (net(*ins_c) * g).sum().backward()
+    finally:
+        T.GRAPH_TRAIN = T_was
+    for l in range(4):
+        _close(ga[l], ins_c[l].grad, f"first forward's gradients after an interleaved second forward, level {l}", rtol=1e-4)
+    (out_b * g).sum().backward()                                  # and the eager second forward still backpropagates
+    assert all(i.grad is not None for i in ins_b)

@@ -145,3 +145,57 @@ def test_bench_loop_single_process_has_no_exchange():
     sweep.run_steps(lambda k, out: out.fill_(k), ex, 0, 3, POSES)
     assert float(ex.frames(2)[0, 0, 0]) == 2.0
     assert sweep.gather_objects(True) == [True]
+
+
+# ---- a whole sweep whose length is not a multiple of the world size, through run_steps ----
+def _ragged_worker(rank, world, port, q, n_poses):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        dev = torch.device("cpu")
+        xyz, = sweep.broadcast_scene_from_rank0(lambda: [torch.from_numpy(synthetic.make_cloud(N))], dev)
+        proj = synthetic.make_proj(W, H, f=30.0)
+        log = []
+
+        def render_into(k, out):
+            log.append(k)
+            out.copy_(_frame(xyz.numpy(), proj, k))
+        ex = sweep.FrameExchange((H, W, 2), dev, torch.float32, 'all')
+        steps = sweep.sweep_steps(n_poses, world)
+        stack = torch.zeros((n_poses, H, W, 2))
+        filled = []
+        for i in range(steps):
+            sweep.run_steps(render_into, ex, i, 1, n_poses)
+            fr = ex.frames(i)
+            for r in range(world):
+                k = i * world + r
+                if k < n_poses:                                  # the wrapped tail (k >= n_poses) is a repeat of the head: dropped
+                    stack[k].copy_(fr[r])
+                    filled.append(k)
+                else:
+                    assert torch.equal(fr[r], stack[sweep.pose_of_step(i, r, world, n_poses)])
+        ex.drain()
+        q.put((rank, log, filled, stack.numpy()))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_ragged_sweep_through_run_steps_two_ranks():
+    n_poses = 5                                                  # 5 % 2 != 0: rank 1 wraps to pose 0 in the last step
+    assert sweep.sweep_steps(n_poses, 2) == 3 and sweep.pose_of_step(2, 1, 2, n_poses) == 0
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_ragged_worker, args=(r, 2, port, q, n_poses)) for r in range(2)]
+    for p in procs:
+        p.start()
+    got = [q.get(timeout=120) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    xyz, proj = synthetic.make_cloud(N), synthetic.make_proj(W, H, f=30.0)
+    ref = np.stack([_frame(xyz, proj, k).numpy() for k in range(n_poses)])
+    for rank, log, filled, stack in got:
+        assert log == ([0, 2, 4] if rank == 0 else [1, 3, 0])        # every step renders on every rank; the tail wraps
+        assert filled == list(range(n_poses))                        # each pose of the sweep received exactly once, in order
+        assert np.array_equal(stack, ref), f"rank {rank}: ragged sweep differs from the single-process frames"
