@@ -355,22 +355,35 @@ def run_train(a, dev, street=None, steps=None, warm=None, cpu_timing=True, do_ve
     targets = torch.from_numpy(rng.random((4, B, 3, S, S)).astype(np.float32)).to(dev)
     tex = pipe.textures[0]
 
+    phases = {"render": 0.0, "forward": 0.0, "loss": 0.0, "backward": 0.0, "adam": 0.0, "rmsprop": 0.0}   # HOST time, no syncs
+
     def forward_backward(views, target):
+        t0 = time.perf_counter()
         data = {'input': {'id': torch.zeros(B, dtype=torch.long)}, 'view_matrix': torch.from_numpy(views),
                 'proj_matrix': torch.from_numpy(np.repeat(proj[None], B, 0))}
         inputs, _ = renderer.render(data)
+        t1 = time.perf_counter()
         out = model(inputs)
+        t2 = time.perf_counter()
         loss = pipe.criterion(out, target) * 1e4
+        t3 = time.perf_counter()
         loss.backward()
+        t4 = time.perf_counter()
+        for k_, v_ in (("render", t1 - t0), ("forward", t2 - t1), ("loss", t3 - t2), ("backward", t4 - t3)):
+            phases[k_] += v_
         return loss
 
     def step(i):
         views = np.stack([synthetic.sweep_pose(int(k)) for k in rng.integers(0, N_POSES, B)])
         loss = forward_backward(views, targets[i % 4])
+        t0 = time.perf_counter()
         pipe.optimizer.step()
         pipe.optimizer.zero_grad()
+        t1 = time.perf_counter()
         extra.step()
         extra.zero_grad()
+        phases["adam"] += t1 - t0
+        phases["rmsprop"] += time.perf_counter() - t1
         return loss
 
     # ---- verification iteration (no optimizer step: the weights the timed loop starts from are the seeded ones)
@@ -471,10 +484,13 @@ def run_train(a, dev, street=None, steps=None, warm=None, cpu_timing=True, do_ve
     for i in range(warm):
         step(i)
     torch.cuda.synchronize()
+    for k_ in phases:
+        phases[k_] = 0.0
     t0 = time.perf_counter()
     for i in range(steps):
         loss = step(warm + i)
     dt_host = time.perf_counter() - t0                             # the host has enqueued everything; the device may still be busy
+    host_phases = {k_: 1e3 * v_ / steps for k_, v_ in phases.items()}
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
     fwd_flops = 187.06e9 * B                                      # conv MACs x 2 at 256x256, measured on the reference module
@@ -516,7 +532,7 @@ def run_train(a, dev, street=None, steps=None, warm=None, cpu_timing=True, do_ve
                                 "dgrad on the Winograd kernels at 1/4 or 1/2.25 of the direct count, wgrad direct) / wall time of "
                                 "a step, the headline's convention; frac_algorithmic = 3 x SURVEY 8d's forward count / wall time"},
            "host_enqueue_ms_per_step": 1e3 * dt_host / steps,      # close to ms_per_step = the step is bound by the host side
-           "step_path": step_path,
+           "step_path": step_path, "host_phases_ms_per_step": host_phases,
            "final_loss": float(loss.detach()), "tuning": _lib.tuning_state(), "cpu_baseline": base, "verified": verified}
     pipe.dataset_unload([DS()])
     return out
@@ -702,6 +718,7 @@ def also_records(a, dev, wl, first=None):
                     "frac": t["roofline"]["frac"], "frac_algorithmic": t["roofline"]["frac_algorithmic"],
                     "frac_convention": "executed MFMA flops / wall time (as roofline.frac of the headline)",
                     "host_enqueue_ms_per_step": t["host_enqueue_ms_per_step"], "step_path": t.get("step_path"),
+                    "host_phases_ms_per_step": t.get("host_phases_ms_per_step"),
                     "final_loss": t["final_loss"], "verified": t["verified"],
                     "what": t["config"]["workload"]}
     return rec

@@ -69,23 +69,8 @@ int read_device_arch(char *name, int len);
 int read_tuning_set(const char *key, int value);
 int read_tuning_get(const char *key, int *value);
 const char *read_tuning_key(int i);
-/* Debug timeline of the following gated-conv launches: 64 bytes per workgroup (direct kernels: s_memrealtime at
- * entry / after prologue / after the k-loop / at exit, HW_ID, XCC_ID, blockIdx.x/y) or per wave (Winograd kernel:
- * entry, end of prologue, ticks spent in unit epilogues split three ways, exit, HW_ID) in `buf` (device);
- * read by tools/trace_conv.py.  NULL switches tracing off (the default). */
-int read_debug_set_trace(void *buf, size_t bytes);
-/* Debug probe: `blocks` workgroups x 4 waves, each wave issues iters*nacc*4 v_mfma_f32_32x32x2_f32
- * (4096 FLOP each) from registers — the sustained matrix-core ceiling for the conv kernels.
- * scratch: >= blocks*256 floats (never written in practice). */
-int read_debug_mfma_probe(int blocks, int iters, int nacc, float *scratch, void *stream);
-/* Issue-model probe (debug): every wave runs `iters` rounds of 16 fp32 MFMAs (kind 0: v_mfma_f32_32x32x2_f32, 1:
- * v_mfma_f32_16x16x4_f32), each followed by K filler instructions of type `filler` (0 independent v_add_f32, 1 ds_read_b128,
- * 2 s_add_u32, 3 dependent v_add_f32 chain, 4 global_load_dwordx4 from gsrc); cycles[blocks * 4] = s_memtime span per wave. */
-/* Operand probe (debug): v_mfma_f32_16x16x4_f32 rate by operand register pattern (mode 0 one A/B pair, 1 a pair per MFMA, 2 the
- * Winograd kernel's float4-component pattern, 3 as 2 with the B operands re-read from LDS every round). */
-int read_debug_operand_probe(int mode, int blocks, int iters, float *scratch, unsigned long long *cycles, void *stream);
-int read_debug_issue_probe(int kind, int filler, int K, int blocks, int iters, float *scratch, unsigned long long *cycles,
-                           const float *gsrc, void *stream);
+/* Debug entry points (timeline trace of the conv kernels, issue / operand / MFMA-ceiling probes) are NOT part of this ABI: they
+ * exist only in libreadhip_debug.so (python -m read_amd.build --debug, -DREAD_DEBUG_KNOBS) and are declared in read_hip_debug.h. */
 
 /* ---------------------------------------------------------------- rasteriser (z-buffer splat) */
 

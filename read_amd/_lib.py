@@ -47,6 +47,14 @@ class SplatGlOpts(C.Structure):
 _vp, _i, _i64, _sz, _f = C.c_void_p, C.c_int, C.c_int64, C.c_size_t, C.c_float
 _pp = C.POINTER(C.c_void_p)
 
+# entry points of the debug build only (include/read_hip_debug.h; READ_HIP_DEBUG=1 loads libreadhip_debug.so)
+DEBUG_SIGNATURES = {
+    "read_debug_set_trace": (_i, [_vp, _sz]),
+    "read_debug_mfma_probe": (_i, [_i, _i, _i, _vp, _vp]),
+    "read_debug_operand_probe": (_i, [_i, _i, _i, _vp, _vp, _vp]),
+    "read_debug_issue_probe": (_i, [_i, _i, _i, _i, _i, _vp, _vp, _vp, _vp]),
+}
+
 # name -> (restype, argtypes): every symbol include/read_hip.h declares
 SIGNATURES = {
     "read_last_error": (C.c_char_p, []),
@@ -55,10 +63,6 @@ SIGNATURES = {
     "read_tuning_set": (_i, [C.c_char_p, _i]),
     "read_tuning_get": (_i, [C.c_char_p, C.POINTER(_i)]),
     "read_tuning_key": (C.c_char_p, [_i]),
-    "read_debug_set_trace": (_i, [_vp, _sz]),
-    "read_debug_mfma_probe": (_i, [_i, _i, _i, _vp, _vp]),
-    "read_debug_operand_probe": (_i, [_i, _i, _i, _vp, _vp, _vp]),
-    "read_debug_issue_probe": (_i, [_i, _i, _i, _i, _i, _vp, _vp, _vp, _vp]),
     "read_splat_workspace_bytes": (_sz, [_i, _i, _i]),
     "read_splat_workspace_init": (_i, [_vp, _sz, _vp]),
     "read_splat_forward": (_i, [_vp, _i64, C.POINTER(_f), _i, _i, _i, _i, _pp, _pp, _vp, _sz, _vp]),
@@ -146,7 +150,10 @@ def lib():
                 f"{LIB_PATH} is missing: the HIP extension is required (there is no CPU fallback). "
                 "Build it with `python -m read_amd.build` (or __graft_entry__.build()).")
         L = C.CDLL(LIB_PATH)
-        for name, (res, args) in SIGNATURES.items():
+        table = dict(SIGNATURES)
+        if os.environ.get("READ_HIP_DEBUG"):
+            table.update(DEBUG_SIGNATURES)
+        for name, (res, args) in table.items():
             fn = getattr(L, name)          # AttributeError here = header/library mismatch
             fn.restype = res
             fn.argtypes = args

@@ -18,7 +18,8 @@ ROOT = os.path.dirname(HERE)
 CSRC = os.path.join(HERE, "csrc")
 OBJ = os.path.join(HERE, "csrc", "_obj")
 LIB = os.path.join(HERE, "libreadhip.so")
-SOURCES = ["api_common.cpp", "splat.hip", "gather.hip", "conv.hip", "train.hip", "unet.cpp", "probe.hip"]
+SOURCES = ["api_common.cpp", "splat.hip", "gather.hip", "conv.hip", "train.hip", "unet.cpp"]
+DEBUG_SOURCES = ["probe.hip"]        # measurement probes (read_hip_debug.h): libreadhip_debug.so only, never the product
 ARCH = "gfx950"
 FLAGS = ["-O3", "-std=c++17", "-fPIC", f"--offload-arch={ARCH}", "-x", "hip",
          "-I", os.path.join(ROOT, "include"), "-I", CSRC, "-Wall", "-Wno-unused-function"]
@@ -47,7 +48,8 @@ def build(force: bool = False, verbose: bool = False, debug: bool = False) -> st
     LIB = os.path.join(HERE, "libreadhip_debug.so" if debug else "libreadhip.so")
     FLAGS = globals()["FLAGS"] + (["-DREAD_DEBUG_KNOBS"] if debug else []) + [f"-D{d}" for d in os.environ.get("READ_EXTRA_DEFINES", "").split()]
     os.makedirs(OBJ, exist_ok=True)
-    headers = [os.path.join(ROOT, "include", "read_hip.h"), os.path.join(CSRC, "common.h")]
+    headers = [os.path.join(ROOT, "include", "read_hip.h"), os.path.join(ROOT, "include", "read_hip_debug.h"), os.path.join(CSRC, "common.h")]
+    SOURCES = globals()["SOURCES"] + (DEBUG_SOURCES if debug else [])
     hipcc = _hipcc()
     jobs = []
     for src in SOURCES:

@@ -67,11 +67,13 @@ int unet_get(const char *key, int *value);
 // Debug: per-workgroup timeline of the next gated-conv launches.  buf = device memory, 64 bytes per
 // workgroup: s_memrealtime (100 MHz) at kernel entry / after the prologue / after the k-loop / at exit,
 // HW_ID, XCC_ID, blockIdx.x, blockIdx.y.  NULL switches it off.
+#ifdef READ_DEBUG_KNOBS
 extern "C" int read_debug_set_trace(void *buf, size_t bytes)
 {
     readhip::conv_set_trace(buf, bytes);
     return READ_OK;
 }
+#endif
 
 // Tuning knobs for A/B measurements on the GPU box (not needed in production).  Every knob of the release library
 // selects between implementations that produce the SAME results; the attribution probes whose results are invalid

@@ -6,6 +6,9 @@
 #include <string.h>
 
 #include "read_hip.h"
+#ifdef READ_DEBUG_KNOBS
+#include "read_hip_debug.h"   // debug build: the probes and the kernel timeline
+#endif
 
 namespace readhip {
 

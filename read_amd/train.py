@@ -189,8 +189,10 @@ def _packed_for(wf, bf, wm, bm, gamma, beta, mean, var, cin, cout, k, identity_b
     else:
         wp = torch.empty(L.read_conv_packed_floats(cin, cout, k), dtype=torch.float32, device=dev)
         _lib.check(L.read_conv_pack_weights_device(cin, cout, k, _kc_for(cin), wf_c.data_ptr(), wm_c.data_ptr(), wp.data_ptr(), st))
-    ev = torch.cuda.Event()
-    ev.record()
+    ev = None
+    if not capturing:             # an event recorded inside a capture must never be waited on from outside it (see backward)
+        ev = torch.cuda.Event()
+        ev.record()
     key = id(wf)
     old = _PACK_CACHE.get(key)
     if old is not None and old[6]() is wf:
@@ -228,8 +230,10 @@ def _pack_dgrad(entry, wf, wm, cin, cout, k):
     else:
         wd = torch.empty(L.read_conv_dgrad_packed_floats(cin, cout, k), dtype=torch.float32, device=dev)
         _lib.check(L.read_conv_pack_dgrad_device(cin, cout, k, 16, wf_c.data_ptr(), wm_c.data_ptr(), wd.data_ptr(), st))
-    ev = torch.cuda.Event()
-    ev.record()
+    ev = None
+    if not torch.cuda.is_current_stream_capturing():
+        ev = torch.cuda.Event()
+        ev.record()
     entry[3] = (wd, ev, wdw)
 
 
@@ -284,7 +288,12 @@ class GatedConvFn(torch.autograd.Function):
             mean = var = stat                        # the backward pass needs the groups' {mean, biased var}, not the buffers
         ctx.bn_train = bool(bn_train)
         ctx.bn_groups = groups
-        ctx.save_for_backward(x, fm, params, wf_c, wm_c, mean, var, gamma.detach() if bn_train else mean)
+        # the weights ride on the context, not in save_for_backward: a captured step's autograd graph is RETAINED and walked again
+        # after every optimizer step (_HybridStepFn) — saved tensors are version-checked, and the optimizer's in-place update of
+        # a parameter would read as "modified by an inplace operation"; a step's backward wants the weights of its own forward,
+        # which are the current ones
+        ctx.weights = (wf_c, wm_c, gamma.detach() if bn_train else None, mean, var)      # mean / var: running buffers or batch statistics
+        ctx.save_for_backward(x, fm, params)
         ctx.cfg = (k, stride, int(elu), H, W, cin, cout, Ho, Wo, bh, vh)
         ctx.wrefs = (weakref.ref(wf), weakref.ref(wm))
         return y
@@ -293,7 +302,8 @@ class GatedConvFn(torch.autograd.Function):
     def backward(ctx, dy):
         L = _lib.lib()
         st = _lib.stream_ptr()
-        x, fm, params, wf, wm, mean, var, gamma_d = ctx.saved_tensors
+        x, fm, params = ctx.saved_tensors
+        wf, wm, gamma_d, mean, var = ctx.weights
         k, stride, elu, H, W, cin, cout, Ho, Wo, bh, vh = ctx.cfg
         dev = x.device
         dy = dy.contiguous()
@@ -338,10 +348,11 @@ class GatedConvFn(torch.autograd.Function):
                 if ctx.pack[3] is None:
                     _pack_dgrad(ctx.pack, wf, wm, cin, cout, k)
                 wd, ev, wdw = ctx.pack[3]
-                torch.cuda.current_stream().wait_event(ev)
-                wd.record_stream(torch.cuda.current_stream())
-                if wdw is not None:
-                    wdw.record_stream(torch.cuda.current_stream())
+                if ev is not None:                   # None: packed by the step's forward HIP graph, ordered by the replay itself
+                    torch.cuda.current_stream().wait_event(ev)
+                    wd.record_stream(torch.cuda.current_stream())
+                    if wdw is not None:
+                        wdw.record_stream(torch.cuda.current_stream())
                 zero = _zero_params(L.read_conv_param_floats(cin // 2), dev)
                 _linear_conv(d_in, 2 * cp, wd, zero, cin // 2, k, 1, dx, wino=wdw, w4=_w4_fits(2 * cp, cin // 2))
             else:
@@ -527,48 +538,69 @@ def stack_batch(x_nchw, level):
 
 
 # -----------------------------------------------------------------------------------------------------------------------
-# The training forward and backward of the UNet as two HIP graphs
+# The training forward of the UNet from a HIP graph, its backward over the autograd graph of the capture
 # -----------------------------------------------------------------------------------------------------------------------
-# Round 3 measured the training step host-bound: 48 of 58 ms were Python around 99 autograd nodes (allocation, cache lookups,
-# ctypes, stream bookkeeping; bench.py host_enqueue_ms_per_step).  The launch sequence of a step is the same every iteration —
-# same shapes, same weights at the same addresses — so it is captured ONCE per batch geometry into a forward and a backward HIP
-# graph (torch.cuda.make_graphed_callables: the autograd-aware wrapper around hipGraph capture of both passes, static input /
-# output / gradient buffers) and replayed: two graph launches per step instead of ~1500 Python-driven ones.  Everything the
-# eager path does per step is inside the graphs — packing the weights' fragment orders (they change with every optimizer
-# step), batch-statistics BatchNorm with its running-buffer updates, the wgrad side stream and its join.
-# What a graph cannot tolerate falls back to the eager path on its own: a second forward before the first one's backward
-# (gradient accumulation over several forwards: the graphs share ONE set of saved activations), parameters moved to other
-# addresses (.cuda() / .to(): the key changes and a new pair is captured), hooks, anomaly mode, a failed capture.
+# Round 3 measured the training step host-bound: 48 of 58 ms were Python — 28 ms building the forward's 99 autograd nodes
+# (allocation, cache lookups, ctypes, stream bookkeeping per layer), 15 ms walking them backward (bench.py host_phases_ms_per_step).
+# The forward's launch sequence is the same every iteration — same shapes, same weights at the same addresses — so it is
+# captured ONCE per batch geometry into a HIP graph (hipGraph through torch.cuda.CUDAGraph) and replayed: one graph launch
+# (5 ms of host time) instead of ~600 Python-driven launches.  The capture runs the per-layer Python with autograd on, so it also
+# leaves the forward's autograd graph behind, its saved activations living in the HIP graph's memory pool; every replay rewrites
+# them in place, and the step's backward walks that SAME retained autograd graph (``torch.autograd.grad(..., retain_graph=True)``)
+# eagerly: the dgrad chain on the launch stream, the weight gradients on the side stream next to it.
+# Why not the backward from a graph as well (it was built first, with torch.cuda.make_graphed_callables, and measured,
+# profiles/README.md): a replayed hipGraph ran its branches back to back on this ROCm — kernel-trace overlap factor 1.06 against
+# 1.51 for the eager two-stream backward — so the step became GPU-bound at 63 ms instead of host-bound at 58.
+# Inside the forward graph: packing the weights' fragment orders (they change with every optimizer step), batch-statistics
+# BatchNorm with its running-buffer updates.  What the scheme cannot tolerate falls back to the per-layer path on its own: a second
+# forward before the first one's backward (the retained graph holds ONE set of activations), parameters moved to other addresses
+# (.cuda() / .to(): the key changes and a new graph is captured), hooks, anomaly mode, a failed capture.
 GRAPH_TRAIN = os.environ.get("READ_AMD_GRAPH_TRAIN", "1") != "0"
-_GRAPH_CACHE_MAX = 4         # (geometry, mode) pairs kept per net: a graph pair holds every activation of its step
+_GRAPH_CACHE_MAX = 4         # (geometry, mode) entries kept per net: an entry holds every activation of its step
 
 
-class _TrainCore(torch.nn.Module):
-    """The callable make_graphed_callables captures: its parameters are the net's parameters."""
+class _HybridStepFn(torch.autograd.Function):
+    """forward: copy the inputs into the capture's static buffers, replay the HIP graph; backward: the retained autograd graph."""
 
-    def __init__(self, net, per_item):
-        super().__init__()
-        self.net = net
-        self.per_item = bool(per_item)
+    @staticmethod
+    def forward(ctx, step, n_in, *tensors):
+        for s_in, x in zip(step.static_in, tensors[:n_in]):
+            if s_in.data_ptr() != x.data_ptr():
+                s_in.data.copy_(x)                   # .data: no version bump on a tensor the retained graph may have saved
+        step.graph.replay()
+        ctx.step = step
+        ctx.n_tensors = len(tensors)
+        return step.out.detach()
 
-    def forward(self, x0, x1, x2, x3):
-        return _unet_forward_train_batch_eager(self.net, [x0, x1, x2, x3], self.per_item)
+    @staticmethod
+    def backward(ctx, gout):
+        step = ctx.step
+        step.pending = False
+        grads = torch.autograd.grad([step.out], step.targets, [gout.contiguous()], retain_graph=True, allow_unused=True)
+        res = [None] * ctx.n_tensors
+        for slot, g in zip(step.target_slots, grads):
+            res[slot] = g
+        return (None, None, *res)
 
 
 class _GraphedStep:
-    def __init__(self, fn):
-        self.fn = fn
+    def __init__(self, graph, static_in, out, params):
+        self.graph, self.static_in, self.out, self.params = graph, static_in, out, params
+        # gradient targets inside the retained graph: the static inputs that require grad, then the parameters — and where each
+        # one's gradient goes in _HybridStepFn's argument list (inputs first, parameters after them)
+        self.targets, self.target_slots = [], []
+        for i, t in enumerate(static_in):
+            if t.requires_grad:
+                self.targets.append(t)
+                self.target_slots.append(i)
+        for j, p_ in enumerate(params):
+            self.targets.append(p_)
+            self.target_slots.append(len(static_in) + j)
         self.pending = False         # a forward whose backward has not run yet: its saved activations are still needed
 
     def __call__(self, xs):
-        out = self.fn(*xs)
         self.pending = True
-        out.register_hook(self._done)
-        return out
-
-    def _done(self, grad):
-        self.pending = False
-        return grad
+        return _HybridStepFn.apply(self, len(xs), *xs, *self.params)
 
 
 def _graph_key(net, xs, per_item):
@@ -580,7 +612,7 @@ def _graph_key(net, xs, per_item):
 
 
 def _graphed_step(net, xs, per_item):
-    """-> the captured step for this geometry, or None (then the caller runs eagerly)."""
+    """-> the captured step for this geometry, or None (then the caller runs the per-layer path)."""
     if not (GRAPH_TRAIN and torch.is_grad_enabled() and all(x.is_cuda and x.dtype == torch.float32 for x in xs)):
         return None
     if torch.cuda.is_current_stream_capturing() or torch.is_anomaly_enabled():
@@ -602,39 +634,53 @@ def _graphed_step(net, xs, per_item):
 
 
 def _capture_step(net, xs, per_item):
-    core = _TrainCore(net, per_item)
-    if not net.training:
-        core.eval()
-    # make_graphed_callables runs three eager warm-up iterations before it captures: in .train() they would move the BatchNorm
-    # running buffers and num_batches_tracked — restored below (capture itself executes nothing)
+    params = [p_ for p_ in net.parameters() if p_.requires_grad]
+    # the eager warm-up below would move the BatchNorm running buffers and num_batches_tracked in .train(): restored afterwards
+    # (the capture itself executes nothing)
     saved = [b.detach().clone() for b in net.buffers()] if net.training else None
-    sample = tuple(x.detach().clone().requires_grad_(x.requires_grad) for x in xs)
+    cur = torch.cuda.current_stream()
     try:
-        fn = torch.cuda.make_graphed_callables(core, sample, num_warmup_iters=2, allow_unused_input=True)
+        static_in = [x.detach().clone().requires_grad_(x.requires_grad) for x in xs]
+        side = torch.cuda.Stream()
+        side.wait_stream(cur)
+        with torch.cuda.stream(side):                        # warm-up: lazy initialisation, allocator, caches — off the capture
+            out = _unet_forward_train_batch_eager(net, static_in, per_item)
+            tg = [t for t in static_in if t.requires_grad] + params
+            if tg:
+                torch.autograd.grad([out], tg, [torch.ones_like(out)], allow_unused=True)
+            del out
+        cur.wait_stream(side)
+        torch.cuda.synchronize()
+        if saved is not None:
+            with torch.no_grad():
+                for b, v in zip(net.buffers(), saved):
+                    b.copy_(v)
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph):                        # autograd is on: the capture leaves the forward's autograd graph behind
+            out = _unet_forward_train_batch_eager(net, static_in, per_item)
     except Exception as e:                                   # capture refused (an API the graph cannot hold, out of memory ...)
         try:
             torch.cuda.synchronize()
         except Exception:
             pass
-        import warnings
-        warnings.warn(f"read_amd: HIP-graph capture of the UNet training step failed ({type(e).__name__}: {e}); "
-                      "this geometry runs eagerly")
-        return False
-    finally:
         if saved is not None:
             with torch.no_grad():
                 for b, v in zip(net.buffers(), saved):
                     b.copy_(v)
-    return _GraphedStep(fn)
+        import warnings
+        warnings.warn(f"read_amd: HIP-graph capture of the UNet training forward failed ({type(e).__name__}: {e}); "
+                      "this geometry runs layer by layer")
+        return False
+    return _GraphedStep(graph, static_in, out, params)
 
 
 def unet_forward_train_batch(net, xs, per_item_statistics=False):
     """xs: four (B,8,h,w) pyramids -> (B,3,H,W) through ONE stacked image.  In ``.train()`` the BatchNorm layers normalise with
     the statistics of the whole batch — ``nn.BatchNorm2d`` on a (B,C,h,w) tensor — unless ``per_item_statistics``: then every item
     is its own batch of one and the running buffers move B times in item order, which is what B separate calls of the net do
-    (``NetAndTexture.forward``, READ/models/compose.py:137-176).  The launches of the step come out of a pair of HIP graphs
-    when the step can be captured (``_graphed_step``), else from the per-layer autograd nodes directly; ``LAST_STEP_PATH`` says
-    which ('graph' / 'eager')."""
+    (``NetAndTexture.forward``, READ/models/compose.py:137-176).  The forward's launches come out of a HIP graph when the step
+    can be captured (``_graphed_step``; its backward then walks the capture's retained autograd graph), else from the per-layer
+    autograd nodes directly; ``LAST_STEP_PATH`` says which ('graph' / 'eager')."""
     global LAST_STEP_PATH
     g = _graphed_step(net, xs, per_item_statistics)
     if g is not None:

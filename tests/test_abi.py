@@ -172,3 +172,16 @@ def test_no_oracle_import_in_product():
             if f.endswith((".py", ".hip", ".cpp", ".h")):
                 src = open(os.path.join(dirpath, f)).read()
                 assert not re.search(r"^\s*(from|import)\s+oracle\b", src, flags=re.M), f
+
+
+def test_release_library_has_no_debug_entry_points():
+    """the measurement probes (csrc/probe.hip) and the kernel timeline switch are entry points of the debug build
+    only (include/read_hip_debug.h, libreadhip_debug.so); the product exports none of them."""
+    L = C.CDLL(_lib.LIB_PATH if not os.environ.get("READ_HIP_DEBUG") else os.path.join(ROOT, "read_amd", "libreadhip.so"))
+    txt = open(os.path.join(ROOT, "include", "read_hip_debug.h")).read()
+    txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
+    names = sorted(set(re.findall(r"\b(read_debug_[a-z0-9_]+)\s*\(", txt)))
+    assert names == sorted(_lib.DEBUG_SIGNATURES) and len(names) == 4
+    for n in names:
+        assert not hasattr(L, n), f"{n} is exported by the release library"
+    assert not any(n.startswith("read_debug") for n in _declared_symbols())

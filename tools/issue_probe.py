@@ -3,6 +3,8 @@ number / kind of filler instructions in its shadow, and the number of waves per 
 
     python tools/issue_probe.py [out.json]
 """
+import os
+os.environ.setdefault("READ_HIP_DEBUG", "1")   # the probes live in libreadhip_debug.so only (python -m read_amd.build --debug)
 import json
 import os
 import sys

@@ -1,4 +1,6 @@
 """Sustained fp32 MFMA ceiling (v_mfma_f32_32x32x2_f32) at several occupancies and durations."""
+import os
+os.environ.setdefault("READ_HIP_DEBUG", "1")   # the probes live in libreadhip_debug.so only (python -m read_amd.build --debug)
 import json
 import os
 import sys

@@ -1,5 +1,7 @@
 """fp32 MFMA rate by operand register pattern (run on the GPU box): python tools/operand_probe.py"""
 import os
+os.environ.setdefault("READ_HIP_DEBUG", "1")   # the probes live in libreadhip_debug.so only (python -m read_amd.build --debug)
+import os
 import sys
 
 import torch

@@ -2,6 +2,8 @@
 
     python tools/trace_conv.py --shape L0 --config 0 --out gpurun_out/trace_L0_c0.npz
 """
+import os
+os.environ.setdefault("READ_HIP_DEBUG", "1")   # the probes live in libreadhip_debug.so only (python -m read_amd.build --debug)
 import argparse
 import os
 import sys
