@@ -307,6 +307,28 @@ int read_conv_pack_dgrad_w4_device(int Cin, int Cout, const float *wf, const flo
 size_t read_conv_dgrad_packed_floats(int Cin, int Cout, int ksize);
 int read_conv_pack_dgrad_device(int Cin, int Cout, int ksize, int kc, const float *wf, const float *wm, float *wpacked,
                                 void *stream);
+/* All packing jobs of a training step in ONE launch.  The optimizer changes every weight every step, so a step re-packs the
+ * parameter block, the forward fragments and the dgrad fragments of every layer: the entry points above are one launch each
+ * (297 per step for READ's UNet).  A host that knows its layers builds a table of jobs ONCE (the tensors keep their addresses
+ * across optimizer steps), uploads it, and calls read_conv_pack_batch once per step.
+ *   kind READ_PACK_PARAMS: out[4 * pad32(Cout)] = bias_f, bias_m, bn scale, bn shift   (read_conv_pack_params_device)
+ *        READ_PACK_DIRECT / _WINO / _W4: the fragment order of read_conv_pack_weights_device / _wino_device / _w4_device;
+ *        mode 1 = the layer's dgrad fragments (read_conv_pack_dgrad_device / _dgrad_wino_device / _dgrad_w4_device).
+ * read_conv_pack_job_prepare (host) validates a job and fills Cp / total / nblocks; the caller then sets first_block to the
+ * running sum of nblocks and passes the grand total as total_blocks. */
+enum { READ_PACK_PARAMS = 0, READ_PACK_DIRECT = 1, READ_PACK_WINO = 2, READ_PACK_W4 = 3 };
+typedef struct read_pack_job {
+    int kind, mode;                         /* mode: 0 the layer's own weights, 1 its dgrad */
+    int Cin, Cout, ksize, kc;               /* kc: channel chunk of the direct order (8 / 16 / 32) */
+    int Cp, first_block, nblocks;           /* derived (prepare) / prefix sum (caller) */
+    float eps;                              /* params job: BatchNorm epsilon */
+    const float *wf, *wm;                   /* (Cout, Cin, k, k) conv_f / conv_m weights */
+    const float *bf, *bm, *gamma, *beta, *mean, *var;   /* params job (bf / bm may be NULL) */
+    float *out;
+    long long total;                        /* floats written (derived) */
+} read_pack_job;
+int read_conv_pack_job_prepare(read_pack_job *job);
+int read_conv_pack_batch(const read_pack_job *jobs_dev, int njobs, int total_blocks, void *stream);
 /* A training batch is ONE tall image: the items stacked vertically, block_h rows per item of which the first valid_h are
  * the item and the rest a separator that stays zero in every activation — it is the zero padding between neighbours, so the
  * convolutions need no batch dimension and one launch covers the batch.  The gate kernels keep the separators zero (forward)

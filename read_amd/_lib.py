@@ -37,6 +37,17 @@ class ConvDesc(C.Structure):
     ]
 
 
+class PackJob(C.Structure):
+    """read_pack_job (include/read_hip.h): one entry of read_conv_pack_batch's table."""
+    _fields_ = [("kind", C.c_int), ("mode", C.c_int), ("Cin", C.c_int), ("Cout", C.c_int), ("ksize", C.c_int), ("kc", C.c_int),
+                ("Cp", C.c_int), ("first_block", C.c_int), ("nblocks", C.c_int), ("eps", C.c_float),
+                ("wf", C.c_void_p), ("wm", C.c_void_p), ("bf", C.c_void_p), ("bm", C.c_void_p), ("gamma", C.c_void_p),
+                ("beta", C.c_void_p), ("mean", C.c_void_p), ("var", C.c_void_p), ("out", C.c_void_p), ("total", C.c_longlong)]
+
+
+PACK_PARAMS, PACK_DIRECT, PACK_WINO, PACK_W4 = 0, 1, 2, 3
+
+
 class SplatGlOpts(C.Structure):
     _fields_ = [("point_size", C.c_float), ("relative", C.c_int), ("min_point_size", C.c_float),
                 ("discard", C.c_void_p), ("drop_threshold", C.c_uint32), ("drop_seed", C.c_uint32),
@@ -90,6 +101,8 @@ SIGNATURES = {
     "read_conv_pack_w4_host": (_i, [_i, _i, _vp, _vp, _vp]),
     "read_gated_conv_forward": (_i, [C.POINTER(ConvDesc), _vp]),
     "read_conv_kernel_family": (_i, [_vp]),
+    "read_conv_pack_job_prepare": (_i, [C.POINTER(PackJob)]),
+    "read_conv_pack_batch": (_i, [_vp, _i, _i, _vp]),
     "read_conv_config_count": (_i, []),
     "read_conv_config_name": (C.c_char_p, [_i]),
     "read_bilinear_up4": (_i, [_vp, _i, _i, _i, _vp, _vp]),

@@ -819,6 +819,8 @@ __global__ __launch_bounds__(256) void cells_pass_kernel(CellCloud cc, Cam1 cam,
     __shared__ unsigned long long s_key[LDS ? 4 * LDS_SLOTS : 1];
     __shared__ int s_pos[LDS ? 4 * LDS_SLOTS : 1];
     __shared__ unsigned s_wl[BIN ? 4 * 128 : 1];                     // per wave: 64 tiles + 64 counts / bases (emit_binned)
+    __shared__ int s_surv[PASS_B ? 2 * 24 : 1];                      // pass B: the workgroup's surviving list entries of one round
+    __shared__ int s_nsurv[2];
     unsigned *wl_tile = s_wl + (BIN ? (threadIdx.x >> 6) * 128 : 0), *wl_cnt = wl_tile + (BIN ? 64 : 0);
     const SplatHeader *hdr = (const SplatHeader *)hdr_v;
     int *next = hdr->parity ? pos0 : pos1;
@@ -891,50 +893,91 @@ __global__ __launch_bounds__(256) void cells_pass_kernel(CellCloud cc, Cam1 cam,
     } else {
         const CellEntryB *list_b = cc.list_b + (size_t)s * cc.nchunks;
         const int n_list = sc->nB;
-        // up to three entries per wave (2.3 on the benchmark scene): their records are fetched together, then each
-        // rectangle's bounds (one 2-byte load per lane for rectangles of <= 64 blocks); survivors are queued in a bit mask
-        // so that the point loop exists once in the code
-        for (int t0 = wave; t0 < n_list; t0 += 3 * n_waves) {
-            const int t1 = t0 + n_waves, t2 = t0 + 2 * n_waves;
-            const CellEntryB e0 = list_b[t0], e1 = list_b[t1 < n_list ? t1 : t0], e2 = list_b[t2 < n_list ? t2 : t0];
-            unsigned todo = 0;
+        // Round = every wave tests up to three entries (2.3 on the benchmark scene): their records are fetched together, then each
+        // rectangle's bounds (one 2-byte load per lane for rectangles of <= 64 blocks).  The survivors of a round (a few per
+        // FRAME on the benchmark scene, none in most workgroups) go to a list of the workgroup and are then run by its four waves
+        // TOGETHER, one 256-point quarter each: a survivor processed by the one wave that found it was four dependent rounds of
+        // load -> project -> bound -> reserve -> store, ~8 us at the tail of a 13 us kernel.  The number of rounds is the same for
+        // every wave of the grid (the barriers are uniform); the two survivor lists alternate so that a round's reset cannot race
+        // with the next round's appends.
+        const int wv = (int)(threadIdx.x >> 6);
+        if (threadIdx.x < 2) s_nsurv[threadIdx.x] = 0;
+        __syncthreads();
+        // EPW entries per wave and round, ALL of them in flight together: the entries first, then the first 64 block bounds of
+        // every rectangle (one 2-byte load per lane and entry; bigger rectangles loop on), then the reductions — a round is one
+        // chain of two dependent memory round trips however many entries it holds, and the benchmark scene (3.6 entries per
+        // wave) needs ONE round instead of the two it took at three entries per round.
+        constexpr int EPW = 6;
+        const int n_rounds = (n_list + EPW * n_waves - 1) / (EPW * n_waves);
+        for (int it = 0; it < n_rounds; ++it) {
+            const int t0 = wave + it * EPW * n_waves, par = it & 1;
+            if (t0 < n_list) {
+                CellEntryB e[EPW];
+                bool have[EPW];
 #pragma unroll
-            for (int j = 0; j < 3; ++j) {
-                const CellEntryB e = j == 0 ? e0 : (j == 1 ? e1 : e2);
-                if (j > 0 && t0 + j * n_waves >= n_list) continue;
-                int bx0 = (int)(e.bx >> 16), bx1 = (int)(e.bx & 0xffffu);
-                const int by0 = (int)(e.by >> 16), by1 = (int)(e.by & 0xffffu);
-                const int rw = bx1 - bx0 + 1, nblk = rw * (by1 - by0 + 1);
-                bool run = rw > 0;
-                if (run && nblk <= 4096) {
-                    float emin = 3.0e38f;                          // min over the rectangle of (1 - far bound)
-                    const float inv_rw = 1.0f / (float)rw;
-                    for (int i = lane; i < nblk; i += 64) {
-                        int ry = (int)(((float)i + 0.5f) * inv_rw);   // i / rw for i < 4096 (exact: |error| << 0.5 / rw)
-                        const int rx = i - ry * rw;
-                        emin = fminf(emin, __uint_as_float((unsigned)hiz_g[(by0 + ry) * nbx + bx0 + rx] << 16));
-                    }
-#pragma unroll
-                    for (int o = 32; o > 0; o >>= 1) emin = fminf(emin, __shfl_xor(emin, o));
-                    run = !(e.e_thr < emin);                       // cull iff every point of the box is behind every bound
+                for (int j = 0; j < EPW; ++j) {
+                    const int t = t0 + j * n_waves;
+                    have[j] = t < n_list;
+                    e[j] = list_b[have[j] ? t : t0];
                 }
-                if (run) todo |= 1u << j;
-                else ++n_cull;
-            }
-            todo = __builtin_amdgcn_readfirstlane(todo);
-            while (todo) {
-                const int j = __builtin_ctz(todo);
-                todo &= todo - 1;
-                const int entry = __builtin_amdgcn_readfirstlane(j == 0 ? e0.chunk : (j == 1 ? e1.chunk : e2.chunk));
-                const int chunk = entry & 0x7fffffff;
-                if (lane == 0) cc.sticky[chunk] = STICKY_FRAMES;
-                ++n_run;
+                int bx0[EPW], by0[EPW], rw[EPW], nblk[EPW];
+                float inv_rw[EPW], emin[EPW];
+                bool run[EPW];
 #pragma unroll
-                for (int k = 0; k < 4; ++k) q[k] = cc.pts[chunk * CELL_CHUNK + lane + 64 * k];
-                strip_points<STATS, ZL2, LDS, BIN>(cc, M, W, H, xlo, xhi, keys, zimg, next, chunk * CELL_CHUNK, 4, lane, st_in,
-                                                   st_atomics, tag, hkey, hpos, ks, entry < 0, bi, wl_tile, wl_cnt, wave & (BIN_SUB - 1),
-                                                   q, -1);
+                for (int j = 0; j < EPW; ++j) {
+                    bx0[j] = (int)(e[j].bx >> 16);
+                    by0[j] = (int)(e[j].by >> 16);
+                    rw[j] = (int)(e[j].bx & 0xffffu) - bx0[j] + 1;
+                    nblk[j] = rw[j] * ((int)(e[j].by & 0xffffu) - by0[j] + 1);
+                    run[j] = have[j] && rw[j] > 0;
+                    inv_rw[j] = 1.0f / (float)(rw[j] > 0 ? rw[j] : 1);
+                    emin[j] = 3.0e38f;                                 // min over the rectangle of (1 - far bound)
+                    if (run[j] && nblk[j] <= 4096 && lane < nblk[j]) {
+                        const int ry = (int)(((float)lane + 0.5f) * inv_rw[j]);   // i / rw for i < 4096 (exact: |error| << 0.5 / rw)
+                        emin[j] = __uint_as_float((unsigned)hiz_g[(by0[j] + ry) * nbx + bx0[j] + lane - ry * rw[j]] << 16);
+                    }
+                }
+                unsigned todo = 0;
+#pragma unroll
+                for (int j = 0; j < EPW; ++j) {
+                    if (!have[j]) continue;
+                    if (run[j] && nblk[j] <= 4096) {
+                        for (int i = lane + 64; i < nblk[j]; i += 64) {
+                            const int ry = (int)(((float)i + 0.5f) * inv_rw[j]);
+                            emin[j] = fminf(emin[j], __uint_as_float((unsigned)hiz_g[(by0[j] + ry) * nbx + bx0[j] + i - ry * rw[j]] << 16));
+                        }
+                        float m = emin[j];
+#pragma unroll
+                        for (int o = 32; o > 0; o >>= 1) m = fminf(m, __shfl_xor(m, o));
+                        run[j] = !(e[j].e_thr < m);                    // cull iff every point of the box is behind every bound
+                    }
+                    if (run[j]) todo |= 1u << j;
+                    else ++n_cull;
+                }
+                todo = __builtin_amdgcn_readfirstlane(todo);
+#pragma unroll
+                for (int j = 0; j < EPW; ++j) {
+                    if (!((todo >> j) & 1u)) continue;
+                    const int entry = __builtin_amdgcn_readfirstlane(e[j].chunk);
+                    if (lane == 0) {
+                        cc.sticky[entry & 0x7fffffff] = STICKY_FRAMES;
+                        s_surv[par * (4 * EPW) + atomicAdd(&s_nsurv[par], 1)] = entry;      // <= EPW per wave and round
+                    }
+                    ++n_run;
+                }
             }
+            __syncthreads();
+            const int ns = s_nsurv[par];
+            if (threadIdx.x == 0) s_nsurv[par ^ 1] = 0;                // the next round's list (nobody touches it before the barrier below)
+            for (int item = wv; item < 4 * ns; item += 4) {
+                const int entry = s_surv[par * 24 + (item >> 2)];
+                const int first = (entry & 0x7fffffff) * CELL_CHUNK + (item & 3) * 256;
+#pragma unroll
+                for (int k = 0; k < 4; ++k) q[k] = cc.pts[first + lane + 64 * k];
+                strip_points<STATS, ZL2, LDS, BIN>(cc, M, W, H, xlo, xhi, keys, zimg, next, first, 1, lane, st_in, st_atomics, tag, hkey,
+                                                   hpos, ks, entry < 0, bi, wl_tile, wl_cnt, wave & (BIN_SUB - 1), q, -1);
+            }
+            __syncthreads();
         }
     }
     if (STATS) {

@@ -32,10 +32,9 @@ int grid_for(long long items, int per_block = 256, int cap = 256 * 16)
 // parameter / weight packing on the device
 // ---------------------------------------------------------------------------------------------------------------------
 // params block of the conv kernels: 4 x CoutPad = bias_f, bias_m, bn_scale, bn_shift (read_conv_pack_params_host)
-__global__ void pack_params_kernel(int Cout, int CoutPad, const float *bf, const float *bm, const float *gamma,
-                                   const float *beta, const float *mean, const float *var, float eps, float *out)
+__device__ __forceinline__ void pack_params_body(int c, int Cout, int CoutPad, const float *bf, const float *bm, const float *gamma,
+                                                 const float *beta, const float *mean, const float *var, float eps, float *out)
 {
-    const int c = blockIdx.x * blockDim.x + threadIdx.x;
     if (c >= CoutPad) return;
     const bool ok = c < Cout;
     const float sc = ok ? gamma[c] / sqrtf(var[c] + eps) : 0.0f;
@@ -44,19 +43,24 @@ __global__ void pack_params_kernel(int Cout, int CoutPad, const float *bf, const
     out[2 * CoutPad + c] = sc;
     out[3 * CoutPad + c] = ok ? beta[c] - mean[c] * sc : 0.0f;
 }
+__global__ void pack_params_kernel(int Cout, int CoutPad, const float *bf, const float *bm, const float *gamma,
+                                   const float *beta, const float *mean, const float *var, float eps, float *out)
+{
+    pack_params_body(blockIdx.x * blockDim.x + threadIdx.x, Cout, CoutPad, bf, bm, gamma, beta, mean, var, eps, out);
+}
 
 // Direct-kernel fragment order of read_conv_pack_weights_host: [chunk][tap][k8][tile(f,m)][lane][4].
 // mode 0: the layer's own weights  W{f|m}[cout][cin][tap]                                    (forward)
 // mode 1: dgrad as a convolution over d[f|m] (2*Cp channels: df then dm, Cp = padded Cout of the layer):
 //         virtual conv with Cin_v = 2*Cp input channels and Cout_v = Cin/2 gated output channels per half;
 //         W_v{half}[co_v][ci_v][tap] = W{ci_v < Cp ? f : m}[ci_v % Cp][half * Cin/2 + co_v][k*k - 1 - tap]   (flipped, transposed)
-__global__ void pack_weights_kernel(int mode, int Cin, int Cout, int ksize, int kc, int Cp, const float *wf, const float *wm,
-                                    float *out, long long total)
+__device__ __forceinline__ void pack_weights_body(int bid, int nblk, int mode, int Cin, int Cout, int ksize, int kc, int Cp, const float *wf,
+                                                  const float *wm, float *out, long long total)
 {
     const int taps = ksize * ksize;
     const int CinV = mode ? 2 * Cp : Cin, CoutV = mode ? Cin / 2 : Cout;
     const int CoutPad = (CoutV + 31) / 32 * 32, NT = CoutPad / 16, KK = kc / 8;
-    for (long long o = (long long)blockIdx.x * blockDim.x + threadIdx.x; o < total; o += (long long)gridDim.x * blockDim.x) {
+    for (long long o = (long long)bid * blockDim.x + threadIdx.x; o < total; o += (long long)nblk * blockDim.x) {
         long long r = o;
         const int j = (int)(r & 3); r >>= 2;
         const int lane = (int)(r & 63); r >>= 6;
@@ -78,6 +82,11 @@ __global__ void pack_weights_kernel(int mode, int Cin, int Cout, int ksize, int 
         out[o] = v;
     }
 }
+__global__ void pack_weights_kernel(int mode, int Cin, int Cout, int ksize, int kc, int Cp, const float *wf, const float *wm,
+                                    float *out, long long total)
+{
+    pack_weights_body((int)blockIdx.x, (int)gridDim.x, mode, Cin, Cout, ksize, kc, Cp, wf, wm, out, total);
+}
 
 // The 3x3 kernel of the (virtual) layer's (cout, cin) pair, or null where the pair does not exist.  mode 0: the layer's own weights;
 // mode 1: dgrad as a convolution over d[f|m] (pack_weights_kernel): flipped, transposed.
@@ -94,14 +103,14 @@ __device__ __forceinline__ const float *w3x3_of(int mode, int Cin, int Cout, int
 // [group][k8 step][row i][j][f|m][lane][4], row 2 negated.  One workgroup per (group, k8 step): thread (lane, e) forms the 4 x 4
 // transform of its pair ONCE (constant indices: the first version looked G up per output element and spent 114 us per layer in
 // scratch traffic) and writes its 2 x 16 outputs, 1 KiB per instruction and workgroup.
-__global__ __launch_bounds__(256) void pack_wino_kernel(int mode, int Cin, int Cout, int Cp, const float *wf, const float *wm, float *out)
+__device__ __forceinline__ void pack_wino_body(int bid, int mode, int Cin, int Cout, int Cp, const float *wf, const float *wm, float *out)
 {
     const int CinV = mode ? 2 * Cp : Cin, CoutV = mode ? Cin / 2 : Cout;
     const int nsteps = CinV / 8;
-    const int st = blockIdx.x % nsteps, g = blockIdx.x / nsteps;
+    const int st = bid % nsteps, g = bid / nsteps;
     const int lane = threadIdx.x >> 2, e = threadIdx.x & 3;
     const int co = g * 32 + (lane & 31), ci = 8 * st + 4 * (lane >> 5) + e;
-    float *o = out + (size_t)blockIdx.x * (16 * 2 * 256) + threadIdx.x;
+    float *o = out + (size_t)bid * (16 * 2 * 256) + threadIdx.x;
 #pragma unroll
     for (int fm = 0; fm < 2; ++fm) {
         const float *k = w3x3_of(mode, Cin, Cout, Cp, wf, wm, fm, co, ci, CoutV);
@@ -125,16 +134,20 @@ __global__ __launch_bounds__(256) void pack_wino_kernel(int mode, int Cin, int C
         }
     }
 }
+__global__ __launch_bounds__(256) void pack_wino_kernel(int mode, int Cin, int Cout, int Cp, const float *wf, const float *wm, float *out)
+{
+    pack_wino_body((int)blockIdx.x, mode, Cin, Cout, Cp, wf, wm, out);
+}
 
 // Winograd F(4x4,3x3) fragment order of read_conv_pack_w4_host: U = G g G^T (6 x 6, evaluated in double, rounded once) per
 // (cout, cin) pair, [group][wave 4][chunk of 16 cin][frequency 6 xi + nu][lane][e]; lane (i = lane & 15, kl = lane >> 4) =
 // U_{i < 8 ? f : m}[xi][nu][cin = 16 chunk + 4 kl + e][cout = 32 group + 8 wave + (i & 7)].  One workgroup per (group, wave, chunk):
 // thread (lane, e) forms the 36 values of its pair and writes them 1 KiB per instruction and workgroup.
-__global__ __launch_bounds__(256) void pack_w4_kernel(int mode, int Cin, int Cout, int Cp, const float *wf, const float *wm, float *out)
+__device__ __forceinline__ void pack_w4_body(int bid, int mode, int Cin, int Cout, int Cp, const float *wf, const float *wm, float *out)
 {
     const int CinV = mode ? 2 * Cp : Cin, CoutV = mode ? Cin / 2 : Cout;
     const int nchunks = CinV / 16;
-    const int chunk = blockIdx.x % nchunks, w = (blockIdx.x / nchunks) & 3, g = blockIdx.x / (4 * nchunks);
+    const int chunk = bid % nchunks, w = (bid / nchunks) & 3, g = bid / (4 * nchunks);
     const int lane = threadIdx.x >> 2, e = threadIdx.x & 3;
     const int slot = lane & 15, fm = slot >> 3;
     const int co = g * 32 + w * 8 + (slot & 7), ci = 16 * chunk + 4 * (lane >> 4) + e;
@@ -154,13 +167,56 @@ __global__ __launch_bounds__(256) void pack_w4_kernel(int mode, int Cin, int Cou
     double h[3][6];                                            // h[b][xi] = sum_a G[xi][a] g[a][b]
 #pragma unroll
     for (int b2 = 0; b2 < 3; ++b2) gmul(wk[0][b2], wk[1][b2], wk[2][b2], h[b2]);
-    float *o = out + (size_t)blockIdx.x * (36 * 256) + threadIdx.x;
+    float *o = out + (size_t)bid * (36 * 256) + threadIdx.x;
 #pragma unroll
     for (int xi = 0; xi < 6; ++xi) {
         double u[6];
         gmul(h[0][xi], h[1][xi], h[2][xi], u);
 #pragma unroll
         for (int nu = 0; nu < 6; ++nu) o[(xi * 6 + nu) * 256] = (float)u[nu];
+    }
+}
+__global__ __launch_bounds__(256) void pack_w4_kernel(int mode, int Cin, int Cout, int Cp, const float *wf, const float *wm, float *out)
+{
+    pack_w4_body((int)blockIdx.x, mode, Cin, Cout, Cp, wf, wm, out);
+}
+
+// Every packing job of a training step in ONE launch (read_conv_pack_batch): a step re-packs the parameter block, the forward
+// fragments and the dgrad fragments of all 99 layers because the optimizer has just changed them — 297 launches of 2 .. 5 us
+// kernels, each with its own allocation and event on the host side and ~8 us of launch gap on the device side.  A workgroup finds
+// its job in the table (first_block is the running sum of the jobs' block counts) and runs that job's body.
+__global__ __launch_bounds__(256) void pack_batch_kernel(const read_pack_job *__restrict__ jobs, int njobs)
+{
+    __shared__ int s_job;
+    if (threadIdx.x == 0) {
+        int lo = 0, hi = njobs - 1;                            // last job with first_block <= blockIdx.x
+        while (lo < hi) {
+            const int mid = (lo + hi + 1) >> 1;
+            if (jobs[mid].first_block <= (int)blockIdx.x) lo = mid;
+            else hi = mid - 1;
+        }
+        s_job = lo;
+    }
+    __syncthreads();
+    const read_pack_job j = jobs[s_job];
+    const int bid = (int)blockIdx.x - j.first_block;
+    if (bid >= j.nblocks) return;
+    switch (j.kind) {
+    case READ_PACK_PARAMS:
+        pack_params_body(bid * 256 + (int)threadIdx.x, j.Cout, (j.Cout + 31) / 32 * 32, j.bf, j.bm, j.gamma, j.beta, j.mean, j.var, j.eps,
+                         j.out);
+        break;
+    case READ_PACK_DIRECT:
+        pack_weights_body(bid, j.nblocks, j.mode, j.Cin, j.Cout, j.ksize, j.kc, j.Cp, j.wf, j.wm, j.out, j.total);
+        break;
+    case READ_PACK_WINO:
+        pack_wino_body(bid, j.mode, j.Cin, j.Cout, j.Cp, j.wf, j.wm, j.out);
+        break;
+    case READ_PACK_W4:
+        pack_w4_body(bid, j.mode, j.Cin, j.Cout, j.Cp, j.wf, j.wm, j.out);
+        break;
+    default:
+        break;
     }
 }
 
@@ -878,6 +934,50 @@ extern "C" int read_conv_pack_dgrad_device(int Cin, int Cout, int ksize, int kc,
     const long long total = (long long)read_conv_dgrad_packed_floats(Cin, Cout, ksize);
     hipLaunchKernelGGL(pack_weights_kernel, dim3(grid_for(total)), dim3(256), 0, as_stream(stream), 1, Cin, Cout, ksize, kc, Cp,
                        wf, wm, wpacked, total);
+    READ_CHECK_LAUNCH();
+    return READ_OK;
+}
+
+// Fills the derived fields of a packing job (Cp, total, nblocks) from its kind / mode / shape; first_block stays the caller's.
+extern "C" int read_conv_pack_job_prepare(read_pack_job *job)
+{
+    READ_CHECK_ARG(job, "read_conv_pack_job_prepare: null job");
+    read_pack_job &j = *job;
+    READ_CHECK_ARG(j.Cout >= 1 && j.out, "read_conv_pack_job_prepare: bad job (Cout %d)", j.Cout);
+    j.Cp = (j.Cout + 7) / 8 * 8;
+    if (j.kind == READ_PACK_PARAMS) {
+        READ_CHECK_ARG(j.gamma && j.beta && j.mean && j.var, "read_conv_pack_job_prepare: params job needs gamma / beta / mean / var");
+        j.total = 4ll * ((j.Cout + 31) / 32 * 32);
+        j.nblocks = ((j.Cout + 31) / 32 * 32 + 255) / 256;
+        return READ_OK;
+    }
+    READ_CHECK_ARG(j.wf && j.wm && j.Cin >= 2 && (j.mode == 0 || j.Cin % 2 == 0), "read_conv_pack_job_prepare: bad weights job");
+    const int CinV = j.mode ? 2 * j.Cp : j.Cin, CoutV = j.mode ? j.Cin / 2 : j.Cout;
+    if (j.kind == READ_PACK_DIRECT) {
+        READ_CHECK_ARG(j.ksize == 1 || j.ksize == 3 || j.ksize == 4, "read_conv_pack_job_prepare: ksize must be 1, 3 or 4");
+        READ_CHECK_ARG((j.kc == 8 || j.kc == 16 || (j.kc == 32 && j.ksize == 1)) && CinV % j.kc == 0,
+                       "read_conv_pack_job_prepare: %d input channels are not a multiple of kc=%d", CinV, j.kc);
+        j.total = (long long)read_conv_packed_floats(CinV, CoutV, j.ksize);
+        const long long b = (j.total + 256 * 8 - 1) / (256 * 8);
+        j.nblocks = (int)(b < 1 ? 1 : (b > 64 ? 64 : b));
+    } else if (j.kind == READ_PACK_WINO) {
+        READ_CHECK_ARG(CinV % 16 == 0, "read_conv_pack_job_prepare: Winograd fragments need Cin %% 16 == 0 (got %d)", CinV);
+        j.total = (long long)read_conv_wino_floats(CinV, CoutV);
+        j.nblocks = (int)(j.total / (32 * 256));
+    } else if (j.kind == READ_PACK_W4) {
+        READ_CHECK_ARG(CinV % 16 == 0, "read_conv_pack_job_prepare: Winograd fragments need Cin %% 16 == 0 (got %d)", CinV);
+        j.total = (long long)read_conv_w4_floats(CinV, CoutV);
+        j.nblocks = (int)(j.total / (36 * 256));
+    } else {
+        READ_CHECK_ARG(false, "read_conv_pack_job_prepare: unknown kind %d", j.kind);
+    }
+    return READ_OK;
+}
+
+extern "C" int read_conv_pack_batch(const read_pack_job *jobs_dev, int njobs, int total_blocks, void *stream)
+{
+    READ_CHECK_ARG(jobs_dev && njobs >= 1 && total_blocks >= 1, "read_conv_pack_batch: empty job table");
+    hipLaunchKernelGGL(pack_batch_kernel, dim3((unsigned)total_blocks), dim3(256), 0, as_stream(stream), jobs_dev, njobs);
     READ_CHECK_LAUNCH();
     return READ_OK;
 }

@@ -89,7 +89,7 @@ USE_W4 = True                # ... and through the F(4x4,3x3) kernel where its u
 USE_WINOGRAD = True          # 3x3 / stride-1 layers with cin % 16 == 0: forward pre-activations and dgrad through the Winograd kernel
 
 
-WGRAD_SIDE_STREAM = True     # weight gradients on a side stream, joined at the end of the backward pass
+WGRAD_SIDE_STREAM = os.environ.get("READ_AMD_WGRAD_SIDE", "1") != "0"   # weight gradients on a side stream, joined at the end of the backward pass
 _SIDE = {}                   # device -> [stream, join queued for the running backward pass]
 
 
@@ -142,15 +142,18 @@ def _zero_params(n, dev):
     return z
 
 
+def _pack_version(wf, bf, wm, bm, gamma, beta, mean, var, identity_bn):
+    if identity_bn:
+        return tuple(t._version for t in (wf, bf, wm, bm)) + (wf.data_ptr(), wm.data_ptr(), 'identity')
+    return tuple(t._version for t in (wf, bf, wm, bm, gamma, beta, mean, var)) + (wf.data_ptr(), wm.data_ptr())
+
+
 def _packed_for(wf, bf, wm, bm, gamma, beta, mean, var, cin, cout, k, identity_bn=False, stride=1):
     """identity_bn (batch-statistics mode): the params block carries the two biases and scale 1 / shift 0 — the launch then
     stores g = act(f) * sigmoid(m) itself and read_bn_train_forward normalises it."""
     L = _lib.lib()
     st = _lib.stream_ptr()
-    if identity_bn:
-        ver = tuple(t._version for t in (wf, bf, wm, bm)) + (wf.data_ptr(), wm.data_ptr(), 'identity')
-    else:
-        ver = tuple(t._version for t in (wf, bf, wm, bm, gamma, beta, mean, var)) + (wf.data_ptr(), wm.data_ptr())
+    ver = _pack_version(wf, bf, wm, bm, gamma, beta, mean, var, identity_bn)
     # While a HIP graph is being captured (GraphedTrainStep) every layer packs afresh: the packing launches must be PART of
     # the graph — it is replayed after every optimizer step — and a cache hit would freeze the fragments of the capture step in.
     capturing = torch.cuda.is_current_stream_capturing()
@@ -158,12 +161,13 @@ def _packed_for(wf, bf, wm, bm, gamma, beta, mean, var, cin, cout, k, identity_b
     if hit is not None and hit[6]() is not wf:              # the id was recycled by another tensor: not this layer's entry
         hit = None
     if hit is not None and hit[0] == ver:
-        cur = torch.cuda.current_stream()
-        cur.wait_event(hit[4])                              # packed on another item's stream
-        hit[1].record_stream(cur)
-        hit[2].record_stream(cur)
-        if hit[5] is not None:
-            hit[5].record_stream(cur)
+        if hit[4] is not None:                              # None: the step's pack plan filled it on this stream, into buffers it keeps
+            cur = torch.cuda.current_stream()
+            cur.wait_event(hit[4])                          # packed on another item's stream
+            hit[1].record_stream(cur)
+            hit[2].record_stream(cur)
+            if hit[5] is not None:
+                hit[5].record_stream(cur)
         return hit
     dev = wf.device
     params = torch.empty(L.read_conv_param_floats(cout), dtype=torch.float32, device=dev)
@@ -237,11 +241,160 @@ def _pack_dgrad(entry, wf, wm, cin, cout, k):
     entry[3] = (wd, ev, wdw)
 
 
+# -----------------------------------------------------------------------------------------------------------------------
+# Every packing job of a step in one launch
+# -----------------------------------------------------------------------------------------------------------------------
+# The optimizer changes every weight every step, so a step re-packs the parameter block, the forward fragments and the dgrad
+# fragments of all 99 layers.  Layer by layer that was 297 launches of 2 .. 5 us kernels per step, each with its allocation, its
+# event and its record_stream calls on the host and ~8 us of launch gap on the device (bench.py: the step is bound by its ~1200
+# launches, host and device alike).  The net's tensors keep their addresses across optimizer steps, so the jobs are tabulated
+# ONCE per (net, BatchNorm mode) — outputs in buffers the plan keeps — and a step is one read_conv_pack_batch launch at the head of
+# the forward pass; the per-layer cache then hits for every layer.
+PACK_BATCH = os.environ.get("READ_AMD_PACK_BATCH", "1") != "0"
+
+
+class _PackPlan:
+    def __init__(self, net, identity_bn):
+        from .unet import layer_table
+        L = _lib.lib()
+        dev = next(net.parameters()).device
+        self.identity_bn = bool(identity_bn)
+        self.layers = []            # (tensors of the layer, cache entry pieces)
+        jobs = []
+
+        def job(kind, mode, cin, cout, k, kc, out, wf=None, wm=None, par=None):
+            j = _lib.PackJob()
+            j.kind, j.mode, j.Cin, j.Cout, j.ksize, j.kc, j.eps = kind, mode, cin, cout, k, kc, BN_EPS
+            j.out = out.data_ptr()
+            if wf is not None:
+                j.wf, j.wm = wf.data_ptr(), wm.data_ptr()
+            if par is not None:
+                j.bf, j.bm, j.gamma, j.beta, j.mean, j.var = (t.data_ptr() if t is not None else None for t in par)
+            _lib.check(L.read_conv_pack_job_prepare(C.byref(j)), "read_conv_pack_job_prepare")
+            jobs.append(j)
+
+        f32 = dict(dtype=torch.float32, device=dev)
+        for (path, cin, cout, k, stride, _elu) in layer_table():
+            if path.startswith("ConvsOut."):                 # in the state dict, never executed (unet.py:181-186)
+                continue
+            node = net
+            for p_ in path.split('.'):
+                node = node._modules[p_]
+            b = node.block
+            n = b['norm']
+            wf, bf, wm, bm = b['conv_f'].weight, b['conv_f'].bias, b['conv_m'].weight, b['conv_m'].bias
+            if not (wf.is_contiguous() and wm.is_contiguous()):
+                raise ValueError("pack plan: non-contiguous weights")
+            # parameter block
+            params = torch.empty(L.read_conv_param_floats(cout), **f32)
+            if self.identity_bn:
+                one, zero = _const_vec(cout, 1.0, dev), _const_vec(cout, 0.0, dev)
+                par = (bf, bm, one, zero, zero, one)
+            else:
+                par = (bf, bm, n.weight, n.bias, n.running_mean, n.running_var)
+            job(_lib.PACK_PARAMS, 0, cin, cout, k, 0, params, par=par)
+            if self.identity_bn:
+                jobs[-1].eps = 0.0                           # scale = 1 / sqrt(1 + 0)
+            # forward fragments: ONE order per layer, the one the launch takes (as _packed_for)
+            wino = None
+            if k == 3 and stride == 1 and cin % 16 == 0 and USE_WINOGRAD:
+                if _w4_fits(cin, cout):
+                    wino = torch.empty(L.read_conv_w4_floats(cin, cout), **f32)
+                    job(_lib.PACK_W4, 0, cin, cout, 3, 16, wino, wf, wm)
+                else:
+                    wino = torch.empty(L.read_conv_wino_floats(cin, cout), **f32)
+                    job(_lib.PACK_WINO, 0, cin, cout, 3, 16, wino, wf, wm)
+                wp = wino
+            else:
+                wp = torch.empty(L.read_conv_packed_floats(cin, cout, k), **f32)
+                job(_lib.PACK_DIRECT, 0, cin, cout, k, _kc_for(cin), wp, wf, wm)
+            # dgrad fragments (as _pack_dgrad) for the layers whose dgrad is a convolution launch
+            dg = None
+            if stride == 1 or (stride == 2 and k == 3):
+                cp = (cout + 7) // 8 * 8
+                if k == 3 and USE_WINOGRAD:
+                    if _w4_fits(2 * cp, cin // 2):
+                        wdw = torch.empty(L.read_conv_dgrad_w4_floats(cin, cout), **f32)
+                        job(_lib.PACK_W4, 1, cin, cout, 3, 16, wdw, wf, wm)
+                    else:
+                        wdw = torch.empty(L.read_conv_dgrad_wino_floats(cin, cout), **f32)
+                        job(_lib.PACK_WINO, 1, cin, cout, 3, 16, wdw, wf, wm)
+                    dg = (wdw, None, wdw)
+                else:
+                    wd = torch.empty(L.read_conv_dgrad_packed_floats(cin, cout, k), **f32)
+                    job(_lib.PACK_DIRECT, 1, cin, cout, k, 16, wd, wf, wm)
+                    dg = (wd, None, None)
+            self.layers.append(((wf, bf, wm, bm, n.weight, n.bias, n.running_mean, n.running_var), params, wp, dg, wino))
+        first = 0
+        for j in jobs:
+            j.first_block = first
+            first += j.nblocks
+        self.total_blocks, self.njobs = first, len(jobs)
+        table = (_lib.PackJob * len(jobs))(*jobs)
+        self.table = torch.frombuffer(bytearray(bytes(table)), dtype=torch.uint8).to(dev)
+        self.signature = None
+
+    def refresh(self):
+        """Pack every layer with its current weights — one launch — unless nothing changed since the last one."""
+        sig = tuple(t._version for ts in self.layers for t in ts[0])
+        if sig == self.signature:
+            return
+        _lib.check(_lib.lib().read_conv_pack_batch(self.table.data_ptr(), self.njobs, self.total_blocks, _lib.stream_ptr()),
+                   "read_conv_pack_batch")
+        self.signature = sig
+        for (ts, params, wp, dg, wino) in self.layers:
+            wf = ts[0]
+            key = id(wf)
+            old = _PACK_CACHE.get(key)
+            if old is not None and old[6]() is wf:
+                ref = old[6]
+            else:
+                ref = weakref.ref(wf)
+                weakref.finalize(wf, _drop_pack, key, ref)
+            _PACK_CACHE[key] = [_pack_version(*ts, self.identity_bn), params, wp, dg, None, wino, ref]
+
+
+def _pack_plan(net, identity_bn):
+    """The net's plan for this BatchNorm mode; rebuilt when a tensor has moved (.cuda() / .to() / a new parameter object)."""
+    ts = net.__dict__.get('_flat_tensors')
+    if ts is None:
+        ts = net.__dict__['_flat_tensors'] = list(net.parameters()) + list(net.buffers())
+    key = (bool(identity_bn), hash(tuple(t.data_ptr() for t in ts)), USE_W4, USE_WINOGRAD)
+    plans = net.__dict__.setdefault('_pack_plans', {})
+    plan = plans.get(key)
+    if plan is None:
+        if len(plans) >= 4:
+            plans.clear()
+        plan = plans[key] = _PackPlan(net, identity_bn)
+    return plan
+
+
+class _GradArena:
+    """The bias / BatchNorm-parameter gradients of every layer of ONE step live in one tensor, zero-filled by ONE launch when the
+    step's first backward node asks for its slice (read_bn_param_grads accumulates): 99 `torch.zeros((4, cout))` per step otherwise."""
+
+    def __init__(self):
+        self.size, self.buf, self.taken = 0, None, set()
+
+    def reserve(self, n):
+        off = self.size
+        self.size += (n + 63) // 64 * 64                    # 256-byte slices
+        return off
+
+    def take(self, off, n, dev):
+        if off in self.taken:                               # a second backward over the same graph (retain_graph): fresh zeros
+            return torch.zeros(n, dtype=torch.float32, device=dev)
+        self.taken.add(off)
+        if self.buf is None:
+            self.buf = torch.zeros(self.size, dtype=torch.float32, device=dev)
+        return self.buf[off:off + n]
+
+
 class GatedConvFn(torch.autograd.Function):
     """y = BN_eval(act(conv_f(x) + b_f) * sigmoid(conv_m(x) + b_m)) for ONE image, x (H,W,Cin) NHWC -> (Ho,Wo,Cout)."""
 
     @staticmethod
-    def forward(ctx, x, wf, bf, wm, bm, gamma, beta, mean, var, k, stride, elu, nb=1, v_num=1, v_den=1, bn_train=False):
+    def forward(ctx, x, wf, bf, wm, bm, gamma, beta, mean, var, k, stride, elu, nb=1, v_num=1, v_den=1, bn_train=False, arena=None):
         L = _lib.lib()
         st = _lib.stream_ptr()
         x = x.contiguous()
@@ -288,6 +441,7 @@ class GatedConvFn(torch.autograd.Function):
             mean = var = stat                        # the backward pass needs the groups' {mean, biased var}, not the buffers
         ctx.bn_train = bool(bn_train)
         ctx.bn_groups = groups
+        ctx.arena = (arena, arena.reserve(4 * cout)) if arena is not None else None
         # the weights ride on the context, not in save_for_backward: a captured step's autograd graph is RETAINED and walked again
         # after every optimizer step (_HybridStepFn) — saved tensors are version-checked, and the optimizer's in-place update of
         # a parameter would read as "modified by an inplace operation"; a step's backward wants the weights of its own forward,
@@ -324,7 +478,10 @@ class GatedConvFn(torch.autograd.Function):
         if WGRAD_SIDE_STREAM:
             ev_dfm = torch.cuda.Event()
             ev_dfm.record(torch.cuda.current_stream(dev))              # d[f|m] (and everything before it) is complete here
-        dbf, dbm, dgamma, dbeta = torch.zeros((4, cout), dtype=torch.float32, device=dev).unbind(0)     # one fill, four rows
+        if ctx.arena is not None:                       # the step's ONE zero-filled tensor for every layer's bias / BatchNorm gradients
+            dbf, dbm, dgamma, dbeta = ctx.arena[0].take(ctx.arena[1], 4 * cout, dev).view(4, cout).unbind(0)
+        else:
+            dbf, dbm, dgamma, dbeta = torch.zeros((4, cout), dtype=torch.float32, device=dev).unbind(0)     # one fill, four rows
         if ctx.bn_train:
             _lib.check(L.read_bn_param_grads_groups(cout, groups, sums.data_ptr(), stat.data_ptr(), BN_EPS, dbf.data_ptr(),
                                                     dbm.data_ptr(), dgamma.data_ptr(), dbeta.data_ptr(), st))
@@ -362,7 +519,7 @@ class GatedConvFn(torch.autograd.Function):
                 _lib.check(L.read_conv_dgrad_generic(dfm.data_ptr(), Ho, Wo, cin, cout, k, stride, wf.data_ptr(), wm.data_ptr(),
                                                      ws.data_ptr(), H, W, dx.data_ptr(), st))
         if not (ctx.needs_input_grad[1] or ctx.needs_input_grad[3]):        # frozen net: nobody asked for weight gradients
-            return dx, None, dbf, None, dbm, dgamma, dbeta, None, None, None, None, None, None, None, None, None
+            return dx, None, dbf, None, dbm, dgamma, dbeta, None, None, None, None, None, None, None, None, None, None
         if FLOP_LOG is not None:
             FLOP_LOG.append(("wgrad", 2.0 * Ho * Wo * cin * 2 * cout * k * k, 0))
         dwf, dwm = torch.empty_like(wf), torch.empty_like(wm)
@@ -397,7 +554,7 @@ class GatedConvFn(torch.autograd.Function):
         else:
             _lib.check(L.read_conv_wgrad(x.data_ptr(), H, W, cin, dfm.data_ptr(), cout, k, stride, dwf.data_ptr(), dwm.data_ptr(), 0,
                                          scratch.data_ptr(), n_scr, st))
-        return dx, dwf, dbf, dwm, dbm, dgamma, dbeta, None, None, None, None, None, None, None, None, None
+        return dx, dwf, dbf, dwm, dbm, dgamma, dbeta, None, None, None, None, None, None, None, None, None, None
 
 
 class Up4Fn(torch.autograd.Function):
@@ -463,7 +620,7 @@ def _bc(net, path, x, k, stride=1, elu=True, blk=(1, 1, 1)):
         # nn.BatchNorm2d bookkeeping (momentum is fixed, so only a counter): one forward call per statistic group
         n.num_batches_tracked += blk[0] if bn_train == BN_PER_ITEM else 1
     return GatedConvFn.apply(x, b['conv_f'].weight, b['conv_f'].bias, b['conv_m'].weight, b['conv_m'].bias, n.weight, n.bias,
-                             n.running_mean, n.running_var, k, stride, elu, *blk, bn_train)
+                             n.running_mean, n.running_var, k, stride, elu, *blk, bn_train, net.__dict__.get('_grad_arena'))
 
 
 def _res_blocks(net, prefix, x, blk):
@@ -493,6 +650,11 @@ def unet_forward_train(net, x, x2, x4, x8, blk=(1, 1, 1)):
     """(h,w,8) NHWC pyramids -> (H,W,3); every tensor carries autograd history.  blk = (nb, v_num, v_den): the tensors hold
     nb items stacked vertically, v_num of every v_den rows of an item's block are valid (the rest: zero separator rows;
     ``stack_batch``).  Nearest resampling, concatenation, products and sums keep the separators zero by themselves."""
+    capturing = torch.cuda.is_current_stream_capturing()
+    if PACK_BATCH and not capturing:
+        _pack_plan(net, bool(net.training)).refresh()      # every layer's parameter block and fragments: one launch
+    # a captured step's autograd graph is walked again every step: its nodes must not share one zero-filled tensor across steps
+    net.__dict__['_grad_arena'] = None if capturing else _GradArena()
     z2, z4, z8 = _scm(net, "SCM2", x2, blk), _scm(net, "SCM1", x4, blk), _scm(net, "SCM0", x8, blk)
     res1 = _res_blocks(net, "Encoder.0", _bc(net, "feat_extract.0", x, 3, blk=blk), blk)
     z = _bc(net, "feat_extract.1", res1, 3, stride=2, blk=blk)
@@ -555,7 +717,11 @@ def stack_batch(x_nchw, level):
 # BatchNorm with its running-buffer updates.  What the scheme cannot tolerate falls back to the per-layer path on its own: a second
 # forward before the first one's backward (the retained graph holds ONE set of activations), parameters moved to other addresses
 # (.cuda() / .to(): the key changes and a new graph is captured), hooks, anomaly mode, a failed capture.
-GRAPH_TRAIN = os.environ.get("READ_AMD_GRAPH_TRAIN", "1") != "0"
+# Measured (profiles/README.md, round 4): the forward's host time falls from 28 to 1.3 ms, but the step does not get shorter —
+# 63 ms against 58: a step is ~1200 launches, the device spends ~8 us of gap on each however they are enqueued, and with the host
+# out of the way the device side is the bound.  So the capture is an OPTION (READ_AMD_GRAPH_TRAIN=1, read_amd.train.GRAPH_TRAIN),
+# not the default; what shortens the step is fewer launches (the pack plan above).
+GRAPH_TRAIN = os.environ.get("READ_AMD_GRAPH_TRAIN", "0") == "1"
 _GRAPH_CACHE_MAX = 4         # (geometry, mode) entries kept per net: an entry holds every activation of its step
 
 
