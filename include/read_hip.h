@@ -282,7 +282,8 @@ int read_bilinear_up4(const float *in, int inH, int inW, int C, float *out, void
  *   forward (training)  read_conv_pack_params_device + read_conv_pack_weights_device, read_gated_conv_forward with
  *                       desc.linear = 1 -> pre-activations [pixels][2*Cout], read_gate_forward -> y
  *   backward            read_gate_backward: dy, [f|m] -> dfm [pixels][2*Cp] (Cp = Cout rounded up to 8; df | dm) and the
- *                       per-channel sums S[4][Cout] = {sum df, sum dm, sum dy, sum dy*g}; read_bn_param_grads turns them
+ *                       per-channel sums S[4][Cout] += {sum df, sum dm, sum dy, sum dy*g} (ACCUMULATED: the caller zero-fills S —
+ *                       one fill for all layers of a step; read_gate_backward_bn clears its own); read_bn_param_grads turns them
  *                       into db_f, db_m, dgamma, dbeta (accumulating);
  *                       dgrad: stride 1 -> read_conv_pack_dgrad_device + read_gated_conv_forward(linear = 1) over dfm with
  *                       Cout := Cin/2, zero biases (the same MFMA kernel with flipped, transposed weights);

@@ -26,6 +26,12 @@ int read_debug_operand_probe(int mode, int blocks, int iters, float *scratch, un
 int read_debug_issue_probe(int kind, int filler, int K, int blocks, int iters, float *scratch, unsigned long long *cycles,
                            const float *gsrc, void *stream);
 
+/* Kernel boundary against grid barrier: `phases` dependent phases over `blocks` workgroups, each touching floats_per_block floats
+ * of its slice of buf — mode 0 as dependent launches, mode 1 as one persistent launch with grid barriers (counter_and_flag: two
+ * unsigned; [1] is set when a barrier gave up waiting). */
+int read_debug_chain_probe(int mode, int blocks, int phases, int floats_per_block, float *buf, unsigned *counter_and_flag,
+                           void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -64,6 +64,7 @@ DEBUG_SIGNATURES = {
     "read_debug_mfma_probe": (_i, [_i, _i, _i, _vp, _vp]),
     "read_debug_operand_probe": (_i, [_i, _i, _i, _vp, _vp, _vp]),
     "read_debug_issue_probe": (_i, [_i, _i, _i, _i, _i, _vp, _vp, _vp, _vp]),
+    "read_debug_chain_probe": (_i, [_i, _i, _i, _i, _vp, _vp, _vp]),
 }
 
 # name -> (restype, argtypes): every symbol include/read_hip.h declares

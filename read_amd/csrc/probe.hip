@@ -248,3 +248,73 @@ extern "C" int read_debug_mfma_probe(int blocks, int iters, int nacc, float *scr
     READ_CHECK_LAUNCH();
     return READ_OK;
 }
+
+
+// ---------------------------------------------------------------------------------------------------------------------
+// What a kernel boundary costs against a grid-wide barrier inside one persistent kernel (the rasteriser's five dependent
+// launches: are they worth merging?).  Every "phase" touches `bytes_per_block` of its workgroup's slice of a buffer (read-modify-
+// write, so a phase depends on the previous one through memory).
+//   mode 0: `phases` dependent launches of `blocks` workgroups.
+//   mode 1: ONE launch; the phases are separated by grid barriers (release fence, one atomic add per workgroup on a counter, spin
+//           on an agent-scope load, acquire fence).  `blocks` must not exceed what the device keeps resident.
+// ---------------------------------------------------------------------------------------------------------------------
+namespace {
+__device__ __forceinline__ void chain_phase(float *buf, int floats_per_block, int phase)
+{
+    float *p = buf + (size_t)blockIdx.x * floats_per_block;
+    for (int i = threadIdx.x; i < floats_per_block; i += blockDim.x) p[i] = p[i] * 1.0001f + (float)phase;
+}
+
+__global__ __launch_bounds__(256) void chain_launch_kernel(float *buf, int floats_per_block, int phase)
+{
+    chain_phase(buf, floats_per_block, phase);
+}
+
+__global__ __launch_bounds__(256) void chain_barrier_kernel(float *buf, int floats_per_block, int phases, unsigned *counter, unsigned *timeout_flag)
+{
+    for (int ph = 0; ph < phases; ++ph) {
+        chain_phase(buf, floats_per_block, ph);
+        if (ph + 1 == phases) break;
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            __threadfence();                                                   // release: this workgroup's stores
+            __hip_atomic_fetch_add(counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const unsigned target = (unsigned)(ph + 1) * gridDim.x;
+            unsigned spins = 0;
+            while (__hip_atomic_load(counter, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
+                __builtin_amdgcn_s_sleep(2);
+                if (++spins > (1u << 22)) {                                    // ~seconds: never hang the box
+                    *timeout_flag = 1u;
+                    break;
+                }
+            }
+            __threadfence();                                                   // acquire: the other workgroups' stores
+        }
+        __syncthreads();
+    }
+}
+}  // namespace
+
+extern "C" int read_debug_chain_probe(int mode, int blocks, int phases, int floats_per_block, float *buf, unsigned *counter_and_flag,
+                                      void *stream)
+{
+    READ_CHECK_ARG(blocks > 0 && phases > 0 && floats_per_block > 0 && buf && counter_and_flag, "read_debug_chain_probe: bad arguments");
+    hipStream_t s = as_stream(stream);
+    if (mode == 0) {
+        for (int ph = 0; ph < phases; ++ph)
+            hipLaunchKernelGGL(chain_launch_kernel, dim3(blocks), dim3(256), 0, s, buf, floats_per_block, ph);
+    } else {
+        int per_cu = 0, dev = 0;
+        hipDeviceProp_t prop;
+        READ_CHECK_HIP(hipGetDevice(&dev));
+        READ_CHECK_HIP(hipGetDeviceProperties(&prop, dev));
+        READ_CHECK_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, chain_barrier_kernel, 256, 0));
+        READ_CHECK_ARG(blocks <= per_cu * prop.multiProcessorCount, "read_debug_chain_probe: %d workgroups are not co-resident (%d x %d)",
+                       blocks, per_cu, prop.multiProcessorCount);
+        READ_CHECK_HIP(hipMemsetAsync(counter_and_flag, 0, 2 * sizeof(unsigned), s));
+        hipLaunchKernelGGL(chain_barrier_kernel, dim3(blocks), dim3(256), 0, s, buf, floats_per_block, phases, counter_and_flag,
+                           counter_and_flag + 1);
+    }
+    READ_CHECK_LAUNCH();
+    return READ_OK;
+}

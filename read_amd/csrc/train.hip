@@ -1000,7 +1000,8 @@ extern "C" int read_gate_backward(const float *dy, const float *fm, int64_t pixe
     READ_CHECK_ARG(block_h == 0 || (W >= 1 && valid_h >= 1 && valid_h <= block_h), "read_gate_backward: bad block geometry");
     if (W < 1) W = 1;
     const int Cp = (Cout + 7) / 8 * 8, CoutPad = (Cout + 31) / 32 * 32;
-    READ_CHECK_HIP(hipMemsetAsync(sums, 0, sizeof(float) * 4 * (size_t)Cout, as_stream(stream)));
+    // sums is ACCUMULATED into: the caller hands it over zero-filled (a step's host zero-fills ONE tensor for all of its layers'
+    // sums and parameter gradients; a memset per layer here was one more ~3 us launch in a chain that is bound by its launches)
     if (Cp <= 8) {
         const int blocks = grid_for(pixels, 32, 2048);
         hipLaunchKernelGGL(gate_backward_kernel<8>, dim3(blocks), dim3(256), 0, as_stream(stream), dy, fm, (long long)pixels, Cout,

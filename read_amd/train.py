@@ -441,7 +441,7 @@ class GatedConvFn(torch.autograd.Function):
             mean = var = stat                        # the backward pass needs the groups' {mean, biased var}, not the buffers
         ctx.bn_train = bool(bn_train)
         ctx.bn_groups = groups
-        ctx.arena = (arena, arena.reserve(4 * cout)) if arena is not None else None
+        ctx.arena = (arena, arena.reserve(8 * cout)) if arena is not None else None      # eval mode: sums + gradients; .train(): gradients
         # the weights ride on the context, not in save_for_backward: a captured step's autograd graph is RETAINED and walked again
         # after every optimizer step (_HybridStepFn) — saved tensors are version-checked, and the optimizer's in-place update of
         # a parameter would read as "modified by an inplace operation"; a step's backward wants the weights of its own forward,
@@ -464,7 +464,13 @@ class GatedConvFn(torch.autograd.Function):
         cp = (cout + 7) // 8 * 8
         dfm = torch.empty((Ho, Wo, 2 * cp), dtype=torch.float32, device=dev)
         groups = ctx.bn_groups
-        sums = torch.empty((groups, 4, cout), dtype=torch.float32, device=dev)
+        # eval-mode BatchNorm: sums[4][cout] and the four parameter-gradient rows are one zero-filled slice [8][cout] — of the step's
+        # arena (ONE fill for all layers) or of a tensor of its own; read_gate_backward / read_bn_param_grads accumulate into it
+        zeroed = None
+        if not ctx.bn_train:
+            zeroed = (ctx.arena[0].take(ctx.arena[1], 8 * cout, dev) if ctx.arena is not None
+                      else torch.zeros(8 * cout, dtype=torch.float32, device=dev)).view(8, cout)
+        sums = zeroed[:4] if zeroed is not None else torch.empty((groups, 4, cout), dtype=torch.float32, device=dev)
         if ctx.bn_train:
             stat = mean                                               # [groups][2][cout]: batch mean / biased variance of the forward pass
             abc = torch.empty((groups, 3, cout), dtype=torch.float32, device=dev)
@@ -478,7 +484,9 @@ class GatedConvFn(torch.autograd.Function):
         if WGRAD_SIDE_STREAM:
             ev_dfm = torch.cuda.Event()
             ev_dfm.record(torch.cuda.current_stream(dev))              # d[f|m] (and everything before it) is complete here
-        if ctx.arena is not None:                       # the step's ONE zero-filled tensor for every layer's bias / BatchNorm gradients
+        if zeroed is not None:
+            dbf, dbm, dgamma, dbeta = zeroed[4:].unbind(0)
+        elif ctx.arena is not None:                     # the step's ONE zero-filled tensor for every layer's bias / BatchNorm gradients
             dbf, dbm, dgamma, dbeta = ctx.arena[0].take(ctx.arena[1], 4 * cout, dev).view(4, cout).unbind(0)
         else:
             dbf, dbm, dgamma, dbeta = torch.zeros((4, cout), dtype=torch.float32, device=dev).unbind(0)     # one fill, four rows

@@ -181,7 +181,7 @@ def test_release_library_has_no_debug_entry_points():
     txt = open(os.path.join(ROOT, "include", "read_hip_debug.h")).read()
     txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
     names = sorted(set(re.findall(r"\b(read_debug_[a-z0-9_]+)\s*\(", txt)))
-    assert names == sorted(_lib.DEBUG_SIGNATURES) and len(names) == 4
+    assert names == sorted(_lib.DEBUG_SIGNATURES) and len(names) == 5
     for n in names:
         assert not hasattr(L, n), f"{n} is exported by the release library"
     assert not any(n.startswith("read_debug") for n in _declared_symbols())
