@@ -50,7 +50,7 @@ sys.path.insert(0, ROOT)
 from read_amd import _lib, camera, synthetic, sweep          # noqa: E402
 from read_amd.frame import FrameRenderer                      # noqa: E402
 from read_amd.texture import gather_pyramid                   # noqa: E402
-from read_amd.unet import pack_state, weight_spec             # noqa: E402
+from read_amd.unet import default_layout, pack_state, weight_spec             # noqa: E402
 
 HBM_PEAK_GBS = 8000.0            # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 FP32_MFMA_PEAK_TFS = 157.3       # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 peak
@@ -130,7 +130,8 @@ class SlabWorkload:
             from read_amd.raster import build_cells
             self.xyz = synthetic.make_cloud(N)
             self.desc = synthetic.make_descriptors(N)
-            return [torch.from_numpy(self.xyz), torch.from_numpy(self.desc), torch.from_numpy(pack_state(self.state)),
+            return [torch.from_numpy(self.xyz), torch.from_numpy(self.desc),
+                    torch.from_numpy(pack_state(self.state, layout=default_layout() if not a.tune else 0)),   # --tune: every order
                     torch.from_numpy(build_cells(self.xyz))]
         xyz_d, desc_d, packed_d, cells_d = sweep.broadcast_scene_from_rank0(make, dev)
         self.proj = synthetic.make_proj(self.W, self.H)

@@ -406,10 +406,20 @@ int read_unet_layer_info(int i, const char **path, int *cin, int *cout, int *ksi
 size_t read_unet_raw_floats(void);
 size_t read_unet_packed_floats(void);
 int read_unet_pack_host(const float *raw_host, float bn_eps, float *packed_host);
+/* Layout of the packed blob.  FULL (the two functions above): every fragment order of every layer — direct, both F(2x2) orders,
+ * F(4x4) where it exists —, so any tuning knob can send a layer to any of its kernels: 952 MB for READ's 121 MB of weights.
+ * LEAN: what the default plan reads — a layer the F(4x4) kernel runs (73 of the 105 launches) carries its F(4x4) order only,
+ * layers that no launch executes (ConvsOut) carry nothing: 451 MB.  read_unet_create_layout refuses a lean blob (READ_EINVAL)
+ * when, under the current tuning state or at a size whose tensors reach 2 GiB, one of those layers would not run on the F(4x4)
+ * kernel.  The raw blob is the same for both layouts. */
+enum { READ_UNET_LAYOUT_FULL = 0, READ_UNET_LAYOUT_LEAN = 1 };
+size_t read_unet_packed_floats_layout(int layout);
+int read_unet_pack_host_layout(const float *raw_host, float bn_eps, float *packed_host, int layout);
 size_t read_unet_workspace_bytes(int H, int W);
 /* H, W multiples of 16 (READ/gl/nn.py:107-109).  `packed` and `ws` are device memory that must
  * outlive the handle. */
 int read_unet_create(read_unet_t **out, const float *packed, int H, int W, void *ws, size_t ws_bytes);
+int read_unet_create_layout(read_unet_t **out, const float *packed, int H, int W, void *ws, size_t ws_bytes, int layout);
 void read_unet_destroy(read_unet_t *u);
 /* x0..x3: NHWC [H>>l][W>>l][8] feature pyramids; rgb: NHWC [H][W][rgb_cstride], channels 0..2
  * written (channel 3 set to 1.0f when rgb_cstride == 4, the viewer's RGBA frame, nn.py:123-124). */

@@ -141,6 +141,9 @@ SIGNATURES = {
     "read_unet_pack_host": (_i, [_vp, _f, _vp]),
     "read_unet_workspace_bytes": (_sz, [_i, _i]),
     "read_unet_create": (_i, [_pp, _vp, _i, _i, _vp, _sz]),
+    "read_unet_create_layout": (_i, [_pp, _vp, _i, _i, _vp, _sz, _i]),
+    "read_unet_packed_floats_layout": (_sz, [_i]),
+    "read_unet_pack_host_layout": (_i, [_vp, _f, _vp, _i]),
     "read_unet_destroy": (None, [_vp]),
     "read_unet_forward": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _vp]),
     "read_unet_launch_count": (_i, [_vp]),

@@ -2871,6 +2871,9 @@ extern "C" int read_gated_conv_forward(const read_conv_desc *desc, void *stream)
     // wpacked to its Winograd fragments (training: read_amd/train.py packs ONE order per layer and step) must never reach a
     // kernel that reads wpacked as the direct order — a tuning knob, a 2 GiB tensor or an odd out_cstride can decline the
     // Winograd kernels after the host has packed for them.
+    if (desc && !desc->wpacked)                            // e.g. a lean UNet blob after a knob sent the layer off the F(4x4) kernel
+        READ_CHECK_ARG(read_conv_kernel_family(desc) != 0,
+                       "read_gated_conv_forward: this launch takes a direct kernel and wpacked is NULL (fragment order not packed)");
     if (desc && desc->wpacked) {
         const int family = read_conv_kernel_family(desc);
         READ_CHECK_ARG(!((const void *)desc->wpacked == (const void *)desc->wpacked_w4 && family != 4) &&

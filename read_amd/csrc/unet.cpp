@@ -65,27 +65,36 @@ struct Arch {
 
 size_t raw_layer_floats(int cin, int cout, int k) { return 2 * ((size_t)cout * cin * k * k + cout) + 4 * (size_t)cout; }
 
-const Arch &arch()
+// Layout of the packed blob.  FULL: every fragment order of every layer (direct + both F(2x2) orders + F(4x4) where they exist):
+// any tuning knob can send a layer to any of its kernels — 952 MB for a 121 MB model.  LEAN: what the default plan reads —
+// a layer the F(4x4) kernel takes carries its F(4x4) order ONLY (that kernel runs 73 of the 105 launches; its layers' other three
+// orders were 500 MB nobody touched), the layers no launch executes (ConvsOut) carry nothing; everything else as in FULL.
+// The raw blob (read_unet_raw_floats) is the same for both.
+Arch build_arch(int layout)
 {
-    static Arch A = [] {
+        const bool lean = layout == READ_UNET_LAYOUT_LEAN;
         Arch a;
         auto add = [&](const std::string &path, int cin, int cout, int k, int s, int elu, int kc) {
-            LayerInfo L{path, cin, cout, k, s, elu, kc, 0, 0, 0, NO_WINO, NO_WINO, NO_WINO};
+            LayerInfo L{path, cin, cout, k, s, elu, kc, 0, NO_WINO, 0, NO_WINO, NO_WINO, NO_WINO};
             L.raw_off = a.raw_floats;
             a.raw_floats += raw_layer_floats(cin, cout, k);
-            L.w_off = a.packed_floats;
-            a.packed_floats += read_conv_packed_floats(cin, cout, k);
+            const bool wino = k == 3 && s == 1 && kc == 16 && cin % 16 == 0, w4 = wino && cin >= 32 && cout % 32 == 0;
+            const bool unused = path.compare(0, 9, "ConvsOut.") == 0;
             L.p_off = a.packed_floats;
             a.packed_floats += read_conv_param_floats(cout);
-            if (k == 3 && s == 1 && kc == 16 && cin % 16 == 0) {
+            if (!(lean && (w4 || unused))) {
+                L.w_off = a.packed_floats;
+                a.packed_floats += read_conv_packed_floats(cin, cout, k);
+            }
+            if (wino && !(lean && (w4 || unused))) {
                 L.wino_off = a.packed_floats;
                 a.packed_floats += read_conv_wino_floats(cin, cout);
                 L.w16_off = a.packed_floats;
                 a.packed_floats += read_conv_wino_floats(cin, cout);
-                if (cin >= 32 && cout % 32 == 0) {
-                    L.w4_off = a.packed_floats;
-                    a.packed_floats += read_conv_w4_floats(cin, cout);
-                }
+            }
+            if (w4 && !(lean && unused)) {
+                L.w4_off = a.packed_floats;
+                a.packed_floats += read_conv_w4_floats(cin, cout);
             }
             a.layers.push_back(L);
         };
@@ -158,8 +167,12 @@ const Arch &arch()
         derive("AFFs.1.conv.0r", 0, BASE * 3, {1});
         derive("AFFs.2.conv.0r", 0, BASE * 7, {2});
         return a;
-    }();
-    return A;
+}
+
+const Arch &arch(int layout = READ_UNET_LAYOUT_FULL)
+{
+    static const Arch A[2] = {build_arch(READ_UNET_LAYOUT_FULL), build_arch(READ_UNET_LAYOUT_LEAN)};
+    return A[layout == READ_UNET_LAYOUT_LEAN ? 1 : 0];
 }
 
 // ------------------------------------------------------------------------------------------
@@ -188,6 +201,7 @@ struct Op {
 
 struct read_unet {
     int H, W;
+    int layout = READ_UNET_LAYOUT_FULL;
     const float *packed;
     char *ws;
     size_t ws_bytes, ws_used;
@@ -250,7 +264,7 @@ struct Builder {
     void conv(const std::string &path, std::vector<std::pair<int, int>> srcs, int out_t, int mul_t = -1,
               int res_t = -1)
     {
-        const Arch &A = arch();
+        const Arch &A = arch(u->layout);
         const LayerInfo &L = A.layers[A.find(path)];
         emit(path, LayerRef{L.cin, L.cout, L.k, L.stride, L.elu, L.w_off, L.p_off, L.wino_off, L.w16_off, L.w4_off}, srcs, out_t, mul_t, res_t, 0,
              PreRef());
@@ -259,7 +273,7 @@ struct Builder {
     // gated ones are the AFF layer itself on the inputs of its own level, with the layer's own bias / BatchNorm.
     void conv_derived(const std::string &name, std::vector<std::pair<int, int>> srcs, int out_t, int linear, PreRef pre)
     {
-        const Arch &A = arch();
+        const Arch &A = arch(u->layout);
         const DerivedInfo &D = A.derived[A.find_derived(name)];
         const LayerInfo &P0 = A.layers[D.parts[0]];
         emit(name, LayerRef{D.cin, D.cout, 1, 1, P0.elu, D.w_off, linear ? D.p_off : P0.p_off, NO_WINO, NO_WINO, NO_WINO}, srcs, out_t, -1, -1,
@@ -298,7 +312,7 @@ struct Builder {
         op.d.ksize = L.k;
         op.d.stride = L.stride;
         op.d.elu = L.elu;
-        op.d.wpacked = u->packed + L.w_off;
+        op.d.wpacked = L.w_off != NO_WINO ? u->packed + L.w_off : nullptr;      // lean blob: absent where the F(4x4) kernel runs the layer
         op.d.params = u->packed + L.p_off;
         op.d.wpacked_wino = L.wino_off != NO_WINO ? u->packed + L.wino_off : nullptr;
         op.d.wpacked_w16 = L.w16_off != NO_WINO ? u->packed + L.w16_off : nullptr;
@@ -560,30 +574,42 @@ extern "C" int read_unet_layer_info(int i, const char **path, int *cin, int *cou
 
 extern "C" size_t read_unet_raw_floats(void) { return arch().raw_floats; }
 extern "C" size_t read_unet_packed_floats(void) { return arch().packed_floats; }
+extern "C" size_t read_unet_packed_floats_layout(int layout)
+{
+    return (layout == READ_UNET_LAYOUT_FULL || layout == READ_UNET_LAYOUT_LEAN) ? arch(layout).packed_floats : 0;
+}
 
 extern "C" int read_unet_pack_host(const float *raw, float bn_eps, float *packed)
 {
+    return read_unet_pack_host_layout(raw, bn_eps, packed, READ_UNET_LAYOUT_FULL);
+}
+
+extern "C" int read_unet_pack_host_layout(const float *raw, float bn_eps, float *packed, int layout)
+{
     READ_CHECK_ARG(raw && packed, "read_unet_pack_host: null pointer");
-    for (const LayerInfo &L : arch().layers) {
+    READ_CHECK_ARG(layout == READ_UNET_LAYOUT_FULL || layout == READ_UNET_LAYOUT_LEAN, "read_unet_pack_host: unknown layout %d", layout);
+    for (const LayerInfo &L : arch(layout).layers) {
         const size_t wn = (size_t)L.cout * L.cin * L.k * L.k;
         const float *wf = raw + L.raw_off, *bf = wf + wn, *wm = bf + L.cout, *bm = wm + wn;
         const float *gamma = bm + L.cout, *beta = gamma + L.cout, *mean = beta + L.cout, *var = mean + L.cout;
-        int rc = read_conv_pack_weights_host(L.cin, L.cout, L.k, L.kc, wf, wm, packed + L.w_off);
+        int rc = read_conv_pack_params_host(L.cout, bf, bm, gamma, beta, mean, var, bn_eps, packed + L.p_off);
         if (rc) return rc;
-        rc = read_conv_pack_params_host(L.cout, bf, bm, gamma, beta, mean, var, bn_eps, packed + L.p_off);
-        if (rc) return rc;
+        if (L.w_off != NO_WINO) {
+            rc = read_conv_pack_weights_host(L.cin, L.cout, L.k, L.kc, wf, wm, packed + L.w_off);
+            if (rc) return rc;
+        }
         if (L.wino_off != NO_WINO) {
             rc = read_conv_pack_wino_host(L.cin, L.cout, wf, wm, packed + L.wino_off);
             if (rc) return rc;
             rc = read_conv_pack_w16_host(L.cin, L.cout, wf, wm, packed + L.w16_off);
             if (rc) return rc;
-            if (L.w4_off != NO_WINO) {
-                rc = read_conv_pack_w4_host(L.cin, L.cout, wf, wm, packed + L.w4_off);
-                if (rc) return rc;
-            }
+        }
+        if (L.w4_off != NO_WINO) {
+            rc = read_conv_pack_w4_host(L.cin, L.cout, wf, wm, packed + L.w4_off);
+            if (rc) return rc;
         }
     }
-    const Arch &A = arch();
+    const Arch &A = arch(layout);
     for (const DerivedInfo &D : A.derived) {
         std::vector<float> wf((size_t)D.cout * D.cin), wm(wf.size()), zero(D.cout, 0.0f), one(D.cout, 1.0f);
         int co0 = 0;
@@ -621,7 +647,13 @@ extern "C" size_t read_unet_workspace_bytes(int H, int W)
 
 extern "C" int read_unet_create(read_unet_t **out, const float *packed, int H, int W, void *ws, size_t ws_bytes)
 {
+    return read_unet_create_layout(out, packed, H, W, ws, ws_bytes, READ_UNET_LAYOUT_FULL);
+}
+
+extern "C" int read_unet_create_layout(read_unet_t **out, const float *packed, int H, int W, void *ws, size_t ws_bytes, int layout)
+{
     READ_CHECK_ARG(out && packed && ws, "read_unet_create: null pointer");
+    READ_CHECK_ARG(layout == READ_UNET_LAYOUT_FULL || layout == READ_UNET_LAYOUT_LEAN, "read_unet_create: unknown layout %d", layout);
     READ_CHECK_ARG((uintptr_t)packed % 16 == 0 && (uintptr_t)ws % 256 == 0, "read_unet_create: misaligned weights/workspace");
     int rc = check_hw(H, W);
     if (rc) return rc;
@@ -633,12 +665,19 @@ extern "C" int read_unet_create(read_unet_t **out, const float *packed, int H, i
     read_unet *u = new read_unet();
     u->H = H;
     u->W = W;
+    u->layout = layout;
     u->packed = packed;
     u->ws = (char *)ws;
     u->ws_bytes = ws_bytes;
     set_error("");
     Builder b{u, false};
     b.build();
+    // a lean blob serves exactly the launches the F(4x4) kernel takes under the CURRENT tuning state and at THIS size: a knob
+    // that sends such a layer elsewhere (conv_w4), or a tensor of 2 GiB and more, needs the full layout
+    for (const Op &op : u->ops)
+        if (op.kind == Op::CONV && !op.d.wpacked && !conv_uses_w4(&op.d))
+            set_error("read_unet_create: layer %s is not run by the F(4x4) kernel here and the lean blob carries no other fragment "
+                      "order for it (pack with READ_UNET_LAYOUT_FULL)", op.label.c_str());
     if (read_last_error()[0]) {   // the builder reports plan inconsistencies through set_error
         delete u;
         return READ_EINVAL;

@@ -12,7 +12,7 @@ from . import _lib
 from .camera import level_sizes, total_matrix
 from .raster import PointCloudRasterizer
 from .texture import gather_pyramid, texture_to_rows
-from .unet import UNetEngine, pack_state
+from .unet import LAYOUT_FULL, UNetEngine, default_layout, layout_of, pack_state
 
 LEVELS = 5          # the reference rasterises and gathers 5 scales; the UNet consumes 4 (unet.py:209-212)
 
@@ -40,10 +40,18 @@ class FrameRenderer:
         tex = torch.as_tensor(texture_cn, dtype=torch.float32).to(self.device).contiguous()
         self.rows = texture_to_rows(tex)
         if torch.is_tensor(unet_state):
-            self.packed = unet_state.to(self.device, torch.float32).contiguous()
+            self.packed = unet_state.to(self.device, torch.float32).contiguous()       # full or lean: read off its length
+            self.unet = UNetEngine(self.packed, H, W)
         else:
-            self.packed = torch.from_numpy(pack_state(unet_state)).to(self.device)
-        self.unet = UNetEngine(self.packed, H, W)
+            # the lean blob (451 of 952 MB: the F(4x4) layers carry their F(4x4) order only) unless the plan cannot be served by it
+            self.packed = torch.from_numpy(pack_state(unet_state, layout=default_layout())).to(self.device)
+            try:
+                self.unet = UNetEngine(self.packed, H, W)
+            except _lib.ReadHipError:
+                if layout_of(self.packed) == LAYOUT_FULL:
+                    raise
+                self.packed = torch.from_numpy(pack_state(unet_state, layout=LAYOUT_FULL)).to(self.device)
+                self.unet = UNetEngine(self.packed, H, W)
         self.proj = None if proj_matrix is None else np.asarray(proj_matrix, np.float32)
         sizes = level_sizes(W, H, levels)
         self.idx = [torch.empty((1, h, w), dtype=torch.int32, device=self.device) for (w, h) in sizes]

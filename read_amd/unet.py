@@ -53,11 +53,31 @@ def raw_blob_from_state(state):
     return blob
 
 
-def pack_state(state, eps=BN_EPS):
+LAYOUT_FULL, LAYOUT_LEAN = 0, 1      # READ_UNET_LAYOUT_*: every fragment order of every layer (952 MB) / what the default plan reads (451 MB)
+
+
+def default_layout():
+    """LEAN unless READ_AMD_FULL_PACK=1 (tuning sessions that send F(4x4) layers to other kernels need the full blob)."""
+    import os
+    return LAYOUT_FULL if os.environ.get("READ_AMD_FULL_PACK") == "1" else LAYOUT_LEAN
+
+
+def layout_of(packed):
+    """The layout of a packed blob, read off its length."""
+    L = _lib.lib()
+    n = int(packed.numel() if torch.is_tensor(packed) else packed.size)
+    for layout in (LAYOUT_FULL, LAYOUT_LEAN):
+        if n == L.read_unet_packed_floats_layout(layout):
+            return layout
+    raise _lib.ReadHipError(f"a packed UNet blob has {L.read_unet_packed_floats_layout(LAYOUT_FULL)} (full) or "
+                            f"{L.read_unet_packed_floats_layout(LAYOUT_LEAN)} (lean) floats, not {n}")
+
+
+def pack_state(state, eps=BN_EPS, layout=LAYOUT_FULL):
     """state dict -> packed fp32 blob (host ndarray) in MFMA fragment order with folded BatchNorm."""
     raw = raw_blob_from_state(state)
-    packed = np.empty(_lib.lib().read_unet_packed_floats(), np.float32)
-    _lib.check(_lib.lib().read_unet_pack_host(raw.ctypes.data, eps, packed.ctypes.data), "read_unet_pack_host")
+    packed = np.empty(_lib.lib().read_unet_packed_floats_layout(layout), np.float32)
+    _lib.check(_lib.lib().read_unet_pack_host_layout(raw.ctypes.data, eps, packed.ctypes.data, layout), "read_unet_pack_host")
     return packed
 
 
@@ -73,7 +93,7 @@ class UNetEngine:
             raise _lib.ReadHipError(f"UNet viewport {W}x{H} is not a positive multiple of 16")
         self.ws = torch.empty(need, dtype=torch.uint8, device=packed_dev.device)
         h = C.c_void_p()
-        _lib.check(L.read_unet_create(C.byref(h), packed_dev.data_ptr(), H, W, self.ws.data_ptr(), need),
+        _lib.check(L.read_unet_create_layout(C.byref(h), packed_dev.data_ptr(), H, W, self.ws.data_ptr(), need, layout_of(packed_dev)),
                    "read_unet_create")
         self.handle = h
 
@@ -185,7 +205,7 @@ class UNet(nn.Module):
             if dev.type != 'cuda':
                 raise _lib.ReadHipError("UNet.forward runs on the GPU: move the module with .cuda() "
                                         "(there is no CPU fallback)")
-            self._packed = torch.from_numpy(pack_state(self.state_dict())).to(dev)
+            self._packed = torch.from_numpy(pack_state(self.state_dict(), layout=self.__dict__.get('_layout', default_layout()))).to(dev)
             self._packed_key = key
             self._engines = {}
         return self._packed
@@ -204,7 +224,18 @@ class UNet(nn.Module):
         packed = self.packed_weights()
         e = self._engines.get((H, W))
         if e is None:
-            e = self._engines[(H, W)] = UNetEngine(packed, H, W)
+            try:
+                e = UNetEngine(packed, H, W)
+            except _lib.ReadHipError:
+                if layout_of(packed) != LAYOUT_LEAN:
+                    raise
+                # the lean blob cannot serve this plan (a tuning knob or a >= 2 GiB tensor keeps a layer off the F(4x4) kernel):
+                # every fragment order, from now on
+                self.__dict__['_layout'] = LAYOUT_FULL
+                self._packed = None
+                packed = self.packed_weights()
+                e = UNetEngine(packed, H, W)
+            self._engines[(H, W)] = e
         return e
 
     # ---- forward -----------------------------------------------------------------------------

@@ -241,3 +241,39 @@ def test_headline_frame_1216x352_vs_oracle(hip):
         kinds = [k for (_, _, _, k) in prof]
         assert len(prof) == 105 and kinds.count(4) >= 73, (len(prof), kinds.count(4), kinds.count(2))
         assert sum(1 for (lbl, _, fl, k) in prof if abs(fl - 15.778971648e9 * (H / 352)) < 1e6 and k != 4) == 0
+
+
+def test_lean_weight_blob_renders_the_same_frame(hip):
+    """the lean packed blob (the F(4x4) layers carry their F(4x4) order only: 451 of 952 MB) gives the frame of the
+    full blob bit for bit — same plan, same kernels, fewer bytes resident —, is what FrameRenderer and the UNet module pack by
+    default, and is refused (then replaced by the full blob) when a tuning knob takes a layer off the F(4x4) kernel."""
+    from read_amd.unet import LAYOUT_FULL, LAYOUT_LEAN, UNetEngine, layout_of, pack_state
+    H, W = 64, 96
+    state = synthetic.make_unet_state(UNET_SPEC, 4)
+    xs = [torch.rand(H >> l, W >> l, 8, device="cuda") for l in range(4)]
+    outs = {}
+    for layout in (LAYOUT_FULL, LAYOUT_LEAN):
+        packed = torch.from_numpy(pack_state(state, layout=layout)).cuda()
+        assert layout_of(packed) == layout
+        outs[layout] = UNetEngine(packed, H, W).forward(*xs).clone()
+    assert torch.equal(outs[LAYOUT_FULL], outs[LAYOUT_LEAN])
+    net = UNet()
+    net.load_state_dict({k: torch.from_numpy(np.asarray(v)) for k, v in state.items()})
+    net.cuda().eval()
+    with torch.no_grad():
+        y = net(*[x.permute(2, 0, 1)[None] for x in xs])
+    assert layout_of(net.packed_weights()) == LAYOUT_LEAN
+    assert torch.equal(y[0].permute(1, 2, 0), outs[LAYOUT_FULL])
+    # F(4x4) switched off: the lean blob cannot serve the plan -> loud refusal at the C level, automatic full blob in the module
+    lean = torch.from_numpy(pack_state(state, layout=LAYOUT_LEAN)).cuda()
+    try:
+        _lib.check(_lib.lib().read_tuning_set(b"conv_w4", 0))
+        with pytest.raises(_lib.ReadHipError, match="lean"):
+            UNetEngine(lean, H, W)
+        net.invalidate()
+        with torch.no_grad():
+            y2 = net(*[x.permute(2, 0, 1)[None] for x in xs])
+        assert layout_of(net.packed_weights()) == LAYOUT_FULL
+        _check_rgb(y2.cpu(), y.cpu(), "F(2x2) kernels from the full blob against F(4x4) from the lean one")
+    finally:
+        _lib.check(_lib.lib().read_tuning_set(b"conv_w4", 32))

@@ -207,3 +207,26 @@ def test_pipeline_optimizer_is_adam_on_the_cpu():
     for p, q in zip(a, b):
         assert torch.equal(p, q)
     assert oa.state_dict()['param_groups'][0].keys() == ob.state_dict()['param_groups'][0].keys()
+
+
+def test_lean_packed_layout_is_a_subset_of_the_full_one():
+    """a blob that carries only the fragment orders the default plan reads (READ_UNET_LAYOUT_LEAN): less than half
+    of the full blob's bytes, every value of it present in the full blob (same packers, fewer orders), layouts told apart by length."""
+    from read_amd import _lib
+    from read_amd.unet import LAYOUT_FULL, LAYOUT_LEAN, layout_of
+    L = _lib.lib()
+    n_full, n_lean = L.read_unet_packed_floats_layout(LAYOUT_FULL), L.read_unet_packed_floats_layout(LAYOUT_LEAN)
+    assert n_full == L.read_unet_packed_floats() and 0 < n_lean < 0.5 * n_full and L.read_unet_packed_floats_layout(7) == 0
+    state = synthetic.make_unet_state(UNET_SPEC, 3)
+    full, lean = pack_state(state, layout=LAYOUT_FULL), pack_state(state, layout=LAYOUT_LEAN)
+    assert full.size == n_full and lean.size == n_lean and np.isfinite(lean).all()
+    assert layout_of(full) == LAYOUT_FULL and layout_of(lean) == LAYOUT_LEAN
+    with pytest.raises(_lib.ReadHipError):
+        layout_of(np.zeros(12345, np.float32))
+    # the F(4x4) order of one layer, found by value in both blobs
+    w4 = np.empty(L.read_conv_w4_floats(64, 64), np.float32)
+    wf = np.ascontiguousarray(state["Encoder.1.layers.0.main.0.block.conv_f.weight"], np.float32)
+    wm = np.ascontiguousarray(state["Encoder.1.layers.0.main.0.block.conv_m.weight"], np.float32)
+    _lib.check(L.read_conv_pack_w4_host(64, 64, wf.ctypes.data, wm.ctypes.data, w4.ctypes.data))
+    probe = w4[:64].tobytes()
+    assert probe in lean.tobytes() and probe in full.tobytes()
