@@ -80,15 +80,21 @@ def parse():
     return p.parse_args()
 
 
-def hip_time_ms(fn, iters):
-    """Average duration of fn() measured with HIP events on the current stream."""
-    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    e0.record()
-    for _ in range(iters):
-        fn()
-    e1.record()
-    e1.synchronize()
-    return e0.elapsed_time(e1) / iters
+def hip_time_ms(fn, iters, batches=5):
+    """Duration of fn() measured with HIP events on the current stream: the MEDIAN over `batches` batches of `iters` calls each —
+    an event pair around back-to-back launches also times the host when the host is late (a 57 ms hiccup right after the CPU
+    baseline's OpenMP threads once read as a 5.7 ms gather); the median of five batches does not."""
+    torch.cuda.synchronize()
+    ts = []
+    for _ in range(batches):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(iters):
+            fn()
+        e1.record()
+        e1.synchronize()
+        ts.append(e0.elapsed_time(e1) / iters)
+    return sorted(ts)[len(ts) // 2]
 
 
 def profiled_traffic():
@@ -665,9 +671,9 @@ def stage_times(wl):
     # (as in the timed loop), not over one repeated pose
     it = iter(range(1, 10 ** 6))
     wl.rasterize(0)
-    ms_splat = hip_time_ms(lambda: wl.rasterize(next(it) % N_POSES), 32)
+    ms_splat = hip_time_ms(lambda: wl.rasterize(next(it) % N_POSES), 16)
     ms_gather = hip_time_ms(lambda: wl.gather(), 10)
-    ms_unet = hip_time_ms(lambda: wl.refine(), 5)
+    ms_unet = hip_time_ms(lambda: wl.refine(), 3)
     return ms_splat, ms_gather, ms_unet
 
 

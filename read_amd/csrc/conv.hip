@@ -2530,7 +2530,7 @@ int launch_gated_conv(const read_conv_desc *d, hipStream_t stream)
     READ_CHECK_ARG(d->ksize == 1 || d->ksize == 3 || d->ksize == 4, "read_gated_conv_forward: ksize must be 1,3,4");
     READ_CHECK_ARG(d->stride == 1 || d->stride == 2, "read_gated_conv_forward: stride must be 1 or 2");
     READ_CHECK_ARG(d->inH >= 1 && d->inW >= 1 && d->Cout >= 1, "read_gated_conv_forward: bad sizes");
-    READ_CHECK_ARG(d->wpacked && d->params && d->out, "read_gated_conv_forward: null weights/params/out");
+    READ_CHECK_ARG((d->wpacked || d->wpacked_w4 || d->wpacked_wino) && d->params && d->out, "read_gated_conv_forward: null weights/params/out");
     READ_CHECK_ARG(d->out_cstride >= (d->linear ? 2 : 1) * d->Cout, "read_gated_conv_forward: out_cstride too small");
     READ_CHECK_ARG(!d->linear || (!d->residual && !d->fill_pad), "read_gated_conv_forward: linear mode takes no residual / fill");
     READ_CHECK_ARG(!d->mul || d->n_src == 1, "read_gated_conv_forward: mul needs a single source");

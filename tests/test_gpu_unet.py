@@ -247,6 +247,7 @@ def test_lean_weight_blob_renders_the_same_frame(hip):
     """the lean packed blob (the F(4x4) layers carry their F(4x4) order only: 451 of 952 MB) gives the frame of the
     full blob bit for bit — same plan, same kernels, fewer bytes resident —, is what FrameRenderer and the UNet module pack by
     default, and is refused (then replaced by the full blob) when a tuning knob takes a layer off the F(4x4) kernel."""
+    from read_amd import _lib
     from read_amd.unet import LAYOUT_FULL, LAYOUT_LEAN, UNetEngine, layout_of, pack_state
     H, W = 64, 96
     state = synthetic.make_unet_state(UNET_SPEC, 4)
