@@ -101,7 +101,7 @@ def profiled_traffic():
     """HBM bytes per launch of the dominant kernel family from the committed rocprofv3 PMC passes (separate FETCH_SIZE /
     WRITE_SIZE runs of this same command, FETCH_SIZE x2 as MI355X_MICROARCH.md prescribes for gfx950, factor re-derived
     there from a kernel of known byte count).  Launch-weighted mean over every launch of the 3x3/s1 kernels."""
-    for name in ("r3_traffic.json", "r2_traffic.json", "r1_traffic.json"):
+    for name in ("r4_traffic.json", "r3_traffic.json", "r2_traffic.json", "r1_traffic.json"):
         path = os.path.join(ROOT, "profiles", name)
         try:
             ks = json.load(open(path))["kernels"]
@@ -109,6 +109,8 @@ def profiled_traffic():
             continue
         n = tot = 0
         for kname, v in ks.items():
+            if kname.startswith("gated_conv_wino4_kernel") and ", 0, 0>" not in kname:
+                continue                                     # the training path's linear launches (LIN = 1, 2): not this family
             if kname.startswith("gated_conv_wino") or (kname.startswith("gated_conv") and "<3, 1, 16" in kname):
                 n += v["launches"]
                 tot += (v["read_bytes"] + v["write_bytes"]) * v["launches"]
@@ -760,6 +762,17 @@ def main():
     ex = sweep.FrameExchange((H, W, 4), dev, torch.float32, None if a.exchange == "none" else a.exchange)
     dt = timed_sweep(wl, ex, a.warmup, a.steps, world, dev)
 
+    # ---- per-kernel figures of rank 0, BEFORE the CPU leg: its 64 OpenMP / 16 torch threads keep the host busy for a while after
+    # they return, and event-timed back-to-back launches then time the late host as well (seen: splat 84.6 vs 90.6 us between
+    # otherwise equal runs)
+    stage = prof = None
+    if rank == 0:
+        stage = stage_times(wl)
+        for _ in range(3):
+            cur = wl.profile()
+            prof = cur if prof is None else [(l, m0 + m1, fl, c) for (l, m0, fl, c), (_, m1, _, _) in zip(prof, cur)]
+        prof = [(l, m / 3.0, fl, c) for (l, m, fl, c) in prof]
+
     # ---- every rank checks one of ITS OWN frames (the first pose it rendered) against the oracle on its host cores
     rc = 0
     my_verified = None
@@ -770,12 +783,7 @@ def main():
     verified_ranks = sweep.gather_objects(None if my_verified is None else bool(my_verified["ok"]))
 
     if rank == 0:
-        ms_splat, ms_gather, ms_unet = stage_times(wl)
-        prof = None
-        for _ in range(3):
-            cur = wl.profile()
-            prof = cur if prof is None else [(l, m0 + m1, fl, c) for (l, m0, fl, c), (_, m1, _, _) in zip(prof, cur)]
-        prof = [(l, m / 3.0, fl, c) for (l, m, fl, c) in prof]
+        ms_splat, ms_gather, ms_unet = stage
         c3_ms = sum(m for (_, m, _, c) in prof if c)
         c3_fl = sum(fl for (_, _, fl, c) in prof if c)
         n_c3 = sum(1 for (_, _, _, c) in prof if c)
