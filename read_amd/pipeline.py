@@ -94,10 +94,17 @@ class _DeviceAdam(optim.Adam):
 
     def step(self, closure=None):
         if not self.state:                                        # nothing has been stepped yet: the state is created below
-            on_gpu = all(p.is_cuda for g in self.param_groups for p in g['params'])
+            # what Adam.__init__ checks and sets for fused=True (torch/optim/adam.py), done here because the parameters only
+            # reach the GPU after the optimizer exists: floating-point parameters on a device the fused kernel supports, not
+            # differentiable, no foreach at the same time; and the flag the AMP grad scaler looks for
+            params = [p for g in self.param_groups for p in g['params']]
+            fusable = (all(p.is_cuda and torch.is_floating_point(p) for p in params)
+                       and not any(g.get('differentiable') for g in self.param_groups))
             for g in self.param_groups:
                 if g.get('fused') is None and not g.get('foreach'):
-                    g['fused'] = True if on_gpu else None
+                    g['fused'] = True if fusable else None
+            if any(g.get('fused') for g in self.param_groups):
+                self._step_supports_amp_scaling = True
         stepped = [p for g in self.param_groups if g.get('fused') for p in g['params'] if p.grad is not None]
         out = super().step(closure)
         if stepped:

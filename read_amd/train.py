@@ -324,7 +324,8 @@ class _PackPlan:
                     wd = torch.empty(L.read_conv_dgrad_packed_floats(cin, cout, k), **f32)
                     job(_lib.PACK_DIRECT, 1, cin, cout, k, 16, wd, wf, wm)
                     dg = (wd, None, None)
-            self.layers.append(((wf, bf, wm, bm, n.weight, n.bias, n.running_mean, n.running_var), params, wp, dg, wino))
+            self.layers.append(((wf, bf, wm, bm, n.weight, n.bias, n.running_mean, n.running_var), params, wp, dg, wino,
+                                (cin, cout, k, stride)))
         first = 0
         for j in jobs:
             j.first_block = first
@@ -342,7 +343,7 @@ class _PackPlan:
         _lib.check(_lib.lib().read_conv_pack_batch(self.table.data_ptr(), self.njobs, self.total_blocks, _lib.stream_ptr()),
                    "read_conv_pack_batch")
         self.signature = sig
-        for (ts, params, wp, dg, wino) in self.layers:
+        for (ts, params, wp, dg, wino, _shape) in self.layers:
             wf = ts[0]
             key = id(wf)
             old = _PACK_CACHE.get(key)

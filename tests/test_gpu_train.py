@@ -639,3 +639,44 @@ def test_training_step_from_hip_graphs_equals_the_eager_step(hip):
         _close(ga[l], ins_c[l].grad, f"first forward's gradients after an interleaved second forward, level {l}", rtol=1e-4)
     (out_b * g).sum().backward()                                  # and the eager second forward still backpropagates
     assert all(i.grad is not None for i in ins_b)
+
+
+def test_pack_plan_equals_the_per_layer_packers_and_follows_the_optimizer(hip):
+    """One read_conv_pack_batch launch (read_amd/train.py _PackPlan) against the per-layer device packers it replaces: parameter
+    block, forward fragments and dgrad fragments of every executed layer bit for bit, in eval-mode and identity (batch-statistics)
+    form; and after a FUSED Adam step (which does not advance torch's version counters by itself) the next refresh
+    packs the stepped weights."""
+    from read_amd import train as T
+    from read_amd.pipeline import _DeviceAdam
+    state = synthetic.make_unet_state(UNET_SPEC, 41)
+    net = UNet()
+    net.load_state_dict({k: torch.from_numpy(np.asarray(v)) for k, v in state.items()})
+    net.cuda()
+    for identity in (False, True):
+        plan = T._PackPlan(net, identity)
+        plan.refresh()
+        torch.cuda.synchronize()
+        assert len(plan.layers) == 99 and plan.njobs == 99 * 2 + sum(1 for l in plan.layers if l[3] is not None)
+        for (ts, params, wp, dg, wino, (cin, cout, k, stride)) in plan.layers:
+            wf, bf, wm, bm, gamma, beta, mean, var = ts
+            T._PACK_CACHE.pop(id(wf), None)                                   # force the per-layer path
+            ref = T._packed_for(wf, bf, wm, bm, gamma, beta, mean, var, cin, cout, k, identity_bn=identity, stride=stride)
+            assert torch.equal(ref[1], params), ("parameter block", cin, cout, k, stride)
+            assert (ref[5] is None) == (wino is None) and torch.equal(ref[2], wp), ("forward fragments", cin, cout, k, stride)
+            if dg is not None:
+                T._pack_dgrad(ref, wf, wm, cin, cout, k)
+                assert torch.equal(ref[3][0], dg[0]), ("dgrad fragments", cin, cout, k, stride)
+            T._PACK_CACHE.pop(id(wf), None)
+    # a fused Adam step: versions bumped by _DeviceAdam, so the plan's signature changes and the refresh repacks
+    net.eval()
+    plan = T._pack_plan(net, False)
+    plan.refresh()
+    before = plan.layers[0][2].clone()
+    opt = _DeviceAdam(net.parameters(), lr=1e-2)
+    xs = [torch.rand(1, 8, 32 >> l, 48 >> l, device="cuda") for l in range(4)]
+    net(*xs).sum().backward()
+    sig = plan.signature
+    opt.step()
+    assert opt.param_groups[0]['fused'] is True and opt._step_supports_amp_scaling
+    plan.refresh()
+    assert plan.signature != sig and not torch.equal(plan.layers[0][2], before)
