@@ -680,3 +680,40 @@ def test_pack_plan_equals_the_per_layer_packers_and_follows_the_optimizer(hip):
     assert opt.param_groups[0]['fused'] is True and opt._step_supports_amp_scaling
     plan.refresh()
     assert plan.signature != sig and not torch.equal(plan.layers[0][2], before)
+
+
+def test_model_and_loss_under_dataparallel_on_one_gpu(hip):
+    """src/train.py:147-148 wraps the merged model in nn.DataParallel by default (--multigpu True).  On one visible GPU DataParallel
+    hands the call to the module itself: the result and the losses must be those of the direct call (more than one GPU — replicas
+    of the HIP-backed modules — is not rebuilt)."""
+    from read_amd import _alias
+    from read_amd.net_texture import ModelAndLoss, NetAndTexture
+    from read_amd.texture import PointTexture
+    H, W, N, B = 32, 48, 2000, 2
+    rng = np.random.default_rng(3)
+    state = synthetic.make_unet_state(UNET_SPEC, 8)
+    net = UNet()
+    net.load_state_dict({k: torch.from_numpy(np.asarray(v)) for k, v in state.items()})
+    tex = PointTexture(8, N, init_method='rand')
+    model = NetAndTexture(net, {0: tex})
+    model.load_textures(0)
+    merged = ModelAndLoss(model, torch.nn.L1Loss()).cuda().eval()
+    keys = "uv_1d_p1,uv_1d_p1_ds1,uv_1d_p1_ds2,uv_1d_p1_ds3,uv_1d_p1_ds4".split(',')
+    maps = [torch.from_numpy(rng.integers(0, N, (B, 1, H >> l, W >> l)).astype(np.float32)).cuda() for l in range(5)]
+    target = torch.rand(B, 3, H, W, device="cuda")
+
+    def inputs():
+        d = {'id': torch.zeros(B, dtype=torch.long)}
+        d.update(dict(zip(keys, maps)))
+        return d
+    _alias.set_result_convention('dict')
+    try:
+        with torch.no_grad():
+            out, losses = merged(inputs(), target, label=None, mask=None)
+            out_dp, losses_dp = torch.nn.DataParallel(merged, device_ids=[0])(inputs(), target, label=None, mask=None)
+        assert torch.equal(out['im_out'], out_dp['im_out'])
+        assert set(losses) == set(losses_dp) == {'vgg_loss', 'huber_loss'}
+        for k in losses:
+            assert torch.equal(losses[k], losses_dp[k])
+    finally:
+        _alias.set_result_convention(None)
