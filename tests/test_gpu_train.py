@@ -713,7 +713,7 @@ def test_model_and_loss_under_dataparallel_on_one_gpu(hip):
             out_dp, losses_dp = torch.nn.DataParallel(merged, device_ids=[0])(inputs(), target, label=None, mask=None)
         assert torch.equal(out['im_out'], out_dp['im_out'])
         assert set(losses) == set(losses_dp) == {'vgg_loss', 'huber_loss'}
-        for k in losses:
-            assert torch.equal(losses[k], losses_dp[k])
+        for k in losses:                                   # the reductions sum with atomics: equal to round-off, not bit for bit
+            assert abs(float(losses[k]) - float(losses_dp[k])) <= 1e-6 * abs(float(losses[k])), k
     finally:
         _alias.set_result_convention(None)
