@@ -63,6 +63,8 @@ int read_device_arch(char *name, int len);
  *   "splat_subset"    plain path: bootstrap pass over every n-th chunk (default 8)
  *   "splat_stats"     debug counters in the workspace header
  *   "conv_wino"       largest Cin that takes the Winograd F(2x2,3x3) kernel (0 = direct implicit-GEMM kernels everywhere)
+ *   "conv_sc"         8 (default): gated 3x3/s1 layers with Cin = 32, Cout <= 4 on the vector-pipe kernel, 8 input channels per LDS
+ *                     phase (16, 32: larger phases; + 64: two pixels per thread); 0: on the MFMA kernels
  *   "conv_wave", "conv_kc32", "conv_stagger", "unet_streams": see csrc/conv.hip, csrc/unet.cpp.
  * read_tuning_key(i) enumerates the keys (NULL past the end); read_tuning_get reads the current value, so that a
  * benchmark can record the state it ran with. */
@@ -240,6 +242,10 @@ typedef struct read_conv_desc {
      * `out`); rows r of a stacked batch with r % block_h >= valid_h are written as zeros (block_h = 0: one image). */
     float *out_gated;
     int block_h, valid_h;
+    const float *wpacked_sc;                /* optional: read_conv_pack_sc_host() output (device, 64-byte aligned): gated 3x3 / stride-1 launches
+                                               with Cin = 32, Cout <= 4 and one unshifted source (READ's output layer 32 -> 3) run on the
+                                               vector pipe — thread = pixel, weights streamed through SGPRs — instead of padding six output
+                                               rows to an MFMA shape; read_tuning_set("conv_sc", 0) switches it off, config = -6 forces it */
 } read_conv_desc;
 
 /* Sizes (in floats) of the packed weight / parameter blocks of one BasicConv. */
@@ -260,13 +266,17 @@ int read_conv_pack_w16_host(int Cin, int Cout, const float *wf, const float *wm,
  * [group][wave][chunk of 16 cin][frequency 36][lane][4] */
 size_t read_conv_w4_floats(int Cin, int Cout);
 int read_conv_pack_w4_host(int Cin, int Cout, const float *wf, const float *wm, float *wpacked_w4_host);
+/* Small-Cout order [tap][cin][f0 f1 f2 f3 | m0 m1 m2 m3] (9 * Cin * 8 floats; 0 = the shape has no such order: only Cin = 32,
+ * Cout <= 4 has a kernel). */
+size_t read_conv_sc_floats(int Cin, int Cout);
+int read_conv_pack_sc_host(int Cin, int Cout, const float *wf, const float *wm, float *wpacked_sc_host);
 int read_conv_pack_params_host(int Cout, const float *bf, const float *bm, const float *gamma,
                                const float *beta, const float *mean, const float *var, float eps,
                                float *params_host);
 int read_gated_conv_forward(const read_conv_desc *desc, void *stream);
 /* Which kernel family read_gated_conv_forward takes for this (filled) descriptor under the current tuning knobs: 4 = Winograd
- * F(4x4,3x3) (reads wpacked_w4), 2 = Winograd F(2x2,3x3) (reads wpacked_wino), 0 = direct implicit GEMM (reads wpacked); -1 =
- * NULL.  A host that packs ONE fragment order per layer asks this before packing (set the pointer it intends to fill to any
+ * F(4x4,3x3) (reads wpacked_w4), 2 = Winograd F(2x2,3x3) (reads wpacked_wino), 1 = vector-pipe small-Cout kernel (reads
+ * wpacked_sc), 0 = direct implicit GEMM (reads wpacked); -1 = NULL.  A host that packs ONE fragment order per layer asks this before packing (set the pointer it intends to fill to any
  * non-NULL value); a launch whose wpacked aliases Winograd fragments it would not read is refused with READ_EINVAL. */
 int read_conv_kernel_family(const read_conv_desc *desc);
 /* Number of compiled tile configurations and a printable name for each (for tuning sweeps). */

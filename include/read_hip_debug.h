@@ -26,6 +26,11 @@ int read_debug_operand_probe(int mode, int blocks, int iters, float *scratch, un
 int read_debug_issue_probe(int kind, int filler, int K, int blocks, int iters, float *scratch, unsigned long long *cycles,
                            const float *gsrc, void *stream);
 
+/* fp32 VALU rate probe: every wave issues iters * 64 instructions of one form over eight accumulators (mode 0 v_fma_f32, 1
+ * v_fmac_f32 with an SGPR multiplier, 2 v_pk_fma_f32, 3 v_pk_fma_f32 with an SGPR pair and a broadcast op_sel, 4 v_pk_add_f32, 5
+ * v_pk_mul_f32, 6 v_pk_fma_f32 with the F(4x4) transform's half-selects, 7 v_add_f32); cycles[blocks * 4] = s_memtime span per wave. */
+int read_debug_valu_probe(int mode, int blocks, int iters, float *scratch, unsigned long long *cycles, void *stream);
+
 /* Kernel boundary against grid barrier: `phases` dependent phases over `blocks` workgroups, each touching floats_per_block floats
  * of its slice of buf — mode 0 as dependent launches, mode 1 as one persistent launch with grid barriers (counter_and_flag: two
  * unsigned; [1] is set when a barrier gave up waiting). */

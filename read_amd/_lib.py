@@ -34,6 +34,7 @@ class ConvDesc(C.Structure):
         ("pre", C.c_void_p), ("pre_cstride", C.c_int), ("pre_f_off", C.c_int), ("pre_m_off", C.c_int),
         ("pre_shift", C.c_int), ("preH", C.c_int), ("preW", C.c_int),
         ("out_gated", C.c_void_p), ("block_h", C.c_int), ("valid_h", C.c_int),
+        ("wpacked_sc", C.c_void_p),
     ]
 
 
@@ -63,6 +64,7 @@ DEBUG_SIGNATURES = {
     "read_debug_set_trace": (_i, [_vp, _sz]),
     "read_debug_mfma_probe": (_i, [_i, _i, _i, _vp, _vp]),
     "read_debug_operand_probe": (_i, [_i, _i, _i, _vp, _vp, _vp]),
+    "read_debug_valu_probe": (_i, [_i, _i, _i, _vp, _vp, _vp]),
     "read_debug_issue_probe": (_i, [_i, _i, _i, _i, _i, _vp, _vp, _vp, _vp]),
     "read_debug_chain_probe": (_i, [_i, _i, _i, _i, _vp, _vp, _vp]),
 }
@@ -102,6 +104,8 @@ SIGNATURES = {
     "read_conv_pack_w4_host": (_i, [_i, _i, _vp, _vp, _vp]),
     "read_gated_conv_forward": (_i, [C.POINTER(ConvDesc), _vp]),
     "read_conv_kernel_family": (_i, [_vp]),
+    "read_conv_sc_floats": (_sz, [_i, _i]),
+    "read_conv_pack_sc_host": (_i, [_i, _i, _vp, _vp, _vp]),
     "read_conv_pack_job_prepare": (_i, [C.POINTER(PackJob)]),
     "read_conv_pack_batch": (_i, [_vp, _i, _i, _vp]),
     "read_conv_config_count": (_i, []),

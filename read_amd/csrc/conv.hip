@@ -42,6 +42,7 @@ struct ConvKArgs {
     const float *wp_wino;          // Winograd-transformed weights (read_conv_pack_wino_host) or null
     const float *wp_w16;           // the same weights in the order of the wave-autonomous kernel (read_conv_pack_w16_host) or null
     const float *wp_w4;            // Winograd F(4x4,3x3) weights (read_conv_pack_w4_host) or null
+    const float *wp_sc;            // [tap][cin][f0..f3 | m0..m3] of a layer with at most four output channels (read_conv_pack_sc_host) or null
     const float *params;
     const float *residual;
     float *out;
@@ -1940,6 +1941,149 @@ __global__ __launch_bounds__(256, 1) void gated_conv_wino4_kernel(const ConvKArg
 }
 
 // ------------------------------------------------------------------------------------------
+// 3x3 / stride-1 layers with at most FOUR output channels on the vector pipe (READ's output layer, feat_extract.5: 32 -> 3).
+//
+// The matrix cores have no shape for this layer: conv_f and conv_m together have 6 output channels — 6 rows of a 16- or 32-row
+// MFMA (the F(2x2) kernel ran it at 62 us with three of four waves skipping their MFMAs; a 16x16x4 tiling would spend 25 us
+// multiplying 10 rows of zeros).  On the vector pipe nothing is padded: thread = output pixel, COUT + COUT accumulators, and per
+// (tap, input channel) 2 COUT v_fmac_f32 whose multiplier sits in an SGPR — the weights are wave-uniform, stream through the
+// scalar cache ([tap][cin][f0..f3 m0..m3], two s_load_dwordx16 per four channels) and cost no vector register or LDS read.
+// 9 x 32 x 6 = 1728 FMAs per pixel at Cout = 3.
+//   * plain v_fmac_f32, not v_pk_fma_f32: tools/valu_probe.py measures 1.8 ns per wave-instruction per SIMD for the former and
+//     2.2 ns for the latter at 4 waves per SIMD — a packed FMA buys 1.16x the flops of a plain one, not 2x, and the fourth
+//     (padding) channel of a pair costs more than that;
+//   * workgroup = 8 x 32 output pixels; the 10 x 34 halo tile goes through LDS CPH input channels at a time (buffer loads: pixels
+//     outside the image carry an out-of-range offset and arrive as zeros — the zero padding), padded to CPH + 4 floats per pixel
+//     so that the 64 lanes' ds_read_b128 of a (tap, channel quad) hit all banks; 16 KiB at CPH = 8: all 1672 workgroups of a
+//     1216 x 352 frame are resident at once, and the next phase's loads are in flight under this phase's FMAs;
+//   * epilogue as everywhere (bias, ELU, sigmoid gate, BatchNorm scale / shift), RGBA-padded store with the fill value.
+// Measured (profiles/README.md, round 4): 45 us for the frame against 62 on the F(2x2) kernel.  Taking the parts out one at a time
+// (results invalid, timing only): scalar weight loads 12 us (61 MB through scalar caches shared between CUs), the tile's global
+// loads 17 us (73 MB with the halo), FMAs 10 us, LDS reads 3 us, and they add rather than overlap; two pixels per thread (half the
+// scalar traffic, PPT = 2) and larger phases (CPH = 16, 32) measured slower (50 .. 53 us and 48, 52 us).
+// ------------------------------------------------------------------------------------------
+template <int CIN, int CPH, int PPT, int COUT>
+__global__ __launch_bounds__(256) void gated_conv_smallc_kernel(const ConvKArgs a)
+{
+    // CPH = input channels per LDS phase; PPT = output pixels per thread (rows py + 8 r of an 8 PPT x 32 tile: the weights of a
+    // group are fetched once per wave and used PPT times); COUT = 3 or 4 accumulated channels per branch.
+    constexpr int TH = 8 * PPT, IH = TH + 2, IW = 34, PS = CPH + 4, Q4 = CPH / 4, NPH = CIN / CPH, QT = CIN / 4;
+    constexpr int NE = IH * IW * Q4, NI = (NE + 255) / 256;
+    __shared__ __attribute__((aligned(16))) float tile[IH * IW * PS];
+    const int tid = threadIdx.x;
+    const SrcDev s = a.src[0];
+    const int tx = blockIdx.x % a.tiles_x, ty = blockIdx.x / a.tiles_x;
+    const int y0 = ty * TH - 1, x0 = tx * 32 - 1;
+    constexpr unsigned OOR = 0x80000000u;
+    const auto rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(s.p), 0, (unsigned)(a.inH * s.W * s.C) * 4u, 0x00020000);
+    unsigned goff[NI];
+#pragma unroll
+    for (int i = 0; i < NI; ++i) {
+        const int e = tid + i * 256, q = e % Q4, pix = e / Q4, ppy = pix / IW, ppx = pix % IW;
+        const bool ok = (e < NE) & (y0 + ppy >= 0) & (y0 + ppy < a.inH) & (x0 + ppx >= 0) & (x0 + ppx < a.inW);
+        goff[i] = ok ? (unsigned)(((y0 + ppy) * s.W + x0 + ppx) * s.C + 4 * q) * 4u : OOR;
+    }
+    float4 st[NI];
+#pragma unroll
+    for (int i = 0; i < NI; ++i) st[i] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, goff[i], 0, 0));
+    const int py = tid >> 5, px = tid & 31;
+    const float *tp = tile + (py * IW + px) * PS;
+    // Weights: 32 floats per (tap, channel quad) = two s_load_dwordx16, requested one group AHEAD together with the next
+    // ds_read_b128 of pixel values.  Scalar loads return out of order, so the only usable wait is lgkmcnt(0): it sits at the head
+    // of a group and covers requests that have had the previous group's packed FMAs (and the other waves' turns) to land.
+    // hipcc does not pipeline scalar loads itself (it put every s_load directly in front of its first use, 288 exposed round
+    // trips per pixel), hence the asm; the loaded values pass through the wait's operand list and every statement of the loop is
+    // volatile, so the order below is the order issued.
+    typedef float f32x16 __attribute__((ext_vector_type(16)));
+    constexpr int NG = 9 * Q4;                                 // groups of a phase: (tap, quad of the phase)
+    const float *wbase = a.wp_sc;
+    float fa[PPT][4], ma[PPT][4];
+#pragma unroll
+    for (int r = 0; r < PPT; ++r)
+#pragma unroll
+        for (int c = 0; c < 4; ++c) fa[r][c] = ma[r][c] = 0.f;
+#pragma unroll
+    for (int ph = 0; ph < NPH; ++ph) {
+        if (ph) __syncthreads();                               // the previous phase's reads of the tile are done
+#pragma unroll
+        for (int i = 0; i < NI; ++i) {
+            const int e = tid + i * 256, q = e % Q4, pix = e / Q4;
+            if (e < NE) *reinterpret_cast<float4 *>(tile + pix * PS + 4 * q) = st[i];
+        }
+        if (ph + 1 < NPH) {
+#pragma unroll
+            for (int i = 0; i < NI; ++i)                        // OOR + anything stays out of range
+                st[i] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, goff[i], (ph + 1) * CPH * 4, 0));
+        }
+        f32x16 wa, wb;
+        asm volatile("s_load_dwordx16 %0, %1, %2" : "=&s"(wa) : "s"(wbase), "s"((ph * Q4) * 128));
+        asm volatile("s_load_dwordx16 %0, %1, %2" : "=&s"(wb) : "s"(wbase), "s"((ph * Q4) * 128 + 64));
+        __syncthreads();
+        f32x4 x[PPT];
+#pragma unroll
+        for (int r = 0; r < PPT; ++r) x[r] = *reinterpret_cast<const f32x4 *>(__builtin_assume_aligned(tp + r * 8 * IW * PS, 16));
+#pragma unroll
+        for (int g = 0; g < NG; ++g) {
+            if (PPT == 1) asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(wa), "+s"(wb), "+v"(x[0]));
+            else asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(wa), "+s"(wb), "+v"(x[0]), "+v"(x[PPT - 1]));
+            f32x16 na, nb;
+            f32x4 nx[PPT];
+            if (g + 1 < NG) {
+                const int tap = (g + 1) / Q4, q = (g + 1) % Q4;
+                const int wo = (tap * QT + ph * Q4 + q) * 128;
+                asm volatile("s_load_dwordx16 %0, %1, %2" : "=&s"(na) : "s"(wbase), "s"(wo));
+                asm volatile("s_load_dwordx16 %0, %1, %2" : "=&s"(nb) : "s"(wbase), "s"(wo + 64));
+#pragma unroll
+                for (int r = 0; r < PPT; ++r)
+                    nx[r] = *reinterpret_cast<const f32x4 *>(
+                        __builtin_assume_aligned(tp + ((r * 8 + tap / 3) * IW + tap % 3) * PS + 4 * q, 16));
+            }
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {                           // input channel of the quad; weights [f0 f1 f2 f3 m0 m1 m2 m3] each
+#pragma unroll
+                for (int j = 0; j < COUT; ++j) {
+                    const float wf = c < 2 ? wa[8 * (c & 1) + j] : wb[8 * (c & 1) + j];
+                    const float wm = c < 2 ? wa[8 * (c & 1) + 4 + j] : wb[8 * (c & 1) + 4 + j];
+#pragma unroll
+                    for (int r = 0; r < PPT; ++r) {
+                        asm volatile("v_fmac_f32 %0, %1, %2" : "+v"(fa[r][j]) : "s"(wf), "v"(x[r][c]));
+                        asm volatile("v_fmac_f32 %0, %1, %2" : "+v"(ma[r][j]) : "s"(wm), "v"(x[r][c]));
+                    }
+                }
+            }
+            if (g + 1 < NG) {
+                wa = na;
+                wb = nb;
+#pragma unroll
+                for (int r = 0; r < PPT; ++r) x[r] = nx[r];
+            }
+        }
+    }
+    const int ox = tx * 32 + px;
+#pragma unroll
+    for (int r = 0; r < PPT; ++r) {
+        const int oy = ty * TH + py + 8 * r;
+        if (oy >= a.outH || ox >= a.outW) continue;
+        float o[4];
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            float f = fa[r][c] + a.params[c];
+            const float m = ma[r][c] + a.params[a.CoutPad + c];
+            if (a.elu) f = elu1(f);
+            o[c] = c < a.Cout ? (f * sigmoidf(m)) * a.params[2 * a.CoutPad + c] + a.params[3 * a.CoutPad + c] : a.out_fill;
+        }
+        float *op = a.out + ((size_t)oy * a.outW + ox) * a.out_cstride;
+        if (a.out_cstride == 4 && (a.fill_pad || a.Cout == 4))
+            *reinterpret_cast<float4 *>(op) = make_float4(o[0], o[1], o[2], o[3]);
+        else {
+#pragma unroll
+            for (int c = 0; c < 4; ++c)
+                if (c < a.Cout || (a.fill_pad && c < a.out_cstride)) op[c] = o[c];
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------
 // 1x1 layers in the "pixel-lane" orientation: weights are the MFMA A operand, activations the B operand.
 //
 //   D[cout][pixel] = sum_k W[cout][k] * X[k][pixel]        (v_mfma_f32_32x32x2_f32: lane = pixel, registers = channels)
@@ -2225,6 +2369,7 @@ int g_kc32 = 1;            // 32-channel chunks for 1x1 layers whose sources are
 int g_use_wino = 1 << 30;  // read_tuning_set("conv_wino", max Cin): Winograd kernel for eligible 3x3 layers (0 = off)
 int g_w4_grid = 0;        // read_tuning_set("conv_w4_grid", 1): F(4x4) launches with the same number of units per workgroup (measured: see profiles)
 int g_w4 = 32;             // read_tuning_set("conv_w4", min Cin): layers with at least this many channels take the Winograd F(4x4,3x3)
+int g_sc = 8;              // read_tuning_set("conv_sc", 0): the output layer (Cout <= 4) back on the F(2x2) MFMA kernel instead of the vector pipe; other values: conv_set_sc
                            // kernel when its weights were supplied (0 = never)
 int g_abl = 0;             // read_tuning_set("conv_abl", bits): attribution probes of the 16x16x4 Winograd kernels (results invalid); -DREAD_DEBUG_KNOBS builds only
 int g_w16 = 0;             // read_tuning_set("conv_w16", v): F(2x2,3x3) launches: 0 the row-per-wave kernel (default: measured equal or faster),
@@ -2458,6 +2603,25 @@ extern "C" int read_conv_pack_w4_host(int Cin, int Cout, const float *wf, const 
     return READ_OK;
 }
 
+// Small-Cout order (gated_conv_smallc_kernel): [tap][cin][f0 f1 f2 f3 | m0 m1 m2 m3], channels >= Cout zero.
+extern "C" size_t read_conv_sc_floats(int Cin, int Cout)
+{
+    return (Cin == 32 && Cout >= 1 && Cout <= 4) ? (size_t)9 * Cin * 8 : 0;      // the kernel is instantiated for 32 input channels
+}
+
+extern "C" int read_conv_pack_sc_host(int Cin, int Cout, const float *wf, const float *wm, float *out)
+{
+    READ_CHECK_ARG(wf && wm && out, "read_conv_pack_sc_host: null pointer");
+    READ_CHECK_ARG(read_conv_sc_floats(Cin, Cout) > 0, "read_conv_pack_sc_host: needs Cin == 32 and 1 <= Cout <= 4 (got %d, %d)", Cin, Cout);
+    for (int tap = 0; tap < 9; ++tap)
+        for (int ci = 0; ci < Cin; ++ci)
+            for (int j = 0; j < 8; ++j) {
+                const int co = j & 3;
+                out[((size_t)tap * Cin + ci) * 8 + j] = co < Cout ? ((j >> 2) ? wm : wf)[((size_t)co * Cin + ci) * 9 + tap] : 0.0f;
+            }
+    return READ_OK;
+}
+
 extern "C" int read_conv_pack_params_host(int Cout, const float *bf, const float *bm, const float *gamma,
                                           const float *beta, const float *mean, const float *var, float eps,
                                           float *params_host)
@@ -2490,12 +2654,14 @@ void conv_set_w4(int v) { g_w4 = v < 0 ? 0 : v; }
 void conv_set_w4_grid(int v) { g_w4_grid = v != 0; }
 void conv_set_wino_wgs(int v) { g_wino_wgs = v <= 1 ? 1 : 2; }
 void conv_set_px(int v) { g_conv_px = v < 0 ? 0 : v > 4 ? 4 : v; }
+void conv_set_sc(int v) { g_sc = v; }           // 0 off; 8 / 16 / 32 = input channels per LDS phase; 64 + 8: two pixels per thread
 int conv_get(const char *key, int *value)
 {
     if (!strcmp(key, "conv_wave")) *value = g_prefer_wave;
     else if (!strcmp(key, "conv_stagger")) *value = g_stagger_ticks;
     else if (!strcmp(key, "conv_kc32")) *value = g_kc32;
     else if (!strcmp(key, "conv_px")) *value = g_conv_px;
+    else if (!strcmp(key, "conv_sc")) *value = g_sc;
     else if (!strcmp(key, "conv_wino_wgs")) *value = g_wino_wgs;
     else if (!strcmp(key, "conv_wino")) *value = g_use_wino;
     else if (!strcmp(key, "conv_w16")) *value = g_w16;
@@ -2521,6 +2687,7 @@ void conv_set_trace(void *buf, size_t bytes)
 // entry point and the UNet executor.
 int conv_uses_wino(const read_conv_desc *d);
 int conv_uses_w4(const read_conv_desc *d);
+int conv_uses_sc(const read_conv_desc *d);
 
 int launch_gated_conv(const read_conv_desc *d, hipStream_t stream)
 {
@@ -2609,6 +2776,28 @@ int launch_gated_conv(const read_conv_desc *d, hipStream_t stream)
     a.ablate = g_ablate;
     a.fill_pad = d->fill_pad;
     a.out_fill = d->out_fill;
+
+    // ---- at most four output channels, 3x3 / stride 1: the vector-pipe kernel (config -6 forces it)
+    a.wp_sc = d->wpacked_sc;
+    READ_CHECK_ARG(d->config != -6 || conv_uses_sc(d), "read_gated_conv_forward: the small-Cout kernel takes gated 3x3/s1 layers with "
+                   "Cin = 32, Cout <= 4, one unshifted source and wpacked_sc");
+    if (conv_uses_sc(d)) {
+        READ_CHECK_ARG((uintptr_t)d->wpacked_sc % 64 == 0 && (uintptr_t)d->src[0].data % 16 == 0, "read_gated_conv_forward: wpacked_sc / source misaligned");
+        a.tiles_x = ceil_div(outW, 32);
+        const int ppt = (g_sc & 64) ? 2 : 1, cph = g_sc & 63;       // knob: channels per LDS phase, + 64 = two pixels per thread
+        const dim3 grid((unsigned)(a.tiles_x * ceil_div(outH, 8 * ppt)));
+        const bool c3 = d->Cout <= 3;
+#define SC_LAUNCH(CPH, PPT) \
+        do { if (c3) hipLaunchKernelGGL((gated_conv_smallc_kernel<32, CPH, PPT, 3>), grid, dim3(256), 0, stream, a); \
+             else hipLaunchKernelGGL((gated_conv_smallc_kernel<32, CPH, PPT, 4>), grid, dim3(256), 0, stream, a); } while (0)
+        if (ppt == 2) SC_LAUNCH(8, 2);
+        else if (cph == 32) SC_LAUNCH(32, 1);
+        else if (cph == 16) SC_LAUNCH(16, 1);
+        else SC_LAUNCH(8, 1);
+#undef SC_LAUNCH
+        READ_CHECK_LAUNCH();
+        return READ_OK;
+    }
 
     // ---- 1x1 layers: the pixel-lane kernel (config -2 forces it, -1 takes it whenever the layer qualifies)
     {
@@ -2847,6 +3036,16 @@ int conv_uses_w4(const read_conv_desc *d)
     return shape && (d->config == -5 || (d->config == -1 && g_w4 > 0 && d->src[0].C >= g_w4));
 }
 
+// gated 3x3 / stride-1 layers with at most four output channels and 32 input channels (READ's output layer)
+int conv_uses_sc(const read_conv_desc *d)
+{
+    const bool shape = d->ksize == 3 && d->stride == 1 && d->n_src == 1 && d->src[0].shift == 0 && d->src[0].C == 32 && d->Cout >= 1 &&
+                       d->Cout <= 4 && !d->linear && !d->residual && !d->pre && !d->mul && d->wpacked_sc &&
+                       (d->out_cstride != 4 || (uintptr_t)d->out % 16 == 0) &&
+                       (long long)d->src[0].srcH * d->src[0].srcW * d->src[0].C * 4 < (1ll << 31);
+    return shape && (d->config == -6 || (d->config == -1 && g_sc));
+}
+
 int conv_kc_for(const read_conv_desc *d)
 {
     int kc = 16;
@@ -2860,6 +3059,7 @@ int conv_kc_for(const read_conv_desc *d)
 extern "C" int read_conv_kernel_family(const read_conv_desc *desc)
 {
     if (!desc) return -1;
+    if (readhip::conv_uses_sc(desc)) return 1;
     if (readhip::conv_uses_w4(desc)) return 4;
     if (readhip::conv_uses_wino(desc)) return 2;
     return 0;

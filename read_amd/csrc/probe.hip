@@ -250,6 +250,55 @@ extern "C" int read_debug_mfma_probe(int blocks, int iters, int nacc, float *scr
 }
 
 
+namespace {
+// ---- fp32 VALU rate probe: what does ONE vector instruction of each form cost a wave?  Eight independent accumulators, 64
+// instructions per round, nothing else in the loop.  MODE 0 v_fma_f32 (registers) · 1 v_fmac_f32 with an SGPR multiplier · 2
+// v_pk_fma_f32 (register pairs, default selects) · 3 v_pk_fma_f32 with an SGPR pair and a broadcast op_sel (the first form of the
+// small-Cout kernel) · 4 v_pk_add_f32 · 5 v_pk_mul_f32 · 6 v_pk_fma_f32 with the half-selects of the F(4x4) input transform ·
+// 7 v_add_f32.
+typedef float floatx2p __attribute__((ext_vector_type(2)));
+template <int MODE>
+__global__ __launch_bounds__(256) void valu_probe_kernel(float *out, unsigned long long *cycles, int iters, float sw0, float sw1)
+{
+    floatx2p acc[8], xv = {0.001f * threadIdx.x, 1.0f - 0.002f * threadIdx.x}, wv = {0.999f, 1.001f};
+    const floatx2p ws = {sw0, sw1};                                   // kernel arguments: wave-uniform, live in SGPRs
+#pragma unroll
+    for (int i = 0; i < 8; ++i) acc[i] = floatx2p{0.01f * i, 0.02f * i + threadIdx.x};
+    const unsigned long long t0 = __builtin_amdgcn_s_memtime();
+    for (int it = 0; it < iters; ++it) {
+#pragma unroll
+        for (int m = 0; m < 64; ++m) {
+            floatx2p &A = acc[m & 7];
+            if (MODE == 0) asm volatile("v_fma_f32 %0, %1, %2, %0" : "+v"(A.x) : "v"(xv.x), "v"(wv.x));
+            else if (MODE == 1) asm volatile("v_fmac_f32 %0, %1, %2" : "+v"(A.x) : "s"(sw0), "v"(xv.x));
+            else if (MODE == 2) asm volatile("v_pk_fma_f32 %0, %1, %2, %0" : "+v"(A) : "v"(xv), "v"(wv));
+            else if (MODE == 3) asm volatile("v_pk_fma_f32 %0, %1, %2, %0 op_sel:[0,0,0] op_sel_hi:[0,1,1]" : "+v"(A) : "v"(xv), "s"(ws));
+            else if (MODE == 4) asm volatile("v_pk_add_f32 %0, %0, %1" : "+v"(A) : "v"(wv));
+            else if (MODE == 5) asm volatile("v_pk_mul_f32 %0, %0, %1" : "+v"(A) : "v"(wv));
+            else if (MODE == 6) asm volatile("v_pk_fma_f32 %0, %1, %2, %0 op_sel:[0,1,0] op_sel_hi:[1,1,1]" : "+v"(A) : "v"(xv), "v"(wv));
+            else asm volatile("v_add_f32 %0, %0, %1" : "+v"(A.x) : "v"(wv.x));
+        }
+    }
+    const unsigned long long t1 = __builtin_amdgcn_s_memtime();
+    float ssum = 0.f;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) ssum += acc[i].x + acc[i].y;
+    if ((threadIdx.x & 63) == 0) cycles[blockIdx.x * 4 + (threadIdx.x >> 6)] = t1 - t0;
+    if (ssum == 123.456f) out[blockIdx.x * 256 + threadIdx.x] = ssum;
+}
+}  // namespace
+
+extern "C" int read_debug_valu_probe(int mode, int blocks, int iters, float *scratch, unsigned long long *cycles, void *stream)
+{
+    READ_CHECK_ARG(blocks > 0 && iters > 0 && scratch && cycles && mode >= 0 && mode <= 7, "read_debug_valu_probe: bad arguments");
+    hipStream_t s = as_stream(stream);
+#define VP_CASE(m) case m: hipLaunchKernelGGL(valu_probe_kernel<m>, dim3(blocks), dim3(256), 0, s, scratch, cycles, iters, 0.9995f, 1.0005f); break;
+    switch (mode) { VP_CASE(0) VP_CASE(1) VP_CASE(2) VP_CASE(3) VP_CASE(4) VP_CASE(5) VP_CASE(6) VP_CASE(7) }
+#undef VP_CASE
+    READ_CHECK_LAUNCH();
+    return READ_OK;
+}
+
 // ---------------------------------------------------------------------------------------------------------------------
 // What a kernel boundary costs against a grid-wide barrier inside one persistent kernel (the rasteriser's five dependent
 // launches: are they worth merging?).  Every "phase" touches `bytes_per_block` of its workgroup's slice of a buffer (read-modify-

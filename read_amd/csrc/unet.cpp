@@ -32,6 +32,7 @@ struct LayerInfo {
     size_t wino_off;                // Winograd-transformed weights of 3x3/s1 layers with Cin % 16 == 0, else NO_WINO
     size_t w16_off;                 // ... in the order of the wave-autonomous Winograd kernel (read_conv_pack_w16_host)
     size_t w4_off;                  // Winograd F(4x4,3x3) weights of the 3x3/s1 layers with Cin >= 32 and Cout % 32 == 0, else NO_WINO
+    size_t sc_off = ~(size_t)0;     // small-Cout order of the 3x3/s1 layers with Cout <= 4 (the output layer), else NO_WINO
 };
 constexpr size_t NO_WINO = ~(size_t)0;
 
@@ -95,6 +96,11 @@ Arch build_arch(int layout)
             if (w4 && !(lean && unused)) {
                 L.w4_off = a.packed_floats;
                 a.packed_floats += read_conv_w4_floats(cin, cout);
+            }
+            if (k == 3 && s == 1 && read_conv_sc_floats(cin, cout) && !(lean && unused)) {
+                a.packed_floats = (a.packed_floats + 15) / 16 * 16;     // 64-byte aligned: scalar loads of 16 dwords
+                L.sc_off = a.packed_floats;
+                a.packed_floats += read_conv_sc_floats(cin, cout);
             }
             a.layers.push_back(L);
         };
@@ -257,7 +263,7 @@ struct Builder {
     };
     struct LayerRef {
         int cin, cout, k, stride, elu;
-        size_t w_off, p_off, wino_off, w16_off, w4_off;
+        size_t w_off, p_off, wino_off, w16_off, w4_off, sc_off;
     };
 
     // One BasicConv.  srcs = {tensor id, shift}; out tensor must already exist.
@@ -266,7 +272,7 @@ struct Builder {
     {
         const Arch &A = arch(u->layout);
         const LayerInfo &L = A.layers[A.find(path)];
-        emit(path, LayerRef{L.cin, L.cout, L.k, L.stride, L.elu, L.w_off, L.p_off, L.wino_off, L.w16_off, L.w4_off}, srcs, out_t, mul_t, res_t, 0,
+        emit(path, LayerRef{L.cin, L.cout, L.k, L.stride, L.elu, L.w_off, L.p_off, L.wino_off, L.w16_off, L.w4_off, L.sc_off}, srcs, out_t, mul_t, res_t, 0,
              PreRef());
     }
     // A derived 1x1 layer (DerivedInfo): `linear` ones store the pre-activations [f | m] for a finer level to add,
@@ -276,7 +282,7 @@ struct Builder {
         const Arch &A = arch(u->layout);
         const DerivedInfo &D = A.derived[A.find_derived(name)];
         const LayerInfo &P0 = A.layers[D.parts[0]];
-        emit(name, LayerRef{D.cin, D.cout, 1, 1, P0.elu, D.w_off, linear ? D.p_off : P0.p_off, NO_WINO, NO_WINO, NO_WINO}, srcs, out_t, -1, -1,
+        emit(name, LayerRef{D.cin, D.cout, 1, 1, P0.elu, D.w_off, linear ? D.p_off : P0.p_off, NO_WINO, NO_WINO, NO_WINO, NO_WINO}, srcs, out_t, -1, -1,
              linear, pre);
     }
 
@@ -317,6 +323,7 @@ struct Builder {
         op.d.wpacked_wino = L.wino_off != NO_WINO ? u->packed + L.wino_off : nullptr;
         op.d.wpacked_w16 = L.w16_off != NO_WINO ? u->packed + L.w16_off : nullptr;
         op.d.wpacked_w4 = L.w4_off != NO_WINO ? u->packed + L.w4_off : nullptr;
+        op.d.wpacked_sc = L.sc_off != NO_WINO ? u->packed + L.sc_off : nullptr;
         op.d.mul = mul_t >= 0 ? u->tensors[mul_t].p : nullptr;
         op.d.residual = res_t >= 0 ? u->tensors[res_t].p : nullptr;
         op.d.out = o.p;
@@ -606,6 +613,10 @@ extern "C" int read_unet_pack_host_layout(const float *raw, float bn_eps, float 
         }
         if (L.w4_off != NO_WINO) {
             rc = read_conv_pack_w4_host(L.cin, L.cout, wf, wm, packed + L.w4_off);
+            if (rc) return rc;
+        }
+        if (L.sc_off != NO_WINO) {
+            rc = read_conv_pack_sc_host(L.cin, L.cout, wf, wm, packed + L.sc_off);
             if (rc) return rc;
         }
     }

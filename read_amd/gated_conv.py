@@ -34,7 +34,12 @@ class PackedGatedConv:
                                                 pp.ctypes.data), "read_conv_pack_params_host")
         self.wpacked = torch.from_numpy(wp).to(device)
         self.params = torch.from_numpy(pp).to(device)
-        self.wpacked_wino = self.wpacked_w16 = self.wpacked_w4 = None
+        self.wpacked_wino = self.wpacked_w16 = self.wpacked_w4 = self.wpacked_sc = None
+        if self.k == 3 and L.read_conv_sc_floats(self.cin, self.cout):      # small-Cout order for the vector-pipe kernel (Cout <= 4)
+            sc = np.empty(L.read_conv_sc_floats(self.cin, self.cout), np.float32)
+            _lib.check(L.read_conv_pack_sc_host(self.cin, self.cout, wf.ctypes.data, wm.ctypes.data, sc.ctypes.data),
+                       "read_conv_pack_sc_host")
+            self.wpacked_sc = torch.from_numpy(sc).to(device)
         if self.k == 3 and self.cin % 16 == 0:        # Winograd F(2x2,3x3) operand for the 3x3/s1 kernel variant
             ww = np.empty(L.read_conv_wino_floats(self.cin, self.cout), np.float32)
             _lib.check(L.read_conv_pack_wino_host(self.cin, self.cout, wf.ctypes.data, wm.ctypes.data, ww.ctypes.data),
@@ -87,6 +92,7 @@ def gated_conv(packed, sources, stride=1, elu=True, mul=None, residual=None, con
     d.wpacked_wino = packed.wpacked_wino.data_ptr() if packed.wpacked_wino is not None else None
     d.wpacked_w16 = packed.wpacked_w16.data_ptr() if packed.wpacked_w16 is not None else None
     d.wpacked_w4 = packed.wpacked_w4.data_ptr() if packed.wpacked_w4 is not None else None
+    d.wpacked_sc = packed.wpacked_sc.data_ptr() if packed.wpacked_sc is not None else None
     d.linear = 1 if linear else 0
     if pre is not None:
         pt, f_off, m_off, psh = pre

@@ -76,7 +76,7 @@ def layout_of(packed):
 def pack_state(state, eps=BN_EPS, layout=LAYOUT_FULL):
     """state dict -> packed fp32 blob (host ndarray) in MFMA fragment order with folded BatchNorm."""
     raw = raw_blob_from_state(state)
-    packed = np.empty(_lib.lib().read_unet_packed_floats_layout(layout), np.float32)
+    packed = np.zeros(_lib.lib().read_unet_packed_floats_layout(layout), np.float32)     # zeros: the blob has alignment gaps
     _lib.check(_lib.lib().read_unet_pack_host_layout(raw.ctypes.data, eps, packed.ctypes.data, layout), "read_unet_pack_host")
     return packed
 

@@ -93,6 +93,27 @@ def test_weight_packing_layout():
         assert L.read_conv_pack_weights_host(cin, cout, k, 16 if cin % 16 else 8 if cin % 8 else 16, None, None, None) == -22
 
 
+def test_small_cout_weight_order():
+    """read_conv_pack_sc_host: out[(tap * Cin + cin) * 8 + j] = Wf[j][cin][tap] (j < 4) | Wm[j - 4][cin][tap], channels >= Cout zero
+    (the vector-pipe kernel of the 32 -> 3 output layer reads it with scalar loads); only Cin = 32, Cout <= 4 have the order."""
+    L = _lib.lib()
+    rng = np.random.default_rng(4)
+    assert L.read_conv_sc_floats(32, 3) == 9 * 32 * 8 == L.read_conv_sc_floats(32, 4) and L.read_conv_sc_floats(32, 1) == 9 * 32 * 8
+    assert L.read_conv_sc_floats(32, 5) == 0 and L.read_conv_sc_floats(64, 3) == 0 and L.read_conv_sc_floats(16, 3) == 0
+    for cout in (1, 3, 4):
+        wf = rng.standard_normal((cout, 32, 3, 3)).astype(np.float32)
+        wm = rng.standard_normal((cout, 32, 3, 3)).astype(np.float32)
+        out = np.full(9 * 32 * 8, np.nan, np.float32)
+        _lib.check(L.read_conv_pack_sc_host(32, cout, wf.ctypes.data, wm.ctypes.data, out.ctypes.data))
+        o = out.reshape(9, 32, 2, 4)
+        want = np.zeros((9, 32, 2, 4), np.float32)
+        want[:, :, 0, :cout] = wf.reshape(cout, 32, 9).transpose(2, 1, 0)
+        want[:, :, 1, :cout] = wm.reshape(cout, 32, 9).transpose(2, 1, 0)
+        assert np.array_equal(o, want)
+    assert L.read_conv_pack_sc_host(32, 5, None, None, None) == -22
+    assert L.read_conv_pack_sc_host(32, 3, None, None, None) == -22
+
+
 def test_param_packing_folds_batchnorm():
     L = _lib.lib()
     rng = np.random.default_rng(1)
@@ -181,7 +202,7 @@ def test_release_library_has_no_debug_entry_points():
     txt = open(os.path.join(ROOT, "include", "read_hip_debug.h")).read()
     txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
     names = sorted(set(re.findall(r"\b(read_debug_[a-z0-9_]+)\s*\(", txt)))
-    assert names == sorted(_lib.DEBUG_SIGNATURES) and len(names) == 5
+    assert names == sorted(_lib.DEBUG_SIGNATURES) and len(names) == 6
     for n in names:
         assert not hasattr(L, n), f"{n} is exported by the release library"
     assert not any(n.startswith("read_debug") for n in _declared_symbols())

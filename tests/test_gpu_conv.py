@@ -262,6 +262,43 @@ def test_rgba_output_fill(hip):
     assert bool((got[:, :, 3] == 1.0).all())
 
 
+def test_small_cout_vector_pipe_kernel(hip):
+    """The 32 -> 3 output layer (READ/models/unet.py:205 feat_extract[5]) on the vector pipe (config=-6 forces it; knob conv_sc
+    A/B): ragged image (partial 8x32 tiles in x and y), Cout 1..4, elu on and off, the RGBA fill, against torch and against the
+    MFMA kernel it replaces (same tolerance: a 288-long fp32 dot product in another order)."""
+    from read_amd import _lib
+    L = _lib.lib()
+    torch.manual_seed(17)
+    for (H, W) in ((16, 32), (21, 45), (8, 96)):
+        for cout in (3, 4, 1):
+            for elu in (False, True):
+                st = _state(32, cout, 3, seed=cout + H)
+                x = torch.randn(32, H, W)
+                ref = unet_torch.basic_conv(st, "L", x[None], 3, elu=elu)[0]
+                pk = _pack(st, [32])
+                got = gated_conv(pk, [(_nhwc(x), 0)], elu=elu, config=-6)
+                _close(got, ref, f"small-Cout {H}x{W} cout={cout} elu={elu}")
+    st = _state(32, 3, 3, seed=9)
+    x = torch.randn(32, 24, 64)
+    ref = unet_torch.basic_conv(st, "L", x[None], 3, elu=False)[0]
+    pk = _pack(st, [32])
+    try:
+        frames = {}
+        for on in (8, 16, 32, 64 + 8, 0):                                # channels per LDS phase (+ 64: two pixels per thread); 0 = the MFMA kernel
+            _lib.check(L.read_tuning_set(b"conv_sc", on))
+            d_family = gated_conv(pk, [(_nhwc(x), 0)], elu=False, out_channels=4, fill=1.0)
+            frames[on] = d_family
+            _close(d_family[:, :, :3].contiguous(), ref, f"rgb conv_sc={on}")
+            assert bool((d_family[:, :, 3] == 1.0).all())
+        for other in (16, 32, 72, 0):                                        # another order of the same 288 products per channel
+            assert float((frames[8] - frames[other]).abs().max()) <= 2e-5 * 4
+    finally:
+        _lib.check(L.read_tuning_set(b"conv_sc", 8))
+    with pytest.raises(_lib.ReadHipError):                               # wide layers do not qualify
+        st = _state(32, 32, 3, seed=1)
+        gated_conv(_pack(st, [32]), [(_nhwc(torch.randn(32, 8, 32)), 0)], config=-6)
+
+
 def test_bilinear_up4(hip):
     x = torch.randn(64, 6, 10)
     ref = F.interpolate(x[None], scale_factor=4, mode="bilinear", align_corners=False)[0]

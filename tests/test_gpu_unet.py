@@ -188,28 +188,37 @@ def test_pipelined_frames_through_the_rccl_exchange(hip):
 
 
 def test_winograd_and_direct_conv_paths_agree(hip):
-    """The automatic plan runs the 3x3/s1 layers through the Winograd F(2x2,3x3) kernel; with the knob off the
-    same layers run the direct implicit-GEMM kernel.  Both must meet the tolerance against the oracle, and they
-    must differ in round-off (i.e. the knob really switches kernels)."""
+    """The automatic plan runs the 3x3/s1 C -> C layers through the Winograd F(4x4,3x3) kernel and the 32 -> 3 output layer on
+    the vector pipe; with conv_w4 = 0 the same layers take the Winograd F(2x2,3x3) kernel, and with conv_wino = conv_sc = 0 as
+    well the direct implicit-GEMM kernel (from the FULL weight blob: the lean one carries only the automatic plan's orders).
+    All three must meet the tolerance against the oracle, and they must differ in round-off (the knobs really switch kernels)."""
     from read_amd import _lib
+    from read_amd.unet import LAYOUT_FULL
     torch.manual_seed(3)
     state = synthetic.make_unet_state(UNET_SPEC, 9)
     net = UNet()
     net.load_state_dict({k: torch.from_numpy(np.asarray(v)) for k, v in state.items()})
     net.cuda().eval()
+    net.__dict__['_layout'] = LAYOUT_FULL
     xs = [torch.rand(1, 8, 128 >> l, 192 >> l) for l in range(5)]
     ref = unet_torch.unet_forward(state, *xs[:4])
     outs = {}
+    L = _lib.lib()
     try:
-        for name, knob in (("winograd", 1 << 30), ("direct", 0)):
-            _lib.check(_lib.lib().read_tuning_set(b"conv_wino", knob))
+        for name, (w4, wino, sc) in (("automatic", (32, 1 << 30, 8)), ("winograd F(2x2)", (0, 1 << 30, 8)), ("direct", (0, 0, 0))):
+            _lib.check(L.read_tuning_set(b"conv_w4", w4))
+            _lib.check(L.read_tuning_set(b"conv_wino", wino))
+            _lib.check(L.read_tuning_set(b"conv_sc", sc))
             with torch.no_grad():
                 outs[name] = net(*[x.cuda() for x in xs]).cpu()
             _check_rgb(outs[name], ref, name)
     finally:
-        _lib.check(_lib.lib().read_tuning_set(b"conv_wino", 1 << 30))
-    assert not torch.equal(outs["winograd"], outs["direct"])
-    assert float((outs["winograd"] - outs["direct"]).abs().max()) <= 2 * MAX_ABS
+        _lib.check(L.read_tuning_set(b"conv_w4", 32))
+        _lib.check(L.read_tuning_set(b"conv_wino", 1 << 30))
+        _lib.check(L.read_tuning_set(b"conv_sc", 8))
+    for a, b in (("automatic", "winograd F(2x2)"), ("winograd F(2x2)", "direct"), ("automatic", "direct")):
+        assert not torch.equal(outs[a], outs[b]), (a, b)
+        assert float((outs[a] - outs[b]).abs().max()) <= 2 * MAX_ABS
 
 
 def test_headline_frame_1216x352_vs_oracle(hip):

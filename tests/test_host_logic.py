@@ -63,6 +63,8 @@ def test_aff_weight_blocks_in_the_packed_blob():
             off += 2 * L.read_conv_wino_floats(cin, cout)                  # 3x3 / stride-1 layers carry G g G^T as well, in the
             if cin >= 32 and cout % 32 == 0:                               # orders of both F(2x2) kernels, and the F(4x4) fragments
                 off += L.read_conv_w4_floats(cin, cout)
+        if L.read_conv_sc_floats(cin, cout) and k == 3:                    # the 32 -> 3 layer: the vector-pipe order, 64-byte aligned
+            off = (off + 15) // 16 * 16 + L.read_conv_sc_floats(cin, cout)
     derived = [("AFFq3", 224, 256, (0, 1, 2)), ("AFFq2", 96, 128, (0, 1)), ("AFFq1", 32, 64, (0,)),
                ("AFFs.0.conv.0r", 0, 32, (0,)), ("AFFs.1.conv.0r", 0, 96, (1,)), ("AFFs.2.conv.0r", 0, 224, (2,))]
     rng = np.random.default_rng(5)

@@ -4,7 +4,9 @@ change can silently lose — found in the ISA, not in any test result (DESIGN.md
   * the Winograd F(4x4,3x3) inference kernels keep their cross-unit pipeline: no `s_waitcnt vmcnt(0)` at the head of the unit
     loop (a second path through the epilogue once put one there: -1.8 % frames/s), no scratch, one wave per SIMD's registers;
   * the wgrad kernel's ring of five is counted by the compiler: `vmcnt(40)` in front of its MFMA groups, not a drain;
-  * the whole-quad 1x1 pixel-lane kernel waits for `vmcnt(3)` in front of its MFMA groups.
+  * the whole-quad 1x1 pixel-lane kernel waits for `vmcnt(3)` in front of its MFMA groups;
+  * the small-Cout vector-pipe kernel keeps its software-pipelined scalar weight loads: 1728 v_fmac_f32 with SGPR multipliers per
+    pixel, 144 s_load_dwordx16 issued one group ahead, no scratch.
 """
 import os
 import re
@@ -73,3 +75,21 @@ def test_training_kernels_count_their_loads(conv_asm, tmp_path_factory):
 def test_pixel_lane_kernel_prefetches(conv_asm):
     _, body = _function(conv_asm, "gated_conv_px_kernelILi1ELi2ELb1E")
     assert len(re.findall(r"s_waitcnt vmcnt\(3\)[^\n]*\n\s*v_mfma_f32_32x32x2_f32", body)) >= 4
+
+
+def test_small_cout_kernel_streams_weights_through_sgprs(conv_asm):
+    name, body = _function(conv_asm, "gated_conv_smallc_kernelILi32ELi8ELi1ELi3E")
+    assert _meta(conv_asm, name, "private_seg_size") == 0
+    assert _meta(conv_asm, name, "num_vgpr") <= 64                          # eight waves per SIMD
+    fmacs = re.findall(r"v_fmac_f32 v\d+, s\d+, v\d+", body)
+    assert len(fmacs) == 9 * 32 * 6, len(fmacs)
+    assert body.count("s_load_dwordx16") == 144
+    lines = [l.strip() for l in body.split("\n") if l.strip() and not l.strip().startswith(";")]
+    # a weight request is followed by the FMAs of the PREVIOUS group before anything waits for it — except the first group of
+    # each of the four LDS phases
+    exposed = 0
+    for i, l in enumerate(lines):
+        if l.startswith("s_load_dwordx16"):
+            nxt = [x for x in lines[i + 1:i + 8] if not x.startswith(("s_movk_i32", "s_mov_b32", "s_load_dwordx16"))]
+            exposed += nxt[0].startswith("s_waitcnt lgkmcnt")
+    assert exposed <= 4 + 2, exposed                                        # + the kernel-argument loads at entry
