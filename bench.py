@@ -507,7 +507,8 @@ def run_train(a, dev, street=None, steps=None, warm=None, cpu_timing=True, do_ve
     algorithmic = 3.0 * fwd_flops / (dt / steps) / 1e12            # forward + dgrad + wgrad, direct-convolution count
     # the flops the step's launches EXECUTE (the convention of the headline's roofline.frac): one instrumented step logs every
     # convolution launch with the kernel family the library takes for it (read_conv_kernel_family) — F(4x4,3x3) executes 1/4
-    # of the direct count, F(2x2,3x3) 1/2.25, direct kernels / wgrad all of it (padded channels and dilated dgrads included)
+    # of the direct count, F(2x2,3x3) 1/2.25, the Winograd-domain wgrad 1/4, direct kernels all of it (padded channels and
+    # dilated dgrads included)
     from read_amd import train as _train
     step_path = _train.LAST_STEP_PATH                              # 'graph': the timed steps replayed the captured HIP graphs
     _train.FLOP_LOG, graph_was = [], _train.GRAPH_TRAIN
@@ -539,9 +540,12 @@ def run_train(a, dev, street=None, steps=None, warm=None, cpu_timing=True, do_ve
                         "winograd_f4_launches": sum(1 for (_, _, f_) in log if f_ == 4),
                         "winograd_f2_launches": sum(1 for (_, _, f_) in log if f_ == 2),
                         "note": "achieved = MFMA flops the step's convolution launches EXECUTE (forward pre-activations and "
-                                "dgrad on the Winograd kernels at 1/4 or 1/2.25 of the direct count, wgrad direct) / wall time of "
-                                "a step, the headline's convention; frac_algorithmic = 3 x SURVEY 8d's forward count / wall time"},
-           "host_enqueue_ms_per_step": 1e3 * dt_host / steps,      # close to ms_per_step = the step is bound by the host side
+                                "dgrad on the Winograd kernels at 1/4 or 1/2.25 of the direct count; the 3x3/s1 weight gradients "
+                                "in the Winograd F(4x4,3x3) domain at 1/4, the others direct) / wall time of a step, the "
+                                "headline's convention; frac_algorithmic = 3 x SURVEY 8d's forward count / wall time"},
+           # host time inside the step's calls WITHOUT a sync: includes waiting for room in the launch queue — the Python / launch
+           # path itself costs 17.5 ms per step (tools/train_host_probe.py: the same at 32 x 32 crops), the step is device-bound
+           "host_enqueue_ms_per_step": 1e3 * dt_host / steps,
            "step_path": step_path, "host_phases_ms_per_step": host_phases,
            "final_loss": float(loss.detach()), "tuning": _lib.tuning_state(), "cpu_baseline": base, "verified": verified}
     pipe.dataset_unload([DS()])

@@ -64,7 +64,8 @@ int read_device_arch(char *name, int len);
  *   "splat_stats"     debug counters in the workspace header
  *   "conv_wino"       largest Cin that takes the Winograd F(2x2,3x3) kernel (0 = direct implicit-GEMM kernels everywhere)
  *   "conv_sc"         8 (default): gated 3x3/s1 layers with Cin = 32, Cout <= 4 on the vector-pipe kernel, 8 input channels per LDS
- *                     phase (16, 32: larger phases; + 64: two pixels per thread); 0: on the MFMA kernels
+ *                     phase (16, 32: larger phases); 0: on the MFMA kernels
+ *   "wgrad_wino"      1 (default): 3x3/s1 weight gradients in the Winograd F(4x4,3x3) domain; 0: direct MFMA kernel
  *   "conv_wave", "conv_kc32", "conv_stagger", "unet_streams": see csrc/conv.hip, csrc/unet.cpp.
  * read_tuning_key(i) enumerates the keys (NULL past the end); read_tuning_get reads the current value, so that a
  * benchmark can record the state it ran with. */
@@ -299,7 +300,10 @@ int read_bilinear_up4(const float *in, int inH, int inW, int C, float *out, void
  *                       Cout := Cin/2, zero biases (the same MFMA kernel with flipped, transposed weights);
  *                       stride 2 -> read_conv_dgrad_generic;
  *                       read_conv_wgrad: x, dfm -> dW_f, dW_m in the PyTorch layout (Cout, Cin, k, k), MFMA, split over
- *                       pixel rows with a scratch of read_conv_wgrad_scratch_floats(). */
+ *                       pixel rows with a scratch of read_conv_wgrad_scratch_floats().  3x3 / stride-1 layers with Cin % 32 == 0 on
+ *                       images of whole 4 x 4 tiles are summed in the Winograd F(4x4,3x3) domain (dg = G^T [sum over tiles of
+ *                       (B^T d B) . (A dY A^T)] G: a quarter of the multiplications; read_tuning_set("wgrad_wino", 0): direct
+ *                       kernel); read_conv_wgrad_family says which: 4 or 0. */
 int read_conv_pack_params_device(int Cout, const float *bf, const float *bm, const float *gamma, const float *beta,
                                  const float *mean, const float *var, float eps, float *params, void *stream);
 int read_conv_pack_weights_device(int Cin, int Cout, int ksize, int kc, const float *wf, const float *wm, float *wpacked,
@@ -379,6 +383,7 @@ int read_conv_dgrad_generic(const float *dfm, int outH, int outW, int Cin, int C
 size_t read_conv_wgrad_scratch_floats(int Cin, int Cout, int ksize, int outH);
 int read_conv_wgrad(const float *x, int inH, int inW, int Cin, const float *dfm, int Cout, int ksize, int stride, float *dwf,
                     float *dwm, int accumulate, float *scratch, size_t scratch_floats, void *stream);
+int read_conv_wgrad_family(int Cin, int ksize, int stride, int inH, int inW);
 /* read_bilinear_up4 for a vertically stacked batch (rows interpolate inside an item only) and the adjoint of both:
  * dout [4*inH][4*inW][C] -> din [inH][inW][C] */
 int read_bilinear_up4_blocks(const float *in, int inH, int inW, int C, float *out, int block_h, int valid_h, void *stream);

@@ -131,6 +131,7 @@ SIGNATURES = {
     "read_conv_dgrad_generic": (_i, [_vp, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp, _i, _i, _vp, _vp]),
     "read_conv_wgrad_scratch_floats": (_sz, [_i, _i, _i, _i]),
     "read_conv_wgrad": (_i, [_vp, _i, _i, _i, _vp, _i, _i, _i, _vp, _vp, _i, _vp, _sz, _vp]),
+    "read_conv_wgrad_family": (_i, [_i, _i, _i, _i, _i]),
     "read_bilinear_up4_blocks": (_i, [_vp, _i, _i, _i, _vp, _i, _i, _vp]),
     "read_bilinear_up4_backward": (_i, [_vp, _i, _i, _i, _vp, _i, _i, _vp]),
     "read_huber_loss": (_i, [_vp, _vp, _i64, _f, _vp, _vp, _vp]),

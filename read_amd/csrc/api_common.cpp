@@ -61,6 +61,8 @@ void conv_set_sc(int v);
 void conv_set_wino_wgs(int v);
 int conv_get(const char *key, int *value);
 void unet_set_streams(int v);
+void train_set_wgrad_wino(int v);
+int train_get(const char *key, int *value);
 void unet_set_aff_split(int v);
 int unet_get(const char *key, int *value);
 }
@@ -81,7 +83,7 @@ extern "C" int read_debug_set_trace(void *buf, size_t bytes)
 // ("conv_ablate") exist only in builds with -DREAD_DEBUG_KNOBS.
 static const char *const k_tuning_keys[] = {"splat_mode", "splat_stats", "splat_subset", "splat_near", "splat_cells",
                                             "splat_cells_sub", "splat_seeds", "splat_items", "splat_strips", "splat_wgs", "splat_zl2", "splat_lds", "splat_bins", "splat_kslot", "unet_streams", "unet_aff_split", "conv_kc32", "conv_px", "conv_sc", "conv_wino_wgs",
-                                            "conv_wino", "conv_w16", "conv_w4", "conv_w4_grid", "conv_stagger", "conv_wave",
+                                            "conv_wino", "conv_w16", "conv_w4", "conv_w4_grid", "conv_stagger", "conv_wave", "wgrad_wino",
 #ifdef READ_DEBUG_KNOBS
                                             "conv_ablate", "conv_abl",
 #endif
@@ -122,6 +124,7 @@ extern "C" int read_tuning_set(const char *key, int value)
     if (!strcmp(key, "conv_wino")) { readhip::conv_set_wino(value); return READ_OK; }         // largest Cin on the Winograd kernel (0 = off)
     if (!strcmp(key, "conv_stagger")) { readhip::conv_set_stagger(value); return READ_OK; }
     if (!strcmp(key, "conv_wave")) { readhip::conv_set_prefer_wave(value != 0); return READ_OK; }
+    if (!strcmp(key, "wgrad_wino")) { readhip::train_set_wgrad_wino(value); return READ_OK; }   // 0: 3x3 weight gradients on the direct kernel
 #ifdef READ_DEBUG_KNOBS
     if (!strcmp(key, "conv_ablate")) { readhip::conv_set_ablate(value); return READ_OK; }
     if (!strcmp(key, "conv_abl")) { readhip::conv_set_abl(value); return READ_OK; }          // probes of the 16x16x4 Winograd kernels
@@ -133,7 +136,7 @@ extern "C" int read_tuning_set(const char *key, int value)
 extern "C" int read_tuning_get(const char *key, int *value)
 {
     READ_CHECK_ARG(key && value, "read_tuning_get: null pointer");
-    if (readhip::splat_get(key, value) || readhip::conv_get(key, value) || readhip::unet_get(key, value)) return READ_OK;
+    if (readhip::splat_get(key, value) || readhip::conv_get(key, value) || readhip::unet_get(key, value) || readhip::train_get(key, value)) return READ_OK;
     readhip::set_error("read_tuning_get: unknown key '%s'", key);
     return READ_EINVAL;
 }

@@ -1960,7 +1960,7 @@ __global__ __launch_bounds__(256, 1) void gated_conv_wino4_kernel(const ConvKArg
 // Measured (profiles/README.md, round 4): 45 us for the frame against 62 on the F(2x2) kernel.  Taking the parts out one at a time
 // (results invalid, timing only): scalar weight loads 12 us (61 MB through scalar caches shared between CUs), the tile's global
 // loads 17 us (73 MB with the halo), FMAs 10 us, LDS reads 3 us, and they add rather than overlap; two pixels per thread (half the
-// scalar traffic, PPT = 2) and larger phases (CPH = 16, 32) measured slower (50 .. 53 us and 48, 52 us).
+// scalar traffic, PPT = 2: measured, not instantiated) and larger phases (CPH = 16, 32) were slower (50 .. 53 us and 48, 52 us).
 // ------------------------------------------------------------------------------------------
 template <int CIN, int CPH, int PPT, int COUT>
 __global__ __launch_bounds__(256) void gated_conv_smallc_kernel(const ConvKArgs a)
@@ -2654,7 +2654,7 @@ void conv_set_w4(int v) { g_w4 = v < 0 ? 0 : v; }
 void conv_set_w4_grid(int v) { g_w4_grid = v != 0; }
 void conv_set_wino_wgs(int v) { g_wino_wgs = v <= 1 ? 1 : 2; }
 void conv_set_px(int v) { g_conv_px = v < 0 ? 0 : v > 4 ? 4 : v; }
-void conv_set_sc(int v) { g_sc = v; }           // 0 off; 8 / 16 / 32 = input channels per LDS phase; 64 + 8: two pixels per thread
+void conv_set_sc(int v) { g_sc = v; }           // 0 off; 8 / 16 / 32 = input channels per LDS phase
 int conv_get(const char *key, int *value)
 {
     if (!strcmp(key, "conv_wave")) *value = g_prefer_wave;
@@ -2784,14 +2784,13 @@ int launch_gated_conv(const read_conv_desc *d, hipStream_t stream)
     if (conv_uses_sc(d)) {
         READ_CHECK_ARG((uintptr_t)d->wpacked_sc % 64 == 0 && (uintptr_t)d->src[0].data % 16 == 0, "read_gated_conv_forward: wpacked_sc / source misaligned");
         a.tiles_x = ceil_div(outW, 32);
-        const int ppt = (g_sc & 64) ? 2 : 1, cph = g_sc & 63;       // knob: channels per LDS phase, + 64 = two pixels per thread
-        const dim3 grid((unsigned)(a.tiles_x * ceil_div(outH, 8 * ppt)));
+        const int cph = g_sc & 63;                                 // knob: channels per LDS phase
+        const dim3 grid((unsigned)(a.tiles_x * ceil_div(outH, 8)));
         const bool c3 = d->Cout <= 3;
 #define SC_LAUNCH(CPH, PPT) \
         do { if (c3) hipLaunchKernelGGL((gated_conv_smallc_kernel<32, CPH, PPT, 3>), grid, dim3(256), 0, stream, a); \
              else hipLaunchKernelGGL((gated_conv_smallc_kernel<32, CPH, PPT, 4>), grid, dim3(256), 0, stream, a); } while (0)
-        if (ppt == 2) SC_LAUNCH(8, 2);
-        else if (cph == 32) SC_LAUNCH(32, 1);
+        if (cph == 32) SC_LAUNCH(32, 1);
         else if (cph == 16) SC_LAUNCH(16, 1);
         else SC_LAUNCH(8, 1);
 #undef SC_LAUNCH

@@ -688,6 +688,227 @@ __global__ void wgrad_reduce_kernel(const float *__restrict__ partial, int split
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
+// wgrad of the 3x3 / stride-1 layers in the Winograd F(4x4,3x3) domain: 4x fewer multiplications than wgrad_mfma_kernel<9>.
+//
+//   forward:  Y = A^T [ sum_ci (G g G^T) . (B^T d B) ] A      per 4 x 4 output tile, d = its 6 x 6 input patch
+//   hence     dg = G^T [ sum_tiles (B^T d B) . (A dY A^T) ] G   — the elementwise products of two 6 x 6 transforms, summed over
+//   the tiles: per frequency (xi, nu) a matrix product  dU[ci][co'] = sum_tiles V[tile][ci] * M[tile][co']  with the TILES as the
+//   reduction dimension — 36 MACs per (tile, ci, co') against 16 pixels x 9 taps = 144 of the direct form.
+// Workgroup = (32 input channels) x (32 channels of d[f|m]) x a range of tile rows; per iteration eight tiles of one tile row:
+//   * thread (tile t = tid >> 5, channel c = tid & 31) loads its channel's 6 x 6 patch of x and its channel's 4 x 4 tile of d[f|m]
+//     straight from the NHWC tensors (a wave's load = two 128-byte rows; the bounds tests are per row and for the first / last
+//     column of the image only: buffer loads with an out-of-range offset return the zero padding), one iteration AHEAD of their
+//     use, transforms both (144 + 90 FMAs / adds) and writes V[36][8][32] and M[36][8][32] to LDS;
+//   * wave w owns frequencies 9w .. 9w + 8: v_mfma_f32_32x32x2_f32 with A[i][k] = V[f][2s + k][i], B[k][j] = M[f][2s + k][j] — both
+//     operands are conflict-free ds_read_b32 — 36 MFMAs per iteration, 144 accumulator registers;
+//   * two workgroups per CU (74 KiB of LDS each) cover each other's transform phases.
+// Partials [split][tile pair][36][32][32] go to the scratch buffer; wgrad_wino4_reduce_kernel sums the splits and applies G^T . G.
+// ---------------------------------------------------------------------------------------------------------------------
+struct Wg4 {
+    static constexpr int TL = 8;                               // tiles per iteration
+    static constexpr int FS = TL * 32;                         // floats per frequency plane
+    static constexpr unsigned OOR = 0x80000000u;
+};
+
+__device__ __forceinline__ void wg4_bt6(const float d0, const float d1, const float d2, const float d3, const float d4, const float d5,
+                                        float &t0, float &t1, float &t2, float &t3, float &t4, float &t5)
+{   // B^T = [4 0 -5 0 1 0; 0 -4 -4 1 1 0; 0 4 -4 -1 1 0; 0 -2 -1 2 1 0; 0 2 -1 -2 1 0; 0 4 0 -5 0 1]
+    const float a = fmaf(-4.0f, d2, d4), b = fmaf(-4.0f, d1, d3), c = d4 - d2, e = d3 - d1;
+    t0 = fmaf(4.0f, d0, fmaf(-5.0f, d2, d4));
+    t1 = a + b;
+    t2 = a - b;
+    t3 = fmaf(2.0f, e, c);
+    t4 = fmaf(-2.0f, e, c);
+    t5 = fmaf(4.0f, d1, fmaf(-5.0f, d3, d5));
+}
+
+__device__ __forceinline__ void wg4_a4(const float y0, const float y1, const float y2, const float y3,
+                                       float &o0, float &o1, float &o2, float &o3, float &o4, float &o5)
+{   // A = [1 0 0 0; 1 1 1 1; 1 -1 1 -1; 1 2 4 8; 1 -2 4 -8; 0 0 0 1]
+    const float s02 = y0 + y2, s13 = y1 + y3, p = fmaf(4.0f, y2, y0), q = fmaf(8.0f, y3, 2.0f * y1);
+    o0 = y0;
+    o1 = s02 + s13;
+    o2 = s02 - s13;
+    o3 = p + q;
+    o4 = p - q;
+    o5 = y3;
+}
+
+__global__ __launch_bounds__(256, 2) void wgrad_wino4_kernel(const float *__restrict__ x, int H, int W, int Cin,
+                                                            const float *__restrict__ dfm, int C2, int tiles_co,
+                                                            int rows_per_split, float *__restrict__ partial)
+{
+    __shared__ float Vs[36 * Wg4::FS], Ms[36 * Wg4::FS];
+    const int tid = threadIdx.x, lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int t = tid >> 5, c = tid & 31;
+    const int ci0 = ((int)blockIdx.x / tiles_co) * 32, co0 = ((int)blockIdx.x % tiles_co) * 32;
+    const int tiles_x = W >> 2, tiles_y = H >> 2, groups_x = (tiles_x + Wg4::TL - 1) / Wg4::TL;
+    const int ty_begin = (int)blockIdx.z * rows_per_split, ty_end = min(tiles_y, ty_begin + rows_per_split);
+    const int n_it = (ty_end - ty_begin) * groups_x;
+    const bool co_ok = co0 + c < C2;
+    const auto xrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(x), 0, (unsigned)(H * W * Cin) * 4u, 0x00020000);
+    const auto drs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(dfm), 0, (unsigned)(H * W * C2) * 4u, 0x00020000);
+    int xcol[6], dcol[4];                                        // wave-uniform column offsets (bytes): SGPRs
+#pragma unroll
+    for (int j = 0; j < 6; ++j) xcol[j] = j * Cin * 4;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) dcol[j] = j * C2 * 4;
+
+    float xr[6][6], dr[4][4];
+    int f_ty = ty_begin, f_g = 0;
+    auto fetch = [&]() {
+        const int tx = f_g * Wg4::TL + t;
+        const bool tile_ok = tx < tiles_x && f_ty < ty_end;
+        const int y0 = 4 * f_ty - 1, x0 = 4 * tx - 1;
+        unsigned base[6], base_l[6], base_r[6];
+#pragma unroll
+        for (int r = 0; r < 6; ++r) {
+            const int yy = y0 + r;
+            const bool ok = tile_ok && yy >= 0 && yy < H;
+            base[r] = ok ? (unsigned)((yy * W + x0 + 1) * Cin + ci0 + c) * 4u : Wg4::OOR;    // column x0 + 1 >= 0: no negative offsets
+            base_l[r] = (ok && x0 >= 0) ? base[r] - (unsigned)Cin * 4u : Wg4::OOR;
+            base_r[r] = x0 + 5 < W ? base[r] : Wg4::OOR;
+        }
+#pragma unroll
+        for (int r = 0; r < 6; ++r)
+#pragma unroll
+            for (int j = 0; j < 6; ++j)
+                xr[r][j] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(xrs, j == 0 ? base_l[r] : j == 5 ? base_r[r] : base[r],
+                                                                                          j == 0 ? 0 : xcol[j - 1], 0));
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const unsigned db = (tile_ok && co_ok) ? (unsigned)(((4 * f_ty + r) * W + 4 * tx) * C2 + co0 + c) * 4u : Wg4::OOR;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) dr[r][j] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(drs, db, dcol[j], 0));
+        }
+        if (++f_g == groups_x) {
+            f_g = 0;
+            ++f_ty;
+        }
+    };
+
+    floatx16 acc[9];
+#pragma unroll
+    for (int f = 0; f < 9; ++f)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[f][r] = 0.0f;
+    const int i32 = lane & 31, kk = lane >> 5;
+    fetch();
+    for (int it = 0; it < n_it; ++it) {
+        {   // V = B^T d B of this thread's (tile, input channel); M = A dY A^T of its (tile, d[f|m] channel)
+            float u[6][6];
+#pragma unroll
+            for (int j = 0; j < 6; ++j)
+                wg4_bt6(xr[0][j], xr[1][j], xr[2][j], xr[3][j], xr[4][j], xr[5][j], u[0][j], u[1][j], u[2][j], u[3][j], u[4][j], u[5][j]);
+            float *vp = Vs + t * 32 + c;
+#pragma unroll
+            for (int r = 0; r < 6; ++r) {
+                float v0, v1, v2, v3, v4, v5;
+                wg4_bt6(u[r][0], u[r][1], u[r][2], u[r][3], u[r][4], u[r][5], v0, v1, v2, v3, v4, v5);
+                vp[(6 * r + 0) * Wg4::FS] = v0;
+                vp[(6 * r + 1) * Wg4::FS] = v1;
+                vp[(6 * r + 2) * Wg4::FS] = v2;
+                vp[(6 * r + 3) * Wg4::FS] = v3;
+                vp[(6 * r + 4) * Wg4::FS] = v4;
+                vp[(6 * r + 5) * Wg4::FS] = v5;
+            }
+            float w[6][4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                wg4_a4(dr[0][j], dr[1][j], dr[2][j], dr[3][j], w[0][j], w[1][j], w[2][j], w[3][j], w[4][j], w[5][j]);
+            float *mp = Ms + t * 32 + c;
+#pragma unroll
+            for (int r = 0; r < 6; ++r) {
+                float m0, m1, m2, m3, m4, m5;
+                wg4_a4(w[r][0], w[r][1], w[r][2], w[r][3], m0, m1, m2, m3, m4, m5);
+                mp[(6 * r + 0) * Wg4::FS] = m0;
+                mp[(6 * r + 1) * Wg4::FS] = m1;
+                mp[(6 * r + 2) * Wg4::FS] = m2;
+                mp[(6 * r + 3) * Wg4::FS] = m3;
+                mp[(6 * r + 4) * Wg4::FS] = m4;
+                mp[(6 * r + 5) * Wg4::FS] = m5;
+            }
+        }
+        fetch();                                                 // the next iteration's patches travel under the MFMAs (zeros past the end)
+        __syncthreads();
+        const float *va = Vs + (wv * 9) * Wg4::FS + kk * 32 + i32, *mb = Ms + (wv * 9) * Wg4::FS + kk * 32 + i32;
+#pragma unroll
+        for (int f = 0; f < 9; ++f)
+#pragma unroll
+            for (int sidx = 0; sidx < Wg4::TL / 2; ++sidx)
+                acc[f] = __builtin_amdgcn_mfma_f32_32x32x2f32(va[f * Wg4::FS + sidx * 64], mb[f * Wg4::FS + sidx * 64], acc[f], 0, 0, 0);
+        __syncthreads();
+    }
+    // D[i][j] sits in lane (j + 32 * ((i >> 2) & 1)), register (i & 3) + 4 * (i >> 3): row i = ci, column j = co'
+    float *dst = partial + ((long long)blockIdx.z * gridDim.x + blockIdx.x) * (36 * 1024) + (long long)(wv * 9) * 1024;
+#pragma unroll
+    for (int f = 0; f < 9; ++f)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int row = (r & 3) + 8 * (r >> 2) + 4 * kk;
+            dst[(f * 32 + row) * 32 + i32] = acc[f][r];
+        }
+}
+
+// Step 1 of the reduction: partial[0][e] = sum over splits of partial[split][e] for every element of the [tile pair][36][ci][co']
+// block — thread = element, so the `splits` reads of a wave are coalesced and there are 36 x 1024 threads per tile pair (one
+// thread per (ci, co') walking all 36 frequencies and all splits was 6500 dependent loads long: 700 us per layer).
+__global__ __launch_bounds__(256) void wgrad_wino4_sum_kernel(float *__restrict__ partial, int splits, long long per_split)
+{
+    for (long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x; e < per_split; e += (long long)gridDim.x * blockDim.x) {
+        float s0 = 0.0f, s1 = 0.0f, s2 = 0.0f, s3 = 0.0f;
+        int k = 0;
+        for (; k + 4 <= splits; k += 4) {
+            s0 += partial[(long long)k * per_split + e];
+            s1 += partial[(long long)(k + 1) * per_split + e];
+            s2 += partial[(long long)(k + 2) * per_split + e];
+            s3 += partial[(long long)(k + 3) * per_split + e];
+        }
+        for (; k < splits; ++k) s0 += partial[(long long)k * per_split + e];
+        partial[e] = (s0 + s1) + (s2 + s3);
+    }
+}
+
+// Step 2: dW{f|m}[co][ci][3][3] (+)= G^T U G with U = the summed [36][ci][co'] block of a tile pair,
+// G = [1/4 0 0; -1/6 -1/6 -1/6; -1/6 1/6 -1/6; 1/24 1/12 1/6; 1/24 -1/12 1/6; 0 0 1].  Thread = (tile pair, ci, co'), co' fastest.
+__global__ __launch_bounds__(256) void wgrad_wino4_reduce_kernel(const float *__restrict__ summed, int tiles_ci, int tiles_co, int Cin,
+                                                                 int Cout, int Cp, float *dwf, float *dwm, int accumulate)
+{
+    const long long tiles = (long long)tiles_ci * tiles_co;
+    for (long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x; e < tiles * 1024; e += (long long)gridDim.x * blockDim.x) {
+        const int col = (int)(e & 31), row = (int)((e >> 5) & 31), tile = (int)(e >> 10);
+        const int ci = (tile / tiles_co) * 32 + row, cp = (tile % tiles_co) * 32 + col;
+        const int half = cp >= Cp ? 1 : 0, co = cp - half * Cp;
+        if (ci >= Cin || co >= Cout || cp >= 2 * Cp) continue;
+        const float *src = summed + (long long)tile * 36 * 1024 + row * 32 + col;
+        float u[6][6];
+#pragma unroll
+        for (int f = 0; f < 36; ++f) u[f / 6][f % 6] = src[f * 1024];
+        // rows: G^T u (3 x 6), then columns: (G^T u) G (3 x 3)
+        float gtu[3][6];
+#pragma unroll
+        for (int j = 0; j < 6; ++j) {
+            const float s12 = u[1][j] + u[2][j], d12 = u[2][j] - u[1][j], s34 = u[3][j] + u[4][j], d34 = u[3][j] - u[4][j];
+            gtu[0][j] = 0.25f * u[0][j] - s12 * (1.0f / 6.0f) + s34 * (1.0f / 24.0f);
+            gtu[1][j] = d12 * (1.0f / 6.0f) + d34 * (1.0f / 12.0f);
+            gtu[2][j] = -s12 * (1.0f / 6.0f) + s34 * (1.0f / 6.0f) + u[5][j];
+        }
+        float *dst = (half ? dwm : dwf) + ((long long)co * Cin + ci) * 9;
+#pragma unroll
+        for (int a = 0; a < 3; ++a) {
+            const float *g = gtu[a];
+            const float s12 = g[1] + g[2], d12 = g[2] - g[1], s34 = g[3] + g[4], d34 = g[3] - g[4];
+            const float o0 = 0.25f * g[0] - s12 * (1.0f / 6.0f) + s34 * (1.0f / 24.0f);
+            const float o1 = d12 * (1.0f / 6.0f) + d34 * (1.0f / 12.0f);
+            const float o2 = -s12 * (1.0f / 6.0f) + s34 * (1.0f / 6.0f) + g[5];
+            dst[3 * a + 0] = accumulate ? dst[3 * a + 0] + o0 : o0;
+            dst[3 * a + 1] = accumulate ? dst[3 * a + 1] + o1 : o1;
+            dst[3 * a + 2] = accumulate ? dst[3 * a + 2] + o2 : o2;
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
 // bilinear x4 upsample, backward (adjoint of bilinear_up4_kernel in conv.hip): thread = (input pixel, 4 channels)
 // gathers the up-to-6x6 output pixels that read it.
 // ---------------------------------------------------------------------------------------------------------------------
@@ -1130,7 +1351,42 @@ extern "C" int read_conv_dgrad_generic(const float *dfm, int outH, int outW, int
     return READ_OK;
 }
 
+namespace readhip {
+int g_wgrad_wino = 1;     // read_tuning_set("wgrad_wino", 0): 3x3 / stride-1 weight gradients back on the direct kernel
+void train_set_wgrad_wino(int v) { g_wgrad_wino = v; }
+int train_get(const char *key, int *value)
+{
+    if (!strcmp(key, "wgrad_wino")) { *value = g_wgrad_wino; return 1; }
+    return 0;
+}
+}  // namespace readhip
+
 namespace {
+// Winograd-domain wgrad: 3x3 / stride 1, whole 32-channel tiles of input channels, whole 4 x 4 tiles of pixels
+bool wgrad_uses_wino4(int Cin, int ksize, int stride, int H, int W)
+{
+    return readhip::g_wgrad_wino && ksize == 3 && stride == 1 && Cin % 32 == 0 && H % 4 == 0 && W % 4 == 0 && H >= 4 && W >= 4;
+}
+struct Wgrad4Plan {
+    int tiles_ci, tiles_co, splits, rows_per_split;
+    size_t partial_floats;
+};
+Wgrad4Plan wgrad4_plan(int Cin, int Cout, int H)
+{
+    Wgrad4Plan p;
+    const int Cp = (Cout + 7) / 8 * 8;
+    p.tiles_ci = Cin / 32;
+    p.tiles_co = (2 * Cp + 31) / 32;
+    const int wgs = p.tiles_ci * p.tiles_co, tiles_y = H / 4;
+    int splits = (512 + wgs - 1) / wgs;                          // two workgroups per CU over the chip
+    if (splits > tiles_y) splits = tiles_y;
+    if (splits < 1) splits = 1;
+    p.rows_per_split = (tiles_y + splits - 1) / splits;
+    p.splits = (tiles_y + p.rows_per_split - 1) / p.rows_per_split;
+    p.partial_floats = (size_t)p.splits * wgs * 36 * 1024;
+    return p;
+}
+
 struct WgradPlan {
     int NT, tap_groups, tiles_ci, tiles_co, splits, rows_per_split;
     int cib;                   // 1x1 layers: NT tiles of input channels per wave (tiles_ci then counts blocks of NT tiles)
@@ -1164,7 +1420,15 @@ WgradPlan wgrad_plan(int Cin, int Cout, int ksize, int outH)
 extern "C" size_t read_conv_wgrad_scratch_floats(int Cin, int Cout, int ksize, int outH)
 {
     if (Cin < 1 || Cout < 1 || outH < 1) return 0;
-    return wgrad_plan(Cin, Cout, ksize, outH).partial_floats;
+    // the larger of the two plans a 3x3 layer may take (the caller does not pass the stride or the width)
+    const size_t direct = wgrad_plan(Cin, Cout, ksize, outH).partial_floats;
+    const size_t wino = (ksize == 3 && Cin % 32 == 0 && outH % 4 == 0) ? wgrad4_plan(Cin, Cout, outH).partial_floats : 0;
+    return direct > wino ? direct : wino;
+}
+
+extern "C" int read_conv_wgrad_family(int Cin, int ksize, int stride, int inH, int inW)
+{
+    return wgrad_uses_wino4(Cin, ksize, stride, inH, inW) ? 4 : 0;
 }
 
 extern "C" int read_conv_wgrad(const float *x, int inH, int inW, int Cin, const float *dfm, int Cout, int ksize, int stride,
@@ -1179,6 +1443,22 @@ extern "C" int read_conv_wgrad(const float *x, int inH, int inW, int Cin, const 
     // the kernel addresses both tensors with 32-bit byte offsets (plus the largest tap offset)
     READ_CHECK_ARG(((long long)inH + ksize) * inW * Cin * 4 < (1ll << 31) && (long long)outH * outW * 2 * Cp * 4 < (1ll << 31),
                    "read_conv_wgrad: tensors of 2 GiB and more are not supported");
+    if (wgrad_uses_wino4(Cin, ksize, stride, inH, inW)) {
+        const Wgrad4Plan q = wgrad4_plan(Cin, Cout, inH);
+        READ_CHECK_ARG(scratch_floats >= q.partial_floats, "read_conv_wgrad: scratch %zu < %zu floats", scratch_floats, q.partial_floats);
+        hipLaunchKernelGGL(wgrad_wino4_kernel, dim3((unsigned)(q.tiles_ci * q.tiles_co), 1, (unsigned)q.splits), dim3(256), 0,
+                           as_stream(stream), x, inH, inW, Cin, dfm, 2 * Cp, q.tiles_co, q.rows_per_split, scratch);
+        READ_CHECK_LAUNCH();
+        const long long per_split = (long long)q.tiles_ci * q.tiles_co * 36 * 1024;
+        if (q.splits > 1) {
+            hipLaunchKernelGGL(wgrad_wino4_sum_kernel, dim3(grid_for(per_split)), dim3(256), 0, as_stream(stream), scratch, q.splits, per_split);
+            READ_CHECK_LAUNCH();
+        }
+        hipLaunchKernelGGL(wgrad_wino4_reduce_kernel, dim3(grid_for((long long)q.tiles_ci * q.tiles_co * 1024)), dim3(256), 0,
+                           as_stream(stream), (const float *)scratch, q.tiles_ci, q.tiles_co, Cin, Cout, Cp, dwf, dwm, accumulate);
+        READ_CHECK_LAUNCH();
+        return READ_OK;
+    }
     const WgradPlan p = wgrad_plan(Cin, Cout, ksize, outH);
     READ_CHECK_ARG(scratch_floats >= p.partial_floats, "read_conv_wgrad: scratch %zu < %zu floats", scratch_floats, p.partial_floats);
     const dim3 grid((unsigned)(p.tiles_ci * p.tiles_co), (unsigned)p.tap_groups, (unsigned)p.splits);

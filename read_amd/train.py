@@ -530,7 +530,7 @@ class GatedConvFn(torch.autograd.Function):
         if not (ctx.needs_input_grad[1] or ctx.needs_input_grad[3]):        # frozen net: nobody asked for weight gradients
             return dx, None, dbf, None, dbm, dgamma, dbeta, None, None, None, None, None, None, None, None, None, None
         if FLOP_LOG is not None:
-            FLOP_LOG.append(("wgrad", 2.0 * Ho * Wo * cin * 2 * cout * k * k, 0))
+            FLOP_LOG.append(("wgrad", 2.0 * Ho * Wo * cin * 2 * cout * k * k, int(L.read_conv_wgrad_family(cin, k, stride, H, W))))
         dwf, dwm = torch.empty_like(wf), torch.empty_like(wm)
         n_scr = L.read_conv_wgrad_scratch_floats(cin, cout, k, Ho)
         scratch = torch.empty(n_scr, dtype=torch.float32, device=dev)

@@ -31,6 +31,7 @@ def _close(got, ref, what, rtol=RTOL):
 @pytest.mark.parametrize("cin,cout,k,stride,elu,H,W", [
     (32, 32, 3, 1, True, 24, 40), (64, 64, 3, 1, False, 17, 33), (8, 32, 3, 1, True, 32, 48), (32, 3, 3, 1, False, 16, 32),
     (48, 40, 3, 1, True, 9, 21),          # F(4x4) linear launches with a padded last channel group, odd image size
+    (64, 64, 3, 1, False, 16, 36), (128, 32, 3, 1, True, 8, 8), (32, 64, 3, 1, True, 136, 32),    # Winograd-domain wgrad: partial tile group, one tile row, several splits
     (480, 32, 1, 1, True, 16, 24), (64, 56, 1, 1, True, 12, 20), (16, 32, 1, 1, True, 9, 31), (128, 64, 1, 1, False, 10, 18),
     (32, 64, 3, 2, True, 32, 48), (128, 256, 3, 2, True, 16, 16), (256, 128, 4, 2, True, 16, 24), (64, 32, 4, 2, True, 32, 32),
 ])
@@ -61,6 +62,46 @@ def test_gated_conv_layer_gradients(hip, cin, cout, k, stride, elu, H, W):
     _close(xd.grad.permute(2, 0, 1)[None], xr.grad, "dx")
     for n in ("wf", "wm", "bf", "bm", "gamma", "beta"):
         _close(dev[n].grad, ref_in[n].grad, "d" + n)
+
+
+def test_winograd_domain_wgrad_equals_the_direct_kernel(hip):
+    """read_conv_wgrad on 3x3 / stride-1 layers: the F(4x4,3x3)-domain kernel (dg = G^T [sum_tiles (B^T d B) . (A dY A^T)] G; 4x
+    fewer multiplications) against the direct MFMA kernel (knob wgrad_wino = 0) and against torch's conv2d weight gradient, on the
+    UNet's channel counts, with partial tile groups (W / 4 not a multiple of 8), a padded d[f|m] tile (Cout = 3), accumulation."""
+    from read_amd import _lib
+    L = _lib.lib()
+    rng = np.random.default_rng(77)
+    for (cin, cout, H, W) in ((32, 32, 128, 64), (64, 64, 64, 96), (128, 128, 32, 36), (256, 256, 16, 16), (32, 3, 32, 64), (64, 40, 20, 28)):
+        cp = (cout + 7) // 8 * 8
+        x = torch.from_numpy(rng.standard_normal((H, W, cin)).astype(np.float32)).cuda()
+        dfm = torch.zeros((H, W, 2 * cp), dtype=torch.float32)
+        dfm[:, :, :cout] = torch.from_numpy(rng.standard_normal((H, W, cout)).astype(np.float32))
+        dfm[:, :, cp:cp + cout] = torch.from_numpy(rng.standard_normal((H, W, cout)).astype(np.float32))
+        dfm = dfm.cuda()
+        n_scr = L.read_conv_wgrad_scratch_floats(cin, cout, 3, H)
+        scratch = torch.empty(n_scr, dtype=torch.float32, device="cuda")
+        got = {}
+        try:
+            for knob in (1, 0):
+                _lib.check(L.read_tuning_set(b"wgrad_wino", knob))
+                dwf = torch.full((cout, cin, 3, 3), 7.0, device="cuda")
+                dwm = torch.full((cout, cin, 3, 3), -3.0, device="cuda")
+                _lib.check(L.read_conv_wgrad(x.data_ptr(), H, W, cin, dfm.data_ptr(), cout, 3, 1, dwf.data_ptr(), dwm.data_ptr(), 0,
+                                             scratch.data_ptr(), n_scr, _lib.stream_ptr()))
+                got[knob] = (dwf.clone(), dwm.clone())
+                _lib.check(L.read_conv_wgrad(x.data_ptr(), H, W, cin, dfm.data_ptr(), cout, 3, 1, dwf.data_ptr(), dwm.data_ptr(), 1,
+                                             scratch.data_ptr(), n_scr, _lib.stream_ptr()))            # accumulate: twice the gradient
+                _close(dwf, 2 * got[knob][0], f"accumulate {cin}->{cout} knob {knob}", rtol=1e-6)
+        finally:
+            _lib.check(L.read_tuning_set(b"wgrad_wino", 1))
+        xc = x.cpu().permute(2, 0, 1)[None].double()
+        for half, name in ((0, "dwf"), (1, "dwm")):
+            g = dfm.cpu()[:, :, half * cp:half * cp + cout].permute(2, 0, 1)[None].double()
+            ref = torch.nn.grad.conv2d_weight(xc, (cout, cin, 3, 3), g, padding=1)
+            e1 = _close(got[1][half], ref, f"winograd {name} {cin}->{cout} {H}x{W}", rtol=2e-5)
+            e0 = _close(got[0][half], ref, f"direct {name} {cin}->{cout} {H}x{W}", rtol=2e-5)
+            print(f"{cin}->{cout} {H}x{W} {name}: winograd {e1:.2e} direct {e0:.2e} of the largest entry")
+        assert not torch.equal(got[1][0], got[0][0])                     # the knob really switches kernels
 
 
 def test_up4_and_huber(hip):
