@@ -446,9 +446,13 @@ def run_train(a, dev, street=None, steps=None, warm=None, cpu_timing=True, do_ve
         t_first = time.perf_counter() - t0
         exact = all(bool(np.array_equal(idx_g[l], maps_o[l])) for l in range(5))
         worst = worst_floor = 0.0
-        n_par = 0
+        n_par, worst_name, over = 0, "", []
         for n, g in grads_g.items():
             e, f = _grad_err(g, st_r[n].grad)
+            if e > worst:
+                worst_name = n
+            if e > 1e-3:
+                over.append((n, round(e, 4)))
             worst, worst_floor, n_par = max(worst, e), max(worst_floor, f), n_par + 1
         touched = torch.from_numpy(np.unique(np.concatenate([m.reshape(-1) for m in maps_o])).astype(np.int64))
         dref = tex_r.grad[0].t()[touched]
@@ -458,7 +462,7 @@ def run_train(a, dev, street=None, steps=None, warm=None, cpu_timing=True, do_ve
         untouched_zero = bool(float(drows_g[rest].abs().max()) == 0.0) if bool(rest.any()) else True
         loss_rel = abs(float(loss_g) - float(loss_o)) / max(abs(float(loss_o)), 1e-30)
         verified = {"raster_bit_exact": exact, "loss": float(loss_g), "loss_oracle": float(loss_o), "loss_rel_err": loss_rel,
-                    "param_grads_compared": n_par, "worst_param_grad_err_of_max": worst,
+                    "param_grads_compared": n_par, "worst_param_grad_err_of_max": worst, "worst_param": worst_name, "params_off_by_more_than_1e-3": over[:12],
                     "worst_param_grad_floor_with_1e-3_rel": worst_floor,
                     "descriptor_rows_compared": int(touched.numel()), "descriptor_grad_err_of_max": e_desc,
                     "descriptor_grad_floor_with_1e-3_rel": f_desc, "untouched_rows_zero": untouched_zero,

@@ -242,6 +242,55 @@ def _pack_dgrad(entry, wf, wm, cin, cout, k):
 
 
 # -----------------------------------------------------------------------------------------------------------------------
+# dgrad of the 4x4 / stride-2 layers (feat_extract.7 / .3 / .4, READ/models/unet.py:198-200) on the Winograd kernel
+# -----------------------------------------------------------------------------------------------------------------------
+# y[o] = sum_a W[a] x[2 o + a - 1]  =>  dx[2 u + p] = sum_{t in 0..2} K_p[t] dy[u + t - 1] with K_0 = [W3, W1, 0], K_1 = [0, W2, W0]
+# (per axis): each of the four pixel parities of dx is a 3x3 / stride-1 correlation over the HALF-resolution d[f|m] — i.e. the
+# stride-1 dgrad of a 3x3 pseudo-layer whose weights are Wp = [0, W1, W3] (even positions) / [W0, W2, 0] (odd positions) along
+# each axis.  Four launches of the F(4x4,3x3) kernel on a quarter of the pixels replace the generic vector kernel (690 us per
+# layer, three layers on the critical path of the backward pass).
+POLYPHASE_DGRAD = os.environ.get("READ_AMD_POLYPHASE", "1") != "0"
+_POLY = {}                   # id(conv_f weight) -> (versions, fragments [4][n], w4 flag)
+_POLY_SEL = {}               # device -> index tensors of the four parities
+
+
+def _poly_fragments(wf, wm, cin, cout, k=4):
+    """k = 3 (stride 2, pad 1) the same way: dx[2 u] = W1 dy[u], dx[2 u + 1] = W2 dy[u] + W0 dy[u + 1] — pseudo-weights
+    [0, W1, 0] / [W0, W2, 0]; instead of the stride-1 dgrad over a zero-dilated d[f|m] (4x the pixels, 3/4 of them zeros)."""
+    L = _lib.lib()
+    key = id(wf)
+    ver = (wf._version, wm._version, wf.data_ptr(), wm.data_ptr())
+    capturing = torch.cuda.is_current_stream_capturing()
+    hit = None if capturing else _POLY.get(key)
+    if hit is not None and hit[0] == ver:
+        cur = torch.cuda.current_stream(wf.device)
+        if hit[3] is not None and hit[4] != cur.cuda_stream:      # packed on another stream (e.g. a graph capture's warm-up)
+            cur.wait_event(hit[3])
+            hit[1].record_stream(cur)
+        return hit[:3]
+    dev = wf.device
+    sel = _POLY_SEL.get((dev, k))
+    if sel is None:                                                            # parity -> source tap of the pseudo taps (k: the zero tap)
+        taps = torch.tensor([[4, 1, 3], [0, 2, 4]] if k == 4 else [[3, 1, 3], [0, 2, 3]], device=dev)
+        sel = _POLY_SEL[(dev, k)] = (taps[[0, 0, 1, 1]][:, :, None], taps[[0, 1, 0, 1]][:, None, :])
+    w5 = torch.nn.functional.pad(torch.stack((wf.detach(), wm.detach())), (0, 1, 0, 1))      # (2, cout, cin, k + 1, k + 1)
+    wp = w5[:, :, :, sel[0], sel[1]].permute(3, 0, 1, 2, 4, 5).contiguous()                    # (parity 2 py + px, f|m, cout, cin, 3, 3)
+    w4 = _w4_fits(2 * ((cout + 7) // 8 * 8), cin // 2)
+    n = L.read_conv_dgrad_w4_floats(cin, cout) if w4 else L.read_conv_dgrad_wino_floats(cin, cout)
+    buf = torch.empty((4, n), dtype=torch.float32, device=dev)
+    pack = L.read_conv_pack_dgrad_w4_device if w4 else L.read_conv_pack_dgrad_wino_device
+    for par in range(4):
+        _lib.check(pack(cin, cout, wp[par, 0].data_ptr(), wp[par, 1].data_ptr(), buf[par].data_ptr(), _lib.stream_ptr()))
+    if not capturing:
+        ev = torch.cuda.Event()
+        ev.record()
+        if key not in _POLY:
+            weakref.finalize(wf, _POLY.pop, key, None)
+        _POLY[key] = (ver, buf, w4, ev, torch.cuda.current_stream(dev).cuda_stream)
+    return (ver, buf, w4)
+
+
+# -----------------------------------------------------------------------------------------------------------------------
 # Every packing job of a step in one launch
 # -----------------------------------------------------------------------------------------------------------------------
 # The optimizer changes every weight every step, so a step re-packs the parameter block, the forward fragments and the dgrad
@@ -410,8 +459,15 @@ class GatedConvFn(torch.autograd.Function):
         ctx.pack = entry
         # the dgrad's fragments too, now: in the backward pass the wgrad kernels of the layers above fill the chip from their side
         # stream and a small packing launch between two dgrads waits 200 us for its turn (10 us here)
-        if entry[3] is None and x.requires_grad and (stride == 1 or (stride == 2 and k == 3 and H % 2 == 0 and W % 2 == 0)):
+        # stride-2 layers: dgrad as four stride-1 dgrads, one per pixel parity (_poly_fragments) — not inside a captured step, whose
+        # retained backward graph is walked again after the weights have changed (the dilated / generic paths stay there)
+        poly = (POLYPHASE_DGRAD and USE_WINOGRAD and stride == 2 and k in (3, 4) and H % 2 == 0 and W % 2 == 0 and cin % 16 == 0
+                and not torch.cuda.is_current_stream_capturing())
+        ctx.poly = poly
+        if entry[3] is None and x.requires_grad and (stride == 1 or (stride == 2 and k == 3 and H % 2 == 0 and W % 2 == 0 and not poly)):
             _pack_dgrad(entry, wf, wm, cin, cout, k)
+        if poly and x.requires_grad:
+            _poly_fragments(wf, wm, cin, cout, k)            # now, for the same reason
         side = _SIDE.get(dev)
         if side is not None:
             side[1] = False          # a backward pass that died before its join callback ran must not mute the next one's
@@ -481,6 +537,16 @@ class GatedConvFn(torch.autograd.Function):
         else:
             _lib.check(L.read_gate_backward(dy.data_ptr(), fm.data_ptr(), Ho * Wo, cout, params.data_ptr(), elu, dfm.data_ptr(),
                                             sums.data_ptr(), Wo, bh, vh, st))
+        # The side stream's outputs are allocated BEFORE the event it waits for: a block the caching allocator hands out here was
+        # freed by main-stream work that precedes the event.  Allocated after the dgrad below, dwf could be the block of a dgrad
+        # temporary whose kernels are still queued on the main stream — the wgrad, ordered only behind ev_dfm, then wrote into memory
+        # the main stream was still using (seen as a garbage dW_f of feat_extract.7 once the dgrad had freed tensors of that size).
+        want_w = ctx.needs_input_grad[1] or ctx.needs_input_grad[3]
+        dwf = dwm = scratch = None
+        if want_w:
+            dwf, dwm = torch.empty_like(wf), torch.empty_like(wm)
+            n_scr = L.read_conv_wgrad_scratch_floats(cin, cout, k, Ho)
+            scratch = torch.empty(n_scr, dtype=torch.float32, device=dev)
         ev_dfm = None
         if WGRAD_SIDE_STREAM:
             ev_dfm = torch.cuda.Event()
@@ -500,8 +566,17 @@ class GatedConvFn(torch.autograd.Function):
         dx = None
         if ctx.needs_input_grad[0]:
             dx = torch.empty((H, W, cin), dtype=torch.float32, device=dev)
-            dilated = stride == 2 and k == 3 and H % 2 == 0 and W % 2 == 0
-            if stride == 1 or dilated:
+            poly = ctx.poly and ctx.wrefs[0]() is not None and ctx.wrefs[1]() is not None
+            dilated = not poly and stride == 2 and k == 3 and H % 2 == 0 and W % 2 == 0
+            if poly:
+                # four 3x3 / stride-1 dgrads over the half-resolution d[f|m], one per pixel parity of dx (_poly_fragments)
+                _, frags, w4 = _poly_fragments(ctx.wrefs[0](), ctx.wrefs[1](), cin, cout, k)  # of the CURRENT weights (cache: packed in forward)
+                zero = _zero_params(L.read_conv_param_floats(cin // 2), dev)
+                for par in range(4):
+                    dxp = torch.empty((Ho, Wo, cin), dtype=torch.float32, device=dev)
+                    _linear_conv(dfm, 2 * cp, frags[par], zero, cin // 2, 3, 1, dxp, wino=frags[par], w4=w4)
+                    dx[par >> 1::2, par & 1::2] = dxp
+            elif stride == 1 or dilated:
                 # dgrad = the same MFMA convolution over d[f|m] with flipped, transposed weights; the two "gate halves" of
                 # the kernel's output tile are simply the two halves of the input channels.  A 3x3 / stride-2 layer is the
                 # stride-1 layer sampled at the even positions, so its dgrad is the stride-1 dgrad of d[f|m] spread onto the
@@ -527,13 +602,10 @@ class GatedConvFn(torch.autograd.Function):
                 ws = torch.empty(L.read_conv_dgrad_generic_floats(cin, cout, k), dtype=torch.float32, device=dev)
                 _lib.check(L.read_conv_dgrad_generic(dfm.data_ptr(), Ho, Wo, cin, cout, k, stride, wf.data_ptr(), wm.data_ptr(),
                                                      ws.data_ptr(), H, W, dx.data_ptr(), st))
-        if not (ctx.needs_input_grad[1] or ctx.needs_input_grad[3]):        # frozen net: nobody asked for weight gradients
+        if not want_w:                                                      # frozen net: nobody asked for weight gradients
             return dx, None, dbf, None, dbm, dgamma, dbeta, None, None, None, None, None, None, None, None, None, None
         if FLOP_LOG is not None:
             FLOP_LOG.append(("wgrad", 2.0 * Ho * Wo * cin * 2 * cout * k * k, int(L.read_conv_wgrad_family(cin, k, stride, H, W))))
-        dwf, dwm = torch.empty_like(wf), torch.empty_like(wm)
-        n_scr = L.read_conv_wgrad_scratch_floats(cin, cout, k, Ho)
-        scratch = torch.empty(n_scr, dtype=torch.float32, device=dev)
         if WGRAD_SIDE_STREAM:
             # nothing downstream of this layer needs its weight gradient before the optimizer step, so it is computed on a
             # side stream while the main stream goes on with the dgrad chain of the layers below; the end of the backward
