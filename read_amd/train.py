@@ -7,7 +7,8 @@ HIP kernels of csrc/train.hip + csrc/conv.hip:
 
   GatedConvFn     forward  = MFMA convolution in linear mode (pre-activations f|m kept) + gate kernel
                   backward = gate backward (+ bias / BatchNorm-affine sums), dgrad (the same MFMA kernel over d[f|m] with
-                             flipped, transposed weights; generic kernel for the six stride-2 layers), MFMA wgrad
+                             flipped, transposed weights; the six stride-2 layers as four stride-1 dgrads, one per pixel
+                             parity), wgrad (3x3/s1: in the Winograd F(4x4,3x3) domain; the others direct MFMA)
   Up4Fn           bilinear x4 and its adjoint
   huber_loss      loss value + gradient in one launch
   SparseDescriptorRMSprop   RMSprop over the descriptor rows a step touched (the reference sweeps all N rows: 960 MB of
