@@ -114,6 +114,29 @@ def test_small_cout_weight_order():
     assert L.read_conv_pack_sc_host(32, 3, None, None, None) == -22
 
 
+def test_wgrad_kernel_choice_and_scratch():
+    """read_conv_wgrad_family: 4 = summed in the Winograd F(4x4,3x3) domain (3x3 / stride 1, whole 32-channel tiles of input
+    channels, whole 4 x 4 pixel tiles), 0 = direct MFMA kernel; the scratch size covers whichever the launch takes; the knob."""
+    L = _lib.lib()
+    assert L.read_conv_wgrad_family(32, 3, 1, 2176, 256) == 4 and L.read_conv_wgrad_family(256, 3, 1, 272, 32) == 4
+    for (cin, k, s_, H, W) in ((8, 3, 1, 64, 64), (48, 3, 1, 64, 64), (32, 3, 2, 64, 64), (32, 1, 1, 64, 64), (32, 4, 2, 64, 64),
+                               (32, 3, 1, 62, 64), (32, 3, 1, 64, 66)):
+        assert L.read_conv_wgrad_family(cin, k, s_, H, W) == 0, (cin, k, s_, H, W)
+    try:
+        _lib.check(L.read_tuning_set(b"wgrad_wino", 0))
+        assert L.read_conv_wgrad_family(32, 3, 1, 2176, 256) == 0
+        v = C.c_int(-1)
+        _lib.check(L.read_tuning_get(b"wgrad_wino", C.byref(v)))
+        assert v.value == 0
+    finally:
+        _lib.check(L.read_tuning_set(b"wgrad_wino", 1))
+    for (cin, cout, H) in ((32, 32, 2176), (256, 256, 272), (64, 3, 128), (128, 40, 36)):
+        tiles = (cin // 32) * ((2 * ((cout + 7) // 8 * 8) + 31) // 32)
+        splits_max = -(-512 // tiles)
+        assert L.read_conv_wgrad_scratch_floats(cin, cout, 3, H) >= min(splits_max, H // 4) * tiles * 36 * 1024 * 0.5
+        assert L.read_conv_wgrad_scratch_floats(cin, cout, 3, H) > 0 and L.read_conv_wgrad_scratch_floats(cin, cout, 3, H + 1) > 0
+
+
 def test_param_packing_folds_batchnorm():
     L = _lib.lib()
     rng = np.random.default_rng(1)

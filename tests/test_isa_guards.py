@@ -6,7 +6,8 @@ change can silently lose — found in the ISA, not in any test result (DESIGN.md
   * the wgrad kernel's ring of five is counted by the compiler: `vmcnt(40)` in front of its MFMA groups, not a drain;
   * the whole-quad 1x1 pixel-lane kernel waits for `vmcnt(3)` in front of its MFMA groups;
   * the small-Cout vector-pipe kernel keeps its software-pipelined scalar weight loads: 1728 v_fmac_f32 with SGPR multipliers per
-    pixel, 144 s_load_dwordx16 issued one group ahead, no scratch.
+    pixel, 144 s_load_dwordx16 issued one group ahead, no scratch;
+  * the Winograd-domain wgrad kernel fits two waves per SIMD (<= 256 registers, no scratch) and issues its 36 MFMAs per iteration.
 """
 import os
 import re
@@ -93,3 +94,16 @@ def test_small_cout_kernel_streams_weights_through_sgprs(conv_asm):
             nxt = [x for x in lines[i + 1:i + 8] if not x.startswith(("s_movk_i32", "s_mov_b32", "s_load_dwordx16"))]
             exposed += nxt[0].startswith("s_waitcnt lgkmcnt")
     assert exposed <= 4 + 2, exposed                                        # + the kernel-argument loads at entry
+
+
+@pytest.fixture(scope="module")
+def train_asm(tmp_path_factory):
+    return _asm("train.hip", tmp_path_factory)
+
+
+def test_winograd_wgrad_kernel_fits_two_waves_per_simd(train_asm):
+    name, body = _function(train_asm, "wgrad_wino4_kernel")
+    assert _meta(train_asm, name, "private_seg_size") == 0
+    assert _meta(train_asm, name, "num_vgpr") + _meta(train_asm, name, "num_agpr") <= 256
+    assert body.count("v_mfma_f32_32x32x2_f32") == 36                     # 9 frequencies x 4 tile pairs per iteration, nothing duplicated
+    assert body.count("buffer_load_dword ") + body.count("buffer_load_dword\t") >= 52 or body.count("buffer_load_dword") >= 52
