@@ -465,6 +465,9 @@ class GatedConvFn(torch.autograd.Function):
         poly = (POLYPHASE_DGRAD and USE_WINOGRAD and stride == 2 and k in (3, 4) and H % 2 == 0 and W % 2 == 0 and cin % 16 == 0
                 and not torch.cuda.is_current_stream_capturing())
         ctx.poly = poly
+        # a captured step's backward (walked eagerly over the retained graph, on the capture's stream) keeps its weight gradients on
+        # that one stream: the side-stream hand-over is only exercised, and only verified, in the per-layer path
+        ctx.side = WGRAD_SIDE_STREAM and not torch.cuda.is_current_stream_capturing()
         if entry[3] is None and x.requires_grad and (stride == 1 or (stride == 2 and k == 3 and H % 2 == 0 and W % 2 == 0 and not poly)):
             _pack_dgrad(entry, wf, wm, cin, cout, k)
         if poly and x.requires_grad:
@@ -549,7 +552,7 @@ class GatedConvFn(torch.autograd.Function):
             n_scr = L.read_conv_wgrad_scratch_floats(cin, cout, k, Ho)
             scratch = torch.empty(n_scr, dtype=torch.float32, device=dev)
         ev_dfm = None
-        if WGRAD_SIDE_STREAM:
+        if ctx.side:
             ev_dfm = torch.cuda.Event()
             ev_dfm.record(torch.cuda.current_stream(dev))              # d[f|m] (and everything before it) is complete here
         if zeroed is not None:
@@ -607,7 +610,7 @@ class GatedConvFn(torch.autograd.Function):
             return dx, None, dbf, None, dbm, dgamma, dbeta, None, None, None, None, None, None, None, None, None, None
         if FLOP_LOG is not None:
             FLOP_LOG.append(("wgrad", 2.0 * Ho * Wo * cin * 2 * cout * k * k, int(L.read_conv_wgrad_family(cin, k, stride, H, W))))
-        if WGRAD_SIDE_STREAM:
+        if ctx.side:
             # nothing downstream of this layer needs its weight gradient before the optimizer step, so it is computed on a
             # side stream while the main stream goes on with the dgrad chain of the layers below; the end of the backward
             # pass joins the streams (_join_side_stream, queued once per pass on the autograd engine)
