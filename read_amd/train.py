@@ -296,8 +296,7 @@ def _poly_fragments(wf, wm, cin, cout, k=4):
 # -----------------------------------------------------------------------------------------------------------------------
 # The optimizer changes every weight every step, so a step re-packs the parameter block, the forward fragments and the dgrad
 # fragments of all 99 layers.  Layer by layer that was 297 launches of 2 .. 5 us kernels per step, each with its allocation, its
-# event and its record_stream calls on the host and ~8 us of launch gap on the device (bench.py: the step is bound by its ~1200
-# launches, host and device alike).  The net's tensors keep their addresses across optimizer steps, so the jobs are tabulated
+# event and its record_stream calls on the host and ~8 us of launch gap on the device (bench.py, round 4 before the wgrad work: ~1200 launches per step).  The net's tensors keep their addresses across optimizer steps, so the jobs are tabulated
 # ONCE per (net, BatchNorm mode) — outputs in buffers the plan keeps — and a step is one read_conv_pack_batch launch at the head of
 # the forward pass; the per-layer cache then hits for every layer.
 PACK_BATCH = os.environ.get("READ_AMD_PACK_BATCH", "1") != "0"
@@ -787,14 +786,16 @@ def stack_batch(x_nchw, level):
 # -----------------------------------------------------------------------------------------------------------------------
 # The training forward of the UNet from a HIP graph, its backward over the autograd graph of the capture
 # -----------------------------------------------------------------------------------------------------------------------
-# Round 3 measured the training step host-bound: 48 of 58 ms were Python — 28 ms building the forward's 99 autograd nodes
-# (allocation, cache lookups, ctypes, stream bookkeeping per layer), 15 ms walking them backward (bench.py host_phases_ms_per_step).
+# Round 3 read the training step as host-bound: 48 of 58 ms of host time inside the step's calls — 28 ms in the forward's 99 autograd
+# nodes, 15 ms walking them backward (bench.py host_phases_ms_per_step).  (Round 4's tools/train_host_probe.py showed most of that to
+# be time blocked on the full launch queue: the Python / launch path costs 17.5 ms per step at any crop size, the step is
+# device-bound.  The capture below stays as an option; it is not what made the step faster.)
 # The forward's launch sequence is the same every iteration — same shapes, same weights at the same addresses — so it is
 # captured ONCE per batch geometry into a HIP graph (hipGraph through torch.cuda.CUDAGraph) and replayed: one graph launch
 # (5 ms of host time) instead of ~600 Python-driven launches.  The capture runs the per-layer Python with autograd on, so it also
 # leaves the forward's autograd graph behind, its saved activations living in the HIP graph's memory pool; every replay rewrites
 # them in place, and the step's backward walks that SAME retained autograd graph (``torch.autograd.grad(..., retain_graph=True)``)
-# eagerly: the dgrad chain on the launch stream, the weight gradients on the side stream next to it.
+# eagerly, on the capture's stream (weight gradients included: ctx.side is off for captured nodes).
 # Why not the backward from a graph as well (it was built first, with torch.cuda.make_graphed_callables, and measured,
 # profiles/README.md): a replayed hipGraph ran its branches back to back on this ROCm — kernel-trace overlap factor 1.06 against
 # 1.51 for the eager two-stream backward — so the step became GPU-bound at 63 ms instead of host-bound at 58.
