@@ -65,7 +65,8 @@ int read_device_arch(char *name, int len);
  *   "conv_wino"       largest Cin that takes the Winograd F(2x2,3x3) kernel (0 = direct implicit-GEMM kernels everywhere)
  *   "conv_sc"         8 (default): gated 3x3/s1 layers with Cin = 32, Cout <= 4 on the vector-pipe kernel, 8 input channels per LDS
  *                     phase (16, 32: larger phases); 0: on the MFMA kernels
- *   "wgrad_wino"      1 (default): 3x3/s1 weight gradients in the Winograd F(4x4,3x3) domain; 0: direct MFMA kernel
+ *   "wgrad_wino"      1 (default): 3x3/s1 weight gradients in the Winograd F(4x4,3x3) domain; 0: direct MFMA kernel; v > 1: the same
+ *                     with 128 v workgroups aimed at (default 256)
  *   "conv_wave", "conv_kc32", "conv_stagger", "unet_streams": see csrc/conv.hip, csrc/unet.cpp.
  * read_tuning_key(i) enumerates the keys (NULL past the end); read_tuning_get reads the current value, so that a
  * benchmark can record the state it ran with. */

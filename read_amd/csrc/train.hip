@@ -777,7 +777,7 @@ __global__ void wgrad_reduce_kernel(const float *__restrict__ partial, int split
 //     use, transforms both (144 + 90 FMAs / adds) and writes V[36][8][32] and M[36][8][32] to LDS;
 //   * wave w owns frequencies 9w .. 9w + 8: v_mfma_f32_32x32x2_f32 with A[i][k] = V[f][2s + k][i], B[k][j] = M[f][2s + k][j] — both
 //     operands are conflict-free ds_read_b32 — 36 MFMAs per iteration, 144 accumulator registers;
-//   * two workgroups per CU (74 KiB of LDS each) cover each other's transform phases.
+//   * 74 KiB of LDS per workgroup (two fit a CU; one per CU over the chip measured best: fewer split-K partials).
 // Partials [split][tile pair][36][32][32] go to the scratch buffer; wgrad_wino4_reduce_kernel sums the splits and applies G^T . G.
 // ---------------------------------------------------------------------------------------------------------------------
 struct Wg4 {
@@ -1461,7 +1461,10 @@ Wgrad4Plan wgrad4_plan(int Cin, int Cout, int H)
     p.tiles_ci = Cin / 32;
     p.tiles_co = (2 * Cp + 31) / 32;
     const int wgs = p.tiles_ci * p.tiles_co, tiles_y = H / 4;
-    int splits = (512 + wgs - 1) / wgs;                          // two workgroups per CU over the chip
+    // one workgroup per CU over the chip (measured, training it/s: 256 workgroups 25.7, 512: 25.5, 768: 24.9, 1024: 24.8, 2048: 23.8 —
+    // fewer splits mean fewer partials to write and sum); knob values > 1: workgroups aimed at / 128
+    const int target = readhip::g_wgrad_wino > 1 ? 128 * readhip::g_wgrad_wino : 256;
+    int splits = (target + wgs - 1) / wgs;
     if (splits > tiles_y) splits = tiles_y;
     if (splits < 1) splits = 1;
     p.rows_per_split = (tiles_y + splits - 1) / splits;

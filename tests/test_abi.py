@@ -132,7 +132,7 @@ def test_wgrad_kernel_choice_and_scratch():
         _lib.check(L.read_tuning_set(b"wgrad_wino", 1))
     for (cin, cout, H) in ((32, 32, 2176), (256, 256, 272), (64, 3, 128), (128, 40, 36)):
         tiles = (cin // 32) * ((2 * ((cout + 7) // 8 * 8) + 31) // 32)
-        splits_max = -(-512 // tiles)
+        splits_max = -(-256 // tiles)
         assert L.read_conv_wgrad_scratch_floats(cin, cout, 3, H) >= min(splits_max, H // 4) * tiles * 36 * 1024 * 0.5
         assert L.read_conv_wgrad_scratch_floats(cin, cout, 3, H) > 0 and L.read_conv_wgrad_scratch_floats(cin, cout, 3, H + 1) > 0
 
