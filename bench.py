@@ -550,6 +550,8 @@ def run_train(a, dev, street=None, steps=None, warm=None, cpu_timing=True, do_ve
            # host time inside the step's calls WITHOUT a sync: includes waiting for room in the launch queue — the Python / launch
            # path itself costs 17.5 ms per step (tools/train_host_probe.py: the same at 32 x 32 crops), the step is device-bound
            "host_enqueue_ms_per_step": 1e3 * dt_host / steps,
+           "bound": "device: tools/train_host_probe.py (profiles/r4_train_host_probe.log) measures the host path of a step at 17.5 ms "
+                    "whatever the crop size; host_enqueue_ms_per_step includes the time blocked on the full launch queue",
            "step_path": step_path, "host_phases_ms_per_step": host_phases,
            "final_loss": float(loss.detach()), "tuning": _lib.tuning_state(), "cpu_baseline": base, "verified": verified}
     pipe.dataset_unload([DS()])
