@@ -65,6 +65,8 @@ int read_device_arch(char *name, int len);
  *   "conv_wino"       largest Cin that takes the Winograd F(2x2,3x3) kernel (0 = direct implicit-GEMM kernels everywhere)
  *   "conv_sc"         8 (default): gated 3x3/s1 layers with Cin = 32, Cout <= 4 on the vector-pipe kernel, 8 input channels per LDS
  *                     phase (16, 32: larger phases); 0: on the MFMA kernels
+ *   "conv_w4x2"       0 (default); 1: EXPERIMENTAL two-waves-per-SIMD cut of the F(4x4,3x3) kernel for inference launches — written at
+ *                     the end of round 4 without GPU time to validate it; tests/test_gpu_conv.py runs it when READ_AMD_TEST_W4X2=1
  *   "wgrad_wino"      1 (default): 3x3/s1 weight gradients in the Winograd F(4x4,3x3) domain; 0: direct MFMA kernel; v > 1: the same
  *                     with 128 v workgroups aimed at (default 256)
  *   "conv_wave", "conv_kc32", "conv_stagger", "unet_streams": see csrc/conv.hip, csrc/unet.cpp.

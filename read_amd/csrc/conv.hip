@@ -1941,6 +1941,366 @@ __global__ __launch_bounds__(256, 1) void gated_conv_wino4_kernel(const ConvKArg
 }
 
 // ------------------------------------------------------------------------------------------
+// EXPERIMENTAL, OFF (read_tuning_set("conv_w4x2", 1)), written at the end of round 4 with no GPU time left to run it: the
+// F(4x4,3x3) kernel above cut for TWO waves per SIMD.  Why (DESIGN.md 12.1 d): one wave per SIMD issues a vector instruction every
+// 5.2 cycles, two waves one every 2.6 (tools/valu_probe.py), and a VALU instruction behind an fp32 MFMA costs 4 - 11.5 cycles with one
+// wave per SIMD against 1.4 - 2.5 with two (tools/issue_probe.py): the transform and the 820-instruction epilogue are paid at the
+// single-wave price above.  The accumulators do not shrink with the tile (36 frequencies x a 16 x 16 MFMA block), so the cut is over
+// FREQUENCIES: eight waves per workgroup, wave (co = w & 3, fh = w >> 2) owns output channels 8 co .. 8 co + 7 and frequency rows
+// 3 fh .. 3 fh + 2 of the 6 x 6 grid — 18 frequencies, 72 accumulators, the SAME weight blob (a wave reads its half of its
+// channel octet's 36 fragments) and the same V buffer.
+//   * input transform by halves: thread (channel c16, tile, h = fh) reads the whole 6 x 6 patch and forms rows 3 h .. 3 h + 2 of
+//     B^T d (8 / 6 packed operations per column pair) and their products with B (the row routine above, 3 x 9): its half's 18
+//     frequencies;
+//   * per 16-channel chunk 72 MFMAs per wave, the shadow schedule of the kernel above compressed onto them;
+//   * output transform by halves (tests/test_wino4x2_model.py): the column pass is local to a frequency row; the row pass is
+//     linear in the rows, so a wave forms partial sums of all four output rows from its three rows, keeps output rows 2 fh, 2 fh + 1
+//     and hands the other two to its partner wave (w ^ 4, by construction on the same SIMD) through LDS — 8 float4 per lane each
+//     way in two rounds of 4 KiB per wave, a message counter and a read counter per wave instead of a workgroup barrier — then gates
+//     its two rows (half of the epilogue's instructions each).
+// Inference launches without the FAM multiply only.  tests/test_gpu_conv.py::test_winograd_f4_two_waves_per_simd_variant runs it
+// against the kernel above when READ_AMD_TEST_W4X2=1.
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(512, 1) void gated_conv_wino4x2_kernel(const ConvKArgs a)
+{
+    using WG = Wino4Geom;
+    constexpr int NI = (WG::NE + 511) / 512;                   // 1360 float4 of a raw chunk over 512 threads: 3 each
+    constexpr int XCH = WG::LDS_FLOATS, XW = 4 * 64 * 4;       // exchange area: 4 float4 slots x 64 lanes per wave (4 KiB)
+    __shared__ __attribute__((aligned(16))) float lds[WG::LDS_FLOATS + 8 * XW];
+    __shared__ int xflag[16];                                  // [w]: messages written by wave w; [8 + w]: messages of its partner wave w has read
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6), co = wv & 3, fh = wv >> 2;
+    const SrcDev s = a.src[0];
+    const int groups = a.CoutPad >> 5, G = gridDim.x;
+    const int g = blockIdx.x % groups;
+    const int n = a.nchunks;
+    if (tid < 16) xflag[tid] = 0;
+
+    int by = (blockIdx.x / groups) / a.tiles_x, bx = (blockIdx.x / groups) % a.tiles_x;      // running unit (8 x 32 pixel block)
+    int pby = by, pbx = bx, pu = blockIdx.x, pchunk = 0;                                     // prefetch cursor (raw patches)
+    auto step_tile = [&](int &ty_, int &tx_) {
+        ty_ += a.wino_dby;
+        tx_ += a.wino_dbx;
+        if (tx_ >= a.tiles_x) {
+            tx_ -= a.tiles_x;
+            ++ty_;
+        }
+    };
+    int loff[NI];
+    unsigned rel[NI], aoff[NI];
+    constexpr unsigned OOR = 0x80000000u;
+#pragma unroll
+    for (int i = 0; i < NI; ++i) {
+        const int e = tid + i * 512, q = e % 4, pix = e / 4;
+        loff[i] = e < WG::NE ? (pix / WG::IW) * WG::RS + (pix % WG::IW) * WG::PS + 4 * q : WG::KC;   // else: pixel 0's pad floats
+        rel[i] = (unsigned)(((pix / WG::IW) * s.W + pix % WG::IW) * s.C + 4 * q) * 4u;
+    }
+    const unsigned src_bytes = (unsigned)(a.inH * s.W * s.C) * 4u;
+    const auto rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(s.p), 0, src_bytes, 0x00020000);
+    auto set_patch = [&]() {
+        const int y0 = pby * 8 - 1, x0 = pbx * 32 - 1;
+        const unsigned base = (unsigned)((y0 * s.W + x0) * s.C) * 4u;          // may wrap: only lanes inside the image use it
+#pragma unroll
+        for (int i = 0; i < NI; ++i) {
+            const int e = tid + i * 512, pix = e / 4, ppy = pix / WG::IW, ppx = pix % WG::IW;
+            const bool ok = (e < WG::NE) & (ppy >= -y0) & (ppy < a.inH - y0) & (ppx >= -x0) & (ppx < a.inW - x0);
+            aoff[i] = ok ? base + rel[i] : OOR;
+        }
+    };
+    auto advance = [&]() {
+        if (++pchunk == n) {
+            pchunk = 0;
+            if (pu + G < a.n_units) {
+                pu += G;
+                step_tile(pby, pbx);
+            }
+            set_patch();
+        }
+    };
+    float4 st[NI];
+    auto gload1 = [&](int i) {
+        st[i] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, aoff[i], pchunk * (WG::KC * 4), 0));
+    };
+    auto lwrite1 = [&](int i, int obuf) {
+        *reinterpret_cast<float4 *>(__builtin_assume_aligned(lds + obuf + loff[i], 16)) = st[i];
+    };
+
+    // ---- transform role: thread = (input channel c16 of the chunk, tile tl, frequency-row half = fh of its wave)
+    const int c16 = tid & 15, tl = (tid >> 4) & 15;
+    const int rbase = ((4 * (tl >> 3)) * WG::IW + 4 * (tl & 7)) * WG::PS + c16;
+    const int vwoff = WG::V0 + tl * 16 + ((c16 >> 2) ^ ((tl >> 1) & 3)) * 4 + (c16 & 3);
+    f32x2 d2[6][3];                                            // the patch as column pairs; after the column step rows 0..2 hold B^T d rows 3 fh ..
+    auto bt3v = [&](int c) {                                   // rows 3 fh .. 3 fh + 2 of B^T applied down column pair c
+        const f32x2 x0 = d2[0][c], x1 = d2[1][c], x2 = d2[2][c], x3 = d2[3][c], x4 = d2[4][c], x5 = d2[5][c];
+        if (fh == 0) {
+            const f32x2 p = pk_add(x3, x4), q = pk_add(x1, x2), r = pk_sub(x4, x3), u = pk_sub(x1, x2);
+            d2[0][c] = __builtin_elementwise_fma(x2, f32x2{-5.0f, -5.0f}, __builtin_elementwise_fma(x0, f32x2{4.0f, 4.0f}, x4));
+            d2[1][c] = __builtin_elementwise_fma(q, f32x2{-4.0f, -4.0f}, p);
+            d2[2][c] = __builtin_elementwise_fma(u, f32x2{4.0f, 4.0f}, r);
+        } else {
+            const f32x2 f = pk_sub(x3, x1), h = pk_sub(x4, x2);
+            d2[0][c] = __builtin_elementwise_fma(f, f32x2{2.0f, 2.0f}, h);
+            d2[1][c] = __builtin_elementwise_fma(f, f32x2{-2.0f, -2.0f}, h);
+            d2[2][c] = __builtin_elementwise_fma(x3, f32x2{-5.0f, -5.0f}, __builtin_elementwise_fma(x1, f32x2{4.0f, 4.0f}, x5));
+        }
+    };
+    const f32x2 KA = {4.0f, -5.0f}, KB = {2.0f, 0.0f};
+    auto bt6row = [&](f32x2 &P0, f32x2 &P1, f32x2 &P2) {        // as in the kernel above: (x0,x1)(x2,x3)(x4,x5) -> (y0,y5)(y1,y2)(y3,y4)
+        f32x2 T, Y05, QU, PR, Y12, Y34, F2, H2;
+        asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[0,0,0] op_sel_hi:[1,0,1]" : "=v"(T) : "v"(P0), "v"(KA), "v"(P2));
+        asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[0,1,0] op_sel_hi:[1,1,1]" : "=v"(Y05) : "v"(P1), "v"(KA), "v"(T));
+        asm("v_pk_add_f32 %0, %1, %2 op_sel:[1,0] op_sel_hi:[1,0] neg_hi:[0,1]" : "=v"(QU) : "v"(P0), "v"(P1));
+        asm("v_pk_add_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[0,1] neg_hi:[0,1]" : "=v"(PR) : "v"(P2), "v"(P1));
+        asm("v_pk_add_f32 %0, %1, %2 op_sel:[1,1] op_sel_hi:[1,1] neg_lo:[0,1] neg_hi:[1,0]" : "=v"(F2) : "v"(P1), "v"(P0));
+        asm("v_pk_add_f32 %0, %1, %2 op_sel:[0,0] op_sel_hi:[0,0] neg_lo:[0,1] neg_hi:[0,1]" : "=v"(H2) : "v"(P2), "v"(P1));
+        asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[0,0,0] op_sel_hi:[1,0,1] neg_lo:[1,0,0]" : "=v"(Y12) : "v"(QU), "v"(KA), "v"(PR));
+        asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[0,0,0] op_sel_hi:[1,0,1]" : "=v"(Y34) : "v"(F2), "v"(KB), "v"(H2));
+        P0 = Y05;
+        P1 = Y12;
+        P2 = Y34;
+    };
+    // step k of the next chunk's transform: -36..-1 reads, 18..20 column pairs, 21..23 rows, 24..32 stores (two each)
+    auto t_step = [&](const float *raw, int vb, int k) {
+        if (k < 0) {
+            const int e = k + 36, r = e / 6, c = e % 6;
+            d2[r][c >> 1][c & 1] = raw[rbase + (r * WG::IW + c) * WG::PS];
+        } else if (k < 21) {
+            bt3v(k - 18);
+        } else if (k < 24) {
+            const int r = k - 21;
+            bt6row(d2[r][0], d2[r][1], d2[r][2]);
+        } else {
+            const int r = (k - 24) / 3, j = (k - 24) % 3;             // pair j of local row r holds frequencies (0, 5), (1, 2), (3, 4) of row 3 fh + r
+            const int f0 = (3 * fh + r) * 6 + (j == 0 ? 0 : j == 1 ? 1 : 3), f1 = (3 * fh + r) * 6 + (j == 0 ? 5 : j == 1 ? 2 : 4);
+            lds[vwoff + vb + f0 * 256] = d2[r][j].x;
+            lds[vwoff + vb + f1 * 256] = d2[r][j].y;
+        }
+    };
+    constexpr int T_FIRST = -36, T_STEPS = 33;
+    constexpr int BAR_M = 63;                                  // MFMA slot of the per-stage barrier (of 72)
+
+    // ---- A operand: the same blob as the kernel above; this wave's half of its octet's fragments.  Ring of 9 (18 % 9 == 0: a
+    // frequency keeps its slot across chunks), fetched 7 ahead
+    const float *const wbase = a.wp_w4 + ((size_t)(g * 4 + co) * n) * (36 * 256);
+    const auto wrsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(wbase), 0, (unsigned)n * (36 * 1024), 0x00020000);
+    const unsigned wvoff = lane * 16;
+    float4 Wq[9];
+    constexpr int WLEAD = 7;
+    auto wload1 = [&](int slot, int chunk, int fql) {
+        Wq[slot] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(wrsrc, wvoff, (chunk * 36 + 18 * fh + fql) * 1024, 0));
+    };
+    // ---- B operand: Vbuf[frequency][tile t16][slot]; ring of 6, fetched 4 ahead
+    const int t16 = lane & 15, kl = lane >> 4;
+    const int vlane = t16 * 16 + 4 * (kl ^ ((t16 >> 1) & 3));
+    float4 Bq[6];
+    auto bload1 = [&](int slot, int vb, int fql) {
+        Bq[slot] = *reinterpret_cast<const float4 *>(__builtin_assume_aligned(lds + WG::V0 + vb + (18 * fh + fql) * 256 + vlane, 16));
+    };
+
+    f32x4 acc[18];
+    const auto out_rsrc = __builtin_amdgcn_make_buffer_rsrc(a.out, 0, (unsigned)(a.outH * a.outW * a.out_cstride) * 4u, 0x00020000);
+    const auto res_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(a.residual ? a.residual : a.out), 0,
+                                                            (unsigned)(a.outH * a.outW * a.Cout) * 4u, 0x00020000);
+
+    // ---- prologue: raw(0), raw(1) -> LDS, raw(2) -> registers, this half's V(0), the first weight fragments and B operands
+    set_patch();
+#pragma unroll
+    for (int i = 0; i < NI; ++i) gload1(i);
+#pragma unroll
+    for (int j = 0; j < WLEAD; ++j) wload1(j, 0, j);
+#pragma unroll
+    for (int i = 0; i < NI; ++i) lwrite1(i, 0);
+    advance();
+#pragma unroll
+    for (int i = 0; i < NI; ++i) gload1(i);
+#pragma unroll
+    for (int i = 0; i < NI; ++i) lwrite1(i, WG::BUF);
+    advance();
+#pragma unroll
+    for (int i = 0; i < NI; ++i) gload1(i);
+    advance();
+    __syncthreads();
+#pragma unroll
+    for (int k = T_FIRST; k < T_STEPS; ++k)
+        if (k < 0 || k >= 18) t_step(lds, 0, k);
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < 4; ++j) bload1(j, 0, j);
+
+    int raw_cur = 0, raw_nxt = WG::BUF;
+    int v_cur = 0, v_nxt = WG::VBUF;
+    int n_msg = 0;                                             // messages this wave has sent (two per unit)
+
+    auto stage_body = [&](auto first_tag, int chunk) {
+        constexpr bool FIRST = decltype(first_tag)::value;
+        int nchunk = chunk + 1;
+        nchunk = nchunk == n ? 0 : nchunk;
+        const float *traw = lds + raw_nxt;
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int pr = 0; pr < 9; ++pr)
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+#pragma unroll
+                for (int sidx = 0; sidx < 2; ++sidx) {
+                    const int fq = 2 * pr + sidx, m = pr * 8 + e * 2 + sidx;
+                    const float4 wv4 = Wq[fq % 9], vv4 = Bq[fq % 6];
+                    const float we = e == 0 ? wv4.x : e == 1 ? wv4.y : e == 2 ? wv4.z : wv4.w;
+                    const float ve = e == 0 ? vv4.x : e == 1 ? vv4.y : e == 2 ? vv4.z : vv4.w;
+                    if (FIRST && e == 0) {
+                        const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+                        acc[fq] = __builtin_amdgcn_mfma_f32_16x16x4f32(we, ve, zero, 0, 0, 0);
+                    } else
+                        acc[fq] = __builtin_amdgcn_mfma_f32_16x16x4f32(we, ve, acc[fq], 0, 0, 0);
+                    // ---- shadow items
+                    const int mm = e * 2 + sidx;
+                    if (mm < 2 && 2 * pr + 4 + mm < 18) bload1((2 * pr + 4 + mm) % 6, v_cur, 2 * pr + 4 + mm);       // B operands 4 ahead
+                    if (mm == 2 || mm == 6) {                                                                        // weights 7 frequencies ahead
+                        const int wf = 2 * pr + WLEAD + (mm == 6);
+                        if (wf < 18) wload1(wf % 9, chunk, wf);
+                        else wload1(wf % 9, nchunk, wf - 18);
+                    }
+                    if (m < 36) t_step(traw, v_nxt, m - 36);                                    // the next chunk's transform: reads ...
+                    if (m >= 38 && m < 44 && !(m & 1)) t_step(traw, v_nxt, 18 + ((m - 38) >> 1));   // ... column pairs ...
+                    if (m >= 44 && m < 50 && !(m & 1)) t_step(traw, v_nxt, 21 + ((m - 44) >> 1));   // ... rows ...
+                    if (m >= 50 && m < 59) t_step(traw, v_nxt, 24 + (m - 50));                  // ... stores
+                    if (m >= 59 && m - 59 < NI) lwrite1(m - 59, raw_cur);                        // raw(chunk + 2): registers -> LDS
+                    if (m > BAR_M && m - (BAR_M + 1) < NI) gload1(m - (BAR_M + 1));              // raw(chunk + 3) -> registers
+                    if (m == BAR_M) {                                                            // V(chunk + 1) and raw(chunk + 2) complete in every wave
+                        __syncthreads();
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) bload1(j, v_nxt, j);
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+        advance();
+        const int o = raw_cur;
+        raw_cur = raw_nxt;
+        raw_nxt = o;
+        const int v = v_cur;
+        v_cur = v_nxt;
+        v_nxt = v;
+    };
+
+    float *const xme = lds + XCH + wv * XW + lane * 4;
+    const float *const xpa = lds + XCH + (wv ^ 4) * XW + lane * 4;
+    for (int u = blockIdx.x; u < a.n_units; u += G) {
+        stage_body(std::true_type{}, 0);
+        for (int chunk = 1; chunk < n; ++chunk) stage_body(std::false_type{}, chunk);
+
+        // ================= unit epilogue =================
+        __builtin_amdgcn_s_setprio(1);
+        const int cq = (lane >> 4) & 1, hf = lane >> 5;
+        const int c0 = g * 32 + co * 8 + 4 * cq;
+        const int oy = by * 8 + 4 * (t16 >> 3) + 2 * fh + hf, ox = bx * 32 + 4 * (t16 & 7);     // this lane finishes ONE row of its tile
+        const f32x4 bf = *reinterpret_cast<const f32x4 *>(a.params + c0);
+        const f32x4 bm = *reinterpret_cast<const f32x4 *>(a.params + a.CoutPad + c0);
+        const f32x4 sc = *reinterpret_cast<const f32x4 *>(a.params + 2 * a.CoutPad + c0);
+        const f32x4 sh = *reinterpret_cast<const f32x4 *>(a.params + 3 * a.CoutPad + c0);
+        unsigned rvoff[4], ovoff[4];
+#pragma unroll
+        for (int px = 0; px < 4; ++px) {
+            const bool in = (oy < a.outH) & (ox + px < a.outW) & (c0 < a.Cout);
+            const int pix = oy * a.outW + ox + px;
+            rvoff[px] = in ? (unsigned)((pix * a.Cout + c0) * 4) : OOR;
+            ovoff[px] = in ? (unsigned)((pix * a.out_cstride + c0) * 4) : OOR;
+        }
+        f32x4 rv[4];
+#pragma unroll
+        for (int px = 0; px < 4; ++px) {
+            rv[px] = f32x4{0.f, 0.f, 0.f, 0.f};
+            if (a.residual) rv[px] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(res_rsrc, rvoff[px], 0, 0));
+        }
+        // column pass, local to a frequency row: T[r][q] from M[r][0..5] (acc[6 r + nu])
+        f32x4 T[3][4];
+#pragma unroll
+        for (int r = 0; r < 3; ++r) {
+            const f32x4 s1 = acc[6 * r + 1] + acc[6 * r + 2], d1 = pk_sub4(acc[6 * r + 1], acc[6 * r + 2]);
+            const f32x4 s2 = acc[6 * r + 3] + acc[6 * r + 4], dd = pk_sub4(acc[6 * r + 3], acc[6 * r + 4]);
+            T[r][0] = acc[6 * r] + s1 + s2;
+            T[r][1] = d1 + 2.0f * dd;
+            T[r][2] = s1 + 4.0f * s2;
+            T[r][3] = d1 + 8.0f * dd + acc[6 * r + 5];
+        }
+        // row pass, this half's three rows of A^T = [1 1 1 | 1 1 0; 0 1 -1 | 2 -2 0; 0 1 1 | 4 4 0; 0 1 -1 | 8 -8 1]: partial sums of
+        // all four output rows; `keep` = rows 2 fh, 2 fh + 1, `give` = the partner's rows
+        f32x4 keep[2][4], give[2][4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            if (fh == 0) {
+                const f32x4 sm = T[1][q] + T[2][q], df = pk_sub4(T[1][q], T[2][q]);
+                keep[0][q] = T[0][q] + sm;
+                keep[1][q] = df;
+                give[0][q] = sm;
+                give[1][q] = df;
+            } else {
+                const f32x4 sm = T[0][q] + T[1][q], df = pk_sub4(T[0][q], T[1][q]);
+                give[0][q] = sm;
+                give[1][q] = 2.0f * df;
+                keep[0][q] = 4.0f * sm;
+                keep[1][q] = 8.0f * df + T[2][q];
+            }
+        }
+        // exchange with the partner wave, two rounds of four float4 per lane (columns 0, 1 then 2, 3)
+#pragma unroll
+        for (int round = 0; round < 2; ++round) {
+            const int seq = n_msg + round + 1;
+            while (__hip_atomic_load(&xflag[8 + (wv ^ 4)], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) < seq - 1) __builtin_amdgcn_s_sleep(1);
+#pragma unroll
+            for (int o = 0; o < 2; ++o)
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+                    *reinterpret_cast<f32x4 *>(__builtin_assume_aligned(xme + (o * 2 + j) * 256, 16)) = give[o][2 * round + j];
+            __hip_atomic_store(&xflag[wv], seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+            while (__hip_atomic_load(&xflag[wv ^ 4], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) < seq) __builtin_amdgcn_s_sleep(1);
+#pragma unroll
+            for (int o = 0; o < 2; ++o)
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+                    keep[o][2 * round + j] += *reinterpret_cast<const f32x4 *>(__builtin_assume_aligned(xpa + (o * 2 + j) * 256, 16));
+            __hip_atomic_store(&xflag[8 + wv], seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+        }
+        n_msg += 2;
+        // lanes 0..31 hold conv_f, lanes 32..63 conv_m: exchange the two rows so that the lower half-wave owns row 2 fh and the upper
+        // half row 2 fh + 1, f in one register and m in the other
+        {
+            constexpr float LOG2E = 1.44269504088896341f;
+#pragma unroll
+            for (int px = 0; px < 4; ++px) {
+                u32x4 u0 = __builtin_bit_cast(u32x4, keep[0][px]), u1 = __builtin_bit_cast(u32x4, keep[1][px]);
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const auto sw = __builtin_amdgcn_permlane32_swap(u0[k], u1[k], false, false);
+                    u0[k] = sw[0];
+                    u1[k] = sw[1];
+                }
+                f32x4 f = __builtin_bit_cast(f32x4, u0) + bf;
+                const f32x4 mm = (__builtin_bit_cast(f32x4, u1) + bm) * -LOG2E;
+                if (a.elu) {
+                    const f32x4 fe = f * LOG2E;
+                    f32x4 e;
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) e[k] = __builtin_amdgcn_exp2f(fe[k]);
+                    e = e + f32x4{-1.0f, -1.0f, -1.0f, -1.0f};
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) f[k] = f[k] > 0.0f ? f[k] : e[k];
+                }
+                f32x4 sg, t;
+#pragma unroll
+                for (int k = 0; k < 4; ++k) t[k] = __builtin_amdgcn_exp2f(mm[k]);
+                t = t + f32x4{1.0f, 1.0f, 1.0f, 1.0f};
+#pragma unroll
+                for (int k = 0; k < 4; ++k) sg[k] = __builtin_amdgcn_rcpf(t[k]);
+                const f32x4 v = (f * sg) * sc + sh + rv[px];
+                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), out_rsrc, ovoff[px], 0, 0);
+            }
+        }
+        step_tile(by, bx);
+        __builtin_amdgcn_s_setprio(0);
+    }
+}
+
+// ------------------------------------------------------------------------------------------
 // 3x3 / stride-1 layers with at most FOUR output channels on the vector pipe (READ's output layer, feat_extract.5: 32 -> 3).
 //
 // The matrix cores have no shape for this layer: conv_f and conv_m together have 6 output channels — 6 rows of a 16- or 32-row
@@ -2368,6 +2728,7 @@ int g_conv_px = 1;         // read_tuning_set("conv_px", v): pixel-lane kernel f
 int g_kc32 = 1;            // 32-channel chunks for 1x1 layers whose sources are all multiples of 32 (read_tuning_set("conv_kc32", 0): 16)
 int g_use_wino = 1 << 30;  // read_tuning_set("conv_wino", max Cin): Winograd kernel for eligible 3x3 layers (0 = off)
 int g_w4_grid = 0;        // read_tuning_set("conv_w4_grid", 1): F(4x4) launches with the same number of units per workgroup (measured: see profiles)
+int g_w4x2 = 0;            // read_tuning_set("conv_w4x2", 1): EXPERIMENTAL two-waves-per-SIMD F(4x4) kernel for inference launches (not validated: off)
 int g_w4 = 32;             // read_tuning_set("conv_w4", min Cin): layers with at least this many channels take the Winograd F(4x4,3x3)
 int g_sc = 8;              // read_tuning_set("conv_sc", 0): the output layer (Cout <= 4) back on the F(2x2) MFMA kernel instead of the vector pipe; other values: conv_set_sc
                            // kernel when its weights were supplied (0 = never)
@@ -2654,6 +3015,7 @@ void conv_set_w4(int v) { g_w4 = v < 0 ? 0 : v; }
 void conv_set_w4_grid(int v) { g_w4_grid = v != 0; }
 void conv_set_wino_wgs(int v) { g_wino_wgs = v <= 1 ? 1 : 2; }
 void conv_set_px(int v) { g_conv_px = v < 0 ? 0 : v > 4 ? 4 : v; }
+void conv_set_w4x2(int v) { g_w4x2 = v != 0; }
 void conv_set_sc(int v) { g_sc = v; }           // 0 off; 8 / 16 / 32 = input channels per LDS phase
 int conv_get(const char *key, int *value)
 {
@@ -2662,6 +3024,7 @@ int conv_get(const char *key, int *value)
     else if (!strcmp(key, "conv_kc32")) *value = g_kc32;
     else if (!strcmp(key, "conv_px")) *value = g_conv_px;
     else if (!strcmp(key, "conv_sc")) *value = g_sc;
+    else if (!strcmp(key, "conv_w4x2")) *value = g_w4x2;
     else if (!strcmp(key, "conv_wino_wgs")) *value = g_wino_wgs;
     else if (!strcmp(key, "conv_wino")) *value = g_use_wino;
     else if (!strcmp(key, "conv_w16")) *value = g_w16;
@@ -2983,6 +3346,11 @@ int launch_gated_conv(const read_conv_desc *d, hipStream_t stream)
             }
         }
 #endif
+        if (g_w4x2 && !d->linear && !d->mul) {   // experimental: eight waves per workgroup, frequencies split over wave pairs
+            hipLaunchKernelGGL(gated_conv_wino4x2_kernel, dim3((unsigned)nwg), dim3(512), 0, stream, a);
+            READ_CHECK_LAUNCH();
+            return READ_OK;
+        }
         hipLaunchKernelGGL(fn4, dim3((unsigned)nwg), dim3(256), 0, stream, a);
         READ_CHECK_LAUNCH();
         return READ_OK;

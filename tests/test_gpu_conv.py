@@ -4,6 +4,7 @@
 Tolerance: the kernel accumulates in exact fp32 (v_mfma_f32_32x32x2_f32) but in a different
 order than oneDNN, so results agree to fp32 round-off of a K-long dot product:
 |diff| <= 2e-5 * max(1, |ref|) for K <= 4320 at unit-scale data."""
+import os
 import re
 
 import numpy as np
@@ -102,6 +103,33 @@ def test_winograd_f4_kernel(hip):
         ref = x1 + unet_torch.basic_conv(st, "L", (x1 * x2)[None], 3, elu=False)[0]
         got = gated_conv(_pack(st, [c]), [(_nhwc(x1), 0)], elu=False, mul=_nhwc(x2), residual=_nhwc(x1))
         _close(got, ref, f"FAM through F(4x4) C={c}", scale=10.0)
+
+
+@pytest.mark.skipif(os.environ.get("READ_AMD_TEST_W4X2") != "1",
+                    reason="the two-waves-per-SIMD F(4x4) kernel is experimental and off (written without GPU time left in round 4); "
+                           "READ_AMD_TEST_W4X2=1 runs it")
+def test_winograd_f4_two_waves_per_simd_variant(hip):
+    """knob conv_w4x2: the frequency-split F(4x4,3x3) kernel (eight waves per workgroup; DESIGN.md 12.1 d, tests/test_wino4x2_model.py)
+    against torch and against the one-wave-per-SIMD kernel on the shapes of test_winograd_f4_kernel."""
+    from read_amd import _lib
+    L = _lib.lib()
+    torch.manual_seed(22)
+    try:
+        for j, (c, H, W) in enumerate([(32, 8, 32), (32, 5, 3), (64, 40, 100), (128, 9, 17), (256, 8, 32), (128, 23, 70), (128, 88, 304),
+                                       (256, 44, 152), (96, 14, 37), (160, 3, 65)]):
+            st = _state(c, c, 3, seed=600 + j)
+            x = torch.randn(c, H, W)
+            res = torch.randn(c, H, W)
+            ref = unet_torch.basic_conv(st, "L", x[None], 3, elu=j % 2 == 0)[0] + res
+            pk = _pack(st, [c])
+            outs = {}
+            for knob in (0, 1):
+                _lib.check(L.read_tuning_set(b"conv_w4x2", knob))
+                outs[knob] = gated_conv(pk, [(_nhwc(x), 0)], elu=j % 2 == 0, residual=_nhwc(res), config=-5)
+                _close(outs[knob], ref, f"F(4x4) conv_w4x2={knob} {c}->{c} {H}x{W}", scale=10.0)
+            assert float((outs[0] - outs[1]).abs().max()) <= 2e-4 * (1 + float(ref.abs().max()))
+    finally:
+        _lib.check(L.read_tuning_set(b"conv_w4x2", 0))
 
 
 def test_winograd_kernel_odd_channel_counts_and_strides(hip):
