@@ -52,3 +52,82 @@ def test_input_transform_by_frequency_row_halves():
     top = np.array([4 * c[0] - 5 * c[2] + c[4], a + b, a - b])
     bot = np.array([cc + 2 * e, cc - 2 * e, 4 * c[1] - 5 * c[3] + c[5]])
     assert np.abs(np.concatenate([top, bot]) - B @ c).max() <= 1e-12
+
+
+def test_lane_level_model_of_the_split_kernel():
+    """The index maps of gated_conv_wino4x2_kernel (csrc/conv.hip), mirrored expression by expression: thread (c16, tile, h) of the
+    half transforms and the V slots it writes, wave (co, fh) with its half of the octet's weight fragments, the 18 accumulators,
+    the partial row pass with keep / give, the hand-over between waves w and w ^ 4, the half-wave swap that pairs conv_f with
+    conv_m, and the pixel / channel each lane ends up storing — against torch's conv2d for both branches."""
+    import torch
+    import torch.nn.functional as F
+    from tests.wino4_ref import LANE, mfma_16x16x4, pack_w4
+    rng = np.random.default_rng(11)
+    cin, cout, H, W = 32, 32, 8, 32                                     # one unit, two 16-channel chunks, one channel group
+    wf = rng.standard_normal((cout, cin, 3, 3)).astype(np.float32) * 0.2
+    wm = rng.standard_normal((cout, cin, 3, 3)).astype(np.float32) * 0.2
+    x = rng.standard_normal((H, W, cin)).astype(np.float32)
+    P = pack_w4(wf, wm).reshape(1, 4, cin // 16, 36, 64, 4)
+    xp = np.zeros((H + 20, W + 68, cin), np.float32)
+    xp[1:H + 1, 1:W + 1] = x
+    t16, kl = LANE & 15, LANE >> 4
+    slot = kl ^ ((t16 >> 1) & 3)
+    acc = np.zeros((8, 18, 64, 4), np.float32)                          # [wave][local frequency][lane][register]
+    tid = np.arange(512)
+    for c in range(cin // 16):
+        vbuf = np.full((36, 16, 16), np.nan, np.float32)
+        for th in tid:                                                  # transform role: c16 = tid & 15, tl = (tid >> 4) & 15, h = tid >> 8
+            c16, tl, h = th & 15, (th >> 4) & 15, th >> 8
+            d = xp[4 * (tl >> 3):4 * (tl >> 3) + 6, 4 * (tl & 7):4 * (tl & 7) + 6, 16 * c + c16]
+            rows = BT[3 * h:3 * h + 3] @ d                              # bt3v: rows 3 h .. 3 h + 2 of B^T d, all six columns
+            V = rows @ BT.T                                             # bt6row on each of the three rows
+            sw = ((c16 >> 2) ^ ((tl >> 1) & 3)) * 4 + (c16 & 3)
+            for r in range(3):
+                for nu in range(6):
+                    vbuf[(3 * h + r) * 6 + nu, tl, sw] = V[r, nu]
+        assert not np.isnan(vbuf).any()
+        for w in range(8):
+            co, fh = w & 3, w >> 2
+            for fql in range(18):
+                fq = 18 * fh + fql
+                Bop = vbuf[fq][t16][:, None, :].reshape(64, 16)[np.arange(64)[:, None], (slot * 4)[:, None] + np.arange(4)[None, :]]
+                for e in range(4):
+                    acc[w, fql] += mfma_16x16x4(P[0, co, c, fq][:, e], Bop[:, e])
+    # epilogue per wave: column pass, partial row pass
+    keep = np.zeros((8, 2, 4, 64, 4), np.float32)
+    give = np.zeros((8, 2, 4, 64, 4), np.float32)
+    for w in range(8):
+        fh = w >> 2
+        T = np.zeros((3, 4, 64, 4), np.float32)
+        for r in range(3):
+            M = acc[w, 6 * r:6 * r + 6]
+            s1, d1, s2, dd = M[1] + M[2], M[1] - M[2], M[3] + M[4], M[3] - M[4]
+            T[r] = np.stack([M[0] + s1 + s2, d1 + 2 * dd, s1 + 4 * s2, d1 + 8 * dd + M[5]])
+        for q in range(4):
+            if fh == 0:
+                sm, df = T[1][q] + T[2][q], T[1][q] - T[2][q]
+                keep[w, 0, q], keep[w, 1, q], give[w, 0, q], give[w, 1, q] = T[0][q] + sm, df, sm, df
+            else:
+                sm, df = T[0][q] + T[1][q], T[0][q] - T[1][q]
+                give[w, 0, q], give[w, 1, q], keep[w, 0, q], keep[w, 1, q] = sm, 2 * df, 4 * sm, 8 * df + T[2][q]
+    f = np.zeros((H, W, cout), np.float32)
+    m = np.zeros((H, W, cout), np.float32)
+    for w in range(8):
+        co, fh = w & 3, w >> 2
+        Y = keep[w] + give[w ^ 4]                                       # the partner's message: its `give` rows are this wave's rows, same (o, q) slots
+        for px in range(4):
+            u0, u1 = Y[0, px].copy(), Y[1, px].copy()                   # rows 2 fh and 2 fh + 1; lanes 0..31 conv_f, 32..63 conv_m
+            u0n, u1n = u0.copy(), u1.copy()
+            u0n[32:], u1n[:32] = u1[:32], u0[32:]                       # v_permlane32_swap: upper half of u0 <-> lower half of u1
+            for l in range(64):
+                cq, hf = (l >> 4) & 1, l >> 5
+                c0 = co * 8 + 4 * cq
+                oy = 4 * ((l & 15) >> 3) + 2 * fh + hf
+                ox = 4 * ((l & 15) & 7) + px
+                f[oy, ox, c0:c0 + 4] = u0n[l]
+                m[oy, ox, c0:c0 + 4] = u1n[l]
+    xt = torch.from_numpy(x).permute(2, 0, 1)[None]
+    ref_f = F.conv2d(xt, torch.from_numpy(wf), padding=1)[0].permute(1, 2, 0).numpy()
+    ref_m = F.conv2d(xt, torch.from_numpy(wm), padding=1)[0].permute(1, 2, 0).numpy()
+    assert np.abs(f - ref_f).max() <= 2e-4 * (1 + np.abs(ref_f).max()), np.abs(f - ref_f).max()
+    assert np.abs(m - ref_m).max() <= 2e-4 * (1 + np.abs(ref_m).max()), np.abs(m - ref_m).max()
