@@ -2030,9 +2030,11 @@ __global__ __launch_bounds__(512, 1) void gated_conv_wino4x2_kernel(const ConvKA
     const int rbase = ((4 * (tl >> 3)) * WG::IW + 4 * (tl & 7)) * WG::PS + c16;
     const int vwoff = WG::V0 + tl * 16 + ((c16 >> 2) ^ ((tl >> 1) & 3)) * 4 + (c16 & 3);
     f32x2 d2[6][3];                                            // the patch as column pairs; after the column step rows 0..2 hold B^T d rows 3 fh ..
-    auto bt3v = [&](int c) {                                   // rows 3 fh .. 3 fh + 2 of B^T applied down column pair c
+    // the half-specific arithmetic takes the half as a compile-time tag: the caller branches ONCE per stage (wave-uniform), so
+    // that no branch sits between the MFMAs
+    auto bt3v = [&](auto half, int c) {                        // rows 3 fh .. 3 fh + 2 of B^T applied down column pair c
         const f32x2 x0 = d2[0][c], x1 = d2[1][c], x2 = d2[2][c], x3 = d2[3][c], x4 = d2[4][c], x5 = d2[5][c];
-        if (fh == 0) {
+        if constexpr (decltype(half)::value == 0) {
             const f32x2 p = pk_add(x3, x4), q = pk_add(x1, x2), r = pk_sub(x4, x3), u = pk_sub(x1, x2);
             d2[0][c] = __builtin_elementwise_fma(x2, f32x2{-5.0f, -5.0f}, __builtin_elementwise_fma(x0, f32x2{4.0f, 4.0f}, x4));
             d2[1][c] = __builtin_elementwise_fma(q, f32x2{-4.0f, -4.0f}, p);
@@ -2060,12 +2062,12 @@ __global__ __launch_bounds__(512, 1) void gated_conv_wino4x2_kernel(const ConvKA
         P2 = Y34;
     };
     // step k of the next chunk's transform: -36..-1 reads, 18..20 column pairs, 21..23 rows, 24..32 stores (two each)
-    auto t_step = [&](const float *raw, int vb, int k) {
+    auto t_step = [&](auto half, const float *raw, int vb, int k) {
         if (k < 0) {
             const int e = k + 36, r = e / 6, c = e % 6;
             d2[r][c >> 1][c & 1] = raw[rbase + (r * WG::IW + c) * WG::PS];
         } else if (k < 21) {
-            bt3v(k - 18);
+            bt3v(half, k - 18);
         } else if (k < 24) {
             const int r = k - 21;
             bt6row(d2[r][0], d2[r][1], d2[r][2]);
@@ -2079,13 +2081,13 @@ __global__ __launch_bounds__(512, 1) void gated_conv_wino4x2_kernel(const ConvKA
     constexpr int T_FIRST = -36, T_STEPS = 33;
     constexpr int BAR_M = 63;                                  // MFMA slot of the per-stage barrier (of 72)
 
-    // ---- A operand: the same blob as the kernel above; this wave's half of its octet's fragments.  Ring of 9 (18 % 9 == 0: a
-    // frequency keeps its slot across chunks), fetched 7 ahead
+    // ---- A operand: the same blob as the kernel above; this wave's half of its octet's fragments.  Ring of 6 (18 % 6 == 0: a
+    // frequency keeps its slot across chunks), fetched 4 ahead (a ring of 9 / 7 ahead spilled: 256 registers per wave at 2 waves per SIMD)
     const float *const wbase = a.wp_w4 + ((size_t)(g * 4 + co) * n) * (36 * 256);
     const auto wrsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(wbase), 0, (unsigned)n * (36 * 1024), 0x00020000);
     const unsigned wvoff = lane * 16;
-    float4 Wq[9];
-    constexpr int WLEAD = 7;
+    float4 Wq[6];
+    constexpr int WLEAD = 4;
     auto wload1 = [&](int slot, int chunk, int fql) {
         Wq[slot] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(wrsrc, wvoff, (chunk * 36 + 18 * fh + fql) * 1024, 0));
     };
@@ -2120,9 +2122,15 @@ __global__ __launch_bounds__(512, 1) void gated_conv_wino4x2_kernel(const ConvKA
     for (int i = 0; i < NI; ++i) gload1(i);
     advance();
     __syncthreads();
+    if (fh == 0) {
 #pragma unroll
-    for (int k = T_FIRST; k < T_STEPS; ++k)
-        if (k < 0 || k >= 18) t_step(lds, 0, k);
+        for (int k = T_FIRST; k < T_STEPS; ++k)
+            if (k < 0 || k >= 18) t_step(std::integral_constant<int, 0>{}, lds, 0, k);
+    } else {
+#pragma unroll
+        for (int k = T_FIRST; k < T_STEPS; ++k)
+            if (k < 0 || k >= 18) t_step(std::integral_constant<int, 1>{}, lds, 0, k);
+    }
     __syncthreads();
 #pragma unroll
     for (int j = 0; j < 4; ++j) bload1(j, 0, j);
@@ -2131,7 +2139,7 @@ __global__ __launch_bounds__(512, 1) void gated_conv_wino4x2_kernel(const ConvKA
     int v_cur = 0, v_nxt = WG::VBUF;
     int n_msg = 0;                                             // messages this wave has sent (two per unit)
 
-    auto stage_body = [&](auto first_tag, int chunk) {
+    auto stage_body = [&](auto first_tag, auto half, int chunk) {
         constexpr bool FIRST = decltype(first_tag)::value;
         int nchunk = chunk + 1;
         nchunk = nchunk == n ? 0 : nchunk;
@@ -2144,7 +2152,7 @@ __global__ __launch_bounds__(512, 1) void gated_conv_wino4x2_kernel(const ConvKA
 #pragma unroll
                 for (int sidx = 0; sidx < 2; ++sidx) {
                     const int fq = 2 * pr + sidx, m = pr * 8 + e * 2 + sidx;
-                    const float4 wv4 = Wq[fq % 9], vv4 = Bq[fq % 6];
+                    const float4 wv4 = Wq[fq % 6], vv4 = Bq[fq % 6];
                     const float we = e == 0 ? wv4.x : e == 1 ? wv4.y : e == 2 ? wv4.z : wv4.w;
                     const float ve = e == 0 ? vv4.x : e == 1 ? vv4.y : e == 2 ? vv4.z : vv4.w;
                     if (FIRST && e == 0) {
@@ -2155,15 +2163,15 @@ __global__ __launch_bounds__(512, 1) void gated_conv_wino4x2_kernel(const ConvKA
                     // ---- shadow items
                     const int mm = e * 2 + sidx;
                     if (mm < 2 && 2 * pr + 4 + mm < 18) bload1((2 * pr + 4 + mm) % 6, v_cur, 2 * pr + 4 + mm);       // B operands 4 ahead
-                    if (mm == 2 || mm == 6) {                                                                        // weights 7 frequencies ahead
+                    if (mm == 2 || mm == 6) {                                                                        // weights 4 frequencies ahead
                         const int wf = 2 * pr + WLEAD + (mm == 6);
-                        if (wf < 18) wload1(wf % 9, chunk, wf);
-                        else wload1(wf % 9, nchunk, wf - 18);
+                        if (wf < 18) wload1(wf % 6, chunk, wf);
+                        else wload1(wf % 6, nchunk, wf - 18);
                     }
-                    if (m < 36) t_step(traw, v_nxt, m - 36);                                    // the next chunk's transform: reads ...
-                    if (m >= 38 && m < 44 && !(m & 1)) t_step(traw, v_nxt, 18 + ((m - 38) >> 1));   // ... column pairs ...
-                    if (m >= 44 && m < 50 && !(m & 1)) t_step(traw, v_nxt, 21 + ((m - 44) >> 1));   // ... rows ...
-                    if (m >= 50 && m < 59) t_step(traw, v_nxt, 24 + (m - 50));                  // ... stores
+                    if (m < 36) t_step(half, traw, v_nxt, m - 36);                                    // the next chunk's transform: reads ...
+                    if (m >= 38 && m < 44 && !(m & 1)) t_step(half, traw, v_nxt, 18 + ((m - 38) >> 1));   // ... column pairs ...
+                    if (m >= 44 && m < 50 && !(m & 1)) t_step(half, traw, v_nxt, 21 + ((m - 44) >> 1));   // ... rows ...
+                    if (m >= 50 && m < 59) t_step(half, traw, v_nxt, 24 + (m - 50));                  // ... stores
                     if (m >= 59 && m - 59 < NI) lwrite1(m - 59, raw_cur);                        // raw(chunk + 2): registers -> LDS
                     if (m > BAR_M && m - (BAR_M + 1) < NI) gload1(m - (BAR_M + 1));              // raw(chunk + 3) -> registers
                     if (m == BAR_M) {                                                            // V(chunk + 1) and raw(chunk + 2) complete in every wave
@@ -2185,8 +2193,13 @@ __global__ __launch_bounds__(512, 1) void gated_conv_wino4x2_kernel(const ConvKA
     float *const xme = lds + XCH + wv * XW + lane * 4;
     const float *const xpa = lds + XCH + (wv ^ 4) * XW + lane * 4;
     for (int u = blockIdx.x; u < a.n_units; u += G) {
-        stage_body(std::true_type{}, 0);
-        for (int chunk = 1; chunk < n; ++chunk) stage_body(std::false_type{}, chunk);
+        if (fh == 0) {
+            stage_body(std::true_type{}, std::integral_constant<int, 0>{}, 0);
+            for (int chunk = 1; chunk < n; ++chunk) stage_body(std::false_type{}, std::integral_constant<int, 0>{}, chunk);
+        } else {
+            stage_body(std::true_type{}, std::integral_constant<int, 1>{}, 0);
+            for (int chunk = 1; chunk < n; ++chunk) stage_body(std::false_type{}, std::integral_constant<int, 1>{}, chunk);
+        }
 
         // ================= unit epilogue =================
         __builtin_amdgcn_s_setprio(1);
