@@ -107,3 +107,21 @@ def test_winograd_wgrad_kernel_fits_two_waves_per_simd(train_asm):
     assert _meta(train_asm, name, "num_vgpr") + _meta(train_asm, name, "num_agpr") <= 256
     assert body.count("v_mfma_f32_32x32x2_f32") == 36                     # 9 frequencies x 4 tile pairs per iteration, nothing duplicated
     assert body.count("buffer_load_dword ") + body.count("buffer_load_dword\t") >= 52 or body.count("buffer_load_dword") >= 52
+
+
+def test_two_waves_per_simd_f4_kernel_fits(conv_asm):
+    """The experimental frequency-split F(4x4) kernel (off; DESIGN.md 12.1 d): what makes it worth trying is two waves per SIMD —
+    at most 256 registers per wave, no scratch, its LDS inside the CU's 160 KiB — and no branch between the MFMAs of a stage."""
+    name, body = _function(conv_asm, "gated_conv_wino4x2_kernel")
+    assert _meta(conv_asm, name, "private_seg_size") == 0
+    assert _meta(conv_asm, name, "num_vgpr") + _meta(conv_asm, name, "num_agpr") <= 256
+    m = re.search(r"\.amdhsa_kernel " + re.escape(name) + r".*?\.amdhsa_group_segment_fixed_size (\d+)", conv_asm, flags=re.S)
+    assert m and int(m.group(1)) <= 160 * 1024
+    lines = body.split("\n")
+    mf = [i for i, l in enumerate(lines) if "v_mfma_f32_16x16x4_f32" in l]
+    assert len(mf) % 72 == 0 and len(mf) >= 4 * 72                       # (first, steady) stage x two halves, each 72 MFMAs
+    for b in range(0, len(mf), 72):
+        blk = lines[mf[b]:mf[b + 71]]
+        assert not any("s_cbranch" in l for l in blk), "a branch between the MFMAs of a stage"
+        assert sum("s_barrier" in l for l in blk) == 1
+        assert not any("vmcnt(0)" in l for l in blk)
