@@ -2202,7 +2202,6 @@ __global__ __launch_bounds__(512, 1) void gated_conv_wino4x2_kernel(const ConvKA
         }
 
         // ================= unit epilogue =================
-        __builtin_amdgcn_s_setprio(1);
         const int cq = (lane >> 4) & 1, hf = lane >> 5;
         const int c0 = g * 32 + co * 8 + 4 * cq;
         const int oy = by * 8 + 4 * (t16 >> 3) + 2 * fh + hf, ox = bx * 32 + 4 * (t16 & 7);     // this lane finishes ONE row of its tile
@@ -2274,6 +2273,7 @@ __global__ __launch_bounds__(512, 1) void gated_conv_wino4x2_kernel(const ConvKA
             __hip_atomic_store(&xflag[8 + wv], seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
         }
         n_msg += 2;
+        __builtin_amdgcn_s_setprio(1);                          // only now: a wave polling its partner's counter must not outrank the partner on their SIMD
         // lanes 0..31 hold conv_f, lanes 32..63 conv_m: exchange the two rows so that the lower half-wave owns row 2 fh and the upper
         // half row 2 fh + 1, f in one register and m in the other
         {
