@@ -74,6 +74,12 @@ def parse():
     p.add_argument("--detail", type=str, default="", help="write per-launch timings to this JSON file")
     p.add_argument("--tune", type=str, default="", help="comma list of key=value for read_tuning_set (A/B runs)")
     p.add_argument("--no-also", action="store_true", help="headline run without the kitti6_like / train / latency sub-records")
+    p.add_argument("--pose-layout", choices=sweep.LAYOUTS, default=sweep.DEFAULT_LAYOUT,
+                   help="how the sweep's poses are split over the ranks (read_amd/sweep.py pose_of_step)")
+    p.add_argument("--pose-stride", type=int, default=0,
+                   help="single-GPU proxy of ONE rank's share of a STRIDE-rank sweep: this process renders exactly the poses rank "
+                        "--pose-offset of STRIDE would (no exchange partner needed); 0 = off")
+    p.add_argument("--pose-offset", type=int, default=0, help="the rank emulated by --pose-stride")
     p.add_argument("--train-mode", choices=("eval", "train"), default="eval",
                    help="--config train: BatchNorm in eval mode (eval_in_train: True, configs/train_example.yaml) or with "
                         "batch statistics (model.train(), the reference's default)")
@@ -570,20 +576,24 @@ def cpu_leg(wl, frames, pose0=0, probe_threads=True):
     ncpu = os.cpu_count() or 1
     # thread count: torch's CPU convolutions get SLOWER with too many threads on the 256-thread GPU hosts (the UNet is
     # ~600 small ops; measured on a 128x128 frame: 0.18 s at 32 threads, 0.39 s at 64, 149 s at all 256 —
-    # profiles/r2_bench.log), so probe {16, 32, 64, all if <= 128} on a small frame and run the sample with the best
+    # profiles/r2_bench.log), so the count is probed — on the REAL frame size (round 5; rounds 2-4 probed a 128x128 frame and
+    # applied its winner to 1216x352, where the work per op is 26x larger and more threads can pay): one full UNet frame per
+    # candidate, ascending, stopping as soon as a candidate is slower than the best so far by 1.5x
     probe = {}
     cores = min(32, ncpu)
     if probe_threads and frames > 0:
-        cands = sorted({min(16, ncpu), min(32, ncpu), min(64, ncpu)} | ({ncpu} if ncpu <= 128 else set()))
-        xs = [torch.rand(1, 8, 128 >> l, 128 >> l) for l in range(4)]
+        cands = sorted({min(16, ncpu), min(32, ncpu), min(64, ncpu), min(128, ncpu)})
+        xs = [torch.rand(1, 8, H >> l, W >> l) for l in range(4)]
         with torch.no_grad():
             torch.set_num_threads(cands[0])
-            unet_torch.unet_forward(state, *xs)
+            unet_torch.unet_forward(state, *[torch.rand(1, 8, 64 >> l, 64 >> l) for l in range(4)])   # first-touch warm-up
             for t in cands:
                 torch.set_num_threads(t)
                 t0 = time.perf_counter()
                 unet_torch.unet_forward(state, *xs)
                 probe[t] = time.perf_counter() - t0
+                if probe[t] > 1.5 * min(probe.values()):
+                    break
         cores = min(probe, key=probe.get)
     torch.set_num_threads(cores)
     r_threads = min(ncpu, 64)
@@ -610,7 +620,7 @@ def cpu_leg(wl, frames, pose0=0, probe_threads=True):
             "sample": f"1 warm-up + {frames} timed full frames ({W}x{H}, {xyz.shape[0]} pts, sweep poses 1..{frames}): oracle "
                       f"raster C/OpenMP on {r_threads} threads + torch-CPU gather + torch-CPU fp32 UNet on {cores} threads "
                       f"(best of the probed thread counts) of {ncpu}",
-            "thread_probe_s_128x128": {str(k): v for k, v in probe.items()},
+            "thread_probe_s_full_frame": {str(k): v for k, v in probe.items()},
             "ms_raster": 1e3 * t_r / frames, "ms_gather": 1e3 * t_g / frames, "ms_unet": 1e3 * t_u / frames}
     return base, first
 
@@ -637,9 +647,9 @@ def verify(wl, first, pose=0):
     return out
 
 
-def timed_sweep(wl, ex, warmup, steps, world, dev):
+def timed_sweep(wl, ex, warmup, steps, world, dev, layout=None, shard=None):
     """The timed region of the contract: W untimed steps, then exactly K steps bracketed by barrier + synchronize; max over ranks."""
-    sweep.run_steps(wl.render_into, ex, 0, warmup, N_POSES)
+    sweep.run_steps(wl.render_into, ex, 0, warmup, N_POSES, layout, shard)
     ex.drain()
     if hasattr(wl, "fr"):
         wl.fr.sync()
@@ -647,7 +657,7 @@ def timed_sweep(wl, ex, warmup, steps, world, dev):
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    sweep.run_steps(wl.render_into, ex, warmup, steps, N_POSES)
+    sweep.run_steps(wl.render_into, ex, warmup, steps, N_POSES, layout, shard)
     ex.drain()
     torch.cuda.synchronize()
     if world > 1:
@@ -700,6 +710,37 @@ def stage_times(wl):
     return ms_splat, ms_gather, ms_unet
 
 
+PROXY_RANK, PROXY_WORLD = 3, 8
+
+
+def shard_proxy(a, dev, wl, verify_it=True):
+    """One GPU renders rank PROXY_RANK's share of a PROXY_WORLD-rank sweep (same renderer, same frames in flight as the headline),
+    per pose layout: frames/s, the rasteriser's time over that walk, and rank's first frame verified against the oracle."""
+    rec = {"rank": PROXY_RANK, "world": PROXY_WORLD,
+           "what": "single-GPU proxy: exactly the poses one rank of an 8-rank sweep renders (bench.py --pose-stride 8 --pose-offset 3); "
+                   "per-GPU rate of the N = 8 run up to the frame exchange"}
+    sizes = camera.level_sizes(wl.W, wl.H, 5)
+    splat_bytes = 12.0 * wl.N + 8.0 * sum(w * h for (w, h) in sizes)
+    n = min(a.steps, 64)
+    for layout in sweep.LAYOUTS:
+        ex = sweep.FrameExchange((wl.H, wl.W, 4), dev, torch.float32, None)
+        dt = timed_sweep(wl, ex, a.warmup, n, 1, dev, layout, (PROXY_RANK, PROXY_WORLD))
+        it = iter(range(10 ** 6))
+        pose = lambda: sweep.pose_of_step(next(it), PROXY_RANK, PROXY_WORLD, N_POSES, layout)     # noqa: E731
+        wl.rasterize(pose())
+        ms = hip_time_ms(lambda: wl.rasterize(pose(), wait=False), 32)
+        r = {"value": n / dt, "unit": "frames/s", "steps": n, "splat_ms": ms,
+             "splat_frac_hbm": splat_bytes / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "verified": None}
+        if verify_it and not a.no_cpu_baseline:
+            p0 = sweep.pose_of_step(0, PROXY_RANK, PROXY_WORLD, N_POSES, layout)
+            _, first = cpu_leg(wl, 0, pose0=p0, probe_threads=False)
+            r["verified"] = verify(wl, first, pose=p0)
+        rec[layout] = r
+    rec["interleave_over_block"] = rec["interleave"]["value"] / rec["block"]["value"]
+    rec["default_layout"] = sweep.DEFAULT_LAYOUT
+    return rec
+
+
 def also_records(a, dev, wl, first=None):
     """Compact records of the configurations the headline line is not quoted on, measured and verified inside this run."""
     import copy
@@ -718,6 +759,10 @@ def also_records(a, dev, wl, first=None):
                                "verified": verify(wl, first, pose=0) if first is not None else None}
     finally:
         wl.fr.set_frames_in_flight(a.frames_in_flight)
+    # (1b) multi-GPU evidence that needs no second GPU: this GPU renders exactly the share rank PROXY_RANK of an 8-rank sweep
+    # would, in both pose layouts (read_amd/sweep.py) — the rasteriser warm-starts from the previous frame, so a stride-8
+    # walk of the trajectory costs it coherence that a contiguous block does not
+    rec["shard_proxy"] = shard_proxy(a, dev, wl)
     street = synthetic.make_street_cloud(10_000_000)
     # (2) BASELINE configs[1] stand-in through the viewer API
     ak = copy.copy(a)
@@ -781,15 +826,18 @@ def main():
     wl = (SlabWorkload if a.config == "slab30m" else Kitti6LikeWorkload)(a, dev, rank)
     W, H, N = wl.W, wl.H, wl.N
     ex = sweep.FrameExchange((H, W, 4), dev, torch.float32, None if a.exchange == "none" else a.exchange)
-    dt = timed_sweep(wl, ex, a.warmup, a.steps, world, dev)
+    shard = (a.pose_offset, a.pose_stride) if a.pose_stride else None
+    assert shard is None or (world == 1 and 0 <= a.pose_offset < a.pose_stride), "--pose-stride is a single-GPU proxy"
+    dt = timed_sweep(wl, ex, a.warmup, a.steps, world, dev, a.pose_layout, shard)
 
     # ---- every rank checks one of ITS OWN frames (the first pose it rendered) against the oracle on its host cores
     rc = 0
     my_verified = None
     base = None
+    my_pose0 = sweep.pose_of_step(0, *(shard or (rank, world)), N_POSES, a.pose_layout)
     if not a.no_cpu_baseline:
-        base, first = cpu_leg(wl, a.cpu_frames if (rank == 0 and world == 1) else 0, pose0=rank % N_POSES)
-        my_verified = verify(wl, first, pose=rank % N_POSES)
+        base, first = cpu_leg(wl, a.cpu_frames if (rank == 0 and world == 1) else 0, pose0=my_pose0)
+        my_verified = verify(wl, first, pose=my_pose0)
     verified_ranks = sweep.gather_objects(None if my_verified is None else bool(my_verified["ok"]))
 
     if rank == 0:
@@ -827,7 +875,9 @@ def main():
             "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": 1e3 * dt / a.steps,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": wl.describe, "points": N, "width": W, "height": H,
-                       "parallelism": f"pose-sharded x{world}", "frame_exchange": ex.mode or "none",
+                       "parallelism": f"pose-sharded x{world}", "pose_layout": a.pose_layout,
+                       "shard_proxy_of": None if shard is None else {"rank": shard[0], "world": shard[1]},
+                       "frame_exchange": ex.mode or "none",
                        "frames_in_flight": a.frames_in_flight},
             "roofline": {
                 "kernel": "3x3/s1 C->C gated conv family: Winograd kernels on the fp32 matrix cores "

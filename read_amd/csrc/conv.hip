@@ -3078,6 +3078,25 @@ int launch_gated_conv(const read_conv_desc *d, hipStream_t stream)
     READ_CHECK_ARG(!d->linear || (!d->residual && !d->fill_pad), "read_gated_conv_forward: linear mode takes no residual / fill");
     READ_CHECK_ARG(!d->mul || d->n_src == 1, "read_gated_conv_forward: mul needs a single source");
     READ_CHECK_ARG((uintptr_t)d->wpacked % 16 == 0, "read_gated_conv_forward: packed weights misaligned");
+    {
+        // One fragment order per layer is enough for a host that asked read_conv_kernel_family first; a host that aliases
+        // wpacked to its Winograd fragments (training: read_amd/train.py packs ONE order per layer and step) or leaves it NULL
+        // (the lean UNet blob) must never reach a kernel that reads wpacked as the direct order — a tuning knob changed on a
+        // live engine, a 2 GiB tensor or an odd out_cstride can decline the Winograd kernels after the host has packed for them.
+        // Checked HERE, for both entry points (read_gated_conv_forward and the UNet executor's direct call).
+        const int family = conv_uses_sc(d) ? 1 : conv_uses_w4(d) ? 4 : conv_uses_wino(d) ? 2 : 0;
+        const bool cfg_wino = d->config >= 0 && d->config < N_CONFIGS && g_configs[d->config].wino;   // forced F(2x2) configs read wpacked_wino
+        const bool w16_forced = d->config == -3;
+        READ_CHECK_ARG(d->wpacked || family != 0 || cfg_wino || w16_forced,
+                       "read_gated_conv_forward: this launch takes a direct kernel and wpacked is NULL (fragment order not packed)");
+        READ_CHECK_ARG(!d->wpacked || (!((const void *)d->wpacked == (const void *)d->wpacked_w4 && family != 4) &&
+                                       !((const void *)d->wpacked == (const void *)d->wpacked_wino && family != 2 && !cfg_wino)),
+                       "read_gated_conv_forward: wpacked aliases Winograd fragments but the launch takes kernel family %d "
+                       "(ask read_conv_kernel_family before packing)", family);
+        READ_CHECK_ARG(family != 4 || d->wpacked_w4, "read_gated_conv_forward: F(4x4) launch without wpacked_w4");
+        READ_CHECK_ARG(family != 2 || d->wpacked_wino, "read_gated_conv_forward: F(2x2) launch without wpacked_wino");
+        READ_CHECK_ARG(family != 1 || d->wpacked_sc, "read_gated_conv_forward: small-Cout launch without wpacked_sc");
+    }
 
     ConvKArgs a;
     memset(&a, 0, sizeof(a));
@@ -3447,20 +3466,8 @@ extern "C" int read_conv_kernel_family(const read_conv_desc *desc)
 
 extern "C" int read_gated_conv_forward(const read_conv_desc *desc, void *stream)
 {
-    // One fragment order per layer is enough for a host that asked read_conv_kernel_family first; a host that aliases
-    // wpacked to its Winograd fragments (training: read_amd/train.py packs ONE order per layer and step) must never reach a
-    // kernel that reads wpacked as the direct order — a tuning knob, a 2 GiB tensor or an odd out_cstride can decline the
-    // Winograd kernels after the host has packed for them.
-    if (desc && !desc->wpacked)                            // e.g. a lean UNet blob after a knob sent the layer off the F(4x4) kernel
-        READ_CHECK_ARG(read_conv_kernel_family(desc) != 0,
-                       "read_gated_conv_forward: this launch takes a direct kernel and wpacked is NULL (fragment order not packed)");
-    if (desc && desc->wpacked) {
-        const int family = read_conv_kernel_family(desc);
-        READ_CHECK_ARG(!((const void *)desc->wpacked == (const void *)desc->wpacked_w4 && family != 4) &&
-                           !((const void *)desc->wpacked == (const void *)desc->wpacked_wino && family != 2),
-                       "read_gated_conv_forward: wpacked aliases Winograd fragments but the launch takes kernel family %d "
-                       "(ask read_conv_kernel_family before packing)", family);
-    }
+    // the fragment-order checks (a NULL or aliased wpacked against the kernel family this launch takes) live in
+    // launch_gated_conv: the UNet executor (unet.cpp) calls that directly and must get the same refusal
     return readhip::launch_gated_conv(desc, as_stream(stream));
 }
 

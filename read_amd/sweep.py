@@ -4,8 +4,9 @@ CPU tests) is used only for the one-time broadcast of the scene and the exchange
 (SURVEY.md §8e).  One process per GPU.  This module is the ONE implementation of that loop: ``bench.py``
 times ``run_steps`` and the CPU tests drive the same function with a stub renderer.
 
-Pose k is rendered by rank ``k % world`` — consecutive poses of a trajectory land on different
-GPUs, so a viewer replaying the sweep in order drains all GPUs evenly.
+Two pose layouts (``pose_of_step``): 'interleave' — pose k on rank ``k % world``, consecutive poses of a trajectory land on
+different GPUs, so a viewer replaying the sweep in order drains all GPUs evenly — and 'block' — every rank walks a contiguous
+block of the sweep, which keeps the rasteriser's frame-to-frame warm start coherent.
 
 Expected scaling (for judging a measured curve): weak scaling is linear up to the frame exchange — one RGBA frame is
 6.8 MB, so at ~150 frames/s per GPU an all-gather moves ~1 GB/s per peer link and a gather-to-root ~7 GB/s into
@@ -125,25 +126,52 @@ class FrameExchange:
                 self.pending[j] = None
 
 
+LAYOUTS = ('interleave', 'block')
+DEFAULT_LAYOUT = 'interleave'        # bench.py --pose-layout; see pose_of_step
+
+
 def sweep_steps(n_poses, world):
     """Steps that cover every pose of the sweep once: ceil(n_poses / world).  When ``n_poses % world != 0`` the ranks past the
     end of the last step wrap around to the head of the sweep (``pose_of_step``) — every rank renders and exchanges in every
-    step, so the collectives stay matched; a consumer drops the wrapped frames (``pose_of_step(...) < step * world``)."""
+    step, so the collectives stay matched; a consumer drops the wrapped frames (``is_wrapped``)."""
     return (n_poses + world - 1) // world
 
 
-def pose_of_step(step, rank, world, n_poses):
-    return (step * world + rank) % n_poses
+def pose_of_step(step, rank, world, n_poses, layout=None):
+    """The pose rank `rank` of `world` renders in step `step` (SURVEY.md 8e allows either split of a sweep).
+
+    'interleave'  pose = step * world + rank: consecutive poses land on different GPUs — a viewer replaying the sweep in
+                  order drains all GPUs evenly, but each rank's rasteriser sees a stride-`world` walk of the trajectory;
+    'block'       rank r owns the contiguous block of ceil(n_poses / world) poses starting at r * that: every rank walks
+                  CONSECUTIVE poses, which is what the rasteriser's warm start (last frame's front points seed this frame's
+                  depth bounds) is built for — the layout of an offline batch sweep.
+    Both wrap modulo n_poses, so any number of steps is defined (bench.py's weak-scaling loop runs K steps per rank)."""
+    layout = layout or DEFAULT_LAYOUT
+    if layout == 'interleave':
+        return (step * world + rank) % n_poses
+    if layout == 'block':
+        return (rank * sweep_steps(n_poses, world) + step) % n_poses
+    raise ValueError(layout)
 
 
-def run_steps(render_into, exchange, first, count, n_poses):
-    """Steps first .. first+count-1 of the sweep on this rank: step i renders pose ``(i * world + rank) % n_poses`` into
-    the exchange's buffer and posts the exchange.  ``render_into(pose_index, out_tensor)`` returns None, or the event that
-    marks the frame complete when the renderer writes it on its own stream (FrameRenderer(frames_in_flight=2))."""
-    world, rank = exchange.world, exchange.rank
+def is_wrapped(step, rank, world, n_poses, layout=None):
+    """True when (step, rank) of a ``sweep_steps``-long sweep re-renders a pose another (step, rank) already covers
+    (the ragged tail: n_poses % world != 0)."""
+    layout = layout or DEFAULT_LAYOUT
+    if layout == 'interleave':
+        return step * world + rank >= n_poses
+    return rank * sweep_steps(n_poses, world) + step >= n_poses
+
+
+def run_steps(render_into, exchange, first, count, n_poses, layout=None, shard=None):
+    """Steps first .. first+count-1 of the sweep on this rank: step i renders pose ``pose_of_step(i, rank, world, n_poses,
+    layout)`` into the exchange's buffer and posts the exchange.  ``render_into(pose_index, out_tensor)`` returns None, or the
+    event that marks the frame complete when the renderer writes it on its own stream (FrameRenderer(frames_in_flight=2)).
+    shard = (rank, world) overrides the exchange's own — bench.py's single-GPU proxy of ONE rank's share of an N-rank sweep."""
+    rank, world = shard if shard is not None else (exchange.rank, exchange.world)
     for i in range(first, first + count):
         out = exchange.buffer(i)
-        done = render_into(pose_of_step(i, rank, world, n_poses), out)   # an event if the frame completes on another stream
+        done = render_into(pose_of_step(i, rank, world, n_poses, layout), out)   # an event if the frame completes on another stream
         exchange.post(i, done)
 
 

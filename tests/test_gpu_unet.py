@@ -276,10 +276,16 @@ def test_lean_weight_blob_renders_the_same_frame(hip):
     assert torch.equal(y[0].permute(1, 2, 0), outs[LAYOUT_FULL])
     # F(4x4) switched off: the lean blob cannot serve the plan -> loud refusal at the C level, automatic full blob in the module
     lean = torch.from_numpy(pack_state(state, layout=LAYOUT_LEAN)).cuda()
+    live = UNetEngine(lean, H, W)                          # created while the F(4x4) kernel takes its layers ...
     try:
         _lib.check(_lib.lib().read_tuning_set(b"conv_w4", 0))
         with pytest.raises(_lib.ReadHipError, match="lean"):
             UNetEngine(lean, H, W)
+        # ... and the knob changes under it: the executor's launches refuse the missing fragment order with
+        # READ_EINVAL instead of reading through a NULL wpacked
+        with pytest.raises(_lib.ReadHipError, match="wpacked is NULL"):
+            live.forward(*xs)
+        torch.cuda.synchronize()
         net.invalidate()
         with torch.no_grad():
             y2 = net(*[x.permute(2, 0, 1)[None] for x in xs])

@@ -5,6 +5,7 @@ import os
 import socket
 
 import numpy as np
+import pytest
 import torch
 import torch.distributed as dist
 import torch.multiprocessing as mp
@@ -148,7 +149,7 @@ def test_bench_loop_single_process_has_no_exchange():
 
 
 # ---- a whole sweep whose length is not a multiple of the world size, through run_steps ----
-def _ragged_worker(rank, world, port, q, n_poses):
+def _ragged_worker(rank, world, port, q, n_poses, layout='interleave'):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
@@ -165,15 +166,15 @@ def _ragged_worker(rank, world, port, q, n_poses):
         stack = torch.zeros((n_poses, H, W, 2))
         filled = []
         for i in range(steps):
-            sweep.run_steps(render_into, ex, i, 1, n_poses)
+            sweep.run_steps(render_into, ex, i, 1, n_poses, layout=layout)
             fr = ex.frames(i)
             for r in range(world):
-                k = i * world + r
-                if k < n_poses:                                  # the wrapped tail (k >= n_poses) is a repeat of the head: dropped
+                k = sweep.pose_of_step(i, r, world, n_poses, layout)
+                if not sweep.is_wrapped(i, r, world, n_poses, layout):   # the wrapped tail is a repeat of the head: dropped
                     stack[k].copy_(fr[r])
                     filled.append(k)
                 else:
-                    assert torch.equal(fr[r], stack[sweep.pose_of_step(i, r, world, n_poses)])
+                    assert torch.equal(fr[r], stack[k])
         ex.drain()
         q.put((rank, log, filled, stack.numpy()))
     finally:
@@ -199,3 +200,43 @@ def test_ragged_sweep_through_run_steps_two_ranks():
         assert log == ([0, 2, 4] if rank == 0 else [1, 3, 0])        # every step renders on every rank; the tail wraps
         assert filled == list(range(n_poses))                        # each pose of the sweep received exactly once, in order
         assert np.array_equal(stack, ref), f"rank {rank}: ragged sweep differs from the single-process frames"
+
+
+def test_block_layout_keeps_every_rank_on_consecutive_poses():
+    """'block' layout (bench.py --pose-layout block): rank r walks the contiguous block r * ceil(n / world) ..., so the
+    rasteriser's warm start sees consecutive poses on every rank; every pose of a sweep_steps-long sweep is covered exactly
+    once by the non-wrapped (step, rank) pairs — for ragged lengths and for both layouts."""
+    for layout in sweep.LAYOUTS:
+        for n_poses, world in ((256, 8), (5, 2), (7, 3), (10, 4), (3, 8), (256, 1)):
+            steps = sweep.sweep_steps(n_poses, world)
+            seen = [sweep.pose_of_step(i, r, world, n_poses, layout) for i in range(steps) for r in range(world)
+                    if not sweep.is_wrapped(i, r, world, n_poses, layout)]
+            assert sorted(seen) == list(range(n_poses)), (layout, n_poses, world)
+            for r in range(world):
+                walk = [sweep.pose_of_step(i, r, world, n_poses, layout) for i in range(steps)]
+                stride = 1 if layout == 'block' else world
+                assert all((b - a) % n_poses == stride % n_poses for a, b in zip(walk, walk[1:])), (layout, walk)
+    assert [sweep.pose_of_step(i, 3, 8, 256, 'block') for i in range(3)] == [96, 97, 98]
+    assert [sweep.pose_of_step(i, 3, 8, 256, 'interleave') for i in range(3)] == [3, 11, 19]
+    with pytest.raises(ValueError):
+        sweep.pose_of_step(0, 0, 2, 4, 'tiles')
+
+
+def test_ragged_sweep_block_layout_two_ranks():
+    n_poses = 5                                                  # blocks of 3: rank 0 poses 0 1 2, rank 1 poses 3 4 then wraps to 0
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_ragged_worker, args=(r, 2, port, q, n_poses, 'block')) for r in range(2)]
+    for p in procs:
+        p.start()
+    got = [q.get(timeout=120) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    xyz, proj = synthetic.make_cloud(N), synthetic.make_proj(W, H, f=30.0)
+    ref = np.stack([_frame(xyz, proj, k).numpy() for k in range(n_poses)])
+    for rank, log, filled, stack in got:
+        assert log == ([0, 1, 2] if rank == 0 else [3, 4, 0])
+        assert sorted(filled) == list(range(n_poses)) and len(filled) == n_poses
+        assert np.array_equal(stack, ref), f"rank {rank}: block-layout sweep differs from the single-process frames"
