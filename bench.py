@@ -366,7 +366,15 @@ def run_train(a, dev, street=None, steps=None, warm=None, cpu_timing=True, do_ve
         model.eval()                                              # eval_in_train: True (configs/train_example.yaml)
     extra = pipe.extra_optimizer([DS()])
     renderer = MyRender([DS()], device_outputs=True)
-    rng = np.random.default_rng(2019)
+    world = dist.get_world_size() if dist.is_initialized() else 1
+    rank = dist.get_rank() if dist.is_initialized() else 0
+    # N > 1: one process per GPU, every rank its own 8 crops; per step ONE all-reduce of the flat gradient arena and ONE
+    # all-gather of the sparse descriptor pairs over RCCL (read_amd/ddp.py) — the reference's nn.DataParallel, rebuilt
+    ddp_step = None
+    if world > 1:
+        from read_amd.ddp import DataParallelStep
+        ddp_step = DataParallelStep(pipe.net, pipe.textures)
+    rng = np.random.default_rng(2019 + rank)
     proj = synthetic.make_proj(S, S).astype(np.float32)
     targets = torch.from_numpy(rng.random((4, B, 3, S, S)).astype(np.float32)).to(dev)
     tex = pipe.textures[0]
@@ -392,6 +400,8 @@ def run_train(a, dev, street=None, steps=None, warm=None, cpu_timing=True, do_ve
     def step(i):
         views = np.stack([synthetic.sweep_pose(int(k)) for k in rng.integers(0, N_POSES, B)])
         loss = forward_backward(views, targets[i % 4])
+        if ddp_step is not None:
+            ddp_step.reduce()
         t0 = time.perf_counter()
         pipe.optimizer.step()
         pipe.optimizer.zero_grad()
@@ -503,6 +513,8 @@ def run_train(a, dev, street=None, steps=None, warm=None, cpu_timing=True, do_ve
     warm = warm if warm is not None else max(a.warmup, 2)
     for i in range(warm):
         step(i)
+    if world > 1:
+        dist.barrier()
     torch.cuda.synchronize()
     for k_ in phases:
         phases[k_] = 0.0
@@ -512,7 +524,14 @@ def run_train(a, dev, street=None, steps=None, warm=None, cpu_timing=True, do_ve
     dt_host = time.perf_counter() - t0                             # the host has enqueued everything; the device may still be busy
     host_phases = {k_: 1e3 * v_ / steps for k_, v_ in phases.items()}
     torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+        torch.cuda.synchronize()
     dt = time.perf_counter() - t0
+    if world > 1:
+        t_ = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(t_, op=dist.ReduceOp.MAX)
+        dt = float(t_.item())
     fwd_flops = 187.06e9 * B                                      # conv MACs x 2 at 256x256, measured on the reference module
     algorithmic = 3.0 * fwd_flops / (dt / steps) / 1e12            # forward + dgrad + wgrad, direct-convolution count
     # the flops the step's launches EXECUTE (the convention of the headline's roofline.frac): one instrumented step logs every
@@ -532,15 +551,17 @@ def run_train(a, dev, street=None, steps=None, warm=None, cpu_timing=True, do_ve
     gain = {4: 4.0, 2: 2.25}
     executed_flops = sum(fl / gain.get(fam, 1.0) for (_, fl, fam) in log)
     achieved = executed_flops / (dt / steps) / 1e12 if log else algorithmic
-    out = {"metric": "training iterations/sec (8 crops of 256x256 per iteration)", "value": steps / dt, "unit": "iters/s",
-           "n_gpus": 1, "steps": steps, "warmup": warm, "ms_per_step": 1e3 * dt / steps, "higher_is_better": True,
+    out = {"metric": "training iterations/sec (8 crops of 256x256 per iteration and GPU)", "value": world * steps / dt, "unit": "iters/s",
+           "n_gpus": world, "steps": steps, "warmup": warm, "ms_per_step": 1e3 * dt / steps, "higher_is_better": True,
            "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
            "config": {"workload": f"BASELINE configs[4] stand-in: TexturePipeline training step on a seeded {N}-point street scene, "
                                   "batch_size 2 x inner_batch 4 = 8 crops of 256x256: MyRender raster (8 cameras x 5 scales) + "
                                   "gather + UNet forward/backward (HIP autograd nodes) + Huber x 1e4 (no VGG term: weights are a "
                                   "download) + Adam(net) + sparse RMSprop(descriptors), BatchNorm "
                                   + ("with batch statistics (model.train())" if bn_train else "in eval mode (eval_in_train)"),
-                      "points": N, "crop": S, "batch": B, "parallelism": "single GPU (DataParallel of the reference not rebuilt)"},
+                      "points": N, "crop": S, "batch": B, "parallelism": "single GPU" if world == 1 else f"data-parallel x{world}: one process per GPU, 8 crops each; per step one RCCL "
+                                     "all-reduce of the flat gradient arena + one all-gather of the sparse descriptor pairs (read_amd/ddp.py)",
+                      "gradient_arena_bytes": None if ddp_step is None else ddp_step.arena.nbytes},
            "roofline": {"kernel": "whole step (MFMA convolutions forward + dgrad + wgrad)", "bound": "mfma",
                         "achieved": achieved, "peak": FP32_MFMA_PEAK_TFS, "unit": "TFLOP/s", "frac": achieved / FP32_MFMA_PEAK_TFS,
                         "traffic": None, "flops_per_step": executed_flops if log else 3.0 * fwd_flops,
@@ -816,11 +837,16 @@ def main():
         dist.init_process_group("nccl", device_id=dev)
 
     if a.config == "train":
-        assert world == 1, "the training step is single-GPU (the reference's nn.DataParallel is not rebuilt)"
-        out = run_train(a, dev)
-        print(json.dumps(out), flush=True)
-        if out["verified"] is not None and not out["verified"]["ok"]:
-            print("bench.py: the training iteration does NOT reproduce the oracle: %r" % (out["verified"],), file=sys.stderr, flush=True)
+        out = run_train(a, dev, cpu_timing=(world == 1), do_verify=(rank == 0))
+        bad = out["verified"] is not None and not out["verified"]["ok"]
+        if rank == 0:
+            print(json.dumps(out), flush=True)
+            if bad:
+                print("bench.py: the training iteration does NOT reproduce the oracle: %r" % (out["verified"],), file=sys.stderr, flush=True)
+        if world > 1:
+            dist.barrier()
+            dist.destroy_process_group()
+        if bad:
             sys.exit(3)
         return
     wl = (SlabWorkload if a.config == "slab30m" else Kitti6LikeWorkload)(a, dev, rank)

@@ -250,6 +250,14 @@ typedef struct read_conv_desc {
                                                with Cin = 32, Cout <= 4 and one unshifted source (READ's output layer 32 -> 3) run on the
                                                vector pipe — thread = pixel, weights streamed through SGPRs — instead of padding six output
                                                rows to an MFMA shape; read_tuning_set("conv_sc", 0) switches it off, config = -6 forces it */
+    int pre_bilinear;                       /* 1: the pre-activation addend is sampled BILINEARLY at 4x (pre_shift must be 2): the value
+                                               nn.Upsample(scale_factor=4, mode='bilinear', align_corners=False) of `pre` has at (y, x)
+                                               (source index 0.25 (dst + 0.5) - 0.5 clamped at 0, neighbours clamped at the edge).  A
+                                               1x1 convolution commutes with bilinear up-sampling as it does with nearest, so the share
+                                               of cat[Upsample4(coarse), fine] -> 1x1 conv that comes from the coarse tensor is computed at
+                                               1/16 of the pixels by a `linear` launch and enters here: no up-sampled tensor is ever
+                                               written (READ/models/unet.py:261-262,269-270,277-278, the Convs.k inputs).  1x1 / stride-1
+                                               layers on the pixel-lane kernel only (16-byte aligned tensors, Cin <= 256, Cout % 4 == 0) */
 } read_conv_desc;
 
 /* Sizes (in floats) of the packed weight / parameter blocks of one BasicConv. */

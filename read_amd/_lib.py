@@ -34,7 +34,7 @@ class ConvDesc(C.Structure):
         ("pre", C.c_void_p), ("pre_cstride", C.c_int), ("pre_f_off", C.c_int), ("pre_m_off", C.c_int),
         ("pre_shift", C.c_int), ("preH", C.c_int), ("preW", C.c_int),
         ("out_gated", C.c_void_p), ("block_h", C.c_int), ("valid_h", C.c_int),
-        ("wpacked_sc", C.c_void_p),
+        ("wpacked_sc", C.c_void_p), ("pre_bilinear", C.c_int),
     ]
 
 

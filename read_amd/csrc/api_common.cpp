@@ -65,6 +65,7 @@ void unet_set_streams(int v);
 void train_set_wgrad_wino(int v);
 int train_get(const char *key, int *value);
 void unet_set_aff_split(int v);
+void unet_set_up_fold(int v);
 int unet_get(const char *key, int *value);
 }
 
@@ -83,7 +84,7 @@ extern "C" int read_debug_set_trace(void *buf, size_t bytes)
 // selects between implementations that produce the SAME results; the attribution probes whose results are invalid
 // ("conv_ablate") exist only in builds with -DREAD_DEBUG_KNOBS.
 static const char *const k_tuning_keys[] = {"splat_mode", "splat_stats", "splat_subset", "splat_near", "splat_cells",
-                                            "splat_cells_sub", "splat_seeds", "splat_items", "splat_strips", "splat_wgs", "splat_zl2", "splat_lds", "splat_bins", "splat_kslot", "unet_streams", "unet_aff_split", "conv_kc32", "conv_px", "conv_sc", "conv_wino_wgs",
+                                            "splat_cells_sub", "splat_seeds", "splat_items", "splat_strips", "splat_wgs", "splat_zl2", "splat_lds", "splat_bins", "splat_kslot", "unet_streams", "unet_aff_split", "unet_up_fold", "conv_kc32", "conv_px", "conv_sc", "conv_wino_wgs",
                                             "conv_wino", "conv_w16", "conv_w4", "conv_w4x2", "conv_w4_grid", "conv_stagger", "conv_wave", "wgrad_wino",
 #ifdef READ_DEBUG_KNOBS
                                             "conv_ablate", "conv_abl",
@@ -115,6 +116,8 @@ extern "C" int read_tuning_set(const char *key, int value)
     if (!strcmp(key, "unet_streams")) { readhip::unet_set_streams(value); return READ_OK; }   // 0: SCM chains on the caller's stream
     // 0: AFF first convs as single 480-channel launches (takes effect for plans created afterwards)
     if (!strcmp(key, "unet_aff_split")) { readhip::unet_set_aff_split(value != 0); return READ_OK; }
+    // 0: Upsample4(bilinear) as a separate pass and Convs.k over the concat (takes effect for plans created afterwards)
+    if (!strcmp(key, "unet_up_fold")) { readhip::unet_set_up_fold(value != 0); return READ_OK; }
     if (!strcmp(key, "conv_wino_wgs")) { readhip::conv_set_wino_wgs(value); return READ_OK; } // persistent Winograd workgroups per CU: 1 or 2
     if (!strcmp(key, "conv_px")) { readhip::conv_set_px(value); return READ_OK; }             // pixel-lane kernel for 1x1 layers
     if (!strcmp(key, "conv_sc")) { readhip::conv_set_sc(value); return READ_OK; }             // vector-pipe kernel for Cout <= 4

@@ -64,6 +64,7 @@ struct ConvKArgs {
     // with pre_moff — partial sums of the same layer computed at a coarser level (nearest up-sampling commutes with a 1x1 conv)
     const float *pre;
     int pre_cstride, pre_foff, pre_moff, pre_shift, pre_W, pre_bytes;
+    int pre_bil, pre_H;            // 1: the addend is the 4x BILINEAR up-sampling of `pre` (read_conv_desc.pre_bilinear; pixel-lane kernel)
     // linear launches of the training path (Winograd kernel): also store the gated output BN(act(f) * sigmoid(m)) here, zero on
     // the separator rows of a stacked batch (rows r with r % blk_h >= blk_valid)
     float *out_gated;
@@ -2592,6 +2593,25 @@ __global__ __launch_bounds__(256, (PT * GW >= 4 ? 2 : 3)) void gated_conv_px_ker
             const bool p_ok = p < npix;
             const int y = p / a.outW, x = p - y * a.outW;
             const size_t pre_pix = a.pre ? ((size_t)(y >> a.pre_shift) * a.pre_W + (x >> a.pre_shift)) * a.pre_cstride : 0;
+            // bilinear addend (pre_bil): the four neighbours and weights of nn.Upsample(x4, bilinear, align_corners=False) at (y, x),
+            // computed exactly as bilinear_up4_kernel does (area_pixel_compute_source_index: 0.25 (dst + 0.5) - 0.5 clamped at 0)
+            size_t bp00 = 0, bp01 = 0, bp10 = 0, bp11 = 0;
+            float bly0 = 0.f, bly1 = 0.f, blx0 = 0.f, blx1 = 0.f;
+            if (a.pre_bil) {
+                float sy = 0.25f * ((float)y + 0.5f) - 0.5f, sx = 0.25f * ((float)x + 0.5f) - 0.5f;
+                sy = sy < 0.f ? 0.f : sy;
+                sx = sx < 0.f ? 0.f : sx;
+                const int y0 = (int)sy, x0 = (int)sx;
+                const int y1 = y0 + (y0 < a.pre_H - 1 ? 1 : 0), x1 = x0 + (x0 < a.pre_W - 1 ? 1 : 0);
+                bly1 = sy - (float)y0;
+                blx1 = sx - (float)x0;
+                bly0 = 1.f - bly1;
+                blx0 = 1.f - blx1;
+                bp00 = ((size_t)y0 * a.pre_W + x0) * a.pre_cstride;
+                bp01 = ((size_t)y0 * a.pre_W + x1) * a.pre_cstride;
+                bp10 = ((size_t)y1 * a.pre_W + x0) * a.pre_cstride;
+                bp11 = ((size_t)y1 * a.pre_W + x1) * a.pre_cstride;
+            }
 #pragma unroll
             for (int g = 0; g < GW; ++g)
 #pragma unroll
@@ -2606,7 +2626,15 @@ __global__ __launch_bounds__(256, (PT * GW >= 4 ? 2 : 3)) void gated_conv_px_ker
                     }
                     f += *reinterpret_cast<const f32x4 *>(a.params + c0);
                     m += *reinterpret_cast<const f32x4 *>(a.params + a.CoutPad + c0);
-                    if (a.pre) {
+                    if (a.pre_bil) {
+                        const float *pf = a.pre + a.pre_foff + c0, *pm = a.pre + a.pre_moff + c0;
+                        const f32x4 f00 = *reinterpret_cast<const f32x4 *>(pf + bp00), f01 = *reinterpret_cast<const f32x4 *>(pf + bp01);
+                        const f32x4 f10 = *reinterpret_cast<const f32x4 *>(pf + bp10), f11 = *reinterpret_cast<const f32x4 *>(pf + bp11);
+                        const f32x4 m00 = *reinterpret_cast<const f32x4 *>(pm + bp00), m01 = *reinterpret_cast<const f32x4 *>(pm + bp01);
+                        const f32x4 m10 = *reinterpret_cast<const f32x4 *>(pm + bp10), m11 = *reinterpret_cast<const f32x4 *>(pm + bp11);
+                        f += bly0 * (blx0 * f00 + blx1 * f01) + bly1 * (blx0 * f10 + blx1 * f11);
+                        m += bly0 * (blx0 * m00 + blx1 * m01) + bly1 * (blx0 * m10 + blx1 * m11);
+                    } else if (a.pre) {
                         f += *reinterpret_cast<const f32x4 *>(a.pre + pre_pix + a.pre_foff + c0);
                         m += *reinterpret_cast<const f32x4 *>(a.pre + pre_pix + a.pre_moff + c0);
                     }
@@ -3143,7 +3171,11 @@ int launch_gated_conv(const read_conv_desc *d, hipStream_t stream)
                            (long long)d->preH * d->preW * d->pre_cstride * 4 < OOB_LIMIT,
                        "read_gated_conv_forward: pre-activation addend %dx%d does not cover the %dx%d output at shift %d", d->preH,
                        d->preW, outH, outW, d->pre_shift);
+        READ_CHECK_ARG(!d->pre_bilinear || (d->pre_shift == 2 && d->ksize == 1 && d->stride == 1),
+                       "read_gated_conv_forward: pre_bilinear needs pre_shift 2 on a 1x1 / stride-1 layer");
         a.pre = d->pre;
+        a.pre_bil = d->pre_bilinear ? 1 : 0;
+        a.pre_H = d->preH;
         a.pre_cstride = d->pre_cstride;
         a.pre_foff = d->pre_f_off;
         a.pre_moff = d->pre_m_off;
@@ -3210,7 +3242,10 @@ int launch_gated_conv(const read_conv_desc *d, hipStream_t stream)
         bool px_pick = false;
         for (int i = 0; i < d->n_src; ++i) px_pick = px_pick || d->src[i].C % 16 != 0;
         px_pick = px_pick || d->Cout % 32 != 0 || g_conv_px >= 3;
-        if (d->config == -2 || (d->config == -1 && g_conv_px && fits && px_pick)) {
+        const bool bil = d->pre && d->pre_bilinear;                // only this kernel samples the addend bilinearly
+        READ_CHECK_ARG(!bil || (fits && d->config < 0), "read_gated_conv_forward: pre_bilinear needs the pixel-lane kernel (1x1/s1, Cin <= 256, "
+                       "Cout %% 4 == 0, 16-byte aligned tensors, automatic config)");
+        if (d->config == -2 || bil || (d->config == -1 && g_conv_px && fits && px_pick)) {
             static int n_cu_p = 0;
             if (!n_cu_p) {
                 int dev = 0;

@@ -172,6 +172,23 @@ Arch build_arch(int layout)
         derive("AFFs.0.conv.0r", 0, BASE, {0});           // what is left at the layer's own level
         derive("AFFs.1.conv.0r", 0, BASE * 3, {1});
         derive("AFFs.2.conv.0r", 0, BASE * 7, {2});
+        // Convs.k = 1x1 over cat[Upsample4_bilinear(fe), r] (unet.py:261-262,269-270,277-278): the half that multiplies the up-sampled
+        // tensor is applied at ITS level (1/16 of the pixels, `linear`) and enters the gated launch as a bilinear pre-activation addend
+        auto derive_of = [&](const std::string &name, const std::string &layer, int ci0, int cin) {
+            const int li = a.find(layer);
+            DerivedInfo D{name, cin, a.layers[li].cout, ci0, {li}, 0, 0};
+            D.w_off = a.packed_floats;
+            a.packed_floats += read_conv_packed_floats(cin, D.cout, 1);
+            D.p_off = a.packed_floats;
+            a.packed_floats += read_conv_param_floats(D.cout);
+            a.derived.push_back(D);
+        };
+        for (int k = 0; k < 3; ++k) {
+            const int Cu = (BASE * 4) >> k;                                  // channels of up4(fe) = channels of r
+            const std::string L = "Convs." + std::to_string(k);
+            derive_of(L + ".u", L, 0, Cu);
+            derive_of(L + ".r", L, Cu, Cu);
+        }
         return a;
 }
 
@@ -226,6 +243,7 @@ namespace {
 size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 
 int g_unet_aff_split = 1;     // read_tuning_set("unet_aff_split", 0): the AFF first convs as single 480-channel launches
+int g_unet_up_fold = 1;       // read_tuning_set("unet_up_fold", 0): bilinear x4 as a separate pass + Convs.k over the 2C-channel concat
 
 struct Builder {
     read_unet *u;
@@ -259,7 +277,7 @@ struct Builder {
     }
 
     struct PreRef {
-        int t = -1, f_off = 0, m_off = 0, shift = 0;
+        int t = -1, f_off = 0, m_off = 0, shift = 0, bilinear = 0;
     };
     struct LayerRef {
         int cin, cout, k, stride, elu;
@@ -337,6 +355,7 @@ struct Builder {
             op.d.pre_f_off = pre.f_off;
             op.d.pre_m_off = pre.m_off;
             op.d.pre_shift = pre.shift;
+            op.d.pre_bilinear = pre.bilinear;
             op.d.preH = pt.H;
             op.d.preW = pt.W;
         }
@@ -468,22 +487,33 @@ struct Builder {
 
         // unet.py:257-265
         int z = resblocks("Decoder.0", zb, 3, BASE * 8);
-        int f7 = tensor("fe7", 4, BASE * 4), u7 = tensor("up7", 2, BASE * 4), c0 = tensor("convs0", 2, BASE * 4);
+        // Convs.k over cat[Upsample4(fe), r]: with unet_up_fold the up-sampled tensor is never written — `Convs.k.u` applies its
+        // weight block to fe at fe's level (linear, [f | m]) and `Convs.k.r` adds the bilinear x4 of that to its pre-activations
+        auto up_conv = [&](int k, int fe, int level, int C, int r, int out) {
+            const std::string L = "Convs." + std::to_string(k);
+            if (g_unet_up_fold) {
+                const int q = tensor("convs" + std::to_string(k) + ".q", level + 2, 2 * C);
+                conv_derived(L + ".u", {{fe, 0}}, q, 1, PreRef());
+                conv_derived(L + ".r", {{r, 0}}, out, 0, PreRef{q, 0, C, 2, 1});
+            } else {
+                const int up = tensor("up" + std::to_string(k), level, C);
+                up4(fe, up);
+                conv(L, {{up, 0}, {r, 0}}, out);
+            }
+        };
+        int f7 = tensor("fe7", 4, BASE * 4), c0 = tensor("convs0", 2, BASE * 4);
         conv("feat_extract.7", {{z, 0}}, f7);
-        up4(f7, u7);
-        conv("Convs.0", {{u7, 0}, {r3, 0}}, c0);
+        up_conv(0, f7, 2, BASE * 4, r3, c0);
         z = resblocks("Decoder.1", c0, 2, BASE * 4);
         // unet.py:268-273
-        int f3 = tensor("fe3", 3, BASE * 2), u3 = tensor("up3", 1, BASE * 2), c1 = tensor("convs1", 1, BASE * 2);
+        int f3 = tensor("fe3", 3, BASE * 2), c1 = tensor("convs1", 1, BASE * 2);
         conv("feat_extract.3", {{z, 0}}, f3);
-        up4(f3, u3);
-        conv("Convs.1", {{u3, 0}, {r2, 0}}, c1);
+        up_conv(1, f3, 1, BASE * 2, r2, c1);
         z = resblocks("Decoder.2", c1, 1, BASE * 2);
         // unet.py:276-282
-        int f4 = tensor("fe4", 2, BASE), u4 = tensor("up4", 0, BASE), c2 = tensor("convs2", 0, BASE);
+        int f4 = tensor("fe4", 2, BASE), c2 = tensor("convs2", 0, BASE);
         conv("feat_extract.4", {{z, 0}}, f4);
-        up4(f4, u4);
-        conv("Convs.2", {{u4, 0}, {r1, 0}}, c2);
+        up_conv(2, f4, 0, BASE, r1, c2);
         z = resblocks("Decoder.3", c2, 0, BASE);
         conv("feat_extract.5", {{z, 0}}, rgb);
         u->ws_used = used;
@@ -793,10 +823,12 @@ extern "C" const float *read_unet_debug_tensor(read_unet_t *u, const char *name,
 namespace readhip {
 void unet_set_streams(int v) { g_unet_streams = v; }
 void unet_set_aff_split(int v) { g_unet_aff_split = v; }
+void unet_set_up_fold(int v) { g_unet_up_fold = v; }
 int unet_get(const char *key, int *value)
 {
     if (!strcmp(key, "unet_streams")) *value = g_unet_streams;
     else if (!strcmp(key, "unet_aff_split")) *value = g_unet_aff_split;
+    else if (!strcmp(key, "unet_up_fold")) *value = g_unet_up_fold;
     else return 0;
     return 1;
 }

@@ -27,8 +27,11 @@ def _world(group=None):
     return dist.get_world_size(group) if (dist.is_available() and dist.is_initialized()) else 1
 
 
+FORCE_COLLECTIVES = False        # tests: issue the collectives on a 1-rank group too (the RCCL path on a single GPU)
+
+
 def _on(group=None):
-    return _world(group) > 1
+    return _world(group) > 1 or (FORCE_COLLECTIVES and dist.is_available() and dist.is_initialized())
 
 
 class GradientArena:
@@ -68,8 +71,7 @@ class GradientArena:
         """Mean over the ranks of every gradient; ``p.grad`` then aliases the arena.  async_op: returns after the collective is
         enqueued (the caller runs the descriptor exchange meanwhile) — call ``wait()`` before the optimizer step."""
         self.pack()
-        w = _world(self.group)
-        if w > 1:
+        if _on(self.group):
             self.pending = dist.all_reduce(self.flat, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
         if not async_op:
             self.wait()
@@ -90,7 +92,7 @@ def exchange_pairs(ids, rows, group=None):
     all-gather), the payloads are padded to the longest rank's length for the collective and trimmed afterwards.  A rank with
     no pairs this step passes empty tensors (every rank must still call).  Without a process group: the input, unscaled."""
     w = _world(group)
-    if w == 1:
+    if not _on(group):
         return ids, rows
     dev = ids.device
     C = rows.shape[1]

@@ -61,7 +61,8 @@ def gated_conv(packed, sources, stride=1, elu=True, mul=None, residual=None, con
     """sources: list of (NHWC tensor (h,w,C), shift).  Returns the NHWC output (outH,outW,Cout).
 
     linear: plain convolution, output channels [conv_f + b_f | conv_m + b_m] (2*Cout).
-    pre: (NHWC tensor, f_off, m_off, shift) pre-activation addend sampled at (y >> shift, x >> shift)."""
+    pre: (NHWC tensor, f_off, m_off, shift[, bilinear]) pre-activation addend sampled at (y >> shift, x >> shift), or — with
+    bilinear = True and shift 2 — as nn.Upsample(x4, bilinear, align_corners=False) of the tensor (include/read_hip.h)."""
     t0, s0 = sources[0]
     inH = (t0.shape[0] >> s0) if s0 >= 0 else (t0.shape[0] << -s0)
     inW = (t0.shape[1] >> s0) if s0 >= 0 else (t0.shape[1] << -s0)
@@ -95,7 +96,8 @@ def gated_conv(packed, sources, stride=1, elu=True, mul=None, residual=None, con
     d.wpacked_sc = packed.wpacked_sc.data_ptr() if packed.wpacked_sc is not None else None
     d.linear = 1 if linear else 0
     if pre is not None:
-        pt, f_off, m_off, psh = pre
+        pt, f_off, m_off, psh = pre[:4]
+        d.pre_bilinear = 1 if (len(pre) > 4 and pre[4]) else 0
         assert pt.is_contiguous() and pt.dtype == torch.float32
         d.pre, d.pre_cstride, d.pre_f_off, d.pre_m_off, d.pre_shift = pt.data_ptr(), pt.shape[2], f_off, m_off, psh
         d.preH, d.preW = pt.shape[0], pt.shape[1]

@@ -114,6 +114,11 @@ class UNetEngine:
                    "read_unet_forward")
         return out
 
+    def launch_labels(self):
+        """Labels of the plan's launches in order (layer paths; ``up4(..)`` for a separate bilinear pass)."""
+        L = _lib.lib()
+        return [L.read_unet_launch_label(self.handle, i).decode() for i in range(L.read_unet_launch_count(self.handle))]
+
     def profile(self, x0, x1, x2, x3, channels=3):
         """One instrumented frame: [(label, ms, flops, is_conv3x3_s1)] per launch (synchronises)."""
         L = _lib.lib()
@@ -215,6 +220,11 @@ class UNet(nn.Module):
         self._packed = None
         self._engines = {}
         self.__dict__['_flat_tensors'] = None
+
+    def launch_labels(self):
+        """Launch labels of the most recently built plan (tests)."""
+        e = list(self._engines.values())
+        return e[-1].launch_labels() if e else []
 
     def load_state_dict(self, *args, **kwargs):
         self.invalidate()

@@ -172,8 +172,18 @@ def test_unet_blob_sizes_and_plan_flops():
         r = 4.0 * (px[0] * 32 * 32 + px[1] * 96 * 64 + px[2] * 224 * 128)
         return (q + r) / 1e9
 
-    for split, launches in ((0, 102), (1, 105)):
+    def up_gflop(H, W, fold):
+        # Convs.k over cat[Upsample4(fe_k), r_k], C = 128 / 64 / 32 at levels 2 / 1 / 0: folded, the up-sampled half is applied to
+        # fe_k at ITS level (two levels coarser, 1/16 of the pixels) — read_conv_desc.pre_bilinear
+        px = [H * W >> (2 * l) for l in range(5)]
+        tot = 0.0
+        for k, (lvl, Cc) in enumerate(((2, 128), (1, 64), (0, 32))):
+            tot += 4.0 * px[lvl] * (2 * Cc) * Cc if not fold else 4.0 * (px[lvl] + px[lvl + 2]) * Cc * Cc
+        return tot / 1e9
+
+    for split, fold, launches in ((0, 0, 102), (1, 0, 105), (0, 1, 102), (1, 1, 105)):
         _lib.check(L.read_tuning_set(b"unet_aff_split", split))
+        _lib.check(L.read_tuning_set(b"unet_up_fold", fold))
         for (H, W, gflop) in [(352, 1216, 1221.73), (256, 256, 187.06)]:
             need = L.read_unet_workspace_bytes(H, W)
             ws = np.empty(need + 256, np.uint8)
@@ -188,7 +198,7 @@ def test_unet_blob_sizes_and_plan_flops():
                 fl = C.c_double()
                 L.read_unet_launch_info(h, i, C.byref(fl), None, None, None, None, None)
                 tot += fl.value
-            want = gflop - aff_gflop(H, W, 0) + aff_gflop(H, W, split)
+            want = gflop - aff_gflop(H, W, 0) + aff_gflop(H, W, split) - up_gflop(H, W, 0) + up_gflop(H, W, fold)
             assert abs(tot / 1e9 - want) < 0.01, (split, tot / 1e9, want)
             L.read_unet_destroy(h)
     assert kc_for([8, 56]) == 8 and kc_for([32, 64, 128, 256]) == 16

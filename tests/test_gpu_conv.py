@@ -239,6 +239,47 @@ def test_coarse_sources_as_pre_activation_addends(hip):
         _lib.check(_lib.lib().read_tuning_set(b"conv_px", 1))
 
 
+def test_bilinear_upsampled_source_as_pre_activation_addend(hip):
+    """Convs.k of read_unet (round 5): a 1x1 conv commutes with BILINEAR up-sampling too, so the half of
+    cat[nn.Upsample(x4, bilinear)(fe), r] -> 1x1 (unet.py:261-262,269-270,277-278) that multiplies the up-sampled tensor is applied
+    to fe at 1/16 of the pixels by a `linear` launch and enters the gated launch as a bilinear pre-activation addend
+    (read_conv_desc.pre_bilinear): the up-sampled tensor is never written.  Reference: torch's own Upsample + the full conv.
+    Ragged sizes (image edges clamp), all three channel counts of the network, and the refusals."""
+    from read_amd import _lib
+    torch.manual_seed(23)
+    up = torch.nn.Upsample(scale_factor=4, mode="bilinear", align_corners=False)
+    for (c, h, w) in ((128, 5, 19), (64, 11, 38), (32, 22, 76), (32, 1, 1), (64, 3, 2)):
+        fe, r = torch.randn(c, h, w), torch.randn(c, 4 * h, 4 * w)
+        st = _state(2 * c, c, 1, seed=40 + c + h)
+        ref = unet_torch.basic_conv(st, "L", torch.cat([up(fe[None]), r[None]], 1), 1, elu=True)[0]
+        b = "L.block."
+
+        def part(c0, c1, own):
+            sub = dict(st)
+            for br in ("conv_f", "conv_m"):
+                sub[b + br + ".weight"] = np.ascontiguousarray(st[b + br + ".weight"][:, c0:c1])
+                if not own:
+                    sub[b + br + ".bias"] = np.zeros(c, np.float32)
+            return _pack(sub, [c1 - c0])
+
+        q = gated_conv(part(0, c, False), [(_nhwc(fe), 0)], linear=True)                      # (h, w, 2c): [f | m] at fe's level
+        got = gated_conv(part(c, 2 * c, True), [(_nhwc(r), 0)], elu=True, pre=(q, 0, c, 2, True))
+        _close(got, ref, f"bilinear addend C={c} {h}x{w}")
+        res = torch.randn(c, 4 * h, 4 * w)                                                     # + residual through the same epilogue
+        got = gated_conv(part(c, 2 * c, True), [(_nhwc(r), 0)], elu=False, pre=(q, 0, c, 2, True), residual=_nhwc(res))
+        ref2 = unet_torch.basic_conv(st, "L", torch.cat([up(fe[None]), r[None]], 1), 1, elu=False)[0] + res
+        _close(got, ref2, f"bilinear addend + residual C={c} {h}x{w}")
+    # refusals: another shift, a 3x3 layer
+    fe, r = torch.randn(32, 4, 4), torch.randn(32, 16, 16)
+    st = _state(32, 32, 1, seed=3)
+    q = gated_conv(_pack(st, [32]), [(_nhwc(fe), 0)], linear=True)
+    with pytest.raises(_lib.ReadHipError, match="pre_bilinear"):
+        gated_conv(_pack(st, [32]), [(_nhwc(r[:, :8, :8].contiguous()), 0)], pre=(q, 0, 32, 1, True))
+    st3 = _state(32, 32, 3, seed=4)
+    with pytest.raises(_lib.ReadHipError):
+        gated_conv(_pack(st3, [32]), [(_nhwc(r), 0)], pre=(q, 0, 32, 2, True))
+
+
 def test_pixel_lane_kernel_for_1x1_layers(hip):
     """config=-2 forces the pixel-lane 1x1 kernel (weights as the MFMA A operand, LDS-resident; activations straight
     from NHWC memory): the 1x1 shapes of the network, ragged pixel counts, resampled / concatenated sources, residual,

@@ -3,6 +3,8 @@ the functional restatement of the reference's modules): per-layer gradients of e
 adjoint, the Huber loss, the full UNet backward on a crop, the sparse descriptor RMSprop against torch.optim.RMSprop, and
 one whole optimisation step through TexturePipeline.  Stated tolerance: gradients rtol 1e-4 of the largest gradient entry of
 the tensor (fp32, different summation orders; wgrad sums ~10^4..10^5 products per weight)."""
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -758,3 +760,81 @@ def test_model_and_loss_under_dataparallel_on_one_gpu(hip):
             assert abs(float(losses[k]) - float(losses_dp[k])) <= 1e-6 * abs(float(losses[k])), k
     finally:
         _alias.set_result_convention(None)
+
+
+def test_data_parallel_step_on_a_single_rank_rccl_group(hip):
+    """SURVEY 8e "Training" / VERDICT r4 #7: the data-parallel exchange (read_amd/ddp.py) on the device — a 1-rank RCCL group with
+    the collectives forced on: the flat gradient arena is all-reduced by RCCL, fused Adam consumes the arena views, the gathered
+    (id, row) pairs feed read_rmsprop_sorted.  With one rank the mean is the identity, so two optimisation steps through
+    DataParallelStep.reduce() must leave EXACTLY the weights and descriptors of the same two steps without it.  (World size 2
+    on gloo: tests/test_ddp_gloo.py.)"""
+    import socket
+    from types import SimpleNamespace
+    import torch.distributed as dist
+    from read_amd import ddp
+    from read_amd.pipeline import TexturePipeline
+    H, W, N = 32, 48, 3000
+
+    class DS:
+        id, name = 0, "scene0"
+        scene_data = {'pointcloud': {'xyz': np.zeros((N, 3), np.float32)}}
+        def load(self): pass
+        def unload(self): pass
+
+    class Crit(torch.nn.Module):
+        def forward(self, out, target):
+            return huber_loss(out, target)
+
+    keys = "uv_1d_p1, uv_1d_p1_ds1, uv_1d_p1_ds2, uv_1d_p1_ds3, uv_1d_p1_ds4".replace(' ', '').split(',')
+
+    def run(with_ddp):
+        rng = np.random.default_rng(16)
+        args = SimpleNamespace(inference=False, descriptor_size=8, texture_activation='none', use_mesh=False, supersampling=1,
+                               lr=1e-3, texture_lr=1e-1, texture_ckpt=None, get_datasets=lambda a: ([DS()], [DS()]),
+                               criterion_module=Crit, criterion_args={}, pipeline='READ.pipelines.ogl.TexturePipeline')
+        pipe = TexturePipeline()
+        pipe.create(args)
+        state = synthetic.make_unet_state(UNET_SPEC, 2)
+        pipe.net.load_state_dict({k: torch.from_numpy(np.asarray(v)) for k, v in state.items()})
+        tex = pipe.textures[0]
+        with torch.no_grad():
+            tex.texture_.copy_(torch.from_numpy(rng.random((1, 8, N)).astype(np.float32)))
+        model = pipe.model.cuda()
+        pipe.dataset_load([DS()])
+        model.cuda().eval()
+        extra = pipe.extra_optimizer([DS()])
+        step = ddp.DataParallelStep(pipe.net, pipe.textures) if with_ddp else None
+        for it in range(2):
+            maps = [rng.integers(0, N, (2, 1, H >> l, W >> l)) for l in range(5)]
+            target = torch.from_numpy(rng.random((2, 3, H, W)).astype(np.float32))
+            inputs = {'id': torch.tensor([0, 0])}
+            inputs.update({k: torch.from_numpy(m).float().cuda() for k, m in zip(keys, maps)})
+            loss = pipe.criterion(model(inputs), target.cuda()) * 1e4
+            loss.backward()
+            if step is not None:
+                step.reduce()
+                assert all(p.grad.data_ptr() == v.data_ptr() for p, v in zip(step.arena.params, step.arena.views))
+            pipe.optimizer.step()
+            pipe.optimizer.zero_grad()
+            extra.step()
+            extra.zero_grad()
+        torch.cuda.synchronize()
+        return ({k: v.detach().cpu().clone() for k, v in pipe.net.state_dict().items()},
+                tex.state_dict()["texture_"].cpu().clone(), None if step is None else step.arena.nbytes)
+
+    want_net, want_tex, _ = run(False)
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    ddp.FORCE_COLLECTIVES = True
+    try:
+        got_net, got_tex, nbytes = run(True)
+    finally:
+        ddp.FORCE_COLLECTIVES = False
+        dist.destroy_process_group()
+    assert nbytes >= 4 * sum(v.numel() for k, v in want_net.items() if v.dtype == torch.float32 and "running" not in k and "num_batches" not in k)
+    for k, v in want_net.items():
+        assert torch.equal(got_net[k], v), f"{k}: the step through the RCCL exchange differs from the plain step"
+    assert torch.equal(got_tex, want_tex), "descriptors after two steps through the pair exchange differ"

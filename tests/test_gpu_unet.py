@@ -221,6 +221,41 @@ def test_winograd_and_direct_conv_paths_agree(hip):
         assert float((outs[a] - outs[b]).abs().max()) <= 2 * MAX_ABS
 
 
+def test_plan_variants_agree_with_the_oracle(hip):
+    """The plan's two algebraic rewrites — AFF inputs of coarser levels applied at their own level (unet_aff_split) and the
+    bilinear x4 up-sampling folded into the Convs.k launches as a pre-activation addend (unet_up_fold, round 5) — against the plan
+    wired exactly as the reference (both off: 480-channel AFF concats, three separate Upsample passes): each meets the tolerance
+    against the oracle, the launch labels say which plan ran, and the rewrites really change the arithmetic (round-off differs)."""
+    from read_amd import _lib
+    torch.manual_seed(5)
+    state = synthetic.make_unet_state(UNET_SPEC, 13)
+    net = UNet()
+    net.load_state_dict({k: torch.from_numpy(np.asarray(v)) for k, v in state.items()})
+    net.cuda().eval()
+    xs = [torch.rand(1, 8, 96 >> l, 160 >> l) for l in range(5)]
+    ref = unet_torch.unet_forward(state, *xs[:4])
+    L = _lib.lib()
+    outs = {}
+    try:
+        for split, fold in ((1, 1), (1, 0), (0, 1), (0, 0)):
+            _lib.check(L.read_tuning_set(b"unet_aff_split", split))
+            _lib.check(L.read_tuning_set(b"unet_up_fold", fold))
+            net.invalidate()                                          # plans are built under the knobs of their creation
+            with torch.no_grad():
+                outs[(split, fold)] = net(*[x.cuda() for x in xs]).cpu()
+            _check_rgb(outs[(split, fold)], ref, f"plan aff_split={split} up_fold={fold}")
+            labels = net.launch_labels()
+            assert any(l.startswith("up4(") for l in labels) == (fold == 0), labels
+            assert ("Convs.2.r" in labels) == (fold == 1) and ("AFFq3" in labels) == (split == 1)
+    finally:
+        _lib.check(L.read_tuning_set(b"unet_aff_split", 1))
+        _lib.check(L.read_tuning_set(b"unet_up_fold", 1))
+        net.invalidate()
+    assert not torch.equal(outs[(1, 1)], outs[(1, 0)]) and not torch.equal(outs[(1, 1)], outs[(0, 1)])
+    for k in outs:
+        assert float((outs[k] - outs[(0, 0)]).abs().max()) <= 2 * MAX_ABS
+
+
 def test_headline_frame_1216x352_vs_oracle(hip):
     """The configuration bench.py times: the full UNet at 1216x352 (every persistent-scheduling path of the 32/64/128/256
     channel Winograd launches at 352x1216 / 176x608 / 88x304 / 44x152) on the descriptor pyramids of a rasterised

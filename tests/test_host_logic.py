@@ -65,12 +65,16 @@ def test_aff_weight_blocks_in_the_packed_blob():
                 off += L.read_conv_w4_floats(cin, cout)
         if L.read_conv_sc_floats(cin, cout) and k == 3:                    # the 32 -> 3 layer: the vector-pipe order, 64-byte aligned
             off = (off + 15) // 16 * 16 + L.read_conv_sc_floats(cin, cout)
-    derived = [("AFFq3", 224, 256, (0, 1, 2)), ("AFFq2", 96, 128, (0, 1)), ("AFFq1", 32, 64, (0,)),
-               ("AFFs.0.conv.0r", 0, 32, (0,)), ("AFFs.1.conv.0r", 0, 96, (1,)), ("AFFs.2.conv.0r", 0, 224, (2,))]
+    aff = lambda *ks: tuple(f"AFFs.{k}.conv.0" for k in ks)                # noqa: E731
+    derived = [("AFFq3", 224, 256, aff(0, 1, 2)), ("AFFq2", 96, 128, aff(0, 1)), ("AFFq1", 32, 64, aff(0)),
+               ("AFFs.0.conv.0r", 0, 32, aff(0)), ("AFFs.1.conv.0r", 0, 96, aff(1)), ("AFFs.2.conv.0r", 0, 224, aff(2))]
+    # round 5: Convs.k over cat[Upsample4(fe), r] split into the half applied at fe's level (.u) and the half at r's level (.r)
+    for k, c in enumerate((128, 64, 32)):
+        derived += [(f"Convs.{k}.u", 0, c, (f"Convs.{k}",)), (f"Convs.{k}.r", c, c, (f"Convs.{k}",))]
     rng = np.random.default_rng(5)
     for name, ci0, cin, affs in derived:
-        wf = np.concatenate([np.asarray(state[f"AFFs.{a}.conv.0.block.conv_f.weight"])[:, ci0:ci0 + cin, 0, 0] for a in affs])
-        wm = np.concatenate([np.asarray(state[f"AFFs.{a}.conv.0.block.conv_m.weight"])[:, ci0:ci0 + cin, 0, 0] for a in affs])
+        wf = np.concatenate([np.asarray(state[f"{a}.block.conv_f.weight"])[:, ci0:ci0 + cin, 0, 0] for a in affs])
+        wm = np.concatenate([np.asarray(state[f"{a}.block.conv_m.weight"])[:, ci0:ci0 + cin, 0, 0] for a in affs])
         cout = wf.shape[0]
         n = L.read_conv_packed_floats(cin, cout, 1)
         blk = packed[off:off + n].reshape(cin // 8, (cout + 31) // 32 * 2, 64, 4)          # [k8 step][tile (f, m)][lane][4]
