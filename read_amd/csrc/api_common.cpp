@@ -85,9 +85,9 @@ extern "C" int read_debug_set_trace(void *buf, size_t bytes)
 // ("conv_ablate") exist only in builds with -DREAD_DEBUG_KNOBS.
 static const char *const k_tuning_keys[] = {"splat_mode", "splat_stats", "splat_subset", "splat_near", "splat_cells",
                                             "splat_cells_sub", "splat_seeds", "splat_items", "splat_strips", "splat_wgs", "splat_zl2", "splat_lds", "splat_bins", "splat_kslot", "unet_streams", "unet_aff_split", "unet_up_fold", "conv_kc32", "conv_px", "conv_sc", "conv_wino_wgs",
-                                            "conv_wino", "conv_w16", "conv_w4", "conv_w4x2", "conv_w4_grid", "conv_stagger", "conv_wave", "wgrad_wino",
+                                            "conv_wino", "conv_w16", "conv_w4", "conv_w4_grid", "conv_stagger", "conv_wave", "wgrad_wino",
 #ifdef READ_DEBUG_KNOBS
-                                            "conv_ablate", "conv_abl",
+                                            "conv_ablate", "conv_abl", "conv_w4x2",
 #endif
                                             nullptr};
 
@@ -122,7 +122,6 @@ extern "C" int read_tuning_set(const char *key, int value)
     if (!strcmp(key, "conv_px")) { readhip::conv_set_px(value); return READ_OK; }             // pixel-lane kernel for 1x1 layers
     if (!strcmp(key, "conv_sc")) { readhip::conv_set_sc(value); return READ_OK; }             // vector-pipe kernel for Cout <= 4
     if (!strcmp(key, "conv_kc32")) { readhip::conv_set_kc32(value); return READ_OK; }
-    if (!strcmp(key, "conv_w4x2")) { readhip::conv_set_w4x2(value); return READ_OK; }         // EXPERIMENTAL (not validated on a GPU yet): two waves per SIMD
     if (!strcmp(key, "conv_w4_grid")) { readhip::conv_set_w4_grid(value); return READ_OK; }   // F(4x4): equal units per workgroup
     if (!strcmp(key, "conv_w4")) { readhip::conv_set_w4(value); return READ_OK; }             // min Cin on the Winograd F(4x4,3x3) kernel (0 = off)
     if (!strcmp(key, "conv_w16")) { readhip::conv_set_w16(value); return READ_OK; }           // wave-autonomous Winograd kernel (0 = row-per-wave)
@@ -133,6 +132,7 @@ extern "C" int read_tuning_set(const char *key, int value)
 #ifdef READ_DEBUG_KNOBS
     if (!strcmp(key, "conv_ablate")) { readhip::conv_set_ablate(value); return READ_OK; }
     if (!strcmp(key, "conv_abl")) { readhip::conv_set_abl(value); return READ_OK; }          // probes of the 16x16x4 Winograd kernels
+    if (!strcmp(key, "conv_w4x2")) { readhip::conv_set_w4x2(value); return READ_OK; }        // the two-waves-per-SIMD F(4x4) kernel (measured slower)
 #endif
     readhip::set_error("read_tuning_set: unknown key '%s'", key);
     return READ_EINVAL;

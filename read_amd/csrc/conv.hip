@@ -1942,26 +1942,22 @@ __global__ __launch_bounds__(256, 1) void gated_conv_wino4_kernel(const ConvKArg
 }
 
 // ------------------------------------------------------------------------------------------
-// EXPERIMENTAL, OFF (read_tuning_set("conv_w4x2", 1)), written at the end of round 4 with no GPU time left to run it: the
-// F(4x4,3x3) kernel above cut for TWO waves per SIMD.  Why (DESIGN.md 12.1 d): one wave per SIMD issues a vector instruction every
-// 5.2 cycles, two waves one every 2.6 (tools/valu_probe.py), and a VALU instruction behind an fp32 MFMA costs 4 - 11.5 cycles with one
-// wave per SIMD against 1.4 - 2.5 with two (tools/issue_probe.py): the transform and the 820-instruction epilogue are paid at the
-// single-wave price above.  The accumulators do not shrink with the tile (36 frequencies x a 16 x 16 MFMA block), so the cut is over
-// FREQUENCIES: eight waves per workgroup, wave (co = w & 3, fh = w >> 2) owns output channels 8 co .. 8 co + 7 and frequency rows
-// 3 fh .. 3 fh + 2 of the 6 x 6 grid — 18 frequencies, 72 accumulators, the SAME weight blob (a wave reads its half of its
-// channel octet's 36 fragments) and the same V buffer.
-//   * input transform by halves: thread (channel c16, tile, h = fh) reads the whole 6 x 6 patch and forms rows 3 h .. 3 h + 2 of
-//     B^T d (8 / 6 packed operations per column pair) and their products with B (the row routine above, 3 x 9): its half's 18
-//     frequencies;
-//   * per 16-channel chunk 72 MFMAs per wave, the shadow schedule of the kernel above compressed onto them;
-//   * output transform by halves (tests/test_wino4x2_model.py): the column pass is local to a frequency row; the row pass is
-//     linear in the rows, so a wave forms partial sums of all four output rows from its three rows, keeps output rows 2 fh, 2 fh + 1
-//     and hands the other two to its partner wave (w ^ 4, by construction on the same SIMD) through LDS — 8 float4 per lane each
-//     way in two rounds of 4 KiB per wave, a message counter and a read counter per wave instead of a workgroup barrier — then gates
-//     its two rows (half of the epilogue's instructions each).
-// Inference launches without the FAM multiply only.  tests/test_gpu_conv.py::test_winograd_f4_two_waves_per_simd_variant runs it
-// against the kernel above when READ_AMD_TEST_W4X2=1.
+// NEGATIVE RESULT, kept in the DEBUG library only (-DREAD_DEBUG_KNOBS, read_tuning_set("conv_w4x2", 1)): the F(4x4,3x3) kernel
+// above cut for TWO waves per SIMD.  Why it was tried (DESIGN.md 12.1 d): one wave per SIMD issues a vector instruction every
+// 5.2 cycles, two waves one every 2.6 (tools/valu_probe.py), and a VALU instruction behind an fp32 MFMA costs 4 - 11.5 cycles with
+// one wave per SIMD against 1.4 - 2.5 with two (tools/issue_probe.py).  The accumulators do not shrink with the tile (36
+// frequencies x a 16 x 16 MFMA block), so the cut is over FREQUENCIES: eight waves per workgroup, wave (co = w & 3, fh = w >> 2) owns
+// output channels 8 co .. 8 co + 7 and frequency rows 3 fh .. 3 fh + 2 of the 6 x 6 grid — 18 frequencies, 72 accumulators, the SAME
+// weight blob and the same V buffer; input transform by halves (each half reads the whole 6 x 6 patch), output transform by halves
+// with a hand-over of partial row sums between the wave pair through LDS (message counters, no workgroup barrier).
+// MEASURED in round 5 (profiles/r5_w4x2_ab.json, tools/w4x2_ab.py; results equal to the kernel above within 7e-6, parity test
+// green): 73.2 / 67.7 / 62.5 / 61.1 us per launch at C = 32 / 64 / 128 / 256 against 71.2 / 66.1 / 59.4 / 56.0 for the one-wave
+// kernel, 214.6 against 220.8 frames/s in bench.py — SLOWER at every level.  The reason is structural, not a tuning state: the
+// split halves the cost of a vector instruction and doubles their number (each wave still reads the whole 6 x 6 patch, runs its own
+// operand rings and address bookkeeping: ~345 non-MFMA instructions per 72 MFMAs and wave, i.e. 690 per SIMD and stage against ~300),
+// and the hand-over adds a dependent LDS round trip per unit.  It is therefore not part of libreadhip.so.
 // ------------------------------------------------------------------------------------------
+#ifdef READ_DEBUG_KNOBS
 __global__ __launch_bounds__(512, 1) void gated_conv_wino4x2_kernel(const ConvKArgs a)
 {
     using WG = Wino4Geom;
@@ -2313,6 +2309,7 @@ __global__ __launch_bounds__(512, 1) void gated_conv_wino4x2_kernel(const ConvKA
         __builtin_amdgcn_s_setprio(0);
     }
 }
+#endif  // READ_DEBUG_KNOBS
 
 // ------------------------------------------------------------------------------------------
 // 3x3 / stride-1 layers with at most FOUR output channels on the vector pipe (READ's output layer, feat_extract.5: 32 -> 3).
@@ -2769,7 +2766,7 @@ int g_conv_px = 1;         // read_tuning_set("conv_px", v): pixel-lane kernel f
 int g_kc32 = 1;            // 32-channel chunks for 1x1 layers whose sources are all multiples of 32 (read_tuning_set("conv_kc32", 0): 16)
 int g_use_wino = 1 << 30;  // read_tuning_set("conv_wino", max Cin): Winograd kernel for eligible 3x3 layers (0 = off)
 int g_w4_grid = 0;        // read_tuning_set("conv_w4_grid", 1): F(4x4) launches with the same number of units per workgroup (measured: see profiles)
-int g_w4x2 = 0;            // read_tuning_set("conv_w4x2", 1): EXPERIMENTAL two-waves-per-SIMD F(4x4) kernel for inference launches (not validated: off)
+int g_w4x2 = 0;            // debug library only: read_tuning_set("conv_w4x2", 1) = the two-waves-per-SIMD F(4x4) kernel (measured slower, round 5)
 int g_w4 = 32;             // read_tuning_set("conv_w4", min Cin): layers with at least this many channels take the Winograd F(4x4,3x3)
 int g_sc = 8;              // read_tuning_set("conv_sc", 0): the output layer (Cout <= 4) back on the F(2x2) MFMA kernel instead of the vector pipe; other values: conv_set_sc
                            // kernel when its weights were supplied (0 = never)
@@ -3065,7 +3062,9 @@ int conv_get(const char *key, int *value)
     else if (!strcmp(key, "conv_kc32")) *value = g_kc32;
     else if (!strcmp(key, "conv_px")) *value = g_conv_px;
     else if (!strcmp(key, "conv_sc")) *value = g_sc;
+#ifdef READ_DEBUG_KNOBS
     else if (!strcmp(key, "conv_w4x2")) *value = g_w4x2;
+#endif
     else if (!strcmp(key, "conv_wino_wgs")) *value = g_wino_wgs;
     else if (!strcmp(key, "conv_wino")) *value = g_use_wino;
     else if (!strcmp(key, "conv_w16")) *value = g_w16;
@@ -3413,11 +3412,13 @@ int launch_gated_conv(const read_conv_desc *d, hipStream_t stream)
             }
         }
 #endif
-        if (g_w4x2 && !d->linear && !d->mul) {   // experimental: eight waves per workgroup, frequencies split over wave pairs
+#ifdef READ_DEBUG_KNOBS
+        if (g_w4x2 && !d->linear && !d->mul) {   // negative result (see the kernel): eight waves per workgroup, frequencies split over wave pairs
             hipLaunchKernelGGL(gated_conv_wino4x2_kernel, dim3((unsigned)nwg), dim3(512), 0, stream, a);
             READ_CHECK_LAUNCH();
             return READ_OK;
         }
+#endif
         hipLaunchKernelGGL(fn4, dim3((unsigned)nwg), dim3(256), 0, stream, a);
         READ_CHECK_LAUNCH();
         return READ_OK;

@@ -243,7 +243,12 @@ namespace {
 size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 
 int g_unet_aff_split = 1;     // read_tuning_set("unet_aff_split", 0): the AFF first convs as single 480-channel launches
-int g_unet_up_fold = 1;       // read_tuning_set("unet_up_fold", 0): bilinear x4 as a separate pass + Convs.k over the 2C-channel concat
+// read_tuning_set("unet_up_fold", 1): the bilinear x4 up-sampling folded into the Convs.k launches (read_conv_desc.pre_bilinear).
+// Built and measured in round 5 (profiles/r5_up_fold_ab.md): results equal (148 dB either way) and 110 MB per frame less written and
+// re-read, but NOT faster — the three tiny `Convs.k.u` launches cost 14 - 22 us each (launch floor of the 1x1 kernels) and the
+// bilinear epilogue gathers 32 float4 per lane: Convs.0 / 1 / 2 take 64.8 / 63.6 / 102.0 us folded against 61.6 / 70.2 / 83.9 with
+// the separate pass (non-family launches 1.346 vs 1.332 ms per frame, 220.8 vs 220.4 frames/s).  Default off.
+int g_unet_up_fold = 0;
 
 struct Builder {
     read_unet *u;

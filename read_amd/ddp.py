@@ -157,7 +157,8 @@ class DataParallelStep:
     scaled pairs of all ranks, which ``SparseDescriptorRMSprop.step()`` then consumes unchanged."""
 
     def __init__(self, net, textures=(), group=None, broadcast=True):
-        self.net, self.textures, self.group = net, list(textures), group
+        # pipeline.textures is {dataset id: PointTexture} (READ/pipelines/ogl.py:82-97): a mapping gives its values
+        self.net, self.textures, self.group = net, list(textures.values() if hasattr(textures, 'values') else textures), group
         self.arena = GradientArena(net.parameters(), group)
         if broadcast:
             broadcast_parameters(net, 0, group)

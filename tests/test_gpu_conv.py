@@ -105,9 +105,9 @@ def test_winograd_f4_kernel(hip):
         _close(got, ref, f"FAM through F(4x4) C={c}", scale=10.0)
 
 
-@pytest.mark.skipif(os.environ.get("READ_AMD_TEST_W4X2") != "1",
-                    reason="the two-waves-per-SIMD F(4x4) kernel is experimental and off (written without GPU time left in round 4); "
-                           "READ_AMD_TEST_W4X2=1 runs it")
+@pytest.mark.skipif(os.environ.get("READ_AMD_TEST_W4X2") != "1" or os.environ.get("READ_HIP_DEBUG") != "1",
+                    reason="the two-waves-per-SIMD F(4x4) kernel was measured slower in round 5 (profiles/r5_w4x2_ab.json) and is "
+                           "compiled into the debug library only; READ_HIP_DEBUG=1 READ_AMD_TEST_W4X2=1 runs its parity test")
 def test_winograd_f4_two_waves_per_simd_variant(hip):
     """knob conv_w4x2: the frequency-split F(4x4,3x3) kernel (eight waves per workgroup; DESIGN.md 12.1 d, tests/test_wino4x2_model.py)
     against torch and against the one-wave-per-SIMD kernel on the shapes of test_winograd_f4_kernel."""

@@ -249,7 +249,7 @@ def test_plan_variants_agree_with_the_oracle(hip):
             assert ("Convs.2.r" in labels) == (fold == 1) and ("AFFq3" in labels) == (split == 1)
     finally:
         _lib.check(L.read_tuning_set(b"unet_aff_split", 1))
-        _lib.check(L.read_tuning_set(b"unet_up_fold", 1))
+        _lib.check(L.read_tuning_set(b"unet_up_fold", 0))             # the default (the fold measured level-to-slower, csrc/unet.cpp)
         net.invalidate()
     assert not torch.equal(outs[(1, 1)], outs[(1, 0)]) and not torch.equal(outs[(1, 1)], outs[(0, 1)])
     for k in outs:
