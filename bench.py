@@ -132,6 +132,7 @@ class SlabWorkload:
     """BASELINE configs[2]: synthetic KITTI-like slab, FrameRenderer (three C calls per frame)."""
     name = "slab30m"
     W, H = 1216, 352
+    announces_next = True            # the sweep's next pose is known: render_into(k, out, next_k)
 
     def __init__(self, a, dev, rank):
         self.N = a.points or 30_000_000
@@ -157,8 +158,10 @@ class SlabWorkload:
         self.describe = (f"BASELINE configs[2]: synthetic {N}-point KITTI-like slab, 1216x352, 8-dim descriptors, "
                          "256-pose sweep, 5-scale raster + gather + 99-conv gated UNet (seeded random weights), RGBA out")
 
-    def render_into(self, k, out):
-        self.fr.render_total(self.total[k], out=out)
+    def render_into(self, k, out, nxt=None):
+        # nxt: the sweep's next pose on this rank (sweep.run_steps(announce_next=True)): the rasteriser prepares that frame's
+        # chunk lists and depth seeds inside this frame's last launch (read_splat_hint_next_camera)
+        self.fr.render_total(self.total[k], out=out, next_total=None if nxt is None else self.total[nxt])
         return self.fr.frame_done                  # None (one frame at a time) or the event of this frame's UNet stream
 
     def timed_frame(self, k):
@@ -171,10 +174,10 @@ class SlabWorkload:
         torch.cuda.synchronize()
         return self.fr.idx, self.fr.depth, bufs[1]
 
-    def rasterize(self, k, wait=True):
+    def rasterize(self, k, wait=True, nxt=None):
         if wait:
             self.fr.sync()                           # three host-side stream synchronisations: not inside a timed loop (wait=False)
-        self.fr.rasterize(self.total[k])
+        self.fr.rasterize(self.total[k], None if nxt is None else self.total[nxt])
         return self.fr.idx, self.fr.depth
 
     def gather(self):
@@ -266,8 +269,11 @@ class Kitti6LikeWorkload:
         if getattr(self, "_cleanup", None):
             shutil.rmtree(self._cleanup, ignore_errors=True)
 
-    def render_into(self, k, out):
+    announces_next = True            # a pose sweep through the viewer API: Scene.announce_next_camera_view
+
+    def render_into(self, k, out, nxt=None):
         self.scene.set_camera_view(self.views[k])
+        self.scene.announce_next_camera_view(None if nxt is None else self.views[nxt])
         out.copy_(self.ogl.infer()["output"])
 
     def timed_frame(self, k):
@@ -279,9 +285,11 @@ class Kitti6LikeWorkload:
         idx, depth = self.rasterize(k)               # the same rasteriser call infer() made, with depth this time
         return idx, depth, out
 
-    def rasterize(self, k, wait=True):
+    def rasterize(self, k, wait=True, nxt=None):
         self.scene.set_camera_view(self.views[k])
-        self.idx, self.depth = self.scene.rasterizer().render(self.scene.total_matrix(), self.W, self.H, self.levels)
+        self.scene.announce_next_camera_view(None if nxt is None else self.views[nxt])
+        self.idx, self.depth = self.scene.rasterizer().render(self.scene.total_matrix(), self.W, self.H, self.levels,
+                                                              next_total=self.scene.take_next_total_matrix())
         return self.idx, self.depth
 
     def gather(self):
@@ -670,7 +678,8 @@ def verify(wl, first, pose=0):
 
 def timed_sweep(wl, ex, warmup, steps, world, dev, layout=None, shard=None):
     """The timed region of the contract: W untimed steps, then exactly K steps bracketed by barrier + synchronize; max over ranks."""
-    sweep.run_steps(wl.render_into, ex, 0, warmup, N_POSES, layout, shard)
+    ann = bool(getattr(wl, "announces_next", False))
+    sweep.run_steps(wl.render_into, ex, 0, warmup, N_POSES, layout, shard, ann)
     ex.drain()
     if hasattr(wl, "fr"):
         wl.fr.sync()
@@ -678,7 +687,7 @@ def timed_sweep(wl, ex, warmup, steps, world, dev, layout=None, shard=None):
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    sweep.run_steps(wl.render_into, ex, warmup, steps, N_POSES, layout, shard)
+    sweep.run_steps(wl.render_into, ex, warmup, steps, N_POSES, layout, shard, ann)
     ex.drain()
     torch.cuda.synchronize()
     if world > 1:
@@ -716,16 +725,44 @@ def stage_times(wl):
     """Per-kernel durations, live, with HIP events on the launch stream."""
     # the rasteriser warm-starts from the previous frame, so it is timed over consecutive poses of the sweep
     # (as in the timed loop), not over one repeated pose
+    import ctypes as C
     it = iter(range(1, 10 ** 6))
-    wl.rasterize(0)
-    # Two figures.  `splat_ms`: frames issued at the pace of rounds 2-3's loop (a few host-side calls between frames) — the sum of
-    # the five kernels' durations plus the gaps inside a frame; it agrees with the per-kernel sum of `rocprofv3 --kernel-trace
-    # --stats` (83 us).  `splat_ms_queued`: 64 frames queued back to back with no host call between them — on top of the kernels
-    # the device then spends ~2-3 us of launch gap per dependent kernel (tools/chain_probe.py): what a consumer pays per frame when
-    # nothing else runs on the device; in the frame loop those gaps are filled by the other frame's UNet launches.
-    ms_splat = hip_time_ms(lambda: wl.rasterize(next(it) % N_POSES), 32)
-    ms_splat_queued = hip_time_ms(lambda: wl.rasterize(next(it) % N_POSES, wait=False), 64, batches=3)
+    ann = bool(getattr(wl, "announces_next", False))
+
+    def frame(wait=True, announce=ann):
+        k = next(it) % N_POSES
+        wl.rasterize(k, wait=wait, nxt=(k + 1) % N_POSES if announce else None)
+
+    wl.rasterize(0, nxt=1 if ann else None)
+    # The rasteriser stage as the timed loop runs it: consecutive poses of the sweep, each frame announcing the next pose
+    # (read_splat_hint_next_camera: 4 dependent launches per frame).  `splat_ms`: frames issued at the pace of rounds 2-4's loop (a
+    # few host-side calls between frames) — the kernels' durations plus the gaps inside a frame.  `splat_ms_queued`: 64 frames
+    # queued back to back with no host call between them — on top of the kernels the device spends ~2-3 us of launch gap per
+    # dependent kernel (tools/chain_probe.py): what a consumer pays per frame when nothing else runs on the device; in the frame
+    # loop those gaps are filled by the other frame's UNet launches.  `splat_ms_unannounced`: the same loop without the
+    # announcement (5 launches, what a viewer with a free camera gets).  `splat_kernels_ms`: HIP events around every launch of a
+    # frame, median of 9 frames (read_splat_profile_last) — their sum is the frame's kernel time without any gap.
+    ms_splat = hip_time_ms(lambda: frame(), 32)
+    ms_splat_queued = hip_time_ms(lambda: frame(wait=False), 64, batches=3)
     STAGE_EXTRA["splat_ms_queued"] = ms_splat_queued
+    if ann:
+        STAGE_EXTRA["splat_ms_unannounced"] = hip_time_ms(lambda: frame(announce=False), 32)
+    try:
+        _lib.check(_lib.lib().read_tuning_set(b"splat_prof", 1))
+        rows = []
+        buf = (C.c_float * 5)()
+        frame()
+        for _ in range(9):
+            frame()
+            _lib.check(_lib.lib().read_splat_profile_last(buf), "read_splat_profile_last")
+            rows.append(list(buf))
+        med = [float(np.median([r[i] for r in rows])) for i in range(5)]
+        STAGE_EXTRA["splat_kernels_ms"] = dict(zip(("seed_classify", "pass_a", "merge_hiz", "pass_b", "resolve_and_next"), med))
+        STAGE_EXTRA["splat_kernel_sum_ms"] = float(sum(med))
+    except _lib.ReadHipError as e:                       # e.g. a cloud below the cell path's size: no per-kernel figures
+        STAGE_EXTRA["splat_kernels_ms"] = str(e)
+    finally:
+        _lib.check(_lib.lib().read_tuning_set(b"splat_prof", 0))
     ms_gather = hip_time_ms(lambda: wl.gather(), 10)
     ms_unet = hip_time_ms(lambda: wl.refine(), 3)
     return ms_splat, ms_gather, ms_unet
@@ -747,9 +784,13 @@ def shard_proxy(a, dev, wl, verify_it=True):
         ex = sweep.FrameExchange((wl.H, wl.W, 4), dev, torch.float32, None)
         dt = timed_sweep(wl, ex, a.warmup, n, 1, dev, layout, (PROXY_RANK, PROXY_WORLD))
         it = iter(range(10 ** 6))
-        pose = lambda: sweep.pose_of_step(next(it), PROXY_RANK, PROXY_WORLD, N_POSES, layout)     # noqa: E731
-        wl.rasterize(pose())
-        ms = hip_time_ms(lambda: wl.rasterize(pose(), wait=False), 32)
+
+        def frame(wait=False):                           # this rank's walk of the sweep, each frame announcing its next pose
+            i = next(it)
+            wl.rasterize(sweep.pose_of_step(i, PROXY_RANK, PROXY_WORLD, N_POSES, layout), wait=wait,
+                         nxt=sweep.pose_of_step(i + 1, PROXY_RANK, PROXY_WORLD, N_POSES, layout))
+        frame(wait=True)
+        ms = hip_time_ms(frame, 32)
         r = {"value": n / dt, "unit": "frames/s", "steps": n, "splat_ms": ms,
              "splat_frac_hbm": splat_bytes / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "verified": None}
         if verify_it and not a.no_cpu_baseline:
@@ -795,6 +836,8 @@ def also_records(a, dev, wl, first=None):
         dt = timed_sweep(kw, ex, a.warmup, n, 1, dev)
         ms_splat, ms_gather, ms_unet = stage_times(kw)
         r = {"value": n / dt, "unit": "frames/s", "ms_per_step": 1e3 * dt / n, "steps": n, "splat_ms": ms_splat,
+             "splat_ms_unannounced": STAGE_EXTRA.get("splat_ms_unannounced"), "splat_kernels_ms": STAGE_EXTRA.get("splat_kernels_ms"),
+             "splat_kernel_sum_ms": STAGE_EXTRA.get("splat_kernel_sum_ms"),
              "gather_ms": ms_gather, "unet_ms": ms_unet, "infer_path": kw.ogl.last_path,
              "splat_frac_hbm": (12.0 * kw.N + 8.0 * sum(w * h for (w, h) in camera.level_sizes(kw.W, kw.H, 5)))
                                / (ms_splat * 1e-3) / 1e9 / HBM_PEAK_GBS,
@@ -926,6 +969,13 @@ def main():
                 "splat_ms": ms_splat, "splat_GBps": splat_bytes / (ms_splat * 1e-3) / 1e9,
                 "splat_frac_hbm": splat_bytes / (ms_splat * 1e-3) / 1e9 / HBM_PEAK_GBS,
                 "splat_algorithmic_bytes": splat_bytes, "splat_ms_queued": STAGE_EXTRA.get("splat_ms_queued"),
+                "splat_ms_unannounced": STAGE_EXTRA.get("splat_ms_unannounced"),
+                "splat_kernels_ms": STAGE_EXTRA.get("splat_kernels_ms"), "splat_kernel_sum_ms": STAGE_EXTRA.get("splat_kernel_sum_ms"),
+                "splat_frac_hbm_kernels": (splat_bytes / (STAGE_EXTRA["splat_kernel_sum_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS
+                                           if STAGE_EXTRA.get("splat_kernel_sum_ms") else None),
+                "splat_note": "splat_ms / splat_frac_hbm: host-paced loop over consecutive sweep poses, next pose announced (what the timed "
+                              "loop does); _queued: 64 frames back to back; _unannounced: without the announcement (5 launches); "
+                              "_kernel_sum: HIP events around each launch of a frame, no gaps",
                 "gather_ms": ms_gather, "gather_GBps": gather_bytes / (ms_gather * 1e-3) / 1e9,
                 "gather_frac_hbm": gather_bytes / (ms_gather * 1e-3) / 1e9 / HBM_PEAK_GBS,
                 "unet_ms": ms_unet, "unet_launches": len(prof), "unet_executed_TFLOPs": all_exec / (ms_unet * 1e-3) / 1e12,

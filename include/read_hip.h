@@ -65,8 +65,11 @@ int read_device_arch(char *name, int len);
  *   "conv_wino"       largest Cin that takes the Winograd F(2x2,3x3) kernel (0 = direct implicit-GEMM kernels everywhere)
  *   "conv_sc"         8 (default): gated 3x3/s1 layers with Cin = 32, Cout <= 4 on the vector-pipe kernel, 8 input channels per LDS
  *                     phase (16, 32: larger phases); 0: on the MFMA kernels
- *   "conv_w4x2"       0 (default); 1: EXPERIMENTAL two-waves-per-SIMD cut of the F(4x4,3x3) kernel for inference launches — written at
- *                     the end of round 4 without GPU time to validate it; tests/test_gpu_conv.py runs it when READ_AMD_TEST_W4X2=1
+ *   "splat_prof"      1: HIP events around every launch of a cell-path frame (read_splat_profile_last); 0 (default)
+ *   "splat_ahead"     1 (default): with an announced next camera (read_splat_hint_next_camera) a cell-path frame's resolve launch
+ *                     also classifies / seeds the next frame — 4 dependent launches per frame instead of 5; 0: always 5
+ *   "unet_up_fold"    0 (default): nn.Upsample(x4, bilinear) as a pass of its own; 1: folded into the Convs.k launches
+ *                     (read_conv_desc.pre_bilinear; measured level-to-slower, profiles/r5_up_fold_ab.md); plans created afterwards
  *   "wgrad_wino"      1 (default): 3x3/s1 weight gradients in the Winograd F(4x4,3x3) domain; 0: direct MFMA kernel; v > 1: the same
  *                     with 128 v workgroups aimed at (default 256)
  *   "conv_wave", "conv_kc32", "conv_stagger", "unet_streams": see csrc/conv.hip, csrc/unet.cpp.
@@ -80,9 +83,9 @@ const char *read_tuning_key(int i);
 
 /* ---------------------------------------------------------------- rasteriser (z-buffer splat) */
 
-/* Bytes of the persistent rasteriser state for ONE (B, W, H): a 4096-byte header, the key images
- * (min(B,8) cameras x W*H x 8 B, depth_bits<<32 | point_id), the hierarchical-Z bound image, two seed images (the
- * warm start of the next frame) and the depth-bound image of the striped path.  A workspace serves the (B, W, H) it
+/* Bytes of the persistent rasteriser state for ONE (B, W, H): an 8192-byte header (frame state, two sets of chunk-list counters),
+ * the key images (min(B,8) cameras x W*H x 8 B, depth_bits<<32 | point_id), the hierarchical-Z bound image, two seed images (the
+ * warm start of the next frame), the two depth-bound images of the cell path (frames alternate between them) and its bins.  A workspace serves the (B, W, H) it
  * was sized for; re-run read_splat_workspace_init before using it with another size.  256-byte aligned. */
 size_t read_splat_workspace_bytes(int B, int W, int H);
 /* Must be called once on a fresh workspace (sets every key to EMPTY).  read_splat_forward
@@ -113,6 +116,18 @@ int read_splat_forward(const float *xyz, int64_t n, const float *M_host, int B, 
  * (csrc/splat.hip).  The tail of the blob is per-frame scratch (chunk lists), so one blob serves one stream at a
  * time.  With cells == NULL, B > 1, n < 2^20, W % 16 != 0 or sizes that are not multiples of 2^(levels-1) the call is
  * exactly read_splat_forward(). */
+/* read_splat_hint_next_camera(workspace, M_next_host): optional, before a read_splat_forward_cells call — "the NEXT call on this
+ * workspace will use camera M_next" (16 floats on the host; NULL withdraws the hint).  A sweep, a trajectory replay or a viewer
+ * that extrapolates its camera knows that matrix one frame ahead.  The hinted frame's last launch then also does the next frame's
+ * first one (chunk classification for M_next, seeds re-projected with M_next into the other bound image): a frame is 4 dependent
+ * launches instead of 5.  Purely a performance device with identical results: if the next call comes with another matrix, size or
+ * tuning state, the prepared state is wiped (two small memsets) and the frame runs as without a hint.  The hint is consumed by
+ * the next forward call on the workspace; the frame counter behind it lives on the host, keyed by the workspace address. */
+int read_splat_hint_next_camera(void *workspace, const float *M_next_host);
+/* Per-kernel durations (ms) of the LAST cell-path frame, HIP events on the launch stream around every launch; needs
+ * read_tuning_set("splat_prof", 1) before the frame.  ms5[0] seeds + classification (0 when the previous frame's resolve launch did
+ * that work), [1] pass A, [2] bin merge + bounds, [3] pass B, [4] resolve (+ the next frame's seeds / classification).  Synchronises. */
+int read_splat_profile_last(float *ms5);
 size_t read_splat_cells_bytes(int64_t n);
 int read_splat_cells_build_host(const float *xyz_host, int64_t n, void *cells_host, size_t cells_bytes);
 int read_splat_forward_cells(const float *xyz, void *cells, int64_t n, const float *M_host, int B, int W, int H,

@@ -30,7 +30,9 @@
 // left-to-right dot products (helper_math.h:1252-1255).
 #include <algorithm>
 #include <atomic>
+#include <mutex>
 #include <thread>
+#include <unordered_map>
 #include <vector>
 
 #include "common.h"
@@ -274,15 +276,20 @@ struct StripCounters {        // 256 bytes per strip, at HEADER_STRIPS_OFFSET + 
     int nA[A_BANDS], nB;      // list lengths, written by the classification blocks of the seed launch (agent-scope atomics)
     int pad0[64 - A_BANDS - 1];
 };
-constexpr size_t HEADER_BYTES = 4096;
+constexpr size_t HEADER_BYTES = 8192;
 constexpr size_t HEADER_STATS_OFFSET = 64;      // 16 x u64 debug counters (read_tuning_set("splat_stats", 1))
-constexpr size_t HEADER_STRIPS_OFFSET = 256;    // MAX_STRIPS x StripCounters
+constexpr size_t HEADER_STRIPS_OFFSET = 256;    // 2 sets x MAX_STRIPS x StripCounters
+// Two SETS of list counters (and two bound images, WsLayout::zimg): frame k of a workspace works in set k & 1.  A frame's
+// resolve leaves ITS set clean (counters zero, bounds "none"), so the OTHER set is clean while a frame runs — which is what lets
+// the resolve launch of frame k already classify the chunks and seed the bounds of frame k + 1 (cells_resolve_next_kernel) when
+// the caller has announced the next camera (read_splat_hint_next_camera).
+constexpr size_t COUNTER_SET_BYTES = MAX_STRIPS * 256;
 static_assert(sizeof(StripCounters) == 256, "StripCounters must be two 128-byte lines");
-static_assert(HEADER_STRIPS_OFFSET + MAX_STRIPS * sizeof(StripCounters) <= HEADER_BYTES, "header too small");
+static_assert(HEADER_STRIPS_OFFSET + 2 * COUNTER_SET_BYTES <= HEADER_BYTES, "header too small");
 
-__device__ __forceinline__ StripCounters *strip_counters(void *hdr, int s)
+__device__ __forceinline__ StripCounters *strip_counters(void *hdr, int set, int s)
 {
-    return reinterpret_cast<StripCounters *>((char *)hdr + HEADER_STRIPS_OFFSET) + s;
+    return reinterpret_cast<StripCounters *>((char *)hdr + HEADER_STRIPS_OFFSET + (size_t)set * COUNTER_SET_BYTES) + s;
 }
 
 // bound[block] = max over the block's pixels of the current depth, +inf if any pixel is still empty.
@@ -495,7 +502,7 @@ __device__ __forceinline__ int classify_chunk(const float *bb, const float *M, i
 // The classification blocks of cells_seed_classify_kernel: one thread per chunk, block-aggregated appends (one atomic
 // per block, list and strip: a per-wave append measured ~8 us of same-address atomics on the critical path).
 __device__ __forceinline__ void classify_block(const CellCloud &cc, const float *M, int W, int H, int sub, float near_count,
-                                               int block, void *hdr, const StripInfo &si)
+                                               int block, void *hdr, int cset, const StripInfo &si)
 {
     constexpr int PER_STRIP = A_BANDS + 1, LISTS = MAX_STRIPS * PER_STRIP;      // per strip: the bands of list A, then list B
     __shared__ int s_cnt[LISTS];
@@ -540,7 +547,7 @@ __device__ __forceinline__ void classify_block(const CellCloud &cc, const float 
     if (threadIdx.x < LISTS) {
         const int s = threadIdx.x / PER_STRIP, k = threadIdx.x % PER_STRIP;
         const int tot = s_cnt[threadIdx.x];
-        StripCounters *sc = strip_counters(hdr, s);
+        StripCounters *sc = strip_counters(hdr, cset, s);
         s_base[threadIdx.x] = tot ? atomicAdd(k < A_BANDS ? &sc->nA[k] : &sc->nB, tot) : 0;     // one atomic per block and list
     }
     __syncthreads();
@@ -551,30 +558,38 @@ __device__ __forceinline__ void classify_block(const CellCloud &cc, const float 
         cc.list_b[(size_t)strip * cc.nchunks + s_base[l] + mine] = e;
 }
 
-__global__ __launch_bounds__(256) void cells_seed_classify_kernel(CellCloud cc, Cam1 cam, int W, int H,
-                                                                  unsigned long long *keys, unsigned *zimg, void *hdr_v,
-                                                                  int *pos0, int *pos1, StripInfo si, int seed_blocks,
-                                                                  int sub, float near_count, int use_seeds)
+// One seed block: 256 pixels of the seed image `pos` (positions, in the cell-ordered cloud, of the front points a previous frame's
+// passes found) are re-projected with THIS camera and their depths stored as bounds.
+__device__ __forceinline__ void seed_block(const CellCloud &cc, const float *M, int W, int H, unsigned *zimg, const int *pos_img,
+                                           int block)
 {
-    if ((int)blockIdx.x >= seed_blocks) {
-        classify_block(cc, cam.m, W, H, sub, near_count, (int)blockIdx.x - seed_blocks, hdr_v, si);
-        return;
-    }
-    const SplatHeader *hdr = (const SplatHeader *)hdr_v;
-    if (!use_seeds || !(hdr->valid == 2 && hdr->W == W && hdr->H == H)) return;
-    const int p = blockIdx.x * blockDim.x + threadIdx.x;
+    const int p = block * 256 + (int)threadIdx.x;
     if (p >= W * H) return;
-    const int pos = (hdr->parity ? pos1 : pos0)[p];
+    const int pos = pos_img[p];
     if ((unsigned)pos >= (unsigned)cc.nchunks * CELL_CHUNK) return;
     const float4 q = cc.pts[pos];
     float d;
     int xx, yy;
-    const int pix = project_one(q.x, q.y, q.z, cam.m, W, H, d, xx, yy);
+    const int pix = project_one(q.x, q.y, q.z, M, W, H, d, xx, yy);
     // the depth of a real point at this pixel bounds the final depth from above; the point itself is folded in when its
     // chunk comes by (ties pass every test).  Colliding seeds race; either value is a valid bound.  (Also storing the
     // seed's KEY with a plain store, so that the seed point can skip its atomic after reading its own key back, was
     // measured slower: the dependent key reads cost more than the ~200 K atomics they saved.)
     if (pix >= 0) zimg[pix] = __float_as_uint(d);
+}
+
+__global__ __launch_bounds__(256) void cells_seed_classify_kernel(CellCloud cc, Cam1 cam, int W, int H,
+                                                                  unsigned *zimg, void *hdr_v, const int *pos_img, int cset,
+                                                                  StripInfo si, int seed_blocks,
+                                                                  int sub, float near_count, int use_seeds)
+{
+    if ((int)blockIdx.x >= seed_blocks) {
+        classify_block(cc, cam.m, W, H, sub, near_count, (int)blockIdx.x - seed_blocks, hdr_v, cset, si);
+        return;
+    }
+    const SplatHeader *hdr = (const SplatHeader *)hdr_v;
+    if (!use_seeds || !(hdr->valid == 2 && hdr->W == W && hdr->H == H)) return;
+    seed_block(cc, cam.m, W, H, zimg, pos_img, (int)blockIdx.x);
 }
 
 // `rounds` x 256 consecutive points of one chunk for one wave and one strip: zimg early-z, then atomic min on the key +
@@ -812,7 +827,7 @@ template <bool PASS_B, bool STATS, bool ZL2, bool LDS, bool BIN>
 __global__ __launch_bounds__(256) void cells_pass_kernel(CellCloud cc, Cam1 cam, int W, int H,
                                                          unsigned long long *keys, unsigned *zimg,
                                                          const unsigned short *__restrict__ hiz_g, int nbx, void *hdr_v,
-                                                         int *pos0, int *pos1, StripInfo si, int sub_items,
+                                                         int *next, int cset, StripInfo si, int sub_items,
                                                          unsigned long long *stats, KeySlots ks, BinInfo bi)
 {
     __shared__ unsigned s_tag[LDS ? 4 * LDS_SLOTS : 1];
@@ -822,9 +837,7 @@ __global__ __launch_bounds__(256) void cells_pass_kernel(CellCloud cc, Cam1 cam,
     __shared__ int s_surv[PASS_B ? 2 * 24 : 1];                      // pass B: the workgroup's surviving list entries of one round
     __shared__ int s_nsurv[2];
     unsigned *wl_tile = s_wl + (BIN ? (threadIdx.x >> 6) * 128 : 0), *wl_cnt = wl_tile + (BIN ? 64 : 0);
-    const SplatHeader *hdr = (const SplatHeader *)hdr_v;
-    int *next = hdr->parity ? pos0 : pos1;
-    const float *M = cam.m;
+    const float *M = cam.m;                                         // (`next`: the seed image this frame's front points go to)
     const int lane = threadIdx.x & 63;
     unsigned *tag = s_tag + (LDS ? (threadIdx.x >> 6) * LDS_SLOTS : 0);
     unsigned long long *hkey = s_key + (LDS ? (threadIdx.x >> 6) * LDS_SLOTS : 0);
@@ -846,7 +859,7 @@ __global__ __launch_bounds__(256) void cells_pass_kernel(CellCloud cc, Cam1 cam,
     if (wg_in_strip >= n_wg) return;
     const int n_waves = n_wg * (int)(blockDim.x >> 6);
     const int wave = __builtin_amdgcn_readfirstlane(wg_in_strip * (int)(blockDim.x >> 6) + (int)(threadIdx.x >> 6));
-    const StripCounters *sc = strip_counters(hdr_v, s);
+    const StripCounters *sc = strip_counters(hdr_v, cset, s);
     const int xlo = 0, xhi = W;                                     // a chunk is processed whole by the strip that lists it
     float4 q[4];
     if (!PASS_B) {
@@ -1196,14 +1209,14 @@ __device__ __forceinline__ unsigned long long kmin(unsigned long long a, unsigne
 // Levels 2..4 are reduced through LDS (16x16 -> 8x8 -> 4x4 -> 2x2 keys).
 // keep: 0 nothing, 1 record the winners' ids (plain-path warm start), 2 striped frame (reset zimg and the strip
 // counters, flip the seed-image parity).
-__global__ __launch_bounds__(256) void splat_resolve_kernel(unsigned long long *__restrict__ keys, int W, int H,
-                                                            int levels, ResolveOut out, int tiles_x,
-                                                            int tiles_y, int *__restrict__ prev_idx,
-                                                            void *hdr_v, int keep, unsigned *__restrict__ zimg, KeySlots ks)
+__device__ __forceinline__ void resolve_tile(unsigned long long *__restrict__ keys, int W, int H,
+                                             int levels, const ResolveOut &out, int tiles_x,
+                                             int *__restrict__ prev_idx,
+                                             void *hdr_v, int keep, unsigned *__restrict__ zimg, int cset, const KeySlots &ks,
+                                             const int blk, const int cam)
 {
     __shared__ unsigned long long s1[256], s2[64], s3[16];
-    const int cam = blockIdx.y;
-    const int tx = blockIdx.x % tiles_x, ty = blockIdx.x / tiles_x;
+    const int tx = blk % tiles_x, ty = blk / tiles_x;
     const int t = threadIdx.x;
     const int qx = t & 15, qy = t >> 4;
     const int x0 = tx * 32 + qx * 2, y0 = ty * 32 + qy * 2;
@@ -1228,17 +1241,17 @@ __global__ __launch_bounds__(256) void splat_resolve_kernel(unsigned long long *
             }
             k[dy][dx] = v;
         }
-    if (keep && blockIdx.x == 0 && blockIdx.y == 0) {
+    if (keep && blk == 0 && cam == 0) {
         SplatHeader *hdr = (SplatHeader *)hdr_v;
         if (keep == 2 && t < MAX_STRIPS) {
-            StripCounters *sc = strip_counters(hdr_v, t);
+            StripCounters *sc = strip_counters(hdr_v, cset, t);       // this frame's set: clean again for the frame after next
             for (int b = 0; b < A_BANDS; ++b) sc->nA[b] = 0;
             sc->nB = 0;
         }
         if (t == 0) {
             // any integer below the padded point count is the position of a real point, i.e. a valid seed, so the two
-            // seed images need no initialisation discipline beyond "flip after every striped frame"
-            if (keep == 2) hdr->parity ^= 1;
+            // seed images need no initialisation discipline: which of them a frame reads and which it writes follows the
+            // host's frame counter (cells_frame), and reading the "wrong" one would only give staler seeds
             hdr->valid = keep;
             hdr->W = W;
             hdr->H = H;
@@ -1282,6 +1295,45 @@ __global__ __launch_bounds__(256) void splat_resolve_kernel(unsigned long long *
     }
 }
 
+
+__global__ __launch_bounds__(256) void splat_resolve_kernel(unsigned long long *__restrict__ keys, int W, int H,
+                                                            int levels, ResolveOut out, int tiles_x,
+                                                            int tiles_y, int *__restrict__ prev_idx,
+                                                            void *hdr_v, int keep, unsigned *__restrict__ zimg, int cset, KeySlots ks)
+{
+    resolve_tile(keys, W, H, levels, out, tiles_x, prev_idx, hdr_v, keep, zimg, cset, ks, (int)blockIdx.x, (int)blockIdx.y);
+}
+
+// The resolve launch of a cell-path frame whose caller has announced the NEXT camera (read_splat_hint_next_camera): next to the
+// tiles of this frame (blocks [0, res_blocks)) the launch carries the classification blocks and the seed blocks of the next
+// frame — cells_seed_classify_kernel's work, which depends on nothing this frame still has to produce: the chunk boxes are
+// static, the seed image was completed by this frame's passes, and the next frame's counter set and bound image are the clean
+// OTHER set (strip_counters).  One dependent launch (2.9 us of chain, tools/chain_probe.py) and ~5 us of a near-empty kernel
+// less per frame; the 115 classification workgroups run beside the 418 tile workgroups instead of alone on the chip.
+struct NextFrame {
+    Cam1 cam;
+    unsigned *zimg;          // the next frame's bound image (clean)
+    const int *pos_img;      // the seed image this frame's passes wrote
+    int cset, sub, use_seeds, class_blocks;
+    float near_count;
+};
+__global__ __launch_bounds__(256) void cells_resolve_next_kernel(unsigned long long *__restrict__ keys, int W, int H,
+                                                                 int levels, ResolveOut out, int tiles_x, int res_blocks,
+                                                                 void *hdr_v, unsigned *__restrict__ zimg, int cset, KeySlots ks,
+                                                                 CellCloud cc, NextFrame nx, StripInfo si)
+{
+    const int b = (int)blockIdx.x;
+    if (b < res_blocks) {
+        resolve_tile(keys, W, H, levels, out, tiles_x, nullptr, hdr_v, 2, zimg, cset, ks, b, 0);
+        return;
+    }
+    if (b < res_blocks + nx.class_blocks) {
+        classify_block(cc, nx.cam.m, W, H, nx.sub, nx.near_count, b - res_blocks, hdr_v, nx.cset, si);
+        return;
+    }
+    if (nx.use_seeds) seed_block(cc, nx.cam.m, W, H, nx.zimg, nx.pos_img, b - res_blocks - nx.class_blocks);
+}
+
 __global__ __launch_bounds__(256) void fill_keys_kernel(unsigned long long *keys, long long count)
 {
     const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -1318,6 +1370,8 @@ int g_splat_kslot = 0;          // key-image layout of the striped path: 0 linea
 int g_splat_lds = 1;            // 1: per-wave LDS hash table in front of the memory-side atomics (strip_points)
 int g_splat_wgs = 4;            // workgroups per CU of the striped passes: 0.0996 / 0.0936 / 0.0893 / 0.0927 / 0.0923 ms at 2 / 3 / 4 / 6 / 8
                                 // (fewer waves = more rounds per wave = finer front-to-back order over the depth bands)
+int g_splat_ahead = 1;          // 1: with an announced next camera (read_splat_hint_next_camera) a frame's resolve launch also classifies and
+                                // seeds the next frame (cells_resolve_next_kernel): 4 dependent launches per frame instead of 5; 0: A/B
 int g_splat_bins = 1;           // 1: pass A appends its candidates to per-tile bins, merged in LDS (emit_binned); 0: one memory-side atomic each
 int g_splat_strips = 1;         // column strips of the striped passes (1, 2, 4 or 8).  8 was best while a strip's list was walked in
                                // Morton order (pass A 61.5 / 75.5 / 70 us at 8 / 2 / 1: fewer atomics with exact bounds); with the
@@ -1326,13 +1380,13 @@ int g_splat_strips = 1;         // column strips of the striped passes (1, 2, 4 
 
 // Workspace layout (fixed by the (B, W, H) it was sized for; one workspace serves one such triple):
 //   [header 4096 B][key images: min(B,8) x W*H x 8 B][hi-z bounds: ceil(W/4)*ceil(H/4) x 4 B][seed image 0: W*H x 4 B]
-//   [seed image 1: W*H x 4 B][zimg: W*H x 4 B depth upper bounds of the striped path, 0xffffffff = none]
+//   [seed image 1: W*H x 4 B][zimg 0, zimg 1: W*H x 4 B each, depth upper bounds of the cell path, 0xffffffff = none]
 struct WsLayout {
     void *hdr;
     unsigned long long *keys;
     unsigned short *hiz;       // 16-bit far bounds (the region keeps its 4 bytes per block)
     int *prev[2];              // plain path: prev[0] = winners' ids; striped path: positions, double buffered
-    unsigned *zimg;
+    unsigned *zimg[2];         // cell path: depth upper bounds, one image per frame parity (set k & 1, see strip_counters)
     unsigned *bin_count;       // striped path, binned pass A: per 32x32 tile, minus one
     uint4 *bin_recs;           // tiles x bin_cap records
     int bin_cap, bin_tiles_x, bin_tiles;
@@ -1360,8 +1414,10 @@ WsLayout ws_layout(void *ws, int B, int W, int H)
         L.prev[i] = (int *)(p + off);
         off += ((size_t)W * H * sizeof(int) + 255) / 256 * 256;
     }
-    L.zimg = (unsigned *)(p + off);
-    off += ((size_t)W * H * sizeof(unsigned) + 255) / 256 * 256;
+    for (int i = 0; i < 2; ++i) {
+        L.zimg[i] = (unsigned *)(p + off);
+        off += ((size_t)W * H * sizeof(unsigned) + 255) / 256 * 256;
+    }
     // bins of the striped path: BIN_SUB sub-bins per tile, <= 64 MiB of records, 32..256 per sub-bin (a full one falls back
     // to the atomics)
     L.bin_tiles_x = ceil_div(W, BIN_TILE);
@@ -1390,9 +1446,7 @@ int device_cus()
     return n_cu;
 }
 
-int resolve_launch(unsigned long long *keys, int nb, int b0, int W, int H, int levels, int32_t *const *idx_levels,
-                   float *const *depth_levels, int level_base, const WsLayout &ws, int keep, hipStream_t stream,
-                   KeySlots ks = KeySlots{0, 0})
+ResolveOut resolve_out(int b0, int W, int H, int levels, int32_t *const *idx_levels, float *const *depth_levels, int level_base)
 {
     ResolveOut out;
     memset(&out, 0, sizeof(out));
@@ -1401,10 +1455,48 @@ int resolve_launch(unsigned long long *keys, int nb, int b0, int W, int H, int l
         if (idx_levels && idx_levels[level_base + l]) out.idx[l] = idx_levels[level_base + l] + lpx * b0;
         if (depth_levels && depth_levels[level_base + l]) out.depth[l] = depth_levels[level_base + l] + lpx * b0;
     }
+    return out;
+}
+
+// cset: the frame's counter set / bound image (cell path, keep == 2)
+int resolve_launch(unsigned long long *keys, int nb, int b0, int W, int H, int levels, int32_t *const *idx_levels,
+                   float *const *depth_levels, int level_base, const WsLayout &ws, int keep, hipStream_t stream,
+                   KeySlots ks = KeySlots{0, 0}, int cset = 0)
+{
+    const ResolveOut out = resolve_out(b0, W, H, levels, idx_levels, depth_levels, level_base);
     const int tiles_x = ceil_div(W, 32), tiles_y = ceil_div(H, 32);
     hipLaunchKernelGGL(splat_resolve_kernel, dim3(tiles_x * tiles_y, nb), dim3(256), 0, stream, keys, W, H,
-                       levels, out, tiles_x, tiles_y, ws.prev[0], ws.hdr, keep, ws.zimg, ks);
+                       levels, out, tiles_x, tiles_y, ws.prev[0], ws.hdr, keep, ws.zimg[cset], cset, ks);
     READ_CHECK_LAUNCH();
+    return READ_OK;
+}
+
+// ---- host-side frame state of a workspace -----------------------------------------------------------------------------
+// Which counter set / bound image / seed image a cell-path frame uses follows a frame counter kept HERE, per workspace address
+// (the workspace itself stays plain caller-owned device memory).  Nothing on the device depends on the parity being "right":
+// both sets are clean between frames (a frame's resolve cleans its own), and either seed image holds positions of real points.
+// The one state that must not be lost is a PREDICTION: cells_resolve_next_kernel has filled the other set for an announced
+// camera — the next call on that workspace either consumes it (same camera, size and knobs) or wipes that set first.
+struct WsHost {
+    unsigned long long frame = 0;
+    bool hinted = false;                 // read_splat_hint_next_camera since the last frame
+    float hint[16];
+    bool pred = false;                   // the set (frame & 1) holds the classification + seeds of camera `pm`
+    float pm[16];
+    int pW = 0, pH = 0, p_sub = 0, p_near = 0, p_ns = 0, p_seeds = 0;
+    void *p_counters = nullptr, *p_zimg = nullptr;
+    size_t p_zimg_bytes = 0;
+};
+std::mutex g_ws_mutex;
+std::unordered_map<void *, WsHost> g_ws_host;
+
+// a pending prediction nobody will consume: wipe the set it dirtied (stream order puts this after the launch that filled it)
+int ws_drop_prediction(WsHost &h, hipStream_t stream)
+{
+    if (!h.pred) return READ_OK;
+    h.pred = false;
+    READ_CHECK_HIP(hipMemsetAsync(h.p_counters, 0, COUNTER_SET_BYTES, stream));
+    READ_CHECK_HIP(hipMemsetAsync(h.p_zimg, 0xff, h.p_zimg_bytes, stream));
     return READ_OK;
 }
 
@@ -1484,6 +1576,23 @@ StripInfo make_strips(int W)
     return si;
 }
 
+// ---- per-kernel durations of the LAST cell-path frame (read_tuning_set("splat_prof", 1) + read_splat_profile_last): HIP events
+// on the launch stream around every launch of the frame.  Slots: 0 seeds + classification (0 when the previous frame's resolve
+// launch did that work), 1 pass A, 2 bin merge + bounds, 3 pass B, 4 resolve (+ the next frame's seeds / classification).
+int g_splat_prof = 0;
+hipEvent_t g_prof_ev[6];
+bool g_prof_made = false, g_prof_valid = false, g_prof_slot0 = false;
+int prof_mark(int i, hipStream_t stream)
+{
+    if (!g_splat_prof) return READ_OK;
+    if (!g_prof_made) {
+        for (auto &e : g_prof_ev) READ_CHECK_HIP(hipEventCreate(&e));
+        g_prof_made = true;
+    }
+    READ_CHECK_HIP(hipEventRecord(g_prof_ev[i], stream));
+    return READ_OK;
+}
+
 int cells_frame(const CellCloud &cc, const float *M_host, int W, int H, int levels, int32_t *const *idx_levels,
                 float *const *depth_levels, const WsLayout &ws, hipStream_t stream)
 {
@@ -1491,11 +1600,26 @@ int cells_frame(const CellCloud &cc, const float *M_host, int W, int H, int leve
     Cam1 cam;
     memcpy(cam.m, M_host, sizeof(cam.m));
     unsigned long long *stats = g_splat_stats ? (unsigned long long *)((char *)ws.hdr + HEADER_STATS_OFFSET) : nullptr;
-    const int seed_blocks = ceil_div(W * H, 256);
-    hipLaunchKernelGGL(cells_seed_classify_kernel, dim3((unsigned)(seed_blocks + ceil_div(cc.nchunks, 256))), dim3(256), 0,
-                       stream, cc, cam, W, H, ws.keys, ws.zimg, ws.hdr, ws.prev[0], ws.prev[1], si,
-                       seed_blocks, g_splat_cells_sub, (float)g_splat_near, g_splat_seeds);
-    READ_CHECK_LAUNCH();
+    const int seed_blocks = ceil_div(W * H, 256), class_blocks = ceil_div(cc.nchunks, 256);
+    // ---- this frame's set; was it prepared by the previous frame's resolve launch?
+    std::lock_guard<std::mutex> lock(g_ws_mutex);
+    WsHost &h = g_ws_host[ws.hdr];
+    const int fp = (int)(h.frame & 1);
+    const bool prepared = h.pred && h.pW == W && h.pH == H && memcmp(h.pm, M_host, sizeof(h.pm)) == 0 && h.p_sub == g_splat_cells_sub &&
+                          h.p_near == g_splat_near && h.p_ns == si.ns && h.p_seeds == g_splat_seeds && h.p_zimg == (void *)ws.zimg[fp];
+    g_prof_valid = false;
+    g_prof_slot0 = !prepared;
+    if (prepared) h.pred = false;                     // consumed
+    else {
+        const int rc = ws_drop_prediction(h, stream);
+        if (rc != READ_OK) return rc;
+        if (prof_mark(0, stream) != READ_OK) return READ_EHIP;
+        hipLaunchKernelGGL(cells_seed_classify_kernel, dim3((unsigned)(seed_blocks + class_blocks)), dim3(256), 0,
+                           stream, cc, cam, W, H, ws.zimg[fp], ws.hdr, (const int *)ws.prev[fp], fp, si,
+                           seed_blocks, g_splat_cells_sub, (float)g_splat_near, g_splat_seeds);
+        READ_CHECK_LAUNCH();
+    }
+    int *const next_pos = ws.prev[fp ^ 1];            // the seed image this frame's passes write: the next frame's (set fp ^ 1) seeds
     const unsigned grid = (unsigned)(device_cus() * g_splat_wgs);
     const int items = g_splat_items;
     KeySlots ks;
@@ -1524,21 +1648,60 @@ int cells_frame(const CellCloud &cc, const float *M_host, int W, int H, int leve
     auto pass_b = stats ? (g_splat_lds ? cells_pass_kernel<true, true, false, true, false> : cells_pass_kernel<true, true, false, false, false>)
                   : g_splat_zl2 ? cells_pass_kernel<true, false, true, false, false>
                   : g_splat_lds ? cells_pass_kernel<true, false, false, true, false> : cells_pass_kernel<true, false, false, false, false>;
-    hipLaunchKernelGGL(pass_a, dim3(grid), dim3(256), 0, stream, cc, cam, W, H, ws.keys, ws.zimg,
-                       (const unsigned short *)ws.hiz, ws.nbx, ws.hdr, ws.prev[0], ws.prev[1], si, items, stats, ks, bi);
+    if (prof_mark(1, stream) != READ_OK) return READ_EHIP;
+    hipLaunchKernelGGL(pass_a, dim3(grid), dim3(256), 0, stream, cc, cam, W, H, ws.keys, ws.zimg[fp],
+                       (const unsigned short *)ws.hiz, ws.nbx, ws.hdr, next_pos, fp, si, items, stats, ks, bi);
     READ_CHECK_LAUNCH();
+    if (prof_mark(2, stream) != READ_OK) return READ_EHIP;
     if (bins)
-        hipLaunchKernelGGL(cells_merge_hiz_kernel, dim3((unsigned)ws.bin_tiles), dim3(256), 0, stream, ws.keys, ws.zimg, W, H,
+        hipLaunchKernelGGL(cells_merge_hiz_kernel, dim3((unsigned)ws.bin_tiles), dim3(256), 0, stream, ws.keys, ws.zimg[fp], W, H,
                            ws.nbx, ws.hiz, bi);
     else
         hipLaunchKernelGGL(cells_hiz_kernel, dim3(ceil_div(ws.nbx * ws.nby, 256)), dim3(256), 0, stream,
-                           (const unsigned long long *)ws.keys, ws.zimg, W, H, ws.nbx, ws.nby, ws.hiz, ks);
+                           (const unsigned long long *)ws.keys, ws.zimg[fp], W, H, ws.nbx, ws.nby, ws.hiz, ks);
     READ_CHECK_LAUNCH();
     bi.recs = nullptr;
-    hipLaunchKernelGGL(pass_b, dim3(grid), dim3(256), 0, stream, cc, cam, W, H, ws.keys, ws.zimg,
-                       (const unsigned short *)ws.hiz, ws.nbx, ws.hdr, ws.prev[0], ws.prev[1], si, items, stats, ks, bi);
+    if (prof_mark(3, stream) != READ_OK) return READ_EHIP;
+    hipLaunchKernelGGL(pass_b, dim3(grid), dim3(256), 0, stream, cc, cam, W, H, ws.keys, ws.zimg[fp],
+                       (const unsigned short *)ws.hiz, ws.nbx, ws.hdr, next_pos, fp, si, items, stats, ks, bi);
     READ_CHECK_LAUNCH();
-    return resolve_launch(ws.keys, 1, 0, W, H, levels, idx_levels, depth_levels, 0, ws, 2, stream, ks);
+    // ---- resolve; with an announced next camera the same launch prepares the next frame's set
+    const bool ahead = h.hinted && g_splat_ahead;
+    h.hinted = false;
+    h.frame += 1;
+    if (prof_mark(4, stream) != READ_OK) return READ_EHIP;
+    if (!ahead) {
+        const int rc = resolve_launch(ws.keys, 1, 0, W, H, levels, idx_levels, depth_levels, 0, ws, 2, stream, ks, fp);
+        if (rc == READ_OK && prof_mark(5, stream) == READ_OK) g_prof_valid = g_splat_prof != 0;
+        return rc;
+    }
+    NextFrame nx;
+    memcpy(nx.cam.m, h.hint, sizeof(nx.cam.m));
+    nx.zimg = ws.zimg[fp ^ 1];
+    nx.pos_img = next_pos;
+    nx.cset = fp ^ 1;
+    nx.sub = g_splat_cells_sub;
+    nx.use_seeds = g_splat_seeds;
+    nx.class_blocks = class_blocks;
+    nx.near_count = (float)g_splat_near;
+    const ResolveOut out = resolve_out(0, W, H, levels, idx_levels, depth_levels, 0);
+    const int tiles_x = ceil_div(W, 32), res_blocks = tiles_x * ceil_div(H, 32);
+    hipLaunchKernelGGL(cells_resolve_next_kernel, dim3((unsigned)(res_blocks + class_blocks + (g_splat_seeds ? seed_blocks : 0))), dim3(256),
+                       0, stream, ws.keys, W, H, levels, out, tiles_x, res_blocks, ws.hdr, ws.zimg[fp], fp, ks, cc, nx, si);
+    READ_CHECK_LAUNCH();
+    h.pred = true;
+    memcpy(h.pm, h.hint, sizeof(h.pm));
+    h.pW = W;
+    h.pH = H;
+    h.p_sub = g_splat_cells_sub;
+    h.p_near = g_splat_near;
+    h.p_ns = si.ns;
+    h.p_seeds = g_splat_seeds;
+    h.p_counters = (char *)ws.hdr + HEADER_STRIPS_OFFSET + (size_t)(fp ^ 1) * COUNTER_SET_BYTES;
+    h.p_zimg = ws.zimg[fp ^ 1];
+    h.p_zimg_bytes = (size_t)W * H * sizeof(unsigned);
+    if (prof_mark(5, stream) == READ_OK) g_prof_valid = g_splat_prof != 0;
+    return READ_OK;
 }
 
 }  // namespace
@@ -1566,6 +1729,8 @@ void splat_set_items(int v) { g_splat_items = v >= 4 ? 4 : (v >= 2 ? 2 : 1); }
 void splat_set_zl2(int v) { g_splat_zl2 = v != 0; }
 void splat_set_lds(int v) { g_splat_lds = v != 0; }
 void splat_set_bins(int v) { g_splat_bins = v != 0; }
+void splat_set_ahead(int v) { g_splat_ahead = v != 0; }
+void splat_set_prof(int v) { g_splat_prof = v != 0; }
 void splat_set_kslot(int v) { g_splat_kslot = v < 0 ? 0 : (v > 2 ? 2 : v); }
 void splat_set_wgs(int v) { g_splat_wgs = v < 1 ? 1 : (v > 16 ? 16 : v); }
 void splat_set_strips(int v) { g_splat_strips = v >= 8 ? 8 : (v >= 4 ? 4 : (v >= 2 ? 2 : 1)); }
@@ -1584,6 +1749,8 @@ int splat_get(const char *key, int *value)
     else if (!strcmp(key, "splat_zl2")) *value = g_splat_zl2;
     else if (!strcmp(key, "splat_lds")) *value = g_splat_lds;
     else if (!strcmp(key, "splat_bins")) *value = g_splat_bins;
+    else if (!strcmp(key, "splat_ahead")) *value = g_splat_ahead;
+    else if (!strcmp(key, "splat_prof")) *value = g_splat_prof;
     else if (!strcmp(key, "splat_kslot")) *value = g_splat_kslot;
     else return 0;
     return 1;
@@ -1602,6 +1769,10 @@ extern "C" int read_splat_workspace_init(void *ws, size_t ws_bytes, void *stream
     READ_CHECK_ARG((uintptr_t)ws % 256 == 0, "read_splat_workspace_init: workspace must be 256-byte aligned");
     const long long count = (long long)(ws_bytes / 8);
     if (count == 0) return READ_OK;
+    {
+        std::lock_guard<std::mutex> lock(g_ws_mutex);
+        g_ws_host.erase(ws);                                       // frame counter, hint and prediction of whatever lived here before
+    }
     hipLaunchKernelGGL(fill_keys_kernel, dim3((unsigned)ceil_div64(count, 256)), dim3(256), 0, as_stream(stream),
                        (unsigned long long *)ws, count);
     READ_CHECK_LAUNCH();
@@ -1633,6 +1804,15 @@ extern "C" int read_splat_forward(const float *xyz, int64_t n, const float *M_ho
     }
     const WsLayout L = ws_layout(ws, B, W, H);
     hipStream_t s = as_stream(stream);
+    {
+        std::lock_guard<std::mutex> lock(g_ws_mutex);             // a cell-path prediction pending on this workspace is not for this call
+        auto it = g_ws_host.find(ws);
+        if (it != g_ws_host.end()) {
+            it->second.hinted = false;
+            const int rc = ws_drop_prediction(it->second, s);
+            if (rc != READ_OK) return rc;
+        }
+    }
     const int mask = (1 << (levels - 1)) - 1;
     if (((W | H) & mask) == 0) {
         // pyramid identity holds (App. A.4): one pass over the points feeds every level
@@ -1823,6 +2003,29 @@ extern "C" int read_splat_cells_build_host(const float *xyz, int64_t n, void *bl
         vol *= e > 1e-6 * ext ? e : (ext > 0 ? 1e-6 * ext : 1.0);   // a flat cloud still gets a finite density
     }
     h->density = (float)((double)n / (vol > 0 ? vol : 1.0));
+    return READ_OK;
+}
+
+extern "C" int read_splat_profile_last(float *ms5)
+{
+    READ_CHECK_ARG(ms5, "read_splat_profile_last: null pointer");
+    READ_CHECK_ARG(g_prof_valid, "read_splat_profile_last: no profiled cell-path frame (read_tuning_set(\"splat_prof\", 1), then a frame)");
+    READ_CHECK_HIP(hipEventSynchronize(g_prof_ev[5]));
+    for (int i = 0; i < 5; ++i) {
+        ms5[i] = 0.0f;
+        if (i == 0 && !g_prof_slot0) continue;
+        READ_CHECK_HIP(hipEventElapsedTime(&ms5[i], g_prof_ev[i], g_prof_ev[i + 1]));
+    }
+    return READ_OK;
+}
+
+extern "C" int read_splat_hint_next_camera(void *ws, const float *M_next_host)
+{
+    READ_CHECK_ARG(ws, "read_splat_hint_next_camera: null workspace");
+    std::lock_guard<std::mutex> lock(g_ws_mutex);
+    WsHost &h = g_ws_host[ws];
+    h.hinted = M_next_host != nullptr;
+    if (M_next_host) memcpy(h.hint, M_next_host, sizeof(h.hint));
     return READ_OK;
 }
 

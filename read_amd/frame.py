@@ -81,8 +81,8 @@ class FrameRenderer:
                 slot["done"].record(torch.cuda.current_stream(self.device))
                 self._slots.append(slot)
 
-    def rasterize(self, total_m):
-        return self.raster.render(total_m, self.W, self.H, self.levels, out=(self.idx, self.depth))
+    def rasterize(self, total_m, next_total=None):
+        return self.raster.render(total_m, self.W, self.H, self.levels, out=(self.idx, self.depth), next_total=next_total)
 
     def gather(self):
         return gather_pyramid(self.rows, self.idx, out=self.feat)
@@ -92,10 +92,11 @@ class FrameRenderer:
         return self.unet.forward(f[0][0], f[1][0], f[2][0], f[3][0], out=self.rgba if out is None else out,
                                  channels=channels)
 
-    def render_total(self, total_m, out=None, channels=4):
-        """total_m = proj @ inv(view) (4x4 fp32) -> (H,W,channels) fp32 frame on the device."""
+    def render_total(self, total_m, out=None, channels=4, next_total=None):
+        """total_m = proj @ inv(view) (4x4 fp32) -> (H,W,channels) fp32 frame on the device.
+        next_total: the NEXT call's matrix when the caller knows it (PointCloudRasterizer.render): one launch less per frame."""
         if not self._slots:
-            self.rasterize(total_m)
+            self.rasterize(total_m, next_total)
             self.gather()
             return self.refine(out, channels)
         slot = self._slots[self._calls % len(self._slots)]
@@ -108,7 +109,7 @@ class FrameRenderer:
         rs = self._raster_stream
         with torch.cuda.stream(rs):
             rs.wait_event(slot["done"])                  # this slot's features were last read by the frame F calls ago
-            self.rasterize(total_m)
+            self.rasterize(total_m, next_total)
             gather_pyramid(self.rows, self.idx, out=slot["feat"])
             slot["ready"].record(rs)
         us = slot["stream"]

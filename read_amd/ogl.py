@@ -76,7 +76,8 @@ class OGL:
                 if raster.n != texture.texture_.shape[-1]:
                     raise ValueError(f"descriptor table has {texture.texture_.shape[-1]} points, the scene cloud {raster.n}")
                 ss = int(model.ss)                               # supersampling: raster at ss x, reduce in the gather
-                idx, _ = raster.render(scene.total_matrix(), ss * W, ss * H, len(fmts), want_depth=False)
+                idx, _ = raster.render(scene.total_matrix(), ss * W, ss * H, len(fmts), want_depth=False,
+                                       next_total=scene.take_next_total_matrix())      # Scene.announce_next_camera_view
                 feats = gather_pyramid(texture.rows(), idx, texture.activation, ss=ss)
                 out = model.net.engine(H, W).forward(feats[0][0], feats[1][0], feats[2][0], feats[3][0], channels=4)
                 net_input = [f.permute(0, 3, 1, 2) for f in feats]

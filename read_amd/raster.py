@@ -57,8 +57,11 @@ class PointCloudRasterizer:
         self._ws = ws
         return ws
 
-    def render(self, total_m, W, H, levels=5, want_depth=True, out=None):
-        """total_m: (B,4,4) or (4,4) fp32 host array/tensor = proj @ inv(view)."""
+    def render(self, total_m, W, H, levels=5, want_depth=True, out=None, next_total=None):
+        """total_m: (B,4,4) or (4,4) fp32 host array/tensor = proj @ inv(view).
+        next_total: the matrix the NEXT call at this size will use, when the caller knows it (a sweep, a trajectory replay): this
+        frame's last launch then also prepares the next frame's chunk lists and depth seeds (read_splat_hint_next_camera —
+        4 dependent launches per frame instead of 5; results identical, a wrong announcement only costs two small memsets)."""
         M = np.ascontiguousarray(total_m.detach().cpu().numpy() if torch.is_tensor(total_m) else total_m,
                                  dtype=np.float32).reshape(-1, 16)
         B = M.shape[0]
@@ -71,6 +74,11 @@ class PointCloudRasterizer:
             idx, dep = out
         ws = self._workspace(B, W, H)
         L = _lib.lib()
+        if next_total is not None and B == 1 and self.cells is not None:
+            Mn = np.ascontiguousarray(next_total.detach().cpu().numpy() if torch.is_tensor(next_total) else next_total,
+                                      dtype=np.float32).reshape(-1, 16)
+            _lib.check(L.read_splat_hint_next_camera(ws.data_ptr(), Mn.ctypes.data_as(C.POINTER(C.c_float))),
+                       "read_splat_hint_next_camera")
         idx_p = _lib.ptr_array([t.data_ptr() for t in idx])
         dep_p = _lib.ptr_array([t.data_ptr() for t in dep]) if dep is not None else None
         _lib.check(L.read_splat_forward_cells(self.xyz.data_ptr(),

@@ -233,6 +233,20 @@ class Scene:
         """m: camera->world pose (viewer.py:264); the GL scene stores inv(m).T, we keep m."""
         self.view_matrix = np.asarray(m, np.float32)
 
+    def announce_next_camera_view(self, m):
+        """Extension (not in NNScene): the pose the NEXT frame will be rendered from, when the caller knows it — a trajectory replay,
+        a sweep, a viewer that extrapolates its camera.  The rasteriser then prepares that frame inside this frame's last launch
+        (PointCloudRasterizer.render(next_total=...)); a wrong announcement costs two small memsets, never a wrong pixel.
+        Consumed by the next render; None withdraws it."""
+        self.next_view_matrix = None if m is None else np.asarray(m, np.float32)
+
+    def take_next_total_matrix(self):
+        m = getattr(self, 'next_view_matrix', None)
+        self.next_view_matrix = None
+        if m is None:
+            return None
+        return (self.proj_matrix @ np.linalg.inv(m.astype(np.float32)) @ self.model_matrix).astype(np.float32)[None]
+
     def set_proj_matrix(self, m):
         self.proj_matrix = np.asarray(m, np.float32)
 

@@ -163,15 +163,21 @@ def is_wrapped(step, rank, world, n_poses, layout=None):
     return rank * sweep_steps(n_poses, world) + step >= n_poses
 
 
-def run_steps(render_into, exchange, first, count, n_poses, layout=None, shard=None):
+def run_steps(render_into, exchange, first, count, n_poses, layout=None, shard=None, announce_next=False):
     """Steps first .. first+count-1 of the sweep on this rank: step i renders pose ``pose_of_step(i, rank, world, n_poses,
     layout)`` into the exchange's buffer and posts the exchange.  ``render_into(pose_index, out_tensor)`` returns None, or the
     event that marks the frame complete when the renderer writes it on its own stream (FrameRenderer(frames_in_flight=2)).
-    shard = (rank, world) overrides the exchange's own — bench.py's single-GPU proxy of ONE rank's share of an N-rank sweep."""
+    shard = (rank, world) overrides the exchange's own — bench.py's single-GPU proxy of ONE rank's share of an N-rank sweep.
+    announce_next: a sweep knows its next pose — ``render_into(pose, out, next_pose)`` gets it as a third argument, so that the
+    rasteriser can prepare the next frame inside this one's last launch (PointCloudRasterizer.render(next_total=...))."""
     rank, world = shard if shard is not None else (exchange.rank, exchange.world)
     for i in range(first, first + count):
         out = exchange.buffer(i)
-        done = render_into(pose_of_step(i, rank, world, n_poses, layout), out)   # an event if the frame completes on another stream
+        pose = pose_of_step(i, rank, world, n_poses, layout)
+        if announce_next:
+            done = render_into(pose, out, pose_of_step(i + 1, rank, world, n_poses, layout))
+        else:
+            done = render_into(pose, out)                              # an event if the frame completes on another stream
         exchange.post(i, done)
 
 

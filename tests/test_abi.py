@@ -44,11 +44,11 @@ def test_layer_table_matches_independent_spec():
 
 def test_bad_arguments_fail_loudly():
     L = _lib.lib()
-    # header + one key image + hi-z bounds + two seed images + the depth-bound image of the striped path
+    # header + one key image + hi-z bounds + two seed images + the two depth-bound images of the cell path (frames alternate)
     # + the bins of its pass A (38 x 11 tiles of 32x32 pixels x 32 sub-bins: a counter and 256 records of 16 bytes each)
     px = 1216 * 352
     bins = 38 * 11 * 32
-    want = 4096 + 8 * px * 8 + 304 * 88 * 4 + 3 * px * 4 + (bins * 4 + 255) // 256 * 256 + bins * 256 * 16
+    want = 8192 + 8 * px * 8 + 304 * 88 * 4 + 4 * px * 4 + (bins * 4 + 255) // 256 * 256 + bins * 256 * 16
     assert L.read_splat_workspace_bytes(1, 1216, 352) == want
     assert L.read_splat_workspace_bytes(9, 1216, 352) == want
     assert L.read_splat_workspace_bytes(0, 10, 10) == 0

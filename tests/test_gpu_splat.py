@@ -98,7 +98,7 @@ def test_workspace_is_left_clean_and_render_is_idempotent(hip):
     b_i, b_d = r.render(Ms, W, H, 5)
     for x, y in zip(a_i + a_d, b_i + b_d):
         assert torch.equal(x, y)
-    keys = r._ws[4096:4096 + W * H * 8].view(torch.int64)
+    keys = r._ws[8192:8192 + W * H * 8].view(torch.int64)          # behind the 8192-byte header
     assert bool((keys == -1).all()), "key images must be EMPTY after a frame"
 
 
@@ -122,6 +122,66 @@ def test_warm_start_sequence_is_exact(hip):
     for b in range(2):
         oi, od = oracle.raster_multiscale(xyz, Ms[b], W, H, 5, threads=8)
         assert np.array_equal(idx[0][b].cpu().numpy(), oi[0])
+
+
+def _exact(r, xyz, proj, k, W, H, nxt=None, what=""):
+    M = camera.total_matrix(proj, synthetic.sweep_pose(k))
+    Mn = None if nxt is None else camera.total_matrix(proj, synthetic.sweep_pose(nxt))
+    idx, dep = r.render(M, W, H, 5, next_total=Mn)
+    oi, od = oracle.raster_multiscale(xyz, M[0], W, H, 5, threads=8)
+    for l in range(5):
+        assert np.array_equal(idx[l][0].cpu().numpy(), oi[l]), f"{what} pose {k} (announced next {nxt}) level {l}"
+        assert np.array_equal(dep[l][0].cpu().numpy().view(np.uint32), od[l].view(np.uint32)), f"{what} pose {k} level {l} depth"
+
+
+def test_announced_next_camera_is_exact_whatever_comes_next(hip):
+    """read_splat_hint_next_camera (round 5): with the next camera announced, a cell-path frame's resolve launch also classifies
+    the chunks and seeds the depth bounds of the next frame (4 dependent launches per frame instead of 5).  Bit-exact against the
+    oracle for: a correctly announced sweep; WRONG announcements (the prepared set must be wiped, not used); an announcement
+    followed by a batch call and by another size on the same object; hints withdrawn; the knob off; and a profiled frame reports
+    no seed / classification launch when the previous frame did that work."""
+    import ctypes as C
+    from read_amd import _lib
+    L = _lib.lib()
+    W, H = 304, 176
+    xyz = synthetic.make_cloud(1_500_000)
+    proj = synthetic.make_proj(W, H, f=180.0)
+    r = PointCloudRasterizer(xyz)
+    assert r.cells is not None
+    seq = [0, 1, 2, 3, 40, 41, 42, 200, 201]
+    for i, k in enumerate(seq):                                  # every frame announces the true next pose
+        _exact(r, xyz, proj, k, W, H, nxt=seq[i + 1] if i + 1 < len(seq) else None, what="announced")
+    for k, wrong in ((5, 90), (6, 6), (7, 150), (150, 8)):      # announcements that do not come true (and one that repeats itself)
+        _exact(r, xyz, proj, k, W, H, nxt=wrong, what="wrong announcement")
+    _exact(r, xyz, proj, 9, W, H, nxt=10, what="before a batch")
+    Ms = camera.total_matrix(proj, np.stack([synthetic.sweep_pose(3), synthetic.sweep_pose(77)]))
+    idx, _ = r.render(Ms, W, H, 5)                               # two cameras: own workspace, plain path
+    for b in range(2):
+        assert np.array_equal(idx[0][b].cpu().numpy(), oracle.raster_multiscale(xyz, Ms[b], W, H, 5, threads=8)[0][0])
+    _exact(r, xyz, proj, 10, W, H, what="announced, after the batch")          # the announcement of pose 10 is consumed here
+    proj2 = synthetic.make_proj(256, 128, f=150.0)
+    _exact(r, xyz, proj, 11, W, H, nxt=12, what="before another size")
+    _exact(r, xyz, proj2, 12, 256, 128, nxt=13, what="other size")
+    _exact(r, xyz, proj2, 13, 256, 128, what="other size, announced")
+    _exact(r, xyz, proj, 12, W, H, what="back, the old announcement still pending")
+    # the profile shows which launches a frame made
+    try:
+        _lib.check(L.read_tuning_set(b"splat_prof", 1))
+        ms = (C.c_float * 5)()
+        _exact(r, xyz, proj, 20, W, H, nxt=21, what="profiled")
+        _lib.check(L.read_splat_profile_last(ms), "read_splat_profile_last")
+        assert ms[0] > 0 and all(ms[i] > 0 for i in (1, 2, 3, 4)), list(ms)     # nobody prepared pose 20: five launches
+        _exact(r, xyz, proj, 21, W, H, nxt=22, what="profiled")
+        _lib.check(L.read_splat_profile_last(ms), "read_splat_profile_last")
+        assert ms[0] == 0 and all(ms[i] > 0 for i in (1, 2, 3, 4)), list(ms)    # pose 21 was prepared by pose 20's resolve: four
+        _lib.check(L.read_tuning_set(b"splat_ahead", 0))
+        _exact(r, xyz, proj, 22, W, H, nxt=23, what="knob off")               # prepared by 21 -> consumed; prepares nothing
+        _exact(r, xyz, proj, 23, W, H, nxt=24, what="knob off")
+        _lib.check(L.read_splat_profile_last(ms), "read_splat_profile_last")
+        assert ms[0] > 0, list(ms)
+    finally:
+        _lib.check(L.read_tuning_set(b"splat_prof", 0))
+        _lib.check(L.read_tuning_set(b"splat_ahead", 1))
 
 
 def test_full_size_30M_properties(hip):
