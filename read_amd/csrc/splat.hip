@@ -402,7 +402,7 @@ struct CellHeader {            // first 256 bytes of the cell-ordered cloud (dev
     float density;             // points per unit volume of the bounding box
 };
 constexpr int CELL_CHUNK = 1024;
-constexpr int STICKY_FRAMES = 8;
+
 constexpr int CELL_VERSION = 2;
 constexpr size_t CELL_HEADER_BYTES = 256;
 
@@ -420,8 +420,10 @@ struct CellCloud {             // device pointers into the blob
     const float *aabb;         // nchunks * 8: min xyz, max xyz, 2 pad
     int *list_a;               // scratch: MAX_STRIPS x A_BANDS x nchunks chunk ids of this frame's lists A (by depth band)
     CellEntryB *list_b;        // scratch: MAX_STRIPS x nchunks
-    unsigned char *sticky;     // scratch: per chunk, frames for which a list-B chunk that survived the bounds stays in list A
+    unsigned char *sticky;     // scratch: per chunk, frames for which a chunk that produced a candidate stays in list A
     int nchunks;
+    int sticky_frames;         // what a chunk's counter is set to when pass B finds it in front of the bounds (splat_sticky; 0: never promoted)
+    int mark_candidates;       // warm-frame policy (splat_hot): ANY chunk one of whose points reaches a bound gets its counter set
 };
 
 struct StripInfo {
@@ -439,7 +441,7 @@ __device__ __forceinline__ int strip_of_column(const StripInfo &si, int x)
 }
 
 // class of one chunk for camera M: 0 dropped, 1 list A, 2 list B (then e fills in); [cx0, cx1] = pixel columns
-__device__ __forceinline__ int classify_chunk(const float *bb, const float *M, int W, int H, float w_split, bool boot,
+__device__ __forceinline__ int classify_chunk(const float *bb, const float *M, int W, int H, float w_split, bool boot, bool warm,
                                               CellEntryB &e, int &cx0, int &cx1, float &wmin_out, int &area_out)
 {
     constexpr float GAMMA = 1e-6f;
@@ -491,7 +493,7 @@ __device__ __forceinline__ int classify_chunk(const float *bb, const float *M, i
     cx0 = (int)ux0;
     cx1 = (int)ux1;
     area_out = (int)((ux1 - ux0 + 1u) * (uy1 - uy0 + 1u));
-    if (wmin < w_split || boot) return 1;
+    if ((!warm && wmin < w_split) || boot) return 1;              // warm frames: list A = the chunks that held front points (sticky)
     const float dmin = (fmaxf(lo[2], -1.0f) + 1.0f) * 0.5f;
     e.e_thr = (1.0f - dmin) + 2.0f * (0.5f * ez + 2e-7f);
     e.bx = (ux0 >> 2) << 16 | (ux1 >> 2);
@@ -502,7 +504,7 @@ __device__ __forceinline__ int classify_chunk(const float *bb, const float *M, i
 // The classification blocks of cells_seed_classify_kernel: one thread per chunk, block-aggregated appends (one atomic
 // per block, list and strip: a per-wave append measured ~8 us of same-address atomics on the critical path).
 __device__ __forceinline__ void classify_block(const CellCloud &cc, const float *M, int W, int H, int sub, float near_count,
-                                               int block, void *hdr, int cset, const StripInfo &si)
+                                               int block, void *hdr, int cset, const StripInfo &si, int warm)
 {
     constexpr int PER_STRIP = A_BANDS + 1, LISTS = MAX_STRIPS * PER_STRIP;      // per strip: the bands of list A, then list B
     __shared__ int s_cnt[LISTS];
@@ -520,7 +522,7 @@ __device__ __forceinline__ void classify_block(const CellCloud &cc, const float 
     int cls = 0, cx0 = 0, cx1 = 0, area = 0;
     float wmin = 0.0f;
     const bool boot = sub > 0 && chunk % sub == 0;
-    if (chunk < cc.nchunks) cls = classify_chunk(cc.aabb + (size_t)chunk * 8, M, W, H, w_split, boot, e, cx0, cx1, wmin, area);
+    if (chunk < cc.nchunks) cls = classify_chunk(cc.aabb + (size_t)chunk * 8, M, W, H, w_split, boot, warm != 0, e, cx0, cx1, wmin, area);
     // Dense chunk: more points than pixels in its rectangle — its points share pixels, so the passes fold them in the LDS
     // table first (strip_points); a sparse chunk's candidates each own a pixel and go to memory directly.  Bit 31 of the entry.
     const int dense_bit = area < CELL_CHUNK ? (int)0x80000000u : 0;
@@ -534,7 +536,7 @@ __device__ __forceinline__ void classify_block(const CellCloud &cc, const float 
     // number of atomics).  Chunk counts grow with the cube of the distance: equal-population bands at t^3.
     // A list-B chunk that survived the bound test is processed by ONE wave at the tail of pass B (the 26 survivors of the
     // benchmark scene cost ~8 us that way).  Survivors are stable from frame to frame, so pass B marks them and the next
-    // STICKY_FRAMES classifications put them into list A, where they are spread over the whole grid; then they are tested again.
+    // splat_sticky classifications put them into list A, where they are spread over the whole grid; then they are tested again.
     if (cls == 2 && cc.sticky[chunk]) {
         cc.sticky[chunk] -= 1;
         cls = 1;
@@ -581,10 +583,10 @@ __device__ __forceinline__ void seed_block(const CellCloud &cc, const float *M, 
 __global__ __launch_bounds__(256) void cells_seed_classify_kernel(CellCloud cc, Cam1 cam, int W, int H,
                                                                   unsigned *zimg, void *hdr_v, const int *pos_img, int cset,
                                                                   StripInfo si, int seed_blocks,
-                                                                  int sub, float near_count, int use_seeds)
+                                                                  int sub, float near_count, int use_seeds, int warm)
 {
     if ((int)blockIdx.x >= seed_blocks) {
-        classify_block(cc, cam.m, W, H, sub, near_count, (int)blockIdx.x - seed_blocks, hdr_v, cset, si);
+        classify_block(cc, cam.m, W, H, sub, near_count, (int)blockIdx.x - seed_blocks, hdr_v, cset, si, warm);
         return;
     }
     const SplatHeader *hdr = (const SplatHeader *)hdr_v;
@@ -765,6 +767,8 @@ __device__ __forceinline__ void strip_points(const CellCloud &cc, const float *M
 #pragma unroll
         for (int k = 0; k < 4; ++k)
             if (((cand >> k) & 1u) && dbits[k] < bound[k]) zimg[pix[k]] = dbits[k];
+        // a chunk one of whose points reached a bound holds front points: it stays in list A for the next frames (classify_block)
+        if (cc.mark_candidates && __ballot(cand != 0u) && lane == 0) cc.sticky[(unsigned)(first + r * 256) / CELL_CHUNK] = (unsigned char)cc.sticky_frames;
         unsigned direct = cand;                                    // candidates that go to memory (bins / atomics) themselves
         if (LDS && use_lds) {                                      // wave-uniform: dense chunk, fold into the wave's table first
 #pragma unroll
@@ -973,7 +977,7 @@ __global__ __launch_bounds__(256) void cells_pass_kernel(CellCloud cc, Cam1 cam,
                     if (!((todo >> j) & 1u)) continue;
                     const int entry = __builtin_amdgcn_readfirstlane(e[j].chunk);
                     if (lane == 0) {
-                        cc.sticky[entry & 0x7fffffff] = STICKY_FRAMES;
+                        cc.sticky[entry & 0x7fffffff] = (unsigned char)cc.sticky_frames;
                         s_surv[par * (4 * EPW) + atomicAdd(&s_nsurv[par], 1)] = entry;      // <= EPW per wave and round
                     }
                     ++n_run;
@@ -1314,7 +1318,7 @@ struct NextFrame {
     Cam1 cam;
     unsigned *zimg;          // the next frame's bound image (clean)
     const int *pos_img;      // the seed image this frame's passes wrote
-    int cset, sub, use_seeds, class_blocks;
+    int cset, sub, use_seeds, class_blocks, warm;
     float near_count;
 };
 __global__ __launch_bounds__(256) void cells_resolve_next_kernel(unsigned long long *__restrict__ keys, int W, int H,
@@ -1328,7 +1332,7 @@ __global__ __launch_bounds__(256) void cells_resolve_next_kernel(unsigned long l
         return;
     }
     if (b < res_blocks + nx.class_blocks) {
-        classify_block(cc, nx.cam.m, W, H, nx.sub, nx.near_count, b - res_blocks, hdr_v, nx.cset, si);
+        classify_block(cc, nx.cam.m, W, H, nx.sub, nx.near_count, b - res_blocks, hdr_v, nx.cset, si, nx.warm);
         return;
     }
     if (nx.use_seeds) seed_block(cc, nx.cam.m, W, H, nx.zimg, nx.pos_img, b - res_blocks - nx.class_blocks);
@@ -1370,6 +1374,10 @@ int g_splat_kslot = 0;          // key-image layout of the striped path: 0 linea
 int g_splat_lds = 1;            // 1: per-wave LDS hash table in front of the memory-side atomics (strip_points)
 int g_splat_wgs = 4;            // workgroups per CU of the striped passes: 0.0996 / 0.0936 / 0.0893 / 0.0927 / 0.0923 ms at 2 / 3 / 4 / 6 / 8
                                 // (fewer waves = more rounds per wave = finer front-to-back order over the depth bands)
+int g_splat_hot = 0;            // > 0: a frame whose camera moved at most this many pixels (camera_shift_px) since the previous frame of the same
+                                // workspace is WARM: its list A = the chunks that held front points in the last frames (sticky), not the
+                                // chunks nearer than the splat_near split — pass A shrinks from ~45 % of the cloud to the visible shell.  0: off
+int g_splat_sticky = 8;         // classifications for which a list-B chunk that pass B found in front of the bounds is listed in A (0: never)
 int g_splat_ahead = 1;          // 1: with an announced next camera (read_splat_hint_next_camera) a frame's resolve launch also classifies and
                                 // seeds the next frame (cells_resolve_next_kernel): 4 dependent launches per frame instead of 5; 0: A/B
 int g_splat_bins = 1;           // 1: pass A appends its candidates to per-tile bins, merged in LDS (emit_binned); 0: one memory-side atomic each
@@ -1486,9 +1494,20 @@ struct WsHost {
     int pW = 0, pH = 0, p_sub = 0, p_near = 0, p_ns = 0, p_seeds = 0;
     void *p_counters = nullptr, *p_zimg = nullptr;
     size_t p_zimg_bytes = 0;
+    const void *p_cells = nullptr;       // ... for the lists in this cell blob, as of its frame count p_cells_frame
+    unsigned long long p_cells_frame = 0;
+    int p_warm = 0;
+    bool have_last = false;              // the previous cell-path frame of this workspace: camera, size, blob (warm / cold decision)
+    float last_m[16];
+    int lW = 0, lH = 0;
+    const void *l_cells = nullptr;
+    unsigned long long l_cells_frame = 0;
 };
 std::mutex g_ws_mutex;
 std::unordered_map<void *, WsHost> g_ws_host;
+// The chunk lists a classification fills live in the CELL BLOB (one blob serves one stream at a time), not in the workspace: a
+// prediction is only good while no other frame — of any workspace — has run over the same blob.  Frames per blob, counted here.
+std::unordered_map<const void *, unsigned long long> g_cells_frames;
 
 // a pending prediction nobody will consume: wipe the set it dirtied (stream order puts this after the launch that filled it)
 int ws_drop_prediction(WsHost &h, hipStream_t stream)
@@ -1576,6 +1595,49 @@ StripInfo make_strips(int W)
     return si;
 }
 
+// How far (pixels) the image of a static scene moves between cameras Ma and Mb: nine rays of Ma's frustum (centre, edges, corners
+// at 0.9 of the half extent) at three NDC depths (camera distances 10x, 100x and 1000x the near plane for READ's projection,
+// utils.py:123-150) are un-projected with Ma^-1 and projected with Mb.  +inf when Ma is singular or a sample falls behind Mb.
+float camera_shift_px(const float *Ma, const float *Mb, int W, int H)
+{
+    double a[4][8];
+    for (int r = 0; r < 4; ++r)
+        for (int c = 0; c < 4; ++c) {
+            a[r][c] = Ma[4 * r + c];
+            a[r][4 + c] = r == c ? 1.0 : 0.0;
+        }
+    for (int c = 0; c < 4; ++c) {                                     // Gauss-Jordan with partial pivoting
+        int piv = c;
+        for (int r = c + 1; r < 4; ++r)
+            if (fabs(a[r][c]) > fabs(a[piv][c])) piv = r;
+        if (fabs(a[piv][c]) < 1e-30) return INFINITY;
+        for (int k = 0; k < 8; ++k) std::swap(a[c][k], a[piv][k]);
+        const double inv = 1.0 / a[c][c];
+        for (int k = 0; k < 8; ++k) a[c][k] *= inv;
+        for (int r = 0; r < 4; ++r)
+            if (r != c) {
+                const double f = a[r][c];
+                for (int k = 0; k < 8; ++k) a[r][k] -= f * a[c][k];
+            }
+    }
+    double worst = 0.0;
+    const double zs[3] = {0.8, 0.98, 0.998};
+    for (int iz = 0; iz < 3; ++iz)
+        for (int iy = -1; iy <= 1; ++iy)
+            for (int ix = -1; ix <= 1; ++ix) {
+                const double ndc[4] = {0.9 * ix, 0.9 * iy, zs[iz], 1.0};
+                double X[4], q[4];
+                for (int r = 0; r < 4; ++r) X[r] = a[r][4] * ndc[0] + a[r][5] * ndc[1] + a[r][6] * ndc[2] + a[r][7] * ndc[3];
+                if (fabs(X[3]) < 1e-30) return INFINITY;
+                for (int r = 0; r < 3; ++r) X[r] /= X[3];
+                for (int r = 0; r < 4; ++r) q[r] = Mb[4 * r] * X[0] + Mb[4 * r + 1] * X[1] + Mb[4 * r + 2] * X[2] + Mb[4 * r + 3];
+                if (!(q[3] > 1e-12)) return INFINITY;
+                const double dx = (q[0] / q[3] - ndc[0]) * 0.5 * W, dy = (q[1] / q[3] - ndc[1]) * 0.5 * H;
+                worst = std::max(worst, std::max(fabs(dx), fabs(dy)));
+            }
+    return (float)worst;
+}
+
 // ---- per-kernel durations of the LAST cell-path frame (read_tuning_set("splat_prof", 1) + read_splat_profile_last): HIP events
 // on the launch stream around every launch of the frame.  Slots: 0 seeds + classification (0 when the previous frame's resolve
 // launch did that work), 1 pass A, 2 bin merge + bounds, 3 pass B, 4 resolve (+ the next frame's seeds / classification).
@@ -1605,8 +1667,14 @@ int cells_frame(const CellCloud &cc, const float *M_host, int W, int H, int leve
     std::lock_guard<std::mutex> lock(g_ws_mutex);
     WsHost &h = g_ws_host[ws.hdr];
     const int fp = (int)(h.frame & 1);
+    unsigned long long &blob_frames = g_cells_frames[(const void *)cc.pts];
+    // warm: the previous frame over this blob was this workspace's, at this size, from a camera at most splat_hot pixels away
+    const bool continuous = h.have_last && h.lW == W && h.lH == H && h.l_cells == (const void *)cc.pts && h.l_cells_frame == blob_frames;
+    const int warm = g_splat_hot > 0 && continuous && camera_shift_px(h.last_m, M_host, W, H) <= (float)g_splat_hot;
     const bool prepared = h.pred && h.pW == W && h.pH == H && memcmp(h.pm, M_host, sizeof(h.pm)) == 0 && h.p_sub == g_splat_cells_sub &&
-                          h.p_near == g_splat_near && h.p_ns == si.ns && h.p_seeds == g_splat_seeds && h.p_zimg == (void *)ws.zimg[fp];
+                          h.p_near == g_splat_near && h.p_ns == si.ns && h.p_seeds == g_splat_seeds && h.p_zimg == (void *)ws.zimg[fp] &&
+                          h.p_cells == (const void *)cc.pts && h.p_cells_frame == blob_frames && h.p_warm == warm;
+    blob_frames += 1;
     g_prof_valid = false;
     g_prof_slot0 = !prepared;
     if (prepared) h.pred = false;                     // consumed
@@ -1616,7 +1684,7 @@ int cells_frame(const CellCloud &cc, const float *M_host, int W, int H, int leve
         if (prof_mark(0, stream) != READ_OK) return READ_EHIP;
         hipLaunchKernelGGL(cells_seed_classify_kernel, dim3((unsigned)(seed_blocks + class_blocks)), dim3(256), 0,
                            stream, cc, cam, W, H, ws.zimg[fp], ws.hdr, (const int *)ws.prev[fp], fp, si,
-                           seed_blocks, g_splat_cells_sub, (float)g_splat_near, g_splat_seeds);
+                           seed_blocks, g_splat_cells_sub, (float)g_splat_near, g_splat_seeds, warm);
         READ_CHECK_LAUNCH();
     }
     int *const next_pos = ws.prev[fp ^ 1];            // the seed image this frame's passes write: the next frame's (set fp ^ 1) seeds
@@ -1669,6 +1737,12 @@ int cells_frame(const CellCloud &cc, const float *M_host, int W, int H, int leve
     const bool ahead = h.hinted && g_splat_ahead;
     h.hinted = false;
     h.frame += 1;
+    h.have_last = true;
+    memcpy(h.last_m, M_host, sizeof(h.last_m));
+    h.lW = W;
+    h.lH = H;
+    h.l_cells = (const void *)cc.pts;
+    h.l_cells_frame = blob_frames;
     if (prof_mark(4, stream) != READ_OK) return READ_EHIP;
     if (!ahead) {
         const int rc = resolve_launch(ws.keys, 1, 0, W, H, levels, idx_levels, depth_levels, 0, ws, 2, stream, ks, fp);
@@ -1684,6 +1758,7 @@ int cells_frame(const CellCloud &cc, const float *M_host, int W, int H, int leve
     nx.use_seeds = g_splat_seeds;
     nx.class_blocks = class_blocks;
     nx.near_count = (float)g_splat_near;
+    nx.warm = g_splat_hot > 0 && camera_shift_px(M_host, h.hint, W, H) <= (float)g_splat_hot;   // what the next frame will decide
     const ResolveOut out = resolve_out(0, W, H, levels, idx_levels, depth_levels, 0);
     const int tiles_x = ceil_div(W, 32), res_blocks = tiles_x * ceil_div(H, 32);
     hipLaunchKernelGGL(cells_resolve_next_kernel, dim3((unsigned)(res_blocks + class_blocks + (g_splat_seeds ? seed_blocks : 0))), dim3(256),
@@ -1700,6 +1775,9 @@ int cells_frame(const CellCloud &cc, const float *M_host, int W, int H, int leve
     h.p_counters = (char *)ws.hdr + HEADER_STRIPS_OFFSET + (size_t)(fp ^ 1) * COUNTER_SET_BYTES;
     h.p_zimg = ws.zimg[fp ^ 1];
     h.p_zimg_bytes = (size_t)W * H * sizeof(unsigned);
+    h.p_cells = (const void *)cc.pts;
+    h.p_cells_frame = blob_frames;
+    h.p_warm = nx.warm;
     if (prof_mark(5, stream) == READ_OK) g_prof_valid = g_splat_prof != 0;
     return READ_OK;
 }
@@ -1730,6 +1808,8 @@ void splat_set_zl2(int v) { g_splat_zl2 = v != 0; }
 void splat_set_lds(int v) { g_splat_lds = v != 0; }
 void splat_set_bins(int v) { g_splat_bins = v != 0; }
 void splat_set_ahead(int v) { g_splat_ahead = v != 0; }
+void splat_set_hot(int v) { g_splat_hot = v < 0 ? 0 : v; }
+void splat_set_sticky(int v) { g_splat_sticky = v < 0 ? 0 : (v > 200 ? 200 : v); }
 void splat_set_prof(int v) { g_splat_prof = v != 0; }
 void splat_set_kslot(int v) { g_splat_kslot = v < 0 ? 0 : (v > 2 ? 2 : v); }
 void splat_set_wgs(int v) { g_splat_wgs = v < 1 ? 1 : (v > 16 ? 16 : v); }
@@ -1750,6 +1830,8 @@ int splat_get(const char *key, int *value)
     else if (!strcmp(key, "splat_lds")) *value = g_splat_lds;
     else if (!strcmp(key, "splat_bins")) *value = g_splat_bins;
     else if (!strcmp(key, "splat_ahead")) *value = g_splat_ahead;
+    else if (!strcmp(key, "splat_hot")) *value = g_splat_hot;
+    else if (!strcmp(key, "splat_sticky")) *value = g_splat_sticky;
     else if (!strcmp(key, "splat_prof")) *value = g_splat_prof;
     else if (!strcmp(key, "splat_kslot")) *value = g_splat_kslot;
     else return 0;
@@ -2059,6 +2141,8 @@ extern "C" int read_splat_forward_cells(const float *xyz, void *cells, int64_t n
     cc.list_b = (CellEntryB *)((char *)cells + o.list_b);
     cc.sticky = (unsigned char *)cells + o.sticky;
     cc.nchunks = (int)cells_chunks(n);
+    cc.sticky_frames = g_splat_sticky;
+    cc.mark_candidates = g_splat_hot > 0 && g_splat_sticky > 0;
     const WsLayout L = ws_layout(ws, B, W, H);
     return cells_frame(cc, M_host, W, H, levels, idx_levels, depth_levels, L, as_stream(stream));
 }

@@ -163,7 +163,7 @@ def test_announced_next_camera_is_exact_whatever_comes_next(hip):
     _exact(r, xyz, proj, 11, W, H, nxt=12, what="before another size")
     _exact(r, xyz, proj2, 12, 256, 128, nxt=13, what="other size")
     _exact(r, xyz, proj2, 13, 256, 128, what="other size, announced")
-    _exact(r, xyz, proj, 12, W, H, what="back, the old announcement still pending")
+    _exact(r, xyz, proj, 12, W, H, what="back: the old preparation is stale (its chunk lists live in the shared cell blob)")
     # the profile shows which launches a frame made
     try:
         _lib.check(L.read_tuning_set(b"splat_prof", 1))
@@ -179,9 +179,19 @@ def test_announced_next_camera_is_exact_whatever_comes_next(hip):
         _exact(r, xyz, proj, 23, W, H, nxt=24, what="knob off")
         _lib.check(L.read_splat_profile_last(ms), "read_splat_profile_last")
         assert ms[0] > 0, list(ms)
+        # warm frames (splat_hot: the camera moved little -> list A = the chunks that held front points) against the near-split
+        # classification, short and long memories of the front chunks, small steps, a jump, and back
+        for hot, sticky in ((0, 4), (48, 1), (48, 8), (10000, 2)):
+            _lib.check(L.read_tuning_set(b"splat_hot", hot))
+            _lib.check(L.read_tuning_set(b"splat_sticky", sticky))
+            seq = [60, 61, 62, 63, 64, 180, 181, 64, 65]
+            for i, k in enumerate(seq):
+                _exact(r, xyz, proj, k, W, H, nxt=seq[i + 1] if (i + 1 < len(seq) and i % 3 != 2) else None, what=f"hot={hot} sticky={sticky}")
     finally:
         _lib.check(L.read_tuning_set(b"splat_prof", 0))
         _lib.check(L.read_tuning_set(b"splat_ahead", 1))
+        _lib.check(L.read_tuning_set(b"splat_hot", 48))
+        _lib.check(L.read_tuning_set(b"splat_sticky", 4))
 
 
 def test_full_size_30M_properties(hip):

@@ -24,6 +24,9 @@ def main():
     ap.add_argument("dir")
     ap.add_argument("--md", default="")
     ap.add_argument("--match", default="gated_conv")
+    ap.add_argument("--chunk", type=int, default=0, help="label every CHUNK consecutive matching dispatches as one group (a tool "
+                    "that launches shape after shape, e.g. tools/sweep_conv.py --main-only --iters 2: 4 launches per level)")
+    ap.add_argument("--labels", default="", help="comma list of names for the chunks")
     a = ap.parse_args()
     f = glob.glob(os.path.join(a.dir, "**", "*counter_collection.csv"), recursive=True)[0]
     disp = collections.OrderedDict()
@@ -32,9 +35,15 @@ def main():
                                                     "dur": int(r["End_Timestamp"]) - int(r["Start_Timestamp"])})
         d[r["Counter_Name"]] = d.get(r["Counter_Name"], 0.0) + float(r["Counter_Value"])
     agg = collections.OrderedDict()
+    labels = [x for x in a.labels.split(",") if x]
+    seen = 0
     for d in disp.values():
         if a.match not in d["name"]:
             continue
+        if a.chunk:
+            ci = seen // a.chunk
+            d["name"] = (labels[ci] if ci < len(labels) else f"chunk{ci}") + " " + d["name"]
+            seen += 1
         g = agg.setdefault((d["name"], d["grid"]), collections.defaultdict(float))
         g["n"] += 1
         for k, v in d.items():
