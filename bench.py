@@ -734,6 +734,11 @@ def stage_times(wl):
         wl.rasterize(k, wait=wait, nxt=(k + 1) % N_POSES if announce else None)
 
     wl.rasterize(0, nxt=1 if ann else None)
+    # steady state of THIS stage: the loop follows the clock (issue-bound kernels), and the clock follows what the device did in the
+    # seconds before — idle during the CPU leg, or power-limited right after the sweep.  ~0.2 s of rasteriser frames first.
+    for _ in range(2000):
+        frame(wait=False)
+    torch.cuda.synchronize()
     # The rasteriser stage as the timed loop runs it: consecutive poses of the sweep, each frame announcing the next pose
     # (read_splat_hint_next_camera: 4 dependent launches per frame).  `splat_ms`: frames issued at the pace of rounds 2-4's loop (a
     # few host-side calls between frames) — the kernels' durations plus the gaps inside a frame.  `splat_ms_queued`: 64 frames

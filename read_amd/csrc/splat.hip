@@ -269,7 +269,7 @@ struct SplatHeader {          // first bytes of the workspace
     int valid;                // 0: no previous frame; 1: prev[0] holds the winners' point ids (plain path);
                               // 2: prev[parity] holds positions in the cell-ordered cloud (striped path)
     int W, H;
-    int parity;               // which of the two seed images the NEXT striped frame reads
+    int parity;               // (rounds 2-4: which seed image the next cell-path frame reads; now the host's frame counter decides)
 };
 constexpr int A_BANDS = 8;    // list A of a strip is kept in depth bands, nearest first
 struct StripCounters {        // 256 bytes per strip, at HEADER_STRIPS_OFFSET + 256 * strip
@@ -423,7 +423,7 @@ struct CellCloud {             // device pointers into the blob
     unsigned char *sticky;     // scratch: per chunk, frames for which a chunk that produced a candidate stays in list A
     int nchunks;
     int sticky_frames;         // what a chunk's counter is set to when pass B finds it in front of the bounds (splat_sticky; 0: never promoted)
-    int mark_candidates;       // warm-frame policy (splat_hot): ANY chunk one of whose points reaches a bound gets its counter set
+    int mark_candidates;       // splat_mark: ANY chunk one of whose points reaches a bound gets its counter set (not only pass B's survivors)
 };
 
 struct StripInfo {
@@ -441,7 +441,7 @@ __device__ __forceinline__ int strip_of_column(const StripInfo &si, int x)
 }
 
 // class of one chunk for camera M: 0 dropped, 1 list A, 2 list B (then e fills in); [cx0, cx1] = pixel columns
-__device__ __forceinline__ int classify_chunk(const float *bb, const float *M, int W, int H, float w_split, bool boot, bool warm,
+__device__ __forceinline__ int classify_chunk(const float *bb, const float *M, int W, int H, float w_split, bool boot,
                                               CellEntryB &e, int &cx0, int &cx1, float &wmin_out, int &area_out)
 {
     constexpr float GAMMA = 1e-6f;
@@ -453,19 +453,31 @@ __device__ __forceinline__ int classify_chunk(const float *bb, const float *M, i
     for (int k = 0; k < 4; ++k)
         S[k] = fabsf(M[4 * k]) * ax + fabsf(M[4 * k + 1]) * ay + fabsf(M[4 * k + 2]) * az + fabsf(M[4 * k + 3]);
     float c[8][4];
-    float wmin = 3.0e38f;
+    float wmin = 3.0e38f, wmax = -3.0e38f;
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
         const float cx = (i & 1) ? mx[0] : mn[0], cy = (i & 2) ? mx[1] : mn[1], cz = (i & 4) ? mx[2] : mn[2];
 #pragma unroll
         for (int k = 0; k < 4; ++k) c[i][k] = M[4 * k] * cx + M[4 * k + 1] * cy + M[4 * k + 2] * cz + M[4 * k + 3] * 1.0f;
         wmin = fminf(wmin, c[i][3]);
+        wmax = fmaxf(wmax, c[i][3]);
     }
     cx0 = 0;
     cx1 = W - 1;
     area_out = W * H;
     wmin_out = wmin > 0.0f ? wmin : 0.0f;
-    if (!(wmin > fmaxf(1e-3f, 1e-5f * S[3]))) return 1;           // a corner at / behind the camera plane: never culled
+    // A box wholly on ONE side of the plane w = 0 is mapped by x -> clip(x) / w(x) onto the convex hull of its corners' images,
+    // whichever side it is: the tests below only use the ratios and |w|.  Round 5: the boxes BEHIND the camera plane (every
+    // corner w < 0) therefore take the same path with |w| = -w — with READ's projection their z / w is > 1 and they are dropped
+    // here.  Rounds 2-4 sent every box with a corner at w <= 0 to list A unexamined: with the camera INSIDE the cloud that is
+    // everything behind it (at the end of the benchmark sweep 64 % of the cloud, walked point by point by pass A for nothing).
+    // Only a box that STRADDLES the plane is never culled.
+    const float w_eps = fmaxf(1e-3f, 1e-5f * S[3]);
+    if (wmax < -w_eps) {
+        wmin = -wmax;                                             // the smallest |w| of the box
+        wmin_out = wmin;
+    } else if (!(wmin > w_eps))
+        return 1;
     float lo[3] = {3.0e38f, 3.0e38f, 3.0e38f}, hi[3] = {-3.0e38f, -3.0e38f, -3.0e38f};
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
@@ -493,7 +505,7 @@ __device__ __forceinline__ int classify_chunk(const float *bb, const float *M, i
     cx0 = (int)ux0;
     cx1 = (int)ux1;
     area_out = (int)((ux1 - ux0 + 1u) * (uy1 - uy0 + 1u));
-    if ((!warm && wmin < w_split) || boot) return 1;              // warm frames: list A = the chunks that held front points (sticky)
+    if (wmin < w_split || boot) return 1;
     const float dmin = (fmaxf(lo[2], -1.0f) + 1.0f) * 0.5f;
     e.e_thr = (1.0f - dmin) + 2.0f * (0.5f * ez + 2e-7f);
     e.bx = (ux0 >> 2) << 16 | (ux1 >> 2);
@@ -504,7 +516,7 @@ __device__ __forceinline__ int classify_chunk(const float *bb, const float *M, i
 // The classification blocks of cells_seed_classify_kernel: one thread per chunk, block-aggregated appends (one atomic
 // per block, list and strip: a per-wave append measured ~8 us of same-address atomics on the critical path).
 __device__ __forceinline__ void classify_block(const CellCloud &cc, const float *M, int W, int H, int sub, float near_count,
-                                               int block, void *hdr, int cset, const StripInfo &si, int warm)
+                                               int block, void *hdr, int cset, const StripInfo &si)
 {
     constexpr int PER_STRIP = A_BANDS + 1, LISTS = MAX_STRIPS * PER_STRIP;      // per strip: the bands of list A, then list B
     __shared__ int s_cnt[LISTS];
@@ -522,7 +534,7 @@ __device__ __forceinline__ void classify_block(const CellCloud &cc, const float 
     int cls = 0, cx0 = 0, cx1 = 0, area = 0;
     float wmin = 0.0f;
     const bool boot = sub > 0 && chunk % sub == 0;
-    if (chunk < cc.nchunks) cls = classify_chunk(cc.aabb + (size_t)chunk * 8, M, W, H, w_split, boot, warm != 0, e, cx0, cx1, wmin, area);
+    if (chunk < cc.nchunks) cls = classify_chunk(cc.aabb + (size_t)chunk * 8, M, W, H, w_split, boot, e, cx0, cx1, wmin, area);
     // Dense chunk: more points than pixels in its rectangle — its points share pixels, so the passes fold them in the LDS
     // table first (strip_points); a sparse chunk's candidates each own a pixel and go to memory directly.  Bit 31 of the entry.
     const int dense_bit = area < CELL_CHUNK ? (int)0x80000000u : 0;
@@ -583,10 +595,10 @@ __device__ __forceinline__ void seed_block(const CellCloud &cc, const float *M, 
 __global__ __launch_bounds__(256) void cells_seed_classify_kernel(CellCloud cc, Cam1 cam, int W, int H,
                                                                   unsigned *zimg, void *hdr_v, const int *pos_img, int cset,
                                                                   StripInfo si, int seed_blocks,
-                                                                  int sub, float near_count, int use_seeds, int warm)
+                                                                  int sub, float near_count, int use_seeds)
 {
     if ((int)blockIdx.x >= seed_blocks) {
-        classify_block(cc, cam.m, W, H, sub, near_count, (int)blockIdx.x - seed_blocks, hdr_v, cset, si, warm);
+        classify_block(cc, cam.m, W, H, sub, near_count, (int)blockIdx.x - seed_blocks, hdr_v, cset, si);
         return;
     }
     const SplatHeader *hdr = (const SplatHeader *)hdr_v;
@@ -767,7 +779,9 @@ __device__ __forceinline__ void strip_points(const CellCloud &cc, const float *M
 #pragma unroll
         for (int k = 0; k < 4; ++k)
             if (((cand >> k) & 1u) && dbits[k] < bound[k]) zimg[pix[k]] = dbits[k];
-        // a chunk one of whose points reached a bound holds front points: it stays in list A for the next frames (classify_block)
+        // A chunk one of whose points reached a bound holds front points.  Beyond the near split (list B) such a chunk survives the
+        // bound test of EVERY frame and is run by ONE workgroup at pass B's tail; marked, the next splat_sticky classifications list
+        // it in A, where it is banded, binned and spread over the grid (surface scenes: far facades hold front points)
         if (cc.mark_candidates && __ballot(cand != 0u) && lane == 0) cc.sticky[(unsigned)(first + r * 256) / CELL_CHUNK] = (unsigned char)cc.sticky_frames;
         unsigned direct = cand;                                    // candidates that go to memory (bins / atomics) themselves
         if (LDS && use_lds) {                                      // wave-uniform: dense chunk, fold into the wave's table first
@@ -1318,7 +1332,7 @@ struct NextFrame {
     Cam1 cam;
     unsigned *zimg;          // the next frame's bound image (clean)
     const int *pos_img;      // the seed image this frame's passes wrote
-    int cset, sub, use_seeds, class_blocks, warm;
+    int cset, sub, use_seeds, class_blocks;
     float near_count;
 };
 __global__ __launch_bounds__(256) void cells_resolve_next_kernel(unsigned long long *__restrict__ keys, int W, int H,
@@ -1332,7 +1346,7 @@ __global__ __launch_bounds__(256) void cells_resolve_next_kernel(unsigned long l
         return;
     }
     if (b < res_blocks + nx.class_blocks) {
-        classify_block(cc, nx.cam.m, W, H, nx.sub, nx.near_count, b - res_blocks, hdr_v, nx.cset, si, nx.warm);
+        classify_block(cc, nx.cam.m, W, H, nx.sub, nx.near_count, b - res_blocks, hdr_v, nx.cset, si);
         return;
     }
     if (nx.use_seeds) seed_block(cc, nx.cam.m, W, H, nx.zimg, nx.pos_img, b - res_blocks - nx.class_blocks);
@@ -1374,10 +1388,9 @@ int g_splat_kslot = 0;          // key-image layout of the striped path: 0 linea
 int g_splat_lds = 1;            // 1: per-wave LDS hash table in front of the memory-side atomics (strip_points)
 int g_splat_wgs = 4;            // workgroups per CU of the striped passes: 0.0996 / 0.0936 / 0.0893 / 0.0927 / 0.0923 ms at 2 / 3 / 4 / 6 / 8
                                 // (fewer waves = more rounds per wave = finer front-to-back order over the depth bands)
-int g_splat_hot = 0;            // > 0: a frame whose camera moved at most this many pixels (camera_shift_px) since the previous frame of the same
-                                // workspace is WARM: its list A = the chunks that held front points in the last frames (sticky), not the
-                                // chunks nearer than the splat_near split — pass A shrinks from ~45 % of the cloud to the visible shell.  0: off
-int g_splat_sticky = 8;         // classifications for which a list-B chunk that pass B found in front of the bounds is listed in A (0: never)
+int g_splat_mark = 1;           // 1: every chunk one of whose points reaches a depth bound is listed in A for the next splat_sticky classifications
+                                // (strip_points); 0: only the chunks pass B found in front of the bounds (rounds 2-4)
+int g_splat_sticky = 2;         // classifications for which a marked list-B chunk is listed in A (0: never; rounds 2-4: 8, pass-B survivors only)
 int g_splat_ahead = 1;          // 1: with an announced next camera (read_splat_hint_next_camera) a frame's resolve launch also classifies and
                                 // seeds the next frame (cells_resolve_next_kernel): 4 dependent launches per frame instead of 5; 0: A/B
 int g_splat_bins = 1;           // 1: pass A appends its candidates to per-tile bins, merged in LDS (emit_binned); 0: one memory-side atomic each
@@ -1496,12 +1509,6 @@ struct WsHost {
     size_t p_zimg_bytes = 0;
     const void *p_cells = nullptr;       // ... for the lists in this cell blob, as of its frame count p_cells_frame
     unsigned long long p_cells_frame = 0;
-    int p_warm = 0;
-    bool have_last = false;              // the previous cell-path frame of this workspace: camera, size, blob (warm / cold decision)
-    float last_m[16];
-    int lW = 0, lH = 0;
-    const void *l_cells = nullptr;
-    unsigned long long l_cells_frame = 0;
 };
 std::mutex g_ws_mutex;
 std::unordered_map<void *, WsHost> g_ws_host;
@@ -1595,49 +1602,6 @@ StripInfo make_strips(int W)
     return si;
 }
 
-// How far (pixels) the image of a static scene moves between cameras Ma and Mb: nine rays of Ma's frustum (centre, edges, corners
-// at 0.9 of the half extent) at three NDC depths (camera distances 10x, 100x and 1000x the near plane for READ's projection,
-// utils.py:123-150) are un-projected with Ma^-1 and projected with Mb.  +inf when Ma is singular or a sample falls behind Mb.
-float camera_shift_px(const float *Ma, const float *Mb, int W, int H)
-{
-    double a[4][8];
-    for (int r = 0; r < 4; ++r)
-        for (int c = 0; c < 4; ++c) {
-            a[r][c] = Ma[4 * r + c];
-            a[r][4 + c] = r == c ? 1.0 : 0.0;
-        }
-    for (int c = 0; c < 4; ++c) {                                     // Gauss-Jordan with partial pivoting
-        int piv = c;
-        for (int r = c + 1; r < 4; ++r)
-            if (fabs(a[r][c]) > fabs(a[piv][c])) piv = r;
-        if (fabs(a[piv][c]) < 1e-30) return INFINITY;
-        for (int k = 0; k < 8; ++k) std::swap(a[c][k], a[piv][k]);
-        const double inv = 1.0 / a[c][c];
-        for (int k = 0; k < 8; ++k) a[c][k] *= inv;
-        for (int r = 0; r < 4; ++r)
-            if (r != c) {
-                const double f = a[r][c];
-                for (int k = 0; k < 8; ++k) a[r][k] -= f * a[c][k];
-            }
-    }
-    double worst = 0.0;
-    const double zs[3] = {0.8, 0.98, 0.998};
-    for (int iz = 0; iz < 3; ++iz)
-        for (int iy = -1; iy <= 1; ++iy)
-            for (int ix = -1; ix <= 1; ++ix) {
-                const double ndc[4] = {0.9 * ix, 0.9 * iy, zs[iz], 1.0};
-                double X[4], q[4];
-                for (int r = 0; r < 4; ++r) X[r] = a[r][4] * ndc[0] + a[r][5] * ndc[1] + a[r][6] * ndc[2] + a[r][7] * ndc[3];
-                if (fabs(X[3]) < 1e-30) return INFINITY;
-                for (int r = 0; r < 3; ++r) X[r] /= X[3];
-                for (int r = 0; r < 4; ++r) q[r] = Mb[4 * r] * X[0] + Mb[4 * r + 1] * X[1] + Mb[4 * r + 2] * X[2] + Mb[4 * r + 3];
-                if (!(q[3] > 1e-12)) return INFINITY;
-                const double dx = (q[0] / q[3] - ndc[0]) * 0.5 * W, dy = (q[1] / q[3] - ndc[1]) * 0.5 * H;
-                worst = std::max(worst, std::max(fabs(dx), fabs(dy)));
-            }
-    return (float)worst;
-}
-
 // ---- per-kernel durations of the LAST cell-path frame (read_tuning_set("splat_prof", 1) + read_splat_profile_last): HIP events
 // on the launch stream around every launch of the frame.  Slots: 0 seeds + classification (0 when the previous frame's resolve
 // launch did that work), 1 pass A, 2 bin merge + bounds, 3 pass B, 4 resolve (+ the next frame's seeds / classification).
@@ -1668,12 +1632,9 @@ int cells_frame(const CellCloud &cc, const float *M_host, int W, int H, int leve
     WsHost &h = g_ws_host[ws.hdr];
     const int fp = (int)(h.frame & 1);
     unsigned long long &blob_frames = g_cells_frames[(const void *)cc.pts];
-    // warm: the previous frame over this blob was this workspace's, at this size, from a camera at most splat_hot pixels away
-    const bool continuous = h.have_last && h.lW == W && h.lH == H && h.l_cells == (const void *)cc.pts && h.l_cells_frame == blob_frames;
-    const int warm = g_splat_hot > 0 && continuous && camera_shift_px(h.last_m, M_host, W, H) <= (float)g_splat_hot;
     const bool prepared = h.pred && h.pW == W && h.pH == H && memcmp(h.pm, M_host, sizeof(h.pm)) == 0 && h.p_sub == g_splat_cells_sub &&
                           h.p_near == g_splat_near && h.p_ns == si.ns && h.p_seeds == g_splat_seeds && h.p_zimg == (void *)ws.zimg[fp] &&
-                          h.p_cells == (const void *)cc.pts && h.p_cells_frame == blob_frames && h.p_warm == warm;
+                          h.p_cells == (const void *)cc.pts && h.p_cells_frame == blob_frames;
     blob_frames += 1;
     g_prof_valid = false;
     g_prof_slot0 = !prepared;
@@ -1684,7 +1645,7 @@ int cells_frame(const CellCloud &cc, const float *M_host, int W, int H, int leve
         if (prof_mark(0, stream) != READ_OK) return READ_EHIP;
         hipLaunchKernelGGL(cells_seed_classify_kernel, dim3((unsigned)(seed_blocks + class_blocks)), dim3(256), 0,
                            stream, cc, cam, W, H, ws.zimg[fp], ws.hdr, (const int *)ws.prev[fp], fp, si,
-                           seed_blocks, g_splat_cells_sub, (float)g_splat_near, g_splat_seeds, warm);
+                           seed_blocks, g_splat_cells_sub, (float)g_splat_near, g_splat_seeds);
         READ_CHECK_LAUNCH();
     }
     int *const next_pos = ws.prev[fp ^ 1];            // the seed image this frame's passes write: the next frame's (set fp ^ 1) seeds
@@ -1737,12 +1698,6 @@ int cells_frame(const CellCloud &cc, const float *M_host, int W, int H, int leve
     const bool ahead = h.hinted && g_splat_ahead;
     h.hinted = false;
     h.frame += 1;
-    h.have_last = true;
-    memcpy(h.last_m, M_host, sizeof(h.last_m));
-    h.lW = W;
-    h.lH = H;
-    h.l_cells = (const void *)cc.pts;
-    h.l_cells_frame = blob_frames;
     if (prof_mark(4, stream) != READ_OK) return READ_EHIP;
     if (!ahead) {
         const int rc = resolve_launch(ws.keys, 1, 0, W, H, levels, idx_levels, depth_levels, 0, ws, 2, stream, ks, fp);
@@ -1758,7 +1713,6 @@ int cells_frame(const CellCloud &cc, const float *M_host, int W, int H, int leve
     nx.use_seeds = g_splat_seeds;
     nx.class_blocks = class_blocks;
     nx.near_count = (float)g_splat_near;
-    nx.warm = g_splat_hot > 0 && camera_shift_px(M_host, h.hint, W, H) <= (float)g_splat_hot;   // what the next frame will decide
     const ResolveOut out = resolve_out(0, W, H, levels, idx_levels, depth_levels, 0);
     const int tiles_x = ceil_div(W, 32), res_blocks = tiles_x * ceil_div(H, 32);
     hipLaunchKernelGGL(cells_resolve_next_kernel, dim3((unsigned)(res_blocks + class_blocks + (g_splat_seeds ? seed_blocks : 0))), dim3(256),
@@ -1777,7 +1731,6 @@ int cells_frame(const CellCloud &cc, const float *M_host, int W, int H, int leve
     h.p_zimg_bytes = (size_t)W * H * sizeof(unsigned);
     h.p_cells = (const void *)cc.pts;
     h.p_cells_frame = blob_frames;
-    h.p_warm = nx.warm;
     if (prof_mark(5, stream) == READ_OK) g_prof_valid = g_splat_prof != 0;
     return READ_OK;
 }
@@ -1808,7 +1761,7 @@ void splat_set_zl2(int v) { g_splat_zl2 = v != 0; }
 void splat_set_lds(int v) { g_splat_lds = v != 0; }
 void splat_set_bins(int v) { g_splat_bins = v != 0; }
 void splat_set_ahead(int v) { g_splat_ahead = v != 0; }
-void splat_set_hot(int v) { g_splat_hot = v < 0 ? 0 : v; }
+void splat_set_mark(int v) { g_splat_mark = v != 0; }
 void splat_set_sticky(int v) { g_splat_sticky = v < 0 ? 0 : (v > 200 ? 200 : v); }
 void splat_set_prof(int v) { g_splat_prof = v != 0; }
 void splat_set_kslot(int v) { g_splat_kslot = v < 0 ? 0 : (v > 2 ? 2 : v); }
@@ -1830,7 +1783,7 @@ int splat_get(const char *key, int *value)
     else if (!strcmp(key, "splat_lds")) *value = g_splat_lds;
     else if (!strcmp(key, "splat_bins")) *value = g_splat_bins;
     else if (!strcmp(key, "splat_ahead")) *value = g_splat_ahead;
-    else if (!strcmp(key, "splat_hot")) *value = g_splat_hot;
+    else if (!strcmp(key, "splat_mark")) *value = g_splat_mark;
     else if (!strcmp(key, "splat_sticky")) *value = g_splat_sticky;
     else if (!strcmp(key, "splat_prof")) *value = g_splat_prof;
     else if (!strcmp(key, "splat_kslot")) *value = g_splat_kslot;
@@ -2142,7 +2095,7 @@ extern "C" int read_splat_forward_cells(const float *xyz, void *cells, int64_t n
     cc.sticky = (unsigned char *)cells + o.sticky;
     cc.nchunks = (int)cells_chunks(n);
     cc.sticky_frames = g_splat_sticky;
-    cc.mark_candidates = g_splat_hot > 0 && g_splat_sticky > 0;
+    cc.mark_candidates = g_splat_mark && g_splat_sticky > 0;
     const WsLayout L = ws_layout(ws, B, W, H);
     return cells_frame(cc, M_host, W, H, levels, idx_levels, depth_levels, L, as_stream(stream));
 }

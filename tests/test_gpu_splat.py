@@ -179,19 +179,55 @@ def test_announced_next_camera_is_exact_whatever_comes_next(hip):
         _exact(r, xyz, proj, 23, W, H, nxt=24, what="knob off")
         _lib.check(L.read_splat_profile_last(ms), "read_splat_profile_last")
         assert ms[0] > 0, list(ms)
-        # warm frames (splat_hot: the camera moved little -> list A = the chunks that held front points) against the near-split
-        # classification, short and long memories of the front chunks, small steps, a jump, and back
-        for hot, sticky in ((0, 4), (48, 1), (48, 8), (10000, 2)):
-            _lib.check(L.read_tuning_set(b"splat_hot", hot))
+        # the promotion of front chunks into list A (splat_mark / splat_sticky): every setting, small steps, a jump, and back
+        for mark, sticky in ((0, 8), (1, 1), (1, 8), (1, 0), (0, 0)):
+            _lib.check(L.read_tuning_set(b"splat_mark", mark))
             _lib.check(L.read_tuning_set(b"splat_sticky", sticky))
             seq = [60, 61, 62, 63, 64, 180, 181, 64, 65]
             for i, k in enumerate(seq):
-                _exact(r, xyz, proj, k, W, H, nxt=seq[i + 1] if (i + 1 < len(seq) and i % 3 != 2) else None, what=f"hot={hot} sticky={sticky}")
+                _exact(r, xyz, proj, k, W, H, nxt=seq[i + 1] if (i + 1 < len(seq) and i % 3 != 2) else None, what=f"mark={mark} sticky={sticky}")
     finally:
         _lib.check(L.read_tuning_set(b"splat_prof", 0))
         _lib.check(L.read_tuning_set(b"splat_ahead", 1))
-        _lib.check(L.read_tuning_set(b"splat_hot", 48))
-        _lib.check(L.read_tuning_set(b"splat_sticky", 4))
+        _lib.check(L.read_tuning_set(b"splat_mark", 1))
+        _lib.check(L.read_tuning_set(b"splat_sticky", 2))
+
+
+def test_camera_plane_sides_of_the_chunk_boxes(hip):
+    """The chunk classification examines a box wholly BEHIND the camera plane (every corner w < 0) like one in front of it
+    (round 5; rounds 2-4 walked such chunks point by point).  (1) Camera deep inside the cloud, most of it behind the camera:
+    bit-exact, and pass A now lists only what lies ahead.  (2) The negated matrix -M gives every point the opposite sign of w and
+    the same ratios clip / w — the reference's acceptance rule (point_render.cu:139) only sees the ratios, so -M must render
+    exactly M's image: here the boxes ahead of the camera are the ones with w < 0."""
+    from read_amd import _lib
+    L = _lib.lib()
+    W, H = 304, 176
+    xyz = synthetic.make_cloud(1_500_000)
+    proj = synthetic.make_proj(W, H, f=180.0)
+    r = PointCloudRasterizer(xyz)
+    assert r.cells is not None
+    try:
+        _lib.check(L.read_tuning_set(b"splat_stats", 1))
+        items = {}
+        for k in (5, 250):                                        # sweep_pose(250): camera at z = -75 of a slab that spans -120 .. -1
+            r.render(camera.total_matrix(proj, synthetic.sweep_pose(k)), W, H, 5)         # settle lists / seeds
+            torch.cuda.synchronize()
+            before = r._ws[64:64 + 128].view(torch.int64).clone()
+            _exact(r, xyz, proj, k, W, H, what="inside the cloud")
+            torch.cuda.synchronize()
+            items[k] = int((r._ws[64:64 + 128].view(torch.int64) - before)[8])               # pass-A items of that frame
+        assert items[250] < 0.8 * items[5], items                  # fewer chunks ahead, not more (rounds 2-4: 3.5x as many)
+    finally:
+        _lib.check(L.read_tuning_set(b"splat_stats", 0))
+    for k in (3, 130, 250):
+        M = camera.total_matrix(proj, synthetic.sweep_pose(k))
+        oi, od = oracle.raster_multiscale(xyz, M[0], W, H, 5, threads=8)
+        oin, odn = oracle.raster_multiscale(xyz, -M[0], W, H, 5, threads=8)
+        idx, dep = r.render(-M, W, H, 5)
+        for l in range(5):
+            assert np.array_equal(oi[l], oin[l]) and np.array_equal(od[l].view(np.uint32), odn[l].view(np.uint32)), "the oracle itself"
+            assert np.array_equal(idx[l][0].cpu().numpy(), oi[l]), f"-M pose {k} level {l}"
+            assert np.array_equal(dep[l][0].cpu().numpy().view(np.uint32), od[l].view(np.uint32))
 
 
 def test_full_size_30M_properties(hip):

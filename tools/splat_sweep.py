@@ -45,6 +45,12 @@ for ks in sys.argv[2:]:
         e1.record()
         torch.cuda.synchronize()
         best = min(best, e0.elapsed_time(e1) / 60)
+    pol = []
+    for k in range(1, 13):                                     # the list-A policy evidence (SplatHeader::pol_near, pol_sticky), frame by frame
+        call(k, k + 1)
+        torch.cuda.synchronize()
+        pol.append(tuple(int(v) for v in r._ws[16:24].view(torch.int32).cpu()))
+    print("   policy evidence (near, sticky) per frame:", pol, flush=True)
     _lib.check(L.read_tuning_set(b"splat_stats", 1))
     r.render(poses[0], W, H)
     torch.cuda.synchronize()
