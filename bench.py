@@ -180,6 +180,10 @@ class SlabWorkload:
         self.fr.rasterize(self.total[k], None if nxt is None else self.total[nxt])
         return self.fr.idx, self.fr.depth
 
+    def bound_raster(self):
+        """call(k, next_k): pose k through the rasteriser with every foreign-call argument built once (PointCloudRasterizer.bind)."""
+        return self.fr.raster.bind(self.W, self.H, self.fr.levels, (self.fr.idx, self.fr.depth), self.total)
+
     def gather(self):
         return self.fr.gather()
 
@@ -291,6 +295,11 @@ class Kitti6LikeWorkload:
         self.idx, self.depth = self.scene.rasterizer().render(self.scene.total_matrix(), self.W, self.H, self.levels,
                                                               next_total=self.scene.take_next_total_matrix())
         return self.idx, self.depth
+
+    def bound_raster(self):
+        total = self.total
+        self.idx, self.depth = self.rasterize(0)
+        return self.scene.rasterizer().bind(self.W, self.H, self.levels, (self.idx, self.depth), [total[k] for k in range(N_POSES)])
 
     def gather(self):
         self.feat = gather_pyramid(self.texture.rows(), self.idx, self.texture.activation)
@@ -726,44 +735,60 @@ def stage_times(wl):
     # the rasteriser warm-starts from the previous frame, so it is timed over consecutive poses of the sweep
     # (as in the timed loop), not over one repeated pose
     import ctypes as C
-    it = iter(range(1, 10 ** 6))
     ann = bool(getattr(wl, "announces_next", False))
+    if hasattr(wl, "fr"):
+        wl.fr.sync()
+    call = wl.bound_raster()
 
-    def frame(wait=True, announce=ann):
-        k = next(it) % N_POSES
-        wl.rasterize(k, wait=wait, nxt=(k + 1) % N_POSES if announce else None)
+    def lap(announce=ann):
+        for k in range(N_POSES):
+            call(k, (k + 1) % N_POSES if announce else None)
 
-    wl.rasterize(0, nxt=1 if ann else None)
-    # steady state of THIS stage: the loop follows the clock (issue-bound kernels), and the clock follows what the device did in the
-    # seconds before — idle during the CPU leg, or power-limited right after the sweep.  ~0.2 s of rasteriser frames first.
-    for _ in range(2000):
-        frame(wait=False)
-    torch.cuda.synchronize()
-    # The rasteriser stage as the timed loop runs it: consecutive poses of the sweep, each frame announcing the next pose
-    # (read_splat_hint_next_camera: 4 dependent launches per frame).  `splat_ms`: frames issued at the pace of rounds 2-4's loop (a
-    # few host-side calls between frames) — the kernels' durations plus the gaps inside a frame.  `splat_ms_queued`: 64 frames
-    # queued back to back with no host call between them — on top of the kernels the device spends ~2-3 us of launch gap per
-    # dependent kernel (tools/chain_probe.py): what a consumer pays per frame when nothing else runs on the device; in the frame
-    # loop those gaps are filled by the other frame's UNet launches.  `splat_ms_unannounced`: the same loop without the
-    # announcement (5 launches, what a viewer with a free camera gets).  `splat_kernels_ms`: HIP events around every launch of a
-    # frame, median of 9 frames (read_splat_profile_last) — their sum is the frame's kernel time without any gap.
-    ms_splat = hip_time_ms(lambda: frame(), 32)
-    ms_splat_queued = hip_time_ms(lambda: frame(wait=False), 64, batches=3)
-    STAGE_EXTRA["splat_ms_queued"] = ms_splat_queued
+    def lap_ms(announce=ann):
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        lap(announce)
+        e1.record()
+        e1.synchronize()
+        return e0.elapsed_time(e1) / N_POSES
+
+    # The rasteriser stage = ONE WHOLE LAP of the 256-pose sweep, the poses in order (the rasteriser warm-starts from the previous
+    # frame), each frame announcing the next pose as the timed loop does (read_splat_hint_next_camera: 4 dependent launches per
+    # frame), frames queued back to back through pre-bound calls (~5 us of host time per frame: the device never waits for the
+    # host).  A frame's cost depends on the pose — the camera travels 76 m into the cloud — so a few dozen poses are not the sweep
+    # (rounds 1-4 timed 160 consecutive poses from wherever the counter stood).  `splat_ms` = median of three laps;
+    # `splat_ms_unannounced`: one lap without the announcement (5 launches: what a viewer with a free camera gets);
+    # `splat_ms_host_paced`: 64 frames through FrameRenderer.rasterize() with a host synchronisation per frame (rounds 2-4's
+    # `splat_ms` loop); `splat_kernels_ms`: HIP events around every launch, mean over a lap (read_splat_profile_last; each figure
+    # carries ~2 us of event overhead), `splat_kernel_sum_ms` their sum.
+    lap()
+    lap()
+    ms_splat = sorted(lap_ms() for _ in range(3))[1]
+    STAGE_EXTRA["splat_ms_queued"] = ms_splat
     if ann:
-        STAGE_EXTRA["splat_ms_unannounced"] = hip_time_ms(lambda: frame(announce=False), 32)
+        lap(False)
+        STAGE_EXTRA["splat_ms_unannounced"] = lap_ms(False)
+        lap()
+    it = iter(range(1, 10 ** 6))
+
+    def frame():
+        k = next(it) % N_POSES
+        wl.rasterize(k, wait=True, nxt=(k + 1) % N_POSES if ann else None)
+    wl.rasterize(0, nxt=1 if ann else None)
+    STAGE_EXTRA["splat_ms_host_paced"] = hip_time_ms(frame, 32, batches=2)
     try:
+        lap()
         _lib.check(_lib.lib().read_tuning_set(b"splat_prof", 1))
         rows = []
         buf = (C.c_float * 5)()
-        frame()
-        for _ in range(9):
-            frame()
+        for k in range(N_POSES):
+            call(k, (k + 1) % N_POSES if ann else None)
             _lib.check(_lib.lib().read_splat_profile_last(buf), "read_splat_profile_last")
             rows.append(list(buf))
-        med = [float(np.median([r[i] for r in rows])) for i in range(5)]
-        STAGE_EXTRA["splat_kernels_ms"] = dict(zip(("seed_classify", "pass_a", "merge_hiz", "pass_b", "resolve_and_next"), med))
-        STAGE_EXTRA["splat_kernel_sum_ms"] = float(sum(med))
+        mean = [float(np.mean([r[i] for r in rows])) for i in range(5)]
+        STAGE_EXTRA["splat_kernels_ms"] = dict(zip(("seed_classify", "pass_a", "merge_hiz", "pass_b", "resolve_and_next"), mean))
+        STAGE_EXTRA["splat_kernel_sum_ms"] = float(sum(mean))
     except _lib.ReadHipError as e:                       # e.g. a cloud below the cell path's size: no per-kernel figures
         STAGE_EXTRA["splat_kernels_ms"] = str(e)
     finally:
@@ -788,14 +813,22 @@ def shard_proxy(a, dev, wl, verify_it=True):
     for layout in sweep.LAYOUTS:
         ex = sweep.FrameExchange((wl.H, wl.W, 4), dev, torch.float32, None)
         dt = timed_sweep(wl, ex, a.warmup, n, 1, dev, layout, (PROXY_RANK, PROXY_WORLD))
-        it = iter(range(10 ** 6))
-
-        def frame(wait=False):                           # this rank's walk of the sweep, each frame announcing its next pose
-            i = next(it)
-            wl.rasterize(sweep.pose_of_step(i, PROXY_RANK, PROXY_WORLD, N_POSES, layout), wait=wait,
-                         nxt=sweep.pose_of_step(i + 1, PROXY_RANK, PROXY_WORLD, N_POSES, layout))
-        frame(wait=True)
-        ms = hip_time_ms(frame, 32)
+        # the rasteriser over this rank's share of ONE sweep (32 poses), each frame announcing its next pose; the first frame of a
+        # pass follows the share's last pose (a jump that a real run does not have) and is left out of the timing
+        call = wl.bound_raster()
+        share = [sweep.pose_of_step(i, PROXY_RANK, PROXY_WORLD, N_POSES, layout) for i in range(sweep.sweep_steps(N_POSES, PROXY_WORLD))]
+        ts = []
+        for rep in range(4):
+            call(share[0], share[1])
+            torch.cuda.synchronize()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for j in range(1, len(share)):
+                call(share[j], share[j + 1] if j + 1 < len(share) else None)
+            e1.record()
+            e1.synchronize()
+            ts.append(e0.elapsed_time(e1) / (len(share) - 1))
+        ms = sorted(ts[1:])[1]
         r = {"value": n / dt, "unit": "frames/s", "steps": n, "splat_ms": ms,
              "splat_frac_hbm": splat_bytes / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "verified": None}
         if verify_it and not a.no_cpu_baseline:
@@ -841,7 +874,8 @@ def also_records(a, dev, wl, first=None):
         dt = timed_sweep(kw, ex, a.warmup, n, 1, dev)
         ms_splat, ms_gather, ms_unet = stage_times(kw)
         r = {"value": n / dt, "unit": "frames/s", "ms_per_step": 1e3 * dt / n, "steps": n, "splat_ms": ms_splat,
-             "splat_ms_unannounced": STAGE_EXTRA.get("splat_ms_unannounced"), "splat_kernels_ms": STAGE_EXTRA.get("splat_kernels_ms"),
+             "splat_ms_unannounced": STAGE_EXTRA.get("splat_ms_unannounced"), "splat_ms_host_paced": STAGE_EXTRA.get("splat_ms_host_paced"),
+             "splat_kernels_ms": STAGE_EXTRA.get("splat_kernels_ms"),
              "splat_kernel_sum_ms": STAGE_EXTRA.get("splat_kernel_sum_ms"),
              "gather_ms": ms_gather, "unet_ms": ms_unet, "infer_path": kw.ogl.last_path,
              "splat_frac_hbm": (12.0 * kw.N + 8.0 * sum(w * h for (w, h) in camera.level_sizes(kw.W, kw.H, 5)))
@@ -974,13 +1008,14 @@ def main():
                 "splat_ms": ms_splat, "splat_GBps": splat_bytes / (ms_splat * 1e-3) / 1e9,
                 "splat_frac_hbm": splat_bytes / (ms_splat * 1e-3) / 1e9 / HBM_PEAK_GBS,
                 "splat_algorithmic_bytes": splat_bytes, "splat_ms_queued": STAGE_EXTRA.get("splat_ms_queued"),
-                "splat_ms_unannounced": STAGE_EXTRA.get("splat_ms_unannounced"),
+                "splat_ms_unannounced": STAGE_EXTRA.get("splat_ms_unannounced"), "splat_ms_host_paced": STAGE_EXTRA.get("splat_ms_host_paced"),
                 "splat_kernels_ms": STAGE_EXTRA.get("splat_kernels_ms"), "splat_kernel_sum_ms": STAGE_EXTRA.get("splat_kernel_sum_ms"),
                 "splat_frac_hbm_kernels": (splat_bytes / (STAGE_EXTRA["splat_kernel_sum_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS
                                            if STAGE_EXTRA.get("splat_kernel_sum_ms") else None),
-                "splat_note": "splat_ms / splat_frac_hbm: host-paced loop over consecutive sweep poses, next pose announced (what the timed "
-                              "loop does); _queued: 64 frames back to back; _unannounced: without the announcement (5 launches); "
-                              "_kernel_sum: HIP events around each launch of a frame, no gaps",
+                "splat_note": "splat_ms / splat_frac_hbm (= splat_ms_queued): mean per frame over ONE WHOLE LAP of the 256-pose sweep, next pose "
+                              "announced as in the timed loop, frames queued back to back (median of 3 laps); _unannounced: a lap without "
+                              "the announcement (5 launches per frame); _host_paced: rounds 2-4's loop (64 frames, a host sync per frame, "
+                              "poses 1..64); _kernel_sum: HIP events around every launch, lap mean",
                 "gather_ms": ms_gather, "gather_GBps": gather_bytes / (ms_gather * 1e-3) / 1e9,
                 "gather_frac_hbm": gather_bytes / (ms_gather * 1e-3) / 1e9 / HBM_PEAK_GBS,
                 "unet_ms": ms_unet, "unet_launches": len(prof), "unet_executed_TFLOPs": all_exec / (ms_unet * 1e-3) / 1e12,

@@ -1388,6 +1388,7 @@ int g_splat_kslot = 0;          // key-image layout of the striped path: 0 linea
 int g_splat_lds = 1;            // 1: per-wave LDS hash table in front of the memory-side atomics (strip_points)
 int g_splat_wgs = 4;            // workgroups per CU of the striped passes: 0.0996 / 0.0936 / 0.0893 / 0.0927 / 0.0923 ms at 2 / 3 / 4 / 6 / 8
                                 // (fewer waves = more rounds per wave = finer front-to-back order over the depth bands)
+int g_splat_wgs_b = 0;          // workgroups per CU of pass B (0: as pass A, splat_wgs)
 int g_splat_mark = 1;           // 1: every chunk one of whose points reaches a depth bound is listed in A for the next splat_sticky classifications
                                 // (strip_points); 0: only the chunks pass B found in front of the bounds (rounds 2-4)
 int g_splat_sticky = 2;         // classifications for which a marked list-B chunk is listed in A (0: never; rounds 2-4: 8, pass-B survivors only)
@@ -1691,7 +1692,7 @@ int cells_frame(const CellCloud &cc, const float *M_host, int W, int H, int leve
     READ_CHECK_LAUNCH();
     bi.recs = nullptr;
     if (prof_mark(3, stream) != READ_OK) return READ_EHIP;
-    hipLaunchKernelGGL(pass_b, dim3(grid), dim3(256), 0, stream, cc, cam, W, H, ws.keys, ws.zimg[fp],
+    hipLaunchKernelGGL(pass_b, dim3((unsigned)(device_cus() * (g_splat_wgs_b > 0 ? g_splat_wgs_b : g_splat_wgs))), dim3(256), 0, stream, cc, cam, W, H, ws.keys, ws.zimg[fp],
                        (const unsigned short *)ws.hiz, ws.nbx, ws.hdr, next_pos, fp, si, items, stats, ks, bi);
     READ_CHECK_LAUNCH();
     // ---- resolve; with an announced next camera the same launch prepares the next frame's set
@@ -1762,6 +1763,7 @@ void splat_set_lds(int v) { g_splat_lds = v != 0; }
 void splat_set_bins(int v) { g_splat_bins = v != 0; }
 void splat_set_ahead(int v) { g_splat_ahead = v != 0; }
 void splat_set_mark(int v) { g_splat_mark = v != 0; }
+void splat_set_wgs_b(int v) { g_splat_wgs_b = v < 0 ? 0 : (v > 16 ? 16 : v); }
 void splat_set_sticky(int v) { g_splat_sticky = v < 0 ? 0 : (v > 200 ? 200 : v); }
 void splat_set_prof(int v) { g_splat_prof = v != 0; }
 void splat_set_kslot(int v) { g_splat_kslot = v < 0 ? 0 : (v > 2 ? 2 : v); }
@@ -1784,6 +1786,7 @@ int splat_get(const char *key, int *value)
     else if (!strcmp(key, "splat_bins")) *value = g_splat_bins;
     else if (!strcmp(key, "splat_ahead")) *value = g_splat_ahead;
     else if (!strcmp(key, "splat_mark")) *value = g_splat_mark;
+    else if (!strcmp(key, "splat_wgs_b")) *value = g_splat_wgs_b;
     else if (!strcmp(key, "splat_sticky")) *value = g_splat_sticky;
     else if (!strcmp(key, "splat_prof")) *value = g_splat_prof;
     else if (!strcmp(key, "splat_kslot")) *value = g_splat_kslot;
