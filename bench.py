@@ -103,11 +103,26 @@ def hip_time_ms(fn, iters, batches=5):
     return sorted(ts)[len(ts) // 2]
 
 
+def profiled_mfma_busy():
+    """MFMA-pipe busy % of the dominant kernel per level from the committed PMC pass (profiles/r5_pmc_mfma_busy.md: rocprofv3
+    SQ_VALU_MFMA_BUSY_CYCLES over the four C -> C shapes) — static, like the traffic figure: counters need rocprofv3 around the process."""
+    path = os.path.join(ROOT, "profiles", "r5_pmc_mfma_busy.md")
+    out = {}
+    try:
+        for line in open(path):
+            if line.startswith("| `L") and "wino4" in line:
+                cells = [c.strip() for c in line.strip().strip("|").split("|")]
+                out[cells[0].strip("`").split(" gated")[0]] = {"avg_us": float(cells[3]), "mfma_busy_pct": float(cells[4]), "valu_per_mfma": float(cells[7])}
+    except (OSError, ValueError, IndexError):
+        return None
+    return out or None
+
+
 def profiled_traffic():
     """HBM bytes per launch of the dominant kernel family from the committed rocprofv3 PMC passes (separate FETCH_SIZE /
     WRITE_SIZE runs of this same command, FETCH_SIZE x2 as MI355X_MICROARCH.md prescribes for gfx950, factor re-derived
     there from a kernel of known byte count).  Launch-weighted mean over every launch of the 3x3/s1 kernels."""
-    for name in ("r4_traffic.json", "r3_traffic.json", "r2_traffic.json", "r1_traffic.json"):
+    for name in ("r5_traffic.json", "r4_traffic.json", "r3_traffic.json", "r2_traffic.json", "r1_traffic.json"):
         path = os.path.join(ROOT, "profiles", name)
         try:
             ks = json.load(open(path))["kernels"]
@@ -996,6 +1011,9 @@ def main():
                 "traffic_unit": "HBM bytes per launch (rocprofv3 FETCH_SIZE*2 + WRITE_SIZE)",
                 "traffic_source": f"static: profiles/{traffic_src} — separate --pmc passes of this command, committed; NOT measured "
                                   "in this run (counters need rocprofv3 around the process)" if traffic_src else None,
+                "mfma_busy": profiled_mfma_busy(),
+                "mfma_busy_source": "static: profiles/r5_pmc_mfma_busy.md — rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES per level, committed; NOT "
+                                    "measured in this run; it agrees with executed flops / time per level (same file)",
                 "frac_algorithmic": algorithmic_tfs / FP32_MFMA_PEAK_TFS,
                 "launches_per_frame": n_c3, "avg_launch_ms": c3_ms / max(n_c3, 1),
                 "executed_flops_per_frame": c3_exec, "algorithmic_flops_per_frame": c3_fl,

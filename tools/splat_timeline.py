@@ -22,6 +22,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("dir")
     ap.add_argument("--skip", type=int, default=20, help="frames to skip at the start (warm-up)")
+    ap.add_argument("--take", type=int, default=0, help="frames to use after the skipped ones (0: all)")
     a = ap.parse_args()
     f = glob.glob(os.path.join(a.dir, "**", "*kernel_trace.csv"), recursive=True)[0]
     rows = [(int(r["Start_Timestamp"]), int(r["End_Timestamp"]), short(r["Kernel_Name"])) for r in csv.DictReader(open(f))]
@@ -33,6 +34,10 @@ def main():
             frames.append(cur)
             cur = []
     frames = frames[a.skip:]
+    if a.take:
+        frames = frames[:a.take]
+    # frames of the counter-collecting (read_tuning_set("splat_stats", 1)) laps of a tool run different kernels: not the product's
+    frames = [fr for fr in frames if not any("<false, true" in n or "<true, true" in n for _, _, n in fr)]
     per = collections.defaultdict(list)
     busy, span, idle, gap, nk = [], [], [], [], []
     for i, fr in enumerate(frames):
