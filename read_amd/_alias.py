@@ -93,31 +93,52 @@ def lazy_reference_getattr(alias_name, relpath, optional_packages=()):
     return __getattr__
 
 
+def _forward_returns_im_out(path):
+    """Does ``UNet.forward`` in the module at `path` RETURN a dict with the key 'im_out' (src/READ/models/unet.py:280)?  Read off the
+    syntax tree — a comment or a string elsewhere in the file that mentions 'im_out' decides nothing."""
+    import ast
+    try:
+        with open(path, "r", errors="replace") as f:
+            tree = ast.parse(f.read())
+    except (OSError, SyntaxError, ValueError):
+        return False
+    for cls in (n for n in ast.walk(tree) if isinstance(n, ast.ClassDef) and n.name == "UNet"):
+        for fn in (n for n in cls.body if isinstance(n, ast.FunctionDef) and n.name == "forward"):
+            for ret in (n for n in ast.walk(fn) if isinstance(n, ast.Return) and isinstance(n.value, ast.Dict)):
+                if any(isinstance(k, ast.Constant) and k.value == "im_out" for k in ret.value.keys):
+                    return True
+    return False
+
+
+_convention_path = None
+
+
 def result_convention():
     """'dict' when the net's result is ``{'im_out': tensor}`` (the reference's ``src`` tree), 'tensor' otherwise (root tree,
     or no checkout).  Order: ``set_result_convention`` / the environment variable ``READ_AMD_RESULT`` (``tensor`` | ``dict``),
-    else the text of the ``READ/models/unet.py`` behind this repo: the ``src`` variant returns ``{'im_out': z}`` (:280)."""
-    global _convention
-    if _convention is None:
-        env = os.environ.get("READ_AMD_RESULT", "").strip().lower()
-        if env in ("tensor", "dict"):
-            _convention = env
-        else:
-            _convention = "tensor"
-            path = reference_file(os.path.join("READ", "models", "unet.py"))
-            if path is not None:
-                try:
-                    with open(path, "r", errors="replace") as f:
-                        if "'im_out'" in f.read():
-                            _convention = "dict"
-                except OSError:
-                    pass
+    else what ``UNet.forward`` of the ``READ/models/unet.py`` behind this repo RETURNS (its syntax tree, not its text).  The
+    detection is remembered per resolved file: when ``sys.path`` changes and another tree moves behind the alias package, the
+    next call looks again."""
+    global _convention, _convention_path
+    env = os.environ.get("READ_AMD_RESULT", "").strip().lower()
+    if _forced is not None:
+        return _forced
+    if env in ("tensor", "dict"):
+        return env
+    path = reference_file(os.path.join("READ", "models", "unet.py"))
+    if _convention is None or path != _convention_path:
+        _convention_path = path
+        _convention = "dict" if (path is not None and _forward_returns_im_out(path)) else "tensor"
     return _convention
+
+
+_forced = None
 
 
 def set_result_convention(value):
     """Force 'tensor' / 'dict' (None = detect again at the next call)."""
-    global _convention
+    global _convention, _forced
     if value not in (None, "tensor", "dict"):
         raise ValueError("result convention is 'tensor', 'dict' or None")
-    _convention = value
+    _forced = value
+    _convention = None

@@ -1388,6 +1388,7 @@ int g_splat_kslot = 0;          // key-image layout of the striped path: 0 linea
 int g_splat_lds = 1;            // 1: per-wave LDS hash table in front of the memory-side atomics (strip_points)
 int g_splat_wgs = 4;            // workgroups per CU of the striped passes: 0.0996 / 0.0936 / 0.0893 / 0.0927 / 0.0923 ms at 2 / 3 / 4 / 6 / 8
                                 // (fewer waves = more rounds per wave = finer front-to-back order over the depth bands)
+int g_splat_cells_batch = 1;    // 1: a batch of cameras runs as B cell-path frames; 0: the plain pass over the whole cloud (rounds 1-4)
 int g_splat_wgs_b = 0;          // workgroups per CU of pass B (0: as pass A, splat_wgs)
 int g_splat_mark = 1;           // 1: every chunk one of whose points reaches a depth bound is listed in A for the next splat_sticky classifications
                                 // (strip_points); 0: only the chunks pass B found in front of the bounds (rounds 2-4)
@@ -1621,7 +1622,7 @@ int prof_mark(int i, hipStream_t stream)
 }
 
 int cells_frame(const CellCloud &cc, const float *M_host, int W, int H, int levels, int32_t *const *idx_levels,
-                float *const *depth_levels, const WsLayout &ws, hipStream_t stream)
+                float *const *depth_levels, const WsLayout &ws, hipStream_t stream, int b0 = 0)
 {
     const StripInfo si = make_strips(W);
     Cam1 cam;
@@ -1701,7 +1702,7 @@ int cells_frame(const CellCloud &cc, const float *M_host, int W, int H, int leve
     h.frame += 1;
     if (prof_mark(4, stream) != READ_OK) return READ_EHIP;
     if (!ahead) {
-        const int rc = resolve_launch(ws.keys, 1, 0, W, H, levels, idx_levels, depth_levels, 0, ws, 2, stream, ks, fp);
+        const int rc = resolve_launch(ws.keys, 1, b0, W, H, levels, idx_levels, depth_levels, 0, ws, 2, stream, ks, fp);
         if (rc == READ_OK && prof_mark(5, stream) == READ_OK) g_prof_valid = g_splat_prof != 0;
         return rc;
     }
@@ -1714,7 +1715,7 @@ int cells_frame(const CellCloud &cc, const float *M_host, int W, int H, int leve
     nx.use_seeds = g_splat_seeds;
     nx.class_blocks = class_blocks;
     nx.near_count = (float)g_splat_near;
-    const ResolveOut out = resolve_out(0, W, H, levels, idx_levels, depth_levels, 0);
+    const ResolveOut out = resolve_out(b0, W, H, levels, idx_levels, depth_levels, 0);
     const int tiles_x = ceil_div(W, 32), res_blocks = tiles_x * ceil_div(H, 32);
     hipLaunchKernelGGL(cells_resolve_next_kernel, dim3((unsigned)(res_blocks + class_blocks + (g_splat_seeds ? seed_blocks : 0))), dim3(256),
                        0, stream, ws.keys, W, H, levels, out, tiles_x, res_blocks, ws.hdr, ws.zimg[fp], fp, ks, cc, nx, si);
@@ -1763,6 +1764,7 @@ void splat_set_lds(int v) { g_splat_lds = v != 0; }
 void splat_set_bins(int v) { g_splat_bins = v != 0; }
 void splat_set_ahead(int v) { g_splat_ahead = v != 0; }
 void splat_set_mark(int v) { g_splat_mark = v != 0; }
+void splat_set_cells_batch(int v) { g_splat_cells_batch = v != 0; }
 void splat_set_wgs_b(int v) { g_splat_wgs_b = v < 0 ? 0 : (v > 16 ? 16 : v); }
 void splat_set_sticky(int v) { g_splat_sticky = v < 0 ? 0 : (v > 200 ? 200 : v); }
 void splat_set_prof(int v) { g_splat_prof = v != 0; }
@@ -1786,6 +1788,7 @@ int splat_get(const char *key, int *value)
     else if (!strcmp(key, "splat_bins")) *value = g_splat_bins;
     else if (!strcmp(key, "splat_ahead")) *value = g_splat_ahead;
     else if (!strcmp(key, "splat_mark")) *value = g_splat_mark;
+    else if (!strcmp(key, "splat_cells_batch")) *value = g_splat_cells_batch;
     else if (!strcmp(key, "splat_wgs_b")) *value = g_splat_wgs_b;
     else if (!strcmp(key, "splat_sticky")) *value = g_splat_sticky;
     else if (!strcmp(key, "splat_prof")) *value = g_splat_prof;
@@ -2074,7 +2077,7 @@ extern "C" int read_splat_forward_cells(const float *xyz, void *cells, int64_t n
     const int mask = levels >= 1 && levels <= READ_MAX_LEVELS ? (1 << (levels - 1)) - 1 : 0;
     // the striped passes serve the single-camera, pyramid-identity case with 128-byte-aligned key rows (the per-frame
     // render path); everything else goes through the plain pass
-    if (!cells || !g_splat_cells || g_splat_mode != MODE_HIZ || B != 1 || n < (1 << 20) || ((W | H) & mask) != 0 ||
+    if (!cells || !g_splat_cells || g_splat_mode != MODE_HIZ || B < 1 || (B > 1 && !g_splat_cells_batch) || n < (1 << 20) || ((W | H) & mask) != 0 ||
         (W & 15) != 0 || !xyz || !M_host || !ws || W < 1 || H < 1)
         return read_splat_forward(xyz, n, M_host, B, W, H, levels, idx_levels, depth_levels, ws, ws_bytes, stream);
     READ_CHECK_ARG(n <= 0xFFFFFFFEll, "read_splat_forward_cells: point ids must fit 32 bits");
@@ -2100,7 +2103,15 @@ extern "C" int read_splat_forward_cells(const float *xyz, void *cells, int64_t n
     cc.sticky_frames = g_splat_sticky;
     cc.mark_candidates = g_splat_mark && g_splat_sticky > 0;
     const WsLayout L = ws_layout(ws, B, W, H);
-    return cells_frame(cc, M_host, W, H, levels, idx_levels, depth_levels, L, as_stream(stream));
+    // A batch of cameras (the training step's 8 crops, MyRender) = B cell-path frames, one after the other through the same workspace
+    // state: each reads only what its chunk lists keep (the plain pass read the whole cloud once per 8 cameras AND projected every
+    // point 8 times: 777 MB and 729 us for 8 crops of a 10 M-point cloud, profiles/r4_hbm_traffic_per_kernel.md).  The seeds a
+    // camera inherits from its predecessor are bounds from real points under ITS matrix — valid, if rarely useful across crops.
+    for (int b = 0; b < B; ++b) {
+        const int rc = cells_frame(cc, M_host + 16 * b, W, H, levels, idx_levels, depth_levels, L, as_stream(stream), b);
+        if (rc != READ_OK) return rc;
+    }
+    return READ_OK;
 }
 
 extern "C" int read_splat_forward_gl(const float *xyz, int64_t n, const float *M_host, int W, int H,

@@ -302,7 +302,16 @@ def _poly_fragments(wf, wm, cin, cout, k=4):
 PACK_BATCH = os.environ.get("READ_AMD_PACK_BATCH", "1") != "0"
 
 
+class _NotBatchPackable(Exception):
+    pass
+
+
 class _PackPlan:
+    """Assumptions a caller may rely on: (1) the fragments are packed on the stream of the refresh() that saw the weights change; a
+    forward on ANOTHER stream waits for that launch (the event below) even when its own refresh() returns early; (2) the buffers are
+    overwritten in place by the next refresh, so a backward pass uses the fragments of the weights AS THEY ARE when it runs —
+    i.e. between a forward and its backward the weights must not be stepped (the usual order: backward, then optimizer.step())."""
+
     def __init__(self, net, identity_bn):
         from .unet import layer_table
         L = _lib.lib()
@@ -333,7 +342,7 @@ class _PackPlan:
             n = b['norm']
             wf, bf, wm, bm = b['conv_f'].weight, b['conv_f'].bias, b['conv_m'].weight, b['conv_m'].bias
             if not (wf.is_contiguous() and wm.is_contiguous()):
-                raise ValueError("pack plan: non-contiguous weights")
+                raise _NotBatchPackable("non-contiguous weights")
             # parameter block
             params = torch.empty(L.read_conv_param_floats(cout), **f32)
             if self.identity_bn:
@@ -383,15 +392,23 @@ class _PackPlan:
         table = (_lib.PackJob * len(jobs))(*jobs)
         self.table = torch.frombuffer(bytearray(bytes(table)), dtype=torch.uint8).to(dev)
         self.signature = None
+        self.stream = self.event = None
 
     def refresh(self):
         """Pack every layer with its current weights — one launch — unless nothing changed since the last one."""
         sig = tuple(t._version for ts in self.layers for t in ts[0])
+        cur = torch.cuda.current_stream()
         if sig == self.signature:
+            if self.event is not None and cur != self.stream and not torch.cuda.is_current_stream_capturing():
+                cur.wait_event(self.event)                # packed on another stream: order this one behind that launch
             return
         _lib.check(_lib.lib().read_conv_pack_batch(self.table.data_ptr(), self.njobs, self.total_blocks, _lib.stream_ptr()),
                    "read_conv_pack_batch")
         self.signature = sig
+        self.stream, self.event = cur, None
+        if not torch.cuda.is_current_stream_capturing():
+            self.event = torch.cuda.Event()
+            self.event.record(cur)
         for (ts, params, wp, dg, wino, _shape) in self.layers:
             wf = ts[0]
             key = id(wf)
@@ -411,11 +428,15 @@ def _pack_plan(net, identity_bn):
         ts = net.__dict__['_flat_tensors'] = list(net.parameters()) + list(net.buffers())
     key = (bool(identity_bn), hash(tuple(t.data_ptr() for t in ts)), USE_W4, USE_WINOGRAD)
     plans = net.__dict__.setdefault('_pack_plans', {})
-    plan = plans.get(key)
-    if plan is None:
-        if len(plans) >= 4:
-            plans.clear()
-        plan = plans[key] = _PackPlan(net, identity_bn)
+    if key in plans:
+        return plans[key]
+    if len(plans) >= 4:
+        plans.clear()
+    try:
+        plan = _PackPlan(net, identity_bn)
+    except _NotBatchPackable:
+        plan = None                # e.g. channels_last weights: every layer packs itself (_packed_for calls .contiguous())
+    plans[key] = plan
     return plan
 
 
@@ -736,7 +757,9 @@ def unet_forward_train(net, x, x2, x4, x8, blk=(1, 1, 1)):
     ``stack_batch``).  Nearest resampling, concatenation, products and sums keep the separators zero by themselves."""
     capturing = torch.cuda.is_current_stream_capturing()
     if PACK_BATCH and not capturing:
-        _pack_plan(net, bool(net.training)).refresh()      # every layer's parameter block and fragments: one launch
+        plan = _pack_plan(net, bool(net.training))         # every layer's parameter block and fragments: one launch
+        if plan is not None:                               # None: a layout the batch packer does not take -> the per-layer packers
+            plan.refresh()
     # a captured step's autograd graph is walked again every step: its nodes must not share one zero-filled tensor across steps
     net.__dict__['_grad_arena'] = None if capturing else _GradArena()
     z2, z4, z8 = _scm(net, "SCM2", x2, blk), _scm(net, "SCM1", x4, blk), _scm(net, "SCM0", x8, blk)
@@ -835,6 +858,9 @@ class _HybridStepFn(torch.autograd.Function):
         return (None, None, *res)
 
 
+_WARNED_PENDING = False
+
+
 class _GraphedStep:
     def __init__(self, graph, static_in, out, params):
         self.graph, self.static_in, self.out, self.params = graph, static_in, out, params
@@ -849,9 +875,11 @@ class _GraphedStep:
             self.targets.append(p_)
             self.target_slots.append(len(static_in) + j)
         self.pending = False         # a forward whose backward has not run yet: its saved activations are still needed
+        self.pending_version = None  # ... and the parameter versions it saw (_graphed_step releases a stale latch)
 
     def __call__(self, xs):
         self.pending = True
+        self.pending_version = tuple(p_._version for p_ in self.params)
         return _HybridStepFn.apply(self, len(xs), *xs, *self.params)
 
 
@@ -880,8 +908,22 @@ def _graphed_step(net, xs, per_item):
         if len(cache) >= _GRAPH_CACHE_MAX:
             cache.pop(next(iter(cache)))
         g = cache[key] = _capture_step(net, xs, per_item)
-    if g is False or g.pending:
+    if g is False:
         return None
+    if g.pending:
+        # A forward whose backward never ran (a validation pass under .train() with gradients on, an exception before backward())
+        # would latch `pending` for good.  Its saved activations can only still be wanted while the weights are the ones it saw:
+        # once an optimizer step has moved them, that forward's graph is spent — release the latch.
+        if tuple(p_._version for p_ in g.params) != g.pending_version:
+            g.pending = False
+        else:
+            global _WARNED_PENDING
+            if not _WARNED_PENDING:
+                _WARNED_PENDING = True
+                import warnings
+                warnings.warn("read_amd.train: a second forward before the first one's backward — this step runs on the per-layer "
+                              "path (READ_AMD_GRAPH_TRAIN=1 replays ONE step's buffers)")
+            return None                                  # a second forward before the first one's backward: that one keeps the buffers
     return g
 
 

@@ -155,10 +155,17 @@ def test_announced_next_camera_is_exact_whatever_comes_next(hip):
         _exact(r, xyz, proj, k, W, H, nxt=wrong, what="wrong announcement")
     _exact(r, xyz, proj, 9, W, H, nxt=10, what="before a batch")
     Ms = camera.total_matrix(proj, np.stack([synthetic.sweep_pose(3), synthetic.sweep_pose(77)]))
-    idx, _ = r.render(Ms, W, H, 5)                               # two cameras: own workspace, plain path
+    idx, _ = r.render(Ms, W, H, 5)                               # two cameras: own workspace, two cell-path frames over the SAME blob
     for b in range(2):
         assert np.array_equal(idx[0][b].cpu().numpy(), oracle.raster_multiscale(xyz, Ms[b], W, H, 5, threads=8)[0][0])
-    _exact(r, xyz, proj, 10, W, H, what="announced, after the batch")          # the announcement of pose 10 is consumed here
+    _exact(r, xyz, proj, 10, W, H, what="announced, then a batch over the blob: the preparation is stale")
+    try:                                                         # ... and the same batch on the plain pass (rounds 1-4)
+        _lib.check(L.read_tuning_set(b"splat_cells_batch", 0))
+        idx, _ = r.render(Ms, W, H, 5)
+        for b in range(2):
+            assert np.array_equal(idx[0][b].cpu().numpy(), oracle.raster_multiscale(xyz, Ms[b], W, H, 5, threads=8)[0][0])
+    finally:
+        _lib.check(L.read_tuning_set(b"splat_cells_batch", 1))
     proj2 = synthetic.make_proj(256, 128, f=150.0)
     _exact(r, xyz, proj, 11, W, H, nxt=12, what="before another size")
     _exact(r, xyz, proj2, 12, 256, 128, nxt=13, what="other size")
