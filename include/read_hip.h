@@ -69,6 +69,8 @@ int read_device_arch(char *name, int len);
  *                     (default 2) classifications, wherever it lies — on surface-like scenes the chunks beyond the near split that hold
  *                     front points then run banded and binned in pass A instead of surviving pass B's bound test every frame
  *                     (street scene 81.7 -> 70.9 us per frame; volumetric slab unchanged); 0: only pass B's survivors are promoted
+ *   "splat_compact"   1 (default): pass A compacts the candidates of a 256-point round into dense lanes before binning them; 0: rounds 2-4
+ *   "splat_cells_batch" 1 (default): a batch of cameras runs as B cell-path frames; 0: the plain pass over the whole cloud
  *   "splat_prof"      1: HIP events around every launch of a cell-path frame (read_splat_profile_last); 0 (default)
  *   "splat_ahead"     1 (default): with an announced next camera (read_splat_hint_next_camera) a cell-path frame's resolve launch
  *                     also classifies / seeds the next frame — 4 dependent launches per frame instead of 5; 0: always 5

@@ -48,6 +48,7 @@ void splat_set_ahead(int v);
 void splat_set_prof(int v);
 void splat_set_mark(int v);
 void splat_set_cells_batch(int v);
+void splat_set_compact(int v);
 void splat_set_wgs_b(int v);
 void splat_set_sticky(int v);
 void splat_set_kslot(int v);
@@ -90,7 +91,7 @@ extern "C" int read_debug_set_trace(void *buf, size_t bytes)
 // selects between implementations that produce the SAME results; the attribution probes whose results are invalid
 // ("conv_ablate") exist only in builds with -DREAD_DEBUG_KNOBS.
 static const char *const k_tuning_keys[] = {"splat_mode", "splat_stats", "splat_subset", "splat_near", "splat_cells",
-                                            "splat_cells_sub", "splat_seeds", "splat_items", "splat_strips", "splat_wgs", "splat_zl2", "splat_lds", "splat_bins", "splat_ahead", "splat_prof", "splat_mark", "splat_cells_batch", "splat_sticky", "splat_wgs_b", "splat_kslot", "unet_streams", "unet_aff_split", "unet_up_fold", "conv_kc32", "conv_px", "conv_sc", "conv_wino_wgs",
+                                            "splat_cells_sub", "splat_seeds", "splat_items", "splat_strips", "splat_wgs", "splat_zl2", "splat_lds", "splat_bins", "splat_ahead", "splat_prof", "splat_mark", "splat_cells_batch", "splat_compact", "splat_sticky", "splat_wgs_b", "splat_kslot", "unet_streams", "unet_aff_split", "unet_up_fold", "conv_kc32", "conv_px", "conv_sc", "conv_wino_wgs",
                                             "conv_wino", "conv_w16", "conv_w4", "conv_w4_grid", "conv_stagger", "conv_wave", "wgrad_wino",
 #ifdef READ_DEBUG_KNOBS
                                             "conv_ablate", "conv_abl", "conv_w4x2",
@@ -119,6 +120,7 @@ extern "C" int read_tuning_set(const char *key, int value)
     if (!strcmp(key, "splat_ahead")) { readhip::splat_set_ahead(value); return READ_OK; }     // 0: never fold the next frame's first launch into this frame's last
     if (!strcmp(key, "splat_wgs_b")) { readhip::splat_set_wgs_b(value); return READ_OK; }     // workgroups per CU of pass B (0: as pass A)
     if (!strcmp(key, "splat_cells_batch")) { readhip::splat_set_cells_batch(value); return READ_OK; }   // 0: camera batches on the plain pass
+    if (!strcmp(key, "splat_compact")) { readhip::splat_set_compact(value); return READ_OK; }  // 0: pass A bins its candidates from four masked slots per lane
     if (!strcmp(key, "splat_mark")) { readhip::splat_set_mark(value); return READ_OK; }       // 0: only pass-B survivors are promoted into list A
     if (!strcmp(key, "splat_sticky")) { readhip::splat_set_sticky(value); return READ_OK; }   // frames a front chunk stays in list A
     if (!strcmp(key, "splat_prof")) { readhip::splat_set_prof(value); return READ_OK; }       // events around the cell path's launches

@@ -638,6 +638,7 @@ struct BinInfo {
     unsigned *count;           // per (tile, sub-bin), minus one
     int cap, tiles_x;
     float inv_w;               // 1 / W (exact row of a pixel index: (pix + 0.5) * inv_w, W * H <= 2^20)
+    int compact;               // splat_compact: a round's candidates are compacted into dense lanes before they are binned
 };
 
 // NC candidates per lane (valid bit k of `valid`): records into the bins; pos[k] = position of the point (next frame's seed)
@@ -734,7 +735,7 @@ __device__ __forceinline__ void strip_points(const CellCloud &cc, const float *M
                                              int lane, unsigned &st_in, unsigned &st_atomics, unsigned *tag,
                                              unsigned long long *hkey, int *hpos, const KeySlots ks, bool use_lds,
                                              const BinInfo &bi, unsigned *wl_tile, unsigned *wl_cnt, int sub,
-                                             float4 (&q)[4], int next_first)
+                                             float4 (&q)[4], int next_first, uint4 *cq = nullptr)
 {
     // q holds the first 256 records of this call (loaded by the caller: point_records); on return it holds the first 256 of
     // the caller's NEXT call (next_first, -1 = none) — their loads run under this call's bound reads and slot reservations
@@ -801,14 +802,53 @@ __device__ __forceinline__ void strip_points(const CellCloud &cc, const float *M
                 if (placed) direct &= ~(1u << k);
             }
         }
+        // Round 5: the ~12 % of a round's 256 points that reach a bound are COMPACTED into dense lanes before they are binned (BIN):
+        // the code behind the bound test then runs once for up to 64 candidates instead of four times, masked, over the four point
+        // slots of every lane (pass A is bound by the number of vector instructions it issues).  Ranks are prefix
+        // counts over the four ballots; the candidates travel through a wave-private queue in LDS (pixel, position, key).
+        bool compacted = false;
+        if (BIN && cq) {
+            unsigned long long mk[4];
+            int rank[4], tot = 0;
+            const unsigned long long lt_mask = (1ull << lane) - 1ull;
 #pragma unroll
-        for (int k = 0; k < 4; ++k)
-            if ((direct >> k) & 1u) {
-                next[pix[k]] = base + 64 * k;                      // a front point of this pixel: next frame's seed
-                if (!BIN) __hip_atomic_fetch_min(keys + key_slot(ks, (unsigned)pix[k]), key[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                if (STATS) st_atomics++;
+            for (int k = 0; k < 4; ++k) {
+                mk[k] = __ballot((direct >> k) & 1u);
+                rank[k] = tot + __builtin_popcountll(mk[k] & lt_mask);
+                tot += __builtin_popcountll(mk[k]);
             }
-        if (BIN && __ballot(direct != 0u)) emit_binned<4>(bi, pix, px, py, key, direct, keys, lane, wl_tile, wl_cnt, sub);
+            if (tot <= 64) {                                           // wave-uniform
+                compacted = true;
+                if (tot) {
+#pragma unroll
+                    for (int k = 0; k < 4; ++k)
+                        if ((direct >> k) & 1u)
+                            cq[rank[k]] = make_uint4((unsigned)pix[k], (unsigned)(base + 64 * k), (unsigned)key[k], (unsigned)(key[k] >> 32));
+                    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");     // the wave's own queue: LDS operations complete in order
+                    const unsigned v = lane < tot ? 1u : 0u;
+                    const uint4 c = cq[lane < tot ? lane : 0];
+                    const int p1[1] = {(int)c.x};
+                    int y1[1], x1[1];
+                    y1[0] = (int)(((float)p1[0] + 0.5f) * bi.inv_w);           // exact for W * H <= 2^20 (as in the table flush below)
+                    x1[0] = p1[0] - y1[0] * W;
+                    const unsigned long long k1[1] = {((unsigned long long)c.w << 32) | c.z};
+                    if (v) next[p1[0]] = (int)c.y;                             // a front point of this pixel: next frame's seed
+                    if (STATS) st_atomics += v;
+                    emit_binned<1>(bi, p1, x1, y1, k1, v, keys, lane, wl_tile, wl_cnt, sub);
+                    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");     // the queue is free again before the next round writes it
+                }
+            }
+        }
+        if (!compacted) {
+#pragma unroll
+            for (int k = 0; k < 4; ++k)
+                if ((direct >> k) & 1u) {
+                    next[pix[k]] = base + 64 * k;                      // a front point of this pixel: next frame's seed
+                    if (!BIN) __hip_atomic_fetch_min(keys + key_slot(ks, (unsigned)pix[k]), key[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    if (STATS) st_atomics++;
+                }
+            if (BIN && __ballot(direct != 0u)) emit_binned<4>(bi, pix, px, py, key, direct, keys, lane, wl_tile, wl_cnt, sub);
+        }
         if (LDS && use_lds) {
             // the wave's own table: its LDS operations complete in program order, no barrier needed
             __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
@@ -852,9 +892,11 @@ __global__ __launch_bounds__(256) void cells_pass_kernel(CellCloud cc, Cam1 cam,
     __shared__ unsigned long long s_key[LDS ? 4 * LDS_SLOTS : 1];
     __shared__ int s_pos[LDS ? 4 * LDS_SLOTS : 1];
     __shared__ unsigned s_wl[BIN ? 4 * 128 : 1];                     // per wave: 64 tiles + 64 counts / bases (emit_binned)
+    __shared__ uint4 s_cq[BIN ? 4 * 64 : 1];                         // per wave: the compacted candidates of a round (strip_points)
     __shared__ int s_surv[PASS_B ? 2 * 24 : 1];                      // pass B: the workgroup's surviving list entries of one round
     __shared__ int s_nsurv[2];
     unsigned *wl_tile = s_wl + (BIN ? (threadIdx.x >> 6) * 128 : 0), *wl_cnt = wl_tile + (BIN ? 64 : 0);
+    uint4 *cq = (BIN && bi.compact) ? s_cq + (threadIdx.x >> 6) * 64 : nullptr;
     const float *M = cam.m;                                         // (`next`: the seed image this frame's front points go to)
     const int lane = threadIdx.x & 63;
     unsigned *tag = s_tag + (LDS ? (threadIdx.x >> 6) * LDS_SLOTS : 0);
@@ -915,7 +957,7 @@ __global__ __launch_bounds__(256) void cells_pass_kernel(CellCloud cc, Cam1 cam,
             ++n_run;
             strip_points<STATS, ZL2, LDS, BIN>(cc, M, W, H, xlo, xhi, keys, zimg, next, chunk * CELL_CHUNK + part0 * rounds * 256,
                                                rounds, lane, st_in, st_atomics, tag, hkey, hpos, ks, entry < 0, bi, wl_tile, wl_cnt,
-                                               wave & (BIN_SUB - 1), q, next_first);
+                                               wave & (BIN_SUB - 1), q, next_first, cq);
             e0 = e1;
             part0 = part1;
             e1 = e2;
@@ -1340,13 +1382,15 @@ __global__ __launch_bounds__(256) void cells_resolve_next_kernel(unsigned long l
                                                                  void *hdr_v, unsigned *__restrict__ zimg, int cset, KeySlots ks,
                                                                  CellCloud cc, NextFrame nx, StripInfo si)
 {
+    // dispatch order = block order: the classification blocks first — theirs is the longest dependent chain of the launch (box ->
+    // class -> LDS count -> one atomic per list -> list write) —, then the tiles, then the seeds
     const int b = (int)blockIdx.x;
-    if (b < res_blocks) {
-        resolve_tile(keys, W, H, levels, out, tiles_x, nullptr, hdr_v, 2, zimg, cset, ks, b, 0);
+    if (b < nx.class_blocks) {
+        classify_block(cc, nx.cam.m, W, H, nx.sub, nx.near_count, b, hdr_v, nx.cset, si);
         return;
     }
-    if (b < res_blocks + nx.class_blocks) {
-        classify_block(cc, nx.cam.m, W, H, nx.sub, nx.near_count, b - res_blocks, hdr_v, nx.cset, si);
+    if (b < nx.class_blocks + res_blocks) {
+        resolve_tile(keys, W, H, levels, out, tiles_x, nullptr, hdr_v, 2, zimg, cset, ks, b - nx.class_blocks, 0);
         return;
     }
     if (nx.use_seeds) seed_block(cc, nx.cam.m, W, H, nx.zimg, nx.pos_img, b - res_blocks - nx.class_blocks);
@@ -1388,6 +1432,7 @@ int g_splat_kslot = 0;          // key-image layout of the striped path: 0 linea
 int g_splat_lds = 1;            // 1: per-wave LDS hash table in front of the memory-side atomics (strip_points)
 int g_splat_wgs = 4;            // workgroups per CU of the striped passes: 0.0996 / 0.0936 / 0.0893 / 0.0927 / 0.0923 ms at 2 / 3 / 4 / 6 / 8
                                 // (fewer waves = more rounds per wave = finer front-to-back order over the depth bands)
+int g_splat_compact = 1;        // 1: pass A compacts a round's candidates before binning them (strip_points); 0: four masked point slots per lane
 int g_splat_cells_batch = 1;    // 1: a batch of cameras runs as B cell-path frames; 0: the plain pass over the whole cloud (rounds 1-4)
 int g_splat_wgs_b = 0;          // workgroups per CU of pass B (0: as pass A, splat_wgs)
 int g_splat_mark = 1;           // 1: every chunk one of whose points reaches a depth bound is listed in A for the next splat_sticky classifications
@@ -1669,6 +1714,7 @@ int cells_frame(const CellCloud &cc, const float *M_host, int W, int H, int leve
         bi.cap = ws.bin_cap;
         bi.tiles_x = ws.bin_tiles_x;
         bi.inv_w = 1.0f / (float)W;
+        bi.compact = g_splat_compact;
     }
     auto pass_a = bins ? (stats ? (g_splat_lds ? cells_pass_kernel<false, true, false, true, true> : cells_pass_kernel<false, true, false, false, true>)
                           : g_splat_zl2 ? cells_pass_kernel<false, false, true, false, true>
@@ -1765,6 +1811,7 @@ void splat_set_bins(int v) { g_splat_bins = v != 0; }
 void splat_set_ahead(int v) { g_splat_ahead = v != 0; }
 void splat_set_mark(int v) { g_splat_mark = v != 0; }
 void splat_set_cells_batch(int v) { g_splat_cells_batch = v != 0; }
+void splat_set_compact(int v) { g_splat_compact = v != 0; }
 void splat_set_wgs_b(int v) { g_splat_wgs_b = v < 0 ? 0 : (v > 16 ? 16 : v); }
 void splat_set_sticky(int v) { g_splat_sticky = v < 0 ? 0 : (v > 200 ? 200 : v); }
 void splat_set_prof(int v) { g_splat_prof = v != 0; }
@@ -1789,6 +1836,7 @@ int splat_get(const char *key, int *value)
     else if (!strcmp(key, "splat_ahead")) *value = g_splat_ahead;
     else if (!strcmp(key, "splat_mark")) *value = g_splat_mark;
     else if (!strcmp(key, "splat_cells_batch")) *value = g_splat_cells_batch;
+    else if (!strcmp(key, "splat_compact")) *value = g_splat_compact;
     else if (!strcmp(key, "splat_wgs_b")) *value = g_splat_wgs_b;
     else if (!strcmp(key, "splat_sticky")) *value = g_splat_sticky;
     else if (!strcmp(key, "splat_prof")) *value = g_splat_prof;

@@ -57,6 +57,10 @@ def test_bad_arguments_fail_loudly():
     rc = L.read_gather_forward(None, 0, 8, 1, None, None, None, 0, None)
     assert rc == -22
     assert L.read_unet_workspace_bytes(100, 100) == 0                  # not a multiple of 16
+    assert L.read_splat_hint_next_camera(None, None) == -22 and b"workspace" in L.read_last_error()
+    assert L.read_splat_profile_last(None) == -22
+    buf = (C.c_float * 5)()
+    assert L.read_splat_profile_last(buf) == -22 and b"splat_prof" in L.read_last_error()      # no profiled frame yet
     with pytest.raises(_lib.ReadHipError):
         _lib.check(L.read_bilinear_up4(None, 4, 4, 8, None, None), "up4")
     d = _lib.ConvDesc()

@@ -190,6 +190,7 @@ def test_announced_next_camera_is_exact_whatever_comes_next(hip):
         for mark, sticky in ((0, 8), (1, 1), (1, 8), (1, 0), (0, 0)):
             _lib.check(L.read_tuning_set(b"splat_mark", mark))
             _lib.check(L.read_tuning_set(b"splat_sticky", sticky))
+            _lib.check(L.read_tuning_set(b"splat_compact", sticky & 1))          # candidates compacted before binning / four masked slots
             seq = [60, 61, 62, 63, 64, 180, 181, 64, 65]
             for i, k in enumerate(seq):
                 _exact(r, xyz, proj, k, W, H, nxt=seq[i + 1] if (i + 1 < len(seq) and i % 3 != 2) else None, what=f"mark={mark} sticky={sticky}")
@@ -198,6 +199,7 @@ def test_announced_next_camera_is_exact_whatever_comes_next(hip):
         _lib.check(L.read_tuning_set(b"splat_ahead", 1))
         _lib.check(L.read_tuning_set(b"splat_mark", 1))
         _lib.check(L.read_tuning_set(b"splat_sticky", 2))
+        _lib.check(L.read_tuning_set(b"splat_compact", 1))
 
 
 def test_camera_plane_sides_of_the_chunk_boxes(hip):
