@@ -173,6 +173,14 @@ def lib():
             raise ReadHipError(
                 f"{LIB_PATH} is missing: the HIP extension is required (there is no CPU fallback). "
                 "Build it with `python -m read_amd.build` (or __graft_entry__.build()).")
+        # torch first: its wheel bundles a HIP runtime of its own, and the process must end up with ONE — loaded in this order
+        # libreadhip.so binds to the runtime torch brought (same soname); the other way round (this library first, through its
+        # RUNPATH to /opt/rocm, then torch's copy) the second runtime reports "no ROCm-capable device" at the first launch — seen
+        # when __graft_entry__.build() and smoke() ran in one process.
+        try:
+            import torch  # noqa: F401
+        except ImportError:
+            pass
         L = C.CDLL(LIB_PATH)
         table = dict(SIGNATURES)
         if os.environ.get("READ_HIP_DEBUG"):

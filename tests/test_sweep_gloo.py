@@ -240,3 +240,18 @@ def test_ragged_sweep_block_layout_two_ranks():
         assert log == ([0, 1, 2] if rank == 0 else [3, 4, 0])
         assert sorted(filled) == list(range(n_poses)) and len(filled) == n_poses
         assert np.array_equal(stack, ref), f"rank {rank}: block-layout sweep differs from the single-process frames"
+
+
+def test_run_steps_announces_the_next_pose():
+    """run_steps(announce_next=True): the renderer is told the pose this rank renders NEXT (the rasteriser prepares that frame inside
+    the current one's last launch) — for both layouts, a shard override (bench.py's single-GPU proxy of rank 3 of 8) and the wrap."""
+    ex = sweep.FrameExchange((2, 2), torch.device("cpu"), torch.float32, None)
+    for layout in sweep.LAYOUTS:
+        seen = []
+        sweep.run_steps(lambda k, out, nxt: seen.append((k, nxt)), ex, 0, 34, 256, layout, (3, 8), True)
+        want = [sweep.pose_of_step(i, 3, 8, 256, layout) for i in range(35)]
+        assert seen == list(zip(want[:-1], want[1:])), layout
+    assert seen[0] == (96, 97) and seen[31] == (127, 128)          # block layout: rank 3 walks 96, 97, ... (and on past its block)
+    plain = []
+    sweep.run_steps(lambda k, out: plain.append(k), ex, 5, 3, 256)
+    assert plain == [5, 6, 7]
