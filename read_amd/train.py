@@ -91,14 +91,19 @@ USE_WINOGRAD = True          # 3x3 / stride-1 layers with cin % 16 == 0: forward
 
 
 WGRAD_SIDE_STREAM = os.environ.get("READ_AMD_WGRAD_SIDE", "1") != "0"   # weight gradients on a side stream, joined at the end of the backward pass
-_SIDE = {}                   # device -> [stream, join queued for the running backward pass]
+_SIDE = {}                   # device -> [streams, join queued for the running backward pass, layer counter]
+
+
+WGRAD_STREAMS = max(1, int(os.environ.get("READ_AMD_WGRAD_STREAMS", "1")))     # side streams the layers' weight gradients rotate over
 
 
 def _side_stream(dev):
+    """The side stream of the NEXT layer's weight gradient (round robin over WGRAD_STREAMS streams)."""
     e = _SIDE.get(dev)
     if e is None:
-        e = _SIDE[dev] = [torch.cuda.Stream(dev), False]
-    return e[0]
+        e = _SIDE[dev] = [[torch.cuda.Stream(dev) for _ in range(WGRAD_STREAMS)], False, 0]
+    e[2] += 1
+    return e[0][e[2] % len(e[0])]
 
 
 def _queue_join(dev):
@@ -109,7 +114,9 @@ def _queue_join(dev):
 
     def join():
         e[1] = False
-        torch.cuda.current_stream(dev).wait_stream(e[0])
+        cur = torch.cuda.current_stream(dev)
+        for st_ in e[0]:
+            cur.wait_stream(st_)
     torch.autograd.Variable._execution_engine.queue_callback(join)
 
 
