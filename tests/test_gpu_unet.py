@@ -137,6 +137,24 @@ def test_frames_in_flight_equal_sequential_frames(hip):
     pipe.sync()
     for i, (g, w) in enumerate(zip(outs, want)):
         assert torch.equal(g, w), f"pipelined frame {i} differs"
+    # ... and with every frame announcing the next pose (round 5: the rasteriser prepares it inside this frame's last launch) —
+    # truthfully, wrongly (the pose after next) and not at all, through both renderers
+    totals = [camera.total_matrix(proj, p) for p in poses]
+    for fr_ in (seq, pipe):
+        for mode in ("true", "wrong", "mixed"):
+            outs = []
+            for i, t in enumerate(totals):
+                nxt = None
+                if mode == "true" and i + 1 < len(totals):
+                    nxt = totals[i + 1]
+                elif mode == "wrong":
+                    nxt = totals[(i + 2) % len(totals)]
+                elif mode == "mixed" and i % 2 == 0 and i + 1 < len(totals):
+                    nxt = totals[i + 1]
+                outs.append(fr_.render_total(t, next_total=nxt).clone() if fr_ is seq else fr_.render_total(t, next_total=nxt))
+            fr_.sync()
+            for i, (g, w) in enumerate(zip(outs, want)):
+                assert torch.equal(g, w), f"announced ({mode}) frame {i} differs"
 
 
 def test_pipelined_frames_through_the_rccl_exchange(hip):
