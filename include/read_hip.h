@@ -58,7 +58,7 @@ int read_device_arch(char *name, int len);
  *   "splat_cells"     0: ignore the cell-ordered copy (plain path everywhere)
  *   "splat_seeds"     0: no warm start from the previous frame
  *   "splat_near"      striped path: expected points per pixel in front of the pass-A split distance (default 12)
- *   "splat_cells_sub" striped path: every n-th chunk joins pass A (default 32, 0 = none)
+ *   "splat_cells_sub" cell path: every n-th chunk joins pass A (default 0 = only on a workspace's first frame, every 32nd; rounds 2-4: 32)
  *   "splat_items"     striped path: work items per 1024-point chunk (1, 2, 4)
  *   "splat_subset"    plain path: bootstrap pass over every n-th chunk (default 8)
  *   "splat_stats"     debug counters in the workspace header
@@ -66,7 +66,7 @@ int read_device_arch(char *name, int len);
  *   "conv_sc"         8 (default): gated 3x3/s1 layers with Cin = 32, Cout <= 4 on the vector-pipe kernel, 8 input channels per LDS
  *                     phase (16, 32: larger phases); 0: on the MFMA kernels
  *   "splat_mark"      1 (default): a chunk one of whose points reaches a depth bound is listed in pass A for the next "splat_sticky"
- *                     (default 2) classifications, wherever it lies — on surface-like scenes the chunks beyond the near split that hold
+ *                     (default 1) classifications, wherever it lies — on surface-like scenes the chunks beyond the near split that hold
  *                     front points then run banded and binned in pass A instead of surviving pass B's bound test every frame
  *                     (street scene 81.7 -> 70.9 us per frame; volumetric slab unchanged); 0: only pass B's survivors are promoted
  *   "splat_compact"   1 (default): pass A compacts the candidates of a 256-point round into dense lanes before binning them; 0: rounds 2-4

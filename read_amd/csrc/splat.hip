@@ -1423,7 +1423,7 @@ int g_splat_stats = 0;         // debug: accumulate counters in the workspace he
                                // B chunks culled, -, B items run)
 int g_splat_near = 12;         // cell path: pass A takes chunks nearer than the depth at which a pixel expects this many points
 int g_splat_cells = 1;         // 0: ignore the cell-ordered copy (A/B)
-int g_splat_cells_sub = 32;    // list A also takes every n-th chunk (0: none): a first bound where nothing is near
+int g_splat_cells_sub = 0;     // list A also takes every n-th chunk (a first bound where nothing is near); 0: only on a workspace's first frame (every 32nd)
 int g_splat_seeds = 1;         // 0: no warm start from the previous frame's front points (A/B)
 int g_splat_items = 4;         // work items per chunk in the striped passes (1, 2 or 4): 0.101 / 0.101 / 0.097 ms per frame
 int g_splat_zl2 = 0;            // 1: early-z loads bypass the L1 (sc1); measured slower (0.107 vs 0.101 ms)
@@ -1437,7 +1437,7 @@ int g_splat_cells_batch = 1;    // 1: a batch of cameras runs as B cell-path fra
 int g_splat_wgs_b = 0;          // workgroups per CU of pass B (0: as pass A, splat_wgs)
 int g_splat_mark = 1;           // 1: every chunk one of whose points reaches a depth bound is listed in A for the next splat_sticky classifications
                                 // (strip_points); 0: only the chunks pass B found in front of the bounds (rounds 2-4)
-int g_splat_sticky = 2;         // classifications for which a marked list-B chunk is listed in A (0: never; rounds 2-4: 8, pass-B survivors only)
+int g_splat_sticky = 1;         // classifications for which a marked list-B chunk is listed in A (0: never; rounds 2-4: 8, pass-B survivors only)
 int g_splat_ahead = 1;          // 1: with an announced next camera (read_splat_hint_next_camera) a frame's resolve launch also classifies and
                                 // seeds the next frame (cells_resolve_next_kernel): 4 dependent launches per frame instead of 5; 0: A/B
 int g_splat_bins = 1;           // 1: pass A appends its candidates to per-tile bins, merged in LDS (emit_binned); 0: one memory-side atomic each
@@ -1679,7 +1679,11 @@ int cells_frame(const CellCloud &cc, const float *M_host, int W, int H, int leve
     WsHost &h = g_ws_host[ws.hdr];
     const int fp = (int)(h.frame & 1);
     unsigned long long &blob_frames = g_cells_frames[(const void *)cc.pts];
-    const bool prepared = h.pred && h.pW == W && h.pH == H && memcmp(h.pm, M_host, sizeof(h.pm)) == 0 && h.p_sub == g_splat_cells_sub &&
+    // every n-th chunk joins list A as a first bound where nothing is near: on a workspace's FIRST frame (no seeds yet) when the knob
+    // leaves it to us (splat_cells_sub 0), never afterwards — the seeds are that bound (lap 75.8 -> 75.1 us with splat_sticky 1)
+    const int sub_now = g_splat_cells_sub > 0 ? g_splat_cells_sub : (h.frame == 0 ? 32 : 0);
+    const int sub_next = g_splat_cells_sub > 0 ? g_splat_cells_sub : 0;
+    const bool prepared = h.pred && h.pW == W && h.pH == H && memcmp(h.pm, M_host, sizeof(h.pm)) == 0 && h.p_sub == sub_now &&
                           h.p_near == g_splat_near && h.p_ns == si.ns && h.p_seeds == g_splat_seeds && h.p_zimg == (void *)ws.zimg[fp] &&
                           h.p_cells == (const void *)cc.pts && h.p_cells_frame == blob_frames;
     blob_frames += 1;
@@ -1692,7 +1696,7 @@ int cells_frame(const CellCloud &cc, const float *M_host, int W, int H, int leve
         if (prof_mark(0, stream) != READ_OK) return READ_EHIP;
         hipLaunchKernelGGL(cells_seed_classify_kernel, dim3((unsigned)(seed_blocks + class_blocks)), dim3(256), 0,
                            stream, cc, cam, W, H, ws.zimg[fp], ws.hdr, (const int *)ws.prev[fp], fp, si,
-                           seed_blocks, g_splat_cells_sub, (float)g_splat_near, g_splat_seeds);
+                           seed_blocks, sub_now, (float)g_splat_near, g_splat_seeds);
         READ_CHECK_LAUNCH();
     }
     int *const next_pos = ws.prev[fp ^ 1];            // the seed image this frame's passes write: the next frame's (set fp ^ 1) seeds
@@ -1757,7 +1761,7 @@ int cells_frame(const CellCloud &cc, const float *M_host, int W, int H, int leve
     nx.zimg = ws.zimg[fp ^ 1];
     nx.pos_img = next_pos;
     nx.cset = fp ^ 1;
-    nx.sub = g_splat_cells_sub;
+    nx.sub = sub_next;
     nx.use_seeds = g_splat_seeds;
     nx.class_blocks = class_blocks;
     nx.near_count = (float)g_splat_near;
@@ -1770,7 +1774,7 @@ int cells_frame(const CellCloud &cc, const float *M_host, int W, int H, int leve
     memcpy(h.pm, h.hint, sizeof(h.pm));
     h.pW = W;
     h.pH = H;
-    h.p_sub = g_splat_cells_sub;
+    h.p_sub = sub_next;
     h.p_near = g_splat_near;
     h.p_ns = si.ns;
     h.p_seeds = g_splat_seeds;

@@ -11,6 +11,9 @@ from read_amd import _lib, camera, synthetic                  # noqa: E402
 from read_amd.raster import PointCloudRasterizer              # noqa: E402
 
 L = _lib.lib()
+for kv in sys.argv[1:]:
+    k_, v_ = kv.split("=")
+    _lib.check(L.read_tuning_set(k_.encode(), int(v_)))
 S, B, N = 256, 8, 10_000_000
 xyz = synthetic.make_street_cloud(N)
 proj = synthetic.make_proj(S, S)

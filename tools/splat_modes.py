@@ -14,7 +14,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from read_amd import _lib, camera, synthetic          # noqa: E402
 from read_amd.raster import PointCloudRasterizer      # noqa: E402
 
-DEFAULTS = {"splat_mode": 7, "splat_cells": 1, "splat_seeds": 1, "splat_near": 12, "splat_cells_sub": 32, "splat_items": 4,
+DEFAULTS = {"splat_mode": 7, "splat_cells": 1, "splat_seeds": 1, "splat_near": 12, "splat_cells_sub": 0, "splat_items": 4,
             "splat_subset": 8, "splat_strips": 1, "splat_zl2": 0, "splat_wgs": 4, "splat_lds": 1, "splat_kslot": 0}
 VARIANTS = [
     ("default: striped cell-ordered passes, zimg early-z, warm start", {}),
