@@ -372,13 +372,16 @@ __global__ __launch_bounds__(256) void splat_seed_kernel(const float *__restrict
 // ---- cell-ordered cloud, XCD-striped passes -------------------------------------------------------------------------
 // read_splat_cells_build_host() sorts the cloud once along a Morton curve and cuts it into chunks of 1024 points with
 // their bounding boxes; every record is (x, y, z, original id), so keys carry the ORIGINAL id and the result is
-// bit-identical to the unsorted pass (atomic min does not care about order).  Per frame, five launches:
+// bit-identical to the unsorted pass (atomic min does not care about order).  Per frame, five launches — FOUR when the caller
+// announced this frame's camera one frame ahead (read_splat_hint_next_camera): the previous frame's resolve launch then already
+// did this frame's seeds and classification (cells_resolve_next_kernel), in the OTHER of the two sets of per-frame state:
 //   cells_seed_classify_kernel
 //       seed blocks      re-project last frame's front points (their POSITIONS in the sorted cloud were left in a
 //                        per-pixel image by the threads that issued atomics — any real point is a valid seed, so that
 //                        image may be written racily) and store their depths into zimg.  No atomics.
-//       classify blocks  one thread per chunk, from the 8 projected corners of its box: outside the frustum -> dropped
-//                        (no point of it is read); nearest corner closer than w_split, or every sub-th chunk -> list A;
+//       classify blocks  one thread per chunk, from the 8 projected corners of its box: outside the frustum — or wholly behind
+//                        the camera plane, round 5 — -> dropped (no point of it is read); nearest corner closer than w_split, a
+//                        chunk that held a front point lately (sticky), or every sub-th chunk on a first frame -> list A;
 //                        the rest -> list B with its screen rectangle and depth threshold.  A chunk is appended to the
 //                        list of the strip that holds the centre column of its rectangle (block-aggregated appends).
 //   cells_pass_kernel<A> workgroup b works on strip b % ns and walks that strip's list A statically: zimg early-z, LDS
@@ -389,7 +392,8 @@ __global__ __launch_bounds__(256) void splat_seed_kernel(const float *__restrict
 //                        per 4x4 block from the (now exact) keys; zimg := exact current depths.  (cells_hiz_kernel without bins.)
 //   cells_pass_kernel<B> same walk over list B: a chunk is skipped when its nearest possible depth is behind the bound
 //                        of EVERY block of its rectangle, otherwise its points run as in pass A.
-//   splat_resolve_kernel levels, keys back to EMPTY, zimg back to "no bound", counters to zero.
+//   splat_resolve_kernel levels, keys back to EMPTY, this frame's zimg back to "no bound", its counters to zero
+//                        (cells_resolve_next_kernel: plus the next frame's classify and seed blocks, for the announced camera).
 // Conservative arithmetic: the fp32 projection of a point and of the box corners differ by rounding; with
 // S_k = sum_j |M_kj| max|box_j| + |M_k3| every computed clip coordinate is within gamma S_k of the exact one, so ndc
 // errors are bounded by gamma (S_k + S_3) / w_min + ulp; the rectangle is widened and the depth test tightened by that
