@@ -7,7 +7,9 @@ change can silently lose — found in the ISA, not in any test result (DESIGN.md
   * the whole-quad 1x1 pixel-lane kernel waits for `vmcnt(3)` in front of its MFMA groups;
   * the small-Cout vector-pipe kernel keeps its software-pipelined scalar weight loads: 1728 v_fmac_f32 with SGPR multipliers per
     pixel, 144 s_load_dwordx16 issued one group ahead, no scratch;
-  * the Winograd-domain wgrad kernel fits two waves per SIMD (<= 256 registers, no scratch) and issues its 36 MFMAs per iteration.
+  * the Winograd-domain wgrad kernel fits two waves per SIMD (<= 256 registers, no scratch) and issues its 36 MFMAs per iteration;
+  * the rasteriser's pass A keeps five waves per SIMD (<= 96 registers, no scratch): round 5's pipelined variant needed 149 - 175 and
+    lost 8 - 19 us per frame to the occupancy it gave up (profiles/r5_pass_a_pipe_ab.md).
 """
 import os
 import re
@@ -123,3 +125,14 @@ def test_two_waves_per_simd_f4_kernel_is_not_in_the_product(conv_asm):
             keys.append(L.read_tuning_key(i).decode())
             i += 1
         assert "conv_w4x2" not in keys and "conv_w4" in keys
+
+
+def test_rasteriser_pass_a_keeps_five_waves_per_simd(tmp_path_factory):
+    """cells_pass_kernel<A> of the product (no statistics, bound image through L1, LDS table, binned candidates): what hides its chain
+    of dependent round trips is the number of resident waves (profiles/r5_pass_a_pipe_ab.md) — 512 registers / 5 waves = 102, the
+    allocation granule is 8."""
+    asm = _asm("splat.hip", tmp_path_factory)
+    name, body = _function(asm, "cells_pass_kernelILb0ELb0ELb0ELb1ELb1E")
+    assert _meta(asm, name, "private_seg_size") == 0, "scratch in pass A"
+    assert _meta(asm, name, "num_vgpr") + _meta(asm, name, "num_agpr") <= 96, "pass A no longer fits five waves per SIMD"
+    assert "global_atomic_add" in body and "ds_write" in body           # the bin reservation and the candidate queue are in this kernel
