@@ -51,8 +51,9 @@ __global__ __launch_bounds__(256) void mfma_f32_probe_kernel(float *out, int ite
 // second wave?  Each wave runs `iters` rounds of 16 MFMAs on independent accumulators; after every MFMA come K fillers
 // (pinned with sched_barrier): FT 0 independent v_add_f32, 1 ds_read_b128 (waited once per round), 2 s_add_u32, 3 v_add_f32 in
 // one dependent chain, 4 global_load_dwordx4 (L2-resident line, waited once per round).  KIND 0: v_mfma_f32_32x32x2_f32
-// (8 accumulators, 2 MFMAs each per round), 1: v_mfma_f32_16x16x4_f32 (16 accumulators).  Lane 0 of every wave stores its
-// s_memtime span.
+// (8 accumulators, 2 MFMAs each per round), 1: v_mfma_f32_16x16x4_f32 (16 accumulators), 2: v_mfma_f32_16x16x32_bf16 (16
+// accumulators; round 5, DESIGN.md 12.1 c: does a vector instruction beside a bf16 MFMA cost what it costs beside an fp32 one?).
+// Lane 0 of every wave stores its s_memtime span.
 typedef float floatx4 __attribute__((ext_vector_type(4)));
 template <int KIND, int FT, int K>
 __global__ __launch_bounds__(256, 2) void issue_probe_kernel(float *out, unsigned long long *cycles, int iters, const float4 *gsrc)
@@ -61,13 +62,20 @@ __global__ __launch_bounds__(256, 2) void issue_probe_kernel(float *out, unsigne
     lbuf[threadIdx.x] = make_float4(1.f, 2.f, 3.f, 4.f);
     __syncthreads();
     floatx16 acc32[KIND == 0 ? 8 : 1];
-    floatx4 acc16[KIND == 1 ? 16 : 1];
+    floatx4 acc16[KIND >= 1 ? 16 : 1];
+    typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+    bf16x8 ha, hb;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        ha[i] = (__bf16)(0.25f + 0.001f * (threadIdx.x & 31) + 0.01f * i);
+        hb[i] = (__bf16)(1.0f - 0.002f * (threadIdx.x & 15) - 0.01f * i);
+    }
 #pragma unroll
     for (int i = 0; i < (KIND == 0 ? 8 : 1); ++i)
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc32[i][r] = 0.0f;
 #pragma unroll
-    for (int i = 0; i < (KIND == 1 ? 16 : 1); ++i) acc16[i] = floatx4{0.f, 0.f, 0.f, 0.f};
+    for (int i = 0; i < (KIND >= 1 ? 16 : 1); ++i) acc16[i] = floatx4{0.f, 0.f, 0.f, 0.f};
     float a0 = 0.37f + 0.001f * threadIdx.x, b0 = 1.0f - 0.002f * threadIdx.x;
     float x[8];
 #pragma unroll
@@ -85,7 +93,8 @@ __global__ __launch_bounds__(256, 2) void issue_probe_kernel(float *out, unsigne
 #pragma unroll
         for (int m = 0; m < 16; ++m) {
             if (KIND == 0) acc32[m & 7] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc32[m & 7], 0, 0, 0);
-            else acc16[m] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0, b0, acc16[m], 0, 0, 0);
+            else if (KIND == 1) acc16[m] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0, b0, acc16[m], 0, 0, 0);
+            else acc16[m] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ha, hb, acc16[m], 0, 0, 0);
 #pragma unroll
             for (int k = 0; k < K; ++k) {
                 const int q = (m * K + k) & 7;
@@ -117,7 +126,7 @@ __global__ __launch_bounds__(256, 2) void issue_probe_kernel(float *out, unsigne
 #pragma unroll
         for (int r = 0; r < 16; ++r) ssum += acc32[i][r];
 #pragma unroll
-    for (int i = 0; i < (KIND == 1 ? 16 : 1); ++i) ssum += acc16[i][0] + acc16[i][3];
+    for (int i = 0; i < (KIND >= 1 ? 16 : 1); ++i) ssum += acc16[i][0] + acc16[i][3];
     if (ssum == 1234.5678f) out[blockIdx.x * blockDim.x + threadIdx.x] = ssum;
     if ((threadIdx.x & 63) == 0) cycles[blockIdx.x * 4 + (threadIdx.x >> 6)] = t1 - t0;
 }
@@ -201,7 +210,7 @@ extern "C" int read_debug_operand_probe(int mode, int blocks, int iters, float *
     return READ_OK;
 }
 
-// kind 0 / 1 = v_mfma_f32_32x32x2_f32 / v_mfma_f32_16x16x4_f32; filler type 0..4 (see issue_probe_kernel); K fillers per MFMA in
+// kind 0 / 1 / 2 = v_mfma_f32_32x32x2_f32 / v_mfma_f32_16x16x4_f32 / v_mfma_f32_16x16x32_bf16; filler type 0..4 (see issue_probe_kernel); K fillers per MFMA in
 // {0,1,2,3,4,6,8,12}; `blocks` workgroups of 4 waves; cycles[blocks * 4] receives every wave's s_memtime span; gsrc: 1 KiB.
 extern "C" int read_debug_issue_probe(int kind, int filler, int K, int blocks, int iters, float *scratch, unsigned long long *cycles,
                                       const float *gsrc, void *stream)
@@ -230,6 +239,15 @@ extern "C" int read_debug_issue_probe(int kind, int filler, int K, int blocks, i
         else if (filler == 6) rc = issue_probe_launch<1, 6>(K, blocks, scratch, cycles, iters, g, s);
         else if (filler == 7) rc = issue_probe_launch<1, 7>(K, blocks, scratch, cycles, iters, g, s);
         else if (filler == 8) rc = issue_probe_launch<1, 8>(K, blocks, scratch, cycles, iters, g, s);
+    }
+    else if (kind == 2) {
+        if (filler == 0) rc = issue_probe_launch<2, 0>(K, blocks, scratch, cycles, iters, g, s);
+        else if (filler == 1) rc = issue_probe_launch<2, 1>(K, blocks, scratch, cycles, iters, g, s);
+        else if (filler == 2) rc = issue_probe_launch<2, 2>(K, blocks, scratch, cycles, iters, g, s);
+        else if (filler == 4) rc = issue_probe_launch<2, 4>(K, blocks, scratch, cycles, iters, g, s);
+        else if (filler == 5) rc = issue_probe_launch<2, 5>(K, blocks, scratch, cycles, iters, g, s);
+        else if (filler == 7) rc = issue_probe_launch<2, 7>(K, blocks, scratch, cycles, iters, g, s);
+        else if (filler == 8) rc = issue_probe_launch<2, 8>(K, blocks, scratch, cycles, iters, g, s);
     }
     if (rc) { set_error("read_debug_issue_probe: unsupported kind / filler / K"); return READ_EINVAL; }
     READ_CHECK_LAUNCH();

@@ -23,7 +23,8 @@ FT = {0: "v_add indep", 1: "ds_read_b128", 2: "s_add", 3: "v_add chain", 4: "glo
 ONLY = [int(v) for v in os.environ.get("PROBE_FILLERS", "0,1,2,3,4,5,6,7,8").split(",")]
 res = []
 iters = 2000
-for kind in (0, 1):
+KINDS = [int(v) for v in os.environ.get("PROBE_KINDS", "0,1").split(",")]      # 2: v_mfma_f32_16x16x32_bf16 (round 5)
+for kind in KINDS:
     for wps in (1, 2):                      # waves per SIMD = workgroups per CU
         blocks = 256 * wps
         for ft in ONLY:
@@ -40,7 +41,7 @@ for kind in (0, 1):
                 ms = e0.elapsed_time(e1)
                 cyc = cycles[:blocks * 4].double()
                 per = float(cyc.mean()) / (iters * 16)          # s_memtime ticks per MFMA slot of ONE wave
-                row = {"mfma": "32x32x2" if kind == 0 else "16x16x4", "waves_per_simd": wps, "filler": FT[ft], "K": K, "ms": ms,
+                row = {"mfma": ("32x32x2", "16x16x4", "16x16x32_bf16")[kind], "waves_per_simd": wps, "filler": FT[ft], "K": K, "ms": ms,
                        "ticks_per_mfma_per_wave": per, "ticks_per_mfma_per_simd": per / wps,
                        "ns_per_mfma_per_simd": 1e6 * ms / (iters * 16 * wps)}
                 print(row, flush=True)
