@@ -140,6 +140,11 @@ int read_splat_forward_cells(const float *xyz, void *cells, int64_t n, const flo
                              int levels, int32_t *const *idx_levels, float *const *depth_levels,
                              void *workspace, size_t workspace_bytes, void *stream);
 
+/* Measurement aid for bench.py (roofline.mfma_sustained): one workgroup of four waves per CU, every wave `iters` rounds of 16 independent
+ * v_mfma_f32_16x16x4_f32 and nothing else.  scratch: >= 256 floats per CU on the device (never written); *flops receives the number of
+ * floating-point operations the launch executes — the caller times the launch on `stream`.  Not on the render path. */
+int read_mfma_f32_rate_probe(int iters, float *scratch, double *flops, void *stream);
+
 /* GL twin features of the rasteriser (READ/gl/programs.py:121-198, READ/gl/render.py:52-85, READ/gl/dataset.py:39-82,
  * READ/datasets/dynamic.py:235-239): ONE level of ONE camera rasterised at its own size W x H with
  *   point_size / relative / min_point_size   "pN" tokens: a square of N pixels; "psN" tokens (relative = 1): side

@@ -85,6 +85,7 @@ SIGNATURES = {
     "read_splat_forward_cells": (_i, [_vp, _vp, _i64, C.POINTER(_f), _i, _i, _i, _i, _pp, _pp, _vp, _sz, _vp]),
     "read_splat_hint_next_camera": (_i, [_vp, C.POINTER(_f)]),
     "read_splat_profile_last": (_i, [C.POINTER(_f)]),
+    "read_mfma_f32_rate_probe": (_i, [_i, _vp, C.POINTER(C.c_double), _vp]),
     "read_splat_forward_gl": (_i, [_vp, _i64, C.POINTER(_f), _i, _i, _vp, _vp, _vp, _vp, _sz, _vp]),
     "read_index_to_float": (_i, [_vp, _i64, _vp, _vp]),
     "read_splat_project_points": (_i, [_vp, _i64, C.POINTER(_f), _i, _i, _vp, _vp, _vp]),

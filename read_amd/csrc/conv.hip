@@ -3507,6 +3507,44 @@ extern "C" int read_gated_conv_forward(const read_conv_desc *desc, void *stream)
     return readhip::launch_gated_conv(desc, as_stream(stream));
 }
 
+// ---- measurement aid (bench.py: roofline.mfma_sustained): the rate the fp32 matrix path delivers when a wave does nothing else.
+// One workgroup of four waves per CU (one wave per SIMD, as the F(4x4) kernel runs), every wave `iters` rounds of 16 independent
+// v_mfma_f32_16x16x4_f32.  The guide's 157 TF peak is quoted at the 2.4 GHz boost clock; under matrix load the chip settles lower,
+// and the fraction of THAT rate is what says how much of the pipe a kernel leaves idle.
+namespace {
+__global__ __launch_bounds__(256, 1) void mfma_f32_rate_kernel(float *out, int iters)
+{
+    f32x4 acc[16];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+    float a0 = 0.37f + 0.001f * threadIdx.x, b0 = 1.0f - 0.002f * threadIdx.x;
+    for (int it = 0; it < iters; ++it) {
+#pragma unroll
+        for (int m = 0; m < 16; ++m) acc[m] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0, b0, acc[m], 0, 0, 0);
+        a0 = a0 * 0.999f + 0.0007f;
+        b0 = b0 * 1.0001f - 0.0001f;
+    }
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) s += acc[i][0] + acc[i][3];
+    if (s == 1234.5678f) out[blockIdx.x * 256 + threadIdx.x] = s;      // never true: keeps the accumulators live
+}
+}  // namespace
+
+extern "C" int read_mfma_f32_rate_probe(int iters, float *scratch, double *flops, void *stream)
+{
+    READ_CHECK_ARG(iters > 0 && scratch && flops, "read_mfma_f32_rate_probe: bad arguments");
+    int dev = 0, cus = 0;
+    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus < 1) {
+        readhip::set_error("read_mfma_f32_rate_probe: cannot query the device");
+        return READ_EHIP;
+    }
+    hipLaunchKernelGGL(mfma_f32_rate_kernel, dim3((unsigned)cus), dim3(256), 0, as_stream(stream), scratch, iters);
+    READ_CHECK_LAUNCH();
+    *flops = (double)cus * 4.0 * (double)iters * 16.0 * 2048.0;            // 16 x 16 x 4 x 2 flops per MFMA
+    return READ_OK;
+}
+
 extern "C" int read_bilinear_up4(const float *in, int inH, int inW, int C, float *out, void *stream)
 {
     READ_CHECK_ARG(in && out && inH >= 1 && inW >= 1, "read_bilinear_up4: null pointer or empty input");

@@ -61,6 +61,7 @@ def test_bad_arguments_fail_loudly():
     assert L.read_splat_profile_last(None) == -22
     buf = (C.c_float * 5)()
     assert L.read_splat_profile_last(buf) == -22 and b"splat_prof" in L.read_last_error()      # no profiled frame yet
+    assert L.read_mfma_f32_rate_probe(0, None, None, None) == -22 and b"read_mfma_f32_rate_probe" in L.read_last_error()
     with pytest.raises(_lib.ReadHipError):
         _lib.check(L.read_bilinear_up4(None, 4, 4, 8, None, None), "up4")
     d = _lib.ConvDesc()

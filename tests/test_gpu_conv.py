@@ -392,3 +392,26 @@ def test_wave_kernel_full_and_tail_units_at_frame_size(hip):
                 got = gated_conv(pk, [(x, 0)], elu=True, residual=res, config=names.index(name))
                 err = float((got - ref).abs().max())
                 assert err <= 1e-5, f"{name} at {W}x{H}x{c}: max diff {err:.3e}"
+
+
+@pytest.mark.gpu
+def test_mfma_rate_probe_reports_a_plausible_matrix_rate(hip):
+    """read_mfma_f32_rate_probe (bench.py: roofline.mfma_sustained): the launch's flop count is what its grid executes, and the rate it
+    measures lies between half of and the whole fp32 matrix peak of the guide (157 TF at 2.4 GHz; 146 measured)."""
+    import ctypes as C
+    from read_amd import _lib
+    L = _lib.lib()
+    scratch = torch.zeros(256 * 1024, dtype=torch.float32, device="cuda")
+    fl = C.c_double(0.0)
+    best = 0.0
+    for _ in range(3):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        _lib.check(L.read_mfma_f32_rate_probe(20000, scratch.data_ptr(), C.byref(fl), _lib.stream_ptr()), "read_mfma_f32_rate_probe")
+        e1.record()
+        e1.synchronize()
+        best = max(best, fl.value / (e0.elapsed_time(e1) * 1e-3) / 1e12)
+    cus = torch.cuda.get_device_properties(0).multi_processor_count
+    assert fl.value == cus * 4 * 20000 * 16 * 2048
+    assert 80.0 < best < 160.0, best
+    assert float(scratch.abs().max()) == 0.0                   # the probe writes nothing
