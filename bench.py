@@ -988,11 +988,10 @@ def main():
         # reads 94-99 us instead of 85-90 (measured in round 4: the rasteriser is latency / issue bound and follows the clock; the
         # F(4x4) figure does not move).  Medians of five batches: a late host (the CPU leg's OpenMP threads) cannot leak into them.
         ms_splat, ms_gather, ms_unet = stage_times(wl)
-        prof = None
-        for _ in range(3):
-            cur = wl.profile()
-            prof = cur if prof is None else [(l, m0 + m1, fl, c) for (l, m0, fl, c), (_, m1, _, _) in zip(prof, cur)]
-        prof = [(l, m / 3.0, fl, c) for (l, m, fl, c) in prof]
+        # per launch: the MEDIAN of five instrumented frames (event intervals around every launch) — one late launch in one pass
+        # (a host hiccup between two event records) moved the mean of three by 5 % in one of the round's runs
+        passes = [wl.profile() for _ in range(5)]
+        prof = [(l, float(np.median([p_[i][1] for p_ in passes])), fl, c) for i, (l, _, fl, c) in enumerate(passes[0])]
         c3_ms = sum(m for (_, m, _, c) in prof if c)
         c3_fl = sum(fl for (_, _, fl, c) in prof if c)
         n_c3 = sum(1 for (_, _, _, c) in prof if c)
