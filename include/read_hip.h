@@ -284,6 +284,13 @@ typedef struct read_conv_desc {
                                                1/16 of the pixels by a `linear` launch and enters here: no up-sampled tensor is ever
                                                written (READ/models/unet.py:261-262,269-270,277-278, the Convs.k inputs).  1x1 / stride-1
                                                layers on the pixel-lane kernel only (16-byte aligned tensors, Cin <= 256, Cout % 4 == 0) */
+    const void *wpacked_w4h;                /* optional: read_conv_pack_w4h_host() output (device): the Winograd F(4x4,3x3) operand split into
+                                               two f16 pieces per weight + one power-of-two scale per output row.  Gated (non-linear)
+                                               launches of the F(4x4) family with Cin % 32 == 0, Cin >= read_tuning("conv_w4h") (default
+                                               32, 0 = never) and Cout % 32 == 0 then run on the f16 matrix cores (v_mfma_f32_16x16x32_f16,
+                                               fp32 accumulation, three piece pairs per product: fp32-level results — DESIGN.md 3.3 (a+),
+                                               profiles/r6_f16split_probe.txt; transformed inputs must stay below 65504 in magnitude,
+                                               i.e. activations below ~650); config = -7 forces it where the shape fits */
 } read_conv_desc;
 
 /* Sizes (in floats) of the packed weight / parameter blocks of one BasicConv. */
@@ -304,6 +311,10 @@ int read_conv_pack_w16_host(int Cin, int Cout, const float *wf, const float *wm,
  * [group][wave][chunk of 16 cin][frequency 36][lane][4] */
 size_t read_conv_w4_floats(int Cin, int Cout);
 int read_conv_pack_w4_host(int Cin, int Cout, const float *wf, const float *wm, float *wpacked_w4_host);
+/* Split-operand F(4x4,3x3) operand (desc.wpacked_w4h): read_conv_w4h_floats(Cin, Cout) = Cin * 36 * 2 * pad32(Cout) + 2 * pad32(Cout)
+ * floats (0: Cin % 32 != 0) — [group][wave][chunk of 32 cin][frequency 36][piece hi | lo][lane][8 halfs], then 1 / scale per output row */
+size_t read_conv_w4h_floats(int Cin, int Cout);
+int read_conv_pack_w4h_host(int Cin, int Cout, const float *wf, const float *wm, void *wpacked_w4h_host);
 /* Small-Cout order [tap][cin][f0 f1 f2 f3 | m0 m1 m2 m3] (9 * Cin * 8 floats; 0 = the shape has no such order: only Cin = 32,
  * Cout <= 4 has a kernel). */
 size_t read_conv_sc_floats(int Cin, int Cout);
@@ -312,8 +323,9 @@ int read_conv_pack_params_host(int Cout, const float *bf, const float *bm, const
                                const float *beta, const float *mean, const float *var, float eps,
                                float *params_host);
 int read_gated_conv_forward(const read_conv_desc *desc, void *stream);
-/* Which kernel family read_gated_conv_forward takes for this (filled) descriptor under the current tuning knobs: 4 = Winograd
- * F(4x4,3x3) (reads wpacked_w4), 2 = Winograd F(2x2,3x3) (reads wpacked_wino), 1 = vector-pipe small-Cout kernel (reads
+/* Which kernel family read_gated_conv_forward takes for this (filled) descriptor under the current tuning knobs: 5 = Winograd
+ * F(4x4,3x3) with split operands on the f16 matrix cores (reads wpacked_w4h), 4 = Winograd F(4x4,3x3) on the fp32 matrix cores
+ * (reads wpacked_w4), 2 = Winograd F(2x2,3x3) (reads wpacked_wino), 1 = vector-pipe small-Cout kernel (reads
  * wpacked_sc), 0 = direct implicit GEMM (reads wpacked); -1 = NULL.  A host that packs ONE fragment order per layer asks this before packing (set the pointer it intends to fill to any
  * non-NULL value); a launch whose wpacked aliases Winograd fragments it would not read is refused with READ_EINVAL. */
 int read_conv_kernel_family(const read_conv_desc *desc);

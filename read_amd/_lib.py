@@ -35,6 +35,7 @@ class ConvDesc(C.Structure):
         ("pre_shift", C.c_int), ("preH", C.c_int), ("preW", C.c_int),
         ("out_gated", C.c_void_p), ("block_h", C.c_int), ("valid_h", C.c_int),
         ("wpacked_sc", C.c_void_p), ("pre_bilinear", C.c_int),
+        ("wpacked_w4h", C.c_void_p),
     ]
 
 
@@ -105,6 +106,8 @@ SIGNATURES = {
     "read_conv_pack_w16_host": (_i, [_i, _i, _vp, _vp, _vp]),
     "read_conv_w4_floats": (_sz, [_i, _i]),
     "read_conv_pack_w4_host": (_i, [_i, _i, _vp, _vp, _vp]),
+    "read_conv_w4h_floats": (_sz, [_i, _i]),
+    "read_conv_pack_w4h_host": (_i, [_i, _i, _vp, _vp, _vp]),
     "read_gated_conv_forward": (_i, [C.POINTER(ConvDesc), _vp]),
     "read_conv_kernel_family": (_i, [_vp]),
     "read_conv_sc_floats": (_sz, [_i, _i]),

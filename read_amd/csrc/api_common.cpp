@@ -15,7 +15,7 @@ void set_error(const char *fmt, ...)
 }  // namespace readhip
 
 extern "C" const char *read_last_error(void) { return readhip::g_err; }
-extern "C" int read_abi_version(void) { return 1; }
+extern "C" int read_abi_version(void) { return 2; }   // 2: read_conv_desc.wpacked_w4h (round 6)
 
 extern "C" int read_device_arch(char *name, int len)
 {
@@ -63,6 +63,7 @@ void conv_set_w16(int v);
 void conv_set_abl(int v);
 void conv_set_w4_grid(int v);
 void conv_set_w4(int v);
+void conv_set_w4h(int v);
 void conv_set_px(int v);
 void conv_set_sc(int v);
 void conv_set_w4x2(int v);
@@ -137,6 +138,7 @@ extern "C" int read_tuning_set(const char *key, int value)
     if (!strcmp(key, "conv_sc")) { readhip::conv_set_sc(value); return READ_OK; }             // vector-pipe kernel for Cout <= 4
     if (!strcmp(key, "conv_kc32")) { readhip::conv_set_kc32(value); return READ_OK; }
     if (!strcmp(key, "conv_w4_grid")) { readhip::conv_set_w4_grid(value); return READ_OK; }   // F(4x4): equal units per workgroup
+    if (!strcmp(key, "conv_w4h")) { readhip::conv_set_w4h(value); return READ_OK; }           // min Cin on the split-operand F(4x4) kernel (f16 matrix cores; 0 = off)
     if (!strcmp(key, "conv_w4")) { readhip::conv_set_w4(value); return READ_OK; }             // min Cin on the Winograd F(4x4,3x3) kernel (0 = off)
     if (!strcmp(key, "conv_w16")) { readhip::conv_set_w16(value); return READ_OK; }           // wave-autonomous Winograd kernel (0 = row-per-wave)
     if (!strcmp(key, "conv_wino")) { readhip::conv_set_wino(value); return READ_OK; }         // largest Cin on the Winograd kernel (0 = off)

@@ -42,6 +42,7 @@ struct ConvKArgs {
     const float *wp_wino;          // Winograd-transformed weights (read_conv_pack_wino_host) or null
     const float *wp_w16;           // the same weights in the order of the wave-autonomous kernel (read_conv_pack_w16_host) or null
     const float *wp_w4;            // Winograd F(4x4,3x3) weights (read_conv_pack_w4_host) or null
+    const void *wp_w4h;            // ... split into f16 piece pairs + row scales (read_conv_pack_w4h_host) or null
     const float *wp_sc;            // [tap][cin][f0..f3 | m0..m3] of a layer with at most four output channels (read_conv_pack_sc_host) or null
     const float *params;
     const float *residual;
@@ -1942,6 +1943,366 @@ __global__ __launch_bounds__(256, 1) void gated_conv_wino4_kernel(const ConvKArg
 }
 
 // ------------------------------------------------------------------------------------------
+// Winograd F(4x4,3x3) with SPLIT fp32 operands on the f16 matrix cores (round 6): v_mfma_f32_16x16x32_f16, fp32 accumulation.
+//
+// Why: the kernel above runs on v_mfma_f32_16x16x4_f32, the 157 TF path that shares the FP32 vector pipe (40 % of its peak); the
+// f16 / bf16 path is 16x faster per instruction-flop and overlaps with plain vector instructions (profiles/r5_issue_probe_bf16.md).
+// How the fp32 values get through an 11-bit significand: every operand is split into TWO f16 pieces
+//     V = Vh + 2^-11 Vl      Vh = f16(V),  Vl = f16((V - Vh) 2^11)        (input transform, per launch)
+//     U' = Uh + Ul           Uh = f16(U s), Ul = f16(U s - Uh)            (host packer; s = a power of two per output row that
+//                                                                          puts max |U s| in [2^14, 2^15): Ul stays a normal number)
+// and the product is the THREE largest piece pairs, summed by three MFMAs into one fp32 accumulator:
+//     U' V ~= (2^-11 Uh) Vl + Ul Vh + Uh Vh        (2^-11 Uh is formed in registers: v_pk_mul_f16, exact)
+// hi + lo carries 22 significant bits (2^-22 relative, RTN), the dropped pair is 2^-22 too; the matrix core sums a 32-channel block
+// before it rounds to fp32 once — measured ON the device against fp64 (tools/probes/f16split_probe.hip, profiles/r6_f16split_probe.txt):
+// relative rms error 0.9e-7 / 1.8e-7 / 3.1e-7 at K = 32 / 256 / 1024 against 1.1e-7 / 2.8e-7 / 5.9e-7 for the fp32 MFMA chain —
+// the split product is MORE accurate than the fp32 instruction it replaces, from |V| ~ 1e-4 up to the f16 overflow at |V| = 65504,
+// i.e. activations up to ~650 (B^T d B amplifies by at most 100); below ~1e-4 the absolute error floors at ~1e-11.
+// The scaled low piece is what makes it two pieces instead of three (bf16 x 3: six MFMAs, 1.5x the weight bytes).
+//
+// Shape: the unit, grid walk, weight ownership (wave w = output channels 8w .. 8w+7, rows 0..7 conv_f, 8..15 conv_m) and the
+// lane-local output transform / gate epilogue are the fp32 kernel's.  What differs:
+//   * chunk = 32 input channels = ONE MFMA k-block: 36 frequencies x 3 MFMAs per chunk and wave (fp32 kernel: 288 for 32 channels);
+//   * A operand: [group][wave][chunk][frequency][piece Uh | Ul][lane][8 halfs], lane (row = lane & 15, k = 8 (lane >> 4) ..+7):
+//     two 1 KiB buffer loads per frequency, eight frequencies ahead, ring of twelve; then 2 CoutPad floats 1 / s (f rows, m rows);
+//   * B operand: V[buffer 2][frequency 36][piece 2][tile 16][slot 4][8 halfs] in LDS = 147,456 bytes — ALL of the LDS budget, so
+//     the raw patches are not staged through LDS: transform thread (tile, channel PAIR) loads its 6 x 6 x 2 patch straight from
+//     L2 (36 buffer_load_dwordx2 with a per-lane offset table; pixels outside the image carry an out-of-range offset and arrive
+//     as zeros), one chunk ahead of its transform, into the registers the transform works in;
+//   * transform in packed fp32 over the channel pair (168 v_pk_*), split 5 instructions per frequency (v_cvt_pk_f16_f32,
+//     2 v_fma_mix_f32, v_pk_mul_f32, v_cvt_pk_f16_f32), one ds_write2st64_b32 per frequency (both pieces);
+//   * slot swizzle slot = q ^ ((-(tile >> 2)) & 3): the four 16-lane groups of ds_read_b128 ({0-3,12-15,20-27}, ...) each cover
+//     all 64 banks, and the 32-lane groups of the transform's stores cover the 32 store banks.
+struct Wino4hGeom {
+    static constexpr int VFREQ = 512;                          // dwords per frequency: 2 pieces x 16 tiles x 64 bytes
+    static constexpr int VBUF = 36 * VFREQ;                    // dwords per V buffer (73,728 bytes)
+    static constexpr int LDS_DWORDS = 2 * VBUF;                // 147,456 bytes
+};
+
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+
+template <bool MUL>
+__global__ __launch_bounds__(256, 1) void gated_conv_wino4h_kernel(const ConvKArgs a)
+{
+    using WG = Wino4hGeom;
+    __shared__ __attribute__((aligned(16))) unsigned lds[WG::LDS_DWORDS];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const SrcDev s = a.src[0];
+    const int groups = a.CoutPad >> 5, G = gridDim.x;
+    const int g = blockIdx.x % groups;
+    const int n = a.nchunks;                                   // 32-channel chunks
+
+    int by = (blockIdx.x / groups) / a.tiles_x, bx = (blockIdx.x / groups) % a.tiles_x;      // running unit (8 x 32 pixel block)
+    int pby = by, pbx = bx, pu = blockIdx.x, pchunk = 0;                                     // prefetch cursor (raw patches)
+    auto step_tile = [&](int &ty_, int &tx_) {
+        ty_ += a.wino_dby;
+        tx_ += a.wino_dbx;
+        if (tx_ >= a.tiles_x) {
+            tx_ -= a.tiles_x;
+            ++ty_;
+        }
+    };
+
+    // ---- transform role: thread = (tile tl, channel pair cp of the 32-channel chunk); wave w = tiles 4w .. 4w+3 (one tile row of
+    // the unit per wave: the patch ROWS are wave-uniform — their offsets travel in SGPRs — the patch COLUMNS are per lane)
+    const int cp = lane & 15, tl = wv * 4 + (lane >> 4);
+    constexpr unsigned OOR = 0x80000000u;
+    unsigned xoff[6];                                          // byte offset of patch column c, channel pair cp (a pixel row, chunk 0);
+                                                               // columns outside the image: out of range, the load returns zeros
+    int rowoff[6];                                             // byte offset of patch row r, clamped into the image ...
+    float rmask[6], rmask_d[6];                                // ... and 0 where it was clamped: rows of the cursor's unit / of the patch in d2
+    bool rclamp = false, rclamp_d = false;                     // any row clamped (top / bottom units only)
+    const unsigned src_bytes = (unsigned)(a.inH * s.W * s.C) * 4u;
+    const auto rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(s.p), 0, src_bytes, 0x00020000);
+    const auto rsrc_mul = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(MUL ? a.mul : s.p), 0, src_bytes, 0x00020000);
+    auto set_patch = [&]() {
+        const int y0 = pby * 8 + 4 * (wv >> 1) - 1, x0 = pbx * 32 + 4 * (tl & 7) - 1;
+        rclamp = false;
+#pragma unroll
+        for (int r = 0; r < 6; ++r) {
+            const int yy = y0 + r;
+            const bool ok = (unsigned)yy < (unsigned)a.inH;
+            const int yc = yy < 0 ? 0 : yy >= a.inH ? a.inH - 1 : yy;
+            rowoff[r] = yc * s.W * s.C * 4;
+            rmask[r] = ok ? 1.0f : 0.0f;
+            rclamp = rclamp || !ok;
+        }
+#pragma unroll
+        for (int c = 0; c < 6; ++c) xoff[c] = (unsigned)(x0 + c) < (unsigned)a.inW ? (unsigned)((x0 + c) * s.C + 2 * cp) * 4u : OOR;
+    };
+    auto advance = [&]() {
+#pragma unroll
+        for (int r = 0; r < 6; ++r) rmask_d[r] = rmask[r];     // the patch just loaded is the next one to be transformed
+        rclamp_d = rclamp;
+        if (++pchunk == n) {
+            pchunk = 0;
+            if (pu + G < a.n_units) {
+                pu += G;
+                step_tile(pby, pbx);
+            }
+            set_patch();
+        }
+    };
+    f32x2 d2[6][6];                                            // the patch of the chunk under transform: (channel 2 cp, 2 cp + 1)
+    f32x2 dm[MUL ? 6 : 1][MUL ? 6 : 1];
+    auto gload = [&](int r, int c) {
+        d2[r][c] = __builtin_bit_cast(f32x2, __builtin_amdgcn_raw_buffer_load_b64(rsrc, xoff[c], rowoff[r] + pchunk * 128, 0));
+        if constexpr (MUL) dm[r][c] = __builtin_bit_cast(f32x2, __builtin_amdgcn_raw_buffer_load_b64(rsrc_mul, xoff[c], rowoff[r] + pchunk * 128, 0));
+    };
+    // 1-D transform with B^T = [4 0 -5 0 1 0; 0 -4 -4 1 1 0; 0 4 -4 -1 1 0; 0 -2 -1 2 1 0; 0 2 -1 -2 1 0; 0 4 0 -5 0 1] on six
+    // channel pairs: 14 packed operations
+    auto bt6 = [](f32x2 &x0, f32x2 &x1, f32x2 &x2, f32x2 &x3, f32x2 &x4, f32x2 &x5) {
+        const f32x2 p = pk_add(x3, x4), q = pk_add(x1, x2), r = pk_sub(x4, x3), u = pk_sub(x1, x2), f = pk_sub(x3, x1), h = pk_sub(x4, x2);
+        const f32x2 y0 = __builtin_elementwise_fma(x2, f32x2{-5.0f, -5.0f}, __builtin_elementwise_fma(x0, f32x2{4.0f, 4.0f}, x4));
+        const f32x2 y5 = __builtin_elementwise_fma(x3, f32x2{-5.0f, -5.0f}, __builtin_elementwise_fma(x1, f32x2{4.0f, 4.0f}, x5));
+        x0 = y0;
+        x1 = __builtin_elementwise_fma(q, f32x2{-4.0f, -4.0f}, p);
+        x2 = __builtin_elementwise_fma(u, f32x2{4.0f, 4.0f}, r);
+        x3 = __builtin_elementwise_fma(f, f32x2{2.0f, 2.0f}, h);
+        x4 = __builtin_elementwise_fma(f, f32x2{-2.0f, -2.0f}, h);
+        x5 = y5;
+    };
+    // V store address (dwords) of this thread: + buffer + frequency * 512 (+ 256: the low piece)
+    const int vwoff = tl * 16 + (((cp >> 2) ^ ((-wv) & 3)) << 2) + (cp & 3);
+    auto split_store = [&](const f32x2 x, int vb, int fq) {
+        unsigned hi, lo;
+        float r0, r1;
+        asm("v_cvt_pk_f16_f32 %0, %1, %2" : "=v"(hi) : "v"(x.x), "v"(x.y));
+        asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel_hi:[1,0,0]" : "=v"(r0) : "v"(hi), "v"(x.x));                    // x - f32(hi), exact
+        asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(r1) : "v"(hi), "v"(x.y));
+        const f32x2 rs = f32x2{r0, r1} * f32x2{2048.0f, 2048.0f};
+        asm("v_cvt_pk_f16_f32 %0, %1, %2" : "=v"(lo) : "v"(rs.x), "v"(rs.y));
+        lds[vwoff + vb + fq * WG::VFREQ] = hi;
+        lds[vwoff + vb + fq * WG::VFREQ + 256] = lo;
+    };
+    // step k of a chunk's transform: 0..5 the column pass of column k; then per row r seven steps: the row pass, six
+    // frequencies (split + store); the row's registers are then refilled with the patch of the chunk after
+    constexpr int T_STEPS = 48;
+    auto t_step = [&](int vb, int k, bool reload) {
+        if (k < 6) {
+            if constexpr (MUL) {
+#pragma unroll
+                for (int r = 0; r < 6; ++r) d2[r][k] = d2[r][k] * dm[r][k];
+            }
+            if (rclamp_d) {                                    // wave-uniform: top / bottom units zero the rows outside the image
+#pragma unroll
+                for (int r = 0; r < 6; ++r) d2[r][k] = d2[r][k] * f32x2{rmask_d[r], rmask_d[r]};
+            }
+            bt6(d2[0][k], d2[1][k], d2[2][k], d2[3][k], d2[4][k], d2[5][k]);
+        } else {
+            const int r = (k - 6) / 7, j = (k - 6) % 7;
+            if (j == 0) bt6(d2[r][0], d2[r][1], d2[r][2], d2[r][3], d2[r][4], d2[r][5]);
+            else {
+                split_store(d2[r][j - 1], vb, r * 6 + j - 1);
+                if (j == 6 && reload) {
+#pragma unroll
+                    for (int c = 0; c < 6; ++c) gload(r, c);
+                }
+            }
+        }
+    };
+
+    // ---- A operand (weights)
+    const char *const wbase = reinterpret_cast<const char *>(a.wp_w4h) + ((size_t)(g * 4 + wv) * n) * (36 * 2048);
+    const auto wrsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<char *>(wbase), 0, (unsigned)n * (36 * 2048), 0x00020000);
+    const unsigned wvoff = lane * 16;
+    constexpr int RW = 9, WLEAD = 6;                           // ring of nine frequencies, fetched six ahead (36 % RW == 0: static slots)
+    u32x4 Wh[RW], Wl[RW];
+    f16x8 Ws[4];                                               // 2^-11 Uh, one frequency pair ahead
+    auto wload = [&](int slot, int chunk, int fq) {
+        Wh[slot] = __builtin_amdgcn_raw_buffer_load_b128(wrsrc, wvoff, (chunk * 36 + fq) * 2048, 0);
+        Wl[slot] = __builtin_amdgcn_raw_buffer_load_b128(wrsrc, wvoff, (chunk * 36 + fq) * 2048 + 1024, 0);
+    };
+    auto wscale = [&](int fq) {
+        const _Float16 k = (_Float16)0x1p-11f;
+        Ws[fq % 4] = __builtin_bit_cast(f16x8, Wh[fq % RW]) * f16x8{k, k, k, k, k, k, k, k};
+    };
+    // ---- B operand
+    const int t16 = lane & 15, kl = lane >> 4;
+    const int vrd = t16 * 16 + ((kl ^ ((-(t16 >> 2)) & 3)) << 2);
+    constexpr int RB = 4;                                      // ring of four frequencies, fetched one pair ahead
+    u32x4 Bh[RB], Bl[RB];
+    auto bload = [&](int slot, int vb, int fq) {
+        Bh[slot] = *reinterpret_cast<const u32x4 *>(__builtin_assume_aligned(lds + vb + fq * WG::VFREQ + vrd, 16));
+        Bl[slot] = *reinterpret_cast<const u32x4 *>(__builtin_assume_aligned(lds + vb + fq * WG::VFREQ + 256 + vrd, 16));
+    };
+
+    f32x4 acc[36];
+    const auto out_rsrc = __builtin_amdgcn_make_buffer_rsrc(a.out, 0, (unsigned)(a.outH * a.outW * a.out_cstride) * 4u, 0x00020000);
+    const auto res_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(a.residual ? a.residual : a.out), 0,
+                                                            (unsigned)(a.outH * a.outW * a.Cout) * 4u, 0x00020000);
+    const float *const wsc = reinterpret_cast<const float *>(a.wp_w4h) + (size_t)n * 2304 * a.CoutPad;       // 1 / s: [f | m][CoutPad]
+
+    // ---- prologue: patch(0) -> registers -> V(0); patch(1) -> registers; the first weight fragments and B operands
+    set_patch();
+#pragma unroll
+    for (int r = 0; r < 6; ++r)
+#pragma unroll
+        for (int c = 0; c < 6; ++c) gload(r, c);
+#pragma unroll
+    for (int j = 0; j < WLEAD; ++j) wload(j, 0, j);
+    advance();
+#pragma unroll
+    for (int k = 0; k < T_STEPS; ++k) t_step(0, k, true);
+    advance();
+    wscale(0);
+    wscale(1);
+    __syncthreads();
+    bload(0, 0, 0);
+    bload(1, 0, 1);
+
+    int v_cur = 0, v_nxt = WG::VBUF;
+    constexpr int BAR_M = 102;                                 // the stage's barrier: in front of the first MFMA of frequency pair 17
+
+    // One stage = one 32-channel chunk: 108 MFMAs (18 frequency pairs x 3 piece pairs x 2); beside them the transform of
+    // chunk + 1 (registers -> v_nxt) and the loads of patch(chunk + 2) into the registers the transform leaves behind.
+    auto stage_body = [&](auto first_tag, int chunk) {
+        constexpr bool FIRST = decltype(first_tag)::value;
+        int nchunk = chunk + 1;                                       // wraps into the next unit (same weights)
+        nchunk = nchunk == n ? 0 : nchunk;
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int pr = 0; pr < 18; ++pr)
+#pragma unroll
+            for (int j = 0; j < 6; ++j) {
+                const int fq = 2 * pr + (j & 1), pc = j >> 1, m = pr * 6 + j;
+                if (m == BAR_M) {
+                    // V(chunk + 1) is complete in every wave (last store at slot 94) and every wave has fetched its last B
+                    // operand of this chunk (slot 97); the first B operands of the next chunk travel under the last six MFMAs
+                    __syncthreads();
+                }
+                const f16x8 av = pc == 0 ? Ws[fq % 4] : __builtin_bit_cast(f16x8, pc == 1 ? Wl[fq % RW] : Wh[fq % RW]);
+                const f16x8 bv = __builtin_bit_cast(f16x8, pc == 0 ? Bl[fq % RB] : Bh[fq % RB]);
+                if (FIRST && pc == 0) {
+                    const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+                    acc[fq] = __builtin_amdgcn_mfma_f32_16x16x32_f16(av, bv, zero, 0, 0, 0);
+                } else
+                    acc[fq] = __builtin_amdgcn_mfma_f32_16x16x32_f16(av, bv, acc[fq], 0, 0, 0);
+                // ---- shadow items
+                if (j < 2) {                                                         // B operands one frequency pair ahead
+                    const int bf = 2 * pr + 2 + j;
+                    if (bf < 36) bload(bf % RB, v_cur, bf);
+                    else bload(bf % RB, v_nxt, bf - 36);
+                } else if (j < 4) {                                                  // weights WLEAD frequencies ahead
+                    const int wf = 2 * pr + WLEAD + (j - 2);
+                    if (wf < 36) wload(wf % RW, chunk, wf);
+                    else wload(wf % RW, nchunk, wf - 36);
+                } else
+                    wscale((2 * pr + 2 + (j - 4)) % 36);                              // 2^-11 Uh of the next frequency pair
+                if (!(m & 1) && (m >> 1) < T_STEPS) t_step(v_nxt, m >> 1, true);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        advance();
+        const int v = v_cur;
+        v_cur = v_nxt;
+        v_nxt = v;
+    };
+
+    for (int u = blockIdx.x; u < a.n_units; u += G) {
+        stage_body(std::true_type{}, 0);
+        for (int chunk = 1; chunk < n; ++chunk) stage_body(std::false_type{}, chunk);
+
+        // ================= unit epilogue (lane-local; the fp32 kernel's, with the rows' 1 / s folded into the bias FMAs) =================
+        __builtin_amdgcn_s_setprio(1);
+        const int cq = (lane >> 4) & 1, hf = lane >> 5;
+        const int c0 = g * 32 + wv * 8 + 4 * cq;
+        const int oy = by * 8 + 4 * (t16 >> 3) + 2 * hf, ox = bx * 32 + 4 * (t16 & 7);           // this lane finishes rows oy, oy + 1
+        const f32x4 bf = *reinterpret_cast<const f32x4 *>(a.params + c0);
+        const f32x4 bm = *reinterpret_cast<const f32x4 *>(a.params + a.CoutPad + c0);
+        const f32x4 sc = *reinterpret_cast<const f32x4 *>(a.params + 2 * a.CoutPad + c0);
+        const f32x4 sh = *reinterpret_cast<const f32x4 *>(a.params + 3 * a.CoutPad + c0);
+        const f32x4 isf = *reinterpret_cast<const f32x4 *>(wsc + c0);
+        constexpr float LOG2E = 1.44269504088896341f;
+        const f32x4 ism = *reinterpret_cast<const f32x4 *>(wsc + a.CoutPad + c0) * -LOG2E;
+        const f32x4 bml = bm * -LOG2E;
+        unsigned rvoff[2][4], ovoff[2][4];
+#pragma unroll
+        for (int py = 0; py < 2; ++py)
+#pragma unroll
+            for (int px = 0; px < 4; ++px) {
+                const bool in = (oy + py < a.outH) & (ox + px < a.outW) & (c0 < a.Cout);
+                const int pix = (oy + py) * a.outW + ox + px;
+                rvoff[py][px] = in ? (unsigned)((pix * a.Cout + c0) * 4) : OOR;
+                ovoff[py][px] = in ? (unsigned)((pix * a.out_cstride + c0) * 4) : OOR;
+            }
+        f32x4 rv[2][4];
+#pragma unroll
+        for (int py = 0; py < 2; ++py)
+#pragma unroll
+            for (int px = 0; px < 4; ++px) {
+                rv[py][px] = f32x4{0.f, 0.f, 0.f, 0.f};
+                if (a.residual)
+                    rv[py][px] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(res_rsrc, rvoff[py][px], 0, 0));
+            }
+        f32x4 Y[4][4];
+        {
+            f32x4 R[4][6];
+#pragma unroll
+            for (int nu = 0; nu < 6; ++nu) {
+                const f32x4 s1 = acc[6 + nu] + acc[12 + nu], d1 = pk_sub4(acc[6 + nu], acc[12 + nu]);
+                const f32x4 s2 = acc[18 + nu] + acc[24 + nu], dd2 = pk_sub4(acc[18 + nu], acc[24 + nu]);
+                R[0][nu] = acc[nu] + s1 + s2;
+                R[1][nu] = d1 + 2.0f * dd2;
+                R[2][nu] = s1 + 4.0f * s2;
+                R[3][nu] = d1 + 8.0f * dd2 + acc[30 + nu];
+            }
+#pragma unroll
+            for (int p = 0; p < 4; ++p) {
+                const f32x4 s1 = R[p][1] + R[p][2], d1 = pk_sub4(R[p][1], R[p][2]);
+                const f32x4 s2 = R[p][3] + R[p][4], dd2 = pk_sub4(R[p][3], R[p][4]);
+                Y[p][0] = R[p][0] + s1 + s2;
+                Y[p][1] = d1 + 2.0f * dd2;
+                Y[p][2] = s1 + 4.0f * s2;
+                Y[p][3] = d1 + 8.0f * dd2 + R[p][5];
+            }
+        }
+        f32x4 Yf[2][4], Ym[2][4];
+#pragma unroll
+        for (int py = 0; py < 2; ++py)
+#pragma unroll
+            for (int px = 0; px < 4; ++px) {
+                u32x4 u0 = __builtin_bit_cast(u32x4, Y[py][px]), u1 = __builtin_bit_cast(u32x4, Y[py + 2][px]);
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const auto sw = __builtin_amdgcn_permlane32_swap(u0[k], u1[k], false, false);
+                    u0[k] = sw[0];
+                    u1[k] = sw[1];
+                }
+                Yf[py][px] = __builtin_bit_cast(f32x4, u0);
+                Ym[py][px] = __builtin_bit_cast(f32x4, u1);
+            }
+#pragma unroll
+        for (int py = 0; py < 2; ++py)
+#pragma unroll
+            for (int px = 0; px < 4; ++px) {
+                f32x4 f = __builtin_elementwise_fma(Yf[py][px], isf, bf);
+                const f32x4 mm = __builtin_elementwise_fma(Ym[py][px], ism, bml);
+                if (a.elu) {
+                    const f32x4 fe = f * LOG2E;
+                    f32x4 e;
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) e[k] = __builtin_amdgcn_exp2f(fe[k]);
+                    e = e + f32x4{-1.0f, -1.0f, -1.0f, -1.0f};
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) f[k] = f[k] > 0.0f ? f[k] : e[k];
+                }
+                f32x4 sg, t;
+#pragma unroll
+                for (int k = 0; k < 4; ++k) t[k] = __builtin_amdgcn_exp2f(mm[k]);
+                t = t + f32x4{1.0f, 1.0f, 1.0f, 1.0f};
+#pragma unroll
+                for (int k = 0; k < 4; ++k) sg[k] = __builtin_amdgcn_rcpf(t[k]);
+                const f32x4 v = (f * sg) * sc + sh + rv[py][px];
+                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), out_rsrc, ovoff[py][px], 0, 0);
+            }
+        step_tile(by, bx);
+        __builtin_amdgcn_s_setprio(0);
+    }
+}
+
+// ------------------------------------------------------------------------------------------
 // NEGATIVE RESULT, kept in the DEBUG library only (-DREAD_DEBUG_KNOBS, read_tuning_set("conv_w4x2", 1)): the F(4x4,3x3) kernel
 // above cut for TWO waves per SIMD.  Why it was tried (DESIGN.md 12.1 d): one wave per SIMD issues a vector instruction every
 // 5.2 cycles, two waves one every 2.6 (tools/valu_probe.py), and a VALU instruction behind an fp32 MFMA costs 4 - 11.5 cycles with
@@ -2768,6 +3129,8 @@ int g_use_wino = 1 << 30;  // read_tuning_set("conv_wino", max Cin): Winograd ke
 int g_w4_grid = 0;        // read_tuning_set("conv_w4_grid", 1): F(4x4) launches with the same number of units per workgroup (measured: see profiles)
 int g_w4x2 = 0;            // debug library only: read_tuning_set("conv_w4x2", 1) = the two-waves-per-SIMD F(4x4) kernel (measured slower, round 5)
 int g_w4 = 32;             // read_tuning_set("conv_w4", min Cin): layers with at least this many channels take the Winograd F(4x4,3x3)
+int g_w4h = 32;            // read_tuning_set("conv_w4h", min Cin): F(4x4) layers with Cin % 32 == 0 and at least this many channels take the split-operand
+                           // kernel on the f16 matrix cores when its operand was supplied (0 = never: the fp32 kernel)
 int g_sc = 8;              // read_tuning_set("conv_sc", 0): the output layer (Cout <= 4) back on the F(2x2) MFMA kernel instead of the vector pipe; other values: conv_set_sc
                            // kernel when its weights were supplied (0 = never)
 int g_abl = 0;             // read_tuning_set("conv_abl", bits): attribution probes of the 16x16x4 Winograd kernels (results invalid); -DREAD_DEBUG_KNOBS builds only
@@ -3002,6 +3365,99 @@ extern "C" int read_conv_pack_w4_host(int Cin, int Cout, const float *wf, const 
     return READ_OK;
 }
 
+// F(4x4,3x3) operand of the split-operand kernel (gated_conv_wino4h_kernel): U = G g G^T in double, scaled per output ROW by the
+// power of two s that puts max |U s| of the row in [2^14, 2^15), cut into Uh = f16(U s) and Ul = f16(U s - Uh) (round to nearest
+// even, both); order [group][wave 4][chunk of 32 cin][frequency 36][piece Uh | Ul][lane][8 halfs], lane (i = lane & 15, kq = lane >> 4)
+// = rows as in read_conv_pack_w4_host, cin = 32 chunk + 8 kq + e; then 2 * CoutPad floats 1 / s ([conv_f rows | conv_m rows]).
+// Sized in floats like every block of a packed blob: Cin * 36 * 2 * CoutPad (the halfs) + 2 * CoutPad.   (tests/wino4h_ref.py)
+extern "C" size_t read_conv_w4h_floats(int Cin, int Cout)
+{
+    if (Cin < 32 || Cin % 32 || Cout < 1) return 0;
+    return (size_t)Cin * 36 * 2 * pad32(Cout) + 2 * (size_t)pad32(Cout);
+}
+
+namespace {
+// double -> IEEE binary16, round to nearest even, subnormals kept (the values are far inside the range: |x| < 2^15)
+unsigned short f16_bits_rtn(double x)
+{
+    const unsigned short sign = std::signbit(x) ? 0x8000u : 0u;
+    double ax = std::fabs(x);
+    if (ax == 0.0) return sign;
+    if (ax >= 65520.0) return (unsigned short)(sign | 0x7c00u);
+    int e;
+    (void)std::frexp(ax, &e);                                  // ax = f 2^e, f in [0.5, 1)
+    int ex = e - 1;                                            // ax = 1.m x 2^ex
+    if (ex < -14) ex = -14;                                    // subnormal: fixed quantum 2^-24
+    const double q = std::ldexp(1.0, ex - 10);                 // quantum of the 11-bit significand
+    const double r = std::nearbyint(ax / q);                   // ties to even (default rounding mode)
+    const double v = r * q;                                    // may have carried into the next binade: recompute the fields
+    if (v >= 65520.0) return (unsigned short)(sign | 0x7c00u);
+    if (v < std::ldexp(1.0, -14)) return (unsigned short)(sign | (unsigned short)std::lrint(v / std::ldexp(1.0, -24)));
+    int e2;
+    (void)std::frexp(v, &e2);
+    const int ex2 = e2 - 1;
+    const unsigned mant = (unsigned)std::lrint(v / std::ldexp(1.0, ex2 - 10)) - 1024u;
+    return (unsigned short)(sign | (unsigned)((ex2 + 15) << 10) | mant);
+}
+double f16_value(unsigned short h)
+{
+    const int e = (h >> 10) & 31, m = h & 1023;
+    const double v = e == 0 ? std::ldexp((double)m, -24) : std::ldexp((double)(1024 + m), e - 25);
+    return (h & 0x8000u) ? -v : v;
+}
+}  // namespace
+
+extern "C" int read_conv_pack_w4h_host(int Cin, int Cout, const float *wf, const float *wm, void *out)
+{
+    READ_CHECK_ARG(wf && wm && out, "read_conv_pack_w4h_host: null pointer");
+    READ_CHECK_ARG(Cin >= 32 && Cin % 32 == 0 && Cout >= 1, "read_conv_pack_w4h_host: needs Cin %% 32 == 0 (got %d)", Cin);
+    static const double G[6][3] = {{0.25, 0.0, 0.0}, {-1.0 / 6, -1.0 / 6, -1.0 / 6}, {-1.0 / 6, 1.0 / 6, -1.0 / 6},
+                                   {1.0 / 24, 1.0 / 12, 1.0 / 6}, {1.0 / 24, -1.0 / 12, 1.0 / 6}, {0.0, 0.0, 1.0}};
+    const int CoutPad = pad32(Cout), nchunks = Cin / 32;
+    unsigned short *h = static_cast<unsigned short *>(out);
+    float *inv = reinterpret_cast<float *>(out) + (size_t)Cin * 36 * 2 * CoutPad;
+    std::vector<double> U((size_t)36 * Cin);
+    for (int row = 0; row < 2 * CoutPad; ++row) {               // row = [f | m] x padded output channel
+        const int fm = row / CoutPad, co = row % CoutPad;
+        double mx = 0.0;
+        if (co < Cout)
+            for (int ci = 0; ci < Cin; ++ci) {
+                const float *k = (fm ? wm : wf) + ((size_t)co * Cin + ci) * 9;
+                for (int fq = 0; fq < 36; ++fq) {
+                    double u = 0.0;
+                    for (int a = 0; a < 3; ++a)
+                        for (int b = 0; b < 3; ++b) u += G[fq / 6][a] * (double)k[a * 3 + b] * G[fq % 6][b];
+                    U[(size_t)fq * Cin + ci] = u;
+                    mx = std::fmax(mx, std::fabs(u));
+                }
+            }
+        else
+            std::fill(U.begin(), U.end(), 0.0);
+        int ex = 0;                                            // s = 2^ex: max |U| s in [2^14, 2^15)
+        if (mx > 0.0 && std::isfinite(mx)) {
+            int e;
+            (void)std::frexp(mx, &e);                          // mx in [2^(e-1), 2^e)
+            ex = 15 - e;
+            if (ex > 60) ex = 60;                              // a row of denormal weights: keep 1 / s an fp32 normal
+            if (ex < -60) ex = -60;
+        }
+        inv[row] = (float)std::ldexp(1.0, -ex);
+        const int g = co / 32, w = (co % 32) / 8, i = (co % 8) + 8 * fm;
+        for (int c = 0; c < nchunks; ++c)
+            for (int fq = 0; fq < 36; ++fq)
+                for (int kq = 0; kq < 4; ++kq)
+                    for (int e = 0; e < 8; ++e) {
+                        const double us = std::ldexp(U[(size_t)fq * Cin + 32 * c + 8 * kq + e], ex);
+                        const unsigned short hi = f16_bits_rtn(us), lo = f16_bits_rtn(us - f16_value(hi));
+                        const size_t frag = ((((size_t)(g * 4 + w) * nchunks + c) * 36 + fq) * 2) * 512;   // halfs; 512 per piece
+                        const int lane = i + 16 * kq;
+                        h[frag + (size_t)lane * 8 + e] = hi;
+                        h[frag + 512 + (size_t)lane * 8 + e] = lo;
+                    }
+    }
+    return READ_OK;
+}
+
 // Small-Cout order (gated_conv_smallc_kernel): [tap][cin][f0 f1 f2 f3 | m0 m1 m2 m3], channels >= Cout zero.
 extern "C" size_t read_conv_sc_floats(int Cin, int Cout)
 {
@@ -3050,6 +3506,7 @@ void conv_set_kc32(int v) { g_kc32 = v; }
 void conv_set_w16(int v) { g_w16 = v != 0; }
 void conv_set_abl(int v) { g_abl = v; }
 void conv_set_w4(int v) { g_w4 = v < 0 ? 0 : v; }
+void conv_set_w4h(int v) { g_w4h = v < 0 ? 0 : v; }
 void conv_set_w4_grid(int v) { g_w4_grid = v != 0; }
 void conv_set_wino_wgs(int v) { g_wino_wgs = v <= 1 ? 1 : 2; }
 void conv_set_px(int v) { g_conv_px = v < 0 ? 0 : v > 4 ? 4 : v; }
@@ -3069,6 +3526,7 @@ int conv_get(const char *key, int *value)
     else if (!strcmp(key, "conv_wino")) *value = g_use_wino;
     else if (!strcmp(key, "conv_w16")) *value = g_w16;
     else if (!strcmp(key, "conv_w4")) *value = g_w4;
+    else if (!strcmp(key, "conv_w4h")) *value = g_w4h;
     else if (!strcmp(key, "conv_w4_grid")) *value = g_w4_grid;
 #ifdef READ_DEBUG_KNOBS
     else if (!strcmp(key, "conv_ablate")) *value = g_ablate;
@@ -3090,6 +3548,7 @@ void conv_set_trace(void *buf, size_t bytes)
 // entry point and the UNet executor.
 int conv_uses_wino(const read_conv_desc *d);
 int conv_uses_w4(const read_conv_desc *d);
+int conv_uses_w4h(const read_conv_desc *d);
 int conv_uses_sc(const read_conv_desc *d);
 
 int launch_gated_conv(const read_conv_desc *d, hipStream_t stream)
@@ -3100,7 +3559,7 @@ int launch_gated_conv(const read_conv_desc *d, hipStream_t stream)
     READ_CHECK_ARG(d->ksize == 1 || d->ksize == 3 || d->ksize == 4, "read_gated_conv_forward: ksize must be 1,3,4");
     READ_CHECK_ARG(d->stride == 1 || d->stride == 2, "read_gated_conv_forward: stride must be 1 or 2");
     READ_CHECK_ARG(d->inH >= 1 && d->inW >= 1 && d->Cout >= 1, "read_gated_conv_forward: bad sizes");
-    READ_CHECK_ARG((d->wpacked || d->wpacked_w4 || d->wpacked_wino) && d->params && d->out, "read_gated_conv_forward: null weights/params/out");
+    READ_CHECK_ARG((d->wpacked || d->wpacked_w4 || d->wpacked_w4h || d->wpacked_wino) && d->params && d->out, "read_gated_conv_forward: null weights/params/out");
     READ_CHECK_ARG(d->out_cstride >= (d->linear ? 2 : 1) * d->Cout, "read_gated_conv_forward: out_cstride too small");
     READ_CHECK_ARG(!d->linear || (!d->residual && !d->fill_pad), "read_gated_conv_forward: linear mode takes no residual / fill");
     READ_CHECK_ARG(!d->mul || d->n_src == 1, "read_gated_conv_forward: mul needs a single source");
@@ -3111,12 +3570,12 @@ int launch_gated_conv(const read_conv_desc *d, hipStream_t stream)
         // (the lean UNet blob) must never reach a kernel that reads wpacked as the direct order — a tuning knob changed on a
         // live engine, a 2 GiB tensor or an odd out_cstride can decline the Winograd kernels after the host has packed for them.
         // Checked HERE, for both entry points (read_gated_conv_forward and the UNet executor's direct call).
-        const int family = conv_uses_sc(d) ? 1 : conv_uses_w4(d) ? 4 : conv_uses_wino(d) ? 2 : 0;
+        const int family = conv_uses_sc(d) ? 1 : conv_uses_w4h(d) ? 5 : conv_uses_w4(d) ? 4 : conv_uses_wino(d) ? 2 : 0;
         const bool cfg_wino = d->config >= 0 && d->config < N_CONFIGS && g_configs[d->config].wino;   // forced F(2x2) configs read wpacked_wino
         const bool w16_forced = d->config == -3;
         READ_CHECK_ARG(d->wpacked || family != 0 || cfg_wino || w16_forced,
                        "read_gated_conv_forward: this launch takes a direct kernel and wpacked is NULL (fragment order not packed)");
-        READ_CHECK_ARG(!d->wpacked || (!((const void *)d->wpacked == (const void *)d->wpacked_w4 && family != 4) &&
+        READ_CHECK_ARG(!d->wpacked || (!((const void *)d->wpacked == (const void *)d->wpacked_w4 && family != 4 && family != 5) &&
                                        !((const void *)d->wpacked == (const void *)d->wpacked_wino && family != 2 && !cfg_wino)),
                        "read_gated_conv_forward: wpacked aliases Winograd fragments but the launch takes kernel family %d "
                        "(ask read_conv_kernel_family before packing)", family);
@@ -3376,9 +3835,12 @@ int launch_gated_conv(const read_conv_desc *d, hipStream_t stream)
     }
     conv_fn fn = c.fn;
     // Winograd F(4x4,3x3): units of 8 x 32 pixels x 32 channels, one persistent workgroup per CU
-    if (conv_uses_w4(d)) {
-        READ_CHECK_ARG((uintptr_t)d->wpacked_w4 % 16 == 0, "read_gated_conv_forward: wpacked_w4 misaligned");
+    const bool w4h = conv_uses_w4h(d);
+    if (w4h || conv_uses_w4(d)) {
+        READ_CHECK_ARG((uintptr_t)(w4h ? d->wpacked_w4h : (const void *)d->wpacked_w4) % 16 == 0, "read_gated_conv_forward: wpacked_w4 / wpacked_w4h misaligned");
         READ_CHECK_ARG(!d->mul || (uintptr_t)d->mul % 16 == 0, "read_gated_conv_forward: mul misaligned");
+        a.wp_w4h = d->wpacked_w4h;
+        if (w4h) a.nchunks = Cin / 32;
         a.tiles_x = ceil_div(outW, 32);
         a.n_units = a.tiles_x * ceil_div(outH, 8) * groups;
         static int n_cu_4 = 0;
@@ -3419,6 +3881,7 @@ int launch_gated_conv(const read_conv_desc *d, hipStream_t stream)
             return READ_OK;
         }
 #endif
+        if (w4h) fn4 = d->mul ? gated_conv_wino4h_kernel<true> : gated_conv_wino4h_kernel<false>;
         hipLaunchKernelGGL(fn4, dim3((unsigned)nwg), dim3(256), 0, stream, a);
         READ_CHECK_LAUNCH();
         return READ_OK;
@@ -3471,6 +3934,23 @@ int conv_uses_w4(const read_conv_desc *d)
     return shape && (d->config == -5 || (d->config == -1 && g_w4 > 0 && d->src[0].C >= g_w4));
 }
 
+// ... on the f16 matrix cores with split operands: the gated (non-linear) launches of that family with whole 32-channel chunks whose
+// split operand was supplied (config -7 forces it; the training path's linear launches stay on the fp32 kernel)
+int conv_uses_w4h(const read_conv_desc *d)
+{
+    if (!d->wpacked_w4h || d->linear || d->src[0].C % 32 != 0 || d->Cout % 32 != 0) return 0;
+    if (d->config == -7) {
+        read_conv_desc t = *d;
+        t.config = -5;
+        t.wpacked_w4 = reinterpret_cast<const float *>(d->wpacked_w4h);    // the shape test of the family (any non-null operand)
+        return conv_uses_w4(&t);
+    }
+    if (d->config != -1 || g_w4h <= 0 || d->src[0].C < g_w4h) return 0;
+    read_conv_desc t = *d;
+    t.wpacked_w4 = reinterpret_cast<const float *>(d->wpacked_w4h);
+    return conv_uses_w4(&t);
+}
+
 // gated 3x3 / stride-1 layers with at most four output channels and 32 input channels (READ's output layer)
 int conv_uses_sc(const read_conv_desc *d)
 {
@@ -3495,6 +3975,7 @@ extern "C" int read_conv_kernel_family(const read_conv_desc *desc)
 {
     if (!desc) return -1;
     if (readhip::conv_uses_sc(desc)) return 1;
+    if (readhip::conv_uses_w4h(desc)) return 5;
     if (readhip::conv_uses_w4(desc)) return 4;
     if (readhip::conv_uses_wino(desc)) return 2;
     return 0;

@@ -105,6 +105,41 @@ def test_winograd_f4_kernel(hip):
         _close(got, ref, f"FAM through F(4x4) C={c}", scale=10.0)
 
 
+def test_winograd_f4_split_operand_kernel(hip):
+    """Winograd F(4x4,3x3) with split fp32 operands on the f16 matrix cores (config -7; round 6): the same shapes, the same oracle
+    and the SAME tolerance as the fp32-matrix-core kernel above — two f16 pieces per operand, three piece pairs per product, fp32
+    accumulation (profiles/r6_f16split_probe.txt: more accurate than the fp32 MFMA chain) — plus: agreement with that kernel to
+    a quarter of the tolerance, top / bottom / left / right border units, several units per workgroup, ELU on / off, FAM."""
+    from read_amd import _lib
+    torch.manual_seed(21)
+    fam = _lib.lib().read_conv_kernel_family
+    for j, (c, H, W) in enumerate([(128, 9, 17), (256, 8, 32), (128, 23, 70), (32, 5, 3), (64, 40, 100), (128, 88, 304), (256, 44, 152),
+                                   (96, 14, 37), (160, 3, 65), (32, 64, 96), (64, 1, 1), (32, 41, 130)]):
+        st = _state(c, c, 3, seed=500 + j)
+        x = torch.randn(c, H, W)
+        res = torch.randn(c, H, W)
+        ref = unet_torch.basic_conv(st, "L", x[None], 3, elu=j % 2 == 0)[0] + res
+        pk = _pack(st, [c])
+        assert pk.wpacked_w4h is not None
+        got = gated_conv(pk, [(_nhwc(x), 0)], elu=j % 2 == 0, residual=_nhwc(res), config=-7)
+        _close(got, ref, f"split-operand F(4x4) {c}->{c} {H}x{W}", scale=10.0)
+        f32 = gated_conv(pk, [(_nhwc(x), 0)], elu=j % 2 == 0, residual=_nhwc(res), config=-5)
+        _close(got, f32.cpu().permute(2, 0, 1), f"split-operand vs fp32 F(4x4) {c}->{c} {H}x{W}", scale=2.5)
+    for c in (64, 128, 256):                               # FAM: x1 + BC(x1 * x2) through the automatic choice
+        x1, x2 = torch.randn(c, 12, 40), torch.randn(c, 12, 40)
+        st = _state(c, c, 3, seed=c + 7)
+        ref = x1 + unet_torch.basic_conv(st, "L", (x1 * x2)[None], 3, elu=False)[0]
+        got = gated_conv(_pack(st, [c]), [(_nhwc(x1), 0)], elu=False, mul=_nhwc(x2), residual=_nhwc(x1), config=-7)
+        _close(got, ref, f"FAM through the split-operand F(4x4) C={c}", scale=10.0)
+    # a wide dynamic range: activations of 1e-3 and of 300 (transformed inputs up to ~3e4, below the f16 limit of 65504)
+    for amp in (1e-3, 300.0):
+        st = _state(64, 64, 3, seed=77)
+        x = torch.randn(64, 24, 40) * amp
+        ref = unet_torch.basic_conv(st, "L", x[None], 3, elu=True)[0]
+        got = gated_conv(_pack(st, [64]), [(_nhwc(x), 0)], elu=True, config=-7)
+        _close(got, ref, f"split-operand F(4x4), activations x {amp}", scale=10.0 * max(1.0, amp))
+
+
 @pytest.mark.skipif(os.environ.get("READ_AMD_TEST_W4X2") != "1" or os.environ.get("READ_HIP_DEBUG") != "1",
                     reason="the two-waves-per-SIMD F(4x4) kernel was measured slower in round 5 (profiles/r5_w4x2_ab.json) and is "
                            "compiled into the debug library only; READ_HIP_DEBUG=1 READ_AMD_TEST_W4X2=1 runs its parity test")

@@ -1,0 +1,71 @@
+"""A/B of the F(4x4) kernels on the four dominant C->C shapes at 1216x352 (run on the GPU box): fp32 matrix cores (config -5)
+against split operands on the f16 matrix cores (config -7), both against the torch-fp32 oracle on the CPU.
+
+    python tools/w4h_ab.py [--iters 20] [--check 1] [--out gpurun_out/r6_w4h_ab.json]
+"""
+import argparse
+import json
+import os
+import sys
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from oracle import unet_torch                                   # noqa: E402  (checker only)
+from read_amd import synthetic                                  # noqa: E402
+from read_amd.gated_conv import PackedGatedConv, gated_conv     # noqa: E402
+
+H, W = 352, 1216
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--iters", type=int, default=20)
+    ap.add_argument("--check", type=int, default=1)
+    ap.add_argument("--out", default="")
+    ap.add_argument("--levels", default="0,1,2,3")
+    a = ap.parse_args()
+    res = {}
+    torch.manual_seed(0)
+    for lvl in [int(v) for v in a.levels.split(",")]:
+        c = 32 << lvl
+        h, w = H >> lvl, W >> lvl
+        st = synthetic.make_unet_state([("L", c, c, 3)], 1)
+        b = "L.block."
+        pk = PackedGatedConv(st[b + "conv_f.weight"], st[b + "conv_f.bias"], st[b + "conv_m.weight"], st[b + "conv_m.bias"],
+                             st[b + "norm.weight"], st[b + "norm.bias"], st[b + "norm.running_mean"], st[b + "norm.running_var"],
+                             src_channels=[c])
+        xc, rc = torch.randn(c, h, w), torch.randn(c, h, w)
+        x, r = xc.permute(1, 2, 0).contiguous().cuda(), rc.permute(1, 2, 0).contiguous().cuda()
+        out = torch.empty(h, w, c, device="cuda")
+        ref = None
+        if a.check:
+            with torch.no_grad():
+                ref = (unet_torch.basic_conv(st, "L", xc[None], 3, elu=True)[0] + rc).permute(1, 2, 0)
+        for name, cfg in (("fp32", -5), ("f16x3", -7)):
+            for _ in range(3):
+                gated_conv(pk, [(x, 0)], elu=True, residual=r, config=cfg, out=out)
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(a.iters):
+                gated_conv(pk, [(x, 0)], elu=True, residual=r, config=cfg, out=out)
+            e1.record()
+            e1.synchronize()
+            us = e0.elapsed_time(e1) / a.iters * 1e3
+            line = f"C={c:3d} {h}x{w} {name:6s} {us:8.2f} us"
+            rec = {"us": us}
+            if ref is not None:
+                d = (out.cpu() - ref)
+                mse = float((d.double() ** 2).mean())
+                rec["max_abs"] = float(d.abs().max())
+                rec["psnr_db"] = 10.0 * torch.log10(ref.abs().max().double() ** 2 / mse).item()
+                line += f"   max |diff| vs torch fp32 {rec['max_abs']:.3e}   {rec['psnr_db']:.1f} dB"
+            res[f"C{c} {name}"] = rec
+            print(line, flush=True)
+    if a.out:
+        with open(a.out, "w") as fh:
+            json.dump(res, fh, indent=1)
+
+
+if __name__ == "__main__":
+    main()
