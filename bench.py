@@ -936,12 +936,63 @@ def also_records(a, dev, wl, first=None):
     return rec
 
 
+def self_launch(a):
+    """`python bench.py --gpus N` with N > 1 and no launcher around it (WORLD_SIZE unset): start the N ranks ourselves — the same
+    argv under `python -m torch.distributed.run --nnodes=1 --nproc-per-node N` on 127.0.0.1 and a free port — and hand their exit
+    code on.  Rank 0's JSON line reaches stdout through the inherited descriptor; the launcher's own chatter goes to stderr.
+    (The reference drives all GPUs from one process, train.py:138-139: its user never types a launcher either.)"""
+    import socket
+    import subprocess
+    with socket.socket() as so:
+        so.bind(("127.0.0.1", 0))
+        port = so.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", str(max(1, (os.cpu_count() or 8) // a.gpus)))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={a.gpus}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    print("bench.py: --gpus %d without a launcher: starting %s" % (a.gpus, " ".join(cmd[1:9])), file=sys.stderr, flush=True)
+    return subprocess.call(cmd, env=env)
+
+
+def stub_main(a, world, rank):
+    """READ_BENCH_STUB=1: the launch / rendezvous / timing / one-JSON-line skeleton of main() with a stub renderer on the gloo
+    backend (no GPU): what tests/test_bench_launch.py runs through the self-launch path at world size 2."""
+    dist.init_process_group("gloo")
+    frame = torch.full((8, 8, 4), float(rank))
+    gathered = [torch.empty_like(frame) for _ in range(world)]
+    for _ in range(a.warmup):
+        dist.all_gather(gathered, frame)
+    dist.barrier()
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        dist.all_gather(gathered, frame)
+    dist.barrier()
+    dt = torch.tensor([time.perf_counter() - t0], dtype=torch.float64)
+    dist.all_reduce(dt, op=dist.ReduceOp.MAX)
+    ok = all(float(g[0, 0, 0]) == float(r) for r, g in enumerate(gathered))
+    flags = [None] * world
+    dist.all_gather_object(flags, bool(ok))
+    if rank == 0:
+        print(json.dumps({"metric": "stub frames/sec (launcher self-test, no renderer)", "value": a.steps * world / float(dt), "unit": "frames/s",
+                          "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": float(dt) / a.steps * 1e3,
+                          "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "stub",
+                          "config": {"workload": "stub"}, "verified_ranks": flags}), flush=True)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
 def main():
     a = parse()
+    if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(self_launch(a))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
-    assert world == a.gpus, f"--gpus {a.gpus} but WORLD_SIZE={world}"
+    assert world == a.gpus, f"--gpus {a.gpus} but WORLD_SIZE={world} (launch N ranks with --gpus N, or give --gpus N alone: bench.py starts them)"
+    if os.environ.get("READ_BENCH_STUB") == "1":
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        return stub_main(a, world, rank)
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     if a.tune:

@@ -1982,7 +1982,10 @@ struct Wino4hGeom {
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
 
-template <bool MUL>
+// ABL (attribution probes, results invalid; -DREAD_DEBUG_KNOBS builds only, read_tuning_set("conv_abl")): 1 no transform arithmetic,
+// 2 no split arithmetic, 4 no V stores, 8 no patch loads, 32 weights loaded once, 64 B operands loaded once, 128 no epilogue,
+// 256 no barrier, 512 no 2^-11 Uh products, 1024 no MFMAs, 2048 / 4096 patch / weight loads from one cache-resident address
+template <bool MUL, int ABL = 0>
 __global__ __launch_bounds__(256, 1) void gated_conv_wino4h_kernel(const ConvKArgs a)
 {
     using WG = Wino4hGeom;
@@ -2048,6 +2051,11 @@ __global__ __launch_bounds__(256, 1) void gated_conv_wino4h_kernel(const ConvKAr
     f32x2 d2[6][6];                                            // the patch of the chunk under transform: (channel 2 cp, 2 cp + 1)
     f32x2 dm[MUL ? 6 : 1][MUL ? 6 : 1];
     auto gload = [&](int r, int c) {
+        if (ABL & 8) return;
+        if (ABL & 2048) {                                      // every patch load from the tensor's first 128 bytes: the instruction without its miss
+            d2[r][c] = __builtin_bit_cast(f32x2, __builtin_amdgcn_raw_buffer_load_b64(rsrc, cp * 8u, 0, 0));
+            return;
+        }
         d2[r][c] = __builtin_bit_cast(f32x2, __builtin_amdgcn_raw_buffer_load_b64(rsrc, xoff[c], rowoff[r] + pchunk * 128, 0));
         if constexpr (MUL) dm[r][c] = __builtin_bit_cast(f32x2, __builtin_amdgcn_raw_buffer_load_b64(rsrc_mul, xoff[c], rowoff[r] + pchunk * 128, 0));
     };
@@ -2069,11 +2077,22 @@ __global__ __launch_bounds__(256, 1) void gated_conv_wino4h_kernel(const ConvKAr
     auto split_store = [&](const f32x2 x, int vb, int fq) {
         unsigned hi, lo;
         float r0, r1;
+        if (ABL & 2) {
+            if (!(ABL & 4)) {
+                lds[vwoff + vb + fq * WG::VFREQ] = __builtin_bit_cast(unsigned, x.x);
+                lds[vwoff + vb + fq * WG::VFREQ + 256] = __builtin_bit_cast(unsigned, x.y);
+            }
+            return;
+        }
         asm("v_cvt_pk_f16_f32 %0, %1, %2" : "=v"(hi) : "v"(x.x), "v"(x.y));
         asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel_hi:[1,0,0]" : "=v"(r0) : "v"(hi), "v"(x.x));                    // x - f32(hi), exact
         asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(r1) : "v"(hi), "v"(x.y));
         const f32x2 rs = f32x2{r0, r1} * f32x2{2048.0f, 2048.0f};
         asm("v_cvt_pk_f16_f32 %0, %1, %2" : "=v"(lo) : "v"(rs.x), "v"(rs.y));
+        if (ABL & 4) {
+            asm volatile("" :: "v"(hi), "v"(lo));
+            return;
+        }
         lds[vwoff + vb + fq * WG::VFREQ] = hi;
         lds[vwoff + vb + fq * WG::VFREQ + 256] = lo;
     };
@@ -2090,10 +2109,12 @@ __global__ __launch_bounds__(256, 1) void gated_conv_wino4h_kernel(const ConvKAr
 #pragma unroll
                 for (int r = 0; r < 6; ++r) d2[r][k] = d2[r][k] * f32x2{rmask_d[r], rmask_d[r]};
             }
-            bt6(d2[0][k], d2[1][k], d2[2][k], d2[3][k], d2[4][k], d2[5][k]);
+            if (!(ABL & 1)) bt6(d2[0][k], d2[1][k], d2[2][k], d2[3][k], d2[4][k], d2[5][k]);
         } else {
             const int r = (k - 6) / 7, j = (k - 6) % 7;
-            if (j == 0) bt6(d2[r][0], d2[r][1], d2[r][2], d2[r][3], d2[r][4], d2[r][5]);
+            if (j == 0) {
+                if (!(ABL & 1)) bt6(d2[r][0], d2[r][1], d2[r][2], d2[r][3], d2[r][4], d2[r][5]);
+            }
             else {
                 split_store(d2[r][j - 1], vb, r * 6 + j - 1);
                 if (j == 6 && reload) {
@@ -2112,6 +2133,11 @@ __global__ __launch_bounds__(256, 1) void gated_conv_wino4h_kernel(const ConvKAr
     u32x4 Wh[RW], Wl[RW];
     f16x8 Ws[4];                                               // 2^-11 Uh, one frequency pair ahead
     auto wload = [&](int slot, int chunk, int fq) {
+        if (ABL & 4096) {                                      // every weight load from one 2 KiB fragment: the instruction without its L2 traffic
+            Wh[slot] = __builtin_amdgcn_raw_buffer_load_b128(wrsrc, wvoff, 0, 0);
+            Wl[slot] = __builtin_amdgcn_raw_buffer_load_b128(wrsrc, wvoff, 1024, 0);
+            return;
+        }
         Wh[slot] = __builtin_amdgcn_raw_buffer_load_b128(wrsrc, wvoff, (chunk * 36 + fq) * 2048, 0);
         Wl[slot] = __builtin_amdgcn_raw_buffer_load_b128(wrsrc, wvoff, (chunk * 36 + fq) * 2048 + 1024, 0);
     };
@@ -2168,14 +2194,17 @@ __global__ __launch_bounds__(256, 1) void gated_conv_wino4h_kernel(const ConvKAr
 #pragma unroll
             for (int j = 0; j < 6; ++j) {
                 const int fq = 2 * pr + (j & 1), pc = j >> 1, m = pr * 6 + j;
-                if (m == BAR_M) {
+                if (m == BAR_M && !(ABL & 256)) {
                     // V(chunk + 1) is complete in every wave (last store at slot 94) and every wave has fetched its last B
                     // operand of this chunk (slot 97); the first B operands of the next chunk travel under the last six MFMAs
                     __syncthreads();
                 }
                 const f16x8 av = pc == 0 ? Ws[fq % 4] : __builtin_bit_cast(f16x8, pc == 1 ? Wl[fq % RW] : Wh[fq % RW]);
                 const f16x8 bv = __builtin_bit_cast(f16x8, pc == 0 ? Bl[fq % RB] : Bh[fq % RB]);
-                if (FIRST && pc == 0) {
+                if (ABL & 1024) {
+                    if (FIRST && pc == 0) acc[fq] = f32x4{0.f, 0.f, 0.f, 0.f};
+                    if (pc == 2) asm volatile("" :: "v"(av), "v"(bv));
+                } else if (FIRST && pc == 0) {
                     const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
                     acc[fq] = __builtin_amdgcn_mfma_f32_16x16x32_f16(av, bv, zero, 0, 0, 0);
                 } else
@@ -2183,13 +2212,15 @@ __global__ __launch_bounds__(256, 1) void gated_conv_wino4h_kernel(const ConvKAr
                 // ---- shadow items
                 if (j < 2) {                                                         // B operands one frequency pair ahead
                     const int bf = 2 * pr + 2 + j;
-                    if (bf < 36) bload(bf % RB, v_cur, bf);
+                    if (ABL & 64) {
+                    } else if (bf < 36) bload(bf % RB, v_cur, bf);
                     else bload(bf % RB, v_nxt, bf - 36);
                 } else if (j < 4) {                                                  // weights WLEAD frequencies ahead
                     const int wf = 2 * pr + WLEAD + (j - 2);
-                    if (wf < 36) wload(wf % RW, chunk, wf);
+                    if (ABL & 32) {
+                    } else if (wf < 36) wload(wf % RW, chunk, wf);
                     else wload(wf % RW, nchunk, wf - 36);
-                } else
+                } else if (!(ABL & 512))
                     wscale((2 * pr + 2 + (j - 4)) % 36);                              // 2^-11 Uh of the next frequency pair
                 if (!(m & 1) && (m >> 1) < T_STEPS) t_step(v_nxt, m >> 1, true);
                 __builtin_amdgcn_sched_barrier(0);
@@ -2209,6 +2240,15 @@ __global__ __launch_bounds__(256, 1) void gated_conv_wino4h_kernel(const ConvKAr
         const int cq = (lane >> 4) & 1, hf = lane >> 5;
         const int c0 = g * 32 + wv * 8 + 4 * cq;
         const int oy = by * 8 + 4 * (t16 >> 3) + 2 * hf, ox = bx * 32 + 4 * (t16 & 7);           // this lane finishes rows oy, oy + 1
+        if (ABL & 128) {                                               // keep the accumulators live with one store per lane
+            f32x4 sum = acc[0];
+#pragma unroll
+            for (int i = 1; i < 36; ++i) sum += acc[i];
+            if (oy < a.outH && ox < a.outW) *reinterpret_cast<f32x4 *>(a.out + ((size_t)oy * a.outW + ox) * a.out_cstride + c0) = sum;
+            step_tile(by, bx);
+            __builtin_amdgcn_s_setprio(0);
+            continue;
+        }
         const f32x4 bf = *reinterpret_cast<const f32x4 *>(a.params + c0);
         const f32x4 bm = *reinterpret_cast<const f32x4 *>(a.params + a.CoutPad + c0);
         const f32x4 sc = *reinterpret_cast<const f32x4 *>(a.params + 2 * a.CoutPad + c0);
@@ -2299,6 +2339,12 @@ __global__ __launch_bounds__(256, 1) void gated_conv_wino4h_kernel(const ConvKAr
             }
         step_tile(by, bx);
         __builtin_amdgcn_s_setprio(0);
+    }
+    if (ABL && a.nchunks == -12345) {                                  // never true: keeps the probes' dead values alive
+        float sink = 0.f;
+#pragma unroll
+        for (int i = 0; i < 36; ++i) sink += d2[i / 6][i % 6].x + d2[i / 6][i % 6].y;
+        a.out[tid] = sink;
     }
 }
 
@@ -3882,6 +3928,17 @@ int launch_gated_conv(const read_conv_desc *d, hipStream_t stream)
         }
 #endif
         if (w4h) fn4 = d->mul ? gated_conv_wino4h_kernel<true> : gated_conv_wino4h_kernel<false>;
+#ifdef READ_DEBUG_KNOBS
+        if (w4h && !d->mul && g_abl) {
+            switch (g_abl) {
+#define READ_ABL_CASE(n) case n: fn4 = gated_conv_wino4h_kernel<false, n>; break;
+            READ_ABL_CASE(1) READ_ABL_CASE(2) READ_ABL_CASE(3) READ_ABL_CASE(4) READ_ABL_CASE(7) READ_ABL_CASE(8) READ_ABL_CASE(15) READ_ABL_CASE(32) READ_ABL_CASE(64)
+            READ_ABL_CASE(128) READ_ABL_CASE(256) READ_ABL_CASE(512) READ_ABL_CASE(1024) READ_ABL_CASE(1007) READ_ABL_CASE(2047 - 1024) READ_ABL_CASE(544) READ_ABL_CASE(2048) READ_ABL_CASE(4096) READ_ABL_CASE(6144) READ_ABL_CASE(40)
+#undef READ_ABL_CASE
+            default: break;
+            }
+        }
+#endif
         hipLaunchKernelGGL(fn4, dim3((unsigned)nwg), dim3(256), 0, stream, a);
         READ_CHECK_LAUNCH();
         return READ_OK;

@@ -51,9 +51,14 @@ class GradientArena:
         for p in self.params:
             offs.append(n)
             n += (p.numel() + 63) // 64 * 64                  # 256-byte slices (fp32)
-        self.flat = torch.zeros(n, dtype=dt, device=dev)
+        # tail: one word per parameter, 1 where this rank HAS a gradient — summed by the same all-reduce, so that a parameter
+        # without a gradient on EVERY rank keeps p.grad = None (Adam / weight decay skip it, as under nn.DataParallel)
+        self.tail = n
+        self.flat = torch.zeros(n + (len(self.params) + 63) // 64 * 64, dtype=dt, device=dev)
         self.views = [self.flat[o:o + p.numel()].view_as(p) for o, p in zip(offs, self.params)]
+        self.flags = self.flat[n:n + len(self.params)]
         self.pending = None
+        self._none = []
 
     @property
     def nbytes(self):
@@ -66,6 +71,10 @@ class GradientArena:
             torch._foreach_copy_([v for v, _ in have], [g for _, g in have])
         if none:
             torch._foreach_zero_(none)
+        self._none = [i for i, p in enumerate(self.params) if p.grad is None]
+        self.flags.fill_(1.0)
+        if self._none:
+            self.flags[torch.tensor(self._none, device=self.flags.device)] = 0.0
 
     def reduce(self, async_op=False):
         """Mean over the ranks of every gradient; ``p.grad`` then aliases the arena.  async_op: returns after the collective is
@@ -81,9 +90,15 @@ class GradientArena:
         if self.pending is not None:
             self.pending.wait()
             self.pending = None
-            self.flat.mul_(1.0 / w)
-        for v, p in zip(self.views, self.params):
-            p.grad = v
+            self.flat[:self.tail].mul_(1.0 / w)
+        # only a parameter without a gradient HERE can be without one everywhere: the common step (every gradient present) reads
+        # nothing back; the rare one costs one small device-to-host copy
+        absent = set()
+        if self._none:
+            got = self.flags[torch.tensor(self._none, device=self.flags.device)].tolist()
+            absent = {i for i, f in zip(self._none, got) if f == 0.0}
+        for i, (v, p) in enumerate(zip(self.views, self.params)):
+            p.grad = None if i in absent else v
 
 
 def exchange_pairs(ids, rows, group=None):
@@ -132,6 +147,21 @@ def sync_buffers(module, src=0, group=None):
         o += b.numel()
 
 
+def broadcast_textures(textures, src=0, group=None):
+    """Every replica's descriptor table := rank `src`'s (one broadcast per table, at construction only).  The per-step exchange
+    keeps the replicas bit-identical only if they START identical: a random init with per-rank seeds, or a checkpoint loaded on
+    one rank, would otherwise diverge silently — each rank applying the same gathered gradient to different rows."""
+    if not _on(group):
+        return
+    for tex in textures:
+        if hasattr(tex, 'sync_texture'):
+            tex.sync_texture()                                 # rows stepped by the sparse optimizer -> texture_
+        dist.broadcast(tex.texture_.data, src, group=group)
+        if hasattr(tex, '_rows'):
+            tex._rows = None                                   # the (N, C) row cache is rebuilt from the received table
+            tex._rows_version = None
+
+
 def broadcast_parameters(module, src=0, group=None):
     """Make every replica start from rank `src`'s weights (one flat broadcast)."""
     if not _on(group):
@@ -154,14 +184,18 @@ class DataParallelStep:
         pipeline.optimizer.step(); extra_optimizer.step()
 
     ``textures``: the PointTexture modules in sparse-training mode; their queued (ids, rows) pairs are replaced by the gathered,
-    scaled pairs of all ranks, which ``SparseDescriptorRMSprop.step()`` then consumes unchanged."""
+    scaled pairs of all ranks, which ``SparseDescriptorRMSprop.step()`` then consumes unchanged.  At construction rank 0's
+    parameters, buffers AND descriptor tables are broadcast (``broadcast=False``: the caller vouches the replicas are identical);
+    with the net in ``.train()`` mode ``reduce()`` also re-broadcasts rank 0's BatchNorm statistics every step."""
 
     def __init__(self, net, textures=(), group=None, broadcast=True):
         # pipeline.textures is {dataset id: PointTexture} (READ/pipelines/ogl.py:82-97): a mapping gives its values
         self.net, self.textures, self.group = net, list(textures.values() if hasattr(textures, 'values') else textures), group
         self.arena = GradientArena(net.parameters(), group)
-        if broadcast:
+        if broadcast:                                    # as torch DDP at construction: parameters, buffers — and the descriptor tables
             broadcast_parameters(net, 0, group)
+            sync_buffers(net, 0, group)
+            broadcast_textures(self.textures, 0, group)
 
     def reduce(self):
         self.arena.reduce(async_op=True)                 # the 121 MB ring all-reduce is on the wire ...
@@ -175,3 +209,5 @@ class DataParallelStep:
             if ids.numel():
                 tex._pending.append((ids, rows))
         self.arena.wait()
+        if self.net.training:                            # BatchNorm running statistics follow rank 0's (nn.DataParallel: replica 0 owns the buffers)
+            sync_buffers(self.net, 0, self.group)

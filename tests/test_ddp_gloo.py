@@ -135,3 +135,55 @@ def test_single_process_is_the_identity():
     # ids survive the bit-cast through the fp32 payload column for the whole int32 range used (< 2^31)
     big = torch.tensor([0, 1, 2 ** 24 + 1, 2 ** 30 + 12345, 2 ** 31 - 1], dtype=torch.int32)
     assert torch.equal(big.view(torch.float32).view(torch.int32), big)
+
+
+def _worker_diverged(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        net = _net(seed=rank)                                       # different weights AND different BatchNorm statistics per rank
+        net[1].running_mean.fill_(float(rank + 1))
+        unused = torch.nn.Parameter(torch.full((3,), float(rank)))   # a parameter no loss ever reaches
+        net.register_parameter("unused", unused)
+        tex = _Tex(8)
+        tex.texture_ = torch.full((1, 8, 50), float(10 + rank))      # per-rank descriptor tables (a 'rand' init with per-rank seeds)
+        tex._rows = "stale"
+        step = ddp.DataParallelStep(net, [tex])
+        start = (tex.texture_.clone(), net[1].running_mean.clone(), unused.detach().clone(), tex._rows)
+        net.train()
+        x, y = _data()
+        xs, ys = x[2 * rank:2 * rank + 2], y[2 * rank:2 * rank + 2]
+        opt = torch.optim.Adam(net.parameters(), lr=0.1, weight_decay=0.1)
+        for it in range(2):
+            torch.nn.functional.huber_loss(net(xs), ys).backward()
+            step.reduce()
+            assert unused.grad is None, "a parameter without a gradient on every rank must stay without one"
+            opt.step()
+            opt.zero_grad()
+        q.put((rank, [t.numpy().copy() if torch.is_tensor(t) else t for t in start], net[1].running_mean.numpy().copy(),
+               net[1].running_var.numpy().copy(), unused.detach().numpy().copy()))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_replicas_that_start_apart_are_brought_together():
+    """the constructor broadcasts rank 0's descriptor tables and buffers as well as the weights (replicas that
+    start from per-rank random textures would otherwise diverge for good); in .train() mode reduce() keeps the BatchNorm
+    statistics on rank 0's; a parameter without a gradient on every rank keeps grad = None (Adam / weight decay leave it alone)."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker_diverged, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    got = sorted([q.get(timeout=180) for _ in procs], key=lambda t: t[0])
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for rank, start, mean, var, unused in got:
+        assert np.all(start[0] == 10.0), f"rank {rank}: descriptor table is not rank 0's"
+        assert np.all(start[1] == 1.0), f"rank {rank}: BatchNorm buffer is not rank 0's"
+        assert np.all(start[2] == 0.0) and start[3] is None          # the unused parameter was broadcast too; the row cache dropped
+        assert np.all(unused == 0.0), "weight decay moved a parameter that has no gradient anywhere"
+    assert np.array_equal(got[0][2], got[1][2]) and np.array_equal(got[0][3], got[1][3])     # running statistics: one trajectory
+    assert not np.all(got[0][2] == 1.0)                              # ... and it did move

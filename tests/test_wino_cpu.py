@@ -88,3 +88,47 @@ def test_winograd_f4_model_and_packer():
     got = np.empty(n, np.float32)
     assert L.read_conv_pack_w4_host(cin, cout, wf.ctypes.data, wm.ctypes.data, got.ctypes.data) == 0
     np.testing.assert_allclose(got, packed, rtol=1e-6, atol=1e-7)
+
+
+def test_split_operand_f4_model_and_packer():
+    """Split-operand F(4x4,3x3) on the f16 matrix cores: the kernel's lane maps and piece arithmetic (tests/wino4h_ref.py) against
+    conv2d at the fp32 kernel's tolerance, the library's host packer against the model's BIT FOR BIT (halfs and row scales), and
+    the properties the arithmetic rests on: max |U s| in [2^14, 2^15), hi + lo = U s to 2^-22, the swizzle bank-conflict free."""
+    from read_amd import _lib
+    from tests.wino4h_ref import filter_transform4_f64, pack_w4h, pack_w4h_blob, row_scale_exp, wino4h_conv_model
+    rng = np.random.default_rng(6)
+    cin, cout, H, W = 64, 40, 11, 40                      # two 32-channel chunks, padded cout, ragged 8 x 32 blocks
+    wf = rng.standard_normal((cout, cin, 3, 3)).astype(np.float32) * 0.2
+    wm = rng.standard_normal((cout, cin, 3, 3)).astype(np.float32) * 0.05
+    wm[3] = 0.0                                           # an all-zero row keeps scale 1
+    x = rng.standard_normal((H, W, cin)).astype(np.float32)
+    halfs, inv = pack_w4h(wf, wm)
+    f, m = wino4h_conv_model(x, halfs, inv, cin, cout)
+    xt = torch.from_numpy(x).permute(2, 0, 1)[None]
+    rf = F.conv2d(xt, torch.from_numpy(wf), padding=1)[0].permute(1, 2, 0).numpy()
+    rm = F.conv2d(xt, torch.from_numpy(wm), padding=1)[0].permute(1, 2, 0).numpy()
+    np.testing.assert_allclose(f, rf, rtol=1e-4, atol=1e-4)          # (the fp32 model: 2e-4; what is left is the fp32 round-off of the transforms)
+    np.testing.assert_allclose(m, rm, rtol=1e-4, atol=1e-4)
+    L = _lib.lib()
+    n = L.read_conv_w4h_floats(cin, cout)
+    blob = pack_w4h_blob(wf, wm)
+    assert n == blob.size and L.read_conv_w4h_floats(48, 32) == 0     # whole 32-channel chunks only
+    got = np.zeros(n, np.float32)
+    assert L.read_conv_pack_w4h_host(cin, cout, wf.ctypes.data, wm.ctypes.data, got.ctypes.data) == 0
+    assert np.array_equal(got.view(np.uint32), blob.view(np.uint32)), "library packer != model packer"
+    U = filter_transform4_f64(wf)
+    ex = row_scale_exp(U)
+    top = np.abs(np.ldexp(U, ex[None, None, None, :])).max(axis=(0, 1, 2))
+    assert np.all((top >= 2.0 ** 14) & (top < 2.0 ** 15))
+    Us = np.ldexp(U, ex[None, None, None, :])
+    hi = Us.astype(np.float16).astype(np.float64)
+    lo = (Us - hi).astype(np.float16).astype(np.float64)
+    assert np.abs(hi + lo - Us).max() <= 2.0 ** -22 * 2.0 ** 15
+    assert inv[1, 3] == 1.0 and inv[0, 0] == np.float32(2.0 ** -float(ex[0]))
+    # ds_read_b128 is served in four 16-lane groups, each must touch 16 different 16-byte slots of a 256-byte bank row
+    lanes = np.arange(64)
+    t, kl = lanes & 15, lanes >> 4
+    addr16 = t * 4 + (kl ^ ((-(t >> 2)) & 3))             # 16-byte units inside one (frequency, piece) block
+    for grp in ([0, 1, 2, 3, 12, 13, 14, 15, 20, 21, 22, 23, 24, 25, 26, 27], [4, 5, 6, 7, 8, 9, 10, 11, 16, 17, 18, 19, 28, 29, 30, 31]):
+        for half in (0, 32):
+            assert len({int(addr16[l + half]) % 16 for l in grp}) == 16

@@ -24,6 +24,7 @@ def main():
     ap.add_argument("--check", type=int, default=1)
     ap.add_argument("--out", default="")
     ap.add_argument("--levels", default="0,1,2,3")
+    ap.add_argument("--abl", default="", help="comma list of conv_abl probe values for the split-operand kernel (READ_HIP_DEBUG=1; results invalid)")
     a = ap.parse_args()
     res = {}
     torch.manual_seed(0)
@@ -62,6 +63,22 @@ def main():
                 line += f"   max |diff| vs torch fp32 {rec['max_abs']:.3e}   {rec['psnr_db']:.1f} dB"
             res[f"C{c} {name}"] = rec
             print(line, flush=True)
+        if a.abl:
+            from read_amd import _lib
+            for v in [int(t) for t in a.abl.split(",")]:
+                _lib.check(_lib.lib().read_tuning_set(b"conv_abl", v))
+                for _ in range(3):
+                    gated_conv(pk, [(x, 0)], elu=True, residual=r, config=-7, out=out)
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                for _ in range(a.iters):
+                    gated_conv(pk, [(x, 0)], elu=True, residual=r, config=-7, out=out)
+                e1.record()
+                e1.synchronize()
+                us = e0.elapsed_time(e1) / a.iters * 1e3
+                res[f"C{c} f16x3 abl {v}"] = {"us": us}
+                print(f"C={c:3d} f16x3 probe {v:5d} {us:8.2f} us", flush=True)
+            _lib.check(_lib.lib().read_tuning_set(b"conv_abl", 0))
     if a.out:
         with open(a.out, "w") as fh:
             json.dump(res, fh, indent=1)
