@@ -9,6 +9,8 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 # READ_HIP_DEBUG=1: the -DREAD_DEBUG_KNOBS build (attribution probes for tools/; python -m read_amd.build --debug)
 LIB_PATH = os.path.join(_HERE, "libreadhip_debug.so" if os.environ.get("READ_HIP_DEBUG") else "libreadhip.so")
+if os.environ.get("READ_HIP_VARIANT"):            # tools only: an A/B build of the same sources (tools/w4h_ab.py)
+    LIB_PATH = os.path.join(_HERE, "libreadhip_v_%s.so" % os.environ["READ_HIP_VARIANT"])
 
 READ_MAX_LEVELS = 5
 READ_CONV_MAX_SRC = 4

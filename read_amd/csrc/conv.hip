@@ -1971,6 +1971,7 @@ __global__ __launch_bounds__(256, 1) void gated_conv_wino4_kernel(const ConvKArg
 //     as zeros), one chunk ahead of its transform, into the registers the transform works in;
 //   * transform in packed fp32 over the channel pair (168 v_pk_*), split 5 instructions per frequency (v_cvt_pk_f16_f32,
 //     2 v_fma_mix_f32, v_pk_mul_f32, v_cvt_pk_f16_f32), one ds_write2st64_b32 per frequency (both pieces);
+//   * FAM's multiply (x1 * x2 in the loader) is NOT taken: those three launches stay on the fp32 kernel (conv_uses_w4h);
 //   * slot swizzle slot = q ^ ((-(tile >> 2)) & 3): the four 16-lane groups of ds_read_b128 ({0-3,12-15,20-27}, ...) each cover
 //     all 64 banks, and the 32-lane groups of the transform's stores cover the 32 store banks.
 struct Wino4hGeom {
@@ -1985,7 +1986,7 @@ typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
 // ABL (attribution probes, results invalid; -DREAD_DEBUG_KNOBS builds only, read_tuning_set("conv_abl")): 1 no transform arithmetic,
 // 2 no split arithmetic, 4 no V stores, 8 no patch loads, 32 weights loaded once, 64 B operands loaded once, 128 no epilogue,
 // 256 no barrier, 512 no 2^-11 Uh products, 1024 no MFMAs, 2048 / 4096 patch / weight loads from one cache-resident address
-template <bool MUL, int ABL = 0>
+template <int ABL = 0>
 __global__ __launch_bounds__(256, 1) void gated_conv_wino4h_kernel(const ConvKArgs a)
 {
     using WG = Wino4hGeom;
@@ -2019,7 +2020,6 @@ __global__ __launch_bounds__(256, 1) void gated_conv_wino4h_kernel(const ConvKAr
     bool rclamp = false, rclamp_d = false;                     // any row clamped (top / bottom units only)
     const unsigned src_bytes = (unsigned)(a.inH * s.W * s.C) * 4u;
     const auto rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(s.p), 0, src_bytes, 0x00020000);
-    const auto rsrc_mul = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(MUL ? a.mul : s.p), 0, src_bytes, 0x00020000);
     auto set_patch = [&]() {
         const int y0 = pby * 8 + 4 * (wv >> 1) - 1, x0 = pbx * 32 + 4 * (tl & 7) - 1;
         rclamp = false;
@@ -2049,7 +2049,6 @@ __global__ __launch_bounds__(256, 1) void gated_conv_wino4h_kernel(const ConvKAr
         }
     };
     f32x2 d2[6][6];                                            // the patch of the chunk under transform: (channel 2 cp, 2 cp + 1)
-    f32x2 dm[MUL ? 6 : 1][MUL ? 6 : 1];
     auto gload = [&](int r, int c) {
         if (ABL & 8) return;
         if (ABL & 2048) {                                      // every patch load from the tensor's first 128 bytes: the instruction without its miss
@@ -2057,7 +2056,6 @@ __global__ __launch_bounds__(256, 1) void gated_conv_wino4h_kernel(const ConvKAr
             return;
         }
         d2[r][c] = __builtin_bit_cast(f32x2, __builtin_amdgcn_raw_buffer_load_b64(rsrc, xoff[c], rowoff[r] + pchunk * 128, 0));
-        if constexpr (MUL) dm[r][c] = __builtin_bit_cast(f32x2, __builtin_amdgcn_raw_buffer_load_b64(rsrc_mul, xoff[c], rowoff[r] + pchunk * 128, 0));
     };
     // 1-D transform with B^T = [4 0 -5 0 1 0; 0 -4 -4 1 1 0; 0 4 -4 -1 1 0; 0 -2 -1 2 1 0; 0 2 -1 -2 1 0; 0 4 0 -5 0 1] on six
     // channel pairs: 14 packed operations
@@ -2101,10 +2099,6 @@ __global__ __launch_bounds__(256, 1) void gated_conv_wino4h_kernel(const ConvKAr
     constexpr int T_STEPS = 48;
     auto t_step = [&](int vb, int k, bool reload) {
         if (k < 6) {
-            if constexpr (MUL) {
-#pragma unroll
-                for (int r = 0; r < 6; ++r) d2[r][k] = d2[r][k] * dm[r][k];
-            }
             if (rclamp_d) {                                    // wave-uniform: top / bottom units zero the rows outside the image
 #pragma unroll
                 for (int r = 0; r < 6; ++r) d2[r][k] = d2[r][k] * f32x2{rmask_d[r], rmask_d[r]};
@@ -2347,6 +2341,346 @@ __global__ __launch_bounds__(256, 1) void gated_conv_wino4h_kernel(const ConvKAr
         a.out[tid] = sink;
     }
 }
+
+// ------------------------------------------------------------------------------------------
+// NEGATIVE RESULT, kept in the DEBUG library only (-DREAD_DEBUG_KNOBS, read_tuning_set("conv_w4h_waves", 8)): the split-operand
+// kernel above cut into SPECIALISED waves — eight per workgroup, two per SIMD: waves 0..3 multiply (MFMA stream, weight ring,
+// B operands, epilogue), waves 4..7 produce (patch loads, input transform, split, V stores).  Same arithmetic, operands, LDS layout
+// and unit walk; results bit-identical to the four-wave kernel (tests/test_gpu_conv.py runs both when the debug library is loaded).
+// Why it was tried (profiles/r6_w4h_ablation.md): in the four-wave kernel the MFMAs alone take 9 us of a 44 us launch at C = 256 and
+// everything else ADDS to them — a wave alone on its SIMD issues in order, its loads return in order (a weight fragment requested
+// behind a patch load waits for that load's miss), the transform's 350 vector instructions sit between its MFMAs.  Two waves with
+// different jobs on a SIMD overlap by construction and have separate vmcnt.
+// MEASURED (round 6, tools/w4h_ab.py): 65.6 / 70.3 / 54.7 / 48.5 us per launch at C = 32 / 64 / 128 / 256 against 59.8 / 52.9 / 47.4 / 44.2
+// for the four-wave kernel — SLOWER at every level.  The probes say why: the multiplying waves ALONE (producers switched off) take
+// 35.5 us at C = 256.  At two waves per SIMD a wave has 256 registers; 144 are accumulators, which leaves a six-frequency weight
+// ring fetched four ahead: 8 KiB in flight per wave, 32 KiB per CU, and an L2 hit under this load takes ~0.5 us — the weight stream
+// (288 KiB per 32 input channels and unit) then runs at 65 GB/s per CU = 4.4 us per stage, where the four-wave kernel (nine-frequency
+// ring, six ahead, 48 KiB in flight per CU) is not weight-bound.  Specialisation trades the issue serialisation for a shallower
+// prefetch, and on this machine the prefetch depth is worth more.  It is therefore not part of libreadhip.so.
+// ------------------------------------------------------------------------------------------
+#ifdef READ_DEBUG_KNOBS
+template <int ABL = 0>
+__global__ __launch_bounds__(512, 1) void gated_conv_wino4h2_kernel(const ConvKArgs a)
+{
+    using WG = Wino4hGeom;
+    __shared__ __attribute__((aligned(16))) unsigned lds[WG::LDS_DWORDS];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const SrcDev s = a.src[0];
+    const int groups = a.CoutPad >> 5, G = gridDim.x;
+    const int g = blockIdx.x % groups;
+    const int n = a.nchunks;                                   // 32-channel chunks
+    constexpr unsigned OOR = 0x80000000u;
+    constexpr int BAR_M = 102;                                 // multiplying waves: the stage's barrier in front of frequency pair 17
+
+    auto step_tile = [&](int &ty_, int &tx_) {
+        ty_ += a.wino_dby;
+        tx_ += a.wino_dbx;
+        if (tx_ >= a.tiles_x) {
+            tx_ -= a.tiles_x;
+            ++ty_;
+        }
+    };
+
+    if (wv >= 4) {
+        // =============================== producing waves: patch -> registers -> B^T d B -> f16 pieces -> V ===============================
+        const int tw = wv - 4;
+        const int cp = lane & 15, tl = tw * 4 + (lane >> 4);
+        int pby = (blockIdx.x / groups) / a.tiles_x, pbx = (blockIdx.x / groups) % a.tiles_x, pu = blockIdx.x, pchunk = 0;
+        unsigned xoff[6];
+        int rowoff[6];
+        float rmask[6], rmask_d[6];
+        bool rclamp = false, rclamp_d = false;
+        const unsigned src_bytes = (unsigned)(a.inH * s.W * s.C) * 4u;
+        const auto rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(s.p), 0, src_bytes, 0x00020000);
+        auto set_patch = [&]() {
+            const int y0 = pby * 8 + 4 * (tw >> 1) - 1, x0 = pbx * 32 + 4 * (tl & 7) - 1;
+            rclamp = false;
+#pragma unroll
+            for (int r = 0; r < 6; ++r) {
+                const int yy = y0 + r;
+                const bool ok = (unsigned)yy < (unsigned)a.inH;
+                const int yc = yy < 0 ? 0 : yy >= a.inH ? a.inH - 1 : yy;
+                rowoff[r] = yc * s.W * s.C * 4;
+                rmask[r] = ok ? 1.0f : 0.0f;
+                rclamp = rclamp || !ok;
+            }
+#pragma unroll
+            for (int c = 0; c < 6; ++c) xoff[c] = (unsigned)(x0 + c) < (unsigned)a.inW ? (unsigned)((x0 + c) * s.C + 2 * cp) * 4u : OOR;
+        };
+        auto advance = [&]() {
+#pragma unroll
+            for (int r = 0; r < 6; ++r) rmask_d[r] = rmask[r];
+            rclamp_d = rclamp;
+            if (++pchunk == n) {
+                pchunk = 0;
+                if (pu + G < a.n_units) {
+                    pu += G;
+                    step_tile(pby, pbx);
+                }
+                set_patch();
+            }
+        };
+        f32x2 d2[6][6];
+        auto gload_all = [&]() {
+            if (ABL & 8) return;
+#pragma unroll
+            for (int r = 0; r < 6; ++r)
+#pragma unroll
+                for (int c = 0; c < 6; ++c) {
+                    d2[r][c] = __builtin_bit_cast(f32x2, __builtin_amdgcn_raw_buffer_load_b64(rsrc, xoff[c], rowoff[r] + pchunk * 128, 0));
+                }
+        };
+        auto bt6 = [](f32x2 &x0, f32x2 &x1, f32x2 &x2, f32x2 &x3, f32x2 &x4, f32x2 &x5) {
+            const f32x2 p = pk_add(x3, x4), q = pk_add(x1, x2), r = pk_sub(x4, x3), u = pk_sub(x1, x2), f = pk_sub(x3, x1), h = pk_sub(x4, x2);
+            const f32x2 y0 = __builtin_elementwise_fma(x2, f32x2{-5.0f, -5.0f}, __builtin_elementwise_fma(x0, f32x2{4.0f, 4.0f}, x4));
+            const f32x2 y5 = __builtin_elementwise_fma(x3, f32x2{-5.0f, -5.0f}, __builtin_elementwise_fma(x1, f32x2{4.0f, 4.0f}, x5));
+            x0 = y0;
+            x1 = __builtin_elementwise_fma(q, f32x2{-4.0f, -4.0f}, p);
+            x2 = __builtin_elementwise_fma(u, f32x2{4.0f, 4.0f}, r);
+            x3 = __builtin_elementwise_fma(f, f32x2{2.0f, 2.0f}, h);
+            x4 = __builtin_elementwise_fma(f, f32x2{-2.0f, -2.0f}, h);
+            x5 = y5;
+        };
+        const int vwoff = tl * 16 + (((cp >> 2) ^ ((-tw) & 3)) << 2) + (cp & 3);
+        auto split_store = [&](const f32x2 x, int vb, int fq) {
+            unsigned hi, lo;
+            float r0, r1;
+            asm("v_cvt_pk_f16_f32 %0, %1, %2" : "=v"(hi) : "v"(x.x), "v"(x.y));
+            asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel_hi:[1,0,0]" : "=v"(r0) : "v"(hi), "v"(x.x));
+            asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(r1) : "v"(hi), "v"(x.y));
+            const f32x2 rs = f32x2{r0, r1} * f32x2{2048.0f, 2048.0f};
+            asm("v_cvt_pk_f16_f32 %0, %1, %2" : "=v"(lo) : "v"(rs.x), "v"(rs.y));
+            lds[vwoff + vb + fq * WG::VFREQ] = hi;
+            lds[vwoff + vb + fq * WG::VFREQ + 256] = lo;
+        };
+        auto transform = [&](int vb) {
+            if (ABL & 1) return;
+#pragma unroll
+            for (int c = 0; c < 6; ++c) {
+                if (rclamp_d) {
+#pragma unroll
+                    for (int r = 0; r < 6; ++r) d2[r][c] = d2[r][c] * f32x2{rmask_d[r], rmask_d[r]};
+                }
+                bt6(d2[0][c], d2[1][c], d2[2][c], d2[3][c], d2[4][c], d2[5][c]);
+            }
+#pragma unroll
+            for (int r = 0; r < 6; ++r) {
+                bt6(d2[r][0], d2[r][1], d2[r][2], d2[r][3], d2[r][4], d2[r][5]);
+#pragma unroll
+                for (int c = 0; c < 6; ++c) split_store(d2[r][c], vb, r * 6 + c);
+            }
+        };
+        // prologue: patch(0) -> V(0); patch(1) on its way
+        set_patch();
+        gload_all();
+        advance();
+        transform(0);
+        gload_all();
+        advance();
+        __syncthreads();                                       // P: V(0) complete
+        int v_nxt = WG::VBUF;
+        for (int u = blockIdx.x; u < a.n_units; u += G)
+            for (int chunk = 0; chunk < n; ++chunk) {
+                transform(v_nxt);                              // chunk + 1 (of this or of the next unit) -> the other buffer
+                gload_all();                                   // chunk + 2: a whole stage to land
+                advance();
+                v_nxt = WG::VBUF - v_nxt;
+                if (!(ABL & 256)) __syncthreads();             // S: V(chunk + 1) complete; V(chunk) free
+            }
+        return;
+    }
+
+    // =============================== multiplying waves ===============================
+    int by = (blockIdx.x / groups) / a.tiles_x, bx = (blockIdx.x / groups) % a.tiles_x;
+    const char *const wbase = reinterpret_cast<const char *>(a.wp_w4h) + ((size_t)(g * 4 + wv) * n) * (36 * 2048);
+    const auto wrsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<char *>(wbase), 0, (unsigned)n * (36 * 2048), 0x00020000);
+    const unsigned wvoff = lane * 16;
+    constexpr int RW = 6, WLEAD = 4;                           // ring of six frequencies, fetched four ahead
+    u32x4 Wh[RW], Wl[RW];
+    f16x8 Ws[2];                                               // 2^-11 Uh of the next frequency pair
+    auto wload = [&](int slot, int chunk, int fq) {
+        Wh[slot] = __builtin_amdgcn_raw_buffer_load_b128(wrsrc, wvoff, (chunk * 36 + fq) * 2048, 0);
+        Wl[slot] = __builtin_amdgcn_raw_buffer_load_b128(wrsrc, wvoff, (chunk * 36 + fq) * 2048 + 1024, 0);
+    };
+    auto wscale = [&](int fq) {
+        const _Float16 k = (_Float16)0x1p-11f;
+        Ws[fq % 2] = __builtin_bit_cast(f16x8, Wh[fq % RW]) * f16x8{k, k, k, k, k, k, k, k};
+    };
+    const int t16 = lane & 15, kl = lane >> 4;
+    const int vrd = t16 * 16 + ((kl ^ ((-(t16 >> 2)) & 3)) << 2);
+    constexpr int RB = 4;
+    u32x4 Bh[RB], Bl[RB];
+    auto bload = [&](int slot, int vb, int fq) {
+        Bh[slot] = *reinterpret_cast<const u32x4 *>(__builtin_assume_aligned(lds + vb + fq * WG::VFREQ + vrd, 16));
+        Bl[slot] = *reinterpret_cast<const u32x4 *>(__builtin_assume_aligned(lds + vb + fq * WG::VFREQ + 256 + vrd, 16));
+    };
+    f32x4 acc[36];
+    const auto out_rsrc = __builtin_amdgcn_make_buffer_rsrc(a.out, 0, (unsigned)(a.outH * a.outW * a.out_cstride) * 4u, 0x00020000);
+    const auto res_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(a.residual ? a.residual : a.out), 0,
+                                                            (unsigned)(a.outH * a.outW * a.Cout) * 4u, 0x00020000);
+    const float *const wsc = reinterpret_cast<const float *>(a.wp_w4h) + (size_t)n * 2304 * a.CoutPad;
+    int v_cur = 0, v_nxt = WG::VBUF;
+
+    // One stage = one 32-channel chunk = 108 MFMAs.  LAST: the unit's last chunk — nothing of the next unit is prefetched (its
+    // rings would have to live through the epilogue: no registers for that at two waves per SIMD)
+    auto stage_body = [&](auto first_tag, auto last_tag, int chunk) {
+        constexpr bool FIRST = decltype(first_tag)::value, LAST = decltype(last_tag)::value;
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int pr = 0; pr < 18; ++pr)
+#pragma unroll
+            for (int j = 0; j < 6; ++j) {
+                const int fq = 2 * pr + (j & 1), pc = j >> 1, m = pr * 6 + j;
+                if (m == BAR_M && !(ABL & 256)) __syncthreads();
+                const f16x8 av = pc == 0 ? Ws[fq % 2] : __builtin_bit_cast(f16x8, pc == 1 ? Wl[fq % RW] : Wh[fq % RW]);
+                const f16x8 bv = __builtin_bit_cast(f16x8, pc == 0 ? Bl[fq % RB] : Bh[fq % RB]);
+                if (ABL & 1024) {
+                    if (FIRST && pc == 0) acc[fq] = f32x4{0.f, 0.f, 0.f, 0.f};
+                    if (pc == 2) asm volatile("" :: "v"(av), "v"(bv));
+                } else if (FIRST && pc == 0) {
+                    const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+                    acc[fq] = __builtin_amdgcn_mfma_f32_16x16x32_f16(av, bv, zero, 0, 0, 0);
+                } else
+                    acc[fq] = __builtin_amdgcn_mfma_f32_16x16x32_f16(av, bv, acc[fq], 0, 0, 0);
+                if (j < 2) {                                                         // B operands one frequency pair ahead
+                    const int bf = 2 * pr + 2 + j;
+                    if (bf < 36) bload(bf % RB, v_cur, bf);
+                    else if (!LAST) bload(bf % RB, v_nxt, bf - 36);
+                } else if (j < 4) {                                                  // weights WLEAD frequencies ahead
+                    const int wf = 2 * pr + WLEAD + (j - 2);
+                    if (wf < 36) wload(wf % RW, chunk, wf);
+                    else if (!LAST) wload(wf % RW, chunk + 1, wf - 36);
+                } else {                                                             // 2^-11 Uh of the next frequency pair
+                    const int sf = 2 * pr + 2 + (j - 4);
+                    if (sf < 36 || !LAST) wscale(sf % 36);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        const int v = v_cur;
+        v_cur = v_nxt;
+        v_nxt = v;
+    };
+
+    __syncthreads();                                           // P
+    for (int u = blockIdx.x; u < a.n_units; u += G) {
+        // prime the rings (first unit: behind the prologue barrier; later units: behind the epilogue)
+#pragma unroll
+        for (int j = 0; j < WLEAD; ++j) wload(j, 0, j);
+        bload(0, v_cur, 0);
+        bload(1, v_cur, 1);
+        wscale(0);
+        wscale(1);
+        if (n == 1) stage_body(std::true_type{}, std::true_type{}, 0);
+        else {
+            stage_body(std::true_type{}, std::false_type{}, 0);
+            for (int chunk = 1; chunk < n - 1; ++chunk) stage_body(std::false_type{}, std::false_type{}, chunk);
+            stage_body(std::false_type{}, std::true_type{}, n - 1);
+        }
+
+        // ================= unit epilogue: two tile rows (p, p + 2) at a time =================
+        __builtin_amdgcn_s_setprio(1);
+        const int cq = (lane >> 4) & 1, hf = lane >> 5;
+        const int c0 = g * 32 + wv * 8 + 4 * cq;
+        const int oy = by * 8 + 4 * (t16 >> 3) + 2 * hf, ox = bx * 32 + 4 * (t16 & 7);
+        if (ABL & 128) {
+            f32x4 sum = acc[0];
+#pragma unroll
+            for (int i = 1; i < 36; ++i) sum += acc[i];
+            if (oy < a.outH && ox < a.outW) *reinterpret_cast<f32x4 *>(a.out + ((size_t)oy * a.outW + ox) * a.out_cstride + c0) = sum;
+            step_tile(by, bx);
+            __builtin_amdgcn_s_setprio(0);
+            continue;
+        }
+        const f32x4 bf = *reinterpret_cast<const f32x4 *>(a.params + c0);
+        const f32x4 sc = *reinterpret_cast<const f32x4 *>(a.params + 2 * a.CoutPad + c0);
+        const f32x4 sh = *reinterpret_cast<const f32x4 *>(a.params + 3 * a.CoutPad + c0);
+        const f32x4 isf = *reinterpret_cast<const f32x4 *>(wsc + c0);
+        constexpr float LOG2E = 1.44269504088896341f;
+        const f32x4 ism = *reinterpret_cast<const f32x4 *>(wsc + a.CoutPad + c0) * -LOG2E;
+        const f32x4 bml = *reinterpret_cast<const f32x4 *>(a.params + a.CoutPad + c0) * -LOG2E;
+#pragma unroll
+        for (int py = 0; py < 2; ++py) {
+            unsigned rvoff[4], ovoff[4];
+            f32x4 rv[4];
+#pragma unroll
+            for (int px = 0; px < 4; ++px) {
+                const bool in = (oy + py < a.outH) & (ox + px < a.outW) & (c0 < a.Cout);
+                const int pix = (oy + py) * a.outW + ox + px;
+                rvoff[px] = in ? (unsigned)((pix * a.Cout + c0) * 4) : OOR;
+                ovoff[px] = in ? (unsigned)((pix * a.out_cstride + c0) * 4) : OOR;
+                rv[px] = f32x4{0.f, 0.f, 0.f, 0.f};
+                if (a.residual) rv[px] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(res_rsrc, rvoff[px], 0, 0));
+            }
+            // rows p = py and p + 2 of A^T M:  p = 0: a0 + s1 + s2 | p = 2: s1 + 4 s2   (s = sums of frequency rows 1,2 / 3,4)
+            //                                  p = 1: d1 + 2 d2    | p = 3: d1 + 8 d2 + a5  (d = differences)
+            f32x4 Ra[6], Rb[6];
+#pragma unroll
+            for (int nu = 0; nu < 6; ++nu) {
+                if (py == 0) {
+                    const f32x4 s1 = acc[6 + nu] + acc[12 + nu], s2 = acc[18 + nu] + acc[24 + nu];
+                    Ra[nu] = acc[nu] + s1 + s2;
+                    Rb[nu] = s1 + 4.0f * s2;
+                } else {
+                    const f32x4 d1 = pk_sub4(acc[6 + nu], acc[12 + nu]), dd2 = pk_sub4(acc[18 + nu], acc[24 + nu]);
+                    Ra[nu] = d1 + 2.0f * dd2;
+                    Rb[nu] = d1 + 8.0f * dd2 + acc[30 + nu];
+                }
+            }
+#pragma unroll
+            for (int px = 0; px < 4; ++px) {
+                // column px of (A^T M) A for both rows
+                f32x4 ya, yb;
+                if (px == 0) {
+                    ya = Ra[0] + (Ra[1] + Ra[2]) + (Ra[3] + Ra[4]);
+                    yb = Rb[0] + (Rb[1] + Rb[2]) + (Rb[3] + Rb[4]);
+                } else if (px == 1) {
+                    ya = pk_sub4(Ra[1], Ra[2]) + 2.0f * pk_sub4(Ra[3], Ra[4]);
+                    yb = pk_sub4(Rb[1], Rb[2]) + 2.0f * pk_sub4(Rb[3], Rb[4]);
+                } else if (px == 2) {
+                    ya = (Ra[1] + Ra[2]) + 4.0f * (Ra[3] + Ra[4]);
+                    yb = (Rb[1] + Rb[2]) + 4.0f * (Rb[3] + Rb[4]);
+                } else {
+                    ya = pk_sub4(Ra[1], Ra[2]) + 8.0f * pk_sub4(Ra[3], Ra[4]) + Ra[5];
+                    yb = pk_sub4(Rb[1], Rb[2]) + 8.0f * pk_sub4(Rb[3], Rb[4]) + Rb[5];
+                }
+                // lanes 0..31 hold conv_f, lanes 32..63 conv_m: after the exchange the lower half-wave owns tile row py, the upper
+                // half row py + 2, f in one register and m in the other
+                u32x4 u0 = __builtin_bit_cast(u32x4, ya), u1 = __builtin_bit_cast(u32x4, yb);
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const auto sw = __builtin_amdgcn_permlane32_swap(u0[k], u1[k], false, false);
+                    u0[k] = sw[0];
+                    u1[k] = sw[1];
+                }
+                f32x4 f = __builtin_elementwise_fma(__builtin_bit_cast(f32x4, u0), isf, bf);
+                const f32x4 mm = __builtin_elementwise_fma(__builtin_bit_cast(f32x4, u1), ism, bml);
+                if (a.elu) {
+                    const f32x4 fe = f * LOG2E;
+                    f32x4 e;
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) e[k] = __builtin_amdgcn_exp2f(fe[k]);
+                    e = e + f32x4{-1.0f, -1.0f, -1.0f, -1.0f};
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) f[k] = f[k] > 0.0f ? f[k] : e[k];
+                }
+                f32x4 sg, t;
+#pragma unroll
+                for (int k = 0; k < 4; ++k) t[k] = __builtin_amdgcn_exp2f(mm[k]);
+                t = t + f32x4{1.0f, 1.0f, 1.0f, 1.0f};
+#pragma unroll
+                for (int k = 0; k < 4; ++k) sg[k] = __builtin_amdgcn_rcpf(t[k]);
+                const f32x4 v = (f * sg) * sc + sh + rv[px];
+                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), out_rsrc, ovoff[px], 0, 0);
+            }
+        }
+        step_tile(by, bx);
+        __builtin_amdgcn_s_setprio(0);
+    }
+}
+
+#endif  // READ_DEBUG_KNOBS
 
 // ------------------------------------------------------------------------------------------
 // NEGATIVE RESULT, kept in the DEBUG library only (-DREAD_DEBUG_KNOBS, read_tuning_set("conv_w4x2", 1)): the F(4x4,3x3) kernel
@@ -3177,6 +3511,7 @@ int g_w4x2 = 0;            // debug library only: read_tuning_set("conv_w4x2", 1
 int g_w4 = 32;             // read_tuning_set("conv_w4", min Cin): layers with at least this many channels take the Winograd F(4x4,3x3)
 int g_w4h = 32;            // read_tuning_set("conv_w4h", min Cin): F(4x4) layers with Cin % 32 == 0 and at least this many channels take the split-operand
                            // kernel on the f16 matrix cores when its operand was supplied (0 = never: the fp32 kernel)
+int g_w4h_waves = 4;       // debug library only: read_tuning_set("conv_w4h_waves", 8) = the split-operand kernel with specialised waves (measured slower, round 6)
 int g_sc = 8;              // read_tuning_set("conv_sc", 0): the output layer (Cout <= 4) back on the F(2x2) MFMA kernel instead of the vector pipe; other values: conv_set_sc
                            // kernel when its weights were supplied (0 = never)
 int g_abl = 0;             // read_tuning_set("conv_abl", bits): attribution probes of the 16x16x4 Winograd kernels (results invalid); -DREAD_DEBUG_KNOBS builds only
@@ -3553,6 +3888,7 @@ void conv_set_w16(int v) { g_w16 = v != 0; }
 void conv_set_abl(int v) { g_abl = v; }
 void conv_set_w4(int v) { g_w4 = v < 0 ? 0 : v; }
 void conv_set_w4h(int v) { g_w4h = v < 0 ? 0 : v; }
+void conv_set_w4h_waves(int v) { g_w4h_waves = v == 4 ? 4 : 8; }
 void conv_set_w4_grid(int v) { g_w4_grid = v != 0; }
 void conv_set_wino_wgs(int v) { g_wino_wgs = v <= 1 ? 1 : 2; }
 void conv_set_px(int v) { g_conv_px = v < 0 ? 0 : v > 4 ? 4 : v; }
@@ -3573,6 +3909,9 @@ int conv_get(const char *key, int *value)
     else if (!strcmp(key, "conv_w16")) *value = g_w16;
     else if (!strcmp(key, "conv_w4")) *value = g_w4;
     else if (!strcmp(key, "conv_w4h")) *value = g_w4h;
+#ifdef READ_DEBUG_KNOBS
+    else if (!strcmp(key, "conv_w4h_waves")) *value = g_w4h_waves;
+#endif
     else if (!strcmp(key, "conv_w4_grid")) *value = g_w4_grid;
 #ifdef READ_DEBUG_KNOBS
     else if (!strcmp(key, "conv_ablate")) *value = g_ablate;
@@ -3927,16 +4266,32 @@ int launch_gated_conv(const read_conv_desc *d, hipStream_t stream)
             return READ_OK;
         }
 #endif
-        if (w4h) fn4 = d->mul ? gated_conv_wino4h_kernel<true> : gated_conv_wino4h_kernel<false>;
+        if (w4h) fn4 = gated_conv_wino4h_kernel<>;
 #ifdef READ_DEBUG_KNOBS
-        if (w4h && !d->mul && g_abl) {
+        if (w4h && g_abl) {
             switch (g_abl) {
-#define READ_ABL_CASE(n) case n: fn4 = gated_conv_wino4h_kernel<false, n>; break;
+#define READ_ABL_CASE(n) case n: fn4 = gated_conv_wino4h_kernel<n>; break;
             READ_ABL_CASE(1) READ_ABL_CASE(2) READ_ABL_CASE(3) READ_ABL_CASE(4) READ_ABL_CASE(7) READ_ABL_CASE(8) READ_ABL_CASE(15) READ_ABL_CASE(32) READ_ABL_CASE(64)
             READ_ABL_CASE(128) READ_ABL_CASE(256) READ_ABL_CASE(512) READ_ABL_CASE(1024) READ_ABL_CASE(1007) READ_ABL_CASE(2047 - 1024) READ_ABL_CASE(544) READ_ABL_CASE(2048) READ_ABL_CASE(4096) READ_ABL_CASE(6144) READ_ABL_CASE(40)
 #undef READ_ABL_CASE
             default: break;
             }
+        }
+#endif
+#ifdef READ_DEBUG_KNOBS
+        if (w4h && g_w4h_waves == 8) {
+            conv_fn fn8 = gated_conv_wino4h2_kernel<>;
+            if (g_abl) {
+                switch (g_abl) {
+#define READ_ABL_CASE(n) case n: fn8 = gated_conv_wino4h2_kernel<n>; break;
+                READ_ABL_CASE(1) READ_ABL_CASE(8) READ_ABL_CASE(9) READ_ABL_CASE(128) READ_ABL_CASE(256) READ_ABL_CASE(1024) READ_ABL_CASE(1033)
+#undef READ_ABL_CASE
+                default: break;
+                }
+            }
+            hipLaunchKernelGGL(fn8, dim3((unsigned)nwg), dim3(512), 0, stream, a);
+            READ_CHECK_LAUNCH();
+            return READ_OK;
         }
 #endif
         hipLaunchKernelGGL(fn4, dim3((unsigned)nwg), dim3(256), 0, stream, a);
@@ -3995,7 +4350,9 @@ int conv_uses_w4(const read_conv_desc *d)
 // split operand was supplied (config -7 forces it; the training path's linear launches stay on the fp32 kernel)
 int conv_uses_w4h(const read_conv_desc *d)
 {
-    if (!d->wpacked_w4h || d->linear || d->src[0].C % 32 != 0 || d->Cout % 32 != 0) return 0;
+    // (FAM's x1 * x2 stays on the fp32 kernel: the second patch costs the transform thread another 72 registers, and the
+    //  variant with a shallower weight ring measured SLOWER than the fp32 kernel — 101 / 79 / 68 us against 77 / 69 / 64 at C = 64 / 128 / 256)
+    if (!d->wpacked_w4h || d->linear || d->mul || d->src[0].C % 32 != 0 || d->Cout % 32 != 0) return 0;
     if (d->config == -7) {
         read_conv_desc t = *d;
         t.config = -5;

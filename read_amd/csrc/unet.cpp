@@ -95,7 +95,8 @@ Arch build_arch(int layout)
                 L.w16_off = a.packed_floats;
                 a.packed_floats += read_conv_wino_floats(cin, cout);
             }
-            const bool w4h = w4 && cin % 32 == 0;                   // the split-operand kernel (f16 matrix cores) runs the layer by default
+            // the split-operand kernel (f16 matrix cores) runs the layer by default — except FAM's x1 * x2 launches (fp32 kernel)
+            const bool w4h = w4 && cin % 32 == 0 && path.compare(0, 3, "FAM") != 0;
             if (w4 && !(lean && (unused || w4h))) {
                 L.w4_off = a.packed_floats;
                 a.packed_floats += read_conv_w4_floats(cin, cout);

@@ -61,9 +61,23 @@ class PackedGatedConv:
                     self.wpacked_w4h = torch.from_numpy(w4h).to(device)
 
 
-def gated_conv(packed, sources, stride=1, elu=True, mul=None, residual=None, config=-1, out=None,
-               out_channels=None, fill=None, linear=False, pre=None):
-    """sources: list of (NHWC tensor (h,w,C), shift).  Returns the NHWC output (outH,outW,Cout).
+def gated_conv(packed, sources, **kw):
+    """One BasicConv launch (read_gated_conv_forward); arguments as conv_desc.  Returns the NHWC output (outH,outW,Cout)."""
+    d, out = _desc(packed, sources, **kw)
+    _lib.check(_lib.lib().read_gated_conv_forward(C.byref(d), _lib.stream_ptr()), "read_gated_conv_forward")
+    return out
+
+
+def conv_desc(packed, sources, **kw):
+    """The filled read_conv_desc of a launch (for read_conv_kernel_family and friends); the tensors it points at stay alive with it."""
+    d, out = _desc(packed, sources, **kw)
+    d._keep = (packed, sources, kw, out)
+    return d
+
+
+def _desc(packed, sources, stride=1, elu=True, mul=None, residual=None, config=-1, out=None,
+          out_channels=None, fill=None, linear=False, pre=None):
+    """sources: list of (NHWC tensor (h,w,C), shift).
 
     linear: plain convolution, output channels [conv_f + b_f | conv_m + b_m] (2*Cout).
     pre: (NHWC tensor, f_off, m_off, shift[, bilinear]) pre-activation addend sampled at (y >> shift, x >> shift), or — with
@@ -107,8 +121,7 @@ def gated_conv(packed, sources, stride=1, elu=True, mul=None, residual=None, con
         assert pt.is_contiguous() and pt.dtype == torch.float32
         d.pre, d.pre_cstride, d.pre_f_off, d.pre_m_off, d.pre_shift = pt.data_ptr(), pt.shape[2], f_off, m_off, psh
         d.preH, d.preW = pt.shape[0], pt.shape[1]
-    _lib.check(_lib.lib().read_gated_conv_forward(C.byref(d), _lib.stream_ptr()), "read_gated_conv_forward")
-    return out
+    return d, out
 
 
 def bilinear_up4(x):

@@ -63,6 +63,26 @@ def test_f4_inference_kernels_keep_the_cross_unit_pipeline(conv_asm):
         assert body.count("v_mfma_f32_16x16x4_f32") == 288                        # first + steady stage, 144 each, nothing duplicated
 
 
+def test_split_operand_f4_kernel_keeps_its_registers_and_pipeline(conv_asm):
+    """gated_conv_wino4h_kernel (f16 matrix cores, round 6): one wave per SIMD with the accumulators in the accumulation file, no
+    scratch (a denser transform cadence once flipped hipcc's allocation to 256 + 22 registers and 1.4 KB of scratch: 720 us per
+    launch instead of 60), 108 MFMAs per stage instance, the patch loads and both operand rings inside the stage, a unit loop
+    that does not drain the memory pipeline — and the specialised-wave variant (measured slower) is not in the product."""
+    for variant in ("gated_conv_wino4h_kernelILi0E",):
+        name, body = _function(conv_asm, variant)
+        assert _meta(conv_asm, name, "private_seg_size") == 0, "scratch in the split-operand F(4x4) kernel"
+        assert _meta(conv_asm, name, "num_vgpr") == 256 and _meta(conv_asm, name, "num_agpr") >= 144
+        assert body.count("v_mfma_f32_16x16x32_f16") == 216                      # first + steady stage
+        assert body.count("v_cvt_pk_f16_f32") == 3 * 72                          # prologue + two stage instances: hi and lo of 36 frequencies
+        assert "v_mfma_f32_16x16x4_f32" not in body
+        lines = body.split("\n")
+        heads = [i for i, l in enumerate(lines) if "Loop Header: Depth=1" in l]
+        assert heads, "unit loop not found"
+        head = "\n".join(lines[heads[0]:heads[0] + 12])
+        assert "vmcnt(0)" not in head, "the unit loop drains the previous unit's stores and loads:\n" + head
+    assert "gated_conv_wino4h2_kernel" not in conv_asm
+
+
 def test_training_kernels_count_their_loads(conv_asm, tmp_path_factory):
     for variant in ("gated_conv_wino4_kernelILb0ELi0ELi1E", "gated_conv_wino4_kernelILb0ELi0ELi2E"):
         name, body = _function(conv_asm, variant)
