@@ -54,6 +54,7 @@ from read_amd.unet import default_layout, pack_state, weight_spec             # 
 
 HBM_PEAK_GBS = 8000.0            # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 FP32_MFMA_PEAK_TFS = 157.3       # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 peak
+F16_MFMA_PEAK_TFS = 2500.0       # MI355X_MICROARCH.md: BF16 / F16 dense peak (~2.5 PF; the sparse figure is never used)
 N_POSES = 256
 PSNR_FLOOR_DB = 120.0            # same guard as tests/test_gpu_unet.py (measured ~148 dB)
 
@@ -1050,12 +1051,18 @@ def main():
         algorithmic_tfs = c3_fl / (c3_ms * 1e-3) / 1e12
         # a launch that ran a Winograd kernel executes fewer MFMA flops than the algorithmic (direct-convolution) count:
         # F(2x2,3x3) 1/2.25 (c == 2), F(4x4,3x3) 1/4 (c == 4)
-        gain = {0: 1.0, 1: 1.0, 2: 2.25, 4: 4.0}
+        # ... and the split-operand F(4x4) kernel (c == 5) forms each of those products from THREE f16 piece pairs on the f16 matrix
+        # cores: it executes 3/4 of the direct count there.  `gain` = direct count / fp32-product count (what an fp32 kernel would run)
+        gain = {0: 1.0, 1: 1.0, 2: 2.25, 4: 4.0, 5: 4.0}
         c3_exec = sum(fl / gain.get(c, 1.0) for (_, _, fl, c) in prof if c)
         n_wino = sum(1 for (_, _, _, c) in prof if c == 2)
         n_wino4 = sum(1 for (_, _, _, c) in prof if c == 4)
-        executed_tfs = c3_exec / (c3_ms * 1e-3) / 1e12
+        n_w4h = sum(1 for (_, _, _, c) in prof if c == 5)
+        executed_tfs = c3_exec / (c3_ms * 1e-3) / 1e12          # fp32-product equivalent: comparable with rounds 3-5
         all_exec = sum(fl / gain.get(c, 1.0) for (_, _, fl, c) in prof)
+        w4h_ms = sum(m for (_, m, _, c) in prof if c == 5)
+        w4h_f16_flops = sum(3.0 * fl / 4.0 for (_, _, fl, c) in prof if c == 5)
+        w4h_tfs = w4h_f16_flops / (w4h_ms * 1e-3) / 1e12 if n_w4h else None
         sizes = camera.level_sizes(W, H, 5)
         splat_bytes = 12.0 * N + 8.0 * sum(w * h for (w, h) in sizes)
         gather_bytes = 68.0 * sum(w * h for (w, h) in sizes)
@@ -1066,18 +1073,31 @@ def main():
                       else "rendered frames/sec @1216x368, kitti6-like 10M pts",
             "value": world * a.steps / dt, "unit": "frames/s",
             "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": 1e3 * dt / a.steps,
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32 (3x3/s1 products from two f16 pieces per operand, three piece pairs, fp32 accumulation)" if n_w4h else "f32",
+            "data": "synthetic",
             "config": {"workload": wl.describe, "points": N, "width": W, "height": H,
                        "parallelism": f"pose-sharded x{world}", "pose_layout": a.pose_layout,
                        "shard_proxy_of": None if shard is None else {"rank": shard[0], "world": shard[1]},
                        "frame_exchange": ex.mode or "none",
                        "frames_in_flight": a.frames_in_flight},
             "roofline": {
-                "kernel": "3x3/s1 C->C gated conv family: Winograd kernels on the fp32 matrix cores "
-                          f"({n_wino} launches F(2x2,3x3), {n_wino4} launches F(4x4,3x3), {n_c3 - n_wino - n_wino4} direct)",
+                "kernel": ("gated_conv_wino4h_kernel: Winograd F(4x4,3x3) with split fp32 operands on the f16 matrix cores "
+                           f"({n_w4h} of the {n_c3} launches of the 3x3/s1 C->C family; {n_wino4} on the fp32-matrix-core F(4x4) kernel, "
+                           f"{n_wino} F(2x2), {n_c3 - n_wino - n_wino4 - n_w4h} direct)") if n_w4h else
+                          ("3x3/s1 C->C gated conv family: Winograd kernels on the fp32 matrix cores "
+                           f"({n_wino} launches F(2x2,3x3), {n_wino4} launches F(4x4,3x3), {n_c3 - n_wino - n_wino4} direct)"),
                 "bound": "mfma",
-                "achieved": executed_tfs, "peak": FP32_MFMA_PEAK_TFS, "unit": "TFLOP/s",
-                "frac": executed_tfs / FP32_MFMA_PEAK_TFS, "traffic": traffic,
+                "achieved": w4h_tfs if n_w4h else executed_tfs, "peak": F16_MFMA_PEAK_TFS if n_w4h else FP32_MFMA_PEAK_TFS, "unit": "TFLOP/s",
+                "frac": (w4h_tfs / F16_MFMA_PEAK_TFS) if n_w4h else executed_tfs / FP32_MFMA_PEAK_TFS,
+                "frac_note": ("executed f16 MFMA flops (3 piece pairs x 1/4 of the direct count) / launch time / the f16 dense peak.  The kernel "
+                              "is NOT matrix-pipe bound on this path: its MFMAs alone take 9 us of a 44 us launch (profiles/r6_w4h_ablation.md); what "
+                              "binds it is the operand stream — 288 KiB of weight fragments + 43 KiB of patch per unit and 32 channels from "
+                              "L2 into one CU, with 48 KiB in flight (`operand_stream`)") if n_w4h else None,
+                "fp32_equivalent": {"achieved": executed_tfs, "peak": FP32_MFMA_PEAK_TFS, "frac": executed_tfs / FP32_MFMA_PEAK_TFS,
+                                    "note": "the fp32 products an fp32-matrix-core kernel would execute for the same launches (direct count / 4 "
+                                            "for F(4x4)) / the family's time / the fp32 MFMA peak: the figure rounds 3-5 reported as frac (0.40)"},
+                "traffic": traffic,
                 "traffic_unit": "HBM bytes per launch (rocprofv3 FETCH_SIZE*2 + WRITE_SIZE)",
                 "traffic_source": f"static: profiles/{traffic_src} — separate --pmc passes of this command, committed; NOT measured "
                                   "in this run (counters need rocprofv3 around the process)" if traffic_src else None,
