@@ -124,9 +124,9 @@ def mfma_sustained_tfs(dev):
 
 
 def profiled_mfma_busy():
-    """MFMA-pipe busy % of the dominant kernel per level from the committed PMC pass (profiles/r5_pmc_mfma_busy.md: rocprofv3
+    """MFMA-pipe busy % of the dominant kernel per level from the committed PMC pass (profiles/r6_pmc_mfma_busy.md: rocprofv3
     SQ_VALU_MFMA_BUSY_CYCLES over the four C -> C shapes) — static, like the traffic figure: counters need rocprofv3 around the process."""
-    path = os.path.join(ROOT, "profiles", "r5_pmc_mfma_busy.md")
+    path = os.path.join(ROOT, "profiles", "r6_pmc_mfma_busy.md")
     out = {}
     try:
         for line in open(path):
@@ -142,7 +142,7 @@ def profiled_traffic():
     """HBM bytes per launch of the dominant kernel family from the committed rocprofv3 PMC passes (separate FETCH_SIZE /
     WRITE_SIZE runs of this same command, FETCH_SIZE x2 as MI355X_MICROARCH.md prescribes for gfx950, factor re-derived
     there from a kernel of known byte count).  Launch-weighted mean over every launch of the 3x3/s1 kernels."""
-    for name in ("r5_traffic.json", "r4_traffic.json", "r3_traffic.json", "r2_traffic.json", "r1_traffic.json"):
+    for name in ("r6_traffic.json", "r5_traffic.json", "r4_traffic.json", "r3_traffic.json", "r2_traffic.json", "r1_traffic.json"):
         path = os.path.join(ROOT, "profiles", name)
         try:
             ks = json.load(open(path))["kernels"]
@@ -152,6 +152,8 @@ def profiled_traffic():
         for kname, v in ks.items():
             if kname.startswith("gated_conv_wino4_kernel") and ", 0, 0>" not in kname:
                 continue                                     # the training path's linear launches (LIN = 1, 2): not this family
+            if kname.startswith("gated_conv_wino4h2"):
+                continue                                     # debug library only
             if kname.startswith("gated_conv_wino") or (kname.startswith("gated_conv") and "<3, 1, 16" in kname):
                 n += v["launches"]
                 tot += (v["read_bytes"] + v["write_bytes"]) * v["launches"]
@@ -894,6 +896,9 @@ def also_records(a, dev, wl, first=None):
                                "verified": verify(wl, first, pose=0) if first is not None else None}
     finally:
         wl.fr.set_frames_in_flight(a.frames_in_flight)
+    # (1a) the UNet stage with the 3x3/s1 family back on the fp32 matrix cores (read_tuning_set("conv_w4h", 0); a second plan from the
+    # full blob, the headline plan's feature pyramid as input): the A/B of the round's kernel, and the fp32-path roofline line
+    rec["fp32_mfma"] = fp32_mfma_record(wl, dev)
     # (1b) multi-GPU evidence that needs no second GPU: this GPU renders exactly the share rank PROXY_RANK of an 8-rank sweep
     # would, in both pose layouts (read_amd/sweep.py) — the rasteriser warm-starts from the previous frame, so a stride-8
     # walk of the trajectory costs it coherence that a contiguous block does not
@@ -935,6 +940,60 @@ def also_records(a, dev, wl, first=None):
                     "final_loss": t["final_loss"], "verified": t["verified"],
                     "what": t["config"]["workload"]}
     return rec
+
+
+def fp32_mfma_record(wl, dev):
+    from read_amd.unet import LAYOUT_FULL, UNetEngine
+    L = _lib.lib()
+    wl.fr.sync()
+    torch.cuda.synchronize()
+    f = wl.fr.feat
+    x = [f[i][0] for i in range(4)]
+    rgba_h = wl.fr.unet.forward(*x, channels=4).clone()            # the headline kernels' frame of these features
+    _lib.check(L.read_tuning_set(b"conv_w4h", 0))
+    try:
+        eng = UNetEngine(torch.from_numpy(pack_state(wl.state, layout=LAYOUT_FULL)).to(dev), wl.H, wl.W)
+        rgba_f = eng.forward(*x, channels=4)
+        ms = hip_time_ms(lambda: eng.forward(*x, channels=4), 10)
+        passes = [eng.profile(*x, channels=4) for _ in range(5)]
+        prof = [(l, float(np.median([p_[i][1] for p_ in passes])), fl, c) for i, (l, _, fl, c) in enumerate(passes[0])]
+        torch.cuda.synchronize()
+        del eng
+    finally:
+        _lib.check(L.read_tuning_set(b"conv_w4h", 32))
+    fam_ms = sum(m for (_, m, _, c) in prof if c)
+    fam_exec = sum(fl / {2: 2.25, 4: 4.0}.get(c, 1.0) for (_, _, fl, c) in prof if c)
+    d = (rgba_h[:, :, :3] - rgba_f[:, :, :3]).double()
+    peak = float(rgba_f[:, :, :3].abs().max())
+    mse = float((d * d).mean())
+    ms_h = hip_time_ms(lambda: wl.fr.unet.forward(*x, channels=4), 10)
+    return {"unet_ms": ms, "unet_ms_headline_kernels": ms_h, "family_ms": fam_ms, "family_launches": sum(1 for p_ in prof if p_[3]),
+            "winograd_f4_launches": sum(1 for p_ in prof if p_[3] == 4),
+            "achieved": fam_exec / (fam_ms * 1e-3) / 1e12, "peak": FP32_MFMA_PEAK_TFS, "unit": "TFLOP/s",
+            "frac": fam_exec / (fam_ms * 1e-3) / 1e12 / FP32_MFMA_PEAK_TFS,
+            "psnr_db_between_the_two_paths": (10.0 * np.log10(peak * peak / mse)) if mse > 0 else float("inf"),
+            "max_abs_diff_between_the_two_paths": float(d.abs().max()),
+            "what": "the UNet stage alone (one plan, one stream), 3x3/s1 family on gated_conv_wino4_kernel (v_mfma_f32_16x16x4_f32) "
+                    "instead of the split-operand kernel; frac = executed fp32 MFMA flops of the family / its launch time / 157.3 TF — "
+                    "rounds 3-5's roofline.frac"}
+
+
+def conv_hip_sha16():
+    import hashlib
+    with open(os.path.join(ROOT, "read_amd", "csrc", "conv.hip"), "rb") as fh:
+        return hashlib.sha256(fh.read()).hexdigest()[:16]
+
+
+def profile_staleness():
+    """The counter figures the line quotes from profiles/ (HBM traffic, MFMA-pipe busy) are static: taken by rocprofv3 around this
+    command and committed with the sha16 of the conv.hip they were taken with (profiles/r6_profile_sources.json).  -> (stale?, note)"""
+    try:
+        src = json.load(open(os.path.join(ROOT, "profiles", "r6_profile_sources.json")))
+    except (OSError, ValueError):
+        return True, "profiles/r6_profile_sources.json is missing: the counter figures cannot be tied to this build"
+    now = conv_hip_sha16()
+    stale = src.get("conv_hip_sha16") != now
+    return stale, {"conv_hip_sha16_profiled": src.get("conv_hip_sha16"), "conv_hip_sha16_now": now, "files": src.get("files")}
 
 
 def self_launch(a):
@@ -1097,12 +1156,12 @@ def main():
                 "fp32_equivalent": {"achieved": executed_tfs, "peak": FP32_MFMA_PEAK_TFS, "frac": executed_tfs / FP32_MFMA_PEAK_TFS,
                                     "note": "the fp32 products an fp32-matrix-core kernel would execute for the same launches (direct count / 4 "
                                             "for F(4x4)) / the family's time / the fp32 MFMA peak: the figure rounds 3-5 reported as frac (0.40)"},
-                "traffic": traffic,
+                "traffic": traffic, "traffic_stale": profile_staleness()[0], "profile_sources": profile_staleness()[1],
                 "traffic_unit": "HBM bytes per launch (rocprofv3 FETCH_SIZE*2 + WRITE_SIZE)",
                 "traffic_source": f"static: profiles/{traffic_src} — separate --pmc passes of this command, committed; NOT measured "
                                   "in this run (counters need rocprofv3 around the process)" if traffic_src else None,
                 "mfma_busy": profiled_mfma_busy(),
-                "mfma_busy_source": "static: profiles/r5_pmc_mfma_busy.md — rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES per level, committed; NOT "
+                "mfma_busy_source": "static: profiles/r6_pmc_mfma_busy.md — rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES per level, committed; NOT "
                                     "measured in this run; it agrees with executed flops / time per level (same file)",
                 "mfma_sustained": sustained, "frac_of_sustained": executed_tfs / sustained if sustained else None,
                 "mfma_sustained_note": "TFLOP/s of back-to-back v_mfma_f32_16x16x4_f32, one wave per SIMD on every CU, measured live in this run "
