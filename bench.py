@@ -374,6 +374,15 @@ def _grad_err(got, ref):
     return float(diff.max()) / scale, float((diff - 1e-3 * ref.abs()).clamp_min(0).max()) / scale
 
 
+def _host_barrier(key="read_bench_verify_done", timeout_s=1800):
+    """All ranks meet on the rendezvous store (TCP, host side): no collective is in flight while a rank is busy on its CPU."""
+    import datetime
+    store = dist.distributed_c10d._get_default_store()
+    n, r = dist.get_world_size(), dist.get_rank()
+    store.set(f"{key}_{r}", "1")
+    store.wait([f"{key}_{i}" for i in range(n)], datetime.timedelta(seconds=timeout_s))
+
+
 def run_train(a, dev, street=None, steps=None, warm=None, cpu_timing=True, do_verify=True):
     """One iteration = what src/train.py:150-265 does per batch with the headless renderer: rasterise 8 cameras x 5 scales
     (MyRender), look the descriptors up, UNet forward, loss, backward, Adam on the net, RMSprop on the descriptors.  The
@@ -565,6 +574,10 @@ def run_train(a, dev, street=None, steps=None, warm=None, cpu_timing=True, do_ve
 
     steps = steps if steps is not None else (a.steps if a.steps != 256 else 10)
     warm = warm if warm is not None else max(a.warmup, 2)
+    if world > 1:
+        # rank 0 alone ran the verification iteration (8 crops through the CPU oracle: tens of seconds): the other ranks wait for it
+        # HERE, on the host-side store, not inside the first warm-up step's all-reduce where the RCCL watchdog would be counting
+        dist.monitored_barrier(timeout=__import__("datetime").timedelta(minutes=30)) if dist.get_backend() == "gloo" else _host_barrier()
     for i in range(warm):
         step(i)
     if world > 1:

@@ -136,6 +136,11 @@ int read_splat_hint_next_camera(void *workspace, const float *M_next_host);
 int read_splat_profile_last(float *ms5);
 size_t read_splat_cells_bytes(int64_t n);
 int read_splat_cells_build_host(const float *xyz_host, int64_t n, void *cells_host, size_t cells_bytes);
+/* The library keeps host-side bookkeeping per cell blob ADDRESS (which frames ran over its chunk lists; a frame prepared for an
+ * announced camera is only consumed while nothing else touched them).  Whoever rewrites a blob in place, copies another cloud's
+ * blob over it, or frees it (the allocator may hand the address out again) calls this: pending preparations made against the old
+ * contents then no longer match and are wiped instead of consumed, and the entry is forgotten.  Cheap; no device work. */
+int read_splat_cells_invalidate(const void *cells, int64_t n);
 int read_splat_forward_cells(const float *xyz, void *cells, int64_t n, const float *M_host, int B, int W, int H,
                              int levels, int32_t *const *idx_levels, float *const *depth_levels,
                              void *workspace, size_t workspace_bytes, void *stream);

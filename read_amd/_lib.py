@@ -85,6 +85,7 @@ SIGNATURES = {
     "read_splat_forward": (_i, [_vp, _i64, C.POINTER(_f), _i, _i, _i, _i, _pp, _pp, _vp, _sz, _vp]),
     "read_splat_cells_bytes": (_sz, [_i64]),
     "read_splat_cells_build_host": (_i, [_vp, _i64, _vp, _sz]),
+    "read_splat_cells_invalidate": (_i, [_vp, _i64]),
     "read_splat_forward_cells": (_i, [_vp, _vp, _i64, C.POINTER(_f), _i, _i, _i, _i, _pp, _pp, _vp, _sz, _vp]),
     "read_splat_hint_next_camera": (_i, [_vp, C.POINTER(_f)]),
     "read_splat_profile_last": (_i, [C.POINTER(_f)]),

@@ -428,6 +428,7 @@ struct CellCloud {             // device pointers into the blob
     int nchunks;
     int sticky_frames;         // what a chunk's counter is set to when pass B finds it in front of the bounds (splat_sticky; 0: never promoted)
     int mark_candidates;       // splat_mark: ANY chunk one of whose points reaches a bound gets its counter set (not only pass B's survivors)
+    long long hdr_n;           // points of the cloud (host bookkeeping: a prediction belongs to one cloud)
 };
 
 struct StripInfo {
@@ -1560,12 +1561,23 @@ struct WsHost {
     size_t p_zimg_bytes = 0;
     const void *p_cells = nullptr;       // ... for the lists in this cell blob, as of its frame count p_cells_frame
     unsigned long long p_cells_frame = 0;
+    long long p_n = 0;                   // ... of a cloud of this many points
 };
 std::mutex g_ws_mutex;
 std::unordered_map<void *, WsHost> g_ws_host;
 // The chunk lists a classification fills live in the CELL BLOB (one blob serves one stream at a time), not in the workspace: a
 // prediction is only good while no other frame — of any workspace — has run over the same blob.  Frames per blob, counted here.
+// The count is ALSO what read_splat_cells_invalidate bumps: a blob that was rewritten, copied over or re-allocated at the address of
+// an old one carries wiped or foreign lists — its owner says so, and every prediction made against the old contents stops matching.
+// Counts never restart (an erased entry would let a stale prediction match frame count 0 again): g_cells_epoch seeds new entries.
 std::unordered_map<const void *, unsigned long long> g_cells_frames;
+unsigned long long g_cells_epoch = 1;
+unsigned long long &cells_frames_of(const void *pts)
+{
+    auto it = g_cells_frames.find(pts);
+    if (it == g_cells_frames.end()) it = g_cells_frames.emplace(pts, (g_cells_epoch++) << 40).first;
+    return it->second;
+}
 
 // a pending prediction nobody will consume: wipe the set it dirtied (stream order puts this after the launch that filled it)
 int ws_drop_prediction(WsHost &h, hipStream_t stream)
@@ -1682,14 +1694,14 @@ int cells_frame(const CellCloud &cc, const float *M_host, int W, int H, int leve
     std::lock_guard<std::mutex> lock(g_ws_mutex);
     WsHost &h = g_ws_host[ws.hdr];
     const int fp = (int)(h.frame & 1);
-    unsigned long long &blob_frames = g_cells_frames[(const void *)cc.pts];
+    unsigned long long &blob_frames = cells_frames_of((const void *)cc.pts);
     // every n-th chunk joins list A as a first bound where nothing is near: on a workspace's FIRST frame (no seeds yet) when the knob
     // leaves it to us (splat_cells_sub 0), never afterwards — the seeds are that bound (lap 75.8 -> 75.1 us with splat_sticky 1)
     const int sub_now = g_splat_cells_sub > 0 ? g_splat_cells_sub : (h.frame == 0 ? 32 : 0);
     const int sub_next = g_splat_cells_sub > 0 ? g_splat_cells_sub : 0;
     const bool prepared = h.pred && h.pW == W && h.pH == H && memcmp(h.pm, M_host, sizeof(h.pm)) == 0 && h.p_sub == sub_now &&
                           h.p_near == g_splat_near && h.p_ns == si.ns && h.p_seeds == g_splat_seeds && h.p_zimg == (void *)ws.zimg[fp] &&
-                          h.p_cells == (const void *)cc.pts && h.p_cells_frame == blob_frames;
+                          h.p_cells == (const void *)cc.pts && h.p_cells_frame == blob_frames && h.p_n == cc.hdr_n;
     blob_frames += 1;
     g_prof_valid = false;
     g_prof_slot0 = !prepared;
@@ -1787,6 +1799,7 @@ int cells_frame(const CellCloud &cc, const float *M_host, int W, int H, int leve
     h.p_zimg_bytes = (size_t)W * H * sizeof(unsigned);
     h.p_cells = (const void *)cc.pts;
     h.p_cells_frame = blob_frames;
+    h.p_n = cc.hdr_n;
     if (prof_mark(5, stream) == READ_OK) g_prof_valid = g_splat_prof != 0;
     return READ_OK;
 }
@@ -2126,6 +2139,15 @@ extern "C" int read_splat_hint_next_camera(void *ws, const float *M_next_host)
     return READ_OK;
 }
 
+extern "C" int read_splat_cells_invalidate(const void *cells, int64_t n)
+{
+    READ_CHECK_ARG(cells && n >= 1, "read_splat_cells_invalidate: null blob or n < 1");
+    const CellOffsets o = cell_offsets(n);
+    std::lock_guard<std::mutex> lock(g_ws_mutex);
+    g_cells_frames.erase((const char *)cells + o.pts);           // the next frame over this address starts a new epoch: no prediction matches it
+    return READ_OK;
+}
+
 extern "C" int read_splat_forward_cells(const float *xyz, void *cells, int64_t n, const float *M_host, int B,
                                         int W, int H, int levels, int32_t *const *idx_levels,
                                         float *const *depth_levels, void *ws, size_t ws_bytes, void *stream)
@@ -2156,6 +2178,7 @@ extern "C" int read_splat_forward_cells(const float *xyz, void *cells, int64_t n
     cc.list_b = (CellEntryB *)((char *)cells + o.list_b);
     cc.sticky = (unsigned char *)cells + o.sticky;
     cc.nchunks = (int)cells_chunks(n);
+    cc.hdr_n = n;
     cc.sticky_frames = g_splat_sticky;
     cc.mark_candidates = g_splat_mark && g_splat_sticky > 0;
     const WsLayout L = ws_layout(ws, B, W, H);

@@ -42,6 +42,8 @@ class PointCloudRasterizer:
             self.cells = cells.to(self.device)
         elif cells and self.n >= self.CELLS_MIN_POINTS:
             self.cells = torch.from_numpy(build_cells(xyz.detach().cpu().numpy())).to(self.device)
+        if self.cells is not None:           # a fresh blob at an address the allocator may have handed out before
+            _lib.check(_lib.lib().read_splat_cells_invalidate(self.cells.data_ptr(), self.n), "read_splat_cells_invalidate")
 
     def _workspace(self, B, W, H):
         """One persistent workspace per (min(B,8), W, H): key images, hi-z bounds and the previous frame's

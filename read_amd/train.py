@@ -850,13 +850,23 @@ class _HybridStepFn(torch.autograd.Function):
             if s_in.data_ptr() != x.data_ptr():
                 s_in.data.copy_(x)                   # .data: no version bump on a tensor the retained graph may have saved
         step.graph.replay()
+        step.generation += 1                         # the static activations now belong to THIS forward
         ctx.step = step
+        ctx.generation = step.generation
         ctx.n_tensors = len(tensors)
         return step.out.detach()
 
     @staticmethod
     def backward(ctx, gout):
         step = ctx.step
+        if ctx.generation != step.generation:
+            # a later forward has replayed the graph over the activations this backward would read (the `pending` latch was
+            # released because the parameters moved in between: a delayed backward after an optimizer step, load_state_dict
+            # or broadcast_parameters).  Eager autograd raises a version error here; returning gradients of the wrong
+            # activations silently would be worse.
+            raise RuntimeError("read_amd.train: backward of a captured forward whose buffers a later forward has replayed "
+                               f"(generation {ctx.generation}, now {step.generation}); run backward before the next forward, "
+                               "or set READ_AMD_GRAPH_TRAIN=0")
         step.pending = False
         grads = torch.autograd.grad([step.out], step.targets, [gout.contiguous()], retain_graph=True, allow_unused=True)
         res = [None] * ctx.n_tensors
@@ -883,6 +893,7 @@ class _GraphedStep:
             self.target_slots.append(len(static_in) + j)
         self.pending = False         # a forward whose backward has not run yet: its saved activations are still needed
         self.pending_version = None  # ... and the parameter versions it saw (_graphed_step releases a stale latch)
+        self.generation = 0          # replays so far: a backward checks that its forward was the LAST one (_HybridStepFn.backward)
 
     def __call__(self, xs):
         self.pending = True

@@ -63,6 +63,8 @@ def test_aff_weight_blocks_in_the_packed_blob():
             off += 2 * L.read_conv_wino_floats(cin, cout)                  # 3x3 / stride-1 layers carry G g G^T as well, in the
             if cin >= 32 and cout % 32 == 0:                               # orders of both F(2x2) kernels, and the F(4x4) fragments
                 off += L.read_conv_w4_floats(cin, cout)
+                if cin % 32 == 0 and not path.startswith("FAM"):           # round 6: ... and their split into f16 piece pairs (not FAM's x1 * x2 layers)
+                    off += L.read_conv_w4h_floats(cin, cout)
         if L.read_conv_sc_floats(cin, cout) and k == 3:                    # the 32 -> 3 layer: the vector-pipe order, 64-byte aligned
             off = (off + 15) // 16 * 16 + L.read_conv_sc_floats(cin, cout)
     aff = lambda *ks: tuple(f"AFFs.{k}.conv.0" for k in ks)                # noqa: E731
@@ -235,4 +237,15 @@ def test_lean_packed_layout_is_a_subset_of_the_full_one():
     wm = np.ascontiguousarray(state["Encoder.1.layers.0.main.0.block.conv_m.weight"], np.float32)
     _lib.check(L.read_conv_pack_w4_host(64, 64, wf.ctypes.data, wm.ctypes.data, w4.ctypes.data))
     probe = w4[:64].tobytes()
-    assert probe in lean.tobytes() and probe in full.tobytes()
+    # round 6: the lean blob carries that layer's SPLIT operand (f16 piece pairs, the kernel the default plan runs) instead of the
+    # fp32 order, the full blob both; FAM's x1 * x2 layers stay on the fp32 kernel and keep the fp32 order in the lean blob too
+    w4h = np.empty(L.read_conv_w4h_floats(64, 64), np.float32)
+    _lib.check(L.read_conv_pack_w4h_host(64, 64, wf.ctypes.data, wm.ctypes.data, w4h.ctypes.data))
+    probe_h = w4h[:64].tobytes()
+    lean_b, full_b = lean.tobytes(), full.tobytes()
+    assert probe_h in lean_b and probe_h in full_b and probe in full_b and probe not in lean_b
+    ff = np.ascontiguousarray(state["FAM2.merge.block.conv_f.weight"], np.float32)
+    fm = np.ascontiguousarray(state["FAM2.merge.block.conv_m.weight"], np.float32)
+    w4f = np.empty(L.read_conv_w4_floats(64, 64), np.float32)
+    _lib.check(L.read_conv_pack_w4_host(64, 64, ff.ctypes.data, fm.ctypes.data, w4f.ctypes.data))
+    assert w4f[:64].tobytes() in lean_b
