@@ -307,6 +307,40 @@ def test_headline_frame_1216x352_vs_oracle(hip):
         assert sum(1 for (lbl, _, fl, k) in prof if abs(fl - 15.778971648e9 * (H / 352)) < 1e6 and k != 4) == 0
 
 
+def test_split_operand_plan_against_the_fp32_plan(hip):
+    """Round 6: the default plan runs 70 of the 73 family launches on the split-operand F(4x4) kernel (f16 matrix cores); with
+    read_tuning_set("conv_w4h", 0) the same blob (full layout) runs them on the fp32-matrix-core kernel.  Both frames against the
+    torch-fp32 oracle at the network guard, and against each other; the lean blob carries the split operand only, so the knob is
+    refused there (loudly) and the module repacks the full blob."""
+    from read_amd import _lib
+    from read_amd.unet import LAYOUT_FULL, LAYOUT_LEAN, UNetEngine, layout_of, pack_state
+    H, W = 96, 160
+    state = synthetic.make_unet_state(UNET_SPEC, 9)
+    torch.manual_seed(3)
+    xs = [torch.rand(H >> l, W >> l, 8, device="cuda") for l in range(4)]
+    with torch.no_grad():
+        ref = unet_torch.unet_forward(state, *[x.permute(2, 0, 1)[None].cpu() for x in xs])[0]
+    full = torch.from_numpy(pack_state(state, layout=LAYOUT_FULL)).cuda()
+    eng = UNetEngine(full, H, W)
+    kinds = [k for (_, _, _, k) in eng.profile(*xs)]
+    assert kinds.count(5) >= 70 and kinds.count(4) == 3
+    split = eng.forward(*xs).clone()
+    _check_rgb(split.permute(2, 0, 1).cpu(), ref, "split-operand plan")
+    try:
+        _lib.check(_lib.lib().read_tuning_set(b"conv_w4h", 0))
+        kinds = [k for (_, _, _, k) in eng.profile(*xs)]
+        assert kinds.count(5) == 0 and kinds.count(4) >= 73
+        fp32 = eng.forward(*xs).clone()
+        _check_rgb(fp32.permute(2, 0, 1).cpu(), ref, "fp32-matrix-core plan")
+        _check_rgb(split.permute(2, 0, 1).cpu(), fp32.permute(2, 0, 1).cpu(), "split-operand plan against the fp32 plan")
+        assert not torch.equal(split, fp32)                    # two different arithmetic paths really ran
+        lean = torch.from_numpy(pack_state(state, layout=LAYOUT_LEAN)).cuda()
+        with pytest.raises(_lib.ReadHipError, match="lean"):
+            UNetEngine(lean, H, W)
+    finally:
+        _lib.check(_lib.lib().read_tuning_set(b"conv_w4h", 32))
+
+
 def test_lean_weight_blob_renders_the_same_frame(hip):
     """the lean packed blob (the F(4x4) layers carry their F(4x4) order only: 451 of 952 MB) gives the frame of the
     full blob bit for bit — same plan, same kernels, fewer bytes resident —, is what FrameRenderer and the UNet module pack by
