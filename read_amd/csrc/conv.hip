@@ -1985,7 +1985,8 @@ typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
 
 // ABL (attribution probes, results invalid; -DREAD_DEBUG_KNOBS builds only, read_tuning_set("conv_abl")): 1 no transform arithmetic,
 // 2 no split arithmetic, 4 no V stores, 8 no patch loads, 32 weights loaded once, 64 B operands loaded once, 128 no epilogue,
-// 256 no barrier, 512 no 2^-11 Uh products, 1024 no MFMAs, 2048 / 4096 patch / weight loads from one cache-resident address
+// 256 no barrier, 512 no 2^-11 Uh products, 1024 no MFMAs, 2048 / 4096 patch / weight loads from one cache-resident address,
+// epilogue: 8192 no residual loads, 16384 one store instead of eight, 32768 no exp / rcp, 65536 no output transform
 template <int ABL = 0>
 __global__ __launch_bounds__(256, 1) void gated_conv_wino4h_kernel(const ConvKArgs a)
 {
@@ -2267,11 +2268,14 @@ __global__ __launch_bounds__(256, 1) void gated_conv_wino4h_kernel(const ConvKAr
 #pragma unroll
             for (int px = 0; px < 4; ++px) {
                 rv[py][px] = f32x4{0.f, 0.f, 0.f, 0.f};
-                if (a.residual)
+                if (a.residual && !(ABL & 8192))
                     rv[py][px] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(res_rsrc, rvoff[py][px], 0, 0));
             }
         f32x4 Y[4][4];
-        {
+        if (ABL & 65536) {
+#pragma unroll
+            for (int i = 0; i < 16; ++i) Y[i >> 2][i & 3] = acc[i] + acc[16 + i] + acc[20 + i];
+        } else {
             f32x4 R[4][6];
 #pragma unroll
             for (int nu = 0; nu < 6; ++nu) {
@@ -2317,18 +2321,22 @@ __global__ __launch_bounds__(256, 1) void gated_conv_wino4h_kernel(const ConvKAr
                     const f32x4 fe = f * LOG2E;
                     f32x4 e;
 #pragma unroll
-                    for (int k = 0; k < 4; ++k) e[k] = __builtin_amdgcn_exp2f(fe[k]);
+                    for (int k = 0; k < 4; ++k) e[k] = (ABL & 32768) ? fe[k] * 0.5f : __builtin_amdgcn_exp2f(fe[k]);
                     e = e + f32x4{-1.0f, -1.0f, -1.0f, -1.0f};
 #pragma unroll
                     for (int k = 0; k < 4; ++k) f[k] = f[k] > 0.0f ? f[k] : e[k];
                 }
                 f32x4 sg, t;
 #pragma unroll
-                for (int k = 0; k < 4; ++k) t[k] = __builtin_amdgcn_exp2f(mm[k]);
+                for (int k = 0; k < 4; ++k) t[k] = (ABL & 32768) ? mm[k] * 0.25f : __builtin_amdgcn_exp2f(mm[k]);
                 t = t + f32x4{1.0f, 1.0f, 1.0f, 1.0f};
 #pragma unroll
-                for (int k = 0; k < 4; ++k) sg[k] = __builtin_amdgcn_rcpf(t[k]);
+                for (int k = 0; k < 4; ++k) sg[k] = (ABL & 32768) ? t[k] * 0.125f : __builtin_amdgcn_rcpf(t[k]);
                 const f32x4 v = (f * sg) * sc + sh + rv[py][px];
+                if ((ABL & 16384) && (py | px)) {
+                    asm volatile("" :: "v"(v));
+                    continue;
+                }
                 __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), out_rsrc, ovoff[py][px], 0, 0);
             }
         step_tile(by, bx);
@@ -4272,7 +4280,7 @@ int launch_gated_conv(const read_conv_desc *d, hipStream_t stream)
             switch (g_abl) {
 #define READ_ABL_CASE(n) case n: fn4 = gated_conv_wino4h_kernel<n>; break;
             READ_ABL_CASE(1) READ_ABL_CASE(2) READ_ABL_CASE(3) READ_ABL_CASE(4) READ_ABL_CASE(7) READ_ABL_CASE(8) READ_ABL_CASE(15) READ_ABL_CASE(32) READ_ABL_CASE(64)
-            READ_ABL_CASE(128) READ_ABL_CASE(256) READ_ABL_CASE(512) READ_ABL_CASE(1024) READ_ABL_CASE(1007) READ_ABL_CASE(2047 - 1024) READ_ABL_CASE(544) READ_ABL_CASE(2048) READ_ABL_CASE(4096) READ_ABL_CASE(6144) READ_ABL_CASE(40)
+            READ_ABL_CASE(128) READ_ABL_CASE(256) READ_ABL_CASE(512) READ_ABL_CASE(1024) READ_ABL_CASE(1007) READ_ABL_CASE(2047 - 1024) READ_ABL_CASE(544) READ_ABL_CASE(2048) READ_ABL_CASE(4096) READ_ABL_CASE(6144) READ_ABL_CASE(40) READ_ABL_CASE(8192) READ_ABL_CASE(16384) READ_ABL_CASE(24576) READ_ABL_CASE(32768) READ_ABL_CASE(65536) READ_ABL_CASE(122880)
 #undef READ_ABL_CASE
             default: break;
             }
