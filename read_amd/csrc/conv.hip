@@ -3543,8 +3543,9 @@ int find_wave_config(int ks, int s, int kc, int P, int QG)
 // kernels (A/B runs).
 int pick_config(int ks, int s, int kc, int groups, int outH, int outW)
 {
-    (void)outH;
-    (void)outW;
+    // round 6 (tools/sweep_small.py): the sweep behind the table below ran at 1216 x 352; on the SCM chains' quarter- and eighth-
+    // resolution images two entries start too few workgroups to fill the chip
+    const long pixels = (long)outH * outW;
     int c = -1;
     if (ks == 3 && s == 1 && kc == 16) {
         if (groups % 4 == 0 && groups % 8 != 0) c = find_config(3, 1, 16, 2, 2, 2, 2, 1, 2);     // 128 ch: 108.8 TF
@@ -3552,9 +3553,13 @@ int pick_config(int ks, int s, int kc, int groups, int outH, int outW)
         else if (groups % 8 == 0) c = find_config(3, 1, 16, 2, 1, 2, 2, 2, 1);
         else c = find_config(3, 1, 16, 1, 1, 4, 1, 2, 1);
     } else if (ks == 3 && s == 1 && kc == 8) {
-        c = g_prefer_wave ? find_wave_config(3, 1, 8, 2, 1) : find_config(3, 1, 8, 1, 1, 4, 1, 2, 2);
+        // small images: 4 x 32-pixel workgroup tiles (SCM1/0.main.0 at 88 x 304 and 44 x 152: 12.1 -> 9.5, 12.0 -> 9.1 us)
+        c = (g_prefer_wave && pixels > 30000) ? find_wave_config(3, 1, 8, 2, 1) : find_config(3, 1, 8, 1, 1, 4, 1, 2, 2);
     } else if (ks == 1 && s == 1 && kc == 32) {
-        if (groups % 4 == 0) c = find_config(1, 1, 32, 2, 2, 2, 2, 1, 2);      // 91 TF at 128 channels
+        // four groups per workgroup only where that still leaves >= 128 workgroups (SCM0.main.1, 64 -> 128 at 44 x 152: 55
+        // workgroups took 20.0 us, one group per wave-autonomous unit 9.0)
+        const long wgs4 = (long)ceil_div(outW, 32) * ceil_div(outH, 4) * (groups / 4);
+        if (groups % 4 == 0 && wgs4 >= 128) c = find_config(1, 1, 32, 2, 2, 2, 2, 1, 2);      // 91 TF at 128 channels
         else c = find_wave_config(1, 1, 32, 1, 1);                            // 99-103 TF (16-channel chunks: 93-97)
     } else if (ks == 1 && s == 1 && kc == 16) {
         if (groups % 4 == 0) c = find_config(1, 1, 16, 2, 2, 2, 2, 1, 2);

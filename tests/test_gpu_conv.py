@@ -139,6 +139,15 @@ def test_winograd_f4_split_operand_kernel(hip):
         ref = unet_torch.basic_conv(st, "L", x[None], 3, elu=True)[0]
         got = gated_conv(_pack(st, [64]), [(_nhwc(x), 0)], elu=True, config=-7)
         _close(got, ref, f"split-operand F(4x4), activations x {amp}", scale=10.0 * max(1.0, amp))
+    # ... and past the f16 limit of the transformed input (|B^T d B| >= 65504: activations of ~1e4) the kernel fails LOUDLY — Inf / NaN,
+    # never a plausible wrong number — while the fp32-matrix-core kernel (read_tuning_set("conv_w4h", 0) / config -5) takes them
+    st = _state(64, 64, 3, seed=78)
+    x = torch.randn(64, 24, 40) * 2.0e4
+    ref = unet_torch.basic_conv(st, "L", x[None], 3, elu=True)[0]
+    got = gated_conv(_pack(st, [64]), [(_nhwc(x), 0)], elu=True, config=-7)
+    assert not bool(torch.isfinite(got).all()), "activations beyond the f16 range must not produce a finite-looking frame"
+    got32 = gated_conv(_pack(st, [64]), [(_nhwc(x), 0)], elu=True, config=-5)
+    _close(got32, ref, "fp32 F(4x4), activations x 2e4", scale=10.0 * 2.0e4)
 
 
 @pytest.mark.skipif(os.environ.get("READ_AMD_TEST_W4X2") != "1" or os.environ.get("READ_HIP_DEBUG") != "1",
