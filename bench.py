@@ -964,6 +964,7 @@ def fp32_mfma_record(wl, dev):
     x = [f[i][0] for i in range(4)]
     rgba_h = wl.fr.unet.forward(*x, channels=4).clone()            # the headline kernels' frame of these features
     _lib.check(L.read_tuning_set(b"conv_w4h", 0))
+    _lib.check(L.read_tuning_set(b"conv_d3h_fam", 0))
     try:
         eng = UNetEngine(torch.from_numpy(pack_state(wl.state, layout=LAYOUT_FULL)).to(dev), wl.H, wl.W)
         rgba_f = eng.forward(*x, channels=4)
@@ -974,6 +975,7 @@ def fp32_mfma_record(wl, dev):
         del eng
     finally:
         _lib.check(L.read_tuning_set(b"conv_w4h", 32))
+        _lib.check(L.read_tuning_set(b"conv_d3h_fam", 32))
     fam_ms = sum(m for (_, m, _, c) in prof if c)
     fam_exec = sum(fl / {2: 2.25, 4: 4.0}.get(c, 1.0) for (_, _, fl, c) in prof if c)
     d = (rgba_h[:, :, :3] - rgba_f[:, :, :3]).double()
@@ -1125,13 +1127,15 @@ def main():
         # F(2x2,3x3) 1/2.25 (c == 2), F(4x4,3x3) 1/4 (c == 4)
         # ... and the split-operand F(4x4) kernel (c == 5) forms each of those products from THREE f16 piece pairs on the f16 matrix
         # cores: it executes 3/4 of the direct count there.  `gain` = direct count / fp32-product count (what an fp32 kernel would run)
-        gain = {0: 1.0, 1: 1.0, 2: 2.25, 4: 4.0, 5: 4.0}
+        # the direct split-operand kernel (c == 6: FAM's launches) executes every product, three piece pairs each
+        gain = {0: 1.0, 1: 1.0, 2: 2.25, 4: 4.0, 5: 4.0, 6: 1.0}
         c3_exec = sum(fl / gain.get(c, 1.0) for (_, _, fl, c) in prof if c)
         n_wino = sum(1 for (_, _, _, c) in prof if c == 2)
         n_wino4 = sum(1 for (_, _, _, c) in prof if c == 4)
         n_w4h = sum(1 for (_, _, _, c) in prof if c == 5)
         executed_tfs = c3_exec / (c3_ms * 1e-3) / 1e12          # fp32-product equivalent: comparable with rounds 3-5
         all_exec = sum(fl / gain.get(c, 1.0) for (_, _, fl, c) in prof)
+        n_d3h = sum(1 for (_, _, _, c) in prof if c == 6)
         w4h_ms = sum(m for (_, m, _, c) in prof if c == 5)
         w4h_f16_flops = sum(3.0 * fl / 4.0 for (_, _, fl, c) in prof if c == 5)
         w4h_tfs = w4h_f16_flops / (w4h_ms * 1e-3) / 1e12 if n_w4h else None
@@ -1155,8 +1159,9 @@ def main():
                        "frames_in_flight": a.frames_in_flight},
             "roofline": {
                 "kernel": ("gated_conv_wino4h_kernel: Winograd F(4x4,3x3) with split fp32 operands on the f16 matrix cores "
-                           f"({n_w4h} of the {n_c3} launches of the 3x3/s1 C->C family; {n_wino4} on the fp32-matrix-core F(4x4) kernel, "
-                           f"{n_wino} F(2x2), {n_c3 - n_wino - n_wino4 - n_w4h} direct)") if n_w4h else
+                           f"({n_w4h} of the {n_c3} launches of the 3x3/s1 C->C family; {n_d3h} (FAM's x1 * x2) on the direct split-operand kernel "
+                           f"gated_conv_d3h_kernel, {n_wino4} on the fp32-matrix-core F(4x4) kernel, "
+                           f"{n_wino} F(2x2), {n_c3 - n_wino - n_wino4 - n_w4h - n_d3h} direct fp32)") if n_w4h else
                           ("3x3/s1 C->C gated conv family: Winograd kernels on the fp32 matrix cores "
                            f"({n_wino} launches F(2x2,3x3), {n_wino4} launches F(4x4,3x3), {n_c3 - n_wino - n_wino4} direct)"),
                 "bound": "mfma",

@@ -296,6 +296,13 @@ typedef struct read_conv_desc {
                                                fp32 accumulation, three piece pairs per product: fp32-level results — DESIGN.md 3.3 (a+),
                                                profiles/r6_f16split_probe.txt; transformed inputs must stay below 65504 in magnitude,
                                                i.e. activations below ~650); config = -7 forces it where the shape fits */
+    const void *wpacked_d3h;                /* optional: read_conv_pack_d3h_host() output (device): the 3x3 weights themselves as two f16 pieces
+                                               per weight + a power-of-two scale per output row.  Gated 3x3 / stride-1 single-source launches
+                                               with Cin % 32 == 0, Cin >= read_tuning("conv_d3h") (default 32, 0 = never) and Cout % 32 == 0
+                                               (FAM's mul included) then run as a DIRECT convolution on the f16 matrix cores — all nine
+                                               taps, three piece pairs per product, fp32 accumulation: no Winograd transform on either
+                                               side, fp32-level results (DESIGN.md 3.3 (a++)); inputs must stay below 65504 in magnitude;
+                                               config = -8 forces it where the shape fits.  Takes precedence over wpacked_w4h / wpacked_w4 */
 } read_conv_desc;
 
 /* Sizes (in floats) of the packed weight / parameter blocks of one BasicConv. */
@@ -320,6 +327,10 @@ int read_conv_pack_w4_host(int Cin, int Cout, const float *wf, const float *wm, 
  * floats (0: Cin % 32 != 0) — [group][wave][chunk of 32 cin][frequency 36][piece hi | lo][lane][8 halfs], then 1 / scale per output row */
 size_t read_conv_w4h_floats(int Cin, int Cout);
 int read_conv_pack_w4h_host(int Cin, int Cout, const float *wf, const float *wm, void *wpacked_w4h_host);
+/* Direct split-operand 3x3 operand (desc.wpacked_d3h): read_conv_d3h_floats(Cin, Cout) = Cin * 18 * pad32(Cout) + 2 * pad32(Cout) floats
+ * (0: Cin % 32 != 0) — [group][row half][chunk of 32 cin][tap 9][row block 2][piece hi | lo][lane][8 halfs], then 1 / scale per output row */
+size_t read_conv_d3h_floats(int Cin, int Cout);
+int read_conv_pack_d3h_host(int Cin, int Cout, const float *wf, const float *wm, void *wpacked_d3h_host);
 /* Small-Cout order [tap][cin][f0 f1 f2 f3 | m0 m1 m2 m3] (9 * Cin * 8 floats; 0 = the shape has no such order: only Cin = 32,
  * Cout <= 4 has a kernel). */
 size_t read_conv_sc_floats(int Cin, int Cout);
@@ -328,7 +339,8 @@ int read_conv_pack_params_host(int Cout, const float *bf, const float *bm, const
                                const float *beta, const float *mean, const float *var, float eps,
                                float *params_host);
 int read_gated_conv_forward(const read_conv_desc *desc, void *stream);
-/* Which kernel family read_gated_conv_forward takes for this (filled) descriptor under the current tuning knobs: 5 = Winograd
+/* Which kernel family read_gated_conv_forward takes for this (filled) descriptor under the current tuning knobs: 6 = direct 3x3 with
+ * split operands on the f16 matrix cores (reads wpacked_d3h), 5 = Winograd
  * F(4x4,3x3) with split operands on the f16 matrix cores (reads wpacked_w4h), 4 = Winograd F(4x4,3x3) on the fp32 matrix cores
  * (reads wpacked_w4), 2 = Winograd F(2x2,3x3) (reads wpacked_wino), 1 = vector-pipe small-Cout kernel (reads
  * wpacked_sc), 0 = direct implicit GEMM (reads wpacked); -1 = NULL.  A host that packs ONE fragment order per layer asks this before packing (set the pointer it intends to fill to any

@@ -43,6 +43,7 @@ struct ConvKArgs {
     const float *wp_w16;           // the same weights in the order of the wave-autonomous kernel (read_conv_pack_w16_host) or null
     const float *wp_w4;            // Winograd F(4x4,3x3) weights (read_conv_pack_w4_host) or null
     const void *wp_w4h;            // ... split into f16 piece pairs + row scales (read_conv_pack_w4h_host) or null
+    const void *wp_d3h;            // the plain 3x3 weights as f16 piece pairs + row scales (read_conv_pack_d3h_host) or null
     const float *wp_sc;            // [tap][cin][f0..f3 | m0..m3] of a layer with at most four output channels (read_conv_pack_sc_host) or null
     const float *params;
     const float *residual;
@@ -2351,6 +2352,313 @@ __global__ __launch_bounds__(256, 1) void gated_conv_wino4h_kernel(const ConvKAr
 }
 
 // ------------------------------------------------------------------------------------------
+// DIRECT 3x3 / stride-1 gated convolution with split fp32 operands on the f16 matrix cores (round 6, second kernel of the round).
+//
+// Why: the attribution of the split-operand Winograd kernel above (profiles/r6_w4h_ablation.md) — its MFMAs are a fifth of its launch,
+// the rest is what Winograd costs around them: an input transform of 350 vector instructions per (tile, channel pair), 36 / 16
+// times the operand volume of the plain product (288 KiB of weight fragments per 32 channels and unit through one CU's load path),
+// a 144-register accumulator set that pins one wave per SIMD, and an output transform in the epilogue.  Winograd trades 4x fewer
+// multiplications for all that; on v_mfma_f32_16x16x32_f16 a multiplication costs a sixteenth of what it costs on the fp32 cores,
+// so the trade runs the other way: this kernel executes ALL 9 taps (4x the MFMAs of F(4x4): 22.9 us per launch at the measured
+// 8.1 ns per MFMA, the same at every level) and needs none of the above —
+//   * operands as in the Winograd kernel: x = xh + 2^-11 xl (f16 pieces, formed ONCE per input element while the patch is staged into
+//     LDS: 10 vector instructions per float4), w s = wh + wl (host packer, power-of-two row scale), products = (2^-11 wh) xl + wl xh
+//     + wh xh, three MFMAs into one fp32 accumulator; no transform multiplies the input by up to 100, so the f16 range now covers
+//     activations up to 65504 (Winograd: ~650);
+//   * unit = 8 x 32 output pixels x 32 output channels (the Winograd kernels' unit, same persistent walk); EIGHT waves, two per SIMD:
+//     wave (rh = w & 1, pq = w >> 1) owns 32 MFMA rows (channels 16 rh .. 16 rh + 15: two row blocks of 8 conv_f + 8 conv_m
+//     channels) x image rows 2 pq, 2 pq + 1 of the unit (four blocks of 16 consecutive pixels): 32 accumulators;
+//   * per 32 input channels: the 10 x 34 patch (fp32, 1360 float4: three coalesced 16-byte loads per thread) -> f16 pieces ->
+//     X[buffer 2][pixel 340][slot 8 = (piece, channel octet) ^ (x & 7)][8 halfs] = 43.5 KB per buffer; a tap is a shifted read of it
+//     (immediate offsets; ds_read_b128, conflict-free by the swizzle), one B fragment feeds both row blocks;
+//   * weights [group][rh][chunk][tap][row block][wh | wl][lane][8 halfs]: 4 KiB per (chunk, tap) and wave for 48 MFMAs (the Winograd
+//     kernel: 2 KiB per 3), straight from L2 into registers two taps ahead; the four waves of a row half ask for the same lines.
+// FAM's x1 * x2 is a multiplication at staging time.  Epilogue: one v_permlane32_swap per register pair brings conv_f and conv_m of
+// a pixel block together (as everywhere), gate / BatchNorm / residual, 16-byte stores — no output transform.
+struct D3hGeom {
+    static constexpr int IH = 10, IW = 34, NPIX = IH * IW;     // patch of a unit
+    static constexpr int XBUF = NPIX * 32;                     // dwords per buffer: 128 bytes per pixel (hi + lo of 32 channels)
+    static constexpr int NE = NPIX * 8, NI = (NE + 511) / 512; // float4 of a patch chunk: 2720 -> 6 per thread?  (8 float4 per pixel)
+};
+
+// ABL (attribution probes, results invalid; debug library): 1 no patch staging, 2 weights loaded once, 4 B operands read once, 8 no epilogue,
+// 16 no barrier, 32 no 2^-11 wh products
+template <bool MUL, int ABL = 0>
+__global__ __launch_bounds__(512, 1) void gated_conv_d3h_kernel(const ConvKArgs a)
+{
+    using DG = D3hGeom;
+    __shared__ __attribute__((aligned(16))) unsigned lds[2 * DG::XBUF];
+    __shared__ __attribute__((aligned(16))) float epar[6][32];  // the group's epilogue parameters: b_f, -log2e b_m, BN scale, BN shift, 1 / s_f, -log2e / s_m
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6), rh = wv & 1, pq = wv >> 1;
+    const SrcDev s = a.src[0];
+    const int groups = a.CoutPad >> 5, G = gridDim.x;
+    const int g = blockIdx.x % groups;
+    const int n = a.nchunks;                                   // 32-channel chunks
+    constexpr unsigned OOR = 0x80000000u;
+
+    int by = (blockIdx.x / groups) / a.tiles_x, bx = (blockIdx.x / groups) % a.tiles_x;      // running unit
+    int pby = by, pbx = bx, pu = blockIdx.x, pchunk = 0;                                     // staging cursor
+    auto step_tile = [&](int &ty_, int &tx_) {
+        ty_ += a.wino_dby;
+        tx_ += a.wino_dbx;
+        if (tx_ >= a.tiles_x) {
+            tx_ -= a.tiles_x;
+            ++ty_;
+        }
+    };
+
+    // ---- staging: thread = float4 e = tid + 512 i of the patch chunk (pixel e >> 3, channel quad e & 7)
+    int soff[DG::NI];                                          // LDS dword offset of the hi piece (+ buffer); lo = the same ^ 16 dwords
+    unsigned rel[DG::NI], aoff[DG::NI];
+#pragma unroll
+    for (int i = 0; i < DG::NI; ++i) {
+        const int e = tid + i * 512, pix = e >> 3, q4 = e & 7, ppx = pix % DG::IW;
+        soff[i] = pix * 32 + ((((q4 >> 1)) ^ (ppx & 7)) << 2) + ((q4 & 1) << 1);
+        rel[i] = (unsigned)(((pix / DG::IW) * s.W + ppx) * s.C + 4 * q4) * 4u;
+    }
+    const unsigned src_bytes = (unsigned)(a.inH * s.W * s.C) * 4u;
+    const auto rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(s.p), 0, src_bytes, 0x00020000);
+    const auto rsrc_mul = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(MUL ? a.mul : s.p), 0, src_bytes, 0x00020000);
+    auto set_patch = [&]() {
+        const int y0 = pby * 8 - 1, x0 = pbx * 32 - 1;
+        const unsigned base = (unsigned)((y0 * s.W + x0) * s.C) * 4u;          // may wrap: only pixels inside the image use it
+#pragma unroll
+        for (int i = 0; i < DG::NI; ++i) {
+            const int e = tid + i * 512, pix = e >> 3, ppy = pix / DG::IW, ppx = pix % DG::IW;
+            const bool ok = (e < DG::NE) & (ppy >= -y0) & (ppy < a.inH - y0) & (ppx >= -x0) & (ppx < a.inW - x0);
+            aoff[i] = ok ? base + rel[i] : OOR;
+        }
+    };
+    auto advance = [&]() {
+        if (++pchunk == n) {
+            pchunk = 0;
+            if (pu + G < a.n_units) {
+                pu += G;
+                step_tile(pby, pbx);
+            }
+            set_patch();
+        }
+    };
+    float4 st[DG::NI], stm[MUL ? DG::NI : 1];
+    auto gload = [&]() {
+#pragma unroll
+        for (int i = 0; i < DG::NI; ++i) {
+            st[i] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, aoff[i], pchunk * 128, 0));
+            if constexpr (MUL) stm[i] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rsrc_mul, aoff[i], pchunk * 128, 0));
+        }
+    };
+    auto split2 = [](float x, float y, unsigned &hi, unsigned &lo) {
+        float r0, r1;
+        asm("v_cvt_pk_f16_f32 %0, %1, %2" : "=v"(hi) : "v"(x), "v"(y));
+        asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel_hi:[1,0,0]" : "=v"(r0) : "v"(hi), "v"(x));                    // x - f32(hi), exact
+        asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(r1) : "v"(hi), "v"(y));
+        const f32x2 rs = f32x2{r0, r1} * f32x2{2048.0f, 2048.0f};
+        asm("v_cvt_pk_f16_f32 %0, %1, %2" : "=v"(lo) : "v"(rs.x), "v"(rs.y));
+    };
+    auto lwrite = [&](int xb) {                                 // registers -> f16 pieces -> X[xb]
+#pragma unroll
+        for (int i = 0; i < DG::NI; ++i) {
+            if ((DG::NI - 1) * 512 + 511 >= DG::NE && i == DG::NI - 1 && tid + i * 512 >= DG::NE) continue;      // the last round is partial
+            float4 v = st[i];
+            if constexpr (MUL) v = make_float4(v.x * stm[i].x, v.y * stm[i].y, v.z * stm[i].z, v.w * stm[i].w);
+            unsigned h0, l0, h1, l1;
+            split2(v.x, v.y, h0, l0);
+            split2(v.z, v.w, h1, l1);
+            typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+            *reinterpret_cast<u32x2 *>(__builtin_assume_aligned(lds + xb + soff[i], 8)) = u32x2{h0, h1};
+            *reinterpret_cast<u32x2 *>(__builtin_assume_aligned(lds + xb + (soff[i] ^ 16), 8)) = u32x2{l0, l1};
+        }
+    };
+
+    // ---- A operand (weights): [group][rh][chunk][tap][row block 2][piece 2][lane][8 halfs]; ring of three taps, two ahead
+    const char *const wbase = reinterpret_cast<const char *>(a.wp_d3h) + ((size_t)(g * 2 + rh) * n) * (9 * 4096);
+    const auto wrsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<char *>(wbase), 0, (unsigned)n * (9 * 4096), 0x00020000);
+    const unsigned wvoff = lane * 16;
+    u32x4 Wh[3][2], Wl[3][2];
+    auto wload = [&](int slot, int chunk, int tap) {
+#pragma unroll
+        for (int rb = 0; rb < 2; ++rb) {
+            Wh[slot][rb] = __builtin_amdgcn_raw_buffer_load_b128(wrsrc, wvoff, ((chunk * 9 + tap) * 4 + rb * 2) * 1024, 0);
+            Wl[slot][rb] = __builtin_amdgcn_raw_buffer_load_b128(wrsrc, wvoff, ((chunk * 9 + tap) * 4 + rb * 2 + 1) * 1024, 0);
+        }
+    };
+    // ---- B operand: lane (pixel nn of the 16-pixel block, channel octet kq); per tap column dx the swizzled slot differs
+    const int nn = lane & 15, kq = lane >> 4;
+    int bho[3], blo[3];                                         // dword offsets inside a pixel row segment, hi / lo piece
+#pragma unroll
+    for (int dx = 0; dx < 3; ++dx) {
+        bho[dx] = nn * 32 + ((kq ^ ((nn + dx) & 7)) << 2);
+        blo[dx] = nn * 32 + (((4 + kq) ^ ((nn + dx) & 7)) << 2);
+    }
+
+    f32x4 acc[2][4];
+    const auto out_rsrc = __builtin_amdgcn_make_buffer_rsrc(a.out, 0, (unsigned)(a.outH * a.outW * a.out_cstride) * 4u, 0x00020000);
+    const auto res_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(a.residual ? a.residual : a.out), 0,
+                                                            (unsigned)(a.outH * a.outW * a.Cout) * 4u, 0x00020000);
+    const float *const wsc = reinterpret_cast<const float *>(a.wp_d3h) + (size_t)n * 576 * a.CoutPad;       // 1 / s: [f | m][CoutPad]
+
+    // ---- prologue: patch(0) -> X[0]; patch(1) on its way; the first two taps' weights; the epilogue's parameters into LDS (a load
+    // from global memory inside a stage would queue behind, and wait for, the weight stream)
+    if (tid < 192) {
+        constexpr float L2E = 1.44269504088896341f;
+        const int arr = tid >> 5, c = g * 32 + (tid & 31);
+        const float v = arr < 4 ? a.params[arr * a.CoutPad + c] : wsc[(arr - 4) * a.CoutPad + c];
+        epar[arr][tid & 31] = (arr == 1 || arr == 5) ? v * -L2E : v;
+    }
+    set_patch();
+    gload();
+    wload(0, 0, 0);
+    wload(1, 0, 1);
+    lwrite(0);
+    advance();
+    gload();
+    __syncthreads();
+    int x_cur = 0, x_nxt = DG::XBUF;
+
+    // B operands of (tap, pixel block): ring of two, fetched one block ahead; A operands: weights two taps ahead (Wh / Wl ring of
+    // three), 2^-11 wh of the next tap formed during this one.  hipcc sinks a load to its first use unless the order is pinned:
+    // every group of six MFMAs ends in a sched_barrier, the loads sit between the groups.
+    u32x4 Bh[2], Bl[2];
+    auto bload = [&](int slot, int xb, int tap, int pb) {
+        const int dy = tap / 3, dx = tap % 3;
+        const int base = xb + ((2 * pq + (pb >> 1) + dy) * DG::IW + 16 * (pb & 1) + dx) * 32;
+        Bh[slot] = *reinterpret_cast<const u32x4 *>(__builtin_assume_aligned(lds + base + bho[dx], 16));
+        Bl[slot] = *reinterpret_cast<const u32x4 *>(__builtin_assume_aligned(lds + base + blo[dx], 16));
+    };
+    f16x8 As[2][2];                                            // [tap & 1][row block]
+    auto ascale = [&](int tap) {
+        const _Float16 k11 = (_Float16)0x1p-11f;
+#pragma unroll
+        for (int rb = 0; rb < 2; ++rb) As[tap & 1][rb] = __builtin_bit_cast(f16x8, Wh[tap % 3][rb]) * f16x8{k11, k11, k11, k11, k11, k11, k11, k11};
+    };
+    auto lwrite1 = [&](int i, int xb) {
+        if ((DG::NI - 1) * 512 + 511 >= DG::NE && i == DG::NI - 1 && tid + i * 512 >= DG::NE) return;
+        float4 v = st[i];
+        if constexpr (MUL) v = make_float4(v.x * stm[i].x, v.y * stm[i].y, v.z * stm[i].z, v.w * stm[i].w);
+        unsigned h0, l0, h1, l1;
+        split2(v.x, v.y, h0, l0);
+        split2(v.z, v.w, h1, l1);
+        typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+        *reinterpret_cast<u32x2 *>(__builtin_assume_aligned(lds + xb + soff[i], 8)) = u32x2{h0, h1};
+        *reinterpret_cast<u32x2 *>(__builtin_assume_aligned(lds + xb + (soff[i] ^ 16), 8)) = u32x2{l0, l1};
+    };
+    ascale(0);
+    bload(0, x_cur, 0, 0);
+
+    // ---- epilogue of a unit: acc[rb][pb], lane (nn, kq), register r = MFMA row 4 kq + r: kq = 0, 1 -> conv_f of channels 4 kq + r of the
+    // row block, kq = 2, 3 -> conv_m of channels 4 (kq - 2) + r; column nn = pixel 16 (pb & 1) + nn of unit row 2 pq + (pb >> 1).
+    // (Running it as shadow work inside the next unit's first stage — accumulators copied, residual requested at once, one output
+    // behind every fourth MFMA group — was built and measured level: 67.9 / 56.3 / 55.3 / 51.0 us against 64.4 / 58.0 / 52.5 / 49.5; what the
+    // "no epilogue" probe removes at level 0 is the residual's and the output's 110 MB, not instructions.)
+    const int cq = kq & 1, hf = lane >> 5;
+    constexpr float LOG2E = 1.44269504088896341f;
+    auto epilogue = [&]() {
+        f32x4 erv[4];
+        unsigned eovo[4];
+#pragma unroll
+        for (int o = 0; o < 4; ++o) {
+            const int rb = o >> 1, rs = o & 1, c0 = g * 32 + rh * 16 + rb * 8 + 4 * cq;
+            const int oy = by * 8 + 2 * pq + rs, ox = bx * 32 + 16 * hf + nn;
+            const bool in = (oy < a.outH) & (ox < a.outW);
+            const int pix = oy * a.outW + ox;
+            const unsigned rvo = in ? (unsigned)((pix * a.Cout + c0) * 4) : OOR;
+            eovo[o] = in ? (unsigned)((pix * a.out_cstride + c0) * 4) : OOR;
+            erv[o] = f32x4{0.f, 0.f, 0.f, 0.f};
+            if (a.residual) erv[o] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(res_rsrc, rvo, 0, 0));
+        }
+#pragma unroll
+        for (int o = 0; o < 4; ++o) {
+            const int rb = o >> 1, rs = o & 1, cl = rh * 16 + rb * 8 + 4 * cq;
+            const f32x4 bf = *reinterpret_cast<const f32x4 *>(&epar[0][cl]), bml = *reinterpret_cast<const f32x4 *>(&epar[1][cl]);
+            const f32x4 sc = *reinterpret_cast<const f32x4 *>(&epar[2][cl]), sh = *reinterpret_cast<const f32x4 *>(&epar[3][cl]);
+            const f32x4 isf = *reinterpret_cast<const f32x4 *>(&epar[4][cl]), ism = *reinterpret_cast<const f32x4 *>(&epar[5][cl]);
+            // lanes 0..31 hold conv_f, lanes 32..63 conv_m: after the exchange the lower half-wave owns pixel block (rs, 0), the upper
+            // half block (rs, 1), f in one register and m in the other
+            u32x4 u0 = __builtin_bit_cast(u32x4, acc[rb][2 * rs]), u1 = __builtin_bit_cast(u32x4, acc[rb][2 * rs + 1]);
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const auto sw = __builtin_amdgcn_permlane32_swap(u0[k], u1[k], false, false);
+                u0[k] = sw[0];
+                u1[k] = sw[1];
+            }
+            f32x4 f = __builtin_elementwise_fma(__builtin_bit_cast(f32x4, u0), isf, bf);
+            const f32x4 mm = __builtin_elementwise_fma(__builtin_bit_cast(f32x4, u1), ism, bml);
+            if (a.elu) {
+                const f32x4 fe = f * LOG2E;
+                f32x4 e;
+#pragma unroll
+                for (int k = 0; k < 4; ++k) e[k] = __builtin_amdgcn_exp2f(fe[k]);
+                e = e + f32x4{-1.0f, -1.0f, -1.0f, -1.0f};
+#pragma unroll
+                for (int k = 0; k < 4; ++k) f[k] = f[k] > 0.0f ? f[k] : e[k];
+            }
+            f32x4 sg, t;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) t[k] = __builtin_amdgcn_exp2f(mm[k]);
+            t = t + f32x4{1.0f, 1.0f, 1.0f, 1.0f};
+#pragma unroll
+            for (int k = 0; k < 4; ++k) sg[k] = __builtin_amdgcn_rcpf(t[k]);
+            const f32x4 v = (f * sg) * sc + sh + erv[o];
+            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), out_rsrc, eovo[o], 0, 0);
+        }
+    };
+
+    auto stage = [&](int chunk) {
+        const int nchunk = chunk + 1 == n ? 0 : chunk + 1;      // wraps into the next unit (same weights)
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int tap = 0; tap < 9; ++tap) {
+#pragma unroll
+            for (int pb = 0; pb < 4; ++pb) {
+                const int m = tap * 4 + pb, cur = m & 1;
+                // ---- loads for later: B operands of the next block (the first block of the next stage waits for the barrier)
+                if (m + 1 < 36 && !(ABL & 4)) bload(cur ^ 1, x_cur, (m + 1) >> 2, (m + 1) & 3);
+                if (pb == 0 && !(ABL & 2)) {                                            // weights two taps ahead
+                    if (tap + 2 < 9) wload((tap + 2) % 3, chunk, tap + 2);
+                    else wload((tap + 2) % 3, nchunk, tap + 2 - 9);
+                }
+                // the next chunk's patch: registers -> pieces -> the other buffer, one float4 per block from tap 2 on
+                if (m >= 8 && m - 8 < DG::NI && !(ABL & 1)) lwrite1(m - 8, x_nxt);
+                if (pb == 3 && tap < 8 && !(ABL & 32)) ascale(tap + 1);                 // its wh arrived a tap ago (slot (tap + 1) % 3)
+                const f16x8 bh = __builtin_bit_cast(f16x8, Bh[cur]), bl = __builtin_bit_cast(f16x8, Bl[cur]);
+#pragma unroll
+                for (int rb = 0; rb < 2; ++rb) acc[rb][pb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(As[tap & 1][rb], bl, acc[rb][pb], 0, 0, 0);
+#pragma unroll
+                for (int rb = 0; rb < 2; ++rb)
+                    acc[rb][pb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, Wl[tap % 3][rb]), bh, acc[rb][pb], 0, 0, 0);
+#pragma unroll
+                for (int rb = 0; rb < 2; ++rb)
+                    acc[rb][pb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, Wh[tap % 3][rb]), bh, acc[rb][pb], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+        if (!(ABL & 32)) ascale(0);                             // tap 0 of the next stage (nine taps: the parity ring restarts)
+        advance();
+        if (!(ABL & 1)) gload();                                // the patch after next: a whole stage to land
+        if (!(ABL & 16)) __syncthreads();                       // X[x_nxt] complete, X[x_cur] free
+        const int t_ = x_cur;
+        x_cur = x_nxt;
+        x_nxt = t_;
+        if (!(ABL & 4)) bload(0, x_cur, 0, 0);                  // first block of the next stage (the last stage of all reads a valid buffer)
+    };
+
+    for (int u = blockIdx.x; u < a.n_units; u += G) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) acc[i >> 2][i & 3] = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int chunk = 0; chunk < n; ++chunk) stage(chunk);
+        if (ABL & 8) {
+            f32x4 sum = acc[0][0];
+#pragma unroll
+            for (int i = 1; i < 8; ++i) sum += acc[i >> 2][i & 3];
+            if (sum[0] == 12345.678f) a.out[tid] = sum[1] + sum[2] + sum[3];
+        } else
+            epilogue();
+        step_tile(by, bx);
+    }
+}
+
+// ------------------------------------------------------------------------------------------
 // NEGATIVE RESULT, kept in the DEBUG library only (-DREAD_DEBUG_KNOBS, read_tuning_set("conv_w4h_waves", 8)): the split-operand
 // kernel above cut into SPECIALISED waves — eight per workgroup, two per SIMD: waves 0..3 multiply (MFMA stream, weight ring,
 // B operands, epilogue), waves 4..7 produce (patch loads, input transform, split, V stores).  Same arithmetic, operands, LDS layout
@@ -3520,6 +3828,11 @@ int g_w4 = 32;             // read_tuning_set("conv_w4", min Cin): layers with a
 int g_w4h = 32;            // read_tuning_set("conv_w4h", min Cin): F(4x4) layers with Cin % 32 == 0 and at least this many channels take the split-operand
                            // kernel on the f16 matrix cores when its operand was supplied (0 = never: the fp32 kernel)
 int g_w4h_waves = 4;       // debug library only: read_tuning_set("conv_w4h_waves", 8) = the split-operand kernel with specialised waves (measured slower, round 6)
+int g_d3h = 0;             // read_tuning_set("conv_d3h", min Cin): gated 3x3 / stride-1 layers with whole 32-channel chunks and at least this many channels take the
+                           // DIRECT split-operand kernel (f16 matrix cores, all nine taps) when its operand was supplied.  Default 0 (never): on plain
+                           // launches it measured 5 - 15 % slower than the Winograd split-operand kernel (profiles/r6_d3h_ab.md) ...
+int g_d3h_fam = 32;        // read_tuning_set("conv_d3h_fam", min Cin): ... and 11 us FASTER per launch than the fp32 kernel on FAM's x1 * x2 launches, which the
+                           // Winograd split-operand kernel does not take: those run on it (0 = never)
 int g_sc = 8;              // read_tuning_set("conv_sc", 0): the output layer (Cout <= 4) back on the F(2x2) MFMA kernel instead of the vector pipe; other values: conv_set_sc
                            // kernel when its weights were supplied (0 = never)
 int g_abl = 0;             // read_tuning_set("conv_abl", bits): attribution probes of the 16x16x4 Winograd kernels (results invalid); -DREAD_DEBUG_KNOBS builds only
@@ -3852,6 +4165,55 @@ extern "C" int read_conv_pack_w4h_host(int Cin, int Cout, const float *wf, const
     return READ_OK;
 }
 
+// Operand of the direct split-operand kernel (gated_conv_d3h_kernel): the 3x3 weights themselves, scaled per output ROW by the power
+// of two s that puts the row's largest |w s| in [2^14, 2^15), cut into wh = f16(w s) and wl = f16(w s - wh); order
+// [group][row half rh 2][chunk of 32 cin][tap 9 = 3 ky + kx][row block rb 2][piece wh | wl][lane][8 halfs], lane (i = lane & 15,
+// kq = lane >> 4) = row i of the block (i < 8: conv_f of channel 32 g + 16 rh + 8 rb + i, else conv_m of channel ... + i - 8), cin = 32
+// chunk + 8 kq + e; then 2 * CoutPad floats 1 / s ([conv_f rows | conv_m rows]).   (tests/d3h_ref.py)
+extern "C" size_t read_conv_d3h_floats(int Cin, int Cout)
+{
+    if (Cin < 32 || Cin % 32 || Cout < 1) return 0;
+    return (size_t)Cin * 18 * pad32(Cout) + 2 * (size_t)pad32(Cout);
+}
+
+extern "C" int read_conv_pack_d3h_host(int Cin, int Cout, const float *wf, const float *wm, void *out)
+{
+    READ_CHECK_ARG(wf && wm && out, "read_conv_pack_d3h_host: null pointer");
+    READ_CHECK_ARG(Cin >= 32 && Cin % 32 == 0 && Cout >= 1, "read_conv_pack_d3h_host: needs Cin %% 32 == 0 (got %d)", Cin);
+    const int CoutPad = pad32(Cout), nchunks = Cin / 32;
+    unsigned short *h = static_cast<unsigned short *>(out);
+    float *inv = reinterpret_cast<float *>(out) + (size_t)Cin * 18 * CoutPad;
+    for (int row = 0; row < 2 * CoutPad; ++row) {               // row = [f | m] x padded output channel
+        const int fm = row / CoutPad, co = row % CoutPad;
+        const float *k = co < Cout ? (fm ? wm : wf) + (size_t)co * Cin * 9 : nullptr;
+        double mx = 0.0;
+        if (k)
+            for (size_t i = 0; i < (size_t)Cin * 9; ++i) mx = std::fmax(mx, std::fabs((double)k[i]));
+        int ex = 0;
+        if (mx > 0.0 && std::isfinite(mx)) {
+            int e;
+            (void)std::frexp(mx, &e);
+            ex = 15 - e;
+            if (ex > 60) ex = 60;
+            if (ex < -60) ex = -60;
+        }
+        inv[row] = (float)std::ldexp(1.0, -ex);
+        const int g = co / 32, rh = (co % 32) / 16, rb = (co % 16) / 8, i = (co % 8) + 8 * fm;
+        for (int c = 0; c < nchunks; ++c)
+            for (int tap = 0; tap < 9; ++tap)
+                for (int kq = 0; kq < 4; ++kq)
+                    for (int e = 0; e < 8; ++e) {
+                        const double ws = k ? std::ldexp((double)k[(size_t)(32 * c + 8 * kq + e) * 9 + tap], ex) : 0.0;
+                        const unsigned short hi = f16_bits_rtn(ws), lo = f16_bits_rtn(ws - f16_value(hi));
+                        const size_t frag = (((((size_t)(g * 2 + rh) * nchunks + c) * 9 + tap) * 2 + rb) * 2) * 512;     // halfs; 512 per piece
+                        const int lane = i + 16 * kq;
+                        h[frag + (size_t)lane * 8 + e] = hi;
+                        h[frag + 512 + (size_t)lane * 8 + e] = lo;
+                    }
+    }
+    return READ_OK;
+}
+
 // Small-Cout order (gated_conv_smallc_kernel): [tap][cin][f0 f1 f2 f3 | m0 m1 m2 m3], channels >= Cout zero.
 extern "C" size_t read_conv_sc_floats(int Cin, int Cout)
 {
@@ -3901,6 +4263,8 @@ void conv_set_w16(int v) { g_w16 = v != 0; }
 void conv_set_abl(int v) { g_abl = v; }
 void conv_set_w4(int v) { g_w4 = v < 0 ? 0 : v; }
 void conv_set_w4h(int v) { g_w4h = v < 0 ? 0 : v; }
+void conv_set_d3h(int v) { g_d3h = v < 0 ? 0 : v; }
+void conv_set_d3h_fam(int v) { g_d3h_fam = v < 0 ? 0 : v; }
 void conv_set_w4h_waves(int v) { g_w4h_waves = v == 4 ? 4 : 8; }
 void conv_set_w4_grid(int v) { g_w4_grid = v != 0; }
 void conv_set_wino_wgs(int v) { g_wino_wgs = v <= 1 ? 1 : 2; }
@@ -3922,6 +4286,8 @@ int conv_get(const char *key, int *value)
     else if (!strcmp(key, "conv_w16")) *value = g_w16;
     else if (!strcmp(key, "conv_w4")) *value = g_w4;
     else if (!strcmp(key, "conv_w4h")) *value = g_w4h;
+    else if (!strcmp(key, "conv_d3h")) *value = g_d3h;
+    else if (!strcmp(key, "conv_d3h_fam")) *value = g_d3h_fam;
 #ifdef READ_DEBUG_KNOBS
     else if (!strcmp(key, "conv_w4h_waves")) *value = g_w4h_waves;
 #endif
@@ -3947,6 +4313,7 @@ void conv_set_trace(void *buf, size_t bytes)
 int conv_uses_wino(const read_conv_desc *d);
 int conv_uses_w4(const read_conv_desc *d);
 int conv_uses_w4h(const read_conv_desc *d);
+int conv_uses_d3h(const read_conv_desc *d);
 int conv_uses_sc(const read_conv_desc *d);
 
 int launch_gated_conv(const read_conv_desc *d, hipStream_t stream)
@@ -3957,7 +4324,7 @@ int launch_gated_conv(const read_conv_desc *d, hipStream_t stream)
     READ_CHECK_ARG(d->ksize == 1 || d->ksize == 3 || d->ksize == 4, "read_gated_conv_forward: ksize must be 1,3,4");
     READ_CHECK_ARG(d->stride == 1 || d->stride == 2, "read_gated_conv_forward: stride must be 1 or 2");
     READ_CHECK_ARG(d->inH >= 1 && d->inW >= 1 && d->Cout >= 1, "read_gated_conv_forward: bad sizes");
-    READ_CHECK_ARG((d->wpacked || d->wpacked_w4 || d->wpacked_w4h || d->wpacked_wino) && d->params && d->out, "read_gated_conv_forward: null weights/params/out");
+    READ_CHECK_ARG((d->wpacked || d->wpacked_w4 || d->wpacked_w4h || d->wpacked_d3h || d->wpacked_wino) && d->params && d->out, "read_gated_conv_forward: null weights/params/out");
     READ_CHECK_ARG(d->out_cstride >= (d->linear ? 2 : 1) * d->Cout, "read_gated_conv_forward: out_cstride too small");
     READ_CHECK_ARG(!d->linear || (!d->residual && !d->fill_pad), "read_gated_conv_forward: linear mode takes no residual / fill");
     READ_CHECK_ARG(!d->mul || d->n_src == 1, "read_gated_conv_forward: mul needs a single source");
@@ -3968,12 +4335,12 @@ int launch_gated_conv(const read_conv_desc *d, hipStream_t stream)
         // (the lean UNet blob) must never reach a kernel that reads wpacked as the direct order — a tuning knob changed on a
         // live engine, a 2 GiB tensor or an odd out_cstride can decline the Winograd kernels after the host has packed for them.
         // Checked HERE, for both entry points (read_gated_conv_forward and the UNet executor's direct call).
-        const int family = conv_uses_sc(d) ? 1 : conv_uses_w4h(d) ? 5 : conv_uses_w4(d) ? 4 : conv_uses_wino(d) ? 2 : 0;
+        const int family = conv_uses_sc(d) ? 1 : conv_uses_d3h(d) ? 6 : conv_uses_w4h(d) ? 5 : conv_uses_w4(d) ? 4 : conv_uses_wino(d) ? 2 : 0;
         const bool cfg_wino = d->config >= 0 && d->config < N_CONFIGS && g_configs[d->config].wino;   // forced F(2x2) configs read wpacked_wino
         const bool w16_forced = d->config == -3;
         READ_CHECK_ARG(d->wpacked || family != 0 || cfg_wino || w16_forced,
                        "read_gated_conv_forward: this launch takes a direct kernel and wpacked is NULL (fragment order not packed)");
-        READ_CHECK_ARG(!d->wpacked || (!((const void *)d->wpacked == (const void *)d->wpacked_w4 && family != 4 && family != 5) &&
+        READ_CHECK_ARG(!d->wpacked || (!((const void *)d->wpacked == (const void *)d->wpacked_w4 && family != 4 && family != 5 && family != 6) &&
                                        !((const void *)d->wpacked == (const void *)d->wpacked_wino && family != 2 && !cfg_wino)),
                        "read_gated_conv_forward: wpacked aliases Winograd fragments but the launch takes kernel family %d "
                        "(ask read_conv_kernel_family before packing)", family);
@@ -4233,12 +4600,14 @@ int launch_gated_conv(const read_conv_desc *d, hipStream_t stream)
     }
     conv_fn fn = c.fn;
     // Winograd F(4x4,3x3): units of 8 x 32 pixels x 32 channels, one persistent workgroup per CU
-    const bool w4h = conv_uses_w4h(d);
-    if (w4h || conv_uses_w4(d)) {
-        READ_CHECK_ARG((uintptr_t)(w4h ? d->wpacked_w4h : (const void *)d->wpacked_w4) % 16 == 0, "read_gated_conv_forward: wpacked_w4 / wpacked_w4h misaligned");
+    const bool d3h = conv_uses_d3h(d), w4h = !d3h && conv_uses_w4h(d);
+    if (d3h || w4h || conv_uses_w4(d)) {
+        READ_CHECK_ARG((uintptr_t)(d3h ? d->wpacked_d3h : w4h ? d->wpacked_w4h : (const void *)d->wpacked_w4) % 16 == 0,
+                       "read_gated_conv_forward: wpacked_w4 / wpacked_w4h / wpacked_d3h misaligned");
+        a.wp_d3h = d->wpacked_d3h;
         READ_CHECK_ARG(!d->mul || (uintptr_t)d->mul % 16 == 0, "read_gated_conv_forward: mul misaligned");
         a.wp_w4h = d->wpacked_w4h;
-        if (w4h) a.nchunks = Cin / 32;
+        if (w4h || d3h) a.nchunks = Cin / 32;
         a.tiles_x = ceil_div(outW, 32);
         a.n_units = a.tiles_x * ceil_div(outH, 8) * groups;
         static int n_cu_4 = 0;
@@ -4279,6 +4648,22 @@ int launch_gated_conv(const read_conv_desc *d, hipStream_t stream)
             return READ_OK;
         }
 #endif
+        if (d3h) {
+            conv_fn fnd = d->mul ? gated_conv_d3h_kernel<true> : gated_conv_d3h_kernel<false>;
+#ifdef READ_DEBUG_KNOBS
+            if (!d->mul && g_abl) {
+                switch (g_abl) {
+#define READ_ABL_CASE(n) case n: fnd = gated_conv_d3h_kernel<false, n>; break;
+                READ_ABL_CASE(1) READ_ABL_CASE(2) READ_ABL_CASE(4) READ_ABL_CASE(8) READ_ABL_CASE(16) READ_ABL_CASE(32) READ_ABL_CASE(7) READ_ABL_CASE(63) READ_ABL_CASE(55)
+#undef READ_ABL_CASE
+                default: break;
+                }
+            }
+#endif
+            hipLaunchKernelGGL(fnd, dim3((unsigned)nwg), dim3(512), 0, stream, a);
+            READ_CHECK_LAUNCH();
+            return READ_OK;
+        }
         if (w4h) fn4 = gated_conv_wino4h_kernel<>;
 #ifdef READ_DEBUG_KNOBS
         if (w4h && g_abl) {
@@ -4378,6 +4763,18 @@ int conv_uses_w4h(const read_conv_desc *d)
     return conv_uses_w4(&t);
 }
 
+// the DIRECT split-operand kernel: the same launches (FAM's x1 * x2 included: a multiplication at staging time); config -8 forces it
+int conv_uses_d3h(const read_conv_desc *d)
+{
+    if (!d->wpacked_d3h || d->linear || d->src[0].C % 32 != 0 || d->Cout % 32 != 0) return 0;
+    const int min_c = d->mul ? g_d3h_fam : g_d3h;
+    if (!(d->config == -8 || (d->config == -1 && min_c > 0 && d->src[0].C >= min_c))) return 0;
+    read_conv_desc t = *d;
+    t.config = -5;
+    t.wpacked_w4 = reinterpret_cast<const float *>(d->wpacked_d3h);        // the shape test of the family (any non-null operand)
+    return conv_uses_w4(&t);
+}
+
 // gated 3x3 / stride-1 layers with at most four output channels and 32 input channels (READ's output layer)
 int conv_uses_sc(const read_conv_desc *d)
 {
@@ -4402,6 +4799,7 @@ extern "C" int read_conv_kernel_family(const read_conv_desc *desc)
 {
     if (!desc) return -1;
     if (readhip::conv_uses_sc(desc)) return 1;
+    if (readhip::conv_uses_d3h(desc)) return 6;
     if (readhip::conv_uses_w4h(desc)) return 5;
     if (readhip::conv_uses_w4(desc)) return 4;
     if (readhip::conv_uses_wino(desc)) return 2;

@@ -17,6 +17,7 @@ int launch_gated_conv(const read_conv_desc *d, hipStream_t stream);
 int conv_uses_wino(const read_conv_desc *d);
 int conv_uses_w4(const read_conv_desc *d);
 int conv_uses_w4h(const read_conv_desc *d);
+int conv_uses_d3h(const read_conv_desc *d);
 }
 using namespace readhip;
 
@@ -35,6 +36,7 @@ struct LayerInfo {
     size_t w4_off;                  // Winograd F(4x4,3x3) weights of the 3x3/s1 layers with Cin >= 32 and Cout % 32 == 0, else NO_WINO
     size_t sc_off = ~(size_t)0;     // small-Cout order of the 3x3/s1 layers with Cout <= 4 (the output layer), else NO_WINO
     size_t w4h_off = ~(size_t)0;    // F(4x4) weights split into f16 piece pairs (read_conv_pack_w4h_host) of the w4 layers with Cin % 32 == 0, else NO_WINO
+    size_t d3h_off = ~(size_t)0;    // the plain 3x3 weights as f16 piece pairs (read_conv_pack_d3h_host) of the same layers, else NO_WINO
 };
 constexpr size_t NO_WINO = ~(size_t)0;
 
@@ -95,15 +97,21 @@ Arch build_arch(int layout)
                 L.w16_off = a.packed_floats;
                 a.packed_floats += read_conv_wino_floats(cin, cout);
             }
-            // the split-operand kernel (f16 matrix cores) runs the layer by default — except FAM's x1 * x2 launches (fp32 kernel)
-            const bool w4h = w4 && cin % 32 == 0 && path.compare(0, 3, "FAM") != 0;
-            if (w4 && !(lean && (unused || w4h))) {
+            // the Winograd split-operand kernel (f16 matrix cores) runs the layer by default — except FAM's x1 * x2 launches, which the
+            // DIRECT split-operand kernel takes
+            const bool fam = path.compare(0, 3, "FAM") == 0;
+            const bool w4h = w4 && cin % 32 == 0 && !fam, d3h = w4 && cin % 32 == 0;
+            if (w4 && !(lean && (unused || w4h || (d3h && fam)))) {
                 L.w4_off = a.packed_floats;
                 a.packed_floats += read_conv_w4_floats(cin, cout);
             }
             if (w4h && !(lean && unused)) {
                 L.w4h_off = a.packed_floats;
                 a.packed_floats += read_conv_w4h_floats(cin, cout);
+            }
+            if (d3h && !(lean && (unused || !fam))) {
+                L.d3h_off = a.packed_floats;
+                a.packed_floats += read_conv_d3h_floats(cin, cout);
             }
             if (k == 3 && s == 1 && read_conv_sc_floats(cin, cout) && !(lean && unused)) {
                 a.packed_floats = (a.packed_floats + 15) / 16 * 16;     // 64-byte aligned: scalar loads of 16 dwords
@@ -294,7 +302,7 @@ struct Builder {
     };
     struct LayerRef {
         int cin, cout, k, stride, elu;
-        size_t w_off, p_off, wino_off, w16_off, w4_off, sc_off, w4h_off = ~(size_t)0;
+        size_t w_off, p_off, wino_off, w16_off, w4_off, sc_off, w4h_off = ~(size_t)0, d3h_off = ~(size_t)0;
     };
 
     // One BasicConv.  srcs = {tensor id, shift}; out tensor must already exist.
@@ -303,7 +311,7 @@ struct Builder {
     {
         const Arch &A = arch(u->layout);
         const LayerInfo &L = A.layers[A.find(path)];
-        emit(path, LayerRef{L.cin, L.cout, L.k, L.stride, L.elu, L.w_off, L.p_off, L.wino_off, L.w16_off, L.w4_off, L.sc_off, L.w4h_off}, srcs, out_t, mul_t, res_t, 0,
+        emit(path, LayerRef{L.cin, L.cout, L.k, L.stride, L.elu, L.w_off, L.p_off, L.wino_off, L.w16_off, L.w4_off, L.sc_off, L.w4h_off, L.d3h_off}, srcs, out_t, mul_t, res_t, 0,
              PreRef());
     }
     // A derived 1x1 layer (DerivedInfo): `linear` ones store the pre-activations [f | m] for a finer level to add,
@@ -356,6 +364,7 @@ struct Builder {
         op.d.wpacked_w4 = L.w4_off != NO_WINO ? u->packed + L.w4_off : nullptr;
         op.d.wpacked_sc = L.sc_off != NO_WINO ? u->packed + L.sc_off : nullptr;
         op.d.wpacked_w4h = L.w4h_off != NO_WINO ? u->packed + L.w4h_off : nullptr;
+        op.d.wpacked_d3h = L.d3h_off != NO_WINO ? u->packed + L.d3h_off : nullptr;
         op.d.mul = mul_t >= 0 ? u->tensors[mul_t].p : nullptr;
         op.d.residual = res_t >= 0 ? u->tensors[res_t].p : nullptr;
         op.d.out = o.p;
@@ -667,6 +676,10 @@ extern "C" int read_unet_pack_host_layout(const float *raw, float bn_eps, float 
             rc = read_conv_pack_w4h_host(L.cin, L.cout, wf, wm, packed + L.w4h_off);
             if (rc) return rc;
         }
+        if (L.d3h_off != NO_WINO) {
+            rc = read_conv_pack_d3h_host(L.cin, L.cout, wf, wm, packed + L.d3h_off);
+            if (rc) return rc;
+        }
     }
     const Arch &A = arch(layout);
     for (const DerivedInfo &D : A.derived) {
@@ -734,7 +747,7 @@ extern "C" int read_unet_create_layout(read_unet_t **out, const float *packed, i
     // a lean blob serves exactly the launches the F(4x4) kernel takes under the CURRENT tuning state and at THIS size: a knob
     // that sends such a layer elsewhere (conv_w4), or a tensor of 2 GiB and more, needs the full layout
     for (const Op &op : u->ops)
-        if (op.kind == Op::CONV && !op.d.wpacked && !conv_uses_w4(&op.d) && !conv_uses_w4h(&op.d))
+        if (op.kind == Op::CONV && !op.d.wpacked && !conv_uses_w4(&op.d) && !conv_uses_w4h(&op.d) && !conv_uses_d3h(&op.d))
             set_error("read_unet_create: layer %s is not run by the F(4x4) kernel here and the lean blob carries no other fragment "
                       "order for it (pack with READ_UNET_LAYOUT_FULL)", op.label.c_str());
     if (read_last_error()[0]) {   // the builder reports plan inconsistencies through set_error
@@ -796,7 +809,8 @@ extern "C" int read_unet_profile(read_unet_t *u, const float *x0, const float *x
         if (is_conv3x3_s1)
             // 0: not in the 3x3/s1 C->C family; 1: direct kernel; 2: Winograd F(2x2,3x3); 4: Winograd F(4x4,3x3)
             //    5: Winograd F(4x4,3x3) with split operands on the f16 matrix cores
-            is_conv3x3_s1[i] = u->ops[i].is_c3s1 ? (u->ops[i].kind != Op::CONV ? 1 : conv_uses_w4h(&u->ops[i].d) ? 5 : conv_uses_w4(&u->ops[i].d) ? 4 :
+            //    6: direct 3x3 with split operands on the f16 matrix cores
+            is_conv3x3_s1[i] = u->ops[i].is_c3s1 ? (u->ops[i].kind != Op::CONV ? 1 : conv_uses_d3h(&u->ops[i].d) ? 6 : conv_uses_w4h(&u->ops[i].d) ? 5 : conv_uses_w4(&u->ops[i].d) ? 4 :
                                                      conv_uses_wino(&u->ops[i].d) ? 2 : 1) : 0;
     }
     return READ_OK;

@@ -34,7 +34,7 @@ class PackedGatedConv:
                                                 pp.ctypes.data), "read_conv_pack_params_host")
         self.wpacked = torch.from_numpy(wp).to(device)
         self.params = torch.from_numpy(pp).to(device)
-        self.wpacked_wino = self.wpacked_w16 = self.wpacked_w4 = self.wpacked_sc = self.wpacked_w4h = None
+        self.wpacked_wino = self.wpacked_w16 = self.wpacked_w4 = self.wpacked_sc = self.wpacked_w4h = self.wpacked_d3h = None
         if self.k == 3 and L.read_conv_sc_floats(self.cin, self.cout):      # small-Cout order for the vector-pipe kernel (Cout <= 4)
             sc = np.empty(L.read_conv_sc_floats(self.cin, self.cout), np.float32)
             _lib.check(L.read_conv_pack_sc_host(self.cin, self.cout, wf.ctypes.data, wm.ctypes.data, sc.ctypes.data),
@@ -59,6 +59,10 @@ class PackedGatedConv:
                     _lib.check(L.read_conv_pack_w4h_host(self.cin, self.cout, wf.ctypes.data, wm.ctypes.data, w4h.ctypes.data),
                                "read_conv_pack_w4h_host")
                     self.wpacked_w4h = torch.from_numpy(w4h).to(device)
+                    d3h = np.empty(L.read_conv_d3h_floats(self.cin, self.cout), np.float32)      # ... and the plain weights as f16 piece pairs
+                    _lib.check(L.read_conv_pack_d3h_host(self.cin, self.cout, wf.ctypes.data, wm.ctypes.data, d3h.ctypes.data),
+                               "read_conv_pack_d3h_host")
+                    self.wpacked_d3h = torch.from_numpy(d3h).to(device)
 
 
 def gated_conv(packed, sources, **kw):
@@ -114,6 +118,7 @@ def _desc(packed, sources, stride=1, elu=True, mul=None, residual=None, config=-
     d.wpacked_w4 = packed.wpacked_w4.data_ptr() if packed.wpacked_w4 is not None else None
     d.wpacked_sc = packed.wpacked_sc.data_ptr() if packed.wpacked_sc is not None else None
     d.wpacked_w4h = packed.wpacked_w4h.data_ptr() if packed.wpacked_w4h is not None else None
+    d.wpacked_d3h = packed.wpacked_d3h.data_ptr() if packed.wpacked_d3h is not None else None
     d.linear = 1 if linear else 0
     if pre is not None:
         pt, f_off, m_off, psh = pre[:4]

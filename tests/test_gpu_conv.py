@@ -105,6 +105,53 @@ def test_winograd_f4_kernel(hip):
         _close(got, ref, f"FAM through F(4x4) C={c}", scale=10.0)
 
 
+def test_direct_split_operand_kernel(hip):
+    """The DIRECT 3x3 kernel with split fp32 operands on the f16 matrix cores (config -8; round 6): every tap executed, no Winograd
+    transform — the oracle and shapes of the F(4x4) tests at the DIRECT kernels' tolerance (|diff| <= 2e-5 (1 + |ref|): nothing
+    multiplies by 8 on the way), ragged sizes, border units, several units per workgroup, ELU on / off, residual, FAM's multiply,
+    a wide dynamic range (activations of 1e-3 and of 2e4: no transform amplifies the input, so the f16 range covers them)."""
+    from read_amd import _lib
+    import ctypes
+    from read_amd.gated_conv import conv_desc
+    torch.manual_seed(31)
+    fam = _lib.lib().read_conv_kernel_family
+    for j, (c, H, W) in enumerate([(128, 9, 17), (256, 8, 32), (128, 23, 70), (32, 5, 3), (64, 40, 100), (128, 88, 304), (256, 44, 152),
+                                   (96, 14, 37), (160, 3, 65), (32, 64, 96), (64, 1, 1), (32, 41, 130), (32, 176, 608)]):
+        st = _state(c, c, 3, seed=700 + j)
+        x = torch.randn(c, H, W)
+        res = torch.randn(c, H, W)
+        ref = unet_torch.basic_conv(st, "L", x[None], 3, elu=j % 2 == 0)[0] + res
+        pk = _pack(st, [c])
+        assert pk.wpacked_d3h is not None
+        got = gated_conv(pk, [(_nhwc(x), 0)], elu=j % 2 == 0, residual=_nhwc(res), config=-8)
+        _close(got, ref, f"direct split-operand 3x3 {c}->{c} {H}x{W}")
+    st = _state(64, 64, 3, seed=9)
+    x1 = _nhwc(torch.randn(64, 12, 40))
+    # automatic choice: FAM's x1 * x2 launches run here (11 us faster than the fp32 kernel), plain launches on the Winograd split-operand
+    # kernel (5 - 15 % faster than this one); read_tuning_set("conv_d3h", 32) / config -8 send the plain ones here too
+    assert fam(ctypes.byref(conv_desc(_pack(st, [64]), [(x1, 0)]))) == 5 and fam(ctypes.byref(conv_desc(_pack(st, [64]), [(x1, 0)], mul=x1))) == 6
+    assert fam(ctypes.byref(conv_desc(_pack(st, [64]), [(x1, 0)], config=-8))) == 6
+    for c in (64, 128, 256):                               # FAM: x1 + BC(x1 * x2) through the automatic choice
+        x1, x2 = torch.randn(c, 12, 40), torch.randn(c, 12, 40)
+        st = _state(c, c, 3, seed=c + 7)
+        ref = x1 + unet_torch.basic_conv(st, "L", (x1 * x2)[None], 3, elu=False)[0]
+        got = gated_conv(_pack(st, [c]), [(_nhwc(x1), 0)], elu=False, mul=_nhwc(x2), residual=_nhwc(x1))
+        _close(got, ref, f"FAM through the direct split-operand kernel C={c}")
+    for amp in (1e-3, 300.0, 2.0e4):
+        st = _state(64, 64, 3, seed=77)
+        x = torch.randn(64, 24, 40) * amp
+        ref = unet_torch.basic_conv(st, "L", x[None], 3, elu=True)[0]
+        got = gated_conv(_pack(st, [64]), [(_nhwc(x), 0)], elu=True, config=-8)
+        _close(got, ref, f"direct split-operand 3x3, activations x {amp}", scale=max(1.0, amp))
+    # different output width than input (Cout != Cin) and a second group count
+    for (cin, cout) in ((32, 64), (128, 32), (64, 96)):
+        st = _state(cin, cout, 3, seed=cin + cout)
+        x = torch.randn(cin, 19, 45)
+        ref = unet_torch.basic_conv(st, "L", x[None], 3, elu=True)[0]
+        got = gated_conv(_pack(st, [cin]), [(_nhwc(x), 0)], elu=True, config=-8)
+        _close(got, ref, f"direct split-operand 3x3 {cin}->{cout}")
+
+
 def test_winograd_f4_split_operand_kernel(hip):
     """Winograd F(4x4,3x3) with split fp32 operands on the f16 matrix cores (config -7; round 6): the same shapes, the same oracle
     and the SAME tolerance as the fp32-matrix-core kernel above — two f16 pieces per operand, three piece pairs per product, fp32
@@ -131,7 +178,9 @@ def test_winograd_f4_split_operand_kernel(hip):
     x1 = _nhwc(torch.randn(64, 12, 40))
     d_plain, d_fam = conv_desc(_pack(st, [64]), [(x1, 0)]), conv_desc(_pack(st, [64]), [(x1, 0)], mul=x1)
     import ctypes
-    assert fam(ctypes.byref(d_plain)) == 5 and fam(ctypes.byref(d_fam)) == 4
+    assert fam(ctypes.byref(d_plain)) == 5 and fam(ctypes.byref(d_fam)) == 6       # automatic: FAM goes to the direct split-operand kernel
+    d_plain.config = d_fam.config = -7
+    assert fam(ctypes.byref(d_plain)) == 5 and fam(ctypes.byref(d_fam)) == 0       # the Winograd split-operand kernel does not take FAM's multiply
     # a wide dynamic range: activations of 1e-3 and of 300 (transformed inputs up to ~3e4, below the f16 limit of 65504)
     for amp in (1e-3, 300.0):
         st = _state(64, 64, 3, seed=77)

@@ -302,13 +302,14 @@ def test_headline_frame_1216x352_vs_oracle(hip):
         prof = fr.unet.profile(f[0][0], f[1][0], f[2][0], f[3][0], channels=4)
         kinds = [k for (_, _, _, k) in prof]
         # (round 6: 5 = the F(4x4) kernel with split operands on the f16 matrix cores — every launch of the family but FAM's three,
-        #  which multiply two tensors in the loader and stay on the fp32-matrix-core kernel, 4)
-        assert len(prof) == 105 and kinds.count(5) >= 70 and kinds.count(4) + kinds.count(5) >= 73, (len(prof), kinds.count(5), kinds.count(4), kinds.count(2))
-        assert sum(1 for (lbl, _, fl, k) in prof if abs(fl - 15.778971648e9 * (H / 352)) < 1e6 and k not in (4, 5)) == 0
+        #  which multiply two tensors in the loader and run on the DIRECT split-operand kernel, 6)
+        assert len(prof) == 105 and kinds.count(5) >= 70 and kinds.count(6) == 3 and kinds.count(4) == 0, (len(prof), kinds.count(5), kinds.count(6), kinds.count(4), kinds.count(2))
+        assert sum(1 for (lbl, _, fl, k) in prof if abs(fl - 15.778971648e9 * (H / 352)) < 1e6 and k not in (5, 6)) == 0
 
 
 def test_split_operand_plan_against_the_fp32_plan(hip):
-    """Round 6: the default plan runs 70 of the 73 family launches on the split-operand F(4x4) kernel (f16 matrix cores); with
+    """Round 6: the default plan runs 70 of the 73 family launches on the split-operand F(4x4) kernel (f16 matrix cores) and FAM's three on the
+    direct split-operand kernel; with
     read_tuning_set("conv_w4h", 0) the same blob (full layout) runs them on the fp32-matrix-core kernel.  Both frames against the
     torch-fp32 oracle at the network guard, and against each other; the lean blob carries the split operand only, so the knob is
     refused there (loudly) and the module repacks the full blob."""
@@ -323,13 +324,13 @@ def test_split_operand_plan_against_the_fp32_plan(hip):
     full = torch.from_numpy(pack_state(state, layout=LAYOUT_FULL)).cuda()
     eng = UNetEngine(full, H, W)
     kinds = [k for (_, _, _, k) in eng.profile(*xs)]
-    assert kinds.count(5) >= 70 and kinds.count(4) == 3
+    assert kinds.count(5) >= 70 and kinds.count(6) == 3 and kinds.count(4) == 0
     split = eng.forward(*xs).clone()
     _check_rgb(split.permute(2, 0, 1).cpu(), ref, "split-operand plan")
     try:
         _lib.check(_lib.lib().read_tuning_set(b"conv_w4h", 0))
         kinds = [k for (_, _, _, k) in eng.profile(*xs)]
-        assert kinds.count(5) == 0 and kinds.count(4) >= 73
+        assert kinds.count(5) == 0 and kinds.count(4) >= 70 and kinds.count(6) == 3        # FAM stays on the direct split-operand kernel
         fp32 = eng.forward(*xs).clone()
         _check_rgb(fp32.permute(2, 0, 1).cpu(), ref, "fp32-matrix-core plan")
         _check_rgb(split.permute(2, 0, 1).cpu(), fp32.permute(2, 0, 1).cpu(), "split-operand plan against the fp32 plan")

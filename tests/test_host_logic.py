@@ -65,6 +65,8 @@ def test_aff_weight_blocks_in_the_packed_blob():
                 off += L.read_conv_w4_floats(cin, cout)
                 if cin % 32 == 0 and not path.startswith("FAM"):           # round 6: ... and their split into f16 piece pairs (not FAM's x1 * x2 layers)
                     off += L.read_conv_w4h_floats(cin, cout)
+                if cin % 32 == 0:                                          # ... and the plain weights as f16 piece pairs (the direct kernel; FAM runs on it)
+                    off += L.read_conv_d3h_floats(cin, cout)
         if L.read_conv_sc_floats(cin, cout) and k == 3:                    # the 32 -> 3 layer: the vector-pipe order, 64-byte aligned
             off = (off + 15) // 16 * 16 + L.read_conv_sc_floats(cin, cout)
     aff = lambda *ks: tuple(f"AFFs.{k}.conv.0" for k in ks)                # noqa: E731
@@ -246,6 +248,9 @@ def test_lean_packed_layout_is_a_subset_of_the_full_one():
     assert probe_h in lean_b and probe_h in full_b and probe in full_b and probe not in lean_b
     ff = np.ascontiguousarray(state["FAM2.merge.block.conv_f.weight"], np.float32)
     fm = np.ascontiguousarray(state["FAM2.merge.block.conv_m.weight"], np.float32)
+    d3f = np.empty(L.read_conv_d3h_floats(64, 64), np.float32)               # FAM: the direct split-operand kernel's operand, in both blobs
+    _lib.check(L.read_conv_pack_d3h_host(64, 64, ff.ctypes.data, fm.ctypes.data, d3f.ctypes.data))
+    assert d3f[:64].tobytes() in lean_b and d3f[:64].tobytes() in full_b
     w4f = np.empty(L.read_conv_w4_floats(64, 64), np.float32)
     _lib.check(L.read_conv_pack_w4_host(64, 64, ff.ctypes.data, fm.ctypes.data, w4f.ctypes.data))
-    assert w4f[:64].tobytes() in lean_b
+    assert w4f[:64].tobytes() in full_b and w4f[:64].tobytes() not in lean_b

@@ -83,6 +83,21 @@ def test_split_operand_f4_kernel_keeps_its_registers_and_pipeline(conv_asm):
     assert "gated_conv_wino4h2_kernel" not in conv_asm
 
 
+def test_direct_split_operand_kernel_fits_two_waves_per_simd(conv_asm):
+    """gated_conv_d3h_kernel (round 6): eight waves per workgroup = two per SIMD, so at most 256 registers per wave, no scratch; 216 MFMAs
+    per stage (9 taps x 4 pixel blocks x 2 row blocks x 3 piece pairs); the weight loads stay ahead of their use (hipcc sinks an
+    unpinned load to its first use: the first version waited vmcnt(0) behind every tap's loads)."""
+    for variant in ("gated_conv_d3h_kernelILb0ELi0E", "gated_conv_d3h_kernelILb1ELi0E"):
+        name, body = _function(conv_asm, variant)
+        assert _meta(conv_asm, name, "private_seg_size") == 0, "scratch in the direct split-operand kernel"
+        assert _meta(conv_asm, name, "num_vgpr") + _meta(conv_asm, name, "num_agpr") <= 256
+        assert body.count("v_mfma_f32_16x16x32_f16") == 216
+        lines = [l.strip() for l in body.split("\n")]
+        mf = [i for i, l in enumerate(lines) if l.startswith("v_mfma_f32_16x16x32_f16")]
+        loop = lines[mf[0]:mf[-1]]
+        assert sum(1 for l in loop if l.startswith("s_waitcnt") and "vmcnt(0)" in l) <= 2, "the stage drains its weight loads"
+
+
 def test_training_kernels_count_their_loads(conv_asm, tmp_path_factory):
     for variant in ("gated_conv_wino4_kernelILb0ELi0ELi1E", "gated_conv_wino4_kernelILb0ELi0ELi2E"):
         name, body = _function(conv_asm, variant)

@@ -132,3 +132,28 @@ def test_split_operand_f4_model_and_packer():
     for grp in ([0, 1, 2, 3, 12, 13, 14, 15, 20, 21, 22, 23, 24, 25, 26, 27], [4, 5, 6, 7, 8, 9, 10, 11, 16, 17, 18, 19, 28, 29, 30, 31]):
         for half in (0, 32):
             assert len({int(addr16[l + half]) % 16 for l in grp}) == 16
+
+
+def test_direct_split_operand_packer_and_arithmetic():
+    """The direct split-operand 3x3 kernel's operand (tests/d3h_ref.py): the library's host packer against the NumPy restatement BIT FOR
+    BIT (halfs and row scales), the three-piece-pair arithmetic against conv2d at the DIRECT kernels' tolerance, and the scale rule."""
+    from read_amd import _lib
+    from tests.d3h_ref import pack_d3h_blob, row_scale_exp, split_conv_model
+    rng = np.random.default_rng(8)
+    cin, cout, H, W = 64, 40, 9, 21
+    wf = rng.standard_normal((cout, cin, 3, 3)).astype(np.float32) * 0.1
+    wm = rng.standard_normal((cout, cin, 3, 3)).astype(np.float32) * 0.03
+    wm[5] = 0.0
+    L = _lib.lib()
+    blob = pack_d3h_blob(wf, wm)
+    n = L.read_conv_d3h_floats(cin, cout)
+    assert n == blob.size == cin * 18 * 64 + 2 * 64 and L.read_conv_d3h_floats(48, 32) == 0
+    got = np.zeros(n, np.float32)
+    assert L.read_conv_pack_d3h_host(cin, cout, wf.ctypes.data, wm.ctypes.data, got.ctypes.data) == 0
+    assert np.array_equal(got.view(np.uint32), blob.view(np.uint32)), "library packer != model packer"
+    ex = row_scale_exp(wf)
+    top = np.abs(np.ldexp(wf.astype(np.float64), ex[:, None, None, None])).max(axis=(1, 2, 3))
+    assert np.all((top >= 2.0 ** 14) & (top < 2.0 ** 15))
+    x = rng.standard_normal((H, W, cin)).astype(np.float32)
+    ref = F.conv2d(torch.from_numpy(x).permute(2, 0, 1)[None], torch.from_numpy(wf), padding=1)[0].permute(1, 2, 0).numpy()
+    np.testing.assert_allclose(split_conv_model(x, wf), ref, rtol=2e-5, atol=2e-5)

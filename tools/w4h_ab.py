@@ -25,6 +25,7 @@ def main():
     ap.add_argument("--out", default="")
     ap.add_argument("--levels", default="0,1,2,3")
     ap.add_argument("--mul", type=int, default=0, help="1: the FAM form x1 + BC(x1 * x2) (the kernels' MUL variants)")
+    ap.add_argument("--cfg", type=int, default=-7, help="kernel the probes run on: -7 the Winograd split-operand kernel, -8 the direct one")
     ap.add_argument("--waves", type=int, default=4, help="kernel the probes run on: 4 (the product kernel) / 8 specialised waves")
     ap.add_argument("--abl", default="", help="comma list of conv_abl probe values for the split-operand kernel (READ_HIP_DEBUG=1; results invalid)")
     a = ap.parse_args()
@@ -49,7 +50,9 @@ def main():
                 ref = (unet_torch.basic_conv(st, "L", (xc * x2c if a.mul else xc)[None], 3, elu=True)[0] + rc).permute(1, 2, 0)
         from read_amd import _lib as _l
         dbg = bool(os.environ.get("READ_HIP_DEBUG"))                 # the specialised-wave kernel lives in the debug library only
-        for name, cfg in (("fp32", -5), ("f16x3", -7)) + ((("f16x3w8", -7),) if dbg else ()):
+        for name, cfg in (("fp32", -5), ("f16x3", -7), ("d3h", -8)) + ((("f16x3w8", -7),) if dbg else ()):
+            if cfg == -7 and a.mul:
+                continue                                     # the Winograd split-operand kernel does not take FAM's multiply
             if dbg:
                 _l.check(_l.lib().read_tuning_set(b"conv_w4h_waves", 8 if name.endswith("w8") else 4))
             for _ in range(3):
@@ -73,15 +76,16 @@ def main():
             print(line, flush=True)
         if a.abl:
             from read_amd import _lib
-            _lib.check(_lib.lib().read_tuning_set(b"conv_w4h_waves", a.waves))
+            if a.cfg == -7:
+                _lib.check(_lib.lib().read_tuning_set(b"conv_w4h_waves", a.waves))
             for v in [int(t) for t in a.abl.split(",")]:
                 _lib.check(_lib.lib().read_tuning_set(b"conv_abl", v))
                 for _ in range(3):
-                    gated_conv(pk, [(x, 0)], elu=True, residual=r, config=-7, out=out, mul=x2)
+                    gated_conv(pk, [(x, 0)], elu=True, residual=r, config=a.cfg, out=out, mul=x2)
                 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                 e0.record()
                 for _ in range(a.iters):
-                    gated_conv(pk, [(x, 0)], elu=True, residual=r, config=-7, out=out, mul=x2)
+                    gated_conv(pk, [(x, 0)], elu=True, residual=r, config=a.cfg, out=out, mul=x2)
                 e1.record()
                 e1.synchronize()
                 us = e0.elapsed_time(e1) / a.iters * 1e3
