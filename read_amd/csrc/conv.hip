@@ -2659,6 +2659,297 @@ __global__ __launch_bounds__(512, 1) void gated_conv_d3h_kernel(const ConvKArgs 
 }
 
 // ------------------------------------------------------------------------------------------
+// The direct split-operand kernel at STRIDE 2 (the encoder's three down-sampling layers, feat_extract.1 / .2 / .6: 291 us of the plan on
+// the fp32 direct kernels).  Same operands, weight blob, waves and stage as gated_conv_d3h_kernel; what differs is the geometry:
+//   * unit = 8 x 16 output pixels x 64 output channels (a PAIR of 32-channel groups): wave (rq = w & 3, ph = w >> 2) owns row quarter rq
+//     of the pair (32 MFMA rows) x output rows 4 ph .. 4 ph + 3 (four blocks of 16 pixels = one image row each);
+//   * the 17 x 33 input patch of a unit is stored as its four PARITY PLANES X[plane (y & 1, x & 1)][9][17][slot][8 halfs] (78 KB per
+//     buffer): tap (dy, dx) of output (r, c) reads plane (dy & 1, dx & 1) at (r + (dy >> 1), c + (dx >> 1)) — consecutive output pixels
+//     are consecutive plane pixels, so a B fragment is the same conflict-free ds_read_b128 as at stride 1.
+struct D3hS2Geom {
+    static constexpr int IH = 17, IW = 33, NPIX = IH * IW;     // input patch of a unit
+    static constexpr int PH = 9, PW = 17;                      // a parity plane (the odd planes use 8 rows / 16 columns of it)
+    static constexpr int XBUF = 4 * PH * PW * 32;              // dwords per buffer (78,336 bytes)
+    static constexpr int NE = NPIX * 8, NI = (NE + 511) / 512; // 4488 float4 of a patch chunk: 9 per thread
+};
+
+// ABL: as gated_conv_d3h_kernel
+template <int ABL = 0>
+__global__ __launch_bounds__(512, 1) void gated_conv_d3h_s2_kernel(const ConvKArgs a)
+{
+    using DG = D3hS2Geom;
+    constexpr bool MUL = false;
+    __shared__ __attribute__((aligned(16))) unsigned lds[2 * DG::XBUF];
+    __shared__ __attribute__((aligned(16))) float epar[6][64];  // the group PAIR's epilogue parameters: b_f, -log2e b_m, BN scale, BN shift, 1 / s_f, -log2e / s_m
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6), rq = wv & 3, rh = rq & 1, ph = wv >> 2;    // row quarter of the 64-channel pair, pixel half
+    const SrcDev s = a.src[0];
+    const int groups = a.CoutPad >> 6, G = gridDim.x;              // group PAIRS (64 output channels per unit)
+    const int gp = blockIdx.x % groups, g = gp * 2 + (rq >> 1);
+    const int n = a.nchunks;                                   // 32-channel chunks
+    constexpr unsigned OOR = 0x80000000u;
+
+    int by = (blockIdx.x / groups) / a.tiles_x, bx = (blockIdx.x / groups) % a.tiles_x;      // running unit
+    int pby = by, pbx = bx, pu = blockIdx.x, pchunk = 0;                                     // staging cursor
+    auto step_tile = [&](int &ty_, int &tx_) {
+        ty_ += a.wino_dby;
+        tx_ += a.wino_dbx;
+        if (tx_ >= a.tiles_x) {
+            tx_ -= a.tiles_x;
+            ++ty_;
+        }
+    };
+
+    // ---- staging: thread = float4 e = tid + 512 i of the patch chunk (pixel e >> 3, channel quad e & 7)
+    int soff[DG::NI];                                          // LDS dword offset of the hi piece (+ buffer); lo = the same ^ 16 dwords
+    unsigned rel[DG::NI], aoff[DG::NI];
+#pragma unroll
+    for (int i = 0; i < DG::NI; ++i) {
+        const int e = tid + i * 512, pix = e >> 3, q4 = e & 7, iy = pix / DG::IW, ix = pix % DG::IW;
+        const int plane = (iy & 1) * 2 + (ix & 1), prow = iy >> 1, pcol = ix >> 1;         // the four parity planes of the patch
+        soff[i] = ((plane * DG::PH + prow) * DG::PW + pcol) * 32 + ((((q4 >> 1)) ^ (pcol & 7)) << 2) + ((q4 & 1) << 1);
+        rel[i] = (unsigned)((iy * s.W + ix) * s.C + 4 * q4) * 4u;
+    }
+    const unsigned src_bytes = (unsigned)(a.inH * s.W * s.C) * 4u;
+    const auto rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(s.p), 0, src_bytes, 0x00020000);
+    const auto rsrc_mul = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(MUL ? a.mul : s.p), 0, src_bytes, 0x00020000);
+    auto set_patch = [&]() {
+        const int y0 = pby * 16 - 1, x0 = pbx * 32 - 1;                         // input origin of the 8 x 16 output unit at stride 2
+        const unsigned base = (unsigned)((y0 * s.W + x0) * s.C) * 4u;          // may wrap: only pixels inside the image use it
+#pragma unroll
+        for (int i = 0; i < DG::NI; ++i) {
+            const int e = tid + i * 512, pix = e >> 3, ppy = pix / DG::IW, ppx = pix % DG::IW;
+            const bool ok = (e < DG::NE) & (ppy >= -y0) & (ppy < a.inH - y0) & (ppx >= -x0) & (ppx < a.inW - x0);
+            aoff[i] = ok ? base + rel[i] : OOR;
+        }
+    };
+    auto advance = [&]() {
+        if (++pchunk == n) {
+            pchunk = 0;
+            if (pu + G < a.n_units) {
+                pu += G;
+                step_tile(pby, pbx);
+            }
+            set_patch();
+        }
+    };
+    float4 st[DG::NI], stm[MUL ? DG::NI : 1];
+    auto gload = [&]() {
+#pragma unroll
+        for (int i = 0; i < DG::NI; ++i) {
+            st[i] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, aoff[i], pchunk * 128, 0));
+            if constexpr (MUL) stm[i] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rsrc_mul, aoff[i], pchunk * 128, 0));
+        }
+    };
+    auto split2 = [](float x, float y, unsigned &hi, unsigned &lo) {
+        float r0, r1;
+        asm("v_cvt_pk_f16_f32 %0, %1, %2" : "=v"(hi) : "v"(x), "v"(y));
+        asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel_hi:[1,0,0]" : "=v"(r0) : "v"(hi), "v"(x));                    // x - f32(hi), exact
+        asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(r1) : "v"(hi), "v"(y));
+        const f32x2 rs = f32x2{r0, r1} * f32x2{2048.0f, 2048.0f};
+        asm("v_cvt_pk_f16_f32 %0, %1, %2" : "=v"(lo) : "v"(rs.x), "v"(rs.y));
+    };
+    auto lwrite = [&](int xb) {                                 // registers -> f16 pieces -> X[xb]
+#pragma unroll
+        for (int i = 0; i < DG::NI; ++i) {
+            if ((DG::NI - 1) * 512 + 511 >= DG::NE && i == DG::NI - 1 && tid + i * 512 >= DG::NE) continue;      // the last round is partial
+            float4 v = st[i];
+            if constexpr (MUL) v = make_float4(v.x * stm[i].x, v.y * stm[i].y, v.z * stm[i].z, v.w * stm[i].w);
+            unsigned h0, l0, h1, l1;
+            split2(v.x, v.y, h0, l0);
+            split2(v.z, v.w, h1, l1);
+            typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+            *reinterpret_cast<u32x2 *>(__builtin_assume_aligned(lds + xb + soff[i], 8)) = u32x2{h0, h1};
+            *reinterpret_cast<u32x2 *>(__builtin_assume_aligned(lds + xb + (soff[i] ^ 16), 8)) = u32x2{l0, l1};
+        }
+    };
+
+    // ---- A operand (weights): [group][rh][chunk][tap][row block 2][piece 2][lane][8 halfs]; ring of three taps, two ahead
+    const char *const wbase = reinterpret_cast<const char *>(a.wp_d3h) + ((size_t)(g * 2 + rh) * n) * (9 * 4096);
+    const auto wrsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<char *>(wbase), 0, (unsigned)n * (9 * 4096), 0x00020000);
+    const unsigned wvoff = lane * 16;
+    u32x4 Wh[3][2], Wl[3][2];
+    auto wload = [&](int slot, int chunk, int tap) {
+#pragma unroll
+        for (int rb = 0; rb < 2; ++rb) {
+            Wh[slot][rb] = __builtin_amdgcn_raw_buffer_load_b128(wrsrc, wvoff, ((chunk * 9 + tap) * 4 + rb * 2) * 1024, 0);
+            Wl[slot][rb] = __builtin_amdgcn_raw_buffer_load_b128(wrsrc, wvoff, ((chunk * 9 + tap) * 4 + rb * 2 + 1) * 1024, 0);
+        }
+    };
+    // ---- B operand: lane (pixel nn of the 16-pixel block, channel octet kq); per tap column dx the swizzled slot differs
+    const int nn = lane & 15, kq = lane >> 4;
+    int bho[3], blo[3];                                         // dword offsets inside a pixel row segment, hi / lo piece
+#pragma unroll
+    for (int dx = 0; dx < 3; ++dx) {
+        bho[dx] = nn * 32 + ((kq ^ ((nn + (dx >> 1)) & 7)) << 2);
+        blo[dx] = nn * 32 + (((4 + kq) ^ ((nn + (dx >> 1)) & 7)) << 2);
+    }
+
+    f32x4 acc[2][4];
+    const auto out_rsrc = __builtin_amdgcn_make_buffer_rsrc(a.out, 0, (unsigned)(a.outH * a.outW * a.out_cstride) * 4u, 0x00020000);
+    const auto res_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(a.residual ? a.residual : a.out), 0,
+                                                            (unsigned)(a.outH * a.outW * a.Cout) * 4u, 0x00020000);
+    const float *const wsc = reinterpret_cast<const float *>(a.wp_d3h) + (size_t)n * 576 * a.CoutPad;       // 1 / s: [f | m][CoutPad]
+
+    // ---- prologue: patch(0) -> X[0]; patch(1) on its way; the first two taps' weights; the epilogue's parameters into LDS (a load
+    // from global memory inside a stage would queue behind, and wait for, the weight stream)
+    if (tid < 384) {
+        constexpr float L2E = 1.44269504088896341f;
+        const int arr = tid >> 6, c = gp * 64 + (tid & 63);
+        const float v = arr < 4 ? a.params[arr * a.CoutPad + c] : wsc[(arr - 4) * a.CoutPad + c];
+        epar[arr][tid & 63] = (arr == 1 || arr == 5) ? v * -L2E : v;
+    }
+    set_patch();
+    gload();
+    wload(0, 0, 0);
+    wload(1, 0, 1);
+    lwrite(0);
+    advance();
+    gload();
+    __syncthreads();
+    int x_cur = 0, x_nxt = DG::XBUF;
+
+    // B operands of (tap, pixel block): ring of two, fetched one block ahead; A operands: weights two taps ahead (Wh / Wl ring of
+    // three), 2^-11 wh of the next tap formed during this one.  hipcc sinks a load to its first use unless the order is pinned:
+    // every group of six MFMAs ends in a sched_barrier, the loads sit between the groups.
+    u32x4 Bh[2], Bl[2];
+    auto bload = [&](int slot, int xb, int tap, int pb) {
+        const int dy = tap / 3, dx = tap % 3;                   // output row 4 ph + pb reads plane (dy & 1, dx & 1) at row + (dy >> 1), column + (dx >> 1)
+        const int base = xb + ((((dy & 1) * 2 + (dx & 1)) * DG::PH + 4 * ph + pb + (dy >> 1)) * DG::PW + (dx >> 1)) * 32;
+        Bh[slot] = *reinterpret_cast<const u32x4 *>(__builtin_assume_aligned(lds + base + bho[dx], 16));
+        Bl[slot] = *reinterpret_cast<const u32x4 *>(__builtin_assume_aligned(lds + base + blo[dx], 16));
+    };
+    f16x8 As[2][2];                                            // [tap & 1][row block]
+    auto ascale = [&](int tap) {
+        const _Float16 k11 = (_Float16)0x1p-11f;
+#pragma unroll
+        for (int rb = 0; rb < 2; ++rb) As[tap & 1][rb] = __builtin_bit_cast(f16x8, Wh[tap % 3][rb]) * f16x8{k11, k11, k11, k11, k11, k11, k11, k11};
+    };
+    auto lwrite1 = [&](int i, int xb) {
+        if ((DG::NI - 1) * 512 + 511 >= DG::NE && i == DG::NI - 1 && tid + i * 512 >= DG::NE) return;
+        float4 v = st[i];
+        if constexpr (MUL) v = make_float4(v.x * stm[i].x, v.y * stm[i].y, v.z * stm[i].z, v.w * stm[i].w);
+        unsigned h0, l0, h1, l1;
+        split2(v.x, v.y, h0, l0);
+        split2(v.z, v.w, h1, l1);
+        typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+        *reinterpret_cast<u32x2 *>(__builtin_assume_aligned(lds + xb + soff[i], 8)) = u32x2{h0, h1};
+        *reinterpret_cast<u32x2 *>(__builtin_assume_aligned(lds + xb + (soff[i] ^ 16), 8)) = u32x2{l0, l1};
+    };
+    ascale(0);
+    bload(0, x_cur, 0, 0);
+
+    // ---- epilogue of a unit: acc[rb][pb], lane (nn, kq), register r = MFMA row 4 kq + r: kq = 0, 1 -> conv_f of channels 4 kq + r of the
+    // row block, kq = 2, 3 -> conv_m of channels 4 (kq - 2) + r; column nn = pixel nn of unit row 4 ph + pb.
+    const int cq = kq & 1, hf = lane >> 5;
+    constexpr float LOG2E = 1.44269504088896341f;
+    auto epilogue = [&]() {
+        f32x4 erv[4];
+        unsigned eovo[4];
+#pragma unroll
+        for (int o = 0; o < 4; ++o) {
+            const int rb = o >> 1, rs = o & 1, c0 = gp * 64 + rq * 16 + rb * 8 + 4 * cq;
+            const int oy = by * 8 + 4 * ph + 2 * rs + hf, ox = bx * 16 + nn;          // blocks (2 rs, 2 rs + 1) = two image rows
+            const bool in = (oy < a.outH) & (ox < a.outW);
+            const int pix = oy * a.outW + ox;
+            const unsigned rvo = in ? (unsigned)((pix * a.Cout + c0) * 4) : OOR;
+            eovo[o] = in ? (unsigned)((pix * a.out_cstride + c0) * 4) : OOR;
+            erv[o] = f32x4{0.f, 0.f, 0.f, 0.f};
+            if (a.residual) erv[o] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(res_rsrc, rvo, 0, 0));
+        }
+#pragma unroll
+        for (int o = 0; o < 4; ++o) {
+            const int rb = o >> 1, rs = o & 1, cl = rq * 16 + rb * 8 + 4 * cq;
+            const f32x4 bf = *reinterpret_cast<const f32x4 *>(&epar[0][cl]), bml = *reinterpret_cast<const f32x4 *>(&epar[1][cl]);
+            const f32x4 sc = *reinterpret_cast<const f32x4 *>(&epar[2][cl]), sh = *reinterpret_cast<const f32x4 *>(&epar[3][cl]);
+            const f32x4 isf = *reinterpret_cast<const f32x4 *>(&epar[4][cl]), ism = *reinterpret_cast<const f32x4 *>(&epar[5][cl]);
+            // lanes 0..31 hold conv_f, lanes 32..63 conv_m: after the exchange the lower half-wave owns image row 2 rs of the wave's four, the
+            // upper half row 2 rs + 1, f in one register and m in the other
+            u32x4 u0 = __builtin_bit_cast(u32x4, acc[rb][2 * rs]), u1 = __builtin_bit_cast(u32x4, acc[rb][2 * rs + 1]);
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const auto sw = __builtin_amdgcn_permlane32_swap(u0[k], u1[k], false, false);
+                u0[k] = sw[0];
+                u1[k] = sw[1];
+            }
+            f32x4 f = __builtin_elementwise_fma(__builtin_bit_cast(f32x4, u0), isf, bf);
+            const f32x4 mm = __builtin_elementwise_fma(__builtin_bit_cast(f32x4, u1), ism, bml);
+            if (a.elu) {
+                const f32x4 fe = f * LOG2E;
+                f32x4 e;
+#pragma unroll
+                for (int k = 0; k < 4; ++k) e[k] = __builtin_amdgcn_exp2f(fe[k]);
+                e = e + f32x4{-1.0f, -1.0f, -1.0f, -1.0f};
+#pragma unroll
+                for (int k = 0; k < 4; ++k) f[k] = f[k] > 0.0f ? f[k] : e[k];
+            }
+            f32x4 sg, t;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) t[k] = __builtin_amdgcn_exp2f(mm[k]);
+            t = t + f32x4{1.0f, 1.0f, 1.0f, 1.0f};
+#pragma unroll
+            for (int k = 0; k < 4; ++k) sg[k] = __builtin_amdgcn_rcpf(t[k]);
+            const f32x4 v = (f * sg) * sc + sh + erv[o];
+            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), out_rsrc, eovo[o], 0, 0);
+        }
+    };
+
+    auto stage = [&](int chunk) {
+        const int nchunk = chunk + 1 == n ? 0 : chunk + 1;      // wraps into the next unit (same weights)
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int tap = 0; tap < 9; ++tap) {
+#pragma unroll
+            for (int pb = 0; pb < 4; ++pb) {
+                const int m = tap * 4 + pb, cur = m & 1;
+                // ---- loads for later: B operands of the next block (the first block of the next stage waits for the barrier)
+                if (m + 1 < 36 && !(ABL & 4)) bload(cur ^ 1, x_cur, (m + 1) >> 2, (m + 1) & 3);
+                if (pb == 0 && !(ABL & 2)) {                                            // weights two taps ahead
+                    if (tap + 2 < 9) wload((tap + 2) % 3, chunk, tap + 2);
+                    else wload((tap + 2) % 3, nchunk, tap + 2 - 9);
+                }
+                // the next chunk's patch: registers -> pieces -> the other buffer, one float4 per block from tap 2 on
+                if (m >= 8 && m - 8 < DG::NI && !(ABL & 1)) lwrite1(m - 8, x_nxt);
+                if (pb == 3 && tap < 8 && !(ABL & 32)) ascale(tap + 1);                 // its wh arrived a tap ago (slot (tap + 1) % 3)
+                const f16x8 bh = __builtin_bit_cast(f16x8, Bh[cur]), bl = __builtin_bit_cast(f16x8, Bl[cur]);
+#pragma unroll
+                for (int rb = 0; rb < 2; ++rb) acc[rb][pb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(As[tap & 1][rb], bl, acc[rb][pb], 0, 0, 0);
+#pragma unroll
+                for (int rb = 0; rb < 2; ++rb)
+                    acc[rb][pb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, Wl[tap % 3][rb]), bh, acc[rb][pb], 0, 0, 0);
+#pragma unroll
+                for (int rb = 0; rb < 2; ++rb)
+                    acc[rb][pb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, Wh[tap % 3][rb]), bh, acc[rb][pb], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+        if (!(ABL & 32)) ascale(0);                             // tap 0 of the next stage (nine taps: the parity ring restarts)
+        advance();
+        if (!(ABL & 1)) gload();                                // the patch after next: a whole stage to land
+        if (!(ABL & 16)) __syncthreads();                       // X[x_nxt] complete, X[x_cur] free
+        const int t_ = x_cur;
+        x_cur = x_nxt;
+        x_nxt = t_;
+        if (!(ABL & 4)) bload(0, x_cur, 0, 0);                  // first block of the next stage (the last stage of all reads a valid buffer)
+    };
+
+    for (int u = blockIdx.x; u < a.n_units; u += G) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) acc[i >> 2][i & 3] = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int chunk = 0; chunk < n; ++chunk) stage(chunk);
+        if (ABL & 8) {
+            f32x4 sum = acc[0][0];
+#pragma unroll
+            for (int i = 1; i < 8; ++i) sum += acc[i >> 2][i & 3];
+            if (sum[0] == 12345.678f) a.out[tid] = sum[1] + sum[2] + sum[3];
+        } else
+            epilogue();
+        step_tile(by, bx);
+    }
+}
+
+
+// ------------------------------------------------------------------------------------------
 // NEGATIVE RESULT, kept in the DEBUG library only (-DREAD_DEBUG_KNOBS, read_tuning_set("conv_w4h_waves", 8)): the split-operand
 // kernel above cut into SPECIALISED waves — eight per workgroup, two per SIMD: waves 0..3 multiply (MFMA stream, weight ring,
 // B operands, epilogue), waves 4..7 produce (patch loads, input transform, split, V stores).  Same arithmetic, operands, LDS layout
@@ -3831,6 +4122,7 @@ int g_w4h_waves = 4;       // debug library only: read_tuning_set("conv_w4h_wave
 int g_d3h = 0;             // read_tuning_set("conv_d3h", min Cin): gated 3x3 / stride-1 layers with whole 32-channel chunks and at least this many channels take the
                            // DIRECT split-operand kernel (f16 matrix cores, all nine taps) when its operand was supplied.  Default 0 (never): on plain
                            // launches it measured 5 - 15 % slower than the Winograd split-operand kernel (profiles/r6_d3h_ab.md) ...
+int g_d3h_s2 = 32;         // read_tuning_set("conv_d3h_s2", min Cin): 3x3 / STRIDE-2 layers on the direct split-operand kernel (0 = never: the fp32 direct kernels)
 int g_d3h_fam = 32;        // read_tuning_set("conv_d3h_fam", min Cin): ... and 11 us FASTER per launch than the fp32 kernel on FAM's x1 * x2 launches, which the
                            // Winograd split-operand kernel does not take: those run on it (0 = never)
 int g_sc = 8;              // read_tuning_set("conv_sc", 0): the output layer (Cout <= 4) back on the F(2x2) MFMA kernel instead of the vector pipe; other values: conv_set_sc
@@ -4265,6 +4557,7 @@ void conv_set_w4(int v) { g_w4 = v < 0 ? 0 : v; }
 void conv_set_w4h(int v) { g_w4h = v < 0 ? 0 : v; }
 void conv_set_d3h(int v) { g_d3h = v < 0 ? 0 : v; }
 void conv_set_d3h_fam(int v) { g_d3h_fam = v < 0 ? 0 : v; }
+void conv_set_d3h_s2(int v) { g_d3h_s2 = v < 0 ? 0 : v; }
 void conv_set_w4h_waves(int v) { g_w4h_waves = v == 4 ? 4 : 8; }
 void conv_set_w4_grid(int v) { g_w4_grid = v != 0; }
 void conv_set_wino_wgs(int v) { g_wino_wgs = v <= 1 ? 1 : 2; }
@@ -4288,6 +4581,7 @@ int conv_get(const char *key, int *value)
     else if (!strcmp(key, "conv_w4h")) *value = g_w4h;
     else if (!strcmp(key, "conv_d3h")) *value = g_d3h;
     else if (!strcmp(key, "conv_d3h_fam")) *value = g_d3h_fam;
+    else if (!strcmp(key, "conv_d3h_s2")) *value = g_d3h_s2;
 #ifdef READ_DEBUG_KNOBS
     else if (!strcmp(key, "conv_w4h_waves")) *value = g_w4h_waves;
 #endif
@@ -4314,6 +4608,7 @@ int conv_uses_wino(const read_conv_desc *d);
 int conv_uses_w4(const read_conv_desc *d);
 int conv_uses_w4h(const read_conv_desc *d);
 int conv_uses_d3h(const read_conv_desc *d);
+int conv_uses_d3h_s2(const read_conv_desc *d);
 int conv_uses_sc(const read_conv_desc *d);
 
 int launch_gated_conv(const read_conv_desc *d, hipStream_t stream)
@@ -4335,7 +4630,7 @@ int launch_gated_conv(const read_conv_desc *d, hipStream_t stream)
         // (the lean UNet blob) must never reach a kernel that reads wpacked as the direct order — a tuning knob changed on a
         // live engine, a 2 GiB tensor or an odd out_cstride can decline the Winograd kernels after the host has packed for them.
         // Checked HERE, for both entry points (read_gated_conv_forward and the UNet executor's direct call).
-        const int family = conv_uses_sc(d) ? 1 : conv_uses_d3h(d) ? 6 : conv_uses_w4h(d) ? 5 : conv_uses_w4(d) ? 4 : conv_uses_wino(d) ? 2 : 0;
+        const int family = conv_uses_sc(d) ? 1 : (conv_uses_d3h(d) || conv_uses_d3h_s2(d)) ? 6 : conv_uses_w4h(d) ? 5 : conv_uses_w4(d) ? 4 : conv_uses_wino(d) ? 2 : 0;
         const bool cfg_wino = d->config >= 0 && d->config < N_CONFIGS && g_configs[d->config].wino;   // forced F(2x2) configs read wpacked_wino
         const bool w16_forced = d->config == -3;
         READ_CHECK_ARG(d->wpacked || family != 0 || cfg_wino || w16_forced,
@@ -4599,6 +4894,27 @@ int launch_gated_conv(const read_conv_desc *d, hipStream_t stream)
         grid = dim3((unsigned)(want < cap ? want : cap), 1);
     }
     conv_fn fn = c.fn;
+    // 3x3 / stride 2 on the direct split-operand kernel: units of 8 x 16 output pixels x 64 channels, one persistent workgroup per CU
+    if (conv_uses_d3h_s2(d)) {
+        READ_CHECK_ARG((uintptr_t)d->wpacked_d3h % 16 == 0, "read_gated_conv_forward: wpacked_d3h misaligned");
+        a.wp_d3h = d->wpacked_d3h;
+        a.nchunks = Cin / 32;
+        a.tiles_x = ceil_div(outW, 16);
+        const int pairs = CoutPad / 64;
+        a.n_units = a.tiles_x * ceil_div(outH, 8) * pairs;
+        int dev = 0, n_cu_s = 256;
+        hipDeviceProp_t prop;
+        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0) n_cu_s = prop.multiProcessorCount;
+        int nwg = a.n_units < n_cu_s ? a.n_units : n_cu_s;
+        nwg -= nwg % pairs;
+        if (nwg < pairs) nwg = pairs;
+        a.wino_dby = (nwg / pairs) / a.tiles_x;
+        a.wino_dbx = (nwg / pairs) % a.tiles_x;
+        a.trace = nullptr;
+        hipLaunchKernelGGL(gated_conv_d3h_s2_kernel<>, dim3((unsigned)nwg), dim3(512), 0, stream, a);
+        READ_CHECK_LAUNCH();
+        return READ_OK;
+    }
     // Winograd F(4x4,3x3): units of 8 x 32 pixels x 32 channels, one persistent workgroup per CU
     const bool d3h = conv_uses_d3h(d), w4h = !d3h && conv_uses_w4h(d);
     if (d3h || w4h || conv_uses_w4(d)) {
@@ -4775,6 +5091,17 @@ int conv_uses_d3h(const read_conv_desc *d)
     return conv_uses_w4(&t);
 }
 
+// ... and at stride 2 (the encoder's down-sampling layers): gated 3x3 / stride-2 single-source launches with whole 32-channel chunks in and
+// whole 64-channel pairs out, no multiplier / addend / fill (config -9 forces it; read_tuning_set("conv_d3h_s2", 0) switches it off)
+int conv_uses_d3h_s2(const read_conv_desc *d)
+{
+    const bool shape = d->wpacked_d3h && !d->linear && !d->mul && !d->pre && !d->fill_pad && d->ksize == 3 && d->stride == 2 && d->n_src == 1 &&
+                       d->src[0].shift == 0 && d->src[0].C % 32 == 0 && d->Cout % 64 == 0 && d->out_cstride % 4 == 0 &&
+                       (long long)d->src[0].srcH * d->src[0].srcW * d->src[0].C * 4 < (1ll << 31) &&
+                       (long long)d->inH * d->inW * d->out_cstride * 4 < (1ll << 31);
+    return shape && (d->config == -9 || (d->config == -1 && g_d3h_s2 > 0 && d->src[0].C >= g_d3h_s2));
+}
+
 // gated 3x3 / stride-1 layers with at most four output channels and 32 input channels (READ's output layer)
 int conv_uses_sc(const read_conv_desc *d)
 {
@@ -4799,7 +5126,7 @@ extern "C" int read_conv_kernel_family(const read_conv_desc *desc)
 {
     if (!desc) return -1;
     if (readhip::conv_uses_sc(desc)) return 1;
-    if (readhip::conv_uses_d3h(desc)) return 6;
+    if (readhip::conv_uses_d3h(desc) || readhip::conv_uses_d3h_s2(desc)) return 6;
     if (readhip::conv_uses_w4h(desc)) return 5;
     if (readhip::conv_uses_w4(desc)) return 4;
     if (readhip::conv_uses_wino(desc)) return 2;

@@ -18,6 +18,7 @@ int conv_uses_wino(const read_conv_desc *d);
 int conv_uses_w4(const read_conv_desc *d);
 int conv_uses_w4h(const read_conv_desc *d);
 int conv_uses_d3h(const read_conv_desc *d);
+int conv_uses_d3h_s2(const read_conv_desc *d);
 }
 using namespace readhip;
 
@@ -85,9 +86,10 @@ Arch build_arch(int layout)
             a.raw_floats += raw_layer_floats(cin, cout, k);
             const bool wino = k == 3 && s == 1 && kc == 16 && cin % 16 == 0, w4 = wino && cin >= 32 && cout % 32 == 0;
             const bool unused = path.compare(0, 9, "ConvsOut.") == 0;
+            const bool d3h_s2 = k == 3 && s == 2 && cin % 32 == 0 && cout % 64 == 0;      // the encoder's down-sampling layers: direct split-operand kernel
             L.p_off = a.packed_floats;
             a.packed_floats += read_conv_param_floats(cout);
-            if (!(lean && (w4 || unused))) {
+            if (!(lean && (w4 || unused || d3h_s2))) {
                 L.w_off = a.packed_floats;
                 a.packed_floats += read_conv_packed_floats(cin, cout, k);
             }
@@ -100,7 +102,7 @@ Arch build_arch(int layout)
             // the Winograd split-operand kernel (f16 matrix cores) runs the layer by default — except FAM's x1 * x2 launches, which the
             // DIRECT split-operand kernel takes
             const bool fam = path.compare(0, 3, "FAM") == 0;
-            const bool w4h = w4 && cin % 32 == 0 && !fam, d3h = w4 && cin % 32 == 0;
+            const bool w4h = w4 && cin % 32 == 0 && !fam, d3h = (w4 && cin % 32 == 0) || d3h_s2;
             if (w4 && !(lean && (unused || w4h || (d3h && fam)))) {
                 L.w4_off = a.packed_floats;
                 a.packed_floats += read_conv_w4_floats(cin, cout);
@@ -109,7 +111,7 @@ Arch build_arch(int layout)
                 L.w4h_off = a.packed_floats;
                 a.packed_floats += read_conv_w4h_floats(cin, cout);
             }
-            if (d3h && !(lean && (unused || !fam))) {
+            if (d3h && !(lean && (unused || !(fam || d3h_s2)))) {
                 L.d3h_off = a.packed_floats;
                 a.packed_floats += read_conv_d3h_floats(cin, cout);
             }
@@ -747,7 +749,7 @@ extern "C" int read_unet_create_layout(read_unet_t **out, const float *packed, i
     // a lean blob serves exactly the launches the F(4x4) kernel takes under the CURRENT tuning state and at THIS size: a knob
     // that sends such a layer elsewhere (conv_w4), or a tensor of 2 GiB and more, needs the full layout
     for (const Op &op : u->ops)
-        if (op.kind == Op::CONV && !op.d.wpacked && !conv_uses_w4(&op.d) && !conv_uses_w4h(&op.d) && !conv_uses_d3h(&op.d))
+        if (op.kind == Op::CONV && !op.d.wpacked && !conv_uses_w4(&op.d) && !conv_uses_w4h(&op.d) && !conv_uses_d3h(&op.d) && !conv_uses_d3h_s2(&op.d))
             set_error("read_unet_create: layer %s is not run by the F(4x4) kernel here and the lean blob carries no other fragment "
                       "order for it (pack with READ_UNET_LAYOUT_FULL)", op.label.c_str());
     if (read_last_error()[0]) {   // the builder reports plan inconsistencies through set_error

@@ -143,6 +143,16 @@ def test_direct_split_operand_kernel(hip):
         ref = unet_torch.basic_conv(st, "L", x[None], 3, elu=True)[0]
         got = gated_conv(_pack(st, [64]), [(_nhwc(x), 0)], elu=True, config=-8)
         _close(got, ref, f"direct split-operand 3x3, activations x {amp}", scale=max(1.0, amp))
+    # STRIDE 2 (the encoder's down-sampling layers; gated_conv_d3h_s2_kernel: the patch as four parity planes): even, odd and ragged sizes
+    for j, (cin, cout, H, W) in enumerate([(32, 64, 24, 80), (64, 128, 22, 46), (128, 256, 44, 152), (32, 64, 13, 37), (64, 64, 2, 2),
+                                          (32, 128, 176, 608)]):
+        st = _state(cin, cout, 3, seed=900 + j)
+        x = torch.randn(cin, H, W)
+        ref = unet_torch.basic_conv(st, "L", x[None], 3, stride=2, elu=j % 2 == 0)[0]
+        pk = _pack(st, [cin])
+        assert fam(ctypes.byref(conv_desc(pk, [(_nhwc(x), 0)], stride=2))) == 6
+        got = gated_conv(pk, [(_nhwc(x), 0)], stride=2, elu=j % 2 == 0)
+        _close(got, ref, f"direct split-operand 3x3 / stride 2 {cin}->{cout} {H}x{W}")
     # different output width than input (Cout != Cin) and a second group count
     for (cin, cout) in ((32, 64), (128, 32), (64, 96)):
         st = _state(cin, cout, 3, seed=cin + cout)

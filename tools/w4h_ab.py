@@ -24,6 +24,7 @@ def main():
     ap.add_argument("--check", type=int, default=1)
     ap.add_argument("--out", default="")
     ap.add_argument("--levels", default="0,1,2,3")
+    ap.add_argument("--s2", type=int, default=0, help="1: the three 3x3 / stride-2 layers instead")
     ap.add_argument("--mul", type=int, default=0, help="1: the FAM form x1 + BC(x1 * x2) (the kernels' MUL variants)")
     ap.add_argument("--cfg", type=int, default=-7, help="kernel the probes run on: -7 the Winograd split-operand kernel, -8 the direct one")
     ap.add_argument("--waves", type=int, default=4, help="kernel the probes run on: 4 (the product kernel) / 8 specialised waves")
@@ -31,6 +32,35 @@ def main():
     a = ap.parse_args()
     res = {}
     torch.manual_seed(0)
+    if a.s2:                                                   # the three stride-2 layers: fp32 direct kernels against the split-operand one
+        from read_amd import _lib as _l2
+        for lvl in (0, 1, 2):
+            cin, cout, h, w = 32 << lvl, 64 << lvl, H >> lvl, W >> lvl
+            st = synthetic.make_unet_state([("L", cin, cout, 3)], 1)
+            b = "L.block."
+            pk = PackedGatedConv(st[b + "conv_f.weight"], st[b + "conv_f.bias"], st[b + "conv_m.weight"], st[b + "conv_m.bias"],
+                                 st[b + "norm.weight"], st[b + "norm.bias"], st[b + "norm.running_mean"], st[b + "norm.running_var"],
+                                 src_channels=[cin])
+            xc = torch.randn(cin, h, w)
+            x = xc.permute(1, 2, 0).contiguous().cuda()
+            out = torch.empty(h // 2, w // 2, cout, device="cuda")
+            with torch.no_grad():
+                ref = unet_torch.basic_conv(st, "L", xc[None], 3, stride=2, elu=True)[0].permute(1, 2, 0)
+            for name, knob in (("fp32 direct", 0), ("split direct", 32)):
+                _l2.check(_l2.lib().read_tuning_set(b"conv_d3h_s2", knob))
+                for _ in range(3):
+                    gated_conv(pk, [(x, 0)], stride=2, elu=True, out=out)
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                for _ in range(a.iters):
+                    gated_conv(pk, [(x, 0)], stride=2, elu=True, out=out)
+                e1.record()
+                e1.synchronize()
+                d = out.cpu() - ref
+                print(f"s2 {cin:3d}->{cout:3d} {h}x{w} {name:12s} {e0.elapsed_time(e1) / a.iters * 1e3:8.2f} us   max |diff| {float(d.abs().max()):.3e}   "
+                      f"{10.0 * torch.log10(ref.abs().max().double() ** 2 / float((d.double() ** 2).mean())).item():.1f} dB", flush=True)
+            _l2.check(_l2.lib().read_tuning_set(b"conv_d3h_s2", 32))
+        return
     for lvl in [int(v) for v in a.levels.split(",")]:
         c = 32 << lvl
         h, w = H >> lvl, W >> lvl
