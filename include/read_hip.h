@@ -331,6 +331,11 @@ int read_conv_pack_w4h_host(int Cin, int Cout, const float *wf, const float *wm,
  * (0: Cin % 32 != 0) — [group][row half][chunk of 32 cin][tap 9][row block 2][piece hi | lo][lane][8 halfs], then 1 / scale per output row */
 size_t read_conv_d3h_floats(int Cin, int Cout);
 int read_conv_pack_d3h_host(int Cin, int Cout, const float *wf, const float *wm, void *wpacked_d3h_host);
+/* ... for a k x k kernel, k = 3 or 4 ([tap k * k] in the order above; Cin * 2 * k * k * pad32(Cout) + 2 * pad32(Cout) floats): with stride 2, Cin % 32 == 0
+ * and Cout % 32 == 0 (the encoder's 3x3 / stride-2 and the decoder's 4x4 / stride-2 layers) desc.wpacked_d3h sends the launch to the stride-2 form
+ * of the direct split-operand kernel (read_tuning("conv_d3h_s2"), default 32, 0 = never; config = -9 forces it) */
+size_t read_conv_dkh_floats(int Cin, int Cout, int ksize);
+int read_conv_pack_dkh_host(int Cin, int Cout, int ksize, const float *wf, const float *wm, void *wpacked_host);
 /* Small-Cout order [tap][cin][f0 f1 f2 f3 | m0 m1 m2 m3] (9 * Cin * 8 floats; 0 = the shape has no such order: only Cin = 32,
  * Cout <= 4 has a kernel). */
 size_t read_conv_sc_floats(int Cin, int Cout);

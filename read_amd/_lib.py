@@ -113,6 +113,8 @@ SIGNATURES = {
     "read_conv_pack_w4h_host": (_i, [_i, _i, _vp, _vp, _vp]),
     "read_conv_d3h_floats": (_sz, [_i, _i]),
     "read_conv_pack_d3h_host": (_i, [_i, _i, _vp, _vp, _vp]),
+    "read_conv_dkh_floats": (_sz, [_i, _i, _i]),
+    "read_conv_pack_dkh_host": (_i, [_i, _i, _i, _vp, _vp, _vp]),
     "read_gated_conv_forward": (_i, [C.POINTER(ConvDesc), _vp]),
     "read_conv_kernel_family": (_i, [_vp]),
     "read_conv_sc_floats": (_sz, [_i, _i]),

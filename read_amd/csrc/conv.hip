@@ -2666,25 +2666,29 @@ __global__ __launch_bounds__(512, 1) void gated_conv_d3h_kernel(const ConvKArgs 
 //   * the 17 x 33 input patch of a unit is stored as its four PARITY PLANES X[plane (y & 1, x & 1)][9][17][slot][8 halfs] (78 KB per
 //     buffer): tap (dy, dx) of output (r, c) reads plane (dy & 1, dx & 1) at (r + (dy >> 1), c + (dx >> 1)) — consecutive output pixels
 //     are consecutive plane pixels, so a B fragment is the same conflict-free ds_read_b128 as at stride 1.
+template <int KS>
 struct D3hS2Geom {
-    static constexpr int IH = 17, IW = 33, NPIX = IH * IW;     // input patch of a unit
+    static constexpr int NT = KS * KS, RING = NT % 3 == 0 ? 3 : 4;   // taps; weight ring (NT % RING == 0: static slots across stages)
+    static constexpr int IH = 14 + KS, IW = 30 + KS, NPIX = IH * IW;   // input patch of a unit: 17 x 33 (3 x 3), 18 x 34 (4 x 4)
     static constexpr int PH = 9, PW = 17;                      // a parity plane (the odd planes use 8 rows / 16 columns of it)
     static constexpr int XBUF = 4 * PH * PW * 32;              // dwords per buffer (78,336 bytes)
-    static constexpr int NE = NPIX * 8, NI = (NE + 511) / 512; // 4488 float4 of a patch chunk: 9 per thread
+    static constexpr int NE = NPIX * 8, NI = (NE + 511) / 512; // 4488 / 4896 float4 of a patch chunk: 9 / 10 per thread
 };
 
 // ABL: as gated_conv_d3h_kernel
-template <int ABL = 0>
+// KS = 4: the decoder's 4 x 4 / stride-2 layers (pad 1): sixteen taps, the same four planes (row / column offsets 0, 1)
+template <int KS = 3, int ABL = 0>
 __global__ __launch_bounds__(512, 1) void gated_conv_d3h_s2_kernel(const ConvKArgs a)
 {
-    using DG = D3hS2Geom;
+    using DG = D3hS2Geom<KS>;
+    constexpr int NT = DG::NT, RING = DG::RING;
     constexpr bool MUL = false;
     __shared__ __attribute__((aligned(16))) unsigned lds[2 * DG::XBUF];
     __shared__ __attribute__((aligned(16))) float epar[6][64];  // the group PAIR's epilogue parameters: b_f, -log2e b_m, BN scale, BN shift, 1 / s_f, -log2e / s_m
     const int tid = threadIdx.x, lane = tid & 63;
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6), rq = wv & 3, rh = rq & 1, ph = wv >> 2;    // row quarter of the 64-channel pair, pixel half
     const SrcDev s = a.src[0];
-    const int groups = a.CoutPad >> 6, G = gridDim.x;              // group PAIRS (64 output channels per unit)
+    const int groups = (a.CoutPad + 63) >> 6, G = gridDim.x;       // group PAIRS (64 output channels per unit; the last pair may be half)
     const int gp = blockIdx.x % groups, g = gp * 2 + (rq >> 1);
     const int n = a.nchunks;                                   // 32-channel chunks
     constexpr unsigned OOR = 0x80000000u;
@@ -2765,22 +2769,22 @@ __global__ __launch_bounds__(512, 1) void gated_conv_d3h_s2_kernel(const ConvKAr
     };
 
     // ---- A operand (weights): [group][rh][chunk][tap][row block 2][piece 2][lane][8 halfs]; ring of three taps, two ahead
-    const char *const wbase = reinterpret_cast<const char *>(a.wp_d3h) + ((size_t)(g * 2 + rh) * n) * (9 * 4096);
-    const auto wrsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<char *>(wbase), 0, (unsigned)n * (9 * 4096), 0x00020000);
+    const char *const wbase = reinterpret_cast<const char *>(a.wp_d3h) + ((size_t)(g * 2 + rh) * n) * (NT * 4096);
+    const auto wrsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<char *>(wbase), 0, g < (a.CoutPad >> 5) ? (unsigned)n * (NT * 4096) : 0u, 0x00020000);   // a missing group: every load out of range
     const unsigned wvoff = lane * 16;
-    u32x4 Wh[3][2], Wl[3][2];
+    u32x4 Wh[RING][2], Wl[RING][2];
     auto wload = [&](int slot, int chunk, int tap) {
 #pragma unroll
         for (int rb = 0; rb < 2; ++rb) {
-            Wh[slot][rb] = __builtin_amdgcn_raw_buffer_load_b128(wrsrc, wvoff, ((chunk * 9 + tap) * 4 + rb * 2) * 1024, 0);
-            Wl[slot][rb] = __builtin_amdgcn_raw_buffer_load_b128(wrsrc, wvoff, ((chunk * 9 + tap) * 4 + rb * 2 + 1) * 1024, 0);
+            Wh[slot][rb] = __builtin_amdgcn_raw_buffer_load_b128(wrsrc, wvoff, ((chunk * NT + tap) * 4 + rb * 2) * 1024, 0);
+            Wl[slot][rb] = __builtin_amdgcn_raw_buffer_load_b128(wrsrc, wvoff, ((chunk * NT + tap) * 4 + rb * 2 + 1) * 1024, 0);
         }
     };
     // ---- B operand: lane (pixel nn of the 16-pixel block, channel octet kq); per tap column dx the swizzled slot differs
     const int nn = lane & 15, kq = lane >> 4;
-    int bho[3], blo[3];                                         // dword offsets inside a pixel row segment, hi / lo piece
+    int bho[KS], blo[KS];                                         // dword offsets inside a pixel row segment, hi / lo piece
 #pragma unroll
-    for (int dx = 0; dx < 3; ++dx) {
+    for (int dx = 0; dx < KS; ++dx) {
         bho[dx] = nn * 32 + ((kq ^ ((nn + (dx >> 1)) & 7)) << 2);
         blo[dx] = nn * 32 + (((4 + kq) ^ ((nn + (dx >> 1)) & 7)) << 2);
     }
@@ -2789,14 +2793,14 @@ __global__ __launch_bounds__(512, 1) void gated_conv_d3h_s2_kernel(const ConvKAr
     const auto out_rsrc = __builtin_amdgcn_make_buffer_rsrc(a.out, 0, (unsigned)(a.outH * a.outW * a.out_cstride) * 4u, 0x00020000);
     const auto res_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(a.residual ? a.residual : a.out), 0,
                                                             (unsigned)(a.outH * a.outW * a.Cout) * 4u, 0x00020000);
-    const float *const wsc = reinterpret_cast<const float *>(a.wp_d3h) + (size_t)n * 576 * a.CoutPad;       // 1 / s: [f | m][CoutPad]
+    const float *const wsc = reinterpret_cast<const float *>(a.wp_d3h) + (size_t)n * (64 * NT) * a.CoutPad;       // 1 / s: [f | m][CoutPad]
 
     // ---- prologue: patch(0) -> X[0]; patch(1) on its way; the first two taps' weights; the epilogue's parameters into LDS (a load
     // from global memory inside a stage would queue behind, and wait for, the weight stream)
     if (tid < 384) {
         constexpr float L2E = 1.44269504088896341f;
         const int arr = tid >> 6, c = gp * 64 + (tid & 63);
-        const float v = arr < 4 ? a.params[arr * a.CoutPad + c] : wsc[(arr - 4) * a.CoutPad + c];
+        const float v = c >= a.CoutPad ? 0.0f : arr < 4 ? a.params[arr * a.CoutPad + c] : wsc[(arr - 4) * a.CoutPad + c];
         epar[arr][tid & 63] = (arr == 1 || arr == 5) ? v * -L2E : v;
     }
     set_patch();
@@ -2814,7 +2818,7 @@ __global__ __launch_bounds__(512, 1) void gated_conv_d3h_s2_kernel(const ConvKAr
     // every group of six MFMAs ends in a sched_barrier, the loads sit between the groups.
     u32x4 Bh[2], Bl[2];
     auto bload = [&](int slot, int xb, int tap, int pb) {
-        const int dy = tap / 3, dx = tap % 3;                   // output row 4 ph + pb reads plane (dy & 1, dx & 1) at row + (dy >> 1), column + (dx >> 1)
+        const int dy = tap / KS, dx = tap % KS;                 // output row 4 ph + pb reads plane (dy & 1, dx & 1) at row + (dy >> 1), column + (dx >> 1)
         const int base = xb + ((((dy & 1) * 2 + (dx & 1)) * DG::PH + 4 * ph + pb + (dy >> 1)) * DG::PW + (dx >> 1)) * 32;
         Bh[slot] = *reinterpret_cast<const u32x4 *>(__builtin_assume_aligned(lds + base + bho[dx], 16));
         Bl[slot] = *reinterpret_cast<const u32x4 *>(__builtin_assume_aligned(lds + base + blo[dx], 16));
@@ -2823,7 +2827,7 @@ __global__ __launch_bounds__(512, 1) void gated_conv_d3h_s2_kernel(const ConvKAr
     auto ascale = [&](int tap) {
         const _Float16 k11 = (_Float16)0x1p-11f;
 #pragma unroll
-        for (int rb = 0; rb < 2; ++rb) As[tap & 1][rb] = __builtin_bit_cast(f16x8, Wh[tap % 3][rb]) * f16x8{k11, k11, k11, k11, k11, k11, k11, k11};
+        for (int rb = 0; rb < 2; ++rb) As[tap & 1][rb] = __builtin_bit_cast(f16x8, Wh[tap % RING][rb]) * f16x8{k11, k11, k11, k11, k11, k11, k11, k11};
     };
     auto lwrite1 = [&](int i, int xb) {
         if ((DG::NI - 1) * 512 + 511 >= DG::NE && i == DG::NI - 1 && tid + i * 512 >= DG::NE) return;
@@ -2898,28 +2902,28 @@ __global__ __launch_bounds__(512, 1) void gated_conv_d3h_s2_kernel(const ConvKAr
         const int nchunk = chunk + 1 == n ? 0 : chunk + 1;      // wraps into the next unit (same weights)
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-        for (int tap = 0; tap < 9; ++tap) {
+        for (int tap = 0; tap < NT; ++tap) {
 #pragma unroll
             for (int pb = 0; pb < 4; ++pb) {
                 const int m = tap * 4 + pb, cur = m & 1;
                 // ---- loads for later: B operands of the next block (the first block of the next stage waits for the barrier)
-                if (m + 1 < 36 && !(ABL & 4)) bload(cur ^ 1, x_cur, (m + 1) >> 2, (m + 1) & 3);
+                if (m + 1 < 4 * NT && !(ABL & 4)) bload(cur ^ 1, x_cur, (m + 1) >> 2, (m + 1) & 3);
                 if (pb == 0 && !(ABL & 2)) {                                            // weights two taps ahead
-                    if (tap + 2 < 9) wload((tap + 2) % 3, chunk, tap + 2);
-                    else wload((tap + 2) % 3, nchunk, tap + 2 - 9);
+                    if (tap + 2 < NT) wload((tap + 2) % RING, chunk, tap + 2);
+                    else wload((tap + 2) % RING, nchunk, tap + 2 - NT);
                 }
                 // the next chunk's patch: registers -> pieces -> the other buffer, one float4 per block from tap 2 on
                 if (m >= 8 && m - 8 < DG::NI && !(ABL & 1)) lwrite1(m - 8, x_nxt);
-                if (pb == 3 && tap < 8 && !(ABL & 32)) ascale(tap + 1);                 // its wh arrived a tap ago (slot (tap + 1) % 3)
+                if (pb == 3 && tap < NT - 1 && !(ABL & 32)) ascale(tap + 1);                 // its wh arrived a tap ago (slot (tap + 1) % 3)
                 const f16x8 bh = __builtin_bit_cast(f16x8, Bh[cur]), bl = __builtin_bit_cast(f16x8, Bl[cur]);
 #pragma unroll
                 for (int rb = 0; rb < 2; ++rb) acc[rb][pb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(As[tap & 1][rb], bl, acc[rb][pb], 0, 0, 0);
 #pragma unroll
                 for (int rb = 0; rb < 2; ++rb)
-                    acc[rb][pb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, Wl[tap % 3][rb]), bh, acc[rb][pb], 0, 0, 0);
+                    acc[rb][pb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, Wl[tap % RING][rb]), bh, acc[rb][pb], 0, 0, 0);
 #pragma unroll
                 for (int rb = 0; rb < 2; ++rb)
-                    acc[rb][pb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, Wh[tap % 3][rb]), bh, acc[rb][pb], 0, 0, 0);
+                    acc[rb][pb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, Wh[tap % RING][rb]), bh, acc[rb][pb], 0, 0, 0);
                 __builtin_amdgcn_sched_barrier(0);
             }
         }
@@ -2933,7 +2937,25 @@ __global__ __launch_bounds__(512, 1) void gated_conv_d3h_s2_kernel(const ConvKAr
         if (!(ABL & 4)) bload(0, x_cur, 0, 0);                  // first block of the next stage (the last stage of all reads a valid buffer)
     };
 
+    // a layer with an odd number of 32-channel groups (feat_extract.4: 64 -> 32): the waves of the pair's missing half stage patches and
+    // keep the barriers, nothing else
+    const bool live = g < (a.CoutPad >> 5);
+    auto stage_idle = [&]() {
+#pragma unroll
+        for (int i = 0; i < DG::NI; ++i) lwrite1(i, x_nxt);
+        advance();
+        gload();
+        __syncthreads();
+        const int t_ = x_cur;
+        x_cur = x_nxt;
+        x_nxt = t_;
+    };
     for (int u = blockIdx.x; u < a.n_units; u += G) {
+        if (!live) {
+            for (int chunk = 0; chunk < n; ++chunk) stage_idle();
+            step_tile(by, bx);
+            continue;
+        }
 #pragma unroll
         for (int i = 0; i < 8; ++i) acc[i >> 2][i & 3] = f32x4{0.f, 0.f, 0.f, 0.f};
         for (int chunk = 0; chunk < n; ++chunk) stage(chunk);
@@ -4462,25 +4484,33 @@ extern "C" int read_conv_pack_w4h_host(int Cin, int Cout, const float *wf, const
 // [group][row half rh 2][chunk of 32 cin][tap 9 = 3 ky + kx][row block rb 2][piece wh | wl][lane][8 halfs], lane (i = lane & 15,
 // kq = lane >> 4) = row i of the block (i < 8: conv_f of channel 32 g + 16 rh + 8 rb + i, else conv_m of channel ... + i - 8), cin = 32
 // chunk + 8 kq + e; then 2 * CoutPad floats 1 / s ([conv_f rows | conv_m rows]).   (tests/d3h_ref.py)
-extern "C" size_t read_conv_d3h_floats(int Cin, int Cout)
+extern "C" size_t read_conv_dkh_floats(int Cin, int Cout, int ksize)
 {
-    if (Cin < 32 || Cin % 32 || Cout < 1) return 0;
-    return (size_t)Cin * 18 * pad32(Cout) + 2 * (size_t)pad32(Cout);
+    if (Cin < 32 || Cin % 32 || Cout < 1 || (ksize != 3 && ksize != 4)) return 0;
+    return (size_t)Cin * 2 * ksize * ksize * pad32(Cout) + 2 * (size_t)pad32(Cout);
 }
-
+extern "C" size_t read_conv_d3h_floats(int Cin, int Cout) { return read_conv_dkh_floats(Cin, Cout, 3); }
+extern "C" int read_conv_pack_dkh_host(int Cin, int Cout, int ksize, const float *wf, const float *wm, void *out);
 extern "C" int read_conv_pack_d3h_host(int Cin, int Cout, const float *wf, const float *wm, void *out)
 {
-    READ_CHECK_ARG(wf && wm && out, "read_conv_pack_d3h_host: null pointer");
-    READ_CHECK_ARG(Cin >= 32 && Cin % 32 == 0 && Cout >= 1, "read_conv_pack_d3h_host: needs Cin %% 32 == 0 (got %d)", Cin);
-    const int CoutPad = pad32(Cout), nchunks = Cin / 32;
+    return read_conv_pack_dkh_host(Cin, Cout, 3, wf, wm, out);
+}
+
+// ... the same for a k x k kernel, k = 3 or 4 (tap = k ky + kx): the 4 x 4 / stride-2 layers run on the stride-2 kernel too
+extern "C" int read_conv_pack_dkh_host(int Cin, int Cout, int ksize, const float *wf, const float *wm, void *out)
+{
+    READ_CHECK_ARG(wf && wm && out, "read_conv_pack_dkh_host: null pointer");
+    READ_CHECK_ARG(ksize == 3 || ksize == 4, "read_conv_pack_dkh_host: ksize must be 3 or 4");
+    READ_CHECK_ARG(Cin >= 32 && Cin % 32 == 0 && Cout >= 1, "read_conv_pack_dkh_host: needs Cin %% 32 == 0 (got %d)", Cin);
+    const int CoutPad = pad32(Cout), nchunks = Cin / 32, NT = ksize * ksize;
     unsigned short *h = static_cast<unsigned short *>(out);
-    float *inv = reinterpret_cast<float *>(out) + (size_t)Cin * 18 * CoutPad;
+    float *inv = reinterpret_cast<float *>(out) + (size_t)Cin * 2 * NT * CoutPad;
     for (int row = 0; row < 2 * CoutPad; ++row) {               // row = [f | m] x padded output channel
         const int fm = row / CoutPad, co = row % CoutPad;
-        const float *k = co < Cout ? (fm ? wm : wf) + (size_t)co * Cin * 9 : nullptr;
+        const float *k = co < Cout ? (fm ? wm : wf) + (size_t)co * Cin * NT : nullptr;
         double mx = 0.0;
         if (k)
-            for (size_t i = 0; i < (size_t)Cin * 9; ++i) mx = std::fmax(mx, std::fabs((double)k[i]));
+            for (size_t i = 0; i < (size_t)Cin * NT; ++i) mx = std::fmax(mx, std::fabs((double)k[i]));
         int ex = 0;
         if (mx > 0.0 && std::isfinite(mx)) {
             int e;
@@ -4492,12 +4522,12 @@ extern "C" int read_conv_pack_d3h_host(int Cin, int Cout, const float *wf, const
         inv[row] = (float)std::ldexp(1.0, -ex);
         const int g = co / 32, rh = (co % 32) / 16, rb = (co % 16) / 8, i = (co % 8) + 8 * fm;
         for (int c = 0; c < nchunks; ++c)
-            for (int tap = 0; tap < 9; ++tap)
+            for (int tap = 0; tap < NT; ++tap)
                 for (int kq = 0; kq < 4; ++kq)
                     for (int e = 0; e < 8; ++e) {
-                        const double ws = k ? std::ldexp((double)k[(size_t)(32 * c + 8 * kq + e) * 9 + tap], ex) : 0.0;
+                        const double ws = k ? std::ldexp((double)k[(size_t)(32 * c + 8 * kq + e) * NT + tap], ex) : 0.0;
                         const unsigned short hi = f16_bits_rtn(ws), lo = f16_bits_rtn(ws - f16_value(hi));
-                        const size_t frag = (((((size_t)(g * 2 + rh) * nchunks + c) * 9 + tap) * 2 + rb) * 2) * 512;     // halfs; 512 per piece
+                        const size_t frag = (((((size_t)(g * 2 + rh) * nchunks + c) * NT + tap) * 2 + rb) * 2) * 512;    // halfs; 512 per piece
                         const int lane = i + 16 * kq;
                         h[frag + (size_t)lane * 8 + e] = hi;
                         h[frag + 512 + (size_t)lane * 8 + e] = lo;
@@ -4900,7 +4930,7 @@ int launch_gated_conv(const read_conv_desc *d, hipStream_t stream)
         a.wp_d3h = d->wpacked_d3h;
         a.nchunks = Cin / 32;
         a.tiles_x = ceil_div(outW, 16);
-        const int pairs = CoutPad / 64;
+        const int pairs = (CoutPad + 63) / 64;
         a.n_units = a.tiles_x * ceil_div(outH, 8) * pairs;
         int dev = 0, n_cu_s = 256;
         hipDeviceProp_t prop;
@@ -4911,7 +4941,8 @@ int launch_gated_conv(const read_conv_desc *d, hipStream_t stream)
         a.wino_dby = (nwg / pairs) / a.tiles_x;
         a.wino_dbx = (nwg / pairs) % a.tiles_x;
         a.trace = nullptr;
-        hipLaunchKernelGGL(gated_conv_d3h_s2_kernel<>, dim3((unsigned)nwg), dim3(512), 0, stream, a);
+        if (d->ksize == 4) hipLaunchKernelGGL((gated_conv_d3h_s2_kernel<4>), dim3((unsigned)nwg), dim3(512), 0, stream, a);
+        else hipLaunchKernelGGL((gated_conv_d3h_s2_kernel<3>), dim3((unsigned)nwg), dim3(512), 0, stream, a);
         READ_CHECK_LAUNCH();
         return READ_OK;
     }
@@ -5095,8 +5126,8 @@ int conv_uses_d3h(const read_conv_desc *d)
 // whole 64-channel pairs out, no multiplier / addend / fill (config -9 forces it; read_tuning_set("conv_d3h_s2", 0) switches it off)
 int conv_uses_d3h_s2(const read_conv_desc *d)
 {
-    const bool shape = d->wpacked_d3h && !d->linear && !d->mul && !d->pre && !d->fill_pad && d->ksize == 3 && d->stride == 2 && d->n_src == 1 &&
-                       d->src[0].shift == 0 && d->src[0].C % 32 == 0 && d->Cout % 64 == 0 && d->out_cstride % 4 == 0 &&
+    const bool shape = d->wpacked_d3h && !d->linear && !d->mul && !d->pre && !d->fill_pad && (d->ksize == 3 || d->ksize == 4) && d->stride == 2 && d->n_src == 1 &&
+                       d->src[0].shift == 0 && d->src[0].C % 32 == 0 && d->Cout % 32 == 0 && d->out_cstride % 4 == 0 &&
                        (long long)d->src[0].srcH * d->src[0].srcW * d->src[0].C * 4 < (1ll << 31) &&
                        (long long)d->inH * d->inW * d->out_cstride * 4 < (1ll << 31);
     return shape && (d->config == -9 || (d->config == -1 && g_d3h_s2 > 0 && d->src[0].C >= g_d3h_s2));

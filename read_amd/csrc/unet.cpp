@@ -86,7 +86,7 @@ Arch build_arch(int layout)
             a.raw_floats += raw_layer_floats(cin, cout, k);
             const bool wino = k == 3 && s == 1 && kc == 16 && cin % 16 == 0, w4 = wino && cin >= 32 && cout % 32 == 0;
             const bool unused = path.compare(0, 9, "ConvsOut.") == 0;
-            const bool d3h_s2 = k == 3 && s == 2 && cin % 32 == 0 && cout % 64 == 0;      // the encoder's down-sampling layers: direct split-operand kernel
+            const bool d3h_s2 = (k == 3 || k == 4) && s == 2 && cin % 32 == 0 && cout % 32 == 0;   // down-sampling (3x3) and decoder (4x4) stride-2 layers: direct split-operand kernel
             L.p_off = a.packed_floats;
             a.packed_floats += read_conv_param_floats(cout);
             if (!(lean && (w4 || unused || d3h_s2))) {
@@ -113,7 +113,7 @@ Arch build_arch(int layout)
             }
             if (d3h && !(lean && (unused || !(fam || d3h_s2)))) {
                 L.d3h_off = a.packed_floats;
-                a.packed_floats += read_conv_d3h_floats(cin, cout);
+                a.packed_floats += read_conv_dkh_floats(cin, cout, k);
             }
             if (k == 3 && s == 1 && read_conv_sc_floats(cin, cout) && !(lean && unused)) {
                 a.packed_floats = (a.packed_floats + 15) / 16 * 16;     // 64-byte aligned: scalar loads of 16 dwords
@@ -679,7 +679,7 @@ extern "C" int read_unet_pack_host_layout(const float *raw, float bn_eps, float 
             if (rc) return rc;
         }
         if (L.d3h_off != NO_WINO) {
-            rc = read_conv_pack_d3h_host(L.cin, L.cout, wf, wm, packed + L.d3h_off);
+            rc = read_conv_pack_dkh_host(L.cin, L.cout, L.k, wf, wm, packed + L.d3h_off);
             if (rc) return rc;
         }
     }

@@ -153,6 +153,15 @@ def test_direct_split_operand_kernel(hip):
         assert fam(ctypes.byref(conv_desc(pk, [(_nhwc(x), 0)], stride=2))) == 6
         got = gated_conv(pk, [(_nhwc(x), 0)], stride=2, elu=j % 2 == 0)
         _close(got, ref, f"direct split-operand 3x3 / stride 2 {cin}->{cout} {H}x{W}")
+    # ... and the decoder's 4 x 4 / stride-2 layers (sixteen taps over the same four planes)
+    for j, (cin, cout, H, W) in enumerate([(128, 64, 44, 152), (256, 128, 22, 76), (64, 64, 10, 18), (32, 64, 7, 33), (64, 32, 88, 304), (32, 96, 9, 21)]):
+        st = _state(cin, cout, 4, seed=950 + j)
+        x = torch.randn(cin, H, W)
+        ref = unet_torch.basic_conv(st, "L", x[None], 4, stride=2, elu=j % 2 == 0)[0]
+        pk = _pack(st, [cin])
+        assert fam(ctypes.byref(conv_desc(pk, [(_nhwc(x), 0)], stride=2))) == 6
+        got = gated_conv(pk, [(_nhwc(x), 0)], stride=2, elu=j % 2 == 0)
+        _close(got, ref, f"direct split-operand 4x4 / stride 2 {cin}->{cout} {H}x{W}")
     # different output width than input (Cout != Cin) and a second group count
     for (cin, cout) in ((32, 64), (128, 32), (64, 96)):
         st = _state(cin, cout, 3, seed=cin + cout)

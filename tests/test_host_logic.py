@@ -67,8 +67,8 @@ def test_aff_weight_blocks_in_the_packed_blob():
                     off += L.read_conv_w4h_floats(cin, cout)
                 if cin % 32 == 0:                                          # ... and the plain weights as f16 piece pairs (the direct kernel; FAM runs on it)
                     off += L.read_conv_d3h_floats(cin, cout)
-        if k == 3 and path in ("feat_extract.1", "feat_extract.2", "feat_extract.6"):      # the stride-2 layers: the direct split-operand kernel's operand
-            off += L.read_conv_d3h_floats(cin, cout)
+        if path in ("feat_extract.1", "feat_extract.2", "feat_extract.6", "feat_extract.3", "feat_extract.4", "feat_extract.7"):   # the stride-2 layers
+            off += L.read_conv_dkh_floats(cin, cout, k)                    # (3x3 and 4x4): the direct split-operand kernel's operand
         if L.read_conv_sc_floats(cin, cout) and k == 3:                    # the 32 -> 3 layer: the vector-pipe order, 64-byte aligned
             off = (off + 15) // 16 * 16 + L.read_conv_sc_floats(cin, cout)
     aff = lambda *ks: tuple(f"AFFs.{k}.conv.0" for k in ks)                # noqa: E731
