@@ -302,7 +302,12 @@ typedef struct read_conv_desc {
                                                (FAM's mul included) then run as a DIRECT convolution on the f16 matrix cores — all nine
                                                taps, three piece pairs per product, fp32 accumulation: no Winograd transform on either
                                                side, fp32-level results (DESIGN.md 3.3 (a++)); inputs must stay below 65504 in magnitude;
-                                               config = -8 forces it where the shape fits.  Takes precedence over wpacked_w4h / wpacked_w4 */
+                                               config = -8 forces it where the shape fits.  Takes precedence over wpacked_w4h / wpacked_w4.
+                                               For a 1x1 / stride-1 layer the same field takes read_conv_pack_dkh_host(Cin, Cout, 1, ...): launches
+                                               (gated or linear, concatenated sources, residual, pre-activation addend) with Cin % 16 == 0,
+                                               read_tuning("conv_pxh") (default 16, 0 = never) <= Cin <= 256, Cout % 4 == 0 and 16-byte aligned
+                                               tensors then run on the split-operand pixel-lane kernel (v_mfma_f32_32x32x16_f16, three piece
+                                               pairs per product, fp32 accumulation); config = -10 forces it where the shape fits */
 } read_conv_desc;
 
 /* Sizes (in floats) of the packed weight / parameter blocks of one BasicConv. */
@@ -333,7 +338,9 @@ size_t read_conv_d3h_floats(int Cin, int Cout);
 int read_conv_pack_d3h_host(int Cin, int Cout, const float *wf, const float *wm, void *wpacked_d3h_host);
 /* ... for a k x k kernel, k = 3 or 4 ([tap k * k] in the order above; Cin * 2 * k * k * pad32(Cout) + 2 * pad32(Cout) floats): with stride 2, Cin % 32 == 0
  * and Cout % 32 == 0 (the encoder's 3x3 / stride-2 and the decoder's 4x4 / stride-2 layers) desc.wpacked_d3h sends the launch to the stride-2 form
- * of the direct split-operand kernel (read_tuning("conv_d3h_s2"), default 32, 0 = never; config = -9 forces it) */
+ * of the direct split-operand kernel (read_tuning("conv_d3h_s2"), default 32, 0 = never; config = -9 forces it).
+ * ksize = 1 (Cin % 16 == 0): the 1x1 layers' operand for the split-operand pixel-lane kernel, Cin * 2 * pad32(Cout) + 2 * pad32(Cout) floats,
+ * [k16 step][tile = 2 group + (f | m)][piece hi | lo][lane][8 halfs] (lane = row (lane & 31) of the tile, cin = 16 step + 8 (lane >> 5) + e), then 1 / scale */
 size_t read_conv_dkh_floats(int Cin, int Cout, int ksize);
 int read_conv_pack_dkh_host(int Cin, int Cout, int ksize, const float *wf, const float *wm, void *wpacked_host);
 /* Small-Cout order [tap][cin][f0 f1 f2 f3 | m0 m1 m2 m3] (9 * Cin * 8 floats; 0 = the shape has no such order: only Cin = 32,
@@ -344,7 +351,8 @@ int read_conv_pack_params_host(int Cout, const float *bf, const float *bm, const
                                const float *beta, const float *mean, const float *var, float eps,
                                float *params_host);
 int read_gated_conv_forward(const read_conv_desc *desc, void *stream);
-/* Which kernel family read_gated_conv_forward takes for this (filled) descriptor under the current tuning knobs: 6 = direct 3x3 with
+/* Which kernel family read_gated_conv_forward takes for this (filled) descriptor under the current tuning knobs: 7 = 1x1 pixel-lane kernel
+ * with split operands on the f16 matrix cores (reads wpacked_d3h of a 1x1 layer), 6 = direct 3x3 with
  * split operands on the f16 matrix cores (reads wpacked_d3h), 5 = Winograd
  * F(4x4,3x3) with split operands on the f16 matrix cores (reads wpacked_w4h), 4 = Winograd F(4x4,3x3) on the fp32 matrix cores
  * (reads wpacked_w4), 2 = Winograd F(2x2,3x3) (reads wpacked_wino), 1 = vector-pipe small-Cout kernel (reads

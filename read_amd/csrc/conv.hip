@@ -4031,6 +4031,294 @@ __global__ __launch_bounds__(256, (PT * GW >= 4 ? 2 : 3)) void gated_conv_px_ker
 }
 
 // ------------------------------------------------------------------------------------------
+// 1x1 layers with SPLIT fp32 operands on the f16 matrix cores, pixel-lane orientation (round 6: the 18 launches outside the
+// 3x3 family that are 1x1 convolutions — SCM tails, AFF, Convs.k — took 635 us per frame on the fp32 matrix cores, 35 - 60 TF).
+//
+//   D[cout][pixel] = sum_k W[cout][k] X[k][pixel]     v_mfma_f32_32x32x16_f16, lane (h = lane >> 5, j = lane & 31):
+//                                                     A[row j][k = 8 h + e], B[k = 8 h + e][pixel j], D as in gated_conv_px_kernel
+//
+// The arithmetic is the direct split-operand kernel's (gated_conv_d3h_kernel): x = xh + 2^-11 xl (two f16 pieces formed from the
+// fp32 activation in registers), w s = wh + wl (host packer, power-of-two row scale s), products (2^-11 wh) xl + wl xh + wh xh into
+// one fp32 accumulator, 1 / s in the epilogue.  The structure is the pixel-lane kernel's: the group set's weight fragments are
+// copied once per persistent workgroup into LDS ([k16 step][tile][wh | wl][lane] x 16 bytes), a wave streams tiles of 32 pixels
+// with no barrier; lane (h, j) loads the 8 consecutive channels 16 step + 8 h .. + 7 of pixel j (two float4) four steps ahead of
+// the MFMAs, from whichever concatenated source holds them (sources are multiples of 8 channels: the two half-waves may read
+// different sources — cat[x(8), main(P - 8)] of SCM.conv; UNI = every source a multiple of 16, one cursor).
+// Three 32-cycle MFMAs replace eight 64-cycle ones per 16 channels and tile pair; what is left is the activation stream.
+template <int PT, int GW, bool FULLQ, bool UNI>
+__global__ __launch_bounds__(256, 2) void gated_conv_pxh_kernel(const ConvKArgs a)
+{
+    extern __shared__ __attribute__((aligned(16))) u32x4 wlh[];      // [k16 step][T tiles (f, m per group)][wh | wl][lane]
+    constexpr int T = 2 * GW;
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int half = lane >> 5, lp = lane & 31;
+    const int nsteps = a.nchunks;                                    // k16 steps = Cin / 16
+    const int nquads = (nsteps + 3) >> 2;                            // the ring advances in quads; steps >= nsteps are empty
+    const int gsets = (a.CoutPad >> 5) / GW;
+    const int gs = blockIdx.x % gsets;                               // channel-group set of this workgroup
+#ifdef READ_DEBUG_KNOBS
+    const int abl = a.ablate;        // attribution probes (results invalid): 1 no epilogue memory traffic, 2 activation loads from one resident line per lane,
+#else                                //   4 no MFMAs, 16 no weight copy
+    constexpr int abl = 0;
+#endif
+    if (!(abl & 16)) {
+        // the set's fragments: T consecutive 2 KiB blocks per k16 step.  Eight 16-byte loads per thread in flight, then their stores
+        // (one load, one store at a time cost a memory round trip per KiB: 16 round trips for 64 KiB)
+        const int NT = a.CoutPad >> 4;                               // 32-row tiles of the layer: (f, m) per group
+        const u32x4 *wp4 = reinterpret_cast<const u32x4 *>(a.wp_d3h);
+        const int total = nsteps * T * 128;
+        for (int i0 = threadIdx.x; i0 < total; i0 += 8 * 256) {
+            u32x4 v[8];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                const int i = i0 + k * 256;
+                const int ic = i < total ? i : total - 1;
+                v[k] = wp4[((size_t)((ic >> 7) / T) * NT + gs * T + (ic >> 7) % T) * 128 + (ic & 127)];
+            }
+#pragma unroll
+            for (int k = 0; k < 8; ++k)
+                if (i0 + k * 256 < total) wlh[i0 + k * 256] = v[k];
+        }
+    }
+    // the set's epilogue parameters behind the fragments: b_f, b_m, BN scale, BN shift, 1 / s_f, 1 / s_m  [6][EP = 32 GW]
+    constexpr int EP = 32 * GW;
+    float *const epar = reinterpret_cast<float *>(wlh + nsteps * T * 128);
+    for (int i = threadIdx.x; i < 6 * EP; i += 256) {
+        const float *const wsc = reinterpret_cast<const float *>(a.wp_d3h) + (size_t)nsteps * 32 * a.CoutPad;     // 1 / s: [f | m][CoutPad]
+        const int arr = i / EP, c = gs * EP + i % EP;
+        epar[i] = arr < 4 ? a.params[arr * a.CoutPad + c] : wsc[(arr - 4) * a.CoutPad + c];
+    }
+    __syncthreads();
+    const int npix = a.outH * a.outW;
+    const int wslots = (gridDim.x / gsets) * 4, w0 = (blockIdx.x / gsets) * 4 + wave;
+    if (w0 >= a.n_units) return;
+
+    // ---- load cursor: (unit, step) of the next activation fragment, four steps ahead of the MFMAs.  Cursor A = channels 16 step ..
+    // + 7 (lower half-wave), cursor B = 16 step + 8 .. + 15 (upper half-wave); both wave-uniform (scalar registers)
+    int lu = w0, lstep = 0;
+    int srcA = 0, coffA = 0, srcB = 0, coffB = 0;
+    SrcDev sdA = a.src[0], sdB = a.src[0];
+    auto reset_cursors = [&]() {
+        srcA = 0;
+        coffA = 0;
+        sdA = a.src[0];
+        if (!UNI) {
+            srcB = 0;
+            coffB = 8;
+            if (a.n_src > 1 && a.src[0].C == 8) {
+                srcB = 1;
+                coffB = 0;
+            }
+            sdB = a.src[srcB];
+        }
+    };
+    auto advance16 = [&](int &src, int &coff, SrcDev &sd) {
+        coff += 16;
+        while (src + 1 < a.n_src && coff >= sd.C) {
+            coff -= sd.C;
+            ++src;
+            sd = a.src[src];
+        }
+    };
+    int ly[PT], lx[PT];
+    auto set_load_unit = [&]() {
+#pragma unroll
+        for (int pt = 0; pt < PT; ++pt) {
+            int p = (lu * PT + pt) * 32 + lp;
+            p = p < npix ? p : npix - 1;                             // past the image (and past the last unit): a valid pixel
+            ly[pt] = p / a.outW;
+            lx[pt] = p - ly[pt] * a.outW;
+        }
+    };
+    float4 ring[4][PT][2];
+    auto load_step = [&](int slot) {
+        if (FULLQ || lstep < nsteps) {
+            const float *p;
+            int sW, sC, sl, sr, coff;
+            if (UNI) {
+                p = sdA.p;
+                sW = sdA.W;
+                sC = sdA.C;
+                sl = sdA.sl;
+                sr = sdA.sr;
+                coff = coffA + 8 * half;
+            } else {
+                p = half ? sdB.p : sdA.p;
+                sW = half ? sdB.W : sdA.W;
+                sC = half ? sdB.C : sdA.C;
+                sl = half ? sdB.sl : sdA.sl;
+                sr = half ? sdB.sr : sdA.sr;
+                coff = half ? coffB : coffA;
+            }
+#pragma unroll
+            for (int pt = 0; pt < PT; ++pt) {
+                const int sy = (ly[pt] << sl) >> sr, sx = (lx[pt] << sl) >> sr;
+                const float4 *q = reinterpret_cast<const float4 *>(p + (sy * sW + sx) * sC + coff);
+                if (abl & 2) q = reinterpret_cast<const float4 *>(p + lane * 8);
+                ring[slot][pt][0] = q[0];
+                ring[slot][pt][1] = q[1];
+            }
+            advance16(srcA, coffA, sdA);
+            if (!UNI) advance16(srcB, coffB, sdB);
+        }
+        if (++lstep == 4 * nquads) {
+            lstep = 0;
+            lu += wslots;
+            reset_cursors();
+            set_load_unit();
+        }
+    };
+    reset_cursors();
+    set_load_unit();
+#pragma unroll
+    for (int e = 0; e < 4; ++e) load_step(e);
+
+    auto split2 = [](float x, float y, unsigned &hi, unsigned &lo) {
+        float r0, r1;
+        asm("v_cvt_pk_f16_f32 %0, %1, %2" : "=v"(hi) : "v"(x), "v"(y));
+        asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel_hi:[1,0,0]" : "=v"(r0) : "v"(hi), "v"(x));                    // x - f32(hi), exact
+        asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(r1) : "v"(hi), "v"(y));
+        const f32x2 rs = f32x2{r0, r1} * f32x2{2048.0f, 2048.0f};
+        asm("v_cvt_pk_f16_f32 %0, %1, %2" : "=v"(lo) : "v"(rs.x), "v"(rs.y));
+    };
+
+    const bool quad_res = a.residual != nullptr;
+    for (int u = w0; u < a.n_units; u += wslots) {
+        floatx16 acc[PT][T];
+#pragma unroll
+        for (int pt = 0; pt < PT; ++pt)
+#pragma unroll
+            for (int t = 0; t < T; ++t)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[pt][t][r] = 0.0f;
+
+        for (int q = 0; q < nquads; ++q) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int st = 4 * q + e;
+                if (FULLQ || st < nsteps) {
+                    u32x4 wh[T], wl[T];
+#pragma unroll
+                    for (int t = 0; t < T; ++t) {
+                        wh[t] = wlh[((st * T + t) * 2) * 64 + lane];
+                        wl[t] = wlh[((st * T + t) * 2 + 1) * 64 + lane];
+                    }
+                    u32x4 bh[PT], bl[PT];
+#pragma unroll
+                    for (int pt = 0; pt < PT; ++pt) {
+                        const float4 v0 = ring[e][pt][0], v1 = ring[e][pt][1];
+                        unsigned h0, h1, h2, h3, l0, l1, l2, l3;
+                        split2(v0.x, v0.y, h0, l0);
+                        split2(v0.z, v0.w, h1, l1);
+                        split2(v1.x, v1.y, h2, l2);
+                        split2(v1.z, v1.w, h3, l3);
+                        bh[pt] = u32x4{h0, h1, h2, h3};
+                        bl[pt] = u32x4{l0, l1, l2, l3};
+                    }
+                    const _Float16 k11 = (_Float16)0x1p-11f;
+                    f16x8 as[T];
+#pragma unroll
+                    for (int t = 0; t < T; ++t) as[t] = __builtin_bit_cast(f16x8, wh[t]) * f16x8{k11, k11, k11, k11, k11, k11, k11, k11};
+                    if (abl & 4) {
+#pragma unroll
+                        for (int pt = 0; pt < PT; ++pt)
+#pragma unroll
+                            for (int t = 0; t < T; ++t) {
+                                acc[pt][t][0] += __builtin_bit_cast(float, bl[pt][0] ^ bh[pt][1] ^ wl[t][0]);
+                                acc[pt][t][1] += __builtin_bit_cast(float, bl[pt][2] ^ bh[pt][3] ^ __builtin_bit_cast(u32x4, as[t])[1]);
+                                acc[pt][t][2] += __builtin_bit_cast(float, bl[pt][1] ^ bh[pt][0] ^ wh[t][2]);
+                                acc[pt][t][3] += __builtin_bit_cast(float, bl[pt][3] ^ bh[pt][2] ^ wh[t][3]);
+                            }
+                        load_step(e);
+                        continue;
+                    }
+#pragma unroll
+                    for (int pt = 0; pt < PT; ++pt)
+#pragma unroll
+                        for (int t = 0; t < T; ++t)
+                            acc[pt][t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(as[t], __builtin_bit_cast(f16x8, bl[pt]), acc[pt][t], 0, 0, 0);
+#pragma unroll
+                    for (int pt = 0; pt < PT; ++pt)
+#pragma unroll
+                        for (int t = 0; t < T; ++t)
+                            acc[pt][t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, wl[t]), __builtin_bit_cast(f16x8, bh[pt]), acc[pt][t], 0, 0, 0);
+#pragma unroll
+                    for (int pt = 0; pt < PT; ++pt)
+#pragma unroll
+                        for (int t = 0; t < T; ++t)
+                            acc[pt][t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, wh[t]), __builtin_bit_cast(f16x8, bh[pt]), acc[pt][t], 0, 0, 0);
+                }
+                load_step(e);                                        // slot e now takes step st + 4 of the stream
+            }
+        }
+
+        // ---- epilogue: lane = (pixel, channel quad), everything 128 bits wide.  Parameters come from LDS (a global load here would
+        // queue behind the next unit's activation loads, which are already in flight, and wait for them: loads return in order);
+        // the addends and the residual of a pixel tile are requested together, in front of the arithmetic.
+#pragma unroll
+        for (int pt = 0; pt < PT; ++pt) {
+            const int p = (u * PT + pt) * 32 + lp;
+            const bool p_ok = p < npix;
+            const int pc = p_ok ? p : npix - 1;
+            const int y = pc / a.outW, x = pc - y * a.outW;
+            const float *const pp = a.pre ? a.pre + ((size_t)(y >> a.pre_shift) * a.pre_W + (x >> a.pre_shift)) * a.pre_cstride : nullptr;
+#pragma unroll
+            for (int g = 0; g < GW; ++g) {
+            f32x4 af[4], am[4];
+            if (a.pre) {
+#pragma unroll
+                for (int qd = 0; qd < 4; ++qd) {
+                    const int c0 = (gs * GW + g) * 32 + 8 * qd + 4 * half, cc = c0 < a.Cout ? c0 : a.Cout - 4;
+                    af[qd] = *reinterpret_cast<const f32x4 *>(pp + a.pre_foff + cc);
+                    am[qd] = *reinterpret_cast<const f32x4 *>(pp + a.pre_moff + cc);
+                }
+            }
+#pragma unroll
+            for (int qd = 0; qd < 4; ++qd) {
+                const int cl = g * 32 + 8 * qd + 4 * half, c0 = gs * GW * 32 + cl;
+                f32x4 f, m;
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    f[k] = acc[pt][2 * g][4 * qd + k];
+                    m[k] = acc[pt][2 * g + 1][4 * qd + k];
+                }
+                f = __builtin_elementwise_fma(f, *reinterpret_cast<const f32x4 *>(&epar[4 * EP + cl]), *reinterpret_cast<const f32x4 *>(&epar[cl]));
+                m = __builtin_elementwise_fma(m, *reinterpret_cast<const f32x4 *>(&epar[5 * EP + cl]), *reinterpret_cast<const f32x4 *>(&epar[EP + cl]));
+                const int cc = c0 < a.Cout ? c0 : a.Cout - 4;
+                if (a.pre) {
+                    f += af[qd];
+                    m += am[qd];
+                }
+                const bool ok = p_ok && c0 < a.Cout;
+                float *op = a.out + (size_t)pc * a.out_cstride + (c0 < a.Cout ? c0 : 0);
+                if (abl & 1) op = a.out + lane * 4;
+                if (a.linear) {
+                    if (ok) {
+                        *reinterpret_cast<f32x4 *>(op) = f;
+                        *reinterpret_cast<f32x4 *>(op + a.Cout) = m;
+                    }
+                    continue;
+                }
+                constexpr float LOG2E = 1.44269504088896341f;
+                if (a.elu) {
+                    const f32x4 fe = f * LOG2E;
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) f[k] = f[k] > 0.0f ? f[k] : __builtin_amdgcn_exp2f(fe[k]) - 1.0f;
+                }
+                const f32x4 mm = m * -LOG2E;
+                f32x4 sg;
+#pragma unroll
+                for (int k = 0; k < 4; ++k) sg[k] = __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(mm[k]));
+                f32x4 v = (f * sg) * *reinterpret_cast<const f32x4 *>(&epar[2 * EP + cl]) + *reinterpret_cast<const f32x4 *>(&epar[3 * EP + cl]);
+                if (quad_res) v += *reinterpret_cast<const f32x4 *>(a.residual + (abl & 1 ? (size_t)lane * 4 : (size_t)pc * a.Cout + cc));
+                if (ok) *reinterpret_cast<f32x4 *>(op) = v;
+            }
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------
 // configuration table
 // ------------------------------------------------------------------------------------------
 typedef void (*conv_fn)(const ConvKArgs);
@@ -4147,6 +4435,8 @@ int g_d3h = 0;             // read_tuning_set("conv_d3h", min Cin): gated 3x3 / 
 int g_d3h_s2 = 32;         // read_tuning_set("conv_d3h_s2", min Cin): 3x3 / STRIDE-2 layers on the direct split-operand kernel (0 = never: the fp32 direct kernels)
 int g_d3h_fam = 32;        // read_tuning_set("conv_d3h_fam", min Cin): ... and 11 us FASTER per launch than the fp32 kernel on FAM's x1 * x2 launches, which the
                            // Winograd split-operand kernel does not take: those run on it (0 = never)
+int g_pxh = 16;            // read_tuning_set("conv_pxh", min Cin): 1x1 / stride-1 layers with Cin % 16 == 0, Cin <= 256 and at least this many input channels take the
+                           // split-operand pixel-lane kernel (f16 matrix cores) when their operand (wpacked_d3h of a 1x1 layer) was supplied (0 = never)
 int g_sc = 8;              // read_tuning_set("conv_sc", 0): the output layer (Cout <= 4) back on the F(2x2) MFMA kernel instead of the vector pipe; other values: conv_set_sc
                            // kernel when its weights were supplied (0 = never)
 int g_abl = 0;             // read_tuning_set("conv_abl", bits): attribution probes of the 16x16x4 Winograd kernels (results invalid); -DREAD_DEBUG_KNOBS builds only
@@ -4486,6 +4776,7 @@ extern "C" int read_conv_pack_w4h_host(int Cin, int Cout, const float *wf, const
 // chunk + 8 kq + e; then 2 * CoutPad floats 1 / s ([conv_f rows | conv_m rows]).   (tests/d3h_ref.py)
 extern "C" size_t read_conv_dkh_floats(int Cin, int Cout, int ksize)
 {
+    if (ksize == 1) return (Cin < 16 || Cin % 16 || Cout < 1) ? 0 : (size_t)Cin * 2 * pad32(Cout) + 2 * (size_t)pad32(Cout);
     if (Cin < 32 || Cin % 32 || Cout < 1 || (ksize != 3 && ksize != 4)) return 0;
     return (size_t)Cin * 2 * ksize * ksize * pad32(Cout) + 2 * (size_t)pad32(Cout);
 }
@@ -4500,7 +4791,44 @@ extern "C" int read_conv_pack_d3h_host(int Cin, int Cout, const float *wf, const
 extern "C" int read_conv_pack_dkh_host(int Cin, int Cout, int ksize, const float *wf, const float *wm, void *out)
 {
     READ_CHECK_ARG(wf && wm && out, "read_conv_pack_dkh_host: null pointer");
-    READ_CHECK_ARG(ksize == 3 || ksize == 4, "read_conv_pack_dkh_host: ksize must be 3 or 4");
+    if (ksize == 1) {
+        // 1x1 layers (gated_conv_pxh_kernel, v_mfma_f32_32x32x16_f16 with the weights as the A operand): the same rows, scales and
+        // pieces in the order [k16 step][tile t = 2 group + (f | m)][wh | wl][lane][8 halfs], lane (i = lane & 31, h = lane >> 5) =
+        // row i of the tile (conv_f / conv_m of channel 32 group + i), cin = 16 step + 8 h + e; then the 2 * CoutPad floats 1 / s.
+        READ_CHECK_ARG(Cin >= 16 && Cin % 16 == 0 && Cout >= 1, "read_conv_pack_dkh_host: a 1x1 layer needs Cin %% 16 == 0 (got %d)", Cin);
+        const int CoutPad = pad32(Cout), nsteps = Cin / 16, NTL = CoutPad / 16;
+        unsigned short *h = static_cast<unsigned short *>(out);
+        float *inv = reinterpret_cast<float *>(out) + (size_t)Cin * 2 * CoutPad;
+        for (int row = 0; row < 2 * CoutPad; ++row) {
+            const int fm = row / CoutPad, co = row % CoutPad;
+            const float *k = co < Cout ? (fm ? wm : wf) + (size_t)co * Cin : nullptr;
+            double mx = 0.0;
+            if (k)
+                for (int i = 0; i < Cin; ++i) mx = std::fmax(mx, std::fabs((double)k[i]));
+            int ex = 0;
+            if (mx > 0.0 && std::isfinite(mx)) {
+                int e;
+                (void)std::frexp(mx, &e);
+                ex = 15 - e;
+                if (ex > 60) ex = 60;
+                if (ex < -60) ex = -60;
+            }
+            inv[row] = (float)std::ldexp(1.0, -ex);
+            const int t = 2 * (co / 32) + fm, i = co % 32;
+            for (int st = 0; st < nsteps; ++st)
+                for (int hh = 0; hh < 2; ++hh)
+                    for (int e = 0; e < 8; ++e) {
+                        const double ws = k ? std::ldexp((double)k[16 * st + 8 * hh + e], ex) : 0.0;
+                        const unsigned short hi = f16_bits_rtn(ws), lo = f16_bits_rtn(ws - f16_value(hi));
+                        const size_t frag = (((size_t)st * NTL + t) * 2) * 512;                   // halfs; 512 per piece
+                        const int lane = i + 32 * hh;
+                        h[frag + (size_t)lane * 8 + e] = hi;
+                        h[frag + 512 + (size_t)lane * 8 + e] = lo;
+                    }
+        }
+        return READ_OK;
+    }
+    READ_CHECK_ARG(ksize == 3 || ksize == 4, "read_conv_pack_dkh_host: ksize must be 1, 3 or 4");
     READ_CHECK_ARG(Cin >= 32 && Cin % 32 == 0 && Cout >= 1, "read_conv_pack_dkh_host: needs Cin %% 32 == 0 (got %d)", Cin);
     const int CoutPad = pad32(Cout), nchunks = Cin / 32, NT = ksize * ksize;
     unsigned short *h = static_cast<unsigned short *>(out);
@@ -4588,6 +4916,7 @@ void conv_set_w4h(int v) { g_w4h = v < 0 ? 0 : v; }
 void conv_set_d3h(int v) { g_d3h = v < 0 ? 0 : v; }
 void conv_set_d3h_fam(int v) { g_d3h_fam = v < 0 ? 0 : v; }
 void conv_set_d3h_s2(int v) { g_d3h_s2 = v < 0 ? 0 : v; }
+void conv_set_pxh(int v) { g_pxh = v < 0 ? 0 : v; }
 void conv_set_w4h_waves(int v) { g_w4h_waves = v == 4 ? 4 : 8; }
 void conv_set_w4_grid(int v) { g_w4_grid = v != 0; }
 void conv_set_wino_wgs(int v) { g_wino_wgs = v <= 1 ? 1 : 2; }
@@ -4612,6 +4941,7 @@ int conv_get(const char *key, int *value)
     else if (!strcmp(key, "conv_d3h")) *value = g_d3h;
     else if (!strcmp(key, "conv_d3h_fam")) *value = g_d3h_fam;
     else if (!strcmp(key, "conv_d3h_s2")) *value = g_d3h_s2;
+    else if (!strcmp(key, "conv_pxh")) *value = g_pxh;
 #ifdef READ_DEBUG_KNOBS
     else if (!strcmp(key, "conv_w4h_waves")) *value = g_w4h_waves;
 #endif
@@ -4640,6 +4970,7 @@ int conv_uses_w4h(const read_conv_desc *d);
 int conv_uses_d3h(const read_conv_desc *d);
 int conv_uses_d3h_s2(const read_conv_desc *d);
 int conv_uses_sc(const read_conv_desc *d);
+int conv_uses_pxh(const read_conv_desc *d);
 
 int launch_gated_conv(const read_conv_desc *d, hipStream_t stream)
 {
@@ -4660,12 +4991,12 @@ int launch_gated_conv(const read_conv_desc *d, hipStream_t stream)
         // (the lean UNet blob) must never reach a kernel that reads wpacked as the direct order — a tuning knob changed on a
         // live engine, a 2 GiB tensor or an odd out_cstride can decline the Winograd kernels after the host has packed for them.
         // Checked HERE, for both entry points (read_gated_conv_forward and the UNet executor's direct call).
-        const int family = conv_uses_sc(d) ? 1 : (conv_uses_d3h(d) || conv_uses_d3h_s2(d)) ? 6 : conv_uses_w4h(d) ? 5 : conv_uses_w4(d) ? 4 : conv_uses_wino(d) ? 2 : 0;
+        const int family = conv_uses_sc(d) ? 1 : conv_uses_pxh(d) ? 7 : (conv_uses_d3h(d) || conv_uses_d3h_s2(d)) ? 6 : conv_uses_w4h(d) ? 5 : conv_uses_w4(d) ? 4 : conv_uses_wino(d) ? 2 : 0;
         const bool cfg_wino = d->config >= 0 && d->config < N_CONFIGS && g_configs[d->config].wino;   // forced F(2x2) configs read wpacked_wino
         const bool w16_forced = d->config == -3;
         READ_CHECK_ARG(d->wpacked || family != 0 || cfg_wino || w16_forced,
                        "read_gated_conv_forward: this launch takes a direct kernel and wpacked is NULL (fragment order not packed)");
-        READ_CHECK_ARG(!d->wpacked || (!((const void *)d->wpacked == (const void *)d->wpacked_w4 && family != 4 && family != 5 && family != 6) &&
+        READ_CHECK_ARG(!d->wpacked || (!((const void *)d->wpacked == (const void *)d->wpacked_w4 && family != 4 && family != 5 && family != 6 && family != 7) &&
                                        !((const void *)d->wpacked == (const void *)d->wpacked_wino && family != 2 && !cfg_wino)),
                        "read_gated_conv_forward: wpacked aliases Winograd fragments but the launch takes kernel family %d "
                        "(ask read_conv_kernel_family before packing)", family);
@@ -4769,6 +5100,51 @@ int launch_gated_conv(const read_conv_desc *d, hipStream_t stream)
         else if (cph == 16) SC_LAUNCH(16, 1);
         else SC_LAUNCH(8, 1);
 #undef SC_LAUNCH
+        READ_CHECK_LAUNCH();
+        return READ_OK;
+    }
+
+    // ---- 1x1 layers on the f16 matrix cores: the split-operand pixel-lane kernel (config -10 forces it)
+    READ_CHECK_ARG(d->config != -10 || conv_uses_pxh(d), "read_gated_conv_forward: the split-operand pixel-lane kernel takes 1x1/s1 layers with "
+                   "Cin %% 16 == 0, Cin <= 256, Cout %% 4 == 0, 16-byte aligned tensors and wpacked_d3h");
+    if (conv_uses_pxh(d)) {
+        READ_CHECK_ARG((uintptr_t)d->wpacked_d3h % 16 == 0, "read_gated_conv_forward: wpacked_d3h misaligned");
+        static int n_cu_h = 0;
+        if (!n_cu_h) {
+            int dev = 0;
+            hipDeviceProp_t prop;
+            n_cu_h = (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess &&
+                      prop.multiProcessorCount > 0) ? prop.multiProcessorCount : 256;
+        }
+        a.wp_d3h = d->wpacked_d3h;
+        const int nsteps = Cin / 16;
+        const int gw = (groups % 2 == 0 && nsteps <= 8) ? 2 : 1;
+        const size_t lds = (size_t)nsteps * 2 * gw * 2048 + 6 * 32 * gw * sizeof(float);     // <= 64 KiB of fragments + parameters: two workgroups per CU
+        const int gsets = groups / gw;
+        const int per_cu = 2;
+        // two pixel tiles per wave where that still gives every resident wave a unit; one on the small images
+        const long slots = (long)n_cu_h * per_cu / gsets * 4;
+        const int pt = gw == 2 ? 1 : ((long)ceil_div(outH * outW, 64) >= (slots > 0 ? slots : 1) ? 2 : 1);
+        a.nchunks = nsteps;
+        a.n_units = ceil_div(outH * outW, 32 * pt);
+        int per_set = (n_cu_h * per_cu) / gsets;
+        const int want = ceil_div(a.n_units, 4);
+        per_set = per_set < 1 ? 1 : per_set;
+        per_set = per_set < want ? per_set : want;
+        const bool fullq = nsteps % 4 == 0;
+        bool uni = true;
+        for (int i = 0; i < d->n_src; ++i) uni = uni && d->src[i].C % 16 == 0;
+        const int shape = gw == 2 ? 0 : pt == 2 ? 1 : 2, vi = shape * 4 + (fullq ? 2 : 0) + (uni ? 1 : 0);
+        static const conv_fn fns[12] = {
+            gated_conv_pxh_kernel<1, 2, false, false>, gated_conv_pxh_kernel<1, 2, false, true>, gated_conv_pxh_kernel<1, 2, true, false>, gated_conv_pxh_kernel<1, 2, true, true>,
+            gated_conv_pxh_kernel<2, 1, false, false>, gated_conv_pxh_kernel<2, 1, false, true>, gated_conv_pxh_kernel<2, 1, true, false>, gated_conv_pxh_kernel<2, 1, true, true>,
+            gated_conv_pxh_kernel<1, 1, false, false>, gated_conv_pxh_kernel<1, 1, false, true>, gated_conv_pxh_kernel<1, 1, true, false>, gated_conv_pxh_kernel<1, 1, true, true>};
+        static bool attr_set_h[12] = {false, false, false, false, false, false, false, false, false, false, false, false};
+        if (!attr_set_h[vi]) {                                       // 64 KiB of dynamic LDS at Cin = 256
+            READ_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(fns[vi]), hipFuncAttributeMaxDynamicSharedMemorySize, 66 * 1024));
+            attr_set_h[vi] = true;
+        }
+        hipLaunchKernelGGL(fns[vi], dim3((unsigned)(per_set * gsets)), dim3(256), lds, stream, a);
         READ_CHECK_LAUNCH();
         return READ_OK;
     }
@@ -5133,6 +5509,24 @@ int conv_uses_d3h_s2(const read_conv_desc *d)
     return shape && (d->config == -9 || (d->config == -1 && g_d3h_s2 > 0 && d->src[0].C >= g_d3h_s2));
 }
 
+// 1x1 / stride-1 layers on the split-operand pixel-lane kernel (gated or linear, any number of sources, residual, nearest pre-activation addend):
+// whole k16 steps, at most 64 KiB of weight fragments per group set, everything 16-byte aligned (config -10 forces it;
+// read_tuning_set("conv_pxh", 0) switches it off)
+int conv_uses_pxh(const read_conv_desc *d)
+{
+    if (!d->wpacked_d3h || d->ksize != 1 || d->stride != 1 || d->mul || d->fill_pad || d->n_src < 1 || d->n_src > READ_CONV_MAX_SRC) return 0;
+    if (d->pre && d->pre_bilinear) return 0;                          // the bilinear addend (an option of the plan, off) stays on the fp32 pixel-lane kernel
+    int Cin = 0;
+    for (int i = 0; i < d->n_src; ++i) {
+        if (d->src[i].C < 8 || d->src[i].C % 8 != 0 || (uintptr_t)d->src[i].data % 16 != 0) return 0;
+        Cin += d->src[i].C;
+    }
+    const bool shape = Cin % 16 == 0 && Cin <= 256 && d->Cout % 4 == 0 && d->out_cstride % 4 == 0 && (uintptr_t)d->out % 16 == 0 &&
+                       (uintptr_t)d->params % 16 == 0 && (!d->residual || (uintptr_t)d->residual % 16 == 0) &&
+                       (!d->pre || ((uintptr_t)d->pre % 16 == 0 && d->pre_cstride % 4 == 0 && d->pre_f_off % 4 == 0 && d->pre_m_off % 4 == 0));
+    return shape && (d->config == -10 || (d->config == -1 && g_pxh > 0 && Cin >= g_pxh));
+}
+
 // gated 3x3 / stride-1 layers with at most four output channels and 32 input channels (READ's output layer)
 int conv_uses_sc(const read_conv_desc *d)
 {
@@ -5157,6 +5551,7 @@ extern "C" int read_conv_kernel_family(const read_conv_desc *desc)
 {
     if (!desc) return -1;
     if (readhip::conv_uses_sc(desc)) return 1;
+    if (readhip::conv_uses_pxh(desc)) return 7;
     if (readhip::conv_uses_d3h(desc) || readhip::conv_uses_d3h_s2(desc)) return 6;
     if (readhip::conv_uses_w4h(desc)) return 5;
     if (readhip::conv_uses_w4(desc)) return 4;

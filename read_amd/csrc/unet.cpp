@@ -49,6 +49,7 @@ struct DerivedInfo {
     int cin, cout, ci0;
     std::vector<int> parts;         // indices into Arch::layers
     size_t w_off, p_off;            // packed weights; parameters (zero biases) — gated finals use their part's own p_off
+    size_t h_off = ~(size_t)0;      // the same weights as f16 piece pairs (read_conv_pack_dkh_host, ksize 1: the split-operand pixel-lane kernel)
 };
 
 struct Arch {
@@ -114,6 +115,11 @@ Arch build_arch(int layout)
             if (d3h && !(lean && (unused || !(fam || d3h_s2)))) {
                 L.d3h_off = a.packed_floats;
                 a.packed_floats += read_conv_dkh_floats(cin, cout, k);
+            }
+            // 1x1 layers: the operand of the split-operand pixel-lane kernel (both layouts: the fp32 order stays beside it as the fallback)
+            if (k == 1 && s == 1 && cin <= 256 && read_conv_dkh_floats(cin, cout, 1)) {
+                L.d3h_off = a.packed_floats;
+                a.packed_floats += read_conv_dkh_floats(cin, cout, 1);
             }
             if (k == 3 && s == 1 && read_conv_sc_floats(cin, cout) && !(lean && unused)) {
                 a.packed_floats = (a.packed_floats + 15) / 16 * 16;     // 64-byte aligned: scalar loads of 16 dwords
@@ -182,6 +188,10 @@ Arch build_arch(int layout)
             a.packed_floats += read_conv_packed_floats(cin, D.cout, 1);
             D.p_off = a.packed_floats;
             a.packed_floats += read_conv_param_floats(D.cout);
+            if (cin <= 256 && read_conv_dkh_floats(cin, D.cout, 1)) {
+                D.h_off = a.packed_floats;
+                a.packed_floats += read_conv_dkh_floats(cin, D.cout, 1);
+            }
             a.derived.push_back(D);
         };
         derive("AFFq3", BASE * 7, BASE * 8, {0, 1, 2});   // z    @1/8 -> partial sums of AFF0, AFF1, AFF2
@@ -199,6 +209,10 @@ Arch build_arch(int layout)
             a.packed_floats += read_conv_packed_floats(cin, D.cout, 1);
             D.p_off = a.packed_floats;
             a.packed_floats += read_conv_param_floats(D.cout);
+            if (cin <= 256 && read_conv_dkh_floats(cin, D.cout, 1)) {
+                D.h_off = a.packed_floats;
+                a.packed_floats += read_conv_dkh_floats(cin, D.cout, 1);
+            }
             a.derived.push_back(D);
         };
         for (int k = 0; k < 3; ++k) {
@@ -323,7 +337,7 @@ struct Builder {
         const Arch &A = arch(u->layout);
         const DerivedInfo &D = A.derived[A.find_derived(name)];
         const LayerInfo &P0 = A.layers[D.parts[0]];
-        emit(name, LayerRef{D.cin, D.cout, 1, 1, P0.elu, D.w_off, linear ? D.p_off : P0.p_off, NO_WINO, NO_WINO, NO_WINO, NO_WINO}, srcs, out_t, -1, -1,
+        emit(name, LayerRef{D.cin, D.cout, 1, 1, P0.elu, D.w_off, linear ? D.p_off : P0.p_off, NO_WINO, NO_WINO, NO_WINO, NO_WINO, NO_WINO, D.h_off}, srcs, out_t, -1, -1,
              linear, pre);
     }
 
@@ -699,6 +713,10 @@ extern "C" int read_unet_pack_host_layout(const float *raw, float bn_eps, float 
         }
         int rc = read_conv_pack_weights_host(D.cin, D.cout, 1, 16, wf.data(), wm.data(), packed + D.w_off);
         if (rc) return rc;
+        if (D.h_off != NO_WINO) {
+            rc = read_conv_pack_dkh_host(D.cin, D.cout, 1, wf.data(), wm.data(), packed + D.h_off);
+            if (rc) return rc;
+        }
         rc = read_conv_pack_params_host(D.cout, zero.data(), zero.data(), one.data(), zero.data(), zero.data(), one.data(), 0.0f,
                                         packed + D.p_off);
         if (rc) return rc;

@@ -59,7 +59,7 @@ class PackedGatedConv:
                     _lib.check(L.read_conv_pack_w4h_host(self.cin, self.cout, wf.ctypes.data, wm.ctypes.data, w4h.ctypes.data),
                                "read_conv_pack_w4h_host")
                     self.wpacked_w4h = torch.from_numpy(w4h).to(device)
-        if self.k in (3, 4) and L.read_conv_dkh_floats(self.cin, self.cout, self.k):     # the plain weights as f16 piece pairs (direct split-operand kernels)
+        if self.k in (1, 3, 4) and L.read_conv_dkh_floats(self.cin, self.cout, self.k):  # the plain weights as f16 piece pairs (direct split-operand kernels; 1x1: pixel-lane)
             dkh = np.empty(L.read_conv_dkh_floats(self.cin, self.cout, self.k), np.float32)
             _lib.check(L.read_conv_pack_dkh_host(self.cin, self.cout, self.k, wf.ctypes.data, wm.ctypes.data, dkh.ctypes.data),
                        "read_conv_pack_dkh_host")

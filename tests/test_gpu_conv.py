@@ -326,8 +326,9 @@ def test_coarse_sources_as_pre_activation_addends(hip):
     xs = [torch.randn(c, H >> i, W >> i) for i, c in enumerate(chans)]            # fine, 1/2, 1/4
     cat = torch.cat([F.interpolate(x[None], size=(H, W), mode="nearest") for x in xs], 1)
     try:
-        for px in (3, 0):
+        for px, pxh in ((1, 16), (3, 0), (0, 0)):                                   # split-operand pixel-lane kernel (default), fp32 pixel-lane, LDS-tiled
             _lib.check(_lib.lib().read_tuning_set(b"conv_px", px))
+            _lib.check(_lib.lib().read_tuning_set(b"conv_pxh", pxh))
             for cout in (32, 64, 128):                                              # one, two, four channel groups
                 st = _state(sum(chans), cout, 1, seed=30 + cout)
                 ref = unet_torch.basic_conv(st, "L", cat, 1, elu=True)[0]
@@ -345,11 +346,12 @@ def test_coarse_sources_as_pre_activation_addends(hip):
                 q1 = gated_conv(part(32, 96, False), [(_nhwc(xs[1]), 0)], linear=True, pre=(q2, 0, cout, 1))  # 1/2, + up(q2)
                 assert q1.shape == (H // 2, W // 2, 2 * cout)
                 got = gated_conv(part(0, 32, True), [(_nhwc(xs[0]), 0)], elu=True, pre=(q1, 0, cout, 1))
-                _close(got, ref, f"AFF split over three levels, Cout={cout}, conv_px={px}")
+                _close(got, ref, f"AFF split over three levels, Cout={cout}, conv_px={px}, conv_pxh={pxh}")
                 lin = F.conv2d(xs[2][None], torch.as_tensor(np.ascontiguousarray(st[b + "conv_f.weight"][:, 96:224])))[0]
                 _close(q2[:, :, :cout].contiguous(), lin, "linear 1x1 partial sum")
     finally:
         _lib.check(_lib.lib().read_tuning_set(b"conv_px", 1))
+        _lib.check(_lib.lib().read_tuning_set(b"conv_pxh", 16))
 
 
 def test_bilinear_upsampled_source_as_pre_activation_addend(hip):
@@ -361,7 +363,10 @@ def test_bilinear_upsampled_source_as_pre_activation_addend(hip):
     from read_amd import _lib
     torch.manual_seed(23)
     up = torch.nn.Upsample(scale_factor=4, mode="bilinear", align_corners=False)
-    for (c, h, w) in ((128, 5, 19), (64, 11, 38), (32, 22, 76), (32, 1, 1), (64, 3, 2)):
+    for (c, h, w) in ((128, 5, 19), (64, 11, 38), (32, 22, 76), (32, 1, 1), (64, 3, 2), (-128, 5, 19), (-32, 9, 7)):
+        # c < 0: the same through the fp32 pixel-lane kernel (conv_pxh = 0); default: the split-operand pixel-lane kernel
+        _lib.check(_lib.lib().read_tuning_set(b"conv_pxh", 0 if c < 0 else 16))
+        c = abs(c)
         fe, r = torch.randn(c, h, w), torch.randn(c, 4 * h, 4 * w)
         st = _state(2 * c, c, 1, seed=40 + c + h)
         ref = unet_torch.basic_conv(st, "L", torch.cat([up(fe[None]), r[None]], 1), 1, elu=True)[0]
@@ -382,6 +387,7 @@ def test_bilinear_upsampled_source_as_pre_activation_addend(hip):
         got = gated_conv(part(c, 2 * c, True), [(_nhwc(r), 0)], elu=False, pre=(q, 0, c, 2, True), residual=_nhwc(res))
         ref2 = unet_torch.basic_conv(st, "L", torch.cat([up(fe[None]), r[None]], 1), 1, elu=False)[0] + res
         _close(got, ref2, f"bilinear addend + residual C={c} {h}x{w}")
+    _lib.check(_lib.lib().read_tuning_set(b"conv_pxh", 16))
     # refusals: another shift, a 3x3 layer
     fe, r = torch.randn(32, 4, 4), torch.randn(32, 16, 16)
     st = _state(32, 32, 1, seed=3)
@@ -422,6 +428,69 @@ def test_pixel_lane_kernel_for_1x1_layers(hip):
     with pytest.raises(_lib.ReadHipError):                               # 3x3 layers do not qualify
         st = _state(32, 32, 3, seed=1)
         gated_conv(_pack(st, [32]), [(_nhwc(torch.randn(32, 8, 32)), 0)], config=-2)
+
+
+def test_split_operand_pixel_lane_kernel_for_1x1_layers(hip):
+    """gated_conv_pxh_kernel (round 6): the 1x1 layers with split fp32 operands on the f16 matrix cores (config=-10 forces it, the
+    default takes it): every 1x1 shape of the network — SCM tails incl. cat[x(8), main(P - 8)] whose half-waves read different
+    sources, padded channel groups (Cout = 56 / 120 / 248), Convs.k, the AFF pieces —, ragged pixel counts, resampled sources, residual,
+    linear launches, all three tile shapes (two groups per wave; two pixel tiles per wave at frame size; one and one on small images).
+    Same reference and the same tolerance as the fp32 kernels."""
+    import ctypes
+    from read_amd import _lib
+    from read_amd.gated_conv import conv_desc
+    fam = _lib.lib().read_conv_kernel_family
+    torch.manual_seed(33)
+    cases = [  # (source channels, shifts, Cout, elu, residual, (H, W))
+        ([16], [0], 32, True, False, (12, 44)), ([32], [0], 56, True, False, (12, 44)), ([8, 56], [0, 0], 64, False, False, (12, 44)),
+        ([64], [0], 120, True, False, (12, 44)), ([8, 120], [0, 0], 128, False, False, (11, 38)),
+        ([128], [0], 248, True, False, (12, 44)), ([8, 248], [0, 0], 256, False, True, (12, 44)), ([128, 128], [0, 0], 128, True, True, (12, 44)),
+        ([32, 64, 128], [2, 1, 0], 128, True, False, (12, 44)), ([32, 64], [1, 0], 64, True, False, (12, 44)),
+        ([64, 64], [0, 0], 32, True, False, (12, 44)), ([24, 8, 16], [0, 0, 0], 32, True, False, (9, 33)),
+        ([32, 32], [0, 0], 32, True, True, (304, 448)),                 # 136 K pixels: two pixel tiles per wave
+        ([256], [0], 256, False, False, (44, 152)), ([96], [0], 64, True, False, (40, 100)),
+    ]
+    for chans, shifts, cout, elu, with_res, (H, W) in cases:
+        xs = [torch.randn(c, H << sh, W << sh) for c, sh in zip(chans, shifts)]
+        cat = torch.cat([F.interpolate(x[None], size=(H, W), mode="nearest") for x in xs], 1)
+        st = _state(sum(chans), cout, 1, seed=sum(chans) + cout)
+        ref = unet_torch.basic_conv(st, "L", cat, 1, elu=elu)[0]
+        res = torch.randn(cout, H, W) if with_res else None
+        pk = _pack(st, chans)
+        assert pk.wpacked_d3h is not None
+        srcs = [(_nhwc(x), sh) for x, sh in zip(xs, shifts)]
+        assert fam(ctypes.byref(conv_desc(pk, srcs))) == 7 and fam(ctypes.byref(conv_desc(pk, srcs, config=-10))) == 7
+        for cfg in (-10, -1):
+            got = gated_conv(pk, srcs, elu=elu, config=cfg, residual=_nhwc(res) if with_res else None)
+            _close(got, ref + (res if with_res else 0), f"pxh {chans} -> {cout} at {H}x{W}, config {cfg}")
+        lin = gated_conv(pk, srcs, linear=True, config=-10)            # [conv_f + b_f | conv_m + b_m]
+        b = "L.block."
+        ref_f = F.conv2d(cat, torch.as_tensor(st[b + "conv_f.weight"]), torch.as_tensor(st[b + "conv_f.bias"]))[0]
+        ref_m = F.conv2d(cat, torch.as_tensor(st[b + "conv_m.weight"]), torch.as_tensor(st[b + "conv_m.bias"]))[0]
+        _close(lin[:, :, :cout].contiguous(), ref_f, f"pxh linear f {chans} -> {cout}")
+        _close(lin[:, :, cout:].contiguous(), ref_m, f"pxh linear m {chans} -> {cout}")
+    # large activations (the f16 pieces cover |x| < 65504) and tiny ones (the low piece is scaled by 2^11: no f16 underflow)
+    for scale in (3000.0, 1e-3):
+        x = torch.randn(64, 12, 44) * scale
+        st = _state(64, 64, 1, seed=5)
+        ref = unet_torch.basic_conv(st, "L", x[None], 1, elu=True)[0]
+        got = gated_conv(_pack(st, [64]), [(_nhwc(x), 0)], elu=True, config=-10)
+        _close(got, ref, f"pxh at input scale {scale}", scale=max(1.0, scale / 30.0))
+    # the knob: conv_pxh = 0 sends the layer back to the fp32 kernels; shapes the kernel does not take
+    try:
+        _lib.check(_lib.lib().read_tuning_set(b"conv_pxh", 0))
+        st = _state(64, 64, 1, seed=6)
+        x = _nhwc(torch.randn(64, 8, 32))
+        assert fam(ctypes.byref(conv_desc(_pack(st, [64]), [(x, 0)]))) == 0
+    finally:
+        _lib.check(_lib.lib().read_tuning_set(b"conv_pxh", 16))
+    st = _state(480, 64, 1, seed=7)                                      # more than 256 input channels: no operand, fp32 kernels
+    assert _pack(st, [480]).wpacked_d3h is None or fam(ctypes.byref(conv_desc(_pack(st, [480]), [(_nhwc(torch.randn(480, 8, 32)), 0)]))) == 0
+    with pytest.raises(_lib.ReadHipError):
+        gated_conv(_pack(st, [480]), [(_nhwc(torch.randn(480, 8, 32)), 0)], config=-10)
+    with pytest.raises(_lib.ReadHipError):                               # 3x3 layers do not qualify
+        st3 = _state(32, 32, 3, seed=1)
+        gated_conv(_pack(st3, [32]), [(_nhwc(torch.randn(32, 8, 32)), 0)], config=-10)
 
 
 def test_fam_multiply_and_residual(hip):

@@ -69,6 +69,8 @@ def test_aff_weight_blocks_in_the_packed_blob():
                     off += L.read_conv_d3h_floats(cin, cout)
         if path in ("feat_extract.1", "feat_extract.2", "feat_extract.6", "feat_extract.3", "feat_extract.4", "feat_extract.7"):   # the stride-2 layers
             off += L.read_conv_dkh_floats(cin, cout, k)                    # (3x3 and 4x4): the direct split-operand kernel's operand
+        if k == 1 and cin <= 256:                                          # 1x1 layers: the split-operand pixel-lane kernel's operand (f16 piece pairs)
+            off += L.read_conv_dkh_floats(cin, cout, 1)
         if L.read_conv_sc_floats(cin, cout) and k == 3:                    # the 32 -> 3 layer: the vector-pipe order, 64-byte aligned
             off = (off + 15) // 16 * 16 + L.read_conv_sc_floats(cin, cout)
     aff = lambda *ks: tuple(f"AFFs.{k}.conv.0" for k in ks)                # noqa: E731
@@ -92,6 +94,12 @@ def test_aff_weight_blocks_in_the_packed_blob():
         par = packed[off + n:off + n + L.read_conv_param_floats(cout)].reshape(4, -1)
         assert not par[0].any() and not par[1].any()                         # zero biases (the gated finals use their AFF's own block)
         off += n + L.read_conv_param_floats(cout)
+        # round 6: ... followed by the same block as f16 piece pairs (read_conv_pack_dkh_host, ksize 1; tests/d3h_ref.py restates it)
+        from tests.d3h_ref import pack_d1h_blob
+        nh = L.read_conv_dkh_floats(cin, cout, 1)
+        assert nh == cin * 2 * ((cout + 31) // 32 * 32) + 2 * ((cout + 31) // 32 * 32)
+        assert np.array_equal(packed[off:off + nh].view(np.uint32), pack_d1h_blob(wf, wm).view(np.uint32)), name
+        off += nh
     assert off == L.read_unet_packed_floats()
 
 

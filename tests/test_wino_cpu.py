@@ -157,3 +157,29 @@ def test_direct_split_operand_packer_and_arithmetic():
     x = rng.standard_normal((H, W, cin)).astype(np.float32)
     ref = F.conv2d(torch.from_numpy(x).permute(2, 0, 1)[None], torch.from_numpy(wf), padding=1)[0].permute(1, 2, 0).numpy()
     np.testing.assert_allclose(split_conv_model(x, wf), ref, rtol=2e-5, atol=2e-5)
+
+
+def test_split_operand_1x1_packer_and_arithmetic():
+    """The 1x1 layers' split operand (gated_conv_pxh_kernel; read_conv_pack_dkh_host with ksize 1): the library's host packer against
+    the NumPy restatement BIT FOR BIT for whole and padded channel groups, the size rule, and the three-piece-pair arithmetic against
+    conv2d at the fp32 kernels' tolerance — also for activations of 3000 and of 1e-3 (the low piece is scaled by 2^11)."""
+    from read_amd import _lib
+    from tests.d3h_ref import pack_d1h_blob, split_1x1_model
+    rng = np.random.default_rng(9)
+    L = _lib.lib()
+    assert L.read_conv_dkh_floats(24, 32, 1) == 0 and L.read_conv_dkh_floats(8, 32, 1) == 0 and L.read_conv_dkh_floats(16, 4, 1) == 16 * 64 + 64
+    for cin, cout in ((16, 32), (64, 56), (128, 248), (48, 4)):
+        wf = rng.standard_normal((cout, cin, 1, 1)).astype(np.float32) * 0.1
+        wm = rng.standard_normal((cout, cin, 1, 1)).astype(np.float32) * 0.03
+        wm[1] = 0.0
+        blob = pack_d1h_blob(wf, wm)
+        cp = (cout + 31) // 32 * 32
+        n = L.read_conv_dkh_floats(cin, cout, 1)
+        assert n == blob.size == cin * 2 * cp + 2 * cp
+        got = np.zeros(n, np.float32)
+        assert L.read_conv_pack_dkh_host(cin, cout, 1, wf.ctypes.data, wm.ctypes.data, got.ctypes.data) == 0
+        assert np.array_equal(got.view(np.uint32), blob.view(np.uint32)), "library packer != model packer"
+        for scale in (1.0, 3000.0, 1e-3):
+            x = rng.standard_normal((7, 13, cin)).astype(np.float32) * np.float32(scale)
+            ref = F.conv2d(torch.from_numpy(x).permute(2, 0, 1)[None].double(), torch.from_numpy(wf).double())[0].permute(1, 2, 0).numpy()
+            np.testing.assert_allclose(split_1x1_model(x, wf), ref, rtol=2e-5, atol=2e-5 * scale)
