@@ -308,6 +308,12 @@ typedef struct read_conv_desc {
                                                read_tuning("conv_pxh") (default 16, 0 = never) <= Cin <= 256, Cout % 4 == 0 and 16-byte aligned
                                                tensors then run on the split-operand pixel-lane kernel (v_mfma_f32_32x32x16_f16, three piece
                                                pairs per product, fp32 accumulation); config = -10 forces it where the shape fits */
+    const void *wpacked_t3h;                /* optional: read_conv_pack_t3h_host() output (device): the 3x3 weights of a layer with 8, 16 or 32 input
+                                               channels as an implicit-GEMM operand (k = tap * Cin + channel, zero-padded to whole steps of 16) in
+                                               f16 piece pairs.  3x3 / stride-1 launches (gated or linear, residual) over ONE unshifted source with
+                                               C <= read_tuning("conv_t3h") (default 8: the layers that read the 8-channel descriptor pyramid; 0 =
+                                               never), Cout % 4 == 0 and 16-byte aligned tensors then run on the split-operand pixel-lane kernel
+                                               (zero padding at the image border, as nn.Conv2d); config = -11 forces it where the shape fits */
 } read_conv_desc;
 
 /* Sizes (in floats) of the packed weight / parameter blocks of one BasicConv. */
@@ -343,6 +349,10 @@ int read_conv_pack_d3h_host(int Cin, int Cout, const float *wf, const float *wm,
  * [k16 step][tile = 2 group + (f | m)][piece hi | lo][lane][8 halfs] (lane = row (lane & 31) of the tile, cin = 16 step + 8 (lane >> 5) + e), then 1 / scale */
 size_t read_conv_dkh_floats(int Cin, int Cout, int ksize);
 int read_conv_pack_dkh_host(int Cin, int Cout, int ksize, const float *wf, const float *wm, void *wpacked_host);
+/* Implicit-GEMM operand of the 3x3 layers with 8, 16 or 32 input channels (desc.wpacked_t3h): the ksize-1 order above for the matrix
+ * W'[cout][tap * Cin + ci] padded to K = pad16(9 * Cin) columns: K * 2 * pad32(Cout) + 2 * pad32(Cout) floats (0: another Cin) */
+size_t read_conv_t3h_floats(int Cin, int Cout);
+int read_conv_pack_t3h_host(int Cin, int Cout, const float *wf, const float *wm, void *wpacked_t3h_host);
 /* Small-Cout order [tap][cin][f0 f1 f2 f3 | m0 m1 m2 m3] (9 * Cin * 8 floats; 0 = the shape has no such order: only Cin = 32,
  * Cout <= 4 has a kernel). */
 size_t read_conv_sc_floats(int Cin, int Cout);
@@ -351,7 +361,8 @@ int read_conv_pack_params_host(int Cout, const float *bf, const float *bm, const
                                const float *beta, const float *mean, const float *var, float eps,
                                float *params_host);
 int read_gated_conv_forward(const read_conv_desc *desc, void *stream);
-/* Which kernel family read_gated_conv_forward takes for this (filled) descriptor under the current tuning knobs: 7 = 1x1 pixel-lane kernel
+/* Which kernel family read_gated_conv_forward takes for this (filled) descriptor under the current tuning knobs: 8 = the same kernel as an
+ * implicit GEMM over a 3x3 layer with 8 - 32 input channels (reads wpacked_t3h), 7 = 1x1 pixel-lane kernel
  * with split operands on the f16 matrix cores (reads wpacked_d3h of a 1x1 layer), 6 = direct 3x3 with
  * split operands on the f16 matrix cores (reads wpacked_d3h), 5 = Winograd
  * F(4x4,3x3) with split operands on the f16 matrix cores (reads wpacked_w4h), 4 = Winograd F(4x4,3x3) on the fp32 matrix cores

@@ -37,7 +37,7 @@ class ConvDesc(C.Structure):
         ("pre_shift", C.c_int), ("preH", C.c_int), ("preW", C.c_int),
         ("out_gated", C.c_void_p), ("block_h", C.c_int), ("valid_h", C.c_int),
         ("wpacked_sc", C.c_void_p), ("pre_bilinear", C.c_int),
-        ("wpacked_w4h", C.c_void_p), ("wpacked_d3h", C.c_void_p),
+        ("wpacked_w4h", C.c_void_p), ("wpacked_d3h", C.c_void_p), ("wpacked_t3h", C.c_void_p),
     ]
 
 
@@ -113,6 +113,8 @@ SIGNATURES = {
     "read_conv_pack_w4h_host": (_i, [_i, _i, _vp, _vp, _vp]),
     "read_conv_d3h_floats": (_sz, [_i, _i]),
     "read_conv_pack_d3h_host": (_i, [_i, _i, _vp, _vp, _vp]),
+    "read_conv_t3h_floats": (_sz, [_i, _i]),
+    "read_conv_pack_t3h_host": (_i, [_i, _i, _vp, _vp, _vp]),
     "read_conv_dkh_floats": (_sz, [_i, _i, _i]),
     "read_conv_pack_dkh_host": (_i, [_i, _i, _i, _vp, _vp, _vp]),
     "read_gated_conv_forward": (_i, [C.POINTER(ConvDesc), _vp]),

@@ -68,6 +68,7 @@ void conv_set_d3h(int v);
 void conv_set_d3h_fam(int v);
 void conv_set_d3h_s2(int v);
 void conv_set_pxh(int v);
+void conv_set_t3h(int v);
 void conv_set_w4h_waves(int v);
 void conv_set_px(int v);
 void conv_set_sc(int v);
@@ -98,7 +99,7 @@ extern "C" int read_debug_set_trace(void *buf, size_t bytes)
 // ("conv_ablate") exist only in builds with -DREAD_DEBUG_KNOBS.
 static const char *const k_tuning_keys[] = {"splat_mode", "splat_stats", "splat_subset", "splat_near", "splat_cells",
                                             "splat_cells_sub", "splat_seeds", "splat_items", "splat_strips", "splat_wgs", "splat_zl2", "splat_lds", "splat_bins", "splat_ahead", "splat_prof", "splat_mark", "splat_cells_batch", "splat_compact", "splat_sticky", "splat_wgs_b", "splat_kslot", "unet_streams", "unet_aff_split", "unet_up_fold", "conv_kc32", "conv_px", "conv_sc", "conv_wino_wgs",
-                                            "conv_wino", "conv_w16", "conv_w4", "conv_w4h", "conv_d3h", "conv_d3h_fam", "conv_d3h_s2", "conv_pxh", "conv_w4_grid", "conv_stagger", "conv_wave", "wgrad_wino",
+                                            "conv_wino", "conv_w16", "conv_w4", "conv_w4h", "conv_d3h", "conv_d3h_fam", "conv_d3h_s2", "conv_pxh", "conv_t3h", "conv_w4_grid", "conv_stagger", "conv_wave", "wgrad_wino",
 #ifdef READ_DEBUG_KNOBS
                                             "conv_ablate", "conv_abl", "conv_w4x2", "conv_w4h_waves",
 #endif
@@ -146,6 +147,7 @@ extern "C" int read_tuning_set(const char *key, int value)
 #ifdef READ_DEBUG_KNOBS
     if (!strcmp(key, "conv_w4h_waves")) { readhip::conv_set_w4h_waves(value); return READ_OK; }   // 8: specialised waves (measured slower); 4: the product kernel
 #endif
+    if (!strcmp(key, "conv_t3h")) { readhip::conv_set_t3h(value); return READ_OK; }           // max Cin of 3x3 layers on the split-operand implicit-GEMM kernel (0 = off)
     if (!strcmp(key, "conv_pxh")) { readhip::conv_set_pxh(value); return READ_OK; }           // min Cin of 1x1 layers on the split-operand pixel-lane kernel (0 = off)
     if (!strcmp(key, "conv_d3h_s2")) { readhip::conv_set_d3h_s2(value); return READ_OK; }     // min Cin of 3x3 / stride-2 layers on the direct split-operand kernel (0 = off)
     if (!strcmp(key, "conv_d3h_fam")) { readhip::conv_set_d3h_fam(value); return READ_OK; }   // min Cin of FAM (x1 * x2) launches on the direct split-operand kernel (0 = off)

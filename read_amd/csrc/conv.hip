@@ -4045,10 +4045,16 @@ __global__ __launch_bounds__(256, (PT * GW >= 4 ? 2 : 3)) void gated_conv_px_ker
 // the MFMAs, from whichever concatenated source holds them (sources are multiples of 8 channels: the two half-waves may read
 // different sources — cat[x(8), main(P - 8)] of SCM.conv; UNI = every source a multiple of 16, one cursor).
 // Three 32-cycle MFMAs replace eight 64-cycle ones per 16 channels and tile pair; what is left is the activation stream.
-template <int PT, int GW, bool FULLQ, bool UNI>
+//
+// MODE 2 (TAPS): the same kernel as an implicit GEMM for 3x3 / stride-1 layers over ONE source of C = 8, 16 or 32 channels (the first layer
+// and the SCM heads read the 8-channel descriptor pyramid; 67 TF on the fp32 direct kernel): k = tap C + channel, 9 C padded to whole
+// k16 steps (read_conv_pack_t3h_host), lane (h, j) loads the 8 channels of ITS tap at pixel j + (dy, dx) through a buffer descriptor
+// (a tap outside the image, or tap 9 of the padding, reads zeros); neighbouring taps hit the same lines in L1 / L2.
+template <int PT, int GW, bool FULLQ, int MODE>
 __global__ __launch_bounds__(256, 2) void gated_conv_pxh_kernel(const ConvKArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) u32x4 wlh[];      // [k16 step][T tiles (f, m per group)][wh | wl][lane]
+    constexpr bool UNI = MODE != 0, TAPS = MODE == 2;
     constexpr int T = 2 * GW;
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int half = lane >> 5, lp = lane & 31;
@@ -4131,8 +4137,24 @@ __global__ __launch_bounds__(256, 2) void gated_conv_pxh_kernel(const ConvKArgs 
         }
     };
     float4 ring[4][PT][2];
+    const auto trsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(a.src[0].p), 0, (unsigned)(a.inH * a.inW * a.src[0].C) * 4u, 0x00020000);
+    const int cshift = a.tiles_y;                                    // TAPS: log2 of the source's channels
     auto load_step = [&](int slot) {
-        if (FULLQ || lstep < nsteps) {
+        if (TAPS) {
+            if (lstep < nsteps) {
+                const int k0 = 16 * lstep + 8 * half;
+                const int tap = k0 >> cshift, coff = k0 & ((1 << cshift) - 1);
+                const int ty = (tap * 11) >> 5, dy = ty - 1, dx = tap - 3 * ty - 1;          // tap / 3 for tap <= 10
+#pragma unroll
+                for (int pt = 0; pt < PT; ++pt) {
+                    const int yy = ly[pt] + dy, xx = lx[pt] + dx;
+                    const bool ok = (tap < 9) & ((unsigned)yy < (unsigned)a.inH) & ((unsigned)xx < (unsigned)a.inW);
+                    const unsigned voff = ok ? (unsigned)((((yy * a.inW + xx) << cshift) + coff) * 4) : 0x80000000u;
+                    ring[slot][pt][0] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(trsrc, voff, 0, 0));
+                    ring[slot][pt][1] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(trsrc, voff, 16, 0));
+                }
+            }
+        } else if (FULLQ || lstep < nsteps) {
             const float *p;
             int sW, sC, sl, sr, coff;
             if (UNI) {
@@ -4437,6 +4459,8 @@ int g_d3h_fam = 32;        // read_tuning_set("conv_d3h_fam", min Cin): ... and 
                            // Winograd split-operand kernel does not take: those run on it (0 = never)
 int g_pxh = 16;            // read_tuning_set("conv_pxh", min Cin): 1x1 / stride-1 layers with Cin % 16 == 0, Cin <= 256 and at least this many input channels take the
                            // split-operand pixel-lane kernel (f16 matrix cores) when their operand (wpacked_d3h of a 1x1 layer) was supplied (0 = never)
+int g_t3h = 8;             // read_tuning_set("conv_t3h", max Cin): 3x3 / stride-1 layers over one source of at most this many channels (8, 16 or 32) take the
+                           // split-operand implicit-GEMM form of that kernel when wpacked_t3h was supplied (0 = never)
 int g_sc = 8;              // read_tuning_set("conv_sc", 0): the output layer (Cout <= 4) back on the F(2x2) MFMA kernel instead of the vector pipe; other values: conv_set_sc
                            // kernel when its weights were supplied (0 = never)
 int g_abl = 0;             // read_tuning_set("conv_abl", bits): attribution probes of the 16x16x4 Winograd kernels (results invalid); -DREAD_DEBUG_KNOBS builds only
@@ -4864,6 +4888,28 @@ extern "C" int read_conv_pack_dkh_host(int Cin, int Cout, int ksize, const float
     return READ_OK;
 }
 
+// 3x3 weights of a layer with 8, 16 or 32 input channels as the implicit-GEMM operand of the split-operand pixel-lane kernel: the matrix
+// W'[cout][k = tap Cin + ci] (tap = 3 ky + kx), k padded with zeros to whole k16 steps, in the 1x1 operand's order (read_conv_pack_dkh_host, ksize 1)
+extern "C" size_t read_conv_t3h_floats(int Cin, int Cout)
+{
+    return (Cin == 8 || Cin == 16 || Cin == 32) && Cout >= 1 ? read_conv_dkh_floats((9 * Cin + 15) / 16 * 16, Cout, 1) : 0;
+}
+
+extern "C" int read_conv_pack_t3h_host(int Cin, int Cout, const float *wf, const float *wm, void *out)
+{
+    READ_CHECK_ARG(wf && wm && out, "read_conv_pack_t3h_host: null pointer");
+    READ_CHECK_ARG(read_conv_t3h_floats(Cin, Cout) > 0, "read_conv_pack_t3h_host: needs Cin = 8, 16 or 32 (got %d)", Cin);
+    const int K = (9 * Cin + 15) / 16 * 16;
+    std::vector<float> f((size_t)Cout * K, 0.0f), m((size_t)Cout * K, 0.0f);
+    for (int co = 0; co < Cout; ++co)
+        for (int ci = 0; ci < Cin; ++ci)
+            for (int tap = 0; tap < 9; ++tap) {
+                f[(size_t)co * K + tap * Cin + ci] = wf[((size_t)co * Cin + ci) * 9 + tap];
+                m[(size_t)co * K + tap * Cin + ci] = wm[((size_t)co * Cin + ci) * 9 + tap];
+            }
+    return read_conv_pack_dkh_host(K, Cout, 1, f.data(), m.data(), out);
+}
+
 // Small-Cout order (gated_conv_smallc_kernel): [tap][cin][f0 f1 f2 f3 | m0 m1 m2 m3], channels >= Cout zero.
 extern "C" size_t read_conv_sc_floats(int Cin, int Cout)
 {
@@ -4917,6 +4963,7 @@ void conv_set_d3h(int v) { g_d3h = v < 0 ? 0 : v; }
 void conv_set_d3h_fam(int v) { g_d3h_fam = v < 0 ? 0 : v; }
 void conv_set_d3h_s2(int v) { g_d3h_s2 = v < 0 ? 0 : v; }
 void conv_set_pxh(int v) { g_pxh = v < 0 ? 0 : v; }
+void conv_set_t3h(int v) { g_t3h = v < 0 ? 0 : v; }
 void conv_set_w4h_waves(int v) { g_w4h_waves = v == 4 ? 4 : 8; }
 void conv_set_w4_grid(int v) { g_w4_grid = v != 0; }
 void conv_set_wino_wgs(int v) { g_wino_wgs = v <= 1 ? 1 : 2; }
@@ -4942,6 +4989,7 @@ int conv_get(const char *key, int *value)
     else if (!strcmp(key, "conv_d3h_fam")) *value = g_d3h_fam;
     else if (!strcmp(key, "conv_d3h_s2")) *value = g_d3h_s2;
     else if (!strcmp(key, "conv_pxh")) *value = g_pxh;
+    else if (!strcmp(key, "conv_t3h")) *value = g_t3h;
 #ifdef READ_DEBUG_KNOBS
     else if (!strcmp(key, "conv_w4h_waves")) *value = g_w4h_waves;
 #endif
@@ -4971,6 +5019,7 @@ int conv_uses_d3h(const read_conv_desc *d);
 int conv_uses_d3h_s2(const read_conv_desc *d);
 int conv_uses_sc(const read_conv_desc *d);
 int conv_uses_pxh(const read_conv_desc *d);
+int conv_uses_t3h(const read_conv_desc *d);
 
 int launch_gated_conv(const read_conv_desc *d, hipStream_t stream)
 {
@@ -4980,7 +5029,7 @@ int launch_gated_conv(const read_conv_desc *d, hipStream_t stream)
     READ_CHECK_ARG(d->ksize == 1 || d->ksize == 3 || d->ksize == 4, "read_gated_conv_forward: ksize must be 1,3,4");
     READ_CHECK_ARG(d->stride == 1 || d->stride == 2, "read_gated_conv_forward: stride must be 1 or 2");
     READ_CHECK_ARG(d->inH >= 1 && d->inW >= 1 && d->Cout >= 1, "read_gated_conv_forward: bad sizes");
-    READ_CHECK_ARG((d->wpacked || d->wpacked_w4 || d->wpacked_w4h || d->wpacked_d3h || d->wpacked_wino) && d->params && d->out, "read_gated_conv_forward: null weights/params/out");
+    READ_CHECK_ARG((d->wpacked || d->wpacked_w4 || d->wpacked_w4h || d->wpacked_d3h || d->wpacked_wino || d->wpacked_t3h) && d->params && d->out, "read_gated_conv_forward: null weights/params/out");
     READ_CHECK_ARG(d->out_cstride >= (d->linear ? 2 : 1) * d->Cout, "read_gated_conv_forward: out_cstride too small");
     READ_CHECK_ARG(!d->linear || (!d->residual && !d->fill_pad), "read_gated_conv_forward: linear mode takes no residual / fill");
     READ_CHECK_ARG(!d->mul || d->n_src == 1, "read_gated_conv_forward: mul needs a single source");
@@ -4991,12 +5040,12 @@ int launch_gated_conv(const read_conv_desc *d, hipStream_t stream)
         // (the lean UNet blob) must never reach a kernel that reads wpacked as the direct order — a tuning knob changed on a
         // live engine, a 2 GiB tensor or an odd out_cstride can decline the Winograd kernels after the host has packed for them.
         // Checked HERE, for both entry points (read_gated_conv_forward and the UNet executor's direct call).
-        const int family = conv_uses_sc(d) ? 1 : conv_uses_pxh(d) ? 7 : (conv_uses_d3h(d) || conv_uses_d3h_s2(d)) ? 6 : conv_uses_w4h(d) ? 5 : conv_uses_w4(d) ? 4 : conv_uses_wino(d) ? 2 : 0;
+        const int family = conv_uses_t3h(d) ? 8 : conv_uses_sc(d) ? 1 : conv_uses_pxh(d) ? 7 : (conv_uses_d3h(d) || conv_uses_d3h_s2(d)) ? 6 : conv_uses_w4h(d) ? 5 : conv_uses_w4(d) ? 4 : conv_uses_wino(d) ? 2 : 0;
         const bool cfg_wino = d->config >= 0 && d->config < N_CONFIGS && g_configs[d->config].wino;   // forced F(2x2) configs read wpacked_wino
         const bool w16_forced = d->config == -3;
         READ_CHECK_ARG(d->wpacked || family != 0 || cfg_wino || w16_forced,
                        "read_gated_conv_forward: this launch takes a direct kernel and wpacked is NULL (fragment order not packed)");
-        READ_CHECK_ARG(!d->wpacked || (!((const void *)d->wpacked == (const void *)d->wpacked_w4 && family != 4 && family != 5 && family != 6 && family != 7) &&
+        READ_CHECK_ARG(!d->wpacked || (!((const void *)d->wpacked == (const void *)d->wpacked_w4 && family != 4 && family != 5 && family != 6 && family != 7 && family != 8) &&
                                        !((const void *)d->wpacked == (const void *)d->wpacked_wino && family != 2 && !cfg_wino)),
                        "read_gated_conv_forward: wpacked aliases Winograd fragments but the launch takes kernel family %d "
                        "(ask read_conv_kernel_family before packing)", family);
@@ -5107,8 +5156,11 @@ int launch_gated_conv(const read_conv_desc *d, hipStream_t stream)
     // ---- 1x1 layers on the f16 matrix cores: the split-operand pixel-lane kernel (config -10 forces it)
     READ_CHECK_ARG(d->config != -10 || conv_uses_pxh(d), "read_gated_conv_forward: the split-operand pixel-lane kernel takes 1x1/s1 layers with "
                    "Cin %% 16 == 0, Cin <= 256, Cout %% 4 == 0, 16-byte aligned tensors and wpacked_d3h");
-    if (conv_uses_pxh(d)) {
-        READ_CHECK_ARG((uintptr_t)d->wpacked_d3h % 16 == 0, "read_gated_conv_forward: wpacked_d3h misaligned");
+    READ_CHECK_ARG(d->config != -11 || conv_uses_t3h(d), "read_gated_conv_forward: the split-operand implicit-GEMM kernel takes 3x3/s1 layers over one "
+                   "unshifted source of 8, 16 or 32 channels with Cout %% 4 == 0, 16-byte aligned tensors and wpacked_t3h");
+    const bool taps = conv_uses_t3h(d);
+    if (taps || conv_uses_pxh(d)) {
+        READ_CHECK_ARG((uintptr_t)(taps ? d->wpacked_t3h : d->wpacked_d3h) % 16 == 0, "read_gated_conv_forward: wpacked_d3h / wpacked_t3h misaligned");
         static int n_cu_h = 0;
         if (!n_cu_h) {
             int dev = 0;
@@ -5116,15 +5168,17 @@ int launch_gated_conv(const read_conv_desc *d, hipStream_t stream)
             n_cu_h = (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess &&
                       prop.multiProcessorCount > 0) ? prop.multiProcessorCount : 256;
         }
-        a.wp_d3h = d->wpacked_d3h;
-        const int nsteps = Cin / 16;
+        a.wp_d3h = taps ? d->wpacked_t3h : d->wpacked_d3h;
+        const int nsteps = taps ? (9 * Cin + 15) / 16 : Cin / 16;
+        if (taps) a.tiles_y = Cin == 8 ? 3 : Cin == 16 ? 4 : 5;     // log2 of the source's channels
         const int gw = (groups % 2 == 0 && nsteps <= 8) ? 2 : 1;
         const size_t lds = (size_t)nsteps * 2 * gw * 2048 + 6 * 32 * gw * sizeof(float);     // <= 64 KiB of fragments + parameters: two workgroups per CU
         const int gsets = groups / gw;
-        const int per_cu = 2;
-        // two pixel tiles per wave where that still gives every resident wave a unit; one on the small images
+        const int per_cu = lds > 78 * 1024 ? 1 : 2;
+        // two pixel tiles per wave as soon as one tile per wave would need a second round of units: a wave's time per unit is the
+        // latency of its activation stream (ring of four steps), the same for one tile or two
         const long slots = (long)n_cu_h * per_cu / gsets * 4;
-        const int pt = gw == 2 ? 1 : ((long)ceil_div(outH * outW, 64) >= (slots > 0 ? slots : 1) ? 2 : 1);
+        const int pt = gw == 2 ? 1 : ((long)ceil_div(outH * outW, 32) > (slots > 0 ? slots : 1) ? 2 : 1);
         a.nchunks = nsteps;
         a.n_units = ceil_div(outH * outW, 32 * pt);
         int per_set = (n_cu_h * per_cu) / gsets;
@@ -5134,14 +5188,15 @@ int launch_gated_conv(const read_conv_desc *d, hipStream_t stream)
         const bool fullq = nsteps % 4 == 0;
         bool uni = true;
         for (int i = 0; i < d->n_src; ++i) uni = uni && d->src[i].C % 16 == 0;
-        const int shape = gw == 2 ? 0 : pt == 2 ? 1 : 2, vi = shape * 4 + (fullq ? 2 : 0) + (uni ? 1 : 0);
-        static const conv_fn fns[12] = {
-            gated_conv_pxh_kernel<1, 2, false, false>, gated_conv_pxh_kernel<1, 2, false, true>, gated_conv_pxh_kernel<1, 2, true, false>, gated_conv_pxh_kernel<1, 2, true, true>,
-            gated_conv_pxh_kernel<2, 1, false, false>, gated_conv_pxh_kernel<2, 1, false, true>, gated_conv_pxh_kernel<2, 1, true, false>, gated_conv_pxh_kernel<2, 1, true, true>,
-            gated_conv_pxh_kernel<1, 1, false, false>, gated_conv_pxh_kernel<1, 1, false, true>, gated_conv_pxh_kernel<1, 1, true, false>, gated_conv_pxh_kernel<1, 1, true, true>};
-        static bool attr_set_h[12] = {false, false, false, false, false, false, false, false, false, false, false, false};
-        if (!attr_set_h[vi]) {                                       // 64 KiB of dynamic LDS at Cin = 256
-            READ_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(fns[vi]), hipFuncAttributeMaxDynamicSharedMemorySize, 66 * 1024));
+        const int shape = gw == 2 ? 0 : pt == 2 ? 1 : 2, vi = taps ? 12 + shape : shape * 4 + (fullq ? 2 : 0) + (uni ? 1 : 0);
+        static const conv_fn fns[15] = {
+            gated_conv_pxh_kernel<1, 2, false, 0>, gated_conv_pxh_kernel<1, 2, false, 1>, gated_conv_pxh_kernel<1, 2, true, 0>, gated_conv_pxh_kernel<1, 2, true, 1>,
+            gated_conv_pxh_kernel<2, 1, false, 0>, gated_conv_pxh_kernel<2, 1, false, 1>, gated_conv_pxh_kernel<2, 1, true, 0>, gated_conv_pxh_kernel<2, 1, true, 1>,
+            gated_conv_pxh_kernel<1, 1, false, 0>, gated_conv_pxh_kernel<1, 1, false, 1>, gated_conv_pxh_kernel<1, 1, true, 0>, gated_conv_pxh_kernel<1, 1, true, 1>,
+            gated_conv_pxh_kernel<1, 2, false, 2>, gated_conv_pxh_kernel<2, 1, false, 2>, gated_conv_pxh_kernel<1, 1, false, 2>};
+        static bool attr_set_h[15] = {false, false, false, false, false, false, false, false, false, false, false, false, false, false, false};
+        if (!attr_set_h[vi]) {                                       // 64 KiB of dynamic LDS at Cin = 256 (74 KiB: 3x3 over 32 channels)
+            READ_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(fns[vi]), hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024));
             attr_set_h[vi] = true;
         }
         hipLaunchKernelGGL(fns[vi], dim3((unsigned)(per_set * gsets)), dim3(256), lds, stream, a);
@@ -5527,6 +5582,20 @@ int conv_uses_pxh(const read_conv_desc *d)
     return shape && (d->config == -10 || (d->config == -1 && g_pxh > 0 && Cin >= g_pxh));
 }
 
+// 3x3 / stride-1 layers over one unshifted source of 8, 16 or 32 channels as an implicit GEMM on the same kernel (k = tap C + channel;
+// read_conv_pack_t3h_host): the layers that read the 8-channel descriptor pyramid by default (read_tuning_set("conv_t3h", max Cin), 0 = never;
+// config -11 forces it)
+int conv_uses_t3h(const read_conv_desc *d)
+{
+    if (!d->wpacked_t3h || d->ksize != 3 || d->stride != 1 || d->mul || d->fill_pad || d->pre || d->n_src != 1 || d->src[0].shift != 0) return 0;
+    const int C = d->src[0].C;
+    const bool shape = (C == 8 || C == 16 || C == 32) && d->Cout % 4 == 0 && d->out_cstride % 4 == 0 && (uintptr_t)d->out % 16 == 0 &&
+                       (uintptr_t)d->src[0].data % 16 == 0 && (uintptr_t)d->params % 16 == 0 && (!d->residual || (uintptr_t)d->residual % 16 == 0) &&
+                       (long long)d->inH * d->inW * C * 4 < (1ll << 31);
+    // (automatic choice from 16 K pixels on: at 44 x 152 the fp32 direct kernel measured 11.5 us against 14.2)
+    return shape && (d->config == -11 || (d->config == -1 && g_t3h > 0 && C <= g_t3h && (long long)d->inH * d->inW >= 16384));
+}
+
 // gated 3x3 / stride-1 layers with at most four output channels and 32 input channels (READ's output layer)
 int conv_uses_sc(const read_conv_desc *d)
 {
@@ -5550,6 +5619,7 @@ int conv_kc_for(const read_conv_desc *d)
 extern "C" int read_conv_kernel_family(const read_conv_desc *desc)
 {
     if (!desc) return -1;
+    if (readhip::conv_uses_t3h(desc)) return 8;
     if (readhip::conv_uses_sc(desc)) return 1;
     if (readhip::conv_uses_pxh(desc)) return 7;
     if (readhip::conv_uses_d3h(desc) || readhip::conv_uses_d3h_s2(desc)) return 6;

@@ -38,6 +38,7 @@ struct LayerInfo {
     size_t sc_off = ~(size_t)0;     // small-Cout order of the 3x3/s1 layers with Cout <= 4 (the output layer), else NO_WINO
     size_t w4h_off = ~(size_t)0;    // F(4x4) weights split into f16 piece pairs (read_conv_pack_w4h_host) of the w4 layers with Cin % 32 == 0, else NO_WINO
     size_t d3h_off = ~(size_t)0;    // the plain 3x3 weights as f16 piece pairs (read_conv_pack_d3h_host) of the same layers, else NO_WINO
+    size_t t3h_off = ~(size_t)0;    // 3x3 / stride-1 layers over the 8-channel pyramid: the implicit-GEMM operand (read_conv_pack_t3h_host), else NO_WINO
 };
 constexpr size_t NO_WINO = ~(size_t)0;
 
@@ -120,6 +121,10 @@ Arch build_arch(int layout)
             if (k == 1 && s == 1 && cin <= 256 && read_conv_dkh_floats(cin, cout, 1)) {
                 L.d3h_off = a.packed_floats;
                 a.packed_floats += read_conv_dkh_floats(cin, cout, 1);
+            }
+            if (k == 3 && s == 1 && cin == IN_CH && read_conv_t3h_floats(cin, cout)) {
+                L.t3h_off = a.packed_floats;
+                a.packed_floats += read_conv_t3h_floats(cin, cout);
             }
             if (k == 3 && s == 1 && read_conv_sc_floats(cin, cout) && !(lean && unused)) {
                 a.packed_floats = (a.packed_floats + 15) / 16 * 16;     // 64-byte aligned: scalar loads of 16 dwords
@@ -318,7 +323,7 @@ struct Builder {
     };
     struct LayerRef {
         int cin, cout, k, stride, elu;
-        size_t w_off, p_off, wino_off, w16_off, w4_off, sc_off, w4h_off = ~(size_t)0, d3h_off = ~(size_t)0;
+        size_t w_off, p_off, wino_off, w16_off, w4_off, sc_off, w4h_off = ~(size_t)0, d3h_off = ~(size_t)0, t3h_off = ~(size_t)0;
     };
 
     // One BasicConv.  srcs = {tensor id, shift}; out tensor must already exist.
@@ -327,7 +332,7 @@ struct Builder {
     {
         const Arch &A = arch(u->layout);
         const LayerInfo &L = A.layers[A.find(path)];
-        emit(path, LayerRef{L.cin, L.cout, L.k, L.stride, L.elu, L.w_off, L.p_off, L.wino_off, L.w16_off, L.w4_off, L.sc_off, L.w4h_off, L.d3h_off}, srcs, out_t, mul_t, res_t, 0,
+        emit(path, LayerRef{L.cin, L.cout, L.k, L.stride, L.elu, L.w_off, L.p_off, L.wino_off, L.w16_off, L.w4_off, L.sc_off, L.w4h_off, L.d3h_off, L.t3h_off}, srcs, out_t, mul_t, res_t, 0,
              PreRef());
     }
     // A derived 1x1 layer (DerivedInfo): `linear` ones store the pre-activations [f | m] for a finer level to add,
@@ -381,6 +386,7 @@ struct Builder {
         op.d.wpacked_sc = L.sc_off != NO_WINO ? u->packed + L.sc_off : nullptr;
         op.d.wpacked_w4h = L.w4h_off != NO_WINO ? u->packed + L.w4h_off : nullptr;
         op.d.wpacked_d3h = L.d3h_off != NO_WINO ? u->packed + L.d3h_off : nullptr;
+        op.d.wpacked_t3h = L.t3h_off != NO_WINO ? u->packed + L.t3h_off : nullptr;
         op.d.mul = mul_t >= 0 ? u->tensors[mul_t].p : nullptr;
         op.d.residual = res_t >= 0 ? u->tensors[res_t].p : nullptr;
         op.d.out = o.p;
@@ -694,6 +700,10 @@ extern "C" int read_unet_pack_host_layout(const float *raw, float bn_eps, float 
         }
         if (L.d3h_off != NO_WINO) {
             rc = read_conv_pack_dkh_host(L.cin, L.cout, L.k, wf, wm, packed + L.d3h_off);
+            if (rc) return rc;
+        }
+        if (L.t3h_off != NO_WINO) {
+            rc = read_conv_pack_t3h_host(L.cin, L.cout, wf, wm, packed + L.t3h_off);
             if (rc) return rc;
         }
     }

@@ -34,7 +34,11 @@ class PackedGatedConv:
                                                 pp.ctypes.data), "read_conv_pack_params_host")
         self.wpacked = torch.from_numpy(wp).to(device)
         self.params = torch.from_numpy(pp).to(device)
-        self.wpacked_wino = self.wpacked_w16 = self.wpacked_w4 = self.wpacked_sc = self.wpacked_w4h = self.wpacked_d3h = None
+        self.wpacked_wino = self.wpacked_w16 = self.wpacked_w4 = self.wpacked_sc = self.wpacked_w4h = self.wpacked_d3h = self.wpacked_t3h = None
+        if self.k == 3 and L.read_conv_t3h_floats(self.cin, self.cout):     # 8 - 32 input channels: the implicit-GEMM operand of the split-operand pixel-lane kernel
+            t3 = np.empty(L.read_conv_t3h_floats(self.cin, self.cout), np.float32)
+            _lib.check(L.read_conv_pack_t3h_host(self.cin, self.cout, wf.ctypes.data, wm.ctypes.data, t3.ctypes.data), "read_conv_pack_t3h_host")
+            self.wpacked_t3h = torch.from_numpy(t3).to(device)
         if self.k == 3 and L.read_conv_sc_floats(self.cin, self.cout):      # small-Cout order for the vector-pipe kernel (Cout <= 4)
             sc = np.empty(L.read_conv_sc_floats(self.cin, self.cout), np.float32)
             _lib.check(L.read_conv_pack_sc_host(self.cin, self.cout, wf.ctypes.data, wm.ctypes.data, sc.ctypes.data),
@@ -120,6 +124,7 @@ def _desc(packed, sources, stride=1, elu=True, mul=None, residual=None, config=-
     d.wpacked_sc = packed.wpacked_sc.data_ptr() if packed.wpacked_sc is not None else None
     d.wpacked_w4h = packed.wpacked_w4h.data_ptr() if packed.wpacked_w4h is not None else None
     d.wpacked_d3h = packed.wpacked_d3h.data_ptr() if packed.wpacked_d3h is not None else None
+    d.wpacked_t3h = packed.wpacked_t3h.data_ptr() if getattr(packed, "wpacked_t3h", None) is not None else None
     d.linear = 1 if linear else 0
     if pre is not None:
         pt, f_off, m_off, psh = pre[:4]

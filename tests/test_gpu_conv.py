@@ -493,6 +493,55 @@ def test_split_operand_pixel_lane_kernel_for_1x1_layers(hip):
         gated_conv(_pack(st3, [32]), [(_nhwc(torch.randn(32, 8, 32)), 0)], config=-10)
 
 
+def test_split_operand_implicit_gemm_for_3x3_layers_over_few_channels(hip):
+    """The TAPS form of gated_conv_pxh_kernel (round 6): 3x3 / stride-1 layers over one source of 8, 16 or 32 channels as an implicit GEMM with
+    split operands (k = tap * Cin + channel).  By default the layers over the 8-channel descriptor pyramid (feat_extract.0, SCM.main.0:
+    family 8); config = -11 / read_tuning_set("conv_t3h", 32) for 16 and 32 channels.  Zero padding at the border (ragged sizes, one-row
+    and one-column images), residual, linear launches, all tile shapes; same reference and tolerance as the fp32 kernels."""
+    import ctypes
+    from read_amd import _lib
+    from read_amd.gated_conv import conv_desc
+    fam = _lib.lib().read_conv_kernel_family
+    torch.manual_seed(35)
+    cases = [  # (Cin, Cout, elu, residual, (H, W))
+        (8, 32, True, False, (37, 61)), (8, 16, True, False, (22, 76)), (8, 64, True, False, (11, 38)), (8, 32, False, True, (9, 33)),
+        (8, 32, True, False, (1, 40)), (8, 32, True, False, (40, 1)), (8, 32, True, False, (3, 3)),
+        (8, 32, True, False, (304, 448)),                               # 136 K pixels: two pixel tiles per wave
+        (16, 32, True, False, (21, 45)), (32, 32, True, True, (21, 45)), (32, 64, False, False, (13, 70)), (32, 4, True, False, (21, 45)),
+    ]
+    for cin, cout, elu, with_res, (H, W) in cases:
+        x = torch.randn(cin, H, W)
+        st = _state(cin, cout, 3, seed=cin + cout + H)
+        ref = unet_torch.basic_conv(st, "L", x[None], 3, elu=elu)[0]
+        res = torch.randn(cout, H, W) if with_res else None
+        pk = _pack(st, [cin])
+        assert pk.wpacked_t3h is not None
+        srcs = [(_nhwc(x), 0)]
+        assert fam(ctypes.byref(conv_desc(pk, srcs, config=-11))) == 8
+        assert (fam(ctypes.byref(conv_desc(pk, srcs))) == 8) == (cin == 8 and H * W >= 16384)      # the default takes it from 16 K pixels on
+        for cfg in ((-11, -1) if cin == 8 else (-11,)):
+            got = gated_conv(pk, srcs, elu=elu, config=cfg, residual=_nhwc(res) if with_res else None)
+            _close(got, ref + (res if with_res else 0), f"t3h {cin} -> {cout} at {H}x{W}, config {cfg}")
+        lin = gated_conv(pk, srcs, linear=True, config=-11)
+        b = "L.block."
+        ref_f = F.conv2d(x[None], torch.as_tensor(st[b + "conv_f.weight"]), torch.as_tensor(st[b + "conv_f.bias"]), padding=1)[0]
+        _close(lin[:, :, :cout].contiguous(), ref_f, f"t3h linear f {cin} -> {cout}")
+    try:                                                                 # the knob
+        st = _state(8, 32, 3, seed=2)
+        x = _nhwc(torch.randn(8, 128, 160))
+        assert fam(ctypes.byref(conv_desc(_pack(st, [8]), [(x, 0)]))) == 8
+        _lib.check(_lib.lib().read_tuning_set(b"conv_t3h", 0))
+        assert fam(ctypes.byref(conv_desc(_pack(st, [8]), [(x, 0)]))) == 0
+        _lib.check(_lib.lib().read_tuning_set(b"conv_t3h", 32))
+        st32 = _state(32, 64, 3, seed=3)
+        assert fam(ctypes.byref(conv_desc(_pack(st32, [32]), [(_nhwc(torch.randn(32, 128, 160)), 0)]))) == 8
+    finally:
+        _lib.check(_lib.lib().read_tuning_set(b"conv_t3h", 8))
+    with pytest.raises(_lib.ReadHipError):                               # 64 input channels: no operand
+        st64 = _state(64, 64, 3, seed=4)
+        gated_conv(_pack(st64, [64]), [(_nhwc(torch.randn(64, 8, 32)), 0)], config=-11)
+
+
 def test_fam_multiply_and_residual(hip):
     """FAM: x1 + BC(x1*x2) (unet.py:114-117) in one launch."""
     torch.manual_seed(3)

@@ -71,6 +71,8 @@ def test_aff_weight_blocks_in_the_packed_blob():
             off += L.read_conv_dkh_floats(cin, cout, k)                    # (3x3 and 4x4): the direct split-operand kernel's operand
         if k == 1 and cin <= 256:                                          # 1x1 layers: the split-operand pixel-lane kernel's operand (f16 piece pairs)
             off += L.read_conv_dkh_floats(cin, cout, 1)
+        if k == 3 and cin == 8:                                            # the layers over the 8-channel pyramid: implicit-GEMM operand (f16 piece pairs)
+            off += L.read_conv_t3h_floats(cin, cout)
         if L.read_conv_sc_floats(cin, cout) and k == 3:                    # the 32 -> 3 layer: the vector-pipe order, 64-byte aligned
             off = (off + 15) // 16 * 16 + L.read_conv_sc_floats(cin, cout)
     aff = lambda *ks: tuple(f"AFFs.{k}.conv.0" for k in ks)                # noqa: E731

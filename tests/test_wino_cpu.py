@@ -183,3 +183,32 @@ def test_split_operand_1x1_packer_and_arithmetic():
             x = rng.standard_normal((7, 13, cin)).astype(np.float32) * np.float32(scale)
             ref = F.conv2d(torch.from_numpy(x).permute(2, 0, 1)[None].double(), torch.from_numpy(wf).double())[0].permute(1, 2, 0).numpy()
             np.testing.assert_allclose(split_1x1_model(x, wf), ref, rtol=2e-5, atol=2e-5 * scale)
+
+
+def test_split_operand_implicit_gemm_packer():
+    """read_conv_pack_t3h_host: the 3x3 weights of a layer with 8, 16 or 32 input channels as the matrix W'[cout][tap * Cin + ci], zero-padded
+    to whole k16 steps, in the 1x1 operand's order — against the NumPy restatement bit for bit; the size rule; the arithmetic of the
+    implicit GEMM (zero padding at the border) against conv2d."""
+    from read_amd import _lib
+    from tests.d3h_ref import pack_d1h_blob, split_conv_model_taps
+    rng = np.random.default_rng(10)
+    L = _lib.lib()
+    assert L.read_conv_t3h_floats(64, 32) == 0 and L.read_conv_t3h_floats(24, 32) == 0 and L.read_conv_t3h_floats(8, 32) == 80 * 64 + 64
+    for cin, cout in ((8, 32), (8, 16), (16, 56), (32, 3)):
+        wf = rng.standard_normal((cout, cin, 3, 3)).astype(np.float32) * 0.1
+        wm = rng.standard_normal((cout, cin, 3, 3)).astype(np.float32) * 0.03
+        K = (9 * cin + 15) // 16 * 16
+        mat = lambda w: np.concatenate([w.transpose(0, 2, 3, 1).reshape(cout, 9 * cin), np.zeros((cout, K - 9 * cin), np.float32)], 1)   # noqa: E731
+        blob = pack_d1h_blob(mat(wf), mat(wm))
+        n = L.read_conv_t3h_floats(cin, cout)
+        assert n == blob.size
+        got = np.zeros(n, np.float32)
+        assert L.read_conv_pack_t3h_host(cin, cout, wf.ctypes.data, wm.ctypes.data, got.ctypes.data) == 0
+        assert np.array_equal(got.view(np.uint32), blob.view(np.uint32)), "library packer != model packer"
+        H, W = 6, 11
+        x = rng.standard_normal((H, W, cin)).astype(np.float32)
+        xp = np.zeros((H + 2, W + 2, cin), np.float32)
+        xp[1:-1, 1:-1] = x
+        cols = np.concatenate([xp[ky:ky + H, kx:kx + W] for ky in range(3) for kx in range(3)] + [np.zeros((H, W, K - 9 * cin), np.float32)], 2)
+        ref = F.conv2d(torch.from_numpy(x).permute(2, 0, 1)[None].double(), torch.from_numpy(wf).double(), padding=1)[0].permute(1, 2, 0).numpy()
+        np.testing.assert_allclose(split_conv_model_taps(cols, mat(wf)), ref, rtol=2e-5, atol=2e-5)
