@@ -1993,6 +1993,7 @@ __global__ __launch_bounds__(256, 1) void gated_conv_wino4h_kernel(const ConvKAr
 {
     using WG = Wino4hGeom;
     __shared__ __attribute__((aligned(16))) unsigned lds[WG::LDS_DWORDS];
+    __shared__ __attribute__((aligned(16))) float epar[6][32];  // the group's epilogue parameters: b_f, -log2e b_m, BN scale, BN shift, 1 / s_f, -log2e / s_m
     const int tid = threadIdx.x, lane = tid & 63;
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
     const SrcDev s = a.src[0];
@@ -2156,6 +2157,15 @@ __global__ __launch_bounds__(256, 1) void gated_conv_wino4h_kernel(const ConvKAr
     const auto res_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(a.residual ? a.residual : a.out), 0,
                                                             (unsigned)(a.outH * a.outW * a.Cout) * 4u, 0x00020000);
     const float *const wsc = reinterpret_cast<const float *>(a.wp_w4h) + (size_t)n * 2304 * a.CoutPad;       // 1 / s: [f | m][CoutPad]
+    // the group is fixed per workgroup: its epilogue parameters go to LDS once.  (Loaded from global memory in every unit's epilogue
+    // they queued behind the next unit's weight and patch loads, already in flight, and the epilogue waited for those: loads return in
+    // order.  Measured on one box, old / new library alternating: 64.9 / 55.3 / 49.2 / 47.3 -> 64.0 / 52.4 / 48.5 / 47.3 us at C = 32 .. 256.)
+    if (tid < 192) {
+        constexpr float L2E = 1.44269504088896341f;
+        const int arr = tid >> 5, c = g * 32 + (tid & 31);
+        const float v = arr < 4 ? a.params[arr * a.CoutPad + c] : wsc[(arr - 4) * a.CoutPad + c];
+        epar[arr][tid & 31] = (arr == 1 || arr == 5) ? v * -L2E : v;
+    }
 
     // ---- prologue: patch(0) -> registers -> V(0); patch(1) -> registers; the first weight fragments and B operands
     set_patch();
@@ -2245,14 +2255,11 @@ __global__ __launch_bounds__(256, 1) void gated_conv_wino4h_kernel(const ConvKAr
             __builtin_amdgcn_s_setprio(0);
             continue;
         }
-        const f32x4 bf = *reinterpret_cast<const f32x4 *>(a.params + c0);
-        const f32x4 bm = *reinterpret_cast<const f32x4 *>(a.params + a.CoutPad + c0);
-        const f32x4 sc = *reinterpret_cast<const f32x4 *>(a.params + 2 * a.CoutPad + c0);
-        const f32x4 sh = *reinterpret_cast<const f32x4 *>(a.params + 3 * a.CoutPad + c0);
-        const f32x4 isf = *reinterpret_cast<const f32x4 *>(wsc + c0);
+        const int cl = wv * 8 + 4 * cq;
+        const f32x4 bf = *reinterpret_cast<const f32x4 *>(&epar[0][cl]), bml = *reinterpret_cast<const f32x4 *>(&epar[1][cl]);
+        const f32x4 sc = *reinterpret_cast<const f32x4 *>(&epar[2][cl]), sh = *reinterpret_cast<const f32x4 *>(&epar[3][cl]);
+        const f32x4 isf = *reinterpret_cast<const f32x4 *>(&epar[4][cl]), ism = *reinterpret_cast<const f32x4 *>(&epar[5][cl]);
         constexpr float LOG2E = 1.44269504088896341f;
-        const f32x4 ism = *reinterpret_cast<const f32x4 *>(wsc + a.CoutPad + c0) * -LOG2E;
-        const f32x4 bml = bm * -LOG2E;
         unsigned rvoff[2][4], ovoff[2][4];
 #pragma unroll
         for (int py = 0; py < 2; ++py)
