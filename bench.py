@@ -973,16 +973,26 @@ def fp32_mfma_record(wl, dev):
         prof = [(l, float(np.median([p_[i][1] for p_ in passes])), fl, c) for i, (l, _, fl, c) in enumerate(passes[0])]
         torch.cuda.synchronize()
         del eng
+        # ... and round 5's whole plan: every split-operand kernel of round 6 off (3x3/s1 family, FAM, stride-2 / 4x4, 1x1, the 8-channel heads)
+        for k_ in (b"conv_d3h_s2", b"conv_pxh", b"conv_t3h"):
+            _lib.check(L.read_tuning_set(k_, 0))
+        eng5 = UNetEngine(torch.from_numpy(pack_state(wl.state, layout=LAYOUT_FULL)).to(dev), wl.H, wl.W)
+        ms_r5 = hip_time_ms(lambda: eng5.forward(*x, channels=4), 10)
+        prof5 = eng5.profile(*x, channels=4)
+        torch.cuda.synchronize()
+        del eng5
     finally:
-        _lib.check(L.read_tuning_set(b"conv_w4h", 32))
-        _lib.check(L.read_tuning_set(b"conv_d3h_fam", 32))
+        for k_, v_ in ((b"conv_w4h", 32), (b"conv_d3h_fam", 32), (b"conv_d3h_s2", 32), (b"conv_pxh", 16), (b"conv_t3h", 8)):
+            _lib.check(L.read_tuning_set(k_, v_))
     fam_ms = sum(m for (_, m, _, c) in prof if c)
     fam_exec = sum(fl / {2: 2.25, 4: 4.0}.get(c, 1.0) for (_, _, fl, c) in prof if c)
     d = (rgba_h[:, :, :3] - rgba_f[:, :, :3]).double()
     peak = float(rgba_f[:, :, :3].abs().max())
     mse = float((d * d).mean())
     ms_h = hip_time_ms(lambda: wl.fr.unet.forward(*x, channels=4), 10)
-    return {"unet_ms": ms, "unet_ms_headline_kernels": ms_h, "family_ms": fam_ms, "family_launches": sum(1 for p_ in prof if p_[3]),
+    return {"unet_ms": ms, "unet_ms_headline_kernels": ms_h, "unet_ms_round5_plan": ms_r5,
+            "other_launches_ms_round5_plan": sum(m for (_, m, _, c) in prof5 if not c),
+            "family_ms": fam_ms, "family_launches": sum(1 for p_ in prof if p_[3]),
             "winograd_f4_launches": sum(1 for p_ in prof if p_[3] == 4),
             "achieved": fam_exec / (fam_ms * 1e-3) / 1e12, "peak": FP32_MFMA_PEAK_TFS, "unit": "TFLOP/s",
             "frac": fam_exec / (fam_ms * 1e-3) / 1e12 / FP32_MFMA_PEAK_TFS,
@@ -990,7 +1000,8 @@ def fp32_mfma_record(wl, dev):
             "max_abs_diff_between_the_two_paths": float(d.abs().max()),
             "what": "the UNet stage alone (one plan, one stream), 3x3/s1 family on gated_conv_wino4_kernel (v_mfma_f32_16x16x4_f32) "
                     "instead of the split-operand kernel; frac = executed fp32 MFMA flops of the family / its launch time / 157.3 TF — "
-                    "rounds 3-5's roofline.frac"}
+                    "rounds 3-5's roofline.frac.  unet_ms_round5_plan: the same with EVERY split-operand kernel of round 6 off (stride-2 / 4x4, "
+                    "1x1 and 8-channel-head layers back on the fp32 kernels too) = round 5's launch plan on this box"}
 
 
 def conv_hip_sha16():
@@ -1206,7 +1217,9 @@ def main():
                               "poses 1..64); _kernel_sum: HIP events around every launch, lap mean",
                 "gather_ms": ms_gather, "gather_GBps": gather_bytes / (ms_gather * 1e-3) / 1e9,
                 "gather_frac_hbm": gather_bytes / (ms_gather * 1e-3) / 1e9 / HBM_PEAK_GBS,
-                "unet_ms": ms_unet, "unet_launches": len(prof), "unet_executed_TFLOPs": all_exec / (ms_unet * 1e-3) / 1e12,
+                "unet_ms": ms_unet, "unet_launches": len(prof), "unet_family_ms": c3_ms, "unet_other_ms": sum(m for (_, m, _, c) in prof if not c),
+                "unet_other_launches": sum(1 for (_, _, _, c) in prof if not c),
+                "unet_executed_TFLOPs": all_exec / (ms_unet * 1e-3) / 1e12,
                 "unet_frac_mfma": all_exec / (ms_unet * 1e-3) / 1e12 / FP32_MFMA_PEAK_TFS,
                 "unet_algorithmic_TFLOPs": all_fl / (ms_unet * 1e-3) / 1e12},
             "tuning": _lib.tuning_state(),

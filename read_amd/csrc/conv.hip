@@ -4068,10 +4068,16 @@ __global__ __launch_bounds__(256, 2) void gated_conv_pxh_kernel(const ConvKArgs 
     const int nsteps = a.nchunks;                                    // k16 steps = Cin / 16
     const int nquads = (nsteps + 3) >> 2;                            // the ring advances in quads; steps >= nsteps are empty
     const int gsets = (a.CoutPad >> 5) / GW;
-    const int gs = blockIdx.x % gsets;                               // channel-group set of this workgroup
-#ifdef READ_DEBUG_KNOBS
-    const int abl = a.ablate;        // attribution probes (results invalid): 1 no epilogue memory traffic, 2 activation loads from one resident line per lane,
-#else                                //   4 no MFMAs, 16 no weight copy
+    // workgroup -> (group set, index inside the set), XCD-aware: consecutive workgroup ids go to the eight XCDs in turn, so the group sets
+    // that read the SAME pixels are ids xcd + 8 (gsets k + gs) — they share an XCD and its L2: the pixels come from memory once per
+    // XCD instead of once per group set (gridDim.x = per_set x gsets with per_set a multiple of 8)
+    const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+    const int gs = slot % gsets, wgi = (slot / gsets) * 8 + xcd;     // channel-group set of this workgroup; its index among the set's workgroups
+#if defined(PXH_ABL)                 // attribution probes (results invalid): 1 no epilogue memory traffic, 2 activation loads from one resident line per lane,
+    constexpr int abl = PXH_ABL;     //   4 no MFMAs, 16 no weight copy.  Compile-time in variant builds (tools/pxh_probe.py), run-time in the debug library
+#elif defined(READ_DEBUG_KNOBS)
+    const int abl = a.ablate;
+#else
     constexpr int abl = 0;
 #endif
     if (!(abl & 16)) {
@@ -4103,7 +4109,7 @@ __global__ __launch_bounds__(256, 2) void gated_conv_pxh_kernel(const ConvKArgs 
     }
     __syncthreads();
     const int npix = a.outH * a.outW;
-    const int wslots = (gridDim.x / gsets) * 4, w0 = (blockIdx.x / gsets) * 4 + wave;
+    const int wslots = (gridDim.x / gsets) * 4, w0 = wgi * 4 + wave;
     if (w0 >= a.n_units) return;
 
     // ---- load cursor: (unit, step) of the next activation fragment, four steps ahead of the MFMAs.  Cursor A = channels 16 step ..
@@ -5192,6 +5198,7 @@ int launch_gated_conv(const read_conv_desc *d, hipStream_t stream)
         const int want = ceil_div(a.n_units, 4);
         per_set = per_set < 1 ? 1 : per_set;
         per_set = per_set < want ? per_set : want;
+        per_set = (per_set + 7) / 8 * 8;                             // the kernel's XCD-aware workgroup map
         const bool fullq = nsteps % 4 == 0;
         bool uni = true;
         for (int i = 0; i < d->n_src; ++i) uni = uni && d->src[i].C % 16 == 0;
