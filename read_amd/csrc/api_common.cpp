@@ -15,7 +15,7 @@ void set_error(const char *fmt, ...)
 }  // namespace readhip
 
 extern "C" const char *read_last_error(void) { return readhip::g_err; }
-extern "C" int read_abi_version(void) { return 2; }   // 2: read_conv_desc.wpacked_w4h (round 6)
+extern "C" int read_abi_version(void) { return 3; }   // 2: read_conv_desc.wpacked_w4h / wpacked_d3h; 3: wpacked_t3h at the end of the struct (round 6)
 
 extern "C" int read_device_arch(char *name, int len)
 {

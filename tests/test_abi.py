@@ -28,7 +28,7 @@ def test_library_exports_every_declared_symbol():
     for n in names:
         assert hasattr(L, n), f"{n} declared in read_hip.h but not exported"
     assert set(names) == set(_lib.SIGNATURES), set(names) ^ set(_lib.SIGNATURES)
-    assert _lib.lib().read_abi_version() == 2
+    assert _lib.lib().read_abi_version() == 3
 
 
 def test_layer_table_matches_independent_spec():
