@@ -1161,7 +1161,7 @@ def main():
             "value": world * a.steps / dt, "unit": "frames/s",
             "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": 1e3 * dt / a.steps,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "f32 (3x3/s1 products from two f16 pieces per operand, three piece pairs, fp32 accumulation)" if n_w4h else "f32",
+            "dtype": "f32 (matrix-core products from two f16 pieces per operand, three piece pairs, fp32 accumulation)" if n_w4h else "f32",
             "data": "synthetic",
             "config": {"workload": wl.describe, "points": N, "width": W, "height": H,
                        "parallelism": f"pose-sharded x{world}", "pose_layout": a.pose_layout,
