@@ -3731,9 +3731,15 @@ __global__ __launch_bounds__(256) void gated_conv_smallc_kernel(const ConvKArgs 
         const bool ok = (e < NE) & (y0 + ppy >= 0) & (y0 + ppy < a.inH) & (x0 + ppx >= 0) & (x0 + ppx < a.inW);
         goff[i] = ok ? (unsigned)(((y0 + ppy) * s.W + x0 + ppx) * s.C + 4 * q) * 4u : OOR;
     }
-    float4 st[NI];
+    // The WHOLE patch is requested here, all phases of a pixel back to back (round 6): fetched phase by phase, 32 bytes of a pixel's
+    // 128-byte line at a time and a phase apart, every line came from memory four times — the counters read 223 MB for a 55 MB
+    // tensor, and 223 MB are the launch's 44 us (profiles/r6_hbm_traffic_per_kernel.md)
+    float4 st[NPH][NI];
 #pragma unroll
-    for (int i = 0; i < NI; ++i) st[i] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, goff[i], 0, 0));
+    for (int i = 0; i < NI; ++i)
+#pragma unroll
+        for (int ph = 0; ph < NPH; ++ph)                        // OOR + anything stays out of range
+            st[ph][i] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, goff[i], ph * CPH * 4, 0));
     const int py = tid >> 5, px = tid & 31;
     const float *tp = tile + (py * IW + px) * PS;
     // Weights: 32 floats per (tap, channel quad) = two s_load_dwordx16, requested one group AHEAD together with the next
@@ -3756,12 +3762,7 @@ __global__ __launch_bounds__(256) void gated_conv_smallc_kernel(const ConvKArgs 
 #pragma unroll
         for (int i = 0; i < NI; ++i) {
             const int e = tid + i * 256, q = e % Q4, pix = e / Q4;
-            if (e < NE) *reinterpret_cast<float4 *>(tile + pix * PS + 4 * q) = st[i];
-        }
-        if (ph + 1 < NPH) {
-#pragma unroll
-            for (int i = 0; i < NI; ++i)                        // OOR + anything stays out of range
-                st[i] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, goff[i], (ph + 1) * CPH * 4, 0));
+            if (e < NE) *reinterpret_cast<float4 *>(tile + pix * PS + 4 * q) = st[ph][i];
         }
         f32x16 wa, wb;
         asm volatile("s_load_dwordx16 %0, %1, %2" : "=&s"(wa) : "s"(wbase), "s"((ph * Q4) * 128));
