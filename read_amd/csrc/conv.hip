@@ -4290,7 +4290,7 @@ __global__ __launch_bounds__(256, 2) void gated_conv_pxh_kernel(const ConvKArgs 
 
         // ---- epilogue: lane = (pixel, channel quad), everything 128 bits wide.  Parameters come from LDS (a global load here would
         // queue behind the next unit's activation loads, which are already in flight, and wait for them: loads return in order);
-        // the addends and the residual of a pixel tile are requested together, in front of the arithmetic.
+        // the addends of a channel group are requested together, in front of the arithmetic.
 #pragma unroll
         for (int pt = 0; pt < PT; ++pt) {
             const int p = (u * PT + pt) * 32 + lp;
@@ -4300,55 +4300,55 @@ __global__ __launch_bounds__(256, 2) void gated_conv_pxh_kernel(const ConvKArgs 
             const float *const pp = a.pre ? a.pre + ((size_t)(y >> a.pre_shift) * a.pre_W + (x >> a.pre_shift)) * a.pre_cstride : nullptr;
 #pragma unroll
             for (int g = 0; g < GW; ++g) {
-            f32x4 af[4], am[4];
-            if (a.pre) {
+                f32x4 af[4], am[4];
+                if (a.pre) {
+#pragma unroll
+                    for (int qd = 0; qd < 4; ++qd) {
+                        const int c0 = (gs * GW + g) * 32 + 8 * qd + 4 * half, cc = c0 < a.Cout ? c0 : a.Cout - 4;
+                        af[qd] = *reinterpret_cast<const f32x4 *>(pp + a.pre_foff + cc);
+                        am[qd] = *reinterpret_cast<const f32x4 *>(pp + a.pre_moff + cc);
+                    }
+                }
 #pragma unroll
                 for (int qd = 0; qd < 4; ++qd) {
-                    const int c0 = (gs * GW + g) * 32 + 8 * qd + 4 * half, cc = c0 < a.Cout ? c0 : a.Cout - 4;
-                    af[qd] = *reinterpret_cast<const f32x4 *>(pp + a.pre_foff + cc);
-                    am[qd] = *reinterpret_cast<const f32x4 *>(pp + a.pre_moff + cc);
-                }
-            }
+                    const int cl = g * 32 + 8 * qd + 4 * half, c0 = gs * GW * 32 + cl;
+                    f32x4 f, m;
 #pragma unroll
-            for (int qd = 0; qd < 4; ++qd) {
-                const int cl = g * 32 + 8 * qd + 4 * half, c0 = gs * GW * 32 + cl;
-                f32x4 f, m;
-#pragma unroll
-                for (int k = 0; k < 4; ++k) {
-                    f[k] = acc[pt][2 * g][4 * qd + k];
-                    m[k] = acc[pt][2 * g + 1][4 * qd + k];
-                }
-                f = __builtin_elementwise_fma(f, *reinterpret_cast<const f32x4 *>(&epar[4 * EP + cl]), *reinterpret_cast<const f32x4 *>(&epar[cl]));
-                m = __builtin_elementwise_fma(m, *reinterpret_cast<const f32x4 *>(&epar[5 * EP + cl]), *reinterpret_cast<const f32x4 *>(&epar[EP + cl]));
-                const int cc = c0 < a.Cout ? c0 : a.Cout - 4;
-                if (a.pre) {
-                    f += af[qd];
-                    m += am[qd];
-                }
-                const bool ok = p_ok && c0 < a.Cout;
-                float *op = a.out + (size_t)pc * a.out_cstride + (c0 < a.Cout ? c0 : 0);
-                if (abl & 1) op = a.out + lane * 4;
-                if (a.linear) {
-                    if (ok) {
-                        *reinterpret_cast<f32x4 *>(op) = f;
-                        *reinterpret_cast<f32x4 *>(op + a.Cout) = m;
+                    for (int k = 0; k < 4; ++k) {
+                        f[k] = acc[pt][2 * g][4 * qd + k];
+                        m[k] = acc[pt][2 * g + 1][4 * qd + k];
                     }
-                    continue;
-                }
-                constexpr float LOG2E = 1.44269504088896341f;
-                if (a.elu) {
-                    const f32x4 fe = f * LOG2E;
+                    f = __builtin_elementwise_fma(f, *reinterpret_cast<const f32x4 *>(&epar[4 * EP + cl]), *reinterpret_cast<const f32x4 *>(&epar[cl]));
+                    m = __builtin_elementwise_fma(m, *reinterpret_cast<const f32x4 *>(&epar[5 * EP + cl]), *reinterpret_cast<const f32x4 *>(&epar[EP + cl]));
+                    const int cc = c0 < a.Cout ? c0 : a.Cout - 4;
+                    if (a.pre) {
+                        f += af[qd];
+                        m += am[qd];
+                    }
+                    const bool ok = p_ok && c0 < a.Cout;
+                    float *op = a.out + (size_t)pc * a.out_cstride + (c0 < a.Cout ? c0 : 0);
+                    if (abl & 1) op = a.out + lane * 4;
+                    if (a.linear) {
+                        if (ok) {
+                            *reinterpret_cast<f32x4 *>(op) = f;
+                            *reinterpret_cast<f32x4 *>(op + a.Cout) = m;
+                        }
+                        continue;
+                    }
+                    constexpr float LOG2E = 1.44269504088896341f;
+                    if (a.elu) {
+                        const f32x4 fe = f * LOG2E;
 #pragma unroll
-                    for (int k = 0; k < 4; ++k) f[k] = f[k] > 0.0f ? f[k] : __builtin_amdgcn_exp2f(fe[k]) - 1.0f;
-                }
-                const f32x4 mm = m * -LOG2E;
-                f32x4 sg;
+                        for (int k = 0; k < 4; ++k) f[k] = f[k] > 0.0f ? f[k] : __builtin_amdgcn_exp2f(fe[k]) - 1.0f;
+                    }
+                    const f32x4 mm = m * -LOG2E;
+                    f32x4 sg;
 #pragma unroll
-                for (int k = 0; k < 4; ++k) sg[k] = __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(mm[k]));
-                f32x4 v = (f * sg) * *reinterpret_cast<const f32x4 *>(&epar[2 * EP + cl]) + *reinterpret_cast<const f32x4 *>(&epar[3 * EP + cl]);
-                if (quad_res) v += *reinterpret_cast<const f32x4 *>(a.residual + (abl & 1 ? (size_t)lane * 4 : (size_t)pc * a.Cout + cc));
-                if (ok) *reinterpret_cast<f32x4 *>(op) = v;
-            }
+                    for (int k = 0; k < 4; ++k) sg[k] = __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(mm[k]));
+                    f32x4 v = (f * sg) * *reinterpret_cast<const f32x4 *>(&epar[2 * EP + cl]) + *reinterpret_cast<const f32x4 *>(&epar[3 * EP + cl]);
+                    if (quad_res) v += *reinterpret_cast<const f32x4 *>(a.residual + (abl & 1 ? (size_t)lane * 4 : (size_t)pc * a.Cout + cc));
+                    if (ok) *reinterpret_cast<f32x4 *>(op) = v;
+                }
             }
         }
     }
